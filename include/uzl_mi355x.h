@@ -1,0 +1,308 @@
+/*
+ * uzl_mi355x.h — C ABI of libuzl_mi355x.so, the MI355X (gfx950) back end for the
+ * one data-parallel hot path of uzliti_slam:
+ *
+ *   (1) feature edge estimation  = 2-NN Hamming match + ratio test + 3-D filter +
+ *       PROSAC/RANSAC 3-point pose + refit + information matrix
+ *       (reference: transformation_estimation/src/feature_transformation_estimator.cpp:32-347)
+ *   (2) SE(3) pose-graph solve   = graph flattening, gauge fixing, Levenberg-Marquardt
+ *       with Huber kernel, write-back
+ *       (reference: graph_optimization/src/g2o_optimizer.cpp:55-349 + the g2o semantics
+ *        it delegates to)
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes and returns an int
+ * status (0 = ok, <0 = error; never throws).  Inputs are borrowed for the duration of the
+ * call and copied to HBM before the call returns; outputs go to caller-provided buffers.
+ * Handles are opaque and thread-safe at handle granularity (one mutex per handle).
+ *
+ * The reference-side classes these functions sit under are
+ *   TransformationEstimator / FeatureTransformationEstimator
+ *     (transformation_estimation/include/transformation_estimation/transformation_estimator.h:45-67,
+ *      .../feature_transformation_estimator.h:33-60)
+ *   GraphOptimizer / G2oOptimizer
+ *     (graph_optimization/include/graph_optimization/graph_optimizer.h:28-56,
+ *      .../g2o_optimizer.h:38-68)
+ * INTEGRATION.md shows the C++ subclasses a maintainer would add on the ROS side.
+ *
+ * Matrix conventions: an SE(3) transform is 12 doubles, row-major 3x4 [R|t]
+ * (the top three rows of Eigen::Isometry3d::matrix()).  A 6x6 information matrix is 36
+ * doubles row-major, parameter order (x,y,z,qx,qy,qz) as in SlamEdge::information_
+ * (graph_slam_common/include/graph_slam_common/slam_edge.h:84).
+ */
+#ifndef UZL_MI355X_H
+#define UZL_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UZL_ABI_VERSION 1
+
+/* ---- status codes (reference: bool returns + ROS_ERROR, SURVEY §8b "Errors") ---- */
+#define UZL_OK                 0
+#define UZL_ERR_BAD_ARG       -1
+#define UZL_ERR_NO_DEVICE     -2
+#define UZL_ERR_HIP           -3
+#define UZL_ERR_NOT_CONVERGED -4   /* PCG hit pcg_max_iter in some LM trial (result still written) */
+#define UZL_ERR_BUSY          -5   /* GraphOptimizer::optimize() returns false while a solve is in flight */
+#define UZL_ERR_OOM           -6
+#define UZL_ERR_NOT_FOUND     -7
+#define UZL_ERR_STATE         -8   /* call order violated (e.g. optimize before set_graph) */
+
+/* feature types: graph_slam_msgs/msg/Features.msg:1-4 */
+#define UZL_FEATURE_BRIEF 1
+#define UZL_FEATURE_ORB   2
+#define UZL_FEATURE_BRISK 3
+#define UZL_FEATURE_FREAK 4
+
+/* edge types: graph_slam_msgs/msg/Edge.msg (TYPE_2D_WHEEL_ODOMETRY is the only one the
+ * optimizer treats specially, g2o_optimizer.cpp:78) */
+#define UZL_EDGE_TYPE_2D_WHEEL_ODOMETRY 0
+#define UZL_EDGE_TYPE_3D_FULL           1
+#define UZL_EDGE_TYPE_2D_LASER          2
+#define UZL_EDGE_TYPE_3D_LASER          3
+
+int         uzl_abi_version(void);
+/* Number of visible HIP devices, or <0 (UZL_ERR_NO_DEVICE) when there is none. */
+int         uzl_device_count(void);
+/* Static string for a status code. */
+const char* uzl_status_string(int status);
+
+/* ======================================================================================
+ *  Edge estimation  (TransformationEstimator family)
+ * ====================================================================================== */
+
+typedef struct uzl_match uzl_match;
+
+/* Mirrors transformation_estimation/cfg/FeatureLinkEstimation.cfg:9-13 field for field,
+ * then the back-end additions.  uzl_match_cfg_default() fills the cfg-file defaults. */
+typedef struct uzl_match_cfg {
+    double   ransac_threshold;         /* 0.2   max 3-D distance of an inlier [m]              */
+    double   link_covariance;          /* 0.01  (unused by the live reference code)           */
+    int32_t  ransac_iteration;         /* 100   number of PROSAC iterations                   */
+    double   ransac_break_percentage;  /* 0.6   early exit when consensus > pct * M           */
+    int32_t  use_epnp;                 /* 1     (unused by the live reference code)           */
+    /* ---- back-end additions ---- */
+    int32_t  do_prosac;                /* 1     growing-prefix sampling (estimateSVD default) */
+    int32_t  device;                   /* HIP device ordinal                                  */
+    uint64_t seed;                     /* counter-based RNG seed; replaces the reference's
+                                          unseeded process-global std::rand      */
+} uzl_match_cfg;
+
+/* One FeatureData (graph_slam_common/include/graph_slam_common/sensor_data.h:49-70). */
+typedef struct uzl_frame {
+    const uint8_t* desc;            /* n rows x bytes_per_desc, row-major (cv::Mat CV_8U)       */
+    int32_t        n;               /* number of keypoints (features_.rows)                     */
+    int32_t        bytes_per_desc;  /* 32 = ORB/BRIEF-256, 64 = BRISK/FREAK-512; multiple of 4  */
+    const double*  pos_xyz;         /* 3 x n column-major (Eigen::MatrixXd feature_positions_)  */
+    const uint8_t* valid3d;         /* n flags (std::vector<bool> valid_3d_)                    */
+    int32_t        feature_type;    /* UZL_FEATURE_*                                            */
+    int32_t        sensor_frame;    /* integer key standing for the sensor_frame_ string        */
+    double         displacement[12];/* SensorData::displacement_                                */
+} uzl_frame;
+
+/* One node-pair job = one call of estimateEdgeImpl(from, to, edge)
+ * (feature_transformation_estimator.cpp:161-171).  A node may carry several FeatureData;
+ * frame ids index the handle's resident frame store and are given through the flat
+ * frame_ids array passed next to the jobs. */
+typedef struct uzl_pair_job {
+    uint64_t job_id;       /* keys the RNG stream; echoed in the result                       */
+    int32_t  from_begin;   /* frames of node `from`: frame_ids[from_begin .. +from_count)     */
+    int32_t  from_count;
+    int32_t  to_begin;     /* frames of node `to`                                             */
+    int32_t  to_count;
+} uzl_pair_job;
+
+/* What estimateEdgeDirect() leaves in the SlamEdge (feature_transformation_estimator.cpp:127-156)
+ * plus the diagnostics the parity tests compare. */
+typedef struct uzl_edge_result {
+    uint64_t job_id;
+    int32_t  ok;               /* return value of estimateEdgeImpl (1 iff a sensor pair matched
+                                  and >= 3 correspondences survived)                          */
+    int32_t  consensus;        /* SlamEdge::matching_score_ (0 when !ok, transformation_estimator.cpp:53-55) */
+    int32_t  n_matches;        /* ratio-test survivors of the chosen sensor pair (score, :78) */
+    int32_t  n_corr;           /* M: survivors of the 3-D validity filter (:101-112)          */
+    int32_t  frame_from;       /* chosen FeatureData pair (frame ids), -1 if none             */
+    int32_t  frame_to;
+    int32_t  iterations_run;   /* PROSAC iterations executed before the early exit            */
+    int32_t  best_iteration;   /* iteration whose hypothesis won                              */
+    double   mse;              /* mean inlier distance (:285-290)                             */
+    double   T[12];            /* SlamEdge::transform_  (from_T_to)                           */
+    double   information[36];  /* SlamEdge::information_ (:133-137)                           */
+} uzl_edge_result;
+
+void uzl_match_cfg_default(uzl_match_cfg* cfg);
+
+/* FeatureTransformationEstimator::FeatureTransformationEstimator (…estimator.cpp:27-30). */
+int  uzl_match_create(const uzl_match_cfg* cfg, uzl_match** out);
+void uzl_match_destroy(uzl_match* h);
+/* FeatureTransformationEstimator::setConfig (…estimator.cpp:350-353). */
+int  uzl_match_set_config(uzl_match* h, const uzl_match_cfg* cfg);
+const char* uzl_match_last_error(uzl_match* h);
+
+/* Upload one FeatureData into the handle's HBM-resident frame store (the reference deep-copies
+ * both SlamNodes per enqueue, transformation_estimator.cpp:39; here a frame is uploaded once and
+ * referenced by every pair job that uses it).  Returns the frame id through *frame_id. */
+int  uzl_match_add_frame(uzl_match* h, const uzl_frame* frame, int32_t* frame_id);
+int  uzl_match_remove_frame(uzl_match* h, int32_t frame_id);
+int  uzl_match_frame_count(uzl_match* h);
+
+/* Batched estimateEdgeImpl: n_jobs independent node pairs in one launch sequence.
+ * Optional diagnostics (may each be NULL): per job, at stride max_corr,
+ *   corr_query / corr_train : the sorted correspondence list (DMatch queryIdx / trainIdx
+ *                             after std::sort, :114), first n_corr entries valid
+ *   corr_dist               : their Hamming distances
+ *   inlier_mask             : final consensus set (maxConsensusSet after the refit, :258)
+ * Blocks until the results are in `results`. */
+int  uzl_match_estimate(uzl_match* h,
+                        int32_t n_jobs, const uzl_pair_job* jobs,
+                        const int32_t* frame_ids, int32_t n_frame_ids,
+                        uzl_edge_result* results,
+                        int32_t max_corr,
+                        int32_t* corr_query, int32_t* corr_train, int32_t* corr_dist,
+                        uint8_t* inlier_mask);
+
+/* Split form of uzl_match_estimate for pipelining: launch enqueues every kernel and the
+ * D2H copies on the handle's stream and returns; collect waits for them. One batch may be
+ * in flight per handle (UZL_ERR_BUSY otherwise). */
+int  uzl_match_launch(uzl_match* h, int32_t n_jobs, const uzl_pair_job* jobs,
+                      const int32_t* frame_ids, int32_t n_frame_ids, int32_t max_corr);
+int  uzl_match_collect(uzl_match* h, uzl_edge_result* results,
+                       int32_t* corr_query, int32_t* corr_train, int32_t* corr_dist,
+                       uint8_t* inlier_mask);
+
+/* Stage M1 alone, for parity tests: cv::BFMatcher(NORM_HAMMING).knnMatch(query=to, train=from, k=2)
+ * (feature_transformation_estimator.cpp:38,58).  Outputs have n(to) entries; an index is -1 when
+ * the train set has fewer rows than the rank asks for. */
+int  uzl_match_knn2(uzl_match* h, int32_t frame_from, int32_t frame_to,
+                    int32_t* idx0, int32_t* dist0, int32_t* idx1, int32_t* dist1);
+
+/* FeatureTransformationEstimator::estimateSVD (…estimator.cpp:178-184) on caller-supplied
+ * correspondences, batched: problem b uses columns [offsets[b], offsets[b+1]) of P and Q
+ * (3 x total column-major).  This is the entry TransformationFilter::EdgeCluster uses
+ * (transformation_filter.cpp:272-275).  Outputs per problem: T (12), consensus, mse,
+ * iterations_run; mask is per column.  job_ids key the RNG streams. */
+int  uzl_ransac_points(uzl_match* h, int32_t n_problems, const int32_t* offsets,
+                       const double* P, const double* Q,
+                       double max_error, int32_t iterations, double break_percentage,
+                       int32_t do_prosac, const uint64_t* job_ids,
+                       double* T, int32_t* consensus, double* mse, int32_t* iterations_run,
+                       uint8_t* mask);
+
+/* Per-kernel timing of the last estimate/launch, measured with HIP events on the handle's
+ * stream when profiling is on.  names/ms arrays of capacity cap; returns the number filled. */
+int  uzl_match_set_profiling(uzl_match* h, int32_t on);
+int  uzl_match_kernel_times(uzl_match* h, int32_t cap, const char** names, double* ms, int32_t* launches);
+
+/* ======================================================================================
+ *  Pose-graph optimisation  (GraphOptimizer family)
+ * ====================================================================================== */
+
+typedef struct uzl_pgo uzl_pgo;
+
+/* Mirrors graph_optimization/cfg/GraphOptimizer.cfg:10-12, then the back-end additions. */
+typedef struct uzl_pgo_cfg {
+    int32_t iterations;               /* 20   LM outer iterations (optimizer_.optimize(iterations), g2o_optimizer.cpp:148) */
+    int32_t use_odometry_parameters;  /* 0    (g2o_optimizer.cpp:209-227; not supported: UZL_ERR_BAD_ARG when set)       */
+    int32_t optimize_xy_only;         /* 0    project poses/measurements to (x,y,yaw) (g2o_optimizer.cpp:164-170)         */
+    /* ---- back-end additions ---- */
+    int32_t device;
+    double  pcg_tol;                  /* stop when r.M^-1 r <= pcg_tol^2 * (r0.M^-1 r0)                */
+    int32_t pcg_max_iter;             /* per linear solve                                             */
+    double  huber_delta;              /* 1.0  (g2o_optimizer.cpp:293)                                 */
+    int32_t verbose;
+} uzl_pgo_cfg;
+
+/* SlamNode as the optimizer sees it (slam_node.h:89-107). Array order = std::map iteration order
+ * of SlamGraph (lexicographic id), which is also the order g2o vertex ids are assigned in
+ * (g2o_optimizer.cpp:64-66,180) and the order setFixedNodes() picks gauge vertices in (:338). */
+typedef struct uzl_node {
+    double  pose[12];   /* SlamNode::pose_   */
+    int32_t fixed;      /* SlamNode::fixed_  */
+} uzl_node;
+
+/* SlamEdge as the optimizer sees it (slam_edge.h:78-92). */
+typedef struct uzl_edge {
+    int32_t from;                 /* index into nodes[] (id_from_), -1 if the node is missing  */
+    int32_t to;                   /* index into nodes[] (id_to_)                               */
+    int32_t type;                 /* UZL_EDGE_TYPE_*                                           */
+    int32_t sensor_from;          /* index into sensors[] (sensor_from_), -1 = identity        */
+    int32_t sensor_to;
+    int32_t valid;                /* passes the TransformationFilter (g2o_optimizer.cpp:97-103);
+                                     non-odometry edges with valid==0 are not optimised        */
+    double  transform[12];        /* transform_           */
+    double  displacement_from[12];/* displacement_from_   */
+    double  displacement_to[12];  /* displacement_to_     */
+    double  information[36];      /* information_         */
+} uzl_edge;
+
+typedef struct uzl_pgo_stats {
+    int32_t iterations_done;   /* LM outer iterations completed (return value of optimize())  */
+    int32_t lm_trials;         /* total inner trials (linear solves)                          */
+    int32_t pcg_iterations;    /* total PCG iterations over all solves                        */
+    int32_t terminated_early;  /* LM returned Terminate (10 rejections or rho == 0)           */
+    int32_t n_vertices;        /* vertices in the system                                      */
+    int32_t n_edges;           /* edges in the system (after the skip rules)                  */
+    int32_t n_gauge_fixed;     /* vertices fixed by setFixedNodes()                           */
+    int32_t pcg_not_converged; /* solves that hit pcg_max_iter                                */
+    double  chi2_initial;      /* activeRobustChi2 before the first iteration                 */
+    double  chi2_final;
+    double  lambda_final;
+    double  solve_ms;          /* wall time of uzl_pgo_optimize, device-resident graph        */
+} uzl_pgo_stats;
+
+void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg);
+
+/* G2oOptimizer::G2oOptimizer (g2o_optimizer.cpp:34-49). */
+int  uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out);
+void uzl_pgo_destroy(uzl_pgo* h);
+/* GraphOptimizer::setConfig (graph_optimizer.cpp:54-57). */
+int  uzl_pgo_set_config(uzl_pgo* h, const uzl_pgo_cfg* cfg);
+const char* uzl_pgo_last_error(uzl_pgo* h);
+
+/* G2oOptimizer::addGraphImpl (g2o_optimizer.cpp:55-104): full rebuild.  Applies the skip rules
+ * (:77, :203-206, :270-274), composes the measurements (:229, :281), the optional xy-only
+ * projection (:164-170, :231-237, :282-288) and marks non-odometry edges robust (:292-294).
+ * sensors: n_sensors x 12 doubles (SlamGraph sensor transforms, :68-71).  Only copies. */
+int  uzl_pgo_add_graph(uzl_pgo* h,
+                       int32_t n_nodes, const uzl_node* nodes,
+                       int32_t n_edges, const uzl_edge* edges,
+                       int32_t n_sensors, const double* sensors);
+
+/* Already-flattened form of the same problem (what addGraphImpl leaves inside g2o):
+ * poses n x 12, fixed n, ij e x 2, meas e x 12, info e x 36, robust e. */
+int  uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t* fixed,
+                       int32_t e, const int32_t* ij, const double* meas, const double* info,
+                       const uint8_t* robust);
+
+/* G2oOptimizer::optimizeImpl (g2o_optimizer.cpp:137-149): initializeOptimization, setFixedNodes
+ * (:301-349) and optimize(iterations).  iterations <= 0 uses cfg.iterations.  Blocks. */
+int  uzl_pgo_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* stats);
+
+/* G2oOptimizer::storeImpl (g2o_optimizer.cpp:106-135): poses out n x 12 (node order of the last
+ * add_graph/set_graph); edge_error out = ||e||_2 per input edge (un-weighted 6-norm, :126),
+ * NaN for edges that were skipped; edge_in_system out = 1 for edges that entered the solve.
+ * Any of the three may be NULL. */
+int  uzl_pgo_store(uzl_pgo* h, double* poses, double* edge_error, uint8_t* edge_in_system);
+
+/* Vertices fixed after the last optimize (input fixed flags + setFixedNodes()), n flags. */
+int  uzl_pgo_get_fixed(uzl_pgo* h, uint8_t* fixed);
+
+int  uzl_pgo_set_profiling(uzl_pgo* h, int32_t on);
+int  uzl_pgo_kernel_times(uzl_pgo* h, int32_t cap, const char** names, double* ms, int32_t* launches);
+
+/* ---- sharded single-graph solve (BASELINE config 4): one handle per rank ------------------
+ * The graph is edge-partitioned: every rank holds all vertices and the edges
+ * [e_begin, e_end) of the flattened problem.  The caller supplies the exchange step: a
+ * function that sums `count` doubles in place across all ranks (RCCL all-reduce on the
+ * device buffer `dev_ptr`, issued on `hip_stream`).  With world_size 1 it is never called. */
+typedef int (*uzl_allreduce_fn)(void* dev_ptr, int64_t count, void* hip_stream, void* user);
+int  uzl_pgo_set_shard(uzl_pgo* h, int32_t rank, int32_t world_size,
+                       uzl_allreduce_fn allreduce, void* user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UZL_MI355X_H */

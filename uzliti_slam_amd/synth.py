@@ -1,0 +1,229 @@
+"""Synthetic workloads for the hot path: pose graphs and descriptor frames.
+
+Pure data generation (numpy); the same arrays feed the HIP path, the oracle and the CPU baseline.
+Graph: seed 12345; descriptors: seed 777 (overridable).  Shapes follow BASELINE.json's configs:
+  C1 100 n / 300 e, C2 1k n / 5k e, C4 10k n / 50k e, C5 20k n;
+  C3 512 pairs x 1000 ORB-256 descriptors.
+"""
+import numpy as np
+
+EDGE_TYPE_ODOM = 0      # graph_slam_msgs/Edge TYPE_2D_WHEEL_ODOMETRY
+EDGE_TYPE_3D_FULL = 1   # graph_slam_msgs/Edge TYPE_3D_FULL
+FEATURE_ORB = 2
+
+
+# ----------------------------------------------------------------------------- SE(3) helpers
+def quat_mul(a, b):
+    """Hamilton product, (w,x,y,z), broadcasting over leading dims."""
+    aw, ax, ay, az = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bw, bx, by, bz = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bw - ax * bx - ay * by - az * bz,
+                     aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw], axis=-1)
+
+
+def quat_from_rotvec(v):
+    v = np.asarray(v, np.float64)
+    th = np.linalg.norm(v, axis=-1, keepdims=True)
+    half = 0.5 * th
+    k = np.where(th > 1e-12, np.sin(half) / np.where(th > 1e-12, th, 1.0), 0.5)
+    return np.concatenate([np.cos(half), k * v], axis=-1)
+
+
+def quat_to_R(q):
+    q = np.asarray(q, np.float64)
+    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.empty(q.shape[:-1] + (3, 3))
+    R[..., 0, 0] = 1 - 2 * (y * y + z * z); R[..., 0, 1] = 2 * (x * y - z * w); R[..., 0, 2] = 2 * (x * z + y * w)
+    R[..., 1, 0] = 2 * (x * y + z * w); R[..., 1, 1] = 1 - 2 * (x * x + z * z); R[..., 1, 2] = 2 * (y * z - x * w)
+    R[..., 2, 0] = 2 * (x * z - y * w); R[..., 2, 1] = 2 * (y * z + x * w); R[..., 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def se3(R, t):
+    """(.,3,3),(.,3) -> (.,3,4)"""
+    return np.concatenate([R, np.asarray(t)[..., None]], axis=-1)
+
+
+def se3_mul(A, B):
+    R = A[..., :3, :3] @ B[..., :3, :3]
+    t = (A[..., :3, :3] @ B[..., :3, 3:4])[..., 0] + A[..., :3, 3]
+    return se3(R, t)
+
+
+def se3_inv(A):
+    Rt = np.swapaxes(A[..., :3, :3], -1, -2)
+    t = -(Rt @ A[..., :3, 3:4])[..., 0]
+    return se3(Rt, t)
+
+
+def se3_from_noise(dt, drot):
+    return se3(quat_to_R(quat_from_rotvec(drot)), dt)
+
+
+def rotation_angle(R):
+    c = np.clip((np.trace(R, axis1=-2, axis2=-1) - 1.0) * 0.5, -1.0, 1.0)
+    return np.arccos(c)
+
+
+def pose_errors(A, B):
+    """Max translation [m] and rotation [rad] difference between two (n,3,4) pose arrays."""
+    A = np.asarray(A).reshape(-1, 3, 4); B = np.asarray(B).reshape(-1, 3, 4)
+    dt = np.linalg.norm(A[:, :, 3] - B[:, :, 3], axis=1)
+    dR = np.swapaxes(A[:, :, :3], 1, 2) @ B[:, :, :3]
+    return float(dt.max(initial=0.0)), float(rotation_angle(dR).max(initial=0.0))
+
+
+# ----------------------------------------------------------------------------- pose graphs
+def make_pose_graph(n_nodes, n_edges, seed=12345, outlier_frac=0.05):
+    """SURVEY §8d 'Synthetic graphs'.  Returns a dict in the reference's data model
+    (SlamNode / SlamEdge fields as arrays), before G1 flattening:
+      nodes_pose (N,12) initial poses = odometry dead reckoning, nodes_fixed (N) [node 0 fixed],
+      gt_pose (N,12), edges {from,to,type,sensor_from,sensor_to,valid,transform,displacement_from,
+      displacement_to,information}."""
+    rng = np.random.default_rng(seed)
+    N = int(n_nodes)
+    n_loop = int(n_edges) - (N - 1)
+    assert n_loop >= 0
+    # --- ground-truth trajectory: 0.3 m steps, +-10 deg heading noise, kept inside a box so that
+    # places are revisited (loop closures need pairs within 1.5 m with |i-j| > 20)
+    side = max(4.0, np.sqrt(N / 3.4))
+    half = 0.5 * side
+    xy = np.zeros((N, 2)); yaw = np.zeros(N); z = np.zeros(N); roll = np.zeros(N); pitch = np.zeros(N)
+    th = rng.uniform(-np.pi, np.pi)
+    dth = rng.normal(0.0, np.deg2rad(10.0), N)
+    dz = rng.normal(0.0, 0.005, N); dr = rng.normal(0.0, np.deg2rad(0.3), N); dp = rng.normal(0.0, np.deg2rad(0.3), N)
+    for i in range(1, N):
+        th = th + dth[i]
+        nxt = xy[i - 1] + 0.3 * np.array([np.cos(th), np.sin(th)])
+        if abs(nxt[0]) > half or abs(nxt[1]) > half:
+            th = np.arctan2(-xy[i - 1, 1], -xy[i - 1, 0]) + dth[i]   # steer back towards the centre
+            nxt = xy[i - 1] + 0.3 * np.array([np.cos(th), np.sin(th)])
+        xy[i] = nxt; yaw[i] = th
+        z[i] = 0.98 * z[i - 1] + dz[i]
+        roll[i] = 0.95 * roll[i - 1] + dr[i]; pitch[i] = 0.95 * pitch[i - 1] + dp[i]
+    yaw[0] = yaw[1] if N > 1 else 0.0
+    qz = quat_from_rotvec(np.stack([np.zeros(N), np.zeros(N), yaw], 1))
+    qy = quat_from_rotvec(np.stack([np.zeros(N), pitch, np.zeros(N)], 1))
+    qx = quat_from_rotvec(np.stack([roll, np.zeros(N), np.zeros(N)], 1))
+    gt = se3(quat_to_R(quat_mul(quat_mul(qz, qy), qx)), np.stack([xy[:, 0], xy[:, 1], z], 1))
+
+    # --- odometry edges i -> i+1 (graph_slam_node.cpp:306-335): dt = 1
+    rel = se3_mul(se3_inv(gt[:-1]), gt[1:])
+    odo = se3_mul(rel, se3_from_noise(rng.normal(0, 0.02, (N - 1, 3)), rng.normal(0, 0.001, (N - 1, 3))))
+    odom_info = np.zeros((6, 6))
+    odom_info[:3, :3] = np.eye(3) / (0.02 ** 2)
+    odom_info[3:, 3:] = np.eye(3) / (0.02 ** 2 * 0.05 ** 2)
+
+    # --- loop closures: pairs within 1.5 m and |i-j| > 20
+    cand = _close_pairs(gt[:, :, 3], 1.5, 20)
+    radius = 1.5
+    while len(cand) < n_loop and radius < 50:
+        radius *= 1.5
+        cand = _close_pairs(gt[:, :, 3], radius, 20 if N > 40 else 1)
+    if len(cand) >= n_loop:
+        sel = rng.choice(len(cand), size=n_loop, replace=False)
+    else:                                    # tiny graphs: allow multi-edges
+        sel = rng.choice(len(cand), size=n_loop, replace=True)
+    sel.sort()
+    pairs = cand[sel]
+    # orient randomly (the reference estimates from close_node/older to current, either direction occurs)
+    flip = rng.random(n_loop) < 0.5
+    lf = np.where(flip, pairs[:, 1], pairs[:, 0]); lt = np.where(flip, pairs[:, 0], pairs[:, 1])
+    lrel = se3_mul(se3_inv(gt[lf]), gt[lt])
+    lz = se3_mul(lrel, se3_from_noise(rng.normal(0, 0.05, (n_loop, 3)), rng.normal(0, 0.01, (n_loop, 3))))
+    outl = rng.random(n_loop) < outlier_frac
+    gross = se3_from_noise(rng.uniform(-2, 2, (n_loop, 3)), rng.uniform(-0.5, 0.5, (n_loop, 3)))
+    lz = np.where(outl[:, None, None], se3_mul(lrel, gross), lz)
+    c = rng.uniform(20, 300, n_loop); m = rng.uniform(0.02, 0.08, n_loop)
+    linfo = np.zeros((n_loop, 6, 6))
+    s = 0.1 * c / m                                               # feature_transformation_estimator.cpp:133-137
+    for k in range(3):
+        linfo[:, k, k] = s; linfo[:, 3 + k, 3 + k] = 100.0 * s
+
+    # --- initial poses: dead reckoning along the odometry chain
+    init = np.empty_like(gt); init[0] = gt[0]
+    for i in range(1, N):
+        init[i] = se3_mul(init[i - 1], odo[i - 1])
+
+    E = (N - 1) + n_loop
+    I12 = np.tile(np.eye(3, 4).reshape(1, 12), (E, 1))
+    edges = dict(
+        **{"from": np.concatenate([np.arange(N - 1), lf]).astype(np.int32)},
+        to=np.concatenate([np.arange(1, N), lt]).astype(np.int32),
+        type=np.concatenate([np.full(N - 1, EDGE_TYPE_ODOM), np.full(n_loop, EDGE_TYPE_3D_FULL)]).astype(np.int32),
+        sensor_from=np.full(E, -1, np.int32), sensor_to=np.full(E, -1, np.int32),
+        valid=np.ones(E, np.int32),
+        transform=np.concatenate([odo.reshape(-1, 12), lz.reshape(-1, 12)]),
+        displacement_from=I12.copy(), displacement_to=I12.copy(),
+        information=np.concatenate([np.tile(odom_info.reshape(1, 36), (N - 1, 1)), linfo.reshape(-1, 36)]),
+    )
+    fixed = np.zeros(N, np.uint8); fixed[0] = 1
+    return dict(nodes_pose=init.reshape(N, 12), nodes_fixed=fixed, gt_pose=gt.reshape(N, 12), edges=edges,
+                n_outliers=int(outl.sum()))
+
+
+def _close_pairs(pos, radius, min_sep):
+    """All (i<j) with ||p_i - p_j|| < radius and j - i > min_sep, sorted lexicographically."""
+    from scipy.spatial import cKDTree
+    pos = np.ascontiguousarray(pos, np.float64)
+    pr = cKDTree(pos).query_pairs(radius, output_type="ndarray").astype(np.int64)
+    if pr.size == 0:
+        return np.zeros((0, 2), np.int64)
+    pr = np.sort(pr, axis=1)
+    pr = pr[(pr[:, 1] - pr[:, 0]) > min_sep]
+    order = np.lexsort((pr[:, 1], pr[:, 0]))
+    return pr[order]
+
+
+# ----------------------------------------------------------------------------- descriptor frames
+def make_pair(rng, n_kp=1000, desc_bytes=32, flip_p=0.08, outlier_frac=0.4, sigma=0.01, invalid_frac=0.1,
+              max_t=1.0, max_rot_deg=20.0):
+    """SURVEY §8d 'Synthetic descriptors': one node pair (frame `from`, frame `to`).
+    Returns (frame_from, frame_to, T_from_to (3,4)) with frames as dicts
+    {desc (n,bytes) u8, pos (3,n) f64, valid (n) u8, feature_type, sensor_frame}."""
+    bits = desc_bytes * 8
+    # landmarks in a 6 x 4 x 3 m box in front of camera A (z forward)
+    lm = np.stack([rng.uniform(-3, 3, n_kp), rng.uniform(-2, 2, n_kp), rng.uniform(0.5, 3.5, n_kp)], 0)
+    dbits = rng.integers(0, 2, (n_kp, bits), dtype=np.uint8)
+    # relative motion: from_T_to
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    ang = np.deg2rad(rng.uniform(0, max_rot_deg))
+    R = quat_to_R(quat_from_rotvec(ax * ang))
+    tv = rng.normal(size=3); tv *= rng.uniform(0, max_t) / np.linalg.norm(tv)
+    T = se3(R, tv)
+
+    def noisy_bits():
+        return dbits ^ (rng.random((n_kp, bits)) < flip_p).astype(np.uint8)
+
+    pos_from = lm + rng.normal(0, sigma, lm.shape)
+    desc_from = np.packbits(noisy_bits(), axis=1)
+    # points seen from `to`: p_to = T^-1 * p_from  (T maps to-frame points into the from frame)
+    pos_to = R.T @ (lm - tv[:, None]) + rng.normal(0, sigma, lm.shape)
+    bits_to = noisy_bits()
+    # 40 % of `to` rows replaced by fresh random descriptors + random 3-D points
+    out = rng.random(n_kp) < outlier_frac
+    n_out = int(out.sum())
+    bits_to[out] = rng.integers(0, 2, (n_out, bits), dtype=np.uint8)
+    pos_to[:, out] = np.stack([rng.uniform(-3, 3, n_out), rng.uniform(-2, 2, n_out), rng.uniform(0.5, 3.5, n_out)], 0)
+    desc_to = np.packbits(bits_to, axis=1)
+    # shuffle the row order of `to` so that trainIdx != queryIdx
+    perm = rng.permutation(n_kp)
+    desc_to = desc_to[perm]; pos_to = pos_to[:, perm]
+    valid_from = (rng.random(n_kp) >= invalid_frac).astype(np.uint8)
+    valid_to = (rng.random(n_kp) >= invalid_frac).astype(np.uint8)
+    pos_from = pos_from.copy(); pos_to = pos_to.copy()
+    pos_from[2, valid_from == 0] = -1.0          # z = -1 when invalid (feature_extraction_core.cpp:286-289)
+    pos_to[2, valid_to == 0] = -1.0
+    f = dict(desc=np.ascontiguousarray(desc_from), pos=np.ascontiguousarray(pos_from), valid=valid_from,
+             feature_type=FEATURE_ORB, sensor_frame=0)
+    t = dict(desc=np.ascontiguousarray(desc_to), pos=np.ascontiguousarray(pos_to), valid=valid_to,
+             feature_type=FEATURE_ORB, sensor_frame=0)
+    return f, t, T
+
+
+def make_pairs(n_pairs, n_kp=1000, desc_bytes=32, seed=777, **kw):
+    rng = np.random.default_rng(seed)
+    return [make_pair(rng, n_kp=n_kp, desc_bytes=desc_bytes, **kw) for _ in range(n_pairs)]
