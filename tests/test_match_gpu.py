@@ -1,0 +1,186 @@
+"""GPU parity tests of the edge-estimation half: HIP path (through the C ABI) vs the CPU oracle.
+Integer work (2-NN indices/distances, correspondence order, RANSAC votes, inlier sets) must be
+bit-exact; the pose/mse/information are float results of the same operation sequence and must
+also match bit for bit."""
+import numpy as np
+import pytest
+
+from uzliti_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher(capi):
+    m = capi.Match(ransac_threshold=0.1, ransac_iteration=100, ransac_break_percentage=0.6, seed=777)
+    yield m
+    m.close()
+
+
+def _add(m, f):
+    return m.add_frame(f["desc"], f["pos"], f["valid"], f["feature_type"], f["sensor_frame"])
+
+
+@pytest.mark.parametrize("nq,nt,nbytes", [(1000, 1000, 32), (300, 300, 64), (257, 513, 32), (7, 9, 32),
+                                          (64, 1, 32), (5, 0, 32), (100, 100, 20), (3000, 1500, 32)])
+def test_knn2_bit_exact(matcher, oracle, nq, nt, nbytes):
+    rng = np.random.default_rng(nq * 7919 + nt)
+    q = rng.integers(0, 256, (nq, nbytes), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, nbytes), dtype=np.uint8)
+    if nt >= 8:                       # deliberate ties and exact duplicates
+        t[5] = t[2]; t[7] = t[2]
+        q[0] = t[2]
+        q[1] = t[2]; q[1, 0] ^= 1
+    ff = matcher.add_frame(t, np.zeros((3, nt)), np.ones(nt, np.uint8))
+    ft = matcher.add_frame(q, np.zeros((3, nq)), np.ones(nq, np.uint8))
+    got = matcher.knn2(ff, ft, nq)
+    want = oracle.knn2(q, t)
+    for g, w, name in zip(got, want, ("idx0", "d0", "idx1", "d1")):
+        assert np.array_equal(g, w), name
+
+
+def _oracle_pair(oracle, f, t, cfg, job_id):
+    return oracle.estimate_edge([f], [t], ransac_threshold=cfg["thr"], ransac_iteration=cfg["it"],
+                                break_percentage=cfg["bp"], do_prosac=cfg.get("prosac", True),
+                                seed=cfg["seed"], job_id=job_id)
+
+
+def _compare(res, diag, j, want):
+    r = res[j]
+    assert r["ok"] == want["ok"]
+    assert r["n_matches"] == want["n_matches"]
+    assert r["n_corr"] == want["n_corr"]
+    m = want["n_corr"]
+    if diag is not None:
+        assert np.array_equal(diag["corr_query"][j, :m], want["corr_query"])
+        assert np.array_equal(diag["corr_train"][j, :m], want["corr_train"])
+        assert np.array_equal(diag["corr_dist"][j, :m], want["corr_dist"])
+        assert np.array_equal(diag["mask"][j, :m], want["mask"]), "inlier set differs"
+    assert r["iterations_run"] == want["iterations_run"]
+    assert r["best_iteration"] == want["best_iteration"]
+    assert r["consensus"] == want["consensus"]
+    assert np.array_equal(r["T"].reshape(3, 4), want["T"]), "pose not bit-identical"
+    assert r["mse"] == want["mse"]
+    assert np.array_equal(r["information"].reshape(6, 6), want["information"])
+
+
+@pytest.mark.parametrize("cfg", [dict(thr=0.1, it=100, bp=0.6, seed=777),
+                                 dict(thr=0.1, it=500, bp=1.0, seed=1),
+                                 dict(thr=0.05, it=300, bp=0.3, seed=5),
+                                 dict(thr=0.2, it=64, bp=0.6, seed=9, prosac=False)])
+def test_estimate_bit_exact_vs_oracle(matcher, oracle, cfg):
+    matcher.set_config(ransac_threshold=cfg["thr"], ransac_iteration=cfg["it"], ransac_break_percentage=cfg["bp"],
+                       seed=cfg["seed"], do_prosac=1 if cfg.get("prosac", True) else 0)
+    pairs = synth.make_pairs(12, n_kp=400, seed=cfg["seed"] + 100)
+    ids = [(_add(matcher, f), _add(matcher, t)) for f, t, _ in pairs]
+    job_ids = [1000 + 3 * j for j in range(len(pairs))]
+    res, diag = matcher.estimate(ids, job_ids=job_ids, max_corr=400)
+    n_ok = 0
+    for j, (f, t, T) in enumerate(pairs):
+        want = _oracle_pair(oracle, f, t, cfg, job_ids[j])
+        _compare(res, diag, j, want)
+        assert res[j]["frame_from"] == ids[j][0] and res[j]["frame_to"] == ids[j][1]
+        n_ok += int(want["consensus"] > 20)
+        if want["consensus"] > 50:        # sanity: the estimate is the true motion
+            assert np.abs(res[j]["T"].reshape(3, 4) - T).max() < 0.05
+    assert n_ok >= len(pairs) // 2
+
+
+def test_estimate_full_size_c3_shape(matcher, oracle):
+    """BASELINE config 3 shape (1000 x 1000 x 256 bit, 500 hypotheses) on a few pairs, bit-exact."""
+    cfg = dict(thr=0.1, it=500, bp=1.0, seed=777)
+    matcher.set_config(ransac_threshold=0.1, ransac_iteration=500, ransac_break_percentage=1.0, seed=777, do_prosac=1)
+    pairs = synth.make_pairs(4, n_kp=1000, seed=777)
+    ids = [(_add(matcher, f), _add(matcher, t)) for f, t, _ in pairs]
+    res, diag = matcher.estimate(ids, max_corr=1000)
+    for j, (f, t, T) in enumerate(pairs):
+        _compare(res, diag, j, _oracle_pair(oracle, f, t, cfg, j))
+
+
+def test_edge_cases(matcher, oracle):
+    matcher.set_config(ransac_threshold=0.1, ransac_iteration=50, ransac_break_percentage=0.6, seed=3, do_prosac=1)
+    rng = np.random.default_rng(11)
+    (f, t, _), = synth.make_pairs(1, n_kp=200, seed=5)
+    cfg = dict(thr=0.1, it=50, bp=0.6, seed=3)
+    cases = []
+    # (a) too few keypoints on one side (< 7): no sensor pair -> ok = 0 (estimator.cpp:47,93)
+    small = dict(desc=t["desc"][:6], pos=t["pos"][:, :6], valid=t["valid"][:6], feature_type=2, sensor_frame=0)
+    cases.append(([f], [small]))
+    # (b) different feature_type -> not matched
+    other = dict(t); other["feature_type"] = 3
+    cases.append(([f], [other]))
+    # (c) different sensor frame -> not matched
+    other2 = dict(t); other2["sensor_frame"] = 4
+    cases.append(([f], [other2]))
+    # (d) nothing valid in 3-D -> M = 0 -> ok = 0
+    inval = dict(t); inval["valid"] = np.zeros_like(t["valid"])
+    cases.append(([f], [inval]))
+    # (e) two FeatureData per node: the pair with more ratio-test survivors wins, first wins ties
+    noise = dict(desc=rng.integers(0, 256, t["desc"].shape, dtype=np.uint8), pos=t["pos"], valid=t["valid"],
+                 feature_type=2, sensor_frame=0)
+    cases.append(([f, noise], [noise, t]))
+    cases.append(([f, f], [t, t]))
+    # (f) pure noise descriptors: few matches, RANSAC finds no consensus of 3
+    cases.append(([noise], [dict(noise, desc=rng.integers(0, 256, t["desc"].shape, dtype=np.uint8))]))
+    jobs = []
+    for fr, to in cases:
+        jobs.append(([_add(matcher, x) for x in fr], [_add(matcher, x) for x in to]))
+    res, diag = matcher.estimate(jobs, max_corr=200)
+    for j, (fr, to) in enumerate(cases):
+        want = oracle.estimate_edge(fr, to, ransac_threshold=0.1, ransac_iteration=50, break_percentage=0.6,
+                                    do_prosac=True, seed=3, job_id=j)
+        _compare(res, diag, j, want)
+        if want["frame_from"] >= 0:
+            assert res[j]["frame_from"] == jobs[j][0][want["frame_from"]]
+            assert res[j]["frame_to"] == jobs[j][1][want["frame_to"]]
+        else:
+            assert res[j]["frame_from"] == -1
+    assert [int(r["ok"]) for r in res[:4]] == [0, 0, 0, 0]
+    assert res[4]["ok"] == 1 and res[5]["ok"] == 1
+    # empty batch
+    res0, _ = matcher.estimate([])
+    assert len(res0) == 0
+
+
+def test_ransac_points_matches_oracle(matcher, oracle):
+    """estimateSVD twin used by TransformationFilter (transformation_filter.cpp:272-275): 200 its, no PROSAC."""
+    rng = np.random.default_rng(3)
+    probs = []
+    for m in (3, 5, 10, 37, 100, 2, 0):
+        P = rng.normal(size=(3, m)) * 2
+        R = synth.quat_to_R(synth.quat_from_rotvec(rng.normal(size=3) * 0.3)); t = rng.normal(size=3)
+        Q = R @ P + t[:, None] + rng.normal(0, 0.02, (3, m))
+        if m >= 10:
+            Q[:, ::4] += rng.normal(0, 2.0, Q[:, ::4].shape)
+        probs.append((P, Q))
+    got = matcher.ransac_points(probs, 0.3, 200, 0.6, do_prosac=False, job_ids=list(range(50, 50 + len(probs))))
+    for b, (P, Q) in enumerate(probs):
+        want = oracle.prosac(P, Q, 0.3, 200, 0.6, do_prosac=False, seed=matcher.cfg.seed, job_id=50 + b)
+        assert got[b]["consensus"] == want["consensus"]
+        assert got[b]["iterations_run"] == want["iterations_run"]
+        assert np.array_equal(got[b]["mask"], want["mask"])
+        assert np.array_equal(got[b]["T"], want["T"])
+        assert got[b]["mse"] == want["mse"]
+
+
+def test_large_frame_global_tile(matcher, oracle):
+    """A frame too large for the LDS correspondence tile takes the HBM-scratch path; same result."""
+    matcher.set_config(ransac_threshold=0.1, ransac_iteration=64, ransac_break_percentage=1.0, seed=2, do_prosac=1)
+    (f, t, T), = synth.make_pairs(1, n_kp=3000, seed=21, outlier_frac=0.2)
+    ids = [(_add(matcher, f), _add(matcher, t))]
+    res, diag = matcher.estimate(ids, max_corr=3000)
+    want = oracle.estimate_edge([f], [t], ransac_threshold=0.1, ransac_iteration=64, break_percentage=1.0,
+                                do_prosac=True, seed=2, job_id=0)
+    _compare(res, diag, 0, want)
+
+
+def test_errors(capi, matcher):
+    with pytest.raises(capi.UzlError) as e:
+        matcher.estimate([(99999, 0)])
+    assert e.value.status == capi.UZL_ERR_NOT_FOUND
+    with pytest.raises(capi.UzlError) as e:
+        matcher.add_frame(np.zeros((4, 30), np.uint8), np.zeros((3, 4)), np.ones(4, np.uint8))
+    assert e.value.status == capi.UZL_ERR_BAD_ARG
+    with pytest.raises(capi.UzlError):
+        matcher.set_config(ransac_iteration=0)
+    matcher.set_config(ransac_iteration=100)

@@ -1,0 +1,356 @@
+"""ctypes binding of libuzl_mi355x.so (include/uzl_mi355x.h) — the only way Python reaches the HIP path.
+
+There is no fallback: if the shared library has not been built, or no HIP device is visible when a
+handle is created, the calls raise.  Tests and bench.py drive the product exclusively through this C ABI.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuzl_mi355x.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+c_f64p = C.POINTER(C.c_double)
+c_i32p = C.POINTER(C.c_int32)
+c_u8p = C.POINTER(C.c_uint8)
+c_u64p = C.POINTER(C.c_uint64)
+
+UZL_OK = 0
+UZL_ERR_BAD_ARG = -1
+UZL_ERR_NO_DEVICE = -2
+UZL_ERR_HIP = -3
+UZL_ERR_NOT_CONVERGED = -4
+UZL_ERR_BUSY = -5
+UZL_ERR_OOM = -6
+UZL_ERR_NOT_FOUND = -7
+UZL_ERR_STATE = -8
+
+
+class UzlError(RuntimeError):
+    def __init__(self, status, msg=""):
+        super().__init__(f"uzl status {status}: {msg}")
+        self.status = status
+
+
+class MatchCfg(C.Structure):
+    _fields_ = [("ransac_threshold", C.c_double), ("link_covariance", C.c_double),
+                ("ransac_iteration", C.c_int32), ("ransac_break_percentage", C.c_double),
+                ("use_epnp", C.c_int32), ("do_prosac", C.c_int32), ("device", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("desc", c_u8p), ("n", C.c_int32), ("bytes_per_desc", C.c_int32),
+                ("pos_xyz", c_f64p), ("valid3d", c_u8p), ("feature_type", C.c_int32),
+                ("sensor_frame", C.c_int32), ("displacement", C.c_double * 12)]
+
+
+class PairJob(C.Structure):
+    _fields_ = [("job_id", C.c_uint64), ("from_begin", C.c_int32), ("from_count", C.c_int32),
+                ("to_begin", C.c_int32), ("to_count", C.c_int32)]
+
+
+class EdgeResult(C.Structure):
+    _fields_ = [("job_id", C.c_uint64), ("ok", C.c_int32), ("consensus", C.c_int32),
+                ("n_matches", C.c_int32), ("n_corr", C.c_int32), ("frame_from", C.c_int32),
+                ("frame_to", C.c_int32), ("iterations_run", C.c_int32), ("best_iteration", C.c_int32),
+                ("mse", C.c_double), ("T", C.c_double * 12), ("information", C.c_double * 36)]
+
+
+EDGE_RESULT_DTYPE = np.dtype([("job_id", "<u8"), ("ok", "<i4"), ("consensus", "<i4"), ("n_matches", "<i4"),
+                              ("n_corr", "<i4"), ("frame_from", "<i4"), ("frame_to", "<i4"),
+                              ("iterations_run", "<i4"), ("best_iteration", "<i4"), ("mse", "<f8"),
+                              ("T", "<f8", (12,)), ("information", "<f8", (36,))], align=True)
+PAIR_JOB_DTYPE = np.dtype([("job_id", "<u8"), ("from_begin", "<i4"), ("from_count", "<i4"),
+                           ("to_begin", "<i4"), ("to_count", "<i4")], align=True)
+
+
+class PgoCfg(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("use_odometry_parameters", C.c_int32),
+                ("optimize_xy_only", C.c_int32), ("device", C.c_int32), ("pcg_tol", C.c_double),
+                ("pcg_max_iter", C.c_int32), ("huber_delta", C.c_double), ("verbose", C.c_int32)]
+
+
+class PgoStats(C.Structure):
+    _fields_ = [("iterations_done", C.c_int32), ("lm_trials", C.c_int32), ("pcg_iterations", C.c_int32),
+                ("terminated_early", C.c_int32), ("n_vertices", C.c_int32), ("n_edges", C.c_int32),
+                ("n_gauge_fixed", C.c_int32), ("pcg_not_converged", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+                ("solve_ms", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+NODE_DTYPE = np.dtype([("pose", "<f8", (12,)), ("fixed", "<i4")], align=True)
+EDGE_DTYPE = np.dtype([("from", "<i4"), ("to", "<i4"), ("type", "<i4"), ("sensor_from", "<i4"),
+                       ("sensor_to", "<i4"), ("valid", "<i4"), ("transform", "<f8", (12,)),
+                       ("displacement_from", "<f8", (12,)), ("displacement_to", "<f8", (12,)),
+                       ("information", "<f8", (36,))], align=True)
+
+_lib = None
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of the in-tree shared library (csrc/Makefile)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
+    return LIB_PATH
+
+
+def lib():
+    """Load libuzl_mi355x.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UzlError(UZL_ERR_STATE, f"{LIB_PATH} is missing: run __graft_entry__.build() / make -C {CSRC}; "
+                                          "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.uzl_status_string.restype = C.c_char_p
+        L.uzl_match_last_error.restype = C.c_char_p
+        L.uzl_match_last_error.argtypes = [C.c_void_p]
+        L.uzl_match_destroy.restype = None
+        L.uzl_match_destroy.argtypes = [C.c_void_p]
+        L.uzl_match_cfg_default.restype = None
+        if hasattr(L, "uzl_pgo_last_error"):
+            L.uzl_pgo_last_error.restype = C.c_char_p
+            L.uzl_pgo_last_error.argtypes = [C.c_void_p]
+            L.uzl_pgo_destroy.restype = None
+            L.uzl_pgo_destroy.argtypes = [C.c_void_p]
+            L.uzl_pgo_cfg_default.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def device_count():
+    return lib().uzl_device_count()
+
+
+# --------------------------------------------------------------------------------------- estimator
+class Match:
+    """Thin object wrapper over the uzl_match_* C ABI."""
+
+    def __init__(self, **cfg):
+        L = lib()
+        c = MatchCfg()
+        L.uzl_match_cfg_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = C.c_void_p()
+        rc = L.uzl_match_create(C.byref(c), C.byref(self._h))
+        if rc != UZL_OK:
+            raise UzlError(rc, L.uzl_status_string(rc).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uzl_match_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != UZL_OK:
+            raise UzlError(rc, lib().uzl_match_last_error(self._h).decode())
+
+    def set_config(self, **cfg):
+        for k, v in cfg.items():
+            setattr(self.cfg, k, v)
+        self._check(lib().uzl_match_set_config(self._h, C.byref(self.cfg)))
+
+    def add_frame(self, desc, pos, valid, feature_type=2, sensor_frame=0):
+        """desc (n,bytes) u8; pos (3,n) f64; valid (n) u8 -> frame id."""
+        d = np.ascontiguousarray(desc, np.uint8)
+        p = np.ascontiguousarray(np.asarray(pos, np.float64).T)   # (n,3) row-major == 3 x n column-major
+        v = np.ascontiguousarray(valid, np.uint8)
+        f = Frame()
+        f.desc = _p(d, c_u8p); f.n = d.shape[0]; f.bytes_per_desc = d.shape[1] if d.ndim == 2 else 0
+        f.pos_xyz = _p(p, c_f64p); f.valid3d = _p(v, c_u8p)
+        f.feature_type = int(feature_type); f.sensor_frame = int(sensor_frame)
+        f.displacement[:] = np.eye(3, 4).reshape(12).tolist()
+        fid = C.c_int32(-1)
+        self._check(lib().uzl_match_add_frame(self._h, C.byref(f), C.byref(fid)))
+        return fid.value
+
+    def remove_frame(self, fid):
+        self._check(lib().uzl_match_remove_frame(self._h, C.c_int32(fid)))
+
+    def frame_count(self):
+        return lib().uzl_match_frame_count(self._h)
+
+    @staticmethod
+    def _jobs(pairs, job_ids):
+        """pairs: list of (from_frame_ids, to_frame_ids) (ints or lists)."""
+        n = len(pairs)
+        jobs = np.zeros(n, PAIR_JOB_DTYPE)
+        ids = []
+        for j, (fr, to) in enumerate(pairs):
+            fr = [fr] if np.isscalar(fr) else list(fr)
+            to = [to] if np.isscalar(to) else list(to)
+            jobs[j]["job_id"] = job_ids[j] if job_ids is not None else j
+            jobs[j]["from_begin"] = len(ids); jobs[j]["from_count"] = len(fr); ids += fr
+            jobs[j]["to_begin"] = len(ids); jobs[j]["to_count"] = len(to); ids += to
+        return jobs, np.asarray(ids, np.int32)
+
+    def estimate(self, pairs, job_ids=None, max_corr=0):
+        """Batched estimateEdgeImpl. Returns (results structured array, diag dict or None)."""
+        jobs, ids = self._jobs(pairs, job_ids)
+        n = len(pairs)
+        res = np.zeros(n, EDGE_RESULT_DTYPE)
+        diag = None
+        cq = ct = cd = mk = None
+        if max_corr > 0:
+            cq = np.empty((n, max_corr), np.int32); ct = np.empty((n, max_corr), np.int32)
+            cd = np.empty((n, max_corr), np.int32); mk = np.empty((n, max_corr), np.uint8)
+            diag = dict(corr_query=cq, corr_train=ct, corr_dist=cd, mask=mk)
+        self._check(lib().uzl_match_estimate(self._h, C.c_int32(n), _p(jobs, C.c_void_p), _p(ids, c_i32p),
+                                             C.c_int32(len(ids)), _p(res, C.c_void_p), C.c_int32(max_corr),
+                                             _p(cq, c_i32p), _p(ct, c_i32p), _p(cd, c_i32p), _p(mk, c_u8p)))
+        return res, diag
+
+    def launch(self, pairs, job_ids=None):
+        jobs, ids = self._jobs(pairs, job_ids)
+        self._n_launched = len(pairs)
+        self._check(lib().uzl_match_launch(self._h, C.c_int32(len(pairs)), _p(jobs, C.c_void_p), _p(ids, c_i32p),
+                                           C.c_int32(len(ids)), C.c_int32(0)))
+
+    def launch_raw(self, jobs, ids):
+        """Pre-built PAIR_JOB_DTYPE array + frame id array (no Python work inside a timed region)."""
+        self._n_launched = len(jobs)
+        self._check(lib().uzl_match_launch(self._h, C.c_int32(len(jobs)), _p(jobs, C.c_void_p), _p(ids, c_i32p),
+                                           C.c_int32(len(ids)), C.c_int32(0)))
+
+    def collect(self, out=None):
+        res = out if out is not None else np.zeros(self._n_launched, EDGE_RESULT_DTYPE)
+        self._check(lib().uzl_match_collect(self._h, _p(res, C.c_void_p), None, None, None, None))
+        return res
+
+    def knn2(self, frame_from, frame_to, nq):
+        out = [np.empty(nq, np.int32) for _ in range(4)]
+        self._check(lib().uzl_match_knn2(self._h, C.c_int32(frame_from), C.c_int32(frame_to),
+                                         *[_p(o, c_i32p) for o in out]))
+        return tuple(out)
+
+    def ransac_points(self, problems, max_error, iterations, break_percentage, do_prosac=True, job_ids=None):
+        """problems: list of (P (3,M), Q (3,M)). Returns list of dicts like oracle.prosac."""
+        nb = len(problems)
+        offs = np.zeros(nb + 1, np.int32)
+        for b, (P, _) in enumerate(problems):
+            offs[b + 1] = offs[b] + np.asarray(P).shape[1]
+        tot = int(offs[-1])
+        Pc = np.empty((max(tot, 1), 3)); Qc = np.empty((max(tot, 1), 3))
+        for b, (P, Q) in enumerate(problems):
+            Pc[offs[b]:offs[b + 1]] = np.asarray(P).T; Qc[offs[b]:offs[b + 1]] = np.asarray(Q).T
+        T = np.empty((nb, 12)); cons = np.empty(nb, np.int32); mse = np.empty(nb); itr = np.empty(nb, np.int32)
+        mask = np.zeros(max(tot, 1), np.uint8)
+        jid = np.asarray(job_ids if job_ids is not None else np.arange(nb), np.uint64)
+        self._check(lib().uzl_ransac_points(self._h, C.c_int32(nb), _p(offs, c_i32p), _p(Pc, c_f64p), _p(Qc, c_f64p),
+                                            C.c_double(max_error), C.c_int32(iterations), C.c_double(break_percentage),
+                                            C.c_int32(1 if do_prosac else 0), _p(jid, c_u64p), _p(T, c_f64p),
+                                            _p(cons, c_i32p), _p(mse, c_f64p), _p(itr, c_i32p), _p(mask, c_u8p)))
+        return [dict(T=T[b].reshape(3, 4), consensus=int(cons[b]), mse=float(mse[b]), iterations_run=int(itr[b]),
+                     mask=mask[offs[b]:offs[b + 1]].copy()) for b in range(nb)]
+
+    def set_profiling(self, on):
+        self._check(lib().uzl_match_set_profiling(self._h, C.c_int32(1 if on else 0)))
+
+    def kernel_times(self):
+        cap = 32
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); ln = (C.c_int32 * cap)()
+        n = lib().uzl_match_kernel_times(self._h, C.c_int32(cap), names, ms, ln)
+        return {names[i].decode(): dict(ms=ms[i], launches=ln[i]) for i in range(max(n, 0))}
+
+
+# --------------------------------------------------------------------------------------- optimizer
+class Pgo:
+    """Thin object wrapper over the uzl_pgo_* C ABI."""
+
+    def __init__(self, **cfg):
+        L = lib()
+        c = PgoCfg()
+        L.uzl_pgo_cfg_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = C.c_void_p()
+        rc = L.uzl_pgo_create(C.byref(c), C.byref(self._h))
+        if rc != UZL_OK:
+            raise UzlError(rc, L.uzl_status_string(rc).decode())
+        self.n = 0
+        self.e_in = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uzl_pgo_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc, allow=()):
+        if rc != UZL_OK and rc not in allow:
+            raise UzlError(rc, lib().uzl_pgo_last_error(self._h).decode())
+        return rc
+
+    def set_config(self, **cfg):
+        for k, v in cfg.items():
+            setattr(self.cfg, k, v)
+        self._check(lib().uzl_pgo_set_config(self._h, C.byref(self.cfg)))
+
+    def add_graph(self, nodes_pose, nodes_fixed, edges, sensors=None):
+        """Reference-shaped input (SlamNode / SlamEdge arrays, see synth.make_pose_graph)."""
+        n = len(nodes_fixed); ne = len(edges["from"])
+        na = np.zeros(max(n, 1), NODE_DTYPE)
+        na["pose"][:n] = np.asarray(nodes_pose, np.float64).reshape(n, 12); na["fixed"][:n] = nodes_fixed
+        ea = np.zeros(max(ne, 1), EDGE_DTYPE)
+        for k in ("from", "to", "type", "sensor_from", "sensor_to", "valid"):
+            ea[k][:ne] = edges[k]
+        for k, w in (("transform", 12), ("displacement_from", 12), ("displacement_to", 12), ("information", 36)):
+            ea[k][:ne] = np.asarray(edges[k], np.float64).reshape(ne, w)
+        S = np.ascontiguousarray(sensors, np.float64).reshape(-1, 12) if sensors is not None and len(sensors) else None
+        self._check(lib().uzl_pgo_add_graph(self._h, C.c_int32(n), _p(na, C.c_void_p), C.c_int32(ne), _p(ea, C.c_void_p),
+                                            C.c_int32(0 if S is None else S.shape[0]), _p(S, c_f64p)))
+        self.n = n; self.e_in = ne
+
+    def set_graph(self, poses, fixed, ij, meas, info, robust):
+        P = np.ascontiguousarray(poses, np.float64).reshape(-1, 12); f = np.ascontiguousarray(fixed, np.uint8)
+        ijc = np.ascontiguousarray(ij, np.int32).reshape(-1, 2)
+        Z = np.ascontiguousarray(meas, np.float64).reshape(-1, 12)
+        Om = np.ascontiguousarray(info, np.float64).reshape(-1, 36); rb = np.ascontiguousarray(robust, np.uint8)
+        self._check(lib().uzl_pgo_set_graph(self._h, C.c_int32(P.shape[0]), _p(P, c_f64p), _p(f, c_u8p),
+                                            C.c_int32(ijc.shape[0]), _p(ijc, c_i32p), _p(Z, c_f64p), _p(Om, c_f64p),
+                                            _p(rb, c_u8p)))
+        self.n = P.shape[0]; self.e_in = ijc.shape[0]
+
+    def optimize(self, iterations=0):
+        st = PgoStats()
+        rc = self._check(lib().uzl_pgo_optimize(self._h, C.c_int32(iterations), C.byref(st)),
+                         allow=(UZL_ERR_NOT_CONVERGED,))
+        d = st.as_dict(); d["status"] = rc
+        return d
+
+    def store(self):
+        poses = np.empty((self.n, 12)); err = np.empty(max(self.e_in, 1)); used = np.empty(max(self.e_in, 1), np.uint8)
+        self._check(lib().uzl_pgo_store(self._h, _p(poses, c_f64p), _p(err, c_f64p), _p(used, c_u8p)))
+        return poses, err[:self.e_in], used[:self.e_in]
+
+    def get_fixed(self):
+        f = np.empty(self.n, np.uint8)
+        self._check(lib().uzl_pgo_get_fixed(self._h, _p(f, c_u8p)))
+        return f
+
+    def set_profiling(self, on):
+        self._check(lib().uzl_pgo_set_profiling(self._h, C.c_int32(1 if on else 0)))
+
+    def kernel_times(self):
+        cap = 64
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); ln = (C.c_int32 * cap)()
+        n = lib().uzl_pgo_kernel_times(self._h, C.c_int32(cap), names, ms, ln)
+        return {names[i].decode(): dict(ms=ms[i], launches=ln[i]) for i in range(max(n, 0))}

@@ -1,0 +1,655 @@
+// match_kernels.hip — gfx950 kernels of the edge-estimation half.
+//
+//   knn2_kernel      M1  brute-force 2-NN Hamming match (feature_transformation_estimator.cpp:38,58):
+//                        one lane per query descriptor (registers), train descriptors streamed through
+//                        the scalar cache (wave-uniform address -> s_load), v_xor + v_bcnt accumulate,
+//                        top-2 kept as packed (distance<<20 | trainIdx) keys with v_med3/v_min.
+//   estimate_kernel  M2..M9  one workgroup per node pair: sensor-pair selection (:73-86), ratio test
+//                        (:65-71), 3-D filter (:101-112), sort by (distance, queryIdx) (:114), gather into
+//                        an LDS tile (:118-124), PROSAC with one hypothesis per lane and LDS-broadcast
+//                        correspondences (:186-243), refit + recount + mse (:245-296), information (:133-137).
+//
+// This translation unit is compiled with -ffp-contract=off: the float pose recipe and the double
+// consensus test round after every operation, exactly like the CPU oracle, so that inlier sets are
+// bit-identical.  Only + - * / sqrt fabs and comparisons appear on that path.
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+#include "match_types.hpp"
+
+namespace uzl {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------
+// M1  2-NN Hamming
+// ------------------------------------------------------------------------------------------------
+// invariant best1 <= best2: new second-best = min(best2, max(best1, key))
+__device__ __forceinline__ uint32_t second_of(uint32_t best1, uint32_t best2, uint32_t key)
+{
+    return min(best2, max(best1, key));
+}
+
+template <int W>
+__global__ __launch_bounds__(kBlock) void knn2_kernel(const uint32_t* __restrict__ arena,
+                                                      const Combo* __restrict__ combos,
+                                                      uint2* __restrict__ knn)
+{
+    const Combo c = combos[blockIdx.y];
+    if (c.words != W) return;                                  // other instantiation's combo
+    const int q0 = blockIdx.x * kBlock;
+    if (q0 >= c.nq) return;                                    // wave-uniform
+    const int q = q0 + (int)threadIdx.x;
+    const int qc = q < c.nq ? q : c.nq - 1;
+    const uint32_t* __restrict__ qd = arena + c.desc_to_off + (size_t)qc * W;
+    uint32_t qw[W];
+#pragma unroll
+    for (int k = 0; k < W; k += 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(qd + k);
+        qw[k] = v.x; qw[k + 1] = v.y; qw[k + 2] = v.z; qw[k + 3] = v.w;
+    }
+    uint32_t best1 = 0xffffffffu, best2 = 0xffffffffu;
+    const uint32_t* __restrict__ td = arena + c.desc_from_off;  // wave-uniform base
+    const int nt = c.nt;
+#pragma unroll 4
+    for (int t = 0; t < nt; ++t) {
+        const uint32_t* __restrict__ tr = td + (size_t)t * W;   // wave-uniform -> scalar loads
+        uint32_t d = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) d += __popc(qw[k] ^ tr[k]);
+        const uint32_t key = (d << kIdxBits) | (uint32_t)t;
+        best2 = second_of(best1, best2, key);
+        best1 = min(best1, key);
+    }
+    if (q < c.nq) knn[c.knn_off + q] = make_uint2(best1, best2);
+}
+
+// generic descriptor width (words not 8 / 16): query words re-read from L1 each step
+__global__ __launch_bounds__(kBlock) void knn2_generic_kernel(const uint32_t* __restrict__ arena,
+                                                              const Combo* __restrict__ combos,
+                                                              uint2* __restrict__ knn)
+{
+    const Combo c = combos[blockIdx.y];
+    if (c.words == 8 || c.words == 16) return;
+    const int q0 = blockIdx.x * kBlock;
+    if (q0 >= c.nq) return;
+    const int q = q0 + (int)threadIdx.x;
+    const int qc = q < c.nq ? q : c.nq - 1;
+    const int W = c.words;
+    const uint32_t* __restrict__ qd = arena + c.desc_to_off + (size_t)qc * W;
+    const uint32_t* __restrict__ td = arena + c.desc_from_off;
+    uint32_t best1 = 0xffffffffu, best2 = 0xffffffffu;
+    for (int t = 0; t < c.nt; ++t) {
+        const uint32_t* __restrict__ tr = td + (size_t)t * W;
+        uint32_t d = 0;
+        for (int k = 0; k < W; ++k) d += __popc(qd[k] ^ tr[k]);
+        const uint32_t key = (d << kIdxBits) | (uint32_t)t;
+        best2 = second_of(best1, best2, key);
+        best1 = min(best1, key);
+    }
+    if (q < c.nq) knn[c.knn_off + q] = make_uint2(best1, best2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// M6a  counter-based sampling (replaces std::random_shuffle on a persistent permutation, :217-225;
+//      see oracle/uzl_oracle_match.c for the equivalence argument)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31; return x;
+}
+__device__ __forceinline__ uint64_t stream_key(uint64_t seed, uint64_t job)
+{
+    return mix64(seed ^ mix64(job + 0x9e3779b97f4a7c15ULL));
+}
+__device__ __forceinline__ uint32_t draw_below(uint64_t key, uint32_t iter, uint32_t k, uint32_t n)
+{
+    const uint64_t h = mix64(key + 0x9e3779b97f4a7c15ULL * (uint64_t)(iter * 4u + k + 1u));
+    return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32);
+}
+__device__ __forceinline__ int prosac_prefix(int iter, int iterations, int m)
+{
+    const int n = (int)ceil(((iter + 3.) / iterations) * m);     // :217
+    return n < m ? n : m;
+}
+// First three steps of a forward Fisher-Yates shuffle over the virtual identity array of length n
+// (step s swaps position s with position j_s drawn from [s, n); a step with n - s < 2 is a no-op).
+// Only positions 0, j0 and j1 can differ from the identity when step 2 runs, which gives the closed
+// form below (same sequence as uzlo_sample3's explicit swap bookkeeping).
+__device__ __forceinline__ void sample3(uint64_t key, int iter, int n, int& s0, int& s1, int& s2)
+{
+    const int j0 = (n >= 2) ? (int)draw_below(key, (uint32_t)iter, 0u, (uint32_t)n) : 0;
+    const int j1 = (n >= 3) ? 1 + (int)draw_below(key, (uint32_t)iter, 1u, (uint32_t)(n - 1)) : 1;
+    const int j2 = (n >= 4) ? 2 + (int)draw_below(key, (uint32_t)iter, 2u, (uint32_t)(n - 2)) : 2;
+    s0 = j0;
+    s1 = (j1 == j0) ? 0 : j1;
+    int v = j2;
+    if (j2 == j0) v = 0;
+    if (j2 == j1) v = (j0 == 1) ? 0 : 1;
+    s2 = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// M7  estimatePoseSVD (:299-314) -> pcl::TransformationFromCorrespondences [EXT], float.
+//     Operation order identical to uzlo_pose_svd / uzlo_svd3f in oracle/uzl_oracle_match.c.
+// ------------------------------------------------------------------------------------------------
+struct PoseAcc {
+    float m1x, m1y, m1z, m2x, m2y, m2z;
+    float c00, c01, c02, c10, c11, c12, c20, c21, c22;
+    float accw;
+};
+__device__ __forceinline__ void pose_init(PoseAcc& a)
+{
+    a.m1x = a.m1y = a.m1z = a.m2x = a.m2y = a.m2z = 0.f;
+    a.c00 = a.c01 = a.c02 = a.c10 = a.c11 = a.c12 = a.c20 = a.c21 = a.c22 = 0.f;
+    a.accw = 0.f;
+}
+__device__ __forceinline__ void pose_add(PoseAcc& a, double px, double py, double pz, double qx, double qy, double qz)
+{
+    const float p0 = (float)px, p1 = (float)py, p2 = (float)pz;
+    const float q0 = (float)qx, q1 = (float)qy, q2 = (float)qz;
+    a.accw += 1.f;
+    const float alpha = 1.f / a.accw;
+    const float om = 1.f - alpha;
+    const float d10 = p0 - a.m1x, d11 = p1 - a.m1y, d12 = p2 - a.m1z;
+    const float d20 = q0 - a.m2x, d21 = q1 - a.m2y, d22 = q2 - a.m2z;
+    a.c00 = om * (a.c00 + alpha * (d20 * d10)); a.c01 = om * (a.c01 + alpha * (d20 * d11)); a.c02 = om * (a.c02 + alpha * (d20 * d12));
+    a.c10 = om * (a.c10 + alpha * (d21 * d10)); a.c11 = om * (a.c11 + alpha * (d21 * d11)); a.c12 = om * (a.c12 + alpha * (d21 * d12));
+    a.c20 = om * (a.c20 + alpha * (d22 * d10)); a.c21 = om * (a.c21 + alpha * (d22 * d11)); a.c22 = om * (a.c22 + alpha * (d22 * d12));
+    a.m1x += alpha * d10; a.m1y += alpha * d11; a.m1z += alpha * d12;
+    a.m2x += alpha * d20; a.m2y += alpha * d21; a.m2z += alpha * d22;
+}
+
+struct M3 { float m[9]; };   // row-major, only ever indexed with compile-time constants
+
+__device__ __forceinline__ float det3f(const M3& a)
+{
+    const float t0 = a.m[0] * (a.m[4] * a.m[8] - a.m[5] * a.m[7]);
+    const float t1 = a.m[1] * (a.m[3] * a.m[8] - a.m[5] * a.m[6]);
+    const float t2 = a.m[2] * (a.m[3] * a.m[7] - a.m[4] * a.m[6]);
+    return (t0 - t1) + t2;
+}
+
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_step(M3& W, M3& U, M3& V, float& maxdiag, bool& rotated)
+{
+    const float precision = 2.f * FLT_EPSILON;
+    const float tiny = FLT_MIN;
+    float thr = precision * maxdiag;
+    if (thr < tiny) thr = tiny;
+    if (!(fabsf(W.m[P * 3 + Q]) > thr || fabsf(W.m[Q * 3 + P]) > thr)) return;
+    rotated = true;
+    const float a = W.m[P * 3 + P], b = W.m[P * 3 + Q], c = W.m[Q * 3 + P], d = W.m[Q * 3 + Q];
+    float c1, s1;
+    const float t = a + d, dd = c - b;
+    if (fabsf(dd) < tiny) { c1 = 1.f; s1 = 0.f; }
+    else { const float u = t / dd; const float tmp = sqrtf(1.f + u * u); s1 = 1.f / tmp; c1 = u / tmp; }
+    const float x = c1 * a + s1 * c;
+    const float y = c1 * b + s1 * d;
+    const float z = -s1 * b + c1 * d;
+    float cj, sj;
+    if (fabsf(y) < tiny) { cj = 1.f; sj = 0.f; }
+    else {
+        const float tau = (z - x) / (2.f * y);
+        const float w = sqrtf(tau * tau + 1.f);
+        const float tt = (tau >= 0.f) ? 1.f / (tau + w) : -1.f / (w - tau);
+        cj = 1.f / sqrtf(tt * tt + 1.f);
+        sj = tt * cj;
+    }
+    const float cl = cj * c1 + sj * s1;
+    const float sl = cj * s1 - sj * c1;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float wp = W.m[P * 3 + k], wq = W.m[Q * 3 + k];
+        W.m[P * 3 + k] = cl * wp + sl * wq;
+        W.m[Q * 3 + k] = cl * wq - sl * wp;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float up = U.m[k * 3 + P], uq = U.m[k * 3 + Q];
+        U.m[k * 3 + P] = cl * up + sl * uq;
+        U.m[k * 3 + Q] = cl * uq - sl * up;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float wp = W.m[k * 3 + P], wq = W.m[k * 3 + Q];
+        W.m[k * 3 + P] = cj * wp - sj * wq;
+        W.m[k * 3 + Q] = sj * wp + cj * wq;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float vp = V.m[k * 3 + P], vq = V.m[k * 3 + Q];
+        V.m[k * 3 + P] = cj * vp - sj * vq;
+        V.m[k * 3 + Q] = sj * vp + cj * vq;
+    }
+    const float mp = fabsf(W.m[P * 3 + P]), mq = fabsf(W.m[Q * 3 + Q]);
+    if (mp > maxdiag) maxdiag = mp;
+    if (mq > maxdiag) maxdiag = mq;
+}
+
+template <int A, int B>
+__device__ __forceinline__ void swap_cols(M3& U, M3& V, float* S)
+{
+    const float ts = S[A]; S[A] = S[B]; S[B] = ts;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float tu = U.m[k * 3 + A]; U.m[k * 3 + A] = U.m[k * 3 + B]; U.m[k * 3 + B] = tu;
+        const float tv = V.m[k * 3 + A]; V.m[k * 3 + A] = V.m[k * 3 + B]; V.m[k * 3 + B] = tv;
+    }
+}
+
+__device__ __forceinline__ void svd3f(const M3& A, M3& U, M3& V)
+{
+    M3 W;
+    float scale = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { const float a = fabsf(A.m[i]); if (a > scale) scale = a; }
+    if (scale == 0.f) scale = 1.f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) W.m[i] = A.m[i] / scale;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { U.m[i] = (i % 4 == 0) ? 1.f : 0.f; V.m[i] = U.m[i]; }
+    float maxdiag = fabsf(W.m[0]);
+    if (fabsf(W.m[4]) > maxdiag) maxdiag = fabsf(W.m[4]);
+    if (fabsf(W.m[8]) > maxdiag) maxdiag = fabsf(W.m[8]);
+    for (int sweep = 0; sweep < 64; sweep++) {
+        bool rotated = false;
+        jacobi_step<1, 0>(W, U, V, maxdiag, rotated);
+        jacobi_step<2, 0>(W, U, V, maxdiag, rotated);
+        jacobi_step<2, 1>(W, U, V, maxdiag, rotated);
+        if (!rotated) break;
+    }
+    float S[3];
+    {
+        float s = W.m[0]; if (s < 0.f) { s = -s; U.m[0] = -U.m[0]; U.m[3] = -U.m[3]; U.m[6] = -U.m[6]; } S[0] = s * scale;
+        s = W.m[4]; if (s < 0.f) { s = -s; U.m[1] = -U.m[1]; U.m[4] = -U.m[4]; U.m[7] = -U.m[7]; } S[1] = s * scale;
+        s = W.m[8]; if (s < 0.f) { s = -s; U.m[2] = -U.m[2]; U.m[5] = -U.m[5]; U.m[8] = -U.m[8]; } S[2] = s * scale;
+    }
+    // selection sort, descending, first maximum wins
+    {
+        int pos = 0;
+        if (S[1] > S[0]) pos = 1;
+        if (pos == 0) { if (S[2] > S[0]) pos = 2; } else { if (S[2] > S[1]) pos = 2; }
+        if (pos == 1) swap_cols<0, 1>(U, V, S);
+        else if (pos == 2) swap_cols<0, 2>(U, V, S);
+        if (S[2] > S[1]) swap_cols<1, 2>(U, V, S);
+    }
+}
+
+__device__ __forceinline__ void pose_finish(const PoseAcc& a, double T[12])
+{
+    M3 C, U, V;
+    C.m[0] = a.c00; C.m[1] = a.c01; C.m[2] = a.c02;
+    C.m[3] = a.c10; C.m[4] = a.c11; C.m[5] = a.c12;
+    C.m[6] = a.c20; C.m[7] = a.c21; C.m[8] = a.c22;
+    svd3f(C, U, V);
+    const float sg = (det3f(U) * det3f(V) < 0.f) ? -1.f : 1.f;
+    float R[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            R[r * 3 + c] = (U.m[r * 3 + 0] * V.m[c * 3 + 0] + U.m[r * 3 + 1] * V.m[c * 3 + 1]) + (U.m[r * 3 + 2] * sg) * V.m[c * 3 + 2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const float rm = (R[r * 3 + 0] * a.m1x + R[r * 3 + 1] * a.m1y) + R[r * 3 + 2] * a.m1z;
+        const float m2 = (r == 0) ? a.m2x : (r == 1) ? a.m2y : a.m2z;
+        const float t = m2 - rm;
+        T[r * 4 + 0] = (double)R[r * 3 + 0];
+        T[r * 4 + 1] = (double)R[r * 3 + 1];
+        T[r * 4 + 2] = (double)R[r * 3 + 2];
+        T[r * 4 + 3] = (double)t;
+    }
+}
+
+// M8 distance^2 / distance of one correspondence under T (operation order of uzlo point_dist)
+__device__ __forceinline__ double point_dist2(const double* __restrict__ pq, const double* T)
+{
+    const double px = pq[0], py = pq[1], pz = pq[2];
+    const double x = ((T[0] * px + T[1] * py) + T[2] * pz) + T[3];
+    const double y = ((T[4] * px + T[5] * py) + T[6] * pz) + T[7];
+    const double z = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
+    const double dx = x - pq[3], dy = y - pq[4], dz = z - pq[5];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// smallest double s with sqrt_rn(s) >= t: then  sqrt(d2) < t  <=>  d2 < s  (sqrt_rn is monotone),
+// which removes the f64 sqrt from the vote loop without changing a single vote.
+__device__ __forceinline__ double sqrt_threshold(double t)
+{
+    if (!(t > 0.)) return 0.;
+    double y = t * t;
+    for (int k = 0; k < 8 && sqrt(y) >= t; k++) y = __longlong_as_double(__double_as_longlong(y) - 1);
+    for (int k = 0; k < 16 && sqrt(y) < t; k++) y = __longlong_as_double(__double_as_longlong(y) + 1);
+    return y;
+}
+
+// ------------------------------------------------------------------------------------------------
+// block helpers (256 threads = 4 waves of 64)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int block_sum(int v, int* s_part)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_part[4];
+    __shared__ int s_misc[8];
+    __shared__ double s_T[12];
+    __shared__ double s_dbl[2];
+
+    const int tid = threadIdx.x;
+    const int jb = blockIdx.x;
+    const Job job = A.jobs[jb];
+    const RansacParams prm = A.prm;
+    const int iters = prm.iterations;
+
+    // ---- LDS carve-up (all offsets multiples of 16 B)
+    uint32_t* s_keys = reinterpret_cast<uint32_t*>(smem);                       // sort_cap u32
+    size_t off = (size_t)A.sort_cap * 4;
+    int* s_cnt = reinterpret_cast<int*>(smem + off);                            // iters (padded to 4)
+    off += (size_t)((iters + 3) & ~3) * 4;
+    double* pq; double* dist; uint8_t* mask;
+    if constexpr (IN_LDS) {
+        pq = reinterpret_cast<double*>(smem + off); off += (size_t)prm.lds_points * 48;
+        dist = reinterpret_cast<double*>(smem + off); off += (size_t)prm.lds_points * 8;
+        mask = smem + off;
+    } else {
+        pq = A.pq_scratch + (size_t)jb * prm.max_corr * 6;
+        dist = A.dist_scratch + (size_t)jb * prm.max_corr;
+        mask = A.mask_scratch + (size_t)jb * prm.max_corr;
+    }
+
+    int r_n_matches = 0, r_frame_from = -1, r_frame_to = -1;
+
+    int M = 0;
+    bool have_pair = false;
+    if (A.P_in == nullptr) {
+        // ---- M3: sensor-pair selection: most ratio-test survivors, first wins ties (:73-86)
+        int best_c = -1, best_score = -1;
+        for (int ci = 0; ci < job.combo_count; ci++) {
+            const Combo c = A.combos[job.combo_begin + ci];
+            const uint2* __restrict__ kn = A.knn + c.knn_off;
+            int cnt = 0;
+            if (c.nt >= 2) {
+                for (int q = tid; q < c.nq; q += kBlock) {
+                    const uint2 k2 = kn[q];
+                    const float d0 = (float)(k2.x >> kIdxBits), d1 = (float)(k2.y >> kIdxBits);
+                    cnt += ((double)d0 < 0.99 * (double)d1) ? 1 : 0;                 // :67
+                }
+            }
+            cnt = block_sum(cnt, s_part);
+            if (cnt > best_score) { best_score = cnt; best_c = ci; }                  // :81
+        }
+        if (best_c >= 0) {
+            have_pair = true;
+            const Combo c = A.combos[job.combo_begin + best_c];
+            r_n_matches = best_score;
+            r_frame_from = c.frame_from; r_frame_to = c.frame_to;
+            const uint2* __restrict__ kn = A.knn + c.knn_off;
+            const uint8_t* __restrict__ vfrom = A.arena + c.valid_from_off;
+            const uint8_t* __restrict__ vto = A.arena + c.valid_to_off;
+            // ---- M2 + M4a: ratio test + valid_3d filter, ordered compaction of (distance, queryIdx) keys
+            for (int i = tid; i < A.sort_cap; i += kBlock) s_keys[i] = 0xffffffffu;
+            __syncthreads();
+            int base = 0;
+            for (int q0 = 0; q0 < c.nq; q0 += kBlock) {
+                const int q = q0 + tid;
+                bool keep = false;
+                uint32_t key = 0;
+                if (q < c.nq && c.nt >= 2) {
+                    const uint2 k2 = kn[q];
+                    const uint32_t d0 = k2.x >> kIdxBits, d1 = k2.y >> kIdxBits;
+                    const uint32_t t0 = k2.x & kIdxMask;
+                    const bool ratio = (double)(float)d0 < 0.99 * (double)(float)d1;
+                    keep = ratio && vfrom[t0] != 0 && vto[q] != 0;                   // :104
+                    key = (d0 << kIdxBits) | (uint32_t)q;
+                }
+                const unsigned long long bal = __ballot(keep);
+                const int lane = tid & 63, wv = tid >> 6;
+                const int wcnt = __popcll(bal);
+                __syncthreads();
+                if (lane == 0) s_part[wv] = wcnt;
+                __syncthreads();
+                int woff = 0;
+                for (int w = 0; w < wv; w++) woff += s_part[w];
+                const int total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+                if (keep) s_keys[base + woff + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+                base += total;
+            }
+            M = base;
+            __syncthreads();
+            // ---- M4b: std::sort by distance (:114), order fixed to (distance, queryIdx): bitonic in LDS
+            int n2 = 1;
+            while (n2 < M) n2 <<= 1;
+            for (int k = 2; k <= n2; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < n2; i += kBlock) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const uint32_t a = s_keys[i], b = s_keys[ixj];
+                            const bool up = (i & k) == 0;
+                            if ((a > b) == up) { s_keys[i] = b; s_keys[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            // ---- M5: gather Xd (from/train) and Pd (to/query) (:118-124); P = Pd, Q = Xd (:130)
+            const double* __restrict__ pfrom = reinterpret_cast<const double*>(A.arena) + c.pos_from_off;
+            const double* __restrict__ pto = reinterpret_cast<const double*>(A.arena) + c.pos_to_off;
+            for (int m = tid; m < M; m += kBlock) {
+                const uint32_t key = s_keys[m];
+                const int q = (int)(key & kIdxMask);
+                const int t = (int)(kn[q].x & kIdxMask);
+                pq[m * 6 + 0] = pto[3 * (size_t)q + 0]; pq[m * 6 + 1] = pto[3 * (size_t)q + 1]; pq[m * 6 + 2] = pto[3 * (size_t)q + 2];
+                pq[m * 6 + 3] = pfrom[3 * (size_t)t + 0]; pq[m * 6 + 4] = pfrom[3 * (size_t)t + 1]; pq[m * 6 + 5] = pfrom[3 * (size_t)t + 2];
+                if (A.corr_query && m < prm.max_corr) {
+                    A.corr_query[(size_t)jb * prm.max_corr + m] = q;
+                    A.corr_train[(size_t)jb * prm.max_corr + m] = t;
+                    A.corr_dist[(size_t)jb * prm.max_corr + m] = (int32_t)(key >> kIdxBits);
+                }
+            }
+        }
+    } else {
+        // uzl_ransac_points: correspondences supplied by the caller (estimateSVD entry, :178-184)
+        have_pair = true;
+        M = job.pq_count;
+        r_n_matches = M;
+        for (int m = tid; m < M; m += kBlock) {
+            const size_t col = (size_t)job.pq_off + m;
+#pragma unroll
+            for (int r = 0; r < 3; r++) { pq[m * 6 + r] = A.P_in[3 * col + r]; pq[m * 6 + 3 + r] = A.Q_in[3 * col + r]; }
+        }
+    }
+    __syncthreads();
+
+    // ---- M6: PROSAC (:186-243), one hypothesis per lane, correspondences broadcast from the tile
+    int max_cons = 0, best_it = -1, it_run = 0;
+    if (have_pair && M >= 3) {
+        const uint64_t key = stream_key(prm.seed, job.job_id);
+        const double thr2 = sqrt_threshold(prm.thresh);
+        bool stop = false;
+        for (int r0 = 0; r0 < iters && !stop; r0 += kBlock) {
+            const int it = r0 + tid;
+            if (it < iters) {
+                const int n = prm.do_prosac ? prosac_prefix(it, iters, M) : M;
+                int s0, s1, s2;
+                sample3(key, it, n, s0, s1, s2);
+                PoseAcc acc;
+                pose_init(acc);
+                pose_add(acc, pq[s0 * 6 + 0], pq[s0 * 6 + 1], pq[s0 * 6 + 2], pq[s0 * 6 + 3], pq[s0 * 6 + 4], pq[s0 * 6 + 5]);
+                pose_add(acc, pq[s1 * 6 + 0], pq[s1 * 6 + 1], pq[s1 * 6 + 2], pq[s1 * 6 + 3], pq[s1 * 6 + 4], pq[s1 * 6 + 5]);
+                pose_add(acc, pq[s2 * 6 + 0], pq[s2 * 6 + 1], pq[s2 * 6 + 2], pq[s2 * 6 + 3], pq[s2 * 6 + 4], pq[s2 * 6 + 5]);
+                double T[12];
+                pose_finish(acc, T);                                                   // :227
+                int cnt = 0;
+                for (int m = 0; m < M; m++) cnt += (point_dist2(pq + m * 6, T) < thr2) ? 1 : 0;   // :230
+                s_cnt[it] = cnt;
+            }
+            __syncthreads();
+            // replay the sequential bookkeeping of :233-242 over this round's votes
+            if (tid == 0) {
+                const int rend = (r0 + kBlock < iters) ? r0 + kBlock : iters;
+                int mc = s_misc[0], bi = s_misc[1], ir = s_misc[2], st = 0;
+                if (r0 == 0) { mc = 0; bi = -1; ir = 0; }
+                for (int i = r0; i < rend; i++) {
+                    const int c = s_cnt[i];
+                    ir = i + 1;
+                    if (c > mc) {
+                        mc = c; bi = i;
+                        if (mc >= 3 && (double)mc > prm.break_pct * (double)M) { st = 1; break; }
+                    }
+                }
+                s_misc[0] = mc; s_misc[1] = bi; s_misc[2] = ir; s_misc[3] = st;
+            }
+            __syncthreads();
+            stop = s_misc[3] != 0;
+        }
+        max_cons = s_misc[0]; best_it = s_misc[1]; it_run = s_misc[2];
+        __syncthreads();
+    }
+
+    // ---- refit on the best consensus set (:245-258), recount, mse (:285-290)
+    double Tfin[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    double mse = 0.;
+    int cons = 0;
+    if (max_cons >= 3) {
+        const uint64_t key = stream_key(prm.seed, job.job_id);
+        const double thr2 = sqrt_threshold(prm.thresh);
+        // hypothesis of the winning iteration, recomputed (bit-identical: same operations)
+        if (tid == 0) {
+            const int n = prm.do_prosac ? prosac_prefix(best_it, iters, M) : M;
+            int s0, s1, s2;
+            sample3(key, best_it, n, s0, s1, s2);
+            PoseAcc acc;
+            pose_init(acc);
+            pose_add(acc, pq[s0 * 6 + 0], pq[s0 * 6 + 1], pq[s0 * 6 + 2], pq[s0 * 6 + 3], pq[s0 * 6 + 4], pq[s0 * 6 + 5]);
+            pose_add(acc, pq[s1 * 6 + 0], pq[s1 * 6 + 1], pq[s1 * 6 + 2], pq[s1 * 6 + 3], pq[s1 * 6 + 4], pq[s1 * 6 + 5]);
+            pose_add(acc, pq[s2 * 6 + 0], pq[s2 * 6 + 1], pq[s2 * 6 + 2], pq[s2 * 6 + 3], pq[s2 * 6 + 4], pq[s2 * 6 + 5]);
+            double T[12];
+            pose_finish(acc, T);
+#pragma unroll
+            for (int k = 0; k < 12; k++) s_T[k] = T[k];
+        }
+        __syncthreads();
+        double T[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = s_T[k];
+        for (int m = tid; m < M; m += kBlock) mask[m] = (point_dist2(pq + m * 6, T) < thr2) ? 1 : 0;   // maxConsensusSet
+        __syncthreads();
+        // pose_function(Pfinal, Qfinal, T) (:257): running mean / covariance in inlier order (sequential recurrence)
+        if (tid == 0) {
+            PoseAcc acc;
+            pose_init(acc);
+            for (int m = 0; m < M; m++)
+                if (mask[m]) pose_add(acc, pq[m * 6 + 0], pq[m * 6 + 1], pq[m * 6 + 2], pq[m * 6 + 3], pq[m * 6 + 4], pq[m * 6 + 5]);
+            double Tr[12];
+            pose_finish(acc, Tr);
+#pragma unroll
+            for (int k = 0; k < 12; k++) s_T[k] = Tr[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 12; k++) Tfin[k] = s_T[k];
+        // maxConsensus = consensus_function(P, Q, T, maxConsensusSet) (:258) and the distances for mse
+        int c = 0;
+        for (int m = tid; m < M; m += kBlock) {
+            const double d2 = point_dist2(pq + m * 6, Tfin);
+            const bool in = d2 < thr2;
+            mask[m] = in ? 1 : 0;
+            dist[m] = sqrt(d2);
+            c += in ? 1 : 0;
+        }
+        cons = block_sum(c, s_part);
+        if (tid == 0) {
+            double e = 0.;
+            for (int m = 0; m < M; m++) if (mask[m]) e += dist[m];                     // :285-289, index order
+            s_dbl[0] = e / cons;                                                        // :290
+        }
+        __syncthreads();
+        mse = s_dbl[0];
+    } else {
+        for (int m = tid; m < M; m += kBlock) mask[m] = 0;                              // :291-294
+        __syncthreads();
+    }
+    if (A.inlier_mask) {
+        for (int m = tid; m < M && m < prm.max_corr; m += kBlock) A.inlier_mask[(size_t)jb * prm.max_corr + m] = mask[m];
+    }
+    if (tid == 0) {
+        uzl_edge_result* res = A.results + jb;
+        const int ok = (have_pair && M >= 3) ? 1 : 0;                                  // :118, :156
+        res->job_id = job.job_id;
+        res->ok = ok;
+        res->consensus = ok ? cons : 0;
+        res->n_matches = r_n_matches;
+        res->n_corr = M;
+        res->frame_from = r_frame_from;
+        res->frame_to = r_frame_to;
+        res->iterations_run = it_run;
+        res->best_iteration = best_it;
+        res->mse = mse;
+#pragma unroll
+        for (int k = 0; k < 12; k++) res->T[k] = Tfin[k];
+        // M9 information matrix (:133-137)
+        double s = 1., sr = 1.;
+        if (cons > 0 && mse > 0) { s = 0.1 * cons / mse; sr = s * 100.; }
+        for (int k = 0; k < 36; k++) res->information[k] = 0.;
+        res->information[0] = s; res->information[7] = s; res->information[14] = s;
+        res->information[21] = sr; res->information[28] = sr; res->information[35] = sr;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+void launch_knn2(const uint32_t* arena, const Combo* combos, int n_combos, int max_nq, uint2* knn,
+                 bool has8, bool has16, bool has_generic, hipStream_t s)
+{
+    if (n_combos <= 0 || max_nq <= 0) return;
+    dim3 grid((max_nq + kBlock - 1) / kBlock, n_combos);
+    if (has8) hipLaunchKernelGGL(knn2_kernel<8>, grid, dim3(kBlock), 0, s, arena, combos, knn);
+    if (has16) hipLaunchKernelGGL(knn2_kernel<16>, grid, dim3(kBlock), 0, s, arena, combos, knn);
+    if (has_generic) hipLaunchKernelGGL(knn2_generic_kernel, grid, dim3(kBlock), 0, s, arena, combos, knn);
+}
+
+size_t estimate_lds_bytes(int sort_cap, int iterations, int lds_points, bool in_lds)
+{
+    size_t b = (size_t)sort_cap * 4 + (size_t)((iterations + 3) & ~3) * 4;
+    if (in_lds) b += (size_t)lds_points * (48 + 8 + 1);
+    return (b + 15) & ~(size_t)15;
+}
+
+hipError_t launch_estimate(const EstimateArgs& a, int n_jobs, bool in_lds, size_t lds_bytes, hipStream_t s)
+{
+    if (n_jobs <= 0) return hipSuccess;
+    if (in_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&estimate_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(estimate_kernel<true>, dim3(n_jobs), dim3(kBlock), lds_bytes, s, a);
+    } else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&estimate_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(estimate_kernel<false>, dim3(n_jobs), dim3(kBlock), lds_bytes, s, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace uzl

@@ -1,0 +1,155 @@
+// uzl_common.hpp — shared host-side plumbing of libuzl_mi355x.so (HIP runtime only, no torch).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/uzl_mi355x.h"
+
+namespace uzl {
+
+struct HipError {
+    hipError_t code;
+    const char* what;
+    const char* file;
+    int line;
+};
+
+#define UZL_HIP(expr)                                                            \
+    do {                                                                         \
+        hipError_t e_ = (expr);                                                  \
+        if (e_ != hipSuccess) throw ::uzl::HipError{e_, #expr, __FILE__, __LINE__}; \
+    } while (0)
+
+// Format a caught HipError into a handle's last_error string; returns the status code.
+inline int report(std::string& last_error, const HipError& e)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d in %s", (int)e.code, hipGetErrorString(e.code),
+             e.file, e.line, e.what);
+    last_error = buf;
+    return (e.code == hipErrorOutOfMemory) ? UZL_ERR_OOM
+           : (e.code == hipErrorNoDevice || e.code == hipErrorInvalidDevice) ? UZL_ERR_NO_DEVICE
+                                                                             : UZL_ERR_HIP;
+}
+
+// Growable device buffer (never shrinks).  Plain hipMalloc: 288 GB of HBM, nothing is paged.
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    void reserve(size_t n, bool keep = false, hipStream_t s = nullptr)
+    {
+        if (n <= cap) return;
+        size_t ncap = cap ? cap : 256;
+        while (ncap < n) ncap *= 2;
+        T* np = nullptr;
+        UZL_HIP(hipMalloc((void**)&np, ncap * sizeof(T)));
+        if (keep && p && cap) {
+            UZL_HIP(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s));
+            UZL_HIP(hipStreamSynchronize(s));
+        }
+        if (p) UZL_HIP(hipFree(p));
+        p = np;
+        cap = ncap;
+    }
+};
+
+// Pinned host staging buffer.
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    void reserve(size_t n)
+    {
+        if (n <= cap) return;
+        size_t ncap = cap ? cap : 256;
+        while (ncap < n) ncap *= 2;
+        if (p) UZL_HIP(hipHostFree(p));
+        p = nullptr;
+        UZL_HIP(hipHostMalloc((void**)&p, ncap * sizeof(T), hipHostMallocDefault));
+        cap = ncap;
+    }
+};
+
+// Per-kernel timing with HIP events on the handle's own stream (bench.py's `roofline.achieved`
+// uses these; torch.cuda.Event would only see torch's current stream).
+class KernelTimer {
+public:
+    bool on = false;
+    ~KernelTimer()
+    {
+        for (auto& e : pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    }
+    void reset()
+    {
+        used_ = 0;
+        acc_.clear();
+    }
+    void begin(const char* name, hipStream_t s)
+    {
+        if (!on) return;
+        if (used_ == pool_.size()) {
+            Pair p;
+            UZL_HIP(hipEventCreate(&p.a));
+            UZL_HIP(hipEventCreate(&p.b));
+            pool_.push_back(p);
+        }
+        pool_[used_].name = name;
+        UZL_HIP(hipEventRecord(pool_[used_].a, s));
+    }
+    void end(hipStream_t s)
+    {
+        if (!on) return;
+        UZL_HIP(hipEventRecord(pool_[used_].b, s));
+        ++used_;
+    }
+    // call after the stream has been synchronised
+    void resolve()
+    {
+        if (!on) return;
+        for (size_t i = 0; i < used_; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pool_[i].a, pool_[i].b) == hipSuccess) {
+                auto& a = acc_[pool_[i].name];
+                a.first += ms;
+                a.second += 1;
+            }
+        }
+        used_ = 0;
+    }
+    int report(int cap, const char** names, double* ms, int32_t* launches) const
+    {
+        int n = 0;
+        for (auto& kv : acc_) {
+            if (n >= cap) break;
+            names[n] = kv.first;
+            ms[n] = kv.second.first;
+            launches[n] = kv.second.second;
+            ++n;
+        }
+        return n;
+    }
+
+private:
+    struct Pair { hipEvent_t a, b; const char* name; };
+    std::vector<Pair> pool_;
+    size_t used_ = 0;
+    struct CStrLess { bool operator()(const char* x, const char* y) const { return strcmp(x, y) < 0; } };
+    std::map<const char*, std::pair<double, int32_t>, CStrLess> acc_;
+};
+
+}  // namespace uzl

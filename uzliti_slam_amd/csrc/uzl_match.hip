@@ -1,0 +1,526 @@
+// uzl_match.hip — host side of the edge-estimation half: frame store in HBM, batched job launch,
+// C ABI (uzl_match_*, uzl_ransac_points).  Mirrors FeatureTransformationEstimator
+// (transformation_estimation/src/feature_transformation_estimator.cpp) as a batched, device-resident
+// service: frames are uploaded once, every node-pair job references them by id.
+#include "uzl_common.hpp"
+#include "match_types.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <new>
+
+namespace uzl {
+
+void launch_knn2(const uint32_t* arena, const Combo* combos, int n_combos, int max_nq, uint2* knn,
+                 bool has8, bool has16, bool has_generic, hipStream_t s);
+size_t estimate_lds_bytes(int sort_cap, int iterations, int lds_points, bool in_lds);
+hipError_t launch_estimate(const EstimateArgs& a, int n_jobs, bool in_lds, size_t lds_bytes, hipStream_t s);
+
+constexpr size_t kLdsBudget = 152 * 1024;   // of the CU's 160 KiB
+
+struct FrameRec {
+    bool alive = false;
+    uint64_t desc_off = 0, pos_off = 0, valid_off = 0;   // byte offsets into the arena
+    int32_t n = 0, words = 0, feature_type = 0, sensor_frame = 0;
+};
+
+}  // namespace uzl
+
+using namespace uzl;
+
+struct uzl_match {
+    std::mutex mu;
+    std::string last_error;
+    uzl_match_cfg cfg;
+    hipStream_t stream = nullptr;
+    // frame arena: one HBM allocation, frames addressed by offset so it can grow
+    DevBuf<uint8_t> arena;
+    size_t arena_used = 0;
+    std::vector<FrameRec> frames;
+    int32_t live_frames = 0;
+    // batch state
+    PinBuf<Combo> h_combos; DevBuf<Combo> d_combos;
+    PinBuf<Job> h_jobs; DevBuf<Job> d_jobs;
+    DevBuf<uint2> d_knn;
+    DevBuf<uzl_edge_result> d_results; PinBuf<uzl_edge_result> h_results;
+    DevBuf<int32_t> d_cq, d_ct, d_cd; DevBuf<uint8_t> d_mask;
+    PinBuf<int32_t> h_cq, h_ct, h_cd; PinBuf<uint8_t> h_mask;
+    DevBuf<double> d_pq_scratch, d_dist_scratch; DevBuf<uint8_t> d_mask_scratch;
+    DevBuf<double> d_P, d_Q;
+    bool in_flight = false;
+    int32_t fl_jobs = 0, fl_stride = 0, fl_max_corr = 0;
+    bool fl_diag = false;
+    KernelTimer timer;
+};
+
+namespace {
+
+int fail(uzl_match* h, int code, const char* msg)
+{
+    h->last_error = msg;
+    return code;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int next_pow2(int v)
+{
+    int p = 4;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Builds combos/jobs, uploads them and enqueues knn2 + estimate + D2H on the handle's stream.
+int do_launch(uzl_match* h, int32_t n_jobs, const uzl_pair_job* jobs, const int32_t* frame_ids,
+              int32_t n_frame_ids, int32_t max_corr)
+{
+    if (h->in_flight) return fail(h, UZL_ERR_BUSY, "a batch is already in flight");
+    if (n_jobs < 0 || (n_jobs > 0 && (!jobs || !frame_ids))) return fail(h, UZL_ERR_BAD_ARG, "null jobs/frame_ids");
+    if (h->cfg.ransac_iteration < 1 || h->cfg.ransac_iteration > kMaxIterations)
+        return fail(h, UZL_ERR_BAD_ARG, "ransac_iteration out of range [1,4096]");
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    h->timer.reset();
+    h->fl_jobs = n_jobs;
+    h->fl_diag = max_corr > 0;
+    h->fl_max_corr = max_corr;
+    if (n_jobs == 0) { h->in_flight = true; h->fl_stride = 0; return UZL_OK; }
+
+    // ---- combos: eligible (from, to) FeatureData pairs in the reference's loop order (:40-49)
+    std::vector<Combo> combos;
+    h->h_jobs.reserve((size_t)n_jobs);
+    int max_nq = 0;
+    int64_t total_q = 0;
+    bool has8 = false, has16 = false, hasg = false;
+    for (int32_t j = 0; j < n_jobs; j++) {
+        const uzl_pair_job& pj = jobs[j];
+        if (pj.from_begin < 0 || pj.to_begin < 0 || pj.from_count < 0 || pj.to_count < 0 ||
+            pj.from_begin + pj.from_count > n_frame_ids || pj.to_begin + pj.to_count > n_frame_ids)
+            return fail(h, UZL_ERR_BAD_ARG, "job frame range outside frame_ids");
+        Job dj;
+        dj.job_id = pj.job_id;
+        dj.combo_begin = (int32_t)combos.size();
+        dj.pq_off = 0; dj.pq_count = 0;
+        for (int32_t a = 0; a < pj.from_count; a++) {
+            const int32_t fid = frame_ids[pj.from_begin + a];
+            if (fid < 0 || fid >= (int32_t)h->frames.size() || !h->frames[fid].alive)
+                return fail(h, UZL_ERR_NOT_FOUND, "unknown from-frame id");
+            const FrameRec& ff = h->frames[fid];
+            for (int32_t b = 0; b < pj.to_count; b++) {
+                const int32_t tid = frame_ids[pj.to_begin + b];
+                if (tid < 0 || tid >= (int32_t)h->frames.size() || !h->frames[tid].alive)
+                    return fail(h, UZL_ERR_NOT_FOUND, "unknown to-frame id");
+                const FrameRec& ft = h->frames[tid];
+                if (!(ff.n >= 7 && ft.n >= 7 && ff.feature_type == ft.feature_type &&
+                      ff.sensor_frame == ft.sensor_frame && ff.words == ft.words)) continue;   // :47-49
+                Combo c;
+                c.desc_from_off = ff.desc_off / 4; c.desc_to_off = ft.desc_off / 4;
+                c.pos_from_off = ff.pos_off / 8; c.pos_to_off = ft.pos_off / 8;
+                c.valid_from_off = ff.valid_off; c.valid_to_off = ft.valid_off;
+                c.nt = ff.n; c.nq = ft.n; c.words = ff.words;
+                c.knn_off = (int32_t)total_q;
+                c.frame_from = fid; c.frame_to = tid;
+                total_q += ft.n;
+                if (total_q > INT32_MAX) return fail(h, UZL_ERR_BAD_ARG, "batch too large (2-NN buffer > 2^31 entries)");
+                max_nq = std::max(max_nq, ft.n);
+                if (c.words == 8) has8 = true; else if (c.words == 16) has16 = true; else hasg = true;
+                combos.push_back(c);
+            }
+        }
+        dj.combo_count = (int32_t)combos.size() - dj.combo_begin;
+        h->h_jobs.p[j] = dj;
+    }
+    const int stride = std::max(max_nq, 1);
+    h->fl_stride = stride;
+    const size_t nc = combos.size();
+    h->h_combos.reserve(std::max<size_t>(nc, 1));
+    if (nc) memcpy(h->h_combos.p, combos.data(), nc * sizeof(Combo));
+    h->d_combos.reserve(std::max<size_t>(nc, 1));
+    h->d_jobs.reserve((size_t)n_jobs);
+    h->d_knn.reserve((size_t)std::max<int64_t>(total_q, 1));
+    h->d_results.reserve((size_t)n_jobs);
+    h->h_results.reserve((size_t)n_jobs);
+    hipStream_t s = h->stream;
+    if (nc) UZL_HIP(hipMemcpyAsync(h->d_combos.p, h->h_combos.p, nc * sizeof(Combo), hipMemcpyHostToDevice, s));
+    UZL_HIP(hipMemcpyAsync(h->d_jobs.p, h->h_jobs.p, (size_t)n_jobs * sizeof(Job), hipMemcpyHostToDevice, s));
+
+    // ---- M1
+    h->timer.begin("knn2", s);
+    launch_knn2(reinterpret_cast<const uint32_t*>(h->arena.p), h->d_combos.p, (int)nc, max_nq, h->d_knn.p,
+                has8, has16, hasg, s);
+    h->timer.end(s);
+    UZL_HIP(hipGetLastError());
+
+    // ---- M2..M9
+    EstimateArgs a;
+    memset(&a, 0, sizeof(a));
+    a.arena = h->arena.p; a.combos = h->d_combos.p; a.jobs = h->d_jobs.p; a.knn = h->d_knn.p;
+    a.prm.thresh = h->cfg.ransac_threshold; a.prm.break_pct = h->cfg.ransac_break_percentage;
+    a.prm.seed = h->cfg.seed; a.prm.iterations = h->cfg.ransac_iteration; a.prm.do_prosac = h->cfg.do_prosac ? 1 : 0;
+    a.prm.max_corr = stride;
+    a.results = h->d_results.p;
+    a.sort_cap = next_pow2(max_nq);
+    if (h->fl_diag) {
+        const size_t tot = (size_t)n_jobs * stride;
+        h->d_cq.reserve(tot); h->d_ct.reserve(tot); h->d_cd.reserve(tot); h->d_mask.reserve(tot);
+        h->h_cq.reserve(tot); h->h_ct.reserve(tot); h->h_cd.reserve(tot); h->h_mask.reserve(tot);
+        a.corr_query = h->d_cq.p; a.corr_train = h->d_ct.p; a.corr_dist = h->d_cd.p; a.inlier_mask = h->d_mask.p;
+    }
+    const int lds_points = (stride + 1) & ~1;
+    bool in_lds = estimate_lds_bytes(a.sort_cap, a.prm.iterations, lds_points, true) <= kLdsBudget;
+    a.prm.lds_points = lds_points;
+    if (!in_lds) {
+        const size_t tot = (size_t)n_jobs * stride;
+        h->d_pq_scratch.reserve(tot * 6); h->d_dist_scratch.reserve(tot); h->d_mask_scratch.reserve(tot);
+        a.pq_scratch = h->d_pq_scratch.p; a.dist_scratch = h->d_dist_scratch.p; a.mask_scratch = h->d_mask_scratch.p;
+    }
+    const size_t lds = estimate_lds_bytes(a.sort_cap, a.prm.iterations, lds_points, in_lds);
+    if (lds > kLdsBudget) return fail(h, UZL_ERR_BAD_ARG, "frame too large for the LDS sort (n > 16384)");
+    h->timer.begin("estimate", s);
+    UZL_HIP(launch_estimate(a, n_jobs, in_lds, lds, s));
+    h->timer.end(s);
+
+    UZL_HIP(hipMemcpyAsync(h->h_results.p, h->d_results.p, (size_t)n_jobs * sizeof(uzl_edge_result), hipMemcpyDeviceToHost, s));
+    if (h->fl_diag) {
+        const size_t tot = (size_t)n_jobs * stride;
+        UZL_HIP(hipMemcpyAsync(h->h_cq.p, h->d_cq.p, tot * 4, hipMemcpyDeviceToHost, s));
+        UZL_HIP(hipMemcpyAsync(h->h_ct.p, h->d_ct.p, tot * 4, hipMemcpyDeviceToHost, s));
+        UZL_HIP(hipMemcpyAsync(h->h_cd.p, h->d_cd.p, tot * 4, hipMemcpyDeviceToHost, s));
+        UZL_HIP(hipMemcpyAsync(h->h_mask.p, h->d_mask.p, tot, hipMemcpyDeviceToHost, s));
+    }
+    h->in_flight = true;
+    return UZL_OK;
+}
+
+int do_collect(uzl_match* h, uzl_edge_result* results, int32_t* corr_query, int32_t* corr_train,
+               int32_t* corr_dist, uint8_t* inlier_mask)
+{
+    if (!h->in_flight) return fail(h, UZL_ERR_STATE, "no batch in flight");
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    UZL_HIP(hipStreamSynchronize(h->stream));
+    h->in_flight = false;
+    h->timer.resolve();
+    const int32_t n = h->fl_jobs;
+    if (n > 0 && !results) return fail(h, UZL_ERR_BAD_ARG, "results is null");
+    if (n > 0) memcpy(results, h->h_results.p, (size_t)n * sizeof(uzl_edge_result));
+    if (h->fl_diag) {
+        const int32_t mc = h->fl_max_corr, st = h->fl_stride;
+        for (int32_t j = 0; j < n; j++) {
+            const int32_t m = std::min(results[j].n_corr, mc);
+            const size_t src = (size_t)j * st, dst = (size_t)j * mc;
+            if (corr_query) { memcpy(corr_query + dst, h->h_cq.p + src, (size_t)m * 4); for (int32_t k = m; k < mc; k++) corr_query[dst + k] = -1; }
+            if (corr_train) { memcpy(corr_train + dst, h->h_ct.p + src, (size_t)m * 4); for (int32_t k = m; k < mc; k++) corr_train[dst + k] = -1; }
+            if (corr_dist) { memcpy(corr_dist + dst, h->h_cd.p + src, (size_t)m * 4); for (int32_t k = m; k < mc; k++) corr_dist[dst + k] = -1; }
+            if (inlier_mask) { memcpy(inlier_mask + dst, h->h_mask.p + src, (size_t)m); for (int32_t k = m; k < mc; k++) inlier_mask[dst + k] = 0; }
+        }
+    }
+    return UZL_OK;
+}
+
+}  // namespace
+
+#define UZL_GUARD_BEGIN(h)                       \
+    if (!(h)) return UZL_ERR_BAD_ARG;            \
+    std::lock_guard<std::mutex> lock_((h)->mu);  \
+    try {
+#define UZL_GUARD_END(h)                                                             \
+    } catch (const ::uzl::HipError& e) { return ::uzl::report((h)->last_error, e); } \
+    catch (const std::bad_alloc&) { (h)->last_error = "host out of memory"; return UZL_ERR_OOM; } \
+    catch (...) { (h)->last_error = "unexpected exception"; return UZL_ERR_HIP; }
+
+extern "C" {
+
+int uzl_abi_version(void) { return UZL_ABI_VERSION; }
+
+int uzl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return UZL_ERR_NO_DEVICE;
+    return n;
+}
+
+const char* uzl_status_string(int status)
+{
+    switch (status) {
+        case UZL_OK: return "ok";
+        case UZL_ERR_BAD_ARG: return "bad argument";
+        case UZL_ERR_NO_DEVICE: return "no HIP device";
+        case UZL_ERR_HIP: return "HIP runtime error";
+        case UZL_ERR_NOT_CONVERGED: return "PCG did not converge";
+        case UZL_ERR_BUSY: return "busy";
+        case UZL_ERR_OOM: return "out of memory";
+        case UZL_ERR_NOT_FOUND: return "not found";
+        case UZL_ERR_STATE: return "call order violated";
+        default: return "unknown status";
+    }
+}
+
+void uzl_match_cfg_default(uzl_match_cfg* cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->ransac_threshold = 0.2;           // cfg/FeatureLinkEstimation.cfg:9
+    cfg->link_covariance = 0.01;           // :10
+    cfg->ransac_iteration = 100;           // :11
+    cfg->ransac_break_percentage = 0.6;    // :12
+    cfg->use_epnp = 1;                     // :13
+    cfg->do_prosac = 1;                    // estimateSVD default argument (feature_transformation_estimator.h:45)
+    cfg->device = 0;
+    cfg->seed = 0;
+}
+
+int uzl_match_create(const uzl_match_cfg* cfg, uzl_match** out)
+{
+    if (!out) return UZL_ERR_BAD_ARG;
+    *out = nullptr;
+    uzl_match_cfg c;
+    if (cfg) c = *cfg; else uzl_match_cfg_default(&c);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return UZL_ERR_NO_DEVICE;
+    if (c.device < 0 || c.device >= ndev) return UZL_ERR_NO_DEVICE;
+    uzl_match* h = new (std::nothrow) uzl_match();
+    if (!h) return UZL_ERR_OOM;
+    h->cfg = c;
+    try {
+        UZL_HIP(hipSetDevice(c.device));
+        UZL_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->arena.reserve((size_t)64 << 20);
+    } catch (const HipError& e) {
+        std::string msg;
+        int code = report(msg, e);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        delete h;
+        return code;
+    }
+    *out = h;
+    return UZL_OK;
+}
+
+void uzl_match_destroy(uzl_match* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    delete h;
+}
+
+int uzl_match_set_config(uzl_match* h, const uzl_match_cfg* cfg)
+{
+    if (!h || !cfg) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (cfg->device != h->cfg.device) return fail(h, UZL_ERR_BAD_ARG, "device cannot change after create");
+    if (cfg->ransac_iteration < 1 || cfg->ransac_iteration > kMaxIterations)
+        return fail(h, UZL_ERR_BAD_ARG, "ransac_iteration out of range [1,4096]");
+    h->cfg = *cfg;
+    return UZL_OK;
+}
+
+const char* uzl_match_last_error(uzl_match* h) { return h ? h->last_error.c_str() : "null handle"; }
+
+int uzl_match_add_frame(uzl_match* h, const uzl_frame* f, int32_t* frame_id)
+{
+    if (!f || !frame_id) return UZL_ERR_BAD_ARG;
+    UZL_GUARD_BEGIN(h)
+    if (f->n < 0 || f->n > kMaxKeypoints) return fail(h, UZL_ERR_BAD_ARG, "frame.n out of range [0,16384]");
+    if (f->bytes_per_desc <= 0 || f->bytes_per_desc % 4 != 0 || f->bytes_per_desc > 508)
+        return fail(h, UZL_ERR_BAD_ARG, "bytes_per_desc must be a multiple of 4 in [4,508]");
+    if (f->n > 0 && (!f->desc || !f->pos_xyz || !f->valid3d)) return fail(h, UZL_ERR_BAD_ARG, "null frame arrays");
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)f->n;
+    const size_t desc_b = n * (size_t)f->bytes_per_desc, pos_b = n * 24, val_b = n;
+    size_t off = align_up(h->arena_used, 256);
+    FrameRec r;
+    r.desc_off = off; off = align_up(off + desc_b, 16);
+    r.pos_off = off; off = align_up(off + pos_b, 16);
+    r.valid_off = off; off += val_b;
+    off = align_up(off + 64, 256);      // tail padding: clamped lanes may read one row past nothing, never past the arena
+    if (h->in_flight && off > h->arena.cap) return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
+    h->arena.reserve(off, /*keep=*/true, h->stream);
+    if (n) {
+        UZL_HIP(hipMemcpyAsync(h->arena.p + r.desc_off, f->desc, desc_b, hipMemcpyHostToDevice, h->stream));
+        UZL_HIP(hipMemcpyAsync(h->arena.p + r.pos_off, f->pos_xyz, pos_b, hipMemcpyHostToDevice, h->stream));
+        UZL_HIP(hipMemcpyAsync(h->arena.p + r.valid_off, f->valid3d, val_b, hipMemcpyHostToDevice, h->stream));
+        UZL_HIP(hipStreamSynchronize(h->stream));   // inputs are borrowed only for the duration of the call
+    }
+    h->arena_used = off;
+    r.alive = true; r.n = f->n; r.words = f->bytes_per_desc / 4;
+    r.feature_type = f->feature_type; r.sensor_frame = f->sensor_frame;
+    h->frames.push_back(r);
+    h->live_frames++;
+    *frame_id = (int32_t)h->frames.size() - 1;
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
+int uzl_match_remove_frame(uzl_match* h, int32_t frame_id)
+{
+    if (!h) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (frame_id < 0 || frame_id >= (int32_t)h->frames.size() || !h->frames[frame_id].alive)
+        return fail(h, UZL_ERR_NOT_FOUND, "unknown frame id");
+    h->frames[frame_id].alive = false;     // arena space is reclaimed when the store empties
+    if (--h->live_frames == 0 && !h->in_flight) { h->arena_used = 0; }
+    return UZL_OK;
+}
+
+int uzl_match_frame_count(uzl_match* h)
+{
+    if (!h) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    return h->live_frames;
+}
+
+int uzl_match_launch(uzl_match* h, int32_t n_jobs, const uzl_pair_job* jobs, const int32_t* frame_ids,
+                     int32_t n_frame_ids, int32_t max_corr)
+{
+    UZL_GUARD_BEGIN(h)
+    return do_launch(h, n_jobs, jobs, frame_ids, n_frame_ids, max_corr);
+    UZL_GUARD_END(h)
+}
+
+int uzl_match_collect(uzl_match* h, uzl_edge_result* results, int32_t* corr_query, int32_t* corr_train,
+                      int32_t* corr_dist, uint8_t* inlier_mask)
+{
+    UZL_GUARD_BEGIN(h)
+    return do_collect(h, results, corr_query, corr_train, corr_dist, inlier_mask);
+    UZL_GUARD_END(h)
+}
+
+int uzl_match_estimate(uzl_match* h, int32_t n_jobs, const uzl_pair_job* jobs, const int32_t* frame_ids,
+                       int32_t n_frame_ids, uzl_edge_result* results, int32_t max_corr, int32_t* corr_query,
+                       int32_t* corr_train, int32_t* corr_dist, uint8_t* inlier_mask)
+{
+    UZL_GUARD_BEGIN(h)
+    const bool diag = corr_query || corr_train || corr_dist || inlier_mask;
+    int rc = do_launch(h, n_jobs, jobs, frame_ids, n_frame_ids, diag ? max_corr : 0);
+    if (rc != UZL_OK) return rc;
+    return do_collect(h, results, corr_query, corr_train, corr_dist, inlier_mask);
+    UZL_GUARD_END(h)
+}
+
+int uzl_match_knn2(uzl_match* h, int32_t frame_from, int32_t frame_to, int32_t* idx0, int32_t* dist0,
+                   int32_t* idx1, int32_t* dist1)
+{
+    UZL_GUARD_BEGIN(h)
+    if (h->in_flight) return fail(h, UZL_ERR_BUSY, "a batch is in flight");
+    if (frame_from < 0 || frame_from >= (int32_t)h->frames.size() || !h->frames[frame_from].alive ||
+        frame_to < 0 || frame_to >= (int32_t)h->frames.size() || !h->frames[frame_to].alive)
+        return fail(h, UZL_ERR_NOT_FOUND, "unknown frame id");
+    const FrameRec& ff = h->frames[frame_from];
+    const FrameRec& ft = h->frames[frame_to];
+    if (ff.words != ft.words) return fail(h, UZL_ERR_BAD_ARG, "descriptor widths differ");
+    if (ft.n == 0) return UZL_OK;
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    Combo c;
+    memset(&c, 0, sizeof(c));
+    c.desc_from_off = ff.desc_off / 4; c.desc_to_off = ft.desc_off / 4;
+    c.nt = ff.n; c.nq = ft.n; c.words = ff.words; c.knn_off = 0;
+    h->h_combos.reserve(1); h->d_combos.reserve(1);
+    h->h_combos.p[0] = c;
+    h->d_knn.reserve((size_t)ft.n);
+    UZL_HIP(hipMemcpyAsync(h->d_combos.p, h->h_combos.p, sizeof(Combo), hipMemcpyHostToDevice, h->stream));
+    launch_knn2(reinterpret_cast<const uint32_t*>(h->arena.p), h->d_combos.p, 1, ft.n, h->d_knn.p,
+                c.words == 8, c.words == 16, c.words != 8 && c.words != 16, h->stream);
+    UZL_HIP(hipGetLastError());
+    std::vector<uint2> keys((size_t)ft.n);
+    UZL_HIP(hipMemcpyAsync(keys.data(), h->d_knn.p, (size_t)ft.n * sizeof(uint2), hipMemcpyDeviceToHost, h->stream));
+    UZL_HIP(hipStreamSynchronize(h->stream));
+    for (int32_t q = 0; q < ft.n; q++) {
+        const uint32_t a = keys[q].x, b = keys[q].y;
+        if (idx0) idx0[q] = (a == 0xffffffffu) ? -1 : (int32_t)(a & kIdxMask);
+        if (dist0) dist0[q] = (a == 0xffffffffu) ? -1 : (int32_t)(a >> kIdxBits);
+        if (idx1) idx1[q] = (b == 0xffffffffu) ? -1 : (int32_t)(b & kIdxMask);
+        if (dist1) dist1[q] = (b == 0xffffffffu) ? -1 : (int32_t)(b >> kIdxBits);
+    }
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
+int uzl_ransac_points(uzl_match* h, int32_t n_problems, const int32_t* offsets, const double* P,
+                      const double* Q, double max_error, int32_t iterations, double break_percentage,
+                      int32_t do_prosac, const uint64_t* job_ids, double* T, int32_t* consensus,
+                      double* mse, int32_t* iterations_run, uint8_t* mask)
+{
+    UZL_GUARD_BEGIN(h)
+    if (h->in_flight) return fail(h, UZL_ERR_BUSY, "a batch is in flight");
+    if (n_problems < 0 || (n_problems > 0 && (!offsets || !P || !Q))) return fail(h, UZL_ERR_BAD_ARG, "null arrays");
+    if (iterations < 1 || iterations > kMaxIterations) return fail(h, UZL_ERR_BAD_ARG, "iterations out of range [1,4096]");
+    if (n_problems == 0) return UZL_OK;
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    const int64_t total = offsets[n_problems];
+    int max_m = 0;
+    h->h_jobs.reserve((size_t)n_problems);
+    for (int32_t b = 0; b < n_problems; b++) {
+        const int32_t m = offsets[b + 1] - offsets[b];
+        if (m < 0) return fail(h, UZL_ERR_BAD_ARG, "offsets must be non-decreasing");
+        max_m = std::max(max_m, m);
+        Job j;
+        j.job_id = job_ids ? job_ids[b] : (uint64_t)b;
+        j.combo_begin = 0; j.combo_count = 0; j.pq_off = offsets[b]; j.pq_count = m;
+        h->h_jobs.p[b] = j;
+    }
+    const int stride = std::max(max_m, 1);
+    hipStream_t s = h->stream;
+    h->d_jobs.reserve((size_t)n_problems);
+    h->d_P.reserve((size_t)std::max<int64_t>(total, 1) * 3);
+    h->d_Q.reserve((size_t)std::max<int64_t>(total, 1) * 3);
+    h->d_results.reserve((size_t)n_problems); h->h_results.reserve((size_t)n_problems);
+    const size_t tot = (size_t)n_problems * stride;
+    h->d_mask.reserve(tot); h->h_mask.reserve(tot);
+    UZL_HIP(hipMemcpyAsync(h->d_jobs.p, h->h_jobs.p, (size_t)n_problems * sizeof(Job), hipMemcpyHostToDevice, s));
+    if (total > 0) {
+        UZL_HIP(hipMemcpyAsync(h->d_P.p, P, (size_t)total * 24, hipMemcpyHostToDevice, s));
+        UZL_HIP(hipMemcpyAsync(h->d_Q.p, Q, (size_t)total * 24, hipMemcpyHostToDevice, s));
+    }
+    EstimateArgs a;
+    memset(&a, 0, sizeof(a));
+    a.jobs = h->d_jobs.p;
+    a.prm.thresh = max_error; a.prm.break_pct = break_percentage; a.prm.seed = h->cfg.seed;
+    a.prm.iterations = iterations; a.prm.do_prosac = do_prosac ? 1 : 0; a.prm.max_corr = stride;
+    a.results = h->d_results.p;
+    a.P_in = h->d_P.p; a.Q_in = h->d_Q.p;
+    a.inlier_mask = h->d_mask.p;
+    a.sort_cap = 4;
+    const int lds_points = (stride + 1) & ~1;
+    a.prm.lds_points = lds_points;
+    const bool in_lds = estimate_lds_bytes(a.sort_cap, iterations, lds_points, true) <= kLdsBudget;
+    if (!in_lds) {
+        h->d_pq_scratch.reserve(tot * 6); h->d_dist_scratch.reserve(tot); h->d_mask_scratch.reserve(tot);
+        a.pq_scratch = h->d_pq_scratch.p; a.dist_scratch = h->d_dist_scratch.p; a.mask_scratch = h->d_mask_scratch.p;
+    }
+    const size_t lds = estimate_lds_bytes(a.sort_cap, iterations, lds_points, in_lds);
+    h->timer.reset();
+    h->timer.begin("ransac_points", s);
+    UZL_HIP(launch_estimate(a, n_problems, in_lds, lds, s));
+    h->timer.end(s);
+    UZL_HIP(hipMemcpyAsync(h->h_results.p, h->d_results.p, (size_t)n_problems * sizeof(uzl_edge_result), hipMemcpyDeviceToHost, s));
+    UZL_HIP(hipMemcpyAsync(h->h_mask.p, h->d_mask.p, tot, hipMemcpyDeviceToHost, s));
+    UZL_HIP(hipStreamSynchronize(s));
+    h->timer.resolve();
+    for (int32_t b = 0; b < n_problems; b++) {
+        const uzl_edge_result& r = h->h_results.p[b];
+        if (T) memcpy(T + 12 * (size_t)b, r.T, sizeof(r.T));
+        if (consensus) consensus[b] = r.consensus;
+        if (mse) mse[b] = r.mse;
+        if (iterations_run) iterations_run[b] = r.iterations_run;
+        if (mask) memcpy(mask + offsets[b], h->h_mask.p + (size_t)b * stride, (size_t)(offsets[b + 1] - offsets[b]));
+    }
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
+int uzl_match_set_profiling(uzl_match* h, int32_t on)
+{
+    if (!h) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->timer.on = on != 0;
+    return UZL_OK;
+}
+
+int uzl_match_kernel_times(uzl_match* h, int32_t cap, const char** names, double* ms, int32_t* launches)
+{
+    if (!h || cap < 0 || (cap > 0 && (!names || !ms || !launches))) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    return h->timer.report(cap, names, ms, launches);
+}
+
+}  // extern "C"
