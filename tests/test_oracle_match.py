@@ -1,0 +1,189 @@
+"""CPU tests (no GPU): pin the C oracle of the matching half against the independent NumPy
+implementation and against known answers derivable from the reference source alone."""
+import math
+
+import numpy as np
+import pytest
+
+import np_reference as NP
+from uzliti_slam_amd import synth
+
+
+@pytest.mark.parametrize("nq,nt,nbytes", [(200, 300, 32), (64, 64, 64), (33, 2, 32), (10, 1, 32), (5, 0, 32), (50, 70, 20)])
+def test_knn2_vs_numpy(oracle, nq, nt, nbytes):
+    rng = np.random.default_rng(nq + 13 * nt)
+    q = rng.integers(0, 256, (nq, nbytes), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, nbytes), dtype=np.uint8)
+    if nt >= 8:
+        t[5] = t[2]; t[7] = t[2]; q[0] = t[2]          # ties: lower train index first
+    got = oracle.knn2(q, t)
+    want = NP.knn2(q, t)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    if nt >= 8:
+        assert got[0][0] == 2 and got[2][0] == 5 and got[1][0] == 0 and got[3][0] == 0
+
+
+def test_ratio_test_boundary(oracle):
+    """d0 < 0.99*d1 (feature_transformation_estimator.cpp:67): equivalent to 100*d0 < 99*d1 on integers."""
+    d1 = np.array([100, 100, 100, 200, 200, 300, 1, 0, 256, 512], np.int32)
+    d0 = np.array([98, 99, 100, 197, 198, 297, 0, 0, 253, 506], np.int32)
+    n = len(d0)
+    idx0 = np.arange(n, dtype=np.int32); idx1 = (idx0 + 1) % n
+    q, t, d, nr = oracle.filter_sort(idx0, d0, idx1, d1, np.ones(n, np.uint8), np.ones(n, np.uint8))
+    keep = 100 * d0.astype(np.int64) < 99 * d1.astype(np.int64)
+    assert nr == keep.sum()
+    assert set(q.tolist()) == set(np.nonzero(keep)[0].tolist())
+    q2, t2, d2, nr2 = NP.filter_sort(idx0, d0, idx1, d1, np.ones(n, np.uint8), np.ones(n, np.uint8))
+    assert np.array_equal(q, q2) and np.array_equal(t, t2) and nr == nr2
+
+
+def test_filter_sort_order_and_validity(oracle):
+    rng = np.random.default_rng(2)
+    nq, nt = 500, 400
+    idx0 = rng.integers(0, nt, nq).astype(np.int32); idx1 = rng.integers(0, nt, nq).astype(np.int32)
+    d0 = rng.integers(0, 40, nq).astype(np.int32); d1 = d0 + rng.integers(0, 5, nq).astype(np.int32)
+    idx1[::17] = -1                                     # fewer than two neighbours -> dropped (:66)
+    vt = (rng.random(nt) > 0.2).astype(np.uint8); vq = (rng.random(nq) > 0.2).astype(np.uint8)
+    got = oracle.filter_sort(idx0, d0, idx1, d1, vt, vq)
+    want = NP.filter_sort(idx0, d0, idx1, d1, vt, vq)
+    for g, w in zip(got[:3], want[:3]):
+        assert np.array_equal(g, w)
+    assert got[3] == want[3]
+    q, t, d, _ = got
+    assert np.all(np.diff(d) >= 0)
+    same = np.diff(d) == 0
+    assert np.all(np.diff(q)[same] > 0)                 # ties ordered by queryIdx
+    assert vt[t].all() and vq[q].all()
+
+
+def test_prosac_prefix_schedule(oracle):
+    """min(ceil((i+3.)/iterations*M), M) (feature_transformation_estimator.cpp:217)."""
+    for iters in (1, 7, 100, 500, 1000):
+        for m in (3, 10, 57, 1000):
+            for i in range(0, iters, max(1, iters // 23)):
+                want = min(int(math.ceil(((i + 3.) / iters) * m)), m)
+                assert oracle.prosac_prefix(i, iters, m) == want
+
+
+def test_sample3_is_a_partial_shuffle_of_the_prefix(oracle):
+    for m, iters in ((3, 10), (4, 10), (10, 100), (10, 3), (200, 500)):
+        seen = set()
+        for i in range(iters):
+            s = oracle.sample3(11, 5, i, iters, m, True)
+            n = oracle.prosac_prefix(i, iters, m)
+            assert len(set(s)) == 3 and min(s) >= 0 and max(s) < m
+            # positions >= n are still the identity, positions < n stay inside the prefix
+            for pos, v in enumerate(s):
+                if pos >= n:
+                    assert v == pos
+                else:
+                    assert v < max(n, pos + 1)
+            seen.add(tuple(s))
+        if m >= 10 and iters >= 100:
+            assert len(seen) > iters // 2
+    # different jobs / seeds give different streams; same key is reproducible
+    a = [oracle.sample3(1, 1, i, 100, 50, False) for i in range(20)]
+    assert a == [oracle.sample3(1, 1, i, 100, 50, False) for i in range(20)]
+    assert a != [oracle.sample3(1, 2, i, 100, 50, False) for i in range(20)]
+    assert a != [oracle.sample3(2, 1, i, 100, 50, False) for i in range(20)]
+
+
+def test_svd3f_vs_numpy(oracle):
+    rng = np.random.default_rng(0)
+    for k in range(500):
+        A = rng.normal(size=(3, 3)).astype(np.float32)
+        if k % 5 == 0:
+            A[:, 2] = A[:, 0] * 2                       # rank deficient (3-point covariance has rank <= 2)
+        if k % 50 == 1:
+            A[:] = 0
+        U, S, V = oracle.svd3f(A)
+        assert np.abs((U * S) @ V.T - A).max() <= 2e-6 * max(1.0, np.abs(A).max())
+        assert np.abs(U @ U.T - np.eye(3)).max() < 1e-5 and np.abs(V @ V.T - np.eye(3)).max() < 1e-5
+        assert np.all(np.diff(S) <= 0) and S[2] >= 0
+        assert np.allclose(S, np.linalg.svd(A.astype(np.float64), compute_uv=False), atol=3e-5 * max(1.0, S[0]))
+
+
+def test_pose_svd_vs_kabsch(oracle):
+    rng = np.random.default_rng(1)
+    for k in range(200):
+        m = 3 if k % 2 == 0 else int(rng.integers(4, 60))
+        P = rng.normal(size=(3, m)) * 2
+        R = synth.quat_to_R(synth.quat_from_rotvec(rng.normal(size=3))); t = rng.normal(size=3)
+        Q = R @ P + t[:, None] + rng.normal(0, 0.01 if m > 3 else 0.0, (3, m))
+        T = oracle.pose_svd(P, Q)
+        K = NP.kabsch(P, Q)
+        assert np.abs(T - K).max() < 2e-4              # float32 recipe vs float64 Kabsch
+        assert abs(np.linalg.det(T[:, :3]) - 1) < 1e-5
+    # reflected / degenerate triples still give a proper rotation
+    P = np.array([[0, 1, 2.0], [0, 0, 0], [0, 0, 0]]); Q = P.copy()        # collinear
+    T = oracle.pose_svd(P, Q)
+    assert abs(np.linalg.det(T[:, :3]) - 1) < 1e-5
+    P = rng.normal(size=(3, 3)); Q = P * np.array([[1], [1], [-1.0]])       # mirror image
+    T = oracle.pose_svd(P, Q)
+    assert abs(np.linalg.det(T[:, :3]) - 1) < 1e-5
+
+
+def test_consensus3d_vs_numpy(oracle):
+    rng = np.random.default_rng(3)
+    P = rng.normal(size=(3, 300)); T = np.concatenate([synth.quat_to_R(synth.quat_from_rotvec(rng.normal(size=3))), rng.normal(size=(3, 1))], 1)
+    Q = T[:, :3] @ P + T[:, 3:4] + rng.normal(0, 0.08, P.shape)
+    c, s = oracle.consensus3d(P, Q, T, 0.1)
+    d = NP.point_distances(P, Q, T)
+    safe = np.abs(d - 0.1) > 1e-12
+    assert np.array_equal(s[safe].astype(bool), d[safe] < 0.1) and c == s.sum()
+
+
+def test_prosac_recovers_motion_and_matches_semantics(oracle):
+    rng = np.random.default_rng(4)
+    m = 120
+    P = rng.uniform(-2, 2, (3, m))
+    R = synth.quat_to_R(synth.quat_from_rotvec(np.array([0.1, -0.2, 0.3]))); t = np.array([0.3, -0.1, 0.2])
+    Q = R @ P + t[:, None] + rng.normal(0, 0.005, P.shape)
+    out = rng.random(m) < 0.3
+    Q[:, out] += rng.normal(0, 1.0, (3, int(out.sum())))
+    r = oracle.prosac(P, Q, 0.05, 200, 1.0, True, seed=1, job_id=2)
+    assert r["iterations_run"] == 200
+    assert r["consensus"] >= (~out).sum() - 3
+    assert np.abs(r["T"][:, :3] - R).max() < 5e-3 and np.abs(r["T"][:, 3] - t).max() < 5e-3
+    # mse is the MEAN inlier distance, not squared (:285-290)
+    d = NP.point_distances(P, Q, r["T"])
+    assert abs(r["mse"] - d[r["mask"] == 1].mean()) < 1e-12
+    assert r["consensus"] == int(r["mask"].sum())
+    # early exit (:239): break as soon as consensus > pct*M
+    r2 = oracle.prosac(P, Q, 0.05, 200, 0.5, True, seed=1, job_id=2)
+    assert r2["iterations_run"] < 200 and r2["best_iteration"] == r2["iterations_run"] - 1
+    # fewer than 3 correspondences or no consensus: T = I, consensus 0 (:291-294)
+    r3 = oracle.prosac(P[:, :2], Q[:, :2], 0.05, 50, 0.6)
+    assert r3["consensus"] == 0 and np.array_equal(r3["T"], np.eye(3, 4)) and r3["mse"] == 0
+    r4 = oracle.prosac(P, rng.normal(size=P.shape) * 50, 1e-4, 50, 0.6)
+    assert r4["consensus"] == 0 and np.array_equal(r4["T"], np.eye(3, 4))
+
+
+def test_information_matrix_formula(oracle):
+    """I6 * (0.1*consensus/mse), rotational block x100, only if consensus>0 && mse>0 (:133-137)."""
+    I = oracle.information(50, 0.02)
+    s = 0.1 * 50 / 0.02
+    assert np.allclose(np.diag(I), [s, s, s, 100 * s, 100 * s, 100 * s]) and np.count_nonzero(I) == 6
+    assert np.array_equal(oracle.information(0, 0.02), np.eye(6))
+    assert np.array_equal(oracle.information(10, 0.0), np.eye(6))
+
+
+def test_estimate_edge_pipeline_vs_numpy_stages(oracle):
+    (f, t, T), = synth.make_pairs(1, n_kp=300, seed=42)
+    r = oracle.estimate_edge([f], [t], ransac_threshold=0.1, ransac_iteration=200, break_percentage=1.0, seed=3, job_id=8)
+    i0, d0, i1, d1 = NP.knn2(t["desc"], f["desc"])           # query = to, train = from (:58)
+    q, tr, d, nr = NP.filter_sort(i0, d0, i1, d1, f["valid"], t["valid"])
+    assert r["n_matches"] == nr and r["n_corr"] == len(q)
+    assert np.array_equal(r["corr_query"], q) and np.array_equal(r["corr_train"], tr) and np.array_equal(r["corr_dist"], d)
+    P = t["pos"][:, q]; Q = f["pos"][:, tr]                   # Pd / Xd (:121-124)
+    dist = NP.point_distances(P, Q, r["T"])
+    safe = np.abs(dist - 0.1) > 1e-9
+    assert np.array_equal(r["mask"][safe].astype(bool), dist[safe] < 0.1)
+    assert r["ok"] == 1 and r["consensus"] == r["mask"].sum() and r["consensus"] > 50
+    assert np.abs(r["T"] - T).max() < 0.02                    # from_T_to recovered
+    assert np.allclose(r["information"], oracle.information(r["consensus"], r["mse"]))
+    # failure semantics: < 7 keypoints -> no sensor pair -> ok = 0, matching_score = 0 (transformation_estimator.cpp:53-55)
+    small = dict(f, desc=f["desc"][:6], pos=f["pos"][:, :6], valid=f["valid"][:6])
+    r0 = oracle.estimate_edge([small], [t])
+    assert r0["ok"] == 0 and r0["consensus"] == 0 and r0["frame_from"] == -1

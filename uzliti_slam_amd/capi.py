@@ -240,7 +240,7 @@ class Match:
         return tuple(out)
 
     def ransac_points(self, problems, max_error, iterations, break_percentage, do_prosac=True, job_ids=None):
-        """problems: list of (P (3,M), Q (3,M)). Returns list of dicts like oracle.prosac."""
+        """problems: list of (P (3,M), Q (3,M)). Returns one dict per problem (T, consensus, mse, iterations_run, mask)."""
         nb = len(problems)
         offs = np.zeros(nb + 1, np.int32)
         for b, (P, _) in enumerate(problems):

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void knn2_generic_kernel(const uint32_t* __
 
 // ------------------------------------------------------------------------------------------------
 // M6a  counter-based sampling (replaces std::random_shuffle on a persistent permutation, :217-225;
-//      see oracle/uzl_oracle_match.c for the equivalence argument)
+//      the equivalence argument is in DESIGN.md, 'Sampling')
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -117,7 +117,7 @@ __device__ __forceinline__ int prosac_prefix(int iter, int iterations, int m)
 // First three steps of a forward Fisher-Yates shuffle over the virtual identity array of length n
 // (step s swaps position s with position j_s drawn from [s, n); a step with n - s < 2 is a no-op).
 // Only positions 0, j0 and j1 can differ from the identity when step 2 runs, which gives the closed
-// form below (same sequence as uzlo_sample3's explicit swap bookkeeping).
+// form below (the parity tests check it against an explicit swap-bookkeeping implementation).
 __device__ __forceinline__ void sample3(uint64_t key, int iter, int n, int& s0, int& s1, int& s2)
 {
     const int j0 = (n >= 2) ? (int)draw_below(key, (uint32_t)iter, 0u, (uint32_t)n) : 0;
@@ -133,7 +133,8 @@ __device__ __forceinline__ void sample3(uint64_t key, int iter, int n, int& s0, 
 
 // ------------------------------------------------------------------------------------------------
 // M7  estimatePoseSVD (:299-314) -> pcl::TransformationFromCorrespondences [EXT], float.
-//     Operation order identical to uzlo_pose_svd / uzlo_svd3f in oracle/uzl_oracle_match.c.
+//     The operation order below is this build's documented recipe ('Float pose recipe');
+//     the parity tests require it to reproduce the CPU restatement bit for bit.
 // ------------------------------------------------------------------------------------------------
 struct PoseAcc {
     float m1x, m1y, m1z, m2x, m2y, m2z;

@@ -1,0 +1,875 @@
+// pgo_kernels.hip — gfx950 kernels of the pose-graph half (G1, G3-G7, G9, G10 of SURVEY §8a).
+//
+// The reference hands the graph to g2o (graph_optimization/src/g2o_optimizer.cpp:137-149):
+// EdgeSE3 error/Jacobians, Huber kernel, block normal equations, Levenberg-Marquardt with a sparse
+// direct solve.  Here the same mathematics runs as flat f64 kernels over SoA edge arrays and a
+// block-CSR of 6x6 blocks; the linear solve is a preconditioned conjugate gradient (design choice of
+// this back end; tolerance tight enough to track the direct solve).
+//
+// Poses live as (t, unit quaternion): the error e = toVectorMQT(Z^-1 Xi^-1 Xj)
+// (graph_slam_common/thirdparty/src/isometry3d_mappings.cpp:94-99) is then pure quaternion algebra
+// with no matrix->quaternion branches in the hot loop.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "pgo_types.hpp"
+
+namespace uzl {
+
+constexpr int kBlk = 256;
+
+// ------------------------------------------------------------------------------------------------
+// small fixed-size algebra (everything stays in registers; indices are compile-time constants)
+// ------------------------------------------------------------------------------------------------
+struct Q4 { double w, x, y, z; };
+struct V3 { double x, y, z; };
+struct M33 { double m[9]; };
+
+__device__ __forceinline__ Q4 qmul(const Q4& a, const Q4& b)
+{
+    return Q4{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+              a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+              a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+              a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Q4 qconj(const Q4& a) { return Q4{a.w, -a.x, -a.y, -a.z}; }
+__device__ __forceinline__ Q4 qnormalize(const Q4& a)
+{
+    const double n = 1.0 / sqrt(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z);
+    return Q4{a.w * n, a.x * n, a.y * n, a.z * n};
+}
+// Eigen::Quaterniond::toRotationMatrix [EXT]
+__device__ __forceinline__ M33 qrot(const Q4& q)
+{
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    M33 R;
+    R.m[0] = 1 - (tyy + tzz); R.m[1] = txy - twz;       R.m[2] = txz + twy;
+    R.m[3] = txy + twz;       R.m[4] = 1 - (txx + tzz); R.m[5] = tyz - twx;
+    R.m[6] = txz - twy;       R.m[7] = tyz + twx;       R.m[8] = 1 - (txx + tyy);
+    return R;
+}
+__device__ __forceinline__ V3 mulv(const M33& R, const V3& v)
+{
+    return V3{R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z,
+              R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+              R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};
+}
+__device__ __forceinline__ V3 mulTv(const M33& R, const V3& v)
+{
+    return V3{R.m[0] * v.x + R.m[3] * v.y + R.m[6] * v.z,
+              R.m[1] * v.x + R.m[4] * v.y + R.m[7] * v.z,
+              R.m[2] * v.x + R.m[5] * v.y + R.m[8] * v.z};
+}
+// Eigen::Quaterniond(Matrix3d) [EXT]; m row-major
+__device__ __forceinline__ Q4 quat_from_R(const double* m)
+{
+    Q4 q;
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.) {
+        t = sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
+    } else if (m[0] >= m[4] && m[0] >= m[8]) {            // i = 0
+        t = sqrt(m[0] - m[4] - m[8] + 1.0);
+        q.x = 0.5 * t; t = 0.5 / t;
+        q.w = (m[7] - m[5]) * t; q.y = (m[3] + m[1]) * t; q.z = (m[6] + m[2]) * t;
+    } else if (m[4] > m[0] && m[4] >= m[8]) {             // i = 1
+        t = sqrt(m[4] - m[8] - m[0] + 1.0);
+        q.y = 0.5 * t; t = 0.5 / t;
+        q.w = (m[2] - m[6]) * t; q.z = (m[7] + m[5]) * t; q.x = (m[1] + m[3]) * t;
+    } else {                                               // i = 2
+        t = sqrt(m[8] - m[0] - m[4] + 1.0);
+        q.z = 0.5 * t; t = 0.5 / t;
+        q.w = (m[3] - m[1]) * t; q.x = (m[2] + m[6]) * t; q.y = (m[5] + m[7]) * t;
+    }
+    return q;
+}
+
+struct Pose { V3 t; Q4 q; };
+__device__ __forceinline__ Pose load_pose(const double* __restrict__ p, int v)
+{
+    const double2* q = reinterpret_cast<const double2*>(p + (size_t)v * 8);
+    const double2 a = q[0], b = q[1], c = q[2], d = q[3];
+    return Pose{V3{a.x, a.y, b.x}, Q4{b.y, c.x, c.y, d.x}};
+}
+__device__ __forceinline__ void store_pose(double* __restrict__ p, int v, const Pose& P)
+{
+    double2* q = reinterpret_cast<double2*>(p + (size_t)v * 8);
+    q[0] = make_double2(P.t.x, P.t.y); q[1] = make_double2(P.t.z, P.q.w);
+    q[2] = make_double2(P.q.x, P.q.y); q[3] = make_double2(P.q.z, 0.);
+}
+// 3x4 row-major [R|t] -> Pose (unit quaternion)
+__device__ __forceinline__ Pose pose_from_T(const double* T)
+{
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    return Pose{V3{T[3], T[7], T[11]}, qnormalize(quat_from_R(R))};
+}
+__device__ __forceinline__ void T_from_pose(const Pose& P, double* T)
+{
+    const M33 R = qrot(P.q);
+    T[0] = R.m[0]; T[1] = R.m[1]; T[2] = R.m[2]; T[3] = P.t.x;
+    T[4] = R.m[3]; T[5] = R.m[4]; T[6] = R.m[5]; T[7] = P.t.y;
+    T[8] = R.m[6]; T[9] = R.m[7]; T[10] = R.m[8]; T[11] = P.t.z;
+}
+__device__ __forceinline__ Pose pose_mul(const Pose& A, const Pose& B)
+{
+    const V3 rb = mulv(qrot(A.q), B.t);
+    return Pose{V3{rb.x + A.t.x, rb.y + A.t.y, rb.z + A.t.z}, qnormalize(qmul(A.q, B.q))};
+}
+__device__ __forceinline__ Pose pose_inv(const Pose& A)
+{
+    const V3 t = mulTv(qrot(A.q), A.t);
+    return Pose{V3{-t.x, -t.y, -t.z}, qconj(A.q)};
+}
+// optimize_xy_only: zero roll, pitch, z through toEuler/fromEuler
+// (g2o_optimizer.cpp:164-170, isometry3d_mappings.cpp:47-75)
+__device__ __forceinline__ Pose project_xy(const Pose& P)
+{
+    // toEuler takes Quaterniond(R) un-normalised; P.q is the normalised quaternion of the same R
+    const double q0 = P.q.w, q1 = P.q.x, q2 = P.q.y, q3 = P.q.z;
+    const double yaw = atan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 * q2 + q3 * q3));
+    const double sy = sin(yaw * 0.5), cy = cos(yaw * 0.5);
+    return Pose{V3{P.t.x, P.t.y, 0.}, Q4{cy, 0., 0., sy}};
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions (deterministic: fixed tree shapes, no atomics)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// all threads get the block total (blockDim = 256)
+__device__ __forceinline__ double block_sum(double v, double* s4)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+__device__ __forceinline__ double block_max(double v, double* s4)
+{
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
+}
+// every block re-reduces the (<= 1024) partials of the previous kernel: same order everywhere
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int count, double* s4)
+{
+    double v = 0.;
+    for (int i = threadIdx.x; i < count; i += kBlk) v += part[i];
+    return block_sum(v, s4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// G1  graph flattening on the device
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlk) void prepare_nodes_kernel(const uzl_node* __restrict__ nodes, int n,
+                                                             int xy_only, double* __restrict__ pose)
+{
+    const int v = blockIdx.x * kBlk + threadIdx.x;
+    if (v >= n) return;
+    Pose P = pose_from_T(nodes[v].pose);                           // addVertex :160-188
+    if (xy_only) P = project_xy(P);                                // :164-170
+    store_pose(pose, v, P);
+}
+
+__global__ __launch_bounds__(kBlk) void prepare_flat_nodes_kernel(const double* __restrict__ poses12, int n,
+                                                                  double* __restrict__ pose)
+{
+    const int v = blockIdx.x * kBlk + threadIdx.x;
+    if (v >= n) return;
+    store_pose(pose, v, pose_from_T(poses12 + (size_t)v * 12));
+}
+
+__device__ __forceinline__ void store_edge(const Pose& Z, const double* __restrict__ info_in, int k, int e,
+                                           double* __restrict__ zinv, double* __restrict__ info)
+{
+    const Pose A = pose_inv(Z);
+    zinv[0 * (size_t)e + k] = A.t.x; zinv[1 * (size_t)e + k] = A.t.y; zinv[2 * (size_t)e + k] = A.t.z;
+    zinv[3 * (size_t)e + k] = A.q.w; zinv[4 * (size_t)e + k] = A.q.x; zinv[5 * (size_t)e + k] = A.q.y;
+    zinv[6 * (size_t)e + k] = A.q.z;
+#pragma unroll
+    for (int i = 0; i < 36; i++) info[(size_t)i * e + k] = info_in[i];
+}
+
+// src[k] = index of the input edge behind system edge k; odom[k] = 1 for TYPE_2D_WHEEL_ODOMETRY
+__global__ __launch_bounds__(kBlk) void prepare_edges_kernel(const uzl_edge* __restrict__ edges,
+                                                             const int32_t* __restrict__ src, int e,
+                                                             const double* __restrict__ sensors, int n_sensors,
+                                                             int xy_only, double* __restrict__ zinv,
+                                                             double* __restrict__ info)
+{
+    const int k = blockIdx.x * kBlk + threadIdx.x;
+    if (k >= e) return;
+    const uzl_edge* ed = edges + src[k];
+    Pose Z = pose_from_T(ed->transform);
+    const Pose Df = pose_from_T(ed->displacement_from);
+    const Pose Dt = pose_from_T(ed->displacement_to);
+    if (ed->type == UZL_EDGE_TYPE_2D_WHEEL_ODOMETRY) {
+        Z = pose_mul(pose_mul(Df, Z), pose_inv(Dt));               // addOdometryEdge :229
+    } else {                                                       // addFeatureEdge :281
+        Pose M = Df;
+        if (ed->sensor_from >= 0 && ed->sensor_from < n_sensors) M = pose_mul(M, pose_from_T(sensors + 12 * (size_t)ed->sensor_from));
+        M = pose_mul(M, Z);
+        if (ed->sensor_to >= 0 && ed->sensor_to < n_sensors) M = pose_mul(M, pose_inv(pose_from_T(sensors + 12 * (size_t)ed->sensor_to)));
+        Z = pose_mul(M, pose_inv(Dt));
+    }
+    if (xy_only) Z = project_xy(Z);                                // :231-237, :282-288
+    store_edge(Z, ed->information, k, e, zinv, info);
+}
+
+__global__ __launch_bounds__(kBlk) void prepare_flat_edges_kernel(const double* __restrict__ meas12,
+                                                                  const double* __restrict__ info36, int e,
+                                                                  double* __restrict__ zinv, double* __restrict__ info)
+{
+    const int k = blockIdx.x * kBlk + threadIdx.x;
+    if (k >= e) return;
+    store_edge(pose_from_T(meas12 + (size_t)k * 12), info36 + (size_t)k * 36, k, e, zinv, info);
+}
+
+// ------------------------------------------------------------------------------------------------
+// G3  EdgeSE3::computeError [EXT]:  e = toVectorMQT(Z^-1 * Xi^-1 * Xj)
+// ------------------------------------------------------------------------------------------------
+struct EdgeGeom {
+    V3 te, tb;
+    Q4 qa, qb, qe;
+    double s;
+};
+__device__ __forceinline__ EdgeGeom edge_geom(const PgoDev& D, const double* __restrict__ pose, int k)
+{
+    const Pose Xi = load_pose(pose, D.ei[k]);
+    const Pose Xj = load_pose(pose, D.ej[k]);
+    const size_t e = (size_t)D.e;
+    const V3 ta{D.zinv[0 * e + k], D.zinv[1 * e + k], D.zinv[2 * e + k]};
+    EdgeGeom G;
+    G.qa = Q4{D.zinv[3 * e + k], D.zinv[4 * e + k], D.zinv[5 * e + k], D.zinv[6 * e + k]};
+    const V3 d{Xj.t.x - Xi.t.x, Xj.t.y - Xi.t.y, Xj.t.z - Xi.t.z};
+    G.tb = mulTv(qrot(Xi.q), d);
+    G.qb = qmul(qconj(Xi.q), Xj.q);
+    const V3 rt = mulv(qrot(G.qa), G.tb);
+    G.te = V3{rt.x + ta.x, rt.y + ta.y, rt.z + ta.z};
+    Q4 qab = qnormalize(qmul(G.qa, G.qb));                          // toCompactQuaternion normalises (:77-82)
+    G.s = (qab.w < 0.) ? -1. : 1.;                                  // ... and flips to w >= 0 (:38-44)
+    G.qe = Q4{G.s * qab.w, G.s * qab.x, G.s * qab.y, G.s * qab.z};
+    return G;
+}
+
+// chi = e^T Omega e, reading Omega from the SoA array
+__device__ __forceinline__ double edge_chi(const PgoDev& D, int k, const double* ev)
+{
+    const size_t e = (size_t)D.e;
+    double chi = 0.;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        double s = 0.;
+#pragma unroll
+        for (int c = 0; c < 6; c++) s += D.info[(size_t)(r * 6 + c) * e + k] * ev[c];
+        chi += ev[r] * s;
+    }
+    return chi;
+}
+
+// G5 RobustKernelHuber::robustify [EXT] (rho0, rho1)
+__device__ __forceinline__ void huber(double e2, double delta, double& rho0, double& rho1)
+{
+    const double dsqr = delta * delta;
+    if (e2 <= dsqr) { rho0 = e2; rho1 = 1.; }
+    else { const double sq = sqrt(e2); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
+}
+
+// activeRobustChi2 over `pose`; block partials -> part_a
+__global__ __launch_bounds__(kBlk) void chi2_kernel(PgoDev D, const double* __restrict__ pose, double delta)
+{
+    __shared__ double s4[4];
+    double acc = 0.;
+    for (int k = blockIdx.x * kBlk + threadIdx.x; k < D.e; k += gridDim.x * kBlk) {
+        const EdgeGeom G = edge_geom(D, pose, k);
+        const double ev[6] = {G.te.x, G.te.y, G.te.z, G.qe.x, G.qe.y, G.qe.z};
+        const double chi = edge_chi(D, k, ev);
+        double r0 = chi, r1 = 1.;
+        if (D.robust[k]) huber(chi, delta, r0, r1);
+        acc += r0;
+    }
+    const double tot = block_sum(acc, s4);
+    if (threadIdx.x == 0) D.part_a[blockIdx.x] = tot;
+}
+
+// G10 storeImpl: ||e||_2 per system edge (g2o_optimizer.cpp:124-131)
+__global__ __launch_bounds__(kBlk) void edge_error_kernel(PgoDev D, const double* __restrict__ pose,
+                                                          double* __restrict__ err)
+{
+    const int k = blockIdx.x * kBlk + threadIdx.x;
+    if (k >= D.e) return;
+    const EdgeGeom G = edge_geom(D, pose, k);
+    err[k] = sqrt(G.te.x * G.te.x + G.te.y * G.te.y + G.te.z * G.te.z + G.qe.x * G.qe.x + G.qe.y * G.qe.y + G.qe.z * G.qe.z);
+}
+
+__global__ __launch_bounds__(kBlk) void poses_out_kernel(const double* __restrict__ pose, int n,
+                                                         double* __restrict__ out12)
+{
+    const int v = blockIdx.x * kBlk + threadIdx.x;
+    if (v >= n) return;
+    double T[12];
+    T_from_pose(load_pose(pose, v), T);
+#pragma unroll
+    for (int i = 0; i < 12; i++) out12[(size_t)v * 12 + i] = T[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// G4 + G6  linearizeOplus + constructQuadraticForm [EXT], one lane per edge.
+//   Ji = [[-Ra, 2 Ra [tb]x], [0, -s((wb I - [vb]x)(wa I + [va]x) - vb va^T)]]
+//   Jj = [[ Re, 0         ], [0,  we I + [ve]x                              ]]
+// (derivation in DESIGN.md, 'Jacobians'; checked against central differences in the tests)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void skew(const double x, const double y, const double z, double* S)
+{
+    S[0] = 0; S[1] = -z; S[2] = y;
+    S[3] = z; S[4] = 0; S[5] = -x;
+    S[6] = -y; S[7] = x; S[8] = 0;
+}
+__device__ __forceinline__ void mat3mul(const double* A, const double* B, double* C)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+}
+
+__global__ __launch_bounds__(kBlk) void linearize_kernel(PgoDev D, const double* __restrict__ pose, double delta)
+{
+    __shared__ double s4[4];
+    double chi_acc = 0.;
+    const size_t E = (size_t)D.e;
+    for (int k = blockIdx.x * kBlk + threadIdx.x; k < D.e; k += gridDim.x * kBlk) {
+        const EdgeGeom G = edge_geom(D, pose, k);
+        const double ev[6] = {G.te.x, G.te.y, G.te.z, G.qe.x, G.qe.y, G.qe.z};
+        // Omega (row-major 6x6) from the SoA array, robustified: Omega' = rho1 * Omega
+        double Om[36];
+#pragma unroll
+        for (int i = 0; i < 36; i++) Om[i] = D.info[(size_t)i * E + k];
+        double Oe[6];
+        double chi = 0.;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            double s = 0.;
+#pragma unroll
+            for (int c = 0; c < 6; c++) s += Om[r * 6 + c] * ev[c];
+            Oe[r] = s;
+            chi += ev[r] * s;
+        }
+        double r0 = chi, r1 = 1.;
+        if (D.robust[k]) huber(chi, delta, r0, r1);
+        chi_acc += r0;
+        const int si = D.slot_i[k], sj = D.slot_j[k];
+        if (si < 0 && sj < 0) continue;
+#pragma unroll
+        for (int i = 0; i < 36; i++) Om[i] *= r1;
+#pragma unroll
+        for (int i = 0; i < 6; i++) Oe[i] *= r1;
+
+        // ---- Jacobian blocks
+        const M33 Ra = qrot(G.qa);
+        const M33 Re = qrot(G.qe);
+        double A11[9], A12[9], A22[9], B22[9];
+        {
+            double S[9], T[9];
+            skew(G.tb.x, G.tb.y, G.tb.z, S);
+            mat3mul(Ra.m, S, T);
+#pragma unroll
+            for (int i = 0; i < 9; i++) { A11[i] = -Ra.m[i]; A12[i] = 2. * T[i]; }
+            double Sa[9], Sb[9], L[9], R[9], P[9];
+            skew(G.qa.x, G.qa.y, G.qa.z, Sa);
+            skew(G.qb.x, G.qb.y, G.qb.z, Sb);
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const double id = (i % 4 == 0) ? 1. : 0.;
+                L[i] = id * G.qb.w - Sb[i];
+                R[i] = id * G.qa.w + Sa[i];
+            }
+            mat3mul(L, R, P);
+            const double vb[3] = {G.qb.x, G.qb.y, G.qb.z}, va[3] = {G.qa.x, G.qa.y, G.qa.z};
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) A22[r * 3 + c] = -G.s * (P[r * 3 + c] - vb[r] * va[c]);
+            double Se[9];
+            skew(G.qe.x, G.qe.y, G.qe.z, Se);
+#pragma unroll
+            for (int i = 0; i < 9; i++) B22[i] = ((i % 4 == 0) ? G.qe.w : 0.) + Se[i];
+        }
+        const double* B11 = Re.m;
+
+        // ---- W_j = Omega' Jj   (Jj = diag(B11, B22))
+        double Wj[36];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                Wj[r * 6 + c] = Om[r * 6 + 0] * B11[0 * 3 + c] + Om[r * 6 + 1] * B11[1 * 3 + c] + Om[r * 6 + 2] * B11[2 * 3 + c];
+                Wj[r * 6 + 3 + c] = Om[r * 6 + 3] * B22[0 * 3 + c] + Om[r * 6 + 4] * B22[1 * 3 + c] + Om[r * 6 + 5] * B22[2 * 3 + c];
+            }
+        // ---- row i:  H_ij = Ji^T Wj ; row j: H_ji = H_ij^T, H_jj = Jj^T Wj
+        double Hij[36];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                Hij[r * 6 + c] = A11[0 * 3 + r] * Wj[0 * 6 + c] + A11[1 * 3 + r] * Wj[1 * 6 + c] + A11[2 * 3 + r] * Wj[2 * 6 + c];
+                Hij[(3 + r) * 6 + c] = A12[0 * 3 + r] * Wj[0 * 6 + c] + A12[1 * 3 + r] * Wj[1 * 6 + c] + A12[2 * 3 + r] * Wj[2 * 6 + c] +
+                                       A22[0 * 3 + r] * Wj[3 * 6 + c] + A22[1 * 3 + r] * Wj[4 * 6 + c] + A22[2 * 3 + r] * Wj[5 * 6 + c];
+            }
+        }
+        if (sj >= 0) {
+            double* __restrict__ bj = D.blk + (size_t)sj * 36;
+            double* __restrict__ dj = D.dcon + (size_t)sj * 36;
+            double* __restrict__ gj = D.gcon + (size_t)sj * 6;
+            if (si >= 0) {
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++) bj[r * 6 + c] = Hij[c * 6 + r];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    dj[r * 6 + c] = B11[0 * 3 + r] * Wj[0 * 6 + c] + B11[1 * 3 + r] * Wj[1 * 6 + c] + B11[2 * 3 + r] * Wj[2 * 6 + c];
+                    dj[(3 + r) * 6 + c] = B22[0 * 3 + r] * Wj[3 * 6 + c] + B22[1 * 3 + r] * Wj[4 * 6 + c] + B22[2 * 3 + r] * Wj[5 * 6 + c];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                gj[r] = B11[0 * 3 + r] * Oe[0] + B11[1 * 3 + r] * Oe[1] + B11[2 * 3 + r] * Oe[2];
+                gj[3 + r] = B22[0 * 3 + r] * Oe[3] + B22[1 * 3 + r] * Oe[4] + B22[2 * 3 + r] * Oe[5];
+            }
+        }
+        if (si >= 0) {
+            double* __restrict__ bi = D.blk + (size_t)si * 36;
+            double* __restrict__ di = D.dcon + (size_t)si * 36;
+            double* __restrict__ gi = D.gcon + (size_t)si * 6;
+            if (sj >= 0) {
+#pragma unroll
+                for (int i = 0; i < 36; i++) bi[i] = Hij[i];
+            }
+            // W_i = Omega' Ji, reusing Wj's registers
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    Wj[r * 6 + c] = Om[r * 6 + 0] * A11[0 * 3 + c] + Om[r * 6 + 1] * A11[1 * 3 + c] + Om[r * 6 + 2] * A11[2 * 3 + c];
+                    Wj[r * 6 + 3 + c] = Om[r * 6 + 0] * A12[0 * 3 + c] + Om[r * 6 + 1] * A12[1 * 3 + c] + Om[r * 6 + 2] * A12[2 * 3 + c] +
+                                        Om[r * 6 + 3] * A22[0 * 3 + c] + Om[r * 6 + 4] * A22[1 * 3 + c] + Om[r * 6 + 5] * A22[2 * 3 + c];
+                }
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    di[r * 6 + c] = A11[0 * 3 + r] * Wj[0 * 6 + c] + A11[1 * 3 + r] * Wj[1 * 6 + c] + A11[2 * 3 + r] * Wj[2 * 6 + c];
+                    di[(3 + r) * 6 + c] = A12[0 * 3 + r] * Wj[0 * 6 + c] + A12[1 * 3 + r] * Wj[1 * 6 + c] + A12[2 * 3 + r] * Wj[2 * 6 + c] +
+                                          A22[0 * 3 + r] * Wj[3 * 6 + c] + A22[1 * 3 + r] * Wj[4 * 6 + c] + A22[2 * 3 + r] * Wj[5 * 6 + c];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                gi[r] = A11[0 * 3 + r] * Oe[0] + A11[1 * 3 + r] * Oe[1] + A11[2 * 3 + r] * Oe[2];
+                gi[3 + r] = A12[0 * 3 + r] * Oe[0] + A12[1 * 3 + r] * Oe[1] + A12[2 * 3 + r] * Oe[2] +
+                            A22[0 * 3 + r] * Oe[3] + A22[1 * 3 + r] * Oe[4] + A22[2 * 3 + r] * Oe[5];
+            }
+        }
+    }
+    const double tot = block_sum(chi_acc, s4);
+    if (threadIdx.x == 0) D.part_a[blockIdx.x] = tot;
+}
+
+// H_aa = sum of the row's dcon, b_a = -sum of gcon; 36+6 lanes... one lane per (row, entry): 42 entries
+// Grid-stride over rows with 6 lanes per row (lane r owns row r of the 6x6 block and b[r]).
+__global__ __launch_bounds__(kBlk) void assemble_kernel(PgoDev D)
+{
+    __shared__ double s4[4];
+    double dmax = 0.;
+    const int lanes_per_blk = kBlk / 6 * 6;       // 252
+    for (int base = blockIdx.x * (kBlk / 6); base < D.nb; base += gridDim.x * (kBlk / 6)) {
+        const int a = base + (int)threadIdx.x / 6, r = (int)threadIdx.x % 6;
+        if ((int)threadIdx.x < lanes_per_blk && a < D.nb) {
+            double h[6] = {0., 0., 0., 0., 0., 0.};
+            double g = 0.;
+            for (int s = D.row_ptr[a]; s < D.row_ptr[a + 1]; s++) {
+                const double* __restrict__ dc = D.dcon + (size_t)s * 36 + r * 6;
+#pragma unroll
+                for (int c = 0; c < 6; c++) h[c] += dc[c];
+                g += D.gcon[(size_t)s * 6 + r];
+            }
+            double* __restrict__ out = D.hdiag + (size_t)a * 36 + r * 6;
+#pragma unroll
+            for (int c = 0; c < 6; c++) out[c] = h[c];
+            D.b[(size_t)a * 6 + r] = -g;
+            dmax = fmax(dmax, fabs(h[r]));
+        }
+    }
+    const double m = block_max(dmax, s4);
+    if (threadIdx.x == 0) D.part_c[blockIdx.x] = m;
+}
+
+// one block: final reductions of the LM bookkeeping scalars.
+//   what = 0: scal[4] = sum(part_a[0..na))            (chi2)
+//   what = 1: ... and scal[5] = sum(part_b[0..nb_))    (chi2 + computeScale)
+//   what = 2: ... and scal[6] = max(part_c[0..nc))     (chi2 + max diagonal for computeLambdaInit)
+__global__ __launch_bounds__(kBlk) void finalize_kernel(PgoDev D, int na, int nb_, int nc, int what)
+{
+    __shared__ double s4[4];
+    const double chi = sum_partials(D.part_a, na, s4);
+    if (threadIdx.x == 0) D.scal[4] = chi;
+    if (what == 1) {
+        const double sc = sum_partials(D.part_b, nb_, s4);
+        if (threadIdx.x == 0) D.scal[5] = sc;
+    }
+    if (what == 2) {
+        double v = 0.;
+        for (int i = threadIdx.x; i < nc; i += kBlk) v = fmax(v, D.part_c[i]);
+        const double m = block_max(v, s4);
+        if (threadIdx.x == 0) D.scal[6] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G8  linear solve: block-Jacobi PCG on (H + lambda I) dx = b
+// ------------------------------------------------------------------------------------------------
+// M_a^-1 = (H_aa + lambda I)^-1 through a 6x6 Cholesky, one lane per row block
+__global__ __launch_bounds__(kBlk) void precond_kernel(PgoDev D)
+{
+    const int a = blockIdx.x * kBlk + threadIdx.x;
+    if (a >= D.nb) return;
+    const double lambda = D.scal[3];
+    double A[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) A[i] = D.hdiag[(size_t)a * 36 + i] + ((i % 7 == 0) ? lambda : 0.);
+    // lower Cholesky A = L L^T (in place, lower part)
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[j * 6 + k] * A[j * 6 + k];
+        d = sqrt(fmax(d, 1e-300));
+        A[j * 6 + j] = d;
+        const double inv = 1. / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s * inv;
+        }
+    }
+    // Linv (lower) by forward substitution, then Minv = Linv^T Linv
+    double Li[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) Li[i] = 0.;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+#pragma unroll
+        for (int r = c; r < 6; r++) {
+            double s = (r == c) ? 1. : 0.;
+#pragma unroll
+            for (int k = c; k < r; k++) s -= A[r * 6 + k] * Li[k * 6 + c];
+            Li[r * 6 + c] = s / A[r * 6 + r];
+        }
+    }
+    double* __restrict__ out = D.minv + (size_t)a * 36;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            double s = 0.;
+#pragma unroll
+            for (int k = (r > c ? r : c); k < 6; k++) s += Li[k * 6 + r] * Li[k * 6 + c];
+            out[r * 6 + c] = s;
+        }
+}
+
+// x = 0, r = b, z = Minv r; partials of r.z -> part_b
+__global__ __launch_bounds__(kBlk) void pcg_init_kernel(PgoDev D)
+{
+    __shared__ double s4[4];
+    __shared__ double sv[kBlk];
+    const int per = kBlk / 6;                        // 42 row blocks per block
+    double acc = 0.;
+    for (int base = blockIdx.x * per; base < D.nb; base += gridDim.x * per) {
+        const int a = base + (int)threadIdx.x / 6, r = (int)threadIdx.x % 6;
+        const bool act = (int)threadIdx.x < per * 6 && a < D.nb;
+        double rv = 0.;
+        if (act) { rv = D.b[(size_t)a * 6 + r]; }
+        __syncthreads();
+        sv[threadIdx.x] = rv;
+        __syncthreads();
+        if (act) {
+            const double* __restrict__ m = D.minv + (size_t)a * 36 + r * 6;
+            const int g0 = (int)threadIdx.x - r;
+            double zz = 0.;
+#pragma unroll
+            for (int c = 0; c < 6; c++) zz += m[c] * sv[g0 + c];
+            D.x[(size_t)a * 6 + r] = 0.;
+            D.r[(size_t)a * 6 + r] = rv;
+            D.z[(size_t)a * 6 + r] = zz;
+            acc += rv * zz;
+        }
+    }
+    const double tot = block_sum(acc, s4);
+    if (threadIdx.x == 0) D.part_b[blockIdx.x] = tot;
+}
+
+// first = 1: rz0 = sum(part_b); p = z; thresholds.   first = 0: beta = rz_new / rz_prev; p = z + beta p.
+__global__ __launch_bounds__(kBlk) void pcg_p_kernel(PgoDev D, int n_part, int first, double tol2)
+{
+    __shared__ double s4[4];
+    if (!first && D.flags[0]) return;
+    const double rz_new = sum_partials(D.part_b, n_part, s4);
+    double beta = 0.;
+    if (!first) { const double rz_prev = D.scal[2]; beta = (rz_prev > 0.) ? rz_new / rz_prev : 0.; }
+    const int tot = D.nb * 6;
+    for (int i = blockIdx.x * kBlk + threadIdx.x; i < tot; i += gridDim.x * kBlk)
+        D.p[i] = first ? D.z[i] : D.z[i] + beta * D.p[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        D.scal[0] = rz_new;
+        if (first) {
+            D.scal[1] = tol2 * rz_new;
+            D.flags[0] = (rz_new <= 0.) ? 1 : 0;
+            D.flags[1] = 0;
+            D.flags[2] = 0;
+        } else {
+            D.flags[1] += 1;
+            if (rz_new <= D.scal[1]) D.flags[0] = 1;
+        }
+    }
+}
+
+// Ap = (H + lambda I) p.  One wave per row block: 10 slot-groups of 6 lanes walk the row's contiguous
+// slots (lane (g, r) owns row r of slot s0+g+10k), then a shuffle tree folds the groups.
+__global__ __launch_bounds__(kBlk) void pcg_spmv_kernel(PgoDev D)
+{
+    __shared__ double s4[4];
+    if (D.flags[0]) return;
+    const double lambda = D.scal[3];
+    const int lane = threadIdx.x & 63, g = lane / 6, r = lane % 6;
+    const bool act = lane < 60;
+    const int wave = blockIdx.x * (kBlk / 64) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (kBlk / 64);
+    double dot = 0.;
+    for (int a = wave; a < D.nb; a += nwaves) {
+        const int s0 = D.row_ptr[a], s1 = D.row_ptr[a + 1];
+        double acc = 0.;
+        if (g == 0) {
+            const double* __restrict__ h = D.hdiag + (size_t)a * 36 + r * 6;
+            const double* __restrict__ pv = D.p + (size_t)a * 6;
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc += h[c] * pv[c];
+            acc += lambda * pv[r];
+        }
+        if (act) {
+            for (int s = s0 + g; s < s1; s += 10) {
+                const int c = D.col[s];
+                if (c >= 0) {
+                    const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
+                    const double2* __restrict__ pv = reinterpret_cast<const double2*>(D.p + (size_t)c * 6);
+                    const double2 b0 = bk[0], b1 = bk[1], b2 = bk[2];
+                    const double2 p0 = pv[0], p1 = pv[1], p2 = pv[2];
+                    acc += b0.x * p0.x + b0.y * p0.y + b1.x * p1.x + b1.y * p1.y + b2.x * p2.x + b2.y * p2.y;
+                }
+            }
+        }
+        // fold the 10 groups: offsets 48, 24, 12, 6 lanes
+        double v;
+        v = __shfl_down(acc, 48); if (lane + 48 < 60) acc += v;
+        v = __shfl_down(acc, 24); if (lane + 24 < 48) acc += v;
+        v = __shfl_down(acc, 12); if (lane + 12 < 24) acc += v;
+        v = __shfl_down(acc, 6);  if (lane + 6 < 12) acc += v;
+        if (lane < 6) {
+            D.ap[(size_t)a * 6 + r] = acc;
+            dot += acc * D.p[(size_t)a * 6 + r];
+        }
+    }
+    const double tot = block_sum(dot, s4);
+    if (threadIdx.x == 0) D.part_a[blockIdx.x] = tot;
+}
+
+// alpha = rz / p.Ap; x += alpha p; r -= alpha Ap; z = Minv r; partials of r.z -> part_b
+__global__ __launch_bounds__(kBlk) void pcg_update_kernel(PgoDev D, int n_part)
+{
+    __shared__ double s4[4];
+    __shared__ double sv[kBlk];
+    if (D.flags[0]) return;
+    const double pAp = sum_partials(D.part_a, n_part, s4);
+    const double rz = D.scal[0];
+    const bool bad = !(pAp > 0.);
+    const double alpha = bad ? 0. : rz / pAp;
+    const int per = kBlk / 6;
+    double acc = 0.;
+    for (int base = blockIdx.x * per; base < D.nb; base += gridDim.x * per) {
+        const int a = base + (int)threadIdx.x / 6, r = (int)threadIdx.x % 6;
+        const bool act = (int)threadIdx.x < per * 6 && a < D.nb;
+        double rv = 0.;
+        if (act) {
+            const size_t i = (size_t)a * 6 + r;
+            D.x[i] += alpha * D.p[i];
+            rv = D.r[i] - alpha * D.ap[i];
+            D.r[i] = rv;
+        }
+        __syncthreads();
+        sv[threadIdx.x] = rv;
+        __syncthreads();
+        if (act) {
+            const double* __restrict__ m = D.minv + (size_t)a * 36 + r * 6;
+            const int g0 = (int)threadIdx.x - r;
+            double zz = 0.;
+#pragma unroll
+            for (int c = 0; c < 6; c++) zz += m[c] * sv[g0 + c];
+            D.z[(size_t)a * 6 + r] = zz;
+            acc += rv * zz;
+        }
+    }
+    const double tot = block_sum(acc, s4);
+    if (threadIdx.x == 0) {
+        D.part_b[blockIdx.x] = tot;
+        if (blockIdx.x == 0) {
+            D.scal[2] = rz;                          // rz_prev for the next pcg_p (which overwrites scal[0])
+            if (bad) { D.flags[0] = 1; D.flags[2] = 1; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G9  VertexSE3::oplusImpl [EXT]: X <- X * fromVectorMQT(dx)   (isometry3d_mappings.cpp:84-91,117-122)
+//     plus the partials of computeScale = sum dx (lambda dx + b) -> part_b
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlk) void oplus_kernel(PgoDev D, const double* __restrict__ pose_in,
+                                                     double* __restrict__ pose_out)
+{
+    __shared__ double s4[4];
+    const double lambda = D.scal[3];
+    double acc = 0.;
+    for (int v = blockIdx.x * kBlk + threadIdx.x; v < D.n; v += gridDim.x * kBlk) {
+        Pose P = load_pose(pose_in, v);
+        const int a = D.v2b[v];
+        if (a >= 0) {
+            const double* __restrict__ dx = D.x + (size_t)a * 6;
+            const double* __restrict__ bb = D.b + (size_t)a * 6;
+            const double d[6] = {dx[0], dx[1], dx[2], dx[3], dx[4], dx[5]};
+#pragma unroll
+            for (int i = 0; i < 6; i++) acc += d[i] * (lambda * d[i] + bb[i]);
+            const V3 rt = mulv(qrot(P.q), V3{d[0], d[1], d[2]});
+            P.t = V3{P.t.x + rt.x, P.t.y + rt.y, P.t.z + rt.z};
+            const double w2 = 1. - (d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+            if (w2 >= 0.) P.q = qnormalize(qmul(P.q, Q4{sqrt(w2), d[3], d[4], d[5]}));   // identity rotation if w2 < 0
+        }
+        store_pose(pose_out, v, P);
+    }
+    const double tot = block_sum(acc, s4);
+    if (threadIdx.x == 0) D.part_b[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int grid_for(int items, int per_block, int cap)
+{
+    int g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return g > cap ? cap : g;
+}
+
+void k_prepare_nodes(const uzl_node* nodes, int n, int xy, double* pose, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(prepare_nodes_kernel, dim3((n + kBlk - 1) / kBlk), dim3(kBlk), 0, s, nodes, n, xy, pose);
+}
+void k_prepare_flat_nodes(const double* poses12, int n, double* pose, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(prepare_flat_nodes_kernel, dim3((n + kBlk - 1) / kBlk), dim3(kBlk), 0, s, poses12, n, pose);
+}
+void k_prepare_edges(const uzl_edge* edges, const int32_t* src, int e, const double* sensors, int ns, int xy,
+                     double* zinv, double* info, hipStream_t s)
+{
+    if (e > 0) hipLaunchKernelGGL(prepare_edges_kernel, dim3((e + kBlk - 1) / kBlk), dim3(kBlk), 0, s, edges, src, e, sensors, ns, xy, zinv, info);
+}
+void k_prepare_flat_edges(const double* meas12, const double* info36, int e, double* zinv, double* info, hipStream_t s)
+{
+    if (e > 0) hipLaunchKernelGGL(prepare_flat_edges_kernel, dim3((e + kBlk - 1) / kBlk), dim3(kBlk), 0, s, meas12, info36, e, zinv, info);
+}
+int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s)
+{
+    const int g = grid_for(D.e, kBlk, kMaxPartials);
+    hipLaunchKernelGGL(chi2_kernel, dim3(g), dim3(kBlk), 0, s, D, pose, delta);
+    return g;
+}
+int k_linearize(const PgoDev& D, const double* pose, double delta, hipStream_t s)
+{
+    const int g = grid_for(D.e, kBlk, kMaxPartials);
+    hipLaunchKernelGGL(linearize_kernel, dim3(g), dim3(kBlk), 0, s, D, pose, delta);
+    return g;
+}
+int k_assemble(const PgoDev& D, hipStream_t s)
+{
+    const int g = grid_for(D.nb, kBlk / 6, kMaxPartials);
+    hipLaunchKernelGGL(assemble_kernel, dim3(g), dim3(kBlk), 0, s, D);
+    return g;
+}
+void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlk), 0, s, D, na, nb_, nc, what);
+}
+void k_precond(const PgoDev& D, hipStream_t s)
+{
+    hipLaunchKernelGGL(precond_kernel, dim3((D.nb + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D);
+}
+int k_pcg_init(const PgoDev& D, hipStream_t s)
+{
+    const int g = grid_for(D.nb, kBlk / 6, kMaxPartials);
+    hipLaunchKernelGGL(pcg_init_kernel, dim3(g), dim3(kBlk), 0, s, D);
+    return g;
+}
+void k_pcg_p(const PgoDev& D, int n_part, int first, double tol2, hipStream_t s)
+{
+    const int g = grid_for(D.nb * 6, kBlk, 512);
+    hipLaunchKernelGGL(pcg_p_kernel, dim3(g), dim3(kBlk), 0, s, D, n_part, first, tol2);
+}
+int k_pcg_spmv(const PgoDev& D, hipStream_t s)
+{
+    const int g = grid_for(D.nb, kBlk / 64, kMaxPartials);
+    hipLaunchKernelGGL(pcg_spmv_kernel, dim3(g), dim3(kBlk), 0, s, D);
+    return g;
+}
+int k_pcg_update(const PgoDev& D, int n_part, hipStream_t s)
+{
+    const int g = grid_for(D.nb, kBlk / 6, kMaxPartials);
+    hipLaunchKernelGGL(pcg_update_kernel, dim3(g), dim3(kBlk), 0, s, D, n_part);
+    return g;
+}
+int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s)
+{
+    const int g = grid_for(D.n, kBlk, kMaxPartials);
+    hipLaunchKernelGGL(oplus_kernel, dim3(g), dim3(kBlk), 0, s, D, pose_in, pose_out);
+    return g;
+}
+void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s)
+{
+    if (D.e > 0) hipLaunchKernelGGL(edge_error_kernel, dim3((D.e + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, pose, err);
+}
+void k_poses_out(const double* pose, int n, double* out12, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(poses_out_kernel, dim3((n + kBlk - 1) / kBlk), dim3(kBlk), 0, s, pose, n, out12);
+}
+
+}  // namespace uzl

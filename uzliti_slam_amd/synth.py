@@ -118,12 +118,14 @@ def make_pose_graph(n_nodes, n_edges, seed=12345, outlier_frac=0.05):
     odom_info[3:, 3:] = np.eye(3) / (0.02 ** 2 * 0.05 ** 2)
 
     # --- loop closures: pairs within 1.5 m and |i-j| > 20
-    cand = _close_pairs(gt[:, :, 3], 1.5, 20)
+    cand = _close_pairs(gt[:, :, 3], 1.5, 20) if n_loop > 0 else np.zeros((0, 2), np.int64)
     radius = 1.5
     while len(cand) < n_loop and radius < 50:
         radius *= 1.5
         cand = _close_pairs(gt[:, :, 3], radius, 20 if N > 40 else 1)
-    if len(cand) >= n_loop:
+    if n_loop == 0:
+        sel = np.zeros(0, np.int64)
+    elif len(cand) >= n_loop:
         sel = rng.choice(len(cand), size=n_loop, replace=False)
     else:                                    # tiny graphs: allow multi-edges
         sel = rng.choice(len(cand), size=n_loop, replace=True)
