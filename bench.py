@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X back end (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+Primary metric   : SE(3) edges optimised / s   on BASELINE config 2 (1k nodes / 5k edges, 20 LM iterations)
+Secondary metric : node pairs matched / s      on BASELINE config 3 (512 pairs x 1000 ORB-256, 500 hypotheses)
+
+A "step" is one pass of the hot path over one batch with the inputs already resident in HBM:
+  primary   step = uzl_pgo_reset + uzl_pgo_optimize(20)   (graph resident, poses restored on the device)
+  secondary step = uzl_match_estimate over the resident frames of 512 node pairs
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank solves its own
+independent graph / its own shard of node pairs: the path partitions into independent units, so there is no
+data-path collective and scaling is weak; torch.distributed is used only for the barrier and the
+max-over-ranks of the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_GOPS = 256 * 4 * 32 * 2.4   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz = 78 643 G lane-ops/s (32-bit VALU)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nodes", type=int, default=1000)
+    ap.add_argument("--edges", type=int, default=5000)
+    ap.add_argument("--lm-iters", type=int, default=20)
+    ap.add_argument("--pairs", type=int, default=512)
+    ap.add_argument("--keypoints", type=int, default=1000)
+    ap.add_argument("--hypotheses", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU-baseline sample")
+    return ap.parse_args()
+
+
+class Dist:
+    """barrier + max-reduce over ranks; a no-op at world size 1 (then torch is never imported)."""
+
+    def __init__(self, n_gpus):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.torch = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            self.torch = torch
+            self.dist = dist
+        if self.world != max(n_gpus, 1):
+            if self.rank == 0:
+                print(f"[bench] --gpus {n_gpus} but WORLD_SIZE={self.world}: using WORLD_SIZE", file=sys.stderr)
+
+    def sync(self):
+        if self.torch is not None:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.torch is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max(self, v):
+        if self.torch is None:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, v):
+        if self.torch is None:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.torch is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(dist, fn, steps):
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    dist.sync()
+    dt = time.perf_counter() - t0
+    dist.barrier()
+    return dist.max(dt)
+
+
+def main():
+    a = parse()
+    dist = Dist(a.gpus)
+    from uzliti_slam_amd import capi, synth
+    capi.lib()
+    dev = dist.local_rank
+
+    # ------------------------------------------------------------------ primary: pose-graph solve
+    g = synth.make_pose_graph(a.nodes, a.edges, seed=12345 + dist.rank)     # one independent graph per rank
+    pgo = capi.Pgo(device=dev, iterations=a.lm_iters)
+    pgo.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])            # H2D once, outside the timed region
+    work = {"edges": 0, "pcg": 0, "trials": 0}
+
+    def pgo_step():
+        pgo.reset()
+        st = pgo.optimize(a.lm_iters)
+        work["edges"] += st["n_edges"] * st["iterations_done"]
+        work["pcg"] += st["pcg_iterations"]; work["trials"] += st["lm_trials"]
+        work["last"] = st
+
+    for _ in range(a.warmup):
+        pgo_step()
+    work.update(edges=0, pcg=0, trials=0)
+    t_pgo = timed(dist, pgo_step, a.steps)
+    edges_total = dist.sum(float(work["edges"]))
+    value = edges_total / t_pgo
+    st = work["last"]
+
+    # roofline of the dominant kernel (PCG SpMV), measured live with HIP events on the solver's stream
+    pgo.set_profiling(True)
+    pgo.reset(); pgo.optimize(a.lm_iters)
+    kt = pgo.kernel_times()
+    pgo.set_profiling(False)
+    spmv = kt.get("pcg_spmv", dict(ms=0.0, launches=1))
+    spmv_us = 1e3 * spmv["ms"] / max(spmv["launches"], 1)
+    nb = st["n_vertices"] - int(pgo.get_fixed().sum())
+    alg_bytes = 288.0 * (nb + st["n_edges"]) + 96.0 * nb        # H once (symmetric) + read p + write Ap  
+    achieved = alg_bytes / (spmv_us * 1e-6) / 1e9 if spmv_us > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("pcg_spmv_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = dict(kernel="pcg_spmv_kernel", bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                    algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(spmv_us, 3), launches=spmv["launches"],
+                    note="working set (H = %.1f MB) is L2/Infinity-Cache resident; launch-latency bound at this size"
+                         % (288e-6 * (nb + 2 * st["n_edges"])))
+    kernels_ms = {k: round(v["ms"], 4) for k, v in sorted(kt.items(), key=lambda x: -x[1]["ms"])}
+
+    # ------------------------------------------------------------------ secondary: match + RANSAC
+    secondary = None
+    matcher = None
+    if not a.no_secondary:
+        per_rank = a.pairs                                                     # weak scaling: fixed work per GPU
+        pairs = synth.make_pairs(per_rank, n_kp=a.keypoints, desc_bytes=32, seed=777 + dist.rank)
+        matcher = capi.Match(device=dev, ransac_threshold=0.1, ransac_iteration=a.hypotheses,
+                             ransac_break_percentage=1.0, do_prosac=1, seed=777)
+        ids = []
+        for f, t, _ in pairs:
+            ids.append((matcher.add_frame(f["desc"], f["pos"], f["valid"]), matcher.add_frame(t["desc"], t["pos"], t["valid"])))
+        jobs, fids = capi.Match._jobs(ids, None)
+        res = np.zeros(per_rank, capi.EDGE_RESULT_DTYPE)
+
+        def match_step():
+            matcher.launch_raw(jobs, fids)
+            matcher.collect(res)
+
+        for _ in range(a.warmup):
+            match_step()
+        t_match = timed(dist, match_step, a.steps)
+        pairs_total = dist.sum(float(per_rank * a.steps))
+        matcher.set_profiling(True)
+        match_step()
+        mk = matcher.kernel_times()
+        matcher.set_profiling(False)
+        knn_ms = mk.get("knn2", dict(ms=0.0))["ms"]
+        word_ops = 2.0 * per_rank * a.keypoints * a.keypoints * 8          # xor + popcount-accumulate per 32-bit word
+        ach = word_ops / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
+        secondary = dict(metric="node-pairs matched/sec", value=round(pairs_total / t_match, 1), unit="pairs/s",
+                         ms_per_step=round(1e3 * t_match / a.steps, 4),
+                         config=dict(workload="BASELINE config 3: %d node pairs x %d ORB-256 descriptors per frame, "
+                                              "2-NN Hamming + %d-hypothesis PROSAC, early exit off" % (per_rank, a.keypoints, a.hypotheses)),
+                         mean_consensus=float(res["consensus"].mean()), ok_fraction=float(res["ok"].mean()),
+                         kernels_ms={k: round(v["ms"], 4) for k, v in mk.items()},
+                         roofline=dict(kernel="knn2_kernel<8>", bound="valu", achieved=round(ach, 1), peak=round(VALU_PEAK_GOPS, 1),
+                                       unit="G lane-ops/s (v_xor_b32 + v_bcnt_u32_b32)", frac=round(ach / VALU_PEAK_GOPS, 4),
+                                       traffic=None, note="integer VALU bound, not HBM/MFMA: 64 KB of descriptors feed 1.6e7 word-ops per pair"))
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    cpu = None
+    if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline:
+        import oracle as O
+        fl = O.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+        fixed, _ = O.set_fixed_nodes(fl["fixed"], fl["ij"])
+        t0 = time.perf_counter(); n_solves = 0; cpu_edges = 0
+        while True:
+            _, so = O.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=a.lm_iters)
+            n_solves += 1; cpu_edges += so["n_edges"] * so["iterations_done"]
+            if time.perf_counter() - t0 > a.cpu_seconds or n_solves >= 64:
+                break
+        dt = time.perf_counter() - t0
+        cpu = dict(value=round(cpu_edges / dt, 1), unit="edges/s", cores=1, kind="port",
+                   sample="%d solve(s) of the same %d-node/%d-edge graph, %d LM iterations each, %.1f s; "
+                          "oracle = C restatement of g2o LM + block sparse direct Cholesky (reference binaries not buildable here)"
+                          % (n_solves, a.nodes, a.edges, a.lm_iters, dt),
+                   host_cpus=os.cpu_count())
+        if secondary is not None:
+            n_cpu_pairs = 0; t0 = time.perf_counter()
+            for f, t, _ in pairs[:64]:
+                O.estimate_edge([f], [t], ransac_threshold=0.1, ransac_iteration=a.hypotheses, break_percentage=1.0,
+                                do_prosac=True, seed=777, job_id=n_cpu_pairs)
+                n_cpu_pairs += 1
+                if time.perf_counter() - t0 > a.cpu_seconds:
+                    break
+            dtm = time.perf_counter() - t0
+            secondary["cpu_baseline"] = dict(value=round(n_cpu_pairs / dtm, 2), unit="pairs/s", cores=1, kind="port",
+                                             sample="%d of the same node pairs, %.1f s" % (n_cpu_pairs, dtm))
+
+    if dist.rank == 0:
+        out = dict(
+            metric="SE(3) edges optimized/sec (node-pairs matched/sec in `secondary`)",
+            value=round(value, 1), unit="edges/s", n_gpus=dist.world, steps=a.steps, warmup=a.warmup,
+            ms_per_step=round(1e3 * t_pgo / a.steps, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+            dtype="f64", data="synthetic",
+            config=dict(workload="BASELINE config 2: %d-node / %d-edge SE(3) pose graph, %d LM iterations, Huber(1) on loop closures; "
+                                 "one independent graph per GPU" % (a.nodes, a.edges, a.lm_iters),
+                        system_edges=st["n_edges"], lm_iterations_done=st["iterations_done"], lm_trials_per_solve=st["lm_trials"],
+                        pcg_iterations_per_solve=st["pcg_iterations"], pcg_tol=pgo.cfg.pcg_tol, preconditioner=("additive multilevel, 8-vertex rigid-body aggregates" if pgo.cfg.preconditioner else "block-Jacobi"),
+                        chi2_initial=st["chi2_initial"], chi2_final=st["chi2_final"]),
+            roofline=roofline, kernels_ms_per_solve=kernels_ms, cpu_baseline=cpu, secondary=secondary)
+        print(json.dumps(out))
+    pgo.close()
+    if matcher is not None:
+        matcher.close()
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -213,6 +213,7 @@ typedef struct uzl_pgo_cfg {
     int32_t pcg_max_iter;             /* per linear solve                                             */
     double  huber_delta;              /* 1.0  (g2o_optimizer.cpp:293)                                 */
     int32_t verbose;
+    int32_t preconditioner;           /* 1 = additive multilevel (8-vertex aggregates, rigid-body modes), 0 = block-Jacobi */
 } uzl_pgo_cfg;
 
 /* SlamNode as the optimizer sees it (slam_node.h:89-107). Array order = std::map iteration order
@@ -276,6 +277,11 @@ int  uzl_pgo_add_graph(uzl_pgo* h,
 int  uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t* fixed,
                        int32_t e, const int32_t* ij, const double* meas, const double* info,
                        const uint8_t* robust);
+
+/* Restore the vertex estimates to what the last add_graph/set_graph left (device-to-device copy):
+ * the reference gets the same effect by calling addGraphImpl again (full rebuild, :57); with the
+ * graph resident in HBM a repeated solve does not need the upload. */
+int  uzl_pgo_reset(uzl_pgo* h);
 
 /* G2oOptimizer::optimizeImpl (g2o_optimizer.cpp:137-149): initializeOptimization, setFixedNodes
  * (:301-349) and optimize(iterations).  iterations <= 0 uses cfg.iterations.  Blocks. */

@@ -154,6 +154,45 @@ def test_set_graph_flat_entry(pgo, oracle):
     assert used.all()
 
 
+def test_block_jacobi_and_multilevel_agree(capi, oracle):
+    """The preconditioner only changes how fast PCG converges, never what it converges to."""
+    g = synth.make_pose_graph(400, 1800, seed=21)
+    out = []
+    for pre in (0, 1):
+        p = capi.Pgo(preconditioner=pre)
+        p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+        st = p.optimize(10)
+        poses, _, _ = p.store()
+        out.append((poses, st))
+        p.close()
+    dt, dr = synth.pose_errors(out[0][0].reshape(-1, 3, 4), out[1][0].reshape(-1, 3, 4))
+    assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+    assert out[1][1]["pcg_iterations"] < 0.5 * out[0][1]["pcg_iterations"], (out[0][1]["pcg_iterations"], out[1][1]["pcg_iterations"])
+    fl = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, _ = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=10)
+    for poses, _ in out:
+        dt, dr = synth.pose_errors(poses.reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+        assert dt < TOL_T and dr < TOL_R
+
+
+@pytest.mark.parametrize("n,e", [(9, 20), (17, 40), (64, 200), (65, 200), (513, 2000)])
+def test_multilevel_hierarchy_edge_sizes(capi, oracle, n, e):
+    """aggregate boundaries: 8^k and 8^k + 1 vertices, partially filled last aggregates."""
+    g = synth.make_pose_graph(n, e, seed=n)
+    p = capi.Pgo()
+    p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    st = p.optimize(8)
+    poses, _, _ = p.store()
+    p.close()
+    assert st["status"] == 0
+    fl = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, _ = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=8)
+    dt, dr = synth.pose_errors(poses.reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+    assert dt < TOL_T and dr < TOL_R, (dt, dr)
+
+
 def test_degenerate_inputs(capi, pgo):
     pgo.set_config(optimize_xy_only=0)
     g = synth.make_pose_graph(20, 40, seed=8)

@@ -71,7 +71,7 @@ PAIR_JOB_DTYPE = np.dtype([("job_id", "<u8"), ("from_begin", "<i4"), ("from_coun
 class PgoCfg(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("use_odometry_parameters", C.c_int32),
                 ("optimize_xy_only", C.c_int32), ("device", C.c_int32), ("pcg_tol", C.c_double),
-                ("pcg_max_iter", C.c_int32), ("huber_delta", C.c_double), ("verbose", C.c_int32)]
+                ("pcg_max_iter", C.c_int32), ("huber_delta", C.c_double), ("verbose", C.c_int32), ("preconditioner", C.c_int32)]
 
 
 class PgoStats(C.Structure):
@@ -328,6 +328,9 @@ class Pgo:
                                             C.c_int32(ijc.shape[0]), _p(ijc, c_i32p), _p(Z, c_f64p), _p(Om, c_f64p),
                                             _p(rb, c_u8p)))
         self.n = P.shape[0]; self.e_in = ijc.shape[0]
+
+    def reset(self):
+        self._check(lib().uzl_pgo_reset(self._h))
 
     def optimize(self, iterations=0):
         st = PgoStats()

@@ -1,0 +1,213 @@
+// pgo_device.hpp — device-side helpers shared by the pose-graph kernel files (small fixed-size algebra,
+// deterministic reductions).  Everything is __forceinline__ and register resident.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "pgo_types.hpp"
+
+namespace uzl {
+
+constexpr int kBlk = 256;
+
+// ------------------------------------------------------------------------------------------------
+// small fixed-size algebra (everything stays in registers; indices are compile-time constants)
+// ------------------------------------------------------------------------------------------------
+struct Q4 { double w, x, y, z; };
+struct V3 { double x, y, z; };
+struct M33 { double m[9]; };
+
+__device__ __forceinline__ Q4 qmul(const Q4& a, const Q4& b)
+{
+    return Q4{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+              a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+              a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+              a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Q4 qconj(const Q4& a) { return Q4{a.w, -a.x, -a.y, -a.z}; }
+__device__ __forceinline__ Q4 qnormalize(const Q4& a)
+{
+    const double n = 1.0 / sqrt(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z);
+    return Q4{a.w * n, a.x * n, a.y * n, a.z * n};
+}
+// Eigen::Quaterniond::toRotationMatrix [EXT]
+__device__ __forceinline__ M33 qrot(const Q4& q)
+{
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    M33 R;
+    R.m[0] = 1 - (tyy + tzz); R.m[1] = txy - twz;       R.m[2] = txz + twy;
+    R.m[3] = txy + twz;       R.m[4] = 1 - (txx + tzz); R.m[5] = tyz - twx;
+    R.m[6] = txz - twy;       R.m[7] = tyz + twx;       R.m[8] = 1 - (txx + tyy);
+    return R;
+}
+__device__ __forceinline__ V3 mulv(const M33& R, const V3& v)
+{
+    return V3{R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z,
+              R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+              R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};
+}
+__device__ __forceinline__ V3 mulTv(const M33& R, const V3& v)
+{
+    return V3{R.m[0] * v.x + R.m[3] * v.y + R.m[6] * v.z,
+              R.m[1] * v.x + R.m[4] * v.y + R.m[7] * v.z,
+              R.m[2] * v.x + R.m[5] * v.y + R.m[8] * v.z};
+}
+// Eigen::Quaterniond(Matrix3d) [EXT]; m row-major
+__device__ __forceinline__ Q4 quat_from_R(const double* m)
+{
+    Q4 q;
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.) {
+        t = sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
+    } else if (m[0] >= m[4] && m[0] >= m[8]) {            // i = 0
+        t = sqrt(m[0] - m[4] - m[8] + 1.0);
+        q.x = 0.5 * t; t = 0.5 / t;
+        q.w = (m[7] - m[5]) * t; q.y = (m[3] + m[1]) * t; q.z = (m[6] + m[2]) * t;
+    } else if (m[4] > m[0] && m[4] >= m[8]) {             // i = 1
+        t = sqrt(m[4] - m[8] - m[0] + 1.0);
+        q.y = 0.5 * t; t = 0.5 / t;
+        q.w = (m[2] - m[6]) * t; q.z = (m[7] + m[5]) * t; q.x = (m[1] + m[3]) * t;
+    } else {                                               // i = 2
+        t = sqrt(m[8] - m[0] - m[4] + 1.0);
+        q.z = 0.5 * t; t = 0.5 / t;
+        q.w = (m[3] - m[1]) * t; q.x = (m[2] + m[6]) * t; q.y = (m[5] + m[7]) * t;
+    }
+    return q;
+}
+
+struct Pose { V3 t; Q4 q; };
+__device__ __forceinline__ Pose load_pose(const double* __restrict__ p, int v)
+{
+    const double2* q = reinterpret_cast<const double2*>(p + (size_t)v * 8);
+    const double2 a = q[0], b = q[1], c = q[2], d = q[3];
+    return Pose{V3{a.x, a.y, b.x}, Q4{b.y, c.x, c.y, d.x}};
+}
+__device__ __forceinline__ void store_pose(double* __restrict__ p, int v, const Pose& P)
+{
+    double2* q = reinterpret_cast<double2*>(p + (size_t)v * 8);
+    q[0] = make_double2(P.t.x, P.t.y); q[1] = make_double2(P.t.z, P.q.w);
+    q[2] = make_double2(P.q.x, P.q.y); q[3] = make_double2(P.q.z, 0.);
+}
+// 3x4 row-major [R|t] -> Pose (unit quaternion)
+__device__ __forceinline__ Pose pose_from_T(const double* T)
+{
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    return Pose{V3{T[3], T[7], T[11]}, qnormalize(quat_from_R(R))};
+}
+__device__ __forceinline__ void T_from_pose(const Pose& P, double* T)
+{
+    const M33 R = qrot(P.q);
+    T[0] = R.m[0]; T[1] = R.m[1]; T[2] = R.m[2]; T[3] = P.t.x;
+    T[4] = R.m[3]; T[5] = R.m[4]; T[6] = R.m[5]; T[7] = P.t.y;
+    T[8] = R.m[6]; T[9] = R.m[7]; T[10] = R.m[8]; T[11] = P.t.z;
+}
+__device__ __forceinline__ Pose pose_mul(const Pose& A, const Pose& B)
+{
+    const V3 rb = mulv(qrot(A.q), B.t);
+    return Pose{V3{rb.x + A.t.x, rb.y + A.t.y, rb.z + A.t.z}, qnormalize(qmul(A.q, B.q))};
+}
+__device__ __forceinline__ Pose pose_inv(const Pose& A)
+{
+    const V3 t = mulTv(qrot(A.q), A.t);
+    return Pose{V3{-t.x, -t.y, -t.z}, qconj(A.q)};
+}
+// optimize_xy_only: zero roll, pitch, z through toEuler/fromEuler
+// (g2o_optimizer.cpp:164-170, isometry3d_mappings.cpp:47-75)
+__device__ __forceinline__ Pose project_xy(const Pose& P)
+{
+    // toEuler takes Quaterniond(R) un-normalised; P.q is the normalised quaternion of the same R
+    const double q0 = P.q.w, q1 = P.q.x, q2 = P.q.y, q3 = P.q.z;
+    const double yaw = atan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 * q2 + q3 * q3));
+    const double sy = sin(yaw * 0.5), cy = cos(yaw * 0.5);
+    return Pose{V3{P.t.x, P.t.y, 0.}, Q4{cy, 0., 0., sy}};
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions (deterministic: fixed tree shapes, no atomics)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// all threads get the block total (blockDim = 256)
+__device__ __forceinline__ double block_sum(double v, double* s4)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+__device__ __forceinline__ double block_max(double v, double* s4)
+{
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
+}
+// every block re-reduces the (<= 1024) partials of the previous kernel: same order everywhere
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int count, double* s4)
+{
+    double v = 0.;
+    for (int i = threadIdx.x; i < count; i += kBlk) v += part[i];
+    return block_sum(v, s4);
+}
+
+// inverse of a symmetric positive definite 6x6 (row-major) through its Cholesky factor
+__device__ __forceinline__ void spd_inverse6(double* A, double* out)
+{
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[j * 6 + k] * A[j * 6 + k];
+        d = sqrt(fmax(d, 1e-300));
+        A[j * 6 + j] = d;
+        const double inv = 1. / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s * inv;
+        }
+    }
+    double Li[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) Li[i] = 0.;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+#pragma unroll
+        for (int r = c; r < 6; r++) {
+            double s = (r == c) ? 1. : 0.;
+#pragma unroll
+            for (int k = c; k < r; k++) s -= A[r * 6 + k] * Li[k * 6 + c];
+            Li[r * 6 + c] = s / A[r * 6 + r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            double s = 0.;
+#pragma unroll
+            for (int k = (r > c ? r : c); k < 6; k++) s += Li[k * 6 + r] * Li[k * 6 + c];
+            out[r * 6 + c] = s;
+        }
+}
+
+}  // namespace uzl

@@ -9,171 +9,9 @@
 // Poses live as (t, unit quaternion): the error e = toVectorMQT(Z^-1 Xi^-1 Xj)
 // (graph_slam_common/thirdparty/src/isometry3d_mappings.cpp:94-99) is then pure quaternion algebra
 // with no matrix->quaternion branches in the hot loop.
-#include <hip/hip_runtime.h>
-#include <cstdint>
-#include "pgo_types.hpp"
+#include "pgo_device.hpp"
 
 namespace uzl {
-
-constexpr int kBlk = 256;
-
-// ------------------------------------------------------------------------------------------------
-// small fixed-size algebra (everything stays in registers; indices are compile-time constants)
-// ------------------------------------------------------------------------------------------------
-struct Q4 { double w, x, y, z; };
-struct V3 { double x, y, z; };
-struct M33 { double m[9]; };
-
-__device__ __forceinline__ Q4 qmul(const Q4& a, const Q4& b)
-{
-    return Q4{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
-              a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
-              a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
-              a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
-}
-__device__ __forceinline__ Q4 qconj(const Q4& a) { return Q4{a.w, -a.x, -a.y, -a.z}; }
-__device__ __forceinline__ Q4 qnormalize(const Q4& a)
-{
-    const double n = 1.0 / sqrt(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z);
-    return Q4{a.w * n, a.x * n, a.y * n, a.z * n};
-}
-// Eigen::Quaterniond::toRotationMatrix [EXT]
-__device__ __forceinline__ M33 qrot(const Q4& q)
-{
-    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
-    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
-    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
-    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
-    M33 R;
-    R.m[0] = 1 - (tyy + tzz); R.m[1] = txy - twz;       R.m[2] = txz + twy;
-    R.m[3] = txy + twz;       R.m[4] = 1 - (txx + tzz); R.m[5] = tyz - twx;
-    R.m[6] = txz - twy;       R.m[7] = tyz + twx;       R.m[8] = 1 - (txx + tyy);
-    return R;
-}
-__device__ __forceinline__ V3 mulv(const M33& R, const V3& v)
-{
-    return V3{R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z,
-              R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
-              R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};
-}
-__device__ __forceinline__ V3 mulTv(const M33& R, const V3& v)
-{
-    return V3{R.m[0] * v.x + R.m[3] * v.y + R.m[6] * v.z,
-              R.m[1] * v.x + R.m[4] * v.y + R.m[7] * v.z,
-              R.m[2] * v.x + R.m[5] * v.y + R.m[8] * v.z};
-}
-// Eigen::Quaterniond(Matrix3d) [EXT]; m row-major
-__device__ __forceinline__ Q4 quat_from_R(const double* m)
-{
-    Q4 q;
-    double t = m[0] + m[4] + m[8];
-    if (t > 0.) {
-        t = sqrt(t + 1.0);
-        q.w = 0.5 * t;
-        t = 0.5 / t;
-        q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
-    } else if (m[0] >= m[4] && m[0] >= m[8]) {            // i = 0
-        t = sqrt(m[0] - m[4] - m[8] + 1.0);
-        q.x = 0.5 * t; t = 0.5 / t;
-        q.w = (m[7] - m[5]) * t; q.y = (m[3] + m[1]) * t; q.z = (m[6] + m[2]) * t;
-    } else if (m[4] > m[0] && m[4] >= m[8]) {             // i = 1
-        t = sqrt(m[4] - m[8] - m[0] + 1.0);
-        q.y = 0.5 * t; t = 0.5 / t;
-        q.w = (m[2] - m[6]) * t; q.z = (m[7] + m[5]) * t; q.x = (m[1] + m[3]) * t;
-    } else {                                               // i = 2
-        t = sqrt(m[8] - m[0] - m[4] + 1.0);
-        q.z = 0.5 * t; t = 0.5 / t;
-        q.w = (m[3] - m[1]) * t; q.x = (m[2] + m[6]) * t; q.y = (m[5] + m[7]) * t;
-    }
-    return q;
-}
-
-struct Pose { V3 t; Q4 q; };
-__device__ __forceinline__ Pose load_pose(const double* __restrict__ p, int v)
-{
-    const double2* q = reinterpret_cast<const double2*>(p + (size_t)v * 8);
-    const double2 a = q[0], b = q[1], c = q[2], d = q[3];
-    return Pose{V3{a.x, a.y, b.x}, Q4{b.y, c.x, c.y, d.x}};
-}
-__device__ __forceinline__ void store_pose(double* __restrict__ p, int v, const Pose& P)
-{
-    double2* q = reinterpret_cast<double2*>(p + (size_t)v * 8);
-    q[0] = make_double2(P.t.x, P.t.y); q[1] = make_double2(P.t.z, P.q.w);
-    q[2] = make_double2(P.q.x, P.q.y); q[3] = make_double2(P.q.z, 0.);
-}
-// 3x4 row-major [R|t] -> Pose (unit quaternion)
-__device__ __forceinline__ Pose pose_from_T(const double* T)
-{
-    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
-    return Pose{V3{T[3], T[7], T[11]}, qnormalize(quat_from_R(R))};
-}
-__device__ __forceinline__ void T_from_pose(const Pose& P, double* T)
-{
-    const M33 R = qrot(P.q);
-    T[0] = R.m[0]; T[1] = R.m[1]; T[2] = R.m[2]; T[3] = P.t.x;
-    T[4] = R.m[3]; T[5] = R.m[4]; T[6] = R.m[5]; T[7] = P.t.y;
-    T[8] = R.m[6]; T[9] = R.m[7]; T[10] = R.m[8]; T[11] = P.t.z;
-}
-__device__ __forceinline__ Pose pose_mul(const Pose& A, const Pose& B)
-{
-    const V3 rb = mulv(qrot(A.q), B.t);
-    return Pose{V3{rb.x + A.t.x, rb.y + A.t.y, rb.z + A.t.z}, qnormalize(qmul(A.q, B.q))};
-}
-__device__ __forceinline__ Pose pose_inv(const Pose& A)
-{
-    const V3 t = mulTv(qrot(A.q), A.t);
-    return Pose{V3{-t.x, -t.y, -t.z}, qconj(A.q)};
-}
-// optimize_xy_only: zero roll, pitch, z through toEuler/fromEuler
-// (g2o_optimizer.cpp:164-170, isometry3d_mappings.cpp:47-75)
-__device__ __forceinline__ Pose project_xy(const Pose& P)
-{
-    // toEuler takes Quaterniond(R) un-normalised; P.q is the normalised quaternion of the same R
-    const double q0 = P.q.w, q1 = P.q.x, q2 = P.q.y, q3 = P.q.z;
-    const double yaw = atan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 * q2 + q3 * q3));
-    const double sy = sin(yaw * 0.5), cy = cos(yaw * 0.5);
-    return Pose{V3{P.t.x, P.t.y, 0.}, Q4{cy, 0., 0., sy}};
-}
-
-// ------------------------------------------------------------------------------------------------
-// reductions (deterministic: fixed tree shapes, no atomics)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
-// all threads get the block total (blockDim = 256)
-__device__ __forceinline__ double block_sum(double v, double* s4)
-{
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
-}
-__device__ __forceinline__ double block_max(double v, double* s4)
-{
-    v = wave_max(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
-}
-// every block re-reduces the (<= 1024) partials of the previous kernel: same order everywhere
-__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int count, double* s4)
-{
-    double v = 0.;
-    for (int i = threadIdx.x; i < count; i += kBlk) v += part[i];
-    return block_sum(v, s4);
-}
 
 // ------------------------------------------------------------------------------------------------
 // G1  graph flattening on the device
@@ -558,51 +396,23 @@ __global__ __launch_bounds__(kBlk) void precond_kernel(PgoDev D)
     double A[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) A[i] = D.hdiag[(size_t)a * 36 + i] + ((i % 7 == 0) ? lambda : 0.);
-    // lower Cholesky A = L L^T (in place, lower part)
+    double out[36];
+    spd_inverse6(A, out);
+    double* __restrict__ dst = D.minv + (size_t)a * 36;
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        double d = A[j * 6 + j];
-#pragma unroll
-        for (int k = 0; k < j; k++) d -= A[j * 6 + k] * A[j * 6 + k];
-        d = sqrt(fmax(d, 1e-300));
-        A[j * 6 + j] = d;
-        const double inv = 1. / d;
-#pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-            double s = A[i * 6 + j];
-#pragma unroll
-            for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k];
-            A[i * 6 + j] = s * inv;
-        }
-    }
-    // Linv (lower) by forward substitution, then Minv = Linv^T Linv
-    double Li[36];
-#pragma unroll
-    for (int i = 0; i < 36; i++) Li[i] = 0.;
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-#pragma unroll
-        for (int r = c; r < 6; r++) {
-            double s = (r == c) ? 1. : 0.;
-#pragma unroll
-            for (int k = c; k < r; k++) s -= A[r * 6 + k] * Li[k * 6 + c];
-            Li[r * 6 + c] = s / A[r * 6 + r];
-        }
-    }
-    double* __restrict__ out = D.minv + (size_t)a * 36;
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            double s = 0.;
-#pragma unroll
-            for (int k = (r > c ? r : c); k < 6; k++) s += Li[k * 6 + r] * Li[k * 6 + c];
-            out[r * 6 + c] = s;
-        }
+    for (int i = 0; i < 36; i++) dst[i] = out[i];
 }
 
-// x = 0, r = b, z = Minv r; partials of r.z -> part_b
-__global__ __launch_bounds__(kBlk) void pcg_init_kernel(PgoDev D)
+// PCG with two launches per iteration and no grid barrier.  Scalars never cross a launch as "the value
+// computed by one block": every block re-reduces the previous launch's block partials in the same order.
+//   pcg_init   : x = 0, r = b, z = M^-1 r, p0 = p1 = 0; partials of r.z -> part_b; flags cleared
+//   pcg_spmv   : rz = sum(part_b); beta = rz / rz_prev (0 in iteration 0); p_new = z + beta p_old for the own
+//                row AND, recomputed on the fly, for every neighbour column (so p never needs a launch of its
+//                own); Ap = (H + lambda I) p_new; partials of p.Ap -> part_a; block 0: rz -> scal[0], stop test
+//   pcg_update : alpha = rz / sum(part_a); x += alpha p; r -= alpha Ap; z = M^-1 r; partials of r.z -> part_b;
+//                block 0: rz_prev = rz, ++iteration
+// p is double-buffered (p_old read, p_new written) because neighbours read p_old while rows write p_new.
+__global__ __launch_bounds__(kBlk) void pcg_init_kernel(PgoDev D, double* __restrict__ p0, double* __restrict__ p1)
 {
     __shared__ double s4[4];
     __shared__ double sv[kBlk];
@@ -622,47 +432,29 @@ __global__ __launch_bounds__(kBlk) void pcg_init_kernel(PgoDev D)
             double zz = 0.;
 #pragma unroll
             for (int c = 0; c < 6; c++) zz += m[c] * sv[g0 + c];
-            D.x[(size_t)a * 6 + r] = 0.;
-            D.r[(size_t)a * 6 + r] = rv;
-            D.z[(size_t)a * 6 + r] = zz;
+            const size_t i = (size_t)a * 6 + r;
+            D.x[i] = 0.; D.r[i] = rv; D.z[i] = zz; p0[i] = 0.; p1[i] = 0.;
             acc += rv * zz;
         }
     }
     const double tot = block_sum(acc, s4);
-    if (threadIdx.x == 0) D.part_b[blockIdx.x] = tot;
-}
-
-// first = 1: rz0 = sum(part_b); p = z; thresholds.   first = 0: beta = rz_new / rz_prev; p = z + beta p.
-__global__ __launch_bounds__(kBlk) void pcg_p_kernel(PgoDev D, int n_part, int first, double tol2)
-{
-    __shared__ double s4[4];
-    if (!first && D.flags[0]) return;
-    const double rz_new = sum_partials(D.part_b, n_part, s4);
-    double beta = 0.;
-    if (!first) { const double rz_prev = D.scal[2]; beta = (rz_prev > 0.) ? rz_new / rz_prev : 0.; }
-    const int tot = D.nb * 6;
-    for (int i = blockIdx.x * kBlk + threadIdx.x; i < tot; i += gridDim.x * kBlk)
-        D.p[i] = first ? D.z[i] : D.z[i] + beta * D.p[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        D.scal[0] = rz_new;
-        if (first) {
-            D.scal[1] = tol2 * rz_new;
-            D.flags[0] = (rz_new <= 0.) ? 1 : 0;
-            D.flags[1] = 0;
-            D.flags[2] = 0;
-        } else {
-            D.flags[1] += 1;
-            if (rz_new <= D.scal[1]) D.flags[0] = 1;
-        }
+    if (threadIdx.x == 0) {
+        D.part_b[blockIdx.x] = tot;
+        if (blockIdx.x == 0) { D.flags[0] = 0; D.flags[1] = 0; D.flags[2] = 0; D.scal[2] = 1.; }
     }
 }
 
-// Ap = (H + lambda I) p.  One wave per row block: 10 slot-groups of 6 lanes walk the row's contiguous
-// slots (lane (g, r) owns row r of slot s0+g+10k), then a shuffle tree folds the groups.
-__global__ __launch_bounds__(kBlk) void pcg_spmv_kernel(PgoDev D)
+// One wave per row block: 10 slot-groups of 6 lanes walk the row's contiguous slots (lane (g, r) owns row r
+// of slot s0+g+10k), then a shuffle tree folds the groups.
+__global__ __launch_bounds__(kBlk) void pcg_spmv_kernel(PgoDev D, const double* __restrict__ p_old,
+                                                        double* __restrict__ p_new, int n_part, double tol2)
 {
     __shared__ double s4[4];
     if (D.flags[0]) return;
+    const int it = D.flags[1];
+    const double rz = sum_partials(D.part_b, n_part, s4);
+    const double beta = (it == 0) ? 0. : rz / D.scal[2];
+    const double thresh = (it == 0) ? tol2 * rz : D.scal[1];
     const double lambda = D.scal[3];
     const int lane = threadIdx.x & 63, g = lane / 6, r = lane % 6;
     const bool act = lane < 60;
@@ -671,23 +463,32 @@ __global__ __launch_bounds__(kBlk) void pcg_spmv_kernel(PgoDev D)
     double dot = 0.;
     for (int a = wave; a < D.nb; a += nwaves) {
         const int s0 = D.row_ptr[a], s1 = D.row_ptr[a + 1];
-        double acc = 0.;
+        double acc = 0., pr = 0.;
         if (g == 0) {
             const double* __restrict__ h = D.hdiag + (size_t)a * 36 + r * 6;
-            const double* __restrict__ pv = D.p + (size_t)a * 6;
+            const double* __restrict__ zv = D.z + (size_t)a * 6;
+            const double* __restrict__ po = p_old + (size_t)a * 6;
 #pragma unroll
-            for (int c = 0; c < 6; c++) acc += h[c] * pv[c];
-            acc += lambda * pv[r];
+            for (int c = 0; c < 6; c++) {
+                const double pc = zv[c] + beta * po[c];
+                acc += h[c] * pc;
+                if (c == r) pr = pc;
+            }
+            acc += lambda * pr;
+            p_new[(size_t)a * 6 + r] = pr;
         }
         if (act) {
             for (int s = s0 + g; s < s1; s += 10) {
                 const int c = D.col[s];
                 if (c >= 0) {
                     const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
-                    const double2* __restrict__ pv = reinterpret_cast<const double2*>(D.p + (size_t)c * 6);
+                    const double2* __restrict__ zv = reinterpret_cast<const double2*>(D.z + (size_t)c * 6);
+                    const double2* __restrict__ po = reinterpret_cast<const double2*>(p_old + (size_t)c * 6);
                     const double2 b0 = bk[0], b1 = bk[1], b2 = bk[2];
-                    const double2 p0 = pv[0], p1 = pv[1], p2 = pv[2];
-                    acc += b0.x * p0.x + b0.y * p0.y + b1.x * p1.x + b1.y * p1.y + b2.x * p2.x + b2.y * p2.y;
+                    const double2 z0 = zv[0], z1 = zv[1], z2 = zv[2];
+                    const double2 o0 = po[0], o1 = po[1], o2 = po[2];
+                    acc += b0.x * (z0.x + beta * o0.x) + b0.y * (z0.y + beta * o0.y) + b1.x * (z1.x + beta * o1.x) +
+                           b1.y * (z1.y + beta * o1.y) + b2.x * (z2.x + beta * o2.x) + b2.y * (z2.y + beta * o2.y);
                 }
             }
         }
@@ -699,15 +500,22 @@ __global__ __launch_bounds__(kBlk) void pcg_spmv_kernel(PgoDev D)
         v = __shfl_down(acc, 6);  if (lane + 6 < 12) acc += v;
         if (lane < 6) {
             D.ap[(size_t)a * 6 + r] = acc;
-            dot += acc * D.p[(size_t)a * 6 + r];
+            dot += acc * pr;
         }
     }
     const double tot = block_sum(dot, s4);
-    if (threadIdx.x == 0) D.part_a[blockIdx.x] = tot;
+    if (threadIdx.x == 0) {
+        D.part_a[blockIdx.x] = tot;
+        if (blockIdx.x == 0) {
+            D.scal[0] = rz;
+            if (it == 0) D.scal[1] = thresh;
+            if (!(rz > thresh) ) D.flags[0] = 1;       // converged (or rz == 0 / NaN): x from the last update is final
+        }
+    }
 }
 
 // alpha = rz / p.Ap; x += alpha p; r -= alpha Ap; z = Minv r; partials of r.z -> part_b
-__global__ __launch_bounds__(kBlk) void pcg_update_kernel(PgoDev D, int n_part)
+__global__ __launch_bounds__(kBlk) void pcg_update_kernel(PgoDev D, const double* __restrict__ p, int n_part)
 {
     __shared__ double s4[4];
     __shared__ double sv[kBlk];
@@ -724,7 +532,7 @@ __global__ __launch_bounds__(kBlk) void pcg_update_kernel(PgoDev D, int n_part)
         double rv = 0.;
         if (act) {
             const size_t i = (size_t)a * 6 + r;
-            D.x[i] += alpha * D.p[i];
+            D.x[i] += alpha * p[i];
             rv = D.r[i] - alpha * D.ap[i];
             D.r[i] = rv;
         }
@@ -745,7 +553,8 @@ __global__ __launch_bounds__(kBlk) void pcg_update_kernel(PgoDev D, int n_part)
     if (threadIdx.x == 0) {
         D.part_b[blockIdx.x] = tot;
         if (blockIdx.x == 0) {
-            D.scal[2] = rz;                          // rz_prev for the next pcg_p (which overwrites scal[0])
+            D.scal[2] = rz;                          // rz_prev for the next pcg_spmv
+            D.flags[1] += 1;
             if (bad) { D.flags[0] = 1; D.flags[2] = 1; }
         }
     }
@@ -834,29 +643,27 @@ void k_precond(const PgoDev& D, hipStream_t s)
 {
     hipLaunchKernelGGL(precond_kernel, dim3((D.nb + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D);
 }
-int k_pcg_init(const PgoDev& D, hipStream_t s)
+int k_pcg_init(const PgoDev& D, double* p0, double* p1, hipStream_t s)
 {
     const int g = grid_for(D.nb, kBlk / 6, kMaxPartials);
-    hipLaunchKernelGGL(pcg_init_kernel, dim3(g), dim3(kBlk), 0, s, D);
+    hipLaunchKernelGGL(pcg_init_kernel, dim3(g), dim3(kBlk), 0, s, D, p0, p1);
     return g;
 }
-void k_pcg_p(const PgoDev& D, int n_part, int first, double tol2, hipStream_t s)
-{
-    const int g = grid_for(D.nb * 6, kBlk, 512);
-    hipLaunchKernelGGL(pcg_p_kernel, dim3(g), dim3(kBlk), 0, s, D, n_part, first, tol2);
-}
-int k_pcg_spmv(const PgoDev& D, hipStream_t s)
+int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s)
 {
     const int g = grid_for(D.nb, kBlk / 64, kMaxPartials);
-    hipLaunchKernelGGL(pcg_spmv_kernel, dim3(g), dim3(kBlk), 0, s, D);
+    hipLaunchKernelGGL(pcg_spmv_kernel, dim3(g), dim3(kBlk), 0, s, D, p_old, p_new, n_part, tol2);
     return g;
 }
-int k_pcg_update(const PgoDev& D, int n_part, hipStream_t s)
+int k_pcg_update(const PgoDev& D, const double* p, int n_part, hipStream_t s)
 {
     const int g = grid_for(D.nb, kBlk / 6, kMaxPartials);
-    hipLaunchKernelGGL(pcg_update_kernel, dim3(g), dim3(kBlk), 0, s, D, n_part);
+    hipLaunchKernelGGL(pcg_update_kernel, dim3(g), dim3(kBlk), 0, s, D, p, n_part);
     return g;
 }
+// grid sizes are pure functions of nb: the host needs them before the first launch (partial counts)
+int g_pcg_spmv(int nb) { return grid_for(nb, kBlk / 64, kMaxPartials); }
+int g_pcg_update(int nb) { return grid_for(nb, kBlk / 6, kMaxPartials); }
 int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s)
 {
     const int g = grid_for(D.n, kBlk, kMaxPartials);

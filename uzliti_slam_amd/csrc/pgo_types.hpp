@@ -15,7 +15,7 @@
 
 namespace uzl {
 
-constexpr int kMaxPartials = 1024;
+constexpr int kMaxPartials = 4096;
 
 struct PgoDev {
     int32_t n, nb, e, nslots;
@@ -48,6 +48,49 @@ struct PgoDev {
     double* part_c;          // [kMaxPartials] block partials (max |H_jj|)
     double* scal;            // [8]: 0 rz, 1 rz threshold, 2 rz_prev, 3 lambda, 4 chi2, 5 scale, 6 diagmax
     int32_t* flags;          // [4]: 0 done, 1 iterations, 2 breakdown
+};
+
+// ---- multilevel preconditioner (aggregation hierarchy with rigid-body-mode coarse spaces) -------------
+// Level 0 = free vertices.  Level l+1 aggregates 8 consecutive level-l entities (index order = time order =
+// the odometry chain), until at most 8 aggregates remain; that top level is solved exactly (dense), every
+// level below contributes its block diagonal (additive multilevel, BPX style):
+//     z = D0^-1 r + P1 ( D1^-1 r1 + P2 ( D2^-1 r2 + ... + P_L A_L^-1 r_L ) ),   r_l = P_l^T r_{l-1}
+// The coarse unknown of an aggregate is a world-frame twist (v, w) about the aggregate's centroid c, the
+// exact null space of a pose graph; for a vertex i (R_i, t_i) in local MQT coordinates
+//     P_i = [[R_i^T, -R_i^T [t_i - c]x], [0, 1/2 R_i^T]],  and between levels  P = [[I, -[c_child - c]x], [0, I]].
+constexpr int kMlMaxLevels = 8;
+constexpr int kMlFanout = 8;
+constexpr int kMlTopMax = 8;          // aggregates at the top level (<= 48 dof dense)
+
+struct MlLevel {
+    int32_t n;                 // entities at this level (level 0: nb)
+    int32_t nslots;            // off-diagonal blocks of A_l (level 0: the block-CSR above)
+    const int32_t* row_ptr;    // [n+1]  (levels >= 1)
+    const int32_t* col;        // [nslots]
+    const int32_t* srow;       // [nslots] row of each slot (levels >= 1)
+    // contribution map used when this level is the FINE side of a Galerkin product A_{l+1} = P^T A_l P
+    const int32_t* tpos;       // [nslots] position of slot s in the sorted contribution array (or -1)
+    // ranges used when this level is the COARSE side
+    const int32_t* off_ptr;    // [nslots+1] contributions of each off-diagonal block
+    const int32_t* diag_ptr;   // [n+1]      same-aggregate contributions of each diagonal block
+    int32_t n_off_contrib;     // diag contributions start here in the contribution array
+    double* blk;               // [nslots][36]
+    double* G;                 // [n][36]   diagonal blocks of A_l(lambda = 0)
+    double* M;                 // [n][36]   diagonal blocks of P^T P chain (lambda multiplier)
+    double* Dinv;              // [n][36]   (G + lambda M)^-1
+    double* geo;               // level 0: [n][12] = R^T (9), d (3); levels >= 1: [n][3] = d = c_self - c_parent
+    double* cen;               // [n][3]  centroid (levels >= 1)
+    double* r;                 // [n][6]  restricted residual
+    double* y;                 // [n][6]  coarse correction
+};
+
+struct MlDev {
+    int32_t levels;            // number of coarse levels L (0 = plain block-Jacobi)
+    MlLevel lv[kMlMaxLevels + 1];
+    double* tmp;               // contribution scratch [max contributions][36]
+    double* tmpG;              // [max n][36]
+    double* tmpM;              // [max n][36]
+    double* top_inv;           // [(6 n_top)^2] dense inverse of A_L(lambda)
 };
 
 // scalars copied back to the host after each LM trial / PCG chunk

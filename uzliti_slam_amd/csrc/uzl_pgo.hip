@@ -26,10 +26,19 @@ int k_linearize(const PgoDev& D, const double* pose, double delta, hipStream_t s
 int k_assemble(const PgoDev& D, hipStream_t s);
 void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s);
 void k_precond(const PgoDev& D, hipStream_t s);
-int k_pcg_init(const PgoDev& D, hipStream_t s);
-void k_pcg_p(const PgoDev& D, int n_part, int first, double tol2, hipStream_t s);
-int k_pcg_spmv(const PgoDev& D, hipStream_t s);
-int k_pcg_update(const PgoDev& D, int n_part, hipStream_t s);
+int k_pcg_init(const PgoDev& D, double* p0, double* p1, hipStream_t s);
+int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
+int k_pcg_update(const PgoDev& D, const double* p, int n_part, hipStream_t s);
+int g_pcg_spmv(int nb);
+int g_pcg_update(int nb);
+void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, int n_l, hipStream_t s);
+void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s);
+void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
+void k_ml_invert(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
+int g_ml_rows(int nb);
+void k_ml_update(const PgoDev& D, const MlDev* ml, const double* p, double* p0, double* p1, int n_part, int init, hipStream_t s);
+bool ml_fits_lds(const int* n_per_level, int levels);
+void k_ml_finish(const PgoDev& D, const MlDev* ml, hipStream_t s);
 int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
@@ -51,11 +60,11 @@ struct uzl_pgo {
     bool have_graph = false, structure_ready = false;
     int32_t n_gauge = 0;
     // ---- device
-    DevBuf<double> pose_a, pose_b;
+    DevBuf<double> pose_a, pose_b, pose_init;
     double* cur = nullptr;
     double* trial = nullptr;
     DevBuf<int32_t> d_v2b, d_b2v, d_ei, d_ej, d_slot_i, d_slot_j, d_row_ptr, d_col, d_src, d_flags;
-    DevBuf<double> d_zinv, d_info, d_blk, d_dcon, d_gcon, d_hdiag, d_minv, d_b, d_x, d_r, d_z, d_p, d_ap;
+    DevBuf<double> d_zinv, d_info, d_blk, d_dcon, d_gcon, d_hdiag, d_minv, d_b, d_x, d_r, d_z, d_p, d_p2, d_ap;
     DevBuf<double> d_part_a, d_part_b, d_part_c, d_scal, d_err, d_out12, d_stage;
     DevBuf<uint8_t> d_robust;
     DevBuf<uzl_node> d_nodes;
@@ -64,6 +73,14 @@ struct uzl_pgo {
     PinBuf<double> h_lambda;
     PgoDev D;
     int prev_pcg_iters = 0;
+    // multilevel preconditioner
+    int ml_levels = 0;
+    std::vector<int32_t> ml_n, ml_nslots;
+    int ml_inner_aggs = 0;
+    DevBuf<uint8_t> ml_arena;
+    DevBuf<MlDev> d_ml;
+    hipGraph_t pcg_graph = nullptr;
+    hipGraphExec_t pcg_graph_exec = nullptr;
     // shard (BASELINE config 4)
     int32_t rank = 0, world = 1;
     uzl_allreduce_fn allreduce = nullptr;
@@ -103,7 +120,7 @@ void set_lambda(uzl_pgo* h, double lambda)
 void alloc_problem(uzl_pgo* h)
 {
     const size_t n = std::max(h->n, 1), e = std::max(h->e, 1);
-    h->pose_a.reserve(n * 8); h->pose_b.reserve(n * 8);
+    h->pose_a.reserve(n * 8); h->pose_b.reserve(n * 8); h->pose_init.reserve(n * 8);
     h->d_zinv.reserve(e * 7); h->d_info.reserve(e * 36); h->d_robust.reserve(e);
     h->d_ei.reserve(e); h->d_ej.reserve(e); h->d_slot_i.reserve(e); h->d_slot_j.reserve(e);
     h->d_v2b.reserve(n);
@@ -154,8 +171,149 @@ int32_t gauge_fix(uzl_pgo* h)
 }
 
 // block-CSR structure over the free vertices: one slot per (free endpoint, system edge)
+
+// Aggregation hierarchy of the multilevel preconditioner (pgo_types.hpp): symbolic part, once per structure.
+void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vector<int32_t>& col0)
+{
+    const int nb = h->nb;
+    h->ml_levels = 0; h->ml_n.assign(1, nb); h->ml_nslots.assign(1, h->nslots); h->ml_inner_aggs = 0;
+    if (h->cfg.preconditioner == 0 || nb <= kMlTopMax) return;
+    int L = 0;
+    while (h->ml_n.back() > kMlTopMax && L < kMlMaxLevels) { h->ml_n.push_back((h->ml_n.back() + kMlFanout - 1) / kMlFanout); L++; }
+    if (!ml_fits_lds(h->ml_n.data(), L)) { h->ml_n.assign(1, nb); return; }     // > ~70k free vertices: block-Jacobi
+    h->ml_levels = L;
+    // per-level host index arrays
+    struct Lv { std::vector<int32_t> row_ptr, col, srow, tpos, off_ptr, diag_ptr; int32_t n_off = 0; };
+    std::vector<Lv> lv((size_t)L + 1);
+    lv[0].col = col0;
+    lv[0].srow.resize(col0.size());
+    for (int a = 0; a < nb; a++) for (int s = row_ptr0[a]; s < row_ptr0[a + 1]; s++) lv[0].srow[s] = a;
+    size_t max_contrib = 1, max_n = (size_t)nb;
+    for (int f = 0; f < L; f++) {
+        Lv& F = lv[f]; Lv& C = lv[f + 1];
+        const int nc = h->ml_n[f + 1];
+        const int ns = (int)F.col.size();
+        struct Off { int32_t A, C, s; };
+        std::vector<Off> off; std::vector<std::pair<int32_t, int32_t>> dg;
+        for (int s = 0; s < ns; s++) {
+            const int c = F.col[s];
+            if (c < 0) continue;
+            const int A = F.srow[s] / kMlFanout, Cc = c / kMlFanout;
+            if (A != Cc) off.push_back({A, Cc, s}); else dg.push_back({A, s});
+        }
+        std::sort(off.begin(), off.end(), [](const Off& x, const Off& y) {
+            if (x.A != y.A) return x.A < y.A;
+            if (x.C != y.C) return x.C < y.C;
+            return x.s < y.s; });
+        std::sort(dg.begin(), dg.end());
+        F.tpos.assign((size_t)std::max(ns, 1), -1);
+        C.row_ptr.assign((size_t)nc + 1, 0);
+        for (size_t k = 0; k < off.size(); k++) {
+            if (k == 0 || off[k].A != off[k - 1].A || off[k].C != off[k - 1].C) {
+                C.srow.push_back(off[k].A); C.col.push_back(off[k].C); C.off_ptr.push_back((int32_t)k);
+                C.row_ptr[off[k].A + 1]++;
+            }
+            F.tpos[off[k].s] = (int32_t)k;
+        }
+        C.off_ptr.push_back((int32_t)off.size());
+        for (int a = 0; a < nc; a++) C.row_ptr[a + 1] += C.row_ptr[a];
+        C.n_off = (int32_t)off.size();
+        C.diag_ptr.assign((size_t)nc + 1, 0);
+        for (size_t k = 0; k < dg.size(); k++) { C.diag_ptr[dg[k].first + 1]++; F.tpos[dg[k].second] = C.n_off + (int32_t)k; }
+        for (int a = 0; a < nc; a++) C.diag_ptr[a + 1] += C.diag_ptr[a];
+        h->ml_nslots.push_back((int32_t)C.col.size());
+        max_contrib = std::max(max_contrib, off.size() + dg.size());
+        max_n = std::max(max_n, (size_t)nc);
+        if (f + 1 < L) h->ml_inner_aggs += nc;
+    }
+    // ---- one arena for everything: first the int arrays (staged on the host), then the doubles
+    size_t bytes = 0;
+    auto take = [&](size_t b) { size_t o = bytes; bytes = (bytes + b + 255) / 256 * 256; return o; };
+    struct IntOff { size_t row_ptr, col, srow, tpos, off_ptr, diag_ptr; };
+    std::vector<IntOff> io((size_t)L + 1);
+    for (int l = 0; l <= L; l++) {
+        Lv& X = lv[l];
+        io[l].row_ptr = take(std::max<size_t>(X.row_ptr.size(), 1) * 4);
+        io[l].col = take(std::max<size_t>(X.col.size(), 1) * 4);
+        io[l].srow = take(std::max<size_t>(X.srow.size(), 1) * 4);
+        io[l].tpos = take(std::max<size_t>(X.tpos.size(), 1) * 4);
+        io[l].off_ptr = take(std::max<size_t>(X.off_ptr.size(), 1) * 4);
+        io[l].diag_ptr = take(std::max<size_t>(X.diag_ptr.size(), 1) * 4);
+    }
+    const size_t int_bytes = bytes;
+    struct DblOff { size_t blk, G, M, Dinv, geo, cen, r, y; };
+    std::vector<DblOff> dof((size_t)L + 1);
+    for (int l = 0; l <= L; l++) {
+        const size_t n = (size_t)std::max(h->ml_n[l], 1), ns = (size_t)std::max(h->ml_nslots[l], 1);
+        dof[l].blk = (l == 0) ? 0 : take(ns * 36 * 8);
+        dof[l].G = (l == 0) ? 0 : take(n * 36 * 8);
+        dof[l].M = (l == 0) ? 0 : take(n * 36 * 8);
+        dof[l].Dinv = (l == 0) ? 0 : take(n * 36 * 8);
+        dof[l].geo = take(n * ((l == 0) ? 12 : 3) * 8);
+        dof[l].cen = take(n * 3 * 8);
+        dof[l].r = take(n * 6 * 8);
+        dof[l].y = take(n * 6 * 8);
+    }
+    const size_t o_tmp = take(max_contrib * 36 * 8), o_tmpG = take(max_n * 36 * 8), o_tmpM = take(max_n * 36 * 8);
+    const size_t o_top = take((size_t)(6 * kMlTopMax) * (6 * kMlTopMax) * 8);
+    h->ml_arena.reserve(bytes);
+    std::vector<uint8_t> stage(int_bytes, 0);
+    auto put = [&](size_t o, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage.data() + o, v.data(), v.size() * 4); };
+    for (int l = 0; l <= L; l++) {
+        put(io[l].row_ptr, lv[l].row_ptr); put(io[l].col, lv[l].col); put(io[l].srow, lv[l].srow);
+        put(io[l].tpos, lv[l].tpos); put(io[l].off_ptr, lv[l].off_ptr); put(io[l].diag_ptr, lv[l].diag_ptr);
+    }
+    hipStream_t s = h->stream;
+    uint8_t* base = h->ml_arena.p;
+    UZL_HIP(hipMemcpyAsync(base, stage.data(), int_bytes, hipMemcpyHostToDevice, s));
+    MlDev M;
+    memset(&M, 0, sizeof(M));
+    M.levels = L;
+    for (int l = 0; l <= L; l++) {
+        MlLevel& X = M.lv[l];
+        X.n = h->ml_n[l]; X.nslots = h->ml_nslots[l];
+        X.row_ptr = (l == 0) ? h->d_row_ptr.p : reinterpret_cast<const int32_t*>(base + io[l].row_ptr);
+        X.col = (l == 0) ? h->d_col.p : reinterpret_cast<const int32_t*>(base + io[l].col);
+        X.srow = reinterpret_cast<const int32_t*>(base + io[l].srow);
+        X.tpos = reinterpret_cast<const int32_t*>(base + io[l].tpos);
+        X.off_ptr = reinterpret_cast<const int32_t*>(base + io[l].off_ptr);
+        X.diag_ptr = reinterpret_cast<const int32_t*>(base + io[l].diag_ptr);
+        X.n_off_contrib = lv[l].n_off;
+        X.blk = (l == 0) ? h->d_blk.p : reinterpret_cast<double*>(base + dof[l].blk);
+        X.G = (l == 0) ? h->d_hdiag.p : reinterpret_cast<double*>(base + dof[l].G);
+        X.M = (l == 0) ? nullptr : reinterpret_cast<double*>(base + dof[l].M);
+        X.Dinv = (l == 0) ? h->d_minv.p : reinterpret_cast<double*>(base + dof[l].Dinv);
+        X.geo = reinterpret_cast<double*>(base + dof[l].geo);
+        X.cen = reinterpret_cast<double*>(base + dof[l].cen);
+        X.r = reinterpret_cast<double*>(base + dof[l].r);
+        X.y = reinterpret_cast<double*>(base + dof[l].y);
+    }
+    M.tmp = reinterpret_cast<double*>(base + o_tmp);
+    M.tmpG = reinterpret_cast<double*>(base + o_tmpG);
+    M.tmpM = reinterpret_cast<double*>(base + o_tmpM);
+    M.top_inv = reinterpret_cast<double*>(base + o_top);
+    h->d_ml.reserve(1);
+    UZL_HIP(hipMemcpyAsync(h->d_ml.p, &M, sizeof(M), hipMemcpyHostToDevice, s));
+    UZL_HIP(hipStreamSynchronize(s));      // stage / M are locals
+}
+
+// numeric part, once per linearisation: geometry, then A_{l+1} = P^T A_l P level by level
+void ml_setup_numeric(uzl_pgo* h)
+{
+    if (h->ml_levels == 0) return;
+    hipStream_t s = h->stream;
+    const int L = h->ml_levels;
+    { Timed t(h, "ml_geometry"); for (int l = 1; l <= L; l++) k_ml_geometry(h->D, h->d_ml.p, h->cur, l, h->ml_n[l], s); }
+    for (int f = 0; f < L; f++) {
+        { Timed t(h, "ml_transform"); k_ml_transform(h->D, h->d_ml.p, f, h->ml_nslots[f] + h->ml_n[f], s); }
+        { Timed t(h, "ml_reduce"); k_ml_reduce(h->d_ml.p, f + 1, h->ml_nslots[f + 1] + h->ml_n[f + 1], s); }
+    }
+}
+
+void destroy_pcg_graph(uzl_pgo* h);
 void build_structure(uzl_pgo* h)
 {
+    destroy_pcg_graph(h);
     const int n = h->n, e = h->e;
     std::vector<int32_t> v2b((size_t)std::max(n, 1)), b2v;
     int nb = 0;
@@ -185,7 +343,7 @@ void build_structure(uzl_pgo* h)
     h->d_b2v.reserve(nbz); h->d_row_ptr.reserve(nbz + 1); h->d_col.reserve(nsz);
     h->d_blk.reserve(nsz * 36); h->d_dcon.reserve(nsz * 36); h->d_gcon.reserve(nsz * 6);
     h->d_hdiag.reserve(nbz * 36); h->d_minv.reserve(nbz * 36); h->d_b.reserve(nbz * 6);
-    h->d_x.reserve(nbz * 6); h->d_r.reserve(nbz * 6); h->d_z.reserve(nbz * 6); h->d_p.reserve(nbz * 6); h->d_ap.reserve(nbz * 6);
+    h->d_x.reserve(nbz * 6); h->d_r.reserve(nbz * 6); h->d_z.reserve(nbz * 6); h->d_p.reserve(nbz * 6); h->d_p2.reserve(nbz * 6); h->d_ap.reserve(nbz * 6);
     if (n > 0) UZL_HIP(hipMemcpyAsync(h->d_v2b.p, v2b.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
     if (nb > 0) UZL_HIP(hipMemcpyAsync(h->d_b2v.p, b2v.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, s));
     UZL_HIP(hipMemcpyAsync(h->d_row_ptr.p, row_ptr.data(), sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice, s));
@@ -207,7 +365,56 @@ void build_structure(uzl_pgo* h)
     D.b = h->d_b.p; D.x = h->d_x.p; D.r = h->d_r.p; D.z = h->d_z.p; D.p = h->d_p.p; D.ap = h->d_ap.p;
     D.part_a = h->d_part_a.p; D.part_b = h->d_part_b.p; D.part_c = h->d_part_c.p;
     D.scal = h->d_scal.p; D.flags = h->d_flags.p;
+    build_ml(h, row_ptr, col);
     h->structure_ready = true;
+}
+
+// enqueue `pairs` x 2 PCG iterations (p0 -> p1 -> p0); kernels no-op once the device `done` flag is set
+void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
+{
+    hipStream_t s = h->stream;
+    const PgoDev& D = h->D;
+    const double tol2 = h->cfg.pcg_tol * h->cfg.pcg_tol;
+    const bool ml = h->ml_levels > 0;
+    const int ga = g_pcg_spmv(D.nb), gu = ml ? g_ml_rows(D.nb) : g_pcg_update(D.nb);
+    double* pb[2] = {h->d_p.p, h->d_p2.p};
+    for (int i = 0; i < 2 * pairs; i++) {
+        double* po = pb[i & 1];
+        double* pn = pb[(i & 1) ^ 1];
+        if (timed) h->timer.begin("pcg_spmv", s);
+        k_pcg_spmv(D, po, pn, gu, tol2, s);
+        if (timed) h->timer.end(s);
+        if (ml) {
+            if (timed) h->timer.begin("ml_update", s);
+            k_ml_update(D, h->d_ml.p, pn, pb[0], pb[1], ga, 0, s);
+            if (timed) { h->timer.end(s); h->timer.begin("ml_finish", s); }
+            k_ml_finish(D, h->d_ml.p, s);
+            if (timed) h->timer.end(s);
+        } else {
+            if (timed) h->timer.begin("pcg_update", s);
+            k_pcg_update(D, pn, ga, s);
+            if (timed) h->timer.end(s);
+        }
+    }
+}
+
+constexpr int kGraphPairs = 8;      // one graph replay = 16 PCG iterations = 32 kernel nodes
+
+void destroy_pcg_graph(uzl_pgo* h)
+{
+    if (h->pcg_graph_exec) { (void)hipGraphExecDestroy(h->pcg_graph_exec); h->pcg_graph_exec = nullptr; }
+    if (h->pcg_graph) { (void)hipGraphDestroy(h->pcg_graph); h->pcg_graph = nullptr; }
+}
+
+// The launch-bound inner loop is captured once per problem structure: every kernel argument (pointers,
+// partial counts, tolerance) is fixed, lambda and the CG scalars live in device memory.
+void ensure_pcg_graph(uzl_pgo* h)
+{
+    if (h->pcg_graph_exec) return;
+    UZL_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_pcg_pairs(h, kGraphPairs, false);
+    UZL_HIP(hipStreamEndCapture(h->stream, &h->pcg_graph));
+    UZL_HIP(hipGraphInstantiate(&h->pcg_graph_exec, h->pcg_graph, nullptr, nullptr, 0));
 }
 
 // one (H + lambda I) dx = b solve; returns PCG iterations used, sets *converged
@@ -215,27 +422,31 @@ int pcg_solve(uzl_pgo* h, bool* converged)
 {
     hipStream_t s = h->stream;
     const PgoDev& D = h->D;
-    const double tol2 = h->cfg.pcg_tol * h->cfg.pcg_tol;
     const int max_it = h->cfg.pcg_max_iter > 0 ? h->cfg.pcg_max_iter : 6 * std::max(h->nb, 1);
+    const bool timed = h->timer.on;                       // per-kernel events need eager launches
     { Timed t(h, "precond"); k_precond(D, s); }
-    int gb;
-    { Timed t(h, "pcg_init"); gb = k_pcg_init(D, s); }
-    { Timed t(h, "pcg_p"); k_pcg_p(D, gb, 1, tol2, s); }
+    if (h->ml_levels > 0) {
+        { Timed t(h, "ml_invert"); k_ml_invert(D, h->d_ml.p, h->ml_inner_aggs, s); }
+        { Timed t(h, "pcg_init"); k_ml_update(D, h->d_ml.p, h->d_p.p, h->d_p.p, h->d_p2.p, 0, 1, s); }
+        { Timed t(h, "ml_finish"); k_ml_finish(D, h->d_ml.p, s); }
+    } else {
+        Timed t(h, "pcg_init"); k_pcg_init(D, h->d_p.p, h->d_p2.p, s);
+    }
+    if (!timed) ensure_pcg_graph(h);
     int launched = 0;
-    // first chunk sized from the previous solve, then fixed chunks; the kernels no-op once `done` is set
-    int chunk = h->prev_pcg_iters > 0 ? std::max(8, (h->prev_pcg_iters * 9) / 10) : 32;
+    // first batch sized from the previous solve, then fixed batches; the kernels no-op once `done` is set
+    int want = h->prev_pcg_iters > 0 ? std::max(16, (h->prev_pcg_iters * 19) / 20) : 2 * kGraphPairs;
     while (true) {
-        chunk = std::min(chunk, max_it - launched);
-        for (int i = 0; i < chunk; i++) {
-            int ga, gu;
-            { Timed t(h, "pcg_spmv"); ga = k_pcg_spmv(D, s); }
-            { Timed t(h, "pcg_update"); gu = k_pcg_update(D, ga, s); }
-            { Timed t(h, "pcg_p"); k_pcg_p(D, gu, 0, tol2, s); }
+        want = std::min(want, max_it - launched);
+        const int reps = std::max(1, (want + 2 * kGraphPairs - 1) / (2 * kGraphPairs));
+        for (int i = 0; i < reps; i++) {
+            if (timed) enqueue_pcg_pairs(h, kGraphPairs, true);
+            else UZL_HIP(hipGraphLaunch(h->pcg_graph_exec, s));
         }
-        launched += chunk;
+        launched += reps * 2 * kGraphPairs;
         fetch_scal(h);
         if (h->h_scal.p->flags[0] || launched >= max_it) break;
-        chunk = 16;
+        want = 2 * kGraphPairs;
     }
     UZL_HIP(hipGetLastError());
     *converged = h->h_scal.p->flags[0] != 0 && h->h_scal.p->flags[2] == 0;
@@ -254,9 +465,11 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     uzl_pgo_stats S;
     memset(&S, 0, sizeof(S));
     // optimizeImpl: initializeOptimization (:139), setFixedNodes (:144-146)
-    h->fixed_eff = h->fixed_in;
-    h->n_gauge = gauge_fix(h);
-    build_structure(h);
+    if (!h->structure_ready) {          // cached until the next add_graph/set_graph
+        h->fixed_eff = h->fixed_in;
+        h->n_gauge = gauge_fix(h);
+        build_structure(h);
+    }
     S.n_vertices = h->n; S.n_edges = h->e; S.n_gauge_fixed = h->n_gauge;
     hipStream_t s = h->stream;
     PgoDev& D = h->D;
@@ -285,6 +498,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         { Timed t(h, "linearize"); gl = k_linearize(D, h->cur, delta, s); }     // computeActiveErrors + buildSystem
         { Timed t(h, "assemble"); ga = k_assemble(D, s); }
         { Timed t(h, "finalize"); k_finalize(D, gl, 0, ga, 2, s); }
+        ml_setup_numeric(h);
         fetch_scal(h);
         current_chi = h->h_scal.p->scal[4];
         if (it == 0) {
@@ -358,6 +572,7 @@ void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg)
     cfg->pcg_max_iter = 0;              // 0 = 6 * free vertices (system dimension)
     cfg->huber_delta = 1.0;             // g2o_optimizer.cpp:293
     cfg->verbose = 0;
+    cfg->preconditioner = 1;            // additive multilevel (rigid-body-mode aggregation); 0 = block-Jacobi
 }
 
 int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
@@ -386,7 +601,10 @@ void uzl_pgo_destroy(uzl_pgo* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->pcg_graph_exec) (void)hipGraphExecDestroy(h->pcg_graph_exec);
+    if (h->pcg_graph) (void)hipGraphDestroy(h->pcg_graph);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -397,6 +615,8 @@ int uzl_pgo_set_config(uzl_pgo* h, const uzl_pgo_cfg* cfg)
     if (cfg->device != h->cfg.device) return fail(h, UZL_ERR_BAD_ARG, "device cannot change after create");
     if (cfg->use_odometry_parameters) return fail(h, UZL_ERR_BAD_ARG, "use_odometry_parameters is not supported");
     if (cfg->iterations < 1 || cfg->pcg_tol <= 0. || cfg->huber_delta <= 0.) return fail(h, UZL_ERR_BAD_ARG, "bad config value");
+    if (cfg->pcg_tol != h->cfg.pcg_tol) destroy_pcg_graph(h);      // the tolerance is a captured kernel argument
+    if (cfg->preconditioner != h->cfg.preconditioner) h->structure_ready = false;
     h->cfg = *cfg;
     return UZL_OK;
 }
@@ -450,6 +670,7 @@ int uzl_pgo_add_graph(uzl_pgo* h, int32_t n_nodes, const uzl_node* nodes, int32_
     k_prepare_edges(h->d_edges.p, h->d_src.p, h->e, h->d_stage.p, n_sensors, h->cfg.optimize_xy_only,
                     h->d_zinv.p, h->d_info.p, s);
     UZL_HIP(hipGetLastError());
+    if (n_nodes) UZL_HIP(hipMemcpyAsync(h->pose_init.p, h->cur, sizeof(double) * 8 * (size_t)n_nodes, hipMemcpyDeviceToDevice, s));
     UZL_HIP(hipStreamSynchronize(s));                          // inputs are borrowed for the duration of the call only
     upload_edges_common(h);
     h->have_graph = true;
@@ -490,9 +711,20 @@ int uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t*
     k_prepare_flat_nodes(d_p, n, h->cur, s);
     k_prepare_flat_edges(d_m, d_i, e, h->d_zinv.p, h->d_info.p, s);
     UZL_HIP(hipGetLastError());
+    if (n) UZL_HIP(hipMemcpyAsync(h->pose_init.p, h->cur, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToDevice, s));
     UZL_HIP(hipStreamSynchronize(s));
     upload_edges_common(h);
     h->have_graph = true;
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
+int uzl_pgo_reset(uzl_pgo* h)
+{
+    UZL_GUARD_BEGIN(h)
+    if (!h->have_graph) return fail(h, UZL_ERR_STATE, "reset before add_graph/set_graph");
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    if (h->n) UZL_HIP(hipMemcpyAsync(h->cur, h->pose_init.p, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
     return UZL_OK;
     UZL_GUARD_END(h)
 }
@@ -517,8 +749,9 @@ int uzl_pgo_store(uzl_pgo* h, double* poses, double* edge_error, uint8_t* edge_i
     }
     std::vector<double> err;
     if (edge_error && h->e > 0) {
-        if (!h->structure_ready) {      // store without optimize: D only needs the edge arrays
+        if (!h->structure_ready) {      // store without optimize: same structure optimize would build
             h->fixed_eff = h->fixed_in;
+            h->n_gauge = gauge_fix(h);
             build_structure(h);
         }
         h->d_err.reserve((size_t)h->e);
