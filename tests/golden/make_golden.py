@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ (run from the repo root: python tests/golden/make_golden.py).
+
+The reference ships no tests or fixtures for this path, and none of its libraries exist in this image,
+so the vectors are produced by the CPU oracle (oracle/), after the oracle itself has been cross-checked against the
+independent NumPy/SciPy implementation in tests/np_reference.py (asserted below before anything is written).
+A fixture is data only: inputs + expected outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.dirname(HERE))
+
+import oracle as O                      # noqa: E402
+import np_reference as NP               # noqa: E402
+from uzliti_slam_amd import synth       # noqa: E402
+
+
+def match_fixture():
+    cfg = dict(ransac_threshold=0.1, ransac_iteration=150, break_percentage=0.6, seed=4242)
+    pairs = synth.make_pairs(3, n_kp=160, seed=99)
+    out = dict(n_pairs=3, **{k: np.array(v) for k, v in cfg.items()})
+    for j, (f, t, T) in enumerate(pairs):
+        r = O.estimate_edge([f], [t], do_prosac=True, job_id=10 + j, **cfg)
+        i0, d0, i1, d1 = O.knn2(t["desc"], f["desc"])
+        n0 = NP.knn2(t["desc"], f["desc"])
+        assert all(np.array_equal(a, b) for a, b in zip((i0, d0, i1, d1), n0)), "oracle knn2 != numpy"
+        q, tr, d, nr = NP.filter_sort(i0, d0, i1, d1, f["valid"], t["valid"])
+        assert np.array_equal(q, r["corr_query"]) and np.array_equal(tr, r["corr_train"]) and nr == r["n_matches"]
+        for side, fr in (("from", f), ("to", t)):
+            out[f"p{j}_{side}_desc"] = fr["desc"]; out[f"p{j}_{side}_pos"] = fr["pos"]; out[f"p{j}_{side}_valid"] = fr["valid"]
+        out[f"p{j}_knn"] = np.stack([i0, d0, i1, d1])
+        for k in ("corr_query", "corr_train", "corr_dist", "mask", "T", "information"):
+            out[f"p{j}_{k}"] = r[k]
+        out[f"p{j}_scalars"] = np.array([r["ok"], r["consensus"], r["n_matches"], r["n_corr"], r["iterations_run"], r["best_iteration"]], np.int64)
+        out[f"p{j}_mse"] = np.array(r["mse"])
+    np.savez_compressed(os.path.join(HERE, "match_3pairs.npz"), **out)
+
+
+def ransac_fixture():
+    rng = np.random.default_rng(17)
+    out = {}
+    ms = (3, 4, 12, 60)
+    for b, m in enumerate(ms):
+        P = rng.normal(size=(3, m)) * 2
+        R = synth.quat_to_R(synth.quat_from_rotvec(rng.normal(size=3) * 0.4)); t = rng.normal(size=3)
+        Q = R @ P + t[:, None] + rng.normal(0, 0.02, (3, m))
+        if m >= 12:
+            Q[:, ::3] += rng.normal(0, 1.5, Q[:, ::3].shape)
+        r = O.prosac(P, Q, 0.3, 200, 0.6, do_prosac=False, seed=7, job_id=b)      # TransformationFilter's call shape
+        out[f"b{b}_P"] = P; out[f"b{b}_Q"] = Q; out[f"b{b}_T"] = r["T"]; out[f"b{b}_mask"] = r["mask"]
+        out[f"b{b}_scalars"] = np.array([r["consensus"], r["iterations_run"], r["best_iteration"]], np.int64)
+        out[f"b{b}_mse"] = np.array(r["mse"])
+    out["n"] = np.array(len(ms))
+    np.savez_compressed(os.path.join(HERE, "ransac_points.npz"), **out)
+
+
+def pgo_fixture():
+    g = synth.make_pose_graph(60, 180, seed=31)
+    fl = O.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    fixed, n_gauge = O.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, st = O.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=20)
+    Pn, sn = NP.pgo_lm(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=20)
+    dt, dr = synth.pose_errors(P.reshape(-1, 3, 4), Pn.reshape(-1, 3, 4))
+    assert dt < 1e-7 and dr < 1e-8, "oracle LM != NumPy/SciPy LM"
+    e = g["edges"]
+    np.savez_compressed(os.path.join(HERE, "pgo_60n_180e.npz"),
+                        nodes_pose=g["nodes_pose"], nodes_fixed=g["nodes_fixed"],
+                        **{"e_" + k: v for k, v in e.items()},
+                        flat_poses=fl["poses"], flat_ij=fl["ij"], flat_meas=fl["meas"], flat_info=fl["info"],
+                        flat_robust=fl["robust"], flat_src=fl["src_edge"], fixed_eff=fixed,
+                        poses_out=P, chi2=np.array([st["chi2_initial"], st["chi2_final"]]),
+                        edge_err=O.edge_error_norms(P, fl["ij"], fl["meas"]))
+    # known answers of the in-tree g2o excerpt (isometry3d_mappings.cpp)
+    rng = np.random.default_rng(5)
+    T = np.stack([synth.se3(synth.quat_to_R(synth.quat_from_rotvec(rng.normal(size=3) * s)), rng.normal(size=3))
+                  for s in (0.1, 1.0, 2.5, 3.1)])
+    np.savez_compressed(os.path.join(HERE, "isometry_kat.npz"), T=T,
+                        mqt=np.stack([O.to_vector_mqt(x) for x in T]),
+                        euler=np.stack([O.to_euler(x[:, :3]) for x in T]))
+
+
+if __name__ == "__main__":
+    match_fixture(); ransac_fixture(); pgo_fixture()
+    print("golden fixtures written to", HERE)

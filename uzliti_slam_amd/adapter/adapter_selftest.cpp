@@ -1,0 +1,97 @@
+// adapter_selftest.cpp — drives the plugin-shaped classes the way GraphSlamNode does
+// (graph_slam/src/graph_slam_node.cpp:46-49, :266, :1138-1150, :1248-1282) on inputs read from a flat binary
+// file written by tests/test_adapter_gpu.py, and writes the results back for comparison with the oracle.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "graph_optimizer.h"
+#include "transformation_estimator.h"
+
+using namespace uzl_adapter;
+
+static void rd(FILE* f, void* p, size_t n) { if (fread(p, 1, n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } }
+
+static std::string node_id(int i) { char b[32]; snprintf(b, sizeof(b), "n%08d", i); return b; }   // lexicographic = numeric order
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) { fprintf(stderr, "usage: adapter_selftest in.bin out.bin\n"); return 2; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    // ---- graph section
+    int32_t n, e, iters, xy;
+    rd(f, &n, 4); rd(f, &e, 4); rd(f, &iters, 4); rd(f, &xy, 4);
+    SlamGraph graph;
+    for (int i = 0; i < n; i++) {
+        SlamNode nd; nd.id_ = node_id(i);
+        int32_t fixed; rd(f, nd.pose_.m.data(), 96); rd(f, &fixed, 4); nd.fixed_ = fixed != 0;
+        graph.addNode(nd);
+    }
+    for (int k = 0; k < e; k++) {
+        SlamEdge ed; char b[32]; snprintf(b, sizeof(b), "e%08d", k); ed.id_ = b;
+        int32_t from, to, type, valid;
+        rd(f, &from, 4); rd(f, &to, 4); rd(f, &type, 4); rd(f, &valid, 4);
+        ed.id_from_ = node_id(from); ed.id_to_ = node_id(to); ed.type_ = (unsigned char)type; ed.valid_ = valid != 0;
+        rd(f, ed.transform_.m.data(), 96); rd(f, ed.information_.data(), 288);
+        graph.addEdge(ed);
+    }
+    // ---- pair section
+    int32_t n_pairs, nkp, bytes;
+    rd(f, &n_pairs, 4); rd(f, &nkp, 4); rd(f, &bytes, 4);
+    std::vector<SlamNode> from_nodes(n_pairs), to_nodes(n_pairs);
+    for (int j = 0; j < n_pairs; j++) {
+        for (int side = 0; side < 2; side++) {
+            FeatureDataPtr fd(new FeatureData());
+            fd->sensor_frame_ = "camera"; fd->feature_type_ = FEATURE_ORB; fd->rows = nkp; fd->bytes_per_row = bytes;
+            fd->features_.resize((size_t)nkp * bytes); fd->feature_positions_.resize((size_t)nkp * 3);
+            std::vector<uint8_t> v(nkp);
+            rd(f, fd->features_.data(), fd->features_.size()); rd(f, fd->feature_positions_.data(), 24 * (size_t)nkp); rd(f, v.data(), nkp);
+            fd->valid_3d_.assign(v.begin(), v.end());
+            SlamNode& nd = side == 0 ? from_nodes[j] : to_nodes[j];
+            char b[32]; snprintf(b, sizeof(b), "%c%06d", side == 0 ? 'f' : 't', j); nd.id_ = b;
+            nd.sensor_data_.push_back(fd);
+        }
+    }
+    fclose(f);
+
+    FILE* o = fopen(argv[2], "wb");
+    // ---- optimizer plugin: optimize() -> callback on the worker thread -> storeOptimizationResults()
+    {
+        Mi355xOptimizer opt(0);
+        GraphOptimizerConfig cfg; cfg.iterations = iters; cfg.optimize_xy_only = xy != 0;
+        opt.setConfig(cfg);
+        std::mutex m; std::condition_variable cv; bool done = false;
+        const bool accepted = opt.optimize(graph, [&] { std::lock_guard<std::mutex> l(m); done = true; cv.notify_all(); });
+        const bool second = opt.optimize(graph, [] {});         // must be refused while the first is in flight... or accepted after
+        { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return done; }); }
+        opt.storeOptimizationResults(graph);
+        int32_t hdr[4] = {accepted ? 1 : 0, second ? 1 : 0, opt.lastStatus(), opt.lastStats().iterations_done};
+        fwrite(hdr, 4, 4, o);
+        double chi[2] = {opt.lastStats().chi2_initial, opt.lastStats().chi2_final};
+        fwrite(chi, 8, 2, o);
+        for (auto& kv : graph.nodes()) { fwrite(kv.second.pose_.m.data(), 8, 12, o); int32_t op = kv.second.optimized_; fwrite(&op, 4, 1, o); }
+        for (auto& kv : graph.edges()) { fwrite(&kv.second.error_, 8, 1, o); fwrite(&kv.second.age_, 8, 1, o); }
+        if (second) {   // the refused/accepted second solve must finish before the optimizer is destroyed
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        }
+    }
+    // ---- estimator plugin: estimateEdge() x n_pairs -> one callback per pair on the worker thread
+    {
+        std::mutex m; std::condition_variable cv; std::vector<SlamEdge> got;
+        Mi355xFeatureTransformationEstimator est([&](SlamEdge e) { std::lock_guard<std::mutex> l(m); got.push_back(e); cv.notify_all(); }, 0, 777);
+        FeatureLinkEstimationConfig c; c.ransac_threshold = 0.1; c.ransac_iteration = 100; c.ransac_break_percentage = 0.6;
+        est.setConfig(c);
+        for (int j = 0; j < n_pairs; j++) est.estimateEdge(from_nodes[j], to_nodes[j]);
+        { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return (int)got.size() == n_pairs; }); }
+        int32_t cnt = (int32_t)got.size(); fwrite(&cnt, 4, 1, o);
+        for (auto& e : got) {
+            int32_t j = atoi(e.id_from_.c_str() + 1); fwrite(&j, 4, 1, o);
+            fwrite(&e.matching_score_, 8, 1, o); fwrite(e.transform_.m.data(), 8, 12, o); fwrite(e.information_.data(), 8, 36, o);
+            int32_t ty = e.type_; fwrite(&ty, 4, 1, o);
+        }
+    }
+    fclose(o);
+    return 0;
+}

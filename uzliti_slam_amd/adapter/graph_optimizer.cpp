@@ -1,0 +1,149 @@
+#include "graph_optimizer.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace uzl_adapter {
+
+GraphOptimizer::GraphOptimizer()
+{
+    graph_optimization_thread_ = std::thread(&GraphOptimizer::graphOptimizationThread, this);
+}
+
+GraphOptimizer::~GraphOptimizer() { stopThread(); }
+
+void GraphOptimizer::stopThread()
+{
+    running = false;
+    opt_cv_.notify_all();
+    if (graph_optimization_thread_.joinable()) graph_optimization_thread_.join();
+}
+
+bool GraphOptimizer::optimize(SlamGraph& graph, std::function<void()> callback)
+{
+    std::lock_guard<std::mutex> lock(opt_mutex_);
+    if (do_optimization_) return false;        // a solve is already in flight
+    callback_ = callback;
+    addGraphImpl(graph);                       // only copies (caller holds its graph mutex)
+    do_optimization_ = true;
+    opt_cv_.notify_all();
+    return true;
+}
+
+void GraphOptimizer::storeOptimizationResults(SlamGraph& graph) { storeImpl(graph); }
+
+void GraphOptimizer::setConfig(GraphOptimizerConfig config)
+{
+    std::lock_guard<std::mutex> lock(opt_mutex_);
+    config_ = config;
+}
+
+// The reference polls every 10 ms with plain bools; here a condition variable wakes the worker.
+void GraphOptimizer::graphOptimizationThread()
+{
+    std::unique_lock<std::mutex> lock(opt_mutex_);
+    while (running) {
+        opt_cv_.wait(lock, [this] { return do_optimization_ || !running; });
+        if (!running) break;
+        std::function<void()> cb = callback_;
+        lock.unlock();                         // no plugin lock while solving / calling back (graph_optimizer.cpp:63-67)
+        optimizeImpl();
+        if (cb) cb();
+        lock.lock();
+        do_optimization_ = false;
+    }
+}
+
+Mi355xOptimizer::Mi355xOptimizer(int device)
+{
+    uzl_pgo_cfg c;
+    uzl_pgo_cfg_default(&c);
+    c.device = device;
+    status_ = uzl_pgo_create(&c, &h_);
+}
+
+Mi355xOptimizer::~Mi355xOptimizer()
+{
+    stopThread();                              // before the handle goes away
+    if (h_) uzl_pgo_destroy(h_);
+}
+
+void Mi355xOptimizer::addGraphImpl(SlamGraph& graph)
+{
+    if (!h_) return;
+    uzl_pgo_cfg c;
+    uzl_pgo_cfg_default(&c);
+    c.iterations = config_.iterations;
+    c.optimize_xy_only = config_.optimize_xy_only ? 1 : 0;
+    uzl_pgo_set_config(h_, &c);
+    // vertices in std::map order = lexicographic id = the order g2o ids are assigned in (g2o_optimizer.cpp:64-66)
+    node_ids_.clear(); edge_ids_.clear();
+    std::map<std::string, int32_t> index;
+    std::vector<uzl_node> nodes;
+    for (auto& kv : graph.nodes()) {
+        uzl_node n;
+        std::memcpy(n.pose, kv.second.pose_.m.data(), sizeof(n.pose));
+        n.fixed = kv.second.fixed_ ? 1 : 0;
+        index[kv.first] = (int32_t)nodes.size();
+        node_ids_.push_back(kv.first);
+        nodes.push_back(n);
+    }
+    std::map<std::string, int32_t> sensor_index;
+    std::vector<double> sensors;
+    for (auto& kv : graph.sensors()) {          // sensor transforms (:68-71)
+        sensor_index[kv.first] = (int32_t)(sensors.size() / 12);
+        sensors.insert(sensors.end(), kv.second.m.begin(), kv.second.m.end());
+    }
+    std::vector<uzl_edge> edges;
+    for (auto& kv : graph.edges()) {
+        const SlamEdge& e = kv.second;
+        uzl_edge u;
+        std::memset(&u, 0, sizeof(u));
+        auto f = index.find(e.id_from_), t = index.find(e.id_to_);
+        u.from = f == index.end() ? -1 : f->second;        // missing endpoints are skipped by the back end (:77)
+        u.to = t == index.end() ? -1 : t->second;
+        u.type = e.type_;
+        auto sf = sensor_index.find(e.sensor_from_), st = sensor_index.find(e.sensor_to_);
+        u.sensor_from = sf == sensor_index.end() ? -1 : sf->second;
+        u.sensor_to = st == sensor_index.end() ? -1 : st->second;
+        // TransformationFilter verdict (:97-103); odometry edges bypass the filter (:78-79)
+        u.valid = (e.type_ == TYPE_2D_WHEEL_ODOMETRY) ? 1 : (e.valid_ ? 1 : 0);
+        std::memcpy(u.transform, e.transform_.m.data(), sizeof(u.transform));
+        std::memcpy(u.displacement_from, e.displacement_from_.m.data(), sizeof(u.displacement_from));
+        std::memcpy(u.displacement_to, e.displacement_to_.m.data(), sizeof(u.displacement_to));
+        std::memcpy(u.information, e.information_.data(), sizeof(u.information));
+        edge_ids_.push_back(kv.first);
+        edges.push_back(u);
+    }
+    status_ = uzl_pgo_add_graph(h_, (int32_t)nodes.size(), nodes.data(), (int32_t)edges.size(), edges.data(),
+                                (int32_t)(sensors.size() / 12), sensors.data());
+}
+
+void Mi355xOptimizer::optimizeImpl()
+{
+    if (!h_ || status_ < 0) return;             // reference: ROS_ERROR + return (g2o_optimizer.cpp:139-142)
+    status_ = uzl_pgo_optimize(h_, config_.iterations, &stats_);
+    if (status_ == UZL_ERR_NOT_CONVERGED) status_ = 0;     // result is still the best available estimate
+}
+
+void Mi355xOptimizer::storeImpl(SlamGraph& graph)
+{
+    if (!h_ || status_ < 0) return;
+    std::vector<double> poses(node_ids_.size() * 12), err(edge_ids_.size() + 1);
+    std::vector<uint8_t> used(edge_ids_.size() + 1);
+    if (uzl_pgo_store(h_, poses.data(), err.data(), used.data()) != UZL_OK) return;
+    for (size_t i = 0; i < node_ids_.size(); i++) {        // :110-117: the graph may have changed meanwhile
+        if (!graph.existsNode(node_ids_[i])) continue;
+        SlamNode& n = graph.node(node_ids_[i]);
+        std::memcpy(n.pose_.m.data(), poses.data() + 12 * i, 12 * sizeof(double));
+        n.optimized_ = true;
+    }
+    for (size_t k = 0; k < edge_ids_.size(); k++) {        // :120-134
+        if (!used[k] || !graph.existsEdge(edge_ids_[k])) continue;
+        SlamEdge& e = graph.edge(edge_ids_[k]);
+        e.age_ += 1;
+        e.error_ = err[k];
+    }
+}
+
+}  // namespace uzl_adapter

@@ -1,0 +1,65 @@
+// graph_optimizer.h — host-side mirror of the reference's GraphOptimizer plugin family
+// (graph_optimization/include/graph_optimization/graph_optimizer.h:28-56, src/graph_optimizer.cpp:22-73) with the
+// MI355X back end in the place of G2oOptimizer (g2o_optimizer.h:38-68).  Same public calls, same threading
+// contract: optimize() copies the graph under the caller's lock and returns, the solve runs on the worker thread,
+// the completion callback fires on the worker thread with no plugin lock held, optimize() returns false while a
+// solve is in flight.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "slam_types.h"
+#include "../../include/uzl_mi355x.h"
+
+namespace uzl_adapter {
+
+class GraphOptimizer {
+public:
+    GraphOptimizer();
+    virtual ~GraphOptimizer();
+    bool optimize(SlamGraph& graph, std::function<void()> callback);      // graph_optimizer.cpp:35-47
+    void storeOptimizationResults(SlamGraph& graph);                      // :49-52
+    void setConfig(GraphOptimizerConfig config);                          // :54-57
+
+protected:
+    void graphOptimizationThread();                                        // :59-73
+    void stopThread();
+    virtual void addGraphImpl(SlamGraph& graph) = 0;
+    virtual void storeImpl(SlamGraph& graph) = 0;
+    virtual void optimizeImpl() = 0;
+
+    std::atomic<bool> running{true};
+    std::thread graph_optimization_thread_;
+    std::mutex opt_mutex_;
+    std::condition_variable opt_cv_;
+    bool do_optimization_ = false;
+    std::function<void()> callback_;
+    GraphOptimizerConfig config_;
+};
+
+// The back end behind the interface: what a maintainer registers instead of G2oOptimizer
+// (graph_slam/src/graph_slam_node.cpp:46).
+class Mi355xOptimizer : public GraphOptimizer {
+public:
+    explicit Mi355xOptimizer(int device = 0);
+    ~Mi355xOptimizer() override;
+    const uzl_pgo_stats& lastStats() const { return stats_; }
+    int lastStatus() const { return status_; }
+
+protected:
+    void addGraphImpl(SlamGraph& graph) override;     // g2o_optimizer.cpp:55-104
+    void storeImpl(SlamGraph& graph) override;        // :106-135
+    void optimizeImpl() override;                     // :137-149
+
+private:
+    uzl_pgo* h_ = nullptr;
+    std::vector<std::string> node_ids_, edge_ids_;    // index <-> string id (the reference's boost::bimap, g2o_optimizer.h:35-36)
+    uzl_pgo_stats stats_{};
+    int status_ = 0;
+    bool applied_xy_ = false;
+};
+
+}  // namespace uzl_adapter

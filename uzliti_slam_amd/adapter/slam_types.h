@@ -1,0 +1,101 @@
+// slam_types.h — minimal stand-ins for the reference's data model, so that the plugin-shaped host classes in
+// this directory compile without ROS / Eigen / OpenCV / boost (none exist in this image).  Member names follow
+//   graph_slam_common/include/graph_slam_common/slam_node.h:89-107   (SlamNode)
+//   graph_slam_common/include/graph_slam_common/slam_edge.h:78-92    (SlamEdge)
+//   graph_slam_common/include/graph_slam_common/sensor_data.h:40-70  (SensorData, FeatureData)
+//   graph_slam_common/include/graph_slam_common/slam_graph.h         (SlamGraph accessors used by the plugins)
+// On a ROS machine these types are the real ones and this header is not used.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace uzl_adapter {
+
+// Eigen::Isometry3d stand-in: top three rows of the 4x4 matrix, row-major [R|t]
+struct Isometry3d {
+    std::array<double, 12> m{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}};
+    static Isometry3d Identity() { return Isometry3d(); }
+};
+
+// graph_slam_msgs/msg/Edge.msg, Features.msg, SensorData.msg constants
+enum { TYPE_2D_WHEEL_ODOMETRY = 0, TYPE_3D_FULL = 1, TYPE_2D_LASER = 2, TYPE_3D_LASER = 3 };
+enum { FEATURE_BRIEF = 1, FEATURE_ORB = 2, FEATURE_BRISK = 3, FEATURE_FREAK = 4 };
+enum { SENSOR_TYPE_FEATURE = 0, SENSOR_TYPE_DEPTH_IMAGE = 1, SENSOR_TYPE_BINARY_GIST = 2, SENSOR_TYPE_LASERSCAN = 3 };
+
+struct SensorData {
+    virtual ~SensorData() = default;
+    int type_ = SENSOR_TYPE_FEATURE;
+    std::string sensor_frame_;
+    Isometry3d displacement_;
+};
+
+struct FeatureData : SensorData {
+    int feature_type_ = FEATURE_ORB;
+    // cv::Mat features_ (CV_8U, rows = keypoints): rows x bytes, row-major
+    std::vector<uint8_t> features_;
+    int rows = 0, bytes_per_row = 0;
+    // Eigen::MatrixXd feature_positions_ (3 x N, column-major)
+    std::vector<double> feature_positions_;
+    std::vector<bool> valid_3d_;
+};
+
+typedef std::shared_ptr<SensorData> SensorDataPtr;
+typedef std::shared_ptr<FeatureData> FeatureDataPtr;
+
+struct SlamNode {
+    std::string id_;
+    Isometry3d pose_;
+    std::vector<SensorDataPtr> sensor_data_;
+    bool fixed_ = false;
+    bool optimized_ = false;
+};
+
+struct SlamEdge {
+    std::string id_, id_from_, id_to_;
+    Isometry3d transform_, displacement_from_, displacement_to_;
+    std::array<double, 36> information_{{1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1}};
+    unsigned char type_ = 0;
+    std::string sensor_from_, sensor_to_;
+    double age_ = 0, error_ = 0, matching_score_ = 0;
+    bool valid_ = false;
+};
+
+// The accessors the two plugin families use (slam_graph.h): ordered by id like the reference's std::map
+class SlamGraph {
+public:
+    void addNode(const SlamNode& n) { nodes_[n.id_] = n; }
+    void addEdge(const SlamEdge& e) { edges_[e.id_] = e; }
+    void addSensor(const std::string& name, const Isometry3d& T) { sensors_[name] = T; }
+    bool existsNode(const std::string& id) const { return nodes_.count(id) != 0; }
+    bool existsEdge(const std::string& id) const { return edges_.count(id) != 0; }
+    SlamNode& node(const std::string& id) { return nodes_.at(id); }
+    SlamEdge& edge(const std::string& id) { return edges_.at(id); }
+    std::map<std::string, SlamNode>& nodes() { return nodes_; }
+    std::map<std::string, SlamEdge>& edges() { return edges_; }
+    std::map<std::string, Isometry3d>& sensors() { return sensors_; }
+
+private:
+    std::map<std::string, SlamNode> nodes_;
+    std::map<std::string, SlamEdge> edges_;
+    std::map<std::string, Isometry3d> sensors_;
+};
+
+// dynamic_reconfigure-generated config structs (cfg/GraphOptimizer.cfg:10-12, cfg/FeatureLinkEstimation.cfg:9-13)
+struct GraphOptimizerConfig {
+    int iterations = 20;
+    bool use_odometry_parameters = false;
+    bool optimize_xy_only = false;
+};
+struct FeatureLinkEstimationConfig {
+    double ransac_threshold = 0.2;
+    double link_covariance = 0.01;
+    int ransac_iteration = 100;
+    double ransac_break_percentage = 0.6;
+    bool use_epnp = true;
+};
+
+}  // namespace uzl_adapter
