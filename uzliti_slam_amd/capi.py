@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuzl_mi355x.so")
+LIB_PATH = os.environ.get("UZL_LIB", os.path.join(_HERE, "libuzl_mi355x.so"))   # UZL_LIB: diagnostic builds only
 CSRC = os.path.join(_HERE, "csrc")
 
 c_f64p = C.POINTER(C.c_double)

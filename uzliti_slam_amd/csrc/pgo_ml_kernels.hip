@@ -15,6 +15,19 @@
 
 namespace uzl {
 
+// Diagnostic build only (-DUZL_STAMPS): where a latency-bound kernel spends its time.  Block 0 / thread 0 adds
+// the 100 MHz s_memrealtime deltas between labelled points into a global table that a test reads back; the
+// table is read by nothing else and no output depends on it.
+#ifdef UZL_STAMPS
+__device__ unsigned long long g_stamps[64];
+#define STAMP_DECL unsigned long long st_prev_ = __builtin_amdgcn_s_memrealtime(); int st_i_ = 0;
+#define STAMP(base) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); \
+        atomicAdd(&g_stamps[(base) + st_i_], n_ - st_prev_); st_prev_ = n_; } st_i_++; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(base) do { } while (0)
+#endif
+
 struct P3 { double X[9], Y[9], Z[9]; };       // P = [[X, Y], [0, Z]]
 
 __device__ __forceinline__ void mat3(const double* A, const double* B, double* C)          // C = A B
@@ -501,6 +514,462 @@ __global__ __launch_bounds__(kMlBlk) void ml_finish_kernel(PgoDev D, const MlDev
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two launches per PCG iteration with the full multilevel preconditioner.
+//
+//   ml_spmv : one workgroup = one level-1 aggregate (8 rows, one wave per row).  beta from the r.z partials,
+//             p = z + beta p_old (own row + recomputed for neighbour columns), Ap, p.Ap partial, and
+//             S1[A] = sum_rows P1^T (Ap)  — the level-1 restriction of Ap.
+//   ml_cg   : one workgroup = one level-2 aggregate (64 rows).  alpha from the p.Ap partials; because
+//             r_new = r - alpha Ap, the restricted residual of EVERY aggregate is r1_old - alpha S1 — no global
+//             pass over r is needed: every workgroup restricts that to level 2.., applies the top inverse and
+//             walks down its own ancestor chain in LDS; then x, r, z for its own 64 rows and the exact r1 of its
+//             own aggregates (so the recursion never accumulates error).  r.z partial -> part_b.
+// All global operands whose address does not depend on alpha/beta are loaded before the partial reduction so
+// that one memory latency covers them (the kernels are latency-, not bandwidth-bound at these sizes).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSpmvBlk = 512;            // 8 waves = 8 rows = one level-1 aggregate
+
+__global__ __launch_bounds__(kSpmvBlk) void ml_spmv_kernel(PgoDev D, MlHot H,
+                                                          const double* __restrict__ p_old, double* __restrict__ p_new,
+                                                          int n_part, double tol2)
+{
+    __shared__ double s8[8];
+    __shared__ double sw[8 * 6];
+    if (D.flags[0]) return;
+    STAMP_DECL
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane / 6, r = lane % 6;
+    const bool lact = lane < 60;
+    const int a = blockIdx.x * kMlFanout + wv;
+    const bool ract = a < D.nb;
+    // ---- prefetch (independent of beta); the r.z partials first: they gate everything else
+    double v = 0.;
+    for (int i = threadIdx.x; i < n_part; i += kSpmvBlk) v += D.part_b[i];
+    int s0 = 0, s1 = 0;
+    if (ract) { s0 = D.row_ptr[a]; s1 = D.row_ptr[a + 1]; }
+    double hrow[6] = {0, 0, 0, 0, 0, 0}, zo[6] = {0, 0, 0, 0, 0, 0}, po[6] = {0, 0, 0, 0, 0, 0}, geo[12];
+    if (ract && g == 0) {
+        const double* __restrict__ h = D.hdiag + (size_t)a * 36 + r * 6;
+        const double* __restrict__ zv = D.z + (size_t)a * 6;
+        const double* __restrict__ pv = p_old + (size_t)a * 6;
+        const double* __restrict__ gg = H.geo0 + (size_t)a * 12;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { hrow[c] = h[c]; zo[c] = zv[c]; po[c] = pv[c]; }
+#pragma unroll
+        for (int c = 0; c < 12; c++) geo[c] = gg[c];
+    }
+    // first two slots of this lane group (rows have ~10 slots: most rows need one pass)
+    double2 b0[2], b1[2], b2[2], z0[2], z1[2], z2[2], o0[2], o1[2], o2[2];
+    bool have[2] = {false, false};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int s = s0 + g + 10 * k;
+        if (ract && lact && s < s1) {
+            const int c = D.col[s];
+            if (c >= 0) {
+                have[k] = true;
+                const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
+                const double2* __restrict__ zv = reinterpret_cast<const double2*>(D.z + (size_t)c * 6);
+                const double2* __restrict__ pv = reinterpret_cast<const double2*>(p_old + (size_t)c * 6);
+                b0[k] = bk[0]; b1[k] = bk[1]; b2[k] = bk[2];
+                z0[k] = zv[0]; z1[k] = zv[1]; z2[k] = zv[2];
+                o0[k] = pv[0]; o1[k] = pv[1]; o2[k] = pv[2];
+            }
+        }
+    }
+    const int it = D.flags[1];
+    const double rz_prev = D.scal[2], thr_old = D.scal[1], lambda = D.scal[3];
+    STAMP(16);     // 16: prefetch issue
+    // ---- beta
+    v = wave_sum(v);
+    if (lane == 0) s8[wv] = v;
+    __syncthreads();
+    const double rz = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    const double beta = (it == 0) ? 0. : rz / rz_prev;
+    const double thresh = (it == 0) ? tol2 * rz : thr_old;
+    STAMP(16);     // 17: partial reduction (prefetch landed)
+    // ---- row product
+    double acc = 0., pr = 0.;
+    if (ract && g == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const double pc = zo[c] + beta * po[c];
+            acc += hrow[c] * pc;
+            if (c == r) pr = pc;
+        }
+        acc += lambda * pr;
+        p_new[(size_t)a * 6 + r] = pr;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (have[k])
+            acc += b0[k].x * (z0[k].x + beta * o0[k].x) + b0[k].y * (z0[k].y + beta * o0[k].y) + b1[k].x * (z1[k].x + beta * o1[k].x) +
+                   b1[k].y * (z1[k].y + beta * o1[k].y) + b2[k].x * (z2[k].x + beta * o2[k].x) + b2[k].y * (z2[k].y + beta * o2[k].y);
+    }
+    if (ract && lact) {
+        for (int s = s0 + g + 20; s < s1; s += 10) {
+            const int c = D.col[s];
+            if (c >= 0) {
+                const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
+                const double2* __restrict__ zv = reinterpret_cast<const double2*>(D.z + (size_t)c * 6);
+                const double2* __restrict__ pv = reinterpret_cast<const double2*>(p_old + (size_t)c * 6);
+                const double2 c0 = bk[0], c1 = bk[1], c2 = bk[2], y0 = zv[0], y1 = zv[1], y2 = zv[2], q0 = pv[0], q1 = pv[1], q2 = pv[2];
+                acc += c0.x * (y0.x + beta * q0.x) + c0.y * (y0.y + beta * q0.y) + c1.x * (y1.x + beta * q1.x) +
+                       c1.y * (y1.y + beta * q1.y) + c2.x * (y2.x + beta * q2.x) + c2.y * (y2.y + beta * q2.y);
+            }
+        }
+    }
+    double t;
+    t = __shfl_down(acc, 48); if (lane + 48 < 60) acc += t;
+    t = __shfl_down(acc, 24); if (lane + 24 < 48) acc += t;
+    t = __shfl_down(acc, 12); if (lane + 12 < 24) acc += t;
+    t = __shfl_down(acc, 6);  if (lane + 6 < 12) acc += t;
+    STAMP(16);     // 18: row product + fold
+    // lanes 0..5 hold Ap[a][0..5]
+    double dot = 0., w = 0.;
+    if (ract && lane < 6) {
+        D.ap[(size_t)a * 6 + r] = acc;
+        dot = acc * pr;
+    }
+    // (P1_a^T Ap_a)[r] needs all six components of the row: broadcast within lanes 0..5
+    const double t0 = __shfl(acc, 0), t1 = __shfl(acc, 1), t2 = __shfl(acc, 2);
+    const double q0 = __shfl(acc, 3), q1 = __shfl(acc, 4), q2 = __shfl(acc, 5);
+    if (ract && lane < 6) {
+        const double u0 = geo[0] * t0 + geo[3] * t1 + geo[6] * t2;
+        const double u1 = geo[1] * t0 + geo[4] * t1 + geo[7] * t2;
+        const double u2 = geo[2] * t0 + geo[5] * t1 + geo[8] * t2;
+        if (r < 3) w = (r == 0) ? u0 : (r == 1) ? u1 : u2;
+        else {
+            const int k = r - 3;
+            const double rq = 0.5 * (geo[k] * q0 + geo[3 + k] * q1 + geo[6 + k] * q2);
+            const double dx = geo[9], dy = geo[10], dz = geo[11];
+            const double cr = (k == 0) ? dy * u2 - dz * u1 : (k == 1) ? dz * u0 - dx * u2 : dx * u1 - dy * u0;
+            w = cr + rq;
+        }
+    }
+    dot = wave_sum(dot);                       // lanes >= 6 hold 0
+    __syncthreads();                           // s8 reuse
+    if (lane < 6) sw[wv * 6 + lane] = w;
+    if (lane == 0) s8[wv] = dot;
+    __syncthreads();
+    if (tid < 6) {
+        double s = 0.;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += sw[k * 6 + tid];
+        H.S1[(size_t)blockIdx.x * 6 + tid] = s;
+    }
+    if (tid == 0) {
+        D.part_a[blockIdx.x] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        if (blockIdx.x == 0) {
+            D.scal[0] = rz;
+            if (it == 0) D.scal[1] = thresh;
+            if (!(rz > thresh)) D.flags[0] = 1;
+        }
+    }
+    STAMP(16);     // 19: S1 + partial stores
+#ifdef UZL_STAMPS
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_stamps[47], 1ull);
+#endif
+}
+
+// init = 1: first application (r = b already stored, exact r1 in r1_old): only the preconditioner part runs.
+// r1_old / r1_new: the level-1 residual is double-buffered like p (other workgroups read r1_old while the owner
+// writes the exact r1_new of its aggregates).
+// Dynamic LDS (doubles): res[levels 2..L] | geo[levels 2..L-1] | top rows | own-chain Dinv+geo |
+//                        level-1 chunk: r (6 x kL1Chunk) + geo (3 x kL1Chunk)          (ml_cg_lds_bytes)
+// Level 1 is streamed through the chunk buffer (bounded LDS for any graph size); its first chunk is loaded into
+// registers before the alpha reduction, so one memory latency covers every operand of the kernel.
+constexpr int kStageU = 4;               // loads in flight per thread per staging batch
+// batched global -> LDS copy: kStageU independent loads per thread are issued before the first store
+__device__ __forceinline__ void stage_to_lds(const double* __restrict__ src, double* dst, int n)
+{
+    for (int base = 0; base < n; base += kStageU * kMlBlk) {
+        double v[kStageU];
+#pragma unroll
+        for (int u = 0; u < kStageU; u++) { const int t = base + u * kMlBlk + (int)threadIdx.x; v[u] = (t < n) ? src[t] : 0.; }
+#pragma unroll
+        for (int u = 0; u < kStageU; u++) { const int t = base + u * kMlBlk + (int)threadIdx.x; if (t < n) dst[t] = v[u]; }
+    }
+}
+
+constexpr int kL1Chunk = 1280;                       // level-1 aggregates per chunk (multiple of 8): 10240 vertices
+constexpr int kL1RU = (6 * kL1Chunk + kMlBlk - 1) / kMlBlk;      // 20 residual values per thread
+constexpr int kL1GU = (3 * kL1Chunk + kMlBlk - 1) / kMlBlk;      // 10 offsets per thread
+
+__global__ __launch_bounds__(kMlBlk) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
+                                                      const double* __restrict__ r1_old, double* __restrict__ r1_new,
+                                                      int n_part, int init)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    __shared__ double s6[6];
+    __shared__ double sv[kMlBlk];
+    __shared__ double sw[kMlBlk];
+    __shared__ double sr1[kAggPerBlk * 6];
+    __shared__ double sy[kAggPerBlk * 6];
+    __shared__ double syc[6];
+    if (D.flags[0]) return;
+    STAMP_DECL
+    const int tid = threadIdx.x;
+    const int Lt = H.levels;
+    const int a = blockIdx.x * kRowsPerBlk + tid / 6, r = tid % 6;
+    const bool act = a < D.nb;
+    const int n1 = H.n[1];
+    const int ntop = 6 * H.n[Lt];
+    // ---- LDS carve-up
+    int roff[kMlMaxLevels + 2], goff[kMlMaxLevels + 2], anc[kMlMaxLevels + 2];
+    int o = 0;
+    for (int l = 2; l <= Lt; l++) { roff[l] = o; o += 6 * H.n[l]; }
+    for (int l = 2; l < Lt; l++) { goff[l] = o; o += 3 * H.n[l]; }
+    const int top_off = o;
+    const int n_top_rows = (Lt == 1) ? kAggPerBlk * 6 : 6;
+    o += n_top_rows * ntop;
+    const int chain_off = o;                                  // (L-2) x 39
+    if (Lt > 2) o += (Lt - 2) * 39;
+    const int c1r = o;                                        // level-1 chunk: residual estimate
+    const int c1g = c1r + 6 * kL1Chunk;                       //                children offsets
+    anc[2] = blockIdx.x;
+    for (int l = 3; l <= Lt; l++) anc[l] = anc[l - 1] / kMlFanout;
+    STAMP(0);      // 0: entry
+    // ---- every global load whose address is known now, before any barrier
+    double part = 0.;
+    if (!init) for (int i = tid; i < n_part; i += kMlBlk) part += D.part_a[i];
+    double xv = 0., rv0 = 0., apv = 0., pv = 0., mrow[6] = {0, 0, 0, 0, 0, 0}, geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (act) {
+        const size_t i = (size_t)a * 6 + r;
+        rv0 = D.r[i];
+        if (!init) { xv = D.x[i]; apv = D.ap[i]; pv = p[i]; }
+        const double* __restrict__ m = D.minv + (size_t)a * 36 + r * 6;
+        const double* __restrict__ gg = H.geo0 + (size_t)a * 12;
+#pragma unroll
+        for (int c = 0; c < 6; c++) mrow[c] = m[c];
+#pragma unroll
+        for (int c = 0; c < 12; c++) geo[c] = gg[c];
+    }
+    double d1row[6] = {0, 0, 0, 0, 0, 0}, g1own[3] = {0, 0, 0};
+    const int A1 = blockIdx.x * kAggPerBlk + tid / 6;
+    if (Lt >= 2 && tid < kAggPerBlk * 6 && A1 < n1) {
+        const double* di = H.Dinv[1] + (size_t)A1 * 36 + (tid % 6) * 6;
+#pragma unroll
+        for (int c = 0; c < 6; c++) d1row[c] = di[c];
+        const double* gq = H.geo[1] + (size_t)A1 * 3;
+        g1own[0] = gq[0]; g1own[1] = gq[1]; g1own[2] = gq[2];
+    }
+    const double rz = init ? 0. : D.scal[0];
+    // first level-1 chunk into registers
+    double r1reg[kL1RU], s1reg[kL1RU], g1reg[kL1GU];
+    const int ch_n = n1 < kL1Chunk ? n1 : kL1Chunk;
+#pragma unroll
+    for (int u = 0; u < kL1RU; u++) {
+        const int t = u * kMlBlk + tid;
+        r1reg[u] = (t < 6 * ch_n) ? r1_old[t] : 0.;
+        s1reg[u] = (!init && t < 6 * ch_n) ? H.S1[t] : 0.;
+    }
+#pragma unroll
+    for (int u = 0; u < kL1GU; u++) {
+        const int t = u * kMlBlk + tid;
+        g1reg[u] = (Lt >= 2 && t < 3 * ch_n) ? H.geo[1][t] : 0.;
+    }
+    // small arrays: upper-level offsets, top-inverse rows, own-chain blocks (a handful of values per thread)
+    for (int l = 2; l < Lt; l++) stage_to_lds(H.geo[l], dyn + goff[l], 3 * H.n[l]);
+    for (int t = tid; t < n_top_rows * ntop; t += kMlBlk) {
+        const int rr = t / ntop, c = t % ntop;
+        const int grow = (Lt == 1) ? (blockIdx.x * kAggPerBlk * 6 + rr) : (6 * anc[Lt] + rr);
+        dyn[top_off + t] = (grow < ntop) ? H.top_inv[(size_t)grow * ntop + c] : 0.;
+    }
+    for (int l = 2; l < Lt; l++) {
+        if (tid < 39)
+            dyn[chain_off + (l - 2) * 39 + tid] = (tid < 36) ? H.Dinv[l][(size_t)anc[l] * 36 + tid] : H.geo[l][(size_t)anc[l] * 3 + (tid - 36)];
+    }
+    STAMP(0);      // 1: prefetch issue
+    double alpha = 0.;
+    bool bad = false;
+    if (!init) {
+        const double pAp = block_sum6(part, s6);                          // barrier: everything above has landed
+        bad = !(pAp > 0.);
+        alpha = bad ? 0. : rz / pAp;
+    }
+    STAMP(0);      // 2: partial reduction
+    // ---- level 1 -> level 2 (or, when level 1 is the top level, straight into the top residual), chunk by chunk
+    for (int cb = 0; cb < n1; cb += kL1Chunk) {
+        const int cn = (n1 - cb < kL1Chunk) ? n1 - cb : kL1Chunk;
+        if (cb > 0) {          // later chunks (graphs > 10k free vertices): loaded here, latency exposed
+#pragma unroll
+            for (int u = 0; u < kL1RU; u++) {
+                const int t = u * kMlBlk + tid;
+                r1reg[u] = (t < 6 * cn) ? r1_old[(size_t)6 * cb + t] : 0.;
+                s1reg[u] = (!init && t < 6 * cn) ? H.S1[(size_t)6 * cb + t] : 0.;
+            }
+#pragma unroll
+            for (int u = 0; u < kL1GU; u++) {
+                const int t = u * kMlBlk + tid;
+                g1reg[u] = (Lt >= 2 && t < 3 * cn) ? H.geo[1][(size_t)3 * cb + t] : 0.;
+            }
+            __syncthreads();   // previous chunk fully consumed
+        }
+        double* dst_r = (Lt == 1) ? (dyn + top_off + n_top_rows * ntop) : (dyn + c1r);   // L == 1: r1 IS the top residual
+#pragma unroll
+        for (int u = 0; u < kL1RU; u++) {
+            const int t = u * kMlBlk + tid;
+            if (t < 6 * cn) dst_r[t] = r1reg[u] - alpha * s1reg[u];
+        }
+#pragma unroll
+        for (int u = 0; u < kL1GU; u++) {
+            const int t = u * kMlBlk + tid;
+            if (Lt >= 2 && t < 3 * cn) dyn[c1g + t] = g1reg[u];
+        }
+        __syncthreads();
+        if (Lt >= 2) {
+            const int p0 = cb / kMlFanout, nPc = (cn + kMlFanout - 1) / kMlFanout;
+            const int tasks = nPc * 6 * kMlFanout;
+            for (int t0 = 0; t0 < tasks; t0 += kMlBlk) {
+                const int t = t0 + tid;
+                const int j = t & 7, ak = t >> 3;
+                const int A = ak / 6, k = ak % 6;
+                const int c = A * kMlFanout + j;
+                double sacc = 0.;
+                if (t < tasks && c < cn) sacc = restrict_comp(dyn + c1g + c * 3, dyn + c1r + c * 6, k);
+                sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
+                if (t < tasks && j == 0) dyn[roff[2] + p0 * 6 + ak] = sacc;
+            }
+        }
+    }
+    __syncthreads();
+    STAMP(0);      // 3: level-1 fold + restriction
+    // ---- restrict up to the top level: 8 lanes per (parent, component), one child each, xor-shuffle fold
+    for (int l = 3; l <= Lt; l++) {
+        const int nC = H.n[l - 1], nP = H.n[l];
+        const int tasks = nP * 6 * kMlFanout;
+        for (int t0 = 0; t0 < tasks; t0 += kMlBlk) {
+            const int t = t0 + tid;
+            const int j = t & 7, ak = t >> 3;
+            const int A = ak / 6, k = ak % 6;
+            const int c = A * kMlFanout + j;
+            double sacc = 0.;
+            if (t < tasks && c < nC) sacc = restrict_comp(dyn + goff[l - 1] + c * 3, dyn + roff[l - 1] + c * 6, k);
+            sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
+            if (t < tasks && j == 0) dyn[roff[l] + ak] = sacc;
+        }
+        __syncthreads();
+    }
+    const double* rtop = (Lt == 1) ? (dyn + top_off + n_top_rows * ntop) : (dyn + roff[Lt]);
+    if (Lt == 1) {
+        if (tid < kAggPerBlk * 6) {
+            double sacc = 0.;
+            for (int c = 0; c < ntop; c++) sacc += dyn[top_off + tid * ntop + c] * rtop[c];
+            sy[tid] = (A1 < n1) ? sacc : 0.;
+        }
+    } else {
+        {   // 8 lanes per top row
+            const int row = tid >> 3, j = tid & 7;
+            double sacc = 0.;
+            if (row < 6) for (int c = j; c < ntop; c += 8) sacc += dyn[top_off + row * ntop + c] * rtop[c];
+            sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
+            if (row < 6 && j == 0) syc[row] = sacc;
+        }
+        __syncthreads();
+        for (int l = Lt - 1; l >= 2; l--) {
+            double sacc = 0.;
+            if (tid < 6) {
+                const double* ch = dyn + chain_off + (l - 2) * 39;
+                const double* rr = dyn + roff[l] + anc[l] * 6;
+#pragma unroll
+                for (int c = 0; c < 6; c++) sacc += ch[tid * 6 + c] * rr[c];
+                sacc += prolong_comp(ch + 36, syc, tid);
+            }
+            __syncthreads();
+            if (tid < 6) syc[tid] = sacc;
+            __syncthreads();
+        }
+    }
+    STAMP(0);      // 4: restrict + top + down chain
+    // ---- own rows: x, r, block-Jacobi part, exact r1 of the own aggregates
+    double rv = rv0;
+    if (act && !init) {
+        const size_t i = (size_t)a * 6 + r;
+        rv = rv0 - alpha * apv;
+        D.x[i] = xv + alpha * pv;
+        D.r[i] = rv;
+    }
+    sv[tid] = act ? rv : 0.;
+    __syncthreads();
+    double zz = 0., w = 0.;
+    if (act) {
+        const int g0 = tid - r;
+#pragma unroll
+        for (int c = 0; c < 6; c++) zz += mrow[c] * sv[g0 + c];
+        const double t0 = sv[g0], t1 = sv[g0 + 1], t2 = sv[g0 + 2];
+        const double u0 = geo[0] * t0 + geo[3] * t1 + geo[6] * t2;
+        const double u1 = geo[1] * t0 + geo[4] * t1 + geo[7] * t2;
+        const double u2 = geo[2] * t0 + geo[5] * t1 + geo[8] * t2;
+        if (r < 3) w = (r == 0) ? u0 : (r == 1) ? u1 : u2;
+        else {
+            const double q0 = sv[g0 + 3], q1 = sv[g0 + 4], q2 = sv[g0 + 5];
+            const int k = r - 3;
+            const double rq = 0.5 * (geo[k] * q0 + geo[3 + k] * q1 + geo[6 + k] * q2);
+            const double dx = geo[9], dy = geo[10], dz = geo[11];
+            const double cr = (k == 0) ? dy * u2 - dz * u1 : (k == 1) ? dz * u0 - dx * u2 : dx * u1 - dy * u0;
+            w = cr + rq;
+        }
+    }
+    sw[tid] = w;
+    __syncthreads();
+    STAMP(0);      // 5: x, r, zJ, w
+    if (tid < kAggPerBlk * 6) {
+        const int la = tid / 6, k = tid % 6;
+        double s = 0.;
+#pragma unroll
+        for (int j = 0; j < kMlFanout; j++) s += sw[(la * kMlFanout + j) * 6 + k];
+        sr1[tid] = s;
+        if (A1 < n1) r1_new[(size_t)A1 * 6 + k] = s;                       // exact, for the next iteration's recursion
+    }
+    __syncthreads();
+    STAMP(0);      // 6: exact r1
+    if (Lt >= 2 && tid < kAggPerBlk * 6) {
+        // y1 = D1^-1 r1 + P2 y2
+        const int la = tid / 6, k = tid % 6;
+        double s = 0.;
+        if (A1 < n1) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) s += d1row[c] * sr1[la * 6 + c];
+            s += prolong_comp(g1own, syc, k);
+        }
+        sy[tid] = s;
+    }
+    __syncthreads();
+    double acc = 0.;
+    if (act) {
+        const double* y = sy + ((tid / 6) / kMlFanout) * 6;
+        double add;
+        if (r < 3) {
+            const double dx = geo[9], dy = geo[10], dz = geo[11];
+            const double vx = y[0] + (y[4] * dz - y[5] * dy);
+            const double vy = y[1] + (y[5] * dx - y[3] * dz);
+            const double vz = y[2] + (y[3] * dy - y[4] * dx);
+            add = geo[r * 3] * vx + geo[r * 3 + 1] * vy + geo[r * 3 + 2] * vz;
+        } else {
+            const int k = r - 3;
+            add = 0.5 * (geo[k * 3] * y[3] + geo[k * 3 + 1] * y[4] + geo[k * 3 + 2] * y[5]);
+        }
+        zz += add;
+        D.z[(size_t)a * 6 + r] = zz;
+        acc = rv * zz;
+    }
+    STAMP(0);      // 7: y1, z
+    const double tot = block_sum6(acc, s6);
+    if (tid == 0) {
+        D.part_b[blockIdx.x] = tot;
+        if (blockIdx.x == 0 && !init) {
+            D.scal[2] = rz;
+            D.flags[1] += 1;
+            if (bad) { D.flags[0] = 1; D.flags[2] = 1; }
+        }
+    }
+    STAMP(0);      // 8: block sum + stores
+#ifdef UZL_STAMPS
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_stamps[31], 1ull);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, int n_l, hipStream_t s)
@@ -523,12 +992,10 @@ void k_ml_invert(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s
 }
 int g_ml_rows(int nb) { return (nb + kRowsPerBlk - 1) / kRowsPerBlk; }
 // the fused finish kernel stages the residuals of levels >= min(2, L) in LDS
+size_t ml_cg_lds_bytes(const int* n, int levels);
 bool ml_fits_lds(const int* n_per_level, int levels)
 {
-    const int g = levels >= 2 ? 2 : 1;
-    long tot = 0;
-    for (int l = g; l <= levels; l++) tot += 6L * n_per_level[l];
-    return tot <= kCoarseLdsDoubles && g_ml_rows(n_per_level[0]) <= kMaxPartials;
+    return ml_cg_lds_bytes(n_per_level, levels) <= 140 * 1024 && (n_per_level[0] + kMlFanout - 1) / kMlFanout <= kMaxPartials;
 }
 void k_ml_update(const PgoDev& D, const MlDev* ml, const double* p, double* p0, double* p1, int n_part, int init, hipStream_t s)
 {
@@ -538,5 +1005,43 @@ void k_ml_finish(const PgoDev& D, const MlDev* ml, hipStream_t s)
 {
     hipLaunchKernelGGL(ml_finish_kernel, dim3(g_ml_rows(D.nb)), dim3(kMlBlk), 0, s, D, ml);
 }
+int g_ml_spmv(int nb) { return (nb + kMlFanout - 1) / kMlFanout; }
+void k_ml_spmv(const PgoDev& D, const MlHot& ml, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s)
+{
+    hipLaunchKernelGGL(ml_spmv_kernel, dim3(g_ml_spmv(D.nb)), dim3(kSpmvBlk), 0, s, D, ml, p_old, p_new, n_part, tol2);
+}
+// dynamic LDS of ml_cg_kernel for a hierarchy (n_per_level[0..levels])
+size_t ml_cg_lds_bytes(const int* n, int levels)
+{
+    size_t d = 0;
+    for (int l = 2; l <= levels; l++) d += 6 * (size_t)n[l];
+    for (int l = 2; l < levels; l++) d += 3 * (size_t)n[l];
+    const size_t ntop = 6 * (size_t)n[levels];
+    d += ((levels == 1) ? (size_t)kAggPerBlk * 6 : 6) * ntop;
+    if (levels > 2) d += (size_t)(levels - 2) * 39;
+    d += (levels == 1) ? ntop : (size_t)9 * kL1Chunk;            // level-1 chunk buffer (L == 1: r1 = top residual)
+    return d * 8;
+}
+hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, const double* p, const double* r1_old, double* r1_new, int n_part,
+                   int init, size_t lds, hipStream_t s)
+{
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ml_cg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(ml_cg_kernel, dim3(g_ml_rows(D.nb)), dim3(kMlBlk), lds, s, D, ml, p, r1_old, r1_new, n_part, init);
+    return hipSuccess;
+}
 
 }  // namespace uzl
+
+#ifdef UZL_STAMPS
+extern "C" int uzl_debug_read_stamps(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(uzl::g_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(uzl::g_stamps), z, sizeof(z)) != hipSuccess) return -3; }
+    return 0;
+}
+#endif

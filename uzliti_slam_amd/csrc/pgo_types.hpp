@@ -91,6 +91,19 @@ struct MlDev {
     double* tmpG;              // [max n][36]
     double* tmpM;              // [max n][36]
     double* top_inv;           // [(6 n_top)^2] dense inverse of A_L(lambda)
+    double* S1;                // [n_1][6] level-1 restriction of A p (written by ml_spmv)
+};
+
+// Hot subset of MlDev passed BY VALUE to the per-iteration kernels (kernel arguments are preloaded; going
+// through the MlDev pointer costs one extra dependent scalar-load round trip per first use).
+struct MlHot {
+    int32_t levels;
+    int32_t n[kMlMaxLevels + 1];
+    const double* geo0;                    // [nb][12]
+    const double* geo[kMlMaxLevels + 1];   // [n_l][3], l >= 1
+    const double* Dinv[kMlMaxLevels + 1];  // [n_l][36], 1 <= l < levels
+    const double* top_inv;
+    double* S1;
 };
 
 // scalars copied back to the host after each LM trial / PCG chunk

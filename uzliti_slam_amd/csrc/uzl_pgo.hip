@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <limits>
 #include <new>
@@ -39,6 +40,10 @@ int g_ml_rows(int nb);
 void k_ml_update(const PgoDev& D, const MlDev* ml, const double* p, double* p0, double* p1, int n_part, int init, hipStream_t s);
 bool ml_fits_lds(const int* n_per_level, int levels);
 void k_ml_finish(const PgoDev& D, const MlDev* ml, hipStream_t s);
+int g_ml_spmv(int nb);
+void k_ml_spmv(const PgoDev& D, const MlHot& ml, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
+size_t ml_cg_lds_bytes(const int* n, int levels);
+hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, const double* p, const double* r1_old, double* r1_new, int n_part, int init, size_t lds, hipStream_t s);
 int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
@@ -77,8 +82,12 @@ struct uzl_pgo {
     int ml_levels = 0;
     std::vector<int32_t> ml_n, ml_nslots;
     int ml_inner_aggs = 0;
+    double* ml_r1[2] = {nullptr, nullptr};     // double-buffered level-1 residual
+    size_t ml_lds = 0;
+    MlHot ml_hot;
     DevBuf<uint8_t> ml_arena;
     DevBuf<MlDev> d_ml;
+    bool no_graph = false;          // UZL_NO_GRAPH=1: eager launches (rocprofv3 --kernel-trace crashes on hipGraphLaunch here)
     hipGraph_t pcg_graph = nullptr;
     hipGraphExec_t pcg_graph_exec = nullptr;
     // shard (BASELINE config 4)
@@ -182,6 +191,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     while (h->ml_n.back() > kMlTopMax && L < kMlMaxLevels) { h->ml_n.push_back((h->ml_n.back() + kMlFanout - 1) / kMlFanout); L++; }
     if (!ml_fits_lds(h->ml_n.data(), L)) { h->ml_n.assign(1, nb); return; }     // > ~70k free vertices: block-Jacobi
     h->ml_levels = L;
+    h->ml_lds = ml_cg_lds_bytes(h->ml_n.data(), L);
     // per-level host index arrays
     struct Lv { std::vector<int32_t> row_ptr, col, srow, tpos, off_ptr, diag_ptr; int32_t n_off = 0; };
     std::vector<Lv> lv((size_t)L + 1);
@@ -256,6 +266,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     }
     const size_t o_tmp = take(max_contrib * 36 * 8), o_tmpG = take(max_n * 36 * 8), o_tmpM = take(max_n * 36 * 8);
     const size_t o_top = take((size_t)(6 * kMlTopMax) * (6 * kMlTopMax) * 8);
+    const size_t o_s1 = take((size_t)std::max(h->ml_n[1], 1) * 6 * 8);
+    const size_t o_r1b = take((size_t)std::max(h->ml_n[1], 1) * 6 * 8);
     h->ml_arena.reserve(bytes);
     std::vector<uint8_t> stage(int_bytes, 0);
     auto put = [&](size_t o, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage.data() + o, v.data(), v.size() * 4); };
@@ -292,6 +304,14 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     M.tmpG = reinterpret_cast<double*>(base + o_tmpG);
     M.tmpM = reinterpret_cast<double*>(base + o_tmpM);
     M.top_inv = reinterpret_cast<double*>(base + o_top);
+    M.S1 = reinterpret_cast<double*>(base + o_s1);
+    h->ml_r1[0] = M.lv[1].r;
+    h->ml_r1[1] = reinterpret_cast<double*>(base + o_r1b);
+    MlHot& Hh = h->ml_hot;
+    memset(&Hh, 0, sizeof(Hh));
+    Hh.levels = L;
+    for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.geo[l] = M.lv[l].geo; Hh.Dinv[l] = M.lv[l].Dinv; }
+    Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.S1 = M.S1;
     h->d_ml.reserve(1);
     UZL_HIP(hipMemcpyAsync(h->d_ml.p, &M, sizeof(M), hipMemcpyHostToDevice, s));
     UZL_HIP(hipStreamSynchronize(s));      // stage / M are locals
@@ -376,25 +396,16 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
     const PgoDev& D = h->D;
     const double tol2 = h->cfg.pcg_tol * h->cfg.pcg_tol;
     const bool ml = h->ml_levels > 0;
-    const int ga = g_pcg_spmv(D.nb), gu = ml ? g_ml_rows(D.nb) : g_pcg_update(D.nb);
+    const int ga = ml ? g_ml_spmv(D.nb) : g_pcg_spmv(D.nb), gu = ml ? g_ml_rows(D.nb) : g_pcg_update(D.nb);
     double* pb[2] = {h->d_p.p, h->d_p2.p};
     for (int i = 0; i < 2 * pairs; i++) {
         double* po = pb[i & 1];
         double* pn = pb[(i & 1) ^ 1];
         if (timed) h->timer.begin("pcg_spmv", s);
-        k_pcg_spmv(D, po, pn, gu, tol2, s);
+        if (ml) k_ml_spmv(D, h->ml_hot, po, pn, gu, tol2, s); else k_pcg_spmv(D, po, pn, gu, tol2, s);
+        if (timed) { h->timer.end(s); h->timer.begin(ml ? "ml_cg" : "pcg_update", s); }
+        if (ml) UZL_HIP(k_ml_cg(D, h->ml_hot, pn, h->ml_r1[i & 1], h->ml_r1[(i & 1) ^ 1], ga, 0, h->ml_lds, s)); else k_pcg_update(D, pn, ga, s);
         if (timed) h->timer.end(s);
-        if (ml) {
-            if (timed) h->timer.begin("ml_update", s);
-            k_ml_update(D, h->d_ml.p, pn, pb[0], pb[1], ga, 0, s);
-            if (timed) { h->timer.end(s); h->timer.begin("ml_finish", s); }
-            k_ml_finish(D, h->d_ml.p, s);
-            if (timed) h->timer.end(s);
-        } else {
-            if (timed) h->timer.begin("pcg_update", s);
-            k_pcg_update(D, pn, ga, s);
-            if (timed) h->timer.end(s);
-        }
     }
 }
 
@@ -423,12 +434,12 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     hipStream_t s = h->stream;
     const PgoDev& D = h->D;
     const int max_it = h->cfg.pcg_max_iter > 0 ? h->cfg.pcg_max_iter : 6 * std::max(h->nb, 1);
-    const bool timed = h->timer.on;                       // per-kernel events need eager launches
+    const bool timed = h->timer.on || h->no_graph;        // per-kernel events (and rocprofv3) need eager launches
     { Timed t(h, "precond"); k_precond(D, s); }
     if (h->ml_levels > 0) {
         { Timed t(h, "ml_invert"); k_ml_invert(D, h->d_ml.p, h->ml_inner_aggs, s); }
         { Timed t(h, "pcg_init"); k_ml_update(D, h->d_ml.p, h->d_p.p, h->d_p.p, h->d_p2.p, 0, 1, s); }
-        { Timed t(h, "ml_finish"); k_ml_finish(D, h->d_ml.p, s); }
+        { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, h->ml_hot, h->d_p.p, h->ml_r1[0], h->ml_r1[0], 0, 1, h->ml_lds, s)); }
     } else {
         Timed t(h, "pcg_init"); k_pcg_init(D, h->d_p.p, h->d_p2.p, s);
     }
@@ -440,7 +451,7 @@ int pcg_solve(uzl_pgo* h, bool* converged)
         want = std::min(want, max_it - launched);
         const int reps = std::max(1, (want + 2 * kGraphPairs - 1) / (2 * kGraphPairs));
         for (int i = 0; i < reps; i++) {
-            if (timed) enqueue_pcg_pairs(h, kGraphPairs, true);
+            if (timed) enqueue_pcg_pairs(h, kGraphPairs, h->timer.on);
             else UZL_HIP(hipGraphLaunch(h->pcg_graph_exec, s));
         }
         launched += reps * 2 * kGraphPairs;
@@ -589,6 +600,7 @@ int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
     if (!h) return UZL_ERR_OOM;
     h->cfg = c;
     memset(&h->D, 0, sizeof(h->D));
+    { const char* ng = getenv("UZL_NO_GRAPH"); h->no_graph = ng && ng[0] == '1'; }
     if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return UZL_ERR_HIP;
