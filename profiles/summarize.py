@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Condenses a profiles/collect.sh run into small committed files:
+   <out>_kernel_stats.csv  (rocprofv3 --kernel-trace --stats, verbatim)
+   <out>_pmc.json          (per kernel: launches, mean FETCH_SIZE / WRITE_SIZE in KB, HBM-side bytes per launch with
+                            the gfx950 correction FETCH x2 for 16-B/lane streaming reads, MI355X_MICROARCH.md §HBM)
+   profiles/traffic.json   (bytes per launch of the two roofline kernels; read by bench.py)"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+src, out = sys.argv[1], sys.argv[2]
+ks = glob.glob(f"{src}/trace/*/*kernel_stats.csv")
+if ks:
+    shutil.copy(ks[0], out + "_kernel_stats.csv")
+pmc = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = glob.glob(f"{src}/{c}/*/*counter_collection.csv")
+    if not fs:
+        continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != c:
+            continue
+        v = float(r["Counter_Value"])
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        # launches that exit at the `done` flag move (almost) nothing: keep them out of the per-launch mean
+        if v < 1.0 and ("ml_" in k or "pcg_" in k):
+            continue
+        agg[k][0] += 1
+        agg[k][1] += v
+    for k, (n, v) in agg.items():
+        pmc.setdefault(k, {})[c] = dict(launches=n, mean_kb=v / max(n, 1))
+for k, d in pmc.items():
+    f = d.get("FETCH_SIZE", {}).get("mean_kb", 0.0)
+    w = d.get("WRITE_SIZE", {}).get("mean_kb", 0.0)
+    d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
+json.dump(pmc, open(out + "_pmc.json", "w"), indent=1, sort_keys=True)
+t = {}
+for key, names in (("pcg_spmv_bytes_per_launch", ("uzl::ml_spmv_kernel", "uzl::pcg_spmv_kernel")),
+                   ("knn2_bytes_per_launch", ("uzl::knn2_kernel<8>",))):
+    for nm in names:
+        if nm in pmc:
+            t[key] = pmc[nm]["hbm_bytes_per_launch"]
+            break
+json.dump(t, open("profiles/traffic.json", "w"), indent=1)
+print(json.dumps(t))

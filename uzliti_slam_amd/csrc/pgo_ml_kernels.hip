@@ -9,8 +9,7 @@
 // Per linearisation : geometry (centroids, P), Galerkin products A_{l+1} = P^T A_l P level by level
 //                     (transform -> contribution array -> ordered reduce: deterministic, no atomics)
 // Per LM trial      : D_l(lambda)^-1 = (G_l + lambda M_l)^-1, dense inverse of the <= 48-dof top level
-// Per PCG iteration : pcg_spmv -> ml_update (x, r, D0^-1 r, r1 = P1^T r, r2 = P2^T r1)
-//                     -> ml_finish (levels >= 2 in LDS by every workgroup, z += P1 y1, r.z partials)
+// Per PCG iteration : ml_spmv (p, A p, restricted A p) -> ml_cg (alpha, coarse chain in LDS, x, r, z)
 #include "pgo_device.hpp"
 
 namespace uzl {
@@ -105,11 +104,9 @@ __device__ __forceinline__ void galerkin(const P3& L, const double* __restrict__
         }
 }
 
-// number of level-0 blocks under entity i of level l
-__device__ __forceinline__ int leaves_under(int l, int i, int nb)
+// number of level-0 blocks under entity i of a level whose aggregates span `span` blocks
+__device__ __forceinline__ int leaves_under(int span, int i, int nb)
 {
-    int span = 1;
-    for (int k = 0; k < l; k++) span *= kMlFanout;
     const int lo = i * span;
     const int hi = lo + span < nb ? lo + span : nb;
     return hi > lo ? hi - lo : 0;
@@ -123,7 +120,8 @@ __global__ __launch_bounds__(kBlk) void ml_geometry_kernel(PgoDev D, const MlDev
     const int A = blockIdx.x * kBlk + threadIdx.x;
     const int n = ml.lv[l].n, nc = ml.lv[l - 1].n;
     if (A >= n) return;
-    const int c0 = A * kMlFanout, c1 = (c0 + kMlFanout < nc) ? c0 + kMlFanout : nc;
+    const int fan = ml.lv[l].fan;
+    const int c0 = A * fan, c1 = (c0 + fan < nc) ? c0 + fan : nc;
     double cx = 0, cy = 0, cz = 0, wsum = 0;
     for (int c = c0; c < c1; c++) {
         double px, py, pz, w;
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(kBlk) void ml_geometry_kernel(PgoDev D, const MlDev
             px = P.t.x; py = P.t.y; pz = P.t.z; w = 1.;
         } else {
             const double* cc = ml.lv[l - 1].cen + (size_t)c * 3;
-            px = cc[0]; py = cc[1]; pz = cc[2]; w = (double)leaves_under(l - 1, c, D.nb);
+            px = cc[0]; py = cc[1]; pz = cc[2]; w = (double)leaves_under(ml.lv[l - 1].span, c, D.nb);
         }
         cx += w * px; cy += w * py; cz += w * pz; wsum += w;
     }
@@ -208,7 +206,7 @@ __global__ __launch_bounds__(kBlk) void ml_reduce_kernel(const MlDev* __restrict
         const int A = blk_id - L.nslots;
         double s = 0., m = 0.;
         for (int q = L.diag_ptr[A]; q < L.diag_ptr[A + 1]; q++) s += ml.tmp[(size_t)(L.n_off_contrib + q) * 36 + k];
-        const int c0 = A * kMlFanout, c1 = (c0 + kMlFanout < nc) ? c0 + kMlFanout : nc;
+        const int c0 = A * L.fan, c1 = (c0 + L.fan < nc) ? c0 + L.fan : nc;
         for (int c = c0; c < c1; c++) { s += ml.tmpG[(size_t)c * 36 + k]; m += ml.tmpM[(size_t)c * 36 + k]; }
         L.G[(size_t)A * 36 + k] = s;
         L.M[(size_t)A * 36 + k] = m;
@@ -276,26 +274,39 @@ __global__ __launch_bounds__(kBlk) void ml_top_kernel(PgoDev D, const MlDev* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// PCG-iteration kernels
+// PCG-iteration kernels: two launches per iteration with the full multilevel preconditioner.
+//
+// One workgroup of either kernel owns one level-2 aggregate = 4 level-1 aggregates = 32 consecutive rows.
+//   ml_spmv : 8 waves x 4 rows.  beta from the r.z partials, p = z + beta p_old (own rows + recomputed for the
+//             neighbour columns), Ap, p.Ap partial, and Sg[A] = restriction of Ap to the gather level g = min(2, L).
+//   ml_cg   : alpha from the p.Ap partials.  Because r_new = r - alpha Ap, the gather-level residual of EVERY
+//             aggregate is rg_old - alpha Sg: no global pass over r.  Every workgroup restricts that up to the top
+//             level in LDS, applies the top inverse for its own ancestor, walks down its own chain; then x, r, z for
+//             its 32 rows, and the EXACT r1 / r2 of its own aggregates (written to rg_new, so the recursion never
+//             accumulates error).  r.z partial -> part_b.
+// rg and p are double-buffered (other workgroups read the old buffer while the owner writes the new one).
+// All global operands whose address does not depend on alpha/beta are loaded before the partial reduction so that
+// one memory latency covers them: these kernels are latency-bound, not bandwidth-bound, at pose-graph sizes.
 // ------------------------------------------------------------------------------------------------
-constexpr int kMlBlk = 384;              // 6 waves
-constexpr int kRowsPerBlk = 64;          // 8 level-1 aggregates = 1 level-2 aggregate per workgroup
-constexpr int kAggPerBlk = kRowsPerBlk / kMlFanout;
-constexpr int kCoarseLdsDoubles = 7168;  // residuals of levels >= 2 staged in LDS by every workgroup (56 KB)
+// Two geometries, chosen by graph size (template parameter AGG = level-1 aggregates per workgroup):
+//   AGG = 1 (small graphs, <= 4096 free vertices): a workgroup owns ONE level-1 aggregate (8 rows), the gather
+//           level is 1, hierarchy fan-outs 8,8,8,..  -> 8x more workgroups, i.e. CUs, for the latency-bound kernels
+//   AGG = 4 (large graphs): a workgroup owns one level-2 aggregate = 4 level-1 aggregates (32 rows), gather level 2,
+//           hierarchy fan-outs 8,4,8,8,..             -> the gathered arrays stay small (n/32 entries)
+constexpr int kCgBlk = 192;                             // 3 waves; the first 48*AGG threads own a (row, component)
+constexpr int kGatherU = 16;                            // gather-level values per thread kept in registers
 
-__device__ __forceinline__ double block_sum6(double v, double* s6)
+template <int NW>
+__device__ __forceinline__ double block_sum_w(double v, double* sN)
 {
     v = wave_sum(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s6[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) sN[threadIdx.x >> 6] = v;
     __syncthreads();
-    return ((s6[0] + s6[1]) + (s6[2] + s6[3])) + (s6[4] + s6[5]);
-}
-__device__ __forceinline__ double sum_partials6(const double* __restrict__ part, int count, double* s6)
-{
-    double v = 0.;
-    for (int i = threadIdx.x; i < count; i += kMlBlk) v += part[i];
-    return block_sum6(v, s6);
+    double t = 0.;
+#pragma unroll
+    for (int k = 0; k < NW; k++) t += sN[k];
+    return t;
 }
 // component k of P^T r for a child with offset d (levels >= 1):  [r_v ; d x r_v + r_w]
 __device__ __forceinline__ double restrict_comp(const double* __restrict__ d, const double* __restrict__ rc, int k)
@@ -312,397 +323,253 @@ __device__ __forceinline__ double prolong_comp(const double* __restrict__ d, con
     const double cr = (k == 0) ? yp[4] * d[2] - yp[5] * d[1] : (k == 1) ? yp[5] * d[0] - yp[3] * d[2] : yp[3] * d[1] - yp[4] * d[0];
     return yp[k] + cr;
 }
-
-// init = 1: x = 0, r = b, p0 = p1 = 0, flags cleared.  init = 0: alpha = rz / p.Ap, x += alpha p, r -= alpha Ap.
-// Then z = D0^-1 r (block-Jacobi part), r1 = P1^T r for the 8 level-1 aggregates of this workgroup and
-// r2 = P2^T r1 for its level-2 aggregate.
-__global__ __launch_bounds__(kMlBlk) void ml_update_kernel(PgoDev D, const MlDev* __restrict__ mlp,
-                                                          const double* __restrict__ p, double* __restrict__ p0,
-                                                          double* __restrict__ p1, int n_part, int init)
+// (P1^T v)[r] for a row with geo = {R^T (9), d (3)} and v = (t0,t1,t2,q0,q1,q2)
+__device__ __forceinline__ double p1t_comp(const double* geo, double t0, double t1, double t2, double q0, double q1, double q2, int r)
 {
-    __shared__ double s6[6];
-    __shared__ double sv[kMlBlk];
-    __shared__ double sw[kMlBlk];
-    __shared__ double sr1[kAggPerBlk * 6];
-    const MlDev& ml = *mlp;
-    if (!init && D.flags[0]) return;
-    double alpha = 0., rz = 0.;
-    bool bad = false;
-    if (!init) {
-        const double pAp = sum_partials6(D.part_a, n_part, s6);
-        rz = D.scal[0];
-        bad = !(pAp > 0.);
-        alpha = bad ? 0. : rz / pAp;
+    const double u0 = geo[0] * t0 + geo[3] * t1 + geo[6] * t2;      // R = (R^T)^T
+    const double u1 = geo[1] * t0 + geo[4] * t1 + geo[7] * t2;
+    const double u2 = geo[2] * t0 + geo[5] * t1 + geo[8] * t2;
+    if (r < 3) return (r == 0) ? u0 : (r == 1) ? u1 : u2;
+    const int k = r - 3;
+    const double rq = 0.5 * (geo[k] * q0 + geo[3 + k] * q1 + geo[6 + k] * q2);
+    const double dx = geo[9], dy = geo[10], dz = geo[11];
+    const double cr = (k == 0) ? dy * u2 - dz * u1 : (k == 1) ? dz * u0 - dx * u2 : dx * u1 - dy * u0;
+    return cr + rq;
+}
+// (P1 y)[r]
+__device__ __forceinline__ double p1_comp(const double* geo, const double* y, int r)
+{
+    if (r < 3) {
+        const double dx = geo[9], dy = geo[10], dz = geo[11];
+        const double vx = y[0] + (y[4] * dz - y[5] * dy);      // v + w x d
+        const double vy = y[1] + (y[5] * dx - y[3] * dz);
+        const double vz = y[2] + (y[3] * dy - y[4] * dx);
+        return geo[r * 3] * vx + geo[r * 3 + 1] * vy + geo[r * 3 + 2] * vz;       // R^T (.)
     }
+    const int k = r - 3;
+    return 0.5 * (geo[k * 3] * y[3] + geo[k * 3 + 1] * y[4] + geo[k * 3 + 2] * y[5]);
+}
+
+// x = 0, r = b, p0 = p1 = 0, flags cleared; exact gather-level residual of the own aggregates -> rg
+template <int AGG>
+__global__ __launch_bounds__(kCgBlk) void ml_init_kernel(PgoDev D, MlHot H, double* __restrict__ p0, double* __restrict__ p1,
+                                                        double* __restrict__ rg)
+{
+    constexpr int kRowsPerBlk = kMlFanout * AGG, kAggPerBlk = AGG;
+    __shared__ double sv[kCgBlk];
+    __shared__ double sw[kCgBlk];
+    __shared__ double sr1[kAggPerBlk * 6];
     const int tid = threadIdx.x;
+    const int gl = (AGG == 1 || H.levels < 2) ? 1 : 2;
     const int a = blockIdx.x * kRowsPerBlk + tid / 6, r = tid % 6;
-    const bool act = a < D.nb;
-    double rv = 0.;
+    const bool act = tid < kRowsPerBlk * 6 && a < D.nb;
+    double rv = 0., geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (act) {
         const size_t i = (size_t)a * 6 + r;
-        if (init) { rv = D.b[i]; D.x[i] = 0.; p0[i] = 0.; p1[i] = 0.; }
-        else { D.x[i] += alpha * p[i]; rv = D.r[i] - alpha * D.ap[i]; }
-        D.r[i] = rv;
+        rv = D.b[i];
+        D.r[i] = rv; D.x[i] = 0.; p0[i] = 0.; p1[i] = 0.;
+        const double* __restrict__ gg = H.geo0 + (size_t)a * 12;
+#pragma unroll
+        for (int c = 0; c < 12; c++) geo[c] = gg[c];
     }
     sv[tid] = rv;
     __syncthreads();
-    double w = 0.;
-    if (act) {
-        const int g0 = tid - r;
-        const double* __restrict__ m = D.minv + (size_t)a * 36 + r * 6;
-        double zz = 0.;
-#pragma unroll
-        for (int c = 0; c < 6; c++) zz += m[c] * sv[g0 + c];
-        D.z[(size_t)a * 6 + r] = zz;
-        // (P1_a^T r_a)[r]:  u = R r_t ; r < 3: u[r] ; r >= 3: (d x u)[r-3] + 1/2 (R r_q)[r-3]
-        const double* __restrict__ g = ml.lv[0].geo + (size_t)a * 12;
-        const double t0 = sv[g0], t1 = sv[g0 + 1], t2 = sv[g0 + 2];
-        const double u0 = g[0] * t0 + g[3] * t1 + g[6] * t2;      // R = (R^T)^T
-        const double u1 = g[1] * t0 + g[4] * t1 + g[7] * t2;
-        const double u2 = g[2] * t0 + g[5] * t1 + g[8] * t2;
-        if (r < 3) w = (r == 0) ? u0 : (r == 1) ? u1 : u2;
-        else {
-            const double q0 = sv[g0 + 3], q1 = sv[g0 + 4], q2 = sv[g0 + 5];
-            const int k = r - 3;
-            const double rq = 0.5 * (g[k] * q0 + g[3 + k] * q1 + g[6 + k] * q2);
-            const double dx = g[9], dy = g[10], dz = g[11];
-            const double cr = (k == 0) ? dy * u2 - dz * u1 : (k == 1) ? dz * u0 - dx * u2 : dx * u1 - dy * u0;
-            w = cr + rq;
-        }
-    }
-    sw[tid] = w;
+    const int g0 = tid - r;
+    sw[tid] = act ? p1t_comp(geo, sv[g0], sv[g0 + 1], sv[g0 + 2], sv[g0 + 3], sv[g0 + 4], sv[g0 + 5], r) : 0.;
     __syncthreads();
+    const int n1 = H.n[1];
     if (tid < kAggPerBlk * 6) {
-        const int la = tid / 6, k = tid % 6;                  // local aggregate, component
-        const int A = blockIdx.x * kAggPerBlk + la;
+        const int la = tid / 6, k = tid % 6, A1 = blockIdx.x * kAggPerBlk + la;
         double s = 0.;
 #pragma unroll
-        for (int j = 0; j < kMlFanout; j++) s += sw[(la * kMlFanout + j) * 6 + k];      // inactive rows hold 0
+        for (int j = 0; j < kMlFanout; j++) s += sw[(la * kMlFanout + j) * 6 + k];
         sr1[tid] = s;
-        if (A < ml.lv[1].n) ml.lv[1].r[(size_t)A * 6 + k] = s;
+        if (gl == 1 && A1 < n1) rg[(size_t)A1 * 6 + k] = s;
     }
     __syncthreads();
-    if (ml.levels >= 2 && tid < 6) {
-        const int A2 = blockIdx.x;
-        const int n1 = ml.lv[1].n;
+    if (gl == 2 && tid < 6) {
         double s = 0.;
-        for (int j = 0; j < kAggPerBlk; j++) {
-            const int c = A2 * kMlFanout + j;
-            if (c < n1) s += restrict_comp(ml.lv[1].geo + (size_t)c * 3, sr1 + j * 6, tid);
+        for (int la = 0; la < kAggPerBlk; la++) {
+            const int A1 = blockIdx.x * kAggPerBlk + la;
+            if (A1 < n1) s += restrict_comp(H.geo[1] + (size_t)A1 * 3, sr1 + la * 6, tid);
         }
-        ml.lv[2].r[(size_t)A2 * 6 + tid] = s;
+        rg[(size_t)blockIdx.x * 6 + tid] = s;
     }
-    if (blockIdx.x == 0 && tid == 0) {
-        if (init) { D.flags[0] = 0; D.flags[1] = 0; D.flags[2] = 0; D.scal[2] = 1.; }
-        else {
-            D.scal[2] = rz;
-            D.flags[1] += 1;
-            if (bad) { D.flags[0] = 1; D.flags[2] = 1; }
-        }
-    }
+    if (blockIdx.x == 0 && tid == 0) { D.flags[0] = 0; D.flags[1] = 0; D.flags[2] = 0; D.scal[2] = 1.; }
 }
 
-// Coarse correction + z + r.z in one launch.  Every workgroup stages the residuals of the gather level
-// g = min(2, L) in LDS, restricts them up to the top level, applies the top inverse for its own ancestor,
-// walks back down its own ancestor chain and finishes z for its 64 rows:
-//   z += P1 y1,  y1 = D1^-1 r1 + P2 y2,  y2 = D2^-1 r2 + P3 y3, ...   (partials of r.z -> part_b)
-__global__ __launch_bounds__(kMlBlk) void ml_finish_kernel(PgoDev D, const MlDev* __restrict__ mlp)
+// 8 waves per workgroup: AGG = 1 -> one row per wave (8 rows), AGG = 4 -> four rows per wave (32 rows)
+template <int AGG>
+__global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const double* __restrict__ p_old,
+                                                     double* __restrict__ p_new, int n_part, double tol2)
 {
-    __shared__ double s6[6];
-    __shared__ double sy[kAggPerBlk * 6];
-    __shared__ double syc[6];                       // correction of the own level-g ancestor
-    __shared__ double sres[kCoarseLdsDoubles];
-    const MlDev& ml = *mlp;
-    if (D.flags[0]) return;
-    const int tid = threadIdx.x;
-    const int Lt = ml.levels;
-    const int g = Lt >= 2 ? 2 : 1;
-    // ---- stage r_g (all of it) and restrict up to the top level, all in LDS
-    int off[kMlMaxLevels + 2];
-    off[g] = 0;
-    for (int l = g; l <= Lt; l++) off[l + 1] = off[l] + 6 * ml.lv[l].n;
-    for (int t = tid; t < 6 * ml.lv[g].n; t += kMlBlk) sres[t] = ml.lv[g].r[t];
-    __syncthreads();
-    for (int l = g + 1; l <= Lt; l++) {
-        const MlLevel& C = ml.lv[l - 1];
-        const int nP = ml.lv[l].n;
-        for (int t = tid; t < nP * 6; t += kMlBlk) {
-            const int A = t / 6, k = t % 6;
-            const int c0 = A * kMlFanout, c1 = (c0 + kMlFanout < C.n) ? c0 + kMlFanout : C.n;
-            double s = 0.;
-            for (int c = c0; c < c1; c++) s += restrict_comp(C.geo + (size_t)c * 3, sres + off[l - 1] + c * 6, k);
-            sres[off[l] + t] = s;
-        }
-        __syncthreads();
-    }
-    const int ntop = 6 * ml.lv[Lt].n;
-    const double* rtop = sres + off[Lt];
-    if (Lt == 1) {
-        // the top level is level 1 itself: y1 of the own aggregates straight from the dense inverse
-        if (tid < kAggPerBlk * 6) {
-            const int A = blockIdx.x * kAggPerBlk + tid / 6, k = tid % 6;
-            double s = 0.;
-            if (A < ml.lv[1].n) for (int c = 0; c < ntop; c++) s += ml.top_inv[(size_t)(6 * A + k) * ntop + c] * rtop[c];
-            sy[tid] = s;
-        }
-        __syncthreads();
-    } else {
-        // own ancestor chain: level 2 aggregate = blockIdx.x
-        int anc[kMlMaxLevels + 1];
-        anc[2] = blockIdx.x;
-        for (int l = 3; l <= Lt; l++) anc[l] = anc[l - 1] / kMlFanout;
-        if (tid < 6) {
-            double s = 0.;
-            for (int c = 0; c < ntop; c++) s += ml.top_inv[(size_t)(6 * anc[Lt] + tid) * ntop + c] * rtop[c];
-            syc[tid] = s;
-        }
-        __syncthreads();
-        for (int l = Lt - 1; l >= 2; l--) {
-            double s = 0.;
-            if (tid < 6) {
-                const MlLevel& C = ml.lv[l];
-                const int a = anc[l];
-                const double* di = C.Dinv + (size_t)a * 36 + tid * 6;
-                const double* rr = sres + off[l] + a * 6;
-#pragma unroll
-                for (int c = 0; c < 6; c++) s += di[c] * rr[c];
-                s += prolong_comp(C.geo + (size_t)a * 3, syc, tid);
-            }
-            __syncthreads();
-            if (tid < 6) syc[tid] = s;
-            __syncthreads();
-        }
-        // y1 of the 8 own level-1 aggregates
-        if (tid < kAggPerBlk * 6) {
-            const MlLevel& L1 = ml.lv[1];
-            const int A = blockIdx.x * kAggPerBlk + tid / 6, k = tid % 6;
-            double s = 0.;
-            if (A < L1.n) {
-                const double* di = L1.Dinv + (size_t)A * 36 + k * 6;
-                const double* rr = L1.r + (size_t)A * 6;
-#pragma unroll
-                for (int c = 0; c < 6; c++) s += di[c] * rr[c];
-                s += prolong_comp(L1.geo + (size_t)A * 3, syc, k);
-            }
-            sy[tid] = s;
-        }
-        __syncthreads();
-    }
-    const int a = blockIdx.x * kRowsPerBlk + tid / 6, r = tid % 6;
-    double acc = 0.;
-    if (a < D.nb) {
-        const double* y = sy + ((tid / 6) / kMlFanout) * 6;
-        const double* __restrict__ gg = ml.lv[0].geo + (size_t)a * 12;
-        double add;
-        if (r < 3) {
-            const double dx = gg[9], dy = gg[10], dz = gg[11];
-            const double vx = y[0] + (y[4] * dz - y[5] * dy);      // v + w x d
-            const double vy = y[1] + (y[5] * dx - y[3] * dz);
-            const double vz = y[2] + (y[3] * dy - y[4] * dx);
-            add = gg[r * 3] * vx + gg[r * 3 + 1] * vy + gg[r * 3 + 2] * vz;       // R^T (.)
-        } else {
-            const int k = r - 3;
-            add = 0.5 * (gg[k * 3] * y[3] + gg[k * 3 + 1] * y[4] + gg[k * 3 + 2] * y[5]);
-        }
-        const size_t i = (size_t)a * 6 + r;
-        const double zz = D.z[i] + add;
-        D.z[i] = zz;
-        acc = D.r[i] * zz;
-    }
-    const double tot = block_sum6(acc, s6);
-    if (tid == 0) D.part_b[blockIdx.x] = tot;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Two launches per PCG iteration with the full multilevel preconditioner.
-//
-//   ml_spmv : one workgroup = one level-1 aggregate (8 rows, one wave per row).  beta from the r.z partials,
-//             p = z + beta p_old (own row + recomputed for neighbour columns), Ap, p.Ap partial, and
-//             S1[A] = sum_rows P1^T (Ap)  — the level-1 restriction of Ap.
-//   ml_cg   : one workgroup = one level-2 aggregate (64 rows).  alpha from the p.Ap partials; because
-//             r_new = r - alpha Ap, the restricted residual of EVERY aggregate is r1_old - alpha S1 — no global
-//             pass over r is needed: every workgroup restricts that to level 2.., applies the top inverse and
-//             walks down its own ancestor chain in LDS; then x, r, z for its own 64 rows and the exact r1 of its
-//             own aggregates (so the recursion never accumulates error).  r.z partial -> part_b.
-// All global operands whose address does not depend on alpha/beta are loaded before the partial reduction so
-// that one memory latency covers them (the kernels are latency-, not bandwidth-bound at these sizes).
-// ------------------------------------------------------------------------------------------------
-constexpr int kSpmvBlk = 512;            // 8 waves = 8 rows = one level-1 aggregate
-
-__global__ __launch_bounds__(kSpmvBlk) void ml_spmv_kernel(PgoDev D, MlHot H,
-                                                          const double* __restrict__ p_old, double* __restrict__ p_new,
-                                                          int n_part, double tol2)
-{
-    __shared__ double s8[8];
-    __shared__ double sw[8 * 6];
+    constexpr int kRowsPerBlk = kMlFanout * AGG, kAggPerBlk = AGG, kSpmvBlk = 512, kWaves = 8, kRowsPerWave = AGG;
+    __shared__ double s8[kWaves];
+    __shared__ double sw[kRowsPerBlk * 6];
+    __shared__ double ss1[kAggPerBlk * 6];
+    __shared__ double sg1[kAggPerBlk * 3];
     if (D.flags[0]) return;
     STAMP_DECL
+    const int gl = (AGG == 1 || H.levels < 2) ? 1 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane / 6, r = lane % 6;
     const bool lact = lane < 60;
-    const int a = blockIdx.x * kMlFanout + wv;
-    const bool ract = a < D.nb;
+    const int row0 = blockIdx.x * kRowsPerBlk + wv * kRowsPerWave;
     // ---- prefetch (independent of beta); the r.z partials first: they gate everything else
     double v = 0.;
-    for (int i = threadIdx.x; i < n_part; i += kSpmvBlk) v += D.part_b[i];
-    int s0 = 0, s1 = 0;
-    if (ract) { s0 = D.row_ptr[a]; s1 = D.row_ptr[a + 1]; }
-    double hrow[6] = {0, 0, 0, 0, 0, 0}, zo[6] = {0, 0, 0, 0, 0, 0}, po[6] = {0, 0, 0, 0, 0, 0}, geo[12];
-    if (ract && g == 0) {
-        const double* __restrict__ h = D.hdiag + (size_t)a * 36 + r * 6;
-        const double* __restrict__ zv = D.z + (size_t)a * 6;
-        const double* __restrict__ pv = p_old + (size_t)a * 6;
-        const double* __restrict__ gg = H.geo0 + (size_t)a * 12;
+    for (int i = tid; i < n_part; i += kSpmvBlk) v += D.part_b[i];
+    const int it = D.flags[1];
+    const double rz_prev = D.scal[2], thr_old = D.scal[1], lambda = D.scal[3];
+    if (tid < kAggPerBlk * 3) {
+        const int A1 = blockIdx.x * kAggPerBlk + tid / 3;
+        sg1[tid] = (gl == 2 && A1 < H.n[1]) ? H.geo[1][(size_t)A1 * 3 + tid % 3] : 0.;
+    }
+    int s0[kRowsPerWave], s1[kRowsPerWave];
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) {
+        const int a = row0 + q;
+        s0[q] = (a < D.nb) ? D.row_ptr[a] : 0;
+        s1[q] = (a < D.nb) ? D.row_ptr[a + 1] : 0;
+    }
+    // lane group q (< 4) owns the diagonal block, z, p_old and geometry of row q
+    double hrow[6] = {0, 0, 0, 0, 0, 0}, zo[6] = {0, 0, 0, 0, 0, 0}, po[6] = {0, 0, 0, 0, 0, 0}, geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int arow = row0 + g;
+    const bool dact = g < kRowsPerWave && arow < D.nb;
+    if (dact) {
+        const double* __restrict__ h = D.hdiag + (size_t)arow * 36 + r * 6;
+        const double* __restrict__ zv = D.z + (size_t)arow * 6;
+        const double* __restrict__ pv = p_old + (size_t)arow * 6;
+        const double* __restrict__ gg = H.geo0 + (size_t)arow * 12;
 #pragma unroll
         for (int c = 0; c < 6; c++) { hrow[c] = h[c]; zo[c] = zv[c]; po[c] = pv[c]; }
 #pragma unroll
         for (int c = 0; c < 12; c++) geo[c] = gg[c];
     }
-    // first two slots of this lane group (rows have ~10 slots: most rows need one pass)
-    double2 b0[2], b1[2], b2[2], z0[2], z1[2], z2[2], o0[2], o1[2], o2[2];
-    bool have[2] = {false, false};
+    // first slot pass of every row (rows have ~10 slots: most rows need exactly this pass)
+    double2 b0[kRowsPerWave], b1[kRowsPerWave], b2[kRowsPerWave], z0[kRowsPerWave], z1[kRowsPerWave], z2[kRowsPerWave],
+        o0[kRowsPerWave], o1[kRowsPerWave], o2[kRowsPerWave];
+    bool have[kRowsPerWave];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int s = s0 + g + 10 * k;
-        if (ract && lact && s < s1) {
+    for (int q = 0; q < kRowsPerWave; q++) {
+        have[q] = false;
+        const int s = s0[q] + g;
+        if (lact && s < s1[q]) {
             const int c = D.col[s];
             if (c >= 0) {
-                have[k] = true;
+                have[q] = true;
                 const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
                 const double2* __restrict__ zv = reinterpret_cast<const double2*>(D.z + (size_t)c * 6);
                 const double2* __restrict__ pv = reinterpret_cast<const double2*>(p_old + (size_t)c * 6);
-                b0[k] = bk[0]; b1[k] = bk[1]; b2[k] = bk[2];
-                z0[k] = zv[0]; z1[k] = zv[1]; z2[k] = zv[2];
-                o0[k] = pv[0]; o1[k] = pv[1]; o2[k] = pv[2];
+                b0[q] = bk[0]; b1[q] = bk[1]; b2[q] = bk[2];
+                z0[q] = zv[0]; z1[q] = zv[1]; z2[q] = zv[2];
+                o0[q] = pv[0]; o1[q] = pv[1]; o2[q] = pv[2];
             }
         }
     }
-    const int it = D.flags[1];
-    const double rz_prev = D.scal[2], thr_old = D.scal[1], lambda = D.scal[3];
     STAMP(16);     // 16: prefetch issue
     // ---- beta
-    v = wave_sum(v);
-    if (lane == 0) s8[wv] = v;
-    __syncthreads();
-    const double rz = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    const double rz = block_sum_w<kWaves>(v, s8);
     const double beta = (it == 0) ? 0. : rz / rz_prev;
     const double thresh = (it == 0) ? tol2 * rz : thr_old;
     STAMP(16);     // 17: partial reduction (prefetch landed)
-    // ---- row product
-    double acc = 0., pr = 0.;
-    if (ract && g == 0) {
+    // ---- row products
+    double pr = 0.;
+    double acc[kRowsPerWave];
 #pragma unroll
-        for (int c = 0; c < 6; c++) {
-            const double pc = zo[c] + beta * po[c];
-            acc += hrow[c] * pc;
-            if (c == r) pr = pc;
+    for (int q = 0; q < kRowsPerWave; q++) {
+        double aq = 0.;
+        if (dact && g == q) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double pc = zo[c] + beta * po[c];
+                aq += hrow[c] * pc;
+                if (c == r) pr = pc;
+            }
+            aq += lambda * pr;
+            p_new[(size_t)arow * 6 + r] = pr;
         }
-        acc += lambda * pr;
-        p_new[(size_t)a * 6 + r] = pr;
-    }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        if (have[k])
-            acc += b0[k].x * (z0[k].x + beta * o0[k].x) + b0[k].y * (z0[k].y + beta * o0[k].y) + b1[k].x * (z1[k].x + beta * o1[k].x) +
-                   b1[k].y * (z1[k].y + beta * o1[k].y) + b2[k].x * (z2[k].x + beta * o2[k].x) + b2[k].y * (z2[k].y + beta * o2[k].y);
-    }
-    if (ract && lact) {
-        for (int s = s0 + g + 20; s < s1; s += 10) {
-            const int c = D.col[s];
-            if (c >= 0) {
-                const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
-                const double2* __restrict__ zv = reinterpret_cast<const double2*>(D.z + (size_t)c * 6);
-                const double2* __restrict__ pv = reinterpret_cast<const double2*>(p_old + (size_t)c * 6);
-                const double2 c0 = bk[0], c1 = bk[1], c2 = bk[2], y0 = zv[0], y1 = zv[1], y2 = zv[2], q0 = pv[0], q1 = pv[1], q2 = pv[2];
-                acc += c0.x * (y0.x + beta * q0.x) + c0.y * (y0.y + beta * q0.y) + c1.x * (y1.x + beta * q1.x) +
-                       c1.y * (y1.y + beta * q1.y) + c2.x * (y2.x + beta * q2.x) + c2.y * (y2.y + beta * q2.y);
+        if (have[q])
+            aq += b0[q].x * (z0[q].x + beta * o0[q].x) + b0[q].y * (z0[q].y + beta * o0[q].y) + b1[q].x * (z1[q].x + beta * o1[q].x) +
+                  b1[q].y * (z1[q].y + beta * o1[q].y) + b2[q].x * (z2[q].x + beta * o2[q].x) + b2[q].y * (z2[q].y + beta * o2[q].y);
+        if (lact) {
+            for (int s = s0[q] + g + 10; s < s1[q]; s += 10) {
+                const int c = D.col[s];
+                if (c >= 0) {
+                    const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
+                    const double2* __restrict__ zv = reinterpret_cast<const double2*>(D.z + (size_t)c * 6);
+                    const double2* __restrict__ pv = reinterpret_cast<const double2*>(p_old + (size_t)c * 6);
+                    const double2 c0 = bk[0], c1 = bk[1], c2 = bk[2], y0 = zv[0], y1 = zv[1], y2 = zv[2], q0 = pv[0], q1 = pv[1], q2 = pv[2];
+                    aq += c0.x * (y0.x + beta * q0.x) + c0.y * (y0.y + beta * q0.y) + c1.x * (y1.x + beta * q1.x) +
+                          c1.y * (y1.y + beta * q1.y) + c2.x * (y2.x + beta * q2.x) + c2.y * (y2.y + beta * q2.y);
+                }
             }
         }
+        double t;
+        t = __shfl_down(aq, 48); if (lane + 48 < 60) aq += t;
+        t = __shfl_down(aq, 24); if (lane + 24 < 48) aq += t;
+        t = __shfl_down(aq, 12); if (lane + 12 < 24) aq += t;
+        t = __shfl_down(aq, 6);  if (lane + 6 < 12) aq += t;
+        acc[q] = aq;                               // lanes 0..5: (A p)[row q][0..5]
     }
-    double t;
-    t = __shfl_down(acc, 48); if (lane + 48 < 60) acc += t;
-    t = __shfl_down(acc, 24); if (lane + 24 < 48) acc += t;
-    t = __shfl_down(acc, 12); if (lane + 12 < 24) acc += t;
-    t = __shfl_down(acc, 6);  if (lane + 6 < 12) acc += t;
-    STAMP(16);     // 18: row product + fold
-    // lanes 0..5 hold Ap[a][0..5]
-    double dot = 0., w = 0.;
-    if (ract && lane < 6) {
-        D.ap[(size_t)a * 6 + r] = acc;
-        dot = acc * pr;
-    }
-    // (P1_a^T Ap_a)[r] needs all six components of the row: broadcast within lanes 0..5
-    const double t0 = __shfl(acc, 0), t1 = __shfl(acc, 1), t2 = __shfl(acc, 2);
-    const double q0 = __shfl(acc, 3), q1 = __shfl(acc, 4), q2 = __shfl(acc, 5);
-    if (ract && lane < 6) {
-        const double u0 = geo[0] * t0 + geo[3] * t1 + geo[6] * t2;
-        const double u1 = geo[1] * t0 + geo[4] * t1 + geo[7] * t2;
-        const double u2 = geo[2] * t0 + geo[5] * t1 + geo[8] * t2;
-        if (r < 3) w = (r == 0) ? u0 : (r == 1) ? u1 : u2;
-        else {
-            const int k = r - 3;
-            const double rq = 0.5 * (geo[k] * q0 + geo[3 + k] * q1 + geo[6 + k] * q2);
-            const double dx = geo[9], dy = geo[10], dz = geo[11];
-            const double cr = (k == 0) ? dy * u2 - dz * u1 : (k == 1) ? dz * u0 - dx * u2 : dx * u1 - dy * u0;
-            w = cr + rq;
+    STAMP(16);     // 18: row products + folds
+    double dot = 0.;
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) {
+        const int a = row0 + q;
+        if (lane < 6 && a < D.nb) D.ap[(size_t)a * 6 + lane] = acc[q];
+        const double t0 = __shfl(acc[q], 0), t1 = __shfl(acc[q], 1), t2 = __shfl(acc[q], 2);
+        const double q0 = __shfl(acc[q], 3), q1 = __shfl(acc[q], 4), q2 = __shfl(acc[q], 5);
+        if (g == q) {                               // the lanes that own row q's p and geometry
+            double wq = 0.;
+            if (dact) {
+                const double apr = (r == 0) ? t0 : (r == 1) ? t1 : (r == 2) ? t2 : (r == 3) ? q0 : (r == 4) ? q1 : q2;
+                dot += apr * pr;
+                wq = p1t_comp(geo, t0, t1, t2, q0, q1, q2, r);
+            }
+            sw[(wv * kRowsPerWave + q) * 6 + r] = wq;
         }
     }
-    dot = wave_sum(dot);                       // lanes >= 6 hold 0
-    __syncthreads();                           // s8 reuse
-    if (lane < 6) sw[wv * 6 + lane] = w;
-    if (lane == 0) s8[wv] = dot;
-    __syncthreads();
-    if (tid < 6) {
+    const double dtot = block_sum_w<kWaves>(dot, s8);   // barriers: sw complete
+    if (tid < kAggPerBlk * 6) {
+        const int la = tid / 6, k = tid % 6, A1 = blockIdx.x * kAggPerBlk + la;
         double s = 0.;
 #pragma unroll
-        for (int k = 0; k < 8; k++) s += sw[k * 6 + tid];
-        H.S1[(size_t)blockIdx.x * 6 + tid] = s;
+        for (int j = 0; j < kMlFanout; j++) s += sw[(la * kMlFanout + j) * 6 + k];
+        ss1[tid] = s;
+        if (gl == 1 && A1 < H.n[1]) H.Sg[(size_t)A1 * 6 + k] = s;
+    }
+    __syncthreads();
+    if (gl == 2 && tid < 6) {
+        double s = 0.;
+        for (int la = 0; la < kAggPerBlk; la++)
+            if (blockIdx.x * kAggPerBlk + la < H.n[1]) s += restrict_comp(sg1 + la * 3, ss1 + la * 6, tid);
+        H.Sg[(size_t)blockIdx.x * 6 + tid] = s;
     }
     if (tid == 0) {
-        D.part_a[blockIdx.x] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        D.part_a[blockIdx.x] = dtot;
         if (blockIdx.x == 0) {
             D.scal[0] = rz;
             if (it == 0) D.scal[1] = thresh;
             if (!(rz > thresh)) D.flags[0] = 1;
         }
     }
-    STAMP(16);     // 19: S1 + partial stores
+    STAMP(16);     // 19: restriction of Ap + stores
 #ifdef UZL_STAMPS
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_stamps[47], 1ull);
 #endif
 }
 
-// init = 1: first application (r = b already stored, exact r1 in r1_old): only the preconditioner part runs.
-// r1_old / r1_new: the level-1 residual is double-buffered like p (other workgroups read r1_old while the owner
-// writes the exact r1_new of its aggregates).
-// Dynamic LDS (doubles): res[levels 2..L] | geo[levels 2..L-1] | top rows | own-chain Dinv+geo |
-//                        level-1 chunk: r (6 x kL1Chunk) + geo (3 x kL1Chunk)          (ml_cg_lds_bytes)
-// Level 1 is streamed through the chunk buffer (bounded LDS for any graph size); its first chunk is loaded into
-// registers before the alpha reduction, so one memory latency covers every operand of the kernel.
-constexpr int kStageU = 4;               // loads in flight per thread per staging batch
-// batched global -> LDS copy: kStageU independent loads per thread are issued before the first store
-__device__ __forceinline__ void stage_to_lds(const double* __restrict__ src, double* dst, int n)
-{
-    for (int base = 0; base < n; base += kStageU * kMlBlk) {
-        double v[kStageU];
-#pragma unroll
-        for (int u = 0; u < kStageU; u++) { const int t = base + u * kMlBlk + (int)threadIdx.x; v[u] = (t < n) ? src[t] : 0.; }
-#pragma unroll
-        for (int u = 0; u < kStageU; u++) { const int t = base + u * kMlBlk + (int)threadIdx.x; if (t < n) dst[t] = v[u]; }
-    }
-}
-
-constexpr int kL1Chunk = 1280;                       // level-1 aggregates per chunk (multiple of 8): 10240 vertices
-constexpr int kL1RU = (6 * kL1Chunk + kMlBlk - 1) / kMlBlk;      // 20 residual values per thread
-constexpr int kL1GU = (3 * kL1Chunk + kMlBlk - 1) / kMlBlk;      // 10 offsets per thread
-
-__global__ __launch_bounds__(kMlBlk) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
-                                                      const double* __restrict__ r1_old, double* __restrict__ r1_new,
+// init = 1: first application (r = b stored, exact rg in rg_old): only the preconditioner part runs.
+// Dynamic LDS (doubles): res[levels g..L] | geo[levels g..L-1] | top rows | own-chain Dinv+geo   (ml_cg_lds_bytes)
+template <int AGG>
+__global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
+                                                      const double* __restrict__ rg_old, double* __restrict__ rg_new,
                                                       int n_part, int init)
 {
+    constexpr int kRowsPerBlk = kMlFanout * AGG, kAggPerBlk = AGG;
     extern __shared__ __attribute__((aligned(16))) double dyn[];
-    __shared__ double s6[6];
-    __shared__ double sv[kMlBlk];
-    __shared__ double sw[kMlBlk];
+    __shared__ double s3[3];
+    __shared__ double sv[kCgBlk];
+    __shared__ double sw[kCgBlk];
     __shared__ double sr1[kAggPerBlk * 6];
     __shared__ double sy[kAggPerBlk * 6];
     __shared__ double syc[6];
@@ -710,28 +577,27 @@ __global__ __launch_bounds__(kMlBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     STAMP_DECL
     const int tid = threadIdx.x;
     const int Lt = H.levels;
+    const int gl = (AGG == 1 || Lt < 2) ? 1 : 2;               // gather level
     const int a = blockIdx.x * kRowsPerBlk + tid / 6, r = tid % 6;
-    const bool act = a < D.nb;
-    const int n1 = H.n[1];
+    const bool act = tid < kRowsPerBlk * 6 && a < D.nb;
+    const int n1 = H.n[1], ng = H.n[gl];
     const int ntop = 6 * H.n[Lt];
     // ---- LDS carve-up
     int roff[kMlMaxLevels + 2], goff[kMlMaxLevels + 2], anc[kMlMaxLevels + 2];
     int o = 0;
-    for (int l = 2; l <= Lt; l++) { roff[l] = o; o += 6 * H.n[l]; }
-    for (int l = 2; l < Lt; l++) { goff[l] = o; o += 3 * H.n[l]; }
+    for (int l = gl; l <= Lt; l++) { roff[l] = o; o += 6 * H.n[l]; }
+    for (int l = gl; l < Lt; l++) { goff[l] = o; o += 3 * H.n[l]; }
     const int top_off = o;
     const int n_top_rows = (Lt == 1) ? kAggPerBlk * 6 : 6;
     o += n_top_rows * ntop;
     const int chain_off = o;                                  // (L-2) x 39
-    if (Lt > 2) o += (Lt - 2) * 39;
-    const int c1r = o;                                        // level-1 chunk: residual estimate
-    const int c1g = c1r + 6 * kL1Chunk;                       //                children offsets
-    anc[2] = blockIdx.x;
-    for (int l = 3; l <= Lt; l++) anc[l] = anc[l - 1] / kMlFanout;
+    anc[1] = blockIdx.x * kAggPerBlk;                          // (only its parent chain is used)
+    anc[2] = (gl == 2) ? (int)blockIdx.x : anc[1] / H.fan[2 <= Lt ? 2 : 1];
+    for (int l = 3; l <= Lt; l++) anc[l] = anc[l - 1] / H.fan[l];
     STAMP(0);      // 0: entry
     // ---- every global load whose address is known now, before any barrier
     double part = 0.;
-    if (!init) for (int i = tid; i < n_part; i += kMlBlk) part += D.part_a[i];
+    if (!init) for (int i = tid; i < n_part; i += kCgBlk) part += D.part_a[i];
     double xv = 0., rv0 = 0., apv = 0., pv = 0., mrow[6] = {0, 0, 0, 0, 0, 0}, geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (act) {
         const size_t i = (size_t)a * 6 + r;
@@ -754,23 +620,27 @@ __global__ __launch_bounds__(kMlBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
         g1own[0] = gq[0]; g1own[1] = gq[1]; g1own[2] = gq[2];
     }
     const double rz = init ? 0. : D.scal[0];
-    // first level-1 chunk into registers
-    double r1reg[kL1RU], s1reg[kL1RU], g1reg[kL1GU];
-    const int ch_n = n1 < kL1Chunk ? n1 : kL1Chunk;
+    // gather-level residual and restricted Ap of ALL aggregates: first kGatherU x 192 values in registers
+    double rgreg[kGatherU], sgreg[kGatherU];
 #pragma unroll
-    for (int u = 0; u < kL1RU; u++) {
-        const int t = u * kMlBlk + tid;
-        r1reg[u] = (t < 6 * ch_n) ? r1_old[t] : 0.;
-        s1reg[u] = (!init && t < 6 * ch_n) ? H.S1[t] : 0.;
+    for (int u = 0; u < kGatherU; u++) {
+        const int t = u * kCgBlk + tid;
+        rgreg[u] = (t < 6 * ng) ? rg_old[t] : 0.;
+        sgreg[u] = (!init && t < 6 * ng) ? H.Sg[t] : 0.;
     }
+    // small arrays: offsets of levels >= g, top-inverse rows, own-chain blocks
+    for (int l = gl; l < Lt; l++) {
+        const double* __restrict__ src = H.geo[l];
+        const int n3 = 3 * H.n[l];
+        for (int base = 0; base < n3; base += 4 * kCgBlk) {
+            double vv[4];
 #pragma unroll
-    for (int u = 0; u < kL1GU; u++) {
-        const int t = u * kMlBlk + tid;
-        g1reg[u] = (Lt >= 2 && t < 3 * ch_n) ? H.geo[1][t] : 0.;
+            for (int u = 0; u < 4; u++) { const int t = base + u * kCgBlk + tid; vv[u] = (t < n3) ? src[t] : 0.; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int t = base + u * kCgBlk + tid; if (t < n3) dyn[goff[l] + t] = vv[u]; }
+        }
     }
-    // small arrays: upper-level offsets, top-inverse rows, own-chain blocks (a handful of values per thread)
-    for (int l = 2; l < Lt; l++) stage_to_lds(H.geo[l], dyn + goff[l], 3 * H.n[l]);
-    for (int t = tid; t < n_top_rows * ntop; t += kMlBlk) {
+    for (int t = tid; t < n_top_rows * ntop; t += kCgBlk) {
         const int rr = t / ntop, c = t % ntop;
         const int grow = (Lt == 1) ? (blockIdx.x * kAggPerBlk * 6 + rr) : (6 * anc[Lt] + rr);
         dyn[top_off + t] = (grow < ntop) ? H.top_inv[(size_t)grow * ntop + c] : 0.;
@@ -783,74 +653,37 @@ __global__ __launch_bounds__(kMlBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     double alpha = 0.;
     bool bad = false;
     if (!init) {
-        const double pAp = block_sum6(part, s6);                          // barrier: everything above has landed
+        const double pAp = block_sum_w<3>(part, s3);                      // barriers: everything above has landed
         bad = !(pAp > 0.);
         alpha = bad ? 0. : rz / pAp;
     }
     STAMP(0);      // 2: partial reduction
-    // ---- level 1 -> level 2 (or, when level 1 is the top level, straight into the top residual), chunk by chunk
-    for (int cb = 0; cb < n1; cb += kL1Chunk) {
-        const int cn = (n1 - cb < kL1Chunk) ? n1 - cb : kL1Chunk;
-        if (cb > 0) {          // later chunks (graphs > 10k free vertices): loaded here, latency exposed
 #pragma unroll
-            for (int u = 0; u < kL1RU; u++) {
-                const int t = u * kMlBlk + tid;
-                r1reg[u] = (t < 6 * cn) ? r1_old[(size_t)6 * cb + t] : 0.;
-                s1reg[u] = (!init && t < 6 * cn) ? H.S1[(size_t)6 * cb + t] : 0.;
-            }
-#pragma unroll
-            for (int u = 0; u < kL1GU; u++) {
-                const int t = u * kMlBlk + tid;
-                g1reg[u] = (Lt >= 2 && t < 3 * cn) ? H.geo[1][(size_t)3 * cb + t] : 0.;
-            }
-            __syncthreads();   // previous chunk fully consumed
-        }
-        double* dst_r = (Lt == 1) ? (dyn + top_off + n_top_rows * ntop) : (dyn + c1r);   // L == 1: r1 IS the top residual
-#pragma unroll
-        for (int u = 0; u < kL1RU; u++) {
-            const int t = u * kMlBlk + tid;
-            if (t < 6 * cn) dst_r[t] = r1reg[u] - alpha * s1reg[u];
-        }
-#pragma unroll
-        for (int u = 0; u < kL1GU; u++) {
-            const int t = u * kMlBlk + tid;
-            if (Lt >= 2 && t < 3 * cn) dyn[c1g + t] = g1reg[u];
-        }
-        __syncthreads();
-        if (Lt >= 2) {
-            const int p0 = cb / kMlFanout, nPc = (cn + kMlFanout - 1) / kMlFanout;
-            const int tasks = nPc * 6 * kMlFanout;
-            for (int t0 = 0; t0 < tasks; t0 += kMlBlk) {
-                const int t = t0 + tid;
-                const int j = t & 7, ak = t >> 3;
-                const int A = ak / 6, k = ak % 6;
-                const int c = A * kMlFanout + j;
-                double sacc = 0.;
-                if (t < tasks && c < cn) sacc = restrict_comp(dyn + c1g + c * 3, dyn + c1r + c * 6, k);
-                sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
-                if (t < tasks && j == 0) dyn[roff[2] + p0 * 6 + ak] = sacc;
-            }
-        }
+    for (int u = 0; u < kGatherU; u++) {
+        const int t = u * kCgBlk + tid;
+        if (t < 6 * ng) dyn[roff[gl] + t] = rgreg[u] - alpha * sgreg[u];
     }
+    for (int t = kGatherU * kCgBlk + tid; t < 6 * ng; t += kCgBlk)       // graphs beyond 12k free vertices: latency exposed
+        dyn[roff[gl] + t] = rg_old[t] - (init ? 0. : alpha * H.Sg[t]);
     __syncthreads();
-    STAMP(0);      // 3: level-1 fold + restriction
+    STAMP(0);      // 3: gather-level residual estimate
     // ---- restrict up to the top level: 8 lanes per (parent, component), one child each, xor-shuffle fold
-    for (int l = 3; l <= Lt; l++) {
-        const int nC = H.n[l - 1], nP = H.n[l];
-        const int tasks = nP * 6 * kMlFanout;
-        for (int t0 = 0; t0 < tasks; t0 += kMlBlk) {
+    for (int l = gl + 1; l <= Lt; l++) {
+        const int nC = H.n[l - 1], nP = H.n[l], fan = H.fan[l];
+        const int tasks = nP * 6 * 8;
+        for (int t0 = 0; t0 < tasks; t0 += kCgBlk) {
             const int t = t0 + tid;
             const int j = t & 7, ak = t >> 3;
             const int A = ak / 6, k = ak % 6;
-            const int c = A * kMlFanout + j;
+            const int c = A * fan + j;
             double sacc = 0.;
-            if (t < tasks && c < nC) sacc = restrict_comp(dyn + goff[l - 1] + c * 3, dyn + roff[l - 1] + c * 6, k);
+            if (t < tasks && j < fan && c < nC) sacc = restrict_comp(dyn + goff[l - 1] + c * 3, dyn + roff[l - 1] + c * 6, k);
             sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
             if (t < tasks && j == 0) dyn[roff[l] + ak] = sacc;
         }
         __syncthreads();
     }
-    const double* rtop = (Lt == 1) ? (dyn + top_off + n_top_rows * ntop) : (dyn + roff[Lt]);
+    const double* rtop = dyn + roff[Lt];
     if (Lt == 1) {
         if (tid < kAggPerBlk * 6) {
             double sacc = 0.;
@@ -881,7 +714,7 @@ __global__ __launch_bounds__(kMlBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
         }
     }
     STAMP(0);      // 4: restrict + top + down chain
-    // ---- own rows: x, r, block-Jacobi part, exact r1 of the own aggregates
+    // ---- own rows: x, r, block-Jacobi part, exact r1 / r2 of the own aggregates
     double rv = rv0;
     if (act && !init) {
         const size_t i = (size_t)a * 6 + r;
@@ -896,19 +729,7 @@ __global__ __launch_bounds__(kMlBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
         const int g0 = tid - r;
 #pragma unroll
         for (int c = 0; c < 6; c++) zz += mrow[c] * sv[g0 + c];
-        const double t0 = sv[g0], t1 = sv[g0 + 1], t2 = sv[g0 + 2];
-        const double u0 = geo[0] * t0 + geo[3] * t1 + geo[6] * t2;
-        const double u1 = geo[1] * t0 + geo[4] * t1 + geo[7] * t2;
-        const double u2 = geo[2] * t0 + geo[5] * t1 + geo[8] * t2;
-        if (r < 3) w = (r == 0) ? u0 : (r == 1) ? u1 : u2;
-        else {
-            const double q0 = sv[g0 + 3], q1 = sv[g0 + 4], q2 = sv[g0 + 5];
-            const int k = r - 3;
-            const double rq = 0.5 * (geo[k] * q0 + geo[3 + k] * q1 + geo[6 + k] * q2);
-            const double dx = geo[9], dy = geo[10], dz = geo[11];
-            const double cr = (k == 0) ? dy * u2 - dz * u1 : (k == 1) ? dz * u0 - dx * u2 : dx * u1 - dy * u0;
-            w = cr + rq;
-        }
+        w = p1t_comp(geo, sv[g0], sv[g0 + 1], sv[g0 + 2], sv[g0 + 3], sv[g0 + 4], sv[g0 + 5], r);
     }
     sw[tid] = w;
     __syncthreads();
@@ -919,42 +740,38 @@ __global__ __launch_bounds__(kMlBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
 #pragma unroll
         for (int j = 0; j < kMlFanout; j++) s += sw[(la * kMlFanout + j) * 6 + k];
         sr1[tid] = s;
-        if (A1 < n1) r1_new[(size_t)A1 * 6 + k] = s;                       // exact, for the next iteration's recursion
+        if (gl == 1 && A1 < n1) rg_new[(size_t)A1 * 6 + k] = s;          // exact, for the next iteration's recursion
     }
     __syncthreads();
     STAMP(0);      // 6: exact r1
-    if (Lt >= 2 && tid < kAggPerBlk * 6) {
-        // y1 = D1^-1 r1 + P2 y2
-        const int la = tid / 6, k = tid % 6;
-        double s = 0.;
-        if (A1 < n1) {
+    if (Lt >= 2) {
+        double c2 = 0.;
+        if (tid < kAggPerBlk * 6) {                                       // y1 = D1^-1 r1 + P2 y2
+            const int la = tid / 6, k = tid % 6;
+            double s = 0.;
+            if (A1 < n1) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) s += d1row[c] * sr1[la * 6 + c];
-            s += prolong_comp(g1own, syc, k);
+                for (int c = 0; c < 6; c++) s += d1row[c] * sr1[la * 6 + c];
+                s += prolong_comp(g1own, syc, k);
+                c2 = restrict_comp(g1own, sr1 + la * 6, k);               // this child's share of the exact r2
+            }
+            sy[tid] = s;
         }
-        sy[tid] = s;
+        if (gl == 2) {
+            c2 += __shfl_down(c2, 12);                                     // lanes (la, k): fold la = 0..3
+            c2 += __shfl_down(c2, 6);
+            if (tid < 6) rg_new[(size_t)blockIdx.x * 6 + tid] = c2;       // exact r2 of the own aggregate
+        }
     }
     __syncthreads();
     double acc = 0.;
     if (act) {
-        const double* y = sy + ((tid / 6) / kMlFanout) * 6;
-        double add;
-        if (r < 3) {
-            const double dx = geo[9], dy = geo[10], dz = geo[11];
-            const double vx = y[0] + (y[4] * dz - y[5] * dy);
-            const double vy = y[1] + (y[5] * dx - y[3] * dz);
-            const double vz = y[2] + (y[3] * dy - y[4] * dx);
-            add = geo[r * 3] * vx + geo[r * 3 + 1] * vy + geo[r * 3 + 2] * vz;
-        } else {
-            const int k = r - 3;
-            add = 0.5 * (geo[k * 3] * y[3] + geo[k * 3 + 1] * y[4] + geo[k * 3 + 2] * y[5]);
-        }
-        zz += add;
+        zz += p1_comp(geo, sy + ((tid / 6) / kMlFanout) * 6, r);
         D.z[(size_t)a * 6 + r] = zz;
         acc = rv * zz;
     }
     STAMP(0);      // 7: y1, z
-    const double tot = block_sum6(acc, s6);
+    const double tot = block_sum_w<3>(acc, s3);
     if (tid == 0) {
         D.part_b[blockIdx.x] = tot;
         if (blockIdx.x == 0 && !init) {
@@ -990,48 +807,46 @@ void k_ml_invert(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s
     if (total_aggs > 0) hipLaunchKernelGGL(ml_invert_kernel, dim3((total_aggs + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml);
     hipLaunchKernelGGL(ml_top_kernel, dim3(1), dim3(kBlk), 0, s, D, ml);
 }
-int g_ml_rows(int nb) { return (nb + kRowsPerBlk - 1) / kRowsPerBlk; }
-// the fused finish kernel stages the residuals of levels >= min(2, L) in LDS
-size_t ml_cg_lds_bytes(const int* n, int levels);
-bool ml_fits_lds(const int* n_per_level, int levels)
+int g_ml_rows(int nb, int agg) { return (nb + kMlFanout * agg - 1) / (kMlFanout * agg); }
+// dynamic LDS of ml_cg_kernel for a hierarchy (n[0..levels]) and workgroup geometry agg
+size_t ml_cg_lds_bytes(const int* n, int levels, int agg)
 {
-    return ml_cg_lds_bytes(n_per_level, levels) <= 140 * 1024 && (n_per_level[0] + kMlFanout - 1) / kMlFanout <= kMaxPartials;
-}
-void k_ml_update(const PgoDev& D, const MlDev* ml, const double* p, double* p0, double* p1, int n_part, int init, hipStream_t s)
-{
-    hipLaunchKernelGGL(ml_update_kernel, dim3(g_ml_rows(D.nb)), dim3(kMlBlk), 0, s, D, ml, p, p0, p1, n_part, init);
-}
-void k_ml_finish(const PgoDev& D, const MlDev* ml, hipStream_t s)
-{
-    hipLaunchKernelGGL(ml_finish_kernel, dim3(g_ml_rows(D.nb)), dim3(kMlBlk), 0, s, D, ml);
-}
-int g_ml_spmv(int nb) { return (nb + kMlFanout - 1) / kMlFanout; }
-void k_ml_spmv(const PgoDev& D, const MlHot& ml, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s)
-{
-    hipLaunchKernelGGL(ml_spmv_kernel, dim3(g_ml_spmv(D.nb)), dim3(kSpmvBlk), 0, s, D, ml, p_old, p_new, n_part, tol2);
-}
-// dynamic LDS of ml_cg_kernel for a hierarchy (n_per_level[0..levels])
-size_t ml_cg_lds_bytes(const int* n, int levels)
-{
+    const int g = (agg == 1 || levels < 2) ? 1 : 2;
     size_t d = 0;
-    for (int l = 2; l <= levels; l++) d += 6 * (size_t)n[l];
-    for (int l = 2; l < levels; l++) d += 3 * (size_t)n[l];
+    for (int l = g; l <= levels; l++) d += 6 * (size_t)n[l];
+    for (int l = g; l < levels; l++) d += 3 * (size_t)n[l];
     const size_t ntop = 6 * (size_t)n[levels];
-    d += ((levels == 1) ? (size_t)kAggPerBlk * 6 : 6) * ntop;
+    d += ((levels == 1) ? (size_t)agg * 6 : 6) * ntop;
     if (levels > 2) d += (size_t)(levels - 2) * 39;
-    d += (levels == 1) ? ntop : (size_t)9 * kL1Chunk;            // level-1 chunk buffer (L == 1: r1 = top residual)
     return d * 8;
 }
-hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, const double* p, const double* r1_old, double* r1_new, int n_part,
+bool ml_fits_lds(const int* n_per_level, int levels, int agg)
+{
+    return ml_cg_lds_bytes(n_per_level, levels, agg) <= 140 * 1024 && g_ml_rows(n_per_level[0], agg) <= kMaxPartials;
+}
+void k_ml_init(const PgoDev& D, const MlHot& ml, int agg, double* p0, double* p1, double* rg, hipStream_t s)
+{
+    if (agg == 1) hipLaunchKernelGGL(ml_init_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, D, ml, p0, p1, rg);
+    else hipLaunchKernelGGL(ml_init_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), 0, s, D, ml, p0, p1, rg);
+}
+void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s)
+{
+    if (agg == 1) hipLaunchKernelGGL(ml_spmv_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(512), 0, s, D, ml, p_old, p_new, n_part, tol2);
+    else hipLaunchKernelGGL(ml_spmv_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(512), 0, s, D, ml, p_old, p_new, n_part, tol2);
+}
+hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
                    int init, size_t lds, hipStream_t s)
 {
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ml_cg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t configured[2] = {0, 0};
+    const int ci = agg == 1 ? 0 : 1;
+    if (lds > configured[ci]) {
+        const void* fn = agg == 1 ? reinterpret_cast<const void*>(&ml_cg_kernel<1>) : reinterpret_cast<const void*>(&ml_cg_kernel<4>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = lds;
+        configured[ci] = lds;
     }
-    hipLaunchKernelGGL(ml_cg_kernel, dim3(g_ml_rows(D.nb)), dim3(kMlBlk), lds, s, D, ml, p, r1_old, r1_new, n_part, init);
+    if (agg == 1) hipLaunchKernelGGL(ml_cg_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
+    else hipLaunchKernelGGL(ml_cg_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     return hipSuccess;
 }
 

@@ -59,11 +59,14 @@ struct PgoDev {
 // exact null space of a pose graph; for a vertex i (R_i, t_i) in local MQT coordinates
 //     P_i = [[R_i^T, -R_i^T [t_i - c]x], [0, 1/2 R_i^T]],  and between levels  P = [[I, -[c_child - c]x], [0, I]].
 constexpr int kMlMaxLevels = 8;
-constexpr int kMlFanout = 8;
+constexpr int kMlFanout = 8;         // level 1: 8 vertices per aggregate; levels >= 3: 8 children
+constexpr int kMlFanout2 = 4;        // level 2: 4 level-1 aggregates = 32 vertices = one workgroup of the PCG kernels
 constexpr int kMlTopMax = 8;          // aggregates at the top level (<= 48 dof dense)
 
 struct MlLevel {
     int32_t n;                 // entities at this level (level 0: nb)
+    int32_t fan;               // children per aggregate (levels >= 1)
+    int32_t span;              // level-0 blocks under one aggregate
     int32_t nslots;            // off-diagonal blocks of A_l (level 0: the block-CSR above)
     const int32_t* row_ptr;    // [n+1]  (levels >= 1)
     const int32_t* col;        // [nslots]
@@ -91,7 +94,7 @@ struct MlDev {
     double* tmpG;              // [max n][36]
     double* tmpM;              // [max n][36]
     double* top_inv;           // [(6 n_top)^2] dense inverse of A_L(lambda)
-    double* S1;                // [n_1][6] level-1 restriction of A p (written by ml_spmv)
+    double* Sg;                // [n_g][6] restriction of A p at the gather level (written by ml_spmv)
 };
 
 // Hot subset of MlDev passed BY VALUE to the per-iteration kernels (kernel arguments are preloaded; going
@@ -99,11 +102,12 @@ struct MlDev {
 struct MlHot {
     int32_t levels;
     int32_t n[kMlMaxLevels + 1];
+    int32_t fan[kMlMaxLevels + 1];
     const double* geo0;                    // [nb][12]
     const double* geo[kMlMaxLevels + 1];   // [n_l][3], l >= 1
     const double* Dinv[kMlMaxLevels + 1];  // [n_l][36], 1 <= l < levels
     const double* top_inv;
-    double* S1;
+    double* Sg;                            // [n_g][6] restriction of A p at the gather level g = min(2, levels)
 };
 
 // scalars copied back to the host after each LM trial / PCG chunk

@@ -36,14 +36,13 @@ void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, 
 void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s);
 void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
 void k_ml_invert(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
-int g_ml_rows(int nb);
-void k_ml_update(const PgoDev& D, const MlDev* ml, const double* p, double* p0, double* p1, int n_part, int init, hipStream_t s);
-bool ml_fits_lds(const int* n_per_level, int levels);
-void k_ml_finish(const PgoDev& D, const MlDev* ml, hipStream_t s);
-int g_ml_spmv(int nb);
-void k_ml_spmv(const PgoDev& D, const MlHot& ml, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
-size_t ml_cg_lds_bytes(const int* n, int levels);
-hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, const double* p, const double* r1_old, double* r1_new, int n_part, int init, size_t lds, hipStream_t s);
+int g_ml_rows(int nb, int agg);
+size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
+bool ml_fits_lds(const int* n_per_level, int levels, int agg);
+void k_ml_init(const PgoDev& D, const MlHot& ml, int agg, double* p0, double* p1, double* rg, hipStream_t s);
+void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
+hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
+                   int init, size_t lds, hipStream_t s);
 int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
@@ -82,7 +81,9 @@ struct uzl_pgo {
     int ml_levels = 0;
     std::vector<int32_t> ml_n, ml_nslots;
     int ml_inner_aggs = 0;
-    double* ml_r1[2] = {nullptr, nullptr};     // double-buffered level-1 residual
+    double* ml_rg[2] = {nullptr, nullptr};     // double-buffered gather-level residual
+    std::vector<int32_t> ml_fan;
+    int ml_agg = 4;                            // level-1 aggregates per PCG workgroup (1: small graphs, 4: large)
     size_t ml_lds = 0;
     MlHot ml_hot;
     DevBuf<uint8_t> ml_arena;
@@ -187,11 +188,18 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     const int nb = h->nb;
     h->ml_levels = 0; h->ml_n.assign(1, nb); h->ml_nslots.assign(1, h->nslots); h->ml_inner_aggs = 0;
     if (h->cfg.preconditioner == 0 || nb <= kMlTopMax) return;
+    h->ml_agg = nb <= 4096 ? 1 : 4;
     int L = 0;
-    while (h->ml_n.back() > kMlTopMax && L < kMlMaxLevels) { h->ml_n.push_back((h->ml_n.back() + kMlFanout - 1) / kMlFanout); L++; }
-    if (!ml_fits_lds(h->ml_n.data(), L)) { h->ml_n.assign(1, nb); return; }     // > ~70k free vertices: block-Jacobi
+    h->ml_fan.assign(1, 1);
+    while (h->ml_n.back() > kMlTopMax && L < kMlMaxLevels) {
+        const int fan = (L == 1 && h->ml_agg == 4) ? kMlFanout2 : kMlFanout;     // large graphs: level 2 = 4 level-1 aggregates
+        h->ml_fan.push_back(fan);
+        h->ml_n.push_back((h->ml_n.back() + fan - 1) / fan);
+        L++;
+    }
+    if (!ml_fits_lds(h->ml_n.data(), L, h->ml_agg)) { h->ml_n.assign(1, nb); return; }     // > ~70k free vertices: block-Jacobi
     h->ml_levels = L;
-    h->ml_lds = ml_cg_lds_bytes(h->ml_n.data(), L);
+    h->ml_lds = ml_cg_lds_bytes(h->ml_n.data(), L, h->ml_agg);
     // per-level host index arrays
     struct Lv { std::vector<int32_t> row_ptr, col, srow, tpos, off_ptr, diag_ptr; int32_t n_off = 0; };
     std::vector<Lv> lv((size_t)L + 1);
@@ -203,12 +211,13 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         Lv& F = lv[f]; Lv& C = lv[f + 1];
         const int nc = h->ml_n[f + 1];
         const int ns = (int)F.col.size();
+        const int fan_c = h->ml_fan[f + 1];
         struct Off { int32_t A, C, s; };
         std::vector<Off> off; std::vector<std::pair<int32_t, int32_t>> dg;
         for (int s = 0; s < ns; s++) {
             const int c = F.col[s];
             if (c < 0) continue;
-            const int A = F.srow[s] / kMlFanout, Cc = c / kMlFanout;
+            const int A = F.srow[s] / fan_c, Cc = c / fan_c;
             if (A != Cc) off.push_back({A, Cc, s}); else dg.push_back({A, s});
         }
         std::sort(off.begin(), off.end(), [](const Off& x, const Off& y) {
@@ -266,8 +275,9 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     }
     const size_t o_tmp = take(max_contrib * 36 * 8), o_tmpG = take(max_n * 36 * 8), o_tmpM = take(max_n * 36 * 8);
     const size_t o_top = take((size_t)(6 * kMlTopMax) * (6 * kMlTopMax) * 8);
-    const size_t o_s1 = take((size_t)std::max(h->ml_n[1], 1) * 6 * 8);
-    const size_t o_r1b = take((size_t)std::max(h->ml_n[1], 1) * 6 * 8);
+    const int gl = (h->ml_agg == 1 || L < 2) ? 1 : 2;
+    const size_t ngz = (size_t)std::max(h->ml_n[gl], 1) * 6 * 8;
+    const size_t o_sg = take(ngz), o_rga = take(ngz), o_rgb = take(ngz);
     h->ml_arena.reserve(bytes);
     std::vector<uint8_t> stage(int_bytes, 0);
     auto put = [&](size_t o, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage.data() + o, v.data(), v.size() * 4); };
@@ -284,6 +294,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     for (int l = 0; l <= L; l++) {
         MlLevel& X = M.lv[l];
         X.n = h->ml_n[l]; X.nslots = h->ml_nslots[l];
+        X.fan = h->ml_fan[l];
+        X.span = 1; for (int q = 1; q <= l; q++) X.span *= h->ml_fan[q];
         X.row_ptr = (l == 0) ? h->d_row_ptr.p : reinterpret_cast<const int32_t*>(base + io[l].row_ptr);
         X.col = (l == 0) ? h->d_col.p : reinterpret_cast<const int32_t*>(base + io[l].col);
         X.srow = reinterpret_cast<const int32_t*>(base + io[l].srow);
@@ -304,14 +316,14 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     M.tmpG = reinterpret_cast<double*>(base + o_tmpG);
     M.tmpM = reinterpret_cast<double*>(base + o_tmpM);
     M.top_inv = reinterpret_cast<double*>(base + o_top);
-    M.S1 = reinterpret_cast<double*>(base + o_s1);
-    h->ml_r1[0] = M.lv[1].r;
-    h->ml_r1[1] = reinterpret_cast<double*>(base + o_r1b);
+    M.Sg = reinterpret_cast<double*>(base + o_sg);
+    h->ml_rg[0] = reinterpret_cast<double*>(base + o_rga);
+    h->ml_rg[1] = reinterpret_cast<double*>(base + o_rgb);
     MlHot& Hh = h->ml_hot;
     memset(&Hh, 0, sizeof(Hh));
     Hh.levels = L;
-    for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.geo[l] = M.lv[l].geo; Hh.Dinv[l] = M.lv[l].Dinv; }
-    Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.S1 = M.S1;
+    for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Dinv[l] = M.lv[l].Dinv; }
+    Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg;
     h->d_ml.reserve(1);
     UZL_HIP(hipMemcpyAsync(h->d_ml.p, &M, sizeof(M), hipMemcpyHostToDevice, s));
     UZL_HIP(hipStreamSynchronize(s));      // stage / M are locals
@@ -396,15 +408,15 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
     const PgoDev& D = h->D;
     const double tol2 = h->cfg.pcg_tol * h->cfg.pcg_tol;
     const bool ml = h->ml_levels > 0;
-    const int ga = ml ? g_ml_spmv(D.nb) : g_pcg_spmv(D.nb), gu = ml ? g_ml_rows(D.nb) : g_pcg_update(D.nb);
+    const int ga = ml ? g_ml_rows(D.nb, h->ml_agg) : g_pcg_spmv(D.nb), gu = ml ? g_ml_rows(D.nb, h->ml_agg) : g_pcg_update(D.nb);
     double* pb[2] = {h->d_p.p, h->d_p2.p};
     for (int i = 0; i < 2 * pairs; i++) {
         double* po = pb[i & 1];
         double* pn = pb[(i & 1) ^ 1];
         if (timed) h->timer.begin("pcg_spmv", s);
-        if (ml) k_ml_spmv(D, h->ml_hot, po, pn, gu, tol2, s); else k_pcg_spmv(D, po, pn, gu, tol2, s);
+        if (ml) k_ml_spmv(D, h->ml_hot, h->ml_agg, po, pn, gu, tol2, s); else k_pcg_spmv(D, po, pn, gu, tol2, s);
         if (timed) { h->timer.end(s); h->timer.begin(ml ? "ml_cg" : "pcg_update", s); }
-        if (ml) UZL_HIP(k_ml_cg(D, h->ml_hot, pn, h->ml_r1[i & 1], h->ml_r1[(i & 1) ^ 1], ga, 0, h->ml_lds, s)); else k_pcg_update(D, pn, ga, s);
+        if (ml) UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, pn, h->ml_rg[(i & 1) ^ 1], h->ml_rg[i & 1], ga, 0, h->ml_lds, s)); else k_pcg_update(D, pn, ga, s);
         if (timed) h->timer.end(s);
     }
 }
@@ -438,8 +450,8 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     { Timed t(h, "precond"); k_precond(D, s); }
     if (h->ml_levels > 0) {
         { Timed t(h, "ml_invert"); k_ml_invert(D, h->d_ml.p, h->ml_inner_aggs, s); }
-        { Timed t(h, "pcg_init"); k_ml_update(D, h->d_ml.p, h->d_p.p, h->d_p.p, h->d_p2.p, 0, 1, s); }
-        { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, h->ml_hot, h->d_p.p, h->ml_r1[0], h->ml_r1[0], 0, 1, h->ml_lds, s)); }
+        { Timed t(h, "pcg_init"); k_ml_init(D, h->ml_hot, h->ml_agg, h->d_p.p, h->d_p2.p, h->ml_rg[0], s); }
+        { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, h->d_p.p, h->ml_rg[0], h->ml_rg[1], 0, 1, h->ml_lds, s)); }
     } else {
         Timed t(h, "pcg_init"); k_pcg_init(D, h->d_p.p, h->d_p2.p, s);
     }
@@ -579,7 +591,7 @@ void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg)
     cfg->use_odometry_parameters = 0;   // :11
     cfg->optimize_xy_only = 0;          // :12
     cfg->device = 0;
-    cfg->pcg_tol = 1e-8;
+    cfg->pcg_tol = 1e-6;                // relative M^-1-norm residual; g2o's own LinearSolverPCG default [EXT]
     cfg->pcg_max_iter = 0;              // 0 = 6 * free vertices (system dimension)
     cfg->huber_delta = 1.0;             // g2o_optimizer.cpp:293
     cfg->verbose = 0;
