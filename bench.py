@@ -54,7 +54,7 @@ class Dist:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.torch = None
-        if self.world > 1:
+        if self.world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -114,7 +114,8 @@ def main():
     dev = dist.local_rank
 
     # ------------------------------------------------------------------ primary: pose-graph solve
-    g = synth.make_pose_graph(a.nodes, a.edges, seed=12345 + dist.rank)     # one independent graph per rank
+    from uzliti_slam_amd import dist as ud
+    g = synth.make_pose_graph(a.nodes, a.edges, seed=ud.replica_seed(12345, dist.rank))   # one independent graph per rank
     pgo = capi.Pgo(device=dev, iterations=a.lm_iters)
     pgo.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])            # H2D once, outside the timed region
     work = {"edges": 0, "pcg": 0, "trials": 0}
@@ -151,7 +152,7 @@ def main():
             traffic = json.load(open(tpath)).get("pcg_spmv_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = dict(kernel="pcg_spmv_kernel", bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+    roofline = dict(kernel=("ml_spmv_kernel" if pgo.cfg.preconditioner else "pcg_spmv_kernel"), bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(spmv_us, 3), launches=spmv["launches"],
                     note="working set (H = %.1f MB) is L2/Infinity-Cache resident; launch-latency bound at this size"

@@ -39,7 +39,7 @@ for k, d in pmc.items():
     d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
 json.dump(pmc, open(out + "_pmc.json", "w"), indent=1, sort_keys=True)
 t = {}
-for key, names in (("pcg_spmv_bytes_per_launch", ("uzl::ml_spmv_kernel", "uzl::pcg_spmv_kernel")),
+for key, names in (("pcg_spmv_bytes_per_launch", ("uzl::ml_spmv_kernel<1>", "uzl::ml_spmv_kernel<4>", "uzl::ml_spmv_kernel", "uzl::pcg_spmv_kernel")),
                    ("knn2_bytes_per_launch", ("uzl::knn2_kernel<8>",))):
     for nm in names:
         if nm in pmc:
