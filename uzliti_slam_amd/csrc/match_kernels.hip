@@ -19,6 +19,17 @@
 
 namespace uzl {
 
+// Diagnostic build only (-DUZL_STAMPS): phase times of estimate_kernel (block 0 / thread 0, 100 MHz clock)
+#ifdef UZL_STAMPS
+__device__ unsigned long long g_mstamps[32];
+#define MSTAMP_DECL unsigned long long st_prev_ = __builtin_amdgcn_s_memrealtime(); int st_i_ = 0;
+#define MSTAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); \
+        atomicAdd(&g_mstamps[st_i_], n_ - st_prev_); st_prev_ = n_; } st_i_++; } while (0)
+#else
+#define MSTAMP_DECL
+#define MSTAMP() do { } while (0)
+#endif
+
 constexpr int kBlock = 256;
 
 // ------------------------------------------------------------------------------------------------
@@ -336,24 +347,29 @@ __device__ __forceinline__ int wave_sum(int v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+constexpr int kEstBlock = 256;          // estimate_kernel: 4 waves; 172 VGPRs + 63 KB LDS allow two workgroups per CU
 __device__ __forceinline__ int block_sum(int v, int* s_part)
 {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
     __syncthreads();
-    return s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < kEstBlock / 64; w++) t += s_part[w];
+    return t;
 }
 
 template <bool IN_LDS>
-__global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
+__global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_part[4];
+    __shared__ int s_part[kEstBlock / 64];
     __shared__ int s_misc[8];
     __shared__ double s_T[12];
     __shared__ double s_dbl[2];
 
+    MSTAMP_DECL
     const int tid = threadIdx.x;
     const int jb = blockIdx.x;
     const Job job = A.jobs[jb];
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
             const uint2* __restrict__ kn = A.knn + c.knn_off;
             int cnt = 0;
             if (c.nt >= 2) {
-                for (int q = tid; q < c.nq; q += kBlock) {
+                for (int q = tid; q < c.nq; q += kEstBlock) {
                     const uint2 k2 = kn[q];
                     const float d0 = (float)(k2.x >> kIdxBits), d1 = (float)(k2.y >> kIdxBits);
                     cnt += ((double)d0 < 0.99 * (double)d1) ? 1 : 0;                 // :67
@@ -406,10 +422,10 @@ __global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
             const uint8_t* __restrict__ vfrom = A.arena + c.valid_from_off;
             const uint8_t* __restrict__ vto = A.arena + c.valid_to_off;
             // ---- M2 + M4a: ratio test + valid_3d filter, ordered compaction of (distance, queryIdx) keys
-            for (int i = tid; i < A.sort_cap; i += kBlock) s_keys[i] = 0xffffffffu;
+            for (int i = tid; i < A.sort_cap; i += kEstBlock) s_keys[i] = 0xffffffffu;
             __syncthreads();
             int base = 0;
-            for (int q0 = 0; q0 < c.nq; q0 += kBlock) {
+            for (int q0 = 0; q0 < c.nq; q0 += kEstBlock) {
                 const int q = q0 + tid;
                 bool keep = false;
                 uint32_t key = 0;
@@ -429,18 +445,21 @@ __global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
                 __syncthreads();
                 int woff = 0;
                 for (int w = 0; w < wv; w++) woff += s_part[w];
-                const int total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+                int total = 0;
+#pragma unroll
+                for (int w = 0; w < kEstBlock / 64; w++) total += s_part[w];
                 if (keep) s_keys[base + woff + __popcll(bal & ((1ull << lane) - 1ull))] = key;
                 base += total;
             }
             M = base;
             __syncthreads();
+            MSTAMP();   // 0: selection + ratio/valid compaction
             // ---- M4b: std::sort by distance (:114), order fixed to (distance, queryIdx): bitonic in LDS
             int n2 = 1;
             while (n2 < M) n2 <<= 1;
             for (int k = 2; k <= n2; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < n2; i += kBlock) {
+                    for (int i = tid; i < n2; i += kEstBlock) {
                         const int ixj = i ^ j;
                         if (ixj > i) {
                             const uint32_t a = s_keys[i], b = s_keys[ixj];
@@ -451,10 +470,11 @@ __global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
                     __syncthreads();
                 }
             }
+            MSTAMP();   // 1: bitonic sort
             // ---- M5: gather Xd (from/train) and Pd (to/query) (:118-124); P = Pd, Q = Xd (:130)
             const double* __restrict__ pfrom = reinterpret_cast<const double*>(A.arena) + c.pos_from_off;
             const double* __restrict__ pto = reinterpret_cast<const double*>(A.arena) + c.pos_to_off;
-            for (int m = tid; m < M; m += kBlock) {
+            for (int m = tid; m < M; m += kEstBlock) {
                 const uint32_t key = s_keys[m];
                 const int q = (int)(key & kIdxMask);
                 const int t = (int)(kn[q].x & kIdxMask);
@@ -472,13 +492,14 @@ __global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
         have_pair = true;
         M = job.pq_count;
         r_n_matches = M;
-        for (int m = tid; m < M; m += kBlock) {
+        for (int m = tid; m < M; m += kEstBlock) {
             const size_t col = (size_t)job.pq_off + m;
 #pragma unroll
             for (int r = 0; r < 3; r++) { pq[m * 6 + r] = A.P_in[3 * col + r]; pq[m * 6 + 3 + r] = A.Q_in[3 * col + r]; }
         }
     }
     __syncthreads();
+    MSTAMP();           // 2: gather
 
     // ---- M6: PROSAC (:186-243), one hypothesis per lane, correspondences broadcast from the tile
     int max_cons = 0, best_it = -1, it_run = 0;
@@ -486,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
         const uint64_t key = stream_key(prm.seed, job.job_id);
         const double thr2 = sqrt_threshold(prm.thresh);
         bool stop = false;
-        for (int r0 = 0; r0 < iters && !stop; r0 += kBlock) {
+        for (int r0 = 0; r0 < iters && !stop; r0 += kEstBlock) {
             const int it = r0 + tid;
             if (it < iters) {
                 const int n = prm.do_prosac ? prosac_prefix(it, iters, M) : M;
@@ -500,13 +521,23 @@ __global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
                 double T[12];
                 pose_finish(acc, T);                                                   // :227
                 int cnt = 0;
-                for (int m = 0; m < M; m++) cnt += (point_dist2(pq + m * 6, T) < thr2) ? 1 : 0;   // :230
+                int m = 0;
+                for (; m + 4 <= M; m += 4) {                // four correspondences per step: their LDS reads overlap
+                    double c[24];
+                    const double2* __restrict__ p2 = reinterpret_cast<const double2*>(pq + m * 6);   // 48-byte points: 16-B aligned
+#pragma unroll
+                    for (int k = 0; k < 12; k++) { const double2 v2 = p2[k]; c[2 * k] = v2.x; c[2 * k + 1] = v2.y; }
+                    __builtin_amdgcn_sched_barrier(0);      // all twelve reads in flight before the first use
+#pragma unroll
+                    for (int u = 0; u < 4; u++) cnt += (point_dist2(c + 6 * u, T) < thr2) ? 1 : 0;   // :230
+                }
+                for (; m < M; m++) cnt += (point_dist2(pq + m * 6, T) < thr2) ? 1 : 0;
                 s_cnt[it] = cnt;
             }
             __syncthreads();
             // replay the sequential bookkeeping of :233-242 over this round's votes
             if (tid == 0) {
-                const int rend = (r0 + kBlock < iters) ? r0 + kBlock : iters;
+                const int rend = (r0 + kEstBlock < iters) ? r0 + kEstBlock : iters;
                 int mc = s_misc[0], bi = s_misc[1], ir = s_misc[2], st = 0;
                 if (r0 == 0) { mc = 0; bi = -1; ir = 0; }
                 for (int i = r0; i < rend; i++) {
@@ -526,6 +557,7 @@ __global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
         __syncthreads();
     }
 
+    MSTAMP();           // 3: hypotheses + votes + bookkeeping
     // ---- refit on the best consensus set (:245-258), recount, mse (:285-290)
     double Tfin[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     double mse = 0.;
@@ -552,25 +584,73 @@ __global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
         double T[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) T[k] = s_T[k];
-        for (int m = tid; m < M; m += kBlock) mask[m] = (point_dist2(pq + m * 6, T) < thr2) ? 1 : 0;   // maxConsensusSet
+        for (int m = tid; m < M; m += kEstBlock) mask[m] = (point_dist2(pq + m * 6, T) < thr2) ? 1 : 0;   // maxConsensusSet
         __syncthreads();
-        // pose_function(Pfinal, Qfinal, T) (:257): running mean / covariance in inlier order (sequential recurrence)
-        if (tid == 0) {
-            PoseAcc acc;
-            pose_init(acc);
-            for (int m = 0; m < M; m++)
-                if (mask[m]) pose_add(acc, pq[m * 6 + 0], pq[m * 6 + 1], pq[m * 6 + 2], pq[m * 6 + 3], pq[m * 6 + 4], pq[m * 6 + 5]);
-            double Tr[12];
-            pose_finish(acc, Tr);
+        MSTAMP();       // 4: winning hypothesis + its mask
+        // pose_function(Pfinal, Qfinal, T) (:257): running mean / covariance in inlier order.  The recurrence is
+        // sequential in the inliers, but its 9 covariance entries are independent of each other: lane (r, c) of wave 0
+        // carries cov[r][c] together with its own copies of mean1[c] and mean2[r] and performs exactly the scalar
+        // operations of pose_add for that entry (bit-identical to the single-lane loop, ~5x shorter dependency chain).
+        if (tid < 64) {
+            const int rr = (tid < 9) ? tid / 3 : 0, cc = (tid < 9) ? tid % 3 : 0;
+            float cov = 0.f, m1 = 0.f, m2 = 0.f, accw = 0.f;
+            for (int m0 = 0; m0 < M; m0 += 8) {
+                float pc[8], qr[8], al[8];
+                bool in[8];
+                double pd[8], qd[8];
+                uint8_t mk[8];
 #pragma unroll
-            for (int k = 0; k < 12; k++) s_T[k] = Tr[k];
+                for (int u = 0; u < 8; u++) {
+                    const int m = (m0 + u < M) ? m0 + u : M - 1;
+                    mk[u] = mask[m]; pd[u] = pq[m * 6 + cc]; qd[u] = pq[m * 6 + 3 + rr];
+                }
+                __builtin_amdgcn_sched_barrier(0);          // all 24 LDS reads in flight before the first use
+                float cntf = accw;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    in[u] = (m0 + u < M) && mk[u] != 0;
+                    pc[u] = (float)pd[u];
+                    qr[u] = (float)qd[u];
+                    // accw only counts inliers (exact small integers in float), so alpha = 1/accw does not depend on
+                    // the recurrence: the eight divisions are taken off its dependency chain
+                    if (in[u]) cntf += 1.f;
+                    al[u] = 1.f / cntf;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (in[u]) {
+                        accw += 1.f;
+                        const float alpha = al[u];
+                        const float om = 1.f - alpha;
+                        const float d1 = pc[u] - m1, d2 = qr[u] - m2;
+                        cov = om * (cov + alpha * (d2 * d1));
+                        m1 += alpha * d1;
+                        m2 += alpha * d2;
+                    }
+                }
+            }
+            // gather the 9 + 3 + 3 values into lane 0
+            PoseAcc acc;
+            acc.c00 = __shfl(cov, 0); acc.c01 = __shfl(cov, 1); acc.c02 = __shfl(cov, 2);
+            acc.c10 = __shfl(cov, 3); acc.c11 = __shfl(cov, 4); acc.c12 = __shfl(cov, 5);
+            acc.c20 = __shfl(cov, 6); acc.c21 = __shfl(cov, 7); acc.c22 = __shfl(cov, 8);
+            acc.m1x = __shfl(m1, 0); acc.m1y = __shfl(m1, 1); acc.m1z = __shfl(m1, 2);       // lanes (0, c)
+            acc.m2x = __shfl(m2, 0); acc.m2y = __shfl(m2, 3); acc.m2z = __shfl(m2, 6);       // lanes (r, 0)
+            acc.accw = accw;
+            if (tid == 0) {
+                double Tr[12];
+                pose_finish(acc, Tr);
+#pragma unroll
+                for (int k = 0; k < 12; k++) s_T[k] = Tr[k];
+            }
         }
         __syncthreads();
+        MSTAMP();       // 5: sequential refit
 #pragma unroll
         for (int k = 0; k < 12; k++) Tfin[k] = s_T[k];
         // maxConsensus = consensus_function(P, Q, T, maxConsensusSet) (:258) and the distances for mse
         int c = 0;
-        for (int m = tid; m < M; m += kBlock) {
+        for (int m = tid; m < M; m += kEstBlock) {
             const double d2 = point_dist2(pq + m * 6, Tfin);
             const bool in = d2 < thr2;
             mask[m] = in ? 1 : 0;
@@ -580,17 +660,28 @@ __global__ __launch_bounds__(kBlock) void estimate_kernel(EstimateArgs A)
         cons = block_sum(c, s_part);
         if (tid == 0) {
             double e = 0.;
-            for (int m = 0; m < M; m++) if (mask[m]) e += dist[m];                     // :285-289, index order
+            int m = 0;
+            for (; m + 8 <= M; m += 8) {                                                // :285-289, index order; loads batched
+                double dv[8];
+                uint8_t mv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { mv[u] = mask[m + u]; dv[u] = dist[m + u]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; u++) e += mv[u] ? dv[u] : 0.;                    // + 0.0 leaves the sum unchanged
+            }
+            for (; m < M; m++) if (mask[m]) e += dist[m];
             s_dbl[0] = e / cons;                                                        // :290
         }
         __syncthreads();
         mse = s_dbl[0];
+        MSTAMP();       // 6: recount + mse
     } else {
-        for (int m = tid; m < M; m += kBlock) mask[m] = 0;                              // :291-294
+        for (int m = tid; m < M; m += kEstBlock) mask[m] = 0;                              // :291-294
         __syncthreads();
     }
     if (A.inlier_mask) {
-        for (int m = tid; m < M && m < prm.max_corr; m += kBlock) A.inlier_mask[(size_t)jb * prm.max_corr + m] = mask[m];
+        for (int m = tid; m < M && m < prm.max_corr; m += kEstBlock) A.inlier_mask[(size_t)jb * prm.max_corr + m] = mask[m];
     }
     if (tid == 0) {
         uzl_edge_result* res = A.results + jb;
@@ -643,14 +734,23 @@ hipError_t launch_estimate(const EstimateArgs& a, int n_jobs, bool in_lds, size_
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&estimate_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(estimate_kernel<true>, dim3(n_jobs), dim3(kBlock), lds_bytes, s, a);
+        hipLaunchKernelGGL(estimate_kernel<true>, dim3(n_jobs), dim3(kEstBlock), lds_bytes, s, a);
     } else {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&estimate_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(estimate_kernel<false>, dim3(n_jobs), dim3(kBlock), lds_bytes, s, a);
+        hipLaunchKernelGGL(estimate_kernel<false>, dim3(n_jobs), dim3(kEstBlock), lds_bytes, s, a);
     }
     return hipGetLastError();
 }
 
 }  // namespace uzl
+
+#ifdef UZL_STAMPS
+extern "C" int uzl_debug_read_mstamps(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(uzl::g_mstamps), sizeof(unsigned long long) * 32) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(uzl::g_mstamps), z, sizeof(z)) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
