@@ -75,6 +75,61 @@ __global__ __launch_bounds__(kBlock) void knn2_kernel(const uint32_t* __restrict
     if (q < c.nq) knn[c.knn_off + q] = make_uint2(best1, best2);
 }
 
+// LDS variant: the train set is staged tile by tile in LDS (coalesced 16-B loads) and every lane reads each train
+// descriptor with broadcast ds_read_b128 (all lanes, same address: conflict-free).  Unlike scalar loads, LDS reads
+// return in order, so the compiler pipelines them; QPL = 2 queries per lane keeps the LDS pipe (8 cycles per
+// descriptor per wave) well below the VALU time (2 x 20 instructions x 2 cycles).
+template <int W, int QPL>
+__global__ __launch_bounds__(kBlock) void knn2_lds_kernel(const uint32_t* __restrict__ arena,
+                                                          const Combo* __restrict__ combos,
+                                                          uint2* __restrict__ knn)
+{
+    constexpr int TILE = 8192 / W;                             // descriptors per 32 KB tile
+    __shared__ uint4 st[TILE * W / 4];
+    const Combo c = combos[blockIdx.y];
+    if (c.words != W) return;
+    const int q0 = blockIdx.x * (kBlock * QPL);
+    if (q0 >= c.nq) return;
+    uint32_t qw[QPL][W];
+    int qi[QPL];
+#pragma unroll
+    for (int u = 0; u < QPL; u++) {
+        qi[u] = q0 + u * kBlock + (int)threadIdx.x;
+        const int qc = qi[u] < c.nq ? qi[u] : c.nq - 1;
+        const uint4* __restrict__ qd = reinterpret_cast<const uint4*>(arena + c.desc_to_off + (size_t)qc * W);
+#pragma unroll
+        for (int k = 0; k < W / 4; k++) { const uint4 v = qd[k]; qw[u][4 * k] = v.x; qw[u][4 * k + 1] = v.y; qw[u][4 * k + 2] = v.z; qw[u][4 * k + 3] = v.w; }
+    }
+    uint32_t best1[QPL], best2[QPL];
+#pragma unroll
+    for (int u = 0; u < QPL; u++) { best1[u] = 0xffffffffu; best2[u] = 0xffffffffu; }
+    const uint4* __restrict__ td4 = reinterpret_cast<const uint4*>(arena + c.desc_from_off);
+    for (int t0 = 0; t0 < c.nt; t0 += TILE) {
+        const int tn = (c.nt - t0 < TILE) ? c.nt - t0 : TILE;
+        __syncthreads();
+        for (int i = threadIdx.x; i < tn * (W / 4); i += kBlock) st[i] = td4[(size_t)t0 * (W / 4) + i];
+        __syncthreads();
+#pragma unroll 4
+        for (int t = 0; t < tn; ++t) {
+            uint32_t tw[W];
+#pragma unroll
+            for (int k = 0; k < W / 4; k++) { const uint4 v = st[t * (W / 4) + k]; tw[4 * k] = v.x; tw[4 * k + 1] = v.y; tw[4 * k + 2] = v.z; tw[4 * k + 3] = v.w; }
+#pragma unroll
+            for (int u = 0; u < QPL; u++) {
+                uint32_t d0 = 0, d1 = 0;
+#pragma unroll
+                for (int k = 0; k < W; k += 2) { d0 += __popc(qw[u][k] ^ tw[k]); d1 += __popc(qw[u][k + 1] ^ tw[k + 1]); }
+                const uint32_t key = ((d0 + d1) << kIdxBits) | (uint32_t)(t0 + t);
+                best2[u] = second_of(best1[u], best2[u], key);
+                best1[u] = min(best1[u], key);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QPL; u++)
+        if (qi[u] < c.nq) knn[c.knn_off + qi[u]] = make_uint2(best1[u], best2[u]);
+}
+
 // generic descriptor width (words not 8 / 16): query words re-read from L1 each step
 __global__ __launch_bounds__(kBlock) void knn2_generic_kernel(const uint32_t* __restrict__ arena,
                                                               const Combo* __restrict__ combos,
