@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--hypotheses", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--sharded", action="store_true",
+                    help="N > 1 only: additionally time ONE 10000-node/50000-edge graph sharded over all ranks "
+                         "(BASELINE config 4, RCCL all-reduce per PCG iteration); reported under `sharded_c4`")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU-baseline sample")
     return ap.parse_args()
 
@@ -199,6 +202,28 @@ def main():
                                        traffic=None, measured_issue_peak=36800.0,
                                        note="integer VALU bound, not HBM/MFMA: 64 KB of descriptors feed 1.6e7 word-ops per pair; `peak` = 256 CU x 128 lanes/clk x 2.4 GHz (2 cycles per wave64 op); profiles/r01_ubench_valu_rates.txt measures 1.5-2.0 ns per wave-instruction per SIMD for v_xor/v_bcnt (~36.8 T lane-ops/s for this mix)"))
 
+    # ------------------------------------------------------------------ optional: config 4, one graph sharded over the ranks
+    sharded_c4 = None
+    if a.sharded and dist.world > 1:
+        import torch
+        import torch.distributed as td
+        from uzliti_slam_amd import sharded as sh
+        g4 = synth.make_pose_graph(10000, 50000, seed=12345)
+        p4 = capi.Pgo(device=dev)
+        p4.set_shard(dist.rank, dist.world, sh.make_rccl_allreduce(td, torch))
+        p4.add_graph(g4["nodes_pose"], g4["nodes_fixed"], g4["edges"])
+
+        def c4_step():
+            p4.reset()
+            return p4.optimize(a.lm_iters)
+        st4 = c4_step()
+        t4 = timed(dist, c4_step, max(1, a.steps // 5))
+        sharded_c4 = dict(metric="SE(3) edges optimized/sec, one graph sharded over all ranks", unit="edges/s", scaling="strong",
+                          value=round(st4["n_edges"] * st4["iterations_done"] * max(1, a.steps // 5) / t4, 1),
+                          ms_per_solve=round(1e3 * t4 / max(1, a.steps // 5), 3), pcg_iterations_per_solve=st4["pcg_iterations"],
+                          exchange="1 all-reduce per PCG iteration + 3 per LM trial", chi2_final=st4["chi2_final"])
+        p4.close()
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     cpu = None
     if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline:
@@ -241,6 +266,8 @@ def main():
                         pcg_iterations_per_solve=st["pcg_iterations"], pcg_tol=pgo.cfg.pcg_tol, preconditioner=("additive multilevel, 8-vertex rigid-body aggregates" if pgo.cfg.preconditioner else "block-Jacobi"),
                         chi2_initial=st["chi2_initial"], chi2_final=st["chi2_final"]),
             roofline=roofline, kernels_ms_per_solve=kernels_ms, cpu_baseline=cpu, secondary=secondary)
+        if sharded_c4 is not None:
+            out["sharded_c4"] = sharded_c4
         print(json.dumps(out))
     pgo.close()
     if matcher is not None:

@@ -1,0 +1,132 @@
+"""GPU test of the sharded single-graph solve (BASELINE config 4's exchange pattern) on ONE device: two handles act
+as rank 0 / rank 1, each linearising half of the edges, with an in-process all-reduce (device -> host, barrier, sum,
+host -> device) standing in for RCCL.  The result must equal the unsharded solve and the oracle."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from uzliti_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class InProcessAllReduce:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.bufs = [None] * world
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.calls = 0
+        self.doubles = 0
+
+    def fn(self, rank):
+        def allreduce(ptr, count, stream):
+            host = np.empty(count, np.float64)
+            assert self.hip.hipStreamSynchronize(ctypes.c_void_p(stream)) == 0
+            assert self.hip.hipMemcpy(host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(8 * count), 2) == 0
+            self.bufs[rank] = host
+            self.barrier.wait(timeout=120)
+            total = self.bufs[0].copy()
+            for r in range(1, self.world):          # fixed order: every rank gets bit-identical sums
+                total += self.bufs[r]
+            self.barrier.wait(timeout=120)
+            assert self.hip.hipMemcpy(ctypes.c_void_p(ptr), total.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(8 * count), 1) == 0
+            if rank == 0:
+                self.calls += 1; self.doubles += count
+            return 0
+        return allreduce
+
+
+@pytest.mark.parametrize("n,e,world", [(300, 1200, 2), (1000, 5000, 2), (600, 2500, 3)])
+def test_sharded_equals_unsharded(capi, oracle, n, e, world):
+    g = synth.make_pose_graph(n, e, seed=n + world)
+    ref = capi.Pgo()
+    ref.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    st_ref = ref.optimize(8)
+    poses_ref, _, _ = ref.store()
+    ref.close()
+
+    ar = InProcessAllReduce(world)
+    out = [None] * world
+
+    def run(rank):
+        try:
+            p = capi.Pgo()
+            p.set_shard(rank, world, ar.fn(rank))
+            p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+            st = p.optimize(8)
+            poses, err, used = p.store()
+            p.close()
+            out[rank] = (poses, st, err)
+        except Exception as ex:      # pragma: no cover
+            out[rank] = ex
+            ar.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    for o in out:
+        assert not isinstance(o, Exception), o
+    for r in range(world):
+        poses, st, err = out[r]
+        assert st["status"] == 0 and st["iterations_done"] == st_ref["iterations_done"]
+        assert abs(st["chi2_initial"] - st_ref["chi2_initial"]) <= 1e-9 * st_ref["chi2_initial"]
+        dt, dr = synth.pose_errors(poses.reshape(-1, 3, 4), poses_ref.reshape(-1, 3, 4))
+        assert dt < 1e-5 and dr < 1e-6, (r, dt, dr)              # same algorithm, different summation order only
+        assert np.array_equal(poses, out[0][0])                  # every rank ends with bit-identical poses
+    fl = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, _ = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=8)
+    dt, dr = synth.pose_errors(out[0][0].reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+    assert dt < 1e-3 and dr < 1e-4
+    # exchange volume: one all-reduce per PCG iteration (iterations are enqueued in batches of 16, so up to 15 run
+    # past convergence per solve) + a handful per LM trial (H_aa|b, chi2, level-1 Galerkin arrays)
+    pcg = out[0][1]["pcg_iterations"]
+    assert pcg <= ar.calls <= pcg + 8 * 3 * (16 + 6), (pcg, ar.calls)
+
+
+def test_sharded_two_processes(capi):
+    """Real multi-process path: torchrun, 2 ranks (both on cuda:0 of the one-GPU box), gloo-staged all-reduce."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(here, "_sharded_worker.py"), "400", "1600", "5"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "SHARDED_OK world=2" in r.stdout
+
+
+def test_rccl_callback_world1(capi):
+    """The RCCL callback (torch.distributed backend "nccl", zero-copy view of the solver's device buffer) driven
+    through every exchange step of a solve with world_size 1: the result must equal the plain solve bit for bit."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from uzliti_slam_amd import sharded
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        g = synth.make_pose_graph(500, 2000, seed=5)
+        poses, st = sharded.solve_sharded(capi, g, 0, 1, dist, torch, iterations=5, device=0, force_callback=True)
+        ref = capi.Pgo()
+        ref.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+        st_ref = ref.optimize(5)
+        pr, _, _ = ref.store()
+        ref.close()
+        assert st["status"] == 0 and st["pcg_iterations"] == st_ref["pcg_iterations"]
+        assert np.array_equal(poses, pr)
+    finally:
+        dist.destroy_process_group()

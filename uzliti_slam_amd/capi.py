@@ -91,6 +91,8 @@ EDGE_DTYPE = np.dtype([("from", "<i4"), ("to", "<i4"), ("type", "<i4"), ("sensor
                        ("displacement_from", "<f8", (12,)), ("displacement_to", "<f8", (12,)),
                        ("information", "<f8", (36,))], align=True)
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+
 _lib = None
 
 
@@ -331,6 +333,22 @@ class Pgo:
 
     def reset(self):
         self._check(lib().uzl_pgo_reset(self._h))
+
+    def set_shard(self, rank, world, allreduce=None):
+        """Sharded single-graph solve (BASELINE config 4).  allreduce(dev_ptr:int, count:int, stream:int) -> int must sum
+        `count` doubles at dev_ptr in place over all ranks (0 = ok).  See uzliti_slam_amd/sharded.py for the RCCL one."""
+        if allreduce is None:
+            self._shard_cb = ALLREDUCE_FN()
+        else:
+            def _cb(ptr, count, stream, user):
+                try:
+                    return int(allreduce(int(ptr or 0), int(count), int(stream or 0)))
+                except Exception:      # never let an exception cross the C ABI
+                    import traceback
+                    traceback.print_exc()
+                    return -1
+            self._shard_cb = ALLREDUCE_FN(_cb)
+        self._check(lib().uzl_pgo_set_shard(self._h, C.c_int32(rank), C.c_int32(world), self._shard_cb, None))
 
     def optimize(self, iterations=0):
         st = PgoStats()

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlk) void chi2_kernel(PgoDev D, const double* __re
 {
     __shared__ double s4[4];
     double acc = 0.;
-    for (int k = blockIdx.x * kBlk + threadIdx.x; k < D.e; k += gridDim.x * kBlk) {
+    for (int k = D.e_begin + blockIdx.x * kBlk + threadIdx.x; k < D.e_end; k += gridDim.x * kBlk) {
         const EdgeGeom G = edge_geom(D, pose, k);
         const double ev[6] = {G.te.x, G.te.y, G.te.z, G.qe.x, G.qe.y, G.qe.z};
         const double chi = edge_chi(D, k, ev);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBlk) void linearize_kernel(PgoDev D, const double*
     __shared__ double s4[4];
     double chi_acc = 0.;
     const size_t E = (size_t)D.e;
-    for (int k = blockIdx.x * kBlk + threadIdx.x; k < D.e; k += gridDim.x * kBlk) {
+    for (int k = D.e_begin + blockIdx.x * kBlk + threadIdx.x; k < D.e_end; k += gridDim.x * kBlk) {
         const EdgeGeom G = edge_geom(D, pose, k);
         const double ev[6] = {G.te.x, G.te.y, G.te.z, G.qe.x, G.qe.y, G.qe.z};
         // Omega (row-major 6x6) from the SoA array, robustified: Omega' = rho1 * Omega
@@ -361,6 +361,16 @@ __global__ __launch_bounds__(kBlk) void assemble_kernel(PgoDev D)
     }
     const double m = block_max(dmax, s4);
     if (threadIdx.x == 0) D.part_c[blockIdx.x] = m;
+}
+
+// max |H_jj| over the assembled diagonal blocks -> part_c (sharded solve: after the all-reduce of hdiag)
+__global__ __launch_bounds__(kBlk) void diagmax_kernel(PgoDev D)
+{
+    __shared__ double s4[4];
+    double m = 0.;
+    for (int i = blockIdx.x * kBlk + threadIdx.x; i < D.nb * 6; i += gridDim.x * kBlk) m = fmax(m, fabs(D.hdiag[(size_t)(i / 6) * 36 + (i % 6) * 7]));
+    const double t = block_max(m, s4);
+    if (threadIdx.x == 0) D.part_c[blockIdx.x] = t;
 }
 
 // one block: final reductions of the LM bookkeeping scalars.
@@ -619,13 +629,13 @@ void k_prepare_flat_edges(const double* meas12, const double* info36, int e, dou
 }
 int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s)
 {
-    const int g = grid_for(D.e, kBlk, kMaxPartials);
+    const int g = grid_for(D.e_end - D.e_begin, kBlk, kMaxPartials);
     hipLaunchKernelGGL(chi2_kernel, dim3(g), dim3(kBlk), 0, s, D, pose, delta);
     return g;
 }
 int k_linearize(const PgoDev& D, const double* pose, double delta, hipStream_t s)
 {
-    const int g = grid_for(D.e, kBlk, kMaxPartials);
+    const int g = grid_for(D.e_end - D.e_begin, kBlk, kMaxPartials);
     hipLaunchKernelGGL(linearize_kernel, dim3(g), dim3(kBlk), 0, s, D, pose, delta);
     return g;
 }
@@ -633,6 +643,12 @@ int k_assemble(const PgoDev& D, hipStream_t s)
 {
     const int g = grid_for(D.nb, kBlk / 6, kMaxPartials);
     hipLaunchKernelGGL(assemble_kernel, dim3(g), dim3(kBlk), 0, s, D);
+    return g;
+}
+int k_diagmax(const PgoDev& D, hipStream_t s)
+{
+    const int g = grid_for(D.nb * 6, kBlk, kMaxPartials);
+    hipLaunchKernelGGL(diagmax_kernel, dim3(g), dim3(kBlk), 0, s, D);
     return g;
 }
 void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s)

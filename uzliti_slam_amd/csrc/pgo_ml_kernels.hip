@@ -177,6 +177,10 @@ __global__ __launch_bounds__(kBlk) void ml_transform_kernel(PgoDev D, const MlDe
         }
     } else if (t < ns + n) {
         const int i = t - ns;
+        if (f == 0 && !D.diag_owner) {          // sharded solve: level-1 arrays are summed over ranks afterwards
+            for (int k = 0; k < 36; k++) { ml.tmpG[(size_t)i * 36 + k] = 0.; ml.tmpM[(size_t)i * 36 + k] = 0.; }
+            return;
+        }
         P3 P;
         make_P(f, geo, i, P);
         const double* G = ((f == 0) ? D.hdiag : L.G) + (size_t)i * 36;
@@ -485,6 +489,7 @@ __global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const d
                 if (c == r) pr = pc;
             }
             aq += lambda * pr;
+            if (!D.diag_owner) aq = 0.;           // sharded solve: the diagonal term is added by one rank only
             p_new[(size_t)arow * 6 + r] = pr;
         }
         if (have[q])

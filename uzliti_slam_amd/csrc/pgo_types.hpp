@@ -19,6 +19,8 @@ constexpr int kMaxPartials = 4096;
 
 struct PgoDev {
     int32_t n, nb, e, nslots;
+    int32_t e_begin, e_end;   // system edges linearised by this rank (sharded solve); [0, e) otherwise
+    int32_t diag_owner;       // 1 on the rank that adds the (H_aa + lambda) p term and the diagonal Galerkin parts
     double* pose;
     double* pose_trial;
     const int32_t* v2b;      // [n]  free-block index or -1

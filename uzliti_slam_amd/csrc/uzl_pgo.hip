@@ -26,6 +26,7 @@ int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s);
 int k_linearize(const PgoDev& D, const double* pose, double delta, hipStream_t s);
 int k_assemble(const PgoDev& D, hipStream_t s);
 void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s);
+int k_diagmax(const PgoDev& D, hipStream_t s);
 void k_precond(const PgoDev& D, hipStream_t s);
 int k_pcg_init(const PgoDev& D, double* p0, double* p1, hipStream_t s);
 int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
@@ -95,6 +96,11 @@ struct uzl_pgo {
     int32_t rank = 0, world = 1;
     uzl_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
+    bool sharded = false;            // an all-reduce callback is set and the multilevel path is active for this structure
+    DevBuf<double> d_red;
+    int64_t iter_span = 0;           // doubles all-reduced per PCG iteration: [A p | restricted A p | p.Ap partials]
+    double* l1_span_ptr = nullptr;   // level-1 Galerkin arrays (blk | G | M), all-reduced once per linearisation
+    int64_t l1_span = 0;
     KernelTimer timer;
 };
 
@@ -124,6 +130,23 @@ void set_lambda(uzl_pgo* h, double lambda)
 {
     h->h_lambda.p[0] = lambda;
     UZL_HIP(hipMemcpyAsync(h->D.scal + 3, h->h_lambda.p, sizeof(double), hipMemcpyHostToDevice, h->stream));
+}
+
+// exchange step of the sharded solve: sum `count` doubles at dev_ptr over all ranks (caller-supplied RCCL all-reduce)
+void shard_allreduce(uzl_pgo* h, double* ptr, int64_t count)
+{
+    if (!h->sharded || count <= 0) return;
+    const int rc = h->allreduce(ptr, count, (void*)h->stream, h->allreduce_user);
+    if (rc != 0) throw HipError{hipErrorUnknown, "all-reduce callback failed", __FILE__, __LINE__};
+}
+// chi2 is a sum over edges: partial per rank
+void shard_allreduce_chi2(uzl_pgo* h)
+{
+    if (!h->sharded) return;
+    h->d_red.reserve(2);
+    UZL_HIP(hipMemcpyAsync(h->d_red.p, h->D.scal + 4, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    shard_allreduce(h, h->d_red.p, 1);
+    UZL_HIP(hipMemcpyAsync(h->D.scal + 4, h->d_red.p, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
 }
 
 // allocate everything that depends on (n, e) only
@@ -287,6 +310,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     }
     hipStream_t s = h->stream;
     uint8_t* base = h->ml_arena.p;
+    UZL_HIP(hipMemsetAsync(base, 0, bytes, s));            // padding between arrays takes part in the sharded all-reduce
     UZL_HIP(hipMemcpyAsync(base, stage.data(), int_bytes, hipMemcpyHostToDevice, s));
     MlDev M;
     memset(&M, 0, sizeof(M));
@@ -324,6 +348,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     Hh.levels = L;
     for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Dinv[l] = M.lv[l].Dinv; }
     Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg;
+    h->l1_span_ptr = M.lv[1].blk;
+    h->l1_span = (int64_t)((M.lv[1].M + (size_t)std::max(h->ml_n[1], 1) * 36) - M.lv[1].blk);
     h->d_ml.reserve(1);
     UZL_HIP(hipMemcpyAsync(h->d_ml.p, &M, sizeof(M), hipMemcpyHostToDevice, s));
     UZL_HIP(hipStreamSynchronize(s));      // stage / M are locals
@@ -339,6 +365,7 @@ void ml_setup_numeric(uzl_pgo* h)
     for (int f = 0; f < L; f++) {
         { Timed t(h, "ml_transform"); k_ml_transform(h->D, h->d_ml.p, f, h->ml_nslots[f] + h->ml_n[f], s); }
         { Timed t(h, "ml_reduce"); k_ml_reduce(h->d_ml.p, f + 1, h->ml_nslots[f + 1] + h->ml_n[f + 1], s); }
+        if (f == 0) shard_allreduce(h, h->l1_span_ptr, h->l1_span);             // level 1 complete on every rank: levels >= 2 need no exchange
     }
 }
 
@@ -374,8 +401,8 @@ void build_structure(uzl_pgo* h)
     const size_t nbz = std::max(nb, 1), nsz = std::max(nslots, 1);
     h->d_b2v.reserve(nbz); h->d_row_ptr.reserve(nbz + 1); h->d_col.reserve(nsz);
     h->d_blk.reserve(nsz * 36); h->d_dcon.reserve(nsz * 36); h->d_gcon.reserve(nsz * 6);
-    h->d_hdiag.reserve(nbz * 36); h->d_minv.reserve(nbz * 36); h->d_b.reserve(nbz * 6);
-    h->d_x.reserve(nbz * 6); h->d_r.reserve(nbz * 6); h->d_z.reserve(nbz * 6); h->d_p.reserve(nbz * 6); h->d_p2.reserve(nbz * 6); h->d_ap.reserve(nbz * 6);
+    h->d_hdiag.reserve(nbz * 42); h->d_minv.reserve(nbz * 36);              // [H_aa | b] contiguous: one all-reduce when sharded
+    h->d_x.reserve(nbz * 6); h->d_r.reserve(nbz * 6); h->d_z.reserve(nbz * 6); h->d_p.reserve(nbz * 6); h->d_p2.reserve(nbz * 6); h->d_ap.reserve(nbz * 12 + kMaxPartials);   // [A p | restricted A p | partials]
     if (n > 0) UZL_HIP(hipMemcpyAsync(h->d_v2b.p, v2b.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
     if (nb > 0) UZL_HIP(hipMemcpyAsync(h->d_b2v.p, b2v.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, s));
     UZL_HIP(hipMemcpyAsync(h->d_row_ptr.p, row_ptr.data(), sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice, s));
@@ -385,7 +412,11 @@ void build_structure(uzl_pgo* h)
         UZL_HIP(hipMemcpyAsync(h->d_slot_j.p, slot_j.data(), sizeof(int32_t) * e, hipMemcpyHostToDevice, s));
     }
     // blocks of slots whose neighbour is fixed are never written: keep them defined
-    if (nslots > 0) UZL_HIP(hipMemsetAsync(h->d_blk.p, 0, sizeof(double) * 36 * (size_t)nslots, s));
+    if (nslots > 0) {
+        UZL_HIP(hipMemsetAsync(h->d_blk.p, 0, sizeof(double) * 36 * (size_t)nslots, s));
+        UZL_HIP(hipMemsetAsync(h->d_dcon.p, 0, sizeof(double) * 36 * (size_t)nslots, s));   // slots of edges other ranks own stay 0
+        UZL_HIP(hipMemsetAsync(h->d_gcon.p, 0, sizeof(double) * 6 * (size_t)nslots, s));
+    }
     UZL_HIP(hipStreamSynchronize(s));       // host vectors go out of scope
     PgoDev& D = h->D;
     D.n = n; D.nb = nb; D.e = e; D.nslots = nslots;
@@ -394,10 +425,28 @@ void build_structure(uzl_pgo* h)
     D.zinv = h->d_zinv.p; D.info = h->d_info.p; D.robust = h->d_robust.p;
     D.slot_i = h->d_slot_i.p; D.slot_j = h->d_slot_j.p; D.row_ptr = h->d_row_ptr.p; D.col = h->d_col.p;
     D.blk = h->d_blk.p; D.dcon = h->d_dcon.p; D.gcon = h->d_gcon.p; D.hdiag = h->d_hdiag.p; D.minv = h->d_minv.p;
-    D.b = h->d_b.p; D.x = h->d_x.p; D.r = h->d_r.p; D.z = h->d_z.p; D.p = h->d_p.p; D.ap = h->d_ap.p;
-    D.part_a = h->d_part_a.p; D.part_b = h->d_part_b.p; D.part_c = h->d_part_c.p;
+    D.b = h->d_hdiag.p + (size_t)nb * 36; D.x = h->d_x.p; D.r = h->d_r.p; D.z = h->d_z.p; D.p = h->d_p.p; D.ap = h->d_ap.p;
+    D.part_a = h->d_ap.p + (size_t)nbz * 12; D.part_b = h->d_part_b.p; D.part_c = h->d_part_c.p;
     D.scal = h->d_scal.p; D.flags = h->d_flags.p;
+    D.e_begin = 0; D.e_end = e; D.diag_owner = 1;
     build_ml(h, row_ptr, col);
+    {   // per-iteration exchange buffer: [A p (6 nb) | restricted A p (6 n_g) | p.Ap partials]
+        const int gl = (h->ml_levels == 0) ? 0 : ((h->ml_agg == 1 || h->ml_levels < 2) ? 1 : 2);
+        const size_t ng6 = gl ? (size_t)h->ml_n[gl] * 6 : 0;
+        if (gl) h->ml_hot.Sg = h->d_ap.p + (size_t)nb * 6;
+        D.part_a = h->d_ap.p + (size_t)nb * 6 + ng6;
+        h->iter_span = (int64_t)((size_t)nb * 6 + ng6 + (gl ? (size_t)g_ml_rows(nb, h->ml_agg) : 0));
+    }
+    // ---- sharded solve (BASELINE config 4): this rank linearises a contiguous range of the system edges
+    // (a callback with world_size 1 still runs every exchange step: that is how the RCCL callback is tested on one GPU;
+    //  graphs too small for the multilevel path are simply solved redundantly by every rank)
+    h->sharded = h->ml_levels > 0 && h->allreduce != nullptr;
+    if (h->sharded) {
+        const int base = e / h->world, rem = e % h->world;
+        D.e_begin = h->rank * base + std::min(h->rank, rem);
+        D.e_end = D.e_begin + base + (h->rank < rem ? 1 : 0);
+        D.diag_owner = h->rank == 0 ? 1 : 0;
+    }
     h->structure_ready = true;
 }
 
@@ -415,7 +464,9 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
         double* pn = pb[(i & 1) ^ 1];
         if (timed) h->timer.begin("pcg_spmv", s);
         if (ml) k_ml_spmv(D, h->ml_hot, h->ml_agg, po, pn, gu, tol2, s); else k_pcg_spmv(D, po, pn, gu, tol2, s);
-        if (timed) { h->timer.end(s); h->timer.begin(ml ? "ml_cg" : "pcg_update", s); }
+        if (timed) h->timer.end(s);
+        if (ml) shard_allreduce(h, h->d_ap.p, h->iter_span);                     // the one exchange per PCG iteration
+        if (timed) h->timer.begin(ml ? "ml_cg" : "pcg_update", s);
         if (ml) UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, pn, h->ml_rg[(i & 1) ^ 1], h->ml_rg[i & 1], ga, 0, h->ml_lds, s)); else k_pcg_update(D, pn, ga, s);
         if (timed) h->timer.end(s);
     }
@@ -446,7 +497,7 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     hipStream_t s = h->stream;
     const PgoDev& D = h->D;
     const int max_it = h->cfg.pcg_max_iter > 0 ? h->cfg.pcg_max_iter : 6 * std::max(h->nb, 1);
-    const bool timed = h->timer.on || h->no_graph;        // per-kernel events (and rocprofv3) need eager launches
+    const bool timed = h->timer.on || h->no_graph || h->sharded;   // per-kernel events, rocprofv3 and the exchange callback need eager launches
     { Timed t(h, "precond"); k_precond(D, s); }
     if (h->ml_levels > 0) {
         { Timed t(h, "ml_invert"); k_ml_invert(D, h->d_ml.p, h->ml_inner_aggs, s); }
@@ -481,7 +532,6 @@ int pcg_solve(uzl_pgo* h, bool* converged)
 int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 {
     if (!h->have_graph) return fail(h, UZL_ERR_STATE, "optimize before add_graph/set_graph");
-    if (h->world > 1) return fail(h, UZL_ERR_BAD_ARG, "sharded solve (world_size > 1) is not available in this build");
     UZL_HIP(hipSetDevice(h->cfg.device));
     const auto t0 = std::chrono::steady_clock::now();
     if (iterations <= 0) iterations = h->cfg.iterations;
@@ -520,7 +570,12 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         D.pose = h->cur; D.pose_trial = h->trial;
         { Timed t(h, "linearize"); gl = k_linearize(D, h->cur, delta, s); }     // computeActiveErrors + buildSystem
         { Timed t(h, "assemble"); ga = k_assemble(D, s); }
+        if (h->sharded) {                                                         // H_aa, b: sums over all ranks' edges
+            shard_allreduce(h, h->d_hdiag.p, (int64_t)h->nb * 42);
+            ga = k_diagmax(D, s);
+        }
         { Timed t(h, "finalize"); k_finalize(D, gl, 0, ga, 2, s); }
+        shard_allreduce_chi2(h);
         ml_setup_numeric(h);
         fetch_scal(h);
         current_chi = h->h_scal.p->scal[4];
@@ -541,6 +596,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             { Timed t(h, "oplus"); go = k_oplus(D, h->cur, h->trial, s); }        // push + update
             { Timed t(h, "chi2"); gc = k_chi2(D, h->trial, delta, s); }           // computeActiveErrors
             { Timed t(h, "finalize"); k_finalize(D, gc, go, 0, 1, s); }
+            shard_allreduce_chi2(h);
             fetch_scal(h);
             const double temp_chi = h->h_scal.p->scal[4];
             const double scale = h->h_scal.p->scal[5] + 1e-3;                     // computeScale + 1e-3
@@ -829,6 +885,7 @@ int uzl_pgo_set_shard(uzl_pgo* h, int32_t rank, int32_t world_size, uzl_allreduc
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(h, UZL_ERR_BAD_ARG, "bad rank/world_size");
     if (world_size > 1 && !allreduce) return fail(h, UZL_ERR_BAD_ARG, "world_size > 1 needs an all-reduce callback");
     h->rank = rank; h->world = world_size; h->allreduce = allreduce; h->allreduce_user = user;
+    h->structure_ready = false;
     return UZL_OK;
 }
 
