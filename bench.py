@@ -197,7 +197,7 @@ def main():
                                               "2-NN Hamming + %d-hypothesis PROSAC, early exit off" % (per_rank, a.keypoints, a.hypotheses)),
                          mean_consensus=float(res["consensus"].mean()), ok_fraction=float(res["ok"].mean()),
                          kernels_ms={k: round(v["ms"], 4) for k, v in mk.items()},
-                         roofline=dict(kernel="knn2_kernel<8>", bound="valu", achieved=round(ach, 1), peak=round(VALU_PEAK_GOPS, 1),
+                         roofline=dict(kernel="knn2_lds_kernel<8, 1>", bound="valu", achieved=round(ach, 1), peak=round(VALU_PEAK_GOPS, 1),
                                        unit="G lane-ops/s (v_xor_b32 + v_bcnt_u32_b32)", frac=round(ach / VALU_PEAK_GOPS, 4),
                                        traffic=None, measured_issue_peak=36800.0,
                                        note="integer VALU bound, not HBM/MFMA: 64 KB of descriptors feed 1.6e7 word-ops per pair; `peak` = 256 CU x 128 lanes/clk x 2.4 GHz (2 cycles per wave64 op); profiles/r01_ubench_valu_rates.txt measures 1.5-2.0 ns per wave-instruction per SIMD for v_xor/v_bcnt (~36.8 T lane-ops/s for this mix)"))

@@ -303,10 +303,97 @@ int  uzl_pgo_kernel_times(uzl_pgo* h, int32_t cap, const char** names, double* m
  * The graph is edge-partitioned: every rank holds all vertices and the edges
  * [e_begin, e_end) of the flattened problem.  The caller supplies the exchange step: a
  * function that sums `count` doubles in place across all ranks (RCCL all-reduce on the
- * device buffer `dev_ptr`, issued on `hip_stream`).  With world_size 1 it is never called. */
+ * device buffer `dev_ptr`, issued on `hip_stream`).  A NULL callback means unsharded. */
 typedef int (*uzl_allreduce_fn)(void* dev_ptr, int64_t count, void* hip_stream, void* user);
 int  uzl_pgo_set_shard(uzl_pgo* h, int32_t rank, int32_t world_size,
                        uzl_allreduce_fn allreduce, void* user);
+
+/* ======================================================================================
+ *  Edge filter  (TransformationFilter / EdgeCluster)
+ *
+ *  The step between the two halves: every non-odometry edge passes through it before it
+ *  reaches the solver (g2o_optimizer.cpp:74-103).  Edges are grouped into clusters by the
+ *  time stamps of their end nodes (transformation_filter.cpp:144-207); a cluster that
+ *  changed is validated by a 3-point RANSAC over the translations of its edges' world-frame
+ *  end poses (:222-291, 200 hypotheses, 0.3 m, no PROSAC prefix); validEdges() (:293-337)
+ *  thins each cluster's valid edges.  The cluster bookkeeping is sequential host logic; the
+ *  pose chains, the RANSAC and the consensus run on the GPU, batched over all changed
+ *  clusters of one calcValidEdges() call.
+ *
+ *  String ids stay in the adapter: edges are addressed by a caller-chosen 64-bit key.
+ *  Where the reference iterates an unordered_map (order unspecified) this build uses
+ *  insertion order; equal matching scores keep insertion order (the reference's std::sort
+ *  is unstable).  RANSAC stream of a cluster evaluation: job id = cluster_uid * 2^20 +
+ *  evaluation counter, keyed with cfg.seed like every other job.
+ * ====================================================================================== */
+
+typedef struct uzl_filter uzl_filter;
+
+typedef struct uzl_filter_cfg {
+    double  max_dt;               /* 5.0   TransformationFilter(max_dt, ...)  transformation_filter.h:82, g2o_optimizer.cpp:46 */
+    double  min_size;             /* 8.0   "cluster_size" ROS parameter (g2o_optimizer.cpp:43-46); header default 10          */
+    int32_t max_cluster_size;     /* 100   transformation_filter.h:82                                                          */
+    int32_t ransac_iterations;    /* 200   transformation_filter.cpp:273                                                       */
+    double  max_error;            /* 0.3   transformation_filter.cpp:272                                                       */
+    double  min_time_span;        /* 2.0   seconds, transformation_filter.cpp:240-241                                          */
+    int32_t max_edges;            /* 5     validEdges(): transformation_filter.cpp:310                                         */
+    int32_t device;
+    uint64_t seed;
+} uzl_filter_cfg;
+
+void uzl_filter_cfg_default(uzl_filter_cfg* cfg);
+
+/* One SlamEdge with its end nodes as TransformationFilter::add(edge, from, to) sees them
+ * (transformation_filter.cpp:138).  3x4 row-major [R|t] like everywhere in this ABI. */
+typedef struct uzl_filter_edge {
+    uint64_t key;                 /* stands for SlamEdge::id_                                        */
+    double   matching_score;      /* SlamEdge::matching_score_                                       */
+    int32_t  valid;               /* SlamEdge::valid_ (initial EdgeData::valid_)                     */
+    int32_t  sensor_from;         /* index into the sensor table, -1 = identity                      */
+    int32_t  sensor_to;
+    int32_t  n_stamps_from;       /* SlamNode::stamps_ of the from node                              */
+    int32_t  n_stamps_to;
+    int32_t  _pad;
+    const int64_t* stamps_from_ns;/* ros::Time as nanoseconds                                        */
+    const int64_t* stamps_to_ns;
+    double   transform[12];       /* SlamEdge::transform_                                            */
+    double   displacement_from[12];
+    double   displacement_to[12];
+    double   pose_from[12];       /* SlamNode::pose_ of the end nodes                                */
+    double   pose_to[12];
+} uzl_filter_edge;
+
+int  uzl_filter_create(const uzl_filter_cfg* cfg, uzl_filter** out);
+void uzl_filter_destroy(uzl_filter* h);
+const char* uzl_filter_last_error(uzl_filter* h);
+
+/* sensor_transforms_ (transformation_filter.h:92): n_sensors x 12 doubles. */
+int  uzl_filter_set_sensors(uzl_filter* h, int32_t n_sensors, const double* sensors);
+/* TransformationFilter::add for each edge in order: a known key only refreshes the stored
+ * edge and end poses (:140-146); a new key is clustered by its stamp pairs (:148-206). */
+int  uzl_filter_add(uzl_filter* h, int32_t n_edges, const uzl_filter_edge* edges);
+/* TransformationFilter::remove (:209-220). */
+int  uzl_filter_remove(uzl_filter* h, int32_t n_keys, const uint64_t* keys);
+/* TransformationFilter::allEdges (:343-350): keys in ascending order; *n = total count. */
+int  uzl_filter_all_edges(uzl_filter* h, int32_t cap, uint64_t* keys, int32_t* n);
+/* TransformationFilter::calcValidEdges (:222-291); n_evaluated = clusters sent to the GPU. */
+int  uzl_filter_calc_valid_edges(uzl_filter* h, int32_t* n_evaluated);
+/* TransformationFilter::validEdges (:293-337): keys in ascending order (std::set order). */
+int  uzl_filter_valid_edges(uzl_filter* h, int32_t cap, uint64_t* keys, int32_t* n);
+
+/* Introspection for parity tests: clusters in clusters_ order. */
+int  uzl_filter_cluster_count(uzl_filter* h);
+typedef struct uzl_cluster_info {
+    uint64_t uid;
+    int64_t  from_start_ns, from_end_ns, to_start_ns, to_end_ns;
+    int32_t  size, consensus, changed, evaluations;
+} uzl_cluster_info;
+int  uzl_filter_cluster_info(uzl_filter* h, int32_t index, uzl_cluster_info* info);
+/* keys and EdgeData::valid_ flags of one cluster, in cluster order; cap >= size. */
+int  uzl_filter_cluster_edges(uzl_filter* h, int32_t index, int32_t cap, uint64_t* keys, uint8_t* valid);
+/* The P / Q columns (3 x size, column-major) and the transform of the cluster's LAST GPU evaluation. */
+int  uzl_filter_cluster_last_eval(uzl_filter* h, int32_t index, int32_t cap, double* P, double* Q, double* T,
+                                  int32_t* ransac_consensus);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@
 #include <cfloat>
 #include <cstdint>
 #include "match_types.hpp"
+#include <cstdlib>
 
 namespace uzl {
 
@@ -770,8 +771,14 @@ void launch_knn2(const uint32_t* arena, const Combo* combos, int n_combos, int m
 {
     if (n_combos <= 0 || max_nq <= 0) return;
     dim3 grid((max_nq + kBlock - 1) / kBlock, n_combos);
-    if (has8) hipLaunchKernelGGL(knn2_kernel<8>, grid, dim3(kBlock), 0, s, arena, combos, knn);
-    if (has16) hipLaunchKernelGGL(knn2_kernel<16>, grid, dim3(kBlock), 0, s, arena, combos, knn);
+    static const bool scalar_path = getenv("UZL_KNN2_SCALAR") != nullptr;   // A/B switch: train rows by scalar loads
+    if (scalar_path) {
+        if (has8) hipLaunchKernelGGL(knn2_kernel<8>, grid, dim3(kBlock), 0, s, arena, combos, knn);
+        if (has16) hipLaunchKernelGGL(knn2_kernel<16>, grid, dim3(kBlock), 0, s, arena, combos, knn);
+    } else {
+        if (has8) hipLaunchKernelGGL((knn2_lds_kernel<8, 1>), grid, dim3(kBlock), 0, s, arena, combos, knn);
+        if (has16) hipLaunchKernelGGL((knn2_lds_kernel<16, 1>), grid, dim3(kBlock), 0, s, arena, combos, knn);
+    }
     if (has_generic) hipLaunchKernelGGL(knn2_generic_kernel, grid, dim3(kBlock), 0, s, arena, combos, knn);
 }
 
