@@ -21,7 +21,7 @@ c_u8p = C.POINTER(C.c_uint8)
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("uzl_oracle_match.c", "uzl_oracle_pgo.c", "uzl_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("uzl_oracle_match.c", "uzl_oracle_pgo.c", "uzl_oracle_filter.c", "uzl_oracle.h")]
     if not force and os.path.exists(_LIB_PATH) and all(
             os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH
@@ -329,3 +329,112 @@ def build_dense(poses, fixed, ij, meas, info, robust, huber_delta=1.0):
                            _p(Z, c_f64p), _p(Om, c_f64p), _p(rb, c_u8p), C.c_double(huber_delta),
                            _p(H, c_f64p), _p(b, c_f64p))
     return H, b
+
+
+# ------------------------------------------------------------------------------- edge filter (uzl_oracle_filter.c)
+class FilterCfg(C.Structure):
+    _fields_ = [("max_dt", C.c_double), ("min_size", C.c_double), ("max_cluster_size", C.c_int32),
+                ("ransac_iterations", C.c_int32), ("max_error", C.c_double), ("min_time_span", C.c_double),
+                ("max_edges", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64)]
+
+
+class FilterEdge(C.Structure):
+    _fields_ = [("key", C.c_uint64), ("matching_score", C.c_double), ("valid", C.c_int32),
+                ("sensor_from", C.c_int32), ("sensor_to", C.c_int32), ("n_stamps_from", C.c_int32),
+                ("n_stamps_to", C.c_int32), ("_pad", C.c_int32),
+                ("stamps_from_ns", C.POINTER(C.c_int64)), ("stamps_to_ns", C.POINTER(C.c_int64)),
+                ("transform", C.c_double * 12), ("displacement_from", C.c_double * 12),
+                ("displacement_to", C.c_double * 12), ("pose_from", C.c_double * 12), ("pose_to", C.c_double * 12)]
+
+
+class ClusterInfo(C.Structure):
+    _fields_ = [("uid", C.c_uint64), ("from_start_ns", C.c_int64), ("from_end_ns", C.c_int64),
+                ("to_start_ns", C.c_int64), ("to_end_ns", C.c_int64), ("size", C.c_int32),
+                ("consensus", C.c_int32), ("changed", C.c_int32), ("evaluations", C.c_int32)]
+
+
+_IDENT12 = (1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0)
+
+
+def _pack_filter_edges(edges):
+    arr = (FilterEdge * max(len(edges), 1))()
+    keep = []
+    for i, e in enumerate(edges):
+        a = arr[i]
+        a.key = int(e["key"]); a.matching_score = float(e.get("matching_score", 0.0)); a.valid = int(e.get("valid", 0))
+        a.sensor_from = int(e.get("sensor_from", -1)); a.sensor_to = int(e.get("sensor_to", -1))
+        sf = np.ascontiguousarray(e.get("stamps_from", ()), np.int64); st = np.ascontiguousarray(e.get("stamps_to", ()), np.int64)
+        keep += [sf, st]
+        a.n_stamps_from = len(sf); a.n_stamps_to = len(st)
+        a.stamps_from_ns = sf.ctypes.data_as(C.POINTER(C.c_int64)); a.stamps_to_ns = st.ctypes.data_as(C.POINTER(C.c_int64))
+        for f in ("transform", "displacement_from", "displacement_to", "pose_from", "pose_to"):
+            v = e.get(f)
+            getattr(a, f)[:] = _IDENT12 if v is None else tuple(np.asarray(v, np.float64).reshape(-1)[:12])
+    return arr, keep
+
+
+class Filter:
+    """CPU checker twin of uzliti_slam_amd.capi.Filter (same method names and return shapes)."""
+
+    def __init__(self, **cfg):
+        L = lib()
+        L.uzlo_filter_create.restype = C.c_void_p
+        L.uzlo_filter_destroy.argtypes = [C.c_void_p]
+        c = FilterCfg()
+        L.uzlo_filter_cfg_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = C.c_void_p(L.uzlo_filter_create(C.byref(c)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uzlo_filter_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_sensors(self, sensors):
+        s = np.ascontiguousarray(sensors, np.float64).reshape(-1, 12)
+        lib().uzlo_filter_set_sensors(self._h, C.c_int32(len(s)), _p(s, c_f64p))
+
+    def add(self, edges):
+        arr, keep = _pack_filter_edges(edges)
+        lib().uzlo_filter_add(self._h, C.c_int32(len(edges)), arr)
+
+    def remove(self, keys):
+        k = np.ascontiguousarray(keys, np.uint64)
+        lib().uzlo_filter_remove(self._h, C.c_int32(len(k)), k.ctypes.data_as(C.POINTER(C.c_uint64)))
+
+    def all_edges(self):
+        n = lib().uzlo_filter_all_edges(self._h, C.c_int32(0), None)
+        out = np.zeros(max(n, 1), np.uint64)
+        lib().uzlo_filter_all_edges(self._h, C.c_int32(len(out)), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return out[:n]
+
+    def valid_edges(self):
+        n = lib().uzlo_filter_valid_edges(self._h, C.c_int32(0), None)
+        out = np.zeros(max(n, 1), np.uint64)
+        lib().uzlo_filter_valid_edges(self._h, C.c_int32(len(out)), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return out[:n]
+
+    def calc_valid_edges(self):
+        return lib().uzlo_filter_calc_valid_edges(self._h)
+
+    def clusters(self, with_eval=False):
+        out = []
+        L = lib()
+        for i in range(L.uzlo_filter_cluster_count(self._h)):
+            ci = ClusterInfo()
+            L.uzlo_filter_cluster_info(self._h, C.c_int32(i), C.byref(ci))
+            d = {f: getattr(ci, f) for f, _ in ci._fields_}
+            keys = np.zeros(max(ci.size, 1), np.uint64); valid = np.zeros(max(ci.size, 1), np.uint8)
+            L.uzlo_filter_cluster_edges(self._h, C.c_int32(i), keys.ctypes.data_as(C.POINTER(C.c_uint64)), _p(valid, c_u8p))
+            d["keys"] = keys[:ci.size]; d["valid"] = valid[:ci.size]
+            if with_eval:
+                cap = max(ci.size + 128, 256)
+                P = np.zeros((cap, 3)); Q = np.zeros((cap, 3)); T = np.zeros(12); rc = C.c_int32()
+                m = L.uzlo_filter_cluster_last_eval(self._h, C.c_int32(i), _p(P, c_f64p), _p(Q, c_f64p), _p(T, c_f64p), C.byref(rc))
+                d.update(P=P[:m].copy(), Q=Q[:m].copy(), T=T, ransac_consensus=rc.value)
+            out.append(d)
+        return out

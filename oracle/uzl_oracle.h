@@ -154,6 +154,35 @@ void uzlo_build_dense(int32_t n, const double* poses, const uint8_t* fixed, int3
                       const double* meas, const double* info, const uint8_t* robust, double huber_delta,
                       double* H, double* b);
 
+/* ---------------- edge filter (uzl_oracle_filter.c): TransformationFilter / EdgeCluster ----------------
+ * transformation_filter.cpp:43-350.  Same POD layouts as include/uzl_mi355x.h so tests can share buffers. */
+typedef struct uzlo_filter uzlo_filter;
+typedef struct uzlo_filter_cfg {
+    double max_dt, min_size; int32_t max_cluster_size, ransac_iterations; double max_error, min_time_span;
+    int32_t max_edges, device; uint64_t seed;
+} uzlo_filter_cfg;
+typedef struct uzlo_filter_edge {
+    uint64_t key; double matching_score; int32_t valid, sensor_from, sensor_to, n_stamps_from, n_stamps_to, _pad;
+    const int64_t* stamps_from_ns; const int64_t* stamps_to_ns;
+    double transform[12], displacement_from[12], displacement_to[12], pose_from[12], pose_to[12];
+} uzlo_filter_edge;
+typedef struct uzlo_cluster_info {
+    uint64_t uid; int64_t from_start_ns, from_end_ns, to_start_ns, to_end_ns; int32_t size, consensus, changed, evaluations;
+} uzlo_cluster_info;
+void uzlo_filter_cfg_default(uzlo_filter_cfg* c);
+uzlo_filter* uzlo_filter_create(const uzlo_filter_cfg* cfg);
+void uzlo_filter_destroy(uzlo_filter* f);
+void uzlo_filter_set_sensors(uzlo_filter* f, int32_t n, const double* sensors);
+void uzlo_filter_add(uzlo_filter* f, int32_t n_edges, const uzlo_filter_edge* edges);
+void uzlo_filter_remove(uzlo_filter* f, int32_t n_keys, const uint64_t* keys);
+int32_t uzlo_filter_all_edges(const uzlo_filter* f, int32_t cap, uint64_t* keys);
+int32_t uzlo_filter_calc_valid_edges(uzlo_filter* f);
+int32_t uzlo_filter_valid_edges(const uzlo_filter* f, int32_t cap, uint64_t* keys);
+int32_t uzlo_filter_cluster_count(const uzlo_filter* f);
+void uzlo_filter_cluster_info(const uzlo_filter* f, int32_t idx, uzlo_cluster_info* o);
+void uzlo_filter_cluster_edges(const uzlo_filter* f, int32_t idx, uint64_t* keys, uint8_t* valid);
+int32_t uzlo_filter_cluster_last_eval(const uzlo_filter* f, int32_t idx, double* P, double* Q, double* T, int32_t* ransac_consensus);
+
 #ifdef __cplusplus
 }
 #endif

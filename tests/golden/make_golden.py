@@ -84,6 +84,58 @@ def pgo_fixture():
                         euler=np.stack([O.to_euler(x[:, :3]) for x in T]))
 
 
+def filter_fixture():
+    """TransformationFilter over a growing graph: inputs per round + expected clusters / verdicts (oracle, after it
+    agreed with the pure-Python restatement np_reference.FilterRef on every round)."""
+    from filter_common import drifted, replay_filter_fixture
+    scn = synth.make_filter_scenario(140, 380, seed=57)
+    cfg = dict(max_dt=5.0, min_size=6.0, max_cluster_size=40, ransac_iterations=80, max_error=0.3, seed=13)
+    E = scn["edges"]; n = len(E); rounds = 5
+    rng = np.random.default_rng(8)
+    cut = np.linspace(0, n, rounds + 1).astype(int)
+    present = np.zeros((rounds, n), np.uint8); cur = np.zeros(n, bool)
+    poses = np.zeros((rounds, 140, 12))
+    for r in range(rounds):
+        cur[cut[r]:cut[r + 1]] = True
+        present[r] = cur                           # edges (re-)added this round; those dropped next round are removed after the add
+        drop = cur & (rng.random(n) < 0.04)
+        cur = cur & ~drop
+        poses[r] = drifted(scn, r, rng).reshape(-1, 12)
+    removed = np.zeros((rounds, n), np.uint8)
+    for r in range(rounds):
+        nxt = present[r + 1] if r + 1 < rounds else present[r]
+        removed[r] = present[r] & ~nxt[:n] if r + 1 < rounds else 0
+    stamps = np.zeros((140, 2), np.int64); nst = np.zeros(140, np.int32)
+    for i, st in enumerate(scn["stamps"]):
+        stamps[i, :len(st)] = st; nst[i] = len(st)
+    z = dict(cfg_names=np.array(list(cfg)), cfg_values=np.array([float(v) for v in cfg.values()]),
+             key=np.array([e["key"] for e in E], np.uint64), score=np.array([e["matching_score"] for e in E]),
+             valid=np.array([e["valid"] for e in E], np.int32), sensor_from=np.array([e["sensor_from"] for e in E], np.int32),
+             sensor_to=np.array([e["sensor_to"] for e in E], np.int32), node_from=np.array([e["node_from"] for e in E], np.int32),
+             node_to=np.array([e["node_to"] for e in E], np.int32), transform=np.stack([e["transform"] for e in E]),
+             displacement_from=np.stack([e["displacement_from"] for e in E]), displacement_to=np.stack([e["displacement_to"] for e in E]),
+             stamps=stamps, n_stamps=nst, sensors=scn["sensors"], poses=poses, present=present, removed=removed)
+    o = O.Filter(**cfg); ref = NP.FilterRef(**cfg)
+
+    def ransac(P, Q, job_id):
+        res = O.prosac(P.T, Q.T, cfg["max_error"], cfg["ransac_iterations"], 1.0, do_prosac=False, seed=cfg["seed"], job_id=job_id)
+        return res["T"], O.consensus3d(P.T, Q.T, res["T"], cfg["max_error"])[1]
+    exp_o = list(replay_filter_fixture(z, o))
+    exp_r = list(replay_filter_fixture(z, ref, calc=lambda f: f.calc_valid_edges(ransac), state=lambda f: f.state()))
+    for a, b in zip(exp_o, exp_r):
+        assert a["evaluated"] == b["evaluated"] and np.array_equal(a["valid_keys"], b["valid_keys"]), "oracle filter != python restatement"
+        assert [c["size"] for c in a["clusters"]] == [c["size"] for c in b["clusters"]]
+        assert all(np.array_equal(x["keys"], y["keys"]) and np.array_equal(x["valid"], y["valid"]) for x, y in zip(a["clusters"], b["clusters"]))
+    assert sum(a["evaluated"] for a in exp_o) >= 4 and len(exp_o[-1]["valid_keys"]) > 5
+    for r, a in enumerate(exp_o):
+        z[f"r{r}_valid_keys"] = a["valid_keys"]; z[f"r{r}_evaluated"] = np.array(a["evaluated"])
+        z[f"r{r}_cluster_info"] = np.array([[c["uid"], c["size"], c["consensus"], c["changed"], c["evaluations"], c["from_start_ns"],
+                                              c["from_end_ns"], c["to_start_ns"], c["to_end_ns"]] for c in a["clusters"]], np.int64).reshape(-1, 9)
+        z[f"r{r}_cluster_keys"] = np.concatenate([c["keys"] for c in a["clusters"]] + [np.zeros(0, np.uint64)])
+        z[f"r{r}_cluster_valid"] = np.concatenate([c["valid"] for c in a["clusters"]] + [np.zeros(0, np.uint8)])
+    np.savez_compressed(os.path.join(HERE, "filter_140n_380e.npz"), **z)
+
+
 if __name__ == "__main__":
-    match_fixture(); ransac_fixture(); pgo_fixture()
+    match_fixture(); ransac_fixture(); pgo_fixture(); filter_fixture()
     print("golden fixtures written to", HERE)

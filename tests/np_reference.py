@@ -210,3 +210,180 @@ def pgo_lm(poses, fixed, ij, meas, info, robust, iterations=20, delta=1.0):
             break
     stats["lambda_final"] = lam
     return X.reshape(-1, 12), stats
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Edge filter: a third, pure-Python statement of TransformationFilter / EdgeCluster
+# (transformation_estimation/src/transformation_filter.cpp:43-350) with the reference's object semantics
+# (shared cluster objects, only the first listing repointed on merge).  Small cases only.  Point pairs are
+# computed with Python floats in the oracle's operation order, so they are bit-identical; the RANSAC itself is
+# passed in (it has its own independent checks above).
+# ------------------------------------------------------------------------------------------------------------
+def _iso_mul(A, B):
+    o = [0.0] * 12
+    for r in range(3):
+        for c in range(3):
+            o[r * 4 + c] = (A[r * 4 + 0] * B[0 * 4 + c] + A[r * 4 + 1] * B[1 * 4 + c]) + A[r * 4 + 2] * B[2 * 4 + c]
+        o[r * 4 + 3] = ((A[r * 4 + 0] * B[3] + A[r * 4 + 1] * B[7]) + A[r * 4 + 2] * B[11]) + A[r * 4 + 3]
+    return o
+
+
+def _iso_inv(A):
+    o = [0.0] * 12
+    for r in range(3):
+        for c in range(3):
+            o[r * 4 + c] = A[c * 4 + r]
+        o[r * 4 + 3] = -((A[0 * 4 + r] * A[3] + A[1 * 4 + r] * A[7]) + A[2 * 4 + r] * A[11])
+    return o
+
+
+_I12 = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0]
+
+
+class _Cluster:
+    def __init__(self, uid, e, tf, tt):
+        self.uid = uid
+        self.fs = self.fe = tf
+        self.ts = self.te = tt
+        self.changed = False
+        self.consensus = 0
+        self.evals = 0
+        self.edges = {}                       # key -> dict (python dicts keep insertion order)
+        self.put(e, tf, tt)
+
+    def put(self, e, tf, tt):
+        d = dict(e); d["t_from"] = tf; d["t_to"] = tt; d["valid_"] = bool(e["valid"])
+        self.edges[e["key"]] = d              # a present key keeps its slot
+        if e["valid"]:
+            self.consensus += 1
+
+    def add(self, e, tf, tt):
+        self.fs = min(tf, self.fs); self.fe = max(tf, self.fe); self.ts = min(tt, self.ts); self.te = max(tt, self.te)
+        self.changed = True
+        self.put(e, tf, tt)
+
+    def is_part(self, tf, tt, max_dt):
+        s = lambda a, b: (a - b) * 1e-9
+        return s(tf, self.fs) > -max_dt and s(tf, self.fe) < max_dt and s(tt, self.ts) > -max_dt and s(tt, self.te) < max_dt
+
+    def merge(self, o):
+        self.fs = min(o.fs, self.fs); self.fe = max(o.fe, self.fe); self.ts = min(o.ts, self.ts); self.te = max(o.te, self.te)
+        self.changed = True
+        self.consensus += o.consensus
+        for k, d in o.edges.items():
+            self.edges.setdefault(k, d)
+
+
+class FilterRef:
+    def __init__(self, max_dt=5.0, min_size=8.0, max_cluster_size=100, ransac_iterations=200, max_error=0.3,
+                 min_time_span=2.0, max_edges=5, seed=0):
+        self.__dict__.update(locals())
+        self.clusters = []
+        self.edges = {}
+        self.sensors = []
+        self.next_uid = 0
+
+    def set_sensors(self, sensors):
+        self.sensors = [list(map(float, s)) for s in np.asarray(sensors).reshape(-1, 12)]
+
+    def add(self, edges):
+        for e in edges:
+            if e["key"] in self.edges:
+                for c in self.edges[e["key"]]:
+                    if e["key"] in c.edges:
+                        d = c.edges[e["key"]]
+                        for f in ("pose_from", "pose_to", "transform", "displacement_from", "displacement_to", "sensor_from",
+                                  "sensor_to", "matching_score", "valid"):
+                            d[f] = e[f]
+                continue
+            for tf in map(int, e["stamps_from"]):
+                for tt in map(int, e["stamps_to"]):
+                    matched = [i for i, c in enumerate(self.clusters)
+                               if len(c.edges) < self.max_cluster_size and c.is_part(tf, tt, self.max_dt)]
+                    if not matched:
+                        c = _Cluster(self.next_uid, e, tf, tt); self.next_uid += 1
+                        self.clusters.append(c)
+                        self.edges.setdefault(e["key"], []).append(c)
+                    else:
+                        c0 = self.clusters[matched[0]]
+                        c0.add(e, tf, tt)
+                        self.edges.setdefault(e["key"], []).append(c0)
+                        for i in reversed(matched[1:]):
+                            ci = self.clusters[i]
+                            if len(c0.edges) + len(ci.edges) < self.max_cluster_size:
+                                for k in ci.edges:
+                                    lst = self.edges.get(k, [])
+                                    for u in range(len(lst)):
+                                        if lst[u] is ci:
+                                            lst[u] = c0
+                                            break
+                                c0.merge(ci)
+                                del self.clusters[i]
+
+    def remove(self, keys):
+        for key in map(int, keys):
+            if key not in self.edges:
+                continue
+            for c in self.edges[key]:
+                if key in c.edges:
+                    if c.edges[key]["valid_"]:
+                        c.consensus -= 1
+                    del c.edges[key]
+                if len(c.edges) == 0:
+                    self.clusters = [x for x in self.clusters if x is not c]
+            del self.edges[key]
+
+    def all_edges(self):
+        return np.array(sorted(self.edges), np.uint64)
+
+    def _points(self, d):
+        Sf = self.sensors[d["sensor_from"]] if 0 <= d["sensor_from"] < len(self.sensors) else _I12
+        St = self.sensors[d["sensor_to"]] if 0 <= d["sensor_to"] < len(self.sensors) else _I12
+        f = lambda v: list(map(float, v))
+        a = _iso_mul(f(d["pose_from"]), f(d["displacement_from"]))
+        a = _iso_mul(a, Sf)
+        a = _iso_mul(a, f(d["transform"]))
+        a = _iso_mul(a, _iso_inv(St))
+        b = _iso_mul(f(d["pose_to"]), f(d["displacement_to"]))
+        return [a[3], a[7], a[11]], [b[3], b[7], b[11]]
+
+    def calc_valid_edges(self, ransac):
+        """ransac(P (m,3), Q (m,3), job_id) -> (T(12), set(m) of consensus3D with that T)"""
+        n = 0
+        for c in self.clusters:
+            if len(c.edges) < self.min_size or not c.changed:
+                continue
+            if abs((c.fs - c.fe) * 1e-9) < self.min_time_span or abs((c.ts - c.te) * 1e-9) < self.min_time_span:
+                continue
+            c.changed = False
+            pq = [self._points(d) for d in c.edges.values()]
+            P = np.array([p for p, _ in pq]); Q = np.array([q for _, q in pq])
+            T, s = ransac(P, Q, (c.uid << 20) + c.evals)
+            c.evals += 1; n += 1
+            c.lastP, c.lastQ = P, Q
+            cons = int(np.sum(s))
+            if cons >= self.min_size and cons >= c.consensus:
+                c.consensus = cons
+                for d, v in zip(c.edges.values(), s):
+                    d["valid_"] = bool(v)
+        return n
+
+    def valid_edges(self):
+        ids = set()
+        for c in self.clusters:
+            v = [d for d in c.edges.values() if d["valid_"]]
+            if len(v) > 2 * self.max_edges:
+                v = sorted(v, key=lambda d: -d["matching_score"])          # python's sort is stable
+                ids.update(d["key"] for d in v[:self.max_edges])
+                inc = len(v) / self.max_edges
+                ids.update(v[int(np.floor(inc * i))]["key"] for i in range(self.max_edges - 1))
+                ids.add(v[-1]["key"])
+            else:
+                ids.update(d["key"] for d in v)
+        return np.array(sorted(ids), np.uint64)
+
+    def state(self):
+        return [dict(uid=c.uid, from_start_ns=c.fs, from_end_ns=c.fe, to_start_ns=c.ts, to_end_ns=c.te, size=len(c.edges),
+                     consensus=c.consensus, changed=int(c.changed), evaluations=c.evals,
+                     keys=np.array(list(c.edges), np.uint64), valid=np.array([d["valid_"] for d in c.edges.values()], np.uint8))
+                for c in self.clusters]

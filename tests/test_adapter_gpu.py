@@ -88,3 +88,94 @@ def test_plugin_shaped_classes_match_oracle(oracle, capi, tmp_path):
             assert abs(score - w["consensus"]) <= 0.15 * w["consensus"] + 5
             assert info[0, 0] > 1 and abs(info[3, 3] - 100 * info[0, 0]) < 1e-9 * info[3, 3]
     assert matched >= len(pairs) // 2
+
+
+def test_optimizer_with_edge_filter_in_the_loop(oracle, capi, tmp_path):
+    """Mi355xOptimizer with its TransformationFilter (g2o_optimizer.cpp:73-103) over a growing graph: per round the
+    set of feature edges handed to the solver must equal the oracle filter's verdict, and the solve on that set must
+    match the oracle solver."""
+    exe = os.path.join(ADAPTER, "adapter_selftest")
+    scn = synth.make_filter_scenario(300, 1000, seed=21, outlier_frac=0.15)
+    g = scn["graph"]; ge = g["edges"]
+    n = 300; ne = len(ge["from"]); rounds, iters, seed, cluster_size = 4, 6, 5, 8.0
+    feat = {e["graph_edge"]: e for e in scn["edges"]}
+    rng = np.random.default_rng(0)
+    order = sorted(feat)                                             # graph edge indices of the feature edges, ascending
+    born = np.zeros(ne, np.int32); dies = np.full(ne, -1, np.int32)
+    for r, k in enumerate(order):
+        born[k] = min(rounds - 1, r * rounds // len(order))
+        if rng.random() < 0.05 and born[k] < rounds - 1:
+            dies[k] = born[k] + 1
+    inp = tmp_path / "fin.bin"; out = tmp_path / "fout.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<iiiiiQd", n, ne, 2, rounds, iters, seed, cluster_size))
+        for i in range(n):
+            st = scn["stamps"][i]
+            f.write(g["nodes_pose"][i].astype("<f8").tobytes()); f.write(struct.pack("<ii", int(g["nodes_fixed"][i]), len(st))); f.write(st.astype("<i8").tobytes())
+        f.write(scn["sensors"].astype("<f8").tobytes())
+        ident = np.eye(3, 4).reshape(12)
+        for k in range(ne):
+            fe = feat.get(k)
+            f.write(struct.pack("<iiiiiiiid", int(ge["from"][k]), int(ge["to"][k]), int(ge["type"][k]), fe["valid"] if fe else 1,
+                                fe["sensor_from"] if fe else -1, fe["sensor_to"] if fe else -1, int(born[k]), int(dies[k]),
+                                fe["matching_score"] if fe else 0.0))
+            f.write((fe["transform"] if fe else ge["transform"][k]).astype("<f8").tobytes())
+            f.write((fe["displacement_from"] if fe else ident).astype("<f8").tobytes())
+            f.write((fe["displacement_to"] if fe else ident).astype("<f8").tobytes())
+            f.write(ge["information"][k].astype("<f8").tobytes())
+    subprocess.check_call([exe, "filter", str(inp), str(out)], timeout=300)
+    raw = open(out, "rb").read()
+    off = 0
+    of = oracle.Filter(max_dt=5.0, min_size=cluster_size, max_cluster_size=100, seed=seed)
+    of.set_sensors(scn["sensors"])
+    present = set()
+    total_used = 0
+    for r in range(rounds):
+        before = np.frombuffer(raw, "<f8", n * 12, off).reshape(n, 12); off += n * 96
+        status, it_done, evaluated, n_sys = struct.unpack_from("<iiii", raw, off); off += 16
+        flags = np.frombuffer(raw, np.int8, 2 * ne, off).reshape(ne, 2); off += 2 * ne
+        after = np.frombuffer(raw, "<f8", n * 12, off).reshape(n, 12); off += n * 96
+        assert status == 0
+        for k in range(ne):
+            if born[k] == r:
+                present.add(k)
+            if dies[k] == r:
+                present.discard(k)
+        # the oracle filter sees what the adapter's filter saw: present feature edges in id order with the current poses
+        batch = []
+        for k in sorted(present):
+            if k not in feat:
+                continue
+            e = dict(feat[k]); e["key"] = k
+            e["stamps_from"] = scn["stamps"][e["node_from"]]; e["stamps_to"] = scn["stamps"][e["node_to"]]
+            e["pose_from"] = before[e["node_from"]]; e["pose_to"] = before[e["node_to"]]
+            batch.append(e)
+        known = set(int(x) for x in of.all_edges())
+        of.add(batch)
+        gone = sorted(known - set(e["key"] for e in batch))
+        if gone:
+            of.remove(np.array(gone, np.uint64))
+        assert of.calc_valid_edges() == evaluated
+        verdict = set(int(x) for x in of.valid_edges())
+        used = set(int(k) for k in np.nonzero(flags[:, 1] == 1)[0])
+        assert used == verdict, (r, sorted(used ^ verdict)[:10])
+        total_used += len(used)
+        assert all(flags[k, 0] == -1 for k in range(ne) if k not in present) and all(flags[k, 0] >= 0 for k in present)
+        # the solve on that edge set
+        sub = sorted(present)
+        e2 = {f: np.asarray(ge[f])[sub].copy() for f in ge}
+        for j, k in enumerate(sub):
+            if k in feat:
+                e2["valid"][j] = 1 if k in verdict else 0
+                e2["transform"][j] = feat[k]["transform"]; e2["displacement_from"][j] = feat[k]["displacement_from"]
+                e2["displacement_to"][j] = feat[k]["displacement_to"]
+                e2["sensor_from"][j] = feat[k]["sensor_from"]; e2["sensor_to"][j] = feat[k]["sensor_to"]
+        fl = oracle.flatten_graph(before, g["nodes_fixed"], e2, sensors=scn["sensors"])
+        assert len(fl["ij"]) == n_sys
+        fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+        P, so = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=iters)
+        if so["terminated_early"] == 0 and it_done == iters:
+            dt, dr = synth.pose_errors(after.reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+            assert dt < 1e-3 and dr < 1e-4, (r, dt, dr)
+    assert off == len(raw)
+    assert total_used > 20                                             # the filter did pass edges to the solver

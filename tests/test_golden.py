@@ -112,3 +112,22 @@ def test_hip_reproduces_pgo_golden(capi):
     dt, dr = synth.pose_errors(poses2.reshape(-1, 3, 4), z["poses_out"].reshape(-1, 3, 4))
     assert dt < 1e-3 and dr < 1e-4
     p.close()
+
+
+def test_oracle_reproduces_filter_golden(oracle):
+    from filter_common import check_against_filter_fixture, replay_filter_fixture
+    z = np.load(os.path.join(G, "filter_140n_380e.npz"))
+    cfg = dict(zip(z["cfg_names"].tolist(), z["cfg_values"].tolist()))
+    for k in ("max_cluster_size", "ransac_iterations", "seed"):
+        cfg[k] = int(cfg[k])
+    check_against_filter_fixture(z, list(replay_filter_fixture(z, oracle.Filter(**cfg))))
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_filter_golden(capi):
+    from filter_common import check_against_filter_fixture, replay_filter_fixture
+    z = np.load(os.path.join(G, "filter_140n_380e.npz"))
+    cfg = dict(zip(z["cfg_names"].tolist(), z["cfg_values"].tolist()))
+    for k in ("max_cluster_size", "ransac_iterations", "seed"):
+        cfg[k] = int(cfg[k])
+    check_against_filter_fixture(z, list(replay_filter_fixture(z, capi.Filter(**cfg))))

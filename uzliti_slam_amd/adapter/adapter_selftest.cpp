@@ -15,8 +15,69 @@ static void rd(FILE* f, void* p, size_t n) { if (fread(p, 1, n, f) != n) { fprin
 
 static std::string node_id(int i) { char b[32]; snprintf(b, sizeof(b), "n%08d", i); return b; }   // lexicographic = numeric order
 
+// ---- "filter" mode: R addGraph/optimize/store rounds with the edge filter in the loop, the way GraphSlamNode drives
+// G2oOptimizer while the graph grows (g2o_optimizer.cpp:55-104).  Input: nodes (pose, stamps), sensors, feature and
+// odometry edges with the round they appear in / disappear in.  Output per round: SlamEdge::valid_ as the solver saw
+// it, poses before and after.
+static int filter_mode(const char* in, const char* out)
+{
+    FILE* f = fopen(in, "rb");
+    if (!f) return 2;
+    int32_t n, e, ns, rounds, iters; uint64_t seed; double cluster_size;
+    rd(f, &n, 4); rd(f, &e, 4); rd(f, &ns, 4); rd(f, &rounds, 4); rd(f, &iters, 4); rd(f, &seed, 8); rd(f, &cluster_size, 8);
+    std::vector<SlamNode> nodes(n);
+    for (int i = 0; i < n; i++) {
+        nodes[i].id_ = node_id(i);
+        int32_t fixed, nst; rd(f, nodes[i].pose_.m.data(), 96); rd(f, &fixed, 4); rd(f, &nst, 4);
+        nodes[i].fixed_ = fixed != 0; nodes[i].stamps_.resize(nst); rd(f, nodes[i].stamps_.data(), 8 * (size_t)nst);
+    }
+    std::vector<Isometry3d> sensors(ns);
+    for (int i = 0; i < ns; i++) rd(f, sensors[i].m.data(), 96);
+    std::vector<SlamEdge> edges(e); std::vector<int32_t> born(e), dies(e);
+    for (int k = 0; k < e; k++) {
+        SlamEdge& ed = edges[k]; char b[32]; snprintf(b, sizeof(b), "e%08d", k); ed.id_ = b;
+        int32_t from, to, type, valid, sf, st; double score;
+        rd(f, &from, 4); rd(f, &to, 4); rd(f, &type, 4); rd(f, &valid, 4); rd(f, &sf, 4); rd(f, &st, 4); rd(f, &born[k], 4); rd(f, &dies[k], 4); rd(f, &score, 8);
+        ed.id_from_ = node_id(from); ed.id_to_ = node_id(to); ed.type_ = (unsigned char)type; ed.valid_ = valid != 0; ed.matching_score_ = score;
+        if (sf >= 0) { char s[32]; snprintf(s, sizeof(s), "sensor%d", sf); ed.sensor_from_ = s; }
+        if (st >= 0) { char s[32]; snprintf(s, sizeof(s), "sensor%d", st); ed.sensor_to_ = s; }
+        rd(f, ed.transform_.m.data(), 96); rd(f, ed.displacement_from_.m.data(), 96); rd(f, ed.displacement_to_.m.data(), 96);
+        rd(f, ed.information_.data(), 288);
+    }
+    fclose(f);
+    FILE* o = fopen(out, "wb");
+    SlamGraph graph;
+    for (auto& nd : nodes) graph.addNode(nd);
+    for (int i = 0; i < ns; i++) { char s[32]; snprintf(s, sizeof(s), "sensor%d", i); graph.addSensor(s, sensors[i]); }
+    Mi355xOptimizer opt(0, /*use_edge_filter=*/true, cluster_size, seed);
+    GraphOptimizerConfig cfg; cfg.iterations = iters;
+    opt.setConfig(cfg);
+    for (int r = 0; r < rounds; r++) {
+        for (int k = 0; k < e; k++) {
+            if (born[k] == r) graph.addEdge(edges[k]);
+            if (dies[k] == r) graph.edges().erase(edges[k].id_);
+        }
+        for (auto& kv : graph.nodes()) fwrite(kv.second.pose_.m.data(), 8, 12, o);              // poses the filter sees
+        std::mutex m; std::condition_variable cv; bool done = false;
+        if (!opt.optimize(graph, [&] { std::lock_guard<std::mutex> l(m); done = true; cv.notify_all(); })) return 3;
+        { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return done; }); }
+        opt.storeOptimizationResults(graph);
+        int32_t hdr[4] = {opt.lastStatus(), opt.lastStats().iterations_done, opt.edgeFilter()->lastEvaluated(), opt.lastStats().n_edges};
+        fwrite(hdr, 4, 4, o);
+        for (int k = 0; k < e; k++) {
+            int8_t v = graph.existsEdge(edges[k].id_) ? (graph.edge(edges[k].id_).valid_ ? 1 : 0) : -1;
+            int8_t u = opt.lastFiltered().count(edges[k].id_) ? 1 : 0;
+            fwrite(&v, 1, 1, o); fwrite(&u, 1, 1, o);
+        }
+        for (auto& kv : graph.nodes()) fwrite(kv.second.pose_.m.data(), 8, 12, o);
+    }
+    fclose(o);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 4 && std::string(argv[1]) == "filter") return filter_mode(argv[2], argv[3]);
     if (argc < 3) { fprintf(stderr, "usage: adapter_selftest in.bin out.bin\n"); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 2;
@@ -59,7 +120,7 @@ int main(int argc, char** argv)
     FILE* o = fopen(argv[2], "wb");
     // ---- optimizer plugin: optimize() -> callback on the worker thread -> storeOptimizationResults()
     {
-        Mi355xOptimizer opt(0);
+        Mi355xOptimizer opt(0, /*use_edge_filter=*/false);      // this section feeds ready-made verdicts in SlamEdge::valid_
         GraphOptimizerConfig cfg; cfg.iterations = iters; cfg.optimize_xy_only = xy != 0;
         opt.setConfig(cfg);
         std::mutex m; std::condition_variable cv; bool done = false;

@@ -1,5 +1,8 @@
 #include "graph_optimizer.h"
 
+#include <set>
+#include <unordered_set>
+
 #include <cmath>
 #include <cstring>
 
@@ -54,12 +57,13 @@ void GraphOptimizer::graphOptimizationThread()
     }
 }
 
-Mi355xOptimizer::Mi355xOptimizer(int device)
+Mi355xOptimizer::Mi355xOptimizer(int device, bool use_edge_filter, double cluster_size, uint64_t seed)
 {
     uzl_pgo_cfg c;
     uzl_pgo_cfg_default(&c);
     c.device = device;
     status_ = uzl_pgo_create(&c, &h_);
+    if (use_edge_filter) edge_filter_.reset(new TransformationFilter(5., (int)cluster_size, 100, device, seed));   // g2o_optimizer.cpp:46
 }
 
 Mi355xOptimizer::~Mi355xOptimizer()
@@ -94,6 +98,28 @@ void Mi355xOptimizer::addGraphImpl(SlamGraph& graph)
         sensor_index[kv.first] = (int32_t)(sensors.size() / 12);
         sensors.insert(sensors.end(), kv.second.m.begin(), kv.second.m.end());
     }
+    // non-odometry edges go through the edge filter (g2o_optimizer.cpp:73-103)
+    if (edge_filter_) {
+        edge_filter_->sensor_transforms_ = graph.sensors();                                   // :71
+        std::unordered_set<std::string> edges_to_remove = edge_filter_->allEdges();           // :74
+        for (auto& kv : graph.edges()) {
+            SlamEdge& e = kv.second;
+            if (!graph.existsNode(e.id_from_) || !graph.existsNode(e.id_to_)) continue;       // :77
+            if (e.type_ == TYPE_2D_WHEEL_ODOMETRY) continue;                                  // :78-79
+            edge_filter_->add(e, graph.node(e.id_from_), graph.node(e.id_to_));               // :83
+            edges_to_remove.erase(e.id_);                                                     // :84
+        }
+        for (const auto& id : edges_to_remove) edge_filter_->remove(id);                      // :89-92
+        edge_filter_->calcValidEdges();                                                       // :96
+    }
+    std::set<std::string>& filtered = filtered_;
+    filtered.clear();
+    if (edge_filter_)
+        for (const SlamEdge& fe : edge_filter_->validEdges()) {                               // :97-102
+            if (!graph.existsEdge(fe.id_)) continue;
+            graph.edge(fe.id_).valid_ = true;
+            filtered.insert(fe.id_);
+        }
     std::vector<uzl_edge> edges;
     for (auto& kv : graph.edges()) {
         const SlamEdge& e = kv.second;
@@ -107,7 +133,7 @@ void Mi355xOptimizer::addGraphImpl(SlamGraph& graph)
         u.sensor_from = sf == sensor_index.end() ? -1 : sf->second;
         u.sensor_to = st == sensor_index.end() ? -1 : st->second;
         // TransformationFilter verdict (:97-103); odometry edges bypass the filter (:78-79)
-        u.valid = (e.type_ == TYPE_2D_WHEEL_ODOMETRY) ? 1 : (e.valid_ ? 1 : 0);
+        u.valid = (e.type_ == TYPE_2D_WHEEL_ODOMETRY) ? 1 : (edge_filter_ ? (filtered.count(kv.first) ? 1 : 0) : (e.valid_ ? 1 : 0));
         std::memcpy(u.transform, e.transform_.m.data(), sizeof(u.transform));
         std::memcpy(u.displacement_from, e.displacement_from_.m.data(), sizeof(u.displacement_from));
         std::memcpy(u.displacement_to, e.displacement_to_.m.data(), sizeof(u.displacement_to));

@@ -8,10 +8,13 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
+#include <set>
 #include <thread>
 
 #include "slam_types.h"
+#include "transformation_filter.h"
 #include "../../include/uzl_mi355x.h"
 
 namespace uzl_adapter {
@@ -44,10 +47,15 @@ protected:
 // (graph_slam/src/graph_slam_node.cpp:46).
 class Mi355xOptimizer : public GraphOptimizer {
 public:
-    explicit Mi355xOptimizer(int device = 0);
+    // use_edge_filter: route non-odometry edges through TransformationFilter like G2oOptimizer::addGraphImpl
+    // (g2o_optimizer.cpp:74-103); false = take SlamEdge::valid_ as the verdict.  cluster_size is the reference's
+    // "cluster_size" ROS parameter (g2o_optimizer.cpp:43-46).
+    explicit Mi355xOptimizer(int device = 0, bool use_edge_filter = true, double cluster_size = 8, uint64_t seed = 0);
     ~Mi355xOptimizer() override;
     const uzl_pgo_stats& lastStats() const { return stats_; }
     int lastStatus() const { return status_; }
+    TransformationFilter* edgeFilter() { return edge_filter_.get(); }
+    const std::set<std::string>& lastFiltered() const { return filtered_; }   // ids the filter passed to the solver in the last addGraph
 
 protected:
     void addGraphImpl(SlamGraph& graph) override;     // g2o_optimizer.cpp:55-104
@@ -56,6 +64,8 @@ protected:
 
 private:
     uzl_pgo* h_ = nullptr;
+    std::unique_ptr<TransformationFilter> edge_filter_;          // g2o_optimizer.h:67
+    std::set<std::string> filtered_;
     std::vector<std::string> node_ids_, edge_ids_;    // index <-> string id (the reference's boost::bimap, g2o_optimizer.h:35-36)
     uzl_pgo_stats stats_{};
     int status_ = 0;

@@ -48,6 +48,7 @@ typedef std::shared_ptr<FeatureData> FeatureDataPtr;
 
 struct SlamNode {
     std::string id_;
+    std::vector<int64_t> stamps_;            // std::vector<ros::Time> in the reference (slam_node.h:90): nanoseconds here
     Isometry3d pose_;
     std::vector<SensorDataPtr> sensor_data_;
     bool fixed_ = false;

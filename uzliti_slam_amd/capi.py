@@ -91,6 +91,54 @@ EDGE_DTYPE = np.dtype([("from", "<i4"), ("to", "<i4"), ("type", "<i4"), ("sensor
                        ("displacement_from", "<f8", (12,)), ("displacement_to", "<f8", (12,)),
                        ("information", "<f8", (36,))], align=True)
 
+class FilterCfg(C.Structure):
+    _fields_ = [("max_dt", C.c_double), ("min_size", C.c_double), ("max_cluster_size", C.c_int32),
+                ("ransac_iterations", C.c_int32), ("max_error", C.c_double), ("min_time_span", C.c_double),
+                ("max_edges", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64)]
+
+
+class FilterEdge(C.Structure):
+    _fields_ = [("key", C.c_uint64), ("matching_score", C.c_double), ("valid", C.c_int32),
+                ("sensor_from", C.c_int32), ("sensor_to", C.c_int32), ("n_stamps_from", C.c_int32),
+                ("n_stamps_to", C.c_int32), ("_pad", C.c_int32),
+                ("stamps_from_ns", C.POINTER(C.c_int64)), ("stamps_to_ns", C.POINTER(C.c_int64)),
+                ("transform", C.c_double * 12), ("displacement_from", C.c_double * 12),
+                ("displacement_to", C.c_double * 12), ("pose_from", C.c_double * 12), ("pose_to", C.c_double * 12)]
+
+
+class ClusterInfo(C.Structure):
+    _fields_ = [("uid", C.c_uint64), ("from_start_ns", C.c_int64), ("from_end_ns", C.c_int64),
+                ("to_start_ns", C.c_int64), ("to_end_ns", C.c_int64), ("size", C.c_int32),
+                ("consensus", C.c_int32), ("changed", C.c_int32), ("evaluations", C.c_int32)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+_IDENT12 = (1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0)
+
+
+def pack_filter_edges(edges, struct=None):
+    """list of dicts (key, matching_score, valid, sensor_from, sensor_to, stamps_from, stamps_to, transform,
+    displacement_from, displacement_to, pose_from, pose_to) -> (ctypes array, keep-alive list).  3x4 row-major
+    transforms (12 doubles); stamps are int64 nanoseconds."""
+    struct = struct or FilterEdge
+    arr = (struct * max(len(edges), 1))()
+    keep = []
+    for i, e in enumerate(edges):
+        a = arr[i]
+        a.key = int(e["key"]); a.matching_score = float(e.get("matching_score", 0.0)); a.valid = int(e.get("valid", 0))
+        a.sensor_from = int(e.get("sensor_from", -1)); a.sensor_to = int(e.get("sensor_to", -1))
+        sf = np.ascontiguousarray(e.get("stamps_from", ()), np.int64); st = np.ascontiguousarray(e.get("stamps_to", ()), np.int64)
+        keep += [sf, st]
+        a.n_stamps_from = len(sf); a.n_stamps_to = len(st)
+        a.stamps_from_ns = sf.ctypes.data_as(C.POINTER(C.c_int64)); a.stamps_to_ns = st.ctypes.data_as(C.POINTER(C.c_int64))
+        for f in ("transform", "displacement_from", "displacement_to", "pose_from", "pose_to"):
+            v = e.get(f)
+            getattr(a, f)[:] = _IDENT12 if v is None else tuple(np.asarray(v, np.float64).reshape(-1)[:12])
+    return arr, keep
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 
 _lib = None
@@ -124,6 +172,13 @@ def lib():
             L.uzl_pgo_destroy.restype = None
             L.uzl_pgo_destroy.argtypes = [C.c_void_p]
             L.uzl_pgo_cfg_default.restype = None
+        if hasattr(L, "uzl_filter_create"):
+            L.uzl_filter_last_error.restype = C.c_char_p
+            L.uzl_filter_last_error.argtypes = [C.c_void_p]
+            L.uzl_filter_destroy.restype = None
+            L.uzl_filter_destroy.argtypes = [C.c_void_p]
+            L.uzl_filter_cfg_default.restype = None
+            L.uzl_filter_cluster_count.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -375,3 +430,81 @@ class Pgo:
         names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); ln = (C.c_int32 * cap)()
         n = lib().uzl_pgo_kernel_times(self._h, C.c_int32(cap), names, ms, ln)
         return {names[i].decode(): dict(ms=ms[i], launches=ln[i]) for i in range(max(n, 0))}
+
+
+# --------------------------------------------------------------------------------------- edge filter
+class Filter:
+    """uzl_filter_* (TransformationFilter / EdgeCluster, transformation_filter.cpp:43-350)."""
+
+    def __init__(self, **cfg):
+        L = lib()
+        c = FilterCfg()
+        L.uzl_filter_cfg_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = C.c_void_p()
+        rc = L.uzl_filter_create(C.byref(c), C.byref(self._h))
+        if rc != UZL_OK:
+            raise UzlError(rc, L.uzl_status_string(rc).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uzl_filter_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise UzlError(rc, lib().uzl_filter_last_error(self._h).decode())
+        return rc
+
+    def set_sensors(self, sensors):
+        s = np.ascontiguousarray(sensors, np.float64).reshape(-1, 12)
+        self._check(lib().uzl_filter_set_sensors(self._h, C.c_int32(len(s)), _p(s, c_f64p)))
+
+    def add(self, edges):
+        arr, keep = pack_filter_edges(edges)
+        self._check(lib().uzl_filter_add(self._h, C.c_int32(len(edges)), arr))
+
+    def remove(self, keys):
+        k = np.ascontiguousarray(keys, np.uint64)
+        self._check(lib().uzl_filter_remove(self._h, C.c_int32(len(k)), _p(k, c_u64p)))
+
+    def _keys(self, fn):
+        n = C.c_int32()
+        self._check(fn(self._h, C.c_int32(0), None, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint64)
+        self._check(fn(self._h, C.c_int32(len(out)), _p(out, c_u64p), C.byref(n)))
+        return out[:n.value]
+
+    def all_edges(self):
+        return self._keys(lib().uzl_filter_all_edges)
+
+    def valid_edges(self):
+        return self._keys(lib().uzl_filter_valid_edges)
+
+    def calc_valid_edges(self):
+        n = C.c_int32()
+        self._check(lib().uzl_filter_calc_valid_edges(self._h, C.byref(n)))
+        return n.value
+
+    def clusters(self, with_eval=False):
+        """clusters_ in order: list of dicts (info + keys + valid [+ P, Q, T, ransac_consensus of the last evaluation])."""
+        out = []
+        for i in range(self._check(lib().uzl_filter_cluster_count(self._h))):
+            ci = ClusterInfo()
+            self._check(lib().uzl_filter_cluster_info(self._h, C.c_int32(i), C.byref(ci)))
+            d = ci.as_dict()
+            keys = np.zeros(max(ci.size, 1), np.uint64); valid = np.zeros(max(ci.size, 1), np.uint8)
+            self._check(lib().uzl_filter_cluster_edges(self._h, C.c_int32(i), C.c_int32(len(keys)), _p(keys, c_u64p), _p(valid, c_u8p)))
+            d["keys"] = keys[:ci.size]; d["valid"] = valid[:ci.size]
+            if with_eval:
+                cap = max(ci.size + 128, 256)
+                P = np.zeros((cap, 3)); Q = np.zeros((cap, 3)); T = np.zeros(12); rc = C.c_int32()
+                m = self._check(lib().uzl_filter_cluster_last_eval(self._h, C.c_int32(i), C.c_int32(cap), _p(P, c_f64p), _p(Q, c_f64p),
+                                                                   _p(T, c_f64p), C.byref(rc)))
+                d.update(P=P[:m].copy(), Q=Q[:m].copy(), T=T, ransac_consensus=rc.value)
+            out.append(d)
+        return out

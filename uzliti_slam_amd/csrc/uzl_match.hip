@@ -4,6 +4,7 @@
 // service: frames are uploaded once, every node-pair job references them by id.
 #include "uzl_common.hpp"
 #include "match_types.hpp"
+#include "match_internal.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -213,6 +214,55 @@ int do_collect(uzl_match* h, uzl_edge_result* results, int32_t* corr_query, int3
             if (inlier_mask) { memcpy(inlier_mask + dst, h->h_mask.p + src, (size_t)m); for (int32_t k = m; k < mc; k++) inlier_mask[dst + k] = 0; }
         }
     }
+    return UZL_OK;
+}
+
+// RANSAC over point sets already resident on the device (3 x total column-major at dP/dQ); enqueues on the handle's
+// stream and leaves results in h->d_results / h->d_mask (row stride *stride_out).  Used by uzl_ransac_points and by
+// the edge filter (uzl_filter.hip), whose pose-chain kernel produces the points on the same stream.
+int enqueue_ransac(uzl_match* h, int32_t n_problems, const int32_t* offsets, const double* dP, const double* dQ,
+                   double max_error, int32_t iterations, double break_percentage, int32_t do_prosac,
+                   const uint64_t* job_ids, int* stride_out)
+{
+    int max_m = 0;
+    h->h_jobs.reserve((size_t)n_problems);
+    for (int32_t b = 0; b < n_problems; b++) {
+        const int32_t m = offsets[b + 1] - offsets[b];
+        max_m = std::max(max_m, m);
+        Job j;
+        j.job_id = job_ids ? job_ids[b] : (uint64_t)b;
+        j.combo_begin = 0; j.combo_count = 0; j.pq_off = offsets[b]; j.pq_count = m;
+        h->h_jobs.p[b] = j;
+    }
+    const int stride = std::max(max_m, 1);
+    hipStream_t s = h->stream;
+    h->d_jobs.reserve((size_t)n_problems);
+    h->d_results.reserve((size_t)n_problems);
+    const size_t tot = (size_t)n_problems * stride;
+    h->d_mask.reserve(tot);
+    UZL_HIP(hipMemcpyAsync(h->d_jobs.p, h->h_jobs.p, (size_t)n_problems * sizeof(Job), hipMemcpyHostToDevice, s));
+    EstimateArgs a;
+    memset(&a, 0, sizeof(a));
+    a.jobs = h->d_jobs.p;
+    a.prm.thresh = max_error; a.prm.break_pct = break_percentage; a.prm.seed = h->cfg.seed;
+    a.prm.iterations = iterations; a.prm.do_prosac = do_prosac ? 1 : 0; a.prm.max_corr = stride;
+    a.results = h->d_results.p;
+    a.P_in = dP; a.Q_in = dQ;
+    a.inlier_mask = h->d_mask.p;
+    a.sort_cap = 4;
+    const int lds_points = (stride + 1) & ~1;
+    a.prm.lds_points = lds_points;
+    const bool in_lds = estimate_lds_bytes(a.sort_cap, iterations, lds_points, true) <= kLdsBudget;
+    if (!in_lds) {
+        h->d_pq_scratch.reserve(tot * 6); h->d_dist_scratch.reserve(tot); h->d_mask_scratch.reserve(tot);
+        a.pq_scratch = h->d_pq_scratch.p; a.dist_scratch = h->d_dist_scratch.p; a.mask_scratch = h->d_mask_scratch.p;
+    }
+    const size_t lds = estimate_lds_bytes(a.sort_cap, iterations, lds_points, in_lds);
+    h->timer.reset();
+    h->timer.begin("ransac_points", s);
+    UZL_HIP(launch_estimate(a, n_problems, in_lds, lds, s));
+    h->timer.end(s);
+    *stride_out = stride;
     return UZL_OK;
 }
 
@@ -447,51 +497,20 @@ int uzl_ransac_points(uzl_match* h, int32_t n_problems, const int32_t* offsets, 
     if (n_problems == 0) return UZL_OK;
     UZL_HIP(hipSetDevice(h->cfg.device));
     const int64_t total = offsets[n_problems];
-    int max_m = 0;
-    h->h_jobs.reserve((size_t)n_problems);
-    for (int32_t b = 0; b < n_problems; b++) {
-        const int32_t m = offsets[b + 1] - offsets[b];
-        if (m < 0) return fail(h, UZL_ERR_BAD_ARG, "offsets must be non-decreasing");
-        max_m = std::max(max_m, m);
-        Job j;
-        j.job_id = job_ids ? job_ids[b] : (uint64_t)b;
-        j.combo_begin = 0; j.combo_count = 0; j.pq_off = offsets[b]; j.pq_count = m;
-        h->h_jobs.p[b] = j;
-    }
-    const int stride = std::max(max_m, 1);
+    for (int32_t b = 0; b < n_problems; b++)
+        if (offsets[b + 1] < offsets[b]) return fail(h, UZL_ERR_BAD_ARG, "offsets must be non-decreasing");
     hipStream_t s = h->stream;
-    h->d_jobs.reserve((size_t)n_problems);
     h->d_P.reserve((size_t)std::max<int64_t>(total, 1) * 3);
     h->d_Q.reserve((size_t)std::max<int64_t>(total, 1) * 3);
-    h->d_results.reserve((size_t)n_problems); h->h_results.reserve((size_t)n_problems);
-    const size_t tot = (size_t)n_problems * stride;
-    h->d_mask.reserve(tot); h->h_mask.reserve(tot);
-    UZL_HIP(hipMemcpyAsync(h->d_jobs.p, h->h_jobs.p, (size_t)n_problems * sizeof(Job), hipMemcpyHostToDevice, s));
     if (total > 0) {
         UZL_HIP(hipMemcpyAsync(h->d_P.p, P, (size_t)total * 24, hipMemcpyHostToDevice, s));
         UZL_HIP(hipMemcpyAsync(h->d_Q.p, Q, (size_t)total * 24, hipMemcpyHostToDevice, s));
     }
-    EstimateArgs a;
-    memset(&a, 0, sizeof(a));
-    a.jobs = h->d_jobs.p;
-    a.prm.thresh = max_error; a.prm.break_pct = break_percentage; a.prm.seed = h->cfg.seed;
-    a.prm.iterations = iterations; a.prm.do_prosac = do_prosac ? 1 : 0; a.prm.max_corr = stride;
-    a.results = h->d_results.p;
-    a.P_in = h->d_P.p; a.Q_in = h->d_Q.p;
-    a.inlier_mask = h->d_mask.p;
-    a.sort_cap = 4;
-    const int lds_points = (stride + 1) & ~1;
-    a.prm.lds_points = lds_points;
-    const bool in_lds = estimate_lds_bytes(a.sort_cap, iterations, lds_points, true) <= kLdsBudget;
-    if (!in_lds) {
-        h->d_pq_scratch.reserve(tot * 6); h->d_dist_scratch.reserve(tot); h->d_mask_scratch.reserve(tot);
-        a.pq_scratch = h->d_pq_scratch.p; a.dist_scratch = h->d_dist_scratch.p; a.mask_scratch = h->d_mask_scratch.p;
-    }
-    const size_t lds = estimate_lds_bytes(a.sort_cap, iterations, lds_points, in_lds);
-    h->timer.reset();
-    h->timer.begin("ransac_points", s);
-    UZL_HIP(launch_estimate(a, n_problems, in_lds, lds, s));
-    h->timer.end(s);
+    int stride = 0;
+    const int rc = enqueue_ransac(h, n_problems, offsets, h->d_P.p, h->d_Q.p, max_error, iterations, break_percentage, do_prosac, job_ids, &stride);
+    if (rc != UZL_OK) return rc;
+    const size_t tot = (size_t)n_problems * stride;
+    h->h_results.reserve((size_t)n_problems); h->h_mask.reserve(tot);
     UZL_HIP(hipMemcpyAsync(h->h_results.p, h->d_results.p, (size_t)n_problems * sizeof(uzl_edge_result), hipMemcpyDeviceToHost, s));
     UZL_HIP(hipMemcpyAsync(h->h_mask.p, h->d_mask.p, tot, hipMemcpyDeviceToHost, s));
     UZL_HIP(hipStreamSynchronize(s));
@@ -524,3 +543,26 @@ int uzl_match_kernel_times(uzl_match* h, int32_t cap, const char** names, double
 }
 
 }  // extern "C"
+
+// ---- internal interface for uzl_filter.hip (match_internal.hpp) ----
+namespace uzl {
+
+hipStream_t match_stream(uzl_match* h) { return h->stream; }
+
+int match_ransac_device(uzl_match* h, int32_t n_problems, const int32_t* offsets, const double* dP, const double* dQ,
+                        double max_error, int32_t iterations, double break_percentage, int32_t do_prosac,
+                        const uint64_t* job_ids, MatchDeviceResults* out)
+{
+    UZL_GUARD_BEGIN(h)
+    if (h->in_flight) return fail(h, UZL_ERR_BUSY, "a batch is in flight");
+    if (iterations < 1 || iterations > kMaxIterations) return fail(h, UZL_ERR_BAD_ARG, "iterations out of range [1,4096]");
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    int stride = 0;
+    const int rc = enqueue_ransac(h, n_problems, offsets, dP, dQ, max_error, iterations, break_percentage, do_prosac, job_ids, &stride);
+    if (rc != UZL_OK) return rc;
+    out->results = h->d_results.p; out->mask = h->d_mask.p; out->stride = stride; out->stream = h->stream;
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
+}  // namespace uzl

@@ -229,3 +229,49 @@ def make_pair(rng, n_kp=1000, desc_bytes=32, flip_p=0.08, outlier_frac=0.4, sigm
 def make_pairs(n_pairs, n_kp=1000, desc_bytes=32, seed=777, **kw):
     rng = np.random.default_rng(seed)
     return [make_pair(rng, n_kp=n_kp, desc_bytes=desc_bytes, **kw) for _ in range(n_pairs)]
+
+
+def make_filter_scenario(n_nodes=400, n_loop=1200, seed=4242, outlier_frac=0.2, two_stamp_frac=0.1):
+    """Synthetic input of the edge filter (TransformationFilter, transformation_filter.cpp:138-291): the loop
+    closures of make_pose_graph as SlamEdge-like dicts, plus node stamps, drifting node poses and two sensors.
+    Returns dict(edges=[...edge dicts without poses...], stamps=[int64 arrays per node], gt (N,3,4), init (N,3,4),
+    sensors (2,12)).  `edge_with_poses(scn, k, poses)` makes the dict uzl_filter_add takes."""
+    g = make_pose_graph(n_nodes, (n_nodes - 1) + n_loop, seed=seed, outlier_frac=outlier_frac)
+    rng = np.random.default_rng(seed + 1)
+    N = n_nodes
+    t0 = 1_400_000_000 * 10**9
+    stamps = []
+    for i in range(N):
+        t = t0 + int(0.5e9 * i) + int(rng.integers(0, 10**7))
+        stamps.append(np.array([t, t + 250_000_000], np.int64) if rng.random() < two_stamp_frac else np.array([t], np.int64))
+    sensors = np.stack([se3(quat_to_R(quat_from_rotvec(np.array([[0.0, 0.1, 0.0]])))[0], np.array([0.2, 0.0, 0.5])),
+                        se3(quat_to_R(quat_from_rotvec(np.array([[0.0, 0.0, 1.5]])))[0], np.array([-0.1, 0.05, 0.4]))])
+    E = g["edges"]
+    loop = np.nonzero(E["type"] != EDGE_TYPE_ODOM)[0]
+    ident = np.eye(3, 4)
+    edges = []
+    for n, k in enumerate(loop):
+        sf, st = int(rng.integers(-1, 2)), int(rng.integers(-1, 2))
+        df = se3_from_noise(rng.normal(0, 0.05, (1, 3)), rng.normal(0, 0.05, (1, 3)))[0] if rng.random() < 0.3 else ident
+        dt = se3_from_noise(rng.normal(0, 0.05, (1, 3)), rng.normal(0, 0.05, (1, 3)))[0] if rng.random() < 0.3 else ident
+        Sf = sensors[sf] if sf >= 0 else ident
+        St = sensors[st] if st >= 0 else ident
+        Z = E["transform"][k].reshape(3, 4)
+        # node-to-node measurement Z = disp_from * S_from * T * S_to^-1 * disp_to^-1  (g2o_optimizer.cpp:281)
+        T = se3_mul(se3_mul(se3_inv(se3_mul(df, Sf)), Z), se3_mul(dt, St))
+        edges.append(dict(key=1000 + 7 * n, matching_score=float(rng.integers(20, 60)), valid=int(rng.random() < 0.15),
+                          sensor_from=sf, sensor_to=st, node_from=int(E["from"][k]), node_to=int(E["to"][k]),
+                          transform=T.reshape(12), displacement_from=np.asarray(df).reshape(12),
+                          displacement_to=np.asarray(dt).reshape(12)))
+    for n, k in enumerate(loop):
+        edges[n]["graph_edge"] = int(k)
+    return dict(edges=edges, stamps=stamps, gt=g["gt_pose"].reshape(N, 3, 4), init=g["nodes_pose"].reshape(N, 3, 4),
+                sensors=sensors.reshape(2, 12), graph=g)
+
+
+def edge_with_poses(scn, k, poses):
+    """Edge k of a filter scenario as uzl_filter_add wants it, with the end nodes' current poses and stamps."""
+    e = dict(scn["edges"][k])
+    e["stamps_from"] = scn["stamps"][e["node_from"]]; e["stamps_to"] = scn["stamps"][e["node_to"]]
+    e["pose_from"] = np.asarray(poses[e["node_from"]]).reshape(12); e["pose_to"] = np.asarray(poses[e["node_to"]]).reshape(12)
+    return e
