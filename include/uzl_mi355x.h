@@ -209,7 +209,7 @@ typedef struct uzl_pgo_cfg {
     int32_t optimize_xy_only;         /* 0    project poses/measurements to (x,y,yaw) (g2o_optimizer.cpp:164-170)         */
     /* ---- back-end additions ---- */
     int32_t device;
-    double  pcg_tol;                  /* stop when r.M^-1 r <= pcg_tol^2 * (r0.M^-1 r0)                */
+    double  pcg_tol;                  /* 1e-5  stop when r.M^-1 r <= pcg_tol^2 * (r0.M^-1 r0)         */
     int32_t pcg_max_iter;             /* per linear solve                                             */
     double  huber_delta;              /* 1.0  (g2o_optimizer.cpp:293)                                 */
     int32_t verbose;
