@@ -1,0 +1,117 @@
+"""End-to-end run of the whole path in the shape of BASELINE config 5 at reduced size: node pairs -> edge estimation
+-> acceptance by score -> edge filter -> pose-graph solve, repeated while the graph grows.  The GPU pipeline (through
+the C ABI) and the CPU oracle pipeline run independently from the same inputs; every stage must agree: edges
+bit-exact, filter verdicts identical, poses within 1e-3 m / 1e-4 rad after the same LM iteration counts."""
+import numpy as np
+import pytest
+
+from uzliti_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(ransac_threshold=0.1, ransac_iteration=200, ransac_break_percentage=0.6, seed=5)
+MIN_SCORE = 30           # GraphSlam.cfg min_matching_score-like gate of the caller (graph_slam_node.cpp:786)
+ROUNDS, LM_ITERS = 4, 6
+
+
+def graph_edges(run, feat, verdict):
+    o = run["odo"]
+    n_o = len(o["from"]); n_f = len(feat)
+    ident = np.eye(3, 4).reshape(12)
+    e = {k: np.concatenate([np.asarray(o[k]), np.zeros((n_f,) + np.asarray(o[k]).shape[1:], np.asarray(o[k]).dtype)]) for k in o}
+    for j, f in enumerate(feat):
+        k = n_o + j
+        e["from"][k] = f["node_from"]; e["to"][k] = f["node_to"]; e["type"][k] = synth.EDGE_TYPE_3D_FULL
+        e["sensor_from"][k] = 0; e["sensor_to"][k] = 0; e["valid"][k] = 1 if f["key"] in verdict else 0
+        e["transform"][k] = f["transform"]; e["displacement_from"][k] = ident; e["displacement_to"][k] = ident
+        e["information"][k] = f["information"]
+    return e
+
+
+def run_pipeline(run, estimate, make_filter, solve):
+    poses = run["init"].copy()
+    feat, log = [], []
+    chunks = np.array_split(np.arange(len(run["pairs"])), ROUNDS)
+    filt = make_filter()
+    filt.set_sensors(run["sensor"].reshape(1, 12))
+    for r, chunk in enumerate(chunks):
+        res = estimate(chunk)
+        for k, e in zip(chunk, res):
+            if e["ok"] and e["consensus"] >= MIN_SCORE:
+                a, b = run["pairs"][k][:2]
+                feat.append(dict(key=int(k), matching_score=float(e["consensus"]), valid=0, sensor_from=0, sensor_to=0,
+                                 node_from=a, node_to=b, transform=np.asarray(e["T"]).reshape(12),
+                                 information=np.asarray(e["information"]).reshape(36),
+                                 displacement_from=np.eye(3, 4).reshape(12), displacement_to=np.eye(3, 4).reshape(12)))
+        batch = []
+        for f in feat:
+            d = dict(f); d["stamps_from"] = run["stamps"][f["node_from"]]; d["stamps_to"] = run["stamps"][f["node_to"]]
+            d["pose_from"] = poses[f["node_from"]].reshape(12); d["pose_to"] = poses[f["node_to"]].reshape(12)
+            batch.append(d)
+        filt.add(batch)
+        n_eval = filt.calc_valid_edges()
+        verdict = set(int(x) for x in filt.valid_edges())
+        poses = solve(poses, graph_edges(run, feat, verdict)).reshape(-1, 3, 4)
+        log.append(dict(results=res, verdict=verdict, poses=poses.copy(), n_eval=n_eval, n_feat=len(feat)))
+    return log
+
+
+def test_online_run_gpu_equals_oracle(capi, oracle):
+    run = synth.make_slam_run(150, seed=2024)
+    n_pairs = len(run["pairs"])
+    assert n_pairs > 150
+
+    # ---- GPU back end
+    m = capi.Match(ransac_threshold=CFG["ransac_threshold"], ransac_iteration=CFG["ransac_iteration"],
+                   ransac_break_percentage=CFG["ransac_break_percentage"], do_prosac=1, seed=CFG["seed"])
+    fid = [m.add_frame(f["desc"], f["pos"], f["valid"]) for f in run["frames"]]        # one upload per node
+    pgo = capi.Pgo()
+
+    def gpu_estimate(chunk):
+        ids = [(fid[run["pairs"][k][2]], fid[run["pairs"][k][3]]) for k in chunk]
+        out, _ = m.estimate(ids, job_ids=[int(k) for k in chunk])
+        return [dict(ok=int(o["ok"]), consensus=int(o["consensus"]), T=o["T"].copy(), information=o["information"].copy(),
+                     mse=float(o["mse"])) for o in out]
+
+    def gpu_solve(poses, edges):
+        pgo.add_graph(poses.reshape(-1, 12), run["fixed"], edges, sensors=run["sensor"].reshape(1, 12))
+        st = pgo.optimize(LM_ITERS)
+        assert st["status"] == 0
+        return pgo.store()[0]
+
+    # ---- CPU oracle
+    def cpu_estimate(chunk):
+        out = []
+        for k in chunk:
+            _, _, fa, fb = run["pairs"][k]
+            e = oracle.estimate_edge([run["frames"][fa]], [run["frames"][fb]], ransac_threshold=CFG["ransac_threshold"],
+                                     ransac_iteration=CFG["ransac_iteration"], break_percentage=CFG["ransac_break_percentage"],
+                                     do_prosac=True, seed=CFG["seed"], job_id=int(k))
+            out.append(dict(ok=int(e["ok"]), consensus=int(e["consensus"]), T=np.asarray(e["T"]).reshape(12),
+                            information=np.asarray(e["information"]).reshape(36), mse=float(e["mse"])))
+        return out
+
+    def cpu_solve(poses, edges):
+        fl = oracle.flatten_graph(poses.reshape(-1, 12), run["fixed"], edges, sensors=run["sensor"].reshape(1, 12))
+        fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+        P, _ = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=LM_ITERS)
+        return P
+
+    fcfg = dict(min_size=6.0, seed=CFG["seed"])
+    G = run_pipeline(run, gpu_estimate, lambda: capi.Filter(**fcfg), gpu_solve)
+    O = run_pipeline(run, cpu_estimate, lambda: oracle.Filter(**fcfg), cpu_solve)
+
+    for r, (a, b) in enumerate(zip(G, O)):
+        for x, y in zip(a["results"], b["results"]):                       # edges: bit-exact
+            assert x["ok"] == y["ok"] and x["consensus"] == y["consensus"]
+            assert np.array_equal(x["T"], y["T"]) and np.array_equal(x["information"], y["information"]) and x["mse"] == y["mse"]
+        assert a["n_feat"] == b["n_feat"] and a["n_eval"] == b["n_eval"], r
+        assert a["verdict"] == b["verdict"], (r, sorted(a["verdict"] ^ b["verdict"]))
+        dt, dr = synth.pose_errors(a["poses"], b["poses"])
+        assert dt < 1e-3 and dr < 1e-4, (r, dt, dr)
+    # the run did something: edges were accepted, clusters evaluated, and the map got better than dead reckoning
+    assert G[-1]["n_feat"] > 100 and sum(x["n_eval"] for x in G) >= 3 and len(G[-1]["verdict"]) >= 10
+    err0 = np.linalg.norm(run["init"][:, :, 3] - run["gt"][:, :, 3], axis=1).mean()
+    err1 = np.linalg.norm(G[-1]["poses"][:, :, 3] - run["gt"][:, :, 3], axis=1).mean()
+    assert err1 < 0.5 * err0, (err0, err1)
+    m.close(); pgo.close()

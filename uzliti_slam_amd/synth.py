@@ -275,3 +275,61 @@ def edge_with_poses(scn, k, poses):
     e["stamps_from"] = scn["stamps"][e["node_from"]]; e["stamps_to"] = scn["stamps"][e["node_to"]]
     e["pose_from"] = np.asarray(poses[e["node_from"]]).reshape(12); e["pose_to"] = np.asarray(poses[e["node_to"]]).reshape(12)
     return e
+
+
+def make_slam_run(n_nodes=150, n_landmarks=1500, seed=2024, max_pairs=400, desc_bytes=32, flip_p=0.06, clutter=0.3,
+                  sigma=0.01, invalid_frac=0.1, alias_frac=0.08):
+    """A small end-to-end run in the shape of BASELINE config 5: a robot revisits places; every node carries one
+    FeatureData frame of the world landmarks it sees (camera frame, metres), loop-closure candidates are node pairs
+    within 1 m (what SlamGraph::getNodesWithinRadius would hand to the estimator, slam_graph.cpp:266-278).
+    Returns dict(gt, init (N,3,4), stamps, odo edges (make_pose_graph layout), frames [dict], sensor (12),
+    pairs [(from, to, frame_from, frame_to)] ordered by the later node = the order they would be produced online;
+    for a fraction `alias_frac` of the pairs the `to` frame is the one of a node 5 steps away (a wrong but
+    geometrically consistent match: the kind of edge the filter and the robust kernel exist for))."""
+    g = make_pose_graph(n_nodes, n_nodes - 1, seed=seed)
+    rng = np.random.default_rng(seed + 7)
+    N = n_nodes
+    gt = g["gt_pose"].reshape(N, 3, 4)
+    # base -> camera: camera z = base x (forward), camera x = -base y, camera y = -base z
+    S = se3(np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]]), np.array([0.1, 0.0, 0.3]))
+    half = 0.5 * max(4.0, np.sqrt(N / 3.4)) + 2.5
+    lm = np.stack([rng.uniform(-half, half, n_landmarks), rng.uniform(-half, half, n_landmarks), rng.uniform(-0.5, 2.5, n_landmarks)], 0)
+    bits = desc_bytes * 8
+    lbits = rng.integers(0, 2, (n_landmarks, bits), dtype=np.uint8)
+    frames = []
+    for i in range(N):
+        C = se3_mul(gt[i], S)                                     # world <- camera
+        pc = C[:, :3].T @ (lm - C[:, 3:4])
+        vis = (pc[2] > 0.3) & (pc[2] < 4.0) & (np.abs(pc[0]) < pc[2]) & (np.abs(pc[1]) < 0.8 * pc[2])
+        idx = np.nonzero(vis)[0]
+        n_c = int(clutter * len(idx)) + 8
+        d = np.concatenate([lbits[idx] ^ (rng.random((len(idx), bits)) < flip_p).astype(np.uint8),
+                            rng.integers(0, 2, (n_c, bits), dtype=np.uint8)])
+        p = np.concatenate([pc[:, idx] + rng.normal(0, sigma, (3, len(idx))),
+                            np.stack([rng.uniform(-2, 2, n_c), rng.uniform(-1.5, 1.5, n_c), rng.uniform(0.3, 4.0, n_c)])], 1)
+        perm = rng.permutation(d.shape[0])
+        d = d[perm]; p = np.ascontiguousarray(p[:, perm])
+        valid = (rng.random(d.shape[0]) >= invalid_frac).astype(np.uint8)
+        p[2, valid == 0] = -1.0
+        frames.append(dict(desc=np.ascontiguousarray(np.packbits(d, axis=1)), pos=p, valid=valid, feature_type=FEATURE_ORB, sensor_frame=0))
+    t0 = 1_400_000_000 * 10**9
+    stamps = [np.array([t0 + int(0.5e9 * i)], np.int64) for i in range(N)]
+    pos = gt[:, :, 3]
+    pairs = []
+    for j in range(N):
+        dd = np.linalg.norm(pos[:j] - pos[j], axis=1) if j else np.zeros(0)
+        for i in np.nonzero(dd < 1.0)[0]:
+            if j - i > 10 and rotation_angle(gt[i][:, :3].T @ gt[j][:, :3]) < np.deg2rad(50):
+                pairs.append((int(i), int(j)) if rng.random() < 0.5 else (int(j), int(i)))
+    if len(pairs) > max_pairs:
+        keep = np.sort(rng.choice(len(pairs), max_pairs, replace=False))
+        pairs = [pairs[k] for k in keep]
+    full = []
+    for a, b in pairs:
+        fb = b
+        if rng.random() < alias_frac:
+            fb = b + 5 if b + 5 < N else b - 5
+        full.append((a, b, a, fb))
+    pairs = full
+    return dict(gt=gt, init=g["nodes_pose"].reshape(N, 3, 4), fixed=g["nodes_fixed"], stamps=stamps, odo=g["edges"], frames=frames,
+                sensor=S.reshape(12), pairs=pairs)
