@@ -651,6 +651,27 @@ int k_diagmax(const PgoDev& D, hipStream_t s)
     hipLaunchKernelGGL(diagmax_kernel, dim3(g), dim3(kBlk), 0, s, D);
     return g;
 }
+// hands scal[0..8) and flags[0..4) to the host through pinned coherent memory (PgoHostScal); seq last
+__global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ scal, const int32_t* __restrict__ flags,
+                                                    PgoHostScal* __restrict__ out, uint32_t seq)
+{
+    const int t = threadIdx.x;
+    if (t < 8) out->scal[t] = scal[t];
+    else if (t < 12) out->flags[t - 8] = flags[t - 8];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void set_scalar_kernel(double* __restrict__ dst, double v) { *dst = v; }
+
+void k_publish(const PgoDev& D, PgoHostScal* out_dev, uint32_t seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, s, D.scal, D.flags, out_dev, seq);
+}
+void k_set_scalar(double* dst, double v, hipStream_t s)
+{
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, dst, v);
+}
 void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s)
 {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlk), 0, s, D, na, nb_, nc, what);

@@ -217,25 +217,195 @@ __global__ __launch_bounds__(kBlk) void ml_reduce_kernel(const MlDev* __restrict
     }
 }
 
-// ---- per LM trial: D_l(lambda)^-1 for the intermediate levels 1..L-1 (one lane per aggregate)
-__global__ __launch_bounds__(kBlk) void ml_invert_kernel(PgoDev D, const MlDev* __restrict__ mlp)
+// ---- per LM trial: the sibling-block smoothers.  One single-wave workgroup per (level l < L, aggregate A of level
+//      l+1): A_l(lambda) restricted to A's children is gathered into LDS ((6 fan)^2 <= 48^2: diagonal blocks plus
+//      every off-diagonal block whose column is a sibling; multi-edges add up in slot order), inverted in place
+//      by Gauss-Jordan without pivoting (SPD), and written to Winv[l][A].  Missing children (last aggregate of a
+//      level) are padded with identity rows.
+constexpr int kSibBlk = 192;
+constexpr int kSibCols = 2048;                          // slot columns of one aggregate staged in LDS
+
+// 1/sqrt(x) from the hardware estimate + two Newton steps (deterministic; accuracy ~1e-15 is ample for a smoother)
+__device__ __forceinline__ double rsqrt_nr(double x)
 {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+// inverse of an SPD 6x6 (row-major) through its Cholesky factor, reciprocal square roots only
+__device__ __forceinline__ void spd_inverse6_rs(double* A, double* out)
+{
+    double inv[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[j * 6 + k] * A[j * 6 + k];
+        inv[j] = rsqrt_nr(fmax(d, 1e-300));
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s * inv[j];
+        }
+    }
+    double Li[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) Li[i] = 0.;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+#pragma unroll
+        for (int r = c; r < 6; r++) {
+            double s = (r == c) ? 1. : 0.;
+#pragma unroll
+            for (int k = c; k < r; k++) s -= A[r * 6 + k] * Li[k * 6 + c];
+            Li[r * 6 + c] = s * inv[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            double s = 0.;
+#pragma unroll
+            for (int k = (r > c ? r : c); k < 6; k++) s += Li[k * 6 + r] * Li[k * 6 + c];
+            out[r * 6 + c] = s;
+        }
+}
+
+// In-place inverse of the M x M SPD matrix in sW (row stride ld) by BLOCK Gauss-Jordan with 6 x 6 pivots: M/6
+// dependent steps instead of M.  Lane (row, part) = tid / 4, tid % 4 holds columns [part*M/4, +M/4) of its row in
+// registers (loops over them unrolled; pivot positions are only ever compared, so register indices stay static).
+// Per pivot block K:  P = A_KK^-1 (every lane, redundantly);  A_Kj <- P A_Kj;  A_iK <- -A_iK P;
+//                     A_ij <- A_ij - A_iK (P A_Kj);  A_KK <- P.
+template <int M>
+__device__ __forceinline__ void block_gauss_jordan(double* __restrict__ sW, double* __restrict__ sPiv, double* __restrict__ sNew,
+                                                   double* __restrict__ sP, int ld, int tid)
+{
+    constexpr int CW = M / 4;                         // 12 or 6: whole 6-blocks
+    const int row = tid >> 2, part = tid & 3, c0 = part * CW;
+    const bool own = row < M;
+    double a[CW];
+#pragma unroll
+    for (int j = 0; j < CW; j++) a[j] = own ? sW[row * ld + c0 + j] : 0.;
+    for (int K = 0; K < M / 6; K++) {
+        const int k0 = 6 * K, kp = k0 / CW, kj0 = k0 - kp * CW;         // pivot columns live in part kp at offset kj0
+        const bool piv = row >= k0 && row < k0 + 6;
+        __syncthreads();                                                // sPiv / sNew of the previous step consumed
+        if (piv) {
+#pragma unroll
+            for (int j = 0; j < CW; j++) sPiv[(row - k0) * M + c0 + j] = a[j];
+        }
+        __syncthreads();
+        double Akk[36], P[36];
+#pragma unroll
+        for (int i = 0; i < 36; i++) Akk[i] = sPiv[(i / 6) * M + k0 + i % 6];
+        spd_inverse6_rs(Akk, P);
+        {   // P goes to LDS so that it can be indexed by run-time row / column numbers
+            double pv = 0.;
+#pragma unroll
+            for (int u = 0; u < 36; u++) pv = (u == (int)threadIdx.x) ? P[u] : pv;
+            if (threadIdx.x < 36) sP[threadIdx.x] = pv;
+        }
+        __syncthreads();
+        if (piv) {
+            const int r = row - k0;
+#pragma unroll
+            for (int j = 0; j < CW; j++) {
+                double v = 0.;
+#pragma unroll
+                for (int q = 0; q < 6; q++) v += sP[r * 6 + q] * sPiv[q * M + c0 + j];
+                sNew[r * M + c0 + j] = v;
+                const int qc = j - kj0;
+                a[j] = (part == kp && qc >= 0 && qc < 6) ? sP[r * 6 + (qc < 0 ? 0 : (qc > 5 ? 5 : qc))] : v;
+            }
+        }
+        __syncthreads();
+        // multipliers f[q] = A_{row, k0+q}: held by the lane (row, kp) at a[kj0 + q]
+        double f[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            double sel = (CW == 12 && kj0 == 6) ? a[(CW == 12 ? 6 : 0) + q] : a[q];
+            f[q] = __shfl(sel, (threadIdx.x & 60) | kp);
+        }
+        if (own && !piv) {
+#pragma unroll
+            for (int j = 0; j < CW; j++) {
+                const int qc = j - kj0;
+                double v;
+                if (part == kp && qc >= 0 && qc < 6) {
+                    v = 0.;
+#pragma unroll
+                    for (int u = 0; u < 6; u++) v -= f[u] * sP[u * 6 + qc];
+                } else {
+                    v = a[j];
+#pragma unroll
+                    for (int u = 0; u < 6; u++) v -= f[u] * sNew[u * M + c0 + j];
+                }
+                a[j] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (own) {
+#pragma unroll
+        for (int j = 0; j < CW; j++) sW[row * ld + c0 + j] = a[j];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kSibBlk) void ml_sibling_kernel(PgoDev D, const MlDev* __restrict__ mlp)
+{
+    __shared__ double sW[48 * 49];
+    __shared__ double sPiv[6 * 48];
+    __shared__ double sNew[6 * 48];
+    __shared__ double sP[36];
+    __shared__ int scol[kSibCols];
     const MlDev& ml = *mlp;
     const double lambda = D.scal[3];
-    int t = blockIdx.x * kBlk + threadIdx.x;
-    for (int l = 1; l < ml.levels; l++) {
-        const MlLevel& L = ml.lv[l];
-        if (t < L.n) {
-            double A[36], out[36];
-#pragma unroll
-            for (int k = 0; k < 36; k++) A[k] = L.G[(size_t)t * 36 + k] + lambda * L.M[(size_t)t * 36 + k];
-            spd_inverse6(A, out);
-#pragma unroll
-            for (int k = 0; k < 36; k++) L.Dinv[(size_t)t * 36 + k] = out[k];
-            return;
+    int A = blockIdx.x, l = 0;
+    while (l < ml.levels && A >= ml.lv[l + 1].n) { A -= ml.lv[l + 1].n; l++; }
+    if (l >= ml.levels) return;
+    const MlLevel& F = ml.lv[l];
+    const int fan = ml.lv[l + 1].fan, m = 6 * fan, ld = 49, nc = F.n;
+    const int t = threadIdx.x;
+    for (int i = t; i < m * ld; i += kSibBlk) sW[i] = 0.;
+    // column indices of the aggregate's rows (one contiguous slot range): all loads in flight at once, so the
+    // per-row scan below walks LDS instead of paying a memory round trip per slot (hub rows have dozens)
+    const int cfirst = A * fan, clast = (cfirst + fan < nc) ? cfirst + fan : nc;
+    const int sbeg = F.row_ptr[cfirst], send = F.row_ptr[clast];
+    for (int i = sbeg + t; i < send && i - sbeg < kSibCols; i += kSibBlk) scol[i - sbeg] = F.col[i];
+    __syncthreads();
+    if (t < m) {
+        const int ch = t / 6, r = t % 6, c = A * fan + ch;
+        if (c >= nc) {
+            sW[t * ld + t] = 1.;
+        } else {
+            const double* __restrict__ G = F.G + (size_t)c * 36 + r * 6;
+            for (int k = 0; k < 6; k++) {
+                double v = G[k];
+                if (l == 0) { if (k == r) v += lambda; } else v += lambda * F.M[(size_t)c * 36 + r * 6 + k];
+                sW[t * ld + ch * 6 + k] = v;
+            }
+            if (l > 0 || D.sibling0) {
+                for (int s = F.row_ptr[c]; s < F.row_ptr[c + 1]; s++) {
+                    const int cc = (s - sbeg < kSibCols) ? scol[s - sbeg] : F.col[s];
+                    if (cc >= 0 && cc / fan == A) {
+                        const int jc = cc - A * fan;
+                        const double* __restrict__ bk = F.blk + (size_t)s * 36 + r * 6;
+                        for (int k = 0; k < 6; k++) sW[t * ld + jc * 6 + k] += bk[k];
+                    }
+                }
+            }
         }
-        t -= L.n;
     }
+    __syncthreads();
+    if (m == 48) block_gauss_jordan<48>(sW, sPiv, sNew, sP, ld, t);
+    else block_gauss_jordan<24>(sW, sPiv, sNew, sP, ld, t);     // fan-out 4 (level 2 of large graphs)
+    double* __restrict__ out = F.Winv + (size_t)A * m * m;
+    for (int i = t; i < m * m; i += kSibBlk) out[i] = sW[(i / m) * ld + i % m];
 }
 
 // ---- per LM trial: dense inverse of the top level A_L(lambda) (<= 48 x 48), one workgroup, in LDS
@@ -293,12 +463,13 @@ __global__ __launch_bounds__(kBlk) void ml_top_kernel(PgoDev D, const MlDev* __r
 // one memory latency covers them: these kernels are latency-bound, not bandwidth-bound, at pose-graph sizes.
 // ------------------------------------------------------------------------------------------------
 // Two geometries, chosen by graph size (template parameter AGG = level-1 aggregates per workgroup):
-//   AGG = 1 (small graphs, <= 4096 free vertices): a workgroup owns ONE level-1 aggregate (8 rows), the gather
+//   AGG = 1 (small graphs, <= 2560 free vertices): a workgroup owns ONE level-1 aggregate (8 rows), the gather
 //           level is 1, hierarchy fan-outs 8,8,8,..  -> 8x more workgroups, i.e. CUs, for the latency-bound kernels
 //   AGG = 4 (large graphs): a workgroup owns one level-2 aggregate = 4 level-1 aggregates (32 rows), gather level 2,
 //           hierarchy fan-outs 8,4,8,8,..             -> the gathered arrays stay small (n/32 entries)
 constexpr int kCgBlk = 192;                             // 3 waves; the first 48*AGG threads own a (row, component)
 constexpr int kGatherU = 16;                            // gather-level values per thread kept in registers
+constexpr int kChain = 6 * 48 + 3;                      // per ancestor level: 6 rows of its sibling-block inverse + its offset d
 
 template <int NW>
 __device__ __forceinline__ double block_sum_w(double v, double* sN)
@@ -578,6 +749,8 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     __shared__ double sr1[kAggPerBlk * 6];
     __shared__ double sy[kAggPerBlk * 6];
     __shared__ double syc[6];
+    __shared__ double szj[kRowsPerBlk * 6];
+    constexpr int kFan2 = (AGG == 1) ? kMlFanout : kMlFanout2;    // children of a level-2 aggregate (build_ml)
     if (D.flags[0]) return;
     STAMP_DECL
     const int tid = threadIdx.x;
@@ -595,7 +768,7 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     const int top_off = o;
     const int n_top_rows = (Lt == 1) ? kAggPerBlk * 6 : 6;
     o += n_top_rows * ntop;
-    const int chain_off = o;                                  // (L-2) x 39
+    const int chain_off = o;                                  // (L-2) x kChain
     anc[1] = blockIdx.x * kAggPerBlk;                          // (only its parent chain is used)
     anc[2] = (gl == 2) ? (int)blockIdx.x : anc[1] / H.fan[2 <= Lt ? 2 : 1];
     for (int l = 3; l <= Lt; l++) anc[l] = anc[l - 1] / H.fan[l];
@@ -603,26 +776,54 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     // ---- every global load whose address is known now, before any barrier
     double part = 0.;
     if (!init) for (int i = tid; i < n_part; i += kCgBlk) part += D.part_a[i];
-    double xv = 0., rv0 = 0., apv = 0., pv = 0., mrow[6] = {0, 0, 0, 0, 0, 0}, geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double xv = 0., rv0 = 0., apv = 0., pv = 0., geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (act) {
         const size_t i = (size_t)a * 6 + r;
         rv0 = D.r[i];
         if (!init) { xv = D.x[i]; apv = D.ap[i]; pv = p[i]; }
-        const double* __restrict__ m = D.minv + (size_t)a * 36 + r * 6;
         const double* __restrict__ gg = H.geo0 + (size_t)a * 12;
-#pragma unroll
-        for (int c = 0; c < 6; c++) mrow[c] = m[c];
 #pragma unroll
         for (int c = 0; c < 12; c++) geo[c] = gg[c];
     }
-    double d1row[6] = {0, 0, 0, 0, 0, 0}, g1own[3] = {0, 0, 0};
+    // level-0 smoother.  AGG = 1: W0^-1 of the own level-1 aggregate (48 x 48), 4 threads per output row, 12 columns
+    // each.  AGG = 4 (large graphs): the level-0 blocks are built block-diagonal (PgoDev::sibling0 = 0: four dense
+    // 48 x 48 slices per workgroup and iteration would cost more traffic than the iterations they save), so every
+    // (row, component) thread needs only the 6 entries of its own diagonal block.
+    double w0[(AGG == 1) ? 12 : 6];
+    if (AGG == 1) {
+        const int out = tid >> 2, part = tid & 3;
+        const int Aq = blockIdx.x;
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(H.Winv[0] + ((size_t)(Aq < n1 ? Aq : 0) * 48 + out) * 48 + part * 12);
+#pragma unroll
+        for (int c = 0; c < 6; c++) { const double2 v = src[c]; w0[2 * c] = v.x; w0[2 * c + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; c++) w0[c] = 0.;
+        if (act) {
+            const int rl = a % kMlFanout;
+            const double* __restrict__ src = H.Winv[0] + ((size_t)(a / kMlFanout) * 48 + rl * 6 + r) * 48 + rl * 6;
+#pragma unroll
+            for (int c = 0; c < 6; c++) w0[c] = src[c];
+        }
+    }
+    // level-1 smoother: the own aggregates' rows of W1^-1 (sibling block of the level-2 parent): (6 AGG) outputs x kFan2 parts
+    double g1own[3] = {0, 0, 0}, w1[6] = {0, 0, 0, 0, 0, 0}, g1x[3] = {0, 0, 0};
     const int A1 = blockIdx.x * kAggPerBlk + tid / 6;
     if (Lt >= 2 && tid < kAggPerBlk * 6 && A1 < n1) {
-        const double* di = H.Dinv[1] + (size_t)A1 * 36 + (tid % 6) * 6;
-#pragma unroll
-        for (int c = 0; c < 6; c++) d1row[c] = di[c];
         const double* gq = H.geo[1] + (size_t)A1 * 3;
         g1own[0] = gq[0]; g1own[1] = gq[1]; g1own[2] = gq[2];
+    }
+    const int o1 = tid / kFan2, part1 = tid % kFan2;
+    const int A1x = blockIdx.x * kAggPerBlk + o1 / 6;
+    const bool l1thr = Lt >= 2 && tid < kAggPerBlk * 6 * kFan2;
+    const bool l1act = l1thr && A1x < n1;
+    if (l1act) {
+        const int m1 = 6 * kFan2, A2 = A1x / kFan2, rowin = (A1x % kFan2) * 6 + o1 % 6;
+        const double* __restrict__ src = H.Winv[1] + ((size_t)A2 * m1 + rowin) * m1 + part1 * 6;
+#pragma unroll
+        for (int c = 0; c < 6; c++) w1[c] = src[c];
+        const double* gq = H.geo[1] + (size_t)A1x * 3;
+        g1x[0] = gq[0]; g1x[1] = gq[1]; g1x[2] = gq[2];
     }
     const double rz = init ? 0. : D.scal[0];
     // gather-level residual and restricted Ap of ALL aggregates: first kGatherU x 192 values in registers
@@ -650,9 +851,10 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
         const int grow = (Lt == 1) ? (blockIdx.x * kAggPerBlk * 6 + rr) : (6 * anc[Lt] + rr);
         dyn[top_off + t] = (grow < ntop) ? H.top_inv[(size_t)grow * ntop + c] : 0.;
     }
-    for (int l = 2; l < Lt; l++) {
-        if (tid < 39)
-            dyn[chain_off + (l - 2) * 39 + tid] = (tid < 36) ? H.Dinv[l][(size_t)anc[l] * 36 + tid] : H.geo[l][(size_t)anc[l] * 3 + (tid - 36)];
+    for (int l = 2; l < Lt; l++) {           // fan-out of levels >= 3 is kMlFanout: 48 x 48 sibling blocks
+        const double* __restrict__ wl = H.Winv[l] + ((size_t)anc[l + 1] * 48 + (size_t)(anc[l] % kMlFanout) * 6) * 48;
+        for (int t = tid; t < kChain; t += kCgBlk)
+            dyn[chain_off + (l - 2) * kChain + t] = (t < 288) ? wl[t] : H.geo[l][(size_t)anc[l] * 3 + (t - 288)];
     }
     STAMP(0);      // 1: prefetch issue
     double alpha = 0.;
@@ -704,17 +906,19 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
             if (row < 6 && j == 0) syc[row] = sacc;
         }
         __syncthreads();
-        for (int l = Lt - 1; l >= 2; l--) {
+        for (int l = Lt - 1; l >= 2; l--) {          // y_l = W_l^-1 [own ancestor's rows] r_l[siblings] + P_{l+1} y_{l+1}
+            const double* ch = dyn + chain_off + (l - 2) * kChain;
+            const int k = tid >> 3, part = tid & 7, sib = anc[l + 1] * kMlFanout + part;
             double sacc = 0.;
-            if (tid < 6) {
-                const double* ch = dyn + chain_off + (l - 2) * 39;
-                const double* rr = dyn + roff[l] + anc[l] * 6;
+            if (tid < 48 && sib < H.n[l]) {
+                const double* rr = dyn + roff[l] + sib * 6;
 #pragma unroll
-                for (int c = 0; c < 6; c++) sacc += ch[tid * 6 + c] * rr[c];
-                sacc += prolong_comp(ch + 36, syc, tid);
+                for (int c = 0; c < 6; c++) sacc += ch[k * 48 + part * 6 + c] * rr[c];
             }
+            sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
+            if (tid < 48 && part == 0) sacc += prolong_comp(ch + 288, syc, k);
             __syncthreads();
-            if (tid < 6) syc[tid] = sacc;
+            if (tid < 48 && part == 0) syc[k] = sacc;
             __syncthreads();
         }
     }
@@ -730,14 +934,25 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     sv[tid] = act ? rv : 0.;
     __syncthreads();
     double zz = 0., w = 0.;
-    if (act) {
+    if (AGG == 1) {   // zJ = W0^-1 r over the own aggregate: 4 partial sums per output row
+        const int part = tid & 3;
+        double ps = 0.;
+#pragma unroll
+        for (int c = 0; c < 12; c++) ps += w0[c] * sv[part * 12 + c];
+        ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2);
+        if (part == 0) szj[tid >> 2] = ps;
+    } else if (act) {
         const int g0 = tid - r;
 #pragma unroll
-        for (int c = 0; c < 6; c++) zz += mrow[c] * sv[g0 + c];
+        for (int c = 0; c < 6; c++) zz += w0[c] * sv[g0 + c];
+    }
+    if (act) {
+        const int g0 = tid - r;
         w = p1t_comp(geo, sv[g0], sv[g0 + 1], sv[g0 + 2], sv[g0 + 3], sv[g0 + 4], sv[g0 + 5], r);
     }
     sw[tid] = w;
     __syncthreads();
+    if (AGG == 1 && act) zz = szj[tid];
     STAMP(0);      // 5: x, r, zJ, w
     if (tid < kAggPerBlk * 6) {
         const int la = tid / 6, k = tid % 6;
@@ -751,22 +966,26 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     STAMP(0);      // 6: exact r1
     if (Lt >= 2) {
         double c2 = 0.;
-        if (tid < kAggPerBlk * 6) {                                       // y1 = D1^-1 r1 + P2 y2
-            const int la = tid / 6, k = tid % 6;
-            double s = 0.;
-            if (A1 < n1) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) s += d1row[c] * sr1[la * 6 + c];
-                s += prolong_comp(g1own, syc, k);
-                c2 = restrict_comp(g1own, sr1 + la * 6, k);               // this child's share of the exact r2
-            }
-            sy[tid] = s;
-        }
+        if (tid < kAggPerBlk * 6 && A1 < n1) c2 = restrict_comp(g1own, sr1 + (tid / 6) * 6, tid % 6);   // this child's share of the exact r2
         if (gl == 2) {
             c2 += __shfl_down(c2, 12);                                     // lanes (la, k): fold la = 0..3
             c2 += __shfl_down(c2, 6);
             if (tid < 6) rg_new[(size_t)blockIdx.x * 6 + tid] = c2;       // exact r2 of the own aggregate
         }
+        // y1 = W1^-1 [own rows] r1[siblings] + P2 y2.  AGG = 1: the siblings' r1 come from the gather-level vector in
+        // LDS (own aggregate: the exact value); AGG = 4: the four siblings are this workgroup's own aggregates.
+        double ps = 0.;
+        if (l1act) {
+            const int sib = (A1x / kFan2) * kFan2 + part1;
+            const double* rs = (AGG == 1) ? ((sib == A1x) ? sr1 : dyn + roff[1] + (size_t)sib * 6) : (sr1 + part1 * 6);
+            if (AGG != 1 || sib < n1) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) ps += w1[c] * rs[c];
+            }
+        }
+        ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2);
+        if (kFan2 == 8) ps += __shfl_xor(ps, 4);
+        if (l1thr && part1 == 0) sy[o1] = l1act ? ps + prolong_comp(g1x, syc, o1 % 6) : 0.;
     }
     __syncthreads();
     double acc = 0.;
@@ -807,9 +1026,9 @@ void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s)
     const long work = (long)blocks36 * 36;
     if (work > 0) hipLaunchKernelGGL(ml_reduce_kernel, dim3((unsigned)((work + kBlk - 1) / kBlk)), dim3(kBlk), 0, s, ml, l);
 }
-void k_ml_invert(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s)
+void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s)
 {
-    if (total_aggs > 0) hipLaunchKernelGGL(ml_invert_kernel, dim3((total_aggs + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml);
+    if (total_aggs > 0) hipLaunchKernelGGL(ml_sibling_kernel, dim3(total_aggs), dim3(kSibBlk), 0, s, D, ml);
     hipLaunchKernelGGL(ml_top_kernel, dim3(1), dim3(kBlk), 0, s, D, ml);
 }
 int g_ml_rows(int nb, int agg) { return (nb + kMlFanout * agg - 1) / (kMlFanout * agg); }
@@ -822,7 +1041,7 @@ size_t ml_cg_lds_bytes(const int* n, int levels, int agg)
     for (int l = g; l < levels; l++) d += 3 * (size_t)n[l];
     const size_t ntop = 6 * (size_t)n[levels];
     d += ((levels == 1) ? (size_t)agg * 6 : 6) * ntop;
-    if (levels > 2) d += (size_t)(levels - 2) * 39;
+    if (levels > 2) d += (size_t)(levels - 2) * kChain;
     return d * 8;
 }
 bool ml_fits_lds(const int* n_per_level, int levels, int agg)

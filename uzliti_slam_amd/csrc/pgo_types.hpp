@@ -21,6 +21,8 @@ struct PgoDev {
     int32_t n, nb, e, nslots;
     int32_t e_begin, e_end;   // system edges linearised by this rank (sharded solve); [0, e) otherwise
     int32_t diag_owner;       // 1 on the rank that adds the (H_aa + lambda) p term and the diagonal Galerkin parts
+    int32_t sibling0;         // 1: the level-0 smoother couples the 8 rows of an aggregate (0 in the sharded solve, whose
+                              //    ranks hold only their own edges' off-diagonal blocks)
     double* pose;
     double* pose_trial;
     const int32_t* v2b;      // [n]  free-block index or -1
@@ -55,8 +57,12 @@ struct PgoDev {
 // ---- multilevel preconditioner (aggregation hierarchy with rigid-body-mode coarse spaces) -------------
 // Level 0 = free vertices.  Level l+1 aggregates 8 consecutive level-l entities (index order = time order =
 // the odometry chain), until at most 8 aggregates remain; that top level is solved exactly (dense), every
-// level below contributes its block diagonal (additive multilevel, BPX style):
-//     z = D0^-1 r + P1 ( D1^-1 r1 + P2 ( D2^-1 r2 + ... + P_L A_L^-1 r_L ) ),   r_l = P_l^T r_{l-1}
+// level below contributes a block-diagonal smoother (additive multilevel, BPX style):
+//     z = W0^-1 r + P1 ( W1^-1 r1 + P2 ( W2^-1 r2 + ... + P_L A_L^-1 r_L ) ),   r_l = P_l^T r_{l-1}
+// where W_l is A_l(lambda) restricted to SIBLINGS (the children of one level-(l+1) aggregate: a dense block of
+// (6 fan)^2 <= 48^2), inverted per LM trial.  Sibling blocks instead of 6x6 diagonal blocks cost one 48x48 matvec
+// slice per workgroup and cut the PCG iterations by a third (the 8 consecutive vertices of an aggregate are
+// tied by the stiff odometry chain).
 // The coarse unknown of an aggregate is a world-frame twist (v, w) about the aggregate's centroid c, the
 // exact null space of a pose graph; for a vertex i (R_i, t_i) in local MQT coordinates
 //     P_i = [[R_i^T, -R_i^T [t_i - c]x], [0, 1/2 R_i^T]],  and between levels  P = [[I, -[c_child - c]x], [0, I]].
@@ -87,6 +93,7 @@ struct MlLevel {
     double* cen;               // [n][3]  centroid (levels >= 1)
     double* r;                 // [n][6]  restricted residual
     double* y;                 // [n][6]  coarse correction
+    double* Winv;              // [n_{l+1}][(6 fan_{l+1})^2]  inverse sibling blocks of THIS level's entities (levels < L)
 };
 
 struct MlDev {
@@ -107,15 +114,19 @@ struct MlHot {
     int32_t fan[kMlMaxLevels + 1];
     const double* geo0;                    // [nb][12]
     const double* geo[kMlMaxLevels + 1];   // [n_l][3], l >= 1
-    const double* Dinv[kMlMaxLevels + 1];  // [n_l][36], 1 <= l < levels
+    const double* Winv[kMlMaxLevels + 1];  // [n_{l+1}][(6 fan_{l+1})^2], 0 <= l < levels
     const double* top_inv;
     double* Sg;                            // [n_g][6] restriction of A p at the gather level g = min(2, levels)
 };
 
-// scalars copied back to the host after each LM trial / PCG chunk
+// scalars handed back to the host after each LM trial / PCG chunk.  The struct lives in pinned, host-coherent memory
+// that a one-workgroup kernel (publish_kernel) writes directly; `seq` is stored last with system-scope release, the
+// host spins on it - a few microseconds instead of the copy + stream-synchronise round trip.
 struct PgoHostScal {
     double scal[8];
     int32_t flags[4];
+    uint32_t seq;
+    uint32_t pad;
 };
 
 }  // namespace uzl

@@ -73,14 +73,14 @@ struct PinBuf {
     PinBuf() = default;
     PinBuf(const PinBuf&) = delete;
     PinBuf& operator=(const PinBuf&) = delete;
-    void reserve(size_t n)
+    void reserve(size_t n, unsigned flags = hipHostMallocDefault)
     {
         if (n <= cap) return;
         size_t ncap = cap ? cap : 256;
         while (ncap < n) ncap *= 2;
         if (p) UZL_HIP(hipHostFree(p));
         p = nullptr;
-        UZL_HIP(hipHostMalloc((void**)&p, ncap * sizeof(T), hipHostMallocDefault));
+        UZL_HIP(hipHostMalloc((void**)&p, ncap * sizeof(T), flags));
         cap = ncap;
     }
 };

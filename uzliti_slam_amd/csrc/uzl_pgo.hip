@@ -28,6 +28,8 @@ int k_assemble(const PgoDev& D, hipStream_t s);
 void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s);
 int k_diagmax(const PgoDev& D, hipStream_t s);
 void k_precond(const PgoDev& D, hipStream_t s);
+void k_publish(const PgoDev& D, PgoHostScal* out_dev, uint32_t seq, hipStream_t s);
+void k_set_scalar(double* dst, double v, hipStream_t s);
 int k_pcg_init(const PgoDev& D, double* p0, double* p1, hipStream_t s);
 int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
 int k_pcg_update(const PgoDev& D, const double* p, int n_part, hipStream_t s);
@@ -36,7 +38,7 @@ int g_pcg_update(int nb);
 void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, int n_l, hipStream_t s);
 void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s);
 void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
-void k_ml_invert(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
+void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
 int g_ml_rows(int nb, int agg);
 size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
 bool ml_fits_lds(const int* n_per_level, int levels, int agg);
@@ -74,7 +76,9 @@ struct uzl_pgo {
     DevBuf<uint8_t> d_robust;
     DevBuf<uzl_node> d_nodes;
     DevBuf<uzl_edge> d_edges;
-    PinBuf<PgoHostScal> h_scal;
+    PinBuf<PgoHostScal> h_scal;      // pinned + coherent: written by publish_kernel, polled by the host
+    PgoHostScal* d_pub = nullptr;    // its device-side address
+    uint32_t pub_seq = 0;
     PinBuf<double> h_lambda;
     PgoDev D;
     int prev_pcg_iters = 0;
@@ -118,18 +122,32 @@ struct Timed {
     ~Timed() { h->timer.end(h->stream); }
 };
 
+// Device scalars -> host.  A one-workgroup kernel at the end of the queued work writes them straight into pinned
+// coherent host memory and bumps a sequence word; the host spins on that word (bounded, then falls back to a stream
+// synchronise so that a failed launch surfaces as an error instead of a hang).
 void fetch_scal(uzl_pgo* h)
 {
-    UZL_HIP(hipMemcpyAsync(h->h_scal.p->scal, h->D.scal, sizeof(double) * 8, hipMemcpyDeviceToHost, h->stream));
-    UZL_HIP(hipMemcpyAsync(h->h_scal.p->flags, h->D.flags, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, h->stream));
-    UZL_HIP(hipStreamSynchronize(h->stream));
+    const uint32_t seq = ++h->pub_seq;
+    k_publish(h->D, h->d_pub, seq, h->stream);
+    volatile PgoHostScal* pub = h->h_scal.p;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (int spin = 0; !seen; spin++) {
+        seen = __atomic_load_n(&h->h_scal.p->seq, __ATOMIC_ACQUIRE) == seq;
+        if (!seen && (spin & 1023) == 1023 &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 50.0) break;
+    }
+    (void)pub;
+    if (!seen || h->timer.on) {
+        UZL_HIP(hipStreamSynchronize(h->stream));
+        if (__atomic_load_n(&h->h_scal.p->seq, __ATOMIC_ACQUIRE) != seq) throw HipError{hipErrorUnknown, "publish_kernel did not run", __FILE__, __LINE__};
+    }
     h->timer.resolve();
 }
 
 void set_lambda(uzl_pgo* h, double lambda)
 {
-    h->h_lambda.p[0] = lambda;
-    UZL_HIP(hipMemcpyAsync(h->D.scal + 3, h->h_lambda.p, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    k_set_scalar(h->D.scal + 3, lambda, h->stream);
 }
 
 // exchange step of the sharded solve: sum `count` doubles at dev_ptr over all ranks (caller-supplied RCCL all-reduce)
@@ -159,7 +177,9 @@ void alloc_problem(uzl_pgo* h)
     h->d_v2b.reserve(n);
     h->d_part_a.reserve(kMaxPartials); h->d_part_b.reserve(kMaxPartials); h->d_part_c.reserve(kMaxPartials);
     h->d_scal.reserve(8); h->d_flags.reserve(4);
-    h->h_scal.reserve(1); h->h_lambda.reserve(1);
+    h->h_scal.reserve(1, hipHostMallocMapped | hipHostMallocCoherent); h->h_lambda.reserve(1);
+    memset(h->h_scal.p, 0, sizeof(PgoHostScal));
+    UZL_HIP(hipHostGetDevicePointer((void**)&h->d_pub, h->h_scal.p, 0));
     h->cur = h->pose_a.p; h->trial = h->pose_b.p;
 }
 
@@ -211,7 +231,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     const int nb = h->nb;
     h->ml_levels = 0; h->ml_n.assign(1, nb); h->ml_nslots.assign(1, h->nslots); h->ml_inner_aggs = 0;
     if (h->cfg.preconditioner == 0 || nb <= kMlTopMax) return;
-    h->ml_agg = nb <= 4096 ? 1 : 4;
+    static const int agg1_max = getenv("UZL_ML_AGG1_MAX") ? atoi(getenv("UZL_ML_AGG1_MAX")) : 2560;   // measured crossover (env: diagnostic override)
+    h->ml_agg = nb <= agg1_max ? 1 : 4;
     int L = 0;
     h->ml_fan.assign(1, 1);
     while (h->ml_n.back() > kMlTopMax && L < kMlMaxLevels) {
@@ -266,7 +287,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         h->ml_nslots.push_back((int32_t)C.col.size());
         max_contrib = std::max(max_contrib, off.size() + dg.size());
         max_n = std::max(max_n, (size_t)nc);
-        if (f + 1 < L) h->ml_inner_aggs += nc;
+        h->ml_inner_aggs += nc;                                   // one sibling block per aggregate of every coarse level
     }
     // ---- one arena for everything: first the int arrays (staged on the host), then the doubles
     size_t bytes = 0;
@@ -283,14 +304,14 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         io[l].diag_ptr = take(std::max<size_t>(X.diag_ptr.size(), 1) * 4);
     }
     const size_t int_bytes = bytes;
-    struct DblOff { size_t blk, G, M, Dinv, geo, cen, r, y; };
+    struct DblOff { size_t blk, G, M, Winv, geo, cen, r, y; };
     std::vector<DblOff> dof((size_t)L + 1);
     for (int l = 0; l <= L; l++) {
         const size_t n = (size_t)std::max(h->ml_n[l], 1), ns = (size_t)std::max(h->ml_nslots[l], 1);
         dof[l].blk = (l == 0) ? 0 : take(ns * 36 * 8);
         dof[l].G = (l == 0) ? 0 : take(n * 36 * 8);
         dof[l].M = (l == 0) ? 0 : take(n * 36 * 8);
-        dof[l].Dinv = (l == 0) ? 0 : take(n * 36 * 8);
+        dof[l].Winv = (l < L) ? take((size_t)std::max(h->ml_n[l + 1], 1) * (size_t)(36 * h->ml_fan[l + 1] * h->ml_fan[l + 1]) * 8) : 0;
         dof[l].geo = take(n * ((l == 0) ? 12 : 3) * 8);
         dof[l].cen = take(n * 3 * 8);
         dof[l].r = take(n * 6 * 8);
@@ -330,7 +351,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         X.blk = (l == 0) ? h->d_blk.p : reinterpret_cast<double*>(base + dof[l].blk);
         X.G = (l == 0) ? h->d_hdiag.p : reinterpret_cast<double*>(base + dof[l].G);
         X.M = (l == 0) ? nullptr : reinterpret_cast<double*>(base + dof[l].M);
-        X.Dinv = (l == 0) ? h->d_minv.p : reinterpret_cast<double*>(base + dof[l].Dinv);
+        X.Winv = (l < L) ? reinterpret_cast<double*>(base + dof[l].Winv) : nullptr;
         X.geo = reinterpret_cast<double*>(base + dof[l].geo);
         X.cen = reinterpret_cast<double*>(base + dof[l].cen);
         X.r = reinterpret_cast<double*>(base + dof[l].r);
@@ -346,7 +367,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     MlHot& Hh = h->ml_hot;
     memset(&Hh, 0, sizeof(Hh));
     Hh.levels = L;
-    for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Dinv[l] = M.lv[l].Dinv; }
+    for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Winv[l] = M.lv[l].Winv; }
     Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg;
     h->l1_span_ptr = M.lv[1].blk;
     h->l1_span = (int64_t)((M.lv[1].M + (size_t)std::max(h->ml_n[1], 1) * 36) - M.lv[1].blk);
@@ -428,7 +449,7 @@ void build_structure(uzl_pgo* h)
     D.b = h->d_hdiag.p + (size_t)nb * 36; D.x = h->d_x.p; D.r = h->d_r.p; D.z = h->d_z.p; D.p = h->d_p.p; D.ap = h->d_ap.p;
     D.part_a = h->d_ap.p + (size_t)nbz * 12; D.part_b = h->d_part_b.p; D.part_c = h->d_part_c.p;
     D.scal = h->d_scal.p; D.flags = h->d_flags.p;
-    D.e_begin = 0; D.e_end = e; D.diag_owner = 1;
+    D.e_begin = 0; D.e_end = e; D.diag_owner = 1; D.sibling0 = 1;      // sibling0 finalised after build_ml
     build_ml(h, row_ptr, col);
     {   // per-iteration exchange buffer: [A p (6 nb) | restricted A p (6 n_g) | p.Ap partials]
         const int gl = (h->ml_levels == 0) ? 0 : ((h->ml_agg == 1 || h->ml_levels < 2) ? 1 : 2);
@@ -437,6 +458,7 @@ void build_structure(uzl_pgo* h)
         D.part_a = h->d_ap.p + (size_t)nb * 6 + ng6;
         h->iter_span = (int64_t)((size_t)nb * 6 + ng6 + (gl ? (size_t)g_ml_rows(nb, h->ml_agg) : 0));
     }
+    D.sibling0 = (h->ml_levels > 0 && h->ml_agg == 1) ? 1 : 0;       // large graphs keep the level-0 smoother block-diagonal
     // ---- sharded solve (BASELINE config 4): this rank linearises a contiguous range of the system edges
     // (a callback with world_size 1 still runs every exchange step: that is how the RCCL callback is tested on one GPU;
     //  graphs too small for the multilevel path are simply solved redundantly by every rank)
@@ -446,6 +468,7 @@ void build_structure(uzl_pgo* h)
         D.e_begin = h->rank * base + std::min(h->rank, rem);
         D.e_end = D.e_begin + base + (h->rank < rem ? 1 : 0);
         D.diag_owner = h->rank == 0 ? 1 : 0;
+        D.sibling0 = 0;
     }
     h->structure_ready = true;
 }
@@ -498,12 +521,12 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     const PgoDev& D = h->D;
     const int max_it = h->cfg.pcg_max_iter > 0 ? h->cfg.pcg_max_iter : 6 * std::max(h->nb, 1);
     const bool timed = h->timer.on || h->no_graph || h->sharded;   // per-kernel events, rocprofv3 and the exchange callback need eager launches
-    { Timed t(h, "precond"); k_precond(D, s); }
     if (h->ml_levels > 0) {
-        { Timed t(h, "ml_invert"); k_ml_invert(D, h->d_ml.p, h->ml_inner_aggs, s); }
+        { Timed t(h, "ml_sibling"); k_ml_sibling(D, h->d_ml.p, h->ml_inner_aggs, s); }
         { Timed t(h, "pcg_init"); k_ml_init(D, h->ml_hot, h->ml_agg, h->d_p.p, h->d_p2.p, h->ml_rg[0], s); }
         { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, h->d_p.p, h->ml_rg[0], h->ml_rg[1], 0, 1, h->ml_lds, s)); }
     } else {
+        { Timed t(h, "precond"); k_precond(D, s); }
         Timed t(h, "pcg_init"); k_pcg_init(D, h->d_p.p, h->d_p2.p, s);
     }
     if (!timed) ensure_pcg_graph(h);
@@ -577,8 +600,10 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         { Timed t(h, "finalize"); k_finalize(D, gl, 0, ga, 2, s); }
         shard_allreduce_chi2(h);
         ml_setup_numeric(h);
-        fetch_scal(h);
-        current_chi = h->h_scal.p->scal[4];
+        if (it == 0 || h->sharded) {                   // later iterations carry chi2 over from the accepted trial: no round trip
+            fetch_scal(h);
+            current_chi = h->h_scal.p->scal[4];
+        }
         if (it == 0) {
             S.chi2_initial = current_chi;
             lambda = 1e-5 * h->h_scal.p->scal[6];                                 // computeLambdaInit: tau * max diag
