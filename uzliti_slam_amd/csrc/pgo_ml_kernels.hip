@@ -583,7 +583,7 @@ __global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const d
     __shared__ double sw[kRowsPerBlk * 6];
     __shared__ double ss1[kAggPerBlk * 6];
     __shared__ double sg1[kAggPerBlk * 3];
-    if (D.flags[0]) return;
+    const int done = D.flags[0];          // tested after the prefetch has been issued
     STAMP_DECL
     const int gl = (AGG == 1 || H.levels < 2) ? 1 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane / 6, r = lane % 6;
@@ -641,6 +641,7 @@ __global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const d
         }
     }
     STAMP(16);     // 16: prefetch issue
+    if (done) return;
     // ---- beta
     const double rz = block_sum_w<kWaves>(v, s8);
     const double beta = (it == 0) ? 0. : rz / rz_prev;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     __shared__ double syc[6];
     __shared__ double szj[kRowsPerBlk * 6];
     constexpr int kFan2 = (AGG == 1) ? kMlFanout : kMlFanout2;    // children of a level-2 aggregate (build_ml)
-    if (D.flags[0]) return;
+    const int done = D.flags[0];          // tested after the prefetch has been issued: its round trip hides behind the others
     STAMP_DECL
     const int tid = threadIdx.x;
     const int Lt = H.levels;
@@ -834,28 +835,37 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
         rgreg[u] = (t < 6 * ng) ? rg_old[t] : 0.;
         sgreg[u] = (!init && t < 6 * ng) ? H.Sg[t] : 0.;
     }
-    // small arrays: offsets of levels >= g, top-inverse rows, own-chain blocks
-    for (int l = gl; l < Lt; l++) {
-        const double* __restrict__ src = H.geo[l];
-        const int n3 = 3 * H.n[l];
-        for (int base = 0; base < n3; base += 4 * kCgBlk) {
-            double vv[4];
+    // small arrays (offsets of levels >= g: one contiguous blob in the arena; the own ancestor's top-inverse rows; the
+    // own-chain sibling rows): staged through registers so that EVERY load is in flight before anything waits
+    constexpr int kGeoU = 6, kTopU = 2, kChainLv = kMlMaxLevels - 2;
+    const int g_tot = (Lt > gl) ? (goff[Lt - 1] + 3 * H.n[Lt - 1] - goff[gl]) : 0;
+    const int top_n = n_top_rows * ntop;
+    const size_t top_base = (size_t)((Lt == 1) ? blockIdx.x * kAggPerBlk * 6 : 6 * anc[Lt]) * ntop;
+    double gv[kGeoU], tv[kTopU], cv[kChainLv][2];
+    {
+        const double* __restrict__ gsrc = H.geo[gl];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int t = base + u * kCgBlk + tid; vv[u] = (t < n3) ? src[t] : 0.; }
+        for (int u = 0; u < kGeoU; u++) { const int t = u * kCgBlk + tid; gv[u] = (t < g_tot) ? gsrc[t] : 0.; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int t = base + u * kCgBlk + tid; if (t < n3) dyn[goff[l] + t] = vv[u]; }
+        for (int u = 0; u < kTopU; u++) {
+            const int t = u * kCgBlk + tid;
+            tv[u] = (t < top_n && top_base + t < (size_t)ntop * ntop) ? H.top_inv[top_base + t] : 0.;
+        }
+#pragma unroll
+        for (int q = 0; q < kChainLv; q++) {       // level l = q + 2; fan-out of levels >= 3 is kMlFanout: 48 x 48 sibling blocks
+            const int l = q + 2;
+            cv[q][0] = 0.; cv[q][1] = 0.;
+            if (l < Lt) {
+                const double* __restrict__ wl = H.Winv[l] + ((size_t)anc[l + 1] * 48 + (size_t)(anc[l] % kMlFanout) * 6) * 48;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int t = u * kCgBlk + tid;
+                    if (t < kChain) cv[q][u] = (t < 288) ? wl[t] : H.geo[l][(size_t)anc[l] * 3 + (t - 288)];
+                }
+            }
         }
     }
-    for (int t = tid; t < n_top_rows * ntop; t += kCgBlk) {
-        const int rr = t / ntop, c = t % ntop;
-        const int grow = (Lt == 1) ? (blockIdx.x * kAggPerBlk * 6 + rr) : (6 * anc[Lt] + rr);
-        dyn[top_off + t] = (grow < ntop) ? H.top_inv[(size_t)grow * ntop + c] : 0.;
-    }
-    for (int l = 2; l < Lt; l++) {           // fan-out of levels >= 3 is kMlFanout: 48 x 48 sibling blocks
-        const double* __restrict__ wl = H.Winv[l] + ((size_t)anc[l + 1] * 48 + (size_t)(anc[l] % kMlFanout) * 6) * 48;
-        for (int t = tid; t < kChain; t += kCgBlk)
-            dyn[chain_off + (l - 2) * kChain + t] = (t < 288) ? wl[t] : H.geo[l][(size_t)anc[l] * 3 + (t - 288)];
-    }
+    if (done) return;
     STAMP(0);      // 1: prefetch issue
     double alpha = 0.;
     bool bad = false;
@@ -872,6 +882,20 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     }
     for (int t = kGatherU * kCgBlk + tid; t < 6 * ng; t += kCgBlk)       // graphs beyond 12k free vertices: latency exposed
         dyn[roff[gl] + t] = rg_old[t] - (init ? 0. : alpha * H.Sg[t]);
+#pragma unroll
+    for (int u = 0; u < kGeoU; u++) { const int t = u * kCgBlk + tid; if (t < g_tot) dyn[goff[gl] + t] = gv[u]; }
+    for (int t = kGeoU * kCgBlk + tid; t < g_tot; t += kCgBlk) dyn[goff[gl] + t] = H.geo[gl][t];      // very large graphs
+#pragma unroll
+    for (int u = 0; u < kTopU; u++) { const int t = u * kCgBlk + tid; if (t < top_n) dyn[top_off + t] = tv[u]; }
+    for (int t = kTopU * kCgBlk + tid; t < top_n; t += kCgBlk)
+        dyn[top_off + t] = (top_base + t < (size_t)ntop * ntop) ? H.top_inv[top_base + t] : 0.;
+#pragma unroll
+    for (int q = 0; q < kChainLv; q++) {
+        if (q + 2 < Lt) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) { const int t = u * kCgBlk + tid; if (t < kChain) dyn[chain_off + q * kChain + t] = cv[q][u]; }
+        }
+    }
     __syncthreads();
     STAMP(0);      // 3: gather-level residual estimate
     // ---- restrict up to the top level: 8 lanes per (parent, component), one child each, xor-shuffle fold

@@ -312,11 +312,15 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         dof[l].G = (l == 0) ? 0 : take(n * 36 * 8);
         dof[l].M = (l == 0) ? 0 : take(n * 36 * 8);
         dof[l].Winv = (l < L) ? take((size_t)std::max(h->ml_n[l + 1], 1) * (size_t)(36 * h->ml_fan[l + 1] * h->ml_fan[l + 1]) * 8) : 0;
-        dof[l].geo = take(n * ((l == 0) ? 12 : 3) * 8);
+        dof[l].geo = (l == 0) ? take(n * 12 * 8) : 0;          // levels >= 1: one contiguous blob (geo_blob below)
         dof[l].cen = take(n * 3 * 8);
         dof[l].r = take(n * 6 * 8);
         dof[l].y = take(n * 6 * 8);
     }
+    size_t geo_blob_doubles = 0;
+    std::vector<size_t> geo_sub((size_t)L + 1, 0);
+    for (int l = 1; l <= L; l++) { geo_sub[l] = geo_blob_doubles; geo_blob_doubles += (size_t)std::max(h->ml_n[l], 1) * 3; }
+    const size_t o_geo_blob = take(geo_blob_doubles * 8 + 64);     // ml_cg copies levels g..L-1 with one linear loop
     const size_t o_tmp = take(max_contrib * 36 * 8), o_tmpG = take(max_n * 36 * 8), o_tmpM = take(max_n * 36 * 8);
     const size_t o_top = take((size_t)(6 * kMlTopMax) * (6 * kMlTopMax) * 8);
     const int gl = (h->ml_agg == 1 || L < 2) ? 1 : 2;
@@ -352,7 +356,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         X.G = (l == 0) ? h->d_hdiag.p : reinterpret_cast<double*>(base + dof[l].G);
         X.M = (l == 0) ? nullptr : reinterpret_cast<double*>(base + dof[l].M);
         X.Winv = (l < L) ? reinterpret_cast<double*>(base + dof[l].Winv) : nullptr;
-        X.geo = reinterpret_cast<double*>(base + dof[l].geo);
+        X.geo = (l == 0) ? reinterpret_cast<double*>(base + dof[l].geo) : reinterpret_cast<double*>(base + o_geo_blob) + geo_sub[l];
         X.cen = reinterpret_cast<double*>(base + dof[l].cen);
         X.r = reinterpret_cast<double*>(base + dof[l].r);
         X.y = reinterpret_cast<double*>(base + dof[l].y);
@@ -495,7 +499,7 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
     }
 }
 
-constexpr int kGraphPairs = 8;      // one graph replay = 16 PCG iterations = 32 kernel nodes
+static const int kGraphPairs = getenv("UZL_GRAPH_PAIRS") ? std::max(1, atoi(getenv("UZL_GRAPH_PAIRS"))) : 8;      // one graph replay = 2 x pairs PCG iterations
 
 void destroy_pcg_graph(uzl_pgo* h)
 {
@@ -532,7 +536,8 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     if (!timed) ensure_pcg_graph(h);
     int launched = 0;
     // first batch sized from the previous solve, then fixed batches; the kernels no-op once `done` is set
-    int want = h->prev_pcg_iters > 0 ? std::max(16, (h->prev_pcg_iters * 19) / 20) : 2 * kGraphPairs;
+    static const int first_pct = getenv("UZL_FIRST_PCT") ? atoi(getenv("UZL_FIRST_PCT")) : 95;
+    int want = h->prev_pcg_iters > 0 ? std::max(2 * kGraphPairs, (h->prev_pcg_iters * first_pct) / 100) : 2 * kGraphPairs;
     while (true) {
         want = std::min(want, max_it - launched);
         const int reps = std::max(1, (want + 2 * kGraphPairs - 1) / (2 * kGraphPairs));
