@@ -205,7 +205,7 @@ typedef struct uzl_pgo uzl_pgo;
 /* Mirrors graph_optimization/cfg/GraphOptimizer.cfg:10-12, then the back-end additions. */
 typedef struct uzl_pgo_cfg {
     int32_t iterations;               /* 20   LM outer iterations (optimizer_.optimize(iterations), g2o_optimizer.cpp:148) */
-    int32_t use_odometry_parameters;  /* 0    (g2o_optimizer.cpp:209-227; not supported: UZL_ERR_BAD_ARG when set)       */
+    int32_t use_odometry_parameters;  /* 0    differential-drive round trip of odometry edges (g2o_optimizer.cpp:209-227)  */
     int32_t optimize_xy_only;         /* 0    project poses/measurements to (x,y,yaw) (g2o_optimizer.cpp:164-170)         */
     /* ---- back-end additions ---- */
     int32_t device;
@@ -237,6 +237,8 @@ typedef struct uzl_edge {
     double  displacement_from[12];/* displacement_from_   */
     double  displacement_to[12];  /* displacement_to_     */
     double  information[36];      /* information_         */
+    double  diff_time;            /* |diff_time_| in seconds: read for odometry edges when
+                                     use_odometry_parameters is set (g2o_optimizer.cpp:211)     */
 } uzl_edge;
 
 typedef struct uzl_pgo_stats {

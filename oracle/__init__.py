@@ -50,7 +50,7 @@ class Edge(C.Structure):
     _fields_ = [("from_", C.c_int32), ("to", C.c_int32), ("type", C.c_int32),
                 ("sensor_from", C.c_int32), ("sensor_to", C.c_int32), ("valid", C.c_int32),
                 ("transform", C.c_double * 12), ("displacement_from", C.c_double * 12),
-                ("displacement_to", C.c_double * 12), ("information", C.c_double * 36)]
+                ("displacement_to", C.c_double * 12), ("information", C.c_double * 36), ("diff_time", C.c_double)]
 
 
 class PgoStats(C.Structure):
@@ -259,7 +259,14 @@ def huber(e2, delta=1.0):
     r = np.empty(3); lib().uzlo_huber(C.c_double(e2), C.c_double(delta), _p(r, c_f64p)); return r
 
 
-def flatten_graph(nodes_pose, nodes_fixed, edges, sensors=None, optimize_xy_only=False):
+def odom_convert(x, y, theta, dt):
+    """g2o OdomConvert round trip (motion -> wheel velocities -> motion), wheel base 1."""
+    out = np.zeros(3)
+    lib().uzlo_odom_convert(C.c_double(x), C.c_double(y), C.c_double(theta), C.c_double(dt), _p(out, c_f64p))
+    return out
+
+
+def flatten_graph(nodes_pose, nodes_fixed, edges, sensors=None, optimize_xy_only=False, use_odometry_parameters=False):
     """G1. edges: dict of arrays (from, to, type, sensor_from, sensor_to, valid, transform (E,12),
     displacement_from (E,12), displacement_to (E,12), information (E,36))."""
     n = len(nodes_fixed); ne = len(edges["from"])
@@ -276,12 +283,14 @@ def flatten_graph(nodes_pose, nodes_fixed, edges, sensors=None, optimize_xy_only
         ea[k].displacement_from[:] = np.asarray(edges["displacement_from"][k]).reshape(12).tolist()
         ea[k].displacement_to[:] = np.asarray(edges["displacement_to"][k]).reshape(12).tolist()
         ea[k].information[:] = np.asarray(edges["information"][k]).reshape(36).tolist()
+        ea[k].diff_time = float(edges["diff_time"][k]) if "diff_time" in edges else 0.0
     S = _f64(sensors).reshape(-1, 12) if sensors is not None and len(sensors) else np.zeros((0, 12))
     poses = np.empty((n, 12)); fixed = np.empty(n, np.uint8); ij = np.empty((max(ne, 1), 2), np.int32)
     meas = np.empty((max(ne, 1), 12)); info = np.empty((max(ne, 1), 36)); robust = np.empty(max(ne, 1), np.uint8)
     src = np.empty(max(ne, 1), np.int32)
     m = lib().uzlo_flatten_graph(C.c_int32(n), na, C.c_int32(ne), ea, C.c_int32(S.shape[0]),
                                  _p(S, c_f64p) if S.size else None, C.c_int32(1 if optimize_xy_only else 0),
+                                 C.c_int32(1 if use_odometry_parameters else 0),
                                  _p(poses, c_f64p), _p(fixed, c_u8p), _p(ij, c_i32p), _p(meas, c_f64p),
                                  _p(info, c_f64p), _p(robust, c_u8p), _p(src, c_i32p))
     return dict(poses=poses, fixed=fixed, ij=ij[:m].copy(), meas=meas[:m].copy(), info=info[:m].copy(),

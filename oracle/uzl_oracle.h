@@ -112,6 +112,7 @@ typedef struct uzlo_node { double pose[12]; int32_t fixed; } uzlo_node;
 typedef struct uzlo_edge {
     int32_t from, to, type, sensor_from, sensor_to, valid;
     double transform[12], displacement_from[12], displacement_to[12], information[36];
+    double diff_time;             /* |SlamEdge::diff_time_| [s] (g2o_optimizer.cpp:211) */
 } uzlo_edge;
 
 typedef struct uzlo_pgo_stats {
@@ -126,8 +127,14 @@ typedef struct uzlo_pgo_stats {
  * index of the input edge each system edge came from. Returns number of system edges. */
 int32_t uzlo_flatten_graph(int32_t n_nodes, const uzlo_node* nodes, int32_t n_edges, const uzlo_edge* edges,
                            int32_t n_sensors, const double* sensors, int32_t optimize_xy_only,
+                           int32_t use_odometry_parameters,
                            double* poses, uint8_t* fixed, int32_t* ij, double* meas, double* info,
                            uint8_t* robust, int32_t* src_edge);
+
+/* g2o sclam2d OdomConvert [EXT] (g2o/types/sclam2d/odometry_measurement.cpp, called at g2o_optimizer.cpp:212-214):
+ * motion (x, y, theta, dt) -> differential-drive wheel velocities (wheel base 1) -> motion.  Identity on exact
+ * circular arcs; any other motion is projected onto the arc with the same heading change. */
+void uzlo_odom_convert(double x, double y, double theta, double dt, double out_xyt[3]);
 
 /* G2: setFixedNodes (g2o_optimizer.cpp:301-349): fixes the smallest-index vertex of every component
  * not reachable from a fixed vertex. Returns how many were fixed. */

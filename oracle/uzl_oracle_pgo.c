@@ -254,8 +254,48 @@ void uzlo_huber(double e2, double delta, double rho[3])
 /* ---------------- G1: addGraphImpl flattening ---------------- */
 static const double I12[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 
+/* g2o::OdomConvert::convertToVelocity followed by convertToMotion(vel, l = 1) [EXT]
+ * (g2o/types/sclam2d/odometry_measurement.cpp; restated from the published source):
+ *   to velocity: |theta| > 1e-7:  px2 = (0,10); px3 = (x,y); px4 = Rot(theta) px2 + px3;
+ *                                 R = y2 (x3 y4 - y3 x4) / (y2 (x3 - x4));  w = |dt| > 1e-7 ? theta/dt : 0;
+ *                                 vl = (2 R w - w)/2;  vr = w + vl
+ *                else             vl = vr = |dt| > 1e-7 ? hypot(x,y)/dt : 0
+ *   to motion:   |vr - vl| > 1e-7: R = l/2 (vl+vr)/(vr-vl); w = (vr-vl)/l; theta = w dt;
+ *                                 (x,y) = Rot(theta) (0,-R) + (0,R)
+ *                else             tv = (vr+vl)/2; theta = 0; x = tv dt; y = 0 */
+void uzlo_odom_convert(double x, double y, double theta, double dt, double out[3])
+{
+    double vl, vr;
+    if (fabs(theta) > 1e-7) {
+        const double c = cos(theta), s = sin(theta);
+        const double y2 = 10.;
+        const double x3 = x, y3 = y;
+        const double x4 = (c * 0. - s * y2) + x3, y4 = (s * 0. + c * y2) + y3;
+        const double R = (y2 * (x3 * y4 - y3 * x4)) / (y2 * (x3 - x4));
+        const double w = (fabs(dt) > 1e-7) ? theta / dt : 0.;
+        vl = (2. * R * w - w) / 2.;
+        vr = w + vl;
+    } else {
+        vl = vr = (fabs(dt) > 1e-7) ? hypot(x, y) / dt : 0.;
+    }
+    const double l = 1.;
+    if (fabs(vr - vl) > 1e-7) {
+        const double R = l * 0.5 * ((vl + vr) / (vr - vl));
+        const double w = (vr - vl) / l;
+        const double th = w * dt;
+        const double c = cos(th), s = sin(th);
+        out[0] = (c * 0. - s * (-R)) + 0.;
+        out[1] = (s * 0. + c * (-R)) + R;
+        out[2] = th;
+    } else {
+        const double tv = 0.5 * (vr + vl);
+        out[0] = tv * dt; out[1] = 0.; out[2] = 0.;
+    }
+}
+
 int32_t uzlo_flatten_graph(int32_t n_nodes, const uzlo_node* nodes, int32_t n_edges, const uzlo_edge* edges,
                            int32_t n_sensors, const double* sensors, int32_t optimize_xy_only,
+                           int32_t use_odometry_parameters,
                            double* poses, uint8_t* fixed, int32_t* ij, double* meas, double* info,
                            uint8_t* robust, int32_t* src_edge)
 {
@@ -276,7 +316,19 @@ int32_t uzlo_flatten_graph(int32_t n_nodes, const uzlo_node* nodes, int32_t n_ed
             double Zm[12], tmp[12], inv[12];
             if (is_odom) {                                                    /* addOdometryEdge :190-259 */
                 if (nodes[ed->from].fixed && !nodes[ed->to].fixed) continue;  /* :203-206 */
-                se3_mul(ed->displacement_from, ed->transform, tmp);           /* :229 */
+                double odom[12];
+                memcpy(odom, ed->transform, sizeof(odom));
+                if (use_odometry_parameters) {                                /* :209-227 */
+                    double R[9], rpy[3], m[3];
+                    se3_rot(odom, R);
+                    uzlo_to_euler(R, rpy);
+                    uzlo_odom_convert(t_(odom, 0), t_(odom, 1), rpy[2], fabs(ed->diff_time), m);
+                    t_(odom, 0) = m[0]; t_(odom, 1) = m[1];
+                    rpy[2] = m[2];
+                    uzlo_from_euler(rpy, R);
+                    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R_(odom, r, c) = R[r * 3 + c];
+                }
+                se3_mul(ed->displacement_from, odom, tmp);                    /* :229 */
                 se3_inv(ed->displacement_to, inv);
                 se3_mul(tmp, inv, Zm);
                 robust[ne] = 0;

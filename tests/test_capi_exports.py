@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(capi):
 def test_struct_layouts_match_header(capi):
     assert ctypes.sizeof(capi.EdgeResult) == capi.EDGE_RESULT_DTYPE.itemsize == 432
     assert ctypes.sizeof(capi.PairJob) == capi.PAIR_JOB_DTYPE.itemsize == 24
-    assert capi.NODE_DTYPE.itemsize == 104 and capi.EDGE_DTYPE.itemsize == 600
+    assert capi.NODE_DTYPE.itemsize == 104 and capi.EDGE_DTYPE.itemsize == 608
     assert ctypes.sizeof(capi.MatchCfg) == 56 and ctypes.sizeof(capi.PgoCfg) == 48
 
 

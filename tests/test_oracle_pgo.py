@@ -156,3 +156,20 @@ def test_two_node_closed_form(oracle):
     poses = np.stack([X0, X1]).reshape(2, 12)
     P, st = oracle.pgo_optimize(poses, [1, 0], [[0, 1]], Z.reshape(1, 12), np.eye(6).reshape(1, 36) * 50, [0], iterations=20)
     assert np.allclose(P[1].reshape(3, 4), synth.se3_mul(X0, Z), atol=1e-9) and st["chi2_final"] < 1e-18
+
+
+def test_odom_convert_known_answers(oracle):
+    """g2o OdomConvert round trip [EXT] (g2o_optimizer.cpp:212-214): identity on exact circular arcs, projection otherwise."""
+    for R, th, dt in ((2.0, 0.3, 0.5), (-1.5, 0.2, 1.0), (5.0, -0.7, 2.0), (0.4, 1.2, 0.1)):
+        x, y = R * np.sin(th), R * (1 - np.cos(th))                  # motion along a circle with its centre at (0, R)
+        out = oracle.odom_convert(x, y, th, dt)
+        assert np.allclose(out, [x, y, th], atol=1e-12), (R, th, out)
+    # straight motion (|theta| <= 1e-7): the lateral component is folded into the forward distance
+    assert np.allclose(oracle.odom_convert(0.3, 0.04, 0.0, 0.5), [np.hypot(0.3, 0.04), 0.0, 0.0], atol=1e-15)
+    # lateral slip on a turning motion: projected onto the arc with the same heading change, R = x cot(theta) + y
+    x, y, th = 0.3, 0.1, 0.2
+    R = x / np.tan(th) + y
+    assert np.allclose(oracle.odom_convert(x, y, th, 1.0), [R * np.sin(th), R * (1 - np.cos(th)), th], atol=1e-12)
+    # no elapsed time: wheel velocities are zero, so is the motion
+    assert np.array_equal(oracle.odom_convert(0.3, 0.1, 0.2, 0.0), [0.0, 0.0, 0.0])
+    assert np.array_equal(oracle.odom_convert(0.3, 0.1, 0.0, 0.0), [0.0, 0.0, 0.0])

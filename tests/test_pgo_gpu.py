@@ -215,8 +215,30 @@ def test_degenerate_inputs(capi, pgo):
         p2.optimize(1)
     assert e.value.status == capi.UZL_ERR_STATE
     p2.close()
-    with pytest.raises(capi.UzlError):
-        capi.Pgo(use_odometry_parameters=1)
+
+
+def test_use_odometry_parameters(capi, oracle):
+    """GraphOptimizerConfig::use_odometry_parameters (g2o_optimizer.cpp:209-227): every odometry measurement goes through
+    g2o's OdomConvert round trip before it is composed with the displacements."""
+    g = synth.make_pose_graph(150, 500, seed=21)
+    e = g["edges"]
+    e["diff_time"][:149] = np.random.default_rng(1).uniform(0.1, 2.0, 149)
+    e["diff_time"][7] = 0.0                                        # no elapsed time: the round trip yields zero motion
+    e["diff_time"][9] = -0.8                                       # fabs() at :211
+    fl = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], e, use_odometry_parameters=True)
+    fl0 = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], e)
+    assert np.abs(fl["meas"][:148] - fl0["meas"][:148]).max() > 1e-4          # the branch does something (lateral slip removed)
+    assert np.array_equal(fl["meas"][148:], fl0["meas"][148:])                # feature edges untouched
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, so = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=8)
+    p = capi.Pgo(use_odometry_parameters=1)
+    p.add_graph(g["nodes_pose"], g["nodes_fixed"], e)
+    st = p.optimize(8)
+    poses, _, _ = p.store()
+    p.close()
+    assert abs(st["chi2_initial"] - so["chi2_initial"]) <= 1e-9 * so["chi2_initial"]
+    dt, dr = synth.pose_errors(poses.reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+    assert dt < 1e-3 and dr < 1e-4, (dt, dr)
 
 
 def test_full_size_properties_c4(pgo):

@@ -79,6 +79,7 @@ void Mi355xOptimizer::addGraphImpl(SlamGraph& graph)
     uzl_pgo_cfg_default(&c);
     c.iterations = config_.iterations;
     c.optimize_xy_only = config_.optimize_xy_only ? 1 : 0;
+    c.use_odometry_parameters = config_.use_odometry_parameters ? 1 : 0;
     uzl_pgo_set_config(h_, &c);
     // vertices in std::map order = lexicographic id = the order g2o ids are assigned in (g2o_optimizer.cpp:64-66)
     node_ids_.clear(); edge_ids_.clear();
@@ -138,6 +139,7 @@ void Mi355xOptimizer::addGraphImpl(SlamGraph& graph)
         std::memcpy(u.displacement_from, e.displacement_from_.m.data(), sizeof(u.displacement_from));
         std::memcpy(u.displacement_to, e.displacement_to_.m.data(), sizeof(u.displacement_to));
         std::memcpy(u.information, e.information_.data(), sizeof(u.information));
+        u.diff_time = e.diff_time_;
         edge_ids_.push_back(kv.first);
         edges.push_back(u);
     }

@@ -62,6 +62,7 @@ struct SlamEdge {
     unsigned char type_ = 0;
     std::string sensor_from_, sensor_to_;
     double age_ = 0, error_ = 0, matching_score_ = 0;
+    double diff_time_ = 0;                   // ros::Duration in the reference (slam_edge.h): seconds here
     bool valid_ = false;
 };
 

@@ -89,7 +89,7 @@ NODE_DTYPE = np.dtype([("pose", "<f8", (12,)), ("fixed", "<i4")], align=True)
 EDGE_DTYPE = np.dtype([("from", "<i4"), ("to", "<i4"), ("type", "<i4"), ("sensor_from", "<i4"),
                        ("sensor_to", "<i4"), ("valid", "<i4"), ("transform", "<f8", (12,)),
                        ("displacement_from", "<f8", (12,)), ("displacement_to", "<f8", (12,)),
-                       ("information", "<f8", (36,))], align=True)
+                       ("information", "<f8", (36,)), ("diff_time", "<f8")], align=True)
 
 class FilterCfg(C.Structure):
     _fields_ = [("max_dt", C.c_double), ("min_size", C.c_double), ("max_cluster_size", C.c_int32),
@@ -371,6 +371,8 @@ class Pgo:
             ea[k][:ne] = edges[k]
         for k, w in (("transform", 12), ("displacement_from", 12), ("displacement_to", 12), ("information", 36)):
             ea[k][:ne] = np.asarray(edges[k], np.float64).reshape(ne, w)
+        if "diff_time" in edges:
+            ea["diff_time"][:ne] = edges["diff_time"]
         S = np.ascontiguousarray(sensors, np.float64).reshape(-1, 12) if sensors is not None and len(sensors) else None
         self._check(lib().uzl_pgo_add_graph(self._h, C.c_int32(n), _p(na, C.c_void_p), C.c_int32(ne), _p(ea, C.c_void_p),
                                             C.c_int32(0 if S is None else S.shape[0]), _p(S, c_f64p)))

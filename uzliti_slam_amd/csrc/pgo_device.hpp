@@ -127,6 +127,46 @@ __device__ __forceinline__ Pose project_xy(const Pose& P)
     return Pose{V3{P.t.x, P.t.y, 0.}, Q4{cy, 0., 0., sy}};
 }
 
+// use_odometry_parameters (g2o_optimizer.cpp:209-227): the odometry measurement's (x, y, yaw) goes through g2o's
+// sclam2d OdomConvert [EXT] - motion -> differential-drive wheel velocities (wheel base 1) -> motion - with roll,
+// pitch and z kept (toEuler / fromEuler of isometry3d_mappings.cpp:47-75).  Identity on exact circular arcs.
+__device__ __forceinline__ Pose odom_round_trip(const Pose& P, double dt)
+{
+    const double q0 = P.q.w, q1 = P.q.x, q2 = P.q.y, q3 = P.q.z;
+    const double roll = atan2(2 * (q0 * q1 + q2 * q3), 1 - 2 * (q1 * q1 + q2 * q2));
+    const double pitch = asin(2 * (q0 * q2 - q3 * q1));
+    const double theta = atan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 * q2 + q3 * q3));
+    const double x = P.t.x, y = P.t.y;
+    double vl, vr;
+    if (fabs(theta) > 1e-7) {
+        const double c = cos(theta), s = sin(theta);
+        const double y2 = 10.;
+        const double x4 = (c * 0. - s * y2) + x, y4 = (s * 0. + c * y2) + y;
+        const double R = (y2 * (x * y4 - y * x4)) / (y2 * (x - x4));
+        const double w = (fabs(dt) > 1e-7) ? theta / dt : 0.;
+        vl = (2. * R * w - w) / 2.;
+        vr = w + vl;
+    } else {
+        vl = vr = (fabs(dt) > 1e-7) ? hypot(x, y) / dt : 0.;
+    }
+    double nx, ny, nth;
+    if (fabs(vr - vl) > 1e-7) {
+        const double R = 0.5 * ((vl + vr) / (vr - vl));
+        const double w = vr - vl;
+        nth = w * dt;
+        const double c = cos(nth), s = sin(nth);
+        nx = (c * 0. - s * (-R)) + 0.;
+        ny = (s * 0. + c * (-R)) + R;
+    } else {
+        nx = 0.5 * (vr + vl) * dt; ny = 0.; nth = 0.;
+    }
+    const double sy = sin(nth * 0.5), cy = cos(nth * 0.5);
+    const double sp = sin(pitch * 0.5), cp = cos(pitch * 0.5);
+    const double sr = sin(roll * 0.5), cr = cos(roll * 0.5);
+    return Pose{V3{nx, ny, P.t.z}, Q4{cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy,
+                                      cr * cp * sy - sr * sp * cy}};
+}
+
 // ------------------------------------------------------------------------------------------------
 // reductions (deterministic: fixed tree shapes, no atomics)
 // ------------------------------------------------------------------------------------------------

@@ -49,7 +49,7 @@ __device__ __forceinline__ void store_edge(const Pose& Z, const double* __restri
 __global__ __launch_bounds__(kBlk) void prepare_edges_kernel(const uzl_edge* __restrict__ edges,
                                                              const int32_t* __restrict__ src, int e,
                                                              const double* __restrict__ sensors, int n_sensors,
-                                                             int xy_only, double* __restrict__ zinv,
+                                                             int xy_only, int odom_params, double* __restrict__ zinv,
                                                              double* __restrict__ info)
 {
     const int k = blockIdx.x * kBlk + threadIdx.x;
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(kBlk) void prepare_edges_kernel(const uzl_edge* __r
     const Pose Df = pose_from_T(ed->displacement_from);
     const Pose Dt = pose_from_T(ed->displacement_to);
     if (ed->type == UZL_EDGE_TYPE_2D_WHEEL_ODOMETRY) {
+        if (odom_params) Z = odom_round_trip(Z, fabs(ed->diff_time));   // :209-227
         Z = pose_mul(pose_mul(Df, Z), pose_inv(Dt));               // addOdometryEdge :229
     } else {                                                       // addFeatureEdge :281
         Pose M = Df;
@@ -618,10 +619,10 @@ void k_prepare_flat_nodes(const double* poses12, int n, double* pose, hipStream_
 {
     if (n > 0) hipLaunchKernelGGL(prepare_flat_nodes_kernel, dim3((n + kBlk - 1) / kBlk), dim3(kBlk), 0, s, poses12, n, pose);
 }
-void k_prepare_edges(const uzl_edge* edges, const int32_t* src, int e, const double* sensors, int ns, int xy,
+void k_prepare_edges(const uzl_edge* edges, const int32_t* src, int e, const double* sensors, int ns, int xy, int odom_params,
                      double* zinv, double* info, hipStream_t s)
 {
-    if (e > 0) hipLaunchKernelGGL(prepare_edges_kernel, dim3((e + kBlk - 1) / kBlk), dim3(kBlk), 0, s, edges, src, e, sensors, ns, xy, zinv, info);
+    if (e > 0) hipLaunchKernelGGL(prepare_edges_kernel, dim3((e + kBlk - 1) / kBlk), dim3(kBlk), 0, s, edges, src, e, sensors, ns, xy, odom_params, zinv, info);
 }
 void k_prepare_flat_edges(const double* meas12, const double* info36, int e, double* zinv, double* info, hipStream_t s)
 {

@@ -19,7 +19,7 @@
 namespace uzl {
 void k_prepare_nodes(const uzl_node* nodes, int n, int xy, double* pose, hipStream_t s);
 void k_prepare_flat_nodes(const double* poses12, int n, double* pose, hipStream_t s);
-void k_prepare_edges(const uzl_edge* edges, const int32_t* src, int e, const double* sensors, int ns, int xy,
+void k_prepare_edges(const uzl_edge* edges, const int32_t* src, int e, const double* sensors, int ns, int xy, int odom_params,
                      double* zinv, double* info, hipStream_t s);
 void k_prepare_flat_edges(const double* meas12, const double* info36, int e, double* zinv, double* info, hipStream_t s);
 int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s);
@@ -693,7 +693,6 @@ int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
     *out = nullptr;
     uzl_pgo_cfg c;
     if (cfg) c = *cfg; else uzl_pgo_cfg_default(&c);
-    if (c.use_odometry_parameters) return UZL_ERR_BAD_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return UZL_ERR_NO_DEVICE;
     if (c.device < 0 || c.device >= ndev) return UZL_ERR_NO_DEVICE;
@@ -726,7 +725,6 @@ int uzl_pgo_set_config(uzl_pgo* h, const uzl_pgo_cfg* cfg)
     if (!h || !cfg) return UZL_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
     if (cfg->device != h->cfg.device) return fail(h, UZL_ERR_BAD_ARG, "device cannot change after create");
-    if (cfg->use_odometry_parameters) return fail(h, UZL_ERR_BAD_ARG, "use_odometry_parameters is not supported");
     if (cfg->iterations < 1 || cfg->pcg_tol <= 0. || cfg->huber_delta <= 0.) return fail(h, UZL_ERR_BAD_ARG, "bad config value");
     if (cfg->pcg_tol != h->cfg.pcg_tol) destroy_pcg_graph(h);      // the tolerance is a captured kernel argument
     if (cfg->preconditioner != h->cfg.preconditioner) h->structure_ready = false;
@@ -780,7 +778,7 @@ int uzl_pgo_add_graph(uzl_pgo* h, int32_t n_nodes, const uzl_node* nodes, int32_
     if (n_sensors) UZL_HIP(hipMemcpyAsync(h->d_stage.p, sensors, sizeof(double) * 12 * (size_t)n_sensors, hipMemcpyHostToDevice, s));
     if (h->e) UZL_HIP(hipMemcpyAsync(h->d_src.p, h->src.data(), sizeof(int32_t) * (size_t)h->e, hipMemcpyHostToDevice, s));
     k_prepare_nodes(h->d_nodes.p, n_nodes, h->cfg.optimize_xy_only, h->cur, s);
-    k_prepare_edges(h->d_edges.p, h->d_src.p, h->e, h->d_stage.p, n_sensors, h->cfg.optimize_xy_only,
+    k_prepare_edges(h->d_edges.p, h->d_src.p, h->e, h->d_stage.p, n_sensors, h->cfg.optimize_xy_only, h->cfg.use_odometry_parameters,
                     h->d_zinv.p, h->d_info.p, s);
     UZL_HIP(hipGetLastError());
     if (n_nodes) UZL_HIP(hipMemcpyAsync(h->pose_init.p, h->cur, sizeof(double) * 8 * (size_t)n_nodes, hipMemcpyDeviceToDevice, s));

@@ -161,6 +161,7 @@ def make_pose_graph(n_nodes, n_edges, seed=12345, outlier_frac=0.05):
         transform=np.concatenate([odo.reshape(-1, 12), lz.reshape(-1, 12)]),
         displacement_from=I12.copy(), displacement_to=I12.copy(),
         information=np.concatenate([np.tile(odom_info.reshape(1, 36), (N - 1, 1)), linfo.reshape(-1, 36)]),
+        diff_time=np.concatenate([np.full(N - 1, 0.5), np.zeros(n_loop)]),      # SlamEdge::diff_time_ [s] of the odometry edges
     )
     fixed = np.zeros(N, np.uint8); fixed[0] = 1
     return dict(nodes_pose=init.reshape(N, 12), nodes_fixed=fixed, gt_pose=gt.reshape(N, 12), edges=edges,
