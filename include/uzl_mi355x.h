@@ -397,6 +397,56 @@ int  uzl_filter_cluster_edges(uzl_filter* h, int32_t index, int32_t cap, uint64_
 int  uzl_filter_cluster_last_eval(uzl_filter* h, int32_t index, int32_t cap, double* P, double* Q, double* T,
                                   int32_t* ransac_consensus);
 
+/* ======================================================================================
+ *  Edge acceptance gate  (GraphSlamNode::newEdgeCallback)
+ *
+ *  The step right after the estimator (graph_slam/src/graph_slam_node.cpp:779-829): an
+ *  estimated edge enters the graph only if no edge of its type joins the two nodes yet,
+ *  its score reaches min_matching_score, its transform stays within max_edge_distance_T/R
+ *  and checkEdgeHeuristic (:1064-1085) finds it plausible: the length of the path that
+ *  SlamGraph::astar (slam_graph.cpp:843-890, a greedy best-first search over the valid
+ *  edges) finds between the nodes bounds how far apart their current poses may be.
+ *  One batch of candidates = one kernel launch, one search per lane; the sequential
+ *  semantics of the callback (an accepted edge is in the graph for the next candidate)
+ *  are replayed on the host over the search results.  Node / edge ids are indices.
+ * ====================================================================================== */
+
+typedef struct uzl_gate uzl_gate;
+
+typedef struct uzl_gate_cfg {
+    double  min_matching_score;   /* 20    graph_slam/cfg/GraphSlam.cfg:18            */
+    double  max_edge_distance_T;  /* 1.0   m,   GraphSlam.cfg:19                      */
+    double  max_edge_distance_R;  /* 20.0  deg, GraphSlam.cfg:20                      */
+    double  scope_size_factor;    /* 0.1   GraphSlam.cfg:34                           */
+    double  min_accept_valid;     /* DBL_MAX  "min_accept_valid" (graph_slam_node.cpp:139) */
+    int32_t device;
+    int32_t _pad;
+} uzl_gate_cfg;
+
+typedef struct uzl_gate_edge {
+    int32_t from, to;             /* node indices (id_from_, id_to_)                  */
+    int32_t type;                 /* UZL_EDGE_TYPE_*                                  */
+    int32_t valid;                /* SlamEdge::valid_ (graph edges; ignored for candidates) */
+    double  matching_score;       /* candidates only                                  */
+    double  transform[12];        /* candidates only: transform_                      */
+} uzl_gate_edge;
+
+void uzl_gate_cfg_default(uzl_gate_cfg* cfg);
+int  uzl_gate_create(const uzl_gate_cfg* cfg, uzl_gate** out);
+void uzl_gate_destroy(uzl_gate* h);
+const char* uzl_gate_last_error(uzl_gate* h);
+/* The graph the callback sees: node poses (n x 12), merged flags (isMerged, may be NULL),
+ * existing edges (from, to, type, valid). */
+int  uzl_gate_set_graph(uzl_gate* h, int32_t n_nodes, const double* poses, const uint8_t* merged,
+                        int32_t n_edges, const uzl_gate_edge* edges);
+/* newEdgeCallback for every candidate in order.  accept[k] = the edge was added to the graph,
+ * valid[k] = its valid_ flag (score >= min_accept_valid), astar_dist[k] = path length found
+ * (-1: the search was not reached, DBL_MAX: target not reachable).  Outputs may be NULL
+ * except accept.  Accepted edges stay in the handle's graph. */
+int  uzl_gate_check(uzl_gate* h, int32_t n_candidates, const uzl_gate_edge* candidates,
+                    uint8_t* accept, uint8_t* valid, double* astar_dist);
+int  uzl_gate_edge_count(uzl_gate* h);
+
 #ifdef __cplusplus
 }
 #endif

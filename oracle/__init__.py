@@ -21,7 +21,7 @@ c_u8p = C.POINTER(C.c_uint8)
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("uzl_oracle_match.c", "uzl_oracle_pgo.c", "uzl_oracle_filter.c", "uzl_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("uzl_oracle_match.c", "uzl_oracle_pgo.c", "uzl_oracle_filter.c", "uzl_oracle_gate.c", "uzl_oracle.h")]
     if not force and os.path.exists(_LIB_PATH) and all(
             os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH
@@ -447,3 +447,62 @@ class Filter:
                 d.update(P=P[:m].copy(), Q=Q[:m].copy(), T=T, ransac_consensus=rc.value)
             out.append(d)
         return out
+
+
+# ------------------------------------------------------------------------------- edge acceptance gate (uzl_oracle_gate.c)
+class GateCfg(C.Structure):
+    _fields_ = [("min_matching_score", C.c_double), ("max_edge_distance_T", C.c_double), ("max_edge_distance_R", C.c_double),
+                ("scope_size_factor", C.c_double), ("min_accept_valid", C.c_double), ("device", C.c_int32), ("pad", C.c_int32)]
+
+
+GATE_EDGE_DTYPE = np.dtype([("from", "<i4"), ("to", "<i4"), ("type", "<i4"), ("valid", "<i4"), ("matching_score", "<f8"),
+                            ("transform", "<f8", (12,))], align=True)
+
+
+class Gate:
+    """CPU checker twin of uzliti_slam_amd.capi.Gate."""
+
+    def __init__(self, **cfg):
+        L = lib()
+        L.uzlo_gate_create.restype = C.c_void_p
+        L.uzlo_gate_destroy.argtypes = [C.c_void_p]
+        L.uzlo_gate_astar.restype = C.c_double
+        L.uzlo_gate_astar.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.uzlo_gate_last_expansions.restype = C.c_int64
+        L.uzlo_gate_last_expansions.argtypes = [C.c_void_p]
+        c = GateCfg()
+        L.uzlo_gate_cfg_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = C.c_void_p(L.uzlo_gate_create(C.byref(c)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uzlo_gate_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_graph(self, poses, edges, merged=None):
+        P = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+        E = np.ascontiguousarray(edges, GATE_EDGE_DTYPE)
+        m = None if merged is None else np.ascontiguousarray(merged, np.uint8)
+        lib().uzlo_gate_set_graph(self._h, C.c_int32(len(P)), _p(P, c_f64p), None if m is None else _p(m, c_u8p), C.c_int32(len(E)),
+                                  E.ctypes.data_as(C.c_void_p) if len(E) else None)
+
+    def astar(self, source, target):
+        return lib().uzlo_gate_astar(self._h, int(source), int(target))
+
+    def last_expansions(self):
+        return lib().uzlo_gate_last_expansions(self._h)
+
+    def check(self, cand):
+        Cn = np.ascontiguousarray(cand, GATE_EDGE_DTYPE)
+        n = len(Cn)
+        acc = np.zeros(max(n, 1), np.uint8); val = np.zeros(max(n, 1), np.uint8); dist = np.zeros(max(n, 1))
+        lib().uzlo_gate_check(self._h, C.c_int32(n), Cn.ctypes.data_as(C.c_void_p) if n else None, _p(acc, c_u8p), _p(val, c_u8p), _p(dist, c_f64p))
+        return acc[:n], val[:n], dist[:n]
+
+    def edge_count(self):
+        return lib().uzlo_gate_edge_count(self._h)

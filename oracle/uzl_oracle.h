@@ -190,6 +190,23 @@ void uzlo_filter_cluster_info(const uzlo_filter* f, int32_t idx, uzlo_cluster_in
 void uzlo_filter_cluster_edges(const uzlo_filter* f, int32_t idx, uint64_t* keys, uint8_t* valid);
 int32_t uzlo_filter_cluster_last_eval(const uzlo_filter* f, int32_t idx, double* P, double* Q, double* T, int32_t* ransac_consensus);
 
+/* ---------------- edge acceptance gate (uzl_oracle_gate.c): newEdgeCallback / checkEdgeHeuristic / astar ----------------
+ * graph_slam_node.cpp:779-829,1064-1085; slam_graph.cpp:838-890.  Same POD layouts as include/uzl_mi355x.h. */
+typedef struct uzlo_gate uzlo_gate;
+typedef struct uzlo_gate_cfg {
+    double min_matching_score, max_edge_distance_T, max_edge_distance_R, scope_size_factor, min_accept_valid;
+    int32_t device, pad;
+} uzlo_gate_cfg;
+typedef struct uzlo_gate_edge { int32_t from, to, type, valid; double matching_score; double transform[12]; } uzlo_gate_edge;
+void uzlo_gate_cfg_default(uzlo_gate_cfg* c);
+uzlo_gate* uzlo_gate_create(const uzlo_gate_cfg* cfg);
+void uzlo_gate_destroy(uzlo_gate* g);
+void uzlo_gate_set_graph(uzlo_gate* g, int32_t n, const double* poses, const uint8_t* merged, int32_t ne, const uzlo_gate_edge* edges);
+double uzlo_gate_astar(uzlo_gate* g, int32_t source, int32_t target);
+void uzlo_gate_check(uzlo_gate* g, int32_t nc, const uzlo_gate_edge* cand, uint8_t* accept, uint8_t* valid, double* astar_dist);
+int32_t uzlo_gate_edge_count(const uzlo_gate* g);
+int64_t uzlo_gate_last_expansions(const uzlo_gate* g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,6 +139,27 @@ def pack_filter_edges(edges, struct=None):
     return arr, keep
 
 
+class GateCfg(C.Structure):
+    _fields_ = [("min_matching_score", C.c_double), ("max_edge_distance_T", C.c_double), ("max_edge_distance_R", C.c_double),
+                ("scope_size_factor", C.c_double), ("min_accept_valid", C.c_double), ("device", C.c_int32), ("_pad", C.c_int32)]
+
+
+GATE_EDGE_DTYPE = np.dtype([("from", "<i4"), ("to", "<i4"), ("type", "<i4"), ("valid", "<i4"), ("matching_score", "<f8"),
+                            ("transform", "<f8", (12,))], align=True)
+
+
+def gate_edges(frm, to, typ, valid=None, score=None, transform=None):
+    n = len(frm)
+    a = np.zeros(max(n, 1), GATE_EDGE_DTYPE)
+    a["from"][:n] = frm; a["to"][:n] = to; a["type"][:n] = typ
+    if valid is not None:
+        a["valid"][:n] = valid
+    if score is not None:
+        a["matching_score"][:n] = score
+    a["transform"][:n] = np.eye(3, 4).reshape(12) if transform is None else np.asarray(transform, np.float64).reshape(n, 12)
+    return a[:n] if n else a[:0]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 
 _lib = None
@@ -172,6 +193,13 @@ def lib():
             L.uzl_pgo_destroy.restype = None
             L.uzl_pgo_destroy.argtypes = [C.c_void_p]
             L.uzl_pgo_cfg_default.restype = None
+        if hasattr(L, "uzl_gate_create"):
+            L.uzl_gate_last_error.restype = C.c_char_p
+            L.uzl_gate_last_error.argtypes = [C.c_void_p]
+            L.uzl_gate_destroy.restype = None
+            L.uzl_gate_destroy.argtypes = [C.c_void_p]
+            L.uzl_gate_cfg_default.restype = None
+            L.uzl_gate_edge_count.argtypes = [C.c_void_p]
         if hasattr(L, "uzl_filter_create"):
             L.uzl_filter_last_error.restype = C.c_char_p
             L.uzl_filter_last_error.argtypes = [C.c_void_p]
@@ -510,3 +538,51 @@ class Filter:
                 d.update(P=P[:m].copy(), Q=Q[:m].copy(), T=T, ransac_consensus=rc.value)
             out.append(d)
         return out
+
+
+# --------------------------------------------------------------------------------------- edge acceptance gate
+class Gate:
+    """uzl_gate_* (GraphSlamNode::newEdgeCallback / checkEdgeHeuristic / SlamGraph::astar)."""
+
+    def __init__(self, **cfg):
+        L = lib()
+        c = GateCfg()
+        L.uzl_gate_cfg_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = C.c_void_p()
+        rc = L.uzl_gate_create(C.byref(c), C.byref(self._h))
+        if rc != UZL_OK:
+            raise UzlError(rc, L.uzl_status_string(rc).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uzl_gate_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise UzlError(rc, lib().uzl_gate_last_error(self._h).decode())
+        return rc
+
+    def set_graph(self, poses, edges, merged=None):
+        """poses (n,12); edges: GATE_EDGE_DTYPE array (from, to, type, valid); merged (n) u8 or None."""
+        P = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+        E = np.ascontiguousarray(edges, GATE_EDGE_DTYPE)
+        m = None if merged is None else np.ascontiguousarray(merged, np.uint8)
+        self._check(lib().uzl_gate_set_graph(self._h, C.c_int32(len(P)), _p(P, c_f64p), _p(m, c_u8p), C.c_int32(len(E)),
+                                             _p(E, C.c_void_p) if len(E) else None))
+
+    def check(self, cand):
+        """-> (accept u8, valid u8, astar_dist f64) per candidate, in order."""
+        Cn = np.ascontiguousarray(cand, GATE_EDGE_DTYPE)
+        n = len(Cn)
+        acc = np.zeros(max(n, 1), np.uint8); val = np.zeros(max(n, 1), np.uint8); dist = np.zeros(max(n, 1))
+        self._check(lib().uzl_gate_check(self._h, C.c_int32(n), _p(Cn, C.c_void_p) if n else None, _p(acc, c_u8p), _p(val, c_u8p), _p(dist, c_f64p)))
+        return acc[:n], val[:n], dist[:n]
+
+    def edge_count(self):
+        return self._check(lib().uzl_gate_edge_count(self._h))

@@ -1,0 +1,244 @@
+// uzl_gate.hip — host side of the edge acceptance gate + its C ABI (uzl_gate_*).
+//
+// Mirrors GraphSlamNode::newEdgeCallback (graph_slam/src/graph_slam_node.cpp:779-829).  Index bookkeeping (isMerged,
+// existsEdge(from, to, type), which edges are in the graph) is host logic; thresholds, the graph search and the
+// plausibility test run on the GPU, one lane per candidate, all candidates of a call in one launch.  The callback's
+// sequential semantics are replayed over the results in candidate order: a candidate that duplicates an edge accepted
+// earlier in the same call is dropped, and when an accepted edge is valid (score >= min_accept_valid: it changes what
+// astar can reach) the remaining candidates are searched again on the updated adjacency.
+#include "uzl_common.hpp"
+#include "gate_types.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <new>
+#include <set>
+#include <tuple>
+
+namespace uzl {
+void launch_gate(const GateArgs& a, hipStream_t s);
+}
+using namespace uzl;
+
+struct uzl_gate {
+    std::mutex mu;
+    std::string last_error;
+    uzl_gate_cfg cfg;
+    hipStream_t stream = nullptr;
+    int32_t n = 0;
+    std::vector<double> poses;
+    std::vector<uint8_t> merged;
+    struct E { int32_t from, to, type, valid; };
+    std::vector<E> edges;
+    std::set<std::tuple<int32_t, int32_t, int32_t>> pair_type;      // (min, max, type) of every edge: existsEdge(from, to, type)
+    bool adj_dirty = true, poses_dirty = true;
+    std::vector<int32_t> adj_ptr, adj_nbr;
+    DevBuf<double> d_poses, d_gs, d_dist;
+    DevBuf<int32_t> d_adj_ptr, d_adj_nbr, d_over;
+    DevBuf<uzl_gate_edge> d_cand;
+    DevBuf<uint8_t> d_run, d_st, d_pre, d_heur;
+    DevBuf<GateHeapEnt> d_heap;
+    PinBuf<uint8_t> h_pre, h_heur;
+    PinBuf<double> h_dist;
+    PinBuf<int32_t> h_over;
+};
+
+namespace {
+
+int fail(uzl_gate* h, int code, const char* msg)
+{
+    h->last_error = msg;
+    return code;
+}
+
+void add_edge(uzl_gate* h, int32_t from, int32_t to, int32_t type, int32_t valid)
+{
+    h->edges.push_back({from, to, type, valid});
+    h->pair_type.insert(std::make_tuple(std::min(from, to), std::max(from, to), type));
+    if (valid && type != UZL_EDGE_TYPE_2D_LASER) h->adj_dirty = true;
+}
+
+// getNeighbors(v, only_valid = true) for every v (slam_graph.cpp:558-578): valid, non-laser edges, both directions
+void build_adjacency(uzl_gate* h)
+{
+    const int n = h->n;
+    h->adj_ptr.assign((size_t)n + 1, 0);
+    for (const auto& e : h->edges) {
+        if (!e.valid || e.type == UZL_EDGE_TYPE_2D_LASER) continue;
+        h->adj_ptr[e.from + 1]++;
+        if (e.to != e.from) h->adj_ptr[e.to + 1]++;
+    }
+    for (int i = 0; i < n; i++) h->adj_ptr[i + 1] += h->adj_ptr[i];
+    h->adj_nbr.assign((size_t)std::max(h->adj_ptr[n], 1), 0);
+    std::vector<int32_t> fill(h->adj_ptr.begin(), h->adj_ptr.end() - 1);
+    for (const auto& e : h->edges) {
+        if (!e.valid || e.type == UZL_EDGE_TYPE_2D_LASER) continue;
+        h->adj_nbr[fill[e.from]++] = e.to;
+        if (e.to != e.from) h->adj_nbr[fill[e.to]++] = e.from;
+    }
+    h->adj_dirty = false;
+}
+
+}  // namespace
+
+#define UZL_GUARD_BEGIN(h)                       \
+    if (!(h)) return UZL_ERR_BAD_ARG;            \
+    std::lock_guard<std::mutex> lock_((h)->mu);  \
+    try {
+#define UZL_GUARD_END(h)                                                             \
+    } catch (const ::uzl::HipError& e) { return ::uzl::report((h)->last_error, e); } \
+    catch (const std::bad_alloc&) { (h)->last_error = "host out of memory"; return UZL_ERR_OOM; } \
+    catch (...) { (h)->last_error = "unexpected exception"; return UZL_ERR_HIP; }
+
+extern "C" {
+
+void uzl_gate_cfg_default(uzl_gate_cfg* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->min_matching_score = 20.0; c->max_edge_distance_T = 1.0; c->max_edge_distance_R = 20.0;
+    c->scope_size_factor = 0.1; c->min_accept_valid = DBL_MAX; c->device = 0;
+}
+
+int uzl_gate_create(const uzl_gate_cfg* cfg, uzl_gate** out)
+{
+    if (!out) return UZL_ERR_BAD_ARG;
+    *out = nullptr;
+    uzl_gate_cfg c;
+    if (cfg) c = *cfg; else uzl_gate_cfg_default(&c);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return UZL_ERR_NO_DEVICE;     // no CPU fallback
+    if (c.device < 0 || c.device >= count) return UZL_ERR_NO_DEVICE;
+    uzl_gate* h = new (std::nothrow) uzl_gate();
+    if (!h) return UZL_ERR_OOM;
+    h->cfg = c;
+    if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return UZL_ERR_HIP;
+    }
+    *out = h;
+    return UZL_OK;
+}
+
+void uzl_gate_destroy(uzl_gate* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    delete h;
+}
+
+const char* uzl_gate_last_error(uzl_gate* h) { return h ? h->last_error.c_str() : "null handle"; }
+
+int uzl_gate_set_graph(uzl_gate* h, int32_t n_nodes, const double* poses, const uint8_t* merged, int32_t n_edges,
+                       const uzl_gate_edge* edges)
+{
+    UZL_GUARD_BEGIN(h)
+    if (n_nodes < 0 || n_edges < 0 || (n_nodes > 0 && !poses) || (n_edges > 0 && !edges)) return fail(h, UZL_ERR_BAD_ARG, "null arrays");
+    h->n = n_nodes;
+    h->poses.assign(poses, poses + 12 * (size_t)n_nodes);
+    h->merged.assign((size_t)n_nodes, 0);
+    if (merged) h->merged.assign(merged, merged + n_nodes);
+    h->edges.clear(); h->pair_type.clear();
+    for (int32_t k = 0; k < n_edges; k++) {
+        const uzl_gate_edge& e = edges[k];
+        if (e.from < 0 || e.to < 0 || e.from >= n_nodes || e.to >= n_nodes) continue;
+        add_edge(h, e.from, e.to, e.type, e.valid ? 1 : 0);
+    }
+    h->adj_dirty = true; h->poses_dirty = true;
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
+int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* accept, uint8_t* valid, double* astar_dist)
+{
+    UZL_GUARD_BEGIN(h)
+    if (nc < 0 || (nc > 0 && (!cand || !accept))) return fail(h, UZL_ERR_BAD_ARG, "null arrays");
+    for (int32_t k = 0; k < nc; k++) { accept[k] = 0; if (valid) valid[k] = 0; if (astar_dist) astar_dist[k] = -1.; }
+    if (nc == 0) return UZL_OK;
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t s = h->stream;
+    const int n = h->n;
+    if (h->poses_dirty) {
+        h->d_poses.reserve(std::max<size_t>(h->poses.size(), 12));
+        if (n) UZL_HIP(hipMemcpyAsync(h->d_poses.p, h->poses.data(), h->poses.size() * 8, hipMemcpyHostToDevice, s));
+        UZL_HIP(hipStreamSynchronize(s));
+        h->poses_dirty = false;
+    }
+    h->d_cand.reserve((size_t)nc); h->d_run.reserve((size_t)nc);
+    h->d_pre.reserve((size_t)nc); h->d_heur.reserve((size_t)nc); h->d_dist.reserve((size_t)nc); h->d_over.reserve(1);
+    h->h_pre.reserve((size_t)nc); h->h_heur.reserve((size_t)nc); h->h_dist.reserve((size_t)nc); h->h_over.reserve(1);
+    UZL_HIP(hipMemcpyAsync(h->d_cand.p, cand, sizeof(uzl_gate_edge) * (size_t)nc, hipMemcpyHostToDevice, s));
+    std::vector<uint8_t> run((size_t)nc);
+    int32_t first = 0;                                        // candidates before `first` are decided
+    constexpr int kChunk = 256;                               // searches per launch (scratch = chunk x (9 n + 16 heap_cap) bytes)
+    while (first < nc) {
+        if (h->adj_dirty) {
+            build_adjacency(h);
+            h->d_adj_ptr.reserve(h->adj_ptr.size()); h->d_adj_nbr.reserve(h->adj_nbr.size());
+            UZL_HIP(hipMemcpyAsync(h->d_adj_ptr.p, h->adj_ptr.data(), h->adj_ptr.size() * 4, hipMemcpyHostToDevice, s));
+            UZL_HIP(hipMemcpyAsync(h->d_adj_nbr.p, h->adj_nbr.data(), h->adj_nbr.size() * 4, hipMemcpyHostToDevice, s));
+            UZL_HIP(hipStreamSynchronize(s));
+        }
+        const int32_t last = std::min(nc, first + kChunk);
+        const int32_t m = last - first;
+        // index checks against the graph as it is now (:784-791); duplicates inside the chunk are caught in the replay
+        for (int32_t k = first; k < last; k++) {
+            const uzl_gate_edge& c = cand[k];
+            bool ok = c.from >= 0 && c.to >= 0 && c.from < n && c.to < n;
+            if (ok) ok = !h->merged[c.from] && !h->merged[c.to];
+            if (ok) ok = h->pair_type.count(std::make_tuple(std::min(c.from, c.to), std::max(c.from, c.to), c.type)) == 0;
+            run[k] = ok ? 1 : 0;
+        }
+        const int heap_cap = (int)std::min<size_t>((size_t)h->adj_nbr.size() + (size_t)n + 1024, (size_t)1 << 28);
+        h->d_gs.reserve((size_t)m * std::max(n, 1)); h->d_st.reserve((size_t)m * std::max(n, 1));
+        h->d_heap.reserve((size_t)m * heap_cap);
+        UZL_HIP(hipMemsetAsync(h->d_st.p, 0, (size_t)m * std::max(n, 1), s));
+        UZL_HIP(hipMemsetAsync(h->d_over.p, 0, 4, s));
+        UZL_HIP(hipMemcpyAsync(h->d_run.p + first, run.data() + first, (size_t)m, hipMemcpyHostToDevice, s));
+        GateArgs a;
+        memset(&a, 0, sizeof(a));
+        a.n = n; a.n_query = m; a.poses = h->d_poses.p; a.adj_ptr = h->d_adj_ptr.p; a.adj_nbr = h->d_adj_nbr.p;
+        a.cand = h->d_cand.p + first; a.run = h->d_run.p + first;
+        a.gs = h->d_gs.p; a.st = h->d_st.p; a.heap = h->d_heap.p; a.heap_cap = heap_cap;
+        a.min_score = h->cfg.min_matching_score; a.max_T = h->cfg.max_edge_distance_T; a.max_R = h->cfg.max_edge_distance_R;
+        a.ssf = h->cfg.scope_size_factor;
+        a.pre_ok = h->d_pre.p + first; a.heur_ok = h->d_heur.p + first; a.dist = h->d_dist.p + first; a.overflow = h->d_over.p;
+        launch_gate(a, s);
+        UZL_HIP(hipGetLastError());
+        UZL_HIP(hipMemcpyAsync(h->h_pre.p + first, h->d_pre.p + first, (size_t)m, hipMemcpyDeviceToHost, s));
+        UZL_HIP(hipMemcpyAsync(h->h_heur.p + first, h->d_heur.p + first, (size_t)m, hipMemcpyDeviceToHost, s));
+        UZL_HIP(hipMemcpyAsync(h->h_dist.p + first, h->d_dist.p + first, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+        UZL_HIP(hipMemcpyAsync(h->h_over.p, h->d_over.p, 4, hipMemcpyDeviceToHost, s));
+        UZL_HIP(hipStreamSynchronize(s));
+        if (h->h_over.p[0]) return fail(h, UZL_ERR_STATE, "graph search ran out of heap space");
+        // replay newEdgeCallback in candidate order over the search results
+        int32_t k = first;
+        for (; k < last; k++) {
+            const uzl_gate_edge& c = cand[k];
+            if (astar_dist) astar_dist[k] = -1.;
+            if (!run[k]) continue;
+            const auto key = std::make_tuple(std::min(c.from, c.to), std::max(c.from, c.to), c.type);
+            if (h->pair_type.count(key)) continue;                                  // joined the graph earlier in this call
+            if (!h->h_pre.p[k]) continue;
+            if (astar_dist) astar_dist[k] = h->h_dist.p[k];
+            if (!h->h_heur.p[k]) continue;
+            const int v = c.matching_score >= h->cfg.min_accept_valid ? 1 : 0;      // :809-811
+            add_edge(h, c.from, c.to, c.type, v);                                   // :812
+            accept[k] = 1; if (valid) valid[k] = (uint8_t)v;
+            if (h->adj_dirty) { k++; break; }                                       // reachability changed: search the rest again
+        }
+        first = k;
+    }
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
+int uzl_gate_edge_count(uzl_gate* h)
+{
+    if (!h) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    return (int)h->edges.size();
+}
+
+}  // extern "C"
