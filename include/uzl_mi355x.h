@@ -447,6 +447,34 @@ int  uzl_gate_check(uzl_gate* h, int32_t n_candidates, const uzl_gate_edge* cand
                     uint8_t* accept, uint8_t* valid, double* astar_dist);
 int  uzl_gate_edge_count(uzl_gate* h);
 
+/* ======================================================================================
+ *  Distance loop-closure candidates  
+ *
+ *  The step before the estimator: SlamGraph::getNodesWithinRadius (slam_graph.cpp:266-278)
+ *  and the filters of its caller (graph_slam_node.cpp:272-289) turn a new node into the list
+ *  of (close node, new node) pairs handed to estimateEdge.  Here for a batch of query nodes:
+ *  one workgroup per query scans all node positions (an HBM-bound streaming scan) and appends
+ *  its hits in node order.  Output jobs are ordered by query, then by node index.
+ * ====================================================================================== */
+typedef struct uzl_radius uzl_radius;
+typedef struct uzl_radius_cfg {
+    double  radius;               /* 0.5   distance_loop_closure_radius, GraphSlam.cfg:15 */
+    double  new_edge_time;        /* 5.0   s, GraphSlam.cfg:21                             */
+    double  max_rotation_deg;     /* 30.0  graph_slam_node.cpp:282                        */
+    int32_t device;
+    int32_t _pad;
+} uzl_radius_cfg;
+void uzl_radius_cfg_default(uzl_radius_cfg* cfg);
+int  uzl_radius_create(const uzl_radius_cfg* cfg, uzl_radius** out);
+void uzl_radius_destroy(uzl_radius* h);
+const char* uzl_radius_last_error(uzl_radius* h);
+/* node poses (n x 12) and stamps_.front() of every node in nanoseconds */
+int  uzl_radius_set_nodes(uzl_radius* h, int32_t n_nodes, const double* poses, const int64_t* stamp_front_ns);
+/* jobs (from = close node, to = query node) for every query node; *n_jobs = total found (may exceed cap:
+ * then only the first cap are written); count_per_query may be NULL. */
+int  uzl_radius_query(uzl_radius* h, int32_t n_queries, const int32_t* query_nodes, int64_t cap,
+                      int32_t* out_from, int32_t* out_to, int32_t* count_per_query, int64_t* n_jobs);
+
 #ifdef __cplusplus
 }
 #endif

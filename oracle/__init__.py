@@ -21,7 +21,7 @@ c_u8p = C.POINTER(C.c_uint8)
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("uzl_oracle_match.c", "uzl_oracle_pgo.c", "uzl_oracle_filter.c", "uzl_oracle_gate.c", "uzl_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("uzl_oracle_match.c", "uzl_oracle_pgo.c", "uzl_oracle_filter.c", "uzl_oracle_gate.c", "uzl_oracle_radius.c", "uzl_oracle.h")]
     if not force and os.path.exists(_LIB_PATH) and all(
             os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH
@@ -506,3 +506,17 @@ class Gate:
 
     def edge_count(self):
         return lib().uzlo_gate_edge_count(self._h)
+
+
+# ------------------------------------------------------------------------------- distance loop-closure candidates
+def radius_candidates(poses, stamps_front_ns, queries, radius=0.5, new_edge_time=5.0, max_rotation_deg=30.0):
+    """-> (from, to, count_per_query): jobs (close node, query node) in query order, then node order."""
+    P = np.ascontiguousarray(poses, np.float64).reshape(-1, 12); n = len(P)
+    st = np.ascontiguousarray(stamps_front_ns, np.int64); q = np.ascontiguousarray(queries, np.int32)
+    L = lib(); L.uzlo_radius_candidates.restype = C.c_int64
+    cap = max(1, n * len(q))
+    f = np.zeros(cap, np.int32); t = np.zeros(cap, np.int32); cnt = np.zeros(max(len(q), 1), np.int32)
+    tot = L.uzlo_radius_candidates(C.c_int32(n), _p(P, c_f64p), st.ctypes.data_as(C.POINTER(C.c_int64)), C.c_double(radius),
+                                   C.c_double(new_edge_time), C.c_double(max_rotation_deg), C.c_int32(len(q)), _p(q, c_i32p),
+                                   C.c_int64(cap), _p(f, c_i32p), _p(t, c_i32p), _p(cnt, c_i32p))
+    return f[:tot].copy(), t[:tot].copy(), cnt[:len(q)].copy()

@@ -207,6 +207,12 @@ void uzlo_gate_check(uzlo_gate* g, int32_t nc, const uzlo_gate_edge* cand, uint8
 int32_t uzlo_gate_edge_count(const uzlo_gate* g);
 int64_t uzlo_gate_last_expansions(const uzlo_gate* g);
 
+/* ---------------- distance loop-closure candidates (uzl_oracle_radius.c) ----------------
+ * slam_graph.cpp:266-278 + graph_slam_node.cpp:272-289.  Returns the total number of jobs (may exceed cap). */
+int64_t uzlo_radius_candidates(int32_t n, const double* poses, const int64_t* stamp_front_ns, double radius, double new_edge_time,
+                               double max_rotation_deg, int32_t nq, const int32_t* queries, int64_t cap, int32_t* out_from,
+                               int32_t* out_to, int32_t* count_per_query);
+
 #ifdef __cplusplus
 }
 #endif

@@ -160,6 +160,11 @@ def gate_edges(frm, to, typ, valid=None, score=None, transform=None):
     return a[:n] if n else a[:0]
 
 
+class RadiusCfg(C.Structure):
+    _fields_ = [("radius", C.c_double), ("new_edge_time", C.c_double), ("max_rotation_deg", C.c_double),
+                ("device", C.c_int32), ("_pad", C.c_int32)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 
 _lib = None
@@ -193,6 +198,12 @@ def lib():
             L.uzl_pgo_destroy.restype = None
             L.uzl_pgo_destroy.argtypes = [C.c_void_p]
             L.uzl_pgo_cfg_default.restype = None
+        if hasattr(L, "uzl_radius_create"):
+            L.uzl_radius_last_error.restype = C.c_char_p
+            L.uzl_radius_last_error.argtypes = [C.c_void_p]
+            L.uzl_radius_destroy.restype = None
+            L.uzl_radius_destroy.argtypes = [C.c_void_p]
+            L.uzl_radius_cfg_default.restype = None
         if hasattr(L, "uzl_gate_create"):
             L.uzl_gate_last_error.restype = C.c_char_p
             L.uzl_gate_last_error.argtypes = [C.c_void_p]
@@ -586,3 +597,47 @@ class Gate:
 
     def edge_count(self):
         return self._check(lib().uzl_gate_edge_count(self._h))
+
+
+# --------------------------------------------------------------------------------------- distance loop-closure candidates
+class Radius:
+    """uzl_radius_* (SlamGraph::getNodesWithinRadius + the caller's filters, graph_slam_node.cpp:272-289)."""
+
+    def __init__(self, **cfg):
+        L = lib()
+        c = RadiusCfg()
+        L.uzl_radius_cfg_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = C.c_void_p()
+        rc = L.uzl_radius_create(C.byref(c), C.byref(self._h))
+        if rc != UZL_OK:
+            raise UzlError(rc, L.uzl_status_string(rc).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uzl_radius_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise UzlError(rc, lib().uzl_radius_last_error(self._h).decode())
+        return rc
+
+    def set_nodes(self, poses, stamps_front_ns):
+        P = np.ascontiguousarray(poses, np.float64).reshape(-1, 12); st = np.ascontiguousarray(stamps_front_ns, np.int64)
+        self.n = len(P)
+        self._check(lib().uzl_radius_set_nodes(self._h, C.c_int32(len(P)), _p(P, c_f64p), st.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def query(self, queries, cap=None):
+        q = np.ascontiguousarray(queries, np.int32)
+        cap = int(cap if cap is not None else max(1, self.n * max(len(q), 1)))
+        f = np.zeros(max(cap, 1), np.int32); t = np.zeros(max(cap, 1), np.int32); cnt = np.zeros(max(len(q), 1), np.int32)
+        tot = C.c_int64()
+        self._check(lib().uzl_radius_query(self._h, C.c_int32(len(q)), _p(q, c_i32p), C.c_int64(cap), _p(f, c_i32p), _p(t, c_i32p),
+                                           _p(cnt, c_i32p), C.byref(tot)))
+        w = min(tot.value, cap)
+        return f[:w].copy(), t[:w].copy(), cnt[:len(q)].copy(), tot.value
