@@ -6,6 +6,7 @@
 set -u
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp UZL_NO_GRAPH=1
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline"

@@ -12,12 +12,13 @@ import shutil
 import sys
 
 src, out = sys.argv[1], sys.argv[2]
-ks = glob.glob(f"{src}/trace/*/*kernel_stats.csv")
+import os
+ks = sorted(glob.glob(f"{src}/trace/*/*kernel_stats.csv"), key=os.path.getmtime, reverse=True)
 if ks:
     shutil.copy(ks[0], out + "_kernel_stats.csv")
 pmc = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    fs = glob.glob(f"{src}/{c}/*/*counter_collection.csv")
+    fs = sorted(glob.glob(f"{src}/{c}/*/*counter_collection.csv"), key=os.path.getmtime, reverse=True)
     if not fs:
         continue
     agg = collections.defaultdict(lambda: [0, 0.0])

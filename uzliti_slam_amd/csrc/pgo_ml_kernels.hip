@@ -10,6 +10,7 @@
 //                     (transform -> contribution array -> ordered reduce: deterministic, no atomics)
 // Per LM trial      : D_l(lambda)^-1 = (G_l + lambda M_l)^-1, dense inverse of the <= 48-dof top level
 // Per PCG iteration : ml_spmv (p, A p, restricted A p) -> ml_cg (alpha, coarse chain in LDS, x, r, z)
+#include <hip/hip_ext.h>
 #include "pgo_device.hpp"
 
 namespace uzl {
@@ -1075,13 +1076,20 @@ void k_ml_init(const PgoDev& D, const MlHot& ml, int agg, double* p0, double* p1
     if (agg == 1) hipLaunchKernelGGL(ml_init_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, D, ml, p0, p1, rg);
     else hipLaunchKernelGGL(ml_init_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), 0, s, D, ml, p0, p1, rg);
 }
-void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s)
+// ev_a / ev_b (profiling only): the dispatch's own start / stop timestamps
+void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s,
+               hipEvent_t ev_a, hipEvent_t ev_b)
 {
+    if (ev_a) {
+        if (agg == 1) hipExtLaunchKernelGGL(ml_spmv_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(512), 0, s, ev_a, ev_b, 0, D, ml, p_old, p_new, n_part, tol2);
+        else hipExtLaunchKernelGGL(ml_spmv_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(512), 0, s, ev_a, ev_b, 0, D, ml, p_old, p_new, n_part, tol2);
+        return;
+    }
     if (agg == 1) hipLaunchKernelGGL(ml_spmv_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(512), 0, s, D, ml, p_old, p_new, n_part, tol2);
     else hipLaunchKernelGGL(ml_spmv_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(512), 0, s, D, ml, p_old, p_new, n_part, tol2);
 }
 hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
-                   int init, size_t lds, hipStream_t s)
+                   int init, size_t lds, hipStream_t s, hipEvent_t ev_a, hipEvent_t ev_b)
 {
     static size_t configured[2] = {0, 0};
     const int ci = agg == 1 ? 0 : 1;
@@ -1090,6 +1098,11 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured[ci] = lds;
+    }
+    if (ev_a) {
+        if (agg == 1) hipExtLaunchKernelGGL(ml_cg_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
+        else hipExtLaunchKernelGGL(ml_cg_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
+        return hipSuccess;
     }
     if (agg == 1) hipLaunchKernelGGL(ml_cg_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     else hipLaunchKernelGGL(ml_cg_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);

@@ -117,6 +117,23 @@ public:
         UZL_HIP(hipEventRecord(pool_[used_].b, s));
         ++used_;
     }
+    // Events for hipExtLaunchKernelGGL(..., start, stop, ...): they take the dispatch's own begin / end timestamps, i.e.
+    // the kernel's execution time as rocprofv3 reports it (hipEventRecord pairs around a ~10 us kernel also count the
+    // dispatch latency and read 1.4-2x too long).  Returns false when profiling is off.
+    bool pair(const char* name, hipEvent_t* a, hipEvent_t* b)
+    {
+        if (!on) return false;
+        if (used_ == pool_.size()) {
+            Pair p;
+            UZL_HIP(hipEventCreate(&p.a));
+            UZL_HIP(hipEventCreate(&p.b));
+            pool_.push_back(p);
+        }
+        pool_[used_].name = name;
+        *a = pool_[used_].a; *b = pool_[used_].b;
+        ++used_;
+        return true;
+    }
     // call after the stream has been synchronised
     void resolve()
     {

@@ -43,9 +43,10 @@ int g_ml_rows(int nb, int agg);
 size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
 bool ml_fits_lds(const int* n_per_level, int levels, int agg);
 void k_ml_init(const PgoDev& D, const MlHot& ml, int agg, double* p0, double* p1, double* rg, hipStream_t s);
-void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
+void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s,
+               hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
-                   int init, size_t lds, hipStream_t s);
+                   int init, size_t lds, hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
@@ -489,13 +490,22 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
     for (int i = 0; i < 2 * pairs; i++) {
         double* po = pb[i & 1];
         double* pn = pb[(i & 1) ^ 1];
-        if (timed) h->timer.begin("pcg_spmv", s);
-        if (ml) k_ml_spmv(D, h->ml_hot, h->ml_agg, po, pn, gu, tol2, s); else k_pcg_spmv(D, po, pn, gu, tol2, s);
-        if (timed) h->timer.end(s);
-        if (ml) shard_allreduce(h, h->d_ap.p, h->iter_span);                     // the one exchange per PCG iteration
-        if (timed) h->timer.begin(ml ? "ml_cg" : "pcg_update", s);
-        if (ml) UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, pn, h->ml_rg[(i & 1) ^ 1], h->ml_rg[i & 1], ga, 0, h->ml_lds, s)); else k_pcg_update(D, pn, ga, s);
-        if (timed) h->timer.end(s);
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (ml) {
+            if (timed) h->timer.pair("pcg_spmv", &ea, &eb);                      // dispatch timestamps: agree with rocprofv3
+            k_ml_spmv(D, h->ml_hot, h->ml_agg, po, pn, gu, tol2, s, ea, eb);
+            shard_allreduce(h, h->d_ap.p, h->iter_span);                         // the one exchange per PCG iteration
+            ea = eb = nullptr;
+            if (timed) h->timer.pair("ml_cg", &ea, &eb);
+            UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, pn, h->ml_rg[(i & 1) ^ 1], h->ml_rg[i & 1], ga, 0, h->ml_lds, s, ea, eb));
+        } else {
+            if (timed) h->timer.begin("pcg_spmv", s);
+            k_pcg_spmv(D, po, pn, gu, tol2, s);
+            if (timed) h->timer.end(s);
+            if (timed) h->timer.begin("pcg_update", s);
+            k_pcg_update(D, pn, ga, s);
+            if (timed) h->timer.end(s);
+        }
     }
 }
 
