@@ -409,6 +409,52 @@ __global__ __launch_bounds__(kSibBlk) void ml_sibling_kernel(PgoDev D, const MlD
     for (int i = t; i < m * m; i += kSibBlk) out[i] = sW[(i / m) * ld + i % m];
 }
 
+__device__ __forceinline__ double prolong_comp(const double* __restrict__ d, const double* __restrict__ yp, int k);
+
+// ---- composite path (small graphs), per LM trial, for l = L-1 .. 1: the whole hierarchy above level l as ONE dense
+//      operator  Y_l = blockdiag(W_l^-1 over sibling groups) + P_{l+1} Y_{l+1} P_{l+1}^T   ((6 n_l)^2, Y_L = A_L^-1).
+//      Y_1 is what ml_cg applies: the coarse correction of an aggregate is 6 rows of Y_1 times the gather-level
+//      residual - one latency-flat dot product instead of a restrict / solve / prolong walk through LDS.
+//      One lane per 6x6 block (B, B').
+__global__ __launch_bounds__(kBlk) void ml_dense_level_kernel(const MlDev* __restrict__ mlp, int l)
+{
+    const MlDev& ml = *mlp;
+    const int n = ml.lv[l].n, t = blockIdx.x * kBlk + threadIdx.x;
+    if (t >= n * n) return;
+    const int B = t / n, Bp = t % n;
+    const int fan = ml.lv[l + 1].fan, np6 = 6 * ml.lv[l + 1].n, m = 6 * fan;
+    const double* __restrict__ Yp = (l + 1 == ml.levels) ? ml.top_inv : ml.Ydense[l + 1];
+    const int pB = B / fan, pBp = Bp / fan;
+    double Yb[36], T1[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) Yb[i] = Yp[(size_t)(6 * pB + i / 6) * np6 + 6 * pBp + i % 6];
+    const double* dB = ml.lv[l].geo + (size_t)B * 3;
+    const double* dBp = ml.lv[l].geo + (size_t)Bp * 3;
+    const double d0[3] = {dB[0], dB[1], dB[2]}, d1[3] = {dBp[0], dBp[1], dBp[2]};
+    // T1 = Yb P(B')^T : row r of T1 = P(B') applied to row r of Yb
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) T1[r * 6 + k] = prolong_comp(d1, Yb + r * 6, k);
+    // out = P(B) T1 : column c of out = P(B) applied to column c of T1
+    double out[36];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const double col[6] = {T1[c], T1[6 + c], T1[12 + c], T1[18 + c], T1[24 + c], T1[30 + c]};
+#pragma unroll
+        for (int k = 0; k < 6; k++) out[k * 6 + c] = prolong_comp(d0, col, k);
+    }
+    if (pB == pBp) {
+        const double* __restrict__ W = ml.lv[l].Winv + (size_t)pB * m * m + (size_t)((B % fan) * 6) * m + (Bp % fan) * 6;
+#pragma unroll
+        for (int i = 0; i < 36; i++) out[i] += W[(i / 6) * m + i % 6];
+    }
+    double* __restrict__ Y = ml.Ydense[l];
+    const int n6 = 6 * n;
+#pragma unroll
+    for (int i = 0; i < 36; i++) Y[(size_t)(6 * B + i / 6) * n6 + 6 * Bp + i % 6] = out[i];
+}
+
 // ---- per LM trial: dense inverse of the top level A_L(lambda) (<= 48 x 48), one workgroup, in LDS
 __global__ __launch_bounds__(kBlk) void ml_top_kernel(PgoDev D, const MlDev* __restrict__ mlp)
 {
@@ -1034,6 +1080,133 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// ml_cg for small graphs (<= 1280 free vertices, one level-1 aggregate per workgroup): the hierarchy above level 1
+// has been folded into the dense operator Y_1 (ml_dense_level_kernel), so the coarse correction of the own aggregate
+// is  y1 = Y_1[rows 6A..6A+5] (rg_old - alpha Sg): every operand is loaded at entry (one memory latency), the
+// restrict / top-solve / prolong walk through LDS and its barriers are gone.  Same preconditioner, same results up to
+// rounding as ml_cg_kernel<1>.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCompU = 5;             // 6 n_1 <= 960 gather-level values: 5 per lane
+__global__ __launch_bounds__(kCgBlk) void ml_cg_comp_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
+                                                           const double* __restrict__ rg_old, double* __restrict__ rg_new,
+                                                           int n_part, int init)
+{
+    __shared__ double s3[3];
+    __shared__ double sv[kCgBlk];
+    __shared__ double sw[kCgBlk];
+    __shared__ double sy[6];
+    __shared__ double szj[48];
+    __shared__ double scomp[3][6];
+    if (D.flags[0]) return;
+    const int tid = threadIdx.x;
+    const int a = blockIdx.x * kMlFanout + tid / 6, r = tid % 6;
+    const bool act = tid < 48 && a < D.nb;
+    const int n1 = H.n[1], ng6 = 6 * n1;
+    // ---- every global load, before any barrier
+    double part = 0.;
+    if (!init) for (int i = tid; i < n_part; i += kCgBlk) part += D.part_a[i];
+    double xv = 0., rv0 = 0., apv = 0., pv = 0., geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (act) {
+        const size_t i = (size_t)a * 6 + r;
+        rv0 = D.r[i];
+        if (!init) { xv = D.x[i]; apv = D.ap[i]; pv = p[i]; }
+        const double* __restrict__ gg = H.geo0 + (size_t)a * 12;
+#pragma unroll
+        for (int c = 0; c < 12; c++) geo[c] = gg[c];
+    }
+    double w0[12];
+    {
+        const int out = tid >> 2, part4 = tid & 3;
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(H.Winv[0] + ((size_t)blockIdx.x * 48 + out) * 48 + part4 * 12);
+#pragma unroll
+        for (int c = 0; c < 6; c++) { const double2 v = src[c]; w0[2 * c] = v.x; w0[2 * c + 1] = v.y; }
+    }
+    const double rz = init ? 0. : D.scal[0];
+    double rgreg[kCompU], sgreg[kCompU], cm[6][kCompU];
+    const double* __restrict__ crow = H.Cmat + (size_t)blockIdx.x * 6 * ng6;
+#pragma unroll
+    for (int u = 0; u < kCompU; u++) {
+        const int t = u * kCgBlk + tid;
+        const bool in = t < ng6;
+        rgreg[u] = in ? rg_old[t] : 0.;
+        sgreg[u] = (!init && in) ? H.Sg[t] : 0.;
+#pragma unroll
+        for (int q = 0; q < 6; q++) cm[q][u] = in ? crow[(size_t)q * ng6 + t] : 0.;
+    }
+    double alpha = 0.;
+    bool bad = false;
+    if (!init) {
+        const double pAp = block_sum_w<3>(part, s3);
+        bad = !(pAp > 0.);
+        alpha = bad ? 0. : rz / pAp;
+    }
+    // ---- coarse correction of the own aggregate: 6 rows of Y_1 times the gather-level residual estimate
+    {
+        double ps[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < kCompU; u++) {
+            const double v = rgreg[u] - alpha * sgreg[u];
+#pragma unroll
+            for (int q = 0; q < 6; q++) ps[q] += cm[q][u] * v;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) ps[q] = wave_sum(ps[q]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) scomp[tid >> 6][q] = ps[q];
+        }
+    }
+    // ---- own rows: x, r, level-0 smoother, exact r1 of the own aggregate
+    double rv = rv0;
+    if (act && !init) {
+        const size_t i = (size_t)a * 6 + r;
+        rv = rv0 - alpha * apv;
+        D.x[i] = xv + alpha * pv;
+        D.r[i] = rv;
+    }
+    sv[tid] = act ? rv : 0.;
+    __syncthreads();
+    double zz = 0., w = 0.;
+    {
+        const int part4 = tid & 3;
+        double ps = 0.;
+#pragma unroll
+        for (int c = 0; c < 12; c++) ps += w0[c] * sv[part4 * 12 + c];
+        ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2);
+        if (part4 == 0) szj[tid >> 2] = ps;
+    }
+    if (act) {
+        const int g0 = tid - r;
+        w = p1t_comp(geo, sv[g0], sv[g0 + 1], sv[g0 + 2], sv[g0 + 3], sv[g0 + 4], sv[g0 + 5], r);
+    }
+    sw[tid] = w;
+    if (tid < 6) sy[tid] = (scomp[0][tid] + scomp[1][tid]) + scomp[2][tid];
+    __syncthreads();
+    if (act) zz = szj[tid];
+    if (tid < 6) {
+        double s = 0.;
+#pragma unroll
+        for (int j = 0; j < kMlFanout; j++) s += sw[j * 6 + tid];
+        if ((int)blockIdx.x < n1) rg_new[(size_t)blockIdx.x * 6 + tid] = s;       // exact r1: the recursion never accumulates error
+    }
+    double acc = 0.;
+    if (act) {
+        zz += p1_comp(geo, sy, r);
+        D.z[(size_t)a * 6 + r] = zz;
+        acc = rv * zz;
+    }
+    const double tot = block_sum_w<3>(acc, s3);
+    if (tid == 0) {
+        D.part_b[blockIdx.x] = tot;
+        if (blockIdx.x == 0 && !init) {
+            D.scal[2] = rz;
+            D.flags[1] += 1;
+            if (bad) { D.flags[0] = 1; D.flags[2] = 1; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, int n_l, hipStream_t s)
@@ -1048,6 +1221,10 @@ void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s)
 {
     const long work = (long)blocks36 * 36;
     if (work > 0) hipLaunchKernelGGL(ml_reduce_kernel, dim3((unsigned)((work + kBlk - 1) / kBlk)), dim3(kBlk), 0, s, ml, l);
+}
+void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s)
+{
+    hipLaunchKernelGGL(ml_dense_level_kernel, dim3((n_l * n_l + kBlk - 1) / kBlk), dim3(kBlk), 0, s, ml, l);
 }
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s)
 {
@@ -1098,6 +1275,11 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured[ci] = lds;
+    }
+    if (agg == 1 && ml.Cmat) {           // small graphs: composite coarse operator
+        if (ev_a) hipExtLaunchKernelGGL(ml_cg_comp_kernel, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
+        else hipLaunchKernelGGL(ml_cg_comp_kernel, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, D, ml, p, rg_old, rg_new, n_part, init);
+        return hipSuccess;
     }
     if (ev_a) {
         if (agg == 1) hipExtLaunchKernelGGL(ml_cg_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);

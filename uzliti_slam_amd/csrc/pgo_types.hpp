@@ -103,6 +103,8 @@ struct MlDev {
     double* tmpG;              // [max n][36]
     double* tmpM;              // [max n][36]
     double* top_inv;           // [(6 n_top)^2] dense inverse of A_L(lambda)
+    double* Ydense[kMlMaxLevels + 1];   // composite path: Y_l = dense (6 n_l)^2 operator "residual of level l -> correction of
+                               // level l" of the whole hierarchy above, 1 <= l < L (Y_L = top_inv); null otherwise
     double* Sg;                // [n_g][6] restriction of A p at the gather level (written by ml_spmv)
 };
 
@@ -116,6 +118,7 @@ struct MlHot {
     const double* geo[kMlMaxLevels + 1];   // [n_l][3], l >= 1
     const double* Winv[kMlMaxLevels + 1];  // [n_{l+1}][(6 fan_{l+1})^2], 0 <= l < levels
     const double* top_inv;
+    const double* Cmat;                    // composite path: Y_1, [6 n_1][6 n_1]; rows 6A..6A+5 belong to workgroup A
     double* Sg;                            // [n_g][6] restriction of A p at the gather level g = min(2, levels)
 };
 

@@ -39,6 +39,7 @@ void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, 
 void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s);
 void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
+void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s);
 int g_ml_rows(int nb, int agg);
 size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
 bool ml_fits_lds(const int* n_per_level, int levels, int agg);
@@ -87,6 +88,7 @@ struct uzl_pgo {
     int ml_levels = 0;
     std::vector<int32_t> ml_n, ml_nslots;
     int ml_inner_aggs = 0;
+    bool ml_comp = false;            // small graphs: hierarchy above level 1 folded into a dense operator (pgo_ml_kernels.hip)
     double* ml_rg[2] = {nullptr, nullptr};     // double-buffered gather-level residual
     std::vector<int32_t> ml_fan;
     int ml_agg = 4;                            // level-1 aggregates per PCG workgroup (1: small graphs, 4: large)
@@ -322,6 +324,11 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     std::vector<size_t> geo_sub((size_t)L + 1, 0);
     for (int l = 1; l <= L; l++) { geo_sub[l] = geo_blob_doubles; geo_blob_doubles += (size_t)std::max(h->ml_n[l], 1) * 3; }
     const size_t o_geo_blob = take(geo_blob_doubles * 8 + 64);     // ml_cg copies levels g..L-1 with one linear loop
+    // composite path: one aggregate per workgroup, at least two coarse levels, 6 n_1 <= 960 (<= 1280 free vertices)
+    static const bool comp_off = getenv("UZL_ML_NO_COMP") != nullptr;                // A/B switch
+    h->ml_comp = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 960;
+    std::vector<size_t> o_dense((size_t)L + 1, 0);
+    if (h->ml_comp) for (int l = 1; l < L; l++) o_dense[l] = take((size_t)(6 * h->ml_n[l]) * (size_t)(6 * h->ml_n[l]) * 8);
     const size_t o_tmp = take(max_contrib * 36 * 8), o_tmpG = take(max_n * 36 * 8), o_tmpM = take(max_n * 36 * 8);
     const size_t o_top = take((size_t)(6 * kMlTopMax) * (6 * kMlTopMax) * 8);
     const int gl = (h->ml_agg == 1 || L < 2) ? 1 : 2;
@@ -366,6 +373,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     M.tmpG = reinterpret_cast<double*>(base + o_tmpG);
     M.tmpM = reinterpret_cast<double*>(base + o_tmpM);
     M.top_inv = reinterpret_cast<double*>(base + o_top);
+    for (int l = 1; l < L; l++) M.Ydense[l] = h->ml_comp ? reinterpret_cast<double*>(base + o_dense[l]) : nullptr;
     M.Sg = reinterpret_cast<double*>(base + o_sg);
     h->ml_rg[0] = reinterpret_cast<double*>(base + o_rga);
     h->ml_rg[1] = reinterpret_cast<double*>(base + o_rgb);
@@ -374,6 +382,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     Hh.levels = L;
     for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Winv[l] = M.lv[l].Winv; }
     Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg;
+    Hh.Cmat = h->ml_comp ? M.Ydense[1] : nullptr;
     h->l1_span_ptr = M.lv[1].blk;
     h->l1_span = (int64_t)((M.lv[1].M + (size_t)std::max(h->ml_n[1], 1) * 36) - M.lv[1].blk);
     h->d_ml.reserve(1);
@@ -537,6 +546,7 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     const bool timed = h->timer.on || h->no_graph || h->sharded;   // per-kernel events, rocprofv3 and the exchange callback need eager launches
     if (h->ml_levels > 0) {
         { Timed t(h, "ml_sibling"); k_ml_sibling(D, h->d_ml.p, h->ml_inner_aggs, s); }
+        if (h->ml_comp) { Timed t(h, "ml_dense"); for (int l = h->ml_levels - 1; l >= 1; l--) k_ml_dense_level(h->d_ml.p, l, h->ml_n[l], s); }
         { Timed t(h, "pcg_init"); k_ml_init(D, h->ml_hot, h->ml_agg, h->d_p.p, h->d_p2.p, h->ml_rg[0], s); }
         { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, h->d_p.p, h->ml_rg[0], h->ml_rg[1], 0, 1, h->ml_lds, s)); }
     } else {
@@ -629,7 +639,11 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         do {
             set_lambda(h, lambda);                                                // setLambda
             bool conv = false;
-            S.pcg_iterations += pcg_solve(h, &conv);                              // _solver->solve()
+            const int pcg_its = pcg_solve(h, &conv);                              // _solver->solve()
+            S.pcg_iterations += pcg_its;
+            if (h->cfg.verbose)
+                fprintf(stderr, "[uzl_pgo] it %d trial %d lambda %.3e pcg %d  rz_end %.3e  rz_stop %.3e  chi2 %.9g\n", it, qmax, lambda, pcg_its,
+                        h->h_scal.p->scal[0], h->h_scal.p->scal[1], current_chi);
             if (!conv) { S.pcg_not_converged++; rc = UZL_ERR_NOT_CONVERGED; }
             S.lm_trials++;
             int go, gc;
