@@ -254,6 +254,8 @@ typedef struct uzl_pgo_stats {
     double  chi2_final;
     double  lambda_final;
     double  solve_ms;          /* wall time of uzl_pgo_optimize, device-resident graph        */
+    int32_t precond_builds;    /* LM iterations that rebuilt the multilevel preconditioner    */
+    int32_t _pad;
 } uzl_pgo_stats;
 
 void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg);

@@ -79,7 +79,7 @@ class PgoStats(C.Structure):
                 ("terminated_early", C.c_int32), ("n_vertices", C.c_int32), ("n_edges", C.c_int32),
                 ("n_gauge_fixed", C.c_int32), ("pcg_not_converged", C.c_int32),
                 ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
-                ("solve_ms", C.c_double)]
+                ("solve_ms", C.c_double), ("precond_builds", C.c_int32), ("_pad", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -88,6 +88,7 @@ struct uzl_pgo {
     int ml_levels = 0;
     std::vector<int32_t> ml_n, ml_nslots;
     int ml_inner_aggs = 0;
+    bool ml_trial_setup = false;     // the preconditioner's per-trial part (sibling inverses, top, dense levels) is due
     bool ml_comp = false;            // small graphs: hierarchy above level 1 folded into a dense operator (pgo_ml_kernels.hip)
     double* ml_rg[2] = {nullptr, nullptr};     // double-buffered gather-level residual
     std::vector<int32_t> ml_fan;
@@ -545,8 +546,11 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     const int max_it = h->cfg.pcg_max_iter > 0 ? h->cfg.pcg_max_iter : 6 * std::max(h->nb, 1);
     const bool timed = h->timer.on || h->no_graph || h->sharded;   // per-kernel events, rocprofv3 and the exchange callback need eager launches
     if (h->ml_levels > 0) {
-        { Timed t(h, "ml_sibling"); k_ml_sibling(D, h->d_ml.p, h->ml_inner_aggs, s); }
-        if (h->ml_comp) { Timed t(h, "ml_dense"); for (int l = h->ml_levels - 1; l >= 1; l--) k_ml_dense_level(h->d_ml.p, l, h->ml_n[l], s); }
+        if (h->ml_trial_setup) {
+            { Timed t(h, "ml_sibling"); k_ml_sibling(D, h->d_ml.p, h->ml_inner_aggs, s); }
+            if (h->ml_comp) { Timed t(h, "ml_dense"); for (int l = h->ml_levels - 1; l >= 1; l--) k_ml_dense_level(h->d_ml.p, l, h->ml_n[l], s); }
+            h->ml_trial_setup = false;
+        }
         { Timed t(h, "pcg_init"); k_ml_init(D, h->ml_hot, h->ml_agg, h->d_p.p, h->d_p2.p, h->ml_rg[0], s); }
         { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, h->d_p.p, h->ml_rg[0], h->ml_rg[1], 0, 1, h->ml_lds, s)); }
     } else {
@@ -613,6 +617,10 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     }
     // optimizer_.optimize(iterations) (:148) -> OptimizationAlgorithmLevenberg::solve [EXT]
     double lambda = 0., ni = 2., current_chi = 0.;
+    static const bool always_refresh = getenv("UZL_ML_ALWAYS_REFRESH") != nullptr;      // A/B switch
+    const double refresh_rel = 1e-3;
+    double last_rel = 1e300;
+    int pcg_ref = 1 << 30, pcg_last = 0;
     for (int it = 0; it < iterations; it++) {
         int gl, ga;
         D.pose = h->cur; D.pose_trial = h->trial;
@@ -624,7 +632,12 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         }
         { Timed t(h, "finalize"); k_finalize(D, gl, 0, ga, 2, s); }
         shard_allreduce_chi2(h);
-        ml_setup_numeric(h);
+        // The multilevel preconditioner is rebuilt only while the linearisation still moves: any SPD preconditioner
+        // gives the same PCG solution, and once chi2 changes by less than refresh_rel per step the hierarchy of the
+        // previous iteration is as good as a fresh one (geometry + Galerkin + inverses are ~170 us per rebuild).
+        // A rebuild is also forced when the iteration count has grown by a third since the last one.
+        const bool refresh = it == 0 || always_refresh || last_rel > refresh_rel || pcg_last > pcg_ref + pcg_ref / 3 + 4;
+        if (refresh) { ml_setup_numeric(h); h->ml_trial_setup = true; S.precond_builds++; }
         if (it == 0 || h->sharded) {                   // later iterations carry chi2 over from the accepted trial: no round trip
             fetch_scal(h);
             current_chi = h->h_scal.p->scal[4];
@@ -639,8 +652,11 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         do {
             set_lambda(h, lambda);                                                // setLambda
             bool conv = false;
+            const bool fresh = h->ml_trial_setup;
             const int pcg_its = pcg_solve(h, &conv);                              // _solver->solve()
             S.pcg_iterations += pcg_its;
+            if (fresh) pcg_ref = pcg_its;
+            pcg_last = pcg_its;
             if (h->cfg.verbose)
                 fprintf(stderr, "[uzl_pgo] it %d trial %d lambda %.3e pcg %d  rz_end %.3e  rz_stop %.3e  chi2 %.9g\n", it, qmax, lambda, pcg_its,
                         h->h_scal.p->scal[0], h->h_scal.p->scal[1], current_chi);
@@ -660,6 +676,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
                 alpha = std::min(alpha, 2. / 3.);
                 lambda *= std::max(1. / 3., alpha);
                 ni = 2.;
+                last_rel = std::fabs(current_chi - temp_chi) / std::max(std::fabs(temp_chi), 1e-300);
                 current_chi = temp_chi;
                 std::swap(h->cur, h->trial);                                      // discardTop
             } else {
