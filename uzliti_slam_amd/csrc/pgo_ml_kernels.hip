@@ -645,12 +645,14 @@ __global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const d
         const int A1 = blockIdx.x * kAggPerBlk + tid / 3;
         sg1[tid] = (gl == 2 && A1 < H.n[1]) ? H.geo[1][(size_t)A1 * 3 + tid % 3] : 0.;
     }
-    int s0[kRowsPerWave], s1[kRowsPerWave];
+    int s0[kRowsPerWave], s1[kRowsPerWave], cf[kRowsPerWave];       // slot range and this lane group's first column: ONE hop (row header)
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) {
         const int a = row0 + q;
-        s0[q] = (a < D.nb) ? D.row_ptr[a] : 0;
-        s1[q] = (a < D.nb) ? D.row_ptr[a + 1] : 0;
+        const int32_t* __restrict__ hd = D.rowhdr + (size_t)(a < D.nb ? a : 0) * 12;
+        s0[q] = (a < D.nb) ? hd[0] : 0;
+        s1[q] = (a < D.nb) ? hd[1] : 0;
+        cf[q] = (a < D.nb && lact) ? hd[2 + g] : -1;
     }
     // lane group q (< 4) owns the diagonal block, z, p_old and geometry of row q
     double hrow[6] = {0, 0, 0, 0, 0, 0}, zo[6] = {0, 0, 0, 0, 0, 0}, po[6] = {0, 0, 0, 0, 0, 0}, geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const d
         have[q] = false;
         const int s = s0[q] + g;
         if (lact && s < s1[q]) {
-            const int c = D.col[s];
+            const int c = cf[q];
             if (c >= 0) {
                 have[q] = true;
                 const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
@@ -760,8 +762,8 @@ __global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const d
         ss1[tid] = s;
         if (gl == 1 && A1 < H.n[1]) H.Sg[(size_t)A1 * 6 + k] = s;
     }
-    __syncthreads();
-    if (gl == 2 && tid < 6) {
+    if (AGG != 1) __syncthreads();
+    if (AGG != 1 && gl == 2 && tid < 6) {
         double s = 0.;
         for (int la = 0; la < kAggPerBlk; la++)
             if (blockIdx.x * kAggPerBlk + la < H.n[1]) s += restrict_comp(sg1 + la * 3, ss1 + la * 6, tid);

@@ -36,6 +36,7 @@ struct PgoDev {
     const int32_t* slot_j;
     const int32_t* row_ptr;  // [nb+1]
     const int32_t* col;      // [nslots]
+    const int32_t* rowhdr;   // [nb][12] = {row_ptr[a], row_ptr[a+1], col of the first 10 slots (-1 past the end)}: one hop instead of two
     double* blk;
     double* dcon;
     double* gcon;

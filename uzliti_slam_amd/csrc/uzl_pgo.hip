@@ -72,7 +72,7 @@ struct uzl_pgo {
     DevBuf<double> pose_a, pose_b, pose_init;
     double* cur = nullptr;
     double* trial = nullptr;
-    DevBuf<int32_t> d_v2b, d_b2v, d_ei, d_ej, d_slot_i, d_slot_j, d_row_ptr, d_col, d_src, d_flags;
+    DevBuf<int32_t> d_v2b, d_b2v, d_ei, d_ej, d_slot_i, d_slot_j, d_row_ptr, d_col, d_rowhdr, d_src, d_flags;
     DevBuf<double> d_zinv, d_info, d_blk, d_dcon, d_gcon, d_hdiag, d_minv, d_b, d_x, d_r, d_z, d_p, d_p2, d_ap;
     DevBuf<double> d_part_a, d_part_b, d_part_c, d_scal, d_err, d_out12, d_stage;
     DevBuf<uint8_t> d_robust;
@@ -443,6 +443,13 @@ void build_structure(uzl_pgo* h)
     if (nb > 0) UZL_HIP(hipMemcpyAsync(h->d_b2v.p, b2v.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, s));
     UZL_HIP(hipMemcpyAsync(h->d_row_ptr.p, row_ptr.data(), sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice, s));
     if (nslots > 0) UZL_HIP(hipMemcpyAsync(h->d_col.p, col.data(), sizeof(int32_t) * nslots, hipMemcpyHostToDevice, s));
+    std::vector<int32_t> rowhdr((size_t)nbz * 12, -1);
+    for (int a = 0; a < nb; a++) {
+        rowhdr[(size_t)a * 12] = row_ptr[a]; rowhdr[(size_t)a * 12 + 1] = row_ptr[a + 1];
+        for (int k = 0; k < 10 && row_ptr[a] + k < row_ptr[a + 1]; k++) rowhdr[(size_t)a * 12 + 2 + k] = col[row_ptr[a] + k];
+    }
+    h->d_rowhdr.reserve(nbz * 12);
+    UZL_HIP(hipMemcpyAsync(h->d_rowhdr.p, rowhdr.data(), sizeof(int32_t) * nbz * 12, hipMemcpyHostToDevice, s));
     if (e > 0) {
         UZL_HIP(hipMemcpyAsync(h->d_slot_i.p, slot_i.data(), sizeof(int32_t) * e, hipMemcpyHostToDevice, s));
         UZL_HIP(hipMemcpyAsync(h->d_slot_j.p, slot_j.data(), sizeof(int32_t) * e, hipMemcpyHostToDevice, s));
@@ -459,7 +466,7 @@ void build_structure(uzl_pgo* h)
     D.pose = h->cur; D.pose_trial = h->trial;
     D.v2b = h->d_v2b.p; D.b2v = h->d_b2v.p; D.ei = h->d_ei.p; D.ej = h->d_ej.p;
     D.zinv = h->d_zinv.p; D.info = h->d_info.p; D.robust = h->d_robust.p;
-    D.slot_i = h->d_slot_i.p; D.slot_j = h->d_slot_j.p; D.row_ptr = h->d_row_ptr.p; D.col = h->d_col.p;
+    D.slot_i = h->d_slot_i.p; D.slot_j = h->d_slot_j.p; D.row_ptr = h->d_row_ptr.p; D.col = h->d_col.p; D.rowhdr = h->d_rowhdr.p;
     D.blk = h->d_blk.p; D.dcon = h->d_dcon.p; D.gcon = h->d_gcon.p; D.hdiag = h->d_hdiag.p; D.minv = h->d_minv.p;
     D.b = h->d_hdiag.p + (size_t)nb * 36; D.x = h->d_x.p; D.r = h->d_r.p; D.z = h->d_z.p; D.p = h->d_p.p; D.ap = h->d_ap.p;
     D.part_a = h->d_ap.p + (size_t)nbz * 12; D.part_b = h->d_part_b.p; D.part_c = h->d_part_c.p;
