@@ -262,3 +262,46 @@ def test_full_size_properties_c4(pgo):
     poses2, _, _ = pgo.store()
     dt2, dr2 = synth.pose_errors(poses2.reshape(-1, 3, 4), poses.reshape(-1, 3, 4))
     assert dt2 < 1e-3 and dr2 < 1e-4
+
+
+def test_rejected_trials_multi_edges_and_hub(capi, oracle):
+    """LM trials that get rejected (lambda grows, same linearisation is solved again), several edges between the same two
+    nodes (their blocks add up in the block-CSR and in the sibling blocks) and a hub vertex with far more than ten slots."""
+    g = synth.make_pose_graph(240, 900, seed=77, outlier_frac=0.35)
+    e = g["edges"]
+    rng = np.random.default_rng(5)
+    # poor initial guess: scramble the dead-reckoning poses (rotations too: that is what makes LM reject steps)
+    P0 = g["nodes_pose"].reshape(-1, 3, 4).copy()
+    P0[1:] = synth.se3_mul(P0[1:], synth.se3_from_noise(rng.normal(0, 1.5, (239, 3)), rng.normal(0, 0.8, (239, 3))))
+    # multi-edges: duplicate 40 loop closures (same endpoints, same measurement)
+    dup = np.arange(300, 340)
+    # hub: 60 extra loop closures from node 100 to nodes 101..160 built from the ground truth
+    gt = g["gt_pose"].reshape(-1, 3, 4)
+    hub_to = np.arange(101, 161)
+    hub_T = synth.se3_mul(synth.se3_inv(gt[[100] * 60]), gt[hub_to]).reshape(-1, 12)
+    def cat(k, extra):
+        return np.concatenate([np.asarray(e[k]), np.asarray(e[k])[dup], extra])
+    ident = np.tile(np.eye(3, 4).reshape(1, 12), (60, 1))
+    info = np.tile((np.eye(6) * 50.0).reshape(1, 36), (60, 1))
+    e2 = {"from": cat("from", np.full(60, 100, np.int32)), "to": cat("to", hub_to.astype(np.int32)),
+          "type": cat("type", np.ones(60, np.int32)), "sensor_from": cat("sensor_from", np.full(60, -1, np.int32)),
+          "sensor_to": cat("sensor_to", np.full(60, -1, np.int32)), "valid": cat("valid", np.ones(60, np.int32)),
+          "transform": cat("transform", hub_T), "displacement_from": cat("displacement_from", ident),
+          "displacement_to": cat("displacement_to", ident), "information": cat("information", info),
+          "diff_time": cat("diff_time", np.zeros(60))}
+    fl = oracle.flatten_graph(P0.reshape(-1, 12), g["nodes_fixed"], e2)
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    its = 8
+    P, so = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=its)
+    # this far from the optimum the LM path is chaotic (a solve error grows ~10x per iteration, measured): solve tightly
+    p = capi.Pgo(pcg_tol=1e-12)
+    p.add_graph(P0.reshape(-1, 12), g["nodes_fixed"], e2)
+    st = p.optimize(its)
+    poses, _, _ = p.store()
+    p.close()
+    assert so["lm_trials"] > so["iterations_done"] + 3, "the case is meant to contain rejected trials"
+    assert st["pcg_not_converged"] == 0
+    assert st["lm_trials"] == so["lm_trials"] and st["iterations_done"] == so["iterations_done"]
+    assert abs(st["chi2_final"] - so["chi2_final"]) <= 1e-6 * so["chi2_final"]
+    dt, dr = synth.pose_errors(poses.reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+    assert dt < 1e-3 and dr < 1e-4, (dt, dr)
