@@ -289,11 +289,13 @@ void uzlo_pose_svd(const double* P, const double* Q, const int32_t* idx, int32_t
  * ------------------------------------------------------------------------------------------ */
 static inline double point_dist(const double* p, const double* q, const double T[12])
 {
-    double x = ((T[0] * p[0] + T[1] * p[1]) + T[2] * p[2]) + T[3];
-    double y = ((T[4] * p[0] + T[5] * p[1]) + T[6] * p[2]) + T[7];
-    double z = ((T[8] * p[0] + T[9] * p[1]) + T[10] * p[2]) + T[11];
+    /* fused multiply-adds, innermost first (this build's recipe, repeated by the HIP kernels operation for
+     * operation; the reference leaves the evaluation order of T * P to Eigen / the compiler) */
+    double x = fma(T[0], p[0], fma(T[1], p[1], fma(T[2], p[2], T[3])));
+    double y = fma(T[4], p[0], fma(T[5], p[1], fma(T[6], p[2], T[7])));
+    double z = fma(T[8], p[0], fma(T[9], p[1], fma(T[10], p[2], T[11])));
     double dx = x - q[0], dy = y - q[1], dz = z - q[2];
-    return sqrt((dx * dx + dy * dy) + dz * dz);
+    return sqrt(fma(dx, dx, fma(dy, dy, dz * dz)));
 }
 
 int32_t uzlo_consensus3d(const double* P, const double* Q, int32_t m, const double T[12],

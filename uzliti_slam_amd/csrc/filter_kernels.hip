@@ -85,11 +85,11 @@ __global__ __launch_bounds__(kFilterBlock) void filter_consensus_kernel(const do
     if (k >= n) return;
     const double* T = results[col_cluster[k]].T;
     const double px = P[3 * (size_t)k], py = P[3 * (size_t)k + 1], pz = P[3 * (size_t)k + 2];
-    const double x = ((T[0] * px + T[1] * py) + T[2] * pz) + T[3];
-    const double y = ((T[4] * px + T[5] * py) + T[6] * pz) + T[7];
-    const double z = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
+    const double x = fma(T[0], px, fma(T[1], py, fma(T[2], pz, T[3])));              // same fused recipe as the estimator's votes
+    const double y = fma(T[4], px, fma(T[5], py, fma(T[6], pz, T[7])));
+    const double z = fma(T[8], px, fma(T[9], py, fma(T[10], pz, T[11])));
     const double dx = x - Q[3 * (size_t)k], dy = y - Q[3 * (size_t)k + 1], dz = z - Q[3 * (size_t)k + 2];
-    set[k] = sqrt((dx * dx + dy * dy) + dz * dz) < max_error ? 1 : 0;
+    set[k] = sqrt(fma(dx, dx, fma(dy, dy, dz * dz))) < max_error ? 1 : 0;
 }
 
 void launch_filter_points(const FilterEdgeDev* edges, int n, const double* sensors, int n_sensors, double* P, double* Q, hipStream_t s)

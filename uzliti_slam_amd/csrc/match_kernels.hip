@@ -375,12 +375,14 @@ __device__ __forceinline__ void pose_finish(const PoseAcc& a, double T[12])
 // M8 distance^2 / distance of one correspondence under T (operation order of uzlo point_dist)
 __device__ __forceinline__ double point_dist2(const double* __restrict__ pq, const double* T)
 {
+    // explicit fused multiply-adds, innermost first: the oracle's point_dist does exactly these (15 instructions per
+    // point instead of 26: the vote loop is f64-VALU-issue bound)
     const double px = pq[0], py = pq[1], pz = pq[2];
-    const double x = ((T[0] * px + T[1] * py) + T[2] * pz) + T[3];
-    const double y = ((T[4] * px + T[5] * py) + T[6] * pz) + T[7];
-    const double z = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
+    const double x = fma(T[0], px, fma(T[1], py, fma(T[2], pz, T[3])));
+    const double y = fma(T[4], px, fma(T[5], py, fma(T[6], pz, T[7])));
+    const double z = fma(T[8], px, fma(T[9], py, fma(T[10], pz, T[11])));
     const double dx = x - pq[3], dy = y - pq[4], dz = z - pq[5];
-    return (dx * dx + dy * dy) + dz * dz;
+    return fma(dx, dx, fma(dy, dy, dz * dz));
 }
 
 // smallest double s with sqrt_rn(s) >= t: then  sqrt(d2) < t  <=>  d2 < s  (sqrt_rn is monotone),
