@@ -784,7 +784,7 @@ __global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const d
 }
 
 // init = 1: first application (r = b stored, exact rg in rg_old): only the preconditioner part runs.
-// Dynamic LDS (doubles): res[levels g..L] | geo[levels g..L-1] | top rows | own-chain Dinv+geo   (ml_cg_lds_bytes)
+// Dynamic LDS (doubles): res[levels g..L] | geo[levels g..L-1] | top rows | own-chain sibling rows + offsets   (ml_cg_lds_bytes)
 template <int AGG>
 __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
                                                       const double* __restrict__ rg_old, double* __restrict__ rg_new,

@@ -41,7 +41,7 @@ struct PgoDev {
     double* dcon;
     double* gcon;
     double* hdiag;           // [nb][36]
-    double* minv;            // [nb][36]  (H_aa + lambda I)^-1
+    double* minv;            // [nb][36]  (H_aa + lambda I)^-1   (block-Jacobi path only; the multilevel path uses MlLevel::Winv)
     double* b;               // [nb][6]
     double* x;               // PCG vectors [nb][6]
     double* r;
@@ -89,7 +89,6 @@ struct MlLevel {
     double* blk;               // [nslots][36]
     double* G;                 // [n][36]   diagonal blocks of A_l(lambda = 0)
     double* M;                 // [n][36]   diagonal blocks of P^T P chain (lambda multiplier)
-    double* Dinv;              // [n][36]   (G + lambda M)^-1
     double* geo;               // level 0: [n][12] = R^T (9), d (3); levels >= 1: [n][3] = d = c_self - c_parent
     double* cen;               // [n][3]  centroid (levels >= 1)
     double* r;                 // [n][6]  restricted residual
