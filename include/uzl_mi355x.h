@@ -477,6 +477,47 @@ int  uzl_radius_set_nodes(uzl_radius* h, int32_t n_nodes, const double* poses, c
 int  uzl_radius_query(uzl_radius* h, int32_t n_queries, const int32_t* query_nodes, int64_t cap,
                       int32_t* out_from, int32_t* out_to, int32_t* count_per_query, int64_t* n_jobs);
 
+/* ======================================================================================
+ *  Appearance-based candidate pairs  (second half)
+ *
+ *  LshSetRecognizer / FastLshSet (place_recognition/src/lsh_set_recognizer.cpp:46-310) behind
+ *  PlaceRecognizer (place_recognizer.cpp:71-215): every place's binary descriptors are cut into
+ *  key_width-byte keys (one exact-match table per byte offset 0, kw, 2 kw, ... below 32); a
+ *  query counts, per earlier place, how many (descriptor, table) keys it shares; places whose
+ *  count / tables reaches T are neighbours, best first, subject to a time gap, a k-nearest
+ *  cut and a reported-once filter.  Here the tables are open-addressing hash tables in HBM
+ *  with per-key entry lists in an append-only arena; a query is two launches (count, insert),
+ *  one lane per (descriptor, table).  Counts are integers: results equal the CPU checker's.
+ * ====================================================================================== */
+typedef struct uzl_places uzl_places;
+typedef struct uzl_places_cfg {
+    int32_t key_width;            /* 8     FastLshSet(key_width = 8), lsh_set_recognizer.h:66           */
+    int32_t min_rows_to_add;      /* 150   a frame is indexed only with more rows (:66, :111)            */
+    double  T;                    /* 10    cfg/PlaceRecognizer.cfg "T": minimum count / tables           */
+    int32_t k_nearest_neighbors;  /* 10    cfg "k_nearest_neighbors"                                     */
+    int32_t device;
+    double  min_time_gap;         /* 5.0   s, place_recognizer.cpp:90                                    */
+} uzl_places_cfg;
+void uzl_places_cfg_default(uzl_places_cfg* cfg);
+int  uzl_places_create(const uzl_places_cfg* cfg, uzl_places** out);
+void uzl_places_destroy(uzl_places* h);
+const char* uzl_places_last_error(uzl_places* h);
+/* PlaceRecognizer::searchAndAddPlace: desc = rows x bytes (bytes >= 32) descriptors of the node's FeatureData,
+ * stamp = node.stamps_.front().  neighbors (capacity cap) receives the place indices, *n_neighbors their number,
+ * *place_index the index given to this place. */
+int  uzl_places_search_and_add(uzl_places* h, const uint8_t* desc, int32_t rows, int32_t bytes, int64_t stamp_ns,
+                               int32_t cap, int32_t* neighbors, int32_t* n_neighbors, int32_t* place_index);
+/* PlaceRecognizer::addPlace */
+int  uzl_places_add(uzl_places* h, const uint8_t* desc, int32_t rows, int32_t bytes, int64_t stamp_ns, int32_t* place_index);
+/* PlaceRecognizer::searchPlace; query_place = the querying node's place index (for the reported-once filter), -1 if none */
+int  uzl_places_search(uzl_places* h, const uint8_t* desc, int32_t rows, int32_t bytes, int64_t stamp_ns, int32_t query_place,
+                       int32_t cap, int32_t* neighbors, int32_t* n_neighbors);
+/* PlaceRecognizer::removePlace: needs the descriptors the place was added with (as the reference does) */
+int  uzl_places_remove(uzl_places* h, int32_t place_index, const uint8_t* desc, int32_t rows, int32_t bytes);
+int  uzl_places_count(uzl_places* h);
+/* collision counts per place of the last search / search_and_add (parity tests); returns their number */
+int  uzl_places_last_counts(uzl_places* h, int32_t cap, int32_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ c_u8p = C.POINTER(C.c_uint8)
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("uzl_oracle_match.c", "uzl_oracle_pgo.c", "uzl_oracle_filter.c", "uzl_oracle_gate.c", "uzl_oracle_radius.c", "uzl_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("uzl_oracle_match.c", "uzl_oracle_pgo.c", "uzl_oracle_filter.c", "uzl_oracle_gate.c", "uzl_oracle_radius.c", "uzl_oracle_places.c", "uzl_oracle.h")]
     if not force and os.path.exists(_LIB_PATH) and all(
             os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH
@@ -520,3 +520,72 @@ def radius_candidates(poses, stamps_front_ns, queries, radius=0.5, new_edge_time
                                    C.c_double(new_edge_time), C.c_double(max_rotation_deg), C.c_int32(len(q)), _p(q, c_i32p),
                                    C.c_int64(cap), _p(f, c_i32p), _p(t, c_i32p), _p(cnt, c_i32p))
     return f[:tot].copy(), t[:tot].copy(), cnt[:len(q)].copy()
+
+
+# ------------------------------------------------------------------------------- appearance-based candidates (uzl_oracle_places.c)
+class PlacesCfg(C.Structure):
+    _fields_ = [("key_width", C.c_int32), ("min_rows_to_add", C.c_int32), ("T", C.c_double), ("k_nearest_neighbors", C.c_int32),
+                ("device", C.c_int32), ("min_time_gap", C.c_double)]
+
+
+class Places:
+    """CPU checker twin of uzliti_slam_amd.capi.Places."""
+
+    def __init__(self, **cfg):
+        L = lib()
+        L.uzlo_places_create.restype = C.c_void_p
+        L.uzlo_places_destroy.argtypes = [C.c_void_p]
+        for f in ("uzlo_places_search_and_add", "uzlo_places_add", "uzlo_places_search", "uzlo_places_count", "uzlo_places_last_counts", "uzlo_places_num_tables"):
+            getattr(L, f).restype = C.c_int32
+        c = PlacesCfg()
+        L.uzlo_places_cfg_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = C.c_void_p(L.uzlo_places_create(C.byref(c)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uzlo_places_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @staticmethod
+    def _d(desc):
+        d = np.ascontiguousarray(desc, np.uint8)
+        return d, (d.shape[0] if d.ndim == 2 else 0), (d.shape[1] if d.ndim == 2 else 32)
+
+    def search_and_add(self, desc, stamp_ns, cap=64):
+        d, rows, nb = self._d(desc)
+        out = np.zeros(max(cap, 1), np.int32); idx = C.c_int32()
+        n = lib().uzlo_places_search_and_add(self._h, _p(d, c_u8p) if rows else None, C.c_int32(rows), C.c_int32(nb), C.c_int64(int(stamp_ns)),
+                                             C.c_int32(cap), _p(out, c_i32p), C.byref(idx))
+        return out[:min(n, cap)].copy(), idx.value
+
+    def add(self, desc, stamp_ns):
+        d, rows, nb = self._d(desc)
+        return lib().uzlo_places_add(self._h, _p(d, c_u8p) if rows else None, C.c_int32(rows), C.c_int32(nb), C.c_int64(int(stamp_ns)))
+
+    def search(self, desc, stamp_ns, query_place=-1, cap=64):
+        d, rows, nb = self._d(desc)
+        out = np.zeros(max(cap, 1), np.int32)
+        n = lib().uzlo_places_search(self._h, _p(d, c_u8p) if rows else None, C.c_int32(rows), C.c_int32(nb), C.c_int64(int(stamp_ns)),
+                                     C.c_int32(query_place), C.c_int32(cap), _p(out, c_i32p))
+        return out[:min(n, cap)].copy()
+
+    def remove(self, place, desc):
+        d, rows, nb = self._d(desc)
+        lib().uzlo_places_remove(self._h, C.c_int32(place), _p(d, c_u8p) if rows else None, C.c_int32(rows), C.c_int32(nb))
+
+    def count(self):
+        return lib().uzlo_places_count(self._h)
+
+    def num_tables(self):
+        return lib().uzlo_places_num_tables(self._h)
+
+    def last_counts(self):
+        n = lib().uzlo_places_last_counts(self._h, C.c_int32(0), None)
+        out = np.zeros(max(n, 1), np.int32)
+        lib().uzlo_places_last_counts(self._h, C.c_int32(len(out)), _p(out, c_i32p))
+        return out[:n]

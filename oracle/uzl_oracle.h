@@ -213,6 +213,25 @@ int64_t uzlo_radius_candidates(int32_t n, const double* poses, const int64_t* st
                                double max_rotation_deg, int32_t nq, const int32_t* queries, int64_t cap, int32_t* out_from,
                                int32_t* out_to, int32_t* count_per_query);
 
+/* ---------------- appearance-based candidates (uzl_oracle_places.c): FastLshSet / LshSetRecognizer / PlaceRecognizer ---------
+ * lsh_set_recognizer.cpp:46-310, place_recognizer.cpp:71-215.  Same cfg layout as include/uzl_mi355x.h. */
+typedef struct uzlo_places uzlo_places;
+typedef struct uzlo_places_cfg {
+    int32_t key_width, min_rows_to_add; double T; int32_t k_nearest_neighbors, device; double min_time_gap;
+} uzlo_places_cfg;
+void uzlo_places_cfg_default(uzlo_places_cfg* c);
+uzlo_places* uzlo_places_create(const uzlo_places_cfg* cfg);
+void uzlo_places_destroy(uzlo_places* h);
+int32_t uzlo_places_search_and_add(uzlo_places* h, const uint8_t* desc, int32_t rows, int32_t bytes, int64_t stamp_ns, int32_t cap,
+                                   int32_t* neighbors, int32_t* place_index);
+int32_t uzlo_places_add(uzlo_places* h, const uint8_t* desc, int32_t rows, int32_t bytes, int64_t stamp_ns);
+int32_t uzlo_places_search(uzlo_places* h, const uint8_t* desc, int32_t rows, int32_t bytes, int64_t stamp_ns, int32_t id_q,
+                           int32_t cap, int32_t* neighbors);
+void uzlo_places_remove(uzlo_places* h, int32_t id, const uint8_t* desc, int32_t rows, int32_t bytes);
+int32_t uzlo_places_count(const uzlo_places* h);
+int32_t uzlo_places_num_tables(const uzlo_places* h);
+int32_t uzlo_places_last_counts(const uzlo_places* h, int32_t cap, int32_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,3 +136,113 @@ def test_online_run_gpu_equals_oracle(capi, oracle):
     err1 = np.linalg.norm(G[-1]["poses"][:, :, 3] - run["gt"][:, :, 3], axis=1).mean()
     assert err1 < 0.75 * err0, (err0, err1)
     m.close(); pgo.close()
+
+
+def test_online_run_with_candidate_producers(capi, oracle):
+    """The same chain with its front end attached: the node pairs are not given but produced, per new node, by the distance
+    search (getNodesWithinRadius + filters) and by appearance (LSH place recognition), each on its own back end."""
+    run = synth.make_slam_run(120, seed=77, flip_p=0.003, alias_frac=0.0)
+    N = len(run["frames"])
+    stamps = np.array([int(s[0]) for s in run["stamps"]], np.int64)
+    rounds = np.array_split(np.arange(N), 4)
+    RAD = dict(radius=1.0, new_edge_time=5.0, max_rotation_deg=30.0)
+
+    def backend(kind):
+        if kind == "gpu":
+            m = capi.Match(ransac_threshold=CFG["ransac_threshold"], ransac_iteration=CFG["ransac_iteration"],
+                           ransac_break_percentage=CFG["ransac_break_percentage"], do_prosac=1, seed=CFG["seed"])
+            fid = [m.add_frame(f["desc"], f["pos"], f["valid"]) for f in run["frames"]]
+            pgo = capi.Pgo(); rad = capi.Radius(**RAD); places = capi.Places(); filt = capi.Filter(min_size=6.0, seed=CFG["seed"]); gate = capi.Gate(**GATE)
+
+            def radius(poses, q):
+                rad.set_nodes(poses.reshape(-1, 12), stamps)
+                f, t, _, _ = rad.query(q)
+                return list(zip(f.tolist(), t.tolist()))
+
+            def estimate(pairs, ids):
+                out, _ = m.estimate([(fid[a], fid[b]) for a, b in pairs], job_ids=ids)
+                return [dict(ok=int(o["ok"]), consensus=int(o["consensus"]), T=o["T"].copy(), information=o["information"].copy()) for o in out]
+
+            def solve(poses, edges):
+                pgo.add_graph(poses.reshape(-1, 12), run["fixed"], edges, sensors=run["sensor"].reshape(1, 12))
+                assert pgo.optimize(LM_ITERS)["status"] == 0
+                return pgo.store()[0]
+        else:
+            places = oracle.Places(); filt = oracle.Filter(min_size=6.0, seed=CFG["seed"]); gate = oracle.Gate(**GATE)
+
+            def radius(poses, q):
+                f, t, _ = oracle.radius_candidates(poses.reshape(-1, 12), stamps, q, **RAD)
+                return list(zip(f.tolist(), t.tolist()))
+
+            def estimate(pairs, ids):
+                out = []
+                for (a, b), k in zip(pairs, ids):
+                    e = oracle.estimate_edge([run["frames"][a]], [run["frames"][b]], ransac_threshold=CFG["ransac_threshold"],
+                                             ransac_iteration=CFG["ransac_iteration"], break_percentage=CFG["ransac_break_percentage"],
+                                             do_prosac=True, seed=CFG["seed"], job_id=int(k))
+                    out.append(dict(ok=int(e["ok"]), consensus=int(e["consensus"]), T=np.asarray(e["T"]).reshape(12),
+                                    information=np.asarray(e["information"]).reshape(36)))
+                return out
+
+            def solve(poses, edges):
+                fl = oracle.flatten_graph(poses.reshape(-1, 12), run["fixed"], edges, sensors=run["sensor"].reshape(1, 12))
+                fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+                return oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=LM_ITERS)[0]
+        filt.set_sensors(run["sensor"].reshape(1, 12))
+        return dict(radius=radius, places=places, estimate=estimate, solve=solve, filt=filt, gate=gate)
+
+    def play(B):
+        poses = run["init"].copy()
+        feat, log, sticky, job = [], [], set(), 0
+        o = run["odo"]
+        for nodes in rounds:
+            # ---- producers, node by node
+            pairs = []
+            near = B["radius"](poses, nodes.astype(np.int32))
+            for j in nodes:
+                nb, idx = B["places"].search_and_add(run["frames"][j]["desc"], stamps[j])
+                assert idx == j
+                cand = [(int(n), int(j)) for n in nb] + [(c, q) for c, q in near if q == j and c < j]
+                for pr in cand:
+                    if pr not in pairs:
+                        pairs.append(pr)
+            ids = list(range(job, job + len(pairs))); job += len(pairs)
+            res = B["estimate"](pairs, ids) if pairs else []
+            ge = capi.gate_edges(np.concatenate([o["from"], [f["node_from"] for f in feat]]).astype(int),
+                                 np.concatenate([o["to"], [f["node_to"] for f in feat]]).astype(int),
+                                 np.concatenate([o["type"], np.ones(len(feat), int)]).astype(int),
+                                 valid=np.concatenate([np.ones(len(o["from"]), int), [1 if f["key"] in sticky else 0 for f in feat]]).astype(int))
+            B["gate"].set_graph(poses.reshape(-1, 12), ge)
+            ok = [i for i, e in enumerate(res) if e["ok"]]
+            acc = np.zeros(0, np.uint8)
+            if ok:
+                acc, _, _ = B["gate"].check(capi.gate_edges([pairs[i][0] for i in ok], [pairs[i][1] for i in ok], [1] * len(ok),
+                                                            score=[float(res[i]["consensus"]) for i in ok],
+                                                            transform=np.array([res[i]["T"] for i in ok]).reshape(-1, 12)))
+            for i, a in zip(ok, acc):
+                if a:
+                    feat.append(dict(key=ids[i], matching_score=float(res[i]["consensus"]), valid=0, sensor_from=0, sensor_to=0,
+                                     node_from=pairs[i][0], node_to=pairs[i][1], transform=np.asarray(res[i]["T"]).reshape(12),
+                                     information=np.asarray(res[i]["information"]).reshape(36),
+                                     displacement_from=np.eye(3, 4).reshape(12), displacement_to=np.eye(3, 4).reshape(12)))
+            batch = []
+            for f in feat:
+                d = dict(f); d["stamps_from"] = run["stamps"][f["node_from"]]; d["stamps_to"] = run["stamps"][f["node_to"]]
+                d["pose_from"] = poses[f["node_from"]].reshape(12); d["pose_to"] = poses[f["node_to"]].reshape(12)
+                batch.append(d)
+            B["filt"].add(batch)
+            B["filt"].calc_valid_edges()
+            verdict = set(int(x) for x in B["filt"].valid_edges())
+            sticky |= verdict
+            poses = B["solve"](poses, graph_edges(run, feat, verdict)).reshape(-1, 3, 4)
+            log.append(dict(pairs=list(pairs), acc=acc.copy(), verdict=verdict, poses=poses.copy(), n_feat=len(feat)))
+        return log
+
+    G = play(backend("gpu")); O = play(backend("cpu"))
+    for r, (a, b) in enumerate(zip(G, O)):
+        assert a["pairs"] == b["pairs"], r                          # produced job lists identical
+        assert np.array_equal(a["acc"], b["acc"]) and a["verdict"] == b["verdict"] and a["n_feat"] == b["n_feat"], r
+        dt, dr = synth.pose_errors(a["poses"], b["poses"])
+        assert dt < 1e-3 and dr < 1e-4, (r, dt, dr)
+    n_pairs = sum(len(x["pairs"]) for x in G)
+    assert n_pairs > 60 and G[-1]["n_feat"] > 20, (n_pairs, G[-1]["n_feat"])

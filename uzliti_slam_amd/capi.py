@@ -165,6 +165,11 @@ class RadiusCfg(C.Structure):
                 ("device", C.c_int32), ("_pad", C.c_int32)]
 
 
+class PlacesCfg(C.Structure):
+    _fields_ = [("key_width", C.c_int32), ("min_rows_to_add", C.c_int32), ("T", C.c_double), ("k_nearest_neighbors", C.c_int32),
+                ("device", C.c_int32), ("min_time_gap", C.c_double)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 
 _lib = None
@@ -198,6 +203,13 @@ def lib():
             L.uzl_pgo_destroy.restype = None
             L.uzl_pgo_destroy.argtypes = [C.c_void_p]
             L.uzl_pgo_cfg_default.restype = None
+        if hasattr(L, "uzl_places_create"):
+            L.uzl_places_last_error.restype = C.c_char_p
+            L.uzl_places_last_error.argtypes = [C.c_void_p]
+            L.uzl_places_destroy.restype = None
+            L.uzl_places_destroy.argtypes = [C.c_void_p]
+            L.uzl_places_cfg_default.restype = None
+            L.uzl_places_count.argtypes = [C.c_void_p]
         if hasattr(L, "uzl_radius_create"):
             L.uzl_radius_last_error.restype = C.c_char_p
             L.uzl_radius_last_error.argtypes = [C.c_void_p]
@@ -641,3 +653,70 @@ class Radius:
                                            _p(cnt, c_i32p), C.byref(tot)))
         w = min(tot.value, cap)
         return f[:w].copy(), t[:w].copy(), cnt[:len(q)].copy(), tot.value
+
+
+# --------------------------------------------------------------------------------------- appearance-based candidates
+class Places:
+    """uzl_places_* (FastLshSet / LshSetRecognizer / PlaceRecognizer, place_recognition/src)."""
+
+    def __init__(self, **cfg):
+        L = lib()
+        c = PlacesCfg()
+        L.uzl_places_cfg_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = C.c_void_p()
+        rc = L.uzl_places_create(C.byref(c), C.byref(self._h))
+        if rc != UZL_OK:
+            raise UzlError(rc, L.uzl_status_string(rc).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uzl_places_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise UzlError(rc, lib().uzl_places_last_error(self._h).decode())
+        return rc
+
+    @staticmethod
+    def _d(desc):
+        d = np.ascontiguousarray(desc, np.uint8)
+        return d, (d.shape[0] if d.ndim == 2 else 0), (d.shape[1] if d.ndim == 2 else 32)
+
+    def search_and_add(self, desc, stamp_ns, cap=64):
+        d, rows, nb = self._d(desc)
+        out = np.zeros(max(cap, 1), np.int32); n = C.c_int32(); idx = C.c_int32()
+        self._check(lib().uzl_places_search_and_add(self._h, _p(d, c_u8p) if rows else None, C.c_int32(rows), C.c_int32(nb), C.c_int64(int(stamp_ns)),
+                                                    C.c_int32(cap), _p(out, c_i32p), C.byref(n), C.byref(idx)))
+        return out[:min(n.value, cap)].copy(), idx.value
+
+    def add(self, desc, stamp_ns):
+        d, rows, nb = self._d(desc)
+        idx = C.c_int32()
+        self._check(lib().uzl_places_add(self._h, _p(d, c_u8p) if rows else None, C.c_int32(rows), C.c_int32(nb), C.c_int64(int(stamp_ns)), C.byref(idx)))
+        return idx.value
+
+    def search(self, desc, stamp_ns, query_place=-1, cap=64):
+        d, rows, nb = self._d(desc)
+        out = np.zeros(max(cap, 1), np.int32); n = C.c_int32()
+        self._check(lib().uzl_places_search(self._h, _p(d, c_u8p) if rows else None, C.c_int32(rows), C.c_int32(nb), C.c_int64(int(stamp_ns)),
+                                            C.c_int32(query_place), C.c_int32(cap), _p(out, c_i32p), C.byref(n)))
+        return out[:min(n.value, cap)].copy()
+
+    def remove(self, place, desc):
+        d, rows, nb = self._d(desc)
+        self._check(lib().uzl_places_remove(self._h, C.c_int32(place), _p(d, c_u8p) if rows else None, C.c_int32(rows), C.c_int32(nb)))
+
+    def count(self):
+        return self._check(lib().uzl_places_count(self._h))
+
+    def last_counts(self):
+        n = self._check(lib().uzl_places_last_counts(self._h, C.c_int32(0), None))
+        out = np.zeros(max(n, 1), np.int32)
+        self._check(lib().uzl_places_last_counts(self._h, C.c_int32(len(out)), _p(out, c_i32p)))
+        return out[:n]
