@@ -103,6 +103,8 @@ struct MlDev {
     double* tmpG;              // [max n][36]
     double* tmpM;              // [max n][36]
     double* top_inv;           // [(6 n_top)^2] dense inverse of A_L(lambda)
+    double* mAP; double* mQ; double* mQY;   // composite path, level 1: [n_1][n_2][36] scratch of the multiplicative operator
+    double* mAS;               // [n_1][n_1][36]
     double* Ydense[kMlMaxLevels + 1];   // composite path: Y_l = dense (6 n_l)^2 operator "residual of level l -> correction of
                                // level l" of the whole hierarchy above, 1 <= l < L (Y_L = top_inv); null otherwise
     double* Sg;                // [n_g][6] restriction of A p at the gather level (written by ml_spmv)

@@ -40,6 +40,7 @@ void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream
 void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
 void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s);
+void k_ml_mult_level1(const PgoDev& D, const MlDev* ml, int n1, int n2, hipStream_t s);
 int g_ml_rows(int nb, int agg);
 size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
 bool ml_fits_lds(const int* n_per_level, int levels, int agg);
@@ -89,7 +90,8 @@ struct uzl_pgo {
     std::vector<int32_t> ml_n, ml_nslots;
     int ml_inner_aggs = 0;
     bool ml_trial_setup = false;     // the preconditioner's per-trial part (sibling inverses, top, dense levels) is due
-    bool ml_comp = false;            // small graphs: hierarchy above level 1 folded into a dense operator (pgo_ml_kernels.hip)
+    bool ml_comp = false;
+    bool ml_mult = false;            // level 1 of the composite operator is multiplicative (pgo_ml_kernels.hip)            // small graphs: hierarchy above level 1 folded into a dense operator (pgo_ml_kernels.hip)
     double* ml_rg[2] = {nullptr, nullptr};     // double-buffered gather-level residual
     std::vector<int32_t> ml_fan;
     int ml_agg = 4;                            // level-1 aggregates per PCG workgroup (1: small graphs, 4: large)
@@ -330,6 +332,10 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     h->ml_comp = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 960;
     std::vector<size_t> o_dense((size_t)L + 1, 0);
     if (h->ml_comp) for (int l = 1; l < L; l++) o_dense[l] = take((size_t)(6 * h->ml_n[l]) * (size_t)(6 * h->ml_n[l]) * 8);
+    static const bool mult_off = getenv("UZL_ML_ADDITIVE") != nullptr;                 // A/B switch
+    h->ml_mult = h->ml_comp && !mult_off;
+    const size_t n12 = h->ml_mult ? (size_t)h->ml_n[1] * h->ml_n[2] * 36 * 8 : 0, n11 = h->ml_mult ? (size_t)h->ml_n[1] * h->ml_n[1] * 36 * 8 : 0;
+    const size_t o_mAP = take(n12), o_mQ = take(n12), o_mQY = take(n12), o_mAS = take(n11);
     const size_t o_tmp = take(max_contrib * 36 * 8), o_tmpG = take(max_n * 36 * 8), o_tmpM = take(max_n * 36 * 8);
     const size_t o_top = take((size_t)(6 * kMlTopMax) * (6 * kMlTopMax) * 8);
     const int gl = (h->ml_agg == 1 || L < 2) ? 1 : 2;
@@ -375,6 +381,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     M.tmpM = reinterpret_cast<double*>(base + o_tmpM);
     M.top_inv = reinterpret_cast<double*>(base + o_top);
     for (int l = 1; l < L; l++) M.Ydense[l] = h->ml_comp ? reinterpret_cast<double*>(base + o_dense[l]) : nullptr;
+    M.mAP = reinterpret_cast<double*>(base + o_mAP); M.mQ = reinterpret_cast<double*>(base + o_mQ);
+    M.mQY = reinterpret_cast<double*>(base + o_mQY); M.mAS = reinterpret_cast<double*>(base + o_mAS);
     M.Sg = reinterpret_cast<double*>(base + o_sg);
     h->ml_rg[0] = reinterpret_cast<double*>(base + o_rga);
     h->ml_rg[1] = reinterpret_cast<double*>(base + o_rgb);
@@ -555,7 +563,11 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     if (h->ml_levels > 0) {
         if (h->ml_trial_setup) {
             { Timed t(h, "ml_sibling"); k_ml_sibling(D, h->d_ml.p, h->ml_inner_aggs, s); }
-            if (h->ml_comp) { Timed t(h, "ml_dense"); for (int l = h->ml_levels - 1; l >= 1; l--) k_ml_dense_level(h->d_ml.p, l, h->ml_n[l], s); }
+            if (h->ml_comp) {
+                Timed t(h, "ml_dense");
+                for (int l = h->ml_levels - 1; l >= (h->ml_mult ? 2 : 1); l--) k_ml_dense_level(h->d_ml.p, l, h->ml_n[l], s);
+                if (h->ml_mult) k_ml_mult_level1(D, h->d_ml.p, h->ml_n[1], h->ml_n[2], s);
+            }
             h->ml_trial_setup = false;
         }
         { Timed t(h, "pcg_init"); k_ml_init(D, h->ml_hot, h->ml_agg, h->d_p.p, h->d_p2.p, h->ml_rg[0], s); }
