@@ -481,6 +481,16 @@ __device__ __forceinline__ void mm6_acc(const double* __restrict__ A, int lda, c
             C[r * 6 + c] += sgn * s;
         }
 }
+__device__ __forceinline__ void mr6_acc(const double* __restrict__ Arow, const double* __restrict__ B, int ldb, double* c6, double sgn)
+{                                                                              // c6 += sgn * Arow(1x6) * B(6x6, ld ldb)
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        double s = 0.;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += Arow[k] * B[k * ldb + c];
+        c6[c] += sgn * s;
+    }
+}
 // diagonal block D_i = G_i + lambda M_i of A_1
 __device__ __forceinline__ void diag6(const MlLevel& F, int i, double lambda, double* Dm)
 {
@@ -507,10 +517,8 @@ __global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev*
         pmat6(F.geo + (size_t)i * 3, Pm);
         mm6_acc(Dm, 6, Pm, 6, acc, 1.);
     }
-    for (int s = F.row_ptr[i]; s < F.row_ptr[i + 1]; s++) {
-        const int j = F.col[s];
-        if (j < 0 || j / fan != p) continue;
-        pmat6(F.geo + (size_t)j * 3, Pm);
+    for (int s = ml.grp_beg[t]; s < ml.grp_end[t]; s++) {              // the slots of row i whose column is a child of p
+        pmat6(F.geo + (size_t)F.col[s] * 3, Pm);
         mm6_acc(F.blk + (size_t)s * 36, 6, Pm, 6, acc, 1.);
     }
     double* o = ml.mAP + (size_t)t * 36;
@@ -518,48 +526,54 @@ __global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev*
     for (int k = 0; k < 36; k++) o[k] = acc[k];
 }
 
-// Q[i][p] = P_i [p == parent(i)] - sum_{j in siblings(i)} S_ij AP[j][p]
+// Q[i][p] = P_i [p == parent(i)] - sum_{j in siblings(i)} S_ij AP[j][p]          (one lane per block ROW: 6x the lanes)
 __global__ __launch_bounds__(kBlk) void ml_mult_q_kernel(const MlDev* __restrict__ mlp)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[1];
     const int n = F.n, np = ml.lv[2].n, fan = ml.lv[2].fan, m = 6 * fan;
-    const int t = blockIdx.x * kBlk + threadIdx.x;
-    if (t >= n * np) return;
+    const int tt = blockIdx.x * kBlk + threadIdx.x;
+    if (tt >= n * np * 6) return;
+    const int t = tt / 6, r = tt % 6;
     const int i = t / np, p = t % np, g = i / fan;
-    double acc[36];
-    if (g == p) pmat6(F.geo + (size_t)i * 3, acc);
-    else {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    if (g == p) {
+        double Pm[36];
+        pmat6(F.geo + (size_t)i * 3, Pm);
 #pragma unroll
-        for (int k = 0; k < 36; k++) acc[k] = 0.;
+        for (int c = 0; c < 6; c++) {
+            double v = 0.;
+#pragma unroll
+            for (int k = 0; k < 6; k++) v = (k == r) ? Pm[k * 6 + c] : v;
+            acc[c] = v;
+        }
     }
-    const double* __restrict__ W = F.Winv + (size_t)g * m * m + (size_t)((i % fan) * 6) * m;
+    const double* __restrict__ W = F.Winv + (size_t)g * m * m + (size_t)((i % fan) * 6 + r) * m;
     for (int q = 0; q < fan; q++) {
         const int j = g * fan + q;
         if (j >= n) break;
-        mm6_acc(W + q * 6, m, ml.mAP + ((size_t)j * np + p) * 36, 6, acc, -1.);
+        mr6_acc(W + q * 6, ml.mAP + ((size_t)j * np + p) * 36, 6, acc, -1.);
     }
-    double* o = ml.mQ + (size_t)t * 36;
+    double* o = ml.mQ + (size_t)t * 36 + r * 6;
 #pragma unroll
-    for (int k = 0; k < 36; k++) o[k] = acc[k];
+    for (int c = 0; c < 6; c++) o[c] = acc[c];
 }
 
-// QY[i][p] = sum_p' Q[i][p'] Y_2[p'][p]
+// QY[i][p] = sum_p' Q[i][p'] Y_2[p'][p]                                           (one lane per block row)
 __global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restrict__ mlp)
 {
     const MlDev& ml = *mlp;
     const int n = ml.lv[1].n, np = ml.lv[2].n, np6 = 6 * np;
-    const int t = blockIdx.x * kBlk + threadIdx.x;
-    if (t >= n * np) return;
+    const int tt = blockIdx.x * kBlk + threadIdx.x;
+    if (tt >= n * np * 6) return;
+    const int t = tt / 6, r = tt % 6;
     const int i = t / np, p = t % np;
     const double* __restrict__ Y2 = (ml.levels == 2) ? ml.top_inv : ml.Ydense[2];
-    double acc[36];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int pp = 0; pp < np; pp++) mr6_acc(ml.mQ + ((size_t)i * np + pp) * 36 + r * 6, Y2 + (size_t)(6 * pp) * np6 + 6 * p, np6, acc, 1.);
+    double* o = ml.mQY + (size_t)t * 36 + r * 6;
 #pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = 0.;
-    for (int pp = 0; pp < np; pp++) mm6_acc(ml.mQ + ((size_t)i * np + pp) * 36, 6, Y2 + (size_t)(6 * pp) * np6 + 6 * p, np6, acc, 1.);
-    double* o = ml.mQY + (size_t)t * 36;
-#pragma unroll
-    for (int k = 0; k < 36; k++) o[k] = acc[k];
+    for (int c = 0; c < 6; c++) o[c] = acc[c];
 }
 
 // AS[j][i'] = sum_{j' in siblings(i')} A_jj' S_j'i'
@@ -581,25 +595,25 @@ __global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev*
         diag6(F, j, lambda, Dm);
         mm6_acc(Dm, 6, W + (size_t)((j % fan) * 6) * m, m, acc, 1.);
     }
-    for (int s = F.row_ptr[j]; s < F.row_ptr[j + 1]; s++) {
-        const int jp = F.col[s];
-        if (jp < 0 || jp / fan != gp) continue;
-        mm6_acc(F.blk + (size_t)s * 36, 6, W + (size_t)((jp % fan) * 6) * m, m, acc, 1.);
-    }
+    const int np = ml.lv[2].n;
+    for (int s = ml.grp_beg[(size_t)j * np + gp]; s < ml.grp_end[(size_t)j * np + gp]; s++)
+        mm6_acc(F.blk + (size_t)s * 36, 6, W + (size_t)((F.col[s] % fan) * 6) * m, m, acc, 1.);
     double* o = ml.mAS + (size_t)t * 36;
 #pragma unroll
     for (int k = 0; k < 36; k++) o[k] = acc[k];
 }
 
 // Y_1[i][i'] = 2 S_ii' - sum_{j in siblings(i)} S_ij AS[j][i'] + sum_p QY[i][p] Q[i'][p]^T
-__global__ __launch_bounds__(kBlk) void ml_mult_final_kernel(const MlDev* __restrict__ mlp)
+__global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restrict__ mlp)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[1];
     const int n = F.n, np = ml.lv[2].n, fan = ml.lv[2].fan, m = 6 * fan;
-    const int t = blockIdx.x * kBlk + threadIdx.x;
-    if (t >= n * n) return;
-    const int i = t / n, ip = t % n, g = i / fan, gp = ip / fan;
+    // one 64-lane workgroup per (group, group') tile of fan x fan blocks: the tile's rows of QY / Q / AS are shared
+    // through L1 instead of being fetched once per block from L2
+    const int g = blockIdx.x / np, gp = blockIdx.x % np;
+    const int i = g * fan + (int)threadIdx.x / fan, ip = gp * fan + (int)threadIdx.x % fan;
+    if ((int)threadIdx.x >= fan * fan || i >= n || ip >= n) return;
     const double* __restrict__ Wi = F.Winv + (size_t)g * m * m + (size_t)((i % fan) * 6) * m;
     double acc[36];
 #pragma unroll
@@ -1406,9 +1420,10 @@ void k_ml_mult_level1(const PgoDev& D, const MlDev* ml, int n1, int n2, hipStrea
     const int g12 = (n1 * n2 + kBlk - 1) / kBlk, g11 = (n1 * n1 + kBlk - 1) / kBlk;
     hipLaunchKernelGGL(ml_mult_ap_kernel, dim3(g12), dim3(kBlk), 0, s, D, ml);
     hipLaunchKernelGGL(ml_mult_as_kernel, dim3(g11), dim3(kBlk), 0, s, D, ml);
-    hipLaunchKernelGGL(ml_mult_q_kernel, dim3(g12), dim3(kBlk), 0, s, ml);
-    hipLaunchKernelGGL(ml_mult_qy_kernel, dim3(g12), dim3(kBlk), 0, s, ml);
-    hipLaunchKernelGGL(ml_mult_final_kernel, dim3(g11), dim3(kBlk), 0, s, ml);
+    const int g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk;
+    hipLaunchKernelGGL(ml_mult_q_kernel, dim3(g12r), dim3(kBlk), 0, s, ml);
+    hipLaunchKernelGGL(ml_mult_qy_kernel, dim3(g12r), dim3(kBlk), 0, s, ml);
+    hipLaunchKernelGGL(ml_mult_final_kernel, dim3(n2 * n2), dim3(64), 0, s, ml);
 }
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s)
 {

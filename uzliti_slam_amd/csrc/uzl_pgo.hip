@@ -336,6 +336,22 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     h->ml_mult = h->ml_comp && !mult_off;
     const size_t n12 = h->ml_mult ? (size_t)h->ml_n[1] * h->ml_n[2] * 36 * 8 : 0, n11 = h->ml_mult ? (size_t)h->ml_n[1] * h->ml_n[1] * 36 * 8 : 0;
     const size_t o_mAP = take(n12), o_mQ = take(n12), o_mQY = take(n12), o_mAS = take(n11);
+    std::vector<int32_t> grp;                                       // [n1*n2] begin | [n1*n2] end
+    size_t o_grp = 0;
+    if (h->ml_mult) {
+        const int n1 = h->ml_n[1], n2 = h->ml_n[2], fan2 = h->ml_fan[2];
+        grp.assign((size_t)2 * n1 * n2, 0);
+        for (int i = 0; i < n1; i++) {
+            int s = lv[1].row_ptr[i];
+            const int send = lv[1].row_ptr[i + 1];
+            for (int p = 0; p < n2; p++) {
+                grp[(size_t)i * n2 + p] = s;
+                while (s < send && lv[1].col[s] / fan2 == p) s++;
+                grp[(size_t)n1 * n2 + (size_t)i * n2 + p] = s;
+            }
+        }
+        o_grp = take(grp.size() * 4);
+    }
     const size_t o_tmp = take(max_contrib * 36 * 8), o_tmpG = take(max_n * 36 * 8), o_tmpM = take(max_n * 36 * 8);
     const size_t o_top = take((size_t)(6 * kMlTopMax) * (6 * kMlTopMax) * 8);
     const int gl = (h->ml_agg == 1 || L < 2) ? 1 : 2;
@@ -381,6 +397,11 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     M.tmpM = reinterpret_cast<double*>(base + o_tmpM);
     M.top_inv = reinterpret_cast<double*>(base + o_top);
     for (int l = 1; l < L; l++) M.Ydense[l] = h->ml_comp ? reinterpret_cast<double*>(base + o_dense[l]) : nullptr;
+    if (h->ml_mult) {
+        UZL_HIP(hipMemcpyAsync(base + o_grp, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, s));
+        M.grp_beg = reinterpret_cast<const int32_t*>(base + o_grp);
+        M.grp_end = M.grp_beg + (size_t)h->ml_n[1] * h->ml_n[2];
+    }
     M.mAP = reinterpret_cast<double*>(base + o_mAP); M.mQ = reinterpret_cast<double*>(base + o_mQ);
     M.mQY = reinterpret_cast<double*>(base + o_mQY); M.mAS = reinterpret_cast<double*>(base + o_mAS);
     M.Sg = reinterpret_cast<double*>(base + o_sg);
@@ -637,7 +658,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     // optimizer_.optimize(iterations) (:148) -> OptimizationAlgorithmLevenberg::solve [EXT]
     double lambda = 0., ni = 2., current_chi = 0.;
     static const bool always_refresh = getenv("UZL_ML_ALWAYS_REFRESH") != nullptr;      // A/B switch
-    const double refresh_rel = 1e-3;
+    static const double refresh_rel = getenv("UZL_ML_REFRESH_REL") ? atof(getenv("UZL_ML_REFRESH_REL")) : 1e-3;
     double last_rel = 1e300;
     int pcg_ref = 1 << 30, pcg_last = 0;
     for (int it = 0; it < iterations; it++) {
