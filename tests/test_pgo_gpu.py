@@ -305,3 +305,16 @@ def test_rejected_trials_multi_edges_and_hub(capi, oracle):
     assert abs(st["chi2_final"] - so["chi2_final"]) <= 1e-6 * so["chi2_final"]
     dt, dr = synth.pose_errors(poses.reshape(-1, 3, 4), P.reshape(-1, 3, 4))
     assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+
+
+@pytest.mark.parametrize("n", [16, 64, 100, 750, 959])
+def test_ns_gemm_matrix_core_layout(capi, n):
+    """the f64 MFMA tile kernel of the Newton-Schulz refinement (X' = 2 X - X T) against numpy, including edge tiles"""
+    import ctypes
+    rng = np.random.default_rng(n)
+    X = rng.normal(size=(n, n)); T = rng.normal(size=(n, n)); out = np.zeros((n, n))
+    f64p = ctypes.POINTER(ctypes.c_double)
+    rc = capi.lib().uzl_debug_ns_gemm(ctypes.c_int(n), X.ctypes.data_as(f64p), T.ctypes.data_as(f64p), out.ctypes.data_as(f64p))
+    assert rc == 0
+    want = 2 * X - X @ T
+    assert np.abs(out - want).max() <= 1e-11 * np.abs(want).max()

@@ -642,6 +642,112 @@ __global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restri
     for (int k = 0; k < 36; k++) Y[(size_t)(6 * i + k / 6) * n6 + 6 * ip + k % 6] = acc[k];
 }
 
+// ---- composite path: Newton-Schulz refinement  X <- 2 X - X A_1 X  of the dense level-1 operator (X = Y_1 is already a
+//      good approximate inverse of A_1: one step squares the error of the cycle, two make it exact to PCG's eyes).
+//      ml_ns_ax_kernel:   T = A_1 X        block-sparse (6x6 blocks) times dense, one lane per (row block, column)
+//      ml_ns_gemm_kernel: X' = 2 X - X T   dense f64 GEMM on the matrix cores (2 n^3 flops, n = 6 n_1 <= 960)
+__global__ __launch_bounds__(kBlk) void ml_ns_ax_kernel(PgoDev D, const MlDev* __restrict__ mlp, const double* __restrict__ X,
+                                                       double* __restrict__ T)
+{
+    const MlDev& ml = *mlp;
+    const MlLevel& F = ml.lv[1];
+    const int n = F.n, n6 = 6 * n;
+    const int t = blockIdx.x * kBlk + threadIdx.x;
+    if (t >= n * n6) return;
+    const int i = t / n6, c = t % n6;
+    const double lambda = D.scal[3];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    {
+        double x[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) x[k] = X[(size_t)(6 * i + k) * n6 + c];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) acc[r] += (F.G[(size_t)i * 36 + r * 6 + k] + lambda * F.M[(size_t)i * 36 + r * 6 + k]) * x[k];
+    }
+    for (int s = F.row_ptr[i]; s < F.row_ptr[i + 1]; s++) {
+        const int j = F.col[s];
+        const double* __restrict__ b = F.blk + (size_t)s * 36;
+        double x[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) x[k] = X[(size_t)(6 * j + k) * n6 + c];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) acc[r] += b[r * 6 + k] * x[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) T[(size_t)(6 * i + r) * n6 + c] = acc[r];
+}
+
+constexpr int kGemmTile = 64, kGemmK = 16;
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+// X' = 2 X - X T on the f64 matrix cores: v_mfma_f64_16x16x4_f64 (lane l feeds A[row l&15][k l>>4] and B[k l>>4][col l&15];
+// the four results of a lane are C[row (l>>4) + 4 r][col l&15], r = 0..3).  A 256-lane workgroup owns a 64 x 64 tile, each
+// of its four waves a 32 x 32 quarter as 2 x 2 MFMA tiles; K is staged through LDS in slabs of 16 (coalesced global
+// reads; one LDS double per MFMA operand, padded rows: no bank pile-up); the next slab is fetched into registers
+// while the matrix cores work on the current one (one workgroup per CU at this size: nothing else would hide the
+// global-load latency of the 47 dependent slabs - 136 -> 55 us at n = 750).
+__global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __restrict__ X, const double* __restrict__ T,
+                                                        double* __restrict__ Xn)
+{
+    __shared__ double sA[kGemmTile][kGemmK + 1];      // X tile: sA[row][k]
+    __shared__ double sB[kGemmK][kGemmTile + 1];      // T tile: sB[k][col]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row0 = blockIdx.y * kGemmTile, col0 = blockIdx.x * kGemmTile;
+    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;          // this wave's quarter
+    const int li = lane & 15, lk = lane >> 4;
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = v4f64{0., 0., 0., 0.};
+    double pa[4], pb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = u * 256 + tid;
+            const int ar = e >> 4, ak = e & 15;                                  // X: consecutive lanes walk k (contiguous in memory)
+            const int gr = row0 + ar, gk = k0 + ak;
+            pa[u] = (gr < n && gk < n) ? X[(size_t)gr * n + gk] : 0.;
+            const int bk = e >> 6, bc = e & 63;                                  // T: consecutive lanes walk the column
+            const int gk2 = k0 + bk, gc = col0 + bc;
+            pb[u] = (gk2 < n && gc < n) ? T[(size_t)gk2 * n + gc] : 0.;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < n; k0 += kGemmK) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = u * 256 + tid;
+            sA[e >> 4][e & 15] = pa[u];
+            sB[e >> 6][e & 63] = pb[u];
+        }
+        __syncthreads();
+        if (k0 + kGemmK < n) fetch(k0 + kGemmK);
+#pragma unroll
+        for (int k4 = 0; k4 < kGemmK; k4 += 4) {
+            const double a0 = sA[wr + li][k4 + lk], a1 = sA[wr + 16 + li][k4 + lk];
+            const double b0 = sB[k4 + lk][wc + li], b1 = sB[k4 + lk][wc + 16 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int gr = row0 + wr + a * 16 + lk + 4 * r, gc = col0 + wc + b * 16 + li;
+                if (gr < n && gc < n) Xn[(size_t)gr * n + gc] = 2. * X[(size_t)gr * n + gc] - acc[a][b][r];
+            }
+}
+
 // ---- per LM trial: dense inverse of the top level A_L(lambda) (<= 48 x 48), one workgroup, in LDS
 __global__ __launch_bounds__(kBlk) void ml_top_kernel(PgoDev D, const MlDev* __restrict__ mlp)
 {
@@ -1425,6 +1531,14 @@ void k_ml_mult_level1(const PgoDev& D, const MlDev* ml, int n1, int n2, hipStrea
     hipLaunchKernelGGL(ml_mult_qy_kernel, dim3(g12r), dim3(kBlk), 0, s, ml);
     hipLaunchKernelGGL(ml_mult_final_kernel, dim3(n2 * n2), dim3(64), 0, s, ml);
 }
+// one Newton-Schulz step: Xn = 2 X - X (A_1 X); T is scratch
+void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int n1, const double* X, double* T, double* Xn, hipStream_t s)
+{
+    const int n6 = 6 * n1;
+    hipLaunchKernelGGL(ml_ns_ax_kernel, dim3((n1 * n6 + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, X, T);
+    const int g = (n6 + kGemmTile - 1) / kGemmTile;
+    hipLaunchKernelGGL(ml_ns_gemm_kernel, dim3(g, g), dim3(256), 0, s, n6, X, T, Xn);
+}
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s)
 {
     if (total_aggs > 0) hipLaunchKernelGGL(ml_sibling_kernel, dim3(total_aggs), dim3(kSibBlk), 0, s, D, ml);
@@ -1500,3 +1614,21 @@ extern "C" int uzl_debug_read_stamps(unsigned long long* out, int reset)
     return 0;
 }
 #endif
+
+// test hook (not part of include/uzl_mi355x.h): out = 2 X - X T for host matrices, through ml_ns_gemm_kernel
+extern "C" int uzl_debug_ns_gemm(int n, const double* X, const double* T, double* out)
+{
+    if (n <= 0 || !X || !T || !out) return -1;
+    double *dX = nullptr, *dT = nullptr, *dO = nullptr;
+    const size_t b = (size_t)n * n * 8;
+    if (hipMalloc((void**)&dX, b) != hipSuccess || hipMalloc((void**)&dT, b) != hipSuccess || hipMalloc((void**)&dO, b) != hipSuccess) return -3;
+    (void)hipMemcpy(dX, X, b, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dT, T, b, hipMemcpyHostToDevice);
+    const int g = (n + uzl::kGemmTile - 1) / uzl::kGemmTile;
+    hipLaunchKernelGGL(uzl::ml_ns_gemm_kernel, dim3(g, g), dim3(256), 0, nullptr, n, dX, dT, dO);
+    const hipError_t e = hipDeviceSynchronize();
+    (void)hipMemcpy(out, dO, b, hipMemcpyDeviceToHost);
+    (void)hipFree(dX); (void)hipFree(dT); (void)hipFree(dO);
+    return e == hipSuccess ? 0 : -3;
+}
+

@@ -107,6 +107,7 @@ struct MlDev {
     const int32_t* grp_end;    // level-2 aggregate p (slots of a row are sorted by column, so the range is contiguous)
     double* mAP; double* mQ; double* mQY;   // composite path, level 1: [n_1][n_2][36] scratch of the multiplicative operator
     double* mAS;               // [n_1][n_1][36]
+    double* nsT; double* nsX;   // composite path: (6 n_1)^2 scratch of the Newton-Schulz refinement of Y_1
     double* Ydense[kMlMaxLevels + 1];   // composite path: Y_l = dense (6 n_l)^2 operator "residual of level l -> correction of
                                // level l" of the whole hierarchy above, 1 <= l < L (Y_L = top_inv); null otherwise
     double* Sg;                // [n_g][6] restriction of A p at the gather level (written by ml_spmv)

@@ -41,6 +41,7 @@ void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
 void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s);
 void k_ml_mult_level1(const PgoDev& D, const MlDev* ml, int n1, int n2, hipStream_t s);
+void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int n1, const double* X, double* T, double* Xn, hipStream_t s);
 int g_ml_rows(int nb, int agg);
 size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
 bool ml_fits_lds(const int* n_per_level, int levels, int agg);
@@ -91,6 +92,8 @@ struct uzl_pgo {
     int ml_inner_aggs = 0;
     bool ml_trial_setup = false;     // the preconditioner's per-trial part (sibling inverses, top, dense levels) is due
     bool ml_comp = false;
+    int ml_ns_steps = 0;             // Newton-Schulz refinements of the dense level-1 operator per rebuild
+    double* ml_ns_T = nullptr; double* ml_ns_X = nullptr; double* ml_y1 = nullptr;
     bool ml_mult = false;            // level 1 of the composite operator is multiplicative (pgo_ml_kernels.hip)            // small graphs: hierarchy above level 1 folded into a dense operator (pgo_ml_kernels.hip)
     double* ml_rg[2] = {nullptr, nullptr};     // double-buffered gather-level residual
     std::vector<int32_t> ml_fan;
@@ -336,6 +339,10 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     h->ml_mult = h->ml_comp && !mult_off;
     const size_t n12 = h->ml_mult ? (size_t)h->ml_n[1] * h->ml_n[2] * 36 * 8 : 0, n11 = h->ml_mult ? (size_t)h->ml_n[1] * h->ml_n[1] * 36 * 8 : 0;
     const size_t o_mAP = take(n12), o_mQ = take(n12), o_mQY = take(n12), o_mAS = take(n11);
+    static const int ns_env = getenv("UZL_ML_NS_STEPS") ? atoi(getenv("UZL_ML_NS_STEPS")) : 2;
+    h->ml_ns_steps = h->ml_mult ? std::max(0, std::min(ns_env, 4)) : 0;
+    const size_t nsq = h->ml_ns_steps ? (size_t)(6 * h->ml_n[1]) * (size_t)(6 * h->ml_n[1]) * 8 : 0;
+    const size_t o_nsT = take(nsq), o_nsX = take(nsq);
     std::vector<int32_t> grp;                                       // [n1*n2] begin | [n1*n2] end
     size_t o_grp = 0;
     if (h->ml_mult) {
@@ -402,6 +409,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         M.grp_beg = reinterpret_cast<const int32_t*>(base + o_grp);
         M.grp_end = M.grp_beg + (size_t)h->ml_n[1] * h->ml_n[2];
     }
+    M.nsT = reinterpret_cast<double*>(base + o_nsT); M.nsX = reinterpret_cast<double*>(base + o_nsX);
+    h->ml_ns_T = M.nsT; h->ml_ns_X = M.nsX; h->ml_y1 = h->ml_comp ? M.Ydense[1] : nullptr;
     M.mAP = reinterpret_cast<double*>(base + o_mAP); M.mQ = reinterpret_cast<double*>(base + o_mQ);
     M.mQY = reinterpret_cast<double*>(base + o_mQY); M.mAS = reinterpret_cast<double*>(base + o_mAS);
     M.Sg = reinterpret_cast<double*>(base + o_sg);
@@ -412,7 +421,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     Hh.levels = L;
     for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Winv[l] = M.lv[l].Winv; }
     Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg;
-    Hh.Cmat = h->ml_comp ? M.Ydense[1] : nullptr;
+    Hh.Cmat = h->ml_comp ? ((h->ml_ns_steps & 1) ? M.nsX : M.Ydense[1]) : nullptr;   // Newton-Schulz steps ping-pong Y_1 <-> nsX
     h->l1_span_ptr = M.lv[1].blk;
     h->l1_span = (int64_t)((M.lv[1].M + (size_t)std::max(h->ml_n[1], 1) * 36) - M.lv[1].blk);
     h->d_ml.reserve(1);
@@ -588,6 +597,8 @@ int pcg_solve(uzl_pgo* h, bool* converged)
                 Timed t(h, "ml_dense");
                 for (int l = h->ml_levels - 1; l >= (h->ml_mult ? 2 : 1); l--) k_ml_dense_level(h->d_ml.p, l, h->ml_n[l], s);
                 if (h->ml_mult) k_ml_mult_level1(D, h->d_ml.p, h->ml_n[1], h->ml_n[2], s);
+                double* xa = h->ml_y1; double* xb = h->ml_ns_X;
+                for (int k = 0; k < h->ml_ns_steps; k++) { k_ml_ns_step(D, h->d_ml.p, h->ml_n[1], xa, h->ml_ns_T, xb, s); std::swap(xa, xb); }
             }
             h->ml_trial_setup = false;
         }
