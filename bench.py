@@ -266,7 +266,7 @@ def main():
             config=dict(workload="BASELINE config 2: %d-node / %d-edge SE(3) pose graph, %d LM iterations, Huber(1) on loop closures; "
                                  "one independent graph per GPU" % (a.nodes, a.edges, a.lm_iters),
                         system_edges=st["n_edges"], lm_iterations_done=st["iterations_done"], lm_trials_per_solve=st["lm_trials"],
-                        pcg_iterations_per_solve=st["pcg_iterations"], preconditioner_builds_per_solve=st["precond_builds"], pcg_tol=pgo.cfg.pcg_tol, preconditioner=("additive multilevel, 8-vertex rigid-body aggregates" if pgo.cfg.preconditioner else "block-Jacobi"),
+                        pcg_iterations_per_solve=st["pcg_iterations"], preconditioner_builds_per_solve=st["precond_builds"], pcg_tol=pgo.cfg.pcg_tol, preconditioner=("multilevel, 8-vertex rigid-body aggregates (small graphs: dense level-1 operator, multiplicative cycle + 2 Newton-Schulz steps on the f64 matrix cores)" if pgo.cfg.preconditioner else "block-Jacobi"),
                         chi2_initial=st["chi2_initial"], chi2_final=st["chi2_final"]),
             roofline=roofline, kernels_ms_per_solve=kernels_ms, cpu_baseline=cpu, secondary=secondary)
         if sharded_c4 is not None:

@@ -94,6 +94,7 @@ struct uzl_pgo {
     bool ml_comp = false;
     int ml_ns_steps = 0;             // Newton-Schulz refinements of the dense level-1 operator per rebuild
     double* ml_ns_T = nullptr; double* ml_ns_X = nullptr; double* ml_y1 = nullptr;
+    double lambda_now = 0., ml_lambda_setup = 0.;   // lambda of the current trial / of the last trial set-up of the hierarchy
     bool ml_mult = false;            // level 1 of the composite operator is multiplicative (pgo_ml_kernels.hip)            // small graphs: hierarchy above level 1 folded into a dense operator (pgo_ml_kernels.hip)
     double* ml_rg[2] = {nullptr, nullptr};     // double-buffered gather-level residual
     std::vector<int32_t> ml_fan;
@@ -157,6 +158,7 @@ void fetch_scal(uzl_pgo* h)
 void set_lambda(uzl_pgo* h, double lambda)
 {
     k_set_scalar(h->D.scal + 3, lambda, h->stream);
+    h->lambda_now = lambda;
 }
 
 // exchange step of the sharded solve: sum `count` doubles at dev_ptr over all ranks (caller-supplied RCCL all-reduce)
@@ -601,6 +603,7 @@ int pcg_solve(uzl_pgo* h, bool* converged)
                 for (int k = 0; k < h->ml_ns_steps; k++) { k_ml_ns_step(D, h->d_ml.p, h->ml_n[1], xa, h->ml_ns_T, xb, s); std::swap(xa, xb); }
             }
             h->ml_trial_setup = false;
+            h->ml_lambda_setup = h->lambda_now;
         }
         { Timed t(h, "pcg_init"); k_ml_init(D, h->ml_hot, h->ml_agg, h->d_p.p, h->d_p2.p, h->ml_rg[0], s); }
         { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, h->d_p.p, h->ml_rg[0], h->ml_rg[1], 0, 1, h->ml_lds, s)); }
@@ -703,9 +706,17 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         do {
             set_lambda(h, lambda);                                                // setLambda
             bool conv = false;
+            // the lambda-dependent inverses of the hierarchy are kept across trials; after rejected steps lambda grows
+            // geometrically and inverses taken at a much smaller lambda stop being a preconditioner at all
+            if (h->ml_levels > 0 && lambda > 8. * h->ml_lambda_setup) h->ml_trial_setup = true;
             const bool fresh = h->ml_trial_setup;
-            const int pcg_its = pcg_solve(h, &conv);                              // _solver->solve()
+            int pcg_its = pcg_solve(h, &conv);                                    // _solver->solve()
             S.pcg_iterations += pcg_its;
+            if (!conv && !fresh && h->ml_levels > 0) {                            // stale hierarchy: retake the inverses once
+                h->ml_trial_setup = true;
+                pcg_its = pcg_solve(h, &conv);
+                S.pcg_iterations += pcg_its;
+            }
             if (fresh) pcg_ref = pcg_its;
             pcg_last = pcg_its;
             if (h->cfg.verbose)
@@ -793,6 +804,7 @@ int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
     h->cfg = c;
     memset(&h->D, 0, sizeof(h->D));
     { const char* ng = getenv("UZL_NO_GRAPH"); h->no_graph = ng && ng[0] == '1'; }
+    if (getenv("UZL_VERBOSE")) h->cfg.verbose = 1;                                    // diagnostic: per-trial PCG log on stderr
     if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return UZL_ERR_HIP;
