@@ -518,6 +518,129 @@ int  uzl_places_count(uzl_places* h);
 /* collision counts per place of the last search / search_and_add (parity tests); returns their number */
 int  uzl_places_last_counts(uzl_places* h, int32_t cap, int32_t* counts);
 
+/* ======================================================================================
+ *  Wire and disk formats  
+ *
+ *  The data formats either side of the path: graph_slam_msgs/{Edge,Node,SensorData,Features,
+ *  Feature}.msg in ROS 1 serialisation (little-endian; string = u32 length + bytes; T[] = u32 count
+ *  + elements; T[N] = elements; time / duration = two 32-bit words; bool = one byte), converted
+ *  to and from the graph objects as Conversions does (graph_slam_common/src/conversions.cpp:43-70,
+ *  217-322) and FeatureData::toMsg / fromMsg do (graph_slam_common/src/sensor_data.cpp:78-167),
+ *  and the one-message-per-file rosbag 2.0 container RosbagStorage writes and reads
+ *  (graph_slam_common/src/rosbag_storage.cpp:62-209).
+ *
+ *  Message headers and strings are host work (a few dozen fields).  The bulk of a stored graph is
+ *  the Feature[] arrays - descriptors travel as one float32 per descriptor BYTE
+ *  (sensor_data.cpp:93-110), 41 + 4 D bytes per keypoint on the wire for 25 + D bytes of content -
+ *  and those are unpacked / packed on the device, straight into / out of the estimator's frame
+ *  arena: an HBM-bound byte shuffle, one launch for any number of frames.
+ *
+ *  Poses: toMsg writes position + Eigen's Quaterniond(R) as (x,y,z,w), un-normalised sign
+ *  (conversions.cpp:57-70); fromMsg is g2o::internal::fromVectorQT = Quaterniond(w,x,y,z)
+ *  .toRotationMatrix() without normalisation (conversions.cpp:229-240,
+ *  graph_slam_common/thirdparty/src/isometry3d_mappings.cpp:131-136).
+ * ====================================================================================== */
+#define UZL_ERR_TRUNCATED   -9    /* message / file ends inside a field, or output capacity too small */
+#define UZL_ERR_UNSUPPORTED -10   /* e.g. compressed rosbag chunk, ragged descriptor lengths           */
+
+/* sensor types: graph_slam_msgs/msg/SensorData.msg:2-6 */
+#define UZL_SENSOR_TYPE_UNKNOWN     0
+#define UZL_SENSOR_TYPE_FEATURE     1
+#define UZL_SENSOR_TYPE_DEPTH_IMAGE 2
+#define UZL_SENSOR_TYPE_BINARY_GIST 3
+#define UZL_SENSOR_TYPE_LASERSCAN   4
+
+/* borrowed bytes (a string or a sub-message); not NUL-terminated */
+typedef struct uzl_span { const char* p; uint64_t n; } uzl_span;
+
+/* graph_slam_msgs/Edge <-> SlamEdge  (Conversions::fromMsg / toMsg, conversions.cpp:242-274) */
+typedef struct uzl_wire_edge {
+    uzl_span id, id_from, id_to, sensor_from, sensor_to;
+    int32_t  type;                 /* uint8 on the wire                                   */
+    int32_t  valid;                /* bool on the wire                                    */
+    double   transform[12];        /* transformation.pose                                 */
+    double   information[36];      /* transformation.covariance, row-major (:48-52,:221-226) */
+    double   displacement_from[12], displacement_to[12];
+    double   error, age, matching_score;
+    int32_t  diff_time_sec, diff_time_nsec;   /* ros::Duration                            */
+} uzl_wire_edge;
+/* bytes uzl_wire_edge_encode will write */
+uint64_t uzl_wire_edge_size(const uzl_wire_edge* e);
+int  uzl_wire_edge_encode(const uzl_wire_edge* e, uint8_t* buf, uint64_t cap, uint64_t* written);
+/* spans of *out point into buf */
+int  uzl_wire_edge_decode(const uint8_t* buf, uint64_t len, uzl_wire_edge* out, uint64_t* consumed);
+
+/* One graph_slam_msgs/SensorData inside a Node message.  Decode fills every field; `raw` is the
+ * whole sub-message (copy-through for sensor types this back end does not touch).  Encode: when
+ * raw.p != NULL the bytes are copied verbatim, otherwise a FEATURE message is written from the
+ * fields below with records = n_features Feature records (uzl_match_frame_to_wire or
+ * uzl_wire_features_pack) and camera_info (raw sensor_msgs/CameraInfo bytes; NULL = a
+ * default-constructed one); depth_image / gist / scan are written empty as SensorData::toMsg
+ * leaves them (sensor_data.cpp:40-49). */
+typedef struct uzl_wire_sensor {
+    uzl_span raw;
+    int32_t  sensor_type;
+    uint32_t stamp_sec, stamp_nsec;   /* header.stamp = SensorData::stamp_                               */
+    uzl_span sensor_frame;            /* header.frame_id: fromMsg takes sensor_frame_ from here (:56)   */
+    double   displacement[12];
+    int32_t  descriptor_type;         /* features.descriptor_type = FeatureData::feature_type_          */
+    int32_t  n_features;
+    int32_t  desc_len;                /* descriptor elements of the first feature (= bytes per row)     */
+    int32_t  uniform;                 /* 1 iff every record has desc_len elements (constant stride)     */
+    uzl_span records;                 /* the n_features Feature records, 41 + 4 desc_len bytes each     */
+    uzl_span camera_info;             /* features.camera_model                                          */
+} uzl_wire_sensor;
+
+/* graph_slam_msgs/Node <-> SlamNode  (Conversions::fromMsg / toMsg, conversions.cpp:276-322) */
+typedef struct uzl_wire_node {
+    uzl_span id;
+    double   pose[12], odom_pose[12];     /* SlamNode::pose_, sub_pose_                    */
+    int32_t  fixed;
+    int32_t  n_stamps, n_edge_ids, n_sensors;
+    double   uncertainty;
+} uzl_wire_node;
+/* Variable parts go to caller arrays: stamps (ns since epoch), edge ids, sensors; counts are always reported in
+ * *out, entries beyond a capacity are parsed but not stored. */
+int  uzl_wire_node_decode(const uint8_t* buf, uint64_t len, uzl_wire_node* out,
+                          int32_t stamp_cap, int64_t* stamps_ns, int32_t edge_cap, uzl_span* edge_ids,
+                          int32_t sensor_cap, uzl_wire_sensor* sensors, uint64_t* consumed);
+uint64_t uzl_wire_node_size(const uzl_wire_node* n, const uzl_span* edge_ids, const uzl_wire_sensor* sensors);
+int  uzl_wire_node_encode(const uzl_wire_node* n, const int64_t* stamps_ns, const uzl_span* edge_ids,
+                          const uzl_wire_sensor* sensors, uint8_t* buf, uint64_t cap, uint64_t* written);
+
+/* bytes of n Feature records with desc_len descriptor elements each */
+uint64_t uzl_wire_features_size(int32_t n, int32_t desc_len);
+
+/* FeatureData::fromMsg (sensor_data.cpp:123-167) on the device for a batch of frames: the Feature records of
+ * frame k (sensors[k].records, n_features, desc_len, descriptor_type; must be uniform and a binary descriptor
+ * type) are uploaded as they are and unpacked by one kernel into the frame arena: descriptor byte =
+ * (unsigned char) of the float (truncation, low 8 bits of the integer), position, is_3d.  sensor_frame_keys[k]
+ * stands for the sensor_frame_ string as in uzl_frame.  uv (optional, 2 x n_features int32 per frame,
+ * concatenated) receives u,v (feature_positions_2d_). */
+int  uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sensor* sensors,
+                               const int32_t* sensor_frame_keys, int32_t* frame_ids, int32_t* uv);
+/* FeatureData::toMsg (sensor_data.cpp:78-121) on the device: Feature records of a resident frame
+ * (keypoint_strength = -1 as :96; uv = 2 x n int32 or NULL for zeros). */
+int  uzl_match_frame_to_wire(uzl_match* h, int32_t frame_id, const int32_t* uv, uint8_t* records, uint64_t cap,
+                             uint64_t* written);
+/* The arena content of a frame (parity tests; desc n x bytes, pos 3 x n, valid n; any may be NULL). */
+int  uzl_match_get_frame(uzl_match* h, int32_t frame_id, uint8_t* desc, double* pos_xyz, uint8_t* valid3d,
+                         int32_t* n, int32_t* bytes_per_desc);
+
+/* ---- rosbag 2.0, as RosbagStorage uses it: one message per file (rosbag_storage.cpp:62-107) ---- */
+typedef struct uzl_bag_msg {
+    uzl_span topic, datatype, md5sum, definition;   /* from the message's connection record */
+    uzl_span data;                                  /* the serialised message                 */
+    uint32_t time_sec, time_nsec;                   /* the record's time                      */
+} uzl_bag_msg;
+/* Every message-data record of an uncompressed bag image, in file order; *n_msgs = number found (may exceed cap). */
+int  uzl_bag_read(const uint8_t* file, uint64_t len, int32_t cap, uzl_bag_msg* msgs, int32_t* n_msgs);
+/* bag.open(Write); bag.write(topic, time, msg); bag.close(): header (4096-byte padded), one chunk with the
+ * connection and the message, its index record, the connection and chunk-info records.  md5sum / definition
+ * are ros::message_traits::{MD5Sum,Definition}<M>::value() of the caller's message type. */
+uint64_t uzl_bag_single_size(const uzl_bag_msg* m);
+int  uzl_bag_write_single(const uzl_bag_msg* m, uint8_t* out, uint64_t cap, uint64_t* written);
+
 #ifdef __cplusplus
 }
 #endif

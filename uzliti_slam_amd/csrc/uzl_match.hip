@@ -5,6 +5,7 @@
 #include "uzl_common.hpp"
 #include "match_types.hpp"
 #include "match_internal.hpp"
+#include "wire_types.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -48,6 +49,8 @@ struct uzl_match {
     PinBuf<int32_t> h_cq, h_ct, h_cd; PinBuf<uint8_t> h_mask;
     DevBuf<double> d_pq_scratch, d_dist_scratch; DevBuf<uint8_t> d_mask_scratch;
     DevBuf<double> d_P, d_Q;
+    // wire batches (uzl_match_add_frames_wire / frame_to_wire): raw Feature records, segment table, u/v, error flag
+    DevBuf<uint32_t> d_wire_stage; DevBuf<WireSeg> d_wire_segs; DevBuf<int32_t> d_wire_uv; DevBuf<int32_t> d_wire_bad;
     bool in_flight = false;
     int32_t fl_jobs = 0, fl_stride = 0, fl_max_corr = 0;
     bool fl_diag = false;
@@ -300,6 +303,8 @@ const char* uzl_status_string(int status)
         case UZL_ERR_OOM: return "out of memory";
         case UZL_ERR_NOT_FOUND: return "not found";
         case UZL_ERR_STATE: return "call order violated";
+        case UZL_ERR_TRUNCATED: return "message truncated or output buffer too small";
+        case UZL_ERR_UNSUPPORTED: return "unsupported format variant";
         default: return "unknown status";
     }
 }
@@ -410,6 +415,132 @@ int uzl_match_remove_frame(uzl_match* h, int32_t frame_id)
     h->frames[frame_id].alive = false;     // arena space is reclaimed when the store empties
     if (--h->live_frames == 0 && !h->in_flight) { h->arena_used = 0; }
     return UZL_OK;
+}
+
+// FeatureData::fromMsg (sensor_data.cpp:123-167) for a batch of frames: raw Feature records go to HBM as they are and one
+// launch unpacks all of them into the arena.
+int uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sensor* sensors, const int32_t* sensor_frame_keys,
+                              int32_t* frame_ids, int32_t* uv)
+{
+    if (n_frames < 0 || (n_frames > 0 && (!sensors || !frame_ids))) return UZL_ERR_BAD_ARG;
+    UZL_GUARD_BEGIN(h)
+    if (n_frames == 0) return UZL_OK;
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    std::vector<WireSeg> segs((size_t)n_frames);
+    std::vector<FrameRec> recs((size_t)n_frames);
+    size_t off = h->arena_used;
+    uint64_t src = 0;
+    int64_t items = 0, feats = 0;
+    for (int32_t k = 0; k < n_frames; k++) {
+        const uzl_wire_sensor& f = sensors[k];
+        if (f.n_features < 0 || f.n_features > kMaxKeypoints) return fail(h, UZL_ERR_BAD_ARG, "frame.n out of range [0,16384]");
+        // binary descriptor types only (sensor_data.cpp:130-140); SURF / SIFT rows are floats and never reach the Hamming matcher
+        if (f.descriptor_type < UZL_FEATURE_BRIEF || f.descriptor_type > UZL_FEATURE_FREAK)
+            return fail(h, UZL_ERR_UNSUPPORTED, "descriptor_type is not a binary descriptor (BRIEF/ORB/BRISK/FREAK)");
+        if (f.n_features > 0) {
+            if (!f.uniform) return fail(h, UZL_ERR_UNSUPPORTED, "Feature records with differing descriptor lengths");
+            if (f.desc_len <= 0 || f.desc_len % 4 != 0 || f.desc_len > 508)
+                return fail(h, UZL_ERR_BAD_ARG, "descriptor length must be a multiple of 4 in [4,508]");
+            if (!f.records.p || f.records.n != uzl_wire_features_size(f.n_features, f.desc_len))
+                return fail(h, UZL_ERR_BAD_ARG, "records span does not hold n_features records of desc_len elements");
+        }
+        const size_t n = (size_t)f.n_features;
+        const int32_t D = f.n_features > 0 ? f.desc_len : 32;
+        off = align_up(off, 256);
+        FrameRec& r = recs[k];
+        r.desc_off = off; off = align_up(off + n * (size_t)D, 16);
+        r.pos_off = off; off = align_up(off + n * 24, 16);
+        r.valid_off = off; off += n;
+        off = align_up(off + 64, 256);
+        r.alive = true; r.n = f.n_features; r.words = D / 4;
+        r.feature_type = f.descriptor_type; r.sensor_frame = sensor_frame_keys ? sensor_frame_keys[k] : 0;
+        WireSeg& g = segs[k];
+        g.item_begin = items; g.feat_begin = feats; g.src_off = src;
+        g.desc_off = r.desc_off; g.pos_off = r.pos_off; g.valid_off = r.valid_off;
+        g.stride = (uint32_t)(41 + 4 * D); g.words = D / 4; g.n = f.n_features; g._pad = 0;
+        items += (int64_t)n * g.words; feats += (int64_t)n;
+        src = align_up(src + (n ? f.records.n : 0), 4);                           // every frame's records start dword-aligned
+    }
+    if (h->in_flight && off > h->arena.cap) return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
+    h->arena.reserve(off, /*keep=*/true, h->stream);
+    h->d_wire_stage.reserve((size_t)(src / 4) + 4);                              // + tail: the dword after the last byte may be read
+    h->d_wire_segs.reserve((size_t)n_frames);
+    h->d_wire_bad.reserve(1);
+    if (uv) h->d_wire_uv.reserve((size_t)std::max<int64_t>(2 * feats, 1));
+    for (int32_t k = 0; k < n_frames; k++)
+        if (sensors[k].n_features > 0)
+            UZL_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t*>(h->d_wire_stage.p) + segs[k].src_off, sensors[k].records.p, sensors[k].records.n,
+                                   hipMemcpyHostToDevice, h->stream));
+    UZL_HIP(hipMemcpyAsync(h->d_wire_segs.p, segs.data(), sizeof(WireSeg) * (size_t)n_frames, hipMemcpyHostToDevice, h->stream));
+    UZL_HIP(hipMemsetAsync(h->d_wire_bad.p, 0, 4, h->stream));
+    h->timer.begin("wire_unpack", h->stream);
+    launch_wire_unpack(h->d_wire_stage.p, h->arena.p, h->d_wire_segs.p, n_frames, items, uv ? h->d_wire_uv.p : nullptr, h->d_wire_bad.p, h->stream);
+    h->timer.end(h->stream);
+    UZL_HIP(hipGetLastError());
+    int32_t bad = 0;
+    UZL_HIP(hipMemcpyAsync(&bad, h->d_wire_bad.p, 4, hipMemcpyDeviceToHost, h->stream));
+    if (uv && feats) UZL_HIP(hipMemcpyAsync(uv, h->d_wire_uv.p, (size_t)feats * 8, hipMemcpyDeviceToHost, h->stream));
+    UZL_HIP(hipStreamSynchronize(h->stream));                                    // inputs are borrowed only for the duration of the call
+    h->timer.resolve();
+    if (bad) return fail(h, UZL_ERR_BAD_ARG, "a Feature record's descriptor count differs from desc_len");
+    h->arena_used = off;
+    for (int32_t k = 0; k < n_frames; k++) {
+        h->frames.push_back(recs[k]);
+        h->live_frames++;
+        frame_ids[k] = (int32_t)h->frames.size() - 1;
+    }
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
+// FeatureData::toMsg (sensor_data.cpp:78-121): the Feature records of a resident frame
+int uzl_match_frame_to_wire(uzl_match* h, int32_t frame_id, const int32_t* uv, uint8_t* records, uint64_t cap, uint64_t* written)
+{
+    UZL_GUARD_BEGIN(h)
+    if (frame_id < 0 || frame_id >= (int32_t)h->frames.size() || !h->frames[frame_id].alive)
+        return fail(h, UZL_ERR_NOT_FOUND, "unknown frame id");
+    const FrameRec& r = h->frames[frame_id];
+    const uint64_t bytes = uzl_wire_features_size(r.n, 4 * r.words);
+    if (written) *written = bytes;
+    if (bytes == 0) return UZL_OK;
+    if (!records || cap < bytes) return fail(h, UZL_ERR_TRUNCATED, "records buffer too small");
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    WireSeg g;
+    memset(&g, 0, sizeof(g));
+    g.desc_off = r.desc_off; g.pos_off = r.pos_off; g.valid_off = r.valid_off;
+    g.stride = (uint32_t)(41 + 16 * r.words); g.words = r.words; g.n = r.n;
+    h->d_wire_stage.reserve((size_t)(bytes / 4) + 4);
+    if (uv) {
+        h->d_wire_uv.reserve((size_t)r.n * 2);
+        UZL_HIP(hipMemcpyAsync(h->d_wire_uv.p, uv, (size_t)r.n * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    h->timer.begin("wire_pack", h->stream);
+    launch_wire_pack(h->arena.p, g, uv ? h->d_wire_uv.p : nullptr, h->d_wire_stage.p, bytes, h->stream);
+    h->timer.end(h->stream);
+    UZL_HIP(hipGetLastError());
+    UZL_HIP(hipMemcpyAsync(records, h->d_wire_stage.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    UZL_HIP(hipStreamSynchronize(h->stream));
+    h->timer.resolve();
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
+int uzl_match_get_frame(uzl_match* h, int32_t frame_id, uint8_t* desc, double* pos_xyz, uint8_t* valid3d, int32_t* n, int32_t* bytes_per_desc)
+{
+    UZL_GUARD_BEGIN(h)
+    if (frame_id < 0 || frame_id >= (int32_t)h->frames.size() || !h->frames[frame_id].alive)
+        return fail(h, UZL_ERR_NOT_FOUND, "unknown frame id");
+    const FrameRec& r = h->frames[frame_id];
+    if (n) *n = r.n;
+    if (bytes_per_desc) *bytes_per_desc = 4 * r.words;
+    if (r.n == 0) return UZL_OK;
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    if (desc) UZL_HIP(hipMemcpyAsync(desc, h->arena.p + r.desc_off, (size_t)r.n * 4 * r.words, hipMemcpyDeviceToHost, h->stream));
+    if (pos_xyz) UZL_HIP(hipMemcpyAsync(pos_xyz, h->arena.p + r.pos_off, (size_t)r.n * 24, hipMemcpyDeviceToHost, h->stream));
+    if (valid3d) UZL_HIP(hipMemcpyAsync(valid3d, h->arena.p + r.valid_off, (size_t)r.n, hipMemcpyDeviceToHost, h->stream));
+    UZL_HIP(hipStreamSynchronize(h->stream));
+    return UZL_OK;
+    UZL_GUARD_END(h)
 }
 
 int uzl_match_frame_count(uzl_match* h)

@@ -717,6 +717,17 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
                 pcg_its = pcg_solve(h, &conv);
                 S.pcg_iterations += pcg_its;
             }
+            if (!conv && (h->ml_mult || h->ml_ns_steps > 0)) {
+                // The multiplicative cycle / its Newton-Schulz refinement is SPD only while the level-1 smoother contracts
+                // (lambda_max(Y_1 A_1) < 2), which block-Jacobi does not guarantee on every graph: fall back, for the rest
+                // of this handle's structure, to the additive operator (a sum of SPD terms) and solve again.
+                h->ml_mult = false; h->ml_ns_steps = 0;
+                h->ml_hot.Cmat = h->ml_y1;
+                destroy_pcg_graph(h);                                             // MlHot is a by-value kernel argument
+                h->ml_trial_setup = true;
+                pcg_its = pcg_solve(h, &conv);
+                S.pcg_iterations += pcg_its;
+            }
             if (fresh) pcg_ref = pcg_its;
             pcg_last = pcg_its;
             if (h->cfg.verbose)
