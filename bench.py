@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--hypotheses", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-formats", action="store_true")
     ap.add_argument("--sharded", action="store_true",
                     help="N > 1 only: additionally time ONE 10000-node/50000-edge graph sharded over all ranks "
                          "(BASELINE config 4, RCCL all-reduce per PCG iteration); reported under `sharded_c4`")
@@ -107,6 +108,50 @@ def timed(dist, fn, steps):
     dt = time.perf_counter() - t0
     dist.barrier()
     return dist.max(dt)
+
+
+def bench_formats(capi, dev, pairs, n_kp):
+    """FeatureData::fromMsg for every frame of the secondary workload in ONE launch: serialised graph_slam_msgs/Feature records
+    (41 + 4 D bytes per keypoint, one float32 per descriptor byte) -> descriptor rows / positions / flags in the frame arena.
+    Pure byte shuffle: HBM bound; algorithmic bytes = records in + arrays out.  Records are built on the host with numpy
+    (layout only, untimed); the timed quantity is the kernel (HIP events on the estimator's stream)."""
+    import ctypes as C
+    from uzliti_slam_amd import wire as W
+    frames = [f for p in pairs for f in p[:2]]
+    D = frames[0]["desc"].shape[1]
+    dt = np.dtype([("u", "<i4"), ("v", "<i4"), ("is_3d", "u1"), ("keypoint_strength", "<f4"), ("count", "<u4"),
+                   ("descriptor", "<f4", (D,)), ("keypoint_position", "<f8", (3,))], align=False)
+    keep = W._Keep()
+    sens = (W.WireSensor * len(frames))()
+    n_kp_total = 0
+    for k, f in enumerate(frames):
+        n = len(f["desc"])
+        rec = np.zeros(n, dt)
+        rec["is_3d"] = f["valid"]; rec["keypoint_strength"] = -1.0; rec["count"] = D
+        rec["descriptor"] = f["desc"]; rec["keypoint_position"] = np.asarray(f["pos"]).T
+        sens[k].sensor_type = 1; sens[k].descriptor_type = 2; sens[k].n_features = n; sens[k].desc_len = D; sens[k].uniform = 1
+        sens[k].records = keep.span(rec.tobytes())
+        n_kp_total += n
+    m = capi.Match(device=dev)
+    m.set_profiling(True)
+    best = None
+    for _ in range(3):
+        ids, _ = W.add_frames_wire(m, sens, len(frames))
+        ms = m.kernel_times().get("wire_unpack", dict(ms=0.0))["ms"]
+        best = ms if best is None or (0 < ms < best) else best
+        for i in ids:
+            m.remove_frame(i)
+    # spot check against the arrays the records were made from
+    ids, _ = W.add_frames_wire(m, sens, len(frames))
+    gd, gp, gv = W.get_frame(m, ids[-1])
+    ok = bool(np.array_equal(gd, frames[-1]["desc"]) and np.array_equal(gp, np.asarray(frames[-1]["pos"], np.float64)) and np.array_equal(gv, np.asarray(frames[-1]["valid"], np.uint8)))
+    m.close()
+    alg = float(n_kp_total) * ((41 + 4 * D) + (D + 25))
+    ach = alg / (best * 1e-3) / 1e9 if best and best > 0 else 0.0
+    return dict(kernel="wire_unpack_kernel", workload="%d frames x %d keypoints, ORB-256: Feature records -> frame arena, one launch" % (len(frames), n_kp),
+                ms=round(best or 0.0, 4), roofline=dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                                                          algorithmic_bytes=alg, traffic=None),
+                matches_source_arrays=ok)
 
 
 def main():
@@ -205,6 +250,11 @@ def main():
                                        traffic=None, measured_issue_peak=36800.0,
                                        note="integer VALU bound, not HBM/MFMA: 64 KB of descriptors feed 1.6e7 word-ops per pair; `peak` = 256 CU x 128 lanes/clk x 2.4 GHz (2 cycles per wave64 op); profiles/r01_ubench_valu_rates.txt measures 1.5-2.0 ns per wave-instruction per SIMD for v_xor/v_bcnt (~36.8 T lane-ops/s for this mix)"))
 
+    # ------------------------------------------------------------------ formats: Feature records -> frame arena
+    formats = None
+    if matcher is not None and dist.rank == 0 and not a.no_formats:
+        formats = bench_formats(capi, dev, pairs, a.keypoints)
+
     # ------------------------------------------------------------------ optional: config 4, one graph sharded over the ranks
     sharded_c4 = None
     if a.sharded and dist.world > 1:
@@ -247,15 +297,14 @@ def main():
                    host_cpus=os.cpu_count())
         if secondary is not None:
             n_cpu_pairs = 0; t0 = time.perf_counter()
-            for f, t, _ in pairs[:64]:
+            while time.perf_counter() - t0 < a.cpu_seconds and n_cpu_pairs < 16384:
+                f, t, _ = pairs[n_cpu_pairs % len(pairs)]
                 O.estimate_edge([f], [t], ransac_threshold=0.1, ransac_iteration=a.hypotheses, break_percentage=1.0,
                                 do_prosac=True, seed=777, job_id=n_cpu_pairs)
                 n_cpu_pairs += 1
-                if time.perf_counter() - t0 > a.cpu_seconds:
-                    break
             dtm = time.perf_counter() - t0
             secondary["cpu_baseline"] = dict(value=round(n_cpu_pairs / dtm, 2), unit="pairs/s", cores=1, kind="port",
-                                             sample="%d of the same node pairs, %.1f s" % (n_cpu_pairs, dtm))
+                                             sample="%d node pairs drawn cyclically from the same %d, %.1f s" % (n_cpu_pairs, len(pairs), dtm))
 
     if dist.rank == 0:
         out = dict(
@@ -269,6 +318,8 @@ def main():
                         pcg_iterations_per_solve=st["pcg_iterations"], preconditioner_builds_per_solve=st["precond_builds"], pcg_tol=pgo.cfg.pcg_tol, preconditioner=("multilevel, 8-vertex rigid-body aggregates (small graphs: dense level-1 operator, multiplicative cycle + 2 Newton-Schulz steps on the f64 matrix cores)" if pgo.cfg.preconditioner else "block-Jacobi"),
                         chi2_initial=st["chi2_initial"], chi2_final=st["chi2_final"]),
             roofline=roofline, kernels_ms_per_solve=kernels_ms, cpu_baseline=cpu, secondary=secondary)
+        if formats is not None:
+            out["formats"] = formats
         if sharded_c4 is not None:
             out["sharded_c4"] = sharded_c4
         print(json.dumps(out))

@@ -426,7 +426,7 @@ int uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sen
     UZL_GUARD_BEGIN(h)
     if (n_frames == 0) return UZL_OK;
     UZL_HIP(hipSetDevice(h->cfg.device));
-    std::vector<WireSeg> segs((size_t)n_frames);
+    std::vector<WireSeg> segs((size_t)n_frames + 1);      // + sentinel
     std::vector<FrameRec> recs((size_t)n_frames);
     size_t off = h->arena_used;
     uint64_t src = 0;
@@ -461,18 +461,21 @@ int uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sen
         items += (int64_t)n * g.words; feats += (int64_t)n;
         src = align_up(src + (n ? f.records.n : 0), 4);                           // every frame's records start dword-aligned
     }
+    memset(&segs[(size_t)n_frames], 0, sizeof(WireSeg));
+    segs[(size_t)n_frames].item_begin = items;
     if (h->in_flight && off > h->arena.cap) return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
     h->arena.reserve(off, /*keep=*/true, h->stream);
     h->d_wire_stage.reserve((size_t)(src / 4) + 4);                              // + tail: the dword after the last byte may be read
-    h->d_wire_segs.reserve((size_t)n_frames);
+    h->d_wire_segs.reserve((size_t)n_frames + 1);
     h->d_wire_bad.reserve(1);
     if (uv) h->d_wire_uv.reserve((size_t)std::max<int64_t>(2 * feats, 1));
     for (int32_t k = 0; k < n_frames; k++)
         if (sensors[k].n_features > 0)
             UZL_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t*>(h->d_wire_stage.p) + segs[k].src_off, sensors[k].records.p, sensors[k].records.n,
                                    hipMemcpyHostToDevice, h->stream));
-    UZL_HIP(hipMemcpyAsync(h->d_wire_segs.p, segs.data(), sizeof(WireSeg) * (size_t)n_frames, hipMemcpyHostToDevice, h->stream));
+    UZL_HIP(hipMemcpyAsync(h->d_wire_segs.p, segs.data(), sizeof(WireSeg) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, h->stream));
     UZL_HIP(hipMemsetAsync(h->d_wire_bad.p, 0, 4, h->stream));
+    h->timer.reset();
     h->timer.begin("wire_unpack", h->stream);
     launch_wire_unpack(h->d_wire_stage.p, h->arena.p, h->d_wire_segs.p, n_frames, items, uv ? h->d_wire_uv.p : nullptr, h->d_wire_bad.p, h->stream);
     h->timer.end(h->stream);
@@ -514,6 +517,7 @@ int uzl_match_frame_to_wire(uzl_match* h, int32_t frame_id, const int32_t* uv, u
         h->d_wire_uv.reserve((size_t)r.n * 2);
         UZL_HIP(hipMemcpyAsync(h->d_wire_uv.p, uv, (size_t)r.n * 8, hipMemcpyHostToDevice, h->stream));
     }
+    h->timer.reset();
     h->timer.begin("wire_pack", h->stream);
     launch_wire_pack(h->arena.p, g, uv ? h->d_wire_uv.p : nullptr, h->d_wire_stage.p, bytes, h->stream);
     h->timer.end(h->stream);

@@ -9,7 +9,7 @@
 // S is odd, nothing in a record is aligned: every access below is an ALIGNED dword access plus v_alignbit, so the
 // loads of neighbouring lanes fall into the same cache lines and coalesce.
 //   unpack: one lane per descriptor WORD of the arena (4 wire floats = 16 unaligned bytes in, one aligned dword out);
-//           the lane of word 0 also moves the keypoint's position, is_3d, u, v and checks the record's D.
+//           the keypoint's position, is_3d, u, v and the check of the record's D are spread over the same lanes.
 //   pack:   one lane per aligned dword of the record stream; each of its four bytes is derived from (record, offset).
 // Algorithmic bytes per keypoint: (41 + 4 D) + (D + 25) (+8 with u,v) in either direction (D = 32: 226 B).
 #include "uzl_common.hpp"
@@ -39,13 +39,16 @@ __device__ __forceinline__ uint32_t float_to_byte(uint32_t bits)
     return (uint32_t)((int32_t)f) & 0xffu;
 }
 
-__device__ __forceinline__ int find_segment(const WireSeg* __restrict__ segs, int n_segs, int64_t item)
+// segs has n_segs + 1 entries (the last one is a sentinel with item_begin = n_items).  The search runs once per wave on
+// its first item (uniform: scalar loads); lanes past a frame boundary step forward from there.
+__device__ __forceinline__ int find_segment(const WireSeg* __restrict__ segs, int n_segs, int64_t first_item, int64_t item)
 {
     int lo = 0, hi = n_segs - 1;
-    while (lo < hi) {                          // last segment whose item_begin <= item
+    while (lo < hi) {                          // last segment whose item_begin <= first_item
         const int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].item_begin <= item) lo = mid; else hi = mid - 1;
+        if (segs[mid].item_begin <= first_item) lo = mid; else hi = mid - 1;
     }
+    while (segs[lo + 1].item_begin <= item) ++lo;
     return lo;
 }
 
@@ -55,35 +58,41 @@ __global__ __launch_bounds__(kWireBlk) void wire_unpack_kernel(const uint32_t* _
 {
     const int64_t item = (int64_t)blockIdx.x * kWireBlk + threadIdx.x;
     if (item >= n_items) return;
-    const WireSeg sg = segs[find_segment(segs, n_segs, item)];
-    const int64_t local = item - sg.item_begin;
-    const int W = sg.words;
-    const int64_t i = local / W;
-    const int w = (int)(local - i * W);
+    const int64_t wave_first = (int64_t)blockIdx.x * kWireBlk + (threadIdx.x & ~63u);
+    const uint32_t f_lo = __builtin_amdgcn_readfirstlane((uint32_t)wave_first), f_hi = __builtin_amdgcn_readfirstlane((uint32_t)(wave_first >> 32));
+    const WireSeg sg = segs[find_segment(segs, n_segs, (int64_t)(((uint64_t)f_hi << 32) | f_lo), item)];
+    const uint32_t local = (uint32_t)(item - sg.item_begin);          // < 16384 * 127
+    const uint32_t W = (uint32_t)sg.words;
+    const uint32_t i = local / W;
+    const uint32_t w = local - i * W;
     const uint64_t rec = sg.src_off + (uint64_t)i * sg.stride;
-    const uint64_t d0 = rec + 17 + 16ull * (uint64_t)w;
-    uint32_t word = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) word |= float_to_byte(load_u32_at(stage, d0 + 4 * k)) << (8 * k);
-    reinterpret_cast<uint32_t*>(arena + sg.desc_off)[i * W + w] = word;
-    if (w == 0) {
-        if (load_u32_at(stage, rec + 13) != (uint32_t)(4 * W)) atomicOr(bad, 1);
-        arena[sg.valid_off + i] = (load_u32_at(stage, rec + 8) & 0xffu) ? 1 : 0;       // std::vector<bool>::push_back(is_3d) (:164)
-        const uint64_t p0 = rec + 17 + 16ull * (uint64_t)W;
-        uint32_t* pos = reinterpret_cast<uint32_t*>(arena + sg.pos_off) + i * 6;          // column i of the 3 x n matrix
-#pragma unroll
-        for (int k = 0; k < 6; k++) pos[k] = load_u32_at(stage, p0 + 4 * k);
-        if (uv) {
-            uv[2 * (sg.feat_begin + i)] = (int32_t)load_u32_at(stage, rec);
-            uv[2 * (sg.feat_begin + i) + 1] = (int32_t)load_u32_at(stage, rec + 4);
-        }
+    const uint64_t d0 = rec + 17 + 16ull * w;
+    // 16 unaligned bytes = five aligned dwords
+    const uint64_t a = d0 >> 2;
+    const uint32_t sh = (uint32_t)(d0 & 3) * 8;
+    const uint32_t x0 = stage[a], x1 = stage[a + 1], x2 = stage[a + 2], x3 = stage[a + 3], x4 = sh ? stage[a + 4] : 0u;
+    const uint32_t word = float_to_byte(__funnelshift_r(x0, x1, sh)) | float_to_byte(__funnelshift_r(x1, x2, sh)) << 8 |
+                          float_to_byte(__funnelshift_r(x2, x3, sh)) << 16 | float_to_byte(__funnelshift_r(x3, x4, sh)) << 24;
+    reinterpret_cast<uint32_t*>(arena + sg.desc_off)[(size_t)i * W + w] = word;
+    // the keypoint's other fields are spread over its lanes: position dwords on lanes 0..5 (strided when W < 6),
+    // is_3d + the descriptor-count check on the last lane, u / v on the lane before it
+    const uint64_t p0 = rec + 17 + 16ull * W;
+    uint32_t* pos = reinterpret_cast<uint32_t*>(arena + sg.pos_off) + (size_t)i * 6;          // column i of the 3 x n matrix
+    for (uint32_t k = w; k < 6; k += W) pos[k] = load_u32_at(stage, p0 + 4 * k);
+    if (w == W - 1) {
+        if (load_u32_at(stage, rec + 13) != 4 * W) atomicOr(bad, 1);
+        arena[sg.valid_off + i] = (load_u32_at(stage, rec + 8) & 0xffu) ? 1 : 0;          // std::vector<bool>::push_back(is_3d) (:164)
+    }
+    if (uv && w == (W > 1 ? W - 2 : 0)) {
+        uv[2 * (sg.feat_begin + i)] = (int32_t)load_u32_at(stage, rec);
+        uv[2 * (sg.feat_begin + i) + 1] = (int32_t)load_u32_at(stage, rec + 4);
     }
 }
 
 // byte q of record i of a frame (toMsg, sensor_data.cpp:78-121)
 __device__ __forceinline__ uint32_t record_byte(const uint8_t* __restrict__ desc, const uint32_t* __restrict__ pos,
                                                 const uint8_t* __restrict__ valid, const int32_t* __restrict__ uv, int D,
-                                                int64_t i, uint32_t q)
+                                                size_t i, uint32_t q)
 {
     if (q < 8) {                                                   // u, v
         const uint32_t v = uv ? (uint32_t)uv[2 * i + (q >> 2)] : 0u;
@@ -110,13 +119,13 @@ __global__ __launch_bounds__(kWireBlk) void wire_pack_kernel(const uint8_t* __re
     const uint32_t* pos = reinterpret_cast<const uint32_t*>(arena + sg.pos_off);
     const uint8_t* valid = arena + sg.valid_off;
     const int D = 4 * sg.words;
-    uint64_t byte = 4ull * (uint64_t)j;
-    int64_t i = (int64_t)(byte / sg.stride);
-    uint32_t q = (uint32_t)(byte - (uint64_t)i * sg.stride);
+    const uint32_t byte = 4u * (uint32_t)j;                          // one frame: < 16384 * 549 bytes
+    uint32_t i = byte / sg.stride;
+    uint32_t q = byte - i * sg.stride;
     uint32_t word = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        if (byte + k < n_bytes) word |= record_byte(desc, pos, valid, uv, D, i, q) << (8 * k);
+        if ((uint64_t)byte + k < n_bytes) word |= record_byte(desc, pos, valid, uv, D, i, q) << (8 * k);
         if (++q == sg.stride) { q = 0; ++i; }
     }
     out[j] = word;
