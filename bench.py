@@ -197,8 +197,9 @@ def main():
     active = min(int(st_prof["pcg_iterations"]), int(spmv["launches"])) or 1
     achieved = alg_bytes * active / (spmv["ms"] * 1e-3) / 1e9 if spmv["ms"] > 0 else 0.0
     traffic = None
+    cfg_name = {(1000, 5000): "BASELINE config 2", (10000, 50000): "BASELINE config 4 size on one GPU", (100, 300): "BASELINE config 1"}.get((a.nodes, a.edges), "custom size")
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and (a.nodes, a.edges) == (1000, 5000):     # the PMC passes were collected on config 2
         try:
             traffic = json.load(open(tpath)).get("pcg_spmv_bytes_per_launch")
         except Exception:
@@ -312,8 +313,8 @@ def main():
             value=round(value, 1), unit="edges/s", n_gpus=dist.world, steps=a.steps, warmup=a.warmup,
             ms_per_step=round(1e3 * t_pgo / a.steps, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
             dtype="f64", data="synthetic",
-            config=dict(workload="BASELINE config 2: %d-node / %d-edge SE(3) pose graph, %d LM iterations, Huber(1) on loop closures; "
-                                 "one independent graph per GPU" % (a.nodes, a.edges, a.lm_iters),
+            config=dict(workload="%s: %d-node / %d-edge SE(3) pose graph, %d LM iterations, Huber(1) on loop closures; "
+                                 "one independent graph per GPU" % (cfg_name, a.nodes, a.edges, a.lm_iters),
                         system_edges=st["n_edges"], lm_iterations_done=st["iterations_done"], lm_trials_per_solve=st["lm_trials"],
                         pcg_iterations_per_solve=st["pcg_iterations"], preconditioner_builds_per_solve=st["precond_builds"], pcg_tol=pgo.cfg.pcg_tol, preconditioner=("multilevel, 8-vertex rigid-body aggregates (small graphs: dense level-1 operator, multiplicative cycle + 2 Newton-Schulz steps on the f64 matrix cores)" if pgo.cfg.preconditioner else "block-Jacobi"),
                         chi2_initial=st["chi2_initial"], chi2_final=st["chi2_final"]),
