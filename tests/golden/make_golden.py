@@ -136,6 +136,51 @@ def filter_fixture():
     np.savez_compressed(os.path.join(HERE, "filter_140n_380e.npz"), **z)
 
 
+def wire_fixture():
+    """graph_slam_msgs Edge / Node messages and a single-message bag, serialised by oracle/wire.py.  Before anything is written
+    the hand-derivable parts are asserted: field offsets of the Edge message, record stride 41 + 4 D, quaternion conventions."""
+    import struct
+    from oracle import wire as OW
+    rng = np.random.default_rng(2024)
+    from scipy.spatial.transform import Rotation
+
+    def pose(big=False):
+        v = rng.normal(size=3); v *= (3.0 if big else rng.uniform(0, 1.2)) / np.linalg.norm(v)
+        T = np.zeros((3, 4)); T[:, :3] = Rotation.from_rotvec(v).as_matrix(); T[:, 3] = rng.normal(size=3)
+        return T.reshape(12)
+    A = rng.normal(size=(6, 6))
+    edge = dict(id="1400000007.5-1400000001.25", id_from="1400000001.25", id_to="1400000007.5", sensor_from="camera_rgb_optical_frame",
+                sensor_to="camera_rgb_optical_frame", type=1, valid=1, transform=pose(big=True), information=(A @ A.T).reshape(36),
+                displacement_from=pose(), displacement_to=pose(), error=0.125, age=3.0, matching_score=87.0, diff_time_sec=6, diff_time_nsec=250000000)
+    eb = OW.encode_edge(edge)
+    o = 4 + len(edge["id"]) + 1 + 4 + len(edge["id_from"]) + 4 + len(edge["id_to"])
+    assert struct.unpack_from("<3d", eb, o + 112) == tuple(edge["transform"][[3, 7, 11]])          # transformation.pose.position
+    q = np.array(struct.unpack_from("<4d", eb, o + 136))                                             # orientation x y z w
+    assert np.allclose(np.abs(Rotation.from_quat(q).as_matrix() - edge["transform"].reshape(3, 4)[:, :3]).max(), 0, atol=1e-14)
+    assert np.array_equal(np.frombuffer(eb, "<f8", 36, o + 168), edge["information"])
+    n, D = 24, 32
+    desc = rng.integers(0, 256, size=(n, D), dtype=np.uint8); pos = rng.normal(size=(3, n)); valid = (rng.random(n) > 0.2).astype(np.uint8)
+    uv = rng.integers(0, 640, size=(n, 2)).astype(np.int32)
+    rec = OW.features_pack(desc, pos, valid, uv)
+    assert len(rec) == n * (41 + 4 * D) and struct.unpack_from("<iiBfI", rec, 0) == (uv[0, 0], uv[0, 1], valid[0], -1.0, D)
+    assert struct.unpack_from("<f", rec, 17 + 4 * 5)[0] == float(desc[0, 5]) and struct.unpack_from("<3d", rec, 17 + 4 * D) == tuple(pos[:, 0])
+    node = dict(id="1400000001.25", stamps_ns=[1400000001250000000, 1400000002000000000], pose=pose(), odom_pose=pose(), edge_ids=[edge["id"], "odo-1"],
+                fixed=0, uncertainty=0.5,
+                sensors=[dict(raw=None, sensor_type=1, stamp_sec=1400000001, stamp_nsec=250000000, sensor_frame="camera_rgb_optical_frame", displacement=pose(),
+                              descriptor_type=2, n_features=n, desc_len=D, records=rec, camera_info=None)])
+    nb = OW.encode_node(node)
+    back, used = OW.decode_node(nb)
+    assert used == len(nb) and back["sensors"][0]["records"] == rec and back["stamps_ns"] == node["stamps_ns"]
+    bag = OW.bag_write_single(b"edge", b"graph_slam_msgs/Edge", b"0" * 32, b"", 1400000010, 1, eb)
+    (m,) = OW.bag_read(bag)
+    assert m["data"] == eb and bag[:13] == b"#ROSBAG V2.0\n"
+    z = dict(edge_bytes=np.frombuffer(eb, np.uint8), node_bytes=np.frombuffer(nb, np.uint8), bag_bytes=np.frombuffer(bag, np.uint8),
+             desc=desc, pos=pos, valid=valid, uv=uv, node_pose=node["pose"], node_odom_pose=node["odom_pose"], sensor_displacement=node["sensors"][0]["displacement"])
+    for k in ("transform", "information", "displacement_from", "displacement_to"):
+        z["edge_" + k] = np.asarray(edge[k])
+    np.savez_compressed(os.path.join(HERE, "wire_msgs.npz"), **z)
+
+
 if __name__ == "__main__":
-    match_fixture(); ransac_fixture(); pgo_fixture(); filter_fixture()
+    match_fixture(); ransac_fixture(); pgo_fixture(); filter_fixture(); wire_fixture()
     print("golden fixtures written to", HERE)

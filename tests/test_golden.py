@@ -131,3 +131,51 @@ def test_hip_reproduces_filter_golden(capi):
     for k in ("max_cluster_size", "ransac_iterations", "seed"):
         cfg[k] = int(cfg[k])
     check_against_filter_fixture(z, list(replay_filter_fixture(z, capi.Filter(**cfg))))
+
+
+# ------------------------------------------------------------------------------------------------ wire / disk formats
+_WIRE_EDGE = dict(id="1400000007.5-1400000001.25", id_from="1400000001.25", id_to="1400000007.5", sensor_from="camera_rgb_optical_frame",
+                  sensor_to="camera_rgb_optical_frame", type=1, valid=1, error=0.125, age=3.0, matching_score=87.0, diff_time_sec=6,
+                  diff_time_nsec=250000000)
+
+
+def _wire_inputs(z):
+    edge = dict(_WIRE_EDGE, **{k: z["edge_" + k] for k in ("transform", "information", "displacement_from", "displacement_to")})
+    sensor = dict(raw=None, sensor_type=1, stamp_sec=1400000001, stamp_nsec=250000000, sensor_frame="camera_rgb_optical_frame",
+                  displacement=z["sensor_displacement"], descriptor_type=2, n_features=len(z["desc"]), desc_len=z["desc"].shape[1], camera_info=None)
+    node = dict(id="1400000001.25", stamps_ns=[1400000001250000000, 1400000002000000000], pose=z["node_pose"], odom_pose=z["node_odom_pose"],
+                edge_ids=[_WIRE_EDGE["id"], "odo-1"], fixed=0, uncertainty=0.5, sensors=[sensor])
+    return edge, node
+
+
+def test_wire_golden_oracle_and_host_codecs():
+    from oracle import wire as OW
+    from uzliti_slam_amd import wire as W
+    z = np.load(os.path.join(G, "wire_msgs.npz"))
+    edge, node = _wire_inputs(z)
+    rec = OW.features_pack(z["desc"], z["pos"], z["valid"], z["uv"])
+    node["sensors"][0]["records"] = rec
+    eb, nb, bag = z["edge_bytes"].tobytes(), z["node_bytes"].tobytes(), z["bag_bytes"].tobytes()
+    assert OW.encode_edge(edge) == eb and W.encode_edge(edge) == eb
+    assert OW.encode_node(node) == nb and W.encode_node(node) == nb
+    args = (b"edge", b"graph_slam_msgs/Edge", b"0" * 32, b"", 1400000010, 1, eb)
+    assert OW.bag_write_single(*args) == bag and W.bag_write_single(*args) == bag
+    (m,) = W.bag_read(bag)
+    d, _ = W.decode_edge(m["data"])
+    assert np.array_equal(d["information"], z["edge_information"]) and np.abs(d["transform"] - z["edge_transform"]).max() < 1e-14
+    s = W.decode_node(nb).fields["sensors"][0]
+    assert s["records"] == rec and s["n_features"] == 24 and s["desc_len"] == 32 and s["uniform"] == 1
+
+
+@pytest.mark.gpu
+def test_wire_golden_on_the_device(capi):
+    from uzliti_slam_amd import wire as W
+    z = np.load(os.path.join(G, "wire_msgs.npz"))
+    d = W.decode_node(z["node_bytes"].tobytes())
+    m = capi.Match()
+    (fid,), uv = W.add_frames_wire(m, d.sensors_c, 1, want_uv=True)
+    desc, pos, valid = W.get_frame(m, fid)
+    assert np.array_equal(desc, z["desc"]) and np.array_equal(pos.view(np.uint64), z["pos"].view(np.uint64))
+    assert np.array_equal(valid, z["valid"]) and np.array_equal(uv, z["uv"])
+    assert W.frame_to_wire(m, fid, z["uv"]) == d.fields["sensors"][0]["records"]
+    m.close()
