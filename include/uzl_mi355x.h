@@ -57,12 +57,18 @@ extern "C" {
 #define UZL_FEATURE_BRISK 3
 #define UZL_FEATURE_FREAK 4
 
-/* edge types: graph_slam_msgs/msg/Edge.msg (TYPE_2D_WHEEL_ODOMETRY is the only one the
+/* edge types: the values of graph_slam_msgs/msg/Edge.msg:1-9, so that SlamEdge::type_ passes through unchanged
+ * (TYPE_2D_WHEEL_ODOMETRY is the only one the
  * optimizer treats specially, g2o_optimizer.cpp:78) */
-#define UZL_EDGE_TYPE_2D_WHEEL_ODOMETRY 0
 #define UZL_EDGE_TYPE_3D_FULL           1
-#define UZL_EDGE_TYPE_2D_LASER          2
-#define UZL_EDGE_TYPE_3D_LASER          3
+#define UZL_EDGE_TYPE_3D_ROTATION       2
+#define UZL_EDGE_TYPE_3D_TRANSLATION    3
+#define UZL_EDGE_TYPE_3D_GPS            4
+#define UZL_EDGE_TYPE_2D_FULL           101
+#define UZL_EDGE_TYPE_2D_ROTATION       102
+#define UZL_EDGE_TYPE_2D_TRANSLATION    103
+#define UZL_EDGE_TYPE_2D_WHEEL_ODOMETRY 104
+#define UZL_EDGE_TYPE_2D_LASER          105
 
 int         uzl_abi_version(void);
 /* Number of visible HIP devices, or <0 (UZL_ERR_NO_DEVICE) when there is none. */

@@ -142,7 +142,7 @@ double uzlo_gate_astar(uzlo_gate* g, int32_t source, int32_t target)
         expansions++;
         for (int32_t q = g->adj_ptr[v]; q < g->adj_ptr[v + 1]; q++) {                   /* getNeighbors(v, true) */
             const gedge* e = &g->edges[g->adj_edge[q]];
-            if (!e->valid || e->type == 2 /* TYPE_2D_LASER */) continue;
+            if (!e->valid || e->type == 105 /* TYPE_2D_LASER, Edge.msg:9 */) continue;
             const int32_t u = (e->from == v) ? e->to : e->from;
             if (st[u] == 2) continue;
             const double tent = gs[v] + node_dist(g, v, u);

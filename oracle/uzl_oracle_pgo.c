@@ -311,7 +311,7 @@ int32_t uzlo_flatten_graph(int32_t n_nodes, const uzlo_node* nodes, int32_t n_ed
         for (int32_t k = 0; k < n_edges; k++) {
             const uzlo_edge* ed = &edges[k];
             if (ed->from < 0 || ed->to < 0 || ed->from >= n_nodes || ed->to >= n_nodes) continue;   /* :77 */
-            const int is_odom = (ed->type == 0);                              /* TYPE_2D_WHEEL_ODOMETRY */
+            const int is_odom = (ed->type == 104);                              /* TYPE_2D_WHEEL_ODOMETRY */
             if ((pass == 0) != is_odom) continue;
             double Zm[12], tmp[12], inv[12];
             if (is_odom) {                                                    /* addOdometryEdge :190-259 */

@@ -15,7 +15,7 @@ def scenario(capi, n, e, seed, n_cand, valid_frac=0.5):
     g = synth.make_pose_graph(n, e, seed=seed)
     ed = g["edges"]
     rng = np.random.default_rng(seed + 100)
-    valid = np.where(ed["type"] == 0, 1, (rng.random(len(ed["type"])) < valid_frac).astype(int))
+    valid = np.where(ed["type"] == synth.EDGE_TYPE_ODOM, 1, (rng.random(len(ed["type"])) < valid_frac).astype(int))
     graph_edges = capi.gate_edges(ed["from"], ed["to"], ed["type"], valid=valid)
     gt = g["gt_pose"].reshape(n, 3, 4)
     # candidates: pairs of nodes within 2 m (some far apart in the graph), transform = noisy relative pose, mixed scores / types
@@ -62,7 +62,7 @@ def test_gate_known_answers_on_gpu(capi, oracle):
     xyz = np.stack([0.3 * np.arange(n), np.zeros(n), np.zeros(n)], 1)
     c = np.concatenate([cand(0, 2, score=19.9), cand(0, 2, score=20.0), cand(2, 0, score=80.0), cand(0, 2, score=80.0, typ=3),
                         cand(3, 5, t=(1.0001, 0, 0)), cand(3, 5, t=(1.0, 0, 0)), cand(6, 8, yaw_deg=20.5), cand(6, 8, yaw_deg=19.5),
-                        cand(0, 1, typ=0), cand(40, 2), cand(-1, 2), cand(0, 10), cand(10, 13)])
+                        cand(0, 1, typ=synth.EDGE_TYPE_ODOM), cand(40, 2), cand(-1, 2), cand(0, 10), cand(10, 13)])
     g = capi.Gate()
     g.set_graph(poses_at(xyz), chain_edges(n))
     acc, val, dist = g.check(c)

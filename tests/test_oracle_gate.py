@@ -17,7 +17,7 @@ def poses_at(xyz):
 
 
 def chain_edges(n, valid=1):
-    return capi.gate_edges(np.arange(n - 1), np.arange(1, n), np.zeros(n - 1, int), valid=np.full(n - 1, valid))
+    return capi.gate_edges(np.arange(n - 1), np.arange(1, n), np.full(n - 1, synth.EDGE_TYPE_ODOM), valid=np.full(n - 1, valid))
 
 
 def cand(frm, to, score=50.0, t=(0.1, 0.0, 0.0), yaw_deg=0.0, typ=1):
@@ -47,7 +47,7 @@ def py_astar(pos, adj, s, t):
 def test_astar_is_greedy_best_first(oracle):
     # 0 -> target 3.  Short route 0-1-3 starts by moving AWAY from the target; the long route 0-2-4-3 moves towards it first.
     pos = np.array([[0, 0, 0], [-1, 0.5, 0], [1, 2, 0], [2, 0, 0], [2.5, 2.5, 0]], float)
-    E = capi.gate_edges([0, 1, 0, 2, 4], [1, 3, 2, 4, 3], [0] * 5, valid=[1] * 5)
+    E = capi.gate_edges([0, 1, 0, 2, 4], [1, 3, 2, 4, 3], [synth.EDGE_TYPE_ODOM] * 5, valid=[1] * 5)
     g = oracle.Gate()
     g.set_graph(poses_at(pos), E)
     d = g.astar(0, 3)
@@ -63,7 +63,7 @@ def test_astar_path_need_not_be_shortest(oracle):
     # the search commits to the neighbour closest to the target; the target is then reached through it although a shorter path exists
     pos = np.array([[0, 0, 0], [1, 0.1, 0], [0.2, -0.5, 0], [2, 0, 0], [1.8, 1.5, 0]], float)
     # edges: 0-1, 1-4, 4-3 (detour via 4), and 0-2, 2-3 (direct but 2 is farther from the target than 1)
-    E = capi.gate_edges([0, 1, 4, 0, 2], [1, 4, 3, 2, 3], [0] * 5, valid=[1] * 5)
+    E = capi.gate_edges([0, 1, 4, 0, 2], [1, 4, 3, 2, 3], [synth.EDGE_TYPE_ODOM] * 5, valid=[1] * 5)
     g = oracle.Gate()
     g.set_graph(poses_at(pos), E)
     adj = {0: [1, 2], 1: [0, 4], 4: [1, 3], 2: [0, 3], 3: [4, 2]}
@@ -76,9 +76,9 @@ def test_astar_path_need_not_be_shortest(oracle):
 def test_astar_ignores_invalid_and_laser_edges_and_unreachable(oracle):
     pos = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0]], float)
     g = oracle.Gate()
-    g.set_graph(poses_at(pos), capi.gate_edges([0, 1], [1, 2], [0, 1], valid=[1, 0]))       # 1-2 not valid
+    g.set_graph(poses_at(pos), capi.gate_edges([0, 1], [1, 2], [synth.EDGE_TYPE_ODOM, synth.EDGE_TYPE_3D_FULL], valid=[1, 0]))       # 1-2 not valid
     assert g.astar(0, 1) == 1.0 and g.astar(0, 2) == DMAX
-    g.set_graph(poses_at(pos), capi.gate_edges([0, 1], [1, 2], [0, 2], valid=[1, 1]))       # 1-2 is TYPE_2D_LASER
+    g.set_graph(poses_at(pos), capi.gate_edges([0, 1], [1, 2], [synth.EDGE_TYPE_ODOM, synth.EDGE_TYPE_2D_LASER], valid=[1, 1]))       # 1-2 is TYPE_2D_LASER
     assert g.astar(0, 2) == DMAX
     assert g.astar(1, 1) == 0.0
 
@@ -88,7 +88,7 @@ def test_astar_equals_python_restatement_on_random_graphs(oracle):
         gph = synth.make_pose_graph(120, 420, seed=seed)
         e = gph["edges"]
         rng = np.random.default_rng(seed)
-        valid = np.where(e["type"] == 0, 1, (rng.random(len(e["type"])) < 0.5).astype(int))
+        valid = np.where(e["type"] == synth.EDGE_TYPE_ODOM, 1, (rng.random(len(e["type"])) < 0.5).astype(int))
         P = gph["nodes_pose"]
         pos = P[:, [3, 7, 11]]
         adj = {i: [] for i in range(120)}
@@ -116,7 +116,7 @@ def test_gate_thresholds_and_duplicates(oracle):
         cand(3, 5, t=(1.0, 0, 0)),                   # exactly 1.0: accepted (<=)
         cand(6, 8, yaw_deg=20.5),                    # rotation above max_edge_distance_R
         cand(6, 8, yaw_deg=19.5),
-        cand(0, 1, typ=0),                           # an odometry edge 0-1 exists with type 0
+        cand(0, 1, typ=synth.EDGE_TYPE_ODOM),        # an odometry edge 0-1 of that type exists
         cand(40, 2), cand(-1, 2),                    # unknown nodes
     ])
     acc, val, dist = g.check(c)

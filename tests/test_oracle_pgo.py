@@ -95,8 +95,13 @@ def test_flatten_rules(oracle):
     assert not (src & {50, 51, 52, 53, 54, 60, 61})
     # odometry first, then feature edges; robust only on feature edges (:292-294)
     types = e["type"][fl["src_edge"]]
-    assert np.all(np.diff((types != 0).astype(int)) >= 0)
-    assert np.array_equal(fl["robust"], (types != 0).astype(np.uint8))
+    assert np.all(np.diff((types != synth.EDGE_TYPE_ODOM).astype(int)) >= 0)
+    assert np.array_equal(fl["robust"], (types != synth.EDGE_TYPE_ODOM).astype(np.uint8))
+    # any type other than TYPE_2D_WHEEL_ODOMETRY (Edge.msg values 1-4, 101-103, 105) goes down the feature-edge branch (:80-103)
+    e2 = {k: v.copy() for k, v in e.items()}
+    e2["type"][e2["type"] != synth.EDGE_TYPE_ODOM] = synth.EDGE_TYPE_2D_LASER
+    fl2 = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], e2)
+    assert np.array_equal(fl2["src_edge"], fl["src_edge"]) and np.array_equal(fl2["robust"], fl["robust"])
     # identity displacements/sensors: measurement == transform
     assert np.allclose(fl["meas"], e["transform"][fl["src_edge"]])
     # xy-only: z, roll, pitch zeroed

@@ -101,7 +101,7 @@ def test_sensor_transforms_and_displacements(pgo, oracle):
     I = np.tile(np.eye(3, 4), (4, 1, 1))
     S = np.concatenate([I[:1], sensors.reshape(-1, 3, 4)])     # index -1 -> identity
     Sf = S[g["edges"]["sensor_from"] + 1]; St = S[g["edges"]["sensor_to"] + 1]
-    odom = g["edges"]["type"] == 0
+    odom = g["edges"]["type"] == synth.EDGE_TYPE_ODOM
     # feature: Z = Df Sf T' St^-1 Dt^-1  =>  T' = Sf^-1 Df^-1 Z St Dt ; odometry: T' = Df^-1 Z Dt
     Tf = synth.se3_mul(synth.se3_mul(synth.se3_inv(Sf), synth.se3_inv(Df)), synth.se3_mul(synth.se3_mul(T, Dt), St))
     To = synth.se3_mul(synth.se3_inv(Df), synth.se3_mul(T, Dt))

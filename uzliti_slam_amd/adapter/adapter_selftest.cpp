@@ -2,11 +2,13 @@
 // (graph_slam/src/graph_slam_node.cpp:46-49, :266, :1138-1150, :1248-1282) on inputs read from a flat binary
 // file written by tests/test_adapter_gpu.py, and writes the results back for comparison with the oracle.
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
 #include "graph_optimizer.h"
+#include "rosbag_storage.h"
 #include "transformation_estimator.h"
 
 using namespace uzl_adapter;
@@ -75,8 +77,107 @@ static int filter_mode(const char* in, const char* out)
     return 0;
 }
 
+// ---- "storage" mode: RosbagStorage the way GraphSlamNode uses it (graph_slam_node.cpp: storeNode / storeEdge per new object,
+// loadGraph at start-up).  A small graph with feature frames from a fixed LCG is stored, two objects are removed, the rest is
+// loaded into a fresh SlamGraph and compared field by field; the directory stays behind for the Python-side check.
+static uint32_t lcg(uint32_t& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
+static Isometry3d lcg_pose(uint32_t& s)
+{
+    const double a = 0.001 * (lcg(s) % 3000), b = 0.001 * (lcg(s) % 1500);      // yaw, pitch
+    const double ca = cos(a), sa = sin(a), cb = cos(b), sb = sin(b);
+    Isometry3d T;
+    T.m = {ca * cb, -sa, ca * sb, 0.01 * (lcg(s) % 1000), sa * cb, ca, sa * sb, 0.01 * (lcg(s) % 1000), -sb, 0., cb, 0.01 * (lcg(s) % 100)};
+    return T;
+}
+static double max_abs_diff(const Isometry3d& a, const Isometry3d& b)
+{
+    double m = 0;
+    for (int i = 0; i < 12; i++) m = std::max(m, std::fabs(a.m[i] - b.m[i]));
+    return m;
+}
+static int storage_mode(const char* dir, const char* out)
+{
+    uzl_match_cfg mc; uzl_match_cfg_default(&mc);
+    uzl_match* est = nullptr;
+    if (uzl_match_create(&mc, &est) != UZL_OK) { fprintf(stderr, "no estimator handle (no HIP device?)\n"); return 3; }
+    uint32_t s = 12345;
+    const int N = 6, E = 9;
+    SlamGraph g;
+    for (int i = 0; i < N; i++) {
+        SlamNode nd; nd.id_ = node_id(i);
+        nd.stamps_ = {1400000000000000000ll + 1000000000ll * i + 5, 1400000000500000000ll + 1000000000ll * i};
+        nd.pose_ = lcg_pose(s); nd.sub_pose_ = lcg_pose(s); nd.fixed_ = i == 0; nd.uncertainty_ = 0.125 * i;
+        nd.edges_ = {"e" + std::to_string(i), "e" + std::to_string(i + 1)};
+        for (int k = 0; k < (i % 3 == 2 ? 2 : 1); k++) {                       // some nodes carry two cameras
+            FeatureDataPtr fd(new FeatureData());
+            fd->type_ = SENSOR_TYPE_FEATURE; fd->stamp_ = nd.stamps_[0]; fd->sensor_frame_ = k ? "cam_right" : "cam_left";
+            fd->displacement_ = lcg_pose(s); fd->feature_type_ = FEATURE_ORB;
+            fd->rows = (i == 4 && k == 0) ? 0 : 100 + 37 * i + k; fd->bytes_per_row = 32;
+            fd->features_.resize((size_t)fd->rows * 32);
+            for (auto& b : fd->features_) b = (uint8_t)lcg(s);
+            fd->feature_positions_.resize((size_t)fd->rows * 3);
+            for (auto& v : fd->feature_positions_) v = 0.001 * (double)(lcg(s) % 8000) - 4.0;
+            fd->feature_positions_2d_.resize((size_t)fd->rows * 2);
+            for (auto& v : fd->feature_positions_2d_) v = (int32_t)(lcg(s) % 640);
+            fd->valid_3d_.resize((size_t)fd->rows);
+            for (size_t q = 0; q < fd->valid_3d_.size(); q++) fd->valid_3d_[q] = lcg(s) % 5 != 0;
+            nd.sensor_data_.push_back(fd);
+        }
+        g.addNode(nd);
+    }
+    for (int k = 0; k < E; k++) {
+        SlamEdge e; char b[32]; snprintf(b, sizeof(b), "e%08d", k); e.id_ = b;
+        e.id_from_ = node_id(k % N); e.id_to_ = node_id((k + 1 + k / N) % N);
+        e.transform_ = lcg_pose(s); e.displacement_from_ = lcg_pose(s); e.displacement_to_ = lcg_pose(s);
+        for (int i = 0; i < 36; i++) e.information_[i] = (i / 6 == i % 6) ? 10.0 + k : 0.01 * (double)((i / 6) * (i % 6));
+        e.type_ = k % 2 ? TYPE_3D_FULL : TYPE_2D_WHEEL_ODOMETRY; e.sensor_from_ = k % 2 ? "cam_left" : ""; e.sensor_to_ = e.sensor_from_;
+        e.age_ = k; e.error_ = 0.5 * k; e.matching_score_ = 40 + k; e.diff_time_ = (k % 3 == 0) ? -1.25 : 2.5 + k; e.valid_ = k % 3 != 1;
+        g.addEdge(e);
+    }
+    RosbagStorage st(est, dir, /*clear_storage=*/true);
+    for (auto& kv : g.nodes()) if (!st.storeNode(kv.second, 1500000000000000000ll)) { fprintf(stderr, "storeNode: %s\n", st.lastError().c_str()); return 4; }
+    for (auto& kv : g.edges()) if (!st.storeEdge(kv.second, 1500000000000000000ll)) { fprintf(stderr, "storeEdge: %s\n", st.lastError().c_str()); return 4; }
+    st.removeNode(node_id(1)); st.removeEdge("e00000003"); st.removeEdge("never-stored");
+    SlamGraph back;
+    RosbagStorage st2(est, dir, false);
+    if (!st2.loadGraph(back)) { fprintf(stderr, "loadGraph: %s\n", st2.lastError().c_str()); return 5; }
+    int bad = 0;
+    if (back.nodes().size() != (size_t)N - 1 || back.edges().size() != (size_t)E - 1 || back.existsNode(node_id(1)) || back.existsEdge("e00000003")) bad |= 1;
+    for (auto& kv : back.nodes()) {
+        const SlamNode& a = g.node(kv.first); const SlamNode& b = kv.second;
+        if (a.stamps_ != b.stamps_ || a.fixed_ != b.fixed_ || a.uncertainty_ != b.uncertainty_ || a.edges_ != b.edges_) bad |= 2;
+        if (max_abs_diff(a.pose_, b.pose_) > 1e-14 || max_abs_diff(a.sub_pose_, b.sub_pose_) > 1e-14) bad |= 4;
+        if (a.sensor_data_.size() != b.sensor_data_.size()) { bad |= 8; continue; }
+        for (size_t k = 0; k < a.sensor_data_.size(); k++) {
+            const FeatureData& x = *std::dynamic_pointer_cast<FeatureData>(a.sensor_data_[k]);
+            const FeatureData& y = *std::dynamic_pointer_cast<FeatureData>(b.sensor_data_[k]);
+            if (x.rows != y.rows || x.features_ != y.features_ || x.feature_positions_ != y.feature_positions_ || x.valid_3d_ != y.valid_3d_ ||
+                x.feature_positions_2d_ != y.feature_positions_2d_ || x.sensor_frame_ != y.sensor_frame_ || x.stamp_ != y.stamp_ ||
+                x.feature_type_ != y.feature_type_ || x.type_ != y.type_ || max_abs_diff(x.displacement_, y.displacement_) > 1e-14) bad |= 16;
+        }
+    }
+    for (auto& kv : back.edges()) {
+        const SlamEdge& a = g.edge(kv.first); const SlamEdge& b = kv.second;
+        if (a.id_from_ != b.id_from_ || a.id_to_ != b.id_to_ || a.type_ != b.type_ || a.sensor_from_ != b.sensor_from_ || a.sensor_to_ != b.sensor_to_ ||
+            a.age_ != b.age_ || a.error_ != b.error_ || a.matching_score_ != b.matching_score_ || a.valid_ != b.valid_ || a.information_ != b.information_ ||
+            std::fabs(a.diff_time_ - b.diff_time_) > 1e-9) bad |= 32;
+        if (max_abs_diff(a.transform_, b.transform_) > 1e-14 || max_abs_diff(a.displacement_from_, b.displacement_from_) > 1e-14) bad |= 64;
+    }
+    FILE* o = fopen(out, "wb");
+    int32_t rep[4] = {bad, (int32_t)back.nodes().size(), (int32_t)back.edges().size(), uzl_match_frame_count(est)};
+    fwrite(rep, 4, 4, o);
+    // the loaded node n00000002's first frame, for the Python side to compare with what it reads from the same file
+    const FeatureData& fd = *std::dynamic_pointer_cast<FeatureData>(back.node(node_id(2)).sensor_data_[0]);
+    int32_t rows = fd.rows; fwrite(&rows, 4, 1, o);
+    fwrite(fd.features_.data(), 1, fd.features_.size(), o); fwrite(fd.feature_positions_.data(), 8, fd.feature_positions_.size(), o);
+    fclose(o);
+    uzl_match_destroy(est);
+    return bad ? 6 : 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 4 && std::string(argv[1]) == "storage") return storage_mode(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "filter") return filter_mode(argv[2], argv[3]);
     if (argc < 3) { fprintf(stderr, "usage: adapter_selftest in.bin out.bin\n"); return 2; }
     FILE* f = fopen(argv[1], "rb");

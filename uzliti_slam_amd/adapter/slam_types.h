@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -22,13 +23,15 @@ struct Isometry3d {
 };
 
 // graph_slam_msgs/msg/Edge.msg, Features.msg, SensorData.msg constants
-enum { TYPE_2D_WHEEL_ODOMETRY = 0, TYPE_3D_FULL = 1, TYPE_2D_LASER = 2, TYPE_3D_LASER = 3 };
+enum { TYPE_3D_FULL = 1, TYPE_3D_ROTATION = 2, TYPE_3D_TRANSLATION = 3, TYPE_3D_GPS = 4, TYPE_2D_FULL = 101, TYPE_2D_ROTATION = 102,
+       TYPE_2D_TRANSLATION = 103, TYPE_2D_WHEEL_ODOMETRY = 104, TYPE_2D_LASER = 105 };
 enum { FEATURE_BRIEF = 1, FEATURE_ORB = 2, FEATURE_BRISK = 3, FEATURE_FREAK = 4 };
-enum { SENSOR_TYPE_FEATURE = 0, SENSOR_TYPE_DEPTH_IMAGE = 1, SENSOR_TYPE_BINARY_GIST = 2, SENSOR_TYPE_LASERSCAN = 3 };
+enum { SENSOR_TYPE_UNKNOWN = 0, SENSOR_TYPE_FEATURE = 1, SENSOR_TYPE_DEPTH_IMAGE = 2, SENSOR_TYPE_BINARY_GIST = 3, SENSOR_TYPE_LASERSCAN = 4 };
 
 struct SensorData {
     virtual ~SensorData() = default;
     int type_ = SENSOR_TYPE_FEATURE;
+    int64_t stamp_ = 0;                      // ros::Time in the reference (sensor_data.h:45): nanoseconds here
     std::string sensor_frame_;
     Isometry3d displacement_;
 };
@@ -40,6 +43,8 @@ struct FeatureData : SensorData {
     int rows = 0, bytes_per_row = 0;
     // Eigen::MatrixXd feature_positions_ (3 x N, column-major)
     std::vector<double> feature_positions_;
+    // Eigen::MatrixXd feature_positions_2d_ (2 x N): pixel coordinates, int32 here as they travel in Feature.msg (u, v)
+    std::vector<int32_t> feature_positions_2d_;
     std::vector<bool> valid_3d_;
 };
 
@@ -50,9 +55,12 @@ struct SlamNode {
     std::string id_;
     std::vector<int64_t> stamps_;            // std::vector<ros::Time> in the reference (slam_node.h:90): nanoseconds here
     Isometry3d pose_;
+    Isometry3d sub_pose_;                    // odometry pose (slam_node.h:91), Node.msg odom_pose
     std::vector<SensorDataPtr> sensor_data_;
     bool fixed_ = false;
     bool optimized_ = false;
+    double uncertainty_ = 0;
+    std::set<std::string> edges_;            // ids of the edges at this node (slam_node.h:104)
 };
 
 struct SlamEdge {

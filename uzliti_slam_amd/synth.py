@@ -7,8 +7,9 @@ Graph: seed 12345; descriptors: seed 777 (overridable).  Shapes follow BASELINE.
 """
 import numpy as np
 
-EDGE_TYPE_ODOM = 0      # graph_slam_msgs/Edge TYPE_2D_WHEEL_ODOMETRY
+EDGE_TYPE_ODOM = 104    # graph_slam_msgs/Edge TYPE_2D_WHEEL_ODOMETRY
 EDGE_TYPE_3D_FULL = 1   # graph_slam_msgs/Edge TYPE_3D_FULL
+EDGE_TYPE_2D_LASER = 105  # graph_slam_msgs/Edge TYPE_2D_LASER
 FEATURE_ORB = 2
 
 
