@@ -317,3 +317,24 @@ def test_stored_graph_loads_into_the_estimator_and_estimates_like_array_frames(c
     for a, b in zip(ra, rb):
         assert a["ok"] == b["ok"] == 1 and a["consensus"] == b["consensus"] and np.array_equal(a["T"], b["T"]) and np.array_equal(a["information"], b["information"])
     m.close()
+
+
+def test_parsers_under_address_and_ub_sanitizers(tmp_path):
+    """The decoders take bytes from disk: 100k mutated / truncated Edge, Node and bag images through an ASan + UBSan build of the
+    host-side codec (sanitizers run on the CPU build only)."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(root, "tests", "golden", "wire_msgs.npz"))
+    seeds = []
+    for k in ("edge_bytes", "node_bytes", "bag_bytes"):
+        p = tmp_path / (k + ".bin"); p.write_bytes(z[k].tobytes()); seeds.append(str(p))
+    exe = str(tmp_path / "fuzz_wire")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-x", "c++",
+                           os.path.join(root, "uzliti_slam_amd", "csrc", "uzl_wire.hip"), os.path.join(root, "tests", "fuzz_wire.cpp"), "-o", exe])
+    out = subprocess.run([exe] + seeds, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "fuzz: 100000 inputs" in out.stdout

@@ -275,7 +275,7 @@ bool parse_fields(const uint8_t* p, uint64_t len, std::vector<Field>& out)
     while (r.ok && r.o < r.n) {
         const uint32_t fl = r.get<uint32_t>();
         const uzl_span f = r.bytes(fl);
-        if (!r.ok) return false;
+        if (!r.ok || f.n == 0) return false;
         const char* eq = static_cast<const char*>(memchr(f.p, '=', f.n));
         if (!eq) return false;
         Field fd;
