@@ -646,54 +646,66 @@ __global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restri
 //      good approximate inverse of A_1: one step squares the error of the cycle, two make it exact to PCG's eyes).
 //      ml_ns_ax_kernel:   T = A_1 X        block-sparse (6x6 blocks) times dense, one lane per (row block, column)
 //      ml_ns_gemm_kernel: X' = 2 X - X T   dense f64 GEMM on the matrix cores (2 n^3 flops, n = 6 n_1 <= 960)
+// one workgroup per (row block i, 256 columns): the row's 6x6 blocks go through LDS once (broadcast reads), every lane owns
+// one column of X and walks the row's neighbours (X rows are read coalesced across the lanes)
+constexpr int kAxChunk = 16;          // off-diagonal blocks staged per pass
 __global__ __launch_bounds__(kBlk) void ml_ns_ax_kernel(PgoDev D, const MlDev* __restrict__ mlp, const double* __restrict__ X,
                                                        double* __restrict__ T)
 {
+    __shared__ double sb[(kAxChunk + 1) * 36];
+    __shared__ int sc[kAxChunk + 1];
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[1];
-    const int n = F.n, n6 = 6 * n;
-    const int t = blockIdx.x * kBlk + threadIdx.x;
-    if (t >= n * n6) return;
-    const int i = t / n6, c = t % n6;
+    const int n6 = 6 * F.n;
+    const int i = blockIdx.x, c = blockIdx.y * kBlk + threadIdx.x, tid = threadIdx.x;
+    const bool act = c < n6;
     const double lambda = D.scal[3];
+    const int s0 = F.row_ptr[i], s1 = F.row_ptr[i + 1];
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    {
-        double x[6];
+    for (int base = s0 - 1; base < s1; base += kAxChunk + 1) {          // "slot" s0 - 1 stands for the diagonal block
+        const int cnt = min(kAxChunk + 1, s1 - base);
+        __syncthreads();
+        for (int e = tid; e < cnt * 36; e += kBlk) {
+            const int q = e / 36, k = e % 36, s = base + q;
+            sb[e] = (s < s0) ? F.G[(size_t)i * 36 + k] + lambda * F.M[(size_t)i * 36 + k] : F.blk[(size_t)s * 36 + k];
+        }
+        if (tid < cnt) sc[tid] = (base + tid < s0) ? i : F.col[base + tid];
+        __syncthreads();
+        if (act) {
+            for (int q = 0; q < cnt; q++) {
+                const int j = sc[q];
+                const double* __restrict__ bq = sb + q * 36;
+                double x[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) x[k] = X[(size_t)(6 * i + k) * n6 + c];
+                for (int k = 0; k < 6; k++) x[k] = X[(size_t)(6 * j + k) * n6 + c];
 #pragma unroll
-        for (int r = 0; r < 6; r++)
+                for (int r = 0; r < 6; r++)
 #pragma unroll
-            for (int k = 0; k < 6; k++) acc[r] += (F.G[(size_t)i * 36 + r * 6 + k] + lambda * F.M[(size_t)i * 36 + r * 6 + k]) * x[k];
+                    for (int k = 0; k < 6; k++) acc[r] += bq[r * 6 + k] * x[k];
+            }
+        }
     }
-    for (int s = F.row_ptr[i]; s < F.row_ptr[i + 1]; s++) {
-        const int j = F.col[s];
-        const double* __restrict__ b = F.blk + (size_t)s * 36;
-        double x[6];
+    if (act) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) x[k] = X[(size_t)(6 * j + k) * n6 + c];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int k = 0; k < 6; k++) acc[r] += b[r * 6 + k] * x[k];
+        for (int r = 0; r < 6; r++) T[(size_t)(6 * i + r) * n6 + c] = acc[r];
     }
-#pragma unroll
-    for (int r = 0; r < 6; r++) T[(size_t)(6 * i + r) * n6 + c] = acc[r];
 }
 
-constexpr int kGemmTile = 64, kGemmK = 16;
+constexpr int kGemmTile = 64, kGemmK = 64;
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 // X' = 2 X - X T on the f64 matrix cores: v_mfma_f64_16x16x4_f64 (lane l feeds A[row l&15][k l>>4] and B[k l>>4][col l&15];
 // the four results of a lane are C[row (l>>4) + 4 r][col l&15], r = 0..3).  A 256-lane workgroup owns a 64 x 64 tile, each
-// of its four waves a 32 x 32 quarter as 2 x 2 MFMA tiles; K is staged through LDS in slabs of 16 (coalesced global
+// of its four waves a 32 x 32 quarter as 2 x 2 MFMA tiles; K is staged through LDS in slabs of 64 (coalesced global
 // reads; one LDS double per MFMA operand, padded rows: no bank pile-up); the next slab is fetched into registers
-// while the matrix cores work on the current one (one workgroup per CU at this size: nothing else would hide the
-// global-load latency of the 47 dependent slabs - 136 -> 55 us at n = 750).
+// while the matrix cores work on the current one.  One workgroup per CU at this size (144 tiles at n = 750), so nothing
+// but the slab's own MFMAs hides the global-load latency of the next slab: with slabs of 16 (47 dependent slabs, 0.2 us
+// of MFMA each) about 1 us per slab stayed exposed (55 us); slabs of 64 leave 12 exposures.
 __global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __restrict__ X, const double* __restrict__ T,
                                                         double* __restrict__ Xn)
 {
     __shared__ double sA[kGemmTile][kGemmK + 1];      // X tile: sA[row][k]
     __shared__ double sB[kGemmK][kGemmTile + 1];      // T tile: sB[k][col]
+    constexpr int kPer = kGemmTile * kGemmK / 256;     // values per lane and operand per slab
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row0 = blockIdx.y * kGemmTile, col0 = blockIdx.x * kGemmTile;
     const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;          // this wave's quarter
@@ -703,15 +715,15 @@ __global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = v4f64{0., 0., 0., 0.};
-    double pa[4], pb[4];
+    double pa[kPer], pb[kPer];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kPer; u++) {
             const int e = u * 256 + tid;
-            const int ar = e >> 4, ak = e & 15;                                  // X: consecutive lanes walk k (contiguous in memory)
+            const int ar = e / kGemmK, ak = e % kGemmK;                          // X: consecutive lanes walk k (contiguous in memory)
             const int gr = row0 + ar, gk = k0 + ak;
             pa[u] = (gr < n && gk < n) ? X[(size_t)gr * n + gk] : 0.;
-            const int bk = e >> 6, bc = e & 63;                                  // T: consecutive lanes walk the column
+            const int bk = e / kGemmTile, bc = e % kGemmTile;                    // T: consecutive lanes walk the column
             const int gk2 = k0 + bk, gc = col0 + bc;
             pb[u] = (gk2 < n && gc < n) ? T[(size_t)gk2 * n + gc] : 0.;
         }
@@ -719,14 +731,14 @@ __global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __
     fetch(0);
     for (int k0 = 0; k0 < n; k0 += kGemmK) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kPer; u++) {
             const int e = u * 256 + tid;
-            sA[e >> 4][e & 15] = pa[u];
-            sB[e >> 6][e & 63] = pb[u];
+            sA[e / kGemmK][e % kGemmK] = pa[u];
+            sB[e / kGemmTile][e % kGemmTile] = pb[u];
         }
         __syncthreads();
         if (k0 + kGemmK < n) fetch(k0 + kGemmK);
-#pragma unroll
+#pragma unroll 4
         for (int k4 = 0; k4 < kGemmK; k4 += 4) {
             const double a0 = sA[wr + li][k4 + lk], a1 = sA[wr + 16 + li][k4 + lk];
             const double b0 = sB[k4 + lk][wc + li], b1 = sB[k4 + lk][wc + 16 + li];
@@ -1535,7 +1547,7 @@ void k_ml_mult_level1(const PgoDev& D, const MlDev* ml, int n1, int n2, hipStrea
 void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int n1, const double* X, double* T, double* Xn, hipStream_t s)
 {
     const int n6 = 6 * n1;
-    hipLaunchKernelGGL(ml_ns_ax_kernel, dim3((n1 * n6 + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, X, T);
+    hipLaunchKernelGGL(ml_ns_ax_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, X, T);
     const int g = (n6 + kGemmTile - 1) / kGemmTile;
     hipLaunchKernelGGL(ml_ns_gemm_kernel, dim3(g, g), dim3(256), 0, s, n6, X, T, Xn);
 }
