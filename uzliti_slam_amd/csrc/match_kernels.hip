@@ -131,6 +131,162 @@ __global__ __launch_bounds__(kBlock) void knn2_lds_kernel(const uint32_t* __rest
         if (qi[u] < c.nq) knn[c.knn_off + qi[u]] = make_uint2(best1[u], best2[u]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Matrix-core variant.  The Hamming distance matrix of two binary descriptor sets IS a GEMM:
+//     d(t, q) = |t| + |q| - 2 <t, q>,   <t, q> = sum over the D bit positions of t_k q_k,
+// so the D-bit descriptors are expanded to D int8 values (0 / 1) and <t, q> for a 32-train x 32-query tile is
+// v_mfma_i32_32x32x32_i8 over D / 32 k-steps (exact integers; both operands take the SAME bit range [32 s + 16 h, +16)
+// for k-step s and lane half h, so the hardware's k order inside a step does not matter).  The accumulator layout puts the
+// query on the lane (col = lane & 31) and 16 train rows in the registers (row = (reg&3) + 8 (reg>>2) + 4 (lane>>5)): every
+// lane keeps a running top-2 for ITS query over the rows it sees, three VALU instructions per distance
+// (v_mad_i32_i24 builds the key (|t| - 2<t,q>) << 20 | t from the per-row word R[t] = |t| << 20 | t, v_med3_i32 + v_min_i32
+// update the pair; |q| is constant per lane and is added at the very end; signed compares keep the order while the
+// partial distance is negative), against 2 x 8 + 3 = 19 for the xor / popcount form; the two lane halves are merged once at the end.
+// One wave owns UT x 32 queries (B fragments expanded once, loop-invariant), a 256-lane workgroup 4 UT x 32; train rows are
+// expanded chunk by chunk into LDS (row stride D + 16 bytes: ds_read_b128 of 16 lanes covers all banks).
+// Ties, keys and the missing-neighbour sentinel are those of knn2_lds_kernel: results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+
+// 4 bits -> 4 bytes of 0 / 1 (bit i -> byte i)
+__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return (nib * 0x00204081u) & 0x01010101u; }
+__device__ __forceinline__ v4i32 spread16(uint32_t bits16)
+{
+    v4i32 v;
+    v.x = (int)spread4(bits16 & 0xfu); v.y = (int)spread4((bits16 >> 4) & 0xfu);
+    v.z = (int)spread4((bits16 >> 8) & 0xfu); v.w = (int)spread4((bits16 >> 12) & 0xfu);
+    return v;
+}
+__device__ __forceinline__ int med3_i32(int a, int b, int c)
+{
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+constexpr int kNegTwoDot = -(1 << (kIdxBits + 1));
+constexpr int kMmInvalid = 1023 << kIdxBits;      // key of a padded train row before |q| is added: above every real key
+
+template <int W, int UT>
+__global__ __launch_bounds__(kBlock) void knn2_mfma_kernel(const uint32_t* __restrict__ arena,
+                                                           const Combo* __restrict__ combos,
+                                                           uint2* __restrict__ knn)
+{
+    constexpr int ROWB = W * 32 + 16;               // bytes per expanded train row in LDS (padded)
+    constexpr int TR = 1024 / W;                    // train rows per chunk: 1024 descriptor words = 4 per lane
+    constexpr int QPB = 4 * UT * 32;                // queries per workgroup
+    __shared__ __attribute__((aligned(16))) uint8_t sA[TR * ROWB];
+    __shared__ __attribute__((aligned(16))) int sR[TR];
+    const Combo c = combos[blockIdx.y];
+    if (c.words != W) return;
+    const int q0 = blockIdx.x * QPB;
+    if (q0 >= c.nq) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, h = lane >> 5;
+    // ---- this lane's queries: B fragments (0 / 1 bytes) and |q|
+    v4i32 bf[UT][W];
+    int pa[UT], qi[UT];
+#pragma unroll
+    for (int u = 0; u < UT; u++) {
+        qi[u] = q0 + (wv * UT + u) * 32 + col;
+        const int qc = qi[u] < c.nq ? qi[u] : c.nq - 1;
+        const uint4* __restrict__ qd = reinterpret_cast<const uint4*>(arena + c.desc_to_off + (size_t)qc * W);
+        int pc = 0;
+#pragma unroll
+        for (int k = 0; k < W / 4; k++) {
+            const uint4 v = qd[k];
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                pc += __popc(w4[j]);
+                bf[u][4 * k + j] = spread16((w4[j] >> (16 * h)) & 0xffffu);
+            }
+        }
+        pa[u] = pc;
+    }
+    int b1[UT], b2[UT];
+#pragma unroll
+    for (int u = 0; u < UT; u++) { b1[u] = 0x7fffffff; b2[u] = 0x7fffffff; }
+    // -2^21 as an opaque uniform value: with a literal the compiler rewrites the multiply-add as shift + subtract (two
+    // instructions).  The instruction is left to the compiler (not inline asm): it is the first reader of the MFMA result and
+    // the compiler, not the hardware, pads the MFMA -> VALU read hazard.
+    int neg2dot = kNegTwoDot;
+    asm volatile("" : "+s"(neg2dot));
+    const uint32_t* __restrict__ td = arena + c.desc_from_off;
+    const int nt = c.nt;
+    // descriptor words of the next chunk are fetched while the matrix cores work on the current one
+    uint32_t nxt[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int widx = i * kBlock + tid, t = widx / W;
+        nxt[i] = (t < nt) ? td[(size_t)t * W + widx % W] : 0u;
+    }
+    for (int t0 = 0; t0 < nt; t0 += TR) {
+        __syncthreads();
+        // ---- expand TR train rows: lane -> 4 descriptor words (coalesced), 32 bytes of 0 / 1 each; R[row] = |t| << 20 | t
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int widx = i * kBlock + tid, row = widx / W, word = widx % W, t = t0 + row;
+            const uint32_t wd = nxt[i];
+            uint4* dst = reinterpret_cast<uint4*>(sA + row * ROWB + word * 32);
+            const v4i32 lo = spread16(wd & 0xffffu), hi = spread16(wd >> 16);
+            dst[0] = make_uint4((uint32_t)lo.x, (uint32_t)lo.y, (uint32_t)lo.z, (uint32_t)lo.w);
+            dst[1] = make_uint4((uint32_t)hi.x, (uint32_t)hi.y, (uint32_t)hi.z, (uint32_t)hi.w);
+            int pc = __popc(wd);
+#pragma unroll
+            for (int m = 1; m < W; m <<= 1) pc += __shfl_xor(pc, m);          // the W lanes of a row are consecutive
+            if (word == 0) sR[row] = (t < nt) ? ((pc << kIdxBits) | t) : (kMmInvalid | (t & (int)kIdxMask));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int widx = i * kBlock + tid, t = t0 + TR + widx / W;
+            nxt[i] = (t < nt) ? td[(size_t)t * W + widx % W] : 0u;
+        }
+        __syncthreads();
+        const int rows_here = min(TR, nt - t0);
+        for (int r0 = 0; r0 < rows_here; r0 += 32) {
+            v16i32 acc[UT];
+#pragma unroll
+            for (int u = 0; u < UT; u++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[u][k] = 0;
+            const uint8_t* arow = sA + (r0 + col) * ROWB + 16 * h;
+#pragma unroll
+            for (int s_ = 0; s_ < W; s_++) {
+                const v4i32 a = *reinterpret_cast<const v4i32*>(arow + 32 * s_);
+#pragma unroll
+                for (int u = 0; u < UT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[u][s_], acc[u], 0, 0, 0);
+            }
+            // rows of this lane's registers: 8 (reg>>2) + 4 h + (reg&3)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const v4i32 rr = *reinterpret_cast<const v4i32*>(sR + r0 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+#pragma unroll
+                    for (int u = 0; u < UT; u++) {
+                        const int kk = __mul24(acc[u][4 * g4 + j], neg2dot) + rr[j];          // v_mad_i32_i24: R - (<t,q> << 21)
+                        b2[u] = med3_i32(b1[u], b2[u], kk);
+                        b1[u] = min(b1[u], kk);
+                    }
+                }
+            }
+        }
+    }
+    // ---- merge the two lane halves (same query, disjoint train rows), add |q|, restore the sentinel
+#pragma unroll
+    for (int u = 0; u < UT; u++) {
+        const int c1 = __shfl_xor(b1[u], 32), c2 = __shfl_xor(b2[u], 32);
+        const int m1 = min(b1[u], c1);
+        const int m2 = min(max(b1[u], c1), min(b2[u], c2));
+        if (h == 0 && qi[u] < c.nq) {
+            const uint32_t k1 = (m1 >= kMmInvalid) ? 0xffffffffu : (uint32_t)(m1 + (pa[u] << kIdxBits));
+            const uint32_t k2 = (m2 >= kMmInvalid) ? 0xffffffffu : (uint32_t)(m2 + (pa[u] << kIdxBits));
+            knn[c.knn_off + qi[u]] = make_uint2(k1, k2);
+        }
+    }
+}
+
 // generic descriptor width (words not 8 / 16): query words re-read from L1 each step
 __global__ __launch_bounds__(kBlock) void knn2_generic_kernel(const uint32_t* __restrict__ arena,
                                                               const Combo* __restrict__ combos,
@@ -774,12 +930,17 @@ void launch_knn2(const uint32_t* arena, const Combo* combos, int n_combos, int m
     if (n_combos <= 0 || max_nq <= 0) return;
     dim3 grid((max_nq + kBlock - 1) / kBlock, n_combos);
     static const bool scalar_path = getenv("UZL_KNN2_SCALAR") != nullptr;   // A/B switch: train rows by scalar loads
+    static const bool valu_path = getenv("UZL_KNN2_VALU") != nullptr;       // A/B switch: xor / popcount on the vector ALU (LDS-staged)
     if (scalar_path) {
         if (has8) hipLaunchKernelGGL(knn2_kernel<8>, grid, dim3(kBlock), 0, s, arena, combos, knn);
         if (has16) hipLaunchKernelGGL(knn2_kernel<16>, grid, dim3(kBlock), 0, s, arena, combos, knn);
-    } else {
+    } else if (valu_path) {
         if (has8) hipLaunchKernelGGL((knn2_lds_kernel<8, 1>), grid, dim3(kBlock), 0, s, arena, combos, knn);
         if (has16) hipLaunchKernelGGL((knn2_lds_kernel<16, 1>), grid, dim3(kBlock), 0, s, arena, combos, knn);
+    } else {
+        // matrix-core path: 256 (W = 8) / 128 (W = 16) queries per workgroup
+        if (has8) hipLaunchKernelGGL((knn2_mfma_kernel<8, 2>), dim3((max_nq + 255) / 256, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
+        if (has16) hipLaunchKernelGGL((knn2_mfma_kernel<16, 1>), dim3((max_nq + 127) / 128, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
     }
     if (has_generic) hipLaunchKernelGGL(knn2_generic_kernel, grid, dim3(kBlock), 0, s, arena, combos, knn);
 }
