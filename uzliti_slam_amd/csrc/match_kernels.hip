@@ -805,44 +805,53 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
         // sequential in the inliers, but its 9 covariance entries are independent of each other: lane (r, c) of wave 0
         // carries cov[r][c] together with its own copies of mean1[c] and mean2[r] and performs exactly the scalar
         // operations of pose_add for that entry (bit-identical to the single-lane loop, ~5x shorter dependency chain).
+        // First, by the whole workgroup: the inliers in order (ballot-ordered compaction) with alpha = 1 / (their 1-based rank):
+        // the sequential wave then walks exactly the inliers, with no per-point branch and no division on its issue slots.
+        // {index, alpha} pairs live in `dist`, which is not used before the recount.
+        int2* sel = reinterpret_cast<int2*>(dist);
+        int n_in = 0;
+        for (int m0 = 0; m0 < M; m0 += kEstBlock) {
+            const int m = m0 + tid, lane = tid & 63, wv = tid >> 6;
+            const bool in = m < M && mask[m] != 0;
+            const unsigned long long bal = __ballot(in);
+            if (lane == 0) s_part[wv] = __popcll(bal);
+            __syncthreads();
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < kEstBlock / 64; w++) { const int c = s_part[w]; tot += c; if (w < wv) woff += c; }
+            if (in) {
+                const int pos = n_in + woff + __popcll(bal & ((1ull << lane) - 1ull));
+                // accw counts inliers in float (exact small integers): alpha = 1 / accw after the increment
+                sel[pos] = make_int2(m, __float_as_int(1.f / (float)(pos + 1)));
+            }
+            n_in += tot;
+            __syncthreads();
+        }
         if (tid < 64) {
             const int rr = (tid < 9) ? tid / 3 : 0, cc = (tid < 9) ? tid % 3 : 0;
-            float cov = 0.f, m1 = 0.f, m2 = 0.f, accw = 0.f;
-            for (int m0 = 0; m0 < M; m0 += 8) {
-                float pc[8], qr[8], al[8];
-                bool in[8];
+            float cov = 0.f, m1 = 0.f, m2 = 0.f;
+            const int n_u = __builtin_amdgcn_readfirstlane(n_in);
+            for (int k0 = 0; k0 < n_u; k0 += 8) {
+                int2 e[8];
                 double pd[8], qd[8];
-                uint8_t mk[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) e[u] = sel[(k0 + u < n_u) ? k0 + u : n_u - 1];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { pd[u] = pq[e[u].x * 6 + cc]; qd[u] = pq[e[u].x * 6 + 3 + rr]; }
+                __builtin_amdgcn_sched_barrier(0);          // all LDS reads in flight before the first use
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int m = (m0 + u < M) ? m0 + u : M - 1;
-                    mk[u] = mask[m]; pd[u] = pq[m * 6 + cc]; qd[u] = pq[m * 6 + 3 + rr];
-                }
-                __builtin_amdgcn_sched_barrier(0);          // all 24 LDS reads in flight before the first use
-                float cntf = accw;
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    in[u] = (m0 + u < M) && mk[u] != 0;
-                    pc[u] = (float)pd[u];
-                    qr[u] = (float)qd[u];
-                    // accw only counts inliers (exact small integers in float), so alpha = 1/accw does not depend on
-                    // the recurrence: the eight divisions are taken off its dependency chain
-                    if (in[u]) cntf += 1.f;
-                    al[u] = 1.f / cntf;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    if (in[u]) {
-                        accw += 1.f;
-                        const float alpha = al[u];
+                    if (k0 + u < n_u) {                     // wave-uniform
+                        const float alpha = __int_as_float(e[u].y);
                         const float om = 1.f - alpha;
-                        const float d1 = pc[u] - m1, d2 = qr[u] - m2;
+                        const float d1 = (float)pd[u] - m1, d2 = (float)qd[u] - m2;
                         cov = om * (cov + alpha * (d2 * d1));
                         m1 += alpha * d1;
                         m2 += alpha * d2;
                     }
                 }
             }
+            const float accw = (float)n_u;
             // gather the 9 + 3 + 3 values into lane 0
             PoseAcc acc;
             acc.c00 = __shfl(cov, 0); acc.c01 = __shfl(cov, 1); acc.c02 = __shfl(cov, 2);
