@@ -671,17 +671,55 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
             // ---- M4b: std::sort by distance (:114), order fixed to (distance, queryIdx): bitonic in LDS
             int n2 = 1;
             while (n2 < M) n2 <<= 1;
-            for (int k = 2; k <= n2; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < n2; i += kEstBlock) {
-                        const int ixj = i ^ j;
-                        if (ixj > i) {
-                            const uint32_t a = s_keys[i], b = s_keys[ixj];
-                            const bool up = (i & k) == 0;
-                            if ((a > b) == up) { s_keys[i] = b; s_keys[ixj] = a; }
+            if (n2 >= kEstBlock) {
+                // Each wave owns a contiguous quarter of the array: every compare-exchange with distance j < n2 / 4 stays
+                // inside one wave's quarter, where program order + the in-order LDS queue are synchronisation enough.  Only
+                // the three stages with j >= n2 / 4 (of 55 at n2 = 1024) cross waves and need workgroup barriers.
+                const int seg = n2 >> 2, lane = tid & 63, wbase = (tid >> 6) * seg;
+                for (int k = 2; k <= n2; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        if (j >= seg) {
+                            __syncthreads();
+                            for (int i = tid; i < n2; i += kEstBlock) {
+                                const int ixj = i ^ j;
+                                if (ixj > i) {
+                                    const uint32_t a = s_keys[i], b = s_keys[ixj];
+                                    const bool up = (i & k) == 0;
+                                    if ((a > b) == up) { s_keys[i] = b; s_keys[ixj] = a; }
+                                }
+                            }
+                            __syncthreads();
+                        } else {
+                            // pair index p -> lower element i (bit log2(j) cleared); two pairs per pass, all four reads in
+                            // flight before the first compare (the stage is LDS-latency bound, not throughput bound)
+                            for (int p0 = lane; p0 < (seg >> 1); p0 += 128) {
+                                const int p1 = p0 + 64;
+                                const bool two = p1 < (seg >> 1);
+                                const int i0 = wbase + (((p0 & ~(j - 1)) << 1) | (p0 & (j - 1)));
+                                const int i1 = two ? wbase + (((p1 & ~(j - 1)) << 1) | (p1 & (j - 1))) : i0;
+                                const uint32_t a0 = s_keys[i0], b0 = s_keys[i0 + j], a1 = s_keys[i1], b1 = s_keys[i1 + j];
+                                if ((a0 > b0) == ((i0 & k) == 0)) { s_keys[i0] = b0; s_keys[i0 + j] = a0; }
+                                if (two && (a1 > b1) == ((i1 & k) == 0)) { s_keys[i1] = b1; s_keys[i1 + j] = a1; }
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's exchanges have landed before its next stage
+                            __builtin_amdgcn_wave_barrier();
                         }
                     }
-                    __syncthreads();
+                }
+                __syncthreads();
+            } else {
+                for (int k = 2; k <= n2; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int i = tid; i < n2; i += kEstBlock) {
+                            const int ixj = i ^ j;
+                            if (ixj > i) {
+                                const uint32_t a = s_keys[i], b = s_keys[ixj];
+                                const bool up = (i & k) == 0;
+                                if ((a > b) == up) { s_keys[i] = b; s_keys[ixj] = a; }
+                            }
+                        }
+                        __syncthreads();
+                    }
                 }
             }
             MSTAMP();   // 1: bitonic sort
