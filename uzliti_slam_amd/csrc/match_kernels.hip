@@ -786,21 +786,37 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
                 for (; m < M; m++) cnt += (point_dist2(pq + m * 6, T) < thr2) ? 1 : 0;
                 s_cnt[it] = cnt;
             }
-            __syncthreads();
-            // replay the sequential bookkeeping of :233-242 over this round's votes
-            if (tid == 0) {
+            // ---- the sequential bookkeeping of :233-242 over this round's votes, without the sequence.  The loop keeps a
+            // running strict maximum (first index wins ties) and stops at the first NEW maximum that satisfies
+            // stop(c) = c >= 3 && c > break_pct * M.  stop() is monotone in c, so the first iteration whose own count satisfies
+            // it is necessarily a new maximum (an earlier count at least as large would have satisfied it first, in this
+            // round or a previous one): the stopping iteration is a ballot, the maximum up to it a reduction.
+            {
+                const int lane = tid & 63, wv = tid >> 6;
+                const int c = (it < iters) ? s_cnt[it] : -1;           // own vote (just written by this lane)
+                const bool trig = c >= 3 && (double)c > prm.break_pct * (double)M;
+                const unsigned long long tb = __ballot(trig);
+                if (lane == 0) s_part[wv] = tb ? (wv * 64 + (int)__builtin_ctzll(tb)) : kEstBlock;
+                __syncthreads();
+                int first = kEstBlock;
+#pragma unroll
+                for (int w = kEstBlock / 64 - 1; w >= 0; w--) first = (s_part[w] < kEstBlock) ? s_part[w] : first;   // lowest wave that has one
+                __syncthreads();
                 const int rend = (r0 + kEstBlock < iters) ? r0 + kEstBlock : iters;
-                int mc = s_misc[0], bi = s_misc[1], ir = s_misc[2], st = 0;
-                if (r0 == 0) { mc = 0; bi = -1; ir = 0; }
-                for (int i = r0; i < rend; i++) {
-                    const int c = s_cnt[i];
-                    ir = i + 1;
-                    if (c > mc) {
-                        mc = c; bi = i;
-                        if (mc >= 3 && (double)mc > prm.break_pct * (double)M) { st = 1; break; }
-                    }
+                const int last = (first < kEstBlock) ? first : rend - r0 - 1;                                 // local index of the last iteration that counts
+                int key = (tid <= last && c >= 0) ? ((c << 8) | (kEstBlock - 1 - tid)) : -1;                    // max count, then lowest index
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o));
+                if (lane == 0) s_part[wv] = key;
+                __syncthreads();
+                int best = -1;
+#pragma unroll
+                for (int w = 0; w < kEstBlock / 64; w++) best = max(best, s_part[w]);
+                if (tid == 0) {
+                    int mc = (r0 == 0) ? 0 : s_misc[0], bi = (r0 == 0) ? -1 : s_misc[1];
+                    if (best >= 0 && (best >> 8) > mc) { mc = best >> 8; bi = r0 + (kEstBlock - 1 - (best & 0xff)); }
+                    s_misc[0] = mc; s_misc[1] = bi; s_misc[2] = r0 + last + 1; s_misc[3] = (first < kEstBlock) ? 1 : 0;
                 }
-                s_misc[0] = mc; s_misc[1] = bi; s_misc[2] = ir; s_misc[3] = st;
             }
             __syncthreads();
             stop = s_misc[3] != 0;
