@@ -931,23 +931,23 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
             const double d2 = point_dist2(pq + m * 6, Tfin);
             const bool in = d2 < thr2;
             mask[m] = in ? 1 : 0;
-            dist[m] = sqrt(d2);
+            dist[m] = in ? sqrt(d2) : 0.;                                                // outliers add + 0.0: the sum is unchanged
             c += in ? 1 : 0;
         }
         cons = block_sum(c, s_part);
         if (tid == 0) {
             double e = 0.;
             int m = 0;
-            for (; m + 8 <= M; m += 8) {                                                // :285-289, index order; loads batched
-                double dv[8];
-                uint8_t mv[8];
+            for (; m + 16 <= M; m += 16) {                                              // :285-289, index order; loads batched
+                double2 dv[8];
+                const double2* __restrict__ d2p = reinterpret_cast<const double2*>(dist + m);
 #pragma unroll
-                for (int u = 0; u < 8; u++) { mv[u] = mask[m + u]; dv[u] = dist[m + u]; }
+                for (int u = 0; u < 8; u++) dv[u] = d2p[u];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 8; u++) e += mv[u] ? dv[u] : 0.;                    // + 0.0 leaves the sum unchanged
+                for (int u = 0; u < 8; u++) { e += dv[u].x; e += dv[u].y; }
             }
-            for (; m < M; m++) if (mask[m]) e += dist[m];
+            for (; m < M; m++) e += dist[m];
             s_dbl[0] = e / cons;                                                        // :290
         }
         __syncthreads();
