@@ -147,11 +147,18 @@ def bench_formats(capi, dev, pairs, n_kp):
     gd, gp, gv = W.get_frame(m, ids[-1])
     ok = bool(np.array_equal(gd, frames[-1]["desc"]) and np.array_equal(gp, np.asarray(frames[-1]["pos"], np.float64)) and np.array_equal(gv, np.asarray(frames[-1]["valid"], np.uint8)))
     m.close()
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and len(frames) == 1024 and n_kp == 1000:                 # the PMC passes were collected on this workload
+        try:
+            traffic = json.load(open(tpath)).get("wire_unpack_bytes_per_launch")
+        except Exception:
+            traffic = None
     alg = float(n_kp_total) * ((41 + 4 * D) + (D + 25))
     ach = alg / (best * 1e-3) / 1e9 if best and best > 0 else 0.0
     return dict(kernel="wire_unpack_kernel", workload="%d frames x %d keypoints, ORB-256: Feature records -> frame arena, one launch" % (len(frames), n_kp),
                 ms=round(best or 0.0, 4), roofline=dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                                                          algorithmic_bytes=alg, traffic=None),
+                                                          algorithmic_bytes=alg, traffic=traffic),
                 matches_source_arrays=ok)
 
 

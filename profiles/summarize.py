@@ -41,7 +41,8 @@ for k, d in pmc.items():
 json.dump(pmc, open(out + "_pmc.json", "w"), indent=1, sort_keys=True)
 t = {}
 for key, names in (("pcg_spmv_bytes_per_launch", ("uzl::ml_spmv_kernel<1>", "uzl::ml_spmv_kernel<4>", "uzl::ml_spmv_kernel", "uzl::pcg_spmv_kernel")),
-                   ("knn2_bytes_per_launch", ("uzl::knn2_lds_kernel<8, 1>", "uzl::knn2_kernel<8>"))):
+                   ("knn2_bytes_per_launch", ("uzl::knn2_mfma_kernel<8, 2>", "uzl::knn2_lds_kernel<8, 1>", "uzl::knn2_kernel<8>")),
+                   ("wire_unpack_bytes_per_launch", ("uzl::wire_unpack_kernel",))):
     for nm in names:
         if nm in pmc:
             t[key] = pmc[nm]["hbm_bytes_per_launch"]
