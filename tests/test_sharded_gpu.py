@@ -39,7 +39,7 @@ class InProcessAllReduce:
         return allreduce
 
 
-@pytest.mark.parametrize("n,e,world", [(300, 1200, 2), (1000, 5000, 2), (600, 2500, 3)])
+@pytest.mark.parametrize("n,e,world", [(300, 1200, 2), (1000, 5000, 2), (600, 2500, 3), (3000, 12000, 2)])
 def test_sharded_equals_unsharded(capi, oracle, n, e, world):
     g = synth.make_pose_graph(n, e, seed=n + world)
     ref = capi.Pgo()

@@ -502,8 +502,9 @@ __device__ __forceinline__ void diag6(const MlLevel& F, int i, double lambda, do
 __global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev* __restrict__ mlp)
 {
     const MlDev& ml = *mlp;
-    const MlLevel& F = ml.lv[1];
-    const int n = F.n, np = ml.lv[2].n, fan = ml.lv[2].fan;
+    const int cl = ml.comp_level;                     // level of the dense operator: 1 (small graphs) or 2 (AGG = 4)
+    const MlLevel& F = ml.lv[cl];
+    const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan;
     const int t = blockIdx.x * kBlk + threadIdx.x;
     if (t >= n * np) return;
     const int i = t / np, p = t % np;
@@ -530,8 +531,9 @@ __global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev*
 __global__ __launch_bounds__(kBlk) void ml_mult_q_kernel(const MlDev* __restrict__ mlp)
 {
     const MlDev& ml = *mlp;
-    const MlLevel& F = ml.lv[1];
-    const int n = F.n, np = ml.lv[2].n, fan = ml.lv[2].fan, m = 6 * fan;
+    const int cl = ml.comp_level;                     // level of the dense operator: 1 (small graphs) or 2 (AGG = 4)
+    const MlLevel& F = ml.lv[cl];
+    const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
     const int tt = blockIdx.x * kBlk + threadIdx.x;
     if (tt >= n * np * 6) return;
     const int t = tt / 6, r = tt % 6;
@@ -563,12 +565,13 @@ __global__ __launch_bounds__(kBlk) void ml_mult_q_kernel(const MlDev* __restrict
 __global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restrict__ mlp)
 {
     const MlDev& ml = *mlp;
-    const int n = ml.lv[1].n, np = ml.lv[2].n, np6 = 6 * np;
+    const int cl = ml.comp_level;
+    const int n = ml.lv[cl].n, np = ml.lv[cl + 1].n, np6 = 6 * np;
     const int tt = blockIdx.x * kBlk + threadIdx.x;
     if (tt >= n * np * 6) return;
     const int t = tt / 6, r = tt % 6;
     const int i = t / np, p = t % np;
-    const double* __restrict__ Y2 = (ml.levels == 2) ? ml.top_inv : ml.Ydense[2];
+    const double* __restrict__ Y2 = (ml.levels == cl + 1) ? ml.top_inv : ml.Ydense[cl + 1];
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int pp = 0; pp < np; pp++) mr6_acc(ml.mQ + ((size_t)i * np + pp) * 36 + r * 6, Y2 + (size_t)(6 * pp) * np6 + 6 * p, np6, acc, 1.);
     double* o = ml.mQY + (size_t)t * 36 + r * 6;
@@ -580,8 +583,9 @@ __global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restric
 __global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev* __restrict__ mlp)
 {
     const MlDev& ml = *mlp;
-    const MlLevel& F = ml.lv[1];
-    const int n = F.n, fan = ml.lv[2].fan, m = 6 * fan;
+    const int cl = ml.comp_level;                     // level of the dense operator: 1 (small graphs) or 2 (AGG = 4)
+    const MlLevel& F = ml.lv[cl];
+    const int n = F.n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
     const int t = blockIdx.x * kBlk + threadIdx.x;
     if (t >= n * n) return;
     const int j = t / n, ip = t % n, gp = ip / fan;
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev*
         diag6(F, j, lambda, Dm);
         mm6_acc(Dm, 6, W + (size_t)((j % fan) * 6) * m, m, acc, 1.);
     }
-    const int np = ml.lv[2].n;
+    const int np = ml.lv[cl + 1].n;
     for (int s = ml.grp_beg[(size_t)j * np + gp]; s < ml.grp_end[(size_t)j * np + gp]; s++)
         mm6_acc(F.blk + (size_t)s * 36, 6, W + (size_t)((F.col[s] % fan) * 6) * m, m, acc, 1.);
     double* o = ml.mAS + (size_t)t * 36;
@@ -607,8 +611,9 @@ __global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev*
 __global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restrict__ mlp)
 {
     const MlDev& ml = *mlp;
-    const MlLevel& F = ml.lv[1];
-    const int n = F.n, np = ml.lv[2].n, fan = ml.lv[2].fan, m = 6 * fan;
+    const int cl = ml.comp_level;                     // level of the dense operator: 1 (small graphs) or 2 (AGG = 4)
+    const MlLevel& F = ml.lv[cl];
+    const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
     // one 64-lane workgroup per (group, group') tile of fan x fan blocks: the tile's rows of QY / Q / AS are shared
     // through L1 instead of being fetched once per block from L2
     const int g = blockIdx.x / np, gp = blockIdx.x % np;
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restri
                 acc[r * 6 + c] += sacc;
             }
     }
-    double* __restrict__ Y = ml.Ydense[1];
+    double* __restrict__ Y = ml.Ydense[cl];
     const int n6 = 6 * n;
 #pragma unroll
     for (int k = 0; k < 36; k++) Y[(size_t)(6 * i + k / 6) * n6 + 6 * ip + k % 6] = acc[k];
@@ -655,7 +660,8 @@ __global__ __launch_bounds__(kBlk) void ml_ns_ax_kernel(PgoDev D, const MlDev* _
     __shared__ double sb[(kAxChunk + 1) * 36];
     __shared__ int sc[kAxChunk + 1];
     const MlDev& ml = *mlp;
-    const MlLevel& F = ml.lv[1];
+    const int cl = ml.comp_level;                     // level of the dense operator: 1 (small graphs) or 2 (AGG = 4)
+    const MlLevel& F = ml.lv[cl];
     const int n6 = 6 * F.n;
     const int i = blockIdx.x, c = blockIdx.y * kBlk + threadIdx.x, tid = threadIdx.x;
     const bool act = c < n6;
@@ -1110,6 +1116,9 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     const int tid = threadIdx.x;
     const int Lt = H.levels;
     const int gl = (AGG == 1 || Lt < 2) ? 1 : 2;               // gather level
+    // AGG = 4 with the dense operator of level 2 (H.Cmat = Y_2, rows 6 A .. 6 A + 5 belong to workgroup A): the level-2
+    // correction is six rows of Y_2 times the gather-level residual; the restrict / top-solve / sibling-chain walk is skipped
+    const bool comp = (AGG == 4) && H.Cmat != nullptr;
     const int a = blockIdx.x * kRowsPerBlk + tid / 6, r = tid % 6;
     const bool act = tid < kRowsPerBlk * 6 && a < D.nb;
     const int n1 = H.n[1], ng = H.n[gl];
@@ -1198,17 +1207,17 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     {
         const double* __restrict__ gsrc = H.geo[gl];
 #pragma unroll
-        for (int u = 0; u < kGeoU; u++) { const int t = u * kCgBlk + tid; gv[u] = (t < g_tot) ? gsrc[t] : 0.; }
+        for (int u = 0; u < kGeoU; u++) { const int t = u * kCgBlk + tid; gv[u] = (!comp && t < g_tot) ? gsrc[t] : 0.; }
 #pragma unroll
         for (int u = 0; u < kTopU; u++) {
             const int t = u * kCgBlk + tid;
-            tv[u] = (t < top_n && top_base + t < (size_t)ntop * ntop) ? H.top_inv[top_base + t] : 0.;
+            tv[u] = (!comp && t < top_n && top_base + t < (size_t)ntop * ntop) ? H.top_inv[top_base + t] : 0.;
         }
 #pragma unroll
         for (int q = 0; q < kChainLv; q++) {       // level l = q + 2; fan-out of levels >= 3 is kMlFanout: 48 x 48 sibling blocks
             const int l = q + 2;
             cv[q][0] = 0.; cv[q][1] = 0.;
-            if (l < Lt) {
+            if (l < Lt && !comp) {
                 const double* __restrict__ wl = H.Winv[l] + ((size_t)anc[l + 1] * 48 + (size_t)(anc[l] % kMlFanout) * 6) * 48;
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
@@ -1234,24 +1243,41 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     }
     for (int t = kGatherU * kCgBlk + tid; t < 6 * ng; t += kCgBlk)       // graphs beyond 12k free vertices: latency exposed
         dyn[roff[gl] + t] = rg_old[t] - (init ? 0. : alpha * H.Sg[t]);
+    if (!comp) {
 #pragma unroll
-    for (int u = 0; u < kGeoU; u++) { const int t = u * kCgBlk + tid; if (t < g_tot) dyn[goff[gl] + t] = gv[u]; }
-    for (int t = kGeoU * kCgBlk + tid; t < g_tot; t += kCgBlk) dyn[goff[gl] + t] = H.geo[gl][t];      // very large graphs
+        for (int u = 0; u < kGeoU; u++) { const int t = u * kCgBlk + tid; if (t < g_tot) dyn[goff[gl] + t] = gv[u]; }
+        for (int t = kGeoU * kCgBlk + tid; t < g_tot; t += kCgBlk) dyn[goff[gl] + t] = H.geo[gl][t];      // very large graphs
 #pragma unroll
-    for (int u = 0; u < kTopU; u++) { const int t = u * kCgBlk + tid; if (t < top_n) dyn[top_off + t] = tv[u]; }
-    for (int t = kTopU * kCgBlk + tid; t < top_n; t += kCgBlk)
-        dyn[top_off + t] = (top_base + t < (size_t)ntop * ntop) ? H.top_inv[top_base + t] : 0.;
+        for (int u = 0; u < kTopU; u++) { const int t = u * kCgBlk + tid; if (t < top_n) dyn[top_off + t] = tv[u]; }
+        for (int t = kTopU * kCgBlk + tid; t < top_n; t += kCgBlk)
+            dyn[top_off + t] = (top_base + t < (size_t)ntop * ntop) ? H.top_inv[top_base + t] : 0.;
 #pragma unroll
-    for (int q = 0; q < kChainLv; q++) {
-        if (q + 2 < Lt) {
+        for (int q = 0; q < kChainLv; q++) {
+            if (q + 2 < Lt) {
 #pragma unroll
-            for (int u = 0; u < 2; u++) { const int t = u * kCgBlk + tid; if (t < kChain) dyn[chain_off + q * kChain + t] = cv[q][u]; }
+                for (int u = 0; u < 2; u++) { const int t = u * kCgBlk + tid; if (t < kChain) dyn[chain_off + q * kChain + t] = cv[q][u]; }
+            }
         }
     }
     __syncthreads();
     STAMP(0);      // 3: gather-level residual estimate
+    if (comp) {
+        // y_2[own aggregate] = Y_2[rows 6 A .. 6 A + 5] . r_2   (32 lanes per row, fixed summation order)
+        const int row = tid >> 5, j = tid & 31, n6 = 6 * ng;
+        double sacc = 0.;
+        if (row < 6) {
+            const double* __restrict__ yr = H.Cmat + ((size_t)blockIdx.x * 6 + row) * n6;
+            const double* __restrict__ rr = dyn + roff[gl];
+#pragma unroll 8
+            for (int t = j; t < n6; t += 32) sacc += yr[t] * rr[t];      // eight global loads in flight per lane
+        }
+        sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
+        sacc += __shfl_xor(sacc, 8); sacc += __shfl_xor(sacc, 16);
+        if (row < 6 && j == 0) syc[row] = sacc;
+        __syncthreads();
+    }
     // ---- restrict up to the top level: 8 lanes per (parent, component), one child each, xor-shuffle fold
-    for (int l = gl + 1; l <= Lt; l++) {
+    for (int l = gl + 1; l <= Lt && !comp; l++) {
         const int nC = H.n[l - 1], nP = H.n[l], fan = H.fan[l];
         const int tasks = nP * 6 * 8;
         for (int t0 = 0; t0 < tasks; t0 += kCgBlk) {
@@ -1273,7 +1299,7 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
             for (int c = 0; c < ntop; c++) sacc += dyn[top_off + tid * ntop + c] * rtop[c];
             sy[tid] = (A1 < n1) ? sacc : 0.;
         }
-    } else {
+    } else if (!comp) {
         {   // 8 lanes per top row
             const int row = tid >> 3, j = tid & 7;
             double sacc = 0.;

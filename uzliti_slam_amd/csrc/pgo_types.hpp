@@ -98,6 +98,7 @@ struct MlLevel {
 
 struct MlDev {
     int32_t levels;            // number of coarse levels L (0 = plain block-Jacobi)
+    int32_t comp_level;        // composite path: level whose dense operator Ydense[comp_level] the PCG kernel applies (1 or 2); 0 = off
     MlLevel lv[kMlMaxLevels + 1];
     double* tmp;               // contribution scratch [max contributions][36]
     double* tmpG;              // [max n][36]

@@ -92,6 +92,7 @@ struct uzl_pgo {
     int ml_inner_aggs = 0;
     bool ml_trial_setup = false;     // the preconditioner's per-trial part (sibling inverses, top, dense levels) is due
     bool ml_comp = false;
+    int ml_cl = 0;                   // level of the dense operator (1: small graphs, 2: AGG = 4), 0 = none
     int ml_ns_steps = 0;             // Newton-Schulz refinements of the dense level-1 operator per rebuild
     double* ml_ns_T = nullptr; double* ml_ns_X = nullptr; double* ml_y1 = nullptr;
     double lambda_now = 0., ml_lambda_setup = 0.;   // lambda of the current trial / of the last trial set-up of the hierarchy
@@ -334,28 +335,36 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     const size_t o_geo_blob = take(geo_blob_doubles * 8 + 64);     // ml_cg copies levels g..L-1 with one linear loop
     // composite path: one aggregate per workgroup, at least two coarse levels, 6 n_1 <= 960 (<= 1280 free vertices)
     static const bool comp_off = getenv("UZL_ML_NO_COMP") != nullptr;                // A/B switch
-    h->ml_comp = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 960;
+    // large graphs (AGG = 4, gather level 2): the same construction one level up - the hierarchy above level 2 as one dense
+    // operator (6 n_2 <= 2400: up to ~12.8k free vertices, 46 MB) that ml_cg_kernel<4> applies instead of its LDS walk
+    static const bool comp4_off = getenv("UZL_ML_NO_COMP4") != nullptr;             // A/B switch
+    static const int comp4_max = getenv("UZL_ML_COMP4_MAX") ? atoi(getenv("UZL_ML_COMP4_MAX")) : 2400;
+    const bool comp1 = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 960;
+    const bool comp4 = !comp_off && !comp4_off && h->ml_agg == 4 && L >= 3 && 6 * h->ml_n[2] <= comp4_max;
+    h->ml_comp = comp1 || comp4;
+    h->ml_cl = comp1 ? 1 : (comp4 ? 2 : 0);
+    const int cl = h->ml_cl;
     std::vector<size_t> o_dense((size_t)L + 1, 0);
-    if (h->ml_comp) for (int l = 1; l < L; l++) o_dense[l] = take((size_t)(6 * h->ml_n[l]) * (size_t)(6 * h->ml_n[l]) * 8);
+    if (h->ml_comp) for (int l = cl; l < L; l++) o_dense[l] = take((size_t)(6 * h->ml_n[l]) * (size_t)(6 * h->ml_n[l]) * 8);
     static const bool mult_off = getenv("UZL_ML_ADDITIVE") != nullptr;                 // A/B switch
     h->ml_mult = h->ml_comp && !mult_off;
-    const size_t n12 = h->ml_mult ? (size_t)h->ml_n[1] * h->ml_n[2] * 36 * 8 : 0, n11 = h->ml_mult ? (size_t)h->ml_n[1] * h->ml_n[1] * 36 * 8 : 0;
+    const size_t n12 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl + 1] * 36 * 8 : 0, n11 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl] * 36 * 8 : 0;
     const size_t o_mAP = take(n12), o_mQ = take(n12), o_mQY = take(n12), o_mAS = take(n11);
     static const int ns_env = getenv("UZL_ML_NS_STEPS") ? atoi(getenv("UZL_ML_NS_STEPS")) : 2;
     h->ml_ns_steps = h->ml_mult ? std::max(0, std::min(ns_env, 4)) : 0;
-    const size_t nsq = h->ml_ns_steps ? (size_t)(6 * h->ml_n[1]) * (size_t)(6 * h->ml_n[1]) * 8 : 0;
+    const size_t nsq = h->ml_ns_steps ? (size_t)(6 * h->ml_n[cl]) * (size_t)(6 * h->ml_n[cl]) * 8 : 0;
     const size_t o_nsT = take(nsq), o_nsX = take(nsq);
     std::vector<int32_t> grp;                                       // [n1*n2] begin | [n1*n2] end
     size_t o_grp = 0;
     if (h->ml_mult) {
-        const int n1 = h->ml_n[1], n2 = h->ml_n[2], fan2 = h->ml_fan[2];
+        const int n1 = h->ml_n[cl], n2 = h->ml_n[cl + 1], fan2 = h->ml_fan[cl + 1];
         grp.assign((size_t)2 * n1 * n2, 0);
         for (int i = 0; i < n1; i++) {
-            int s = lv[1].row_ptr[i];
-            const int send = lv[1].row_ptr[i + 1];
+            int s = lv[cl].row_ptr[i];
+            const int send = lv[cl].row_ptr[i + 1];
             for (int p = 0; p < n2; p++) {
                 grp[(size_t)i * n2 + p] = s;
-                while (s < send && lv[1].col[s] / fan2 == p) s++;
+                while (s < send && lv[cl].col[s] / fan2 == p) s++;
                 grp[(size_t)n1 * n2 + (size_t)i * n2 + p] = s;
             }
         }
@@ -405,14 +414,15 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     M.tmpG = reinterpret_cast<double*>(base + o_tmpG);
     M.tmpM = reinterpret_cast<double*>(base + o_tmpM);
     M.top_inv = reinterpret_cast<double*>(base + o_top);
-    for (int l = 1; l < L; l++) M.Ydense[l] = h->ml_comp ? reinterpret_cast<double*>(base + o_dense[l]) : nullptr;
+    for (int l = 1; l < L; l++) M.Ydense[l] = (h->ml_comp && l >= cl) ? reinterpret_cast<double*>(base + o_dense[l]) : nullptr;
+    M.comp_level = cl;
     if (h->ml_mult) {
         UZL_HIP(hipMemcpyAsync(base + o_grp, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, s));
         M.grp_beg = reinterpret_cast<const int32_t*>(base + o_grp);
-        M.grp_end = M.grp_beg + (size_t)h->ml_n[1] * h->ml_n[2];
+        M.grp_end = M.grp_beg + (size_t)h->ml_n[cl] * h->ml_n[cl + 1];
     }
     M.nsT = reinterpret_cast<double*>(base + o_nsT); M.nsX = reinterpret_cast<double*>(base + o_nsX);
-    h->ml_ns_T = M.nsT; h->ml_ns_X = M.nsX; h->ml_y1 = h->ml_comp ? M.Ydense[1] : nullptr;
+    h->ml_ns_T = M.nsT; h->ml_ns_X = M.nsX; h->ml_y1 = h->ml_comp ? M.Ydense[cl] : nullptr;
     M.mAP = reinterpret_cast<double*>(base + o_mAP); M.mQ = reinterpret_cast<double*>(base + o_mQ);
     M.mQY = reinterpret_cast<double*>(base + o_mQY); M.mAS = reinterpret_cast<double*>(base + o_mAS);
     M.Sg = reinterpret_cast<double*>(base + o_sg);
@@ -423,7 +433,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     Hh.levels = L;
     for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Winv[l] = M.lv[l].Winv; }
     Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg;
-    Hh.Cmat = h->ml_comp ? ((h->ml_ns_steps & 1) ? M.nsX : M.Ydense[1]) : nullptr;   // Newton-Schulz steps ping-pong Y_1 <-> nsX
+    Hh.Cmat = h->ml_comp ? ((h->ml_ns_steps & 1) ? M.nsX : M.Ydense[cl]) : nullptr;   // Newton-Schulz steps ping-pong Y_cl <-> nsX
     h->l1_span_ptr = M.lv[1].blk;
     h->l1_span = (int64_t)((M.lv[1].M + (size_t)std::max(h->ml_n[1], 1) * 36) - M.lv[1].blk);
     h->d_ml.reserve(1);
@@ -597,10 +607,11 @@ int pcg_solve(uzl_pgo* h, bool* converged)
             { Timed t(h, "ml_sibling"); k_ml_sibling(D, h->d_ml.p, h->ml_inner_aggs, s); }
             if (h->ml_comp) {
                 Timed t(h, "ml_dense");
-                for (int l = h->ml_levels - 1; l >= (h->ml_mult ? 2 : 1); l--) k_ml_dense_level(h->d_ml.p, l, h->ml_n[l], s);
-                if (h->ml_mult) k_ml_mult_level1(D, h->d_ml.p, h->ml_n[1], h->ml_n[2], s);
+                const int cl = h->ml_cl;
+                for (int l = h->ml_levels - 1; l >= (h->ml_mult ? cl + 1 : cl); l--) k_ml_dense_level(h->d_ml.p, l, h->ml_n[l], s);
+                if (h->ml_mult) k_ml_mult_level1(D, h->d_ml.p, h->ml_n[cl], h->ml_n[cl + 1], s);
                 double* xa = h->ml_y1; double* xb = h->ml_ns_X;
-                for (int k = 0; k < h->ml_ns_steps; k++) { k_ml_ns_step(D, h->d_ml.p, h->ml_n[1], xa, h->ml_ns_T, xb, s); std::swap(xa, xb); }
+                for (int k = 0; k < h->ml_ns_steps; k++) { k_ml_ns_step(D, h->d_ml.p, h->ml_n[cl], xa, h->ml_ns_T, xb, s); std::swap(xa, xb); }
             }
             h->ml_trial_setup = false;
             h->ml_lambda_setup = h->lambda_now;
