@@ -336,9 +336,10 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     // composite path: one aggregate per workgroup, at least two coarse levels, 6 n_1 <= 960 (<= 1280 free vertices)
     static const bool comp_off = getenv("UZL_ML_NO_COMP") != nullptr;                // A/B switch
     // large graphs (AGG = 4, gather level 2): the same construction one level up - the hierarchy above level 2 as one dense
-    // operator (6 n_2 <= 2400: up to ~12.8k free vertices, 46 MB) that ml_cg_kernel<4> applies instead of its LDS walk
+    // operator (6 n_2 <= 4096: up to ~21.8k free vertices, 134 MB; measured 733 -> 332 ms at 20k / 100k, the rebuild's two
+    // Newton-Schulz GEMMs take 7 ms there) that ml_cg_kernel<4> applies instead of its LDS walk
     static const bool comp4_off = getenv("UZL_ML_NO_COMP4") != nullptr;             // A/B switch
-    static const int comp4_max = getenv("UZL_ML_COMP4_MAX") ? atoi(getenv("UZL_ML_COMP4_MAX")) : 2400;
+    static const int comp4_max = getenv("UZL_ML_COMP4_MAX") ? atoi(getenv("UZL_ML_COMP4_MAX")) : 4096;
     const bool comp1 = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 960;
     const bool comp4 = !comp_off && !comp4_off && h->ml_agg == 4 && L >= 3 && 6 * h->ml_n[2] <= comp4_max;
     h->ml_comp = comp1 || comp4;
