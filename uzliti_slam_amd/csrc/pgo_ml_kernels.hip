@@ -1419,7 +1419,8 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
 // restrict / top-solve / prolong walk through LDS and its barriers are gone.  Same preconditioner, same results up to
 // rounding as ml_cg_kernel<1>.
 // ------------------------------------------------------------------------------------------------
-constexpr int kCompU = 5;             // 6 n_1 <= 960 gather-level values: 5 per lane
+// kCompU gather-level values per lane: 5 covers 6 n_1 <= 960 (<= 1280 free vertices), 8 covers 6 n_1 <= 1536 (<= 2048)
+template <int kCompU>
 __global__ __launch_bounds__(kCgBlk) void ml_cg_comp_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
                                                            const double* __restrict__ rg_old, double* __restrict__ rg_new,
                                                            int n_part, int init)
@@ -1628,8 +1629,14 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
         configured[ci] = lds;
     }
     if (agg == 1 && ml.Cmat) {           // small graphs: composite coarse operator
-        if (ev_a) hipExtLaunchKernelGGL(ml_cg_comp_kernel, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
-        else hipLaunchKernelGGL(ml_cg_comp_kernel, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, D, ml, p, rg_old, rg_new, n_part, init);
+        const bool small = 6 * ml.n[1] <= 5 * kCgBlk;
+        if (ev_a) {
+            if (small) hipExtLaunchKernelGGL(ml_cg_comp_kernel<5>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
+            else hipExtLaunchKernelGGL(ml_cg_comp_kernel<8>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
+        } else {
+            if (small) hipLaunchKernelGGL(ml_cg_comp_kernel<5>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, D, ml, p, rg_old, rg_new, n_part, init);
+            else hipLaunchKernelGGL(ml_cg_comp_kernel<8>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, D, ml, p, rg_old, rg_new, n_part, init);
+        }
         return hipSuccess;
     }
     if (ev_a) {

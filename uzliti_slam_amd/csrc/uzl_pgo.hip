@@ -243,7 +243,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     const int nb = h->nb;
     h->ml_levels = 0; h->ml_n.assign(1, nb); h->ml_nslots.assign(1, h->nslots); h->ml_inner_aggs = 0;
     if (h->cfg.preconditioner == 0 || nb <= kMlTopMax) return;
-    static const int agg1_max = getenv("UZL_ML_AGG1_MAX") ? atoi(getenv("UZL_ML_AGG1_MAX")) : 2560;   // measured crossover (env: diagnostic override)
+    static const int agg1_max = getenv("UZL_ML_AGG1_MAX") ? atoi(getenv("UZL_ML_AGG1_MAX")) : 2048;   // up to here the level-1 dense operator applies (6 n_1 <= 1536); above, AGG = 4 with the level-2 one (measured: 2500 vertices 65.7 -> 38.2 ms)
     h->ml_agg = nb <= agg1_max ? 1 : 4;
     int L = 0;
     h->ml_fan.assign(1, 1);
@@ -340,7 +340,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     // Newton-Schulz GEMMs take 7 ms there) that ml_cg_kernel<4> applies instead of its LDS walk
     static const bool comp4_off = getenv("UZL_ML_NO_COMP4") != nullptr;             // A/B switch
     static const int comp4_max = getenv("UZL_ML_COMP4_MAX") ? atoi(getenv("UZL_ML_COMP4_MAX")) : 4096;
-    const bool comp1 = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 960;
+    const bool comp1 = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 1536;     // ml_cg_comp_kernel<5> / <8>
     const bool comp4 = !comp_off && !comp4_off && h->ml_agg == 4 && L >= 3 && 6 * h->ml_n[2] <= comp4_max;
     h->ml_comp = comp1 || comp4;
     h->ml_cl = comp1 ? 1 : (comp4 ? 2 : 0);
