@@ -177,9 +177,10 @@ def test_block_jacobi_and_multilevel_agree(capi, oracle):
         assert dt < TOL_T and dr < TOL_R
 
 
-@pytest.mark.parametrize("n,e", [(9, 20), (17, 40), (64, 200), (65, 200), (513, 2000)])
+@pytest.mark.parametrize("n,e", [(9, 20), (17, 40), (64, 200), (65, 200), (513, 2000), (1281, 5000), (1800, 7000), (2049, 8000)])
 def test_multilevel_hierarchy_edge_sizes(capi, oracle, n, e):
-    """aggregate boundaries: 8^k and 8^k + 1 vertices, partially filled last aggregates."""
+    """aggregate boundaries: 8^k and 8^k + 1 vertices, partially filled last aggregates; 1281 / 1800: the level-1 dense operator
+    beyond 960 columns (ml_cg_comp_kernel<8>); 2049: the first size on the four-aggregates-per-workgroup path."""
     g = synth.make_pose_graph(n, e, seed=n)
     p = capi.Pgo()
     p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
