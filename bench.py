@@ -5,6 +5,7 @@
 
 Primary metric   : SE(3) edges optimised / s   on BASELINE config 2 (1k nodes / 5k edges, 20 LM iterations)
 Secondary metric : node pairs matched / s      on BASELINE config 3 (512 pairs x 1000 ORB-256, 500 hypotheses)
+`formats` block  : Feature records -> frame arena for the 1024 frames of config 3 (HBM-bound byte shuffle; rank 0 only)
 
 A "step" is one pass of the hot path over one batch with the inputs already resident in HBM:
   primary   step = uzl_pgo_reset + uzl_pgo_optimize(20)   (graph resident, poses restored on the device)
