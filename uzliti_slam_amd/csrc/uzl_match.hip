@@ -457,15 +457,15 @@ int uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sen
         WireSeg& g = segs[k];
         g.item_begin = items; g.feat_begin = feats; g.src_off = src;
         g.desc_off = r.desc_off; g.pos_off = r.pos_off; g.valid_off = r.valid_off;
-        g.stride = (uint32_t)(41 + 4 * D); g.words = D / 4; g.n = f.n_features; g._pad = 0;
-        items += (int64_t)n * g.words; feats += (int64_t)n;
-        src = align_up(src + (n ? f.records.n : 0), 4);                           // every frame's records start dword-aligned
+        g.stride = (uint32_t)(41 + 4 * D); g.words = D / 4; g.n = f.n_features; g._pad = wire_kpb(g.stride);
+        items += ((int64_t)n + g._pad - 1) / g._pad; feats += (int64_t)n;          // items: workgroups
+        src = align_up(src + (n ? f.records.n : 0), 16);                          // every frame's records start 16-byte aligned
     }
     memset(&segs[(size_t)n_frames], 0, sizeof(WireSeg));
     segs[(size_t)n_frames].item_begin = items;
     if (h->in_flight && off > h->arena.cap) return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
     h->arena.reserve(off, /*keep=*/true, h->stream);
-    h->d_wire_stage.reserve((size_t)(src / 4) + 4);                              // + tail: the dword after the last byte may be read
+    h->d_wire_stage.reserve((size_t)(src / 4) + 8);                              // + tail: the 16 bytes after the last record may be read
     h->d_wire_segs.reserve((size_t)n_frames + 1);
     h->d_wire_bad.reserve(1);
     if (uv) h->d_wire_uv.reserve((size_t)std::max<int64_t>(2 * feats, 1));

@@ -8,12 +8,15 @@
 // keypoint on the wire for 25 + D bytes of content: both directions are pure byte shuffles bound by HBM bandwidth.
 // S is odd, nothing in a record is aligned: every access below is an ALIGNED dword access plus v_alignbit, so the
 // loads of neighbouring lanes fall into the same cache lines and coalesce.
-//   unpack: one lane per descriptor WORD of the arena (4 wire floats = 16 unaligned bytes in, one aligned dword out);
-//           the keypoint's position, is_3d, u, v and the check of the record's D are spread over the same lanes.
+//   unpack: a workgroup stages its byte range of the record stream in LDS with coalesced 16-byte loads, then one lane per
+//           descriptor WORD of the arena (4 wire floats = 16 unaligned bytes from LDS in, one aligned dword out); the keypoint's
+//           position, is_3d, u, v and the check of the record's D are spread over the same lanes.
 //   pack:   one lane per aligned dword of the record stream; each of its four bytes is derived from (record, offset).
 // Algorithmic bytes per keypoint: (41 + 4 D) + (D + 25) (+8 with u,v) in either direction (D = 32: 226 B).
 #include "uzl_common.hpp"
 #include "wire_types.hpp"
+
+#include <algorithm>
 
 namespace uzl {
 
@@ -39,53 +42,62 @@ __device__ __forceinline__ uint32_t float_to_byte(uint32_t bits)
     return (uint32_t)((int32_t)f) & 0xffu;
 }
 
-// segs has n_segs + 1 entries (the last one is a sentinel with item_begin = n_items).  The search runs once per wave on
-// its first item (uniform: scalar loads); lanes past a frame boundary step forward from there.
-__device__ __forceinline__ int find_segment(const WireSeg* __restrict__ segs, int n_segs, int64_t first_item, int64_t item)
+// One workgroup = up to WireSeg::kpb keypoints of one frame (segs[k].item_begin = first WORKGROUP of frame k; the last entry is a
+// sentinel).  Phase 1: the workgroup's byte range of the record stream goes to LDS with coalesced 16-byte loads (the access shape
+// HBM serves at full rate; the range starts at an arbitrary byte, so it is fetched from the 16-byte boundary below it).  Phase 2:
+// every lane assembles one descriptor word from five ALIGNED LDS dwords + v_alignbit and stores it coalesced; the keypoint's
+// position dwords, is_3d, u / v and the check of the record's descriptor count are spread over the same lanes.
+// (Measured: one lane per word straight from global memory 86 us for 231 MB; this form 74 us; the same with a register-staged
+// prefetch of the next chunk and 1 - 8 chunks per workgroup 116 us: many small workgroups balance better than few pipelined ones.)
+constexpr int kWireLdsBytes = 16384;    // measured on 231 MB: 8 KB 62 us, 12 KB 56, 16 KB 52, 20 KB 57, 32 KB 74 (more resident workgroups hide the stage's load latency)
+__device__ __forceinline__ uint32_t lds_u32_at(const uint32_t* __restrict__ l32, uint32_t off)
 {
-    int lo = 0, hi = n_segs - 1;
-    while (lo < hi) {                          // last segment whose item_begin <= first_item
-        const int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].item_begin <= first_item) lo = mid; else hi = mid - 1;
-    }
-    while (segs[lo + 1].item_begin <= item) ++lo;
-    return lo;
+    const uint32_t w = off >> 2, sh = (off & 3) * 8;
+    const uint32_t lo = l32[w];
+    if (sh == 0) return lo;
+    return __funnelshift_r(lo, l32[w + 1], sh);
 }
 
-__global__ __launch_bounds__(kWireBlk) void wire_unpack_kernel(const uint32_t* __restrict__ stage, uint8_t* __restrict__ arena,
-                                                               const WireSeg* __restrict__ segs, int n_segs, int64_t n_items,
+__global__ __launch_bounds__(kWireBlk) void wire_unpack_kernel(const uint4* __restrict__ stage, uint8_t* __restrict__ arena,
+                                                               const WireSeg* __restrict__ segs, int n_segs,
                                                                int32_t* __restrict__ uv, int32_t* __restrict__ bad)
 {
-    const int64_t item = (int64_t)blockIdx.x * kWireBlk + threadIdx.x;
-    if (item >= n_items) return;
-    const int64_t wave_first = (int64_t)blockIdx.x * kWireBlk + (threadIdx.x & ~63u);
-    const uint32_t f_lo = __builtin_amdgcn_readfirstlane((uint32_t)wave_first), f_hi = __builtin_amdgcn_readfirstlane((uint32_t)(wave_first >> 32));
-    const WireSeg sg = segs[find_segment(segs, n_segs, (int64_t)(((uint64_t)f_hi << 32) | f_lo), item)];
-    const uint32_t local = (uint32_t)(item - sg.item_begin);          // < 16384 * 127
-    const uint32_t W = (uint32_t)sg.words;
-    const uint32_t i = local / W;
-    const uint32_t w = local - i * W;
-    const uint64_t rec = sg.src_off + (uint64_t)i * sg.stride;
-    const uint64_t d0 = rec + 17 + 16ull * w;
-    // 16 unaligned bytes = five aligned dwords
-    const uint64_t a = d0 >> 2;
-    const uint32_t sh = (uint32_t)(d0 & 3) * 8;
-    const uint32_t x0 = stage[a], x1 = stage[a + 1], x2 = stage[a + 2], x3 = stage[a + 3], x4 = sh ? stage[a + 4] : 0u;
-    const uint32_t word = float_to_byte(__funnelshift_r(x0, x1, sh)) | float_to_byte(__funnelshift_r(x1, x2, sh)) << 8 |
-                          float_to_byte(__funnelshift_r(x2, x3, sh)) << 16 | float_to_byte(__funnelshift_r(x3, x4, sh)) << 24;
-    reinterpret_cast<uint32_t*>(arena + sg.desc_off)[(size_t)i * W + w] = word;
-    // the keypoint's other fields are spread over its lanes: position dwords on lanes 0..5 (strided when W < 6),
-    // is_3d + the descriptor-count check on the last lane, u / v on the lane before it
-    const uint64_t p0 = rec + 17 + 16ull * W;
-    uint32_t* pos = reinterpret_cast<uint32_t*>(arena + sg.pos_off) + (size_t)i * 6;          // column i of the 3 x n matrix
-    for (uint32_t k = w; k < 6; k += W) pos[k] = load_u32_at(stage, p0 + 4 * k);
-    if (w == W - 1) {
-        if (load_u32_at(stage, rec + 13) != 4 * W) atomicOr(bad, 1);
-        arena[sg.valid_off + i] = (load_u32_at(stage, rec + 8) & 0xffu) ? 1 : 0;          // std::vector<bool>::push_back(is_3d) (:164)
+    __shared__ uint4 sraw[kWireLdsBytes / 16 + 4];
+    const int tid = threadIdx.x;
+    const int64_t blk = blockIdx.x;
+    int lo = 0, hi = n_segs - 1;
+    while (lo < hi) {                          // last frame whose first workgroup <= blk (uniform: scalar loads)
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].item_begin <= blk) lo = mid; else hi = mid - 1;
     }
-    if (uv && w == (W > 1 ? W - 2 : 0)) {
-        uv[2 * (sg.feat_begin + i)] = (int32_t)load_u32_at(stage, rec);
-        uv[2 * (sg.feat_begin + i) + 1] = (int32_t)load_u32_at(stage, rec + 4);
+    const WireSeg sg = segs[lo];
+    const uint32_t kpb = (uint32_t)sg._pad, W = (uint32_t)sg.words, stride = sg.stride;
+    const uint32_t kp0 = (uint32_t)(blk - sg.item_begin) * kpb;
+    const uint32_t nkp = min(kpb, (uint32_t)sg.n - kp0);
+    const uint64_t start = sg.src_off + (uint64_t)kp0 * stride, a0 = start & ~15ull;
+    const uint32_t base = (uint32_t)(start - a0), n16 = (base + nkp * stride + 15) >> 4;
+    for (uint32_t i = tid; i < n16; i += kWireBlk) sraw[i] = stage[(a0 >> 4) + i];
+    __syncthreads();
+    const uint32_t* __restrict__ l32 = reinterpret_cast<const uint32_t*>(sraw);
+    uint32_t* __restrict__ desc = reinterpret_cast<uint32_t*>(arena + sg.desc_off) + (size_t)kp0 * W;
+    for (uint32_t item = tid; item < nkp * W; item += kWireBlk) {
+        const uint32_t i = item / W, w = item - i * W;
+        const uint32_t rec = base + i * stride, d0 = rec + 17 + 16 * w;
+        const uint32_t a = d0 >> 2, sh = (d0 & 3) * 8;
+        const uint32_t x0 = l32[a], x1 = l32[a + 1], x2 = l32[a + 2], x3 = l32[a + 3], x4 = sh ? l32[a + 4] : 0u;
+        desc[item] = float_to_byte(__funnelshift_r(x0, x1, sh)) | float_to_byte(__funnelshift_r(x1, x2, sh)) << 8 |
+                     float_to_byte(__funnelshift_r(x2, x3, sh)) << 16 | float_to_byte(__funnelshift_r(x3, x4, sh)) << 24;
+        const uint32_t p0 = rec + 17 + 16 * W;
+        uint32_t* pos = reinterpret_cast<uint32_t*>(arena + sg.pos_off) + (size_t)(kp0 + i) * 6;          // column of the 3 x n matrix
+        for (uint32_t k = w; k < 6; k += W) pos[k] = lds_u32_at(l32, p0 + 4 * k);
+        if (w == W - 1) {
+            if (lds_u32_at(l32, rec + 13) != 4 * W) atomicOr(bad, 1);
+            arena[sg.valid_off + kp0 + i] = (lds_u32_at(l32, rec + 8) & 0xffu) ? 1 : 0;                   // std::vector<bool>::push_back(is_3d) (:164)
+        }
+        if (uv && w == (W > 1 ? W - 2 : 0)) {
+            uv[2 * (sg.feat_begin + kp0 + i)] = (int32_t)lds_u32_at(l32, rec);
+            uv[2 * (sg.feat_begin + kp0 + i) + 1] = (int32_t)lds_u32_at(l32, rec + 4);
+        }
     }
 }
 
@@ -131,12 +143,15 @@ __global__ __launch_bounds__(kWireBlk) void wire_pack_kernel(const uint8_t* __re
     out[j] = word;
 }
 
-void launch_wire_unpack(const uint32_t* stage, uint8_t* arena, const WireSeg* segs, int n_segs, int64_t n_items, int32_t* uv, int32_t* bad,
+// keypoints per workgroup for a record stride: as many as fit the LDS stage, at most 128
+int wire_kpb(uint32_t stride) { return (int)std::max<uint32_t>(1u, std::min<uint32_t>(128u, (kWireLdsBytes - 16) / stride)); }
+
+void launch_wire_unpack(const uint32_t* stage, uint8_t* arena, const WireSeg* segs, int n_segs, int64_t n_blocks, int32_t* uv, int32_t* bad,
                         hipStream_t s)
 {
-    if (n_items <= 0) return;
-    const int64_t blocks = (n_items + kWireBlk - 1) / kWireBlk;
-    hipLaunchKernelGGL(wire_unpack_kernel, dim3((unsigned)blocks), dim3(kWireBlk), 0, s, stage, arena, segs, n_segs, n_items, uv, bad);
+    if (n_blocks <= 0) return;
+    hipLaunchKernelGGL(wire_unpack_kernel, dim3((unsigned)n_blocks), dim3(kWireBlk), 0, s, reinterpret_cast<const uint4*>(stage), arena, segs, n_segs,
+                       uv, bad);
 }
 
 void launch_wire_pack(const uint8_t* arena, const WireSeg& sg, const int32_t* uv, uint32_t* out, uint64_t n_bytes, hipStream_t s)
