@@ -248,6 +248,13 @@ def main():
         matcher.set_profiling(False)
         knn_ms = mk.get("knn2", dict(ms=0.0))["ms"]
         valu_path = os.environ.get("UZL_KNN2_VALU") is not None or os.environ.get("UZL_KNN2_SCALAR") is not None
+        knn_traffic = None
+        tpath2 = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath2) and (per_rank, a.keypoints) == (512, 1000) and not valu_path:      # PMC passes were collected on this workload / kernel
+            try:
+                knn_traffic = json.load(open(tpath2)).get("knn2_bytes_per_launch")
+            except Exception:
+                knn_traffic = None
         if valu_path:
             word_ops = 2.0 * per_rank * a.keypoints * a.keypoints * 8          # xor + popcount-accumulate per 32-bit word
             ach = word_ops / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
@@ -259,7 +266,7 @@ def main():
             ops = 2.0 * per_rank * a.keypoints * a.keypoints * 256.0
             ach = ops / (knn_ms * 1e-3) / 1e12 if knn_ms > 0 else 0.0
             sec_roof = dict(kernel="knn2_mfma_kernel<8, 2>", bound="mfma", achieved=round(ach, 1), peak=MFMA_I8_PEAK_TOPS, unit="TOP/s (int8, dense)",
-                            frac=round(ach / MFMA_I8_PEAK_TOPS, 4), traffic=None,
+                            frac=round(ach / MFMA_I8_PEAK_TOPS, 4), traffic=knn_traffic,
                             note="v_mfma_i32_32x32x32_i8 over 0/1-expanded 256-bit descriptors (2 x 1000 x 1000 x 256 ops per pair); `peak` = 2 x the "
                                  "~2.5 PFLOP/s dense bf16 rate (MI355X_MICROARCH.md, matrix-core table); the vector ALU that folds each 32 x 32 tile "
                                  "into the per-query top-2 (3 instructions per distance) issues beside the matrix pipe and is the tighter of the two bounds")
