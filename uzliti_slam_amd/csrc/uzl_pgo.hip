@@ -94,19 +94,30 @@ struct uzl_pgo {
     bool ml_comp = false;
     int ml_cl = 0;                   // level of the dense operator (1: small graphs, 2: AGG = 4), 0 = none
     int ml_ns_steps = 0;             // Newton-Schulz refinements of the dense level-1 operator per rebuild
-    double* ml_ns_T = nullptr; double* ml_ns_X = nullptr; double* ml_y1 = nullptr;
-    double lambda_now = 0., ml_lambda_setup = 0.;   // lambda of the current trial / of the last trial set-up of the hierarchy
+    // Two complete copies of the preconditioner's numeric state (arena, device descriptor, kernel-argument block, PCG graph): the
+    // solver applies copy `ml_ix` while a rebuild for the next LM iteration runs on `stream2` into the other one.
+    struct MlBuf {
+        MlDev* dml = nullptr;                  // device copy of the descriptor
+        MlHot hot;                             // hot subset, by-value kernel argument
+        double* rg[2] = {nullptr, nullptr};    // double-buffered gather-level residual
+        double* y1 = nullptr; double* nsT = nullptr; double* nsX = nullptr;
+        double* l1_span_ptr = nullptr;         // level-1 Galerkin arrays (blk | G | M), all-reduced once per linearisation
+        hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+        double lambda_setup = 0.;              // lambda of the last trial set-up of this copy
+    } mlb[2];
+    int ml_ix = 0;
+    bool ml_pending = false;                   // a rebuild into copy ml_ix ^ 1 is in flight on stream2
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_lin = nullptr, ev_setup = nullptr;
+    DevBuf<double> d_scal2;                    // lambda slot (scal[3]) for the kernels of an asynchronous rebuild
+    double lambda_now = 0.;          // lambda of the current trial
     bool ml_mult = false;            // level 1 of the composite operator is multiplicative (pgo_ml_kernels.hip)            // small graphs: hierarchy above level 1 folded into a dense operator (pgo_ml_kernels.hip)
-    double* ml_rg[2] = {nullptr, nullptr};     // double-buffered gather-level residual
     std::vector<int32_t> ml_fan;
     int ml_agg = 4;                            // level-1 aggregates per PCG workgroup (1: small graphs, 4: large)
     size_t ml_lds = 0;
-    MlHot ml_hot;
     DevBuf<uint8_t> ml_arena;
     DevBuf<MlDev> d_ml;
     bool no_graph = false;          // UZL_NO_GRAPH=1: eager launches (rocprofv3 --kernel-trace crashes on hipGraphLaunch here)
-    hipGraph_t pcg_graph = nullptr;
-    hipGraphExec_t pcg_graph_exec = nullptr;
     // shard (BASELINE config 4)
     int32_t rank = 0, world = 1;
     uzl_allreduce_fn allreduce = nullptr;
@@ -114,7 +125,6 @@ struct uzl_pgo {
     bool sharded = false;            // an all-reduce callback is set and the multilevel path is active for this structure
     DevBuf<double> d_red;
     int64_t iter_span = 0;           // doubles all-reduced per PCG iteration: [A p | restricted A p | p.Ap partials]
-    double* l1_span_ptr = nullptr;   // level-1 Galerkin arrays (blk | G | M), all-reduced once per linearisation
     int64_t l1_span = 0;
     KernelTimer timer;
 };
@@ -376,7 +386,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     const int gl = (h->ml_agg == 1 || L < 2) ? 1 : 2;
     const size_t ngz = (size_t)std::max(h->ml_n[gl], 1) * 6 * 8;
     const size_t o_sg = take(ngz), o_rga = take(ngz), o_rgb = take(ngz);
-    h->ml_arena.reserve(bytes);
+    const size_t buf_bytes = (bytes + 255) / 256 * 256;
+    h->ml_arena.reserve(2 * buf_bytes);
     std::vector<uint8_t> stage(int_bytes, 0);
     auto put = [&](size_t o, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage.data() + o, v.data(), v.size() * 4); };
     for (int l = 0; l <= L; l++) {
@@ -384,75 +395,106 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         put(io[l].tpos, lv[l].tpos); put(io[l].off_ptr, lv[l].off_ptr); put(io[l].diag_ptr, lv[l].diag_ptr);
     }
     hipStream_t s = h->stream;
-    uint8_t* base = h->ml_arena.p;
-    UZL_HIP(hipMemsetAsync(base, 0, bytes, s));            // padding between arrays takes part in the sharded all-reduce
-    UZL_HIP(hipMemcpyAsync(base, stage.data(), int_bytes, hipMemcpyHostToDevice, s));
-    MlDev M;
-    memset(&M, 0, sizeof(M));
-    M.levels = L;
-    for (int l = 0; l <= L; l++) {
-        MlLevel& X = M.lv[l];
-        X.n = h->ml_n[l]; X.nslots = h->ml_nslots[l];
-        X.fan = h->ml_fan[l];
-        X.span = 1; for (int q = 1; q <= l; q++) X.span *= h->ml_fan[q];
-        X.row_ptr = (l == 0) ? h->d_row_ptr.p : reinterpret_cast<const int32_t*>(base + io[l].row_ptr);
-        X.col = (l == 0) ? h->d_col.p : reinterpret_cast<const int32_t*>(base + io[l].col);
-        X.srow = reinterpret_cast<const int32_t*>(base + io[l].srow);
-        X.tpos = reinterpret_cast<const int32_t*>(base + io[l].tpos);
-        X.off_ptr = reinterpret_cast<const int32_t*>(base + io[l].off_ptr);
-        X.diag_ptr = reinterpret_cast<const int32_t*>(base + io[l].diag_ptr);
-        X.n_off_contrib = lv[l].n_off;
-        X.blk = (l == 0) ? h->d_blk.p : reinterpret_cast<double*>(base + dof[l].blk);
-        X.G = (l == 0) ? h->d_hdiag.p : reinterpret_cast<double*>(base + dof[l].G);
-        X.M = (l == 0) ? nullptr : reinterpret_cast<double*>(base + dof[l].M);
-        X.Winv = (l < L) ? reinterpret_cast<double*>(base + dof[l].Winv) : nullptr;
-        X.geo = (l == 0) ? reinterpret_cast<double*>(base + dof[l].geo) : reinterpret_cast<double*>(base + o_geo_blob) + geo_sub[l];
-        X.cen = reinterpret_cast<double*>(base + dof[l].cen);
-        X.r = reinterpret_cast<double*>(base + dof[l].r);
-        X.y = reinterpret_cast<double*>(base + dof[l].y);
+    h->d_ml.reserve(2);
+    h->d_scal2.reserve(8);
+    MlDev Mh[2];
+    for (int bi = 0; bi < 2; bi++) {
+        uint8_t* base = h->ml_arena.p + (size_t)bi * buf_bytes;
+        UZL_HIP(hipMemsetAsync(base, 0, bytes, s));            // padding between arrays takes part in the sharded all-reduce
+        UZL_HIP(hipMemcpyAsync(base, stage.data(), int_bytes, hipMemcpyHostToDevice, s));
+        MlDev& M = Mh[bi];
+        memset(&M, 0, sizeof(M));
+        M.levels = L;
+        for (int l = 0; l <= L; l++) {
+            MlLevel& X = M.lv[l];
+            X.n = h->ml_n[l]; X.nslots = h->ml_nslots[l];
+            X.fan = h->ml_fan[l];
+            X.span = 1; for (int q = 1; q <= l; q++) X.span *= h->ml_fan[q];
+            X.row_ptr = (l == 0) ? h->d_row_ptr.p : reinterpret_cast<const int32_t*>(base + io[l].row_ptr);
+            X.col = (l == 0) ? h->d_col.p : reinterpret_cast<const int32_t*>(base + io[l].col);
+            X.srow = reinterpret_cast<const int32_t*>(base + io[l].srow);
+            X.tpos = reinterpret_cast<const int32_t*>(base + io[l].tpos);
+            X.off_ptr = reinterpret_cast<const int32_t*>(base + io[l].off_ptr);
+            X.diag_ptr = reinterpret_cast<const int32_t*>(base + io[l].diag_ptr);
+            X.n_off_contrib = lv[l].n_off;
+            X.blk = (l == 0) ? h->d_blk.p : reinterpret_cast<double*>(base + dof[l].blk);
+            X.G = (l == 0) ? h->d_hdiag.p : reinterpret_cast<double*>(base + dof[l].G);
+            X.M = (l == 0) ? nullptr : reinterpret_cast<double*>(base + dof[l].M);
+            X.Winv = (l < L) ? reinterpret_cast<double*>(base + dof[l].Winv) : nullptr;
+            X.geo = (l == 0) ? reinterpret_cast<double*>(base + dof[l].geo) : reinterpret_cast<double*>(base + o_geo_blob) + geo_sub[l];
+            X.cen = reinterpret_cast<double*>(base + dof[l].cen);
+            X.r = reinterpret_cast<double*>(base + dof[l].r);
+            X.y = reinterpret_cast<double*>(base + dof[l].y);
+        }
+        M.tmp = reinterpret_cast<double*>(base + o_tmp);
+        M.tmpG = reinterpret_cast<double*>(base + o_tmpG);
+        M.tmpM = reinterpret_cast<double*>(base + o_tmpM);
+        M.top_inv = reinterpret_cast<double*>(base + o_top);
+        for (int l = 1; l < L; l++) M.Ydense[l] = (h->ml_comp && l >= cl) ? reinterpret_cast<double*>(base + o_dense[l]) : nullptr;
+        M.comp_level = cl;
+        if (h->ml_mult) {
+            UZL_HIP(hipMemcpyAsync(base + o_grp, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, s));
+            M.grp_beg = reinterpret_cast<const int32_t*>(base + o_grp);
+            M.grp_end = M.grp_beg + (size_t)h->ml_n[cl] * h->ml_n[cl + 1];
+        }
+        M.nsT = reinterpret_cast<double*>(base + o_nsT); M.nsX = reinterpret_cast<double*>(base + o_nsX);
+        M.mAP = reinterpret_cast<double*>(base + o_mAP); M.mQ = reinterpret_cast<double*>(base + o_mQ);
+        M.mQY = reinterpret_cast<double*>(base + o_mQY); M.mAS = reinterpret_cast<double*>(base + o_mAS);
+        M.Sg = reinterpret_cast<double*>(base + o_sg);
+        uzl_pgo::MlBuf& B = h->mlb[bi];
+        B.dml = h->d_ml.p + bi;
+        B.nsT = M.nsT; B.nsX = M.nsX; B.y1 = h->ml_comp ? M.Ydense[cl] : nullptr;
+        B.rg[0] = reinterpret_cast<double*>(base + o_rga);
+        B.rg[1] = reinterpret_cast<double*>(base + o_rgb);
+        B.lambda_setup = 0.;
+        MlHot& Hh = B.hot;
+        memset(&Hh, 0, sizeof(Hh));
+        Hh.levels = L;
+        for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Winv[l] = M.lv[l].Winv; }
+        Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg;
+        Hh.Cmat = h->ml_comp ? ((h->ml_ns_steps & 1) ? M.nsX : M.Ydense[cl]) : nullptr;   // Newton-Schulz steps ping-pong Y_cl <-> nsX
+        B.l1_span_ptr = M.lv[1].blk;
+        h->l1_span = (int64_t)((M.lv[1].M + (size_t)std::max(h->ml_n[1], 1) * 36) - M.lv[1].blk);
     }
-    M.tmp = reinterpret_cast<double*>(base + o_tmp);
-    M.tmpG = reinterpret_cast<double*>(base + o_tmpG);
-    M.tmpM = reinterpret_cast<double*>(base + o_tmpM);
-    M.top_inv = reinterpret_cast<double*>(base + o_top);
-    for (int l = 1; l < L; l++) M.Ydense[l] = (h->ml_comp && l >= cl) ? reinterpret_cast<double*>(base + o_dense[l]) : nullptr;
-    M.comp_level = cl;
-    if (h->ml_mult) {
-        UZL_HIP(hipMemcpyAsync(base + o_grp, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, s));
-        M.grp_beg = reinterpret_cast<const int32_t*>(base + o_grp);
-        M.grp_end = M.grp_beg + (size_t)h->ml_n[cl] * h->ml_n[cl + 1];
-    }
-    M.nsT = reinterpret_cast<double*>(base + o_nsT); M.nsX = reinterpret_cast<double*>(base + o_nsX);
-    h->ml_ns_T = M.nsT; h->ml_ns_X = M.nsX; h->ml_y1 = h->ml_comp ? M.Ydense[cl] : nullptr;
-    M.mAP = reinterpret_cast<double*>(base + o_mAP); M.mQ = reinterpret_cast<double*>(base + o_mQ);
-    M.mQY = reinterpret_cast<double*>(base + o_mQY); M.mAS = reinterpret_cast<double*>(base + o_mAS);
-    M.Sg = reinterpret_cast<double*>(base + o_sg);
-    h->ml_rg[0] = reinterpret_cast<double*>(base + o_rga);
-    h->ml_rg[1] = reinterpret_cast<double*>(base + o_rgb);
-    MlHot& Hh = h->ml_hot;
-    memset(&Hh, 0, sizeof(Hh));
-    Hh.levels = L;
-    for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Winv[l] = M.lv[l].Winv; }
-    Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg;
-    Hh.Cmat = h->ml_comp ? ((h->ml_ns_steps & 1) ? M.nsX : M.Ydense[cl]) : nullptr;   // Newton-Schulz steps ping-pong Y_cl <-> nsX
-    h->l1_span_ptr = M.lv[1].blk;
-    h->l1_span = (int64_t)((M.lv[1].M + (size_t)std::max(h->ml_n[1], 1) * 36) - M.lv[1].blk);
-    h->d_ml.reserve(1);
-    UZL_HIP(hipMemcpyAsync(h->d_ml.p, &M, sizeof(M), hipMemcpyHostToDevice, s));
-    UZL_HIP(hipStreamSynchronize(s));      // stage / M are locals
+    h->ml_ix = 0; h->ml_pending = false;
+    UZL_HIP(hipMemcpyAsync(h->d_ml.p, Mh, sizeof(Mh), hipMemcpyHostToDevice, s));
+    UZL_HIP(hipStreamSynchronize(s));      // stage / Mh are locals
 }
 
 // numeric part, once per linearisation: geometry, then A_{l+1} = P^T A_l P level by level
-void ml_setup_numeric(uzl_pgo* h)
+void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed)
 {
     if (h->ml_levels == 0) return;
-    hipStream_t s = h->stream;
     const int L = h->ml_levels;
-    { Timed t(h, "ml_geometry"); for (int l = 1; l <= L; l++) k_ml_geometry(h->D, h->d_ml.p, h->cur, l, h->ml_n[l], s); }
+    MlDev* dml = h->mlb[bi].dml;
+    if (timed) h->timer.begin("ml_geometry", s);
+    for (int l = 1; l <= L; l++) k_ml_geometry(D, dml, h->cur, l, h->ml_n[l], s);
+    if (timed) h->timer.end(s);
     for (int f = 0; f < L; f++) {
-        { Timed t(h, "ml_transform"); k_ml_transform(h->D, h->d_ml.p, f, h->ml_nslots[f] + h->ml_n[f], s); }
-        { Timed t(h, "ml_reduce"); k_ml_reduce(h->d_ml.p, f + 1, h->ml_nslots[f + 1] + h->ml_n[f + 1], s); }
-        if (f == 0) shard_allreduce(h, h->l1_span_ptr, h->l1_span);             // level 1 complete on every rank: levels >= 2 need no exchange
+        if (timed) h->timer.begin("ml_transform", s);
+        k_ml_transform(D, dml, f, h->ml_nslots[f] + h->ml_n[f], s);
+        if (timed) { h->timer.end(s); h->timer.begin("ml_reduce", s); }
+        k_ml_reduce(dml, f + 1, h->ml_nslots[f + 1] + h->ml_n[f + 1], s);
+        if (timed) h->timer.end(s);
+        if (f == 0) shard_allreduce(h, h->mlb[bi].l1_span_ptr, h->l1_span);     // level 1 complete on every rank: levels >= 2 need no exchange
+    }
+}
+
+// lambda-dependent part: inverse sibling blocks, top level, dense operator (+ multiplicative cycle, Newton-Schulz refinement)
+void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed)
+{
+    uzl_pgo::MlBuf& B = h->mlb[bi];
+    if (timed) h->timer.begin("ml_sibling", s);
+    k_ml_sibling(D, B.dml, h->ml_inner_aggs, s);
+    if (timed) h->timer.end(s);
+    if (h->ml_comp) {
+        if (timed) h->timer.begin("ml_dense", s);
+        const int cl = h->ml_cl;
+        for (int l = h->ml_levels - 1; l >= (h->ml_mult ? cl + 1 : cl); l--) k_ml_dense_level(B.dml, l, h->ml_n[l], s);
+        if (h->ml_mult) k_ml_mult_level1(D, B.dml, h->ml_n[cl], h->ml_n[cl + 1], s);
+        double* xa = B.y1; double* xb = B.nsX;
+        for (int k = 0; k < h->ml_ns_steps; k++) { k_ml_ns_step(D, B.dml, h->ml_n[cl], xa, B.nsT, xb, s); std::swap(xa, xb); }
+        if (timed) h->timer.end(s);
     }
 }
 
@@ -527,7 +569,7 @@ void build_structure(uzl_pgo* h)
     {   // per-iteration exchange buffer: [A p (6 nb) | restricted A p (6 n_g) | p.Ap partials]
         const int gl = (h->ml_levels == 0) ? 0 : ((h->ml_agg == 1 || h->ml_levels < 2) ? 1 : 2);
         const size_t ng6 = gl ? (size_t)h->ml_n[gl] * 6 : 0;
-        if (gl) h->ml_hot.Sg = h->d_ap.p + (size_t)nb * 6;
+        if (gl) { h->mlb[0].hot.Sg = h->d_ap.p + (size_t)nb * 6; h->mlb[1].hot.Sg = h->mlb[0].hot.Sg; }
         D.part_a = h->d_ap.p + (size_t)nb * 6 + ng6;
         h->iter_span = (int64_t)((size_t)nb * 6 + ng6 + (gl ? (size_t)g_ml_rows(nb, h->ml_agg) : 0));
     }
@@ -561,11 +603,11 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
         hipEvent_t ea = nullptr, eb = nullptr;
         if (ml) {
             if (timed) h->timer.pair("pcg_spmv", &ea, &eb);                      // dispatch timestamps: agree with rocprofv3
-            k_ml_spmv(D, h->ml_hot, h->ml_agg, po, pn, gu, tol2, s, ea, eb);
+            k_ml_spmv(D, h->mlb[h->ml_ix].hot, h->ml_agg, po, pn, gu, tol2, s, ea, eb);
             shard_allreduce(h, h->d_ap.p, h->iter_span);                         // the one exchange per PCG iteration
             ea = eb = nullptr;
             if (timed) h->timer.pair("ml_cg", &ea, &eb);
-            UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, pn, h->ml_rg[(i & 1) ^ 1], h->ml_rg[i & 1], ga, 0, h->ml_lds, s, ea, eb));
+            UZL_HIP(k_ml_cg(D, h->mlb[h->ml_ix].hot, h->ml_agg, pn, h->mlb[h->ml_ix].rg[(i & 1) ^ 1], h->mlb[h->ml_ix].rg[i & 1], ga, 0, h->ml_lds, s, ea, eb));
         } else {
             if (timed) h->timer.begin("pcg_spmv", s);
             k_pcg_spmv(D, po, pn, gu, tol2, s);
@@ -581,19 +623,22 @@ static const int kGraphPairs = getenv("UZL_GRAPH_PAIRS") ? std::max(1, atoi(gete
 
 void destroy_pcg_graph(uzl_pgo* h)
 {
-    if (h->pcg_graph_exec) { (void)hipGraphExecDestroy(h->pcg_graph_exec); h->pcg_graph_exec = nullptr; }
-    if (h->pcg_graph) { (void)hipGraphDestroy(h->pcg_graph); h->pcg_graph = nullptr; }
+    for (auto& B : h->mlb) {
+        if (B.graph_exec) { (void)hipGraphExecDestroy(B.graph_exec); B.graph_exec = nullptr; }
+        if (B.graph) { (void)hipGraphDestroy(B.graph); B.graph = nullptr; }
+    }
 }
 
-// The launch-bound inner loop is captured once per problem structure: every kernel argument (pointers,
+// The launch-bound inner loop is captured once per problem structure and preconditioner copy: every kernel argument (pointers,
 // partial counts, tolerance) is fixed, lambda and the CG scalars live in device memory.
 void ensure_pcg_graph(uzl_pgo* h)
 {
-    if (h->pcg_graph_exec) return;
+    uzl_pgo::MlBuf& B = h->mlb[h->ml_ix];
+    if (B.graph_exec) return;
     UZL_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     enqueue_pcg_pairs(h, kGraphPairs, false);
-    UZL_HIP(hipStreamEndCapture(h->stream, &h->pcg_graph));
-    UZL_HIP(hipGraphInstantiate(&h->pcg_graph_exec, h->pcg_graph, nullptr, nullptr, 0));
+    UZL_HIP(hipStreamEndCapture(h->stream, &B.graph));
+    UZL_HIP(hipGraphInstantiate(&B.graph_exec, B.graph, nullptr, nullptr, 0));
 }
 
 // one (H + lambda I) dx = b solve; returns PCG iterations used, sets *converged
@@ -605,20 +650,13 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     const bool timed = h->timer.on || h->no_graph || h->sharded;   // per-kernel events, rocprofv3 and the exchange callback need eager launches
     if (h->ml_levels > 0) {
         if (h->ml_trial_setup) {
-            { Timed t(h, "ml_sibling"); k_ml_sibling(D, h->d_ml.p, h->ml_inner_aggs, s); }
-            if (h->ml_comp) {
-                Timed t(h, "ml_dense");
-                const int cl = h->ml_cl;
-                for (int l = h->ml_levels - 1; l >= (h->ml_mult ? cl + 1 : cl); l--) k_ml_dense_level(h->d_ml.p, l, h->ml_n[l], s);
-                if (h->ml_mult) k_ml_mult_level1(D, h->d_ml.p, h->ml_n[cl], h->ml_n[cl + 1], s);
-                double* xa = h->ml_y1; double* xb = h->ml_ns_X;
-                for (int k = 0; k < h->ml_ns_steps; k++) { k_ml_ns_step(D, h->d_ml.p, h->ml_n[cl], xa, h->ml_ns_T, xb, s); std::swap(xa, xb); }
-            }
+            ml_setup_trial(h, h->ml_ix, s, D, true);
             h->ml_trial_setup = false;
-            h->ml_lambda_setup = h->lambda_now;
+            h->mlb[h->ml_ix].lambda_setup = h->lambda_now;
         }
-        { Timed t(h, "pcg_init"); k_ml_init(D, h->ml_hot, h->ml_agg, h->d_p.p, h->d_p2.p, h->ml_rg[0], s); }
-        { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, h->ml_hot, h->ml_agg, h->d_p.p, h->ml_rg[0], h->ml_rg[1], 0, 1, h->ml_lds, s)); }
+        uzl_pgo::MlBuf& B = h->mlb[h->ml_ix];
+        { Timed t(h, "pcg_init"); k_ml_init(D, B.hot, h->ml_agg, h->d_p.p, h->d_p2.p, B.rg[0], s); }
+        { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, B.hot, h->ml_agg, h->d_p.p, B.rg[0], B.rg[1], 0, 1, h->ml_lds, s)); }
     } else {
         { Timed t(h, "precond"); k_precond(D, s); }
         Timed t(h, "pcg_init"); k_pcg_init(D, h->d_p.p, h->d_p2.p, s);
@@ -633,7 +671,7 @@ int pcg_solve(uzl_pgo* h, bool* converged)
         const int reps = std::max(1, (want + 2 * kGraphPairs - 1) / (2 * kGraphPairs));
         for (int i = 0; i < reps; i++) {
             if (timed) enqueue_pcg_pairs(h, kGraphPairs, h->timer.on);
-            else UZL_HIP(hipGraphLaunch(h->pcg_graph_exec, s));
+            else UZL_HIP(hipGraphLaunch(h->mlb[h->ml_ix].graph_exec, s));
         }
         launched += reps * 2 * kGraphPairs;
         fetch_scal(h);
@@ -687,8 +725,23 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     static const double refresh_rel = getenv("UZL_ML_REFRESH_REL") ? atof(getenv("UZL_ML_REFRESH_REL")) : 1e-3;
     double last_rel = 1e300;
     int pcg_ref = 1 << 30, pcg_last = 0;
+    // Asynchronous rebuild: from the second LM iteration on a wanted rebuild runs on stream2 into the OTHER copy of the
+    // hierarchy while this iteration's PCG still uses the current one (any SPD preconditioner gives the same solution; one
+    // that is one linearisation old costs a few iterations, a rebuild on the critical path costs ~0.4 ms).  The copy is
+    // adopted at the start of the next iteration, which has to wait for it anyway before it overwrites H and the poses.
+    static const bool async_off = getenv("UZL_ML_SYNC_REBUILD") != nullptr;             // A/B switch
+    // (small graphs only: at 10k vertices the rebuild's Newton-Schulz GEMMs take more from the overlapped PCG than they give back:
+    // 113.2 -> 115.1 ms; config 2: 11.09 -> 10.67 ms with 540 instead of 517 PCG iterations)
+    const bool async_ok = !async_off && h->ml_levels > 0 && h->ml_cl == 1 && !h->sharded && !h->timer.on && h->stream2 != nullptr;
+    bool adopted = false;
+    h->ml_ix = 0; h->ml_pending = false;
     for (int it = 0; it < iterations; it++) {
         int gl, ga;
+        adopted = false;
+        if (h->ml_pending) {                                                      // the copy built during the last iteration
+            UZL_HIP(hipStreamWaitEvent(s, h->ev_setup, 0));
+            h->ml_ix ^= 1; h->ml_pending = false; adopted = true;
+        }
         D.pose = h->cur; D.pose_trial = h->trial;
         { Timed t(h, "linearize"); gl = k_linearize(D, h->cur, delta, s); }     // computeActiveErrors + buildSystem
         { Timed t(h, "assemble"); ga = k_assemble(D, s); }
@@ -703,7 +756,12 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         // previous iteration is as good as a fresh one (geometry + Galerkin + inverses are ~170 us per rebuild).
         // A rebuild is also forced when the iteration count has grown by a third since the last one.
         const bool refresh = it == 0 || always_refresh || last_rel > refresh_rel || pcg_last > pcg_ref + pcg_ref / 3 + 4;
-        if (refresh) { ml_setup_numeric(h); h->ml_trial_setup = true; S.precond_builds++; }
+        bool launch_async = false;
+        if (refresh) {
+            S.precond_builds++;
+            if (it == 0 || !async_ok) { ml_setup_numeric(h, h->ml_ix, s, D, true); h->ml_trial_setup = true; }
+            else launch_async = true;                                             // needs this iteration's lambda: below
+        }
         if (it == 0 || h->sharded) {                   // later iterations carry chi2 over from the accepted trial: no round trip
             fetch_scal(h);
             current_chi = h->h_scal.p->scal[4];
@@ -713,6 +771,19 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             lambda = 1e-5 * h->h_scal.p->scal[6];                                 // computeLambdaInit: tau * max diag
             ni = 2.;
         }
+        if (launch_async) {
+            const int nb_ix = h->ml_ix ^ 1;
+            UZL_HIP(hipEventRecord(h->ev_lin, s));                                // H, b and the poses of this linearisation are final
+            UZL_HIP(hipStreamWaitEvent(h->stream2, h->ev_lin, 0));
+            PgoDev D2 = D;
+            D2.scal = h->d_scal2.p;                                               // the trial loop below moves scal[3] on the main stream
+            k_set_scalar(D2.scal + 3, lambda, h->stream2);
+            ml_setup_numeric(h, nb_ix, h->stream2, D2, false);
+            ml_setup_trial(h, nb_ix, h->stream2, D2, false);
+            h->mlb[nb_ix].lambda_setup = lambda;
+            UZL_HIP(hipEventRecord(h->ev_setup, h->stream2));
+            h->ml_pending = true;
+        }
         double rho = 0.;
         int qmax = 0;
         do {
@@ -720,8 +791,8 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             bool conv = false;
             // the lambda-dependent inverses of the hierarchy are kept across trials; after rejected steps lambda grows
             // geometrically and inverses taken at a much smaller lambda stop being a preconditioner at all
-            if (h->ml_levels > 0 && lambda > 8. * h->ml_lambda_setup) h->ml_trial_setup = true;
-            const bool fresh = h->ml_trial_setup;
+            if (h->ml_levels > 0 && lambda > 8. * h->mlb[h->ml_ix].lambda_setup) h->ml_trial_setup = true;
+            const bool fresh = h->ml_trial_setup || (adopted && qmax == 0);
             int pcg_its = pcg_solve(h, &conv);                                    // _solver->solve()
             S.pcg_iterations += pcg_its;
             if (!conv && !fresh && h->ml_levels > 0) {                            // stale hierarchy: retake the inverses once
@@ -734,7 +805,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
                 // (lambda_max(Y_1 A_1) < 2), which block-Jacobi does not guarantee on every graph: fall back, for the rest
                 // of this handle's structure, to the additive operator (a sum of SPD terms) and solve again.
                 h->ml_mult = false; h->ml_ns_steps = 0;
-                h->ml_hot.Cmat = h->ml_y1;
+                for (auto& B : h->mlb) B.hot.Cmat = B.y1;
                 destroy_pcg_graph(h);                                             // MlHot is a by-value kernel argument
                 h->ml_trial_setup = true;
                 pcg_its = pcg_solve(h, &conv);
@@ -775,6 +846,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     }
     S.chi2_final = current_chi;
     S.lambda_final = lambda;
+    if (h->ml_pending) { UZL_HIP(hipStreamSynchronize(h->stream2)); h->ml_pending = false; }   // a rebuild nobody will use: let it drain
     UZL_HIP(hipStreamSynchronize(s));
     S.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (st) *st = S;
@@ -828,7 +900,15 @@ int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
     memset(&h->D, 0, sizeof(h->D));
     { const char* ng = getenv("UZL_NO_GRAPH"); h->no_graph = ng && ng[0] == '1'; }
     if (getenv("UZL_VERBOSE")) h->cfg.verbose = 1;                                    // diagnostic: per-trial PCG log on stderr
-    if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, -1) != hipSuccess ||      // rebuilds ahead of the PCG they overlap with
+
+        hipEventCreateWithFlags(&h->ev_lin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_setup, hipEventDisableTiming) != hipSuccess) {
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        if (h->stream2) (void)hipStreamDestroy(h->stream2);
+        if (h->ev_lin) (void)hipEventDestroy(h->ev_lin);
+        if (h->ev_setup) (void)hipEventDestroy(h->ev_setup);
         delete h;
         return UZL_ERR_HIP;
     }
@@ -841,8 +921,11 @@ void uzl_pgo_destroy(uzl_pgo* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->pcg_graph_exec) (void)hipGraphExecDestroy(h->pcg_graph_exec);
-    if (h->pcg_graph) (void)hipGraphDestroy(h->pcg_graph);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    destroy_pcg_graph(h);
+    if (h->ev_lin) (void)hipEventDestroy(h->ev_lin);
+    if (h->ev_setup) (void)hipEventDestroy(h->ev_setup);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
