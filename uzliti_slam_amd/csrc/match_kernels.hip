@@ -146,6 +146,7 @@ __global__ __launch_bounds__(kBlock) void knn2_lds_kernel(const uint32_t* __rest
 // expanded chunk by chunk into LDS (row stride D + 16 bytes: ds_read_b128 of 16 lanes covers all banks).
 // Ties, keys and the missing-neighbour sentinel are those of knn2_lds_kernel: results are bit-identical.
 // ------------------------------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef int v16i32 __attribute__((ext_vector_type(16)));
 
@@ -758,9 +759,11 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
     if (have_pair && M >= 3) {
         const uint64_t key = stream_key(prm.seed, job.job_id);
         const double thr2 = sqrt_threshold(prm.thresh);
+        const bool vote_valu = A.vote_valu != 0;             // A/B switch (UZL_VOTE_VALU=1): the 17-instruction loop on the vector ALU
         bool stop = false;
         for (int r0 = 0; r0 < iters && !stop; r0 += kEstBlock) {
             const int it = r0 + tid;
+            double T[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (it < iters) {
                 const int n = prm.do_prosac ? prosac_prefix(it, iters, M) : M;
                 int s0, s1, s2;
@@ -770,8 +773,63 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
                 pose_add(acc, pq[s0 * 6 + 0], pq[s0 * 6 + 1], pq[s0 * 6 + 2], pq[s0 * 6 + 3], pq[s0 * 6 + 4], pq[s0 * 6 + 5]);
                 pose_add(acc, pq[s1 * 6 + 0], pq[s1 * 6 + 1], pq[s1 * 6 + 2], pq[s1 * 6 + 3], pq[s1 * 6 + 4], pq[s1 * 6 + 5]);
                 pose_add(acc, pq[s2 * 6 + 0], pq[s2 * 6 + 1], pq[s2 * 6 + 2], pq[s2 * 6 + 3], pq[s2 * 6 + 4], pq[s2 * 6 + 5]);
-                double T[12];
                 pose_finish(acc, T);                                                   // :227
+            }
+            if (!vote_valu) {
+                // ---- votes on the f64 matrix cores (:230).  v_mfma_f64_16x16x4_f64 is, bit for bit, the chain
+                // acc = fma(a_k, b_k, acc) for k = 0..3 from acc = C (measured on 512 000 random outputs), so with
+                // a = (T3, T2, T1, T0) of one row of the pose and b = (1, pz, py, px) it computes exactly
+                // fma(T0, px, fma(T1, py, fma(T2, pz, T3))) - point_dist2's transform - for 16 hypotheses x 16 points per
+                // instruction.  Each wave votes for the 64 hypotheses its lanes hold: 4 tiles of 16, three MFMAs (x, y, z) per
+                // tile and 16 points; what is left for the vector ALU per (hypothesis, point) is three subtractions, the
+                // squared norm (one mul, two fma), the compare and the count: 8 instructions instead of 17.
+                const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+                double a[4][3];                      // [tile][row of T]: element 3 - lk of that row, of hypothesis 16 tile + li
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const int src = 16 * q + li;
+                        const double v0 = __shfl(T[4 * c + 3], src), v1 = __shfl(T[4 * c + 2], src), v2 = __shfl(T[4 * c + 1], src),
+                                     v3 = __shfl(T[4 * c + 0], src);
+                        a[q][c] = (lk == 0) ? v0 : (lk == 1) ? v1 : (lk == 2) ? v2 : v3;
+                    }
+                int cnt4[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) cnt4[q][r] = 0;
+                for (int m0 = 0; m0 < M; m0 += 16) {
+                    const int m = (m0 + li < M) ? m0 + li : M - 1;
+                    const bool pv = m0 + li < M;
+                    const double* __restrict__ pm = pq + m * 6;
+                    const double b = (lk == 0) ? 1. : pm[3 - lk];        // (1, pz, py, px)
+                    const double qx = pm[3], qy = pm[4], qz = pm[5];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const v4f64 z4 = {0., 0., 0., 0.};
+                        const v4f64 X = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b, z4, 0, 0, 0);
+                        const v4f64 Y = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b, z4, 0, 0, 0);
+                        const v4f64 Z = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][2], b, z4, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {                     // hypothesis 16 q + lk + 4 r, point m0 + li
+                            const double dx = X[r] - qx, dy = Y[r] - qy, dz = Z[r] - qz;
+                            const double d2 = fma(dx, dx, fma(dy, dy, dz * dz));
+                            cnt4[q][r] += (pv && d2 < thr2) ? 1 : 0;
+                        }
+                    }
+                }
+                // the 16 lanes of one lk hold the same hypotheses' partial counts over different points
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        int c = cnt4[q][r];
+                        c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4); c += __shfl_xor(c, 8);
+                        const int hit = r0 + (tid & ~63) + 16 * q + lk + 4 * r;
+                        if (li == 0 && hit < iters) s_cnt[hit] = c;
+                    }
+            } else if (it < iters) {
                 int cnt = 0;
                 int m = 0;
                 for (; m + 4 <= M; m += 4) {                // four correspondences per step: their LDS reads overlap
@@ -786,6 +844,7 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
                 for (; m < M; m++) cnt += (point_dist2(pq + m * 6, T) < thr2) ? 1 : 0;
                 s_cnt[it] = cnt;
             }
+            __syncthreads();                                // votes of other lanes' hypotheses are in s_cnt
             // ---- the sequential bookkeeping of :233-242 over this round's votes, without the sequence.  The loop keeps a
             // running strict maximum (first index wins ties) and stops at the first NEW maximum that satisfies
             // stop(c) = c >= 3 && c > break_pct * M.  stop() is monotone in c, so the first iteration whose own count satisfies

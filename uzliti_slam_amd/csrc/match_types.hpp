@@ -64,6 +64,7 @@ struct EstimateArgs {
     double* dist_scratch;          // n_jobs x max_corr
     uint8_t* mask_scratch;         // n_jobs x max_corr
     int32_t sort_cap;              // power of two >= max nq in the batch (LDS sort array length)
+    int32_t vote_valu;             // 1: consensus votes on the vector ALU (A/B switch); 0: on the f64 matrix cores
 };
 
 }  // namespace uzl
