@@ -22,7 +22,10 @@ def _add(m, f):
 
 
 @pytest.mark.parametrize("nq,nt,nbytes", [(1000, 1000, 32), (300, 300, 64), (257, 513, 32), (7, 9, 32),
-                                          (64, 1, 32), (5, 0, 32), (100, 100, 20), (3000, 1500, 32)])
+                                          (64, 1, 32), (5, 0, 32), (100, 100, 20), (3000, 1500, 32),
+                                          # tile boundaries of the matrix-core kernel: 32 train rows / 32 queries per MFMA tile,
+                                          # 128 (W = 8) or 64 (W = 16) train rows per LDS chunk, 256 / 128 queries per workgroup
+                                          (33, 31, 32), (129, 127, 32), (256, 128, 32), (255, 129, 64), (1, 2, 32), (128, 65, 64)])
 def test_knn2_bit_exact(matcher, oracle, nq, nt, nbytes):
     rng = np.random.default_rng(nq * 7919 + nt)
     q = rng.integers(0, 256, (nq, nbytes), dtype=np.uint8)
