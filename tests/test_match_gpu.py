@@ -32,6 +32,7 @@ def test_knn2_bit_exact(matcher, oracle, nq, nt, nbytes):
     t = rng.integers(0, 256, (nt, nbytes), dtype=np.uint8)
     if nt >= 8:                       # deliberate ties and exact duplicates
         t[5] = t[2]; t[7] = t[2]
+        t[nt - 1] = t[2]              # the same tie again in the last tile / chunk: lower index must still win
         q[0] = t[2]
         q[1] = t[2]; q[1, 0] ^= 1
     ff = matcher.add_frame(t, np.zeros((3, nt)), np.ones(nt, np.uint8))
