@@ -161,7 +161,9 @@ int do_launch(uzl_match* h, int32_t n_jobs, const uzl_pair_job* jobs, const int3
     a.prm.thresh = h->cfg.ransac_threshold; a.prm.break_pct = h->cfg.ransac_break_percentage;
     a.prm.seed = h->cfg.seed; a.prm.iterations = h->cfg.ransac_iteration; a.prm.do_prosac = h->cfg.do_prosac ? 1 : 0;
     a.prm.max_corr = stride;
-    a.results = h->d_results.p;
+    // results go straight to the pinned host array the caller's copy is taken from (432 B per job written over PCIe by one lane;
+    // hipHostMalloc memory is mapped into the device's address space): no device-to-host copy operation behind the kernel
+    a.results = h->h_results.p;
     a.sort_cap = next_pow2(max_nq);
     { static const bool vv = getenv("UZL_VOTE_VALU") != nullptr; a.vote_valu = vv ? 1 : 0; }
     if (h->fl_diag) {
@@ -184,7 +186,6 @@ int do_launch(uzl_match* h, int32_t n_jobs, const uzl_pair_job* jobs, const int3
     UZL_HIP(launch_estimate(a, n_jobs, in_lds, lds, s));
     h->timer.end(s);
 
-    UZL_HIP(hipMemcpyAsync(h->h_results.p, h->d_results.p, (size_t)n_jobs * sizeof(uzl_edge_result), hipMemcpyDeviceToHost, s));
     if (h->fl_diag) {
         const size_t tot = (size_t)n_jobs * stride;
         UZL_HIP(hipMemcpyAsync(h->h_cq.p, h->d_cq.p, tot * 4, hipMemcpyDeviceToHost, s));
