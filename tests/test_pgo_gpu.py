@@ -339,3 +339,41 @@ def test_ns_gemm_matrix_core_layout(capi, n):
     assert rc == 0
     want = 2 * X - X @ T
     assert np.abs(out - want).max() <= 1e-11 * np.abs(want).max()
+
+
+def test_handles_driven_from_concurrent_threads(capi):
+    """One handle per host thread (the reference runs each plugin on its own worker thread, graph_optimizer.cpp:35-73,
+    transformation_estimator.cpp:22-62): concurrent solves and match batches give exactly what the same calls give one after the other."""
+    import threading
+    graphs = [synth.make_pose_graph(n, e, seed=s) for n, e, s in ((300, 1200, 1), (900, 4000, 2), (1500, 6000, 3), (2600, 10000, 4))]
+    pairs = synth.make_pairs(24, n_kp=400, seed=8)
+
+    def solve(g):
+        p = capi.Pgo()
+        p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+        out = []
+        for _ in range(2):
+            p.reset(); st = p.optimize(6); out.append((st["status"], st["chi2_final"], p.store()[0].copy()))
+        p.close()
+        return out
+
+    def match():
+        m = capi.Match(ransac_threshold=0.1, ransac_iteration=200, ransac_break_percentage=0.6, seed=3)
+        ids = [(m.add_frame(f["desc"], f["pos"], f["valid"]), m.add_frame(t["desc"], t["pos"], t["valid"])) for f, t, _ in pairs]
+        res = [m.estimate(ids)[0] for _ in range(3)]
+        m.close()
+        return [(r["consensus"], r["T"].copy()) for r in res[-1]]
+
+    ref = [solve(g) for g in graphs] + [match(), match()]
+    got = [None] * 6
+    def run(i):
+        got[i] = solve(graphs[i]) if i < 4 else match()
+    th = [threading.Thread(target=run, args=(i,)) for i in range(6)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for i in range(4):
+        for (s0, c0, p0), (s1, c1, p1) in zip(ref[i], got[i]):
+            assert s0 == s1 == 0 and c0 == c1 and np.array_equal(p0, p1)
+    for i in (4, 5):
+        for (c0, T0), (c1, T1) in zip(ref[i], got[i]):
+            assert c0 == c1 and np.array_equal(T0, T1)
