@@ -278,7 +278,7 @@ def _record(hdr, data):
 
 def bag_write_single(topic, datatype, md5sum, definition, sec, nsec, data):
     """rosbag::Bag::open(Write) / write(topic, time, msg) / close() for one message (rosbag_storage.cpp:62-76): file header
-    record padded to 4096 bytes, one uncompressed chunk (connection + message), its index record, then the index section
+    record (header + padding = 4096 bytes: data_len = 4096 - header_len as rosbag::Bag::writeFileHeaderRecord sets it), one uncompressed chunk (connection + message), its index record, then the index section
     (connection, chunk info)."""
     t = struct.pack("<II", sec, nsec)
     conn = _record({b"op": b"\x07", b"conn": struct.pack("<I", 0), b"topic": topic},
@@ -287,13 +287,13 @@ def bag_write_single(topic, datatype, md5sum, definition, sec, nsec, data):
     chunk = _record({b"op": b"\x05", b"compression": b"none", b"size": struct.pack("<I", len(conn) + len(msg))}, conn + msg)
     index = _record({b"op": b"\x04", b"ver": struct.pack("<I", 1), b"conn": struct.pack("<I", 0), b"count": struct.pack("<I", 1)},
                     t + struct.pack("<I", len(conn)))
-    chunk_pos = len(BAG_MAGIC) + 4096
+    chunk_pos = len(BAG_MAGIC) + 4 + 4 + 4096          # 4117
     info = _record({b"op": b"\x06", b"ver": struct.pack("<I", 1), b"chunk_pos": struct.pack("<Q", chunk_pos), b"start_time": t,
                     b"end_time": t, b"count": struct.pack("<I", 1)}, struct.pack("<II", 0, 1))
     index_pos = chunk_pos + len(chunk) + len(index)
     h = _fields({b"op": b"\x03", b"index_pos": struct.pack("<Q", index_pos), b"conn_count": struct.pack("<I", 1),
                  b"chunk_count": struct.pack("<I", 1)})
-    pad = 4096 - 4 - len(h) - 4
+    pad = 4096 - len(h)
     head = struct.pack("<I", len(h)) + h + struct.pack("<I", pad) + b" " * pad
     return BAG_MAGIC + head + chunk + index + conn + info
 

@@ -157,11 +157,14 @@ def test_bag_single_message_matches_the_oracle_and_reads_back():
     args = (b"edge", b"graph_slam_msgs/Edge", b"0123456789abcdef0123456789abcdef", b"string id\nuint8 type\n", 1400000000, 1, data)
     img = W.bag_write_single(*args)
     assert img == OW.bag_write_single(*args)
-    assert img[:13] == b"#ROSBAG V2.0\n" and img[13 + 4096:13 + 4096 + 4] != b"    "
-    # header record is padded to 4096 bytes and index_pos points at the connection record of the index section
+    # rosbag::Bag::writeFileHeaderRecord: data_len = FILE_HEADER_LENGTH (4096) - header_len, so header + padding = 4096 bytes, the
+    # record 4104 and the first chunk record starts at byte 13 + 4104 = 4117; index_pos points at the connection record of the index section
+    assert img[:13] == b"#ROSBAG V2.0\n" and img[4117 - 4:4117] == b"    " and img[4117:4117 + 4] != b"    "
     (hl,) = struct.unpack_from("<I", img, 13)
     (dl,) = struct.unpack_from("<I", img, 13 + 4 + hl)
-    assert 4 + hl + 4 + dl == 4096
+    assert hl + dl == 4096
+    (cl,) = struct.unpack_from("<I", img, 4117)
+    assert OW._parse_fields(img[4121:4121 + cl])[b"op"] == b"\x05"                      # the chunk record
     hdr = OW._parse_fields(img[17:17 + hl])
     (index_pos,) = struct.unpack("<Q", hdr[b"index_pos"])
     (l2,) = struct.unpack_from("<I", img, index_pos)

@@ -17,7 +17,10 @@ GraphOptimizer::~GraphOptimizer() { stopThread(); }
 
 void GraphOptimizer::stopThread()
 {
-    running = false;
+    {   // under the mutex: a store + notify between the worker's predicate check and its block would be a lost wakeup
+        std::lock_guard<std::mutex> lock(opt_mutex_);
+        running = false;
+    }
     opt_cv_.notify_all();
     if (graph_optimization_thread_.joinable()) graph_optimization_thread_.join();
 }

@@ -13,7 +13,10 @@ TransformationEstimator::~TransformationEstimator() { stopThread(); }
 
 void TransformationEstimator::stopThread()
 {
-    running_ = false;
+    {   // under the mutex, so that the worker cannot miss the wakeup between its predicate check and its block
+        std::lock_guard<std::mutex> lock(estimation_mutex_);
+        running_ = false;
+    }
     estimation_cv_.notify_all();
     if (estimation_thread_.joinable()) estimation_thread_.join();
 }

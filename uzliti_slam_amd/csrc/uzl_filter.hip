@@ -309,8 +309,8 @@ int uzl_filter_calc_valid_edges(uzl_filter* h, int32_t* n_evaluated)
         if (!c->changed) continue;                                                          // :236
         if (std::fabs(sec(c->from_start, c->from_end)) < h->cfg.min_time_span ||
             std::fabs(sec(c->to_start, c->to_end)) < h->cfg.min_time_span) continue;        // :240-244
-        c->changed = false;                                                                 // :247
-        todo.push_back(c.get());
+        todo.push_back(c.get());                                                            // `changed` is cleared (:247) once the results are back:
+                                                                                            // a failed or refused batch leaves the clusters due
         offsets.push_back(offsets.back() + c->size());
         job_ids.push_back((c->uid << 20) + (uint64_t)c->evaluations);
     }
@@ -355,6 +355,7 @@ int uzl_filter_calc_valid_edges(uzl_filter* h, int32_t* n_evaluated)
         const uint8_t* set = h->h_set.p + offsets[b];
         int consensus = 0;
         for (int k = 0; k < m; k++) consensus += set[k];
+        c->changed = false;                                                                 // :247
         c->evaluations++;
         c->lastP.assign(h->h_P.p + 3 * (size_t)offsets[b], h->h_P.p + 3 * (size_t)offsets[b + 1]);
         c->lastQ.assign(h->h_Q.p + 3 * (size_t)offsets[b], h->h_Q.p + 3 * (size_t)offsets[b + 1]);

@@ -98,7 +98,7 @@ int do_launch(uzl_match* h, int32_t n_jobs, const uzl_pair_job* jobs, const int3
     for (int32_t j = 0; j < n_jobs; j++) {
         const uzl_pair_job& pj = jobs[j];
         if (pj.from_begin < 0 || pj.to_begin < 0 || pj.from_count < 0 || pj.to_count < 0 ||
-            pj.from_begin + pj.from_count > n_frame_ids || pj.to_begin + pj.to_count > n_frame_ids)
+            (int64_t)pj.from_begin + pj.from_count > n_frame_ids || (int64_t)pj.to_begin + pj.to_count > n_frame_ids)
             return fail(h, UZL_ERR_BAD_ARG, "job frame range outside frame_ids");
         Job dj;
         dj.job_id = pj.job_id;
@@ -478,7 +478,7 @@ int uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sen
                                    hipMemcpyHostToDevice, h->stream));
     UZL_HIP(hipMemcpyAsync(h->d_wire_segs.p, segs.data(), sizeof(WireSeg) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, h->stream));
     UZL_HIP(hipMemsetAsync(h->d_wire_bad.p, 0, 4, h->stream));
-    h->timer.reset();
+    if (!h->in_flight) h->timer.reset();       // the events of a batch still in flight are resolved by its collect
     h->timer.begin("wire_unpack", h->stream);
     launch_wire_unpack(h->d_wire_stage.p, h->arena.p, h->d_wire_segs.p, n_frames, items, uv ? h->d_wire_uv.p : nullptr, h->d_wire_bad.p, h->stream);
     h->timer.end(h->stream);
@@ -520,7 +520,7 @@ int uzl_match_frame_to_wire(uzl_match* h, int32_t frame_id, const int32_t* uv, u
         h->d_wire_uv.reserve((size_t)r.n * 2);
         UZL_HIP(hipMemcpyAsync(h->d_wire_uv.p, uv, (size_t)r.n * 8, hipMemcpyHostToDevice, h->stream));
     }
-    h->timer.reset();
+    if (!h->in_flight) h->timer.reset();
     h->timer.begin("wire_pack", h->stream);
     launch_wire_pack(h->arena.p, g, uv ? h->d_wire_uv.p : nullptr, h->d_wire_stage.p, bytes, h->stream);
     h->timer.end(h->stream);
@@ -635,6 +635,7 @@ int uzl_ransac_points(uzl_match* h, int32_t n_problems, const int32_t* offsets, 
     if (n_problems == 0) return UZL_OK;
     UZL_HIP(hipSetDevice(h->cfg.device));
     const int64_t total = offsets[n_problems];
+    if (offsets[0] < 0) return fail(h, UZL_ERR_BAD_ARG, "offsets[0] must be >= 0");
     for (int32_t b = 0; b < n_problems; b++)
         if (offsets[b + 1] < offsets[b]) return fail(h, UZL_ERR_BAD_ARG, "offsets must be non-decreasing");
     hipStream_t s = h->stream;

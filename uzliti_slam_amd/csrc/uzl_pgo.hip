@@ -735,6 +735,10 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     const bool async_ok = !async_off && h->ml_levels > 0 && h->ml_cl == 1 && !h->sharded && !h->timer.on && h->stream2 != nullptr;
     bool adopted = false;
     h->ml_ix = 0; h->ml_pending = false;
+    struct DrainRebuild {                      // an exception must not leave a rebuild running on stream2 behind the handle's back
+        uzl_pgo* h;
+        ~DrainRebuild() { if (h->ml_pending) { (void)hipStreamSynchronize(h->stream2); h->ml_pending = false; } }
+    } drain{h};
     for (int it = 0; it < iterations; it++) {
         int gl, ga;
         adopted = false;
@@ -804,6 +808,10 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
                 // The multiplicative cycle / its Newton-Schulz refinement is SPD only while the level-1 smoother contracts
                 // (lambda_max(Y_1 A_1) < 2), which block-Jacobi does not guarantee on every graph: fall back, for the rest
                 // of this handle's structure, to the additive operator (a sum of SPD terms) and solve again.
+                if (h->ml_pending) {                                              // the copy being built on stream2 still holds the
+                    UZL_HIP(hipStreamSynchronize(h->stream2));                    // multiplicative operator: drop it and rebuild
+                    h->ml_pending = false; last_rel = 1e300;                      // synchronously at the next linearisation
+                }
                 h->ml_mult = false; h->ml_ns_steps = 0;
                 for (auto& B : h->mlb) B.hot.Cmat = B.y1;
                 destroy_pcg_graph(h);                                             // MlHot is a by-value kernel argument

@@ -264,7 +264,8 @@ void put_node(Writer& w, const uzl_wire_node& n, const int64_t* stamps_ns, const
 // ---------------------------------------------------------------------------------------------- rosbag 2.0
 constexpr char kBagMagic[] = "#ROSBAG V2.0\n";
 constexpr uint64_t kBagMagicLen = 13;
-constexpr uint64_t kBagHeaderRecord = 4096;            // rosbag pads the file header record to 4 KiB
+constexpr uint64_t kBagFileHeaderLength = 4096;        // rosbag FILE_HEADER_LENGTH: writeFileHeaderRecord sets data_len = 4096 - header_len,
+                                                       // so the whole record is 4 + header_len + 4 + (4096 - header_len) = 4104 bytes
 
 struct Field { uzl_span name, value; };
 // one record header: fields "name=value", each with a u32 length
@@ -405,16 +406,16 @@ void put_bag(Writer& w, const uzl_bag_msg& m)
     const uint64_t msg_rec = 4 + fields_len(msg_hdr, 3) + 4 + m.data.n;
     const uint32_t chunk_size = (uint32_t)(conn_rec + msg_rec);
     const FieldOut chunk_hdr[3] = {{"compression", "none", 4}, {"op", &op_chunk, 1}, {"size", &chunk_size, 4}};
-    const uint64_t chunk_pos = kBagMagicLen + kBagHeaderRecord;
+    const uint64_t chunk_pos = kBagMagicLen + 4 + 4 + kBagFileHeaderLength;   // 4117
     const uint64_t chunk_rec = 4 + fields_len(chunk_hdr, 3) + 4 + chunk_size;
     const FieldOut idx_hdr[4] = {{"conn", &conn, 4}, {"count", &one, 4}, {"op", &op_idx, 1}, {"ver", &ver, 4}};
     const uint64_t idx_rec = 4 + fields_len(idx_hdr, 4) + 4 + 12;
     const uint64_t index_pos = chunk_pos + chunk_rec + idx_rec;
-    // file header record, padded with spaces to 4096 bytes
+    // file header record: header + space padding = 4096 bytes (rosbag::Bag::writeFileHeaderRecord)
     w.put(kBagMagic, kBagMagicLen);
     const FieldOut bag_hdr[4] = {{"chunk_count", &one, 4}, {"conn_count", &one, 4}, {"index_pos", &index_pos, 8}, {"op", &op_hdr, 1}};
     put_record_header(w, bag_hdr, 4);
-    const uint64_t pad = kBagHeaderRecord - 4 - fields_len(bag_hdr, 4) - 4;
+    const uint64_t pad = kBagFileHeaderLength - fields_len(bag_hdr, 4);
     w.val<uint32_t>((uint32_t)pad);
     w.fill(' ', pad);
     // chunk

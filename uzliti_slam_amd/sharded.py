@@ -19,15 +19,23 @@ class _DevView:
         self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(count),), "typestr": "<f8", "version": 2}
 
 
-def make_rccl_allreduce(dist, torch):
+def make_rccl_allreduce(dist, torch, device=None):
     """all-reduce callback for capi.Pgo.set_shard built on torch.distributed (RCCL).  The solver's kernels run on
     the handle's own HIP stream, RCCL on torch's: both sides are fenced with device-wide synchronisation, which is
-    correct (and adequate: the collective is latency-bound anyway)."""
+    correct but slow - the native exchange (`Pgo.set_shard_rccl`, the handle owns the communicator and issues
+    ncclAllReduce on its own stream without any host synchronisation) is the product path; this callback remains for
+    callers that already hold a torch process group.  `device` = the handle's HIP device ordinal (pinned here: a view made
+    on another current device would silently become a copy and the reduced values would never reach the solver)."""
+    dev = torch.cuda.current_device() if device is None else int(device)
+
     def allreduce(ptr, count, stream):
-        torch.cuda.synchronize()                       # the solver's stream has produced the buffer
-        t = torch.as_tensor(_DevView(ptr, count), device="cuda")
+        torch.cuda.set_device(dev)
+        torch.cuda.synchronize(dev)                    # the solver's stream has produced the buffer
+        t = torch.as_tensor(_DevView(ptr, count), device="cuda:%d" % dev)
+        if t.data_ptr() != int(ptr):
+            return -1                                  # not a zero-copy view
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()                       # reduced values visible before the solver's next kernel
+        torch.cuda.synchronize(dev)                    # reduced values visible before the solver's next kernel
         return 0
     return allreduce
 
@@ -54,9 +62,12 @@ def make_staged_allreduce(dist, torch):
 
 def solve_sharded(capi, graph, rank, world, dist, torch, iterations=20, device=None, staged=False, force_callback=False):
     """Convenience: one rank's part of a sharded solve.  Returns (poses, stats) - identical on every rank."""
-    p = capi.Pgo(device=device if device is not None else rank)
-    mk = make_staged_allreduce if staged else make_rccl_allreduce
-    p.set_shard(rank, world, mk(dist, torch) if (world > 1 or force_callback) else None)
+    dev = device if device is not None else rank
+    p = capi.Pgo(device=dev)
+    cb = None
+    if world > 1 or force_callback:
+        cb = make_staged_allreduce(dist, torch) if staged else make_rccl_allreduce(dist, torch, dev)
+    p.set_shard(rank, world, cb)
     p.add_graph(graph["nodes_pose"], graph["nodes_fixed"], graph["edges"])
     st = p.optimize(iterations)
     poses, _, _ = p.store()
