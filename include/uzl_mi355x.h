@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define UZL_ABI_VERSION 1
+#define UZL_ABI_VERSION 2
 
 /* ---- status codes (reference: bool returns + ROS_ERROR, SURVEY §8b "Errors") ---- */
 #define UZL_OK                 0
@@ -261,6 +261,11 @@ typedef struct uzl_pgo_stats {
     double  lambda_final;
     double  solve_ms;          /* wall time of uzl_pgo_optimize, device-resident graph        */
     int32_t precond_builds;    /* LM iterations that rebuilt the multilevel preconditioner    */
+    int32_t exchange_calls;    /* sharded solve: all-reduce calls issued by this optimize()   */
+    double  structure_ms;      /* part of solve_ms spent on what the reference's full rebuild per addGraphImpl (:57) implies here:
+                                  setFixedNodes, block-CSR structure, aggregation hierarchy, (first solve) PCG graph capture */
+    double  exchange_ms;       /* sharded solve: host time inside the exchange step (callback) or enqueueing it (native RCCL) */
+    int32_t structure_reused;  /* 1: the structure of the previous graph was kept (same vertices / edge endpoints / fixed flags) */
     int32_t _pad;
 } uzl_pgo_stats;
 

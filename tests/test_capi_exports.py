@@ -38,7 +38,7 @@ def test_defaults_mirror_the_cfg_files(capi):
     p = capi.PgoCfg(); capi.lib().uzl_pgo_cfg_default(ctypes.byref(p))
     # graph_optimization/cfg/GraphOptimizer.cfg:10-12
     assert (p.iterations, p.use_odometry_parameters, p.optimize_xy_only, p.huber_delta) == (20, 0, 0, 1.0)
-    assert capi.lib().uzl_abi_version() == 1
+    assert capi.lib().uzl_abi_version() == 2
     assert capi.lib().uzl_status_string(-1) == b"bad argument"
 
 

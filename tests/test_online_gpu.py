@@ -1,0 +1,121 @@
+"""BASELINE config 5 through uzliti_slam_amd/online.py: node-pair match jobs feed a growing graph that is re-optimised every 256
+edges (estimator -> acceptance gate -> edge filter -> solver, all on the GPU through the C ABI).
+
+At reduced size every solve is compared with the CPU oracle's pipeline on the same schedule; at the full size of the config
+(4096 pairs, 20k nodes: the oracle's direct solves would take tens of minutes) the run is checked through properties."""
+import numpy as np
+import pytest
+
+from uzliti_slam_amd import online, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _edges_subset(e, keep):
+    return {k: np.asarray(v)[keep] for k, v in e.items()}
+
+
+def test_reduced_online_run_matches_the_oracle(capi, oracle):
+    """1500 nodes / 384 pairs / 300 keypoints: same accepted edges, same filter verdicts and poses within 1e-3 m / 1e-4 rad of an
+    oracle run that replays the identical schedule (gate, filter and solver of the CPU checker)."""
+    run = synth.make_online_run(1500, 384, n_kp=300)
+    mc = dict(ransac_iteration=200)
+    o = online.OnlineSlam(run, match_batch=100, lm_iterations=8, match_cfg=mc)
+    o.upload_frames()
+    # ---- oracle replay, driven by the same class through stand-ins of the four handles
+    class OMatch:
+        def __init__(s): s.fr = []
+        def add_frame(s, d, p, v): s.fr.append(dict(desc=d, pos=p, valid=v, feature_type=2, sensor_frame=0)); return len(s.fr) - 1
+        def launch_raw(s, jobs, fids): s.jobs, s.fids = jobs.copy(), fids.copy()
+        def collect(s, out):
+            for i, j in enumerate(s.jobs):
+                e = oracle.estimate_edge([s.fr[s.fids[j["from_begin"]]]], [s.fr[s.fids[j["to_begin"]]]], ransac_threshold=0.1,
+                                         ransac_iteration=200, break_percentage=0.6, do_prosac=True, seed=777, job_id=int(j["job_id"]))
+                out[i]["job_id"] = j["job_id"]; out[i]["ok"] = e["ok"]; out[i]["consensus"] = e["consensus"]
+                out[i]["T"] = np.asarray(e["T"]).reshape(12); out[i]["information"] = np.asarray(e["information"]).reshape(36); out[i]["mse"] = e["mse"]
+            return out
+        def close(s): pass
+
+    class OPgo:
+        def add_graph(s, poses, fixed, edges): s.g = (np.array(poses), np.array(fixed), {k: np.array(v) for k, v in edges.items()})
+        def optimize(s, its):
+            fl = oracle.flatten_graph(*s.g)
+            fx, ng = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+            s.P, so = oracle.pgo_optimize(fl["poses"], fx, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=its)
+            so = dict(so); so.update(status=0, n_edges=len(fl["ij"]), pcg_iterations=0)
+            return so
+        def store(s): return s.P.reshape(-1, 12), None, None
+        def close(s): pass
+
+    class OFilter:
+        def __init__(s, f): s.f = f
+        def set_sensors(s, x): s.f.set_sensors(x)
+        def add_packed(s, fe):
+            st = run["stamps_ns"]; base = st.ctypes.data
+            s.f.add([dict(key=int(r["key"]), matching_score=float(r["matching_score"]), valid=int(r["valid"]), sensor_from=-1, sensor_to=-1,
+                          stamps_from=st[(int(r["stamps_from_ns"]) - base) // 8:][:1], stamps_to=st[(int(r["stamps_to_ns"]) - base) // 8:][:1],
+                          transform=r["transform"], displacement_from=r["displacement_from"], displacement_to=r["displacement_to"],
+                          pose_from=r["pose_from"], pose_to=r["pose_to"]) for r in fe])
+        def calc_valid_edges(s): return s.f.calc_valid_edges()
+        def valid_edges(s): return np.asarray(s.f.valid_edges())
+        def close(s): pass
+
+    c = online.OnlineSlam.__new__(online.OnlineSlam)
+    c.__dict__.update({k: v for k, v in o.__dict__.items()})
+    c.poses = o.poses.copy(); c.results = o.results.copy(); c.solves = []; c.accept_log = []; c.t = dict(o.t)
+    c.matcher = OMatch(); c.gate = oracle.Gate(); c.filt = OFilter(oracle.Filter(seed=777)); c.filt.set_sensors(online.I12.reshape(1, 12)); c.pgo = OPgo()
+    c.fid = {}
+    for k in range(c.P):
+        f, t = run["frames"][k]
+        c.fid[k] = (c.matcher.add_frame(f["desc"], f["pos"], f["valid"]), c.matcher.add_frame(t["desc"], t["pos"], t["valid"]))
+    o.run_all(); c.run_all()
+    assert len(o.solves) == len(c.solves) >= 5
+    assert np.array_equal(o.results["consensus"], c.results["consensus"]) and np.array_equal(o.results["T"], c.results["T"])   # edges bit-exact
+    assert o.accept_log == c.accept_log and len(o.accept_log) > 300                    # gate verdicts identical
+    assert np.array_equal(o.f_key, c.f_key) and np.array_equal(o.f_sticky, c.f_sticky)     # filter verdicts identical
+    assert int(o.f_sticky.sum()) >= 30
+    for a, b in zip(o.solves, c.solves):
+        assert (a["n_nodes"], a["n_feature_valid"], a["n_edges"]) == (b["n_nodes"], b["n_feature_valid"], b["n_edges"])
+    dt, dr = synth.pose_errors(o.poses, c.poses)
+    assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+    o.close()
+
+
+@pytest.fixture(scope="module")
+def full_run():
+    return synth.make_online_run(20000, 4096, n_kp=1000)
+
+
+def test_full_size_run_properties(capi, full_run):
+    """BASELINE config 5 at its size: 4096 pairs x 1000 ORB-256 keypoints, graph growing to 20k nodes, re-optimised every 256 edges."""
+    run = full_run
+    a = online.OnlineSlam(run, match_batch=512)
+    a.upload_frames()
+    a.run_all()
+    assert a.cur == 20000 and len(a.solves) >= 75
+    assert all(s["status"] == 0 and s["pcg_not_converged"] == 0 for s in a.solves)
+    # chi2 never rises within a re-optimisation (LM only accepts descent steps)
+    assert all(s["chi2_final"] <= s["chi2_initial"] * (1 + 1e-12) for s in a.solves)
+    # the map is better than dead reckoning, by a wide margin
+    gt = run["gt"]
+    ate0 = np.linalg.norm(run["init"][:, :, 3] - gt[:, :, 3], axis=1).mean(); ate1 = np.linalg.norm(a.poses[:, :, 3] - gt[:, :, 3], axis=1).mean()
+    assert ate1 < 0.5 * ate0, (ate0, ate1)
+    # aliased pairs (wrong place) mostly do not survive gate + filter
+    alias = run["pair_alias"]
+    assert alias[a.f_key[a.f_sticky]].mean() < 0.5 * alias.mean()
+    # ---- the accepted-edge list, the filter verdicts and the poses do not depend on the match batch size
+    b = online.OnlineSlam(run, match_batch=4096)
+    b.upload_frames()
+    b.run_all()
+    assert a.accept_log == b.accept_log and np.array_equal(a.f_key, b.f_key) and np.array_equal(a.f_sticky, b.f_sticky)
+    assert np.array_equal(a.poses, b.poses)
+    assert [s["n_nodes"] for s in a.solves] == [s["n_nodes"] for s in b.solves]
+    # ---- the last re-optimisation equals a solve of the same input on a fresh handle: nothing of the 90-odd earlier structures
+    #      leaks into the last one
+    fresh = capi.Pgo()
+    fresh.add_graph(*a.last_input)
+    st = fresh.optimize(20)
+    assert st["status"] == 0 and st["n_edges"] == a.solves[-1]["n_edges"]
+    dt, dr = synth.pose_errors(fresh.store()[0].reshape(-1, 3, 4), a.poses)
+    assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+    fresh.close(); a.close(); b.close()

@@ -79,7 +79,8 @@ class PgoStats(C.Structure):
                 ("terminated_early", C.c_int32), ("n_vertices", C.c_int32), ("n_edges", C.c_int32),
                 ("n_gauge_fixed", C.c_int32), ("pcg_not_converged", C.c_int32),
                 ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
-                ("solve_ms", C.c_double), ("precond_builds", C.c_int32), ("_pad", C.c_int32)]
+                ("solve_ms", C.c_double), ("precond_builds", C.c_int32), ("exchange_calls", C.c_int32),
+                ("structure_ms", C.c_double), ("exchange_ms", C.c_double), ("structure_reused", C.c_int32), ("_pad", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -104,6 +105,14 @@ class FilterEdge(C.Structure):
                 ("stamps_from_ns", C.POINTER(C.c_int64)), ("stamps_to_ns", C.POINTER(C.c_int64)),
                 ("transform", C.c_double * 12), ("displacement_from", C.c_double * 12),
                 ("displacement_to", C.c_double * 12), ("pose_from", C.c_double * 12), ("pose_to", C.c_double * 12)]
+
+
+# numpy mirror of uzl_filter_edge (pointers as addresses): batches of thousands of edges are packed without a Python loop
+FILTER_EDGE_DTYPE = np.dtype([("key", "<u8"), ("matching_score", "<f8"), ("valid", "<i4"), ("sensor_from", "<i4"), ("sensor_to", "<i4"),
+                              ("n_stamps_from", "<i4"), ("n_stamps_to", "<i4"), ("_pad", "<i4"), ("stamps_from_ns", "<u8"),
+                              ("stamps_to_ns", "<u8"), ("transform", "<f8", (12,)), ("displacement_from", "<f8", (12,)),
+                              ("displacement_to", "<f8", (12,)), ("pose_from", "<f8", (12,)), ("pose_to", "<f8", (12,))], align=True)
+assert FILTER_EDGE_DTYPE.itemsize == C.sizeof(FilterEdge)
 
 
 class ClusterInfo(C.Structure):
@@ -520,6 +529,12 @@ class Filter:
     def add(self, edges):
         arr, keep = pack_filter_edges(edges)
         self._check(lib().uzl_filter_add(self._h, C.c_int32(len(edges)), arr))
+
+    def add_packed(self, arr):
+        """arr: FILTER_EDGE_DTYPE array; the stamp arrays its pointer fields address must stay alive for the call."""
+        a = np.ascontiguousarray(arr, FILTER_EDGE_DTYPE)
+        if len(a):
+            self._check(lib().uzl_filter_add(self._h, C.c_int32(len(a)), _p(a, C.c_void_p)))
 
     def remove(self, keys):
         k = np.ascontiguousarray(keys, np.uint64)

@@ -521,6 +521,7 @@ __global__ __launch_bounds__(kBlk) void pcg_spmv_kernel(PgoDev D, const double* 
             D.scal[0] = rz;
             if (it == 0) D.scal[1] = thresh;
             if (!(rz > thresh) ) D.flags[0] = 1;       // converged (or rz == 0 / NaN): x from the last update is final
+            if (!(rz >= 0.)) D.flags[2] = 1;           // negative / NaN r.M^-1 r: breakdown
         }
     }
 }
@@ -664,6 +665,27 @@ __global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ 
     if (t == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void set_scalar_kernel(double* __restrict__ dst, double v) { *dst = v; }
+
+// After PCG has set `done`: scal[7] = |r|^2 / |b|^2 with the recurrence residual r (= b - (H + lambda) x up to rounding for ANY
+// step lengths and directions, so it is the true residual even when the preconditioner misbehaved).  The host refuses a
+// "converged" solve whose residual has not come down (uzl_pgo.hip, pcg_solve).  One workgroup; a no-op until `done`.
+__global__ __launch_bounds__(1024) void residual_guard_kernel(PgoDev D)
+{
+    __shared__ double sr[16], sb[16];
+    if (!D.flags[0]) return;
+    const int n = D.nb * 6;
+    double rr = 0., bb = 0.;
+    for (int i = threadIdx.x; i < n; i += 1024) { const double r = D.r[i], b = D.b[i]; rr += r * r; bb += b * b; }
+    for (int o = 32; o; o >>= 1) { rr += __shfl_xor(rr, o); bb += __shfl_xor(bb, o); }
+    if ((threadIdx.x & 63) == 0) { sr[threadIdx.x >> 6] = rr; sb[threadIdx.x >> 6] = bb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        rr = 0.; bb = 0.;
+        for (int w = 0; w < 16; w++) { rr += sr[w]; bb += sb[w]; }
+        D.scal[7] = bb > 0. ? rr / bb : 0.;
+    }
+}
+void k_residual_guard(const PgoDev& D, hipStream_t s) { hipLaunchKernelGGL(residual_guard_kernel, dim3(1), dim3(1024), 0, s, D); }
 
 void k_publish(const PgoDev& D, PgoHostScal* out_dev, uint32_t seq, hipStream_t s)
 {

@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const d
             D.scal[0] = rz;
             if (it == 0) D.scal[1] = thresh;
             if (!(rz > thresh)) D.flags[0] = 1;
+            if (!(rz >= 0.)) D.flags[2] = 1;      // r.M^-1 r < 0 (or NaN): M^-1 is not positive definite - breakdown, not convergence
         }
     }
     STAMP(16);     // 19: restriction of Ap + stores

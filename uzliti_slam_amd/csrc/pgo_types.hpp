@@ -51,7 +51,7 @@ struct PgoDev {
     double* part_a;          // [kMaxPartials] block partials (p.Ap, chi2, ...)
     double* part_b;          // [kMaxPartials] block partials (r.z, scale, ...)
     double* part_c;          // [kMaxPartials] block partials (max |H_jj|)
-    double* scal;            // [8]: 0 rz, 1 rz threshold, 2 rz_prev, 3 lambda, 4 chi2, 5 scale, 6 diagmax
+    double* scal;            // [8]: 0 rz, 1 rz threshold, 2 rz_prev, 3 lambda, 4 chi2, 5 scale, 6 diagmax, 7 |r|^2 / |b|^2 after PCG
     int32_t* flags;          // [4]: 0 done, 1 iterations, 2 breakdown
 };
 

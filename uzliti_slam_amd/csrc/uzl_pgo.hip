@@ -30,6 +30,7 @@ int k_diagmax(const PgoDev& D, hipStream_t s);
 void k_precond(const PgoDev& D, hipStream_t s);
 void k_publish(const PgoDev& D, PgoHostScal* out_dev, uint32_t seq, hipStream_t s);
 void k_set_scalar(double* dst, double v, hipStream_t s);
+void k_residual_guard(const PgoDev& D, hipStream_t s);
 int k_pcg_init(const PgoDev& D, double* p0, double* p1, hipStream_t s);
 int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
 int k_pcg_update(const PgoDev& D, const double* p, int n_part, hipStream_t s);
@@ -126,6 +127,13 @@ struct uzl_pgo {
     DevBuf<double> d_red;
     int64_t iter_span = 0;           // doubles all-reduced per PCG iteration: [A p | restricted A p | p.Ap partials]
     int64_t l1_span = 0;
+    // per-optimize accounting (uzl_pgo_stats)
+    double structure_ms = 0., exchange_ms = 0.;
+    int32_t exchange_calls = 0;
+    bool structure_reused = false;
+    double last_residual_ratio = 0.;
+    int32_t guard_trips = 0;
+    bool mult_banned = false;        // the multiplicative operator broke down on a graph of this handle: later structures start additive
     KernelTimer timer;
 };
 
@@ -176,7 +184,10 @@ void set_lambda(uzl_pgo* h, double lambda)
 void shard_allreduce(uzl_pgo* h, double* ptr, int64_t count)
 {
     if (!h->sharded || count <= 0) return;
+    const auto t0 = std::chrono::steady_clock::now();
     const int rc = h->allreduce(ptr, count, (void*)h->stream, h->allreduce_user);
+    h->exchange_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->exchange_calls++;
     if (rc != 0) throw HipError{hipErrorUnknown, "all-reduce callback failed", __FILE__, __LINE__};
 }
 // chi2 is a sum over edges: partial per rank
@@ -358,7 +369,9 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     std::vector<size_t> o_dense((size_t)L + 1, 0);
     if (h->ml_comp) for (int l = cl; l < L; l++) o_dense[l] = take((size_t)(6 * h->ml_n[l]) * (size_t)(6 * h->ml_n[l]) * 8);
     static const bool mult_off = getenv("UZL_ML_ADDITIVE") != nullptr;                 // A/B switch
-    h->ml_mult = h->ml_comp && !mult_off;
+    // A handle whose graphs made the multiplicative operator break down (chain-like graphs: few loop closures per vertex, the
+    // shape of an online run) keeps the additive operator for its later structures instead of failing once per add_graph.
+    h->ml_mult = h->ml_comp && !mult_off && !h->mult_banned;
     const size_t n12 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl + 1] * 36 * 8 : 0, n11 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl] * 36 * 8 : 0;
     const size_t o_mAP = take(n12), o_mQ = take(n12), o_mQY = take(n12), o_mAS = take(n11);
     static const int ns_env = getenv("UZL_ML_NS_STEPS") ? atoi(getenv("UZL_ML_NS_STEPS")) : 2;
@@ -619,6 +632,7 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
     }
 }
 
+constexpr double kResidualGuard = 1e-4;     // |r|^2 / |b|^2 a solve under the multiplicative operator must reach (legitimate solves: 1e-10 .. 1e-6)
 static const int kGraphPairs = getenv("UZL_GRAPH_PAIRS") ? std::max(1, atoi(getenv("UZL_GRAPH_PAIRS"))) : 8;      // one graph replay = 2 x pairs PCG iterations
 
 void destroy_pcg_graph(uzl_pgo* h)
@@ -635,10 +649,12 @@ void ensure_pcg_graph(uzl_pgo* h)
 {
     uzl_pgo::MlBuf& B = h->mlb[h->ml_ix];
     if (B.graph_exec) return;
+    const auto t0 = std::chrono::steady_clock::now();
     UZL_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     enqueue_pcg_pairs(h, kGraphPairs, false);
     UZL_HIP(hipStreamEndCapture(h->stream, &B.graph));
     UZL_HIP(hipGraphInstantiate(&B.graph_exec, B.graph, nullptr, nullptr, 0));
+    h->structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 // one (H + lambda I) dx = b solve; returns PCG iterations used, sets *converged
@@ -674,12 +690,19 @@ int pcg_solve(uzl_pgo* h, bool* converged)
             else UZL_HIP(hipGraphLaunch(h->mlb[h->ml_ix].graph_exec, s));
         }
         launched += reps * 2 * kGraphPairs;
+        k_residual_guard(D, s);                                   // a no-op until `done` is set
         fetch_scal(h);
         if (h->h_scal.p->flags[0] || launched >= max_it) break;
         want = 2 * kGraphPairs;
     }
     UZL_HIP(hipGetLastError());
     *converged = h->h_scal.p->flags[0] != 0 && h->h_scal.p->flags[2] == 0;
+    // The multiplicative cycle / Newton-Schulz operator is not SPD by construction (see the fallback in do_optimize).  The
+    // recurrence residual r is the true residual of x whatever the preconditioner did, so a solve under that operator which
+    // claims convergence in the M^-1 norm while |r| has not come down by kResidualGuard relative to |b| is refused and the
+    // caller falls back to the additive operator (a sum of SPD terms, whose M^-1 norm is a norm).
+    h->last_residual_ratio = h->h_scal.p->scal[7];
+    if (*converged && (h->ml_mult || h->ml_ns_steps > 0) && !(h->last_residual_ratio <= kResidualGuard)) { *converged = false; h->guard_trips++; }
     const int iters = h->h_scal.p->flags[1];
     h->prev_pcg_iters = iters;
     return iters;
@@ -694,10 +717,14 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     uzl_pgo_stats S;
     memset(&S, 0, sizeof(S));
     // optimizeImpl: initializeOptimization (:139), setFixedNodes (:144-146)
+    h->structure_ms = 0.; h->exchange_ms = 0.; h->exchange_calls = 0;
+    S.structure_reused = h->structure_ready ? 1 : 0;
     if (!h->structure_ready) {          // cached until the next add_graph/set_graph
+        const auto ts = std::chrono::steady_clock::now();
         h->fixed_eff = h->fixed_in;
         h->n_gauge = gauge_fix(h);
         build_structure(h);
+        h->structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
     }
     S.n_vertices = h->n; S.n_edges = h->e; S.n_gauge_fixed = h->n_gauge;
     hipStream_t s = h->stream;
@@ -812,7 +839,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
                     UZL_HIP(hipStreamSynchronize(h->stream2));                    // multiplicative operator: drop it and rebuild
                     h->ml_pending = false; last_rel = 1e300;                      // synchronously at the next linearisation
                 }
-                h->ml_mult = false; h->ml_ns_steps = 0;
+                h->ml_mult = false; h->ml_ns_steps = 0; h->mult_banned = true;
                 for (auto& B : h->mlb) B.hot.Cmat = B.y1;
                 destroy_pcg_graph(h);                                             // MlHot is a by-value kernel argument
                 h->ml_trial_setup = true;
@@ -822,8 +849,8 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             if (fresh) pcg_ref = pcg_its;
             pcg_last = pcg_its;
             if (h->cfg.verbose)
-                fprintf(stderr, "[uzl_pgo] it %d trial %d lambda %.3e pcg %d  rz_end %.3e  rz_stop %.3e  chi2 %.9g\n", it, qmax, lambda, pcg_its,
-                        h->h_scal.p->scal[0], h->h_scal.p->scal[1], current_chi);
+                fprintf(stderr, "[uzl_pgo] it %d trial %d lambda %.3e pcg %d  rz_end %.3e  rz_stop %.3e  |r|2/|b|2 %.3e  conv %d  chi2 %.9g\n", it, qmax, lambda, pcg_its,
+                        h->h_scal.p->scal[0], h->h_scal.p->scal[1], h->last_residual_ratio, (int)conv, current_chi);
             if (!conv) { S.pcg_not_converged++; rc = UZL_ERR_NOT_CONVERGED; }
             S.lm_trials++;
             int go, gc;
@@ -857,6 +884,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     if (h->ml_pending) { UZL_HIP(hipStreamSynchronize(h->stream2)); h->ml_pending = false; }   // a rebuild nobody will use: let it drain
     UZL_HIP(hipStreamSynchronize(s));
     S.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    S.structure_ms = h->structure_ms; S.exchange_ms = h->exchange_ms; S.exchange_calls = h->exchange_calls;
     if (st) *st = S;
     if (rc != UZL_OK) h->last_error = "PCG hit pcg_max_iter in at least one LM trial";
     return rc;

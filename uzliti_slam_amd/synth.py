@@ -184,7 +184,7 @@ def _close_pairs(pos, radius, min_sep):
 
 # ----------------------------------------------------------------------------- descriptor frames
 def make_pair(rng, n_kp=1000, desc_bytes=32, flip_p=0.08, outlier_frac=0.4, sigma=0.01, invalid_frac=0.1,
-              max_t=1.0, max_rot_deg=20.0):
+              max_t=1.0, max_rot_deg=20.0, T=None):
     """SURVEY §8d 'Synthetic descriptors': one node pair (frame `from`, frame `to`).
     Returns (frame_from, frame_to, T_from_to (3,4)) with frames as dicts
     {desc (n,bytes) u8, pos (3,n) f64, valid (n) u8, feature_type, sensor_frame}."""
@@ -192,12 +192,16 @@ def make_pair(rng, n_kp=1000, desc_bytes=32, flip_p=0.08, outlier_frac=0.4, sigm
     # landmarks in a 6 x 4 x 3 m box in front of camera A (z forward)
     lm = np.stack([rng.uniform(-3, 3, n_kp), rng.uniform(-2, 2, n_kp), rng.uniform(0.5, 3.5, n_kp)], 0)
     dbits = rng.integers(0, 2, (n_kp, bits), dtype=np.uint8)
-    # relative motion: from_T_to
-    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
-    ang = np.deg2rad(rng.uniform(0, max_rot_deg))
-    R = quat_to_R(quat_from_rotvec(ax * ang))
-    tv = rng.normal(size=3); tv *= rng.uniform(0, max_t) / np.linalg.norm(tv)
-    T = se3(R, tv)
+    # relative motion: from_T_to (random inside the acceptance gate unless the caller gives it)
+    if T is None:
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = np.deg2rad(rng.uniform(0, max_rot_deg))
+        R = quat_to_R(quat_from_rotvec(ax * ang))
+        tv = rng.normal(size=3); tv *= rng.uniform(0, max_t) / np.linalg.norm(tv)
+        T = se3(R, tv)
+    else:
+        T = np.asarray(T, np.float64).reshape(3, 4)
+        R = T[:, :3]; tv = T[:, 3]
 
     def noisy_bits():
         return dbits ^ (rng.random((n_kp, bits)) < flip_p).astype(np.uint8)
@@ -335,3 +339,66 @@ def make_slam_run(n_nodes=150, n_landmarks=1500, seed=2024, max_pairs=400, desc_
     pairs = full
     return dict(gt=gt, init=g["nodes_pose"].reshape(N, 3, 4), fixed=g["nodes_fixed"], stamps=stamps, odo=g["edges"], frames=frames,
                 sensor=S.reshape(12), pairs=pairs)
+
+
+def make_online_run(n_nodes=20000, n_pairs=4096, n_kp=1000, seed=12345, desc_seed=777, alias_frac=0.05, desc_bytes=32,
+                    max_pair_dist=0.9, max_pair_rot_deg=17.0, burst=16):
+    """BASELINE config 5: `n_pairs` node-pair match jobs feeding a graph that grows to `n_nodes` nodes.
+    The trajectory, odometry edges and dead-reckoned start poses are make_pose_graph's (seed 12345); the node pairs are places the
+    robot revisits (closer than max_pair_dist, heading within max_pair_rot_deg: inside the acceptance gate, GraphSlam.cfg:19-20),
+    ordered by their later node = the order the candidate producers would emit them online.  Every pair carries its own two
+    FeatureData frames in the camera frame (make_pair's recipe, seed 777: 1000 landmarks, 8 % bit flips, 40 % clutter, 1 cm noise,
+    10 % without depth) whose relative motion is the ground-truth relative pose of the two nodes; for a fraction `alias_frac` the
+    frames come from a random motion instead (perceptual aliasing: a confident but wrong edge, what the gate, the filter and the
+    Huber kernel exist for).  Camera = base (identity sensor transform).
+    Returns dict(gt, init (N,3,4), fixed, odo (make_pose_graph edge arrays), stamps_ns (N) int64,
+                 pair_from, pair_to, pair_later (P) int32, pair_alias (P) bool, frames: list of P (frame_from, frame_to))."""
+    g = make_pose_graph(n_nodes, n_nodes - 1, seed=seed)
+    N = n_nodes
+    gt = g["gt_pose"].reshape(N, 3, 4)
+    rng = np.random.default_rng(desc_seed)
+    cand = _close_pairs(gt[:, :, 3], max_pair_dist, 20)
+    if len(cand):
+        rot = rotation_angle(np.swapaxes(gt[cand[:, 0], :, :3], 1, 2) @ gt[cand[:, 1], :, :3])
+        cand = cand[rot < np.deg2rad(max_pair_rot_deg)]
+    if len(cand) < n_pairs:
+        raise ValueError("trajectory has only %d revisits for %d pairs" % (len(cand), n_pairs))
+    # Revisits come in bursts: while the robot passes an old place, several consecutive new nodes each match several consecutive old
+    # ones (the candidate producers emit every node within the radius, graph_slam_node.cpp:272-289) - and the edge filter only
+    # validates clusters of >= 8 such edges (transformation_filter.cpp:233).  Draw seed revisits and take up to `burst` candidates
+    # whose two nodes lie within +-6 nodes (3 s) of the seed's.
+    key = cand[:, 0] * np.int64(N) + cand[:, 1]               # cand is sorted lexicographically, so key is ascending
+    chosen = np.zeros(len(cand), bool)
+    n_chosen = 0
+    for seed_ix in rng.permutation(len(cand)):
+        if n_chosen >= n_pairs:
+            break
+        if chosen[seed_ix]:
+            continue
+        i0, j0 = cand[seed_ix]
+        near = []
+        for i in range(max(0, i0 - 6), min(N, i0 + 7)):
+            lo = np.searchsorted(key, i * np.int64(N) + max(0, j0 - 6)); hi = np.searchsorted(key, i * np.int64(N) + min(N - 1, j0 + 6), side="right")
+            near.extend(range(lo, hi))
+        near = np.array([k for k in near if not chosen[k]], np.int64)
+        if len(near) > burst:
+            near = rng.choice(near, size=burst, replace=False)
+        near = near[:n_pairs - n_chosen]
+        chosen[near] = True; n_chosen += len(near)
+    if n_chosen < n_pairs:
+        raise ValueError("could not draw %d pairs" % n_pairs)
+    pr = cand[chosen]                                         # i < j, lexicographic
+    order = np.lexsort((pr[:, 0], pr[:, 1]))                  # by later node j, then i
+    pr = pr[order]
+    flip = rng.random(n_pairs) < 0.5
+    pf = np.where(flip, pr[:, 1], pr[:, 0]).astype(np.int32); pt = np.where(flip, pr[:, 0], pr[:, 1]).astype(np.int32)
+    alias = rng.random(n_pairs) < alias_frac
+    rel = se3_mul(se3_inv(gt[pf]), gt[pt])                    # from_T_to
+    frames = []
+    for k in range(n_pairs):
+        f, t, _ = make_pair(rng, n_kp=n_kp, desc_bytes=desc_bytes, T=None if alias[k] else rel[k])
+        frames.append((f, t))
+    t0 = 1_400_000_000 * 10**9
+    stamps = (t0 + (0.5e9 * np.arange(N)).astype(np.int64)).astype(np.int64)
+    return dict(gt=gt, init=g["nodes_pose"].reshape(N, 3, 4), fixed=g["nodes_fixed"], odo=g["edges"], stamps_ns=stamps,
+                pair_from=pf, pair_to=pt, pair_later=pr[:, 1].astype(np.int32), pair_alias=alias, frames=frames)
