@@ -4,20 +4,24 @@
   python bench.py --gpus N --steps K --warmup W
 
 Primary metric   : SE(3) edges optimised / s   on BASELINE config 2 (1k nodes / 5k edges, 20 LM iterations)
-Secondary metric : node pairs matched / s      on BASELINE config 3 (512 pairs x 1000 ORB-256, 500 hypotheses)
-`formats` block  : Feature records -> frame arena for the 1024 frames of config 3 (HBM-bound byte shuffle; rank 0 only)
+`secondary`      : node pairs matched / s      on BASELINE config 3 (512 pairs x 1000 ORB-256, 500 hypotheses)
+`c4_1gpu`        : the north-star line: 10k nodes / 50k edges on ONE GPU against the CPU path (1 thread and all cores)   [N = 1]
+`online_c5`      : BASELINE config 5: 4096 pair jobs feeding a graph that grows to 20k nodes, re-optimised every 256 edges
+`formats`        : Feature records -> frame arena for the 1024 frames of config 3 (HBM-bound byte shuffle)           [rank 0]
+`rooflines`      : every kernel SURVEY section 8(d) names, each against the roof that bounds it
 
 A "step" is one pass of the hot path over one batch with the inputs already resident in HBM:
   primary   step = uzl_pgo_reset + uzl_pgo_optimize(20)   (graph resident, poses restored on the device)
   secondary step = uzl_match_estimate over the resident frames of 512 node pairs
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank solves its own
-independent graph / its own shard of node pairs: the path partitions into independent units, so there is no
-data-path collective and scaling is weak; torch.distributed is used only for the barrier and the
-max-over-ranks of the timed region.
+With --gpus N > 1 (one rank per GPU under torch.distributed.run; when RANK is not set this script starts the ranks itself, before
+anything touches the GPU) every rank solves its own independent graph / its own shard of node pairs: the path partitions into
+independent units, so there is no data-path collective and scaling is weak; torch.distributed is used only for the barrier and
+the max-over-ranks of the timed region.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,9 +30,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GOPS = 256 * 4 * 32 * 2.4   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz = 78 643 G lane-ops/s (32-bit VALU)
 MFMA_I8_PEAK_TOPS = 5000.0            # MI355X_MICROARCH.md: int8 MFMA = 2 x the ~2.5 PFLOP/s dense bf16 rate
+F64_PEAK_TFLOPS = 78.6                # MI355X_MICROARCH.md: f64 vector = f64 matrix = 78.6 TFLOP/s
+TRAFFIC_JSON = os.path.join("profiles", "traffic.json")
 
 
 def parse():
@@ -45,11 +51,29 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-formats", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the 10k/50k one-GPU block (N = 1 only)")
+    ap.add_argument("--no-online", action="store_true", help="skip the BASELINE config 5 block")
+    ap.add_argument("--online-nodes", type=int, default=20000)
+    ap.add_argument("--online-pairs", type=int, default=4096)
     ap.add_argument("--sharded", action="store_true",
                     help="N > 1 only: additionally time ONE 10000-node/50000-edge graph sharded over all ranks "
-                         "(BASELINE config 4, RCCL all-reduce per PCG iteration); reported under `sharded_c4`")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU-baseline sample")
+                         "(BASELINE config 4, native RCCL all-reduce per PCG iteration); reported under `sharded_c4`")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-baseline sample of the primary / secondary block")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a child process (nothing in this
+    process has touched the GPU yet) and relay: rank 0 of the child prints the JSON line to the inherited stdout."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 class Dist:
@@ -60,6 +84,7 @@ class Dist:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.torch = None
+        self.dist = None
         if self.world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
             import torch
             import torch.distributed as dist
@@ -68,9 +93,8 @@ class Dist:
             dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             self.torch = torch
             self.dist = dist
-        if self.world != max(n_gpus, 1):
-            if self.rank == 0:
-                print(f"[bench] --gpus {n_gpus} but WORLD_SIZE={self.world}: using WORLD_SIZE", file=sys.stderr)
+        if self.world != max(n_gpus, 1) and self.rank == 0:
+            print(f"[bench] --gpus {n_gpus} but WORLD_SIZE={self.world}: using WORLD_SIZE", file=sys.stderr)
 
     def sync(self):
         if self.torch is not None:
@@ -81,19 +105,18 @@ class Dist:
             self.dist.barrier()
             self.torch.cuda.synchronize()
 
-    def max(self, v):
+    def _red(self, v, op):
         if self.torch is None:
             return v
         t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(t, op=op)
         return float(t.item())
 
+    def max(self, v):
+        return self._red(v, self.dist.ReduceOp.MAX) if self.torch is not None else v
+
     def sum(self, v):
-        if self.torch is None:
-            return v
-        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
+        return self._red(v, self.dist.ReduceOp.SUM) if self.torch is not None else v
 
     def close(self):
         if self.torch is not None:
@@ -112,12 +135,125 @@ def timed(dist, fn, steps):
     return dist.max(dt)
 
 
+def traffic_of(key, applies):
+    """PMC-measured HBM bytes per launch, collected by profiles/collect.sh on the default workloads (separate --pmc passes); this
+    run does not measure it - `traffic_source` in the JSON says where it comes from."""
+    if not applies:
+        return None
+    try:
+        return json.load(open(os.path.join(ROOT, TRAFFIC_JSON))).get(key)
+    except Exception:
+        return None
+
+
+def roof(kernel, bound, achieved, peak, unit, **extra):
+    d = dict(kernel=kernel, bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit, frac=round(achieved / peak, 5) if peak else None)
+    d.update(extra)
+    return d
+
+
+# ---------------------------------------------------------------------------------------------------------------------- pose graph
+def pgo_block(capi, synth, dist, dev, a, nodes, edges, steps, warmup, seed, xy=False):
+    """resident-graph solve loop + live per-kernel profile of one more solve"""
+    g = synth.make_pose_graph(nodes, edges, seed=seed)
+    pgo = capi.Pgo(device=dev, iterations=a.lm_iters, optimize_xy_only=1 if xy else 0)
+    t0 = time.perf_counter()
+    pgo.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])            # H2D + flattening kernels, outside the timed region
+    h2d_ms = 1e3 * (time.perf_counter() - t0)
+    work = {"edges": 0}
+
+    def step():
+        pgo.reset()
+        st = pgo.optimize(a.lm_iters)
+        work["edges"] += st["n_edges"] * st["iterations_done"]
+        work["last"] = st
+
+    for _ in range(warmup):
+        step()
+    work["edges"] = 0
+    t = timed(dist, step, steps)
+    t0 = time.perf_counter()
+    pgo.store()
+    d2h_ms = 1e3 * (time.perf_counter() - t0)
+    return dict(g=g, pgo=pgo, t=t, edges=work["edges"], st=work["last"], h2d_ms=h2d_ms, d2h_ms=d2h_ms)
+
+
+def pgo_profile(pgo, a):
+    pgo.set_profiling(True)
+    pgo.reset(); st = pgo.optimize(a.lm_iters)
+    kt = pgo.kernel_times()
+    pgo.set_profiling(False)
+    return st, kt
+
+
+def pgo_rooflines(pgo, st, st_prof, kt, nodes, edges, is_default):
+    nb = st["n_vertices"] - int(pgo.get_fixed().sum())
+    E = st["n_edges"]
+    out = []
+    spmv = kt.get("pcg_spmv", dict(ms=0.0, launches=1))
+    alg = 288.0 * (nb + E) + 96.0 * nb        # H once (symmetric) + read p + write Ap  (DESIGN.md section 4)
+    # launches after the device-side `done` flag are ~0.7 us no-ops that move nothing: bytes are counted for the launches that did
+    # work (= PCG iterations of the profiled solve) over the kernel's whole measured time
+    active = min(int(st_prof["pcg_iterations"]), int(spmv["launches"])) or 1
+    ach = alg * active / (spmv["ms"] * 1e-3) / 1e9 if spmv["ms"] > 0 else 0.0
+    agg4 = nb > 2048
+    out.append(roof("ml_spmv_kernel<%d>" % (4 if agg4 else 1) if pgo.cfg.preconditioner else "pcg_spmv_kernel", "hbm", ach, HBM_PEAK_GBS, "GB/s",
+                    traffic=traffic_of("pcg_spmv_bytes_per_launch" if not agg4 else "pcg_spmv4_bytes_per_launch", is_default),
+                    algorithmic_bytes_per_launch=alg, avg_launch_us=round(1e3 * spmv["ms"] / max(spmv["launches"], 1), 3),
+                    launches=spmv["launches"], active_launches=active,
+                    note="working set (H = %.1f MB) is L2 / Infinity-Cache resident; launch-latency bound at this size" % (288e-6 * (nb + 2 * E))))
+    lin = kt.get("linearize")
+    if lin and lin["ms"] > 0:
+        alg_l = 632.0 * E + 336.0 * st["n_vertices"]                      # SURVEY section 8(d): B_lin = 632 E + 336 N
+        out.append(roof("linearize_kernel", "hbm", alg_l * lin["launches"] / (lin["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s",
+                        traffic=traffic_of("linearize_bytes_per_launch", is_default and not agg4), algorithmic_bytes_per_launch=alg_l,
+                        avg_launch_us=round(1e3 * lin["ms"] / lin["launches"], 3), launches=lin["launches"],
+                        note="the sparse Hessian build: one lane per edge, 344 B in, two 624 B slot records out (assembly is a gather, no atomics)"))
+    gm = kt.get("ml_ns_gemm")
+    if gm and gm["ms"] > 0:
+        n1 = (nb + 7) // 8
+        n_c = n1 if not agg4 else (n1 + 3) // 4
+        flop = 2.0 * (6.0 * n_c) ** 3
+        out.append(roof("ml_ns_gemm_kernel", "mfma", flop * gm["launches"] / (gm["ms"] * 1e-3) / 1e12, F64_PEAK_TFLOPS, "TFLOP/s (f64 matrix cores)",
+                        traffic=None, flop_per_launch=flop, n=int(6 * n_c), avg_launch_us=round(1e3 * gm["ms"] / gm["launches"], 3), launches=gm["launches"],
+                        note="the block-GEMM of the path: X' = 2X - X(AX), v_mfma_f64_16x16x4_f64, 64 x 64 tiles; %d launches per solve" % gm["launches"]))
+    return out
+
+
+def cpu_pgo(O, g, a, seconds, threads_list, max_solves=64):
+    """the CPU path on this host: C restatement of g2o LM + block sparse direct Cholesky (`-O3 -march=native -fopenmp`, built here)"""
+    fl = O.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    fixed, _ = O.set_fixed_nodes(fl["fixed"], fl["ij"])
+    out = {}
+    for th in threads_list:
+        t0 = time.perf_counter(); n_solves = 0; cpu_edges = 0
+        while True:
+            _, so = O.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=a.lm_iters, native_threads=th)
+            n_solves += 1; cpu_edges += so["n_edges"] * so["iterations_done"]
+            if time.perf_counter() - t0 > seconds or n_solves >= max_solves:
+                break
+        dt = time.perf_counter() - t0
+        out[th] = dict(value=round(cpu_edges / dt, 1), seconds_per_solve=round(dt / n_solves, 4), solves=n_solves, seconds=round(dt, 2),
+                       cholesky_share=round(so["t_numeric_ms"] / max(so["t_total_ms"], 1e-9), 3))
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+# ---------------------------------------------------------------------------------------------------------------------- formats
 def bench_formats(capi, dev, pairs, n_kp):
     """FeatureData::fromMsg for every frame of the secondary workload in ONE launch: serialised graph_slam_msgs/Feature records
     (41 + 4 D bytes per keypoint, one float32 per descriptor byte) -> descriptor rows / positions / flags in the frame arena.
     Pure byte shuffle: HBM bound; algorithmic bytes = records in + arrays out.  Records are built on the host with numpy
     (layout only, untimed); the timed quantity is the kernel (HIP events on the estimator's stream)."""
-    import ctypes as C
     from uzliti_slam_amd import wire as W
     frames = [f for p in pairs for f in p[:2]]
     D = frames[0]["desc"].shape[1]
@@ -143,94 +279,62 @@ def bench_formats(capi, dev, pairs, n_kp):
         best = ms if best is None or (0 < ms < best) else best
         for i in ids:
             m.remove_frame(i)
-    # spot check against the arrays the records were made from
-    ids, _ = W.add_frames_wire(m, sens, len(frames))
+    ids, _ = W.add_frames_wire(m, sens, len(frames))                        # spot check against the arrays the records were made from
     gd, gp, gv = W.get_frame(m, ids[-1])
     ok = bool(np.array_equal(gd, frames[-1]["desc"]) and np.array_equal(gp, np.asarray(frames[-1]["pos"], np.float64)) and np.array_equal(gv, np.asarray(frames[-1]["valid"], np.uint8)))
     m.close()
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and len(frames) == 1024 and n_kp == 1000:                 # the PMC passes were collected on this workload
-        try:
-            traffic = json.load(open(tpath)).get("wire_unpack_bytes_per_launch")
-        except Exception:
-            traffic = None
     alg = float(n_kp_total) * ((41 + 4 * D) + (D + 25))
     ach = alg / (best * 1e-3) / 1e9 if best and best > 0 else 0.0
     return dict(kernel="wire_unpack_kernel", workload="%d frames x %d keypoints, ORB-256: Feature records -> frame arena, one launch" % (len(frames), n_kp),
-                ms=round(best or 0.0, 4), roofline=dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                                                          algorithmic_bytes=alg, traffic=traffic),
+                ms=round(best or 0.0, 4),
+                roofline=roof("wire_unpack_kernel", "hbm", ach, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=alg,
+                              traffic=traffic_of("wire_unpack_bytes_per_launch", len(frames) == 1024 and n_kp == 1000), traffic_source=TRAFFIC_JSON),
                 matches_source_arrays=ok)
 
 
+# ---------------------------------------------------------------------------------------------------------------------- main
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a))
     dist = Dist(a.gpus)
     from uzliti_slam_amd import capi, synth
+    from uzliti_slam_amd import dist as ud
     capi.lib()
     dev = dist.local_rank
+    is_c2 = (a.nodes, a.edges) == (1000, 5000)
 
-    # ------------------------------------------------------------------ primary: pose-graph solve
-    from uzliti_slam_amd import dist as ud
-    g = synth.make_pose_graph(a.nodes, a.edges, seed=ud.replica_seed(12345, dist.rank))   # one independent graph per rank
-    pgo = capi.Pgo(device=dev, iterations=a.lm_iters)
-    pgo.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])            # H2D once, outside the timed region
-    work = {"edges": 0, "pcg": 0, "trials": 0}
-
-    def pgo_step():
-        pgo.reset()
-        st = pgo.optimize(a.lm_iters)
-        work["edges"] += st["n_edges"] * st["iterations_done"]
-        work["pcg"] += st["pcg_iterations"]; work["trials"] += st["lm_trials"]
-        work["last"] = st
-
-    for _ in range(a.warmup):
-        pgo_step()
-    work.update(edges=0, pcg=0, trials=0)
-    t_pgo = timed(dist, pgo_step, a.steps)
-    edges_total = dist.sum(float(work["edges"]))
-    value = edges_total / t_pgo
-    st = work["last"]
-
-    # roofline of the dominant kernel (PCG SpMV), measured live with HIP events on the solver's stream
-    pgo.set_profiling(True)
-    pgo.reset(); st_prof = pgo.optimize(a.lm_iters)
-    kt = pgo.kernel_times()
-    pgo.set_profiling(False)
-    spmv = kt.get("pcg_spmv", dict(ms=0.0, launches=1))
-    spmv_us = 1e3 * spmv["ms"] / max(spmv["launches"], 1)
-    nb = st["n_vertices"] - int(pgo.get_fixed().sum())
-    alg_bytes = 288.0 * (nb + st["n_edges"]) + 96.0 * nb        # H once (symmetric) + read p + write Ap  
-    # launches after the device-side `done` flag are ~0.7 us no-ops that move nothing: count bytes for the
-    # launches that did work (= PCG iterations of the profiled solve) over the kernel's whole measured time
-    active = min(int(st_prof["pcg_iterations"]), int(spmv["launches"])) or 1
-    achieved = alg_bytes * active / (spmv["ms"] * 1e-3) / 1e9 if spmv["ms"] > 0 else 0.0
-    traffic = None
-    cfg_name = {(1000, 5000): "BASELINE config 2", (10000, 50000): "BASELINE config 4 size on one GPU", (100, 300): "BASELINE config 1"}.get((a.nodes, a.edges), "custom size")
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and (a.nodes, a.edges) == (1000, 5000):     # the PMC passes were collected on config 2
-        try:
-            traffic = json.load(open(tpath)).get("pcg_spmv_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = dict(kernel=("ml_spmv_kernel" if pgo.cfg.preconditioner else "pcg_spmv_kernel"), bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                    algorithmic_bytes_per_launch=alg_bytes, avg_launch_us=round(spmv_us, 3), launches=spmv["launches"], active_launches=active,
-                    note="working set (H = %.1f MB) is L2/Infinity-Cache resident; launch-latency bound at this size"
-                         % (288e-6 * (nb + 2 * st["n_edges"])))
+    # ------------------------------------------------------------------ primary: pose-graph solve, one independent graph per rank
+    B = pgo_block(capi, synth, dist, dev, a, a.nodes, a.edges, a.steps, a.warmup, ud.replica_seed(12345, dist.rank))
+    pgo, g, st, t_pgo = B["pgo"], B["g"], B["st"], B["t"]
+    value = dist.sum(float(B["edges"])) / t_pgo
+    st_prof, kt = pgo_profile(pgo, a)
+    rooflines = pgo_rooflines(pgo, st, st_prof, kt, a.nodes, a.edges, is_c2)
+    roofline = dict(rooflines[0]); roofline["traffic_source"] = TRAFFIC_JSON
     kernels_ms = {k: round(v["ms"], 4) for k, v in sorted(kt.items(), key=lambda x: -x[1]["ms"])}
+    cfg_name = {(1000, 5000): "BASELINE config 2", (10000, 50000): "BASELINE config 4 size on one GPU", (100, 300): "BASELINE config 1"}.get((a.nodes, a.edges), "custom size")
+    # the deployed operating point (iti_slam_launch/yaml/slam.yaml:50-53): optimize_xy_only = true, same graph
+    Bxy = pgo_block(capi, synth, dist, dev, a, a.nodes, a.edges, max(2, a.steps // 2), 1, ud.replica_seed(12345, dist.rank), xy=True)
+    xy_only = dict(value=round(dist.sum(float(Bxy["edges"])) / Bxy["t"], 1), unit="edges/s", ms_per_solve=round(1e3 * Bxy["t"] / max(2, a.steps // 2), 4),
+                   lm_iterations_done=Bxy["st"]["iterations_done"], pcg_iterations_per_solve=Bxy["st"]["pcg_iterations"],
+                   chi2_final=Bxy["st"]["chi2_final"], note="optimize_xy_only = true (poses and measurements projected to x, y, yaw; g2o_optimizer.cpp:164-170)")
+    Bxy["pgo"].close()
 
     # ------------------------------------------------------------------ secondary: match + RANSAC
     secondary = None
     matcher = None
+    pairs = None
     if not a.no_secondary:
         per_rank = a.pairs                                                     # weak scaling: fixed work per GPU
         pairs = synth.make_pairs(per_rank, n_kp=a.keypoints, desc_bytes=32, seed=777 + dist.rank)
         matcher = capi.Match(device=dev, ransac_threshold=0.1, ransac_iteration=a.hypotheses,
                              ransac_break_percentage=1.0, do_prosac=1, seed=777)
-        ids = []
-        for f, t, _ in pairs:
-            ids.append((matcher.add_frame(f["desc"], f["pos"], f["valid"]), matcher.add_frame(t["desc"], t["pos"], t["valid"])))
+
+        def upload():
+            return [(matcher.add_frame(f["desc"], f["pos"], f["valid"]), matcher.add_frame(t["desc"], t["pos"], t["valid"])) for f, t, _ in pairs]
+        t0 = time.perf_counter()
+        ids = upload()
+        upload_ms = 1e3 * (time.perf_counter() - t0)
         jobs, fids = capi.Match._jobs(ids, None)
         res = np.zeros(per_rank, capi.EDGE_RESULT_DTYPE)
 
@@ -242,97 +346,165 @@ def main():
             match_step()
         t_match = timed(dist, match_step, a.steps)
         pairs_total = dist.sum(float(per_rank * a.steps))
+        # SURVEY section 8(d) defines pairs/s as submit -> results INCLUDING the H2D of the descriptors: one pass that uploads every
+        # frame (pageable host arrays, one add_frame per FeatureData as the adapter does) and estimates; never `value`
+        for fa, fb in ids:
+            matcher.remove_frame(fa); matcher.remove_frame(fb)
+        dist.barrier(); t0 = time.perf_counter()
+        ids2 = upload(); jobs2, fids2 = capi.Match._jobs(ids2, None)
+        matcher.launch_raw(jobs2, fids2); matcher.collect(res)
+        t_incl = dist.max(time.perf_counter() - t0)
+        jobs, fids = jobs2, fids2
         matcher.set_profiling(True)
         match_step()
         mk = matcher.kernel_times()
         matcher.set_profiling(False)
-        knn_ms = mk.get("knn2", dict(ms=0.0))["ms"]
-        valu_path = os.environ.get("UZL_KNN2_VALU") is not None or os.environ.get("UZL_KNN2_SCALAR") is not None
-        knn_traffic = None
-        tpath2 = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath2) and (per_rank, a.keypoints) == (512, 1000) and not valu_path:      # PMC passes were collected on this workload / kernel
-            try:
-                knn_traffic = json.load(open(tpath2)).get("knn2_bytes_per_launch")
-            except Exception:
-                knn_traffic = None
-        if valu_path:
-            word_ops = 2.0 * per_rank * a.keypoints * a.keypoints * 8          # xor + popcount-accumulate per 32-bit word
-            ach = word_ops / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
-            sec_roof = dict(kernel="knn2_lds_kernel<8, 1>", bound="valu", achieved=round(ach, 1), peak=round(VALU_PEAK_GOPS, 1),
-                            unit="G lane-ops/s (v_xor_b32 + v_bcnt_u32_b32)", frac=round(ach / VALU_PEAK_GOPS, 4), traffic=None, measured_issue_peak=36800.0,
-                            note="integer VALU bound (A/B path UZL_KNN2_VALU=1): 64 KB of descriptors feed 1.6e7 word-ops per pair")
-        else:
-            # Hamming matrix as an int8 GEMM: d = |t| + |q| - 2 <t,q>, <t,q> over D = 256 expanded bit positions
-            ops = 2.0 * per_rank * a.keypoints * a.keypoints * 256.0
-            ach = ops / (knn_ms * 1e-3) / 1e12 if knn_ms > 0 else 0.0
-            sec_roof = dict(kernel="knn2_mfma_kernel<8, 2>", bound="mfma", achieved=round(ach, 1), peak=MFMA_I8_PEAK_TOPS, unit="TOP/s (int8, dense)",
-                            frac=round(ach / MFMA_I8_PEAK_TOPS, 4), traffic=knn_traffic,
-                            note="v_mfma_i32_32x32x32_i8 over 0/1-expanded 256-bit descriptors (2 x 1000 x 1000 x 256 ops per pair); `peak` = 2 x the "
-                                 "~2.5 PFLOP/s dense bf16 rate (MI355X_MICROARCH.md, matrix-core table); the vector ALU that folds each 32 x 32 tile "
-                                 "into the per-query top-2 (3 instructions per distance) issues beside the matrix pipe and is the tighter of the two bounds")
+        knn_ms = mk.get("knn2", dict(ms=0.0))["ms"]; est_ms = mk.get("estimate", dict(ms=0.0))["ms"]
+        is_c3 = (per_rank, a.keypoints) == (512, 1000)
+        # Hamming matrix as an int8 GEMM: d = |t| + |q| - 2 <t,q>, <t,q> over D = 256 expanded bit positions
+        ops = 2.0 * per_rank * a.keypoints * a.keypoints * 256.0
+        ach = ops / (knn_ms * 1e-3) / 1e12 if knn_ms > 0 else 0.0
+        knn_roof = roof("knn2_mfma_kernel<8, 2>", "mfma", ach, MFMA_I8_PEAK_TOPS, "TOP/s (int8, dense)", traffic=traffic_of("knn2_bytes_per_launch", is_c3),
+                        traffic_source=TRAFFIC_JSON, ms=round(knn_ms, 4),
+                        note="v_mfma_i32_32x32x32_i8 over 0/1-expanded 256-bit descriptors (2 x 1000 x 1000 x 256 ops per pair); `peak` = 2 x the "
+                             "~2.5 PFLOP/s dense bf16 rate (MI355X_MICROARCH.md); the vector ALU that folds each 32 x 32 tile into the per-query "
+                             "top-2 (3 instructions per distance) issues beside the matrix pipe and is the tighter of the two bounds")
+        # RANSAC scoring: SURVEY section 8(d): hypotheses x M x 27 flop per pair (transform 18, difference 3, squared norm 5, compare 1)
+        flop = 27.0 * a.hypotheses * float(res["n_corr"].sum())
+        ach_e = flop / (est_ms * 1e-3) / 1e12 if est_ms > 0 else 0.0
+        est_roof = roof("estimate_kernel", "f64", ach_e, F64_PEAK_TFLOPS, "TFLOP/s (f64; transform on the matrix cores, norm / compare on the vector ALU)",
+                        traffic=None, ms=round(est_ms, 4), mean_correspondences=float(res["n_corr"].mean()),
+                        note="27 x hypotheses x M flop per pair; the kernel also sorts, samples, fits 500 float poses, refits and scores each job, "
+                             "all inside one workgroup with the point tile in LDS - about 35 % of its time is the vote loop this figure prices")
+        rooflines += [knn_roof, est_roof]
         secondary = dict(metric="node-pairs matched/sec", value=round(pairs_total / t_match, 1), unit="pairs/s",
                          ms_per_step=round(1e3 * t_match / a.steps, 4),
                          config=dict(workload="BASELINE config 3: %d node pairs x %d ORB-256 descriptors per frame, "
                                               "2-NN Hamming + %d-hypothesis PROSAC, early exit off" % (per_rank, a.keypoints, a.hypotheses)),
+                         upload_inclusive=dict(value=round(dist.sum(float(per_rank)) / t_incl, 1), unit="pairs/s", ms=round(1e3 * t_incl, 3),
+                                               h2d_ms=round(upload_ms, 3), h2d_mbytes=round(2e-6 * per_rank * a.keypoints * (32 + 24 + 1), 1),
+                                               note="add_frame of all %d frames from pageable host memory + one estimate (SURVEY 8d's definition); "
+                                                    "in the running system a frame is uploaded once per node and reused by every pair it takes part in" % (2 * per_rank)),
                          mean_consensus=float(res["consensus"].mean()), ok_fraction=float(res["ok"].mean()),
                          kernels_ms={k: round(v["ms"], 4) for k, v in mk.items()},
-                         roofline=sec_roof)
+                         roofline=knn_roof)
 
     # ------------------------------------------------------------------ formats: Feature records -> frame arena
     formats = None
     if matcher is not None and dist.rank == 0 and not a.no_formats:
         formats = bench_formats(capi, dev, pairs, a.keypoints)
 
+    # ------------------------------------------------------------------ north star: 10k / 50k on ONE GPU (N = 1 only)
+    c4 = None
+    if dist.world == 1 and not a.no_c4 and is_c2:
+        steps4 = max(3, a.steps // 3)
+        B4 = pgo_block(capi, synth, dist, dev, a, 10000, 50000, steps4, 1, 12345)
+        st4p, kt4 = pgo_profile(B4["pgo"], a)
+        r4 = pgo_rooflines(B4["pgo"], B4["st"], st4p, kt4, 10000, 50000, True)
+        for r in r4:
+            r["traffic_source"] = TRAFFIC_JSON
+        c4 = dict(metric="SE(3) edges optimized/sec, 10k nodes / 50k edges, one GPU", value=round(B4["edges"] / B4["t"], 1), unit="edges/s",
+                  ms_per_solve=round(1e3 * B4["t"] / steps4, 3), solves_timed=steps4, h2d_ms=round(B4["h2d_ms"], 3), d2h_ms=round(B4["d2h_ms"], 3),
+                  lm_iterations_done=B4["st"]["iterations_done"], pcg_iterations_per_solve=B4["st"]["pcg_iterations"],
+                  chi2_initial=B4["st"]["chi2_initial"], chi2_final=B4["st"]["chi2_final"], roofline=r4[0], rooflines=r4,
+                  kernels_ms_per_solve={k: round(v["ms"], 4) for k, v in sorted(kt4.items(), key=lambda x: -x[1]["ms"])})
+        if not a.no_cpu_baseline:
+            import oracle as O
+            ncpu = len(os.sched_getaffinity(0))
+            cb = cpu_pgo(O, B4["g"], a, 1.0, [1, ncpu], max_solves=1)          # one solve each: ~20 s per solve on one core
+            c4["cpu_baseline"] = dict(value=cb[1]["value"], unit="edges/s", cores=1, kind="port", seconds_per_solve=cb[1]["seconds_per_solve"],
+                                      all_cores=dict(value=cb[ncpu]["value"], cores=ncpu, seconds_per_solve=cb[ncpu]["seconds_per_solve"],
+                                                     note="OpenMP over the edges as in a g2o built with it; the sparse Cholesky (%.0f %% of the solve) is serial, "
+                                                          "as CSparse is" % (100 * cb[1]["cholesky_share"])),
+                                      nproc=ncpu, cpu=cpu_model(), sample="1 solve per thread count of the same graph, %d LM iterations" % a.lm_iters,
+                                      build="gcc -O3 -march=native -fopenmp on this host")
+            c4["speedup_vs_cpu_1_thread"] = round(cb[1]["seconds_per_solve"] / (B4["t"] / steps4), 1)
+            c4["speedup_vs_cpu_all_cores"] = round(cb[ncpu]["seconds_per_solve"] / (B4["t"] / steps4), 1)
+        B4["pgo"].close()
+
+    # ------------------------------------------------------------------ BASELINE config 5: match jobs feeding a growing graph
+    online_c5 = None
+    if not a.no_online and is_c2:
+        from uzliti_slam_amd import online
+        run = synth.make_online_run(a.online_nodes, a.online_pairs, n_kp=a.keypoints)
+        o = online.OnlineSlam(run, device=dev, rank=dist.rank, world=dist.world, tdist=dist.dist, match_batch=512)
+        o.upload_frames()
+        dist.barrier(); t0 = time.perf_counter()
+        o.run_all()
+        dist.sync(); wall = dist.max(time.perf_counter() - t0)
+        if dist.rank == 0:
+            s = o.summary(wall)
+            gt = run["gt"]
+            online_c5 = dict(metric="BASELINE config 5: %d node-pair jobs -> acceptance gate -> edge filter -> graph growing to %d nodes, re-optimised every 256 edges"
+                                    % (a.online_pairs, a.online_nodes),
+                             wall_s=round(wall, 3), pairs_per_s=round(s["pairs_per_s_wall"], 1), edges_per_s=round(s["edges_per_s_wall"], 1),
+                             edges_per_s_inside_optimize=round(s["edges_per_s_solver"], 1), solves=s["n_solves"],
+                             add_graph_ms_per_solve=round(s["add_graph_ms_per_solve"], 3), structure_ms_per_solve=round(s["structure_ms_per_solve"], 3),
+                             optimize_ms_per_solve=round(s["optimize_ms_per_solve"], 3), seconds=s["seconds"], feature_edges_accepted=s["feature_edges_accepted"],
+                             feature_edges_valid=s["feature_edges_valid"], pcg_iterations=s["pcg_iterations"], lm_iterations=s["lm_iterations"],
+                             not_converged=s["not_converged"],
+                             ate_dead_reckoning_m=round(float(np.linalg.norm(run["init"][:, :, 3] - gt[:, :, 3], axis=1).mean()), 3),
+                             ate_online_m=round(float(np.linalg.norm(o.poses[:, :, 3] - gt[:, :, 3], axis=1).mean()), 3),
+                             parallelism="pair jobs sharded over %d rank(s) per batch of 512, results gathered in job order; gate, filter and solver on rank 0, "
+                                         "the next batch's matching in flight during the solve" % dist.world,
+                             note="rebuild per re-optimise = add_graph (upload + flattening) + structure (gauge, block-CSR, hierarchy, graph capture)")
+        o.close()
+
     # ------------------------------------------------------------------ optional: config 4, one graph sharded over the ranks
     sharded_c4 = None
     if a.sharded and dist.world > 1:
-        import torch
-        import torch.distributed as td
-        from uzliti_slam_amd import sharded as sh
         g4 = synth.make_pose_graph(10000, 50000, seed=12345)
         p4 = capi.Pgo(device=dev)
-        p4.set_shard(dist.rank, dist.world, sh.make_rccl_allreduce(td, torch))
+        uid = capi.rccl_unique_id() if dist.rank == 0 else None
+        box = [uid]
+        dist.dist.broadcast_object_list(box, src=0)
+        p4.set_shard_rccl(dist.rank, dist.world, box[0])
         p4.add_graph(g4["nodes_pose"], g4["nodes_fixed"], g4["edges"])
 
         def c4_step():
             p4.reset()
             return p4.optimize(a.lm_iters)
         st4 = c4_step()
-        t4 = timed(dist, c4_step, max(1, a.steps // 5))
+        n4 = max(1, a.steps // 5)
+        t4 = timed(dist, c4_step, n4)
         sharded_c4 = dict(metric="SE(3) edges optimized/sec, one graph sharded over all ranks", unit="edges/s", scaling="strong",
-                          value=round(st4["n_edges"] * st4["iterations_done"] * max(1, a.steps // 5) / t4, 1),
-                          ms_per_solve=round(1e3 * t4 / max(1, a.steps // 5), 3), pcg_iterations_per_solve=st4["pcg_iterations"],
-                          exchange="1 all-reduce per PCG iteration + 3 per LM trial", chi2_final=st4["chi2_final"])
+                          value=round(st4["n_edges"] * st4["iterations_done"] * n4 / t4, 1),
+                          ms_per_solve=round(1e3 * t4 / n4, 3), pcg_iterations_per_solve=st4["pcg_iterations"],
+                          exchange="native RCCL: 1 all-reduce per PCG iteration + 3 per LM trial, on the solver's stream", exchange_calls=st4["exchange_calls"],
+                          chi2_final=st4["chi2_final"])
         p4.close()
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     cpu = None
     if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline:
         import oracle as O
-        fl = O.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
-        fixed, _ = O.set_fixed_nodes(fl["fixed"], fl["ij"])
-        t0 = time.perf_counter(); n_solves = 0; cpu_edges = 0
-        while True:
-            _, so = O.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=a.lm_iters)
-            n_solves += 1; cpu_edges += so["n_edges"] * so["iterations_done"]
-            if time.perf_counter() - t0 > a.cpu_seconds or n_solves >= 64:
-                break
-        dt = time.perf_counter() - t0
-        cpu = dict(value=round(cpu_edges / dt, 1), unit="edges/s", cores=1, kind="port",
+        ncpu = len(os.sched_getaffinity(0))
+        cb = cpu_pgo(O, g, a, a.cpu_seconds, [1, ncpu])
+        cpu = dict(value=cb[1]["value"], unit="edges/s", cores=1, kind="port",
                    sample="%d solve(s) of the same %d-node/%d-edge graph, %d LM iterations each, %.1f s; "
-                          "oracle = C restatement of g2o LM + block sparse direct Cholesky (reference binaries not buildable here)"
-                          % (n_solves, a.nodes, a.edges, a.lm_iters, dt),
-                   host_cpus=os.cpu_count())
+                          "oracle = C restatement of g2o LM + block sparse direct Cholesky (reference binaries not buildable here), gcc -O3 -march=native -fopenmp on this host"
+                          % (cb[1]["solves"], a.nodes, a.edges, a.lm_iters, cb[1]["seconds"]),
+                   all_cores=dict(value=cb[ncpu]["value"], cores=ncpu, note="OpenMP over the edges (g2o's own parallelism); the Cholesky is serial as CSparse is"),
+                   nproc=ncpu, cpu=cpu_model())
         if secondary is not None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            def one(k):
+                f, t, _ = pairs[k % len(pairs)]
+                O.estimate_edge([f], [t], ransac_threshold=0.1, ransac_iteration=a.hypotheses, break_percentage=1.0, do_prosac=True, seed=777, job_id=k)
             n_cpu_pairs = 0; t0 = time.perf_counter()
             while time.perf_counter() - t0 < a.cpu_seconds and n_cpu_pairs < 16384:
-                f, t, _ = pairs[n_cpu_pairs % len(pairs)]
-                O.estimate_edge([f], [t], ransac_threshold=0.1, ransac_iteration=a.hypotheses, break_percentage=1.0,
-                                do_prosac=True, seed=777, job_id=n_cpu_pairs)
-                n_cpu_pairs += 1
+                one(n_cpu_pairs); n_cpu_pairs += 1
             dtm = time.perf_counter() - t0
+            # all cores: one estimator thread per core over independent pairs (ctypes releases the GIL inside the C call)
+            n_all = max(ncpu * 4, int(n_cpu_pairs / max(dtm, 1e-9) * ncpu * min(a.cpu_seconds, 5.0)))
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(ncpu) as ex:
+                list(ex.map(one, range(n_all)))
+            dta = time.perf_counter() - t0
             secondary["cpu_baseline"] = dict(value=round(n_cpu_pairs / dtm, 2), unit="pairs/s", cores=1, kind="port",
-                                             sample="%d node pairs drawn cyclically from the same %d, %.1f s" % (n_cpu_pairs, len(pairs), dtm))
+                                             sample="%d node pairs drawn cyclically from the same %d, %.1f s" % (n_cpu_pairs, len(pairs), dtm),
+                                             all_cores=dict(value=round(n_all / dta, 2), cores=ncpu, sample="%d pairs over %d threads, %.1f s" % (n_all, ncpu, dta)))
 
     if dist.rank == 0:
         out = dict(
@@ -343,13 +515,15 @@ def main():
             config=dict(workload="%s: %d-node / %d-edge SE(3) pose graph, %d LM iterations, Huber(1) on loop closures; "
                                  "one independent graph per GPU" % (cfg_name, a.nodes, a.edges, a.lm_iters),
                         system_edges=st["n_edges"], lm_iterations_done=st["iterations_done"], lm_trials_per_solve=st["lm_trials"],
-                        pcg_iterations_per_solve=st["pcg_iterations"], preconditioner_builds_per_solve=st["precond_builds"], pcg_tol=pgo.cfg.pcg_tol, preconditioner=("multilevel, 8-vertex rigid-body aggregates (small graphs: dense level-1 operator, multiplicative cycle + 2 Newton-Schulz steps on the f64 matrix cores)" if pgo.cfg.preconditioner else "block-Jacobi"),
+                        pcg_iterations_per_solve=st["pcg_iterations"], preconditioner_builds_per_solve=st["precond_builds"], pcg_tol=pgo.cfg.pcg_tol,
+                        preconditioner=("multilevel, 8-vertex rigid-body aggregates (small graphs: dense level-1 operator, multiplicative cycle + 2 Newton-Schulz steps on the f64 matrix cores)" if pgo.cfg.preconditioner else "block-Jacobi"),
                         chi2_initial=st["chi2_initial"], chi2_final=st["chi2_final"]),
-            roofline=roofline, kernels_ms_per_solve=kernels_ms, cpu_baseline=cpu, secondary=secondary)
-        if formats is not None:
-            out["formats"] = formats
-        if sharded_c4 is not None:
-            out["sharded_c4"] = sharded_c4
+            h2d_ms=round(B["h2d_ms"], 3), d2h_ms=round(B["d2h_ms"], 3),
+            roofline=roofline, rooflines=rooflines, traffic_source=TRAFFIC_JSON + " (rocprofv3 --pmc passes of profiles/collect.sh on the default workloads; not measured in this run)",
+            kernels_ms_per_solve=kernels_ms, cpu_baseline=cpu, xy_only=xy_only, secondary=secondary)
+        for k, v in (("formats", formats), ("c4_1gpu", c4), ("online_c5", online_c5), ("sharded_c4", sharded_c4)):
+            if v is not None:
+                out[k] = v
         print(json.dumps(out))
     pgo.close()
     if matcher is not None:

@@ -323,6 +323,18 @@ typedef int (*uzl_allreduce_fn)(void* dev_ptr, int64_t count, void* hip_stream, 
 int  uzl_pgo_set_shard(uzl_pgo* h, int32_t rank, int32_t world_size,
                        uzl_allreduce_fn allreduce, void* user);
 
+/* The same exchange owned by the handle (SURVEY section 8b "Threading": the multi-GPU handle owns its RCCL communicator).
+ * One process per GPU; rank 0 creates an id with uzl_rccl_unique_id and hands the bytes to the other ranks by whatever channel the
+ * caller has (the reference's ROS parameter server, a file, MPI, torch.distributed ...); then EVERY rank calls
+ * uzl_pgo_set_shard_rccl with the same id (collective: returns when all world_size ranks have joined).  The handle then issues
+ * ncclAllReduce(sum, f64, in place) on its own HIP stream between its kernels - stream-ordered, no host synchronisation, no
+ * callback - and destroys the communicator in uzl_pgo_destroy (or when the shard setting changes).  librccl.so is loaded on the
+ * first call only (dlopen), so processes that never shard a graph do not pay for it.
+ *   id buffer: UZL_RCCL_UNIQUE_ID_BYTES bytes.  world_size 1 is allowed (every exchange step still runs: a one-GPU test of the path). */
+#define UZL_RCCL_UNIQUE_ID_BYTES 128
+int  uzl_rccl_unique_id(void* id_out, int32_t cap);
+int  uzl_pgo_set_shard_rccl(uzl_pgo* h, int32_t rank, int32_t world_size, const void* unique_id, int32_t id_bytes);
+
 /* ======================================================================================
  *  Edge filter  (TransformationFilter / EdgeCluster)
  *

@@ -81,6 +81,21 @@ def lib():
     return _lib
 
 
+_native = None
+
+
+def native_lib():
+    """The same C sources built on THIS machine with -O3 -march=native -fopenmp (oracle/Makefile target `native`): the CPU
+    baseline of bench.py.  Never used as a checker (the portable build is), never shipped (oracle/_native/ is ignored)."""
+    global _native
+    if _native is None:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native"])
+        _native = C.CDLL(os.path.join(_HERE, "_native", "libuzl_oracle_native.so"))
+        _native.uzlo_pgo_optimize.restype = C.c_int32
+        _native.uzlo_has_openmp.restype = C.c_int32
+    return _native
+
+
 def _p(a, t):
     return a.ctypes.data_as(t)
 
@@ -303,12 +318,17 @@ def set_fixed_nodes(fixed, ij):
     return f, c
 
 
-def pgo_optimize(poses, fixed, ij, meas, info, robust, iterations=20, huber_delta=1.0):
-    """G3-G9 on the flattened problem. Returns (poses_out (n,12), stats dict)."""
+def pgo_optimize(poses, fixed, ij, meas, info, robust, iterations=20, huber_delta=1.0, native_threads=None):
+    """G3-G9 on the flattened problem. Returns (poses_out (n,12), stats dict).
+    native_threads = k: run the -march=native / OpenMP baseline build with k threads over the edges (bench.py only)."""
     P = _f64(poses).reshape(-1, 12).copy(); f = _u8(fixed); ijc = _i32(ij).reshape(-1, 2)
     Z = _f64(meas).reshape(-1, 12); Om = _f64(info).reshape(-1, 36); rb = _u8(robust)
     st = PgoStats()
-    lib().uzlo_pgo_optimize(C.c_int32(P.shape[0]), _p(P, c_f64p), _p(f, c_u8p), C.c_int32(ijc.shape[0]),
+    L = lib()
+    if native_threads is not None:
+        L = native_lib()
+        L.uzlo_set_threads(C.c_int32(int(native_threads)))
+    L.uzlo_pgo_optimize(C.c_int32(P.shape[0]), _p(P, c_f64p), _p(f, c_u8p), C.c_int32(ijc.shape[0]),
                             _p(ijc, c_i32p), _p(Z, c_f64p), _p(Om, c_f64p), _p(rb, c_u8p),
                             C.c_double(huber_delta), C.c_int32(iterations), C.byref(st))
     return P, st.as_dict()

@@ -152,6 +152,11 @@ void uzlo_edge_error_norms(int32_t n, const double* poses, int32_t e, const int3
                            const double* meas, double* err);
 
 /* chi2 (activeRobustChi2) of the flattened problem */
+/* baseline builds only (oracle/Makefile target `native`, -fopenmp): threads over the edges as g2o does when built with OpenMP;
+ * the sparse Cholesky stays serial like CSparse.  Results do not depend on the thread count. */
+void    uzlo_set_threads(int32_t threads);
+int32_t uzlo_has_openmp(void);
+
 double uzlo_chi2(int32_t n, const double* poses, int32_t e, const int32_t* ij, const double* meas,
                  const double* info, const uint8_t* robust, double huber_delta);
 

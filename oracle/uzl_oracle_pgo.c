@@ -418,10 +418,35 @@ static void linearize_edge(const double* poses, const int32_t* ij, const double*
     if (want_jac) uzlo_edge_jacobians(Xi, Xj, Z, L->Ji, L->Jj);
 }
 
+/* Threads of the "all cores" baseline build (-fopenmp, oracle/Makefile target `native`): g2o parallelises over the edges
+ * (computeActiveErrors / linearizeOplus under OpenMP when built so) and leaves CSparse serial; the same split here.  Every
+ * per-edge quantity is computed in parallel and ACCUMULATED SERIALLY IN EDGE ORDER, so results are bit-identical to the
+ * single-thread build for any thread count. */
+static int g_threads = 1;
+void uzlo_set_threads(int32_t t) { g_threads = t > 0 ? t : 1; }
+int32_t uzlo_has_openmp(void)
+{
+#ifdef _OPENMP
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 double uzlo_chi2(int32_t n, const double* poses, int32_t e, const int32_t* ij, const double* meas,
                  const double* info, const uint8_t* robust, double huber_delta)
 {
     double s = 0;
+#ifdef _OPENMP
+    if (g_threads > 1 && e > 256) {
+        double* r0 = (double*)malloc(sizeof(double) * (size_t)e);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (int32_t k = 0; k < e; k++) { lin_t L; linearize_edge(poses, ij, meas, info, robust, huber_delta, k, 0, &L); r0[k] = L.rho0; }
+        for (int32_t k = 0; k < e; k++) s += r0[k];
+        free(r0);
+        return s;
+    }
+#endif
     lin_t L;
     for (int32_t k = 0; k < e; k++) { linearize_edge(poses, ij, meas, info, robust, huber_delta, k, 0, &L); s += L.rho0; }
     return s;
@@ -791,8 +816,16 @@ int32_t uzlo_pgo_optimize(int32_t n, double* poses, const uint8_t* fixed, int32_
         double current_chi = 0;
         lin_t L;
         double OJi[36], OJj[36], T[36];
+        lin_t* Lall = NULL;
+#ifdef _OPENMP
+        if (g_threads > 1 && e > 256) {                                  /* errors + Jacobians of all edges in parallel */
+            Lall = (lin_t*)malloc(sizeof(lin_t) * (size_t)e);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+            for (int32_t k = 0; k < e; k++) linearize_edge(poses, ij, meas, info, robust, huber_delta, k, 1, &Lall[k]);
+        }
+#endif
         for (int32_t k = 0; k < e; k++) {
-            linearize_edge(poses, ij, meas, info, robust, huber_delta, k, 1, &L);
+            if (Lall) L = Lall[k]; else linearize_edge(poses, ij, meas, info, robust, huber_delta, k, 1, &L);
             current_chi += L.rho0;
             const int32_t a = blk[ij[2 * k]], b = blk[ij[2 * k + 1]];
             double Oe[6];
@@ -814,6 +847,7 @@ int32_t uzlo_pgo_optimize(int32_t n, double* poses, const uint8_t* fixed, int32_
                 for (int q = 0; q < 36; q++) Ho[36 * (size_t)o + q] += T[q];
             }
         }
+        free(Lall);
         S.t_linearize_ms += now_ms() - tl;
         if (it == 0) {
             S.chi2_initial = current_chi;

@@ -251,6 +251,18 @@ def device_count():
     return lib().uzl_device_count()
 
 
+RCCL_UNIQUE_ID_BYTES = 128
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId through the library (rank 0); the bytes go to the other ranks by any channel."""
+    buf = (C.c_char * RCCL_UNIQUE_ID_BYTES)()
+    rc = lib().uzl_rccl_unique_id(buf, C.c_int32(RCCL_UNIQUE_ID_BYTES))
+    if rc != UZL_OK:
+        raise UzlError(rc, "uzl_rccl_unique_id")
+    return bytes(buf.raw)
+
+
 # --------------------------------------------------------------------------------------- estimator
 class Match:
     """Thin object wrapper over the uzl_match_* C ABI."""
@@ -466,6 +478,11 @@ class Pgo:
                     return -1
             self._shard_cb = ALLREDUCE_FN(_cb)
         self._check(lib().uzl_pgo_set_shard(self._h, C.c_int32(rank), C.c_int32(world), self._shard_cb, None))
+
+    def set_shard_rccl(self, rank, world, unique_id):
+        """Native exchange: the handle owns the RCCL communicator (collective call: every rank, same id from rccl_unique_id())."""
+        buf = (C.c_char * RCCL_UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._check(lib().uzl_pgo_set_shard_rccl(self._h, C.c_int32(rank), C.c_int32(world), buf, C.c_int32(RCCL_UNIQUE_ID_BYTES)))
 
     def optimize(self, iterations=0):
         st = PgoStats()

@@ -499,10 +499,9 @@ __device__ __forceinline__ void diag6(const MlLevel& F, int i, double lambda, do
 }
 
 // AP[i][p] = sum_j A_ij P_j over the children j of level-2 aggregate p
-__global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev* __restrict__ mlp)
+__global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
-    const int cl = ml.comp_level;                     // level of the dense operator: 1 (small graphs) or 2 (AGG = 4)
     const MlLevel& F = ml.lv[cl];
     const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan;
     const int t = blockIdx.x * kBlk + threadIdx.x;
@@ -518,7 +517,7 @@ __global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev*
         pmat6(F.geo + (size_t)i * 3, Pm);
         mm6_acc(Dm, 6, Pm, 6, acc, 1.);
     }
-    for (int s = ml.grp_beg[t]; s < ml.grp_end[t]; s++) {              // the slots of row i whose column is a child of p
+    for (int s = ml.grp_beg[cl][t]; s < ml.grp_end[cl][t]; s++) {              // the slots of row i whose column is a child of p
         pmat6(F.geo + (size_t)F.col[s] * 3, Pm);
         mm6_acc(F.blk + (size_t)s * 36, 6, Pm, 6, acc, 1.);
     }
@@ -528,10 +527,9 @@ __global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev*
 }
 
 // Q[i][p] = P_i [p == parent(i)] - sum_{j in siblings(i)} S_ij AP[j][p]          (one lane per block ROW: 6x the lanes)
-__global__ __launch_bounds__(kBlk) void ml_mult_q_kernel(const MlDev* __restrict__ mlp)
+__global__ __launch_bounds__(kBlk) void ml_mult_q_kernel(const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
-    const int cl = ml.comp_level;                     // level of the dense operator: 1 (small graphs) or 2 (AGG = 4)
     const MlLevel& F = ml.lv[cl];
     const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
     const int tt = blockIdx.x * kBlk + threadIdx.x;
@@ -562,10 +560,9 @@ __global__ __launch_bounds__(kBlk) void ml_mult_q_kernel(const MlDev* __restrict
 }
 
 // QY[i][p] = sum_p' Q[i][p'] Y_2[p'][p]                                           (one lane per block row)
-__global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restrict__ mlp)
+__global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
-    const int cl = ml.comp_level;
     const int n = ml.lv[cl].n, np = ml.lv[cl + 1].n, np6 = 6 * np;
     const int tt = blockIdx.x * kBlk + threadIdx.x;
     if (tt >= n * np * 6) return;
@@ -580,10 +577,9 @@ __global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restric
 }
 
 // AS[j][i'] = sum_{j' in siblings(i')} A_jj' S_j'i'
-__global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev* __restrict__ mlp)
+__global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
-    const int cl = ml.comp_level;                     // level of the dense operator: 1 (small graphs) or 2 (AGG = 4)
     const MlLevel& F = ml.lv[cl];
     const int n = F.n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
     const int t = blockIdx.x * kBlk + threadIdx.x;
@@ -600,7 +596,7 @@ __global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev*
         mm6_acc(Dm, 6, W + (size_t)((j % fan) * 6) * m, m, acc, 1.);
     }
     const int np = ml.lv[cl + 1].n;
-    for (int s = ml.grp_beg[(size_t)j * np + gp]; s < ml.grp_end[(size_t)j * np + gp]; s++)
+    for (int s = ml.grp_beg[cl][(size_t)j * np + gp]; s < ml.grp_end[cl][(size_t)j * np + gp]; s++)
         mm6_acc(F.blk + (size_t)s * 36, 6, W + (size_t)((F.col[s] % fan) * 6) * m, m, acc, 1.);
     double* o = ml.mAS + (size_t)t * 36;
 #pragma unroll
@@ -608,10 +604,9 @@ __global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev*
 }
 
 // Y_1[i][i'] = 2 S_ii' - sum_{j in siblings(i)} S_ij AS[j][i'] + sum_p QY[i][p] Q[i'][p]^T
-__global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restrict__ mlp)
+__global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
-    const int cl = ml.comp_level;                     // level of the dense operator: 1 (small graphs) or 2 (AGG = 4)
     const MlLevel& F = ml.lv[cl];
     const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
     // one 64-lane workgroup per (group, group') tile of fan x fan blocks: the tile's rows of QY / Q / AS are shared
@@ -654,13 +649,12 @@ __global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restri
 // one workgroup per (row block i, 256 columns): the row's 6x6 blocks go through LDS once (broadcast reads), every lane owns
 // one column of X and walks the row's neighbours (X rows are read coalesced across the lanes)
 constexpr int kAxChunk = 16;          // off-diagonal blocks staged per pass
-__global__ __launch_bounds__(kBlk) void ml_ns_ax_kernel(PgoDev D, const MlDev* __restrict__ mlp, const double* __restrict__ X,
+__global__ __launch_bounds__(kBlk) void ml_ns_ax_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl, const double* __restrict__ X,
                                                        double* __restrict__ T)
 {
     __shared__ double sb[(kAxChunk + 1) * 36];
     __shared__ int sc[kAxChunk + 1];
     const MlDev& ml = *mlp;
-    const int cl = ml.comp_level;                     // level of the dense operator: 1 (small graphs) or 2 (AGG = 4)
     const MlLevel& F = ml.lv[cl];
     const int n6 = 6 * F.n;
     const int i = blockIdx.x, c = blockIdx.y * kBlk + threadIdx.x, tid = threadIdx.x;
@@ -1561,23 +1555,25 @@ void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s)
 {
     hipLaunchKernelGGL(ml_dense_level_kernel, dim3((n_l * n_l + kBlk - 1) / kBlk), dim3(kBlk), 0, s, ml, l);
 }
-void k_ml_mult_level1(const PgoDev& D, const MlDev* ml, int n1, int n2, hipStream_t s)
+void k_ml_mult_level(const PgoDev& D, const MlDev* ml, int lev, int n1, int n2, hipStream_t s)
 {
     const int g12 = (n1 * n2 + kBlk - 1) / kBlk, g11 = (n1 * n1 + kBlk - 1) / kBlk;
-    hipLaunchKernelGGL(ml_mult_ap_kernel, dim3(g12), dim3(kBlk), 0, s, D, ml);
-    hipLaunchKernelGGL(ml_mult_as_kernel, dim3(g11), dim3(kBlk), 0, s, D, ml);
+    hipLaunchKernelGGL(ml_mult_ap_kernel, dim3(g12), dim3(kBlk), 0, s, D, ml, lev);
+    hipLaunchKernelGGL(ml_mult_as_kernel, dim3(g11), dim3(kBlk), 0, s, D, ml, lev);
     const int g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk;
-    hipLaunchKernelGGL(ml_mult_q_kernel, dim3(g12r), dim3(kBlk), 0, s, ml);
-    hipLaunchKernelGGL(ml_mult_qy_kernel, dim3(g12r), dim3(kBlk), 0, s, ml);
-    hipLaunchKernelGGL(ml_mult_final_kernel, dim3(n2 * n2), dim3(64), 0, s, ml);
+    hipLaunchKernelGGL(ml_mult_q_kernel, dim3(g12r), dim3(kBlk), 0, s, ml, lev);
+    hipLaunchKernelGGL(ml_mult_qy_kernel, dim3(g12r), dim3(kBlk), 0, s, ml, lev);
+    hipLaunchKernelGGL(ml_mult_final_kernel, dim3(n2 * n2), dim3(64), 0, s, ml, lev);
 }
-// one Newton-Schulz step: Xn = 2 X - X (A_1 X); T is scratch
-void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int n1, const double* X, double* T, double* Xn, hipStream_t s)
+// one Newton-Schulz step at level `lev`: Xn = 2 X - X (A_lev X); T is scratch
+void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int lev, int n1, const double* X, double* T, double* Xn, hipStream_t s,
+                  hipEvent_t ev_a, hipEvent_t ev_b)
 {
     const int n6 = 6 * n1;
-    hipLaunchKernelGGL(ml_ns_ax_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, X, T);
+    hipLaunchKernelGGL(ml_ns_ax_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, lev, X, T);
     const int g = (n6 + kGemmTile - 1) / kGemmTile;
-    hipLaunchKernelGGL(ml_ns_gemm_kernel, dim3(g, g), dim3(256), 0, s, n6, X, T, Xn);
+    if (ev_a) hipExtLaunchKernelGGL(ml_ns_gemm_kernel, dim3(g, g), dim3(256), 0, s, ev_a, ev_b, 0, n6, X, T, Xn);     // dispatch timestamps of the GEMM alone
+    else hipLaunchKernelGGL(ml_ns_gemm_kernel, dim3(g, g), dim3(256), 0, s, n6, X, T, Xn);
 }
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s)
 {

@@ -104,8 +104,9 @@ struct MlDev {
     double* tmpG;              // [max n][36]
     double* tmpM;              // [max n][36]
     double* top_inv;           // [(6 n_top)^2] dense inverse of A_L(lambda)
-    const int32_t* grp_beg;    // composite path: [n_1][n_2] first / one-past-last slot of level-1 row i whose column lies in
-    const int32_t* grp_end;    // level-2 aggregate p (slots of a row are sorted by column, so the range is contiguous)
+    const int32_t* grp_beg[kMlMaxLevels + 1];   // composite path, levels comp_level .. L-1: [n_l][n_{l+1}] first / one-past-last slot of
+    const int32_t* grp_end[kMlMaxLevels + 1];   // level-l row i whose column lies in level-(l+1) aggregate p (slots of a row are sorted by
+                                                // column, so the range is contiguous)
     double* mAP; double* mQ; double* mQY;   // composite path, level 1: [n_1][n_2][36] scratch of the multiplicative operator
     double* mAS;               // [n_1][n_1][36]
     double* nsT; double* nsX;   // composite path: (6 n_1)^2 scratch of the Newton-Schulz refinement of Y_1
