@@ -231,6 +231,33 @@ def estimate_edge(frames_from, frames_to, ransac_threshold=0.2, ransac_iteration
                 corr_query=cq[:m].copy(), corr_train=ct[:m].copy(), corr_dist=cd[:m].copy(), mask=mk[:m].copy())
 
 
+def set_vote_recipe(recipe):
+    """0 = fused (default, = the HIP kernels), 1 = the reference build's unfused evaluation order.  Process-global; tests only."""
+    lib().uzlo_set_vote_recipe(C.c_int32(int(recipe)))
+
+
+def vote_recipe_diff(P, Q, max_error, iterations, do_prosac=True, seed=0, job_id=0):
+    """(tests, differing verdicts, smallest |distance - threshold|) over every hypothesis of a PROSAC run, both recipes."""
+    Pc = _f64(np.asarray(P).T); Qc = _f64(np.asarray(Q).T)
+    nt = C.c_int64(); nd = C.c_int64(); mm = C.c_double()
+    lib().uzlo_vote_recipe_diff(_p(Pc, c_f64p), _p(Qc, c_f64p), C.c_int32(Pc.shape[0]), C.c_double(max_error), C.c_int32(iterations),
+                                C.c_int32(1 if do_prosac else 0), C.c_uint64(seed), C.c_uint64(job_id), C.byref(nt), C.byref(nd), C.byref(mm))
+    return nt.value, nd.value, mm.value
+
+
+def estimate_edge_batch(pairs, ransac_threshold=0.2, ransac_iteration=100, break_percentage=0.6, do_prosac=True, seed=0,
+                        job_id0=0, threads=1, native=True):
+    """bench.py's all-core matching baseline: pairs = [(frame_from, frame_to), ...], `threads` estimator threads inside the
+    -march=native / OpenMP build.  Returns (ok, consensus) arrays."""
+    af, k1 = _mk_frames([p[0] for p in pairs]); at, k2 = _mk_frames([p[1] for p in pairs])
+    res = (EdgeResult * len(pairs))()
+    L = native_lib() if native else lib()
+    L.uzlo_estimate_edge_batch(C.c_int32(len(pairs)), af, at, C.c_double(ransac_threshold), C.c_int32(ransac_iteration),
+                               C.c_double(break_percentage), C.c_int32(1 if do_prosac else 0), C.c_uint64(seed), C.c_uint64(job_id0),
+                               C.c_int32(threads), res)
+    return np.array([r.ok for r in res]), np.array([r.consensus for r in res])
+
+
 # ------------------------------------------------------------------ pose-graph half
 def quat_from_R(R):
     q = np.empty(4); lib().uzlo_quat_from_R(_p(_f64(R).reshape(9), c_f64p), _p(q, c_f64p)); return q

@@ -90,6 +90,19 @@ void uzlo_estimate_edge(const uzlo_frame* from, int32_t n_from, const uzlo_frame
                         uzlo_edge_result* res, int32_t max_corr,
                         int32_t* corr_query, int32_t* corr_train, int32_t* corr_dist, uint8_t* mask);
 
+/* Vote recipe of consensus3D: 0 = fused (default; what the HIP kernels compute), 1 = the reference build's unfused order
+ * (uzl_oracle_match.c, "Vote recipes").  Process-global: tests only. */
+void uzlo_set_vote_recipe(int32_t recipe);
+void uzlo_vote_recipe_diff(const double* P, const double* Q, int32_t m, double max_error, int32_t iterations, int32_t do_prosac,
+                           uint64_t seed, uint64_t job_id, int64_t* n_tests, int64_t* n_diff, double* min_margin);
+
+/* Baseline builds only (-fopenmp): n_pairs independent single-frame pairs, `threads` estimator threads (the reference runs one
+ * estimator thread per plugin instance; "all cores" = one instance per core).  Pair k uses frames from[k] / to[k], job id
+ * job_id0 + k; results[k] as uzlo_estimate_edge leaves them.  Without OpenMP the loop is serial. */
+void uzlo_estimate_edge_batch(int32_t n_pairs, const uzlo_frame* from, const uzlo_frame* to,
+                              double ransac_threshold, int32_t ransac_iteration, double break_percentage,
+                              int32_t do_prosac, uint64_t seed, uint64_t job_id0, int32_t threads, uzlo_edge_result* results);
+
 /* ---------------- pose-graph half ---------------- */
 
 /* in-tree g2o excerpt: graph_slam_common/thirdparty/src/isometry3d_mappings.cpp */

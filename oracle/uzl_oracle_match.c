@@ -287,15 +287,61 @@ void uzlo_pose_svd(const double* P, const double* Q, const int32_t* idx, int32_t
 /* ------------------------------------------------------------------------------------------
  * M8  consensus3D (:337-347): P' = T*[P;1]; set[i] = ||P'_i - Q_i|| < thresh (double, strict).
  * ------------------------------------------------------------------------------------------ */
-static inline double point_dist(const double* p, const double* q, const double T[12])
+/* Vote recipes.  0 (default, the one the HIP kernels repeat operation for operation): fused multiply-adds, innermost first.
+ * 1 = the reference binary's evaluation: its package is built with -msse2 -msse3 -mssse3 -O3 (transformation_estimation/
+ * CMakeLists.txt:9, no FMA), Eigen 3.2 evaluates `T * P.colwise().homogeneous()` as linear() * P (3 x 3 times 3 x M through the
+ * general product: acc += R(r,k) * p(k) for k = 0, 1, 2, every product and sum rounded) and then adds the translation;
+ * `(P - Q).colwise().norm()` is sqrt((dx*dx + dy*dy) + dz*dz).  The two differ by an ulp or two of the distance, i.e. only a
+ * point within ~1e-17 m of the threshold can vote differently; tests/test_oracle_match.py counts how often that happens. */
+static int g_vote_recipe = 0;
+void uzlo_set_vote_recipe(int32_t r) { g_vote_recipe = r; }
+
+static inline double point_dist_fused(const double* p, const double* q, const double T[12])
 {
-    /* fused multiply-adds, innermost first (this build's recipe, repeated by the HIP kernels operation for
-     * operation; the reference leaves the evaluation order of T * P to Eigen / the compiler) */
     double x = fma(T[0], p[0], fma(T[1], p[1], fma(T[2], p[2], T[3])));
     double y = fma(T[4], p[0], fma(T[5], p[1], fma(T[6], p[2], T[7])));
     double z = fma(T[8], p[0], fma(T[9], p[1], fma(T[10], p[2], T[11])));
     double dx = x - q[0], dy = y - q[1], dz = z - q[2];
     return sqrt(fma(dx, dx, fma(dy, dy, dz * dz)));
+}
+static inline double point_dist_reference_order(const double* p, const double* q, const double T[12])
+{
+    /* -ffp-contract=off: none of this is fused */
+    double x = ((T[0] * p[0] + T[1] * p[1]) + T[2] * p[2]) + T[3];
+    double y = ((T[4] * p[0] + T[5] * p[1]) + T[6] * p[2]) + T[7];
+    double z = ((T[8] * p[0] + T[9] * p[1]) + T[10] * p[2]) + T[11];
+    double dx = x - q[0], dy = y - q[1], dz = z - q[2];
+    return sqrt((dx * dx + dy * dy) + dz * dz);
+}
+static inline double point_dist(const double* p, const double* q, const double T[12])
+{
+    return g_vote_recipe ? point_dist_reference_order(p, q, T) : point_dist_fused(p, q, T);
+}
+
+/* Every hypothesis of a PROSAC run (no early exit) voted under both recipes: number of (hypothesis, point) tests and of tests
+ * whose verdict differs; min_margin = the smallest | distance - threshold | met (fused recipe). */
+void uzlo_vote_recipe_diff(const double* P, const double* Q, int32_t m, double max_error, int32_t iterations, int32_t do_prosac,
+                           uint64_t seed, uint64_t job_id, int64_t* n_tests, int64_t* n_diff, double* min_margin)
+{
+    int64_t nt = 0, nd = 0;
+    double mm = 1e300;
+    if (m >= 3) {
+        for (int32_t i = 0; i < iterations; i++) {
+            int32_t s[3];
+            double Tt[12];
+            uzlo_sample3(seed, job_id, i, iterations, m, do_prosac, s);
+            uzlo_pose_svd(P, Q, s, 3, Tt);
+            for (int32_t k = 0; k < m; k++) {
+                const double a = point_dist_fused(P + 3 * (size_t)k, Q + 3 * (size_t)k, Tt);
+                const double b = point_dist_reference_order(P + 3 * (size_t)k, Q + 3 * (size_t)k, Tt);
+                nd += (a < max_error) != (b < max_error);
+                const double g = fabs(a - max_error);
+                if (g < mm) mm = g;
+                nt++;
+            }
+        }
+    }
+    *n_tests = nt; *n_diff = nd; *min_margin = mm;
 }
 
 int32_t uzlo_consensus3d(const double* P, const double* Q, int32_t m, const double T[12],
@@ -440,4 +486,18 @@ void uzlo_estimate_edge(const uzlo_frame* from, int32_t n_from, const uzlo_frame
         free(mk); free(Xd);
     }
     free(bq);
+}
+
+
+void uzlo_estimate_edge_batch(int32_t n_pairs, const uzlo_frame* from, const uzlo_frame* to,
+                              double ransac_threshold, int32_t ransac_iteration, double break_percentage,
+                              int32_t do_prosac, uint64_t seed, uint64_t job_id0, int32_t threads, uzlo_edge_result* results)
+{
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1)
+#endif
+    for (int32_t k = 0; k < n_pairs; k++)
+        uzlo_estimate_edge(from + k, 1, to + k, 1, ransac_threshold, ransac_iteration, break_percentage, do_prosac, seed,
+                           job_id0 + (uint64_t)k, results + k, 0, NULL, NULL, NULL, NULL);
 }

@@ -119,3 +119,33 @@ def test_full_size_run_properties(capi, full_run):
     dt, dr = synth.pose_errors(fresh.store()[0].reshape(-1, 3, 4), a.poses)
     assert dt < 1e-3 and dr < 1e-4, (dt, dr)
     fresh.close(); a.close(); b.close()
+
+
+def test_two_ranks_equal_one_rank(capi, tmp_path):
+    """Multi-process path of config 5: torchrun, 2 ranks (both on cuda:0 of the one-GPU box, gloo for the result gather): pair jobs
+    sharded per batch, gate / filter / solver on rank 0.  Outcome must be identical to the one-rank run, bit for bit."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    n_nodes, n_pairs, n_kp = 1200, 300, 200
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "two_ranks.npz")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(here, "_online_worker.py"), out, str(n_nodes), str(n_pairs), str(n_kp)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("ONLINE_OK world=2") == 2
+    z = np.load(out)
+    run = synth.make_online_run(n_nodes, n_pairs, n_kp=n_kp)
+    o = online.OnlineSlam(run, match_batch=300, lm_iterations=6, match_cfg=dict(ransac_iteration=100))
+    o.upload_frames()
+    o.run_all()
+    assert np.array_equal(z["consensus"], o.results["consensus"]) and np.array_equal(z["T"], o.results["T"])
+    assert np.array_equal(z["accept"], np.array(o.accept_log)) and np.array_equal(z["f_key"], o.f_key) and np.array_equal(z["f_sticky"], o.f_sticky)
+    assert np.array_equal(z["poses"], o.poses)
+    assert len(o.solves) >= 4 and int(o.f_sticky.sum()) > 0
+    o.close()

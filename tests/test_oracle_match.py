@@ -187,3 +187,43 @@ def test_estimate_edge_pipeline_vs_numpy_stages(oracle):
     small = dict(f, desc=f["desc"][:6], pos=f["pos"][:, :6], valid=f["valid"][:6])
     r0 = oracle.estimate_edge([small], [t])
     assert r0["ok"] == 0 and r0["consensus"] == 0 and r0["frame_from"] == -1
+
+
+def test_vote_recipe_fused_vs_reference_order(oracle):
+    """The consensus test is evaluated with fused multiply-adds (oracle = HIP kernels); the reference binary is built without FMA
+    (transformation_estimation/CMakeLists.txt:9) and Eigen evaluates T * P as (R p) + t.  This test quantifies the difference on
+    BASELINE config 3's workload (128 of its 512 pairs here; the full 512 run in tests/diag/vote_recipe_c3.py) and on the golden
+    fixture: every (hypothesis, point) vote under both recipes, and the final edge (mask, consensus, transform, mse) of the
+    whole estimator under both.  Votes may differ only for a point within rounding of the threshold; none does."""
+    import os
+    from uzliti_slam_amd import synth
+    pairs = synth.make_pairs(128, n_kp=1000, seed=777)
+    tests = diffs = 0
+    margin = 1e300
+    try:
+        for j, (f, t, _) in enumerate(pairs):
+            oracle.set_vote_recipe(0)
+            a = oracle.estimate_edge([f], [t], ransac_threshold=0.1, ransac_iteration=500, break_percentage=1.0, do_prosac=True, seed=777, job_id=j)
+            P = t["pos"][:, a["corr_query"]]; Q = f["pos"][:, a["corr_train"]]
+            nt, nd, mm = oracle.vote_recipe_diff(P, Q, 0.1, 500, True, 777, j)
+            tests += nt; diffs += nd; margin = min(margin, mm)
+            oracle.set_vote_recipe(1)
+            b = oracle.estimate_edge([f], [t], ransac_threshold=0.1, ransac_iteration=500, break_percentage=1.0, do_prosac=True, seed=777, job_id=j)
+            assert np.array_equal(a["mask"], b["mask"]) and a["consensus"] == b["consensus"] and a["best_iteration"] == b["best_iteration"]
+            assert np.array_equal(a["T"], b["T"])
+            # the mean inlier distance (and the information matrix scaled by it, :133-137) differs by rounding of the distances; nothing else does
+            assert abs(a["mse"] - b["mse"]) <= 1e-14 * abs(a["mse"]) and np.allclose(a["information"], b["information"], rtol=1e-14, atol=0)
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "match_3pairs.npz"))
+        for j in range(int(z["n_pairs"])):
+            fr = dict(desc=z[f"p{j}_from_desc"], pos=z[f"p{j}_from_pos"], valid=z[f"p{j}_from_valid"])
+            to = dict(desc=z[f"p{j}_to_desc"], pos=z[f"p{j}_to_pos"], valid=z[f"p{j}_to_valid"])
+            kw = dict(ransac_threshold=float(z["ransac_threshold"]), ransac_iteration=int(z["ransac_iteration"]),
+                      break_percentage=float(z["break_percentage"]), do_prosac=True, seed=int(z["seed"]), job_id=10 + j)
+            oracle.set_vote_recipe(1)
+            b = oracle.estimate_edge([fr], [to], **kw)
+            assert np.array_equal(b["mask"], z[f"p{j}_mask"]) and np.array_equal(b["T"], z[f"p{j}_T"])      # the fixture holds under the reference order too
+    finally:
+        oracle.set_vote_recipe(0)
+    assert tests > 4e7
+    assert diffs == 0, (diffs, tests)
+    assert margin > 1e-13            # the closest any point came to the threshold: orders of magnitude above the recipes' ~1e-17 m difference
