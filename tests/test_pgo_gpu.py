@@ -393,3 +393,40 @@ def test_chain_like_graphs(capi, oracle, n, e, its):
         _check(p, oracle, synth.make_pose_graph(n // 2, e // 2 + 20, seed=5), iterations=its)
     finally:
         p.close()
+
+
+def test_vertex_order_does_not_matter(capi, oracle):
+    """The aggregates of the preconditioner are 8 consecutive blocks of an order derived from the graph (heaviest-edge chains,
+    uzl_pgo.hip aggregation_order), not of the node index: renumbered nodes, two sessions with interleaved ids (merged / global-scope
+    graphs, graph_slam_node.cpp:401-576) and graphs without an odometry chain must solve to the oracle's result with iteration
+    counts close to the time-ordered case (with index-order aggregates they were 7x / 4-6x higher)."""
+    n, e, its = 1000, 5000, 10
+    g = synth.make_pose_graph(n, e)
+    p = capi.Pgo()
+    try:
+        st_nat, _ = _check(p, oracle, g, iterations=its)
+        rng = np.random.default_rng(1)
+        perm = rng.permutation(n)
+        st_perm, _ = _check(p, oracle, synth.permute_graph(g, perm), iterations=its)
+        st_rev, _ = _check(p, oracle, synth.permute_graph(g, np.arange(n)[::-1].copy()), iterations=its)
+        st_two, _ = _check(p, oracle, synth.interleave_sessions(synth.make_pose_graph(n // 2, e // 2, seed=1), synth.make_pose_graph(n // 2, e // 2, seed=2)),
+                           iterations=its)
+        base = st_nat["pcg_iterations"]
+        assert st_perm["pcg_iterations"] <= 1.25 * base and st_rev["pcg_iterations"] <= 1.25 * base and st_two["pcg_iterations"] <= 1.5 * base, \
+            (base, st_perm["pcg_iterations"], st_rev["pcg_iterations"], st_two["pcg_iterations"])
+        # the permuted solve is the SAME problem: same chi2 trajectory end point, poses equal after un-permuting
+        p.add_graph(**{k: v for k, v in zip(("nodes_pose", "nodes_fixed", "edges"), (g["nodes_pose"], g["nodes_fixed"], g["edges"]))})
+        p.optimize(its); P0 = p.store()[0]
+        gp = synth.permute_graph(g, perm)
+        p.add_graph(gp["nodes_pose"], gp["nodes_fixed"], gp["edges"])
+        p.optimize(its); P1 = p.store()[0]
+        dt, dr = synth.pose_errors(P1[perm].reshape(-1, 3, 4), P0.reshape(-1, 3, 4))
+        assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+        # no odometry chain at all / a broken one: harder systems (weaker coupling), still the oracle's answer, bounded iteration counts
+        st_no, _ = _check(p, oracle, synth.drop_odometry(g), iterations=20)
+        st_5, _ = _check(p, oracle, synth.drop_odometry(g, keep_every=5), iterations=20)
+        assert st_no["n_gauge_fixed"] > 0                                    # components without a fixed node got their gauge
+        assert st_no["pcg_iterations"] / st_no["lm_trials"] < 200 and st_5["pcg_iterations"] / st_5["lm_trials"] < 320, \
+            (st_no["pcg_iterations"], st_no["lm_trials"], st_5["pcg_iterations"], st_5["lm_trials"])
+    finally:
+        p.close()

@@ -105,6 +105,7 @@ struct uzl_pgo {
     std::vector<int32_t> ij;       // system edges, 2 per edge
     std::vector<int32_t> src;      // system edge -> input edge
     std::vector<uint8_t> robust;
+    std::vector<double> edge_w;    // trace of each system edge's information matrix: the coupling strength the aggregation order follows
     bool have_graph = false, structure_ready = false;
     int32_t n_gauge = 0;
     // ---- device
@@ -577,16 +578,68 @@ void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool tim
     }
 }
 
+// Order of the free vertices in the block system.  The multilevel preconditioner aggregates 8 CONSECUTIVE blocks, which is only a
+// good coarse space when consecutive blocks are strongly coupled.  In a single session the node ids are time-ordered (std::map
+// order = trajectory order, graph_slam_node.cpp:294) and the index order is already that; in merged / global-scope graphs
+// (graph_slam_node.cpp:401-576, 665-777: ids of several sessions interleave) or graphs without an odometry chain it is not, and
+// the PCG iteration count grows 4-7x (tests/diag/vertex_order.py).  So the order is computed from the graph: starting at the
+// lowest-index unvisited free vertex, follow the heaviest edge (trace of the information matrix; odometry edges are the stiff
+// ones) to an unvisited free vertex until stuck, then extend the same chain backwards from the start; repeat.  Ties go to the lower
+// index.  A time-ordered single-session graph comes out in index order (nothing changes for it); O(N + E), deterministic.
+std::vector<int32_t> aggregation_order(const uzl_pgo* h)
+{
+    const int n = h->n, e = h->e;
+    std::vector<int32_t> ptr((size_t)n + 1, 0);
+    auto is_free = [&](int v) { return !h->fixed_eff[v]; };
+    for (int k = 0; k < e; k++) {
+        const int a = h->ij[2 * k], b = h->ij[2 * k + 1];
+        if (is_free(a) && is_free(b)) { ptr[a + 1]++; ptr[b + 1]++; }
+    }
+    for (int v = 0; v < n; v++) ptr[v + 1] += ptr[v];
+    std::vector<int32_t> nbr((size_t)std::max(ptr[n], 1));
+    std::vector<double> wgt((size_t)std::max(ptr[n], 1));
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    const bool have_w = h->edge_w.size() == (size_t)e;
+    for (int k = 0; k < e; k++) {
+        const int a = h->ij[2 * k], b = h->ij[2 * k + 1];
+        if (!(is_free(a) && is_free(b))) continue;
+        const double w = have_w ? h->edge_w[k] : 1.;
+        nbr[fill[a]] = b; wgt[fill[a]++] = w;
+        nbr[fill[b]] = a; wgt[fill[b]++] = w;
+    }
+    std::vector<uint8_t> seen((size_t)std::max(n, 1), 0);
+    std::vector<int32_t> order, back;
+    order.reserve((size_t)n);
+    auto next_of = [&](int v) {
+        int best = -1; double bw = -1.;
+        for (int q = ptr[v]; q < ptr[v + 1]; q++) {
+            const int u = nbr[q];
+            if (seen[u]) continue;
+            if (wgt[q] > bw || (wgt[q] == bw && u < best)) { bw = wgt[q]; best = u; }
+        }
+        return best;
+    };
+    for (int start = 0; start < n; start++) {
+        if (!is_free(start) || seen[start]) continue;
+        const size_t first = order.size();
+        for (int v = start; v >= 0; v = next_of(v)) { seen[v] = 1; order.push_back(v); }
+        back.clear();
+        for (int v = next_of(start); v >= 0; v = next_of(v)) { seen[v] = 1; back.push_back(v); }
+        if (!back.empty()) {                                     // chain = reverse(back) + forward part
+            order.insert(order.begin() + (std::ptrdiff_t)first, back.rbegin(), back.rend());
+        }
+    }
+    return order;
+}
+
 void destroy_pcg_graph(uzl_pgo* h);
 void build_structure(uzl_pgo* h)
 {
     destroy_pcg_graph(h);
     const int n = h->n, e = h->e;
-    std::vector<int32_t> v2b((size_t)std::max(n, 1)), b2v;
-    int nb = 0;
-    for (int v = 0; v < n; v++) {
-        if (h->fixed_eff[v]) v2b[v] = -1; else { v2b[v] = nb++; b2v.push_back(v); }
-    }
+    std::vector<int32_t> v2b((size_t)std::max(n, 1), -1), b2v = aggregation_order(h);
+    const int nb = (int)b2v.size();
+    for (int b = 0; b < nb; b++) v2b[b2v[b]] = b;
     h->nb = nb;
     std::vector<int32_t> row_ptr((size_t)nb + 1, 0);
     for (int k = 0; k < e; k++) {
@@ -1066,7 +1119,7 @@ int uzl_pgo_add_graph(uzl_pgo* h, int32_t n_nodes, const uzl_node* nodes, int32_
     h->fixed_in.assign((size_t)n_nodes, 0);
     for (int v = 0; v < n_nodes; v++) h->fixed_in[v] = nodes[v].fixed ? 1 : 0;
     // skip rules; odometry edges are added while iterating (:78-79), filtered feature edges after (:100-103)
-    h->ij.clear(); h->src.clear(); h->robust.clear();
+    h->ij.clear(); h->src.clear(); h->robust.clear(); h->edge_w.clear();
     for (int pass = 0; pass < 2; pass++) {
         for (int k = 0; k < n_edges; k++) {
             const uzl_edge& ed = edges[k];
@@ -1082,6 +1135,7 @@ int uzl_pgo_add_graph(uzl_pgo* h, int32_t n_nodes, const uzl_node* nodes, int32_
             }
             h->ij.push_back(ed.from); h->ij.push_back(ed.to);
             h->src.push_back(k);
+            { double tr = 0.; for (int r = 0; r < 6; r++) tr += ed.information[r * 7]; h->edge_w.push_back(tr); }
             h->robust.push_back(odom ? 0 : 1);                                                     // Huber on feature edges (:292-294)
         }
     }
@@ -1126,6 +1180,8 @@ int uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t*
     h->robust.assign(robust, robust + e);
     h->src.resize((size_t)e);
     std::iota(h->src.begin(), h->src.end(), 0);
+    h->edge_w.resize((size_t)e);
+    for (int k = 0; k < e; k++) { double tr = 0.; for (int r = 0; r < 6; r++) tr += info[36 * (size_t)k + r * 7]; h->edge_w[k] = tr; }
     alloc_problem(h);
     hipStream_t s = h->stream;
     const size_t stage = (size_t)std::max(n, 1) * 12 + (size_t)std::max(e, 1) * 48;

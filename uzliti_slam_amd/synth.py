@@ -402,3 +402,71 @@ def make_online_run(n_nodes=20000, n_pairs=4096, n_kp=1000, seed=12345, desc_see
     stamps = (t0 + (0.5e9 * np.arange(N)).astype(np.int64)).astype(np.int64)
     return dict(gt=gt, init=g["nodes_pose"].reshape(N, 3, 4), fixed=g["nodes_fixed"], odo=g["edges"], stamps_ns=stamps,
                 pair_from=pf, pair_to=pt, pair_later=pr[:, 1].astype(np.int32), pair_alias=alias, frames=frames)
+
+
+def permute_graph(g, perm):
+    """The same pose graph with its nodes renumbered: new index of old node i = perm[i] (edges keep their order).  What a merged /
+    global-scope graph looks like to the optimizer: std::map order is no longer trajectory order (graph_slam_node.cpp:401-576)."""
+    perm = np.asarray(perm)
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    e = {k: np.array(v) for k, v in g["edges"].items()}
+    e["from"] = perm[e["from"]].astype(np.int32); e["to"] = perm[e["to"]].astype(np.int32)
+    out = dict(g)
+    out["nodes_pose"] = np.asarray(g["nodes_pose"])[inv]; out["nodes_fixed"] = np.asarray(g["nodes_fixed"])[inv]
+    out["gt_pose"] = np.asarray(g["gt_pose"])[inv]; out["edges"] = e
+    return out
+
+
+def interleave_sessions(ga, gb, n_cross=40, seed=3):
+    """Two recorded sessions in one graph, node ids interleaved (a0, b0, a1, b1, ...: ids start with the stamp, two robots
+    recording at the same time), joined by `n_cross` inter-session loop closures; session b's node 0 is not fixed."""
+    rng = np.random.default_rng(seed)
+    na, nb = len(ga["nodes_fixed"]), len(gb["nodes_fixed"])
+    n = min(na, nb)
+    ia = np.concatenate([2 * np.arange(n), 2 * n + np.arange(na - n)]); ib = np.concatenate([2 * np.arange(n) + 1, 2 * n + np.arange(nb - n)])
+    if na > n:
+        ib = ib
+    N = na + nb
+    pose = np.zeros((N, 12)); fixed = np.zeros(N, np.uint8); gt = np.zeros((N, 12))
+    # session b lives 3 m to the side of session a (same world frame)
+    off = np.eye(3, 4); off[1, 3] = 3.0
+    def shift(P):
+        return se3_mul(off, np.asarray(P).reshape(-1, 3, 4)).reshape(-1, 12)
+    pose[ia] = ga["nodes_pose"]; pose[ib] = shift(gb["nodes_pose"]); gt[ia] = ga["gt_pose"]; gt[ib] = shift(gb["gt_pose"])
+    fixed[ia] = ga["nodes_fixed"]
+    ea, eb = ga["edges"], gb["edges"]
+    e = {k: np.concatenate([np.asarray(ea[k]), np.asarray(eb[k])]) for k in ea}
+    e["from"] = np.concatenate([ia[ea["from"]], ib[eb["from"]]]).astype(np.int32)
+    e["to"] = np.concatenate([ia[ea["to"]], ib[eb["to"]]]).astype(np.int32)
+    # inter-session closures between nodes that are close in the world
+    G = gt.reshape(-1, 3, 4)
+    from scipy.spatial import cKDTree
+    d, j = cKDTree(G[ib][:, :, 3]).query(G[ia][:, :, 3])
+    cand = np.argsort(d)[: max(n_cross * 4, n_cross)]
+    sel = rng.choice(cand, size=min(n_cross, len(cand)), replace=False)
+    f = ia[sel]; t = ib[j[sel]]
+    Z = se3_mul(se3_mul(se3_inv(G[f]), G[t]), se3_from_noise(rng.normal(0, 0.05, (len(sel), 3)), rng.normal(0, 0.01, (len(sel), 3))))
+    info = np.zeros((len(sel), 6, 6))
+    for k in range(3):
+        info[:, k, k] = 500.0; info[:, 3 + k, 3 + k] = 50000.0
+    I12 = np.tile(np.eye(3, 4).reshape(1, 12), (len(sel), 1))
+    extra = {"from": f.astype(np.int32), "to": t.astype(np.int32), "type": np.full(len(sel), EDGE_TYPE_3D_FULL, np.int32),
+             "sensor_from": np.full(len(sel), -1, np.int32), "sensor_to": np.full(len(sel), -1, np.int32), "valid": np.ones(len(sel), np.int32),
+             "transform": Z.reshape(-1, 12), "displacement_from": I12, "displacement_to": I12.copy(), "information": info.reshape(-1, 36),
+             "diff_time": np.zeros(len(sel))}
+    e = {k: np.concatenate([e[k], extra[k]]) for k in e}
+    return dict(nodes_pose=pose, nodes_fixed=fixed, gt_pose=gt, edges=e)
+
+
+def drop_odometry(g, keep_every=0):
+    """The graph without its odometry chain (only feature edges; `keep_every` > 0 keeps every k-th odometry edge): what remains when
+    odometry was never recorded as TYPE_2D_WHEEL_ODOMETRY edges.  Components without a fixed node get their gauge from setFixedNodes."""
+    e = g["edges"]
+    odo = np.asarray(e["type"]) == EDGE_TYPE_ODOM
+    keep = ~odo
+    if keep_every > 0:
+        idx = np.nonzero(odo)[0]
+        keep[idx[::keep_every]] = True
+    out = dict(g)
+    out["edges"] = {k: np.asarray(v)[keep] for k, v in e.items()}
+    return out
