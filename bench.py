@@ -5,6 +5,7 @@
 
 Primary metric   : SE(3) edges optimised / s   on BASELINE config 2 (1k nodes / 5k edges, 20 LM iterations)
 `secondary`      : node pairs matched / s      on BASELINE config 3 (512 pairs x 1000 ORB-256, 500 hypotheses)
+`batched`        : 16 independent config-2 graphs per GPU through one launch sequence (uzl_pgo_batch_*)
 `c4_1gpu`        : the north-star line: 10k nodes / 50k edges on ONE GPU against the CPU path (1 thread and all cores)   [N = 1]
 `online_c5`      : BASELINE config 5: 4096 pair jobs feeding a graph that grows to 20k nodes, re-optimised every 256 edges
 `formats`        : Feature records -> frame arena for the 1024 frames of config 3 (HBM-bound byte shuffle)           [rank 0]
@@ -53,6 +54,8 @@ def parse():
     ap.add_argument("--no-formats", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the 10k/50k one-GPU block (N = 1 only)")
     ap.add_argument("--no-online", action="store_true", help="skip the BASELINE config 5 block")
+    ap.add_argument("--no-batched", action="store_true", help="skip the batched multi-graph block")
+    ap.add_argument("--batch", type=int, default=16, help="graphs per batch of the batched block")
     ap.add_argument("--online-nodes", type=int, default=20000)
     ap.add_argument("--online-pairs", type=int, default=4096)
     ap.add_argument("--sharded", action="store_true",
@@ -394,6 +397,32 @@ def main():
     if matcher is not None and dist.rank == 0 and not a.no_formats:
         formats = bench_formats(capi, dev, pairs, a.keypoints)
 
+    # ------------------------------------------------------------------ batched: B independent config-2 graphs, one launch sequence
+    batched = None
+    if not a.no_batched and is_c2:
+        nB = a.batch
+        bt = capi.PgoBatch(nB, device=dev, iterations=a.lm_iters)
+        for k in range(nB):
+            gk = synth.make_pose_graph(a.nodes, a.edges, seed=ud.replica_seed(12345, dist.rank) + 1000 * k)
+            bt.graphs[k].add_graph(gk["nodes_pose"], gk["nodes_fixed"], gk["edges"])
+        wb = {"edges": 0}
+
+        def batch_step():
+            for p_ in bt.graphs:
+                p_.reset()
+            for st_ in bt.optimize(a.lm_iters):
+                wb["edges"] += st_["n_edges"] * st_["iterations_done"]
+
+        batch_step(); wb["edges"] = 0
+        nsteps_b = max(3, a.steps // 2)
+        t_b = timed(dist, batch_step, nsteps_b)
+        vb = dist.sum(float(wb["edges"])) / t_b
+        batched = dict(metric="SE(3) edges optimized/sec, %d independent config-2 graphs per GPU in one launch sequence (uzl_pgo_batch_*)" % nB,
+                       value=round(vb, 1), unit="edges/s", graphs=nB, graphs_batched=bt.n_batched, ms_per_batch=round(1e3 * t_b / nsteps_b, 3),
+                       ms_per_graph=round(1e3 * t_b / nsteps_b / nB, 4), vs_single_graph=round(vb / value, 2),
+                       note="every graph's poses are bit-identical to its own uzl_pgo_optimize (tests/test_batch_gpu.py); the single-graph figure is `value`")
+        bt.close()
+
     # ------------------------------------------------------------------ north star: 10k / 50k on ONE GPU (N = 1 only)
     c4 = None
     if dist.world == 1 and not a.no_c4 and is_c2:
@@ -523,7 +552,7 @@ def main():
             h2d_ms=round(B["h2d_ms"], 3), d2h_ms=round(B["d2h_ms"], 3),
             roofline=roofline, rooflines=rooflines, traffic_source=TRAFFIC_JSON + " (rocprofv3 --pmc passes of profiles/collect.sh on the default workloads; not measured in this run)",
             kernels_ms_per_solve=kernels_ms, cpu_baseline=cpu, xy_only=xy_only, secondary=secondary)
-        for k, v in (("formats", formats), ("c4_1gpu", c4), ("online_c5", online_c5), ("sharded_c4", sharded_c4)):
+        for k, v in (("batched", batched), ("formats", formats), ("c4_1gpu", c4), ("online_c5", online_c5), ("sharded_c4", sharded_c4)):
             if v is not None:
                 out[k] = v
         print(json.dumps(out))

@@ -335,6 +335,25 @@ int  uzl_pgo_set_shard(uzl_pgo* h, int32_t rank, int32_t world_size,
 int  uzl_rccl_unique_id(void* id_out, int32_t cap);
 int  uzl_pgo_set_shard_rccl(uzl_pgo* h, int32_t rank, int32_t world_size, const void* unique_id, int32_t id_bytes);
 
+/* ---- batched solve: many small graphs through one launch sequence ---------------------------
+ * A 1k-node graph uses ~3 % of an MI355X (125 workgroups per launch, two dependent launches per PCG iteration).  Independent
+ * graphs - the disjoint subgraphs / local scopes / per-robot graphs of SURVEY section 8e row 2, or the disconnected components
+ * setFixedNodes() finds (g2o_optimizer.cpp:301-349) given as separate graphs - are therefore solved together: every kernel is
+ * launched once for the whole batch (blockIdx.z = graph), the host runs the Levenberg-Marquardt decisions of all graphs in
+ * lock step.  Each graph's result (poses, chi2, iteration counts) is bit-identical to uzl_pgo_optimize on that graph alone.
+ * The batch owns n_graphs ordinary handles: fill them with uzl_pgo_add_graph / uzl_pgo_set_graph, read them with uzl_pgo_store.
+ * Graphs are launched together when they are of the small-graph class (<= 2048 free vertices) and have the same hierarchy shape
+ * (same number of free vertices per level, e.g. same-size graphs); otherwise, and for any graph whose solve meets an anomaly, the
+ * call falls back to one uzl_pgo_optimize per graph - same results, no batching.  *n_batched = graphs solved in the batch. */
+typedef struct uzl_pgo_batch uzl_pgo_batch;
+int  uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch** out);
+void uzl_pgo_batch_destroy(uzl_pgo_batch* b);
+const char* uzl_pgo_batch_last_error(uzl_pgo_batch* b);
+int  uzl_pgo_batch_size(uzl_pgo_batch* b);
+uzl_pgo* uzl_pgo_batch_graph(uzl_pgo_batch* b, int32_t i);            /* borrowed: destroyed with the batch */
+int  uzl_pgo_batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats /* n_graphs entries, may be NULL */,
+                            int32_t* n_batched /* may be NULL */);
+
 /* ======================================================================================
  *  Edge filter  (TransformationFilter / EdgeCluster)
  *

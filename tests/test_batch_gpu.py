@@ -1,0 +1,81 @@
+"""Batched multi-graph solve (uzl_pgo_batch_*): B independent graphs through one launch sequence.  Every graph's result must be
+bit-identical to uzl_pgo_optimize of that graph alone, and (through that) within the north-star tolerance of the oracle."""
+import numpy as np
+import pytest
+
+from uzliti_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(capi, g, its):
+    p = capi.Pgo()
+    p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    st = p.optimize(its)
+    poses, err, used = p.store()
+    p.close()
+    return st, poses, err
+
+
+@pytest.mark.parametrize("n,e,B,its", [(1000, 5000, 16, 20), (300, 1200, 5, 8), (2000, 9000, 3, 6)])
+def test_batch_is_bit_identical_to_single_solves(capi, oracle, n, e, B, its):
+    graphs = [synth.make_pose_graph(n, e, seed=100 + 7 * k, outlier_frac=0.05 + 0.02 * (k % 3)) for k in range(B)]
+    bt = capi.PgoBatch(B)
+    for k, g in enumerate(graphs):
+        bt.graphs[k].add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    stats = bt.optimize(its)
+    assert bt.n_batched == B                                     # same-size graphs: one batch, no fallback
+    for k, g in enumerate(graphs):
+        st1, poses1, err1 = _single(capi, g, its)
+        poses, err, _ = bt.graphs[k].store()
+        assert np.array_equal(poses, poses1), k                  # bit for bit
+        assert np.array_equal(err, err1, equal_nan=True)
+        for f in ("iterations_done", "lm_trials", "pcg_iterations", "precond_builds", "terminated_early", "n_edges", "n_gauge_fixed"):
+            assert stats[k][f] == st1[f], (k, f, stats[k][f], st1[f])
+        assert stats[k]["chi2_initial"] == st1["chi2_initial"] and stats[k]["chi2_final"] == st1["chi2_final"] and stats[k]["lambda_final"] == st1["lambda_final"]
+    # and one of them against the oracle's direct solve
+    g = graphs[1]
+    fl = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, _ = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=its)
+    dt, dr = synth.pose_errors(bt.graphs[1].store()[0].reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+    assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+    # a second solve continues from the current poses, like uzl_pgo_optimize does; reset() restores the inputs
+    for k in range(B):
+        bt.graphs[k].reset()
+    again = bt.optimize(its)
+    assert all(np.array_equal(bt.graphs[k].store()[0], _single(capi, graphs[k], its)[1]) for k in range(min(B, 3)))
+    assert [a["pcg_iterations"] for a in again] == [s["pcg_iterations"] for s in stats]
+    bt.close()
+
+
+def test_mixed_shapes_fall_back_to_single_solves(capi):
+    """Graphs that do not share a hierarchy shape (or are too large for the small-graph class) are solved one by one inside the
+    call: same results, n_batched = 0."""
+    shapes = [(400, 1500), (1000, 5000), (3000, 12000)]
+    graphs = [synth.make_pose_graph(n, e, seed=5 + k) for k, (n, e) in enumerate(shapes)]
+    bt = capi.PgoBatch(len(graphs))
+    for k, g in enumerate(graphs):
+        bt.graphs[k].add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    stats = bt.optimize(6)
+    assert bt.n_batched == 0
+    for k, g in enumerate(graphs):
+        st1, poses1, _ = _single(capi, g, 6)
+        assert np.array_equal(bt.graphs[k].store()[0], poses1) and stats[k]["pcg_iterations"] == st1["pcg_iterations"]
+    bt.close()
+
+
+def test_chain_like_graphs_in_a_batch(capi, oracle):
+    """Chain-like graphs (few loop closures) and zero-residual graphs: rejected trials, early termination and, where the solver
+    meets an anomaly, the per-graph fallback - results still equal the single solves."""
+    graphs = [synth.make_pose_graph(1500, 1500 + 10 * k, seed=40 + k) for k in range(4)]
+    graphs[3] = synth.make_pose_graph(1500, 1499, seed=9)              # a pure odometry chain: chi2 = 0 from the start
+    bt = capi.PgoBatch(len(graphs))
+    for k, g in enumerate(graphs):
+        bt.graphs[k].add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    stats = bt.optimize(12)
+    for k, g in enumerate(graphs):
+        st1, poses1, _ = _single(capi, g, 12)
+        assert np.array_equal(bt.graphs[k].store()[0], poses1), k
+        assert stats[k]["iterations_done"] == st1["iterations_done"] and stats[k]["lm_trials"] == st1["lm_trials"]
+    bt.close()

@@ -511,6 +511,58 @@ class Pgo:
         return {names[i].decode(): dict(ms=ms[i], launches=ln[i]) for i in range(max(n, 0))}
 
 
+class PgoBatch:
+    """uzl_pgo_batch_*: n independent graphs solved through one launch sequence.  `graphs[i]` is an ordinary Pgo over handle i
+    (add_graph / set_graph / reset / store); optimize() solves them all and returns one stats dict per graph."""
+
+    def __init__(self, n_graphs, **cfg):
+        L = lib()
+        c = PgoCfg()
+        L.uzl_pgo_cfg_default(C.byref(c))
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.cfg = c
+        self._b = C.c_void_p()
+        L.uzl_pgo_batch_graph.restype = C.c_void_p
+        L.uzl_pgo_batch_graph.argtypes = [C.c_void_p, C.c_int32]
+        L.uzl_pgo_batch_last_error.restype = C.c_char_p
+        L.uzl_pgo_batch_last_error.argtypes = [C.c_void_p]
+        L.uzl_pgo_batch_destroy.restype = None
+        L.uzl_pgo_batch_destroy.argtypes = [C.c_void_p]
+        rc = L.uzl_pgo_batch_create(C.byref(c), C.c_int32(n_graphs), C.byref(self._b))
+        if rc != UZL_OK:
+            raise UzlError(rc, L.uzl_status_string(rc).decode())
+        self.graphs = []
+        for i in range(n_graphs):
+            p = Pgo.__new__(Pgo)
+            p.cfg = c; p._h = C.c_void_p(L.uzl_pgo_batch_graph(self._b, i)); p.n = 0; p.e_in = 0
+            p.close = lambda: None                       # borrowed: the batch destroys it
+            self.graphs.append(p)
+        self.n_batched = 0
+
+    def optimize(self, iterations=0):
+        n = len(self.graphs)
+        st = (PgoStats * n)(); nb = C.c_int32()
+        rc = lib().uzl_pgo_batch_optimize(self._b, C.c_int32(iterations), st, C.byref(nb))
+        if rc not in (UZL_OK, UZL_ERR_NOT_CONVERGED):
+            raise UzlError(rc, lib().uzl_pgo_batch_last_error(self._b).decode())
+        self.n_batched = nb.value
+        out = []
+        for i in range(n):
+            d = st[i].as_dict(); d["status"] = rc
+            out.append(d)
+        return out
+
+    def close(self):
+        if getattr(self, "_b", None):
+            for p in self.graphs:
+                p._h = None
+            lib().uzl_pgo_batch_destroy(self._b)
+            self._b = None
+
+    __del__ = close
+
+
 # --------------------------------------------------------------------------------------- edge filter
 class Filter:
     """uzl_filter_* (TransformationFilter / EdgeCluster, transformation_filter.cpp:43-350)."""

@@ -132,7 +132,7 @@ __device__ __forceinline__ void huber(double e2, double delta, double& rho0, dou
 }
 
 // activeRobustChi2 over `pose`; block partials -> part_a
-__global__ __launch_bounds__(kBlk) void chi2_kernel(PgoDev D, const double* __restrict__ pose, double delta)
+__device__ __forceinline__ void chi2_kernel_body(PgoDev D, const double* __restrict__ pose, double delta)
 {
     __shared__ double s4[4];
     double acc = 0.;
@@ -146,6 +146,10 @@ __global__ __launch_bounds__(kBlk) void chi2_kernel(PgoDev D, const double* __re
     }
     const double tot = block_sum(acc, s4);
     if (threadIdx.x == 0) D.part_a[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(kBlk) void chi2_kernel(PgoDev D, const double* __restrict__ pose, double delta)
+{
+    chi2_kernel_body(D, pose, delta);
 }
 
 // G10 storeImpl: ||e||_2 per system edge (g2o_optimizer.cpp:124-131)
@@ -189,7 +193,7 @@ __device__ __forceinline__ void mat3mul(const double* A, const double* B, double
         for (int c = 0; c < 3; c++) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
 }
 
-__global__ __launch_bounds__(kBlk) void linearize_kernel(PgoDev D, const double* __restrict__ pose, double delta)
+__device__ __forceinline__ void linearize_kernel_body(PgoDev D, const double* __restrict__ pose, double delta)
 {
     __shared__ double s4[4];
     double chi_acc = 0.;
@@ -334,10 +338,14 @@ __global__ __launch_bounds__(kBlk) void linearize_kernel(PgoDev D, const double*
     const double tot = block_sum(chi_acc, s4);
     if (threadIdx.x == 0) D.part_a[blockIdx.x] = tot;
 }
+__global__ __launch_bounds__(kBlk) void linearize_kernel(PgoDev D, const double* __restrict__ pose, double delta)
+{
+    linearize_kernel_body(D, pose, delta);
+}
 
 // H_aa = sum of the row's dcon, b_a = -sum of gcon; 36+6 lanes... one lane per (row, entry): 42 entries
 // Grid-stride over rows with 6 lanes per row (lane r owns row r of the 6x6 block and b[r]).
-__global__ __launch_bounds__(kBlk) void assemble_kernel(PgoDev D)
+__device__ __forceinline__ void assemble_kernel_body(PgoDev D)
 {
     __shared__ double s4[4];
     double dmax = 0.;
@@ -363,6 +371,10 @@ __global__ __launch_bounds__(kBlk) void assemble_kernel(PgoDev D)
     const double m = block_max(dmax, s4);
     if (threadIdx.x == 0) D.part_c[blockIdx.x] = m;
 }
+__global__ __launch_bounds__(kBlk) void assemble_kernel(PgoDev D)
+{
+    assemble_kernel_body(D);
+}
 
 // max |H_jj| over the assembled diagonal blocks -> part_c (sharded solve: after the all-reduce of hdiag)
 __global__ __launch_bounds__(kBlk) void diagmax_kernel(PgoDev D)
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(kBlk) void diagmax_kernel(PgoDev D)
 //   what = 0: scal[4] = sum(part_a[0..na))            (chi2)
 //   what = 1: ... and scal[5] = sum(part_b[0..nb_))    (chi2 + computeScale)
 //   what = 2: ... and scal[6] = max(part_c[0..nc))     (chi2 + max diagonal for computeLambdaInit)
-__global__ __launch_bounds__(kBlk) void finalize_kernel(PgoDev D, int na, int nb_, int nc, int what)
+__device__ __forceinline__ void finalize_kernel_body(PgoDev D, int na, int nb_, int nc, int what)
 {
     __shared__ double s4[4];
     const double chi = sum_partials(D.part_a, na, s4);
@@ -393,6 +405,10 @@ __global__ __launch_bounds__(kBlk) void finalize_kernel(PgoDev D, int na, int nb
         const double m = block_max(v, s4);
         if (threadIdx.x == 0) D.scal[6] = m;
     }
+}
+__global__ __launch_bounds__(kBlk) void finalize_kernel(PgoDev D, int na, int nb_, int nc, int what)
+{
+    finalize_kernel_body(D, na, nb_, nc, what);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -576,7 +592,7 @@ __global__ __launch_bounds__(kBlk) void pcg_update_kernel(PgoDev D, const double
 // G9  VertexSE3::oplusImpl [EXT]: X <- X * fromVectorMQT(dx)   (isometry3d_mappings.cpp:84-91,117-122)
 //     plus the partials of computeScale = sum dx (lambda dx + b) -> part_b
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlk) void oplus_kernel(PgoDev D, const double* __restrict__ pose_in,
+__device__ __forceinline__ void oplus_kernel_body(PgoDev D, const double* __restrict__ pose_in,
                                                      double* __restrict__ pose_out)
 {
     __shared__ double s4[4];
@@ -601,16 +617,116 @@ __global__ __launch_bounds__(kBlk) void oplus_kernel(PgoDev D, const double* __r
     const double tot = block_sum(acc, s4);
     if (threadIdx.x == 0) D.part_b[blockIdx.x] = tot;
 }
+__global__ __launch_bounds__(kBlk) void oplus_kernel(PgoDev D, const double* __restrict__ pose_in, double* __restrict__ pose_out)
+{
+    oplus_kernel_body(D, pose_in, pose_out);
+}
 
-// ------------------------------------------------------------------------------------------------
-// launchers
-// ------------------------------------------------------------------------------------------------
 static inline int grid_for(int items, int per_block, int cap)
 {
     int g = (items + per_block - 1) / per_block;
     if (g < 1) g = 1;
     return g > cap ? cap : g;
 }
+
+// ------------------------------------------------------------------------------------------------
+// batched twins (uzl_pgo_batch_*): graph = blockIdx.z, arguments from its slot, phase from its mask
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void residual_guard_kernel_body(PgoDev D);
+#define UZL_BATCH_ENTER(PHASE)                                   \
+    const BatchSlot& S = slots[blockIdx.z];                      \
+    const BatchDyn dy = dyn[blockIdx.z];                         \
+    if (!(dy.mask & (PHASE))) return;
+
+__global__ __launch_bounds__(kBlk) void linearize_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, double delta)
+{
+    UZL_BATCH_ENTER(kPhLin)
+    if ((int)blockIdx.x >= S.g_edges) return;
+    linearize_kernel_body(S.D, S.pose[dy.cur], delta);
+}
+__global__ __launch_bounds__(kBlk) void assemble_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
+{
+    UZL_BATCH_ENTER(kPhLin)
+    if ((int)blockIdx.x >= S.g_asm) return;
+    assemble_kernel_body(S.D);
+}
+// what = 2: after linearize + assemble (kPhLin); what = 1: after oplus + chi2 (kPhEval)
+__global__ __launch_bounds__(kBlk) void finalize_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int what)
+{
+    UZL_BATCH_ENTER(what == 2 ? kPhLin : kPhEval)
+    if (what == 2) finalize_kernel_body(S.D, S.g_edges, 0, S.g_asm, 2);
+    else finalize_kernel_body(S.D, S.g_edges, S.g_oplus, 0, 1);
+}
+__global__ __launch_bounds__(kBlk) void oplus_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
+{
+    UZL_BATCH_ENTER(kPhEval)
+    if ((int)blockIdx.x >= S.g_oplus) return;
+    oplus_kernel_body(S.D, S.pose[dy.cur], S.pose[dy.cur ^ 1]);
+}
+__global__ __launch_bounds__(kBlk) void chi2_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, double delta)
+{
+    UZL_BATCH_ENTER(kPhEval)
+    if ((int)blockIdx.x >= S.g_edges) return;
+    chi2_kernel_body(S.D, S.pose[dy.cur ^ 1], delta);
+}
+__global__ __launch_bounds__(1024) void residual_guard_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
+{
+    UZL_BATCH_ENTER(kPhSolve)
+    residual_guard_kernel_body(S.D);
+}
+// lambda of the round's trial into every graph's scal[3]; lambda of a run-ahead rebuild into scal2[3]
+__global__ __launch_bounds__(kBlk) void set_lambda_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int nbatch)
+{
+    const int g = blockIdx.x * kBlk + threadIdx.x;
+    if (g >= nbatch) return;
+    const BatchDyn dy = dyn[g];
+    if (dy.mask & kPhLambda) slots[g].D.scal[3] = dy.lambda;
+    if ((dy.mask & (kPhNumeric | kPhTrialBuild)) && dy.build_scal2) slots[g].scal2[3] = dy.lambda_build;
+}
+// every graph's scal[0..8) / flags[0..4) into the pinned array, then one sequence word
+__global__ __launch_bounds__(64) void publish_batch_kernel(const BatchSlot* __restrict__ slots, int nbatch, PgoHostScal* __restrict__ out, uint32_t seq)
+{
+    const int t = threadIdx.x;
+    for (int g = 0; g < nbatch; g++) {
+        if (t < 8) out[g].scal[t] = slots[g].D.scal[t];
+        else if (t < 12) out[g].flags[t - 8] = slots[g].D.flags[t - 8];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&out[nbatch].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void kb_linearize(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_asm, double delta, hipStream_t s)
+{
+    hipLaunchKernelGGL(linearize_batch_kernel, dim3(g_edges, 1, nb_), dim3(kBlk), 0, s, sl, dy, delta);
+    hipLaunchKernelGGL(assemble_batch_kernel, dim3(g_asm, 1, nb_), dim3(kBlk), 0, s, sl, dy);
+    hipLaunchKernelGGL(finalize_batch_kernel, dim3(1, 1, nb_), dim3(kBlk), 0, s, sl, dy, 2);
+}
+void kb_eval(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_oplus, double delta, hipStream_t s)
+{
+    hipLaunchKernelGGL(oplus_batch_kernel, dim3(g_oplus, 1, nb_), dim3(kBlk), 0, s, sl, dy);
+    hipLaunchKernelGGL(chi2_batch_kernel, dim3(g_edges, 1, nb_), dim3(kBlk), 0, s, sl, dy, delta);
+    hipLaunchKernelGGL(finalize_batch_kernel, dim3(1, 1, nb_), dim3(kBlk), 0, s, sl, dy, 1);
+}
+void kb_residual_guard(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s)
+{
+    hipLaunchKernelGGL(residual_guard_batch_kernel, dim3(1, 1, nb_), dim3(1024), 0, s, sl, dy);
+}
+void kb_set_lambda(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s)
+{
+    hipLaunchKernelGGL(set_lambda_batch_kernel, dim3((nb_ + kBlk - 1) / kBlk), dim3(kBlk), 0, s, sl, dy, nb_);
+}
+void kb_publish(const BatchSlot* sl, int nb_, PgoHostScal* out_dev, uint32_t seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(publish_batch_kernel, dim3(1), dim3(64), 0, s, sl, nb_, out_dev, seq);
+}
+int g_edges_for(int e) { return grid_for(e, kBlk, kMaxPartials); }
+int g_asm_for(int nb) { return grid_for(nb, kBlk / 6, kMaxPartials); }
+int g_oplus_for(int n) { return grid_for(n, kBlk, kMaxPartials); }
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
 
 void k_prepare_nodes(const uzl_node* nodes, int n, int xy, double* pose, hipStream_t s)
 {
@@ -669,7 +785,7 @@ __global__ void set_scalar_kernel(double* __restrict__ dst, double v) { *dst = v
 // After PCG has set `done`: scal[7] = |r|^2 / |b|^2 with the recurrence residual r (= b - (H + lambda) x up to rounding for ANY
 // step lengths and directions, so it is the true residual even when the preconditioner misbehaved).  The host refuses a
 // "converged" solve whose residual has not come down (uzl_pgo.hip, pcg_solve).  One workgroup; a no-op until `done`.
-__global__ __launch_bounds__(1024) void residual_guard_kernel(PgoDev D)
+__device__ __forceinline__ void residual_guard_kernel_body(PgoDev D)
 {
     __shared__ double sr[16], sb[16];
     if (!D.flags[0]) return;
@@ -684,6 +800,10 @@ __global__ __launch_bounds__(1024) void residual_guard_kernel(PgoDev D)
         for (int w = 0; w < 16; w++) { rr += sr[w]; bb += sb[w]; }
         D.scal[7] = bb > 0. ? rr / bb : 0.;
     }
+}
+__global__ __launch_bounds__(1024) void residual_guard_kernel(PgoDev D)
+{
+    residual_guard_kernel_body(D);
 }
 void k_residual_guard(const PgoDev& D, hipStream_t s) { hipLaunchKernelGGL(residual_guard_kernel, dim3(1), dim3(1024), 0, s, D); }
 

@@ -114,7 +114,7 @@ __device__ __forceinline__ int leaves_under(int span, int i, int nb)
 }
 
 // ---- geometry of level l (>= 1): centroid of every aggregate, then the children's offsets d
-__global__ __launch_bounds__(kBlk) void ml_geometry_kernel(PgoDev D, const MlDev* __restrict__ mlp,
+__device__ __forceinline__ void ml_geometry_kernel_body(PgoDev D, const MlDev* __restrict__ mlp,
                                                           const double* __restrict__ pose, int l)
 {
     const MlDev& ml = *mlp;
@@ -155,10 +155,14 @@ __global__ __launch_bounds__(kBlk) void ml_geometry_kernel(PgoDev D, const MlDev
         }
     }
 }
+__global__ __launch_bounds__(kBlk) void ml_geometry_kernel(PgoDev D, const MlDev* __restrict__ mlp, const double* __restrict__ pose, int l)
+{
+    ml_geometry_kernel_body(D, mlp, pose, l);
+}
 
 // ---- Galerkin transform of level f: every off-diagonal block and every diagonal block of A_f (and of M_f)
 //      is mapped through its two prolongation blocks and dropped into its sorted contribution position
-__global__ __launch_bounds__(kBlk) void ml_transform_kernel(PgoDev D, const MlDev* __restrict__ mlp, int f)
+__device__ __forceinline__ void ml_transform_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int f)
 {
     const MlDev& ml = *mlp;
     const MlLevel& L = ml.lv[f];
@@ -194,9 +198,13 @@ __global__ __launch_bounds__(kBlk) void ml_transform_kernel(PgoDev D, const MlDe
         }
     }
 }
+__global__ __launch_bounds__(kBlk) void ml_transform_kernel(PgoDev D, const MlDev* __restrict__ mlp, int f)
+{
+    ml_transform_kernel_body(D, mlp, f);
+}
 
 // ---- ordered reduction of the contributions into A_l (off-diagonal blocks), G_l and M_l
-__global__ __launch_bounds__(kBlk) void ml_reduce_kernel(const MlDev* __restrict__ mlp, int l)
+__device__ __forceinline__ void ml_reduce_kernel_body(const MlDev* __restrict__ mlp, int l)
 {
     const MlDev& ml = *mlp;
     const MlLevel& L = ml.lv[l];
@@ -216,6 +224,10 @@ __global__ __launch_bounds__(kBlk) void ml_reduce_kernel(const MlDev* __restrict
         L.G[(size_t)A * 36 + k] = s;
         L.M[(size_t)A * 36 + k] = m;
     }
+}
+__global__ __launch_bounds__(kBlk) void ml_reduce_kernel(const MlDev* __restrict__ mlp, int l)
+{
+    ml_reduce_kernel_body(mlp, l);
 }
 
 // ---- per LM trial: the sibling-block smoothers.  One single-wave workgroup per (level l < L, aggregate A of level
@@ -357,7 +369,7 @@ __device__ __forceinline__ void block_gauss_jordan(double* __restrict__ sW, doub
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kSibBlk) void ml_sibling_kernel(PgoDev D, const MlDev* __restrict__ mlp)
+__device__ __forceinline__ void ml_sibling_kernel_body(PgoDev D, const MlDev* __restrict__ mlp)
 {
     __shared__ double sW[48 * 49];
     __shared__ double sPiv[6 * 48];
@@ -407,6 +419,10 @@ __global__ __launch_bounds__(kSibBlk) void ml_sibling_kernel(PgoDev D, const MlD
     else block_gauss_jordan<24>(sW, sPiv, sNew, sP, ld, t);     // fan-out 4 (level 2 of large graphs)
     double* __restrict__ out = F.Winv + (size_t)A * m * m;
     for (int i = t; i < m * m; i += kSibBlk) out[i] = sW[(i / m) * ld + i % m];
+}
+__global__ __launch_bounds__(kSibBlk) void ml_sibling_kernel(PgoDev D, const MlDev* __restrict__ mlp)
+{
+    ml_sibling_kernel_body(D, mlp);
 }
 
 __device__ __forceinline__ double prolong_comp(const double* __restrict__ d, const double* __restrict__ yp, int k);
@@ -499,7 +515,7 @@ __device__ __forceinline__ void diag6(const MlLevel& F, int i, double lambda, do
 }
 
 // AP[i][p] = sum_j A_ij P_j over the children j of level-2 aggregate p
-__global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl)
+__device__ __forceinline__ void ml_mult_ap_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
@@ -525,9 +541,13 @@ __global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev*
 #pragma unroll
     for (int k = 0; k < 36; k++) o[k] = acc[k];
 }
+__global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl)
+{
+    ml_mult_ap_kernel_body(D, mlp, cl);
+}
 
 // Q[i][p] = P_i [p == parent(i)] - sum_{j in siblings(i)} S_ij AP[j][p]          (one lane per block ROW: 6x the lanes)
-__global__ __launch_bounds__(kBlk) void ml_mult_q_kernel(const MlDev* __restrict__ mlp, int cl)
+__device__ __forceinline__ void ml_mult_q_kernel_body(const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
@@ -558,9 +578,13 @@ __global__ __launch_bounds__(kBlk) void ml_mult_q_kernel(const MlDev* __restrict
 #pragma unroll
     for (int c = 0; c < 6; c++) o[c] = acc[c];
 }
+__global__ __launch_bounds__(kBlk) void ml_mult_q_kernel(const MlDev* __restrict__ mlp, int cl)
+{
+    ml_mult_q_kernel_body(mlp, cl);
+}
 
 // QY[i][p] = sum_p' Q[i][p'] Y_2[p'][p]                                           (one lane per block row)
-__global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restrict__ mlp, int cl)
+__device__ __forceinline__ void ml_mult_qy_kernel_body(const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
     const int n = ml.lv[cl].n, np = ml.lv[cl + 1].n, np6 = 6 * np;
@@ -575,9 +599,13 @@ __global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restric
 #pragma unroll
     for (int c = 0; c < 6; c++) o[c] = acc[c];
 }
+__global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restrict__ mlp, int cl)
+{
+    ml_mult_qy_kernel_body(mlp, cl);
+}
 
 // AS[j][i'] = sum_{j' in siblings(i')} A_jj' S_j'i'
-__global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl)
+__device__ __forceinline__ void ml_mult_as_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
@@ -602,9 +630,13 @@ __global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev*
 #pragma unroll
     for (int k = 0; k < 36; k++) o[k] = acc[k];
 }
+__global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl)
+{
+    ml_mult_as_kernel_body(D, mlp, cl);
+}
 
 // Y_1[i][i'] = 2 S_ii' - sum_{j in siblings(i)} S_ij AS[j][i'] + sum_p QY[i][p] Q[i'][p]^T
-__global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restrict__ mlp, int cl)
+__device__ __forceinline__ void ml_mult_final_kernel_body(const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
@@ -641,6 +673,10 @@ __global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restri
 #pragma unroll
     for (int k = 0; k < 36; k++) Y[(size_t)(6 * i + k / 6) * n6 + 6 * ip + k % 6] = acc[k];
 }
+__global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restrict__ mlp, int cl)
+{
+    ml_mult_final_kernel_body(mlp, cl);
+}
 
 // ---- composite path: Newton-Schulz refinement  X <- 2 X - X A_1 X  of the dense level-1 operator (X = Y_1 is already a
 //      good approximate inverse of A_1: one step squares the error of the cycle, two make it exact to PCG's eyes).
@@ -649,7 +685,7 @@ __global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restri
 // one workgroup per (row block i, 256 columns): the row's 6x6 blocks go through LDS once (broadcast reads), every lane owns
 // one column of X and walks the row's neighbours (X rows are read coalesced across the lanes)
 constexpr int kAxChunk = 16;          // off-diagonal blocks staged per pass
-__global__ __launch_bounds__(kBlk) void ml_ns_ax_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl, const double* __restrict__ X,
+__device__ __forceinline__ void ml_ns_ax_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl, const double* __restrict__ X,
                                                        double* __restrict__ T)
 {
     __shared__ double sb[(kAxChunk + 1) * 36];
@@ -690,6 +726,10 @@ __global__ __launch_bounds__(kBlk) void ml_ns_ax_kernel(PgoDev D, const MlDev* _
         for (int r = 0; r < 6; r++) T[(size_t)(6 * i + r) * n6 + c] = acc[r];
     }
 }
+__global__ __launch_bounds__(kBlk) void ml_ns_ax_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl, const double* __restrict__ X, double* __restrict__ T)
+{
+    ml_ns_ax_kernel_body(D, mlp, cl, X, T);
+}
 
 constexpr int kGemmTile = 64, kGemmK = 64;
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -700,7 +740,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // while the matrix cores work on the current one.  One workgroup per CU at this size (144 tiles at n = 750), so nothing
 // but the slab's own MFMAs hides the global-load latency of the next slab: with slabs of 16 (47 dependent slabs, 0.2 us
 // of MFMA each) about 1 us per slab stayed exposed (55 us); slabs of 64 leave 12 exposures.
-__global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __restrict__ X, const double* __restrict__ T,
+__device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __restrict__ X, const double* __restrict__ T,
                                                         double* __restrict__ Xn)
 {
     __shared__ double sA[kGemmTile][kGemmK + 1];      // X tile: sA[row][k]
@@ -759,9 +799,13 @@ __global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __
                 if (gr < n && gc < n) Xn[(size_t)gr * n + gc] = 2. * X[(size_t)gr * n + gc] - acc[a][b][r];
             }
 }
+__global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __restrict__ X, const double* __restrict__ T, double* __restrict__ Xn)
+{
+    ml_ns_gemm_kernel_body(n, X, T, Xn);
+}
 
 // ---- per LM trial: dense inverse of the top level A_L(lambda) (<= 48 x 48), one workgroup, in LDS
-__global__ __launch_bounds__(kBlk) void ml_top_kernel(PgoDev D, const MlDev* __restrict__ mlp)
+__device__ __forceinline__ void ml_top_kernel_body(PgoDev D, const MlDev* __restrict__ mlp)
 {
     __shared__ double sA[48 * 97];      // [A | I], row stride 97 (odd: no bank pile-up on column walks)
     const MlDev& ml = *mlp;
@@ -797,6 +841,10 @@ __global__ __launch_bounds__(kBlk) void ml_top_kernel(PgoDev D, const MlDev* __r
         __syncthreads();
     }
     for (int i = threadIdx.x; i < n * n; i += kBlk) ml.top_inv[i] = sA[(i / n) * ld + n + i % n];
+}
+__global__ __launch_bounds__(kBlk) void ml_top_kernel(PgoDev D, const MlDev* __restrict__ mlp)
+{
+    ml_top_kernel_body(D, mlp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -879,7 +927,7 @@ __device__ __forceinline__ double p1_comp(const double* geo, const double* y, in
 
 // x = 0, r = b, p0 = p1 = 0, flags cleared; exact gather-level residual of the own aggregates -> rg
 template <int AGG>
-__global__ __launch_bounds__(kCgBlk) void ml_init_kernel(PgoDev D, MlHot H, double* __restrict__ p0, double* __restrict__ p1,
+__device__ __forceinline__ void ml_init_kernel_body(PgoDev D, MlHot H, double* __restrict__ p0, double* __restrict__ p1,
                                                         double* __restrict__ rg)
 {
     constexpr int kRowsPerBlk = kMlFanout * AGG, kAggPerBlk = AGG;
@@ -924,10 +972,15 @@ __global__ __launch_bounds__(kCgBlk) void ml_init_kernel(PgoDev D, MlHot H, doub
     }
     if (blockIdx.x == 0 && tid == 0) { D.flags[0] = 0; D.flags[1] = 0; D.flags[2] = 0; D.scal[2] = 1.; }
 }
+template <int AGG>
+__global__ __launch_bounds__(kCgBlk) void ml_init_kernel(PgoDev D, MlHot H, double* __restrict__ p0, double* __restrict__ p1, double* __restrict__ rg)
+{
+    ml_init_kernel_body<AGG>(D, H, p0, p1, rg);
+}
 
 // 8 waves per workgroup: AGG = 1 -> one row per wave (8 rows), AGG = 4 -> four rows per wave (32 rows)
 template <int AGG>
-__global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const double* __restrict__ p_old,
+__device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const double* __restrict__ p_old,
                                                      double* __restrict__ p_new, int n_part, double tol2)
 {
     constexpr int kRowsPerBlk = kMlFanout * AGG, kAggPerBlk = AGG, kSpmvBlk = 512, kWaves = 8, kRowsPerWave = AGG;
@@ -1087,6 +1140,11 @@ __global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const d
 #ifdef UZL_STAMPS
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_stamps[47], 1ull);
 #endif
+}
+template <int AGG>
+__global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const double* __restrict__ p_old, double* __restrict__ p_new, int n_part, double tol2)
+{
+    ml_spmv_kernel_body<AGG>(D, H, p_old, p_new, n_part, tol2);
 }
 
 // init = 1: first application (r = b stored, exact rg in rg_old): only the preconditioner part runs.
@@ -1416,7 +1474,7 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
 // ------------------------------------------------------------------------------------------------
 // kCompU gather-level values per lane: 5 covers 6 n_1 <= 960 (<= 1280 free vertices), 8 covers 6 n_1 <= 1536 (<= 2048)
 template <int kCompU>
-__global__ __launch_bounds__(kCgBlk) void ml_cg_comp_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
+__device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const double* __restrict__ p,
                                                            const double* __restrict__ rg_old, double* __restrict__ rg_new,
                                                            int n_part, int init)
 {
@@ -1534,6 +1592,11 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_comp_kernel(PgoDev D, MlHot H, c
         }
     }
 }
+template <int kCompU>
+__global__ __launch_bounds__(kCgBlk) void ml_cg_comp_kernel(PgoDev D, MlHot H, const double* __restrict__ p, const double* __restrict__ rg_old, double* __restrict__ rg_new, int n_part, int init)
+{
+    ml_cg_comp_kernel_body<kCompU>(D, H, p, rg_old, rg_new, n_part, init);
+}
 
 // ------------------------------------------------------------------------------------------------
 // launchers
@@ -1645,6 +1708,168 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
     else hipLaunchKernelGGL(ml_cg_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     return hipSuccess;
 }
+
+// ------------------------------------------------------------------------------------------------
+// batched twins (uzl_pgo_batch_*): graph = blockIdx.z; see pgo_types.hpp (BatchSlot / BatchDyn)
+// ------------------------------------------------------------------------------------------------
+// set-up kernels run in two passes per round: pass 0 = (re)build into BatchDyn::build_ix (numeric part and / or trial part, lambda
+// from scal2 when the rebuild runs ahead of the trial loop), pass 1 = trial part on the copy the PCG applies (lambda from scal)
+#define UZL_BATCH_SETUP(PHASE0, PHASE1)                                                  \
+    const BatchSlot& S = slots[blockIdx.z];                                              \
+    const BatchDyn dy = dyn[blockIdx.z];                                                 \
+    if (!(dy.mask & (pass == 0 ? (PHASE0) : (PHASE1)))) return;                          \
+    const int c = pass == 0 ? dy.build_ix : dy.ix;                                       \
+    PgoDev D = S.D;                                                                      \
+    if (pass == 0 && dy.build_scal2) D.scal = S.scal2;
+
+__global__ __launch_bounds__(kBlk) void ml_geometry_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int l)
+{
+    const int pass = 0;
+    UZL_BATCH_SETUP(kPhNumeric, 0)
+    ml_geometry_kernel_body(D, S.dml[c], S.pose[dy.cur], l);
+}
+__global__ __launch_bounds__(kBlk) void ml_transform_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int f)
+{
+    const int pass = 0;
+    UZL_BATCH_SETUP(kPhNumeric, 0)
+    ml_transform_kernel_body(D, S.dml[c], f);
+}
+__global__ __launch_bounds__(kBlk) void ml_reduce_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int l)
+{
+    const int pass = 0;
+    UZL_BATCH_SETUP(kPhNumeric, 0)
+    (void)D;
+    ml_reduce_kernel_body(S.dml[c], l);
+}
+__global__ __launch_bounds__(kSibBlk) void ml_sibling_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    ml_sibling_kernel_body(D, S.dml[c]);
+}
+__global__ __launch_bounds__(kBlk) void ml_top_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    ml_top_kernel_body(D, S.dml[c]);
+}
+__global__ __launch_bounds__(kBlk) void ml_mult_ap_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    ml_mult_ap_kernel_body(D, S.dml[c], lev);
+}
+__global__ __launch_bounds__(kBlk) void ml_mult_as_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    ml_mult_as_kernel_body(D, S.dml[c], lev);
+}
+__global__ __launch_bounds__(kBlk) void ml_mult_q_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    (void)D;
+    ml_mult_q_kernel_body(S.dml[c], lev);
+}
+__global__ __launch_bounds__(kBlk) void ml_mult_qy_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    (void)D;
+    ml_mult_qy_kernel_body(S.dml[c], lev);
+}
+__global__ __launch_bounds__(64) void ml_mult_final_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    (void)D;
+    ml_mult_final_kernel_body(S.dml[c], lev);
+}
+// Newton-Schulz step k at level lev: X ping-pongs between Ydense[lev] and nsX, starting in Ydense[lev]
+__global__ __launch_bounds__(kBlk) void ml_ns_ax_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev, int k)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
+    ml_ns_ax_kernel_body(D, S.dml[c], lev, X, S.nsT[c]);
+}
+__global__ __launch_bounds__(256) void ml_ns_gemm_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev, int k, int n6)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    (void)D;
+    const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
+    double* Xn = (k & 1) ? S.dense[c][lev] : S.nsX[c];
+    ml_ns_gemm_kernel_body(n6, X, S.nsT[c], Xn);
+}
+__global__ __launch_bounds__(kCgBlk) void ml_init_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
+{
+    const BatchSlot& S = slots[blockIdx.z];
+    const BatchDyn dy = dyn[blockIdx.z];
+    if (!(dy.mask & kPhSolve)) return;
+    ml_init_kernel_body<1>(S.D, S.hot[dy.ix], S.pbuf[0], S.pbuf[1], S.rg[dy.ix][0]);
+}
+// PCG iteration i of a replay (parity = i & 1): p_old = pbuf[parity], p_new = pbuf[parity ^ 1]
+// (forcing two 512-lane workgroups per CU with amdgpu_waves_per_eu(4, 4) costs 68 B of scratch per lane and is slower: 69.4 vs 65.4 ms
+//  per 16-graph batch)
+__global__ __launch_bounds__(512) void ml_spmv_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int parity, double tol2)
+{
+    const BatchSlot& S = slots[blockIdx.z];
+    const BatchDyn dy = dyn[blockIdx.z];
+    if (!(dy.mask & kPhSolve)) return;
+    ml_spmv_kernel_body<1>(S.D, S.hot[dy.ix], S.pbuf[parity], S.pbuf[parity ^ 1], S.g_rows, tol2);
+}
+template <int kCompU>
+__global__ __launch_bounds__(kCgBlk) void ml_cg_comp_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int parity, int init)
+{
+    const BatchSlot& S = slots[blockIdx.z];
+    const BatchDyn dy = dyn[blockIdx.z];
+    if (!(dy.mask & kPhSolve)) return;
+    if (init) ml_cg_comp_kernel_body<kCompU>(S.D, S.hot[dy.ix], S.pbuf[0], S.rg[dy.ix][0], S.rg[dy.ix][1], 0, 1);
+    else ml_cg_comp_kernel_body<kCompU>(S.D, S.hot[dy.ix], S.pbuf[parity ^ 1], S.rg[dy.ix][parity ^ 1], S.rg[dy.ix][parity], S.g_rows, 0);
+}
+
+// numeric part of a rebuild (geometry, Galerkin products level by level) for every graph with kPhNumeric
+void kb_ml_numeric(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int levels, const int* n_lv, const int* max_work_t, const int* max_work_r, hipStream_t s)
+{
+    for (int l = 1; l <= levels; l++)
+        hipLaunchKernelGGL(ml_geometry_batch_kernel, dim3((n_lv[l] + kBlk - 1) / kBlk, 1, nbatch), dim3(kBlk), 0, s, sl, dy, l);
+    for (int f = 0; f < levels; f++) {
+        if (max_work_t[f] > 0) hipLaunchKernelGGL(ml_transform_batch_kernel, dim3((max_work_t[f] + kBlk - 1) / kBlk, 1, nbatch), dim3(kBlk), 0, s, sl, dy, f);
+        const long work = (long)max_work_r[f + 1] * 36;
+        if (work > 0) hipLaunchKernelGGL(ml_reduce_batch_kernel, dim3((unsigned)((work + kBlk - 1) / kBlk), 1, nbatch), dim3(kBlk), 0, s, sl, dy, f + 1);
+    }
+}
+// lambda-dependent part (multiplicative operator, composite level cl = 1): the launch sequence of ml_setup_trial
+void kb_ml_trial(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int pass, int levels, int cl, const int* n_lv, int inner_aggs, int ns_steps,
+                 int upper_ns, hipStream_t s)
+{
+    if (inner_aggs > 0) hipLaunchKernelGGL(ml_sibling_batch_kernel, dim3(inner_aggs, 1, nbatch), dim3(kSibBlk), 0, s, sl, dy, pass);
+    hipLaunchKernelGGL(ml_top_batch_kernel, dim3(1, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass);
+    for (int l = levels - 1; l >= cl; l--) {
+        const int n1 = n_lv[l], n2 = n_lv[l + 1];
+        const int g12 = (n1 * n2 + kBlk - 1) / kBlk, g11 = (n1 * n1 + kBlk - 1) / kBlk, g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk;
+        hipLaunchKernelGGL(ml_mult_ap_batch_kernel, dim3(g12, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l);
+        hipLaunchKernelGGL(ml_mult_as_batch_kernel, dim3(g11, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l);
+        hipLaunchKernelGGL(ml_mult_q_batch_kernel, dim3(g12r, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l);
+        hipLaunchKernelGGL(ml_mult_qy_batch_kernel, dim3(g12r, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l);
+        hipLaunchKernelGGL(ml_mult_final_batch_kernel, dim3(n2 * n2, 1, nbatch), dim3(64), 0, s, sl, dy, pass, l);
+        const int steps = l > cl ? upper_ns : ns_steps;
+        const int n6 = 6 * n1, gg = (n6 + kGemmTile - 1) / kGemmTile;
+        for (int k = 0; k < steps; k++) {
+            hipLaunchKernelGGL(ml_ns_ax_batch_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l, k);
+            hipLaunchKernelGGL(ml_ns_gemm_batch_kernel, dim3(gg, gg, nbatch), dim3(256), 0, s, sl, dy, pass, l, k, n6);
+        }
+    }
+}
+void kb_ml_init(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, hipStream_t s)
+{
+    hipLaunchKernelGGL(ml_init_batch_kernel, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy);
+    if (small) hipLaunchKernelGGL(ml_cg_comp_batch_kernel<5>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, 0, 1);
+    else hipLaunchKernelGGL(ml_cg_comp_batch_kernel<8>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, 0, 1);
+}
+// PCG iterations 2 * pairs (p0 -> p1 -> p0 ...), every graph with kPhSolve; kernels no-op for graphs whose `done` flag is set
+void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, int pairs, double tol2, hipStream_t s)
+{
+    for (int i = 0; i < 2 * pairs; i++) {
+        hipLaunchKernelGGL(ml_spmv_batch_kernel, dim3(g_rows, 1, nbatch), dim3(512), 0, s, sl, dy, i & 1, tol2);
+        if (small) hipLaunchKernelGGL(ml_cg_comp_batch_kernel<5>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, i & 1, 0);
+        else hipLaunchKernelGGL(ml_cg_comp_batch_kernel<8>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, i & 1, 0);
+    }
+}
+bool ml_comp_small(int n1) { return 6 * n1 <= 5 * kCgBlk; }
 
 }  // namespace uzl
 

@@ -129,6 +129,36 @@ struct MlHot {
     double* Sg;                            // [n_g][6] restriction of A p at the gather level g = min(2, levels)
 };
 
+// ---- batched solve: B graphs of identical hierarchy shape advance through one launch sequence (uzl_pgo_batch_*) ----------------
+// Every batched kernel is the single-graph kernel's body, instantiated a second time with its arguments taken from slot
+// blockIdx.z instead of the kernel-argument segment: same arithmetic, same order, bit-identical results.  The host's scalar
+// decisions (which graphs linearise, rebuild, take another trial) reach the kernels as a phase mask per graph.
+constexpr int kBatchMax = 256;
+enum BatchPhase : int32_t { kPhLin = 1, kPhNumeric = 2, kPhTrialBuild = 4, kPhTrialCur = 8, kPhSolve = 16, kPhEval = 32, kPhLambda = 64 };
+struct BatchSlot {
+    PgoDev D;                                  // pose / pose_trial unused: the pose buffers are picked through BatchDyn::cur
+    MlHot hot[2];                              // hot subset of the two hierarchy copies
+    const MlDev* dml[2];
+    double* rg[2][2];                          // per copy: double-buffered gather-level residual
+    double* dense[2][kMlMaxLevels + 1];        // per copy: Ydense[l]
+    double* nsT[2];
+    double* nsX[2];
+    double* pbuf[2];                           // PCG direction, ping-pong
+    double* pose[2];
+    double* scal2;                             // [8] lambda slot ([3]) of a rebuild that runs ahead of the trial loop
+    int32_t g_edges, g_asm, g_oplus, g_rows;   // grids (= partial counts) of the single-graph launches
+};
+struct BatchDyn {                              // host -> device once per round
+    double  lambda;                            // kPhLambda: lambda of this round's trial (-> D.scal[3])
+    double  lambda_build;                      // lambda of a rebuild into build_ix (-> scal2[3]) when build_scal2
+    int32_t mask;                              // BatchPhase bits
+    int32_t cur;                               // pose buffer holding the current estimate
+    int32_t ix;                                // hierarchy copy the PCG applies
+    int32_t build_ix;                          // copy the kPhNumeric / kPhTrialBuild set-up kernels write
+    int32_t build_scal2;                       // 1: those kernels read lambda from scal2
+    int32_t pad;
+};
+
 // scalars handed back to the host after each LM trial / PCG chunk.  The struct lives in pinned, host-coherent memory
 // that a one-workgroup kernel (publish_kernel) writes directly; `seq` is stored last with system-scope release, the
 // host spins on it - a few microseconds instead of the copy + stream-synchronise round trip.

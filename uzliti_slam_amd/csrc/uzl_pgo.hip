@@ -53,6 +53,21 @@ void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, d
 hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
                    int init, size_t lds, hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s);
+// batched twins (pgo_kernels.hip / pgo_ml_kernels.hip)
+void kb_linearize(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_asm, double delta, hipStream_t s);
+void kb_eval(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_oplus, double delta, hipStream_t s);
+void kb_residual_guard(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s);
+void kb_set_lambda(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s);
+void kb_publish(const BatchSlot* sl, int nb_, PgoHostScal* out_dev, uint32_t seq, hipStream_t s);
+int g_edges_for(int e);
+int g_asm_for(int nb);
+int g_oplus_for(int n);
+void kb_ml_numeric(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int levels, const int* n_lv, const int* max_work_t, const int* max_work_r, hipStream_t s);
+void kb_ml_trial(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int pass, int levels, int cl, const int* n_lv, int inner_aggs, int ns_steps,
+                 int upper_ns, hipStream_t s);
+void kb_ml_init(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, hipStream_t s);
+void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, int pairs, double tol2, hipStream_t s);
+bool ml_comp_small(int n1);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
 }  // namespace uzl
@@ -172,11 +187,16 @@ struct uzl_pgo {
     bool structure_reused = false;
     double last_residual_ratio = 0.;
     int32_t guard_trips = 0;
+    uint64_t structure_gen = 0;      // bumped by build_structure: batches rebuild their slots when it moves
     bool mult_banned = false;        // the multiplicative operator broke down on a graph of this handle: later structures start additive
     KernelTimer timer;
 };
 
 namespace {
+
+constexpr int kUpperNs = 4;               // Newton-Schulz steps of the dense levels above the composite level (even: the result ends in Ydense[l])
+static const bool always_refresh = getenv("UZL_ML_ALWAYS_REFRESH") != nullptr;      // A/B switch
+static const double refresh_rel = getenv("UZL_ML_REFRESH_REL") ? atof(getenv("UZL_ML_REFRESH_REL")) : 1e-3;
 
 int fail(uzl_pgo* h, int code, const char* msg)
 {
@@ -560,7 +580,6 @@ void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool tim
         // levels above does (eig up to ~3 on chain-like graphs: tests/diag/cycle_spectrum.py), so those levels are built the same
         // way from the top down: cycle around the (numerically) exact level above, then kUpperNs Newton-Schulz steps.  They are
         // small ((6 n_l)^2 with n_l <= n_cl / 8): a few launches per level.
-        constexpr int kUpperNs = 4;                                          // even: the result ends in Ydense[l]
         for (int l = L - 1; l > cl; l--) {
             k_ml_mult_level(D, B.dml, l, h->ml_n[l], h->ml_n[l + 1], s);
             double* xa = h->ml_dense_ptr[bi][l]; double* xb = B.nsX;
@@ -718,6 +737,7 @@ void build_structure(uzl_pgo* h)
         D.sibling0 = 0;
     }
     h->structure_ready = true;
+    h->structure_gen++;
 }
 
 // enqueue `pairs` x 2 PCG iterations (p0 -> p1 -> p0); kernels no-op once the device `done` flag is set
@@ -870,8 +890,6 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     }
     // optimizer_.optimize(iterations) (:148) -> OptimizationAlgorithmLevenberg::solve [EXT]
     double lambda = 0., ni = 2., current_chi = 0.;
-    static const bool always_refresh = getenv("UZL_ML_ALWAYS_REFRESH") != nullptr;      // A/B switch
-    static const double refresh_rel = getenv("UZL_ML_REFRESH_REL") ? atof(getenv("UZL_ML_REFRESH_REL")) : 1e-3;
     double last_rel = 1e300;
     int pcg_ref = 1 << 30, pcg_last = 0;
     // Asynchronous rebuild: from the second LM iteration on a wanted rebuild runs on stream2 into the OTHER copy of the
@@ -1330,6 +1348,463 @@ int uzl_pgo_set_shard_rccl(uzl_pgo* h, int32_t rank, int32_t world_size, const v
     h->structure_ready = false;
     return UZL_OK;
     UZL_GUARD_END(h)
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+//  Batched solve: B independent graphs through ONE launch sequence (uzl_pgo_batch_*)
+//
+//  One config-2-sized graph leaves the chip ~97 % idle (125 workgroups per launch, two dependent launches per PCG iteration);
+//  several handles on several streams do not recover it (tests/diag/multi_handle.py: 4 handles 1.9x, 16 handles 1.5x - the
+//  launches serialise).  Here every kernel of the solve is launched once for all graphs (blockIdx.z = graph, arguments from a slot
+//  array, per-graph phase mask), so a PCG iteration of B graphs costs two launches, like one graph's.  The kernels are the
+//  single-graph kernels' bodies; the host below replays do_optimize's scalar logic per graph, in lock step, one LM trial per
+//  round: every graph's poses, chi2 and iteration counts are bit-identical to a uzl_pgo_optimize of that graph alone.
+//  Batched together are graphs of the "small graph" class (<= 2048 free vertices: dense level-1 operator) with identical
+//  hierarchy shape; anything else - and any graph that meets an anomaly (PCG not converged, breakdown) - is solved by the
+//  single-graph path, so results never depend on whether a graph was batched.
+// =====================================================================================================================
+struct uzl_pgo_batch {
+    std::mutex mu;
+    std::string last_error;
+    uzl_pgo_cfg cfg;
+    std::vector<uzl_pgo*> h;
+    hipStream_t stream = nullptr;
+    DevBuf<BatchSlot> d_slots;
+    DevBuf<BatchDyn> d_dyn;
+    PinBuf<BatchDyn> h_dyn;               // ring of staging copies (kDynRing x B)
+    int ring = 0;
+    PinBuf<PgoHostScal> h_pub;            // B entries + one for the sequence word
+    PgoHostScal* d_pub = nullptr;
+    uint32_t pub_seq = 0;
+    DevBuf<double> d_start;               // poses at the start of the solve (anomaly fallback)
+    std::vector<uint64_t> slot_gen;       // structure generation each slot was built from
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    int32_t last_batched = 0;
+};
+
+namespace {
+constexpr int kDynRing = 16;
+
+int bfail(uzl_pgo_batch* b, int code, const char* msg) { b->last_error = msg; return code; }
+
+void batch_destroy_graph(uzl_pgo_batch* b)
+{
+    if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
+    if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
+}
+
+// per-graph state of the Levenberg-Marquardt loop: the locals of do_optimize
+struct BatchLM {
+    int it = 0, qmax = 0;
+    double lambda = 0., ni = 2., current_chi = 0., last_rel = 1e300;
+    int pcg_ref = 1 << 30, pcg_last = 0;
+    int ml_ix = 0, cur = 0;
+    bool pending = false, adopted = false, trial_setup = false, need_lin = true, finished = false, anomaly = false, fresh = false;
+    double lambda_setup[2] = {0., 0.};
+    uzl_pgo_stats S;
+};
+
+void batch_upload_dyn(uzl_pgo_batch* b, const std::vector<BatchDyn>& dyn)
+{
+    const size_t B = dyn.size();
+    BatchDyn* stage = b->h_dyn.p + (size_t)(b->ring++ % kDynRing) * B;
+    memcpy(stage, dyn.data(), sizeof(BatchDyn) * B);
+    UZL_HIP(hipMemcpyAsync(b->d_dyn.p, stage, sizeof(BatchDyn) * B, hipMemcpyHostToDevice, b->stream));
+}
+
+void batch_fetch(uzl_pgo_batch* b)
+{
+    const int B = (int)b->h.size();
+    const uint32_t seq = ++b->pub_seq;
+    kb_publish(b->d_slots.p, B, b->d_pub, seq, b->stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (int spin = 0; !seen; spin++) {
+        seen = __atomic_load_n(&b->h_pub.p[B].seq, __ATOMIC_ACQUIRE) == seq;
+        if (!seen && (spin & 1023) == 1023 &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 200.0) break;
+    }
+    if (!seen) {
+        UZL_HIP(hipStreamSynchronize(b->stream));
+        if (__atomic_load_n(&b->h_pub.p[B].seq, __ATOMIC_ACQUIRE) != seq) throw HipError{hipErrorUnknown, "publish_batch_kernel did not run", __FILE__, __LINE__};
+    }
+    b->ring = 0;       // everything enqueued before the publish has executed: the staging ring is free again
+}
+
+bool batch_eligible(const uzl_pgo_batch* b)
+{
+    const uzl_pgo* a = b->h[0];
+    for (const uzl_pgo* h : b->h) {
+        if (!(h->ml_levels > 0 && h->ml_agg == 1 && h->ml_comp && h->ml_mult && h->ml_cl == 1 && !h->sharded && h->nb > 0 && h->e > 0 &&
+              !h->timer.on && h->stream2 != nullptr)) return false;
+        // same shape from level 1 up (the level-0 size may differ by the few vertices the gauge / skip rules remove: only grids depend on it)
+        if (h->ml_n.size() != a->ml_n.size() || !std::equal(h->ml_n.begin() + 1, h->ml_n.end(), a->ml_n.begin() + 1) ||
+            h->ml_ns_steps != a->ml_ns_steps || h->ml_levels != a->ml_levels || h->cfg.device != a->cfg.device) return false;
+    }
+    return (int)b->h.size() <= kBatchMax;
+}
+
+void batch_build_slots(uzl_pgo_batch* b)
+{
+    const int B = (int)b->h.size();
+    bool stale = b->slot_gen.size() != (size_t)B;
+    for (int g = 0; g < B && !stale; g++) stale = b->slot_gen[g] != b->h[g]->structure_gen;
+    if (!stale) return;
+    batch_destroy_graph(b);
+    std::vector<BatchSlot> sl((size_t)B);
+    for (int g = 0; g < B; g++) {
+        uzl_pgo* h = b->h[g];
+        BatchSlot& S = sl[g];
+        memset(&S, 0, sizeof(S));
+        S.D = h->D;
+        for (int c = 0; c < 2; c++) {
+            S.hot[c] = h->mlb[c].hot; S.dml[c] = h->mlb[c].dml;
+            S.rg[c][0] = h->mlb[c].rg[0]; S.rg[c][1] = h->mlb[c].rg[1];
+            for (int l = 0; l <= kMlMaxLevels; l++) S.dense[c][l] = h->ml_dense_ptr[c][l];
+            S.nsT[c] = h->mlb[c].nsT; S.nsX[c] = h->mlb[c].nsX;
+        }
+        S.pbuf[0] = h->d_p.p; S.pbuf[1] = h->d_p2.p;
+        S.pose[0] = h->pose_a.p; S.pose[1] = h->pose_b.p;
+        S.scal2 = h->d_scal2.p;
+        S.g_edges = g_edges_for(h->e); S.g_asm = g_asm_for(h->nb); S.g_oplus = g_oplus_for(h->n); S.g_rows = g_ml_rows(h->nb, 1);
+    }
+    b->d_slots.reserve((size_t)B); b->d_dyn.reserve((size_t)B);
+    b->h_dyn.reserve((size_t)B * kDynRing);
+    b->h_pub.reserve((size_t)B + 1, hipHostMallocMapped | hipHostMallocCoherent);
+    memset(b->h_pub.p, 0, sizeof(PgoHostScal) * ((size_t)B + 1));
+    UZL_HIP(hipHostGetDevicePointer((void**)&b->d_pub, b->h_pub.p, 0));
+    UZL_HIP(hipMemcpyAsync(b->d_slots.p, sl.data(), sizeof(BatchSlot) * (size_t)B, hipMemcpyHostToDevice, b->stream));
+    UZL_HIP(hipStreamSynchronize(b->stream));          // sl is a local
+    b->slot_gen.resize((size_t)B);
+    for (int g = 0; g < B; g++) b->slot_gen[g] = b->h[g]->structure_gen;
+}
+
+int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, int32_t* n_batched)
+{
+    const int B = (int)b->h.size();
+    if (n_batched) *n_batched = 0;
+    for (uzl_pgo* h : b->h) if (!h->have_graph) return bfail(b, UZL_ERR_STATE, "optimize before every graph of the batch has been set");
+    UZL_HIP(hipSetDevice(b->cfg.device));
+    const auto t0 = std::chrono::steady_clock::now();
+    // per graph: optimizeImpl's initializeOptimization + setFixedNodes (:139-146), structure
+    std::vector<double> structure_ms((size_t)B, 0.);
+    std::vector<int32_t> reused((size_t)B, 0);
+    for (int g = 0; g < B; g++) {
+        uzl_pgo* h = b->h[g];
+        if (iterations <= 0) iterations = h->cfg.iterations;
+        reused[g] = h->structure_ready ? 1 : 0;
+        if (!h->structure_ready) {
+            const auto ts = std::chrono::steady_clock::now();
+            h->fixed_eff = h->fixed_in;
+            h->n_gauge = gauge_fix(h);
+            build_structure(h);
+            structure_ms[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
+        }
+        UZL_HIP(hipStreamSynchronize(h->stream));
+    }
+    int rc_all = UZL_OK;
+    if (!batch_eligible(b)) {            // not one class / one shape: every graph through the single-graph path
+        if (b->cfg.verbose)
+            for (const uzl_pgo* h : b->h)
+                fprintf(stderr, "[uzl_pgo_batch] not batched: levels %d agg %d comp %d mult %d cl %d sharded %d nb %d e %d timer %d no_graph %d n1 %d ns %d\n", h->ml_levels,
+                        h->ml_agg, (int)h->ml_comp, (int)h->ml_mult, h->ml_cl, (int)h->sharded, h->nb, h->e, (int)h->timer.on, (int)h->no_graph,
+                        h->ml_n.size() > 1 ? h->ml_n[1] : -1, h->ml_ns_steps);
+        for (int g = 0; g < B; g++) {
+            uzl_pgo_stats S;
+            const int rc = do_optimize(b->h[g], iterations, &S);
+            if (rc != UZL_OK && rc != UZL_ERR_NOT_CONVERGED) { b->last_error = b->h[g]->last_error; return rc; }
+            if (rc != UZL_OK) rc_all = rc;
+            if (stats) stats[g] = S;
+        }
+        b->last_batched = 0;
+        return rc_all;
+    }
+    batch_build_slots(b);
+    hipStream_t s = b->stream;
+    const uzl_pgo* h0 = b->h[0];
+    const int L = h0->ml_levels, cl = h0->ml_cl, g_rows = g_ml_rows(h0->nb, 1);
+    const bool small = ml_comp_small(h0->ml_n[1]);
+    const double delta = b->cfg.huber_delta, tol2 = b->cfg.pcg_tol * b->cfg.pcg_tol;
+    int max_g_edges = 1, max_g_asm = 1, max_g_oplus = 1, max_inner = 0;
+    std::vector<int> n_lv((size_t)L + 2, 0), max_wt((size_t)L + 2, 0), max_wr((size_t)L + 2, 0);
+    for (int l = 0; l <= L; l++) n_lv[l] = h0->ml_n[l];
+    for (const uzl_pgo* h : b->h) {
+        max_g_edges = std::max(max_g_edges, g_edges_for(h->e)); max_g_asm = std::max(max_g_asm, g_asm_for(h->nb));
+        max_g_oplus = std::max(max_g_oplus, g_oplus_for(h->n)); max_inner = std::max(max_inner, h->ml_inner_aggs);
+        for (int l = 0; l <= L; l++) {
+            max_wt[l] = std::max(max_wt[l], h->ml_nslots[l] + h->ml_n[l]);
+            max_wr[l] = std::max(max_wr[l], h->ml_nslots[l] + h->ml_n[l]);
+        }
+    }
+    // start poses (anomaly fallback) and LM state
+    size_t tot_n = 0;
+    for (const uzl_pgo* h : b->h) tot_n += (size_t)h->n * 8;
+    b->d_start.reserve(std::max<size_t>(tot_n, 8));
+    std::vector<BatchLM> G((size_t)B);
+    {
+        size_t off = 0;
+        for (int g = 0; g < B; g++) {
+            uzl_pgo* h = b->h[g];
+            UZL_HIP(hipMemcpyAsync(b->d_start.p + off, h->cur, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
+            off += (size_t)h->n * 8;
+            memset(&G[g].S, 0, sizeof(uzl_pgo_stats));
+            G[g].S.n_vertices = h->n; G[g].S.n_edges = h->e; G[g].S.n_gauge_fixed = h->n_gauge;
+            G[g].S.structure_ms = structure_ms[g]; G[g].S.structure_reused = reused[g];
+            G[g].cur = (h->cur == h->pose_a.p) ? 0 : 1;
+            h->ml_ix = 0; h->ml_pending = false;
+        }
+    }
+    const bool eager = h0->no_graph;      // UZL_NO_GRAPH=1 (rocprofv3 --kernel-trace runs): the replay's launches one by one
+    if (!b->graph_exec && !eager) {       // the PCG replay: 2 x kGraphPairs iterations of all graphs
+        UZL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, kGraphPairs, tol2, s);
+        UZL_HIP(hipStreamEndCapture(s, &b->graph));
+        UZL_HIP(hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
+    }
+    std::vector<BatchDyn> dyn((size_t)B);
+    auto base_dyn = [&]() {
+        for (int g = 0; g < B; g++) {
+            memset(&dyn[g], 0, sizeof(BatchDyn));
+            dyn[g].cur = G[g].cur; dyn[g].ix = G[g].ml_ix; dyn[g].build_ix = G[g].ml_ix;
+        }
+    };
+    int max_nb = 1;
+    for (const uzl_pgo* h : b->h) max_nb = std::max(max_nb, h->nb);
+    const int max_it = b->cfg.pcg_max_iter > 0 ? b->cfg.pcg_max_iter : 6 * max_nb;
+    int prev_pcg = 0;
+    int n_active = B;
+    while (n_active > 0) {
+        // ---- stage 1: linearise the graphs that start a new LM iteration; first iteration: numeric set-up, chi2 and lambda_0
+        base_dyn();
+        bool any_lin = false, any_it0 = false;
+        for (int g = 0; g < B; g++) {
+            BatchLM& X = G[g];
+            if (X.finished || !X.need_lin) continue;
+            X.adopted = false;
+            if (X.pending) { X.ml_ix ^= 1; X.pending = false; X.adopted = true; }
+            dyn[g].ix = X.ml_ix; dyn[g].build_ix = X.ml_ix;
+            dyn[g].mask |= kPhLin;
+            any_lin = true;
+            if (X.it == 0) { dyn[g].mask |= kPhNumeric; any_it0 = true; }
+        }
+        std::vector<uint8_t> ahead((size_t)B, 0);
+        if (any_lin) {
+            batch_upload_dyn(b, dyn);
+            kb_linearize(b->d_slots.p, b->d_dyn.p, B, max_g_edges, max_g_asm, delta, s);
+            for (int g = 0; g < B; g++) {
+                BatchLM& X = G[g];
+                if (!(dyn[g].mask & kPhLin)) continue;
+                const bool refresh = X.it == 0 || always_refresh || X.last_rel > refresh_rel || X.pcg_last > X.pcg_ref + X.pcg_ref / 3 + 4;
+                if (refresh) {
+                    X.S.precond_builds++;
+                    if (X.it == 0) X.trial_setup = true; else ahead[g] = 1;
+                }
+            }
+            if (any_it0) {
+                kb_ml_numeric(b->d_slots.p, b->d_dyn.p, B, L, n_lv.data(), max_wt.data(), max_wr.data(), s);
+                batch_fetch(b);
+                for (int g = 0; g < B; g++) {
+                    BatchLM& X = G[g];
+                    if (!(dyn[g].mask & kPhLin) || X.it != 0) continue;
+                    X.current_chi = b->h_pub.p[g].scal[4];
+                    X.S.chi2_initial = X.current_chi;
+                    X.lambda = 1e-5 * b->h_pub.p[g].scal[6];                        // computeLambdaInit: tau * max diag
+                    X.ni = 2.;
+                }
+            }
+        }
+        // ---- stage 2: rebuilds that run ahead: into the copy the PCG does not use, with this iteration's lambda; adopted next iteration
+        bool any_ahead = false;
+        base_dyn();
+        for (int g = 0; g < B; g++) {
+            if (!ahead[g]) continue;
+            BatchLM& X = G[g];
+            dyn[g].mask = kPhNumeric | kPhTrialBuild; dyn[g].build_ix = X.ml_ix ^ 1; dyn[g].build_scal2 = 1; dyn[g].lambda_build = X.lambda;
+            X.lambda_setup[X.ml_ix ^ 1] = X.lambda; X.pending = true;
+            any_ahead = true;
+        }
+        if (any_ahead) {
+            batch_upload_dyn(b, dyn);
+            kb_set_lambda(b->d_slots.p, b->d_dyn.p, B, s);
+            kb_ml_numeric(b->d_slots.p, b->d_dyn.p, B, L, n_lv.data(), max_wt.data(), max_wr.data(), s);
+            kb_ml_trial(b->d_slots.p, b->d_dyn.p, B, 0, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s);
+        }
+        // ---- stage 3: one LM trial of every active graph: (H + lambda I) dx = b
+        base_dyn();
+        bool any_trial_cur = false;
+        for (int g = 0; g < B; g++) {
+            BatchLM& X = G[g];
+            if (X.finished) continue;
+            dyn[g].mask = kPhLambda | kPhSolve; dyn[g].lambda = X.lambda;
+            if (X.lambda > 8. * X.lambda_setup[X.ml_ix]) X.trial_setup = true;
+            X.fresh = X.trial_setup || (X.adopted && X.qmax == 0);
+            if (X.trial_setup) { dyn[g].mask |= kPhTrialCur; X.lambda_setup[X.ml_ix] = X.lambda; X.trial_setup = false; any_trial_cur = true; }
+        }
+        batch_upload_dyn(b, dyn);
+        kb_set_lambda(b->d_slots.p, b->d_dyn.p, B, s);
+        if (any_trial_cur) kb_ml_trial(b->d_slots.p, b->d_dyn.p, B, 1, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s);
+        kb_ml_init(b->d_slots.p, b->d_dyn.p, B, g_rows, small, s);
+        {
+            int launched = 0;
+            int want = prev_pcg > 0 ? std::max(2 * kGraphPairs, (prev_pcg * 95) / 100) : 2 * kGraphPairs;
+            while (true) {
+                want = std::min(want, max_it - launched);
+                const int reps = std::max(1, (want + 2 * kGraphPairs - 1) / (2 * kGraphPairs));
+                for (int i = 0; i < reps; i++) {
+                    if (eager) kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, kGraphPairs, tol2, s);
+                    else UZL_HIP(hipGraphLaunch(b->graph_exec, s));
+                }
+                launched += reps * 2 * kGraphPairs;
+                kb_residual_guard(b->d_slots.p, b->d_dyn.p, B, s);
+                batch_fetch(b);
+                bool all_done = true;
+                for (int g = 0; g < B; g++) if ((dyn[g].mask & kPhSolve) && !b->h_pub.p[g].flags[0]) all_done = false;
+                if (all_done || launched >= max_it) break;
+                want = 2 * kGraphPairs;
+            }
+            UZL_HIP(hipGetLastError());
+        }
+        prev_pcg = 0;
+        for (int g = 0; g < B; g++) {
+            BatchLM& X = G[g];
+            if (!(dyn[g].mask & kPhSolve)) continue;
+            const PgoHostScal& P = b->h_pub.p[g];
+            bool conv = P.flags[0] != 0 && P.flags[2] == 0;
+            if (conv && !(P.scal[7] <= kResidualGuard)) conv = false;
+            const int its = P.flags[1];
+            X.S.pcg_iterations += its; X.S.lm_trials++;
+            prev_pcg = std::max(prev_pcg, its);
+            if (!conv) {                                                          // the single-graph path sorts it out from the start poses
+                if (b->h[g]->cfg.verbose)
+                    fprintf(stderr, "[uzl_pgo_batch] graph %d it %d trial %d lambda %.3e: pcg %d done %d breakdown %d |r|2/|b|2 %.3e -> single-graph path\n",
+                            g, X.it, X.qmax, X.lambda, its, (int)P.flags[0], (int)P.flags[2], P.scal[7]);
+                X.anomaly = true; X.finished = true; n_active--; continue;
+            }
+            if (X.fresh) X.pcg_ref = its;
+            X.pcg_last = its;
+        }
+        // ---- stage 4: retraction, chi2 of the trial, rho, accept / reject
+        base_dyn();
+        bool any_eval = false;
+        for (int g = 0; g < B; g++) if (!G[g].finished) { dyn[g].mask = kPhEval; any_eval = true; }
+        if (!any_eval) break;
+        batch_upload_dyn(b, dyn);
+        kb_eval(b->d_slots.p, b->d_dyn.p, B, max_g_edges, max_g_oplus, delta, s);
+        batch_fetch(b);
+        for (int g = 0; g < B; g++) {
+            BatchLM& X = G[g];
+            if (!(dyn[g].mask & kPhEval)) continue;
+            const double temp_chi = b->h_pub.p[g].scal[4];
+            const double scale = b->h_pub.p[g].scal[5] + 1e-3;                    // computeScale + 1e-3
+            const double rho = (X.current_chi - temp_chi) / scale;
+            if (rho > 0 && std::isfinite(temp_chi)) {                             // good step
+                double alpha = 1. - std::pow(2 * rho - 1, 3);
+                alpha = std::min(alpha, 2. / 3.);
+                X.lambda *= std::max(1. / 3., alpha);
+                X.ni = 2.;
+                X.last_rel = std::fabs(X.current_chi - temp_chi) / std::max(std::fabs(temp_chi), 1e-300);
+                X.current_chi = temp_chi;
+                X.cur ^= 1;                                                       // discardTop
+            } else {
+                X.lambda *= X.ni;
+                X.ni *= 2.;
+            }
+            X.qmax++;
+            if (rho < 0 && X.qmax < 10) { X.need_lin = false; continue; }         // another trial on the same linearisation
+            X.S.iterations_done = X.it + 1;
+            if (X.qmax == 10 || rho == 0) { X.S.terminated_early = 1; X.finished = true; n_active--; continue; }     // Terminate
+            X.it++; X.qmax = 0; X.need_lin = true;
+            if (X.it >= iterations) { X.finished = true; n_active--; }
+        }
+    }
+    UZL_HIP(hipStreamSynchronize(s));
+    const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    int batched = 0;
+    size_t off = 0;
+    for (int g = 0; g < B; g++) {
+        uzl_pgo* h = b->h[g];
+        BatchLM& X = G[g];
+        if (!X.anomaly) {
+            h->cur = X.cur ? h->pose_b.p : h->pose_a.p; h->trial = X.cur ? h->pose_a.p : h->pose_b.p;
+            X.S.chi2_final = X.current_chi; X.S.lambda_final = X.lambda; X.S.solve_ms = wall;
+            if (stats) stats[g] = X.S;
+            batched++;
+        } else {
+            UZL_HIP(hipMemcpyAsync(h->cur, b->d_start.p + off, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
+            UZL_HIP(hipStreamSynchronize(s));
+            uzl_pgo_stats S;
+            const int rc = do_optimize(h, iterations, &S);
+            if (rc != UZL_OK && rc != UZL_ERR_NOT_CONVERGED) { b->last_error = h->last_error; return rc; }
+            if (rc != UZL_OK) rc_all = rc;
+            if (stats) stats[g] = S;
+        }
+        off += (size_t)h->n * 8;
+    }
+    b->last_batched = batched;
+    if (n_batched) *n_batched = batched;
+    return rc_all;
+}
+
+}  // namespace
+
+#define UZL_BGUARD_BEGIN(b)                      \
+    if (!(b)) return UZL_ERR_BAD_ARG;            \
+    std::lock_guard<std::mutex> lock_((b)->mu);  \
+    try {
+#define UZL_BGUARD_END(b)                                                            \
+    } catch (const ::uzl::HipError& e) { return ::uzl::report((b)->last_error, e); } \
+    catch (const std::bad_alloc&) { (b)->last_error = "host out of memory"; return UZL_ERR_OOM; } \
+    catch (...) { (b)->last_error = "unexpected exception"; return UZL_ERR_HIP; }
+
+extern "C" {
+
+int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch** out)
+{
+    if (!out || n_graphs < 1 || n_graphs > kBatchMax) return UZL_ERR_BAD_ARG;
+    *out = nullptr;
+    uzl_pgo_cfg c;
+    if (cfg) c = *cfg; else uzl_pgo_cfg_default(&c);
+    uzl_pgo_batch* b = new (std::nothrow) uzl_pgo_batch();
+    if (!b) return UZL_ERR_OOM;
+    b->cfg = c;
+    if (getenv("UZL_VERBOSE")) b->cfg.verbose = 1;
+    for (int32_t g = 0; g < n_graphs; g++) {
+        uzl_pgo* h = nullptr;
+        const int rc = uzl_pgo_create(&c, &h);
+        if (rc != UZL_OK) { for (uzl_pgo* x : b->h) uzl_pgo_destroy(x); delete b; return rc; }
+        b->h.push_back(h);
+    }
+    if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+        for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
+        delete b;
+        return UZL_ERR_HIP;
+    }
+    *out = b;
+    return UZL_OK;
+}
+
+void uzl_pgo_batch_destroy(uzl_pgo_batch* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->cfg.device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    batch_destroy_graph(b);
+    for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+const char* uzl_pgo_batch_last_error(uzl_pgo_batch* b) { return b ? b->last_error.c_str() : "null handle"; }
+int uzl_pgo_batch_size(uzl_pgo_batch* b) { return b ? (int)b->h.size() : UZL_ERR_BAD_ARG; }
+uzl_pgo* uzl_pgo_batch_graph(uzl_pgo_batch* b, int32_t i) { return (b && i >= 0 && i < (int32_t)b->h.size()) ? b->h[(size_t)i] : nullptr; }
+
+int uzl_pgo_batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, int32_t* n_batched)
+{
+    UZL_BGUARD_BEGIN(b)
+    return batch_optimize(b, iterations, stats, n_batched);
+    UZL_BGUARD_END(b)
 }
 
 }  // extern "C"
