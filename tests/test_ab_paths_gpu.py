@@ -15,7 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _run(**env):
-    e = dict(os.environ, **env)
+    # the switches only exist in the diagnostic build of the library (csrc/Makefile target `diag`, -DUZL_DIAG)
+    diag = os.path.join(os.path.dirname(HERE), "uzliti_slam_amd", "libuzl_mi355x_diag.so")
+    assert os.path.exists(diag), "build the diagnostic library: make -C uzliti_slam_amd/csrc diag"
+    e = dict(os.environ, UZL_LIB=diag, **env)
     out = subprocess.run([sys.executable, os.path.join(HERE, "_ab_worker.py")], env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads(out.stdout.strip().splitlines()[-1])
@@ -23,6 +26,13 @@ def _run(**env):
 
 def test_alternative_kernel_paths_agree():
     ref = _run()
+    # the shipped library ignores the switches: same digests as the diagnostic build without any switch set
+    e = dict(os.environ, UZL_KNN2_VALU="1", UZL_VOTE_VALU="1", UZL_ML_NO_COMP4="1", UZL_ML_ADDITIVE="1")
+    e.pop("UZL_LIB", None)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_ab_worker.py")], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    shipped = json.loads(out.stdout.strip().splitlines()[-1])
+    assert shipped["match"] == ref["match"] and shipped["large"]["pcg"] == ref["large"]["pcg"] and shipped["small"]["poses"] == ref["small"]["poses"]
     valu = _run(UZL_KNN2_VALU="1", UZL_VOTE_VALU="1")
     assert valu["match"] == ref["match"], "matrix-core matcher / votes differ from the vector-ALU kernels"
     alt = _run(UZL_ML_SYNC_REBUILD="1", UZL_ML_NO_COMP4="1")

@@ -188,3 +188,41 @@ def test_errors(capi, matcher):
     with pytest.raises(capi.UzlError):
         matcher.set_config(ransac_iteration=0)
     matcher.set_config(ransac_iteration=100)
+
+
+def test_c3_full_batch_properties(capi, oracle):
+    """BASELINE config 3 at its size: 512 node pairs x 1000 ORB-256 descriptors, 500 hypotheses, one batch.  The oracle needs ~2 ms per
+    pair, so 32 evenly spaced pairs are compared bit for bit; all 512 are checked through properties: results do not depend on
+    how the pairs are batched, the estimated motion is the one the frames were generated with, inliers are the planted ones."""
+    cfg = dict(ransac_threshold=0.1, ransac_iteration=500, ransac_break_percentage=1.0, do_prosac=1, seed=777)
+    pairs = synth.make_pairs(512, n_kp=1000, desc_bytes=32, seed=777)
+    m = capi.Match(**cfg)
+    ids = [(m.add_frame(f["desc"], f["pos"], f["valid"]), m.add_frame(t["desc"], t["pos"], t["valid"])) for f, t, _ in pairs]
+    res, diag = m.estimate(ids, max_corr=1000)
+    assert res["ok"].all() and (res["iterations_run"] == 500).all()
+    # (a) batching does not matter: four batches of 128 with the same job ids give the same bytes
+    parts = [m.estimate(ids[k:k + 128], job_ids=list(range(k, k + 128)))[0] for k in range(0, 512, 128)]
+    again = np.concatenate(parts)
+    for f in ("consensus", "n_corr", "n_matches", "best_iteration", "mse", "T", "information"):
+        assert np.array_equal(res[f], again[f]), f
+    # (b) 32 pairs against the oracle, bit for bit
+    for j in range(0, 512, 16):
+        f, t, _ = pairs[j]
+        w = oracle.estimate_edge([f], [t], ransac_threshold=0.1, ransac_iteration=500, break_percentage=1.0, do_prosac=True, seed=777, job_id=j)
+        k = w["n_corr"]
+        assert res[j]["consensus"] == w["consensus"] and res[j]["n_corr"] == k and res[j]["best_iteration"] == w["best_iteration"]
+        assert np.array_equal(diag["mask"][j, :k], w["mask"]) and np.array_equal(diag["corr_query"][j, :k], w["corr_query"])
+        assert np.array_equal(res[j]["T"].reshape(3, 4), w["T"]) and res[j]["mse"] == w["mse"]
+    # (c) the motion is recovered (1 cm point noise, ~480 inliers): translation within 1 cm, rotation within 0.2 degrees
+    Tgt = np.array([p[2] for p in pairs])
+    dt, dr = synth.pose_errors(res["T"].reshape(-1, 3, 4), Tgt)
+    assert dt < 0.01 and dr < np.deg2rad(0.2), (dt, dr)
+    # (d) consensus = correspondences whose residual under the returned transform is below the threshold (recount in numpy, 1e-9 band)
+    for j in range(0, 512, 37):
+        k = res[j]["n_corr"]
+        f, t, _ = pairs[j]
+        P = t["pos"][:, diag["corr_query"][j, :k]]; Q = f["pos"][:, diag["corr_train"][j, :k]]
+        T = res[j]["T"].reshape(3, 4)
+        d = np.linalg.norm(T[:, :3] @ P + T[:, 3:4] - Q, axis=0)
+        assert np.array_equal(diag["mask"][j, :k][np.abs(d - 0.1) > 1e-9] != 0, (d < 0.1)[np.abs(d - 0.1) > 1e-9])
+    m.close()

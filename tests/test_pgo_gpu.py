@@ -430,3 +430,27 @@ def test_vertex_order_does_not_matter(capi, oracle):
             (st_no["pcg_iterations"], st_no["lm_trials"], st_5["pcg_iterations"], st_5["lm_trials"])
     finally:
         p.close()
+
+
+def test_20k_nodes_100k_edges_properties(capi):
+    """The largest graph the dense level-2 operator serves (BASELINE config 5's node count with config 4's edge density).  The
+    oracle's direct solve would take minutes; checked through properties: LM only descends, the solve is reproducible bit for
+    bit, a solve at a 100x tighter PCG tolerance lands within the parity bar of the default one, the map beats dead reckoning."""
+    g = synth.make_pose_graph(20000, 100000)
+    out = []
+    for tol in (1e-5, 1e-5, 1e-7):
+        p = capi.Pgo(pcg_tol=tol)
+        p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+        st = p.optimize(20)
+        out.append((st, p.store()[0]))
+        p.close()
+    (s0, P0), (s1, P1), (s2, P2) = out
+    assert s0["status"] == 0 and s0["iterations_done"] == 20 and s0["pcg_not_converged"] == 0
+    assert s0["chi2_final"] < 0.2 * s0["chi2_initial"]
+    assert np.array_equal(P0, P1) and s0["pcg_iterations"] == s1["pcg_iterations"]
+    dt, dr = synth.pose_errors(P0.reshape(-1, 3, 4), P2.reshape(-1, 3, 4))
+    assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+    gt = g["gt_pose"].reshape(-1, 3, 4)
+    e0 = np.linalg.norm(g["nodes_pose"].reshape(-1, 3, 4)[:, :, 3] - gt[:, :, 3], axis=1).mean()
+    e1 = np.linalg.norm(P0.reshape(-1, 3, 4)[:, :, 3] - gt[:, :, 3], axis=1).mean()
+    assert e1 < 0.1 * e0, (e0, e1)

@@ -16,7 +16,7 @@
 #include <cfloat>
 #include <cstdint>
 #include "match_types.hpp"
-#include <cstdlib>
+#include "uzl_common.hpp"
 
 namespace uzl {
 
@@ -1051,8 +1051,8 @@ void launch_knn2(const uint32_t* arena, const Combo* combos, int n_combos, int m
 {
     if (n_combos <= 0 || max_nq <= 0) return;
     dim3 grid((max_nq + kBlock - 1) / kBlock, n_combos);
-    static const bool scalar_path = getenv("UZL_KNN2_SCALAR") != nullptr;   // A/B switch: train rows by scalar loads
-    static const bool valu_path = getenv("UZL_KNN2_VALU") != nullptr;       // A/B switch: xor / popcount on the vector ALU (LDS-staged)
+    static const bool scalar_path = diag_flag("UZL_KNN2_SCALAR");   // A/B switch: train rows by scalar loads
+    static const bool valu_path = diag_flag("UZL_KNN2_VALU");       // A/B switch: xor / popcount on the vector ALU (LDS-staged)
     if (scalar_path) {
         if (has8) hipLaunchKernelGGL(knn2_kernel<8>, grid, dim3(kBlock), 0, s, arena, combos, knn);
         if (has16) hipLaunchKernelGGL(knn2_kernel<16>, grid, dim3(kBlock), 0, s, arena, combos, knn);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -12,6 +13,21 @@
 #include "../../include/uzl_mi355x.h"
 
 namespace uzl {
+
+// A/B switches (alternative kernels, preconditioner variants, scheduling constants) exist for measurements and for the tests that
+// prove the variants agree.  They are read from the environment ONLY in the diagnostic build (`make diag` -> libuzl_mi355x_diag.so,
+// -DUZL_DIAG; tests and tests/diag scripts select it with UZL_LIB); in the shipped library every one of them is a compile-time
+// constant.  Two run-time switches remain in both builds because a profiler / a debugging session needs them on the product:
+// UZL_NO_GRAPH=1 (eager launches: rocprofv3's kernel tracer cannot follow hipGraph replays on this image) and UZL_VERBOSE=1.
+#ifdef UZL_DIAG
+inline bool diag_flag(const char* name) { return getenv(name) != nullptr; }
+inline int diag_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+inline double diag_double(const char* name, double dflt) { const char* v = getenv(name); return v ? atof(v) : dflt; }
+#else
+constexpr bool diag_flag(const char*) { return false; }
+constexpr int diag_int(const char*, int dflt) { return dflt; }
+constexpr double diag_double(const char*, double dflt) { return dflt; }
+#endif
 
 struct HipError {
     hipError_t code;

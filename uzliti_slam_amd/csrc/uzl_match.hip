@@ -165,7 +165,7 @@ int do_launch(uzl_match* h, int32_t n_jobs, const uzl_pair_job* jobs, const int3
     // hipHostMalloc memory is mapped into the device's address space): no device-to-host copy operation behind the kernel
     a.results = h->h_results.p;
     a.sort_cap = next_pow2(max_nq);
-    { static const bool vv = getenv("UZL_VOTE_VALU") != nullptr; a.vote_valu = vv ? 1 : 0; }
+    { static const bool vv = diag_flag("UZL_VOTE_VALU"); a.vote_valu = vv ? 1 : 0; }
     if (h->fl_diag) {
         const size_t tot = (size_t)n_jobs * stride;
         h->d_cq.reserve(tot); h->d_ct.reserve(tot); h->d_cd.reserve(tot); h->d_mask.reserve(tot);
@@ -255,7 +255,7 @@ int enqueue_ransac(uzl_match* h, int32_t n_problems, const int32_t* offsets, con
     a.P_in = dP; a.Q_in = dQ;
     a.inlier_mask = h->d_mask.p;
     a.sort_cap = 4;
-    { static const bool vv = getenv("UZL_VOTE_VALU") != nullptr; a.vote_valu = vv ? 1 : 0; }
+    { static const bool vv = diag_flag("UZL_VOTE_VALU"); a.vote_valu = vv ? 1 : 0; }
     const int lds_points = (stride + 1) & ~1;
     a.prm.lds_points = lds_points;
     const bool in_lds = estimate_lds_bytes(a.sort_cap, iterations, lds_points, true) <= kLdsBudget;

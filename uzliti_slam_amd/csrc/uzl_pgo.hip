@@ -195,8 +195,8 @@ struct uzl_pgo {
 namespace {
 
 constexpr int kUpperNs = 4;               // Newton-Schulz steps of the dense levels above the composite level (even: the result ends in Ydense[l])
-static const bool always_refresh = getenv("UZL_ML_ALWAYS_REFRESH") != nullptr;      // A/B switch
-static const double refresh_rel = getenv("UZL_ML_REFRESH_REL") ? atof(getenv("UZL_ML_REFRESH_REL")) : 1e-3;
+static const bool always_refresh = diag_flag("UZL_ML_ALWAYS_REFRESH");      // A/B switch
+static const double refresh_rel = diag_double("UZL_ML_REFRESH_REL", 1e-3);
 
 int fail(uzl_pgo* h, int code, const char* msg)
 {
@@ -325,7 +325,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     const int nb = h->nb;
     h->ml_levels = 0; h->ml_n.assign(1, nb); h->ml_nslots.assign(1, h->nslots); h->ml_inner_aggs = 0;
     if (h->cfg.preconditioner == 0 || nb <= kMlTopMax) return;
-    static const int agg1_max = getenv("UZL_ML_AGG1_MAX") ? atoi(getenv("UZL_ML_AGG1_MAX")) : 2048;   // up to here the level-1 dense operator applies (6 n_1 <= 1536); above, AGG = 4 with the level-2 one (measured: 2500 vertices 65.7 -> 38.2 ms)
+    static const int agg1_max = diag_int("UZL_ML_AGG1_MAX", 2048);   // up to here the level-1 dense operator applies (6 n_1 <= 1536); above, AGG = 4 with the level-2 one (measured: 2500 vertices 65.7 -> 38.2 ms)
     h->ml_agg = nb <= agg1_max ? 1 : 4;
     int L = 0;
     h->ml_fan.assign(1, 1);
@@ -416,12 +416,12 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     for (int l = 1; l <= L; l++) { geo_sub[l] = geo_blob_doubles; geo_blob_doubles += (size_t)std::max(h->ml_n[l], 1) * 3; }
     const size_t o_geo_blob = take(geo_blob_doubles * 8 + 64);     // ml_cg copies levels g..L-1 with one linear loop
     // composite path: one aggregate per workgroup, at least two coarse levels, 6 n_1 <= 960 (<= 1280 free vertices)
-    static const bool comp_off = getenv("UZL_ML_NO_COMP") != nullptr;                // A/B switch
+    static const bool comp_off = diag_flag("UZL_ML_NO_COMP");                // A/B switch
     // large graphs (AGG = 4, gather level 2): the same construction one level up - the hierarchy above level 2 as one dense
     // operator (6 n_2 <= 4096: up to ~21.8k free vertices, 134 MB; measured 733 -> 332 ms at 20k / 100k, the rebuild's two
     // Newton-Schulz GEMMs take 7 ms there) that ml_cg_kernel<4> applies instead of its LDS walk
-    static const bool comp4_off = getenv("UZL_ML_NO_COMP4") != nullptr;             // A/B switch
-    static const int comp4_max = getenv("UZL_ML_COMP4_MAX") ? atoi(getenv("UZL_ML_COMP4_MAX")) : 4096;
+    static const bool comp4_off = diag_flag("UZL_ML_NO_COMP4");             // A/B switch
+    static const int comp4_max = diag_int("UZL_ML_COMP4_MAX", 4096);
     const bool comp1 = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 1536;     // ml_cg_comp_kernel<5> / <8>
     const bool comp4 = !comp_off && !comp4_off && h->ml_agg == 4 && L >= 3 && 6 * h->ml_n[2] <= comp4_max;
     h->ml_comp = comp1 || comp4;
@@ -429,13 +429,13 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     const int cl = h->ml_cl;
     std::vector<size_t> o_dense((size_t)L + 1, 0);
     if (h->ml_comp) for (int l = cl; l < L; l++) o_dense[l] = take((size_t)(6 * h->ml_n[l]) * (size_t)(6 * h->ml_n[l]) * 8);
-    static const bool mult_off = getenv("UZL_ML_ADDITIVE") != nullptr;                 // A/B switch
+    static const bool mult_off = diag_flag("UZL_ML_ADDITIVE");                 // A/B switch
     // A handle whose graphs made the multiplicative operator break down (chain-like graphs: few loop closures per vertex, the
     // shape of an online run) keeps the additive operator for its later structures instead of failing once per add_graph.
     h->ml_mult = h->ml_comp && !mult_off && !h->mult_banned;
     const size_t n12 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl + 1] * 36 * 8 : 0, n11 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl] * 36 * 8 : 0;
     const size_t o_mAP = take(n12), o_mQ = take(n12), o_mQY = take(n12), o_mAS = take(n11);
-    static const int ns_env = getenv("UZL_ML_NS_STEPS") ? atoi(getenv("UZL_ML_NS_STEPS")) : 2;
+    static const int ns_env = diag_int("UZL_ML_NS_STEPS", 2);
     h->ml_ns_steps = h->ml_mult ? std::max(0, std::min(ns_env, 4)) : 0;
     const size_t nsq = h->ml_mult ? (size_t)(6 * h->ml_n[cl]) * (size_t)(6 * h->ml_n[cl]) * 8 : 0;     // also the scratch of the levels above cl
     const size_t o_nsT = take(nsq), o_nsX = take(nsq);
@@ -775,7 +775,7 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
 // the linearisation moves and at ~1e-3 once LM has converged and b itself is rounding noise (a 1e-4 guard tripped there and threw a
 // healthy operator away); an operator that is not SPD leaves |r| of the order of |b| or above.
 constexpr double kResidualGuard = 0.25;
-static const int kGraphPairs = getenv("UZL_GRAPH_PAIRS") ? std::max(1, atoi(getenv("UZL_GRAPH_PAIRS"))) : 8;      // one graph replay = 2 x pairs PCG iterations
+static const int kGraphPairs = std::max(1, diag_int("UZL_GRAPH_PAIRS", 8));      // one graph replay = 2 x pairs PCG iterations
 
 void destroy_pcg_graph(uzl_pgo* h)
 {
@@ -822,7 +822,7 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     if (!timed) ensure_pcg_graph(h);
     int launched = 0;
     // first batch sized from the previous solve, then fixed batches; the kernels no-op once `done` is set
-    static const int first_pct = getenv("UZL_FIRST_PCT") ? atoi(getenv("UZL_FIRST_PCT")) : 95;
+    static const int first_pct = diag_int("UZL_FIRST_PCT", 95);
     int want = h->prev_pcg_iters > 0 ? std::max(2 * kGraphPairs, (h->prev_pcg_iters * first_pct) / 100) : 2 * kGraphPairs;
     while (true) {
         want = std::min(want, max_it - launched);
@@ -896,7 +896,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     // hierarchy while this iteration's PCG still uses the current one (any SPD preconditioner gives the same solution; one
     // that is one linearisation old costs a few iterations, a rebuild on the critical path costs ~0.4 ms).  The copy is
     // adopted at the start of the next iteration, which has to wait for it anyway before it overwrites H and the poses.
-    static const bool async_off = getenv("UZL_ML_SYNC_REBUILD") != nullptr;             // A/B switch
+    static const bool async_off = diag_flag("UZL_ML_SYNC_REBUILD");             // A/B switch
     // (small graphs only: at 10k vertices the rebuild's Newton-Schulz GEMMs take more from the overlapped PCG than they give back:
     // 113.2 -> 115.1 ms; config 2: 11.09 -> 10.67 ms with 540 instead of 517 PCG iterations)
     const bool async_ok = !async_off && h->ml_levels > 0 && h->ml_cl == 1 && !h->sharded && !h->timer.on && h->stream2 != nullptr;
