@@ -209,7 +209,7 @@ def pgo_rooflines(pgo, st, st_prof, kt, nodes, edges, is_default):
     if lin and lin["ms"] > 0:
         alg_l = 632.0 * E + 336.0 * st["n_vertices"]                      # B_lin = 632 E + 336 N
         out.append(roof("linearize_kernel", "hbm", alg_l * lin["launches"] / (lin["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s",
-                        traffic=traffic_of("linearize_bytes_per_launch", is_default and not agg4), algorithmic_bytes_per_launch=alg_l,
+                        traffic=traffic_of("c4_linearize_bytes_per_launch" if agg4 else "linearize_bytes_per_launch", is_default), algorithmic_bytes_per_launch=alg_l,
                         avg_launch_us=round(1e3 * lin["ms"] / lin["launches"], 3), launches=lin["launches"],
                         note="the sparse Hessian build: one lane per edge, 344 B in, two 624 B slot records out (assembly is a gather, no atomics)"))
     gm = kt.get("ml_ns_gemm")

@@ -38,10 +38,44 @@ for k, d in pmc.items():
     f = d.get("FETCH_SIZE", {}).get("mean_kb", 0.0)
     w = d.get("WRITE_SIZE", {}).get("mean_kb", 0.0)
     d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
+# the 10k/50k run: its own kernel stats; its counters only add kernels config 2 does not launch (ml_spmv_kernel<4>) or are kept
+# under a c4_ prefix
+for tag in ("c4_trace", "batch_trace", "online_trace"):
+    ks2 = sorted(glob.glob(f"{src}/{tag}/*/*kernel_stats.csv") + glob.glob(f"{src}/{tag}/*kernel_stats.csv"), key=os.path.getmtime, reverse=True)
+    if ks2:
+        shutil.copy(ks2[0], out + "_" + tag.replace("_trace", "") + "_kernel_stats.csv")
+pmc4 = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = sorted(glob.glob(f"{src}/c4_{c}/*/*counter_collection.csv"), key=os.path.getmtime, reverse=True)
+    if not fs:
+        continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != c:
+            continue
+        v = float(r["Counter_Value"])
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if v < 1.0 and ("ml_" in k or "pcg_" in k):
+            continue
+        agg[k][0] += 1
+        agg[k][1] += v
+    for k, (n, v) in agg.items():
+        pmc4.setdefault(k, {})[c] = dict(launches=n, mean_kb=v / max(n, 1))
+for k, d in pmc4.items():
+    f = d.get("FETCH_SIZE", {}).get("mean_kb", 0.0)
+    w = d.get("WRITE_SIZE", {}).get("mean_kb", 0.0)
+    d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
+    pmc["c4:" + k] = d
+    if k not in pmc:
+        pmc[k] = d
 json.dump(pmc, open(out + "_pmc.json", "w"), indent=1, sort_keys=True)
 t = {}
-for key, names in (("pcg_spmv_bytes_per_launch", ("uzl::ml_spmv_kernel<1>", "uzl::ml_spmv_kernel<4>", "uzl::ml_spmv_kernel", "uzl::pcg_spmv_kernel")),
+for key, names in (("pcg_spmv_bytes_per_launch", ("uzl::ml_spmv_kernel<1>", "uzl::pcg_spmv_kernel")),
+                   ("pcg_spmv4_bytes_per_launch", ("uzl::ml_spmv_kernel<4>",)),
+                   ("c4_linearize_bytes_per_launch", ("c4:uzl::linearize_kernel",)),
+                   ("linearize_bytes_per_launch", ("uzl::linearize_kernel",)),
                    ("knn2_bytes_per_launch", ("uzl::knn2_mfma_kernel<8, 2>", "uzl::knn2_lds_kernel<8, 1>", "uzl::knn2_kernel<8>")),
+                   ("estimate_bytes_per_launch", ("uzl::estimate_kernel",)),
                    ("wire_unpack_bytes_per_launch", ("uzl::wire_unpack_kernel",))):
     for nm in names:
         if nm in pmc:

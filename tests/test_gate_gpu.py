@@ -77,3 +77,62 @@ def test_gate_known_answers_on_gpu(capi, oracle):
     assert len(acc) == 0
     with pytest.raises(capi.UzlError):
         capi.Gate(device=99)
+
+
+def _counts(capi, g):
+    import ctypes as C
+    w = C.c_int64(); l = C.c_int64()
+    capi.lib().uzl_debug_gate_counts(g._h, C.byref(w), C.byref(l))
+    return w.value, l.value
+
+
+def test_wave_search_on_long_chains_multi_edges_and_overflow(capi, oracle):
+    """The wave-per-candidate search (open list in LDS, neighbours in parallel lanes) against the CPU checker where it differs from
+    the lane kernel structurally: paths of thousands of hops along the odometry chain (an online run's shape), a node with more
+    neighbours than a node record holds, multi-edges (the same neighbour listed twice), and a graph dense enough that an open
+    list outgrows LDS and the search is redone by the lane kernel."""
+    rng = np.random.default_rng(3)
+    # (a) chain-like: 6000 nodes, few valid loop closures; candidates between nodes thousands of hops apart
+    g = synth.make_pose_graph(6000, 6300, seed=11)
+    ed = g["edges"]
+    valid = np.where(ed["type"] == synth.EDGE_TYPE_ODOM, 1, (rng.random(len(ed["type"])) < 0.03).astype(int))     # 9 shortcuts
+    E = capi.gate_edges(ed["from"], ed["to"], ed["type"], valid=valid)
+    gt = g["gt_pose"].reshape(-1, 3, 4)
+    from uzliti_slam_amd.synth import _close_pairs
+    pr = _close_pairs(gt[:, :, 3], 0.9, 1500)[:300]
+    rel = synth.se3_mul(synth.se3_inv(gt[pr[:, 0]]), gt[pr[:, 1]])
+    c = capi.gate_edges(pr[:, 0], pr[:, 1], np.ones(len(pr), int), score=np.full(len(pr), 50.0), transform=rel.reshape(-1, 12))
+    G = capi.Gate(max_edge_distance_R=360.0); O = oracle.Gate(max_edge_distance_R=360.0)
+    G.set_graph(g["nodes_pose"], E); O.set_graph(g["nodes_pose"], E)
+    ag, vg, dg = G.check(c); ao, vo, do = O.check(c)
+    assert np.array_equal(ag, ao) and dg.tobytes() == do.tobytes()
+    assert (dg[dg < DMAX] > 100.0).sum() > 50                                 # paths of hundreds of hops (0.3 m each) were walked
+    w, l = _counts(capi, G)
+    assert w > 0 and l == 0                                                  # all of them by the wave kernel
+    G.close(); O.close()
+    # (b) a hub with 40 neighbours + every edge of the graph listed twice (two edge types between the same nodes)
+    g = synth.make_pose_graph(400, 1600, seed=12)
+    ed = g["edges"]
+    hub = np.stack([np.zeros(40, int) + 7, rng.choice(np.arange(20, 400), 40, replace=False)], 1)
+    fr = np.concatenate([ed["from"], ed["from"], hub[:, 0]]); to = np.concatenate([ed["to"], ed["to"], hub[:, 1]])
+    ty = np.concatenate([ed["type"], np.full(len(ed["type"]), 3), np.ones(40, int)])
+    E = capi.gate_edges(fr, to, ty, valid=np.ones(len(fr), int))
+    a = rng.integers(0, 400, 300); b = rng.integers(0, 400, 300); keep = a != b
+    c = capi.gate_edges(a[keep], b[keep], np.full(keep.sum(), 2), score=np.full(keep.sum(), 50.0))
+    G = capi.Gate(max_edge_distance_T=100.0, max_edge_distance_R=360.0); O = oracle.Gate(max_edge_distance_T=100.0, max_edge_distance_R=360.0)
+    G.set_graph(g["nodes_pose"], E); O.set_graph(g["nodes_pose"], E)
+    ag, vg, dg = G.check(c); ao, vo, do = O.check(c)
+    assert np.array_equal(ag, ao) and dg.tobytes() == do.tobytes()
+    G.close(); O.close()
+    # (c) dense random graph: frontiers of thousands of nodes -> some open lists overflow LDS and fall back to the lane kernel
+    n = 6000
+    P = np.tile(np.eye(3, 4).reshape(1, 12), (n, 1)); P[:, [3, 7, 11]] = rng.uniform(-30, 30, (n, 3))
+    fr = rng.integers(0, n, 60000); to = rng.integers(0, n, 60000); keep = fr != to
+    E = capi.gate_edges(fr[keep], to[keep], np.ones(keep.sum(), int), valid=np.ones(keep.sum(), int))
+    far = np.argsort(P[:, 3])                                                 # from one side of the cloud to the other, against the heuristic's grain
+    c = capi.gate_edges(far[:64], far[::-1][:64], np.full(64, 2), score=np.full(64, 50.0))
+    G = capi.Gate(max_edge_distance_T=100.0, max_edge_distance_R=360.0); O = oracle.Gate(max_edge_distance_T=100.0, max_edge_distance_R=360.0)
+    G.set_graph(P, E); O.set_graph(P, E)
+    ag, vg, dg = G.check(c); ao, vo, do = O.check(c)
+    assert np.array_equal(ag, ao) and dg.tobytes() == do.tobytes()
+    G.close(); O.close()

@@ -29,6 +29,32 @@ struct GateArgs {
     uint8_t* heur_ok;               // checkEdgeHeuristic (:1064-1085)
     double* dist;                   // astar path length, DBL_MAX = not reachable, -1 = not searched
     int32_t* overflow;              // set when a heap ran out of space
+    int32_t keep_unrun;             // 1: leave the outputs of candidates with run == 0 alone (they hold gate_wave_kernel's verdicts)
+};
+
+// ---- wave-per-candidate search (gate_wave_kernel) ----
+// one 64-byte record per node: what an expansion needs from a node in ONE load
+struct GateNodeRec {
+    double  px, py, pz;             // translation of the node's pose
+    int32_t deg;                    // number of neighbours (valid, non-laser edges)
+    int32_t adj;                    // start of the node's neighbour list in adj_nbr (for deg > kGateRecNbr)
+    int32_t nbr[8];                 // the first neighbours, in adjacency order
+};
+constexpr int kGateRecNbr = 8;
+constexpr int kGateOpenCap = 2048;  // open-list entries held in LDS per candidate; a search that needs more is redone by gate_kernel
+struct GateState { double g; int32_t st; int32_t pad; };     // per (candidate, node): g-score and 0 none / 1 open / 2 closed
+
+struct GateWaveArgs {
+    int32_t n, n_query;
+    const double* poses;            // [n][12] (checkEdgeHeuristic needs the rotations)
+    const GateNodeRec* rec;         // [n]
+    const int32_t* adj_nbr;
+    const uzl_gate_edge* cand;
+    const uint8_t* run;
+    GateState* gst;                 // [n_query][n], zeroed by the host
+    double min_score, max_T, max_R, ssf;
+    uint8_t* pre_ok; uint8_t* heur_ok; double* dist;
+    uint8_t* redo;                  // [n_query] 1 = open list overflowed: search this candidate with gate_kernel
 };
 
 }  // namespace uzl

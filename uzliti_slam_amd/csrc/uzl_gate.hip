@@ -17,6 +17,7 @@
 
 namespace uzl {
 void launch_gate(const GateArgs& a, hipStream_t s);
+void launch_gate_wave(const GateWaveArgs& a, hipStream_t s);
 }
 using namespace uzl;
 
@@ -38,6 +39,13 @@ struct uzl_gate {
     DevBuf<uzl_gate_edge> d_cand;
     DevBuf<uint8_t> d_run, d_st, d_pre, d_heur;
     DevBuf<GateHeapEnt> d_heap;
+    std::vector<GateNodeRec> rec;
+    DevBuf<GateNodeRec> d_rec;
+    DevBuf<GateState> d_gst;
+    DevBuf<uint8_t> d_redo;
+    PinBuf<uint8_t> h_redo;
+    bool lane_kernel_only = false;   // A/B (diagnostic build, UZL_GATE_LANE=1): every search through gate_kernel, as in round 1
+    int64_t n_wave = 0, n_lane = 0;  // searches run by either kernel (uzl_gate_search_counts)
     PinBuf<uint8_t> h_pre, h_heur;
     PinBuf<double> h_dist;
     PinBuf<int32_t> h_over;
@@ -76,6 +84,14 @@ void build_adjacency(uzl_gate* h)
         h->adj_nbr[fill[e.from]++] = e.to;
         if (e.to != e.from) h->adj_nbr[fill[e.to]++] = e.from;
     }
+    // node records of the wave-per-candidate search: position, degree, first neighbours in adjacency order
+    h->rec.assign((size_t)std::max(n, 1), GateNodeRec{});
+    for (int v = 0; v < n; v++) {
+        GateNodeRec& r = h->rec[v];
+        r.px = h->poses[12 * (size_t)v + 3]; r.py = h->poses[12 * (size_t)v + 7]; r.pz = h->poses[12 * (size_t)v + 11];
+        r.deg = h->adj_ptr[v + 1] - h->adj_ptr[v]; r.adj = h->adj_ptr[v];
+        for (int j = 0; j < kGateRecNbr; j++) r.nbr[j] = j < r.deg ? h->adj_nbr[h->adj_ptr[v] + j] : -1;
+    }
     h->adj_dirty = false;
 }
 
@@ -112,6 +128,7 @@ int uzl_gate_create(const uzl_gate_cfg* cfg, uzl_gate** out)
     uzl_gate* h = new (std::nothrow) uzl_gate();
     if (!h) return UZL_ERR_OOM;
     h->cfg = c;
+    h->lane_kernel_only = diag_flag("UZL_GATE_LANE");
     if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return UZL_ERR_HIP;
@@ -178,6 +195,8 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
             h->d_adj_ptr.reserve(h->adj_ptr.size()); h->d_adj_nbr.reserve(h->adj_nbr.size());
             UZL_HIP(hipMemcpyAsync(h->d_adj_ptr.p, h->adj_ptr.data(), h->adj_ptr.size() * 4, hipMemcpyHostToDevice, s));
             UZL_HIP(hipMemcpyAsync(h->d_adj_nbr.p, h->adj_nbr.data(), h->adj_nbr.size() * 4, hipMemcpyHostToDevice, s));
+            h->d_rec.reserve(h->rec.size());
+            UZL_HIP(hipMemcpyAsync(h->d_rec.p, h->rec.data(), h->rec.size() * sizeof(GateNodeRec), hipMemcpyHostToDevice, s));
             UZL_HIP(hipStreamSynchronize(s));
         }
         const int32_t last = std::min(nc, first + kChunk);
@@ -190,12 +209,44 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
             if (ok) ok = h->pair_type.count(std::make_tuple(std::min(c.from, c.to), std::max(c.from, c.to), c.type)) == 0;
             run[k] = ok ? 1 : 0;
         }
-        const int heap_cap = (int)std::min<size_t>((size_t)h->adj_nbr.size() + (size_t)n + 1024, (size_t)1 << 28);
-        h->d_gs.reserve((size_t)m * std::max(n, 1)); h->d_st.reserve((size_t)m * std::max(n, 1));
-        h->d_heap.reserve((size_t)m * heap_cap);
-        UZL_HIP(hipMemsetAsync(h->d_st.p, 0, (size_t)m * std::max(n, 1), s));
-        UZL_HIP(hipMemsetAsync(h->d_over.p, 0, 4, s));
         UZL_HIP(hipMemcpyAsync(h->d_run.p + first, run.data() + first, (size_t)m, hipMemcpyHostToDevice, s));
+        // ---- one wave per candidate, open list in LDS
+        h->d_gst.reserve((size_t)m * std::max(n, 1)); h->d_redo.reserve((size_t)nc); h->h_redo.reserve((size_t)nc);
+        UZL_HIP(hipMemsetAsync(h->d_gst.p, 0, sizeof(GateState) * (size_t)m * std::max(n, 1), s));
+        GateWaveArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.n = n; wa.n_query = m; wa.poses = h->d_poses.p; wa.rec = h->d_rec.p; wa.adj_nbr = h->d_adj_nbr.p;
+        wa.cand = h->d_cand.p + first; wa.run = h->d_run.p + first; wa.gst = h->d_gst.p;
+        wa.min_score = h->cfg.min_matching_score; wa.max_T = h->cfg.max_edge_distance_T; wa.max_R = h->cfg.max_edge_distance_R;
+        wa.ssf = h->cfg.scope_size_factor;
+        wa.pre_ok = h->d_pre.p + first; wa.heur_ok = h->d_heur.p + first; wa.dist = h->d_dist.p + first; wa.redo = h->d_redo.p + first;
+        if (!h->lane_kernel_only) {
+            launch_gate_wave(wa, s);
+            UZL_HIP(hipGetLastError());
+            UZL_HIP(hipMemcpyAsync(h->h_redo.p + first, h->d_redo.p + first, (size_t)m, hipMemcpyDeviceToHost, s));
+            UZL_HIP(hipStreamSynchronize(s));
+        }
+        bool any_redo = h->lane_kernel_only;
+        for (int32_t k = first; k < last && !any_redo; k++) any_redo = h->h_redo.p[k] != 0;
+        for (int32_t k = first; k < last; k++) {
+            if (!run[k]) continue;
+            if (h->lane_kernel_only || h->h_redo.p[k]) h->n_lane++; else h->n_wave++;
+        }
+        if (any_redo) {
+            // candidates whose open list outgrew LDS (or all of them under the A/B switch): the lane kernel with its heap in HBM.
+            // Its outputs overwrite pre_ok / heur_ok / dist of every candidate it runs for.
+            std::vector<uint8_t> run2((size_t)m);
+            for (int32_t k = 0; k < m; k++) run2[k] = (run[first + k] && (h->lane_kernel_only || h->h_redo.p[first + k])) ? 1 : 0;
+            UZL_HIP(hipMemcpyAsync(h->d_run.p + first, run2.data(), (size_t)m, hipMemcpyHostToDevice, s));
+            UZL_HIP(hipStreamSynchronize(s));
+        }
+        const int heap_cap = (int)std::min<size_t>((size_t)h->adj_nbr.size() + (size_t)n + 1024, (size_t)1 << 28);
+        if (any_redo) {
+            h->d_gs.reserve((size_t)m * std::max(n, 1)); h->d_st.reserve((size_t)m * std::max(n, 1));
+            h->d_heap.reserve((size_t)m * heap_cap);
+            UZL_HIP(hipMemsetAsync(h->d_st.p, 0, (size_t)m * std::max(n, 1), s));
+        }
+        UZL_HIP(hipMemsetAsync(h->d_over.p, 0, 4, s));
         GateArgs a;
         memset(&a, 0, sizeof(a));
         a.n = n; a.n_query = m; a.poses = h->d_poses.p; a.adj_ptr = h->d_adj_ptr.p; a.adj_nbr = h->d_adj_nbr.p;
@@ -204,7 +255,8 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
         a.min_score = h->cfg.min_matching_score; a.max_T = h->cfg.max_edge_distance_T; a.max_R = h->cfg.max_edge_distance_R;
         a.ssf = h->cfg.scope_size_factor;
         a.pre_ok = h->d_pre.p + first; a.heur_ok = h->d_heur.p + first; a.dist = h->d_dist.p + first; a.overflow = h->d_over.p;
-        launch_gate(a, s);
+        a.keep_unrun = h->lane_kernel_only ? 0 : 1;
+        if (any_redo) launch_gate(a, s);
         UZL_HIP(hipGetLastError());
         UZL_HIP(hipMemcpyAsync(h->h_pre.p + first, h->d_pre.p + first, (size_t)m, hipMemcpyDeviceToHost, s));
         UZL_HIP(hipMemcpyAsync(h->h_heur.p + first, h->d_heur.p + first, (size_t)m, hipMemcpyDeviceToHost, s));
@@ -232,6 +284,16 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
     }
     return UZL_OK;
     UZL_GUARD_END(h)
+}
+
+// parity tests / diagnostics (not part of include/uzl_mi355x.h): searches run so far by the wave kernel and by the lane kernel
+int uzl_debug_gate_counts(uzl_gate* h, int64_t* n_wave, int64_t* n_lane)
+{
+    if (!h) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (n_wave) *n_wave = h->n_wave;
+    if (n_lane) *n_lane = h->n_lane;
+    return UZL_OK;
 }
 
 int uzl_gate_edge_count(uzl_gate* h)
