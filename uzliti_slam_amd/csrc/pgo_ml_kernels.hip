@@ -1003,47 +1003,67 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         const int A1 = blockIdx.x * kAggPerBlk + tid / 3;
         sg1[tid] = (gl == 2 && A1 < H.n[1]) ? H.geo[1][(size_t)A1 * 3 + tid % 3] : 0.;
     }
-    int s0[kRowsPerWave], s1[kRowsPerWave], cf[kRowsPerWave];       // slot range and this lane group's first column: ONE hop (row header)
+    // slot range and this lane group's columns of the first TWO slot passes: ONE hop (row header).  Rows have ~10 slots on the
+    // BASELINE graphs, i.e. four in ten need a second pass; with its column already here the second pass is one more round trip
+    // instead of two per row (column index, then block and vectors), and rows of a wave take it together instead of one by one.
+    int s0[kRowsPerWave], s1[kRowsPerWave], cf[kRowsPerWave], cf2[kRowsPerWave];
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) {
         const int a = row0 + q;
-        const int32_t* __restrict__ hd = D.rowhdr + (size_t)(a < D.nb ? a : 0) * 12;
+        const int32_t* __restrict__ hd = D.rowhdr + (size_t)(a < D.nb ? a : 0) * kRowHdr;
         s0[q] = (a < D.nb) ? hd[0] : 0;
         s1[q] = (a < D.nb) ? hd[1] : 0;
         cf[q] = (a < D.nb && lact) ? hd[2 + g] : -1;
+        cf2[q] = (a < D.nb && lact) ? hd[12 + g] : -1;
     }
-    // lane group q (< 4) owns the diagonal block, z, p_old and geometry of row q
-    double hrow[6] = {0, 0, 0, 0, 0, 0}, zo[6] = {0, 0, 0, 0, 0, 0}, po[6] = {0, 0, 0, 0, 0, 0}, geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // Every lane (g, r) multiplies row r of a 6x6 block with the 6-vector z + beta p_old of the block's column.  The six lanes of a
+    // group need the same vector: each loads ONE component (the six loads of a group are one contiguous 48 B) and the vector is
+    // assembled by shuffles - 4 VGPRs per (row, pass) instead of 24, which is what lets a second workgroup share the CU (the kernel
+    // is latency-bound: 313 workgroups of a 10k graph on 256 CUs took two rounds).  Same products, same summation order.
+    const int gbase = g * 6;                      // first lane of this lane's group
+    // lane group q (< AGG) owns the diagonal block, z, p_old and geometry of row q
+    double hrow[6] = {0, 0, 0, 0, 0, 0}, zo_r = 0., po_r = 0.;
     const int arow = row0 + g;
     const bool dact = g < kRowsPerWave && arow < D.nb;
     if (dact) {
         const double* __restrict__ h = D.hdiag + (size_t)arow * 36 + r * 6;
-        const double* __restrict__ zv = D.z + (size_t)arow * 6;
-        const double* __restrict__ pv = p_old + (size_t)arow * 6;
-        const double* __restrict__ gg = H.geo0 + (size_t)arow * 12;
 #pragma unroll
-        for (int c = 0; c < 6; c++) { hrow[c] = h[c]; zo[c] = zv[c]; po[c] = pv[c]; }
-#pragma unroll
-        for (int c = 0; c < 12; c++) geo[c] = gg[c];
+        for (int c = 0; c < 6; c++) hrow[c] = h[c];
+        zo_r = D.z[(size_t)arow * 6 + r]; po_r = p_old[(size_t)arow * 6 + r];
     }
     // first slot pass of every row (rows have ~10 slots: most rows need exactly this pass)
-    double2 b0[kRowsPerWave], b1[kRowsPerWave], b2[kRowsPerWave], z0[kRowsPerWave], z1[kRowsPerWave], z2[kRowsPerWave],
-        o0[kRowsPerWave], o1[kRowsPerWave], o2[kRowsPerWave];
+    double2 b0[kRowsPerWave], b1[kRowsPerWave], b2[kRowsPerWave];
+    double zr[kRowsPerWave], orr[kRowsPerWave];
     bool have[kRowsPerWave];
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) {
-        have[q] = false;
+        have[q] = false; zr[q] = 0.; orr[q] = 0.;
         const int s = s0[q] + g;
         if (lact && s < s1[q]) {
             const int c = cf[q];
             if (c >= 0) {
                 have[q] = true;
                 const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
-                const double2* __restrict__ zv = reinterpret_cast<const double2*>(D.z + (size_t)c * 6);
-                const double2* __restrict__ pv = reinterpret_cast<const double2*>(p_old + (size_t)c * 6);
                 b0[q] = bk[0]; b1[q] = bk[1]; b2[q] = bk[2];
-                z0[q] = zv[0]; z1[q] = zv[1]; z2[q] = zv[2];
-                o0[q] = pv[0]; o1[q] = pv[1]; o2[q] = pv[2];
+                zr[q] = D.z[(size_t)c * 6 + r]; orr[q] = p_old[(size_t)c * 6 + r];
+            }
+        }
+    }
+    // second slot pass: one row per wave (AGG = 1) has the registers to fetch it up front as well
+    double2 c0[kRowsPerWave], c1[kRowsPerWave], c2[kRowsPerWave];
+    double yr[kRowsPerWave], qr[kRowsPerWave];
+    bool have2[kRowsPerWave];
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) {
+        have2[q] = false; yr[q] = 0.; qr[q] = 0.;
+        if (AGG == 1) {
+            const int s = s0[q] + g + 10;
+            const int c = cf2[q];
+            if (lact && s < s1[q] && c >= 0) {
+                have2[q] = true;
+                const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
+                c0[q] = bk[0]; c1[q] = bk[1]; c2[q] = bk[2];
+                yr[q] = D.z[(size_t)c * 6 + r]; qr[q] = p_old[(size_t)c * 6 + r];
             }
         }
     }
@@ -1053,38 +1073,73 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     const double beta = (it == 0) ? 0. : rz / rz_prev;
     const double thresh = (it == 0) ? tol2 * rz : thr_old;
     STAMP(16);     // 17: partial reduction (prefetch landed)
-    // ---- row products
-    double pr = 0.;
+    // ---- row products: diagonal block + first slot pass of every row ...
+    const double pr = zo_r + beta * po_r;             // component r of the new direction of row `arow` (lanes with dact)
     double acc[kRowsPerWave];
+    {
+        const double d0 = __shfl(pr, gbase), d1 = __shfl(pr, gbase + 1), d2 = __shfl(pr, gbase + 2), d3 = __shfl(pr, gbase + 3),
+                     d4 = __shfl(pr, gbase + 4), d5 = __shfl(pr, gbase + 5);
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; q++) {
+            double aq = 0.;
+            if (dact && g == q) {
+                aq += hrow[0] * d0; aq += hrow[1] * d1; aq += hrow[2] * d2; aq += hrow[3] * d3; aq += hrow[4] * d4; aq += hrow[5] * d5;
+                aq += lambda * pr;
+                if (!D.diag_owner) aq = 0.;           // sharded solve: the diagonal term is added by one rank only
+                p_new[(size_t)arow * 6 + r] = pr;
+            }
+            const double pc = zr[q] + beta * orr[q];
+            const double v0 = __shfl(pc, gbase), v1 = __shfl(pc, gbase + 1), v2 = __shfl(pc, gbase + 2), v3 = __shfl(pc, gbase + 3),
+                         v4 = __shfl(pc, gbase + 4), v5 = __shfl(pc, gbase + 5);
+            if (have[q]) aq += b0[q].x * v0 + b0[q].y * v1 + b1[q].x * v2 + b1[q].y * v3 + b2[q].x * v4 + b2[q].y * v5;
+            acc[q] = aq;
+        }
+    }
+    // ... the second pass of all rows of the wave in one round trip (AGG > 1: into the registers the first pass has just freed) ...
+    if (AGG != 1) {
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; q++) {
+            const int s = s0[q] + g + 10;
+            const int c = cf2[q];
+            if (lact && s < s1[q] && c >= 0) {
+                have2[q] = true;
+                const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
+                c0[q] = bk[0]; c1[q] = bk[1]; c2[q] = bk[2];
+                yr[q] = D.z[(size_t)c * 6 + r]; qr[q] = p_old[(size_t)c * 6 + r];
+            }
+        }
+    }
+    // ... then whatever a long row has beyond 20 slots, and the folds (same summation order as a slot-by-slot walk)
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) {
-        double aq = 0.;
-        if (dact && g == q) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                const double pc = zo[c] + beta * po[c];
-                aq += hrow[c] * pc;
-                if (c == r) pr = pc;
-            }
-            aq += lambda * pr;
-            if (!D.diag_owner) aq = 0.;           // sharded solve: the diagonal term is added by one rank only
-            p_new[(size_t)arow * 6 + r] = pr;
+        double aq = acc[q];
+        {
+            const double pc = yr[q] + beta * qr[q];
+            const double v0 = __shfl(pc, gbase), v1 = __shfl(pc, gbase + 1), v2 = __shfl(pc, gbase + 2), v3 = __shfl(pc, gbase + 3),
+                         v4 = __shfl(pc, gbase + 4), v5 = __shfl(pc, gbase + 5);
+            if (have2[q]) aq += c0[q].x * v0 + c0[q].y * v1 + c1[q].x * v2 + c1[q].y * v3 + c2[q].x * v4 + c2[q].y * v5;
         }
-        if (have[q])
-            aq += b0[q].x * (z0[q].x + beta * o0[q].x) + b0[q].y * (z0[q].y + beta * o0[q].y) + b1[q].x * (z1[q].x + beta * o1[q].x) +
-                  b1[q].y * (z1[q].y + beta * o1[q].y) + b2[q].x * (z2[q].x + beta * o2[q].x) + b2[q].y * (z2[q].y + beta * o2[q].y);
-        if (lact) {
-            for (int s = s0[q] + g + 10; s < s1[q]; s += 10) {
+        // rows with more than 20 slots are rare (hubs): the wave walks their remaining passes together (a uniform trip count, so
+        // that the shuffles stay convergent)
+        const int smax = __builtin_amdgcn_readfirstlane(s1[q]);
+        for (int sb = s0[q] + 20; sb < smax; sb += 10) {
+            const int s = sb + g;
+            double2 e0 = make_double2(0., 0.), e1 = e0, e2 = e0;
+            double wz = 0., wp = 0.;
+            bool hv = false;
+            if (lact && s < s1[q]) {
                 const int c = D.col[s];
                 if (c >= 0) {
+                    hv = true;
                     const double2* __restrict__ bk = reinterpret_cast<const double2*>(D.blk + (size_t)s * 36 + r * 6);
-                    const double2* __restrict__ zv = reinterpret_cast<const double2*>(D.z + (size_t)c * 6);
-                    const double2* __restrict__ pv = reinterpret_cast<const double2*>(p_old + (size_t)c * 6);
-                    const double2 c0 = bk[0], c1 = bk[1], c2 = bk[2], y0 = zv[0], y1 = zv[1], y2 = zv[2], q0 = pv[0], q1 = pv[1], q2 = pv[2];
-                    aq += c0.x * (y0.x + beta * q0.x) + c0.y * (y0.y + beta * q0.y) + c1.x * (y1.x + beta * q1.x) +
-                          c1.y * (y1.y + beta * q1.y) + c2.x * (y2.x + beta * q2.x) + c2.y * (y2.y + beta * q2.y);
+                    e0 = bk[0]; e1 = bk[1]; e2 = bk[2];
+                    wz = D.z[(size_t)c * 6 + r]; wp = p_old[(size_t)c * 6 + r];
                 }
             }
+            const double pc = wz + beta * wp;
+            const double v0 = __shfl(pc, gbase), v1 = __shfl(pc, gbase + 1), v2 = __shfl(pc, gbase + 2), v3 = __shfl(pc, gbase + 3),
+                         v4 = __shfl(pc, gbase + 4), v5 = __shfl(pc, gbase + 5);
+            if (hv) aq += e0.x * v0 + e0.y * v1 + e1.x * v2 + e1.y * v3 + e2.x * v4 + e2.y * v5;
         }
         double t;
         t = __shfl_down(aq, 48); if (lane + 48 < 60) aq += t;
@@ -1094,6 +1149,12 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         acc[q] = aq;                               // lanes 0..5: (A p)[row q][0..5]
     }
     STAMP(16);     // 18: row products + folds
+    double geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};         // geometry of row `arow`: fetched here, not held across the row products
+    if (dact) {
+        const double* __restrict__ gg = H.geo0 + (size_t)arow * 12;
+#pragma unroll
+        for (int c = 0; c < 12; c++) geo[c] = gg[c];
+    }
     double dot = 0.;
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) {
@@ -1141,8 +1202,9 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_stamps[47], 1ull);
 #endif
 }
+// 4 waves per SIMD = two 512-lane workgroups per CU (<= 128 VGPRs; the body needs 96 at AGG = 1 and ~144 unconstrained at AGG = 4)
 template <int AGG>
-__global__ __launch_bounds__(512) void ml_spmv_kernel(PgoDev D, MlHot H, const double* __restrict__ p_old, double* __restrict__ p_new, int n_part, double tol2)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void ml_spmv_kernel(PgoDev D, MlHot H, const double* __restrict__ p_old, double* __restrict__ p_new, int n_part, double tol2)
 {
     ml_spmv_kernel_body<AGG>(D, H, p_old, p_new, n_part, tol2);
 }

@@ -16,6 +16,7 @@
 namespace uzl {
 
 constexpr int kMaxPartials = 4096;
+constexpr int kRowHdr = 24;          // ints per row header (96 B: one and a half cache lines)
 
 struct PgoDev {
     int32_t n, nb, e, nslots;
@@ -36,7 +37,7 @@ struct PgoDev {
     const int32_t* slot_j;
     const int32_t* row_ptr;  // [nb+1]
     const int32_t* col;      // [nslots]
-    const int32_t* rowhdr;   // [nb][12] = {row_ptr[a], row_ptr[a+1], col of the first 10 slots (-1 past the end)}: one hop instead of two
+    const int32_t* rowhdr;   // [nb][kRowHdr] = {row_ptr[a], row_ptr[a+1], col of the first 20 slots (-1 past the end), pad}: one hop instead of two
     double* blk;
     double* dcon;
     double* gcon;

@@ -687,13 +687,13 @@ void build_structure(uzl_pgo* h)
     if (nb > 0) UZL_HIP(hipMemcpyAsync(h->d_b2v.p, b2v.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, s));
     UZL_HIP(hipMemcpyAsync(h->d_row_ptr.p, row_ptr.data(), sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice, s));
     if (nslots > 0) UZL_HIP(hipMemcpyAsync(h->d_col.p, col.data(), sizeof(int32_t) * nslots, hipMemcpyHostToDevice, s));
-    std::vector<int32_t> rowhdr((size_t)nbz * 12, -1);
+    std::vector<int32_t> rowhdr((size_t)nbz * kRowHdr, -1);
     for (int a = 0; a < nb; a++) {
-        rowhdr[(size_t)a * 12] = row_ptr[a]; rowhdr[(size_t)a * 12 + 1] = row_ptr[a + 1];
-        for (int k = 0; k < 10 && row_ptr[a] + k < row_ptr[a + 1]; k++) rowhdr[(size_t)a * 12 + 2 + k] = col[row_ptr[a] + k];
+        rowhdr[(size_t)a * kRowHdr] = row_ptr[a]; rowhdr[(size_t)a * kRowHdr + 1] = row_ptr[a + 1];
+        for (int k = 0; k < 20 && row_ptr[a] + k < row_ptr[a + 1]; k++) rowhdr[(size_t)a * kRowHdr + 2 + k] = col[row_ptr[a] + k];
     }
-    h->d_rowhdr.reserve(nbz * 12);
-    UZL_HIP(hipMemcpyAsync(h->d_rowhdr.p, rowhdr.data(), sizeof(int32_t) * nbz * 12, hipMemcpyHostToDevice, s));
+    h->d_rowhdr.reserve(nbz * kRowHdr);
+    UZL_HIP(hipMemcpyAsync(h->d_rowhdr.p, rowhdr.data(), sizeof(int32_t) * nbz * kRowHdr, hipMemcpyHostToDevice, s));
     if (e > 0) {
         UZL_HIP(hipMemcpyAsync(h->d_slot_i.p, slot_i.data(), sizeof(int32_t) * e, hipMemcpyHostToDevice, s));
         UZL_HIP(hipMemcpyAsync(h->d_slot_j.p, slot_j.data(), sizeof(int32_t) * e, hipMemcpyHostToDevice, s));
