@@ -292,7 +292,7 @@ void uzlo_pose_svd(const double* P, const double* Q, const int32_t* idx, int32_t
  * CMakeLists.txt:9, no FMA), Eigen 3.2 evaluates `T * P.colwise().homogeneous()` as linear() * P (3 x 3 times 3 x M through the
  * general product: acc += R(r,k) * p(k) for k = 0, 1, 2, every product and sum rounded) and then adds the translation;
  * `(P - Q).colwise().norm()` is sqrt((dx*dx + dy*dy) + dz*dz).  The two differ by an ulp or two of the distance, i.e. only a
- * point within ~1e-17 m of the threshold can vote differently; tests/test_oracle_match.py counts how often that happens. */
+ * point within ~1e-16 m of the threshold can vote differently; tests/test_oracle_match.py counts how often that happens. */
 static int g_vote_recipe = 0;
 void uzlo_set_vote_recipe(int32_t r) { g_vote_recipe = r; }
 

@@ -226,4 +226,4 @@ def test_vote_recipe_fused_vs_reference_order(oracle):
         oracle.set_vote_recipe(0)
     assert tests > 4e7
     assert diffs == 0, (diffs, tests)
-    assert margin > 1e-13            # the closest any point came to the threshold: orders of magnitude above the recipes' ~1e-17 m difference
+    assert margin > 1e-13            # the closest any point came to the threshold: orders of magnitude above the recipes' ~1e-16 m difference
