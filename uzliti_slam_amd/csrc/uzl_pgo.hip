@@ -435,8 +435,13 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     h->ml_mult = h->ml_comp && !mult_off && !h->mult_banned;
     const size_t n12 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl + 1] * 36 * 8 : 0, n11 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl] * 36 * 8 : 0;
     const size_t o_mAP = take(n12), o_mQ = take(n12), o_mQY = take(n12), o_mAS = take(n11);
-    static const int ns_env = diag_int("UZL_ML_NS_STEPS", 2);
-    h->ml_ns_steps = h->ml_mult ? std::max(0, std::min(ns_env, 4)) : 0;
+    // Newton-Schulz steps of the composite operator per rebuild: 2; 4 on large loopy graphs (AGG = 4, >= 6 slots per row), where two
+    // more GEMM pairs per rebuild buy a quarter of the PCG iterations (10k/50k 1882 -> 1455 per solve, 107.7 -> 94.1 ms; 5k/25k 68.6 ->
+    // 62.3; 20k/100k 242 -> 224) - on chain-like graphs of that size they cost more than they save (20k/21.7k: 209 -> 261 ms), on
+    // small graphs the count barely moves (config 2: 538 -> 511 for +0.3 ms).  tests/diag/ns_sweep.sh
+    static const int ns_env = diag_int("UZL_ML_NS_STEPS", -1);
+    const int ns_auto = (h->ml_agg == 4 && h->nslots >= 6 * nb) ? 4 : 2;
+    h->ml_ns_steps = h->ml_mult ? std::max(0, std::min(ns_env >= 0 ? ns_env : ns_auto, 4)) : 0;
     const size_t nsq = h->ml_mult ? (size_t)(6 * h->ml_n[cl]) * (size_t)(6 * h->ml_n[cl]) * 8 : 0;     // also the scratch of the levels above cl
     const size_t o_nsT = take(nsq), o_nsX = take(nsq);
     // slot ranges by parent aggregate, for every level the multiplicative cycle is built at (cl .. L-1): [n_l*n_{l+1}] begin | end
