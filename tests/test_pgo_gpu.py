@@ -454,3 +454,42 @@ def test_20k_nodes_100k_edges_properties(capi):
     e0 = np.linalg.norm(g["nodes_pose"].reshape(-1, 3, 4)[:, :, 3] - gt[:, :, 3], axis=1).mean()
     e1 = np.linalg.norm(P0.reshape(-1, 3, 4)[:, :, 3] - gt[:, :, 3], axis=1).mean()
     assert e1 < 0.1 * e0, (e0, e1)
+
+
+def test_structure_is_kept_when_only_values_change(capi, oracle):
+    """A re-optimisation of a graph whose vertices, fixed flags, system edges and edge weights did not change (the timer-driven
+    optimize() of graph_slam_node.cpp:1138-1150 on an unchanged or merely moved graph) keeps gauge, block-CSR, hierarchy arrays and
+    the captured PCG graph; any structural change rebuilds.  Either way the result is the one a fresh handle computes."""
+    g = synth.make_pose_graph(1200, 5000, seed=21)
+    p = capi.Pgo()
+    p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    s1 = p.optimize(6)
+    assert s1["structure_reused"] == 0 and s1["structure_ms"] > 0
+    # same topology, moved poses and measurements
+    g2 = dict(g); g2["nodes_pose"] = p.store()[0]
+    e2 = {k: np.array(v) for k, v in g["edges"].items()}
+    e2["transform"] = e2["transform"] + 1e-3 * np.random.default_rng(0).normal(size=e2["transform"].shape) * (np.arange(12) % 4 == 3)
+    g2["edges"] = e2
+    p.add_graph(g2["nodes_pose"], g2["nodes_fixed"], g2["edges"])
+    s2 = p.optimize(6)
+    assert s2["structure_reused"] == 1 and s2["structure_ms"] < 0.25 * s1["structure_ms"]
+    fresh = capi.Pgo()
+    fresh.add_graph(g2["nodes_pose"], g2["nodes_fixed"], g2["edges"])
+    sf = fresh.optimize(6)
+    assert np.array_equal(p.store()[0], fresh.store()[0]) and s2["pcg_iterations"] == sf["pcg_iterations"]
+    _check(fresh, oracle, g2, iterations=6)
+    # one edge fewer: rebuilt
+    e3 = {k: np.asarray(v)[:-1] for k, v in e2.items()}
+    p.add_graph(g2["nodes_pose"], g2["nodes_fixed"], e3)
+    s3 = p.optimize(3)
+    assert s3["structure_reused"] == 0 and s3["n_edges"] == s2["n_edges"] - 1
+    # the same last edge present but not valid (TransformationFilter verdict): the SAME system as without it - kept
+    e4 = {k: np.array(v) for k, v in e2.items()}
+    e4["valid"][-1] = 0
+    p.add_graph(g2["nodes_pose"], g2["nodes_fixed"], e4)
+    assert p.optimize(3)["structure_reused"] == 1
+    # another edge loses its verdict: rebuilt
+    e4["valid"][-2] = 0
+    p.add_graph(g2["nodes_pose"], g2["nodes_fixed"], e4)
+    assert p.optimize(3)["structure_reused"] == 0
+    p.close(); fresh.close()

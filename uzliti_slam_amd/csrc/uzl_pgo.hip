@@ -1040,6 +1040,28 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 
 }  // namespace
 
+// what the structure of a handle was built from (moved out before a new graph is read in, compared afterwards)
+struct StructureKey {
+    bool ready = false;
+    int32_t n = 0;
+    std::vector<uint8_t> fixed_in, robust;
+    std::vector<int32_t> ij;
+    std::vector<double> edge_w;
+};
+static StructureKey take_structure_key(uzl_pgo* h)
+{
+    StructureKey k;
+    k.ready = h->structure_ready && h->have_graph;
+    if (!k.ready) return k;
+    k.n = h->n;
+    k.fixed_in.swap(h->fixed_in); k.robust.swap(h->robust); k.ij.swap(h->ij); k.edge_w.swap(h->edge_w);
+    return k;
+}
+static bool same_structure(const uzl_pgo* h, const StructureKey& k)
+{
+    return k.ready && k.n == h->n && k.fixed_in == h->fixed_in && k.ij == h->ij && k.robust == h->robust && k.edge_w == h->edge_w;
+}
+
 #define UZL_GUARD_BEGIN(h)                       \
     if (!(h)) return UZL_ERR_BAD_ARG;            \
     std::lock_guard<std::mutex> lock_((h)->mu);  \
@@ -1137,7 +1159,12 @@ int uzl_pgo_add_graph(uzl_pgo* h, int32_t n_nodes, const uzl_node* nodes, int32_
         (n_sensors > 0 && !sensors))
         return fail(h, UZL_ERR_BAD_ARG, "null or negative-size input");
     UZL_HIP(hipSetDevice(h->cfg.device));
-    h->have_graph = false; h->structure_ready = false;         // clear() (:57)
+    // clear() (:57): the reference rebuilds everything.  Here the structure of the previous graph (gauge, block-CSR, aggregation order,
+    // hierarchy arrays, captured PCG graph) is kept when the new graph has the same vertices, fixed flags, system edges and edge
+    // weights - a timer-driven re-optimisation of an unchanged graph, or one whose poses / measurements only moved - and rebuilt
+    // otherwise; either way the solve is the one a fresh handle would run (same order, same operators).
+    StructureKey old_key = take_structure_key(h);
+    h->have_graph = false; h->structure_ready = false;
     h->n = n_nodes; h->e_in = n_edges;
     h->fixed_in.assign((size_t)n_nodes, 0);
     for (int v = 0; v < n_nodes; v++) h->fixed_in[v] = nodes[v].fixed ? 1 : 0;
@@ -1181,6 +1208,7 @@ int uzl_pgo_add_graph(uzl_pgo* h, int32_t n_nodes, const uzl_node* nodes, int32_
     UZL_HIP(hipStreamSynchronize(s));                          // inputs are borrowed for the duration of the call only
     upload_edges_common(h);
     h->have_graph = true;
+    h->structure_ready = same_structure(h, old_key);
     return UZL_OK;
     UZL_GUARD_END(h)
 }
@@ -1195,6 +1223,7 @@ int uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t*
         if (ij[2 * k] < 0 || ij[2 * k] >= n || ij[2 * k + 1] < 0 || ij[2 * k + 1] >= n || ij[2 * k] == ij[2 * k + 1])
             return fail(h, UZL_ERR_BAD_ARG, "edge endpoint out of range");
     UZL_HIP(hipSetDevice(h->cfg.device));
+    StructureKey old_key = take_structure_key(h);
     h->have_graph = false; h->structure_ready = false;
     h->n = n; h->e_in = e; h->e = e;
     h->fixed_in.assign(fixed, fixed + n);
@@ -1224,6 +1253,7 @@ int uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t*
     UZL_HIP(hipStreamSynchronize(s));
     upload_edges_common(h);
     h->have_graph = true;
+    h->structure_ready = same_structure(h, old_key);
     return UZL_OK;
     UZL_GUARD_END(h)
 }
