@@ -245,14 +245,23 @@ def vote_recipe_diff(P, Q, max_error, iterations, do_prosac=True, seed=0, job_id
     return nt.value, nd.value, mm.value
 
 
+class PreparedPairs:
+    """Frame structs of a list of (frame_from, frame_to), built once: timing a batch must not time this Python loop."""
+
+    def __init__(self, pairs):
+        self.n = len(pairs)
+        self.af, self._k1 = _mk_frames([p[0] for p in pairs])
+        self.at, self._k2 = _mk_frames([p[1] for p in pairs])
+
+
 def estimate_edge_batch(pairs, ransac_threshold=0.2, ransac_iteration=100, break_percentage=0.6, do_prosac=True, seed=0,
                         job_id0=0, threads=1, native=True):
     """bench.py's all-core matching baseline: pairs = [(frame_from, frame_to), ...], `threads` estimator threads inside the
     -march=native / OpenMP build.  Returns (ok, consensus) arrays."""
-    af, k1 = _mk_frames([p[0] for p in pairs]); at, k2 = _mk_frames([p[1] for p in pairs])
-    res = (EdgeResult * len(pairs))()
+    prep = pairs if isinstance(pairs, PreparedPairs) else PreparedPairs(pairs)
+    res = (EdgeResult * prep.n)()
     L = native_lib() if native else lib()
-    L.uzlo_estimate_edge_batch(C.c_int32(len(pairs)), af, at, C.c_double(ransac_threshold), C.c_int32(ransac_iteration),
+    L.uzlo_estimate_edge_batch(C.c_int32(prep.n), prep.af, prep.at, C.c_double(ransac_threshold), C.c_int32(ransac_iteration),
                                C.c_double(break_percentage), C.c_int32(1 if do_prosac else 0), C.c_uint64(seed), C.c_uint64(job_id0),
                                C.c_int32(threads), res)
     return np.array([r.ok for r in res]), np.array([r.consensus for r in res])
