@@ -1211,8 +1211,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void m
 
 // init = 1: first application (r = b stored, exact rg in rg_old): only the preconditioner part runs.
 // Dynamic LDS (doubles): res[levels g..L] | geo[levels g..L-1] | top rows | own-chain sibling rows + offsets   (ml_cg_lds_bytes)
-template <int AGG>
-__global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
+// COMP (AGG = 4 only): the dense level-2 operator is present - a compile-time fact, so that the registers and LDS staging of the
+// restrict / top-solve / sibling-chain walk it replaces are not allocated (230 -> fewer VGPRs: more workgroups per CU for a kernel
+// whose level-2 product streams 6 rows of Y_2 per workgroup)
+template <int AGG, bool COMP = false>
+__global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? 3 : 1))) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
                                                       const double* __restrict__ rg_old, double* __restrict__ rg_new,
                                                       int n_part, int init)
 {
@@ -1233,7 +1236,8 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     const int gl = (AGG == 1 || Lt < 2) ? 1 : 2;               // gather level
     // AGG = 4 with the dense operator of level 2 (H.Cmat = Y_2, rows 6 A .. 6 A + 5 belong to workgroup A): the level-2
     // correction is six rows of Y_2 times the gather-level residual; the restrict / top-solve / sibling-chain walk is skipped
-    const bool comp = (AGG == 4) && H.Cmat != nullptr;
+    constexpr bool comp = (AGG == 4) && COMP;
+    constexpr int kGU = comp ? 12 : kGatherU;      // gather-level values per thread held in registers (COMP: 12 x 192 covers 12k vertices at 168 VGPRs without a spill)
     const int a = blockIdx.x * kRowsPerBlk + tid / 6, r = tid % 6;
     const bool act = tid < kRowsPerBlk * 6 && a < D.nb;
     const int n1 = H.n[1], ng = H.n[gl];
@@ -1304,10 +1308,10 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
         g1x[0] = gq[0]; g1x[1] = gq[1]; g1x[2] = gq[2];
     }
     const double rz = init ? 0. : D.scal[0];
-    // gather-level residual and restricted Ap of ALL aggregates: first kGatherU x 192 values in registers
-    double rgreg[kGatherU], sgreg[kGatherU];
+    // gather-level residual and restricted Ap of ALL aggregates: first kGU x 192 values in registers
+    double rgreg[kGU], sgreg[kGU];
 #pragma unroll
-    for (int u = 0; u < kGatherU; u++) {
+    for (int u = 0; u < kGU; u++) {
         const int t = u * kCgBlk + tid;
         rgreg[u] = (t < 6 * ng) ? rg_old[t] : 0.;
         sgreg[u] = (!init && t < 6 * ng) ? H.Sg[t] : 0.;
@@ -1352,11 +1356,11 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
     }
     STAMP(0);      // 2: partial reduction
 #pragma unroll
-    for (int u = 0; u < kGatherU; u++) {
+    for (int u = 0; u < kGU; u++) {
         const int t = u * kCgBlk + tid;
         if (t < 6 * ng) dyn[roff[gl] + t] = rgreg[u] - alpha * sgreg[u];
     }
-    for (int t = kGatherU * kCgBlk + tid; t < 6 * ng; t += kCgBlk)       // graphs beyond 12k free vertices: latency exposed
+    for (int t = kGU * kCgBlk + tid; t < 6 * ng; t += kCgBlk)       // graphs beyond 12k free vertices: latency exposed
         dyn[roff[gl] + t] = rg_old[t] - (init ? 0. : alpha * H.Sg[t]);
     if (!comp) {
 #pragma unroll
@@ -1381,10 +1385,14 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_kernel(PgoDev D, MlHot H, const 
         const int row = tid >> 5, j = tid & 31, n6 = 6 * ng;
         double sacc = 0.;
         if (row < 6) {
-            const double* __restrict__ yr = H.Cmat + ((size_t)blockIdx.x * 6 + row) * n6;
-            const double* __restrict__ rr = dyn + roff[gl];
+            // 16-byte loads, eight in flight per lane (n6 = 6 n_2 is even, rows are 16-byte aligned): at 20k vertices Y_2 (112 MB, and
+            // a second hierarchy copy beside it) no longer fits the Infinity Cache and this product streams from HBM
+            const double2* __restrict__ yr = reinterpret_cast<const double2*>(H.Cmat + ((size_t)blockIdx.x * 6 + row) * n6);
+            const double2* __restrict__ rr = reinterpret_cast<const double2*>(dyn + roff[gl]);
+            double s0 = 0., s1 = 0.;
 #pragma unroll 8
-            for (int t = j; t < n6; t += 32) sacc += yr[t] * rr[t];      // eight global loads in flight per lane
+            for (int t = j; t < (n6 >> 1); t += 32) { const double2 y = yr[t], x = rr[t]; s0 += y.x * x.x; s1 += y.y * x.y; }
+            sacc = s0 + s1;
         }
         sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
         sacc += __shfl_xor(sacc, 8); sacc += __shfl_xor(sacc, 16);
@@ -1742,10 +1750,12 @@ void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, d
 hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
                    int init, size_t lds, hipStream_t s, hipEvent_t ev_a, hipEvent_t ev_b)
 {
-    static size_t configured[2] = {0, 0};
-    const int ci = agg == 1 ? 0 : 1;
+    static size_t configured[3] = {0, 0, 0};
+    const bool comp4 = agg != 1 && ml.Cmat != nullptr;
+    const int ci = agg == 1 ? 0 : (comp4 ? 2 : 1);
     if (lds > configured[ci]) {
-        const void* fn = agg == 1 ? reinterpret_cast<const void*>(&ml_cg_kernel<1>) : reinterpret_cast<const void*>(&ml_cg_kernel<4>);
+        const void* fn = agg == 1 ? reinterpret_cast<const void*>(&ml_cg_kernel<1>)
+                                  : (comp4 ? reinterpret_cast<const void*>(&ml_cg_kernel<4, true>) : reinterpret_cast<const void*>(&ml_cg_kernel<4>));
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured[ci] = lds;
@@ -1763,10 +1773,12 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
     }
     if (ev_a) {
         if (agg == 1) hipExtLaunchKernelGGL(ml_cg_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
+        else if (comp4) hipExtLaunchKernelGGL((ml_cg_kernel<4, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
         else hipExtLaunchKernelGGL(ml_cg_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
         return hipSuccess;
     }
     if (agg == 1) hipLaunchKernelGGL(ml_cg_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
+    else if (comp4) hipLaunchKernelGGL((ml_cg_kernel<4, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     else hipLaunchKernelGGL(ml_cg_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     return hipSuccess;
 }
