@@ -22,52 +22,10 @@ def test_reduced_online_run_matches_the_oracle(capi, oracle):
     mc = dict(ransac_iteration=200)
     o = online.OnlineSlam(run, match_batch=100, lm_iterations=8, match_cfg=mc)
     o.upload_frames()
-    # ---- oracle replay, driven by the same class through stand-ins of the four handles
-    class OMatch:
-        def __init__(s): s.fr = []
-        def add_frame(s, d, p, v): s.fr.append(dict(desc=d, pos=p, valid=v, feature_type=2, sensor_frame=0)); return len(s.fr) - 1
-        def launch_raw(s, jobs, fids): s.jobs, s.fids = jobs.copy(), fids.copy()
-        def collect(s, out):
-            for i, j in enumerate(s.jobs):
-                e = oracle.estimate_edge([s.fr[s.fids[j["from_begin"]]]], [s.fr[s.fids[j["to_begin"]]]], ransac_threshold=0.1,
-                                         ransac_iteration=200, break_percentage=0.6, do_prosac=True, seed=777, job_id=int(j["job_id"]))
-                out[i]["job_id"] = j["job_id"]; out[i]["ok"] = e["ok"]; out[i]["consensus"] = e["consensus"]
-                out[i]["T"] = np.asarray(e["T"]).reshape(12); out[i]["information"] = np.asarray(e["information"]).reshape(36); out[i]["mse"] = e["mse"]
-            return out
-        def close(s): pass
-
-    class OPgo:
-        def add_graph(s, poses, fixed, edges): s.g = (np.array(poses), np.array(fixed), {k: np.array(v) for k, v in edges.items()})
-        def optimize(s, its):
-            fl = oracle.flatten_graph(*s.g)
-            fx, ng = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
-            s.P, so = oracle.pgo_optimize(fl["poses"], fx, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=its)
-            so = dict(so); so.update(status=0, n_edges=len(fl["ij"]), pcg_iterations=0)
-            return so
-        def store(s): return s.P.reshape(-1, 12), None, None
-        def close(s): pass
-
-    class OFilter:
-        def __init__(s, f): s.f = f
-        def set_sensors(s, x): s.f.set_sensors(x)
-        def add_packed(s, fe):
-            st = run["stamps_ns"]; base = st.ctypes.data
-            s.f.add([dict(key=int(r["key"]), matching_score=float(r["matching_score"]), valid=int(r["valid"]), sensor_from=-1, sensor_to=-1,
-                          stamps_from=st[(int(r["stamps_from_ns"]) - base) // 8:][:1], stamps_to=st[(int(r["stamps_to_ns"]) - base) // 8:][:1],
-                          transform=r["transform"], displacement_from=r["displacement_from"], displacement_to=r["displacement_to"],
-                          pose_from=r["pose_from"], pose_to=r["pose_to"]) for r in fe])
-        def calc_valid_edges(s): return s.f.calc_valid_edges()
-        def valid_edges(s): return np.asarray(s.f.valid_edges())
-        def close(s): pass
-
-    c = online.OnlineSlam.__new__(online.OnlineSlam)
-    c.__dict__.update({k: v for k, v in o.__dict__.items()})
-    c.poses = o.poses.copy(); c.results = o.results.copy(); c.solves = []; c.accept_log = []; c.t = dict(o.t)
-    c.matcher = OMatch(); c.gate = oracle.Gate(); c.filt = OFilter(oracle.Filter(seed=777)); c.filt.set_sensors(online.I12.reshape(1, 12)); c.pgo = OPgo()
-    c.fid = {}
-    for k in range(c.P):
-        f, t = run["frames"][k]
-        c.fid[k] = (c.matcher.add_frame(f["desc"], f["pos"], f["valid"]), c.matcher.add_frame(t["desc"], t["pos"], t["valid"]))
+    # ---- oracle replay, driven by the same class through stand-ins of the four handles (tests/online_stubs.py)
+    from online_stubs import oracle_backends
+    c = online.OnlineSlam(run, match_batch=100, lm_iterations=8, match_cfg=mc, backends=oracle_backends(oracle, run, ransac_iteration=200))
+    c.upload_frames()
     o.run_all(); c.run_all()
     assert len(o.solves) == len(c.solves) >= 5
     assert np.array_equal(o.results["consensus"], c.results["consensus"]) and np.array_equal(o.results["T"], c.results["T"])   # edges bit-exact

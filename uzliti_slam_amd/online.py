@@ -52,7 +52,9 @@ class OnlineSlam:
     """State of one online run.  `run` = synth.make_online_run(...) (or any dict of the same layout)."""
 
     def __init__(self, run, device=0, reopt_edges=256, lm_iterations=20, lookahead=None, match_cfg=None, gate_cfg=None,
-                 filter_cfg=None, pgo_cfg=None, match_batch=512, rank=0, world=1, tdist=None, solve_rank=0, log=None):
+                 filter_cfg=None, pgo_cfg=None, match_batch=512, rank=0, world=1, tdist=None, solve_rank=0, log=None, backends=None):
+        """backends: optional dict(matcher=, gate=, filt=, pgo=) of objects with the capi.Match / Gate / Filter / Pgo methods this
+        driver calls - the tests replay the schedule on the CPU checker through it; the product path leaves it None."""
         self.run = run
         self.N = len(run["fixed"])
         self.P = len(run["pair_from"])
@@ -65,14 +67,20 @@ class OnlineSlam:
         self.log = log
         mc = dict(ransac_threshold=0.1, ransac_iteration=500, ransac_break_percentage=0.6, do_prosac=1, seed=777)
         mc.update(match_cfg or {})
-        self.matcher = capi.Match(device=device, **mc)
         self.gate = self.filt = self.pgo = None
-        if self.is_solver:
-            self.gate = capi.Gate(device=device, **(gate_cfg or {}))
-            fc = dict(seed=mc["seed"]); fc.update(filter_cfg or {})
-            self.filt = capi.Filter(device=device, **fc)
-            self.filt.set_sensors(I12.reshape(1, 12))
-            self.pgo = capi.Pgo(device=device, iterations=self.lm_iterations, **(pgo_cfg or {}))
+        if backends is not None:
+            self.matcher = backends["matcher"]
+            if self.is_solver:
+                self.gate, self.filt, self.pgo = backends["gate"], backends["filt"], backends["pgo"]
+                self.filt.set_sensors(I12.reshape(1, 12))
+        else:
+            self.matcher = capi.Match(device=device, **mc)
+            if self.is_solver:
+                self.gate = capi.Gate(device=device, **(gate_cfg or {}))
+                fc = dict(seed=mc["seed"]); fc.update(filter_cfg or {})
+                self.filt = capi.Filter(device=device, **fc)
+                self.filt.set_sensors(I12.reshape(1, 12))
+                self.pgo = capi.Pgo(device=device, iterations=self.lm_iterations, **(pgo_cfg or {}))
         o = run["odo"]
         self.odo_T = np.asarray(o["transform"], np.float64).reshape(-1, 3, 4)[: self.N - 1]
         self.odo_info = np.asarray(o["information"], np.float64).reshape(-1, 36)[: self.N - 1]
