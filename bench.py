@@ -422,6 +422,31 @@ def main():
                        ms_per_graph=round(1e3 * t_b / nsteps_b / nB, 4), vs_single_graph=round(vb / value, 2),
                        note="every graph's poses are bit-identical to its own uzl_pgo_optimize (tests/test_batch_gpu.py); the single-graph figure is `value`")
         bt.close()
+        # the regime batching is for: many small graphs (BASELINE config 1 size: 100 nodes / 300 edges - local scopes, per-robot graphs)
+        nS = 64
+        g1 = [synth.make_pose_graph(100, 300, seed=ud.replica_seed(777, dist.rank) + 1000 * k) for k in range(nS)]
+        one = capi.Pgo(device=dev, iterations=a.lm_iters)
+        one.add_graph(g1[0]["nodes_pose"], g1[0]["nodes_fixed"], g1[0]["edges"]); one.optimize(a.lm_iters)
+        t0 = time.perf_counter(); e1 = 0
+        for _ in range(5):
+            one.reset(); st_ = one.optimize(a.lm_iters); e1 += st_["n_edges"] * st_["iterations_done"]
+        t_one = time.perf_counter() - t0
+        one.close()
+        bs = capi.PgoBatch(nS, device=dev, iterations=a.lm_iters)
+        for k in range(nS):
+            bs.graphs[k].add_graph(g1[k]["nodes_pose"], g1[k]["nodes_fixed"], g1[k]["edges"])
+        bs.optimize(a.lm_iters)
+        t0 = time.perf_counter(); eS = 0
+        for _ in range(5):
+            for p_ in bs.graphs:
+                p_.reset()
+            for st_ in bs.optimize(a.lm_iters):
+                eS += st_["n_edges"] * st_["iterations_done"]
+        t_S = time.perf_counter() - t0
+        batched["small_graphs"] = dict(workload="%d graphs of BASELINE config 1 size (100 nodes / 300 edges), %d LM iterations" % (nS, a.lm_iters),
+                                       value=round(eS / t_S, 1), unit="edges/s", graphs_batched=bs.n_batched, ms_per_batch=round(1e3 * t_S / 5, 3),
+                                       one_graph_alone=round(e1 / t_one, 1), vs_one_graph_alone=round((eS / t_S) / (e1 / t_one), 1))
+        bs.close()
 
     # ------------------------------------------------------------------ north star: 10k / 50k on ONE GPU (N = 1 only)
     c4 = None

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: aggregate edges/s of uzl_pgo_batch_* over B config-2 graphs (B = 1, 2, 4, ... from argv)."""
+"""Diagnostic: aggregate edges/s of uzl_pgo_batch_* over B graphs of NODES / EDGES (environment; default config 2), B = 1, 2, 4, ... from argv."""
 import os
 import sys
 import time
@@ -7,10 +7,11 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from uzliti_slam_amd import capi, synth    # noqa: E402
 
+N = int(os.environ.get("NODES", "1000")); E = int(os.environ.get("EDGES", str(5 * N)))
 for B in [int(x) for x in sys.argv[1:]] or [1, 4, 16, 64]:
     bt = capi.PgoBatch(B)
     for k in range(B):
-        g = synth.make_pose_graph(1000, 5000, seed=12345 + 1000 * k)
+        g = synth.make_pose_graph(N, E, seed=12345 + 1000 * k)
         bt.graphs[k].add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
     bt.optimize(20)
     reps = 5
