@@ -241,6 +241,26 @@ def cpu_pgo(O, g, a, seconds, threads_list, max_solves=64):
     return out
 
 
+def effective_cpus():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a one-GPU job a share of
+    its host, e.g. 16 of 256 hardware threads; threads beyond the quota only time-slice)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -464,7 +484,7 @@ def main():
                   kernels_ms_per_solve={k: round(v["ms"], 4) for k, v in sorted(kt4.items(), key=lambda x: -x[1]["ms"])})
         if not a.no_cpu_baseline:
             import oracle as O
-            ncpu = len(os.sched_getaffinity(0))
+            ncpu = effective_cpus()
             nth = min(ncpu, 16)                                                # OpenMP over 50k edges: more threads only add fork/join cost
             cb = cpu_pgo(O, B4["g"], a, 1.0, [1, nth], max_solves=1)           # one solve each: ~20 s per solve on one core
             c4["cpu_baseline"] = dict(value=cb[1]["value"], unit="edges/s", cores=1, kind="port", seconds_per_solve=cb[1]["seconds_per_solve"],
@@ -472,7 +492,7 @@ def main():
                                                      note="OpenMP over the edges as in a g2o built with it (%d of the host's %d cores: the edge loops are %.0f %% of the "
                                                           "solve, more threads only add fork/join cost); the sparse Cholesky (%.0f %%) is serial, as CSparse is"
                                                           % (nth, ncpu, 100 * (1 - cb[1]["cholesky_share"]), 100 * cb[1]["cholesky_share"])),
-                                      nproc=ncpu, cpu=cpu_model(), sample="1 solve per thread count of the same graph, %d LM iterations" % a.lm_iters,
+                                      nproc=ncpu, hardware_threads=os.cpu_count(), cpu=cpu_model(), sample="1 solve per thread count of the same graph, %d LM iterations" % a.lm_iters,
                                       build="gcc -O3 -march=native -fopenmp on this host")
             c4["speedup_vs_cpu_1_thread"] = round(cb[1]["seconds_per_solve"] / (B4["t"] / steps4), 1)
             c4["speedup_vs_cpu_all_cores"] = round(cb[nth]["seconds_per_solve"] / (B4["t"] / steps4), 1)
@@ -534,7 +554,7 @@ def main():
     cpu = None
     if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline:
         import oracle as O
-        ncpu = len(os.sched_getaffinity(0))
+        ncpu = effective_cpus()
         nth = min(ncpu, 8)
         cb = cpu_pgo(O, g, a, a.cpu_seconds, [1, nth])
         cpu = dict(value=cb[1]["value"], unit="edges/s", cores=1, kind="port",
@@ -543,7 +563,7 @@ def main():
                           % (cb[1]["solves"], a.nodes, a.edges, a.lm_iters, cb[1]["seconds"]),
                    all_cores=dict(value=cb[nth]["value"], cores=nth, note="OpenMP over the edges (g2o's own parallelism; %d of %d cores - 5000 edges do not feed more); "
                                                                            "the Cholesky (%.0f %% of the solve) is serial as CSparse is" % (nth, ncpu, 100 * cb[1]["cholesky_share"])),
-                   nproc=ncpu, cpu=cpu_model())
+                   nproc=ncpu, hardware_threads=os.cpu_count(), cpu=cpu_model())
         if secondary is not None:
             kw = dict(ransac_threshold=0.1, ransac_iteration=a.hypotheses, break_percentage=1.0, do_prosac=True, seed=777)
             fp = [(f, t) for f, t, _ in pairs]
