@@ -62,6 +62,9 @@ def parse():
                     help="N > 1 only: additionally time ONE 10000-node/50000-edge graph sharded over all ranks "
                          "(BASELINE config 4, native RCCL all-reduce per PCG iteration); reported under `sharded_c4`")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-baseline sample of the primary / secondary block")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rehearsal of the N > 1 code paths on a box with fewer GPUs than ranks: process group over gloo, rank r on device "
+                         "r %% device_count (RCCL refuses two ranks on one device); the numbers mean nothing")
     return ap.parse_args()
 
 
@@ -82,18 +85,25 @@ def spawn_ranks(a):
 class Dist:
     """barrier + max-reduce over ranks; a no-op at world size 1 (then torch is never imported)."""
 
-    def __init__(self, n_gpus):
+    def __init__(self, n_gpus, rehearse_gloo=False):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.torch = None
         self.dist = None
+        self.rehearsal = False
         if self.world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            torch.cuda.set_device(self.local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            if rehearse_gloo:
+                self.local_rank = self.local_rank % max(torch.cuda.device_count(), 1)
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("gloo")
+                self.rehearsal = True
+            else:
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             self.torch = torch
             self.dist = dist
         if self.world != max(n_gpus, 1) and self.rank == 0:
@@ -111,7 +121,7 @@ class Dist:
     def _red(self, v, op):
         if self.torch is None:
             return v
-        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cpu" if self.rehearsal else "cuda")
         self.dist.all_reduce(t, op=op)
         return float(t.item())
 
@@ -320,7 +330,7 @@ def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(a))
-    dist = Dist(a.gpus)
+    dist = Dist(a.gpus, a.rehearse_gloo)
     from uzliti_slam_amd import capi, synth
     from uzliti_slam_amd import dist as ud
     capi.lib()
@@ -591,7 +601,7 @@ def main():
             metric="SE(3) edges optimized/sec (node-pairs matched/sec in `secondary`)",
             value=round(value, 1), unit="edges/s", n_gpus=dist.world, steps=a.steps, warmup=a.warmup,
             ms_per_step=round(1e3 * t_pgo / a.steps, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype="f64", data="synthetic",
+            dtype="f64", data="synthetic" if not dist.rehearsal else "synthetic (REHEARSAL over gloo, ranks sharing devices: not a measurement)",
             config=dict(workload="%s: %d-node / %d-edge SE(3) pose graph, %d LM iterations, Huber(1) on loop closures; "
                                  "one independent graph per GPU" % (cfg_name, a.nodes, a.edges, a.lm_iters),
                         system_edges=st["n_edges"], lm_iterations_done=st["iterations_done"], lm_trials_per_solve=st["lm_trials"],
