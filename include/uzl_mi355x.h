@@ -344,7 +344,9 @@ int  uzl_pgo_set_shard_rccl(uzl_pgo* h, int32_t rank, int32_t world_size, const 
  * The batch owns n_graphs ordinary handles: fill them with uzl_pgo_add_graph / uzl_pgo_set_graph, read them with uzl_pgo_store.
  * Graphs are launched together when they are of the small-graph class (<= 2048 free vertices) and have the same hierarchy shape
  * (same number of free vertices per level, e.g. same-size graphs); otherwise, and for any graph whose solve meets an anomaly, the
- * call falls back to one uzl_pgo_optimize per graph - same results, no batching.  *n_batched = graphs solved in the batch. */
+ * call falls back to one uzl_pgo_optimize per graph - same results, no batching.  *n_batched = graphs solved in the batch.
+ * stats[g].solve_ms of a batched graph is the wall time of the whole batch call.  The graphs' handles must not be used from other
+ * threads while uzl_pgo_batch_optimize runs (it drives them without taking their mutexes). */
 typedef struct uzl_pgo_batch uzl_pgo_batch;
 int  uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch** out);
 void uzl_pgo_batch_destroy(uzl_pgo_batch* b);
