@@ -447,7 +447,33 @@ def main():
         nsteps_b = max(3, a.steps // 2)
         t_b = timed(dist, batch_step, nsteps_b)
         vb = dist.sum(float(wb["edges"])) / t_b
+        # the same PCG kernel bodies with the chip full: their rate against the HBM roof (the working set streams from the Infinity Cache)
+        bt.set_profiling(True)
+        for p_ in bt.graphs:
+            p_.reset()
+        stp = bt.optimize(a.lm_iters)
+        ktb = bt.kernel_times()
+        bt.set_profiling(False)
+        b_roofs = []
+        nbf = st["n_vertices"] - int(pgo.get_fixed().sum())
+        sp_b = ktb.get("ml_spmv_batch")
+        if sp_b and sp_b["ms"] > 0:
+            # a launch does work for the graphs still iterating: sum of the graphs' PCG iterations x per-graph bytes over the kernel's time
+            work = sum(x["pcg_iterations"] for x in stp)
+            alg1 = 288.0 * (nbf + st["n_edges"]) + 96.0 * nbf
+            ach_b = alg1 * work / (sp_b["ms"] * 1e-3) / 1e9
+            b_roofs.append(roof("ml_spmv_batch_kernel", "hbm", ach_b, HBM_PEAK_GBS, "GB/s", traffic=None, avg_launch_us=round(1e3 * sp_b["ms"] / sp_b["launches"], 3),
+                                launches=sp_b["launches"], algorithmic_bytes_per_graph_iteration=alg1))
+        cg_b = ktb.get("ml_cg_comp_batch")
+        if cg_b and cg_b["ms"] > 0:
+            n1b = (nbf + 7) // 8
+            alg_y = 8.0 * (6.0 * n1b) ** 2 + 8.0 * 48 * 48 * n1b + 10 * 48.0 * nbf      # dense level-1 operator + sibling blocks + vectors, per graph iteration
+            ach_c = alg_y * sum(x["pcg_iterations"] for x in stp) / (cg_b["ms"] * 1e-3) / 1e9
+            b_roofs.append(roof("ml_cg_comp_batch_kernel<5>", "hbm", ach_c, HBM_PEAK_GBS, "GB/s", traffic=None, avg_launch_us=round(1e3 * cg_b["ms"] / cg_b["launches"], 3),
+                                launches=cg_b["launches"], algorithmic_bytes_per_graph_iteration=alg_y,
+                                note="every workgroup streams its 6 rows of the graph's dense level-1 operator: 16 graphs x 4.5 MB per iteration do not fit the L2s"))
         batched = dict(metric="SE(3) edges optimized/sec, %d independent config-2 graphs per GPU in one launch sequence (uzl_pgo_batch_*)" % nB,
+                       rooflines=b_roofs,
                        value=round(vb, 1), unit="edges/s", graphs=nB, graphs_batched=bt.n_batched, ms_per_batch=round(1e3 * t_b / nsteps_b, 3),
                        ms_per_graph=round(1e3 * t_b / nsteps_b / nB, 4), vs_single_graph=round(vb / value, 2),
                        note="every graph's poses are bit-identical to its own uzl_pgo_optimize (tests/test_batch_gpu.py); the single-graph figure is `value`")

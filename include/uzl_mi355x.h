@@ -355,6 +355,9 @@ int  uzl_pgo_batch_size(uzl_pgo_batch* b);
 uzl_pgo* uzl_pgo_batch_graph(uzl_pgo_batch* b, int32_t i);            /* borrowed: destroyed with the batch */
 int  uzl_pgo_batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats /* n_graphs entries, may be NULL */,
                             int32_t* n_batched /* may be NULL */);
+/* per-kernel timing of the two PCG kernels of the last batch solve (as uzl_pgo_set_profiling / uzl_pgo_kernel_times) */
+int  uzl_pgo_batch_set_profiling(uzl_pgo_batch* b, int32_t on);
+int  uzl_pgo_batch_kernel_times(uzl_pgo_batch* b, int32_t cap, const char** names, double* ms, int32_t* launches);
 
 /* ======================================================================================
  *  Edge filter  (TransformationFilter / EdgeCluster)

@@ -553,6 +553,15 @@ class PgoBatch:
             out.append(d)
         return out
 
+    def set_profiling(self, on):
+        lib().uzl_pgo_batch_set_profiling(self._b, C.c_int32(1 if on else 0))
+
+    def kernel_times(self):
+        cap = 16
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); ln = (C.c_int32 * cap)()
+        n = lib().uzl_pgo_batch_kernel_times(self._b, C.c_int32(cap), names, ms, ln)
+        return {names[i].decode(): dict(ms=ms[i], launches=ln[i]) for i in range(max(n, 0))}
+
     def close(self):
         if getattr(self, "_b", None):
             for p in self.graphs:

@@ -1935,9 +1935,17 @@ void kb_ml_init(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows,
     else hipLaunchKernelGGL(ml_cg_comp_batch_kernel<8>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, 0, 1);
 }
 // PCG iterations 2 * pairs (p0 -> p1 -> p0 ...), every graph with kPhSolve; kernels no-op for graphs whose `done` flag is set
-void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, int pairs, double tol2, hipStream_t s)
+// ev (profiling only, may be null): 4 events per iteration - spmv start / stop, cg start / stop (dispatch timestamps)
+void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, int pairs, double tol2, hipStream_t s,
+                     hipEvent_t* ev)
 {
     for (int i = 0; i < 2 * pairs; i++) {
+        if (ev) {
+            hipExtLaunchKernelGGL(ml_spmv_batch_kernel, dim3(g_rows, 1, nbatch), dim3(512), 0, s, ev[4 * i], ev[4 * i + 1], 0, sl, dy, i & 1, tol2);
+            if (small) hipExtLaunchKernelGGL(ml_cg_comp_batch_kernel<5>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, ev[4 * i + 2], ev[4 * i + 3], 0, sl, dy, i & 1, 0);
+            else hipExtLaunchKernelGGL(ml_cg_comp_batch_kernel<8>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, ev[4 * i + 2], ev[4 * i + 3], 0, sl, dy, i & 1, 0);
+            continue;
+        }
         hipLaunchKernelGGL(ml_spmv_batch_kernel, dim3(g_rows, 1, nbatch), dim3(512), 0, s, sl, dy, i & 1, tol2);
         if (small) hipLaunchKernelGGL(ml_cg_comp_batch_kernel<5>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, i & 1, 0);
         else hipLaunchKernelGGL(ml_cg_comp_batch_kernel<8>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, i & 1, 0);

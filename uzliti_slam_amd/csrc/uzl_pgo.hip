@@ -66,7 +66,8 @@ void kb_ml_numeric(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int leve
 void kb_ml_trial(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int pass, int levels, int cl, const int* n_lv, int inner_aggs, int ns_steps,
                  int upper_ns, hipStream_t s);
 void kb_ml_init(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, hipStream_t s);
-void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, int pairs, double tol2, hipStream_t s);
+void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, int pairs, double tol2, hipStream_t s,
+                     hipEvent_t* ev = nullptr);
 bool ml_comp_small(int n1);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
@@ -1417,6 +1418,7 @@ struct uzl_pgo_batch {
     std::vector<uint64_t> slot_gen;       // structure generation each slot was built from
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     int32_t last_batched = 0;
+    KernelTimer timer;                    // profiling (uzl_pgo_batch_set_profiling): the two PCG kernels, launched eagerly with event pairs
 };
 
 namespace {
@@ -1591,7 +1593,8 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             h->ml_ix = 0; h->ml_pending = false;
         }
     }
-    const bool eager = h0->no_graph;      // UZL_NO_GRAPH=1 (rocprofv3 --kernel-trace runs): the replay's launches one by one
+    const bool eager = h0->no_graph || b->timer.on;      // UZL_NO_GRAPH=1 (rocprofv3 --kernel-trace runs) / profiling: the replay's launches one by one
+    b->timer.reset();
     if (!b->graph_exec && !eager) {       // the PCG replay: 2 x kGraphPairs iterations of all graphs
         UZL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, kGraphPairs, tol2, s);
@@ -1688,12 +1691,20 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
                 want = std::min(want, max_it - launched);
                 const int reps = std::max(1, (want + 2 * kGraphPairs - 1) / (2 * kGraphPairs));
                 for (int i = 0; i < reps; i++) {
-                    if (eager) kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, kGraphPairs, tol2, s);
+                    if (eager && b->timer.on) {
+                        std::vector<hipEvent_t> ev((size_t)8 * kGraphPairs);
+                        for (int q = 0; q < 2 * kGraphPairs; q++) {
+                            b->timer.pair("ml_spmv_batch", &ev[4 * q], &ev[4 * q + 1]);
+                            b->timer.pair("ml_cg_comp_batch", &ev[4 * q + 2], &ev[4 * q + 3]);
+                        }
+                        kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, kGraphPairs, tol2, s, ev.data());
+                    } else if (eager) kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, kGraphPairs, tol2, s);
                     else UZL_HIP(hipGraphLaunch(b->graph_exec, s));
                 }
                 launched += reps * 2 * kGraphPairs;
                 kb_residual_guard(b->d_slots.p, b->d_dyn.p, B, s);
                 batch_fetch(b);
+                if (b->timer.on) { UZL_HIP(hipStreamSynchronize(s)); b->timer.resolve(); }
                 bool all_done = true;
                 for (int g = 0; g < B; g++) if ((dyn[g].mask & kPhSolve) && !b->h_pub.p[g].flags[0]) all_done = false;
                 if (all_done || launched >= max_it) break;
@@ -1834,6 +1845,21 @@ void uzl_pgo_batch_destroy(uzl_pgo_batch* b)
 const char* uzl_pgo_batch_last_error(uzl_pgo_batch* b) { return b ? b->last_error.c_str() : "null handle"; }
 int uzl_pgo_batch_size(uzl_pgo_batch* b) { return b ? (int)b->h.size() : UZL_ERR_BAD_ARG; }
 uzl_pgo* uzl_pgo_batch_graph(uzl_pgo_batch* b, int32_t i) { return (b && i >= 0 && i < (int32_t)b->h.size()) ? b->h[(size_t)i] : nullptr; }
+
+int uzl_pgo_batch_set_profiling(uzl_pgo_batch* b, int32_t on)
+{
+    if (!b) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(b->mu);
+    b->timer.on = on != 0;
+    return UZL_OK;
+}
+
+int uzl_pgo_batch_kernel_times(uzl_pgo_batch* b, int32_t cap, const char** names, double* ms, int32_t* launches)
+{
+    if (!b || cap < 0 || (cap > 0 && (!names || !ms || !launches))) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(b->mu);
+    return b->timer.report(cap, names, ms, launches);
+}
 
 int uzl_pgo_batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, int32_t* n_batched)
 {
