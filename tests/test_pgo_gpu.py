@@ -493,3 +493,17 @@ def test_structure_is_kept_when_only_values_change(capi, oracle):
     p.add_graph(g2["nodes_pose"], g2["nodes_fixed"], e4)
     assert p.optimize(3)["structure_reused"] == 0
     p.close(); fresh.close()
+
+
+def test_random_shapes_against_oracle():
+    """Randomized sweep (tests/diag/stress_pgo.py): sizes 150 .. 5000, 1.01 .. 5 edges per node, 0 - 20 % outliers, natural / renumbered /
+    broken odometry chain, xy-only or not, 3 / 8 / 15 LM iterations - every case within the north-star tolerance of the oracle's
+    direct solve after the same iteration count.  Seed 11 is the sweep on which a fixed 1e-5 PCG tolerance left two sparse-loop
+    graphs 1.2e-4 / 1.7e-4 rad off after 3 iterations (large first steps): the first iterations now solve 10x tighter."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "diag", "stress_pgo.py"), "110", "11"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "110 cases, 0 misses" in r.stdout

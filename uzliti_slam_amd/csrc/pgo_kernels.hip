@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kBlk) void pcg_spmv_kernel(PgoDev D, const double* 
     const int it = D.flags[1];
     const double rz = sum_partials(D.part_b, n_part, s4);
     const double beta = (it == 0) ? 0. : rz / D.scal[2];
-    const double thresh = (it == 0) ? tol2 * rz : D.scal[1];
+    const double thresh = (it == 0) ? (tol2 * D.scal[8]) * rz : D.scal[1];      // scal[8]: the LM iteration's tightening of pcg_tol^2 (uzl_pgo.hip)
     const double lambda = D.scal[3];
     const int lane = threadIdx.x & 63, g = lane / 6, r = lane % 6;
     const bool act = lane < 60;
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(kBlk) void set_lambda_batch_kernel(const BatchSlot*
     const int g = blockIdx.x * kBlk + threadIdx.x;
     if (g >= nbatch) return;
     const BatchDyn dy = dyn[g];
-    if (dy.mask & kPhLambda) slots[g].D.scal[3] = dy.lambda;
+    if (dy.mask & kPhLambda) { slots[g].D.scal[3] = dy.lambda; slots[g].D.scal[8] = dy.tol_factor2; }
     if ((dy.mask & (kPhNumeric | kPhTrialBuild)) && dy.build_scal2) slots[g].scal2[3] = dy.lambda_build;
 }
 // every graph's scal[0..8) / flags[0..4) into the pinned array, then one sequence word
@@ -781,6 +781,7 @@ __global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ 
     if (t == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void set_scalar_kernel(double* __restrict__ dst, double v) { *dst = v; }
+__global__ void set_scalar2_kernel(double* __restrict__ dst_a, double va, double* __restrict__ dst_b, double vb) { *dst_a = va; *dst_b = vb; }
 
 // After PCG has set `done`: scal[7] = |r|^2 / |b|^2 with the recurrence residual r (= b - (H + lambda) x up to rounding for ANY
 // step lengths and directions, so it is the true residual even when the preconditioner misbehaved).  The host refuses a
@@ -814,6 +815,10 @@ void k_publish(const PgoDev& D, PgoHostScal* out_dev, uint32_t seq, hipStream_t 
 void k_set_scalar(double* dst, double v, hipStream_t s)
 {
     hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, dst, v);
+}
+void k_set_scalar2(double* dst_a, double va, double* dst_b, double vb, hipStream_t s)
+{
+    hipLaunchKernelGGL(set_scalar2_kernel, dim3(1), dim3(1), 0, s, dst_a, va, dst_b, vb);
 }
 void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s)
 {

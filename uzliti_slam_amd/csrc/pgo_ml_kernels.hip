@@ -1071,7 +1071,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     // ---- beta
     const double rz = block_sum_w<kWaves>(v, s8);
     const double beta = (it == 0) ? 0. : rz / rz_prev;
-    const double thresh = (it == 0) ? tol2 * rz : thr_old;
+    const double thresh = (it == 0) ? (tol2 * D.scal[8]) * rz : thr_old;       // scal[8]: the LM iteration's tightening of pcg_tol^2 (uzl_pgo.hip)
     STAMP(16);     // 17: partial reduction (prefetch landed)
     // ---- row products: diagonal block + first slot pass of every row ...
     const double pr = zo_r + beta * po_r;             // component r of the new direction of row `arow` (lanes with dact)

@@ -52,7 +52,8 @@ struct PgoDev {
     double* part_a;          // [kMaxPartials] block partials (p.Ap, chi2, ...)
     double* part_b;          // [kMaxPartials] block partials (r.z, scale, ...)
     double* part_c;          // [kMaxPartials] block partials (max |H_jj|)
-    double* scal;            // [8]: 0 rz, 1 rz threshold, 2 rz_prev, 3 lambda, 4 chi2, 5 scale, 6 diagmax, 7 |r|^2 / |b|^2 after PCG
+    double* scal;            // [16]: 0 rz, 1 rz threshold, 2 rz_prev, 3 lambda, 4 chi2, 5 scale, 6 diagmax, 7 |r|^2 / |b|^2 after PCG,
+                             //       8 factor on pcg_tol^2 for this LM iteration's solves (host: do_optimize); 0..7 go back to the host
     int32_t* flags;          // [4]: 0 done, 1 iterations, 2 breakdown
 };
 
@@ -158,6 +159,7 @@ struct BatchDyn {                              // host -> device once per round
     int32_t build_ix;                          // copy the kPhNumeric / kPhTrialBuild set-up kernels write
     int32_t build_scal2;                       // 1: those kernels read lambda from scal2
     int32_t pad;
+    double  tol_factor2;                       // kPhLambda: factor on pcg_tol^2 of this round's solve (-> D.scal[8])
 };
 
 // scalars handed back to the host after each LM trial / PCG chunk.  The struct lives in pinned, host-coherent memory

@@ -30,6 +30,7 @@ int k_diagmax(const PgoDev& D, hipStream_t s);
 void k_precond(const PgoDev& D, hipStream_t s);
 void k_publish(const PgoDev& D, PgoHostScal* out_dev, uint32_t seq, hipStream_t s);
 void k_set_scalar(double* dst, double v, hipStream_t s);
+void k_set_scalar2(double* dst_a, double va, double* dst_b, double vb, hipStream_t s);
 void k_residual_guard(const PgoDev& D, hipStream_t s);
 int k_pcg_init(const PgoDev& D, double* p0, double* p1, hipStream_t s);
 int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
@@ -234,9 +235,17 @@ void fetch_scal(uzl_pgo* h)
     h->timer.resolve();
 }
 
-void set_lambda(uzl_pgo* h, double lambda)
+// PCG tolerance of one LM iteration.  cfg.pcg_tol is relative (M^-1 norm of the residual), so the error it leaves in the step is
+// proportional to the step: at the first iteration and while chi2 still drops by more than kTightRel per step the steps are large
+// (a dead-reckoned start is metres and tenths of radians off) and a 1e-5 solve left up to 1.7e-4 rad against the direct solve on
+// sparse-loop graphs after 3 iterations (tests/diag/stress_pgo.py: 2 of 150 random cases over the 1e-4 rad bar).  Those iterations
+// solve 10x tighter; once the steps are small the configured tolerance is more than enough.  Costs ~2 % of a config-2 solve.
+constexpr double kTightRel = 0.1, kTightFactor = 0.1;
+inline double tol_factor2(int it, double last_rel) { return (it == 0 || last_rel > kTightRel) ? kTightFactor * kTightFactor : 1.0; }
+
+void set_lambda(uzl_pgo* h, double lambda, double tol_f2)
 {
-    k_set_scalar(h->D.scal + 3, lambda, h->stream);
+    k_set_scalar2(h->D.scal + 3, lambda, h->D.scal + 8, tol_f2, h->stream);
     h->lambda_now = lambda;
 }
 
@@ -271,7 +280,7 @@ void alloc_problem(uzl_pgo* h)
     h->d_ei.reserve(e); h->d_ej.reserve(e); h->d_slot_i.reserve(e); h->d_slot_j.reserve(e);
     h->d_v2b.reserve(n);
     h->d_part_a.reserve(kMaxPartials); h->d_part_b.reserve(kMaxPartials); h->d_part_c.reserve(kMaxPartials);
-    h->d_scal.reserve(8); h->d_flags.reserve(4);
+    h->d_scal.reserve(16); h->d_flags.reserve(4);
     h->h_scal.reserve(1, hipHostMallocMapped | hipHostMallocCoherent); h->h_lambda.reserve(1);
     memset(h->h_scal.p, 0, sizeof(PgoHostScal));
     UZL_HIP(hipHostGetDevicePointer((void**)&h->d_pub, h->h_scal.p, 0));
@@ -479,7 +488,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     }
     hipStream_t s = h->stream;
     h->d_ml.reserve(2);
-    h->d_scal2.reserve(8);
+    h->d_scal2.reserve(16);
     MlDev Mh[2];
     for (int bi = 0; bi < 2; bi++) {
         uint8_t* base = h->ml_arena.p + (size_t)bi * buf_bytes;
@@ -963,8 +972,9 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         }
         double rho = 0.;
         int qmax = 0;
+        const double tol_f2 = tol_factor2(it, last_rel);
         do {
-            set_lambda(h, lambda);                                                // setLambda
+            set_lambda(h, lambda, tol_f2);                                        // setLambda (+ this iteration's PCG tolerance)
             bool conv = false;
             // the lambda-dependent inverses of the hierarchy are kept across trials; after rejected steps lambda grows
             // geometrically and inverses taken at a much smaller lambda stop being a preconditioner at all
@@ -1440,6 +1450,7 @@ struct BatchLM {
     int ml_ix = 0, cur = 0;
     bool pending = false, adopted = false, trial_setup = false, need_lin = true, finished = false, anomaly = false, fresh = false;
     double lambda_setup[2] = {0., 0.};
+    double tol_f2 = 1.;
     uzl_pgo_stats S;
 };
 
@@ -1676,6 +1687,8 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             BatchLM& X = G[g];
             if (X.finished) continue;
             dyn[g].mask = kPhLambda | kPhSolve; dyn[g].lambda = X.lambda;
+            if (X.qmax == 0) X.tol_f2 = tol_factor2(X.it, X.last_rel);           // fixed for the trials of one LM iteration, like do_optimize
+            dyn[g].tol_factor2 = X.tol_f2;
             if (X.lambda > 8. * X.lambda_setup[X.ml_ix]) X.trial_setup = true;
             X.fresh = X.trial_setup || (X.adopted && X.qmax == 0);
             if (X.trial_setup) { dyn[g].mask |= kPhTrialCur; X.lambda_setup[X.ml_ix] = X.lambda; X.trial_setup = false; any_trial_cur = true; }
