@@ -226,3 +226,16 @@ def test_c3_full_batch_properties(capi, oracle):
         d = np.linalg.norm(T[:, :3] @ P + T[:, 3:4] - Q, axis=0)
         assert np.array_equal(diag["mask"][j, :k][np.abs(d - 0.1) > 1e-9] != 0, (d < 0.1)[np.abs(d - 0.1) > 1e-9])
     m.close()
+
+
+def test_random_shapes_against_oracle():
+    """Randomized sweep (tests/diag/stress_match.py): frame sizes 7 .. 2700, 256- and 512-bit descriptors, outlier / validity fractions,
+    thresholds, 1 .. 1000 iterations, early exit, PROSAC on / off, duplicate descriptors (2-NN ties), smaller train than query sets,
+    nodes with several FeatureData of mixed sensor frames / feature types - every edge bit-exact against the oracle."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "diag", "stress_match.py"), "50", "9"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ", 0 misses" in r.stdout
