@@ -467,11 +467,11 @@ def main():
         cg_b = ktb.get("ml_cg_comp_batch")
         if cg_b and cg_b["ms"] > 0:
             n1b = (nbf + 7) // 8
-            alg_y = 8.0 * (6.0 * n1b) ** 2 + 8.0 * 48 * 48 * n1b + 10 * 48.0 * nbf      # dense level-1 operator + sibling blocks + vectors, per graph iteration
+            alg_y = 4.0 * (6.0 * n1b) ** 2 + 8.0 * 48 * 48 * n1b + 10 * 48.0 * nbf      # dense level-1 operator (f32 copy) + sibling blocks + vectors, per graph iteration
             ach_c = alg_y * sum(x["pcg_iterations"] for x in stp) / (cg_b["ms"] * 1e-3) / 1e9
             b_roofs.append(roof("ml_cg_comp_batch_kernel<5>", "hbm", ach_c, HBM_PEAK_GBS, "GB/s", traffic=None, avg_launch_us=round(1e3 * cg_b["ms"] / cg_b["launches"], 3),
                                 launches=cg_b["launches"], algorithmic_bytes_per_graph_iteration=alg_y,
-                                note="every workgroup streams its 6 rows of the graph's dense level-1 operator: 16 graphs x 4.5 MB per iteration do not fit the L2s"))
+                                note="every workgroup streams its 6 rows of the graph's dense level-1 operator (f32 copy, 2.25 MB per graph) and its 48 x 48 smoother block"))
         batched = dict(metric="SE(3) edges optimized/sec, %d independent config-2 graphs per GPU in one launch sequence (uzl_pgo_batch_*)" % nB,
                        rooflines=b_roofs,
                        value=round(vb, 1), unit="edges/s", graphs=nB, graphs_batched=bt.n_batched, ms_per_batch=round(1e3 * t_b / nsteps_b, 3),

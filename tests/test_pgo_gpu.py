@@ -330,15 +330,35 @@ def test_rejected_trials_multi_edges_and_hub(capi, oracle):
 
 @pytest.mark.parametrize("n", [16, 64, 100, 750, 959])
 def test_ns_gemm_matrix_core_layout(capi, n):
-    """the f64 MFMA tile kernel of the Newton-Schulz refinement (X' = 2 X - X T) against numpy, including edge tiles"""
+    """the f64 MFMA tile kernel of the Newton-Schulz refinement (X' = 2 X - X T) against numpy, including edge tiles.  The kernel
+    computes the 64 x 64 tiles on and above the diagonal and mirrors them (X, A and X A X are symmetric in the refinement)."""
     import ctypes
     rng = np.random.default_rng(n)
-    X = rng.normal(size=(n, n)); T = rng.normal(size=(n, n)); out = np.zeros((n, n))
     f64p = ctypes.POINTER(ctypes.c_double)
-    rc = capi.lib().uzl_debug_ns_gemm(ctypes.c_int(n), X.ctypes.data_as(f64p), T.ctypes.data_as(f64p), out.ctypes.data_as(f64p))
-    assert rc == 0
-    want = 2 * X - X @ T
+
+    def run(X, T):
+        out = np.zeros((n, n))
+        rc = capi.lib().uzl_debug_ns_gemm(ctypes.c_int(n), np.ascontiguousarray(X).ctypes.data_as(f64p), np.ascontiguousarray(T).ctypes.data_as(f64p),
+                                          out.ctypes.data_as(f64p))
+        assert rc == 0
+        return out
+
+    # arbitrary operands: upper tiles = 2 X - X T, lower tiles = their mirror images
+    X = rng.normal(size=(n, n)); T = rng.normal(size=(n, n))
+    full = 2 * X - X @ T
+    ti = np.arange(n) // 64
+    upper = ti[:, None] <= ti[None, :]
+    want = np.where(upper, full, full.T)
+    out = run(X, T)
     assert np.abs(out - want).max() <= 1e-11 * np.abs(want).max()
+    # the refinement's operands: X symmetric, T = A X with A symmetric -> the whole matrix, symmetric to the last bit off the diagonal tiles
+    A = rng.normal(size=(n, n)); A = A + A.T
+    X = rng.normal(size=(n, n)); X = X + X.T
+    out = run(X, A @ X)
+    want = 2 * X - X @ A @ X
+    assert np.abs(out - want).max() <= 1e-10 * np.abs(want).max()
+    off = ti[:, None] != ti[None, :]
+    assert np.array_equal(out[off], out.T[off])
 
 
 def test_handles_driven_from_concurrent_threads(capi):

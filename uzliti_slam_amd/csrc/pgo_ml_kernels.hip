@@ -747,7 +747,16 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
     __shared__ double sB[kGemmK][kGemmTile + 1];      // T tile: sB[k][col]
     constexpr int kPer = kGemmTile * kGemmK / 256;     // values per lane and operand per slab
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int row0 = blockIdx.y * kGemmTile, col0 = blockIdx.x * kGemmTile;
+    // X, A and therefore X (A X) are symmetric: only the tiles on and above the diagonal are computed (blockIdx.x counts them row by
+    // row), every result is stored twice.  Half the flops of the rebuild's dominant kernel, and X' is symmetric to the last bit
+    // outside the diagonal tiles - which PCG wants from its preconditioner anyway.
+    const int gt = (n + kGemmTile - 1) / kGemmTile;
+    int ti = (int)(((double)(2 * gt + 1) - sqrt((double)(2 * gt + 1) * (double)(2 * gt + 1) - 8. * (double)blockIdx.x)) * 0.5);
+    ti = ti < 0 ? 0 : (ti > gt - 1 ? gt - 1 : ti);
+    while (ti > 0 && ti * gt - ti * (ti - 1) / 2 > (int)blockIdx.x) ti--;                 // first tile of row ti: ti gt - ti (ti - 1) / 2
+    while (ti + 1 < gt && (ti + 1) * gt - (ti + 1) * ti / 2 <= (int)blockIdx.x) ti++;
+    const int tj = ti + ((int)blockIdx.x - (ti * gt - ti * (ti - 1) / 2));
+    const int row0 = ti * kGemmTile, col0 = tj * kGemmTile;
     const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;          // this wave's quarter
     const int li = lane & 15, lk = lane >> 4;
     v4f64 acc[2][2];
@@ -796,7 +805,11 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int gr = row0 + wr + a * 16 + lk + 4 * r, gc = col0 + wc + b * 16 + li;
-                if (gr < n && gc < n) Xn[(size_t)gr * n + gc] = 2. * X[(size_t)gr * n + gc] - acc[a][b][r];
+                if (gr < n && gc < n) {
+                    const double v = 2. * X[(size_t)gr * n + gc] - acc[a][b][r];
+                    Xn[(size_t)gr * n + gc] = v;
+                    if (ti != tj) Xn[(size_t)gc * n + gr] = v;
+                }
             }
 }
 __global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __restrict__ X, const double* __restrict__ T, double* __restrict__ Xn)
@@ -842,6 +855,28 @@ __device__ __forceinline__ void ml_top_kernel_body(PgoDev D, const MlDev* __rest
     }
     for (int i = threadIdx.x; i < n * n; i += kBlk) ml.top_inv[i] = sA[(i / n) * ld + n + i % n];
 }
+// The dense operator the PCG kernels apply, rounded to f32 once per rebuild (MlHot::Cmat32).  It is the largest stream of an
+// iteration (config 2: 4.5 of 10 MB; 20k vertices: 112 MB); a preconditioner does not need the last 29 bits, and being rounded once,
+// outside the iteration, it is still one fixed linear operator for the whole solve.  Four columns per lane; pad columns are zero.
+__device__ __forceinline__ void ml_cmat32_body(const double* __restrict__ src, float* __restrict__ dst, int n6, int stride)
+{
+    const int q4 = stride >> 2;
+    const long t = (long)blockIdx.x * kBlk + threadIdx.x;
+    if (t >= (long)n6 * q4) return;
+    const int row = (int)(t / q4), c = (int)(t % q4) * 4;
+    const double* __restrict__ sr = src + (size_t)row * n6 + c;
+    float4 o;
+    o.x = (float)sr[0];                       // c < n6 always (stride - n6 < 4)
+    o.y = (c + 1 < n6) ? (float)sr[1] : 0.f;
+    o.z = (c + 2 < n6) ? (float)sr[2] : 0.f;
+    o.w = (c + 3 < n6) ? (float)sr[3] : 0.f;
+    *reinterpret_cast<float4*>(dst + (size_t)row * stride + c) = o;
+}
+__global__ __launch_bounds__(kBlk) void ml_cmat32_kernel(const double* __restrict__ src, float* __restrict__ dst, int n6, int stride)
+{
+    ml_cmat32_body(src, dst, n6, stride);
+}
+
 __global__ __launch_bounds__(kBlk) void ml_top_kernel(PgoDev D, const MlDev* __restrict__ mlp)
 {
     ml_top_kernel_body(D, mlp);
@@ -898,6 +933,29 @@ __device__ __forceinline__ double prolong_comp(const double* __restrict__ d, con
     const double cr = (k == 0) ? yp[4] * d[2] - yp[5] * d[1] : (k == 1) ? yp[5] * d[0] - yp[3] * d[2] : yp[3] * d[1] - yp[4] * d[0];
     return yp[k] + cr;
 }
+// Workgroup-wide sum of n block partials, lane `tid` of BLK taking elements tid, tid + BLK, ...: the first NU per lane are fetched
+// together at kernel entry (independent loads: one round trip, and whatever is issued behind them is in flight at the same time),
+// the rest - graphs beyond NU * BLK workgroups - one by one.  A `for (...) s += part[i]` loop waits for every load in turn AND
+// holds back every load that follows it in program order: four serial round trips in front of ml_cg at 20k vertices.
+// Same summation order as that loop.
+template <int BLK, int NU>
+__device__ __forceinline__ void part_issue(const double* __restrict__ part, int n, int tid, double (&v)[NU])
+{
+#pragma unroll
+    for (int u = 0; u < NU; u++) { const int i = tid + u * BLK; const double x = part[i < n ? i : 0]; v[u] = (i < n) ? x : 0.; }
+}
+template <int BLK, int NU>
+__device__ __forceinline__ double part_fold(const double* __restrict__ part, int n, int tid, const double (&v)[NU])
+{
+    double s = v[0];
+#pragma unroll
+    for (int u = 1; u < NU; u++) s += v[u];
+    for (int i = tid + NU * BLK; i < n; i += BLK) s += part[i];
+    return s;
+}
+// (the geometry of a row lives in registers: its entries are picked with selects, never with a computed index - a computed
+//  index sends the array through scratch memory, one more dependent round trip in kernels that are nothing but round trips)
+__device__ __forceinline__ double sel3(int k, double a, double b, double c) { return (k == 0) ? a : (k == 1) ? b : c; }
 // (P1^T v)[r] for a row with geo = {R^T (9), d (3)} and v = (t0,t1,t2,q0,q1,q2)
 __device__ __forceinline__ double p1t_comp(const double* geo, double t0, double t1, double t2, double q0, double q1, double q2, int r)
 {
@@ -906,7 +964,7 @@ __device__ __forceinline__ double p1t_comp(const double* geo, double t0, double 
     const double u2 = geo[2] * t0 + geo[5] * t1 + geo[8] * t2;
     if (r < 3) return (r == 0) ? u0 : (r == 1) ? u1 : u2;
     const int k = r - 3;
-    const double rq = 0.5 * (geo[k] * q0 + geo[3 + k] * q1 + geo[6 + k] * q2);
+    const double rq = 0.5 * (sel3(k, geo[0], geo[1], geo[2]) * q0 + sel3(k, geo[3], geo[4], geo[5]) * q1 + sel3(k, geo[6], geo[7], geo[8]) * q2);
     const double dx = geo[9], dy = geo[10], dz = geo[11];
     const double cr = (k == 0) ? dy * u2 - dz * u1 : (k == 1) ? dz * u0 - dx * u2 : dx * u1 - dy * u0;
     return cr + rq;
@@ -914,15 +972,16 @@ __device__ __forceinline__ double p1t_comp(const double* geo, double t0, double 
 // (P1 y)[r]
 __device__ __forceinline__ double p1_comp(const double* geo, const double* y, int r)
 {
+    const int k = (r < 3) ? r : r - 3;
+    const double g0 = sel3(k, geo[0], geo[3], geo[6]), g1 = sel3(k, geo[1], geo[4], geo[7]), g2 = sel3(k, geo[2], geo[5], geo[8]);   // row k of R^T
     if (r < 3) {
         const double dx = geo[9], dy = geo[10], dz = geo[11];
         const double vx = y[0] + (y[4] * dz - y[5] * dy);      // v + w x d
         const double vy = y[1] + (y[5] * dx - y[3] * dz);
         const double vz = y[2] + (y[3] * dy - y[4] * dx);
-        return geo[r * 3] * vx + geo[r * 3 + 1] * vy + geo[r * 3 + 2] * vz;       // R^T (.)
+        return g0 * vx + g1 * vy + g2 * vz;       // R^T (.)
     }
-    const int k = r - 3;
-    return 0.5 * (geo[k * 3] * y[3] + geo[k * 3 + 1] * y[4] + geo[k * 3 + 2] * y[5]);
+    return 0.5 * (g0 * y[3] + g1 * y[4] + g2 * y[5]);
 }
 
 // x = 0, r = b, p0 = p1 = 0, flags cleared; exact gather-level residual of the own aggregates -> rg
@@ -995,8 +1054,8 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     const bool lact = lane < 60;
     const int row0 = blockIdx.x * kRowsPerBlk + wv * kRowsPerWave;
     // ---- prefetch (independent of beta); the r.z partials first: they gate everything else
-    double v = 0.;
-    for (int i = tid; i < n_part; i += kSpmvBlk) v += D.part_b[i];
+    double vpart[2];
+    part_issue<kSpmvBlk, 2>(D.part_b, n_part, tid, vpart);
     const int it = D.flags[1];
     const double rz_prev = D.scal[2], thr_old = D.scal[1], lambda = D.scal[3];
     if (tid < kAggPerBlk * 3) {
@@ -1069,7 +1128,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     }
     STAMP(16);     // 16: prefetch issue
     // ---- beta
-    const double rz = block_sum_w<kWaves>(v, s8);
+    const double rz = block_sum_w<kWaves>(part_fold<kSpmvBlk, 2>(D.part_b, n_part, tid, vpart), s8);
     const double beta = (it == 0) ? 0. : rz / rz_prev;
     const double thresh = (it == 0) ? (tol2 * D.scal[8]) * rz : thr_old;       // scal[8]: the LM iteration's tightening of pcg_tol^2 (uzl_pgo.hip)
     STAMP(16);     // 17: partial reduction (prefetch landed)
@@ -1243,21 +1302,25 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? 3
     const int n1 = H.n[1], ng = H.n[gl];
     const int ntop = 6 * H.n[Lt];
     // ---- LDS carve-up
+    // (COMP uses none of this: the gather-level vector sits at offset 0 and nothing else is staged.  Left in, the tables - computed
+    //  indices, so scratch memory - and the integer divisions of the ancestor chain run in front of the kernel's first load.)
     int roff[kMlMaxLevels + 2], goff[kMlMaxLevels + 2], anc[kMlMaxLevels + 2];
-    int o = 0;
-    for (int l = gl; l <= Lt; l++) { roff[l] = o; o += 6 * H.n[l]; }
-    for (int l = gl; l < Lt; l++) { goff[l] = o; o += 3 * H.n[l]; }
-    const int top_off = o;
+    int o = 0, top_off = 0, chain_off = 0;
     const int n_top_rows = (Lt == 1) ? kAggPerBlk * 6 : 6;
-    o += n_top_rows * ntop;
-    const int chain_off = o;                                  // (L-2) x kChain
-    anc[1] = blockIdx.x * kAggPerBlk;                          // (only its parent chain is used)
-    anc[2] = (gl == 2) ? (int)blockIdx.x : anc[1] / H.fan[2 <= Lt ? 2 : 1];
-    for (int l = 3; l <= Lt; l++) anc[l] = anc[l - 1] / H.fan[l];
+    if (!comp) {
+        for (int l = gl; l <= Lt; l++) { roff[l] = o; o += 6 * H.n[l]; }
+        for (int l = gl; l < Lt; l++) { goff[l] = o; o += 3 * H.n[l]; }
+        top_off = o;
+        o += n_top_rows * ntop;
+        chain_off = o;                                        // (L-2) x kChain
+        anc[1] = blockIdx.x * kAggPerBlk;                      // (only its parent chain is used)
+        anc[2] = (gl == 2) ? (int)blockIdx.x : anc[1] / H.fan[2 <= Lt ? 2 : 1];
+        for (int l = 3; l <= Lt; l++) anc[l] = anc[l - 1] / H.fan[l];
+    }
     STAMP(0);      // 0: entry
     // ---- every global load whose address is known now, before any barrier
-    double part = 0.;
-    if (!init) for (int i = tid; i < n_part; i += kCgBlk) part += D.part_a[i];
+    double vpart[4] = {0., 0., 0., 0.};
+    if (!init) part_issue<kCgBlk, 4>(D.part_a, n_part, tid, vpart);
     double xv = 0., rv0 = 0., apv = 0., pv = 0., geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (act) {
         const size_t i = (size_t)a * 6 + r;
@@ -1319,9 +1382,9 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? 3
     // small arrays (offsets of levels >= g: one contiguous blob in the arena; the own ancestor's top-inverse rows; the
     // own-chain sibling rows): staged through registers so that EVERY load is in flight before anything waits
     constexpr int kGeoU = 6, kTopU = 2, kChainLv = kMlMaxLevels - 2;
-    const int g_tot = (Lt > gl) ? (goff[Lt - 1] + 3 * H.n[Lt - 1] - goff[gl]) : 0;
+    const int g_tot = (!comp && Lt > gl) ? (goff[Lt - 1] + 3 * H.n[Lt - 1] - goff[gl]) : 0;
     const int top_n = n_top_rows * ntop;
-    const size_t top_base = (size_t)((Lt == 1) ? blockIdx.x * kAggPerBlk * 6 : 6 * anc[Lt]) * ntop;
+    const size_t top_base = comp ? 0 : (size_t)((Lt == 1) ? blockIdx.x * kAggPerBlk * 6 : 6 * anc[Lt]) * ntop;
     double gv[kGeoU], tv[kTopU], cv[kChainLv][2];
     {
         const double* __restrict__ gsrc = H.geo[gl];
@@ -1350,7 +1413,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? 3
     double alpha = 0.;
     bool bad = false;
     if (!init) {
-        const double pAp = block_sum_w<3>(part, s3);                      // barriers: everything above has landed
+        const double pAp = block_sum_w<3>(part_fold<kCgBlk, 4>(D.part_a, n_part, tid, vpart), s3);     // barriers: everything above has landed
         bad = !(pAp > 0.);
         alpha = bad ? 0. : rz / pAp;
     }
@@ -1358,10 +1421,21 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? 3
 #pragma unroll
     for (int u = 0; u < kGU; u++) {
         const int t = u * kCgBlk + tid;
-        if (t < 6 * ng) dyn[roff[gl] + t] = rgreg[u] - alpha * sgreg[u];
+        if (t < 6 * ng) dyn[t] = rgreg[u] - alpha * sgreg[u];          // (roff[gl] = 0)
     }
-    for (int t = kGU * kCgBlk + tid; t < 6 * ng; t += kCgBlk)       // graphs beyond 12k free vertices: latency exposed
-        dyn[roff[gl] + t] = rg_old[t] - (init ? 0. : alpha * H.Sg[t]);
+    for (int t0 = kGU * kCgBlk + tid; t0 < 6 * ng; t0 += 4 * kCgBlk) {     // graphs beyond 12k free vertices: four values per lane and round trip
+        double ra[4], sa[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + u * kCgBlk, tt = (t < 6 * ng) ? t : 0;
+            ra[u] = rg_old[tt]; sa[u] = init ? 0. : H.Sg[tt];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + u * kCgBlk;
+            if (t < 6 * ng) dyn[t] = ra[u] - alpha * sa[u];
+        }
+    }
     if (!comp) {
 #pragma unroll
         for (int u = 0; u < kGeoU; u++) { const int t = u * kCgBlk + tid; if (t < g_tot) dyn[goff[gl] + t] = gv[u]; }
@@ -1385,13 +1459,25 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? 3
         const int row = tid >> 5, j = tid & 31, n6 = 6 * ng;
         double sacc = 0.;
         if (row < 6) {
-            // 16-byte loads, eight in flight per lane (n6 = 6 n_2 is even, rows are 16-byte aligned): at 20k vertices Y_2 (112 MB, and
-            // a second hierarchy copy beside it) no longer fits the Infinity Cache and this product streams from HBM
-            const double2* __restrict__ yr = reinterpret_cast<const double2*>(H.Cmat + ((size_t)blockIdx.x * 6 + row) * n6);
-            const double2* __restrict__ rr = reinterpret_cast<const double2*>(dyn + roff[gl]);
-            double s0 = 0., s1 = 0.;
+            // Y_2 as f32 (H.Cmat32), 16-byte loads = four columns, eight in flight per lane; accumulation in f64.  At 20k vertices the
+            // f64 operator (112 MB, and a second hierarchy copy beside it) did not fit the Infinity Cache; half of it does.
+            const float* __restrict__ yrow = H.Cmat32 + ((size_t)blockIdx.x * 6 + row) * H.c32_stride;
+            const float4* __restrict__ yr = reinterpret_cast<const float4*>(yrow);
+            const double2* __restrict__ rr = reinterpret_cast<const double2*>(dyn);          // roff[gl] = 0
+            double s0 = 0., s1 = 0., s2 = 0., s3q = 0.;
+            const int n4 = n6 >> 2;
 #pragma unroll 8
-            for (int t = j; t < (n6 >> 1); t += 32) { const double2 y = yr[t], x = rr[t]; s0 += y.x * x.x; s1 += y.y * x.y; }
+            for (int t = j; t < n4; t += 32) {
+                const float4 y = yr[t];
+                const double2 xa = rr[2 * t], xb = rr[2 * t + 1];
+                s0 += (double)y.x * xa.x; s1 += (double)y.y * xa.y; s2 += (double)y.z * xb.x; s3q += (double)y.w * xb.y;
+            }
+            if ((n6 & 2) && j == 0) {                 // 6 n_2 is even: at most one pair beyond the last full quad
+                const float2 y = *reinterpret_cast<const float2*>(yrow + 4 * n4);
+                const double2 xa = rr[2 * n4];
+                s0 += (double)y.x * xa.x; s1 += (double)y.y * xa.y;
+            }
+            s0 += s2; s1 += s3q;
             sacc = s0 + s1;
         }
         sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
@@ -1415,8 +1501,9 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? 3
         }
         __syncthreads();
     }
-    const double* rtop = dyn + roff[Lt];
-    if (Lt == 1) {
+    // (COMP: none of the offset tables is used - with computed indices they would live in scratch memory)
+    const double* rtop = dyn + (comp ? 0 : roff[Lt]);
+    if (!comp && Lt == 1) {
         if (tid < kAggPerBlk * 6) {
             double sacc = 0.;
             for (int c = 0; c < ntop; c++) sacc += dyn[top_off + tid * ntop + c] * rtop[c];
@@ -1560,8 +1647,8 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
     const bool act = tid < 48 && a < D.nb;
     const int n1 = H.n[1], ng6 = 6 * n1;
     // ---- every global load, before any barrier
-    double part = 0.;
-    if (!init) for (int i = tid; i < n_part; i += kCgBlk) part += D.part_a[i];
+    double vpart[4] = {0., 0., 0., 0.};
+    if (!init) part_issue<kCgBlk, 4>(D.part_a, n_part, tid, vpart);
     double xv = 0., rv0 = 0., apv = 0., pv = 0., geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (act) {
         const size_t i = (size_t)a * 6 + r;
@@ -1579,8 +1666,10 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
         for (int c = 0; c < 6; c++) { const double2 v = src[c]; w0[2 * c] = v.x; w0[2 * c + 1] = v.y; }
     }
     const double rz = init ? 0. : D.scal[0];
-    double rgreg[kCompU], sgreg[kCompU], cm[6][kCompU];
-    const double* __restrict__ crow = H.Cmat + (size_t)blockIdx.x * 6 * ng6;
+    double rgreg[kCompU], sgreg[kCompU];
+    float cm[6][kCompU];                   // six rows of Y_1 (f32 copy): half the bytes and half the registers of the f64 operator
+    const int cst = H.c32_stride;
+    const float* __restrict__ crow = H.Cmat32 + (size_t)blockIdx.x * 6 * cst;
 #pragma unroll
     for (int u = 0; u < kCompU; u++) {
         const int t = u * kCgBlk + tid;
@@ -1588,12 +1677,12 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
         rgreg[u] = in ? rg_old[t] : 0.;
         sgreg[u] = (!init && in) ? H.Sg[t] : 0.;
 #pragma unroll
-        for (int q = 0; q < 6; q++) cm[q][u] = in ? crow[(size_t)q * ng6 + t] : 0.;
+        for (int q = 0; q < 6; q++) { const float y = crow[(size_t)q * cst + (in ? t : 0)]; cm[q][u] = in ? y : 0.f; }   // unconditional loads: all 30 in flight together
     }
     double alpha = 0.;
     bool bad = false;
     if (!init) {
-        const double pAp = block_sum_w<3>(part, s3);
+        const double pAp = block_sum_w<3>(part_fold<kCgBlk, 4>(D.part_a, n_part, tid, vpart), s3);
         bad = !(pAp > 0.);
         alpha = bad ? 0. : rz / pAp;
     }
@@ -1604,7 +1693,7 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
         for (int u = 0; u < kCompU; u++) {
             const double v = rgreg[u] - alpha * sgreg[u];
 #pragma unroll
-            for (int q = 0; q < 6; q++) ps[q] += cm[q][u] * v;
+            for (int q = 0; q < 6; q++) ps[q] += (double)cm[q][u] * v;
         }
 #pragma unroll
         for (int q = 0; q < 6; q++) ps[q] = wave_sum(ps[q]);
@@ -1704,9 +1793,15 @@ void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int lev, int n1, const doubl
 {
     const int n6 = 6 * n1;
     hipLaunchKernelGGL(ml_ns_ax_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, lev, X, T);
-    const int g = (n6 + kGemmTile - 1) / kGemmTile;
-    if (ev_a) hipExtLaunchKernelGGL(ml_ns_gemm_kernel, dim3(g, g), dim3(256), 0, s, ev_a, ev_b, 0, n6, X, T, Xn);     // dispatch timestamps of the GEMM alone
-    else hipLaunchKernelGGL(ml_ns_gemm_kernel, dim3(g, g), dim3(256), 0, s, n6, X, T, Xn);
+    const int g = (n6 + kGemmTile - 1) / kGemmTile, gtri = g * (g + 1) / 2;     // tiles on and above the diagonal
+    if (ev_a) hipExtLaunchKernelGGL(ml_ns_gemm_kernel, dim3(gtri), dim3(256), 0, s, ev_a, ev_b, 0, n6, X, T, Xn);     // dispatch timestamps of the GEMM alone
+    else hipLaunchKernelGGL(ml_ns_gemm_kernel, dim3(gtri), dim3(256), 0, s, n6, X, T, Xn);
+}
+void k_ml_cmat32(const MlHot& hot, int n6, hipStream_t s)
+{
+    if (!hot.Cmat || !hot.Cmat32) return;
+    const long work = (long)n6 * (hot.c32_stride >> 2);
+    hipLaunchKernelGGL(ml_cmat32_kernel, dim3((unsigned)((work + kBlk - 1) / kBlk)), dim3(kBlk), 0, s, hot.Cmat, const_cast<float*>(hot.Cmat32), n6, hot.c32_stride);
 }
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s)
 {
@@ -1868,6 +1963,13 @@ __global__ __launch_bounds__(256) void ml_ns_gemm_batch_kernel(const BatchSlot* 
     double* Xn = (k & 1) ? S.dense[c][lev] : S.nsX[c];
     ml_ns_gemm_kernel_body(n6, X, S.nsT[c], Xn);
 }
+__global__ __launch_bounds__(kBlk) void ml_cmat32_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int n6)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    (void)D;
+    const MlHot& H = S.hot[c];
+    ml_cmat32_body(H.Cmat, const_cast<float*>(H.Cmat32), n6, H.c32_stride);
+}
 __global__ __launch_bounds__(kCgBlk) void ml_init_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
 {
     const BatchSlot& S = slots[blockIdx.z];
@@ -1924,9 +2026,12 @@ void kb_ml_trial(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int pass, 
         const int n6 = 6 * n1, gg = (n6 + kGemmTile - 1) / kGemmTile;
         for (int k = 0; k < steps; k++) {
             hipLaunchKernelGGL(ml_ns_ax_batch_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l, k);
-            hipLaunchKernelGGL(ml_ns_gemm_batch_kernel, dim3(gg, gg, nbatch), dim3(256), 0, s, sl, dy, pass, l, k, n6);
+            hipLaunchKernelGGL(ml_ns_gemm_batch_kernel, dim3(gg * (gg + 1) / 2, 1, nbatch), dim3(256), 0, s, sl, dy, pass, l, k, n6);
         }
     }
+    const int n6 = 6 * n_lv[cl];
+    const long work = (long)n6 * (((n6 + 3) & ~3) >> 2);
+    hipLaunchKernelGGL(ml_cmat32_batch_kernel, dim3((unsigned)((work + kBlk - 1) / kBlk), 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, n6);
 }
 void kb_ml_init(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, hipStream_t s)
 {
@@ -1974,7 +2079,7 @@ extern "C" int uzl_debug_ns_gemm(int n, const double* X, const double* T, double
     (void)hipMemcpy(dX, X, b, hipMemcpyHostToDevice);
     (void)hipMemcpy(dT, T, b, hipMemcpyHostToDevice);
     const int g = (n + uzl::kGemmTile - 1) / uzl::kGemmTile;
-    hipLaunchKernelGGL(uzl::ml_ns_gemm_kernel, dim3(g, g), dim3(256), 0, nullptr, n, dX, dT, dO);
+    hipLaunchKernelGGL(uzl::ml_ns_gemm_kernel, dim3(g * (g + 1) / 2), dim3(256), 0, nullptr, n, dX, dT, dO);
     const hipError_t e = hipDeviceSynchronize();
     (void)hipMemcpy(out, dO, b, hipMemcpyDeviceToHost);
     (void)hipFree(dX); (void)hipFree(dT); (void)hipFree(dO);

@@ -127,7 +127,10 @@ struct MlHot {
     const double* geo[kMlMaxLevels + 1];   // [n_l][3], l >= 1
     const double* Winv[kMlMaxLevels + 1];  // [n_{l+1}][(6 fan_{l+1})^2], 0 <= l < levels
     const double* top_inv;
-    const double* Cmat;                    // composite path: Y_1, [6 n_1][6 n_1]; rows 6A..6A+5 belong to workgroup A
+    const double* Cmat;                    // composite path: Y_cl as built (f64), [6 n_cl][6 n_cl]; null = no dense operator
+    const float* Cmat32;                   // the copy the PCG kernels apply: Y_cl rounded to f32, [6 n_cl][c32_stride] (rows 6A..6A+5 belong to
+    int32_t c32_stride;                    // workgroup A; stride = 6 n_cl rounded up to 4, pad = 0).  A preconditioner needs no more, the
+    int32_t c32_pad;                       // operator is still one fixed linear map per solve, and it is the kernels' largest stream.
     double* Sg;                            // [n_g][6] restriction of A p at the gather level g = min(2, levels)
 };
 

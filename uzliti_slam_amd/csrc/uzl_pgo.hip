@@ -43,6 +43,7 @@ void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
 void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s);
 void k_ml_mult_level(const PgoDev& D, const MlDev* ml, int lev, int n1, int n2, hipStream_t s);
+void k_ml_cmat32(const MlHot& hot, int n6, hipStream_t s);
 void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int lev, int n1, const double* X, double* T, double* Xn, hipStream_t s,
                   hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 int g_ml_rows(int nb, int agg);
@@ -454,6 +455,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     h->ml_ns_steps = h->ml_mult ? std::max(0, std::min(ns_env >= 0 ? ns_env : ns_auto, 4)) : 0;
     const size_t nsq = h->ml_mult ? (size_t)(6 * h->ml_n[cl]) * (size_t)(6 * h->ml_n[cl]) * 8 : 0;     // also the scratch of the levels above cl
     const size_t o_nsT = take(nsq), o_nsX = take(nsq);
+    const int c32_stride = h->ml_comp ? ((6 * h->ml_n[cl] + 3) & ~3) : 0;
+    const size_t o_c32 = take(h->ml_comp ? (size_t)(6 * h->ml_n[cl]) * c32_stride * 4 : 0);      // f32 copy of Y_cl: what the PCG kernels read
     // slot ranges by parent aggregate, for every level the multiplicative cycle is built at (cl .. L-1): [n_l*n_{l+1}] begin | end
     std::vector<std::vector<int32_t>> grp((size_t)L + 1);
     std::vector<size_t> o_grp((size_t)L + 1, 0);
@@ -548,6 +551,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Winv[l] = M.lv[l].Winv; }
         Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg;
         Hh.Cmat = h->ml_comp ? ((h->ml_ns_steps & 1) ? M.nsX : M.Ydense[cl]) : nullptr;   // Newton-Schulz steps ping-pong Y_cl <-> nsX
+        Hh.Cmat32 = h->ml_comp ? reinterpret_cast<const float*>(base + o_c32) : nullptr;
+        Hh.c32_stride = c32_stride;
         B.l1_span_ptr = M.lv[1].blk;
         h->l1_span = (int64_t)((M.lv[1].M + (size_t)std::max(h->ml_n[1], 1) * 36) - M.lv[1].blk);
     }
@@ -587,6 +592,7 @@ void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool tim
         const int cl = h->ml_cl, L = h->ml_levels;
         if (!h->ml_mult) {                                                   // additive operator: Y_l = blockdiag(W_l^-1) + P Y_{l+1} P^T
             for (int l = L - 1; l >= cl; l--) k_ml_dense_level(B.dml, l, h->ml_n[l], s);
+            k_ml_cmat32(B.hot, 6 * h->ml_n[cl], s);
             if (timed) h->timer.end(s);
             return;
         }
@@ -609,6 +615,7 @@ void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool tim
             k_ml_ns_step(D, B.dml, cl, h->ml_n[cl], xa, B.nsT, xb, s, ea, eb);
             std::swap(xa, xb);
         }
+        k_ml_cmat32(B.hot, 6 * h->ml_n[cl], s);
     }
 }
 
