@@ -635,14 +635,14 @@ __global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev*
     ml_mult_as_kernel_body(D, mlp, cl);
 }
 
-// Y_1[i][i'] = 2 S_ii' - sum_{j in siblings(i)} S_ij AS[j][i'] + sum_p QY[i][p] Q[i'][p]^T
+// Y_1[i][i'] = 2 S_ii' - sum_{j in siblings(i)} S_ij AS[j][i']      (+ sum_p QY[i][p] Q[i'][p]^T: ml_mult_qyqt_kernel, on the matrix cores)
 __device__ __forceinline__ void ml_mult_final_kernel_body(const MlDev* __restrict__ mlp, int cl)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
     const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
-    // one 64-lane workgroup per (group, group') tile of fan x fan blocks: the tile's rows of QY / Q / AS are shared
-    // through L1 instead of being fetched once per block from L2
+    // one 64-lane workgroup per (group, group') tile of fan x fan blocks: the tile's rows of AS are shared through L1 instead of
+    // being fetched once per block from L2
     const int g = blockIdx.x / np, gp = blockIdx.x % np;
     const int i = g * fan + (int)threadIdx.x / fan, ip = gp * fan + (int)threadIdx.x % fan;
     if ((int)threadIdx.x >= fan * fan || i >= n || ip >= n) return;
@@ -653,20 +653,10 @@ __device__ __forceinline__ void ml_mult_final_kernel_body(const MlDev* __restric
     for (int q = 0; q < fan; q++) {
         const int j = g * fan + q;
         if (j >= n) break;
+        // AS[j][.] is zero in the columns of group gp unless j belongs to gp or row j of A has a block there (ml_mult_as_kernel):
+        // almost every tile of a large graph skips its reads
+        if (g != gp && ml.grp_beg[cl][(size_t)j * np + gp] == ml.grp_end[cl][(size_t)j * np + gp]) continue;
         mm6_acc(Wi + q * 6, m, ml.mAS + ((size_t)j * n + ip) * 36, 6, acc, -1.);
-    }
-    for (int p = 0; p < np; p++) {
-        const double* __restrict__ a = ml.mQY + ((size_t)i * np + p) * 36;
-        const double* __restrict__ b = ml.mQ + ((size_t)ip * np + p) * 36;
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                double sacc = 0.;
-#pragma unroll
-                for (int k = 0; k < 6; k++) sacc += a[r * 6 + k] * b[c * 6 + k];      // QY[i][p] Q[i'][p]^T
-                acc[r * 6 + c] += sacc;
-            }
     }
     double* __restrict__ Y = ml.Ydense[cl];
     const int n6 = 6 * n;
@@ -733,6 +723,15 @@ __global__ __launch_bounds__(kBlk) void ml_ns_ax_kernel(PgoDev D, const MlDev* _
 
 constexpr int kGemmTile = 64, kGemmK = 64;
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+// tile (ti <= tj) number `b` of the gt (gt + 1) / 2 tiles on and above the diagonal, counted row by row
+__device__ __forceinline__ void tri_tile(int gt, int b, int& ti, int& tj)
+{
+    int t = (int)(((double)(2 * gt + 1) - sqrt((double)(2 * gt + 1) * (double)(2 * gt + 1) - 8. * (double)b)) * 0.5);
+    t = t < 0 ? 0 : (t > gt - 1 ? gt - 1 : t);
+    while (t > 0 && t * gt - t * (t - 1) / 2 > b) t--;                       // first tile of row t: t gt - t (t - 1) / 2
+    while (t + 1 < gt && (t + 1) * gt - (t + 1) * t / 2 <= b) t++;
+    ti = t; tj = t + (b - (t * gt - t * (t - 1) / 2));
+}
 // X' = 2 X - X T on the f64 matrix cores: v_mfma_f64_16x16x4_f64 (lane l feeds A[row l&15][k l>>4] and B[k l>>4][col l&15];
 // the four results of a lane are C[row (l>>4) + 4 r][col l&15], r = 0..3).  A 256-lane workgroup owns a 64 x 64 tile, each
 // of its four waves a 32 x 32 quarter as 2 x 2 MFMA tiles; K is staged through LDS in slabs of 64 (coalesced global
@@ -751,11 +750,8 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
     // row), every result is stored twice.  Half the flops of the rebuild's dominant kernel, and X' is symmetric to the last bit
     // outside the diagonal tiles - which PCG wants from its preconditioner anyway.
     const int gt = (n + kGemmTile - 1) / kGemmTile;
-    int ti = (int)(((double)(2 * gt + 1) - sqrt((double)(2 * gt + 1) * (double)(2 * gt + 1) - 8. * (double)blockIdx.x)) * 0.5);
-    ti = ti < 0 ? 0 : (ti > gt - 1 ? gt - 1 : ti);
-    while (ti > 0 && ti * gt - ti * (ti - 1) / 2 > (int)blockIdx.x) ti--;                 // first tile of row ti: ti gt - ti (ti - 1) / 2
-    while (ti + 1 < gt && (ti + 1) * gt - (ti + 1) * ti / 2 <= (int)blockIdx.x) ti++;
-    const int tj = ti + ((int)blockIdx.x - (ti * gt - ti * (ti - 1) / 2));
+    int ti, tj;
+    tri_tile(gt, (int)blockIdx.x, ti, tj);
     const int row0 = ti * kGemmTile, col0 = tj * kGemmTile;
     const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;          // this wave's quarter
     const int li = lane & 15, lk = lane >> 4;
@@ -815,6 +811,85 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
 __global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __restrict__ X, const double* __restrict__ T, double* __restrict__ Xn)
 {
     ml_ns_gemm_kernel_body(n, X, T, Xn);
+}
+
+// Y_cl += QY Q^T on the f64 matrix cores - the last term of the multiplicative cycle, 2 (6 n_cl)^2 (6 n_{cl+1}) flops (13 GFLOP at 20k
+// vertices, where one lane per 6 x 6 block took 1.3 ms per rebuild).  Same tiling as ml_ns_gemm_kernel: 64 x 64 tiles on and above the
+// diagonal, mirrored (the cycle's operator is symmetric).  QY and Q are stored as [entity][parent][6 x 6] blocks, so
+//   A(row 6 i + r, k 6 p + c) = QY[i][p][r][c],   B(k 6 p + c, col 6 i' + r) = Q[i'][p][r][c];
+// both are walked along k by consecutive lanes (runs of 6 doubles; the operands are a few MB and stay in L2).
+__device__ __forceinline__ void ml_mult_qyqt_kernel_body(const MlDev* __restrict__ mlp, int cl)
+{
+    __shared__ double sA[kGemmTile][kGemmK + 1];      // sA[row][k]
+    __shared__ double sB[kGemmTile][kGemmK + 1];      // sB[col][k]
+    constexpr int kPer = kGemmTile * kGemmK / 256;
+    const MlDev& ml = *mlp;
+    const int np = ml.lv[cl + 1].n, n = 6 * ml.lv[cl].n, kd = 6 * np;
+    const double* __restrict__ QY = ml.mQY;
+    const double* __restrict__ Q = ml.mQ;
+    double* __restrict__ Y = ml.Ydense[cl];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int gt = (n + kGemmTile - 1) / kGemmTile;
+    int ti, tj;
+    tri_tile(gt, (int)blockIdx.x, ti, tj);
+    const int row0 = ti * kGemmTile, col0 = tj * kGemmTile;
+    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+    const int li = lane & 15, lk = lane >> 4;
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = v4f64{0., 0., 0., 0.};
+    double pa[kPer], pb[kPer];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < kPer; u++) {
+            const int e = u * 256 + tid;
+            const int er = e / kGemmK, ek = e % kGemmK;                           // consecutive lanes walk k
+            const int gk = k0 + ek, p = gk / 6, c = gk % 6;
+            const int gr = row0 + er, gc = col0 + er;
+            pa[u] = (gr < n && gk < kd) ? QY[((size_t)(gr / 6) * np + p) * 36 + (gr % 6) * 6 + c] : 0.;
+            pb[u] = (gc < n && gk < kd) ? Q[((size_t)(gc / 6) * np + p) * 36 + (gc % 6) * 6 + c] : 0.;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < kd; k0 += kGemmK) {
+#pragma unroll
+        for (int u = 0; u < kPer; u++) {
+            const int e = u * 256 + tid;
+            sA[e / kGemmK][e % kGemmK] = pa[u];
+            sB[e / kGemmK][e % kGemmK] = pb[u];
+        }
+        __syncthreads();
+        if (k0 + kGemmK < kd) fetch(k0 + kGemmK);
+#pragma unroll 4
+        for (int k4 = 0; k4 < kGemmK; k4 += 4) {
+            const double a0 = sA[wr + li][k4 + lk], a1 = sA[wr + 16 + li][k4 + lk];
+            const double b0 = sB[wc + li][k4 + lk], b1 = sB[wc + 16 + li][k4 + lk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int gr = row0 + wr + a * 16 + lk + 4 * r, gc = col0 + wc + b * 16 + li;
+                if (gr < n && gc < n) {
+                    const double v = Y[(size_t)gr * n + gc] + acc[a][b][r];
+                    Y[(size_t)gr * n + gc] = v;
+                    if (ti != tj) Y[(size_t)gc * n + gr] = v;
+                }
+            }
+}
+__global__ __launch_bounds__(256) void ml_mult_qyqt_kernel(const MlDev* __restrict__ mlp, int cl)
+{
+    ml_mult_qyqt_kernel_body(mlp, cl);
 }
 
 // ---- per LM trial: dense inverse of the top level A_L(lambda) (<= 48 x 48), one workgroup, in LDS
@@ -1273,8 +1348,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void m
 // COMP (AGG = 4 only): the dense level-2 operator is present - a compile-time fact, so that the registers and LDS staging of the
 // restrict / top-solve / sibling-chain walk it replaces are not allocated (230 -> fewer VGPRs: more workgroups per CU for a kernel
 // whose level-2 product streams 6 rows of Y_2 per workgroup)
-template <int AGG, bool COMP = false>
-__global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? 3 : 1))) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
+// YPRE (COMP, 6 n_2 <= 2304 = up to ~12k free vertices): the workgroup's six rows of Y_2 fit the register file (18 x 16 B per lane), so
+// they are fetched at entry with everything else and the level-2 product runs out of registers the moment alpha is known - one
+// memory round trip per launch instead of two (10k/50k: 12.7 -> ~9 us).  ~220 VGPRs: two workgroups per CU, enough for the <= 375
+// workgroups of such a graph.
+constexpr int kYU = 18;
+template <int AGG, bool COMP = false, bool YPRE = false>
+__global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (YPRE ? 2 : 3) : 1))) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
                                                       const double* __restrict__ rg_old, double* __restrict__ rg_new,
                                                       int n_part, int init)
 {
@@ -1409,6 +1489,18 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? 3
             }
         }
     }
+    float4 yreg[YPRE ? kYU : 1];
+    float2 ytail = make_float2(0.f, 0.f);
+    if (YPRE) {                                   // issued last: everything the alpha path needs returns first
+        const int row = tid >> 5, j = tid & 31, n6 = 6 * ng, n4 = n6 >> 2;
+        const float* __restrict__ yrow = H.Cmat32 + ((size_t)blockIdx.x * 6 + (row < 6 ? row : 0)) * H.c32_stride;
+        const float4* __restrict__ yr = reinterpret_cast<const float4*>(yrow);
+#pragma unroll
+        for (int u = 0; u < (YPRE ? kYU : 1); u++) {
+            yreg[u] = yr[j + 32 * u];             // (past the row's end: never used; the buffer carries 16 KB of slack behind its last row)
+        }
+        if (n6 & 2) ytail = *reinterpret_cast<const float2*>(yrow + 4 * n4);
+    }
     STAMP(0);      // 1: prefetch issue
     double alpha = 0.;
     bool bad = false;
@@ -1458,7 +1550,27 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? 3
         // y_2[own aggregate] = Y_2[rows 6 A .. 6 A + 5] . r_2   (32 lanes per row, fixed summation order)
         const int row = tid >> 5, j = tid & 31, n6 = 6 * ng;
         double sacc = 0.;
-        if (row < 6) {
+        if (YPRE) {
+            const double2* __restrict__ rr = reinterpret_cast<const double2*>(dyn);
+            double s0 = 0., s1 = 0., s2 = 0., s3q = 0.;
+            const int n4 = n6 >> 2;
+#pragma unroll
+            for (int u = 0; u < (YPRE ? kYU : 1); u++) {
+                const int t = j + 32 * u;
+                if (t < n4) {
+                    const float4 y = yreg[u];
+                    const double2 xa = rr[2 * t], xb = rr[2 * t + 1];
+                    s0 += (double)y.x * xa.x; s1 += (double)y.y * xa.y; s2 += (double)y.z * xb.x; s3q += (double)y.w * xb.y;
+                }
+                if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of at most four steps in registers at a time
+            }
+            if ((n6 & 2) && j == 0) {
+                const double2 xa = rr[2 * n4];
+                s0 += (double)ytail.x * xa.x; s1 += (double)ytail.y * xa.y;
+            }
+            s0 += s2; s1 += s3q;
+            sacc = (row < 6) ? s0 + s1 : 0.;
+        } else if (row < 6) {
             // Y_2 as f32 (H.Cmat32), 16-byte loads = four columns, eight in flight per lane; accumulation in f64.  At 20k vertices the
             // f64 operator (112 MB, and a second hierarchy copy beside it) did not fit the Infinity Cache; half of it does.
             const float* __restrict__ yrow = H.Cmat32 + ((size_t)blockIdx.x * 6 + row) * H.c32_stride;
@@ -1786,6 +1898,8 @@ void k_ml_mult_level(const PgoDev& D, const MlDev* ml, int lev, int n1, int n2, 
     hipLaunchKernelGGL(ml_mult_q_kernel, dim3(g12r), dim3(kBlk), 0, s, ml, lev);
     hipLaunchKernelGGL(ml_mult_qy_kernel, dim3(g12r), dim3(kBlk), 0, s, ml, lev);
     hipLaunchKernelGGL(ml_mult_final_kernel, dim3(n2 * n2), dim3(64), 0, s, ml, lev);
+    const int gt = (6 * n1 + kGemmTile - 1) / kGemmTile;
+    hipLaunchKernelGGL(ml_mult_qyqt_kernel, dim3(gt * (gt + 1) / 2), dim3(256), 0, s, ml, lev);
 }
 // one Newton-Schulz step at level `lev`: Xn = 2 X - X (A_lev X); T is scratch
 void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int lev, int n1, const double* X, double* T, double* Xn, hipStream_t s,
@@ -1845,12 +1959,14 @@ void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, d
 hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
                    int init, size_t lds, hipStream_t s, hipEvent_t ev_a, hipEvent_t ev_b)
 {
-    static size_t configured[3] = {0, 0, 0};
+    static size_t configured[4] = {0, 0, 0, 0};
     const bool comp4 = agg != 1 && ml.Cmat != nullptr;
-    const int ci = agg == 1 ? 0 : (comp4 ? 2 : 1);
+    const bool ypre = comp4 && ml.levels >= 2 && 6 * ml.n[2] <= 4 * 32 * kYU;       // the six rows of Y_2 fit the registers
+    const int ci = agg == 1 ? 0 : (comp4 ? (ypre ? 3 : 2) : 1);
     if (lds > configured[ci]) {
         const void* fn = agg == 1 ? reinterpret_cast<const void*>(&ml_cg_kernel<1>)
-                                  : (comp4 ? reinterpret_cast<const void*>(&ml_cg_kernel<4, true>) : reinterpret_cast<const void*>(&ml_cg_kernel<4>));
+                                  : (comp4 ? (ypre ? reinterpret_cast<const void*>(&ml_cg_kernel<4, true, true>) : reinterpret_cast<const void*>(&ml_cg_kernel<4, true>))
+                                           : reinterpret_cast<const void*>(&ml_cg_kernel<4>));
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured[ci] = lds;
@@ -1868,11 +1984,13 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
     }
     if (ev_a) {
         if (agg == 1) hipExtLaunchKernelGGL(ml_cg_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
+        else if (ypre) hipExtLaunchKernelGGL((ml_cg_kernel<4, true, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
         else if (comp4) hipExtLaunchKernelGGL((ml_cg_kernel<4, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
         else hipExtLaunchKernelGGL(ml_cg_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
         return hipSuccess;
     }
     if (agg == 1) hipLaunchKernelGGL(ml_cg_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
+    else if (ypre) hipLaunchKernelGGL((ml_cg_kernel<4, true, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     else if (comp4) hipLaunchKernelGGL((ml_cg_kernel<4, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     else hipLaunchKernelGGL(ml_cg_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     return hipSuccess;
@@ -1948,6 +2066,12 @@ __global__ __launch_bounds__(64) void ml_mult_final_batch_kernel(const BatchSlot
     (void)D;
     ml_mult_final_kernel_body(S.dml[c], lev);
 }
+__global__ __launch_bounds__(256) void ml_mult_qyqt_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
+{
+    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
+    (void)D;
+    ml_mult_qyqt_kernel_body(S.dml[c], lev);
+}
 // Newton-Schulz step k at level lev: X ping-pongs between Ydense[lev] and nsX, starting in Ydense[lev]
 __global__ __launch_bounds__(kBlk) void ml_ns_ax_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev, int k)
 {
@@ -2022,6 +2146,8 @@ void kb_ml_trial(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int pass, 
         hipLaunchKernelGGL(ml_mult_q_batch_kernel, dim3(g12r, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l);
         hipLaunchKernelGGL(ml_mult_qy_batch_kernel, dim3(g12r, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l);
         hipLaunchKernelGGL(ml_mult_final_batch_kernel, dim3(n2 * n2, 1, nbatch), dim3(64), 0, s, sl, dy, pass, l);
+        { const int gt = (6 * n1 + kGemmTile - 1) / kGemmTile;
+          hipLaunchKernelGGL(ml_mult_qyqt_batch_kernel, dim3(gt * (gt + 1) / 2, 1, nbatch), dim3(256), 0, s, sl, dy, pass, l); }
         const int steps = l > cl ? upper_ns : ns_steps;
         const int n6 = 6 * n1, gg = (n6 + kGemmTile - 1) / kGemmTile;
         for (int k = 0; k < steps; k++) {

@@ -456,7 +456,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     const size_t nsq = h->ml_mult ? (size_t)(6 * h->ml_n[cl]) * (size_t)(6 * h->ml_n[cl]) * 8 : 0;     // also the scratch of the levels above cl
     const size_t o_nsT = take(nsq), o_nsX = take(nsq);
     const int c32_stride = h->ml_comp ? ((6 * h->ml_n[cl] + 3) & ~3) : 0;
-    const size_t o_c32 = take(h->ml_comp ? (size_t)(6 * h->ml_n[cl]) * c32_stride * 4 : 0);      // f32 copy of Y_cl: what the PCG kernels read
+    const size_t o_c32 = take(h->ml_comp ? (size_t)(6 * h->ml_n[cl]) * c32_stride * 4 + 16384 : 0);      // f32 copy of Y_cl: what the PCG kernels read (+ slack: ml_cg_kernel<4, true, true> prefetches 18 x 512 B per row unconditionally)
     // slot ranges by parent aggregate, for every level the multiplicative cycle is built at (cl .. L-1): [n_l*n_{l+1}] begin | end
     std::vector<std::vector<int32_t>> grp((size_t)L + 1);
     std::vector<size_t> o_grp((size_t)L + 1, 0);
