@@ -12,6 +12,7 @@
 // Per PCG iteration : ml_spmv (p, A p, restricted A p) -> ml_cg (alpha, coarse chain in LDS, x, r, z)
 #include <hip/hip_ext.h>
 #include "pgo_device.hpp"
+#include "uzl_common.hpp"
 
 namespace uzl {
 
@@ -1112,12 +1113,26 @@ __global__ __launch_bounds__(kCgBlk) void ml_init_kernel(PgoDev D, MlHot H, doub
     ml_init_kernel_body<AGG>(D, H, p0, p1, rg);
 }
 
-// 8 waves per workgroup: AGG = 1 -> one row per wave (8 rows), AGG = 4 -> four rows per wave (32 rows)
+// restricted A p of gather-level entity t / 6, component t % 6.  Gather level 2 (AGG = 4): the sum of ml_spmv's two half-aggregate parts
+template <int AGG>
+__device__ __forceinline__ double sg_at(const double* __restrict__ Sg, int gl, int t)
+{
+    if (AGG == 1 || gl != 2) return Sg[t];
+    const double2 v = reinterpret_cast<const double2*>(Sg)[t];          // [aggregate][component][half]: one 16-byte load, no index arithmetic
+    return v.x + v.y;
+}
+// AGG = 1: 8 waves per workgroup, one row per wave (8 rows = one level-1 aggregate).
+// AGG = 4: four rows per wave, 4 waves per workgroup (kSpmvWaves4): 16 rows = HALF a level-2 aggregate; the two halves' restricted
+//   A p go to Sg[aggregate][component][half] and ml_cg adds them (sg_at).  The kernel's time is set by the busiest CU (one 32-row workgroup
+//   per CU took 15.5 us, two 23.7): 313 workgroups of a 10k-vertex graph on 256 CUs left 57 CUs with twice the work of the rest;
+//   626 half workgroups put at most 1.5 times the mean on one CU.
+constexpr int kSpmvWaves4 = 4;
 template <int AGG>
 __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const double* __restrict__ p_old,
                                                      double* __restrict__ p_new, int n_part, double tol2)
 {
-    constexpr int kRowsPerBlk = kMlFanout * AGG, kAggPerBlk = AGG, kSpmvBlk = 512, kWaves = 8, kRowsPerWave = AGG;
+    constexpr int kWaves = (AGG == 1) ? 8 : kSpmvWaves4, kSpmvBlk = 64 * kWaves, kRowsPerWave = AGG;
+    constexpr int kRowsPerBlk = kWaves * kRowsPerWave, kAggPerBlk = kRowsPerBlk / kMlFanout;
     __shared__ double s8[kWaves];
     __shared__ double sw[kRowsPerBlk * 6];
     __shared__ double ss1[kAggPerBlk * 6];
@@ -1320,7 +1335,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         double s = 0.;
         for (int la = 0; la < kAggPerBlk; la++)
             if (blockIdx.x * kAggPerBlk + la < H.n[1]) s += restrict_comp(sg1 + la * 3, ss1 + la * 6, tid);
-        H.Sg[(size_t)blockIdx.x * 6 + tid] = s;
+        H.Sg[((size_t)(blockIdx.x / (8 / kSpmvWaves4)) * 6 + tid) * (8 / kSpmvWaves4) + blockIdx.x % (8 / kSpmvWaves4)] = s;     // [aggregate][component][half]
     }
     if (tid == 0) {
         D.part_a[blockIdx.x] = dtot;
@@ -1338,7 +1353,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
 }
 // 4 waves per SIMD = two 512-lane workgroups per CU (<= 128 VGPRs; the body needs 96 at AGG = 1 and ~144 unconstrained at AGG = 4)
 template <int AGG>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void ml_spmv_kernel(PgoDev D, MlHot H, const double* __restrict__ p_old, double* __restrict__ p_new, int n_part, double tol2)
+__global__ __launch_bounds__(AGG == 1 ? 512 : 64 * kSpmvWaves4) __attribute__((amdgpu_waves_per_eu(4))) void ml_spmv_kernel(PgoDev D, MlHot H, const double* __restrict__ p_old, double* __restrict__ p_new, int n_part, double tol2)
 {
     ml_spmv_kernel_body<AGG>(D, H, p_old, p_new, n_part, tol2);
 }
@@ -1352,8 +1367,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void m
 // they are fetched at entry with everything else and the level-2 product runs out of registers the moment alpha is known - one
 // memory round trip per launch instead of two (10k/50k: 12.7 -> ~9 us).  ~220 VGPRs: two workgroups per CU, enough for the <= 375
 // workgroups of such a graph.
+// VPRE (COMP, larger graphs: 12k .. 21.8k vertices): alpha and the gather-level residual estimate v = rg - alpha Sg come from
+// ml_alpha_kernel, launched in front.  Without it every one of the 400 - 680 workgroups reduces the same partials and stages the same
+// two (with the half-aggregate parts: three) 30-KB vectors through its registers - at 20k vertices that, not the product with Y_2,
+// was most of the kernel (33 us per launch).
 constexpr int kYU = 18;
-template <int AGG, bool COMP = false, bool YPRE = false>
+template <int AGG, bool COMP = false, bool YPRE = false, bool VPRE = false>
 __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (YPRE ? 2 : 3) : 1))) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
                                                       const double* __restrict__ rg_old, double* __restrict__ rg_new,
                                                       int n_part, int init)
@@ -1400,7 +1419,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     STAMP(0);      // 0: entry
     // ---- every global load whose address is known now, before any barrier
     double vpart[4] = {0., 0., 0., 0.};
-    if (!init) part_issue<kCgBlk, 4>(D.part_a, n_part, tid, vpart);
+    if (!init && !VPRE) part_issue<kCgBlk, 4>(D.part_a, n_part, tid, vpart);
     double xv = 0., rv0 = 0., apv = 0., pv = 0., geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (act) {
         const size_t i = (size_t)a * 6 + r;
@@ -1452,12 +1471,16 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     }
     const double rz = init ? 0. : D.scal[0];
     // gather-level residual and restricted Ap of ALL aggregates: first kGU x 192 values in registers
+    // (every workgroup reads the same two vectors: started at the same element they would all pull the same cache line from the
+    //  same L2 channel at the same moment - each starts at a different 1.5-KB piece instead)
     double rgreg[kGU], sgreg[kGU];
+    const int urot = (blockIdx.x >> 3) % kGU;              // workgroups of one XCD (blockIdx.x mod 8) get all kGU offsets
 #pragma unroll
     for (int u = 0; u < kGU; u++) {
-        const int t = u * kCgBlk + tid;
-        rgreg[u] = (t < 6 * ng) ? rg_old[t] : 0.;
-        sgreg[u] = (!init && t < 6 * ng) ? H.Sg[t] : 0.;
+        const int uu = (u + urot >= kGU) ? u + urot - kGU : u + urot;
+        const int t = uu * kCgBlk + tid;
+        rgreg[u] = (t < 6 * ng) ? (VPRE ? H.Vg[t] : rg_old[t]) : 0.;
+        sgreg[u] = (!VPRE && !init && t < 6 * ng) ? sg_at<AGG>(H.Sg, gl, t) : 0.;
     }
     // small arrays (offsets of levels >= g: one contiguous blob in the arena; the own ancestor's top-inverse rows; the
     // own-chain sibling rows): staged through registers so that EVERY load is in flight before anything waits
@@ -1504,7 +1527,9 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     STAMP(0);      // 1: prefetch issue
     double alpha = 0.;
     bool bad = false;
-    if (!init) {
+    if (VPRE) {
+        alpha = D.scal[9]; bad = D.scal[10] != 0.;
+    } else if (!init) {
         const double pAp = block_sum_w<3>(part_fold<kCgBlk, 4>(D.part_a, n_part, tid, vpart), s3);     // barriers: everything above has landed
         bad = !(pAp > 0.);
         alpha = bad ? 0. : rz / pAp;
@@ -1512,20 +1537,21 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     STAMP(0);      // 2: partial reduction
 #pragma unroll
     for (int u = 0; u < kGU; u++) {
-        const int t = u * kCgBlk + tid;
-        if (t < 6 * ng) dyn[t] = rgreg[u] - alpha * sgreg[u];          // (roff[gl] = 0)
+        const int uu = (u + urot >= kGU) ? u + urot - kGU : u + urot;
+        const int t = uu * kCgBlk + tid;
+        if (t < 6 * ng) dyn[t] = VPRE ? rgreg[u] : rgreg[u] - alpha * sgreg[u];          // (roff[gl] = 0)
     }
     for (int t0 = kGU * kCgBlk + tid; t0 < 6 * ng; t0 += 4 * kCgBlk) {     // graphs beyond 12k free vertices: four values per lane and round trip
         double ra[4], sa[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int t = t0 + u * kCgBlk, tt = (t < 6 * ng) ? t : 0;
-            ra[u] = rg_old[tt]; sa[u] = init ? 0. : H.Sg[tt];
+            ra[u] = VPRE ? H.Vg[tt] : rg_old[tt]; sa[u] = (VPRE || init) ? 0. : sg_at<AGG>(H.Sg, gl, tt);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int t = t0 + u * kCgBlk;
-            if (t < 6 * ng) dyn[t] = ra[u] - alpha * sa[u];
+            if (t < 6 * ng) dyn[t] = VPRE ? ra[u] : ra[u] - alpha * sa[u];
         }
     }
     if (!comp) {
@@ -1578,7 +1604,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
             const double2* __restrict__ rr = reinterpret_cast<const double2*>(dyn);          // roff[gl] = 0
             double s0 = 0., s1 = 0., s2 = 0., s3q = 0.;
             const int n4 = n6 >> 2;
-#pragma unroll 8
+#pragma unroll 16
             for (int t = j; t < n4; t += 32) {
                 const float4 y = yr[t];
                 const double2 xa = rr[2 * t], xb = rr[2 * t + 1];
@@ -1732,6 +1758,25 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
 #ifdef UZL_STAMPS
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_stamps[31], 1ull);
 #endif
+}
+
+// alpha = r.z / p.Ap and v = rg - alpha Sg for ml_cg_kernel<4, true, false, true>: every workgroup sums the p.Ap partials (same order,
+// same alpha), each writes 256 entries of v; workgroup 0 leaves alpha and the breakdown flag in scal[9], scal[10].
+__global__ __launch_bounds__(256) void ml_alpha_kernel(PgoDev D, MlHot H, const double* __restrict__ rg_old, int n_part)
+{
+    __shared__ double s4[4];
+    if (D.flags[0]) return;
+    const int tid = threadIdx.x, t = blockIdx.x * 256 + tid, n6 = 6 * H.n[2];
+    double vp[4];
+    part_issue<256, 4>(D.part_a, n_part, tid, vp);
+    double rgv = 0., sgv = 0.;
+    if (t < n6) { rgv = rg_old[t]; sgv = sg_at<4>(H.Sg, 2, t); }
+    const double rz = D.scal[0];
+    const double pAp = block_sum_w<4>(part_fold<256, 4>(D.part_a, n_part, tid, vp), s4);
+    const bool bad = !(pAp > 0.);
+    const double alpha = bad ? 0. : rz / pAp;
+    if (t < n6) H.Vg[t] = rgv - alpha * sgv;
+    if (blockIdx.x == 0 && tid == 0) { D.scal[9] = alpha; D.scal[10] = bad ? 1. : 0.; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1923,6 +1968,8 @@ void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t 
     hipLaunchKernelGGL(ml_top_kernel, dim3(1), dim3(kBlk), 0, s, D, ml);
 }
 int g_ml_rows(int nb, int agg) { return (nb + kMlFanout * agg - 1) / (kMlFanout * agg); }
+// workgroups of ml_spmv (= p.Ap partials ml_cg sums): AGG = 4 runs two half workgroups per level-2 aggregate
+int g_ml_spmv(int nb, int agg) { return agg == 1 ? g_ml_rows(nb, 1) : g_ml_rows(nb, agg) * (8 / kSpmvWaves4); }
 // dynamic LDS of ml_cg_kernel for a hierarchy (n[0..levels]) and workgroup geometry agg
 size_t ml_cg_lds_bytes(const int* n, int levels, int agg)
 {
@@ -1937,7 +1984,7 @@ size_t ml_cg_lds_bytes(const int* n, int levels, int agg)
 }
 bool ml_fits_lds(const int* n_per_level, int levels, int agg)
 {
-    return ml_cg_lds_bytes(n_per_level, levels, agg) <= 140 * 1024 && g_ml_rows(n_per_level[0], agg) <= kMaxPartials;
+    return ml_cg_lds_bytes(n_per_level, levels, agg) <= 140 * 1024 && g_ml_spmv(n_per_level[0], agg) <= kMaxPartials;
 }
 void k_ml_init(const PgoDev& D, const MlHot& ml, int agg, double* p0, double* p1, double* rg, hipStream_t s)
 {
@@ -1950,22 +1997,28 @@ void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, d
 {
     if (ev_a) {
         if (agg == 1) hipExtLaunchKernelGGL(ml_spmv_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(512), 0, s, ev_a, ev_b, 0, D, ml, p_old, p_new, n_part, tol2);
-        else hipExtLaunchKernelGGL(ml_spmv_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(512), 0, s, ev_a, ev_b, 0, D, ml, p_old, p_new, n_part, tol2);
+        else hipExtLaunchKernelGGL(ml_spmv_kernel<4>, dim3(g_ml_spmv(D.nb, 4)), dim3(64 * kSpmvWaves4), 0, s, ev_a, ev_b, 0, D, ml, p_old, p_new, n_part, tol2);
         return;
     }
     if (agg == 1) hipLaunchKernelGGL(ml_spmv_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(512), 0, s, D, ml, p_old, p_new, n_part, tol2);
-    else hipLaunchKernelGGL(ml_spmv_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(512), 0, s, D, ml, p_old, p_new, n_part, tol2);
+    else hipLaunchKernelGGL(ml_spmv_kernel<4>, dim3(g_ml_spmv(D.nb, 4)), dim3(64 * kSpmvWaves4), 0, s, D, ml, p_old, p_new, n_part, tol2);
 }
 hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
                    int init, size_t lds, hipStream_t s, hipEvent_t ev_a, hipEvent_t ev_b)
 {
-    static size_t configured[4] = {0, 0, 0, 0};
+    static size_t configured[5] = {0, 0, 0, 0, 0};
     const bool comp4 = agg != 1 && ml.Cmat != nullptr;
     const bool ypre = comp4 && ml.levels >= 2 && 6 * ml.n[2] <= 4 * 32 * kYU;       // the six rows of Y_2 fit the registers
-    const int ci = agg == 1 ? 0 : (comp4 ? (ypre ? 3 : 2) : 1);
+    static const bool no_vpre = diag_flag("UZL_NO_VPRE");                            // A/B switch (diagnostic build)
+    const bool vpre = comp4 && !ypre && !init && ml.Vg != nullptr && !no_vpre;      // alpha and rg - alpha Sg prepared once, by ml_alpha_kernel
+    // COMP stages nothing but the gather-level vector: asking for the LDS of the full restrict / top / chain walk (52 KB at 20k
+    // vertices) held the kernel at two workgroups per CU - 625 workgroups ran in two rounds
+    if (comp4) lds = (size_t)6 * ml.n[2] * 8 + 64;
+    const int ci = agg == 1 ? 0 : (comp4 ? (ypre ? 3 : (vpre ? 4 : 2)) : 1);
     if (lds > configured[ci]) {
         const void* fn = agg == 1 ? reinterpret_cast<const void*>(&ml_cg_kernel<1>)
-                                  : (comp4 ? (ypre ? reinterpret_cast<const void*>(&ml_cg_kernel<4, true, true>) : reinterpret_cast<const void*>(&ml_cg_kernel<4, true>))
+                                  : (comp4 ? (ypre ? reinterpret_cast<const void*>(&ml_cg_kernel<4, true, true>)
+                                                   : (vpre ? reinterpret_cast<const void*>(&ml_cg_kernel<4, true, false, true>) : reinterpret_cast<const void*>(&ml_cg_kernel<4, true>)))
                                            : reinterpret_cast<const void*>(&ml_cg_kernel<4>));
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1985,12 +2038,20 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
     if (ev_a) {
         if (agg == 1) hipExtLaunchKernelGGL(ml_cg_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
         else if (ypre) hipExtLaunchKernelGGL((ml_cg_kernel<4, true, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
+        else if (vpre) {
+            hipLaunchKernelGGL(ml_alpha_kernel, dim3((6 * ml.n[2] + 255) / 256), dim3(256), 0, s, D, ml, rg_old, n_part);
+            hipExtLaunchKernelGGL((ml_cg_kernel<4, true, false, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
+        }
         else if (comp4) hipExtLaunchKernelGGL((ml_cg_kernel<4, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
         else hipExtLaunchKernelGGL(ml_cg_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
         return hipSuccess;
     }
     if (agg == 1) hipLaunchKernelGGL(ml_cg_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     else if (ypre) hipLaunchKernelGGL((ml_cg_kernel<4, true, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
+    else if (vpre) {
+        hipLaunchKernelGGL(ml_alpha_kernel, dim3((6 * ml.n[2] + 255) / 256), dim3(256), 0, s, D, ml, rg_old, n_part);
+        hipLaunchKernelGGL((ml_cg_kernel<4, true, false, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
+    }
     else if (comp4) hipLaunchKernelGGL((ml_cg_kernel<4, true>), dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     else hipLaunchKernelGGL(ml_cg_kernel<4>, dim3(g_ml_rows(D.nb, 4)), dim3(kCgBlk), lds, s, D, ml, p, rg_old, rg_new, n_part, init);
     return hipSuccess;

@@ -53,7 +53,8 @@ struct PgoDev {
     double* part_b;          // [kMaxPartials] block partials (r.z, scale, ...)
     double* part_c;          // [kMaxPartials] block partials (max |H_jj|)
     double* scal;            // [16]: 0 rz, 1 rz threshold, 2 rz_prev, 3 lambda, 4 chi2, 5 scale, 6 diagmax, 7 |r|^2 / |b|^2 after PCG,
-                             //       8 factor on pcg_tol^2 for this LM iteration's solves (host: do_optimize); 0..7 go back to the host
+                             //       8 factor on pcg_tol^2 for this LM iteration's solves (host: do_optimize), 9 alpha and 10 breakdown of the current PCG
+                             //       iteration (ml_alpha_kernel -> ml_cg_kernel); 0..7 go back to the host
     int32_t* flags;          // [4]: 0 done, 1 iterations, 2 breakdown
 };
 
@@ -131,7 +132,8 @@ struct MlHot {
     const float* Cmat32;                   // the copy the PCG kernels apply: Y_cl rounded to f32, [6 n_cl][c32_stride] (rows 6A..6A+5 belong to
     int32_t c32_stride;                    // workgroup A; stride = 6 n_cl rounded up to 4, pad = 0).  A preconditioner needs no more, the
     int32_t c32_pad;                       // operator is still one fixed linear map per solve, and it is the kernels' largest stream.
-    double* Sg;                            // [n_g][6] restriction of A p at the gather level g = min(2, levels)
+    double* Sg;                            // [n_g][6] restriction of A p at the gather level g = min(2, levels) (gather level 2: [n_2][6][2], see sg_at)
+    double* Vg;                            // [6 n_2] gather-level residual estimate rg - alpha Sg prepared by ml_alpha_kernel (graphs of 12k .. 21.8k vertices)
 };
 
 // ---- batched solve: B graphs of identical hierarchy shape advance through one launch sequence (uzl_pgo_batch_*) ----------------

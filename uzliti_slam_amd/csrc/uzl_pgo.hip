@@ -47,6 +47,7 @@ void k_ml_cmat32(const MlHot& hot, int n6, hipStream_t s);
 void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int lev, int n1, const double* X, double* T, double* Xn, hipStream_t s,
                   hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 int g_ml_rows(int nb, int agg);
+int g_ml_spmv(int nb, int agg);
 size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
 bool ml_fits_lds(const int* n_per_level, int levels, int agg);
 void k_ml_init(const PgoDev& D, const MlHot& ml, int agg, double* p0, double* p1, double* rg, hipStream_t s);
@@ -479,8 +480,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     const size_t o_tmp = take(max_contrib * 36 * 8), o_tmpG = take(max_n * 36 * 8), o_tmpM = take(max_n * 36 * 8);
     const size_t o_top = take((size_t)(6 * kMlTopMax) * (6 * kMlTopMax) * 8);
     const int gl = (h->ml_agg == 1 || L < 2) ? 1 : 2;
-    const size_t ngz = (size_t)std::max(h->ml_n[gl], 1) * 6 * 8;
-    const size_t o_sg = take(ngz), o_rga = take(ngz), o_rgb = take(ngz);
+    const size_t ngz = (size_t)std::max(h->ml_n[gl], 1) * 6 * 8 * 2;          // (x 2: the gather-level-2 Sg holds two parts per entity)
+    const size_t o_sg = take(ngz), o_rga = take(ngz), o_rgb = take(ngz), o_vg = take(ngz);
     const size_t buf_bytes = (bytes + 255) / 256 * 256;
     h->ml_arena.reserve(2 * buf_bytes);
     std::vector<uint8_t> stage(int_bytes, 0);
@@ -549,7 +550,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         memset(&Hh, 0, sizeof(Hh));
         Hh.levels = L;
         for (int l = 0; l <= L; l++) { Hh.n[l] = h->ml_n[l]; Hh.fan[l] = h->ml_fan[l]; Hh.geo[l] = M.lv[l].geo; Hh.Winv[l] = M.lv[l].Winv; }
-        Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg;
+        Hh.geo0 = M.lv[0].geo; Hh.top_inv = M.top_inv; Hh.Sg = M.Sg; Hh.Vg = reinterpret_cast<double*>(base + o_vg);
         Hh.Cmat = h->ml_comp ? ((h->ml_ns_steps & 1) ? M.nsX : M.Ydense[cl]) : nullptr;   // Newton-Schulz steps ping-pong Y_cl <-> nsX
         Hh.Cmat32 = h->ml_comp ? reinterpret_cast<const float*>(base + o_c32) : nullptr;
         Hh.c32_stride = c32_stride;
@@ -741,10 +742,10 @@ void build_structure(uzl_pgo* h)
     build_ml(h, row_ptr, col);
     {   // per-iteration exchange buffer: [A p (6 nb) | restricted A p (6 n_g) | p.Ap partials]
         const int gl = (h->ml_levels == 0) ? 0 : ((h->ml_agg == 1 || h->ml_levels < 2) ? 1 : 2);
-        const size_t ng6 = gl ? (size_t)h->ml_n[gl] * 6 : 0;
+        const size_t ng6 = gl ? (size_t)h->ml_n[gl] * 6 * (gl == 2 ? 2 : 1) : 0;      // gather level 2: two half-aggregate parts per entity (sg_at)
         if (gl) { h->mlb[0].hot.Sg = h->d_ap.p + (size_t)nb * 6; h->mlb[1].hot.Sg = h->mlb[0].hot.Sg; }
         D.part_a = h->d_ap.p + (size_t)nb * 6 + ng6;
-        h->iter_span = (int64_t)((size_t)nb * 6 + ng6 + (gl ? (size_t)g_ml_rows(nb, h->ml_agg) : 0));
+        h->iter_span = (int64_t)((size_t)nb * 6 + ng6 + (gl ? (size_t)g_ml_spmv(nb, h->ml_agg) : 0));
     }
     D.sibling0 = (h->ml_levels > 0 && h->ml_agg == 1) ? 1 : 0;       // large graphs keep the level-0 smoother block-diagonal
     // ---- sharded solve (BASELINE config 4): this rank linearises a contiguous range of the system edges
@@ -769,7 +770,7 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
     const PgoDev& D = h->D;
     const double tol2 = h->cfg.pcg_tol * h->cfg.pcg_tol;
     const bool ml = h->ml_levels > 0;
-    const int ga = ml ? g_ml_rows(D.nb, h->ml_agg) : g_pcg_spmv(D.nb), gu = ml ? g_ml_rows(D.nb, h->ml_agg) : g_pcg_update(D.nb);
+    const int ga = ml ? g_ml_spmv(D.nb, h->ml_agg) : g_pcg_spmv(D.nb), gu = ml ? g_ml_rows(D.nb, h->ml_agg) : g_pcg_update(D.nb);   // partials written by spmv / by cg
     double* pb[2] = {h->d_p.p, h->d_p2.p};
     for (int i = 0; i < 2 * pairs; i++) {
         double* po = pb[i & 1];
