@@ -1351,9 +1351,10 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_stamps[47], 1ull);
 #endif
 }
-// 4 waves per SIMD = two 512-lane workgroups per CU (<= 128 VGPRs; the body needs 96 at AGG = 1 and ~144 unconstrained at AGG = 4)
+// AGG = 1: 4 waves per SIMD = two 512-lane workgroups per CU (<= 128 VGPRs; the body needs 98).  AGG = 4: 140 VGPRs, 3 waves per SIMD =
+// three 256-lane workgroups per CU (held at 128 it spilled 44 B per lane and was slower: 18.5 vs 17.3 us at 10k vertices)
 template <int AGG>
-__global__ __launch_bounds__(AGG == 1 ? 512 : 64 * kSpmvWaves4) __attribute__((amdgpu_waves_per_eu(4))) void ml_spmv_kernel(PgoDev D, MlHot H, const double* __restrict__ p_old, double* __restrict__ p_new, int n_part, double tol2)
+__global__ __launch_bounds__(AGG == 1 ? 512 : 64 * kSpmvWaves4) __attribute__((amdgpu_waves_per_eu(AGG == 1 ? 4 : 3))) void ml_spmv_kernel(PgoDev D, MlHot H, const double* __restrict__ p_old, double* __restrict__ p_new, int n_part, double tol2)
 {
     ml_spmv_kernel_body<AGG>(D, H, p_old, p_new, n_part, tol2);
 }
