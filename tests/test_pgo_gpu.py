@@ -343,9 +343,10 @@ def test_ns_gemm_matrix_core_layout(capi, n):
         assert rc == 0
         return out
 
-    # arbitrary operands: upper tiles = 2 X - X T, lower tiles = their mirror images
+    # arbitrary operands: the X tile of the product is read through X's symmetry (as X[k][row]), so upper tiles = 2 X - X^T T,
+    # lower tiles = their mirror images
     X = rng.normal(size=(n, n)); T = rng.normal(size=(n, n))
-    full = 2 * X - X @ T
+    full = 2 * X - X.T @ T
     ti = np.arange(n) // 64
     upper = ti[:, None] <= ti[None, :]
     want = np.where(upper, full, full.T)

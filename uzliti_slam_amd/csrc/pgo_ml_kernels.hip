@@ -743,8 +743,14 @@ __device__ __forceinline__ void tri_tile(int gt, int b, int& ti, int& tj)
 __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __restrict__ X, const double* __restrict__ T,
                                                         double* __restrict__ Xn)
 {
-    __shared__ double sA[kGemmTile][kGemmK + 1];      // X tile: sA[row][k]
-    __shared__ double sB[kGemmK][kGemmTile + 1];      // T tile: sB[k][col]
+    // Both operand tiles sit k-major in LDS, s[k][i ^ 16 (k & 1)]: the 16 x 4 (row or column, k) doubles one MFMA operand read takes
+    // then fall into 64 different banks per half wave (rows padded to 65 doubles put (i, k) and (i + 1, k - 1) on the same bank: 2- to
+    // 4-way conflicts on every read).  The X tile is read through X's symmetry (X[k][row], lanes along the row: contiguous in memory
+    // and in LDS) - X is symmetric in the refinement.  Measured: no faster than the padded layout (1.32 ms at n = 3750, 40 TFLOP/s) -
+    // with 64 x 64 tiles the kernel moves 8 flops per operand byte, 5.4 TB/s out of the Infinity Cache at that rate: the operand
+    // stream, not the LDS and not the matrix pipe, sets the pace (slabs of 32 with four workgroups per CU: 1.21 ms, and slower at n = 750).
+    __shared__ double sA[kGemmK][kGemmTile];          // sA[k][row ^ swz(k)] = X[row][k]
+    __shared__ double sB[kGemmK][kGemmTile];          // sB[k][col ^ swz(k)] = T[k][col]
     constexpr int kPer = kGemmTile * kGemmK / 256;     // values per lane and operand per slab
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // X, A and therefore X (A X) are symmetric: only the tiles on and above the diagonal are computed (blockIdx.x counts them row by
@@ -766,28 +772,28 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
 #pragma unroll
         for (int u = 0; u < kPer; u++) {
             const int e = u * 256 + tid;
-            const int ar = e / kGemmK, ak = e % kGemmK;                          // X: consecutive lanes walk k (contiguous in memory)
-            const int gr = row0 + ar, gk = k0 + ak;
-            pa[u] = (gr < n && gk < n) ? X[(size_t)gr * n + gk] : 0.;
-            const int bk = e / kGemmTile, bc = e % kGemmTile;                    // T: consecutive lanes walk the column
-            const int gk2 = k0 + bk, gc = col0 + bc;
-            pb[u] = (gk2 < n && gc < n) ? T[(size_t)gk2 * n + gc] : 0.;
+            const int ek = e / kGemmTile, ei = e % kGemmTile;                    // consecutive lanes walk the row / column index
+            const int gk = k0 + ek, gr = row0 + ei, gc = col0 + ei;
+            pa[u] = (gk < n && gr < n) ? X[(size_t)gk * n + gr] : 0.;            // = X[gr][gk]
+            pb[u] = (gk < n && gc < n) ? T[(size_t)gk * n + gc] : 0.;
         }
     };
     fetch(0);
+    const int sw = (lk & 1) << 4;                       // k4 is a multiple of 4: (k4 + lk) & 1 = lk & 1
     for (int k0 = 0; k0 < n; k0 += kGemmK) {
 #pragma unroll
         for (int u = 0; u < kPer; u++) {
             const int e = u * 256 + tid;
-            sA[e / kGemmK][e % kGemmK] = pa[u];
-            sB[e / kGemmTile][e % kGemmTile] = pb[u];
+            const int ek = e / kGemmTile, ei = (e % kGemmTile) ^ ((ek & 1) << 4);
+            sA[ek][ei] = pa[u];
+            sB[ek][ei] = pb[u];
         }
         __syncthreads();
         if (k0 + kGemmK < n) fetch(k0 + kGemmK);
 #pragma unroll 4
         for (int k4 = 0; k4 < kGemmK; k4 += 4) {
-            const double a0 = sA[wr + li][k4 + lk], a1 = sA[wr + 16 + li][k4 + lk];
-            const double b0 = sB[k4 + lk][wc + li], b1 = sB[k4 + lk][wc + 16 + li];
+            const double a0 = sA[k4 + lk][(wr + li) ^ sw], a1 = sA[k4 + lk][(wr + 16 + li) ^ sw];
+            const double b0 = sB[k4 + lk][(wc + li) ^ sw], b1 = sB[k4 + lk][(wc + 16 + li) ^ sw];
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
