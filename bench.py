@@ -226,10 +226,15 @@ def pgo_rooflines(pgo, st, st_prof, kt, nodes, edges, is_default):
     if gm and gm["ms"] > 0:
         n1 = (nb + 7) // 8
         n_c = n1 if not agg4 else (n1 + 3) // 4
-        flop = 2.0 * (6.0 * n_c) ** 3
+        # the product is symmetric: the kernel computes the 64 x 64 tiles on and above the diagonal and mirrors them; flops = what it executes
+        n6 = int(6 * n_c); gt = (n6 + 63) // 64
+        ext = [min(64, n6 - 64 * i) for i in range(gt)]
+        upper = sum(ext[i] * ext[j] for i in range(gt) for j in range(i, gt))
+        flop = 2.0 * n6 * upper
         out.append(roof("ml_ns_gemm_kernel", "mfma", flop * gm["launches"] / (gm["ms"] * 1e-3) / 1e12, F64_PEAK_TFLOPS, "TFLOP/s (f64 matrix cores)",
-                        traffic=None, flop_per_launch=flop, n=int(6 * n_c), avg_launch_us=round(1e3 * gm["ms"] / gm["launches"], 3), launches=gm["launches"],
-                        note="the block-GEMM of the path: X' = 2X - X(AX), v_mfma_f64_16x16x4_f64, 64 x 64 tiles; %d launches per solve" % gm["launches"]))
+                        traffic=None, flop_per_launch=flop, n=n6, avg_launch_us=round(1e3 * gm["ms"] / gm["launches"], 3), launches=gm["launches"],
+                        note="the block-GEMM of the path: X' = 2X - X(AX), v_mfma_f64_16x16x4_f64, 64 x 64 tiles on and above the diagonal (the product is symmetric: "
+                             "%.0f %% of 2 n^3); %d launches per solve" % (100.0 * flop / (2.0 * n6 ** 3), gm["launches"])))
     return out
 
 
