@@ -1772,13 +1772,14 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
 __global__ __launch_bounds__(256) void ml_alpha_kernel(PgoDev D, MlHot H, const double* __restrict__ rg_old, int n_part)
 {
     __shared__ double s4[4];
-    if (D.flags[0]) return;
+    const int done = D.flags[0];                  // checked behind the loads: 15 workgroups, nothing to save by leaving before them
     const int tid = threadIdx.x, t = blockIdx.x * 256 + tid, n6 = 6 * H.n[2];
     double vp[4];
     part_issue<256, 4>(D.part_a, n_part, tid, vp);
     double rgv = 0., sgv = 0.;
     if (t < n6) { rgv = rg_old[t]; sgv = sg_at<4>(H.Sg, 2, t); }
     const double rz = D.scal[0];
+    if (done) return;
     const double pAp = block_sum_w<4>(part_fold<256, 4>(D.part_a, n_part, tid, vp), s4);
     const bool bad = !(pAp > 0.);
     const double alpha = bad ? 0. : rz / pAp;

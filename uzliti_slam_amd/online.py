@@ -185,7 +185,8 @@ class OnlineSlam:
             acc, _, _ = self.gate.check(cands)
         else:
             acc = np.zeros(0, np.uint8)
-        self.t["gate"] += time.perf_counter() - t0
+        t_gate = time.perf_counter() - t0
+        self.t["gate"] += t_gate
         # ---- trigger: first node boundary with >= reopt_edges new edges
         per_node = np.ones(hi - self.cur, np.int64)
         np.add.at(per_node, later[cand_pair[acc != 0]] - self.cur, 1)
@@ -213,7 +214,7 @@ class OnlineSlam:
         n_nodes = last + 1
         self.cur = n_nodes
         if not len(trig) and not final:
-            self.t["host"] += time.perf_counter() - t_host
+            self.t["host"] += time.perf_counter() - t_host - t_gate
             return True
         # ---- keep the matcher busy while the solver runs: the next batch is launched before, collected after
         self._launch_next()
@@ -233,7 +234,8 @@ class OnlineSlam:
         valid_keys = self.filt.valid_edges().astype(np.int64)
         self.f_sticky |= np.isin(self.f_key, valid_keys)                            # graph.edge(id).valid_ = true (:101)
         in_solve = np.isin(self.f_key, valid_keys)
-        self.t["filter"] += time.perf_counter() - t0
+        t_filter = time.perf_counter() - t0
+        self.t["filter"] += t_filter
         # ---- re-optimise (addGraphImpl: full rebuild; optimizeImpl; storeImpl)
         e = self._graph_edges(n_nodes)
         e["valid"][n_nodes - 1:] = in_solve                                         # only validEdges() enter the solve (:98-103)
@@ -254,7 +256,7 @@ class OnlineSlam:
             self.log("solve %3d: %5d nodes %5d feature edges (%d valid)  chi2 %.4g -> %.4g  %d LM its %d pcg  add %.1f ms opt %.1f ms"
                      % (len(self.solves), n_nodes, nf, int(in_solve.sum()), st["chi2_initial"], st["chi2_final"], st["iterations_done"],
                         st["pcg_iterations"], st["add_graph_ms"], st["optimize_ms"]))
-        self.t["host"] += time.perf_counter() - t_host - (t3 - t0)
+        self.t["host"] += time.perf_counter() - t_host - (t3 - t0) - t_gate - t_filter        # this driver's own bookkeeping
         return self.cur < self.N
 
     def run_all(self):
