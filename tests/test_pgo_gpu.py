@@ -416,6 +416,20 @@ def test_chain_like_graphs(capi, oracle, n, e, its):
         p.close()
 
 
+@pytest.mark.parametrize("n,e", [(10000, 10800), (12600, 13600), (20000, 21700), (23000, 24600)])
+def test_large_sparse_graphs_on_every_kernel_path_against_oracle(capi, oracle, n, e):
+    """The large-graph PCG kernels against the oracle's direct solve at sizes the oracle still finishes in a second (few loop closures:
+    little fill): 10k = six rows of the level-2 operator in registers (ml_cg_kernel<4, true, true>), 12.6k and 20k = ml_alpha_kernel +
+    streamed rows (ml_cg_kernel<4, true, false, true>; 6 n_2 = 2364 / 3750), 23k = no dense level-2 operator (6 n_2 > 4096:
+    ml_cg_kernel<4>, restrict / top solve / prolong through LDS); ml_spmv_kernel<4> in half-aggregate workgroups throughout."""
+    p = capi.Pgo()
+    try:
+        st, so = _check(p, oracle, synth.make_pose_graph(n, e, seed=n), iterations=6)
+        assert st["pcg_not_converged"] == 0
+    finally:
+        p.close()
+
+
 def test_vertex_order_does_not_matter(capi, oracle):
     """The aggregates of the preconditioner are 8 consecutive blocks of an order derived from the graph (heaviest-edge chains,
     uzl_pgo.hip aggregation_order), not of the node index: renumbered nodes, two sessions with interleaved ids (merged / global-scope
