@@ -51,6 +51,14 @@ struct uzl_match {
     DevBuf<double> d_P, d_Q;
     // wire batches (uzl_match_add_frames_wire / frame_to_wire): raw Feature records, segment table, u/v, error flag
     DevBuf<uint32_t> d_wire_stage; DevBuf<WireSeg> d_wire_segs; DevBuf<int32_t> d_wire_uv; DevBuf<int32_t> d_wire_bad;
+    // uzl_match_add_frame staging: the caller's three arrays are packed into pinned memory in the frame's arena layout and go up as ONE
+    // asynchronous copy; the call returns without waiting (the inputs are no longer needed once packed).  Two halves: a half is reused
+    // only after the copies issued from it have completed (event).
+    PinBuf<uint8_t> h_up;
+    hipEvent_t up_ev[2] = {nullptr, nullptr};
+    bool up_pending[2] = {false, false};
+    int up_half = 0;
+    size_t up_used = 0;
     bool in_flight = false;
     int32_t fl_jobs = 0, fl_stride = 0, fl_max_corr = 0;
     bool fl_diag = false;
@@ -66,6 +74,7 @@ int fail(uzl_match* h, int code, const char* msg)
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t kUpHalf = 8u << 20;          // bytes per half of the add_frame staging buffer
 
 int next_pow2(int v)
 {
@@ -358,6 +367,7 @@ void uzl_match_destroy(uzl_match* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    for (auto& e : h->up_ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -394,10 +404,30 @@ int uzl_match_add_frame(uzl_match* h, const uzl_frame* f, int32_t* frame_id)
     if (h->in_flight && off > h->arena.cap) return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
     h->arena.reserve(off, /*keep=*/true, h->stream);
     if (n) {
-        UZL_HIP(hipMemcpyAsync(h->arena.p + r.desc_off, f->desc, desc_b, hipMemcpyHostToDevice, h->stream));
-        UZL_HIP(hipMemcpyAsync(h->arena.p + r.pos_off, f->pos_xyz, pos_b, hipMemcpyHostToDevice, h->stream));
-        UZL_HIP(hipMemcpyAsync(h->arena.p + r.valid_off, f->valid3d, val_b, hipMemcpyHostToDevice, h->stream));
-        UZL_HIP(hipStreamSynchronize(h->stream));   // inputs are borrowed only for the duration of the call
+        const size_t span = r.valid_off + val_b - r.desc_off;        // [desc | pad | pos | pad | valid] as it lies in the arena
+        if (span <= kUpHalf) {
+            if (!h->h_up.p) {
+                h->h_up.reserve(2 * kUpHalf);
+                for (auto& e : h->up_ev) UZL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            if (h->up_used + span > kUpHalf) {                       // this half is full: close it, move to the other one once it is free
+                UZL_HIP(hipEventRecord(h->up_ev[h->up_half], h->stream));
+                h->up_pending[h->up_half] = true;
+                h->up_half ^= 1; h->up_used = 0;
+                if (h->up_pending[h->up_half]) { UZL_HIP(hipEventSynchronize(h->up_ev[h->up_half])); h->up_pending[h->up_half] = false; }
+            }
+            uint8_t* st = h->h_up.p + (size_t)h->up_half * kUpHalf + h->up_used;
+            memcpy(st, f->desc, desc_b);
+            memcpy(st + (r.pos_off - r.desc_off), f->pos_xyz, pos_b);
+            memcpy(st + (r.valid_off - r.desc_off), f->valid3d, val_b);
+            UZL_HIP(hipMemcpyAsync(h->arena.p + r.desc_off, st, span, hipMemcpyHostToDevice, h->stream));
+            h->up_used += align_up(span, 256);
+        } else {                                                     // a frame larger than the staging half: straight from the caller's arrays
+            UZL_HIP(hipMemcpyAsync(h->arena.p + r.desc_off, f->desc, desc_b, hipMemcpyHostToDevice, h->stream));
+            UZL_HIP(hipMemcpyAsync(h->arena.p + r.pos_off, f->pos_xyz, pos_b, hipMemcpyHostToDevice, h->stream));
+            UZL_HIP(hipMemcpyAsync(h->arena.p + r.valid_off, f->valid3d, val_b, hipMemcpyHostToDevice, h->stream));
+            UZL_HIP(hipStreamSynchronize(h->stream));   // inputs are borrowed only for the duration of the call
+        }
     }
     h->arena_used = off;
     r.alive = true; r.n = f->n; r.words = f->bytes_per_desc / 4;
