@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: randomized solver-vs-oracle sweep over graph sizes, loop densities, outlier fractions, orders and xy-only.
-  python tests/diag/stress_pgo.py [n_cases] [seed]      prints one line per case and a summary; exit code 1 on any miss"""
+  python tests/diag/stress_pgo.py [n_cases] [seed] [large]     prints one line per case and a summary; exit code 1 on any miss
+  `large`: sizes 7000 .. 24000 at 1.01 .. 1.3 edges per node (the oracle's direct solve stays fast on sparse graphs) - the large-graph
+  kernel paths (rows of the level-2 operator in registers / ml_alpha_kernel / no dense level-2 operator)."""
 import os
 import sys
 import time
@@ -13,11 +15,16 @@ from uzliti_slam_amd import capi, synth              # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"
 bad = 0
 p = capi.Pgo()
 for k in range(n_cases):
-    n = int(rng.choice([150, 400, 900, 1500, 2300, 3500, 5000]))
-    dens = float(rng.choice([1.01, 1.05, 1.3, 2.0, 3.5, 5.0]))
+    if LARGE:
+        n = int(rng.choice([7000, 9500, 12000, 12500, 15000, 19000, 23000]))
+        dens = float(rng.choice([1.01, 1.05, 1.15, 1.3]))
+    else:
+        n = int(rng.choice([150, 400, 900, 1500, 2300, 3500, 5000]))
+        dens = float(rng.choice([1.01, 1.05, 1.3, 2.0, 3.5, 5.0]))
     e = max(n - 1, int(n * dens))
     its = int(rng.choice([3, 8, 15]))
     xy = bool(rng.random() < 0.25)

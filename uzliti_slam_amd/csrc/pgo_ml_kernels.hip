@@ -1143,7 +1143,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     __shared__ double sw[kRowsPerBlk * 6];
     __shared__ double ss1[kAggPerBlk * 6];
     __shared__ double sg1[kAggPerBlk * 3];
-    if (D.flags[0]) return;               // (a launch after convergence must stay a ~0.6 us no-op: 16-iteration graph batches overshoot)
+    const int done = D.flags[0];            // looked at behind the first loads (below): its round trip runs beside theirs, not in front
     STAMP_DECL
     const int gl = (AGG == 1 || H.levels < 2) ? 1 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane / 6, r = lane % 6;
@@ -1154,10 +1154,6 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     part_issue<kSpmvBlk, 2>(D.part_b, n_part, tid, vpart);
     const int it = D.flags[1];
     const double rz_prev = D.scal[2], thr_old = D.scal[1], lambda = D.scal[3];
-    if (tid < kAggPerBlk * 3) {
-        const int A1 = blockIdx.x * kAggPerBlk + tid / 3;
-        sg1[tid] = (gl == 2 && A1 < H.n[1]) ? H.geo[1][(size_t)A1 * 3 + tid % 3] : 0.;
-    }
     // slot range and this lane group's columns of the first TWO slot passes: ONE hop (row header).  Rows have ~10 slots on the
     // BASELINE graphs, i.e. four in ten need a second pass; with its column already here the second pass is one more round trip
     // instead of two per row (column index, then block and vectors), and rows of a wave take it together instead of one by one.
@@ -1170,6 +1166,13 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         s1[q] = (a < D.nb) ? hd[1] : 0;
         cf[q] = (a < D.nb && lact) ? hd[2 + g] : -1;
         cf2[q] = (a < D.nb && lact) ? hd[12 + g] : -1;
+    }
+    // (a launch after convergence must stay cheap: 16-iteration graph batches overshoot.  Leaving here costs it the issue of the loads
+    //  above - nothing waits for them - and saves every working launch the done flag's round trip in front of its first load.)
+    if (done) return;
+    if (tid < kAggPerBlk * 3) {
+        const int A1 = blockIdx.x * kAggPerBlk + tid / 3;
+        sg1[tid] = (gl == 2 && A1 < H.n[1]) ? H.geo[1][(size_t)A1 * 3 + tid % 3] : 0.;
     }
     // Every lane (g, r) multiplies row r of a 6x6 block with the 6-vector z + beta p_old of the block's column.  The six lanes of a
     // group need the same vector: each loads ONE component (the six loads of a group are one contiguous 48 B) and the vector is
