@@ -150,7 +150,9 @@ const char* uzl_match_last_error(uzl_match* h);
 
 /* Upload one FeatureData into the handle's HBM-resident frame store (the reference deep-copies
  * both SlamNodes per enqueue, transformation_estimator.cpp:39; here a frame is uploaded once and
- * referenced by every pair job that uses it).  Returns the frame id through *frame_id. */
+ * referenced by every pair job that uses it).  Returns the frame id through *frame_id.  The frame's arrays are
+ * borrowed for the duration of the call only: they are packed into pinned staging memory and go up as one
+ * asynchronous copy on the handle's stream, in front of whatever the handle is asked to do next. */
 int  uzl_match_add_frame(uzl_match* h, const uzl_frame* frame, int32_t* frame_id);
 int  uzl_match_remove_frame(uzl_match* h, int32_t frame_id);
 int  uzl_match_frame_count(uzl_match* h);
