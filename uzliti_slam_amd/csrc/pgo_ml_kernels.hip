@@ -1119,6 +1119,14 @@ __global__ __launch_bounds__(kCgBlk) void ml_init_kernel(PgoDev D, MlHot H, doub
     ml_init_kernel_body<AGG>(D, H, p0, p1, rg);
 }
 
+// This file is compiled with -ffp-contract=off (two geometries of one kernel body must give the same bits): the products that matter
+// for speed say fma() themselves.
+__device__ __forceinline__ double dot6(double2 a0, double2 a1, double2 a2, double v0, double v1, double v2, double v3, double v4, double v5)
+{
+    double t = a0.x * v0;
+    t = fma(a0.y, v1, t); t = fma(a1.x, v2, t); t = fma(a1.y, v3, t); t = fma(a2.x, v4, t); t = fma(a2.y, v5, t);
+    return t;
+}
 // restricted A p of gather-level entity t / 6, component t % 6.  Gather level 2 (AGG = 4): the sum of ml_spmv's two half-aggregate parts
 template <int AGG>
 __device__ __forceinline__ double sg_at(const double* __restrict__ Sg, int gl, int t)
@@ -1133,13 +1141,20 @@ __device__ __forceinline__ double sg_at(const double* __restrict__ Sg, int gl, i
 //   per CU took 15.5 us, two 23.7): 313 workgroups of a 10k-vertex graph on 256 CUs left 57 CUs with twice the work of the rest;
 //   626 half workgroups put at most 1.5 times the mean on one CU.
 constexpr int kSpmvWaves4 = 4;
-template <int AGG>
+// Geometry of the workgroup (RPW rows per wave x WAVES waves) is separate from the hierarchy it serves (AGG): the batched solve runs
+// the AGG = 1 hierarchy with four rows per wave in 128-lane workgroups (ml_spmv_batch_kernel) - four times the bytes in flight per
+// wave when sixteen graphs fill the chip - where a single small graph wants one row per wave for the shortest chain.  Both give the
+// same bits: every sum that crosses rows or lanes is taken in an order that does not depend on the geometry (row sums of six
+// components, then rows in order; the r.z partials in groups of 64, then groups in order).
+template <int AGG, int RPW = AGG, int WAVES = (AGG == 1 ? 8 : kSpmvWaves4)>
 __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const double* __restrict__ p_old,
                                                      double* __restrict__ p_new, int n_part, double tol2)
 {
-    constexpr int kWaves = (AGG == 1) ? 8 : kSpmvWaves4, kSpmvBlk = 64 * kWaves, kRowsPerWave = AGG;
+    constexpr int kWaves = WAVES, kRowsPerWave = RPW;
     constexpr int kRowsPerBlk = kWaves * kRowsPerWave, kAggPerBlk = kRowsPerBlk / kMlFanout;
-    __shared__ double s8[kWaves];
+    constexpr int kGrpU = (kWaves >= 8) ? 2 : 4;          // groups of 64 r.z partials a wave fetches up front (1024 / 1024 / 512 partials in all)
+    __shared__ double sgrp[kMaxPartials / 64];
+    __shared__ double sd[kRowsPerBlk * 6];
     __shared__ double sw[kRowsPerBlk * 6];
     __shared__ double ss1[kAggPerBlk * 6];
     __shared__ double sg1[kAggPerBlk * 3];
@@ -1150,8 +1165,13 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     const bool lact = lane < 60;
     const int row0 = blockIdx.x * kRowsPerBlk + wv * kRowsPerWave;
     // ---- prefetch (independent of beta); the r.z partials first: they gate everything else
-    double vpart[2];
-    part_issue<kSpmvBlk, 2>(D.part_b, n_part, tid, vpart);
+    double vpart[kGrpU];                      // wave wv takes groups wv, wv + kWaves, ...; lane = element of the group
+#pragma unroll
+    for (int u = 0; u < kGrpU; u++) {
+        const int i = (wv + u * kWaves) * 64 + lane;
+        const double x = D.part_b[i < n_part ? i : 0];
+        vpart[u] = (i < n_part) ? x : 0.;
+    }
     const int it = D.flags[1];
     const double rz_prev = D.scal[2], thr_old = D.scal[1], lambda = D.scal[3];
     // slot range and this lane group's columns of the first TWO slot passes: ONE hop (row header).  Rows have ~10 slots on the
@@ -1214,7 +1234,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) {
         have2[q] = false; yr[q] = 0.; qr[q] = 0.;
-        if (AGG == 1) {
+        if (kRowsPerWave == 1) {
             const int s = s0[q] + g + 10;
             const int c = cf2[q];
             if (lact && s < s1[q] && c >= 0) {
@@ -1227,34 +1247,53 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     }
     STAMP(16);     // 16: prefetch issue
     // ---- beta
-    const double rz = block_sum_w<kWaves>(part_fold<kSpmvBlk, 2>(D.part_b, n_part, tid, vpart), s8);
+    const int n_grp = (n_part + 63) >> 6;
+#pragma unroll
+    for (int u = 0; u < kGrpU; u++) {
+        const int gi = wv + u * kWaves;
+        const double sgi = wave_sum(vpart[u]);
+        if (lane == 0 && gi < n_grp) sgrp[gi] = sgi;
+    }
+    for (int gi = wv + kGrpU * kWaves; gi < n_grp; gi += kWaves) {       // beyond kGrpU * kWaves * 64 partials: one group per round trip
+        const int i = gi * 64 + lane;
+        const double sgi = wave_sum(i < n_part ? D.part_b[i] : 0.);
+        if (lane == 0) sgrp[gi] = sgi;
+    }
+    __syncthreads();
+    double rz = 0.;
+    for (int gi = 0; gi < n_grp; gi++) rz += sgrp[gi];
     const double beta = (it == 0) ? 0. : rz / rz_prev;
     const double thresh = (it == 0) ? (tol2 * D.scal[8]) * rz : thr_old;       // scal[8]: the LM iteration's tightening of pcg_tol^2 (uzl_pgo.hip)
     STAMP(16);     // 17: partial reduction (prefetch landed)
     // ---- row products: diagonal block + first slot pass of every row ...
-    const double pr = zo_r + beta * po_r;             // component r of the new direction of row `arow` (lanes with dact)
+    const double pr = fma(beta, po_r, zo_r);          // component r of the new direction of row `arow` (lanes with dact)
     double acc[kRowsPerWave];
     {
         const double d0 = __shfl(pr, gbase), d1 = __shfl(pr, gbase + 1), d2 = __shfl(pr, gbase + 2), d3 = __shfl(pr, gbase + 3),
                      d4 = __shfl(pr, gbase + 4), d5 = __shfl(pr, gbase + 5);
 #pragma unroll
         for (int q = 0; q < kRowsPerWave; q++) {
-            double aq = 0.;
+            double dterm = 0.;                        // (H_aa + lambda I) p of row q, in the lanes of group q (they hold H_aa and p)
             if (dact && g == q) {
-                aq += hrow[0] * d0; aq += hrow[1] * d1; aq += hrow[2] * d2; aq += hrow[3] * d3; aq += hrow[4] * d4; aq += hrow[5] * d5;
-                aq += lambda * pr;
-                if (!D.diag_owner) aq = 0.;           // sharded solve: the diagonal term is added by one rank only
+                dterm = hrow[0] * d0; dterm = fma(hrow[1], d1, dterm); dterm = fma(hrow[2], d2, dterm); dterm = fma(hrow[3], d3, dterm);
+                dterm = fma(hrow[4], d4, dterm); dterm = fma(hrow[5], d5, dterm);
+                dterm = fma(lambda, pr, dterm);
+                if (!D.diag_owner) dterm = 0.;        // sharded solve: the diagonal term is added by one rank only
                 p_new[(size_t)arow * 6 + r] = pr;
             }
-            const double pc = zr[q] + beta * orr[q];
+            // it enters the row's fold in lane group 0 whatever group computed it (with one row per wave that is the same group):
+            // the fold adds the ten groups in a fixed tree, so the place decides the rounding
+            const double dmov = (kRowsPerWave == 1) ? dterm : __shfl(dterm, 6 * q + (lane < 6 ? lane : 0));
+            double aq = (g == 0) ? dmov : 0.;
+            const double pc = fma(beta, orr[q], zr[q]);
             const double v0 = __shfl(pc, gbase), v1 = __shfl(pc, gbase + 1), v2 = __shfl(pc, gbase + 2), v3 = __shfl(pc, gbase + 3),
                          v4 = __shfl(pc, gbase + 4), v5 = __shfl(pc, gbase + 5);
-            if (have[q]) aq += b0[q].x * v0 + b0[q].y * v1 + b1[q].x * v2 + b1[q].y * v3 + b2[q].x * v4 + b2[q].y * v5;
+            if (have[q]) aq += dot6(b0[q], b1[q], b2[q], v0, v1, v2, v3, v4, v5);
             acc[q] = aq;
         }
     }
-    // ... the second pass of all rows of the wave in one round trip (AGG > 1: into the registers the first pass has just freed) ...
-    if (AGG != 1) {
+    // ... the second pass of all rows of the wave in one round trip (several rows per wave: into the registers the first pass has just freed) ...
+    if (kRowsPerWave != 1) {
 #pragma unroll
         for (int q = 0; q < kRowsPerWave; q++) {
             const int s = s0[q] + g + 10;
@@ -1272,10 +1311,10 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     for (int q = 0; q < kRowsPerWave; q++) {
         double aq = acc[q];
         {
-            const double pc = yr[q] + beta * qr[q];
+            const double pc = fma(beta, qr[q], yr[q]);
             const double v0 = __shfl(pc, gbase), v1 = __shfl(pc, gbase + 1), v2 = __shfl(pc, gbase + 2), v3 = __shfl(pc, gbase + 3),
                          v4 = __shfl(pc, gbase + 4), v5 = __shfl(pc, gbase + 5);
-            if (have2[q]) aq += c0[q].x * v0 + c0[q].y * v1 + c1[q].x * v2 + c1[q].y * v3 + c2[q].x * v4 + c2[q].y * v5;
+            if (have2[q]) aq += dot6(c0[q], c1[q], c2[q], v0, v1, v2, v3, v4, v5);
         }
         // rows with more than 20 slots are rare (hubs): the wave walks their remaining passes together (a uniform trip count, so
         // that the shuffles stay convergent)
@@ -1294,10 +1333,10 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
                     wz = D.z[(size_t)c * 6 + r]; wp = p_old[(size_t)c * 6 + r];
                 }
             }
-            const double pc = wz + beta * wp;
+            const double pc = fma(beta, wp, wz);
             const double v0 = __shfl(pc, gbase), v1 = __shfl(pc, gbase + 1), v2 = __shfl(pc, gbase + 2), v3 = __shfl(pc, gbase + 3),
                          v4 = __shfl(pc, gbase + 4), v5 = __shfl(pc, gbase + 5);
-            if (hv) aq += e0.x * v0 + e0.y * v1 + e1.x * v2 + e1.y * v3 + e2.x * v4 + e2.y * v5;
+            if (hv) aq += dot6(e0, e1, e2, v0, v1, v2, v3, v4, v5);
         }
         double t;
         t = __shfl_down(aq, 48); if (lane + 48 < 60) aq += t;
@@ -1313,7 +1352,6 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
 #pragma unroll
         for (int c = 0; c < 12; c++) geo[c] = gg[c];
     }
-    double dot = 0.;
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) {
         const int a = row0 + q;
@@ -1321,16 +1359,28 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         const double t0 = __shfl(acc[q], 0), t1 = __shfl(acc[q], 1), t2 = __shfl(acc[q], 2);
         const double q0 = __shfl(acc[q], 3), q1 = __shfl(acc[q], 4), q2 = __shfl(acc[q], 5);
         if (g == q) {                               // the lanes that own row q's p and geometry
-            double wq = 0.;
+            double wq = 0., dq = 0.;
             if (dact) {
                 const double apr = (r == 0) ? t0 : (r == 1) ? t1 : (r == 2) ? t2 : (r == 3) ? q0 : (r == 4) ? q1 : q2;
-                dot += apr * pr;
+                dq = apr * pr;
                 wq = p1t_comp(geo, t0, t1, t2, q0, q1, q2, r);
             }
             sw[(wv * kRowsPerWave + q) * 6 + r] = wq;
+            sd[(wv * kRowsPerWave + q) * 6 + r] = dq;
         }
     }
-    const double dtot = block_sum_w<kWaves>(dot, s8);   // barriers: sw complete
+    __syncthreads();                                    // sw, sd complete
+    // p.Ap of the workgroup's rows: six components per row, then the rows in order (independent of how rows map to waves)
+    double dtot = 0.;
+    if (wv == 0) {
+        double rs = 0.;
+        if (lane < kRowsPerBlk) {
+            const double* dd = sd + lane * 6;
+            rs = ((dd[0] + dd[1]) + (dd[2] + dd[3])) + (dd[4] + dd[5]);
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsPerBlk; i++) dtot += __shfl(rs, i);
+    }
     if (tid < kAggPerBlk * 6) {
         const int la = tid / 6, k = tid % 6, A1 = blockIdx.x * kAggPerBlk + la;
         double s = 0.;
@@ -1367,6 +1417,7 @@ __global__ __launch_bounds__(AGG == 1 ? 512 : 64 * kSpmvWaves4) __attribute__((a
 {
     ml_spmv_kernel_body<AGG>(D, H, p_old, p_new, n_part, tol2);
 }
+constexpr int kSpmvBatchRpw = 4, kSpmvBatchWaves = 2;      // ml_spmv_batch_kernel: 8 rows = one level-1 aggregate in 128 lanes
 
 // init = 1: first application (r = b stored, exact rg in rg_old): only the preconditioner part runs.
 // Dynamic LDS (doubles): res[levels g..L] | geo[levels g..L-1] | top rows | own-chain sibling rows + offsets   (ml_cg_lds_bytes)
@@ -1549,7 +1600,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     for (int u = 0; u < kGU; u++) {
         const int uu = (u + urot >= kGU) ? u + urot - kGU : u + urot;
         const int t = uu * kCgBlk + tid;
-        if (t < 6 * ng) dyn[t] = VPRE ? rgreg[u] : rgreg[u] - alpha * sgreg[u];          // (roff[gl] = 0)
+        if (t < 6 * ng) dyn[t] = VPRE ? rgreg[u] : fma(-alpha, sgreg[u], rgreg[u]);          // (roff[gl] = 0)
     }
     for (int t0 = kGU * kCgBlk + tid; t0 < 6 * ng; t0 += 4 * kCgBlk) {     // graphs beyond 12k free vertices: four values per lane and round trip
         double ra[4], sa[4];
@@ -1596,7 +1647,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
                 if (t < n4) {
                     const float4 y = yreg[u];
                     const double2 xa = rr[2 * t], xb = rr[2 * t + 1];
-                    s0 += (double)y.x * xa.x; s1 += (double)y.y * xa.y; s2 += (double)y.z * xb.x; s3q += (double)y.w * xb.y;
+                    s0 = fma((double)y.x, xa.x, s0); s1 = fma((double)y.y, xa.y, s1); s2 = fma((double)y.z, xb.x, s2); s3q = fma((double)y.w, xb.y, s3q);
                 }
                 if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of at most four steps in registers at a time
             }
@@ -1618,7 +1669,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
             for (int t = j; t < n4; t += 32) {
                 const float4 y = yr[t];
                 const double2 xa = rr[2 * t], xb = rr[2 * t + 1];
-                s0 += (double)y.x * xa.x; s1 += (double)y.y * xa.y; s2 += (double)y.z * xb.x; s3q += (double)y.w * xb.y;
+                s0 = fma((double)y.x, xa.x, s0); s1 = fma((double)y.y, xa.y, s1); s2 = fma((double)y.z, xb.x, s2); s3q = fma((double)y.w, xb.y, s3q);
             }
             if ((n6 & 2) && j == 0) {                 // 6 n_2 is even: at most one pair beyond the last full quad
                 const float2 y = *reinterpret_cast<const float2*>(yrow + 4 * n4);
@@ -1687,8 +1738,8 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     double rv = rv0;
     if (act && !init) {
         const size_t i = (size_t)a * 6 + r;
-        rv = rv0 - alpha * apv;
-        D.x[i] = xv + alpha * pv;
+        rv = fma(-alpha, apv, rv0);
+        D.x[i] = fma(alpha, pv, xv);
         D.r[i] = rv;
     }
     sv[tid] = act ? rv : 0.;
@@ -1698,13 +1749,13 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
         const int part = tid & 3;
         double ps = 0.;
 #pragma unroll
-        for (int c = 0; c < 12; c++) ps += w0[c] * sv[part * 12 + c];
+        for (int c = 0; c < 12; c++) ps = fma(w0[c], sv[part * 12 + c], ps);
         ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2);
         if (part == 0) szj[tid >> 2] = ps;
     } else if (act) {
         const int g0 = tid - r;
 #pragma unroll
-        for (int c = 0; c < 6; c++) zz += w0[c] * sv[g0 + c];
+        for (int c = 0; c < 6; c++) zz = fma(w0[c], sv[g0 + c], zz);
     }
     if (act) {
         const int g0 = tid - r;
@@ -1740,7 +1791,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
             const double* rs = (AGG == 1) ? ((sib == A1x) ? sr1 : dyn + roff[1] + (size_t)sib * 6) : (sr1 + part1 * 6);
             if (AGG != 1 || sib < n1) {
 #pragma unroll
-                for (int c = 0; c < 6; c++) ps += w1[c] * rs[c];
+                for (int c = 0; c < 6; c++) ps = fma(w1[c], rs[c], ps);
             }
         }
         ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2);
@@ -1859,9 +1910,9 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
         double ps[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < kCompU; u++) {
-            const double v = rgreg[u] - alpha * sgreg[u];
+            const double v = fma(-alpha, sgreg[u], rgreg[u]);
 #pragma unroll
-            for (int q = 0; q < 6; q++) ps[q] += (double)cm[q][u] * v;
+            for (int q = 0; q < 6; q++) ps[q] = fma((double)cm[q][u], v, ps[q]);
         }
 #pragma unroll
         for (int q = 0; q < 6; q++) ps[q] = wave_sum(ps[q]);
@@ -1874,8 +1925,8 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
     double rv = rv0;
     if (act && !init) {
         const size_t i = (size_t)a * 6 + r;
-        rv = rv0 - alpha * apv;
-        D.x[i] = xv + alpha * pv;
+        rv = fma(-alpha, apv, rv0);
+        D.x[i] = fma(alpha, pv, xv);
         D.r[i] = rv;
     }
     sv[tid] = act ? rv : 0.;
@@ -1885,7 +1936,7 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
         const int part4 = tid & 3;
         double ps = 0.;
 #pragma unroll
-        for (int c = 0; c < 12; c++) ps += w0[c] * sv[part4 * 12 + c];
+        for (int c = 0; c < 12; c++) ps = fma(w0[c], sv[part4 * 12 + c], ps);
         ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2);
         if (part4 == 0) szj[tid >> 2] = ps;
     }
@@ -2173,15 +2224,15 @@ __global__ __launch_bounds__(kCgBlk) void ml_init_batch_kernel(const BatchSlot* 
     if (!(dy.mask & kPhSolve)) return;
     ml_init_kernel_body<1>(S.D, S.hot[dy.ix], S.pbuf[0], S.pbuf[1], S.rg[dy.ix][0]);
 }
-// PCG iteration i of a replay (parity = i & 1): p_old = pbuf[parity], p_new = pbuf[parity ^ 1]
-// (forcing two 512-lane workgroups per CU with amdgpu_waves_per_eu(4, 4) costs 68 B of scratch per lane and is slower: 69.4 vs 65.4 ms
-//  per 16-graph batch)
-__global__ __launch_bounds__(512) void ml_spmv_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int parity, double tol2)
+// PCG iteration i of a replay (parity = i & 1): p_old = pbuf[parity], p_new = pbuf[parity ^ 1].  Four rows per wave, two waves per
+// level-1 aggregate (see ml_spmv_kernel_body): with B graphs in flight the kernel is bound by the bytes it keeps in flight, not by the
+// length of one wave's chain - the same body as the single solve's kernel, the same bits.
+__global__ __launch_bounds__(64 * kSpmvBatchWaves) __attribute__((amdgpu_waves_per_eu(3))) void ml_spmv_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int parity, double tol2)
 {
     const BatchSlot& S = slots[blockIdx.z];
     const BatchDyn dy = dyn[blockIdx.z];
     if (!(dy.mask & kPhSolve)) return;
-    ml_spmv_kernel_body<1>(S.D, S.hot[dy.ix], S.pbuf[parity], S.pbuf[parity ^ 1], S.g_rows, tol2);
+    ml_spmv_kernel_body<1, kSpmvBatchRpw, kSpmvBatchWaves>(S.D, S.hot[dy.ix], S.pbuf[parity], S.pbuf[parity ^ 1], S.g_rows, tol2);
 }
 template <int kCompU>
 __global__ __launch_bounds__(kCgBlk) void ml_cg_comp_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int parity, int init)
@@ -2244,12 +2295,12 @@ void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_
 {
     for (int i = 0; i < 2 * pairs; i++) {
         if (ev) {
-            hipExtLaunchKernelGGL(ml_spmv_batch_kernel, dim3(g_rows, 1, nbatch), dim3(512), 0, s, ev[4 * i], ev[4 * i + 1], 0, sl, dy, i & 1, tol2);
+            hipExtLaunchKernelGGL(ml_spmv_batch_kernel, dim3(g_rows, 1, nbatch), dim3(64 * kSpmvBatchWaves), 0, s, ev[4 * i], ev[4 * i + 1], 0, sl, dy, i & 1, tol2);
             if (small) hipExtLaunchKernelGGL(ml_cg_comp_batch_kernel<5>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, ev[4 * i + 2], ev[4 * i + 3], 0, sl, dy, i & 1, 0);
             else hipExtLaunchKernelGGL(ml_cg_comp_batch_kernel<8>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, ev[4 * i + 2], ev[4 * i + 3], 0, sl, dy, i & 1, 0);
             continue;
         }
-        hipLaunchKernelGGL(ml_spmv_batch_kernel, dim3(g_rows, 1, nbatch), dim3(512), 0, s, sl, dy, i & 1, tol2);
+        hipLaunchKernelGGL(ml_spmv_batch_kernel, dim3(g_rows, 1, nbatch), dim3(64 * kSpmvBatchWaves), 0, s, sl, dy, i & 1, tol2);
         if (small) hipLaunchKernelGGL(ml_cg_comp_batch_kernel<5>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, i & 1, 0);
         else hipLaunchKernelGGL(ml_cg_comp_batch_kernel<8>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, i & 1, 0);
     }
