@@ -1041,14 +1041,14 @@ __device__ __forceinline__ double sel3(int k, double a, double b, double c) { re
 // (P1^T v)[r] for a row with geo = {R^T (9), d (3)} and v = (t0,t1,t2,q0,q1,q2)
 __device__ __forceinline__ double p1t_comp(const double* geo, double t0, double t1, double t2, double q0, double q1, double q2, int r)
 {
-    const double u0 = geo[0] * t0 + geo[3] * t1 + geo[6] * t2;      // R = (R^T)^T
-    const double u1 = geo[1] * t0 + geo[4] * t1 + geo[7] * t2;
-    const double u2 = geo[2] * t0 + geo[5] * t1 + geo[8] * t2;
+    const double u0 = fma(geo[6], t2, fma(geo[3], t1, geo[0] * t0));      // R = (R^T)^T
+    const double u1 = fma(geo[7], t2, fma(geo[4], t1, geo[1] * t0));
+    const double u2 = fma(geo[8], t2, fma(geo[5], t1, geo[2] * t0));
     if (r < 3) return (r == 0) ? u0 : (r == 1) ? u1 : u2;
     const int k = r - 3;
-    const double rq = 0.5 * (sel3(k, geo[0], geo[1], geo[2]) * q0 + sel3(k, geo[3], geo[4], geo[5]) * q1 + sel3(k, geo[6], geo[7], geo[8]) * q2);
+    const double rq = 0.5 * fma(sel3(k, geo[6], geo[7], geo[8]), q2, fma(sel3(k, geo[3], geo[4], geo[5]), q1, sel3(k, geo[0], geo[1], geo[2]) * q0));
     const double dx = geo[9], dy = geo[10], dz = geo[11];
-    const double cr = (k == 0) ? dy * u2 - dz * u1 : (k == 1) ? dz * u0 - dx * u2 : dx * u1 - dy * u0;
+    const double cr = (k == 0) ? fma(dy, u2, -(dz * u1)) : (k == 1) ? fma(dz, u0, -(dx * u2)) : fma(dx, u1, -(dy * u0));
     return cr + rq;
 }
 // (P1 y)[r]
@@ -1058,12 +1058,12 @@ __device__ __forceinline__ double p1_comp(const double* geo, const double* y, in
     const double g0 = sel3(k, geo[0], geo[3], geo[6]), g1 = sel3(k, geo[1], geo[4], geo[7]), g2 = sel3(k, geo[2], geo[5], geo[8]);   // row k of R^T
     if (r < 3) {
         const double dx = geo[9], dy = geo[10], dz = geo[11];
-        const double vx = y[0] + (y[4] * dz - y[5] * dy);      // v + w x d
-        const double vy = y[1] + (y[5] * dx - y[3] * dz);
-        const double vz = y[2] + (y[3] * dy - y[4] * dx);
-        return g0 * vx + g1 * vy + g2 * vz;       // R^T (.)
+        const double vx = y[0] + fma(y[4], dz, -(y[5] * dy));      // v + w x d
+        const double vy = y[1] + fma(y[5], dx, -(y[3] * dz));
+        const double vz = y[2] + fma(y[3], dy, -(y[4] * dx));
+        return fma(g2, vz, fma(g1, vy, g0 * vx));       // R^T (.)
     }
-    return 0.5 * (g0 * y[3] + g1 * y[4] + g2 * y[5]);
+    return 0.5 * fma(g2, y[5], fma(g1, y[4], g0 * y[3]));
 }
 
 // x = 0, r = b, p0 = p1 = 0, flags cleared; exact gather-level residual of the own aggregates -> rg
