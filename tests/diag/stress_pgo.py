@@ -16,6 +16,7 @@ from uzliti_slam_amd import capi, synth              # noqa: E402
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"
+ONLY = int(os.environ.get("ONLY", "-1"))          # run case ONLY alone (same random stream), with the solver's trial log
 bad = 0
 p = capi.Pgo()
 for k in range(n_cases):
@@ -34,7 +35,9 @@ for k in range(n_cases):
         g = synth.permute_graph(g, rng.permutation(n))
     elif kind == "no_odo" and dens >= 2.0:
         g = synth.drop_odometry(g, keep_every=int(rng.choice([0, 4])))
-    p.set_config(optimize_xy_only=1 if xy else 0)
+    if ONLY >= 0 and k != ONLY:
+        continue
+    p.set_config(optimize_xy_only=1 if xy else 0, verbose=1 if ONLY >= 0 else 0)
     p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
     t0 = time.time(); st = p.optimize(its); dt = time.time() - t0
     poses = p.store()[0]

@@ -1145,7 +1145,7 @@ constexpr int kSpmvWaves4 = 4;
 // the AGG = 1 hierarchy with four rows per wave in 128-lane workgroups (ml_spmv_batch_kernel) - four times the bytes in flight per
 // wave when sixteen graphs fill the chip - where a single small graph wants one row per wave for the shortest chain.  Both give the
 // same bits: every sum that crosses rows or lanes is taken in an order that does not depend on the geometry (row sums of six
-// components, then rows in order; the r.z partials in groups of 64, then groups in order).
+// components, then rows pairwise by index; the r.z partials in groups of 64, then groups in order).
 template <int AGG, int RPW = AGG, int WAVES = (AGG == 1 ? 8 : kSpmvWaves4)>
 __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const double* __restrict__ p_old,
                                                      double* __restrict__ p_new, int n_part, double tol2)
@@ -1251,8 +1251,10 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
 #pragma unroll
     for (int u = 0; u < kGrpU; u++) {
         const int gi = wv + u * kWaves;
-        const double sgi = wave_sum(vpart[u]);
-        if (lane == 0 && gi < n_grp) sgrp[gi] = sgi;
+        if (gi < n_grp) {                                  // (uniform in the wave)
+            const double sgi = wave_sum(vpart[u]);
+            if (lane == 0) sgrp[gi] = sgi;
+        }
     }
     for (int gi = wv + kGrpU * kWaves; gi < n_grp; gi += kWaves) {       // beyond kGrpU * kWaves * 64 partials: one group per round trip
         const int i = gi * 64 + lane;
@@ -1370,16 +1372,16 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         }
     }
     __syncthreads();                                    // sw, sd complete
-    // p.Ap of the workgroup's rows: six components per row, then the rows in order (independent of how rows map to waves)
+    // p.Ap of the workgroup's rows: six components per row, then the rows pairwise by row index (a tree that does not depend on how
+    // rows map to waves; every lane < kRowsPerBlk ends with the same bits)
     double dtot = 0.;
     if (wv == 0) {
-        double rs = 0.;
         if (lane < kRowsPerBlk) {
             const double* dd = sd + lane * 6;
-            rs = ((dd[0] + dd[1]) + (dd[2] + dd[3])) + (dd[4] + dd[5]);
+            dtot = ((dd[0] + dd[1]) + (dd[2] + dd[3])) + (dd[4] + dd[5]);
         }
 #pragma unroll
-        for (int i = 0; i < kRowsPerBlk; i++) dtot += __shfl(rs, i);
+        for (int o = 1; o < kRowsPerBlk; o <<= 1) dtot += __shfl_xor(dtot, o);
     }
     if (tid < kAggPerBlk * 6) {
         const int la = tid / 6, k = tid % 6, A1 = blockIdx.x * kAggPerBlk + la;

@@ -242,8 +242,18 @@ void fetch_scal(uzl_pgo* h)
 // (a dead-reckoned start is metres and tenths of radians off) and a 1e-5 solve left up to 1.7e-4 rad against the direct solve on
 // sparse-loop graphs after 3 iterations (tests/diag/stress_pgo.py: 2 of 150 random cases over the 1e-4 rad bar).  Those iterations
 // solve 10x tighter; once the steps are small the configured tolerance is more than enough.  Costs ~2 % of a config-2 solve.
+// A solve that needed many iterations says the preconditioned system is badly conditioned (sqrt(kappa) ~ iterations / ln(2 / tol)), and
+// the error a given residual tolerance leaves in the step grows with it: a 3500-vertex chain with two loop closures (beam-like: rotations
+// integrate to positions; the piecewise-rigid coarse spaces capture its bending modes poorly) took 1900 iterations per solve and ended
+// 2.9e-3 m / 1.3e-4 rad off the direct solve after 8 iterations.  Past kHardIts iterations of the previous solve the tolerance shrinks
+// in proportion (BASELINE-like graphs stay below: 27 - 140 per solve).
 constexpr double kTightRel = 0.1, kTightFactor = 0.1;
-inline double tol_factor2(int it, double last_rel) { return (it == 0 || last_rel > kTightRel) ? kTightFactor * kTightFactor : 1.0; }
+constexpr int kHardIts = 128;
+inline double tol_factor2(int it, double last_rel, int pcg_last)
+{
+    const double hard = pcg_last > kHardIts ? (double)kHardIts / (double)pcg_last : 1.0;
+    return ((it == 0 || last_rel > kTightRel) ? kTightFactor * kTightFactor : 1.0) * (hard * hard);
+}
 
 void set_lambda(uzl_pgo* h, double lambda, double tol_f2)
 {
@@ -980,7 +990,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         }
         double rho = 0.;
         int qmax = 0;
-        const double tol_f2 = tol_factor2(it, last_rel);
+        const double tol_f2 = tol_factor2(it, last_rel, pcg_last);
         do {
             set_lambda(h, lambda, tol_f2);                                        // setLambda (+ this iteration's PCG tolerance)
             bool conv = false;
@@ -1695,7 +1705,7 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             BatchLM& X = G[g];
             if (X.finished) continue;
             dyn[g].mask = kPhLambda | kPhSolve; dyn[g].lambda = X.lambda;
-            if (X.qmax == 0) X.tol_f2 = tol_factor2(X.it, X.last_rel);           // fixed for the trials of one LM iteration, like do_optimize
+            if (X.qmax == 0) X.tol_f2 = tol_factor2(X.it, X.last_rel, X.pcg_last);           // fixed for the trials of one LM iteration, like do_optimize
             dyn[g].tol_factor2 = X.tol_f2;
             if (X.lambda > 8. * X.lambda_setup[X.ml_ix]) X.trial_setup = true;
             X.fresh = X.trial_setup || (X.adopted && X.qmax == 0);
