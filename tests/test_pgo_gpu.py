@@ -430,6 +430,20 @@ def test_large_sparse_graphs_on_every_kernel_path_against_oracle(capi, oracle, n
         p.close()
 
 
+def test_near_tree_graph_without_odometry(capi, oracle):
+    """A graph whose odometry chain is gone and whose loop closures barely connect it (3500 vertices, 3501 system edges): beam-like, the
+    preconditioned system is badly conditioned (1900 PCG iterations per solve) and a residual tolerance that is fine elsewhere left
+    2.9e-3 m / 1.3e-4 rad against the direct solve (tests/diag/stress_pgo.py seed 21, case 5).  The tolerance shrinks with the previous
+    solve's iteration count (uzl_pgo.hip kHardIts)."""
+    g = synth.drop_odometry(synth.make_pose_graph(3500, 7000, seed=779627, outlier_frac=0.2), keep_every=0)
+    p = capi.Pgo()
+    try:
+        st, so = _check(p, oracle, g, iterations=8)
+        assert st["pcg_not_converged"] == 0
+    finally:
+        p.close()
+
+
 def test_vertex_order_does_not_matter(capi, oracle):
     """The aggregates of the preconditioner are 8 consecutive blocks of an order derived from the graph (heaviest-edge chains,
     uzl_pgo.hip aggregation_order), not of the node index: renumbered nodes, two sessions with interleaved ids (merged / global-scope
