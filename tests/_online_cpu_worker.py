@@ -9,15 +9,14 @@ import torch.distributed as dist
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
 import oracle as O                                  # noqa: E402
-from online_stubs import oracle_backends            # noqa: E402
-from uzliti_slam_amd import online, synth           # noqa: E402
+from online_stubs import oracle_online              # noqa: E402
+from uzliti_slam_amd import synth                   # noqa: E402
 
 out, n_nodes, n_pairs, n_kp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 run = synth.make_online_run(n_nodes, n_pairs, n_kp=n_kp)
-o = online.OnlineSlam(run, rank=rank, world=world, tdist=dist, match_batch=40, lm_iterations=4, reopt_edges=64,
-                      backends=oracle_backends(O, run, ransac_iteration=60, solver=(rank == 0)))
+o = oracle_online(O, run, ransac_iteration=60, rank=rank, world=world, tdist=dist, match_batch=40, lm_iterations=4, reopt_edges=64)
 o.upload_frames()
 assert 0 < len(o.fid) < n_pairs                     # this rank holds only its shard of the frames
 o.run_all()

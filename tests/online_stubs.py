@@ -72,8 +72,17 @@ class OFilter:
         pass
 
 
-def oracle_backends(oracle, run, ransac_iteration=200, seed=777, solver=True):
-    b = dict(matcher=OMatch(oracle, ransac_iteration, seed))
-    if solver:
-        b.update(gate=oracle.Gate(), filt=OFilter(oracle, run["stamps_ns"], seed=seed), pgo=OPgo(oracle))
-    return b
+def oracle_online(oracle, run, ransac_iteration=200, seed=777, gate_cfg=None, **kw):
+    """uzliti_slam_amd.online.OnlineSlam with its four handles replaced by the CPU checker's: the product class is driven unchanged,
+    only the handle factory is overridden here, under tests/."""
+    from uzliti_slam_amd import online
+
+    class OracleOnlineSlam(online.OnlineSlam):
+        def _open_handles(self, device, mc, gate_cfg_, filter_cfg, pgo_cfg):
+            self.matcher = OMatch(oracle, ransac_iteration, seed)
+            if self.is_solver:
+                self.gate = oracle.Gate(**(gate_cfg_ or {}))
+                self.filt = OFilter(oracle, run["stamps_ns"], seed=seed)
+                self.pgo = OPgo(oracle)
+
+    return OracleOnlineSlam(run, gate_cfg=gate_cfg, **kw)

@@ -23,8 +23,8 @@ def test_reduced_online_run_matches_the_oracle(capi, oracle):
     o = online.OnlineSlam(run, match_batch=100, lm_iterations=8, match_cfg=mc)
     o.upload_frames()
     # ---- oracle replay, driven by the same class through stand-ins of the four handles (tests/online_stubs.py)
-    from online_stubs import oracle_backends
-    c = online.OnlineSlam(run, match_batch=100, lm_iterations=8, match_cfg=mc, backends=oracle_backends(oracle, run, ransac_iteration=200))
+    from online_stubs import oracle_online
+    c = oracle_online(oracle, run, ransac_iteration=200, match_batch=100, lm_iterations=8, match_cfg=mc)
     c.upload_frames()
     o.run_all(); c.run_all()
     assert len(o.solves) == len(c.solves) >= 5
@@ -39,12 +39,32 @@ def test_reduced_online_run_matches_the_oracle(capi, oracle):
     o.close()
 
 
+def test_reduced_online_run_with_min_accept_valid(capi, oracle):
+    """min_accept_valid finite (the launch files use 150 / 200; graph_slam_node.cpp:809-811): accepted edges above it are valid from
+    acceptance on, which changes what A* can walk in every later interval.  GPU run == oracle replay."""
+    from online_stubs import oracle_online
+    run = synth.make_online_run(1200, 300, n_kp=200)
+    mc = dict(ransac_iteration=100)
+    gc = dict(min_accept_valid=70.0)
+    o = online.OnlineSlam(run, match_batch=100, lm_iterations=6, match_cfg=mc, gate_cfg=gc)
+    c = oracle_online(oracle, run, ransac_iteration=100, match_batch=100, lm_iterations=6, match_cfg=mc, gate_cfg=gc)
+    o.upload_frames(); c.upload_frames()
+    o.run_all(); c.run_all()
+    hi = o.f_score >= 70.0
+    assert hi.any() and (~hi).any() and o.f_sticky[hi].all()
+    assert o.accept_log == c.accept_log and np.array_equal(o.f_key, c.f_key) and np.array_equal(o.f_sticky, c.f_sticky)
+    assert len(o.solves) == len(c.solves) >= 4
+    dt, dr = synth.pose_errors(o.poses, c.poses)
+    assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+    o.close()
+
+
 @pytest.fixture(scope="module")
 def full_run():
     return synth.make_online_run(20000, 4096, n_kp=1000)
 
 
-def test_full_size_run_properties(capi, full_run):
+def test_full_size_run_properties(capi, oracle, full_run):
     """BASELINE config 5 at its size: 4096 pairs x 1000 ORB-256 keypoints, graph growing to 20k nodes, re-optimised every 256 edges."""
     run = full_run
     a = online.OnlineSlam(run, match_batch=512)
@@ -76,6 +96,15 @@ def test_full_size_run_properties(capi, full_run):
     assert st["status"] == 0 and st["n_edges"] == a.solves[-1]["n_edges"]
     dt, dr = synth.pose_errors(fresh.store()[0].reshape(-1, 3, 4), a.poses)
     assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+    # ---- and it is within the parity bar of the CPU checker's direct solve of the same input at full size (20k nodes: the graph is
+    #      near-tree, so the oracle's Cholesky has little fill and takes seconds).  G2oOptimizer::optimizeImpl, g2o_optimizer.cpp:137-149
+    fl = oracle.flatten_graph(*a.last_input)
+    fx, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, so = oracle.pgo_optimize(fl["poses"], fx, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=20)
+    assert so["n_edges"] == st["n_edges"]
+    dt, dr = synth.pose_errors(a.poses, P.reshape(-1, 3, 4))
+    assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+    assert abs(a.solves[-1]["chi2_final"] - so["chi2_final"]) <= 1e-6 * abs(so["chi2_final"]) + 1e-9
     fresh.close(); a.close(); b.close()
 
 

@@ -52,9 +52,7 @@ class OnlineSlam:
     """State of one online run.  `run` = synth.make_online_run(...) (or any dict of the same layout)."""
 
     def __init__(self, run, device=0, reopt_edges=256, lm_iterations=20, lookahead=None, match_cfg=None, gate_cfg=None,
-                 filter_cfg=None, pgo_cfg=None, match_batch=512, rank=0, world=1, tdist=None, solve_rank=0, log=None, backends=None):
-        """backends: optional dict(matcher=, gate=, filt=, pgo=) of objects with the capi.Match / Gate / Filter / Pgo methods this
-        driver calls - the tests replay the schedule on the CPU checker through it; the product path leaves it None."""
+                 filter_cfg=None, pgo_cfg=None, match_batch=512, rank=0, world=1, tdist=None, solve_rank=0, log=None):
         self.run = run
         self.N = len(run["fixed"])
         self.P = len(run["pair_from"])
@@ -68,19 +66,9 @@ class OnlineSlam:
         mc = dict(ransac_threshold=0.1, ransac_iteration=500, ransac_break_percentage=0.6, do_prosac=1, seed=777)
         mc.update(match_cfg or {})
         self.gate = self.filt = self.pgo = None
-        if backends is not None:
-            self.matcher = backends["matcher"]
-            if self.is_solver:
-                self.gate, self.filt, self.pgo = backends["gate"], backends["filt"], backends["pgo"]
-                self.filt.set_sensors(I12.reshape(1, 12))
-        else:
-            self.matcher = capi.Match(device=device, **mc)
-            if self.is_solver:
-                self.gate = capi.Gate(device=device, **(gate_cfg or {}))
-                fc = dict(seed=mc["seed"]); fc.update(filter_cfg or {})
-                self.filt = capi.Filter(device=device, **fc)
-                self.filt.set_sensors(I12.reshape(1, 12))
-                self.pgo = capi.Pgo(device=device, iterations=self.lm_iterations, **(pgo_cfg or {}))
+        self._open_handles(device, mc, gate_cfg, filter_cfg, pgo_cfg)
+        if self.is_solver:
+            self.filt.set_sensors(I12.reshape(1, 12))
         o = run["odo"]
         self.odo_T = np.asarray(o["transform"], np.float64).reshape(-1, 3, 4)[: self.N - 1]
         self.odo_info = np.asarray(o["information"], np.float64).reshape(-1, 36)[: self.N - 1]
@@ -97,6 +85,15 @@ class OnlineSlam:
         self.solves = []
         self.t = dict(match_wait=0.0, gate=0.0, filter=0.0, add_graph=0.0, optimize=0.0, store=0.0, host=0.0, upload=0.0)
         self.accept_log = []                          # (pair index, accepted) in gate order
+
+    def _open_handles(self, device, mc, gate_cfg, filter_cfg, pgo_cfg):
+        """The four C-ABI handles of the path (estimator on every rank; gate, filter and solver on the solver rank)."""
+        self.matcher = capi.Match(device=device, **mc)
+        if self.is_solver:
+            self.gate = capi.Gate(device=device, **(gate_cfg or {}))
+            fc = dict(seed=mc["seed"]); fc.update(filter_cfg or {})
+            self.filt = capi.Filter(device=device, **fc)
+            self.pgo = capi.Pgo(device=device, iterations=self.lm_iterations, **(pgo_cfg or {}))
 
     # ------------------------------------------------------------------ frames + matching
     def upload_frames(self):
@@ -182,9 +179,9 @@ class OnlineSlam:
         if len(cand_pair):
             cands = capi.gate_edges(run["pair_from"][cand_pair], run["pair_to"][cand_pair], np.ones(len(cand_pair), int),
                                     score=res["consensus"][ok].astype(np.float64), transform=res["T"][ok])
-            acc, _, _ = self.gate.check(cands)
+            acc, val, _ = self.gate.check(cands)
         else:
-            acc = np.zeros(0, np.uint8)
+            acc = np.zeros(0, np.uint8); val = np.zeros(0, np.uint8)
         t_gate = time.perf_counter() - t0
         self.t["gate"] += t_gate
         # ---- trigger: first node boundary with >= reopt_edges new edges
@@ -208,7 +205,9 @@ class OnlineSlam:
         self.f_to = np.concatenate([self.f_to, run["pair_to"][take].astype(np.int32)])
         self.f_score = np.concatenate([self.f_score, r["consensus"].astype(np.float64)])
         self.f_T = np.concatenate([self.f_T, r["T"]]); self.f_info = np.concatenate([self.f_info, r["information"]])
-        self.f_sticky = np.concatenate([self.f_sticky, np.zeros(len(take), bool)])
+        # edge.valid_ = true for an accepted edge with matching_score >= min_accept_valid (graph_slam_node.cpp:809-811): it stays valid
+        # in every later set_graph (A* walks valid edges only) and filter pass, whatever the filter says about it afterwards
+        self.f_sticky = np.concatenate([self.f_sticky, val[commit & (acc != 0)] != 0])
         n_new_edges = (last + 1 - self.cur) + len(take)
         self.edges_since += n_new_edges
         n_nodes = last + 1
