@@ -58,9 +58,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="graphs per batch of the batched block")
     ap.add_argument("--online-nodes", type=int, default=20000)
     ap.add_argument("--online-pairs", type=int, default=4096)
-    ap.add_argument("--sharded", action="store_true",
-                    help="N > 1 only: additionally time ONE 10000-node/50000-edge graph sharded over all ranks "
-                         "(BASELINE config 4, native RCCL all-reduce per PCG iteration); reported under `sharded_c4`")
+    ap.add_argument("--sharded", action="store_true", help="(default for N > 1; kept for old command lines)")
+    ap.add_argument("--no-sharded", action="store_true",
+                    help="skip `sharded_c4` (N > 1: ONE 10000-node/50000-edge graph sharded over all ranks, BASELINE config 4, native RCCL "
+                         "all-reduce per PCG iteration) and `c4_1gpu.sharded_world1` (N = 1: the same path with a one-rank communicator)")
+    ap.add_argument("--sharded-world1-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-baseline sample of the primary / secondary block")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 code paths on a box with fewer GPUs than ranks: process group over gloo, rank r on device "
@@ -186,9 +188,9 @@ def pgo_block(capi, synth, dist, dev, a, nodes, edges, steps, warmup, seed, xy=F
     work["edges"] = 0
     t = timed(dist, step, steps)
     t0 = time.perf_counter()
-    pgo.store()
+    poses = pgo.store()[0]
     d2h_ms = 1e3 * (time.perf_counter() - t0)
-    return dict(g=g, pgo=pgo, t=t, edges=work["edges"], st=work["last"], h2d_ms=h2d_ms, d2h_ms=d2h_ms)
+    return dict(g=g, pgo=pgo, t=t, edges=work["edges"], st=work["last"], h2d_ms=h2d_ms, d2h_ms=d2h_ms, poses=poses)
 
 
 def pgo_profile(pgo, a):
@@ -246,7 +248,9 @@ def cpu_pgo(O, g, a, seconds, threads_list, max_solves=64):
     for th in threads_list:
         t0 = time.perf_counter(); n_solves = 0; cpu_edges = 0
         while True:
-            _, so = O.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=a.lm_iters, native_threads=th)
+            P, so = O.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=a.lm_iters, native_threads=th)
+            if "poses" not in out:
+                out["poses"], out["stats"] = P, dict(so)                    # kept: the parity block compares the GPU solve of the same graph with it
             n_solves += 1; cpu_edges += so["n_edges"] * so["iterations_done"]
             if time.perf_counter() - t0 > seconds or n_solves >= max_solves:
                 break
@@ -254,6 +258,21 @@ def cpu_pgo(O, g, a, seconds, threads_list, max_solves=64):
         out[th] = dict(value=round(cpu_edges / dt, 1), seconds_per_solve=round(dt / n_solves, 4), solves=n_solves, seconds=round(dt, 2),
                        cholesky_share=round(so["t_numeric_ms"] / max(so["t_total_ms"], 1e-9), 3))
     return out
+
+
+PARITY_T, PARITY_R = 1e-3, 1e-4          # BASELINE.json north_star: within 1e-3 m / 1e-4 rad of the CPU path after the same iteration count
+
+
+def parity_block(synth, poses_gpu, st, cb):
+    """GPU solve against the CPU checker's direct solve of the same graph, same LM iteration count (G2oOptimizer::optimizeImpl,
+    g2o_optimizer.cpp:137-149).  The CPU solve is the one cpu_baseline times; a miss makes the run exit non-zero."""
+    so = cb["stats"]
+    dt, dr = synth.pose_errors(np.asarray(poses_gpu).reshape(-1, 3, 4), np.asarray(cb["poses"]).reshape(-1, 3, 4))
+    chi2_rel = abs(st["chi2_final"] - so["chi2_final"]) / max(abs(so["chi2_final"]), 1e-300)
+    return dict(dt_m=float(dt), dr_rad=float(dr), chi2_rel=float(chi2_rel), lm_iterations_equal=bool(st["iterations_done"] == so["iterations_done"]),
+                lm_trials_equal=bool(st["lm_trials"] == so["lm_trials"]), lm_trials=[int(st["lm_trials"]), int(so["lm_trials"])],
+                bar=dict(dt_m=PARITY_T, dr_rad=PARITY_R), ok=bool(dt < PARITY_T and dr < PARITY_R),
+                against="oracle/ (C restatement of g2o LM + sparse direct Cholesky), the solve cpu_baseline times; parity unpinned (DESIGN.md section 2)")
 
 
 def effective_cpus():
@@ -330,9 +349,62 @@ def bench_formats(capi, dev, pairs, n_kp):
                 matches_source_arrays=ok)
 
 
-# ---------------------------------------------------------------------------------------------------------------------- main
+# ---------------------------------------------------------------------------------------------------------------------- config 4, sharded
+def sharded_block(capi, synth, dist, dev, a, rank, world, budget_s=20.0):
+    """BASELINE config 4: ONE 10k-node / 50k-edge graph, edges partitioned over the ranks, vertices replicated, native RCCL all-reduce of
+    [A p | restricted A p | p.Ap partials] per PCG iteration on the solver's stream.  Strong scaling; never `value`."""
+    g4 = synth.make_pose_graph(10000, 50000, seed=12345)
+    p4 = capi.Pgo(device=dev)
+    box = [capi.rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.dist.broadcast_object_list(box, src=0)
+    p4.set_shard_rccl(rank, world, box[0])
+    p4.add_graph(g4["nodes_pose"], g4["nodes_fixed"], g4["edges"])
+
+    def c4_step():
+        p4.reset()
+        return p4.optimize(a.lm_iters)
+    t0 = time.perf_counter()
+    st4 = c4_step()                                                            # warm-up: structure, communicator, first launches
+    first_s = time.perf_counter() - t0
+    n4 = int(max(1, min(max(1, a.steps // 5), budget_s / max(first_s, 1e-3))))  # capped at ~budget_s seconds of solves
+    if world > 1:                                                              # every rank must time the same number of solves
+        n4 = int(dist._red(float(n4), dist.dist.ReduceOp.MIN))
+    acc = dict(ex_ms=0.0, ex_calls=0)
+
+    def timed_step():
+        st_ = c4_step()
+        acc["ex_ms"] += st_["exchange_ms"]; acc["ex_calls"] += st_["exchange_calls"]
+    t4 = timed(dist, timed_step, n4)
+    out = dict(metric="SE(3) edges optimized/sec, one 10k-node / 50k-edge graph sharded over all ranks (BASELINE config 4)", unit="edges/s", scaling="strong",
+               value=round(st4["n_edges"] * st4["iterations_done"] * n4 / t4, 1), n_ranks=world,
+               ms_per_solve=round(1e3 * t4 / n4, 3), solves_timed=n4, pcg_iterations_per_solve=st4["pcg_iterations"], lm_trials_per_solve=st4["lm_trials"],
+               exchange="native RCCL (communicator owned by the handle): 1 all-reduce per PCG iteration + 3 per LM trial, on the solver's stream",
+               exchange_calls_per_solve=acc["ex_calls"] // n4,
+               exchange_ms_per_solve=round(acc["ex_ms"] / n4, 3), exchange_ms_note="host time inside the ncclAllReduce calls of rank 0 (enqueue cost; the collective itself runs on the stream)",
+               chi2_final=st4["chi2_final"])
+    p4.close()
+    return out
+
+
+def sharded_world1_child(a):
+    """`c4_1gpu.sharded_world1`, run in a process of its own so that a stalled RCCL bootstrap is a missing block, not a hung bench: the
+    10k/50k graph through uzl_pgo_set_shard_rccl(0, 1): every exchange step of the sharded path with a one-rank communicator - what the
+    eager launches and the RCCL call per PCG iteration cost on top of the hipGraph-captured solve."""
+    from uzliti_slam_amd import capi, synth
+
+    class One:                      # the Dist interface at world 1
+        rank = 0; world = 1; dist = None
+        def barrier(self): pass
+        def sync(self): pass
+        def max(self, v): return v
+    print(json.dumps(sharded_block(capi, synth, One(), 0, a, 0, 1)))
+
+
 def main():
     a = parse()
+    if a.sharded_world1_child:
+        return sharded_world1_child(a)
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(a))
     dist = Dist(a.gpus, a.rehearse_gloo)
@@ -341,6 +413,7 @@ def main():
     capi.lib()
     dev = dist.local_rank
     is_c2 = (a.nodes, a.edges) == (1000, 5000)
+    parity_fail = []
 
     # ------------------------------------------------------------------ primary: pose-graph solve, one independent graph per rank
     B = pgo_block(capi, synth, dist, dev, a, a.nodes, a.edges, a.steps, a.warmup, ud.replica_seed(12345, dist.rank))
@@ -535,9 +608,25 @@ def main():
                                                           % (nth, ncpu, 100 * (1 - cb[1]["cholesky_share"]), 100 * cb[1]["cholesky_share"])),
                                       nproc=ncpu, hardware_threads=os.cpu_count(), cpu=cpu_model(), sample="1 solve per thread count of the same graph, %d LM iterations" % a.lm_iters,
                                       build="gcc -O3 -march=native -fopenmp on this host")
+            c4["parity"] = parity_block(synth, B4["poses"], B4["st"], cb)
+            if not c4["parity"]["ok"]:
+                parity_fail.append(("c4_1gpu", c4["parity"]))
             c4["speedup_vs_cpu_1_thread"] = round(cb[1]["seconds_per_solve"] / (B4["t"] / steps4), 1)
             c4["speedup_vs_cpu_all_cores"] = round(cb[nth]["seconds_per_solve"] / (B4["t"] / steps4), 1)
         B4["pgo"].close()
+        if not a.no_sharded:
+            env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--sharded-world1-child", "--steps", str(a.steps), "--lm-iters", str(a.lm_iters)],
+                                   env=env, capture_output=True, text=True, timeout=240)
+                w1 = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else dict(error=(r.stderr or r.stdout)[-400:])
+            except Exception as ex:                                            # timeout / no JSON: reported, not fatal
+                w1 = dict(error=repr(ex)[:400])
+            if "ms_per_solve" in w1:
+                w1["vs_graph_captured_solve"] = round(w1["ms_per_solve"] / c4["ms_per_solve"], 3)
+                w1["note"] = ("same graph, same kernels, world_size 1: the ratio is the cost of the sharded path's structure on one GPU "
+                              "(RCCL call per PCG iteration, block-diagonal level-0 smoother, synchronous rebuilds)")
+            c4["sharded_world1"] = w1
 
     # ------------------------------------------------------------------ BASELINE config 5: match jobs feeding a growing graph
     online_c5 = None
@@ -569,35 +658,20 @@ def main():
 
     # ------------------------------------------------------------------ optional: config 4, one graph sharded over the ranks
     sharded_c4 = None
-    if a.sharded and dist.world > 1:
-        g4 = synth.make_pose_graph(10000, 50000, seed=12345)
-        p4 = capi.Pgo(device=dev)
-        uid = capi.rccl_unique_id() if dist.rank == 0 else None
-        box = [uid]
-        dist.dist.broadcast_object_list(box, src=0)
-        p4.set_shard_rccl(dist.rank, dist.world, box[0])
-        p4.add_graph(g4["nodes_pose"], g4["nodes_fixed"], g4["edges"])
-
-        def c4_step():
-            p4.reset()
-            return p4.optimize(a.lm_iters)
-        st4 = c4_step()
-        n4 = max(1, a.steps // 5)
-        t4 = timed(dist, c4_step, n4)
-        sharded_c4 = dict(metric="SE(3) edges optimized/sec, one graph sharded over all ranks", unit="edges/s", scaling="strong",
-                          value=round(st4["n_edges"] * st4["iterations_done"] * n4 / t4, 1),
-                          ms_per_solve=round(1e3 * t4 / n4, 3), pcg_iterations_per_solve=st4["pcg_iterations"],
-                          exchange="native RCCL: 1 all-reduce per PCG iteration + 3 per LM trial, on the solver's stream", exchange_calls=st4["exchange_calls"],
-                          chi2_final=st4["chi2_final"])
-        p4.close()
+    if dist.world > 1 and not a.no_sharded and not dist.rehearsal:
+        sharded_c4 = sharded_block(capi, synth, dist, dev, a, dist.rank, dist.world)
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     cpu = None
+    parity = None
     if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline:
         import oracle as O
         ncpu = effective_cpus()
         nth = min(ncpu, 8)
         cb = cpu_pgo(O, g, a, a.cpu_seconds, [1, nth])
+        parity = parity_block(synth, B["poses"], st, cb)
+        if not parity["ok"]:
+            parity_fail.append(("primary", parity))
         cpu = dict(value=cb[1]["value"], unit="edges/s", cores=1, kind="port",
                    sample="%d solve(s) of the same %d-node/%d-edge graph, %d LM iterations each, %.1f s; "
                           "oracle = C restatement of g2o LM + block sparse direct Cholesky (reference binaries not buildable here), gcc -O3 -march=native -fopenmp on this host"
@@ -637,11 +711,13 @@ def main():
                                  "one independent graph per GPU" % (cfg_name, a.nodes, a.edges, a.lm_iters),
                         system_edges=st["n_edges"], lm_iterations_done=st["iterations_done"], lm_trials_per_solve=st["lm_trials"],
                         pcg_iterations_per_solve=st["pcg_iterations"], preconditioner_builds_per_solve=st["precond_builds"], pcg_tol=pgo.cfg.pcg_tol,
-                        preconditioner=("multilevel, 8-vertex rigid-body aggregates (small graphs: dense level-1 operator, multiplicative cycle + 2 Newton-Schulz steps on the f64 matrix cores)" if pgo.cfg.preconditioner else "block-Jacobi"),
+                        preconditioner=("multilevel, 8-vertex rigid-body aggregates (small graphs: dense level-1 operator, multiplicative cycle + 2 Newton-Schulz steps on the f64 matrix cores; "
+                                        "the PCG kernels apply an f32 COPY of that dense coarse operator (ml_cmat32_kernel) with f64 accumulation - preconditioner only: x, r, p, A p and every "
+                                        "reduction are f64, the converged solution does not depend on it)" if pgo.cfg.preconditioner else "block-Jacobi"),
                         chi2_initial=st["chi2_initial"], chi2_final=st["chi2_final"]),
             h2d_ms=round(B["h2d_ms"], 3), d2h_ms=round(B["d2h_ms"], 3),
             roofline=roofline, rooflines=rooflines, traffic_source=TRAFFIC_JSON + " (rocprofv3 --pmc passes of profiles/collect.sh on the default workloads; not measured in this run)",
-            kernels_ms_per_solve=kernels_ms, cpu_baseline=cpu, xy_only=xy_only, secondary=secondary)
+            kernels_ms_per_solve=kernels_ms, cpu_baseline=cpu, parity=parity, xy_only=xy_only, secondary=secondary)
         for k, v in (("batched", batched), ("formats", formats), ("c4_1gpu", c4), ("online_c5", online_c5), ("sharded_c4", sharded_c4)):
             if v is not None:
                 out[k] = v
@@ -650,6 +726,9 @@ def main():
     if matcher is not None:
         matcher.close()
     dist.close()
+    if parity_fail:
+        print("[bench] PARITY MISS: %s" % json.dumps(parity_fail), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":
