@@ -45,12 +45,12 @@ def test_reduced_online_run_with_min_accept_valid(capi, oracle):
     from online_stubs import oracle_online
     run = synth.make_online_run(1200, 300, n_kp=200)
     mc = dict(ransac_iteration=100)
-    gc = dict(min_accept_valid=70.0)
+    gc = dict(min_accept_valid=97.0)
     o = online.OnlineSlam(run, match_batch=100, lm_iterations=6, match_cfg=mc, gate_cfg=gc)
     c = oracle_online(oracle, run, ransac_iteration=100, match_batch=100, lm_iterations=6, match_cfg=mc, gate_cfg=gc)
     o.upload_frames(); c.upload_frames()
     o.run_all(); c.run_all()
-    hi = o.f_score >= 70.0
+    hi = o.f_score >= 97.0
     assert hi.any() and (~hi).any() and o.f_sticky[hi].all()
     assert o.accept_log == c.accept_log and np.array_equal(o.f_key, c.f_key) and np.array_equal(o.f_sticky, c.f_sticky)
     assert len(o.solves) == len(c.solves) >= 4

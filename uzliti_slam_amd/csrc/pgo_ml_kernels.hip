@@ -239,56 +239,6 @@ __global__ __launch_bounds__(kBlk) void ml_reduce_kernel(const MlDev* __restrict
 constexpr int kSibBlk = 192;
 constexpr int kSibCols = 2048;                          // slot columns of one aggregate staged in LDS
 
-// 1/sqrt(x) from the hardware estimate + two Newton steps (deterministic; accuracy ~1e-15 is ample for a smoother)
-__device__ __forceinline__ double rsqrt_nr(double x)
-{
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y;
-}
-// inverse of an SPD 6x6 (row-major) through its Cholesky factor, reciprocal square roots only
-__device__ __forceinline__ void spd_inverse6_rs(double* A, double* out)
-{
-    double inv[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        double d = A[j * 6 + j];
-#pragma unroll
-        for (int k = 0; k < j; k++) d -= A[j * 6 + k] * A[j * 6 + k];
-        inv[j] = rsqrt_nr(fmax(d, 1e-300));
-#pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-            double s = A[i * 6 + j];
-#pragma unroll
-            for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k];
-            A[i * 6 + j] = s * inv[j];
-        }
-    }
-    double Li[36];
-#pragma unroll
-    for (int i = 0; i < 36; i++) Li[i] = 0.;
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-#pragma unroll
-        for (int r = c; r < 6; r++) {
-            double s = (r == c) ? 1. : 0.;
-#pragma unroll
-            for (int k = c; k < r; k++) s -= A[r * 6 + k] * Li[k * 6 + c];
-            Li[r * 6 + c] = s * inv[r];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            double s = 0.;
-#pragma unroll
-            for (int k = (r > c ? r : c); k < 6; k++) s += Li[k * 6 + r] * Li[k * 6 + c];
-            out[r * 6 + c] = s;
-        }
-}
-
 // In-place inverse of the M x M SPD matrix in sW (row stride ld) by BLOCK Gauss-Jordan with 6 x 6 pivots: M/6
 // dependent steps instead of M.  Lane (row, part) = tid / 4, tid % 4 holds columns [part*M/4, +M/4) of its row in
 // registers (loops over them unrolled; pivot positions are only ever compared, so register indices stay static).

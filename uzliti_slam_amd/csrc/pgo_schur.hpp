@@ -1,0 +1,54 @@
+// pgo_schur.hpp — Schur reduction of the chain interiors of a pose graph (north_star's "Schur-reduced PCG").
+//
+// The reference's graphs are an odometry chain (addOdometryEdge, graph_optimization/src/g2o_optimizer.cpp:190-259) plus loop
+// closures (addFeatureEdge, :261-299).  In an online run most vertices carry nothing but their two odometry edges: in the block
+// system (H + lambda I) dx = b such a vertex couples to its two chain neighbours only.  Maximal runs of those vertices are
+// eliminated EXACTLY by block-tridiagonal elimination (one wave per run, runs are independent), the PCG then runs on the Schur
+// complement over the remaining "separator" vertices (loop-closure endpoints, hubs, and every (cap+1)-th vertex of a long run so
+// that no run is longer than `cap`), and the interiors follow by back-substitution.  Exact linear algebra on an SPD system: the
+// LM trajectory is the one of the full solve up to the PCG tolerance.
+//
+//   run:  s0 - v1 - v2 - ... - vk - s1        (s0 / s1: separator, or absent = fixed vertex / end of the chain)
+//   forward sweep, m = 1..k, with D'_1 = H_11 + lambda I, g'_1 = b_1, C_1 = H_{s0,v1}:
+//       Dinv = D'_m^-1;  u_m = Dinv g'_m;  W_m = Dinv C_m^T;  T_m = Dinv E_m          (E_m = H_{vm, next})
+//       S_L -= C_m W_m;  g_L -= C_m u_m;  C_{m+1} = -C_m T_m;  D'_{m+1} = H_{m+1,m+1} + lambda I - E_m^T T_m;  g'_{m+1} = b_{m+1} - E_m^T u_m
+//   after vk:  S_R = -E_k^T T_k,  g_R = -E_k^T u_k,  F = C_{k+1} = fill block H'_{s0,s1}
+//   back-substitution, m = k..1:   x_m = u_m - W_m x_{s0} - T_m x_{next}
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace uzl {
+
+constexpr int kSchurElim = 78;        // doubles kept per eliminated vertex: u (6) | W (36) | T (36)
+constexpr int kSchurRunOut = 120;     // doubles written per run: S_L (36) | g_L (6) | S_R (36) | g_R (6) | F (36)
+
+// device view (by-value kernel argument)
+struct SchurDev {
+    int32_t n_runs, n_int, nbr, nslots_r;
+    const int32_t* run_ptr;     // [n_runs+1] into run_rows / slotP / slotN
+    const int32_t* run_rows;    // [n_int] full-system row of every eliminated vertex, in chain order
+    const int32_t* slotP;       // [n_int] slot (full block-CSR) of the block H_{v, previous element of the run / s0}; -1 = none
+    const int32_t* slotN;       // [n_int] slot of H_{v, next element / s1}; -1 = none
+    const int32_t* endL;        // [n_runs] reduced row of s0, -1 = none
+    const int32_t* endR;        // [n_runs] reduced row of s1, -1 = none
+    const int32_t* sep_rows;    // [nbr] full-system row of every reduced row (ascending)
+    const int32_t* rsrc;        // [nslots_r] >= 0: slot of the full system whose block is copied; < 0: -(2 run + side) - 1, fill block F (side 0) / F^T (side 1)
+    const int32_t* inc_ptr;     // [nbr+1] runs incident to each reduced row
+    const int32_t* inc;         // 4 run + side: 0 = row is s0 (S_L, g_L), 1 = row is s1 (S_R, g_R), 2 = s0 == s1 (S_L + S_R + F + F^T, g_L + g_R)
+    double* elim;               // [n_int][kSchurElim]
+    double* runout;             // [n_runs][kSchurRunOut]
+};
+
+// host-side plan: which rows are eliminated, the runs, and the block-CSR of the reduced system
+struct SchurPlan {
+    int32_t nb = 0, nbr = 0, n_int = 0, n_runs = 0, nslots_r = 0, longest_run = 0;
+    std::vector<int32_t> full2red;                            // [nb] reduced row or -1
+    std::vector<int32_t> run_ptr, run_rows, slotP, slotN, endL, endR, sep_rows, rsrc, inc_ptr, inc;
+    std::vector<int32_t> row_ptr, col;                        // reduced block-CSR
+};
+
+// Plans the reduction of a block-CSR (row_ptr / col over free vertices, col = -1 for a fixed neighbour).  `cap` = longest run.
+SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vector<int32_t>& col, int cap);
+
+}  // namespace uzl

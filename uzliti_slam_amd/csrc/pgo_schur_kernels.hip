@@ -1,0 +1,307 @@
+// pgo_schur_kernels.hip — Schur reduction of chain interiors: host-side plan + the three kernels (pgo_schur.hpp has the recurrences).
+//
+//   schur_eliminate_kernel : one wave per run; forward block-tridiagonal elimination of (H + lambda I) along the run.  Lane (r, c) of
+//                            the first 36 owns element (r, c) of every 6x6 block; operands of a product are staged in LDS (broadcast
+//                            reads).  Writes u | W | T per eliminated vertex and S_L | g_L | S_R | g_R | F per run.
+//   schur_assemble_kernel  : the reduced system: off-diagonal blocks (copies of the separator-separator blocks + the runs' fill
+//                            blocks), diagonal blocks and right-hand side (own + contributions of the incident runs, in run order:
+//                            a gather, no atomics, bit-reproducible).
+//   schur_backsub_kernel   : x of the separators copied to their full-system rows; one wave per run walks it backwards.
+// HBM-bound in principle (algorithmic bytes per eliminated vertex: 3 blocks of 288 B in, 78 doubles out and in again), latency-bound
+// in practice: a run is a chain of <= cap dependent 6x6 steps.
+#include <algorithm>
+
+#include "pgo_device.hpp"
+#include "pgo_schur.hpp"
+
+namespace uzl {
+
+// ------------------------------------------------------------------------------------------------------------------ host: the plan
+SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vector<int32_t>& col, int cap)
+{
+    SchurPlan P;
+    P.nb = nb;
+    if (cap < 1) cap = 1;
+    auto deg = [&](int a) { return row_ptr[a + 1] - row_ptr[a]; };
+    // a chain interior: one or two incident edges, to different neighbours (a double edge makes both ends separators)
+    std::vector<uint8_t> cand((size_t)std::max(nb, 1), 0);
+    for (int a = 0; a < nb; a++) {
+        const int d = deg(a);
+        if (d == 1) cand[a] = 1;
+        else if (d == 2) { const int c0 = col[row_ptr[a]], c1 = col[row_ptr[a] + 1]; cand[a] = !(c0 >= 0 && c0 == c1); }
+    }
+    std::vector<uint8_t> is_int(cand), seen((size_t)std::max(nb, 1), 0);
+    // the slot that leads on from `a` when it was entered through in_slot (-1: a leaf entered from its missing side)
+    auto way_on = [&](int a, int in_slot) {
+        if (deg(a) == 1) return in_slot < 0 ? row_ptr[a] : -1;
+        return in_slot == row_ptr[a] ? row_ptr[a] + 1 : row_ptr[a];
+    };
+    auto slot_to = [&](int a, int c) { for (int s = row_ptr[a]; s < row_ptr[a + 1]; s++) if (col[s] == c) return s; return -1; };
+    // pass 1: every (cap+1)-th vertex of a long chain is promoted to a separator, so that no run is longer than cap
+    auto walk_promote = [&](int start, int in_slot) {
+        int cur = start, len = 0;
+        while (cur >= 0 && cand[cur] && !seen[cur]) {
+            seen[cur] = 1;
+            if (len == cap) { is_int[cur] = 0; len = 0; } else len++;
+            const int out = way_on(cur, in_slot);
+            if (out < 0) break;
+            const int nx = col[out];
+            if (nx < 0) break;
+            in_slot = slot_to(nx, cur);
+            cur = nx;
+        }
+    };
+    auto outer_slot = [&](int a, const std::vector<uint8_t>& inner) {      // slot of `a` that leads out of the chain (-1: a leaf's missing side), or -2 if none does
+        if (deg(a) == 1) return -1;
+        for (int s = row_ptr[a]; s < row_ptr[a + 1]; s++) { const int c = col[s]; if (c < 0 || !inner[c]) return s; }
+        return -2;
+    };
+    for (int a = 0; a < nb; a++) {
+        if (!cand[a] || seen[a]) continue;
+        const int o = outer_slot(a, cand);
+        if (o == -2) continue;
+        // enter from the outer side: a leaf is entered "from nowhere", i.e. its one slot is the way on
+        walk_promote(a, o);
+    }
+    for (int a = 0; a < nb; a++) {                       // cycles of candidates only (no separator, no fixed vertex on them): break them
+        if (!cand[a] || seen[a]) continue;
+        seen[a] = 1; is_int[a] = 0;
+        const int nx = col[row_ptr[a]];
+        if (nx >= 0) walk_promote(nx, slot_to(nx, a));
+    }
+    // reduced numbering
+    P.full2red.assign((size_t)std::max(nb, 1), -1);
+    for (int a = 0; a < nb; a++) if (!is_int[a]) { P.full2red[a] = (int32_t)P.sep_rows.size(); P.sep_rows.push_back(a); }
+    P.nbr = (int32_t)P.sep_rows.size();
+    P.n_int = nb - P.nbr;
+    // pass 2: the runs
+    std::vector<uint8_t> in_run((size_t)std::max(nb, 1), 0);
+    P.run_ptr.push_back(0);
+    auto red_of = [&](int slot) { return (slot >= 0 && col[slot] >= 0) ? P.full2red[col[slot]] : -1; };
+    for (int a = 0; a < nb; a++) {
+        if (!is_int[a] || in_run[a]) continue;
+        const int o = outer_slot(a, is_int);
+        if (o == -2) continue;                           // not an end of its run: reached from the end with the lower row
+        int cur = a, in_slot = o;                        // in_slot = -1: a leaf's missing side
+        P.endL.push_back(red_of(in_slot));
+        int len = 0;
+        while (true) {
+            in_run[cur] = 1; len++;
+            P.run_rows.push_back(cur);
+            P.slotP.push_back((in_slot >= 0 && col[in_slot] >= 0) ? in_slot : -1);
+            const int out = way_on(cur, in_slot);
+            P.slotN.push_back((out >= 0 && col[out] >= 0) ? out : -1);
+            const int nx = out >= 0 ? col[out] : -1;
+            if (nx < 0 || !is_int[nx] || in_run[nx]) { P.endR.push_back((nx >= 0 && !is_int[nx]) ? P.full2red[nx] : -1); break; }
+            in_slot = slot_to(nx, cur);
+            cur = nx;
+        }
+        P.longest_run = std::max(P.longest_run, len);
+        P.run_ptr.push_back((int32_t)P.run_rows.size());
+    }
+    P.n_runs = (int32_t)P.endL.size();
+    // reduced block-CSR: kept blocks in slot order, then the fill blocks of the incident runs in run order
+    std::vector<std::vector<int32_t>> inc((size_t)std::max(P.nbr, 1));
+    for (int r = 0; r < P.n_runs; r++) {
+        const int L = P.endL[r], R = P.endR[r];
+        if (L >= 0 && L == R) inc[L].push_back(4 * r + 2);
+        else { if (L >= 0) inc[L].push_back(4 * r + 0); if (R >= 0) inc[R].push_back(4 * r + 1); }
+    }
+    P.row_ptr.assign((size_t)P.nbr + 1, 0);
+    P.inc_ptr.assign((size_t)P.nbr + 1, 0);
+    for (int i = 0; i < P.nbr; i++) {
+        const int a = P.sep_rows[i];
+        for (int s = row_ptr[a]; s < row_ptr[a + 1]; s++) {
+            const int c = col[s];
+            if (c >= 0 && !is_int[c]) { P.col.push_back(P.full2red[c]); P.rsrc.push_back(s); }
+        }
+        for (int32_t code : inc[i]) {
+            const int r = code >> 2, side = code & 3;
+            P.inc.push_back(code);
+            if (side == 2) continue;                     // both ends here: diagonal only
+            const int other = side == 0 ? P.endR[r] : P.endL[r];
+            if (other >= 0) { P.col.push_back(other); P.rsrc.push_back(-(2 * r + side) - 1); }
+        }
+        P.row_ptr[i + 1] = (int32_t)P.col.size();
+        P.inc_ptr[i + 1] = (int32_t)P.inc.size();
+    }
+    P.nslots_r = (int32_t)P.col.size();
+    return P;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ device
+// C(r, c) = sum_k A[r][k] B[k][c] for the lane's (r, c); A, B row-major 6x6 in LDS.  TA / TB: use the transpose.
+template <bool TA, bool TB>
+__device__ __forceinline__ double mm6(const double* __restrict__ A, const double* __restrict__ B, int r, int c)
+{
+    double s = 0.;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s = fma(TA ? A[k * 6 + r] : A[r * 6 + k], TB ? B[c * 6 + k] : B[k * 6 + c], s);
+    return s;
+}
+template <bool TA>
+__device__ __forceinline__ double mv6(const double* __restrict__ A, const double* __restrict__ v, int r)
+{
+    double s = 0.;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s = fma(TA ? A[k * 6 + r] : A[r * 6 + k], v[k], s);
+    return s;
+}
+
+// One wave per run.  LDS matrices are private to the wave; with a single-wave workgroup __syncthreads() orders its LDS traffic.
+__global__ __launch_bounds__(64) void schur_eliminate_kernel(PgoDev D, SchurDev S)
+{
+    __shared__ double sD[36], sDi[36], sC[36], sE[36], sT[36], sW[36], sg[6], su[6];
+    const int run = blockIdx.x;
+    if (run >= S.n_runs) return;
+    const int lane = threadIdx.x, r = lane / 6, c = lane % 6;
+    const bool act = lane < 36, vec = lane < 6;
+    const double lambda = D.scal[3];
+    const int p0 = S.run_ptr[run], p1 = S.run_ptr[run + 1];
+    const bool hasL = S.endL[run] >= 0;
+    const bool hasR = S.endR[run] >= 0;
+    double dupd = 0., gupd = 0.;              // D'_m - (H_mm + lambda I), g'_m - b_m: what the eliminated predecessor left
+    double accSL = 0., accgL = 0., cval = 0.;
+    if (hasL && act) cval = D.blk[(size_t)S.slotP[p0] * 36 + c * 6 + r];          // C_1 = H_{s0,v1} = H_{v1,s0}^T
+    for (int p = p0; p < p1; p++) {
+        const int v = S.run_rows[p];
+        const int sn = S.slotN[p];
+        const bool hasN = sn >= 0 && (p + 1 < p1 || hasR);
+        if (act) {
+            sD[lane] = D.hdiag[(size_t)v * 36 + lane] + ((r == c) ? lambda : 0.) + dupd;
+            sE[lane] = hasN ? D.blk[(size_t)sn * 36 + lane] : 0.;
+            sC[lane] = cval;
+        }
+        if (vec) sg[lane] = D.b[(size_t)v * 6 + lane] + gupd;
+        __syncthreads();
+        // Dinv: every lane inverts the same 36 numbers (Cholesky, registers only) and keeps its own element
+        double A[36], Di[36];
+#pragma unroll
+        for (int i = 0; i < 36; i++) A[i] = sD[i];
+        spd_inverse6_rs(A, Di);
+        double mine = 0.;
+#pragma unroll
+        for (int i = 0; i < 36; i++) mine = (i == lane) ? Di[i] : mine;
+        if (act) sDi[lane] = mine;
+        __syncthreads();
+        double tval = 0., wval = 0., uval = 0.;
+        if (act) {
+            if (hasN) tval = mm6<false, false>(sDi, sE, r, c);        // T = Dinv E
+            if (hasL) wval = mm6<false, true>(sDi, sC, r, c);         // W = Dinv C^T
+            sT[lane] = tval; sW[lane] = wval;
+        }
+        if (vec) { uval = mv6<false>(sDi, sg, lane); su[lane] = uval; }
+        double* __restrict__ out = S.elim + (size_t)p * kSchurElim;
+        if (vec) out[lane] = uval;
+        if (act) { out[6 + lane] = wval; out[42 + lane] = tval; }
+        __syncthreads();
+        dupd = 0.; gupd = 0.;
+        if (act) {
+            if (hasL) accSL -= mm6<false, false>(sC, sW, r, c);      // S_L -= C W
+            if (hasL && hasN) cval = -mm6<false, false>(sC, sT, r, c);   // C' = -C T
+            else cval = 0.;
+            if (hasN) dupd = -mm6<true, false>(sE, sT, r, c);         // -E^T T
+        }
+        if (vec) {
+            if (hasL) accgL -= mv6<false>(sC, su, lane);
+            if (hasN) gupd = -mv6<true>(sE, su, lane);
+        }
+        __syncthreads();                                               // LDS is rewritten at the top of the next step
+    }
+    double* __restrict__ ro = S.runout + (size_t)run * kSchurRunOut;
+    if (act) { ro[lane] = accSL; ro[42 + lane] = hasR ? dupd : 0.; ro[84 + lane] = (hasL && hasR) ? cval : 0.; }
+    if (vec) { ro[36 + lane] = accgL; ro[78 + lane] = hasR ? gupd : 0.; }
+}
+
+// Reduced system: item t / 36 = off-diagonal block (copy or fill), then diagonal block, then (6 lanes) right-hand side
+__global__ __launch_bounds__(kBlk) void schur_assemble_kernel(PgoDev D, PgoDev R, SchurDev S)
+{
+    const int t = blockIdx.x * kBlk + threadIdx.x;
+    const int item = t / 36, k = t % 36, kt = (k % 6) * 6 + k / 6;
+    if (item < S.nslots_r) {
+        const int src = S.rsrc[item];
+        double v;
+        if (src >= 0) v = D.blk[(size_t)src * 36 + k];
+        else {
+            const int code = -src - 1, run = code >> 1, side = code & 1;
+            const double* __restrict__ F = S.runout + (size_t)run * kSchurRunOut + 84;
+            v = side == 0 ? F[k] : F[kt];
+        }
+        R.blk[(size_t)item * 36 + k] = v;
+        return;
+    }
+    const int i = item - S.nslots_r;
+    if (i >= S.nbr) return;
+    const int a = S.sep_rows[i];
+    double h = D.hdiag[(size_t)a * 36 + k];
+    double g = (k < 6) ? D.b[(size_t)a * 6 + k] : 0.;
+    for (int q = S.inc_ptr[i]; q < S.inc_ptr[i + 1]; q++) {
+        const int code = S.inc[q], run = code >> 2, side = code & 3;
+        const double* __restrict__ ro = S.runout + (size_t)run * kSchurRunOut;
+        if (side == 0) { h += ro[k]; if (k < 6) g += ro[36 + k]; }
+        else if (side == 1) { h += ro[42 + k]; if (k < 6) g += ro[78 + k]; }
+        else { h += (ro[k] + ro[42 + k]) + (ro[84 + k] + ro[84 + kt]); if (k < 6) g += ro[36 + k] + ro[78 + k]; }
+    }
+    R.hdiag[(size_t)i * 36 + k] = h;
+    if (k < 6) R.b[(size_t)i * 6 + k] = g;
+}
+
+// blocks [0, n_runs): one wave per run, backwards; blocks behind: x of the separators to their full-system rows
+__global__ __launch_bounds__(64) void schur_backsub_kernel(PgoDev D, PgoDev R, SchurDev S)
+{
+    __shared__ double sx0[6], sxn[6], sp[36];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= S.n_runs) {
+        const int t = ((int)blockIdx.x - S.n_runs) * 64 + lane;
+        if (t < S.nbr * 6) D.x[(size_t)S.sep_rows[t / 6] * 6 + t % 6] = R.x[t];
+        return;
+    }
+    const int run = blockIdx.x, c = lane % 6;
+    const bool act = lane < 36, vec = lane < 6;
+    const int p0 = S.run_ptr[run], p1 = S.run_ptr[run + 1];
+    const int eL = S.endL[run], eR = S.endR[run];
+    if (vec) {
+        sx0[lane] = eL >= 0 ? R.x[(size_t)eL * 6 + lane] : 0.;
+        sxn[lane] = eR >= 0 ? R.x[(size_t)eR * 6 + lane] : 0.;
+    }
+    // the next step's operands are fetched before this step's chain link: they do not depend on it
+    const double* __restrict__ e = S.elim + (size_t)(p1 - 1) * kSchurElim;
+    double w = act ? e[6 + lane] : 0., t = act ? e[42 + lane] : 0., u = vec ? e[lane] : 0.;
+    __syncthreads();
+    for (int p = p1 - 1; p >= p0; p--) {
+        double wn = 0., tn = 0., un = 0.;
+        if (p > p0) {
+            const double* __restrict__ en = S.elim + (size_t)(p - 1) * kSchurElim;
+            if (act) { wn = en[6 + lane]; tn = en[42 + lane]; }
+            if (vec) un = en[lane];
+        }
+        if (act) sp[lane] = fma(w, sx0[c], t * sxn[c]);
+        __syncthreads();
+        double x = 0.;
+        if (vec) {
+            const double* __restrict__ q = sp + lane * 6;
+            x = u - (((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]));
+            D.x[(size_t)S.run_rows[p] * 6 + lane] = x;
+        }
+        if (vec) sxn[lane] = x;                                         // (read by all lanes before the barrier above, next read behind the one below)
+        __syncthreads();
+        w = wn; t = tn; u = un;
+    }
+}
+
+void k_schur_eliminate(const PgoDev& D, const SchurDev& S, hipStream_t s)
+{
+    if (S.n_runs > 0) hipLaunchKernelGGL(schur_eliminate_kernel, dim3(S.n_runs), dim3(64), 0, s, D, S);
+}
+void k_schur_assemble(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s)
+{
+    const long items = (long)(S.nslots_r + S.nbr) * 36;
+    if (items > 0) hipLaunchKernelGGL(schur_assemble_kernel, dim3((unsigned)((items + kBlk - 1) / kBlk)), dim3(kBlk), 0, s, D, R, S);
+}
+void k_schur_backsub(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s)
+{
+    const int g = S.n_runs + (S.nbr * 6 + 63) / 64;
+    if (g > 0) hipLaunchKernelGGL(schur_backsub_kernel, dim3(g), dim3(64), 0, s, D, R, S);
+}
+
+}  // namespace uzl
