@@ -219,6 +219,10 @@ typedef struct uzl_pgo_cfg {
     int32_t device;
     double  pcg_tol;                  /* 1e-5  stop when r.M^-1 r <= pcg_tol^2 * (r0.M^-1 r0)         */
     int32_t pcg_max_iter;             /* per linear solve                                             */
+    int32_t schur_reduce;             /* 0 = auto: vertices that carry nothing but their two chain (odometry, g2o_optimizer.cpp:190-259)
+                                         edges are eliminated exactly from (H + lambda I) per LM trial and PCG runs on the Schur
+                                         complement over the rest, when they are a third or more of the free vertices; -1 = never.
+                                         (occupies what used to be padding: layout unchanged)           */
     double  huber_delta;              /* 1.0  (g2o_optimizer.cpp:293)                                 */
     int32_t verbose;
     int32_t preconditioner;           /* 1 = additive multilevel (8-vertex aggregates, rigid-body modes), 0 = block-Jacobi */
@@ -268,7 +272,7 @@ typedef struct uzl_pgo_stats {
                                   setFixedNodes, block-CSR structure, aggregation hierarchy, (first solve) PCG graph capture */
     double  exchange_ms;       /* sharded solve: host time inside the exchange step (callback) or enqueueing it (native RCCL) */
     int32_t structure_reused;  /* 1: the structure of the previous graph was kept (same vertices / edge endpoints / fixed flags) */
-    int32_t _pad;
+    int32_t n_eliminated;      /* free vertices Schur-eliminated ahead of the PCG (chain interiors), 0 = full system */
 } uzl_pgo_stats;
 
 void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg);
@@ -315,6 +319,14 @@ int  uzl_pgo_get_fixed(uzl_pgo* h, uint8_t* fixed);
 
 int  uzl_pgo_set_profiling(uzl_pgo* h, int32_t on);
 int  uzl_pgo_kernel_times(uzl_pgo* h, int32_t cap, const char** names, double* ms, int32_t* launches);
+
+/* The Schur plan of uzl_pgo_cfg::schur_reduce for a block structure given as CSR over nb free vertices (col = -1: fixed neighbour):
+ * which rows are chain interiors (one or two incident edges, to different neighbours; g2o_optimizer.cpp:190-259 builds that chain),
+ * how they group into runs of at most `cap` vertices, and the block structure of the Schur complement over the rest.  Host code
+ * only (no device).  red_row / run_id / run_pos: nb entries (-1 where not applicable); red_row_ptr: nb + 1 entries; red_col:
+ * cap_slots entries (UZL_ERR_BAD_ARG if the reduced system has more blocks). */
+int  uzl_pgo_schur_plan(int32_t nb, const int32_t* row_ptr, const int32_t* col, int32_t cap, int32_t* red_row, int32_t* run_id,
+                        int32_t* run_pos, int32_t* red_row_ptr, int32_t* red_col, int32_t cap_slots, int32_t* n_reduced, int32_t* n_runs);
 
 /* ---- sharded single-graph solve (BASELINE config 4): one handle per rank ------------------
  * The graph is edge-partitioned: every rank holds all vertices and the edges

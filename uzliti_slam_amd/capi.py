@@ -71,7 +71,8 @@ PAIR_JOB_DTYPE = np.dtype([("job_id", "<u8"), ("from_begin", "<i4"), ("from_coun
 class PgoCfg(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("use_odometry_parameters", C.c_int32),
                 ("optimize_xy_only", C.c_int32), ("device", C.c_int32), ("pcg_tol", C.c_double),
-                ("pcg_max_iter", C.c_int32), ("huber_delta", C.c_double), ("verbose", C.c_int32), ("preconditioner", C.c_int32)]
+                ("pcg_max_iter", C.c_int32), ("schur_reduce", C.c_int32), ("huber_delta", C.c_double), ("verbose", C.c_int32),
+                ("preconditioner", C.c_int32)]
 
 
 class PgoStats(C.Structure):
@@ -80,7 +81,7 @@ class PgoStats(C.Structure):
                 ("n_gauge_fixed", C.c_int32), ("pcg_not_converged", C.c_int32),
                 ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
                 ("solve_ms", C.c_double), ("precond_builds", C.c_int32), ("exchange_calls", C.c_int32),
-                ("structure_ms", C.c_double), ("exchange_ms", C.c_double), ("structure_reused", C.c_int32), ("_pad", C.c_int32)]
+                ("structure_ms", C.c_double), ("exchange_ms", C.c_double), ("structure_reused", C.c_int32), ("n_eliminated", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -702,6 +703,23 @@ class Gate:
 
     def edge_count(self):
         return self._check(lib().uzl_gate_edge_count(self._h))
+
+
+def schur_plan(row_ptr, col, cap=24):
+    """uzl_pgo_schur_plan (host only) -> dict(red_row, run_id, run_pos, row_ptr, col, n_reduced, n_runs)."""
+    rp = np.ascontiguousarray(row_ptr, np.int32); cl = np.ascontiguousarray(col, np.int32)
+    nb = len(rp) - 1
+    red_row = np.empty(max(nb, 1), np.int32); run_id = np.empty(max(nb, 1), np.int32); run_pos = np.empty(max(nb, 1), np.int32)
+    rrp = np.zeros(nb + 1, np.int32); cap_slots = len(cl) + 2 * nb + 2; rcol = np.empty(cap_slots, np.int32)
+    nr = C.c_int32(); nruns = C.c_int32()
+    i32 = C.POINTER(C.c_int32)
+    rc = lib().uzl_pgo_schur_plan(C.c_int32(nb), rp.ctypes.data_as(i32), cl.ctypes.data_as(i32), C.c_int32(cap), red_row.ctypes.data_as(i32),
+                                  run_id.ctypes.data_as(i32), run_pos.ctypes.data_as(i32), rrp.ctypes.data_as(i32), rcol.ctypes.data_as(i32),
+                                  C.c_int32(cap_slots), C.byref(nr), C.byref(nruns))
+    if rc != UZL_OK:
+        raise UzlError(rc, lib().uzl_status_string(rc).decode())
+    return dict(red_row=red_row[:nb], run_id=run_id[:nb], run_pos=run_pos[:nb], row_ptr=rrp[:nr.value + 1], col=rcol[:rrp[nr.value]],
+                n_reduced=nr.value, n_runs=nruns.value)
 
 
 # --------------------------------------------------------------------------------------- distance loop-closure candidates

@@ -289,6 +289,33 @@ __global__ __launch_bounds__(64) void schur_backsub_kernel(PgoDev D, PgoDev R, S
     }
 }
 
+}  // namespace uzl
+
+// The plan uzl_pgo_optimize works with, for a caller-supplied block structure: pure host code (no device needed).
+extern "C" int uzl_pgo_schur_plan(int32_t nb, const int32_t* row_ptr, const int32_t* col, int32_t cap, int32_t* red_row, int32_t* run_id,
+                                  int32_t* run_pos, int32_t* red_row_ptr, int32_t* red_col, int32_t cap_slots, int32_t* n_reduced,
+                                  int32_t* n_runs)
+{
+    if (nb < 0 || !row_ptr || (nb > 0 && (!red_row || !run_id || !run_pos)) || !red_row_ptr || !n_reduced || !n_runs) return UZL_ERR_BAD_ARG;
+    for (int a = 0; a < nb; a++) if (row_ptr[a + 1] < row_ptr[a]) return UZL_ERR_BAD_ARG;
+    if (nb > 0 && row_ptr[nb] > 0 && !col) return UZL_ERR_BAD_ARG;
+    try {
+        const std::vector<int32_t> rp(row_ptr, row_ptr + nb + 1), cl(col, col + (nb > 0 ? row_ptr[nb] : 0));
+        for (int32_t c : cl) if (c < -1 || c >= nb) return UZL_ERR_BAD_ARG;
+        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap);
+        if (P.nslots_r > cap_slots || (P.nslots_r > 0 && !red_col)) return UZL_ERR_BAD_ARG;
+        for (int a = 0; a < nb; a++) { red_row[a] = P.full2red[a]; run_id[a] = -1; run_pos[a] = -1; }
+        for (int r = 0; r < P.n_runs; r++)
+            for (int q = P.run_ptr[r]; q < P.run_ptr[r + 1]; q++) { run_id[P.run_rows[q]] = r; run_pos[P.run_rows[q]] = q - P.run_ptr[r]; }
+        for (int i = 0; i <= P.nbr; i++) red_row_ptr[i] = P.row_ptr[i];
+        for (int k = 0; k < P.nslots_r; k++) red_col[k] = P.col[k];
+        *n_reduced = P.nbr; *n_runs = P.n_runs;
+        return UZL_OK;
+    } catch (...) { return UZL_ERR_OOM; }
+}
+
+namespace uzl {
+
 void k_schur_eliminate(const PgoDev& D, const SchurDev& S, hipStream_t s)
 {
     if (S.n_runs > 0) hipLaunchKernelGGL(schur_eliminate_kernel, dim3(S.n_runs), dim3(64), 0, s, D, S);

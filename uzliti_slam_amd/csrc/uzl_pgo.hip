@@ -7,6 +7,7 @@
 // accept/reject logic of g2o's OptimizationAlgorithmLevenberg [EXT].
 #include "uzl_common.hpp"
 #include "pgo_types.hpp"
+#include "pgo_schur.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -74,6 +75,9 @@ void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_
 bool ml_comp_small(int n1);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
+void k_schur_eliminate(const PgoDev& D, const SchurDev& S, hipStream_t s);
+void k_schur_assemble(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s);
+void k_schur_backsub(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s);
 }  // namespace uzl
 
 using namespace uzl;
@@ -142,6 +146,17 @@ struct uzl_pgo {
     uint32_t pub_seq = 0;
     PinBuf<double> h_lambda;
     PgoDev D;
+    // The system the PCG (and its preconditioner) sees: D itself, or - when chain interiors are Schur-eliminated (pgo_schur.hpp) - the
+    // reduced system over the separator vertices.  scal / flags / part_b / part_c are shared with D.
+    PgoDev Dp;
+    double* pbuf[2] = {nullptr, nullptr};      // PCG direction, ping-pong (of the Dp system)
+    struct Reduced {
+        bool on = false;
+        int32_t n_int = 0, n_runs = 0, longest_run = 0;
+        DevBuf<int32_t> run_ptr, run_rows, slotP, slotN, endL, endR, sep_rows, rsrc, inc_ptr, inc, row_ptr, col, rowhdr, b2v;
+        DevBuf<double> elim, runout, blk, hdiag, minv, x, r, z, p, p2, ap;
+        SchurDev S;
+    } red;
     int prev_pcg_iters = 0;
     // multilevel preconditioner
     int ml_levels = 0;
@@ -342,10 +357,11 @@ int32_t gauge_fix(uzl_pgo* h)
 // block-CSR structure over the free vertices: one slot per (free endpoint, system edge)
 
 // Aggregation hierarchy of the multilevel preconditioner (pgo_types.hpp): symbolic part, once per structure.
-void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vector<int32_t>& col0)
+// (nb, nslots, d_*: the block system the PCG solves - the full one or the Schur-reduced one)
+void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vector<int32_t>& col0, int nb, int nslots,
+              const int32_t* d_row_ptr, const int32_t* d_col, double* d_blk, double* d_hdiag)
 {
-    const int nb = h->nb;
-    h->ml_levels = 0; h->ml_n.assign(1, nb); h->ml_nslots.assign(1, h->nslots); h->ml_inner_aggs = 0;
+    h->ml_levels = 0; h->ml_n.assign(1, nb); h->ml_nslots.assign(1, nslots); h->ml_inner_aggs = 0;
     if (h->cfg.preconditioner == 0 || nb <= kMlTopMax) return;
     static const int agg1_max = diag_int("UZL_ML_AGG1_MAX", 2048);   // up to here the level-1 dense operator applies (6 n_1 <= 1536); above, AGG = 4 with the level-2 one (measured: 2500 vertices 65.7 -> 38.2 ms)
     h->ml_agg = nb <= agg1_max ? 1 : 4;
@@ -462,7 +478,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     // 62.3; 20k/100k 242 -> 224) - on chain-like graphs of that size they cost more than they save (20k/21.7k: 209 -> 261 ms), on
     // small graphs the count barely moves (config 2: 538 -> 511 for +0.3 ms).  tests/diag/ns_sweep.sh
     static const int ns_env = diag_int("UZL_ML_NS_STEPS", -1);
-    const int ns_auto = (h->ml_agg == 4 && h->nslots >= 6 * nb) ? 4 : 2;
+    const int ns_auto = (h->ml_agg == 4 && nslots >= 6 * nb) ? 4 : 2;
     h->ml_ns_steps = h->ml_mult ? std::max(0, std::min(ns_env >= 0 ? ns_env : ns_auto, 4)) : 0;
     const size_t nsq = h->ml_mult ? (size_t)(6 * h->ml_n[cl]) * (size_t)(6 * h->ml_n[cl]) * 8 : 0;     // also the scratch of the levels above cl
     const size_t o_nsT = take(nsq), o_nsX = take(nsq);
@@ -516,15 +532,15 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
             X.n = h->ml_n[l]; X.nslots = h->ml_nslots[l];
             X.fan = h->ml_fan[l];
             X.span = 1; for (int q = 1; q <= l; q++) X.span *= h->ml_fan[q];
-            X.row_ptr = (l == 0) ? h->d_row_ptr.p : reinterpret_cast<const int32_t*>(base + io[l].row_ptr);
-            X.col = (l == 0) ? h->d_col.p : reinterpret_cast<const int32_t*>(base + io[l].col);
+            X.row_ptr = (l == 0) ? d_row_ptr : reinterpret_cast<const int32_t*>(base + io[l].row_ptr);
+            X.col = (l == 0) ? d_col : reinterpret_cast<const int32_t*>(base + io[l].col);
             X.srow = reinterpret_cast<const int32_t*>(base + io[l].srow);
             X.tpos = reinterpret_cast<const int32_t*>(base + io[l].tpos);
             X.off_ptr = reinterpret_cast<const int32_t*>(base + io[l].off_ptr);
             X.diag_ptr = reinterpret_cast<const int32_t*>(base + io[l].diag_ptr);
             X.n_off_contrib = lv[l].n_off;
-            X.blk = (l == 0) ? h->d_blk.p : reinterpret_cast<double*>(base + dof[l].blk);
-            X.G = (l == 0) ? h->d_hdiag.p : reinterpret_cast<double*>(base + dof[l].G);
+            X.blk = (l == 0) ? d_blk : reinterpret_cast<double*>(base + dof[l].blk);
+            X.G = (l == 0) ? d_hdiag : reinterpret_cast<double*>(base + dof[l].G);
             X.M = (l == 0) ? nullptr : reinterpret_cast<double*>(base + dof[l].M);
             X.Winv = (l < L) ? reinterpret_cast<double*>(base + dof[l].Winv) : nullptr;
             X.geo = (l == 0) ? reinterpret_cast<double*>(base + dof[l].geo) : reinterpret_cast<double*>(base + o_geo_blob) + geo_sub[l];
@@ -749,19 +765,69 @@ void build_structure(uzl_pgo* h)
     D.part_a = h->d_ap.p + (size_t)nbz * 12; D.part_b = h->d_part_b.p; D.part_c = h->d_part_c.p;
     D.scal = h->d_scal.p; D.flags = h->d_flags.p;
     D.e_begin = 0; D.e_end = e; D.diag_owner = 1; D.sibling0 = 1;      // sibling0 finalised after build_ml
-    build_ml(h, row_ptr, col);
+    // ---- Schur reduction of the chain interiors (pgo_schur.hpp): when a third or more of the free vertices carry nothing but their two
+    //      chain edges, the PCG runs on the Schur complement over the others.  Not with a sharded solve (its ranks hold partial blocks).
+    uzl_pgo::Reduced& Rd = h->red;
+    Rd.on = false; Rd.n_int = 0; Rd.n_runs = 0; Rd.longest_run = 0;
+    PgoDev& Dp = h->Dp;
+    static const int schur_diag = diag_int("UZL_SCHUR", 1);                  // A/B switches (diagnostic build)
+    static const int schur_cap = diag_int("UZL_SCHUR_CAP", 24);
+    static const int schur_min_pct = diag_int("UZL_SCHUR_MIN_PCT", 33);
+    const bool may_shard = h->allreduce != nullptr || h->rccl_comm != nullptr;
+    std::vector<int32_t> rrow_ptr, rcol;
+    if (h->cfg.schur_reduce >= 0 && schur_diag && !may_shard && nb > 0) {
+        SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap);
+        if (P.n_int >= 64 && (int64_t)100 * P.n_int >= (int64_t)schur_min_pct * nb) {
+            Rd.on = true; Rd.n_int = P.n_int; Rd.n_runs = P.n_runs; Rd.longest_run = P.longest_run;
+            const size_t nr = (size_t)std::max(P.nbr, 1), nsr = (size_t)std::max(P.nslots_r, 1), ni = (size_t)P.n_int, nru = (size_t)P.n_runs;
+            auto up = [&](DevBuf<int32_t>& b, const std::vector<int32_t>& v, size_t min_n) {
+                b.reserve(std::max(v.size(), min_n));
+                if (!v.empty()) UZL_HIP(hipMemcpyAsync(b.p, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, s));
+            };
+            up(Rd.run_ptr, P.run_ptr, 1); up(Rd.run_rows, P.run_rows, 1); up(Rd.slotP, P.slotP, 1); up(Rd.slotN, P.slotN, 1);
+            up(Rd.endL, P.endL, 1); up(Rd.endR, P.endR, 1); up(Rd.sep_rows, P.sep_rows, 1); up(Rd.rsrc, P.rsrc, 1);
+            up(Rd.inc_ptr, P.inc_ptr, 1); up(Rd.inc, P.inc, 1); up(Rd.row_ptr, P.row_ptr, 1); up(Rd.col, P.col, 1);
+            std::vector<int32_t> rb2v((size_t)P.nbr), rhdr(nr * kRowHdr, -1);
+            for (int i = 0; i < P.nbr; i++) {
+                rb2v[i] = b2v[P.sep_rows[i]];
+                rhdr[(size_t)i * kRowHdr] = P.row_ptr[i]; rhdr[(size_t)i * kRowHdr + 1] = P.row_ptr[i + 1];
+                for (int k = 0; k < 20 && P.row_ptr[i] + k < P.row_ptr[i + 1]; k++) rhdr[(size_t)i * kRowHdr + 2 + k] = P.col[P.row_ptr[i] + k];
+            }
+            up(Rd.b2v, rb2v, 1); up(Rd.rowhdr, rhdr, 1);
+            Rd.elim.reserve(std::max<size_t>(ni, 1) * kSchurElim); Rd.runout.reserve(std::max<size_t>(nru, 1) * kSchurRunOut);
+            Rd.blk.reserve(nsr * 36); Rd.hdiag.reserve(nr * 42); Rd.minv.reserve(nr * 36);
+            Rd.x.reserve(nr * 6); Rd.r.reserve(nr * 6); Rd.z.reserve(nr * 6); Rd.p.reserve(nr * 6); Rd.p2.reserve(nr * 6); Rd.ap.reserve(nr * 12 + kMaxPartials);
+            UZL_HIP(hipStreamSynchronize(s));                                  // P's vectors and the two locals go out of scope
+            SchurDev& S = Rd.S;
+            S.n_runs = P.n_runs; S.n_int = P.n_int; S.nbr = P.nbr; S.nslots_r = P.nslots_r;
+            S.run_ptr = Rd.run_ptr.p; S.run_rows = Rd.run_rows.p; S.slotP = Rd.slotP.p; S.slotN = Rd.slotN.p; S.endL = Rd.endL.p; S.endR = Rd.endR.p;
+            S.sep_rows = Rd.sep_rows.p; S.rsrc = Rd.rsrc.p; S.inc_ptr = Rd.inc_ptr.p; S.inc = Rd.inc.p; S.elim = Rd.elim.p; S.runout = Rd.runout.p;
+            Dp = D;
+            Dp.nb = P.nbr; Dp.nslots = P.nslots_r; Dp.b2v = Rd.b2v.p; Dp.row_ptr = Rd.row_ptr.p; Dp.col = Rd.col.p; Dp.rowhdr = Rd.rowhdr.p;
+            Dp.blk = Rd.blk.p; Dp.hdiag = Rd.hdiag.p; Dp.minv = Rd.minv.p; Dp.b = Rd.hdiag.p + (size_t)P.nbr * 36;
+            Dp.x = Rd.x.p; Dp.r = Rd.r.p; Dp.z = Rd.z.p; Dp.p = Rd.p.p; Dp.ap = Rd.ap.p; Dp.part_a = Rd.ap.p + nr * 12;
+            Dp.dcon = nullptr; Dp.gcon = nullptr;                              // the reduced system is assembled by schur_assemble_kernel
+            rrow_ptr.swap(P.row_ptr); rcol.swap(P.col);
+        }
+    }
+    PgoDev& Dsys = Rd.on ? Dp : D;                                             // what the PCG kernels get
+    const int nbp = Dsys.nb;
+    double* apbuf = Rd.on ? Rd.ap.p : h->d_ap.p;
+    if (Rd.on) build_ml(h, rrow_ptr, rcol, nbp, Dsys.nslots, Rd.row_ptr.p, Rd.col.p, Rd.blk.p, Rd.hdiag.p);
+    else build_ml(h, row_ptr, col, nb, nslots, h->d_row_ptr.p, h->d_col.p, h->d_blk.p, h->d_hdiag.p);
     {   // per-iteration exchange buffer: [A p (6 nb) | restricted A p (6 n_g) | p.Ap partials]
         const int gl = (h->ml_levels == 0) ? 0 : ((h->ml_agg == 1 || h->ml_levels < 2) ? 1 : 2);
         const size_t ng6 = gl ? (size_t)h->ml_n[gl] * 6 * (gl == 2 ? 2 : 1) : 0;      // gather level 2: two half-aggregate parts per entity (sg_at)
-        if (gl) { h->mlb[0].hot.Sg = h->d_ap.p + (size_t)nb * 6; h->mlb[1].hot.Sg = h->mlb[0].hot.Sg; }
-        D.part_a = h->d_ap.p + (size_t)nb * 6 + ng6;
-        h->iter_span = (int64_t)((size_t)nb * 6 + ng6 + (gl ? (size_t)g_ml_spmv(nb, h->ml_agg) : 0));
+        if (gl) { h->mlb[0].hot.Sg = apbuf + (size_t)nbp * 6; h->mlb[1].hot.Sg = h->mlb[0].hot.Sg; }
+        Dsys.part_a = apbuf + (size_t)nbp * 6 + ng6;
+        h->iter_span = (int64_t)((size_t)nbp * 6 + ng6 + (gl ? (size_t)g_ml_spmv(nbp, h->ml_agg) : 0));
     }
-    D.sibling0 = (h->ml_levels > 0 && h->ml_agg == 1) ? 1 : 0;       // large graphs keep the level-0 smoother block-diagonal
+    Dsys.sibling0 = (h->ml_levels > 0 && h->ml_agg == 1) ? 1 : 0;     // large graphs keep the level-0 smoother block-diagonal
+    D.sibling0 = Dsys.sibling0;
     // ---- sharded solve (BASELINE config 4): this rank linearises a contiguous range of the system edges
     // (a callback with world_size 1 still runs every exchange step: that is how the RCCL callback is tested on one GPU;
     //  graphs too small for the multilevel path are simply solved redundantly by every rank)
-    h->sharded = h->ml_levels > 0 && (h->allreduce != nullptr || h->rccl_comm != nullptr);
+    h->sharded = h->ml_levels > 0 && may_shard;
     if (h->sharded) {
         const int base = e / h->world, rem = e % h->world;
         D.e_begin = h->rank * base + std::min(h->rank, rem);
@@ -769,6 +835,8 @@ void build_structure(uzl_pgo* h)
         D.diag_owner = h->rank == 0 ? 1 : 0;
         D.sibling0 = 0;
     }
+    if (!Rd.on) Dp = D;
+    h->pbuf[0] = Rd.on ? Rd.p.p : h->d_p.p; h->pbuf[1] = Rd.on ? Rd.p2.p : h->d_p2.p;
     h->structure_ready = true;
     h->structure_gen++;
 }
@@ -777,11 +845,11 @@ void build_structure(uzl_pgo* h)
 void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
 {
     hipStream_t s = h->stream;
-    const PgoDev& D = h->D;
+    const PgoDev& D = h->Dp;
     const double tol2 = h->cfg.pcg_tol * h->cfg.pcg_tol;
     const bool ml = h->ml_levels > 0;
     const int ga = ml ? g_ml_spmv(D.nb, h->ml_agg) : g_pcg_spmv(D.nb), gu = ml ? g_ml_rows(D.nb, h->ml_agg) : g_pcg_update(D.nb);   // partials written by spmv / by cg
-    double* pb[2] = {h->d_p.p, h->d_p2.p};
+    double* pb[2] = {h->pbuf[0], h->pbuf[1]};
     for (int i = 0; i < 2 * pairs; i++) {
         double* po = pb[i & 1];
         double* pn = pb[(i & 1) ^ 1];
@@ -789,7 +857,7 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
         if (ml) {
             if (timed) h->timer.pair("pcg_spmv", &ea, &eb);                      // dispatch timestamps: agree with rocprofv3
             k_ml_spmv(D, h->mlb[h->ml_ix].hot, h->ml_agg, po, pn, gu, tol2, s, ea, eb);
-            shard_allreduce(h, h->d_ap.p, h->iter_span);                         // the one exchange per PCG iteration
+            shard_allreduce(h, D.ap, h->iter_span);                              // the one exchange per PCG iteration
             ea = eb = nullptr;
             if (timed) h->timer.pair("ml_cg", &ea, &eb);
             UZL_HIP(k_ml_cg(D, h->mlb[h->ml_ix].hot, h->ml_agg, pn, h->mlb[h->ml_ix].rg[(i & 1) ^ 1], h->mlb[h->ml_ix].rg[i & 1], ga, 0, h->ml_lds, s, ea, eb));
@@ -836,8 +904,9 @@ void ensure_pcg_graph(uzl_pgo* h)
 int pcg_solve(uzl_pgo* h, bool* converged)
 {
     hipStream_t s = h->stream;
-    const PgoDev& D = h->D;
-    const int max_it = h->cfg.pcg_max_iter > 0 ? h->cfg.pcg_max_iter : 6 * std::max(h->nb, 1);
+    const PgoDev& D = h->Dp;
+    if (D.nb == 0) { *converged = true; h->prev_pcg_iters = 0; h->last_residual_ratio = 0.; return 0; }     // every free vertex was Schur-eliminated: nothing left to iterate on
+    const int max_it = h->cfg.pcg_max_iter > 0 ? h->cfg.pcg_max_iter : 6 * std::max(D.nb, 1);
     const bool timed = h->timer.on || h->no_graph || h->sharded;   // per-kernel events, rocprofv3 and the exchange callback need eager launches
     if (h->ml_levels > 0) {
         if (h->ml_trial_setup) {
@@ -846,11 +915,11 @@ int pcg_solve(uzl_pgo* h, bool* converged)
             h->mlb[h->ml_ix].lambda_setup = h->lambda_now;
         }
         uzl_pgo::MlBuf& B = h->mlb[h->ml_ix];
-        { Timed t(h, "pcg_init"); k_ml_init(D, B.hot, h->ml_agg, h->d_p.p, h->d_p2.p, B.rg[0], s); }
-        { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, B.hot, h->ml_agg, h->d_p.p, B.rg[0], B.rg[1], 0, 1, h->ml_lds, s)); }
+        { Timed t(h, "pcg_init"); k_ml_init(D, B.hot, h->ml_agg, h->pbuf[0], h->pbuf[1], B.rg[0], s); }
+        { Timed t(h, "ml_cg"); UZL_HIP(k_ml_cg(D, B.hot, h->ml_agg, h->pbuf[0], B.rg[0], B.rg[1], 0, 1, h->ml_lds, s)); }
     } else {
         { Timed t(h, "precond"); k_precond(D, s); }
-        Timed t(h, "pcg_init"); k_pcg_init(D, h->d_p.p, h->d_p2.p, s);
+        Timed t(h, "pcg_init"); k_pcg_init(D, h->pbuf[0], h->pbuf[1], s);
     }
     if (!timed) ensure_pcg_graph(h);
     int launched = 0;
@@ -904,6 +973,15 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     S.n_vertices = h->n; S.n_edges = h->e; S.n_gauge_fixed = h->n_gauge;
     hipStream_t s = h->stream;
     PgoDev& D = h->D;
+    PgoDev& Dp = h->Dp;                       // the system the PCG solves: D, or the Schur complement over the separator vertices
+    const bool red = h->red.on;
+    const SchurDev& SD = h->red.S;
+    S.n_eliminated = red ? h->red.n_int : 0;
+    // (H + lambda I) with the chain interiors eliminated: once per lambda, i.e. per LM trial (pgo_schur.hpp)
+    auto schur_reduce = [&]() {
+        { Timed t(h, "schur_eliminate"); k_schur_eliminate(D, SD, s); }
+        { Timed t(h, "schur_assemble"); k_schur_assemble(D, Dp, SD, s); }
+    };
     const double delta = h->cfg.huber_delta;
     h->timer.reset();
     h->prev_pcg_iters = 0;
@@ -947,6 +1025,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             h->ml_ix ^= 1; h->ml_pending = false; adopted = true;
         }
         D.pose = h->cur; D.pose_trial = h->trial;
+        Dp.pose = h->cur; Dp.pose_trial = h->trial;
         { Timed t(h, "linearize"); gl = k_linearize(D, h->cur, delta, s); }     // computeActiveErrors + buildSystem
         { Timed t(h, "assemble"); ga = k_assemble(D, s); }
         if (h->sharded) {                                                         // H_aa, b: sums over all ranks' edges
@@ -961,16 +1040,28 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         // A rebuild is also forced when the iteration count has grown by a third since the last one.
         const bool refresh = it == 0 || always_refresh || last_rel > refresh_rel || pcg_last > pcg_ref + pcg_ref / 3 + 4;
         bool launch_async = false;
+        bool fetched = false;
+        if (red) {                                      // the hierarchy is built on the reduced system, which needs lambda: lambda_0 first
+            if (it == 0) {
+                fetch_scal(h); fetched = true;
+                current_chi = h->h_scal.p->scal[4];
+                S.chi2_initial = current_chi;
+                lambda = 1e-5 * h->h_scal.p->scal[6];                             // computeLambdaInit: tau * max diag
+                ni = 2.;
+            }
+            k_set_scalar(D.scal + 3, lambda, s);
+            schur_reduce();
+        }
         if (refresh) {
             S.precond_builds++;
-            if (it == 0 || !async_ok) { ml_setup_numeric(h, h->ml_ix, s, D, true); h->ml_trial_setup = true; }
+            if (it == 0 || !async_ok) { ml_setup_numeric(h, h->ml_ix, s, Dp, true); h->ml_trial_setup = true; }
             else launch_async = true;                                             // needs this iteration's lambda: below
         }
-        if (it == 0 || h->sharded) {                   // later iterations carry chi2 over from the accepted trial: no round trip
+        if ((it == 0 || h->sharded) && !fetched) {     // later iterations carry chi2 over from the accepted trial: no round trip
             fetch_scal(h);
             current_chi = h->h_scal.p->scal[4];
         }
-        if (it == 0) {
+        if (it == 0 && !fetched) {
             S.chi2_initial = current_chi;
             lambda = 1e-5 * h->h_scal.p->scal[6];                                 // computeLambdaInit: tau * max diag
             ni = 2.;
@@ -979,7 +1070,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             const int nb_ix = h->ml_ix ^ 1;
             UZL_HIP(hipEventRecord(h->ev_lin, s));                                // H, b and the poses of this linearisation are final
             UZL_HIP(hipStreamWaitEvent(h->stream2, h->ev_lin, 0));
-            PgoDev D2 = D;
+            PgoDev D2 = Dp;
             D2.scal = h->d_scal2.p;                                               // the trial loop below moves scal[3] on the main stream
             k_set_scalar(D2.scal + 3, lambda, h->stream2);
             ml_setup_numeric(h, nb_ix, h->stream2, D2, false);
@@ -993,6 +1084,10 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         const double tol_f2 = tol_factor2(it, last_rel, pcg_last);
         do {
             set_lambda(h, lambda, tol_f2);                                        // setLambda (+ this iteration's PCG tolerance)
+            if (red && qmax > 0) {                                                // a rejected step moved lambda: the Schur complement with it
+                if (h->ml_pending) UZL_HIP(hipStreamWaitEvent(s, h->ev_setup, 0));   // (a rebuild running ahead on stream2 still reads the old one)
+                schur_reduce();
+            }
             bool conv = false;
             // the lambda-dependent inverses of the hierarchy are kept across trials; after rejected steps lambda grows
             // geometrically and inverses taken at a much smaller lambda stop being a preconditioner at all
@@ -1030,6 +1125,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
                         h->h_scal.p->scal[0], h->h_scal.p->scal[1], h->last_residual_ratio, (int)conv, current_chi);
             if (!conv) { S.pcg_not_converged++; rc = UZL_ERR_NOT_CONVERGED; }
             S.lm_trials++;
+            if (red) { Timed t(h, "schur_backsub"); k_schur_backsub(D, Dp, SD, s); }   // dx of the eliminated vertices from the separators'
             int go, gc;
             { Timed t(h, "oplus"); go = k_oplus(D, h->cur, h->trial, s); }        // push + update
             { Timed t(h, "chi2"); gc = k_chi2(D, h->trial, delta, s); }           // computeActiveErrors
@@ -1115,6 +1211,7 @@ void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg)
     // count (measured deviation scales linearly with this value)
     cfg->pcg_tol = 1e-5;
     cfg->pcg_max_iter = 0;              // 0 = 6 * free vertices (system dimension)
+    cfg->schur_reduce = 0;              // 0 = Schur-eliminate chain interiors when a third of the free vertices are (pgo_schur.hpp); -1 = never
     cfg->huber_delta = 1.0;             // g2o_optimizer.cpp:293
     cfg->verbose = 0;
     cfg->preconditioner = 1;            // additive multilevel (rigid-body-mode aggregation); 0 = block-Jacobi
@@ -1173,7 +1270,7 @@ int uzl_pgo_set_config(uzl_pgo* h, const uzl_pgo_cfg* cfg)
     if (cfg->device != h->cfg.device) return fail(h, UZL_ERR_BAD_ARG, "device cannot change after create");
     if (cfg->iterations < 1 || cfg->pcg_tol <= 0. || cfg->huber_delta <= 0.) return fail(h, UZL_ERR_BAD_ARG, "bad config value");
     if (cfg->pcg_tol != h->cfg.pcg_tol) destroy_pcg_graph(h);      // the tolerance is a captured kernel argument
-    if (cfg->preconditioner != h->cfg.preconditioner) h->structure_ready = false;
+    if (cfg->preconditioner != h->cfg.preconditioner || cfg->schur_reduce != h->cfg.schur_reduce) h->structure_ready = false;
     h->cfg = *cfg;
     return UZL_OK;
 }
@@ -1503,7 +1600,7 @@ bool batch_eligible(const uzl_pgo_batch* b)
 {
     const uzl_pgo* a = b->h[0];
     for (const uzl_pgo* h : b->h) {
-        if (!(h->ml_levels > 0 && h->ml_agg == 1 && h->ml_comp && h->ml_mult && h->ml_cl == 1 && !h->sharded && h->nb > 0 && h->e > 0 &&
+        if (!(h->ml_levels > 0 && h->ml_agg == 1 && h->ml_comp && h->ml_mult && h->ml_cl == 1 && !h->sharded && !h->red.on && h->nb > 0 && h->e > 0 &&
               !h->timer.on && h->stream2 != nullptr)) return false;
         // same shape from level 1 up (the level-0 size may differ by the few vertices the gauge / skip rules remove: only grids depend on it)
         if (h->ml_n.size() != a->ml_n.size() || !std::equal(h->ml_n.begin() + 1, h->ml_n.end(), a->ml_n.begin() + 1) ||
