@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kBlk) void pcg_init_kernel(PgoDev D, double* __rest
 #pragma unroll
             for (int c = 0; c < 6; c++) zz += m[c] * sv[g0 + c];
             const size_t i = (size_t)a * 6 + r;
-            D.x[i] = 0.; D.r[i] = rv; D.z[i] = zz; p0[i] = 0.; p1[i] = 0.;
+            D.x[i] = 0.; D.xs[i] = 0.; D.r[i] = rv; D.z[i] = zz; p0[i] = 0.; p1[i] = 0.;
             acc += rv * zz;
         }
     }
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(kBlk) void pcg_spmv_kernel(PgoDev D, const double* 
         D.part_a[blockIdx.x] = tot;
         if (blockIdx.x == 0) {
             D.scal[0] = rz;
-            if (it == 0) D.scal[1] = thresh;
+            if (it == 0) { D.scal[1] = thresh; D.scal[11] = rz; }
             if (!(rz > thresh) ) D.flags[0] = 1;       // converged (or rz == 0 / NaN): x from the last update is final
             if (!(rz >= 0.)) D.flags[2] = 1;           // negative / NaN r.M^-1 r: breakdown
         }
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(kBlk) void set_lambda_batch_kernel(const BatchSlot*
     const int g = blockIdx.x * kBlk + threadIdx.x;
     if (g >= nbatch) return;
     const BatchDyn dy = dyn[g];
-    if (dy.mask & kPhLambda) { slots[g].D.scal[3] = dy.lambda; slots[g].D.scal[8] = dy.tol_factor2; }
+    if (dy.mask & kPhLambda) { slots[g].D.scal[3] = dy.lambda; slots[g].D.scal[8] = dy.tol_factor2; slots[g].D.scal[12] = dy.eps_t; slots[g].D.scal[13] = dy.eps_r; }
     if ((dy.mask & (kPhNumeric | kPhTrialBuild)) && dy.build_scal2) slots[g].scal2[3] = dy.lambda_build;
 }
 // every graph's scal[0..8) / flags[0..4) into the pinned array, then one sequence word
@@ -782,6 +782,66 @@ __global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ 
 }
 __global__ void set_scalar_kernel(double* __restrict__ dst, double v) { *dst = v; }
 __global__ void set_scalar2_kernel(double* __restrict__ dst_a, double va, double* __restrict__ dst_b, double vb) { *dst_a = va; *dst_b = vb; }
+// lambda, the floor factor on pcg_tol^2 and the step accuracy of this trial's solve
+__global__ void set_trial_kernel(double* __restrict__ scal, double lambda, double tol_f2, double eps_t, double eps_r)
+{
+    scal[3] = lambda; scal[8] = tol_f2; scal[12] = eps_t; scal[13] = eps_r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// When to stop the PCG: an a-posteriori estimate of the error left in the LM step, in the units of the parity bar.
+// Every kGraphPairs * 2 iterations (one graph replay) one workgroup looks at how far x moved since its last look,
+//     s = x_k - x_{k-d},   e_k = x* - x_k = sum_{j >= k} alpha_j p_j,   so   e_{k-d} = s + e_k ;
+// with the error contracting by q per window (q^2 = ratio of r.M^-1 r over the window, the energy norm of the error when M ~ A),
+// |e_k| ~ q / (1 - q) |s|.  The solve stops when kProgressSafety times that estimate - largest translation component [m] and largest
+// rotation (quaternion vector, ~ half-angle) component over all vertices - is below what the host asks for (scal[12], scal[13]:
+// a fraction of BASELINE's 1e-3 m / 1e-4 rad spread over the LM iterations), and the recurrence residual has come down
+// (|r|^2 <= kProgressResidual |b|^2: a preconditioner that is not SPD does not get past that).  A step of 1e-7 m is accepted after
+// the first look; a step of metres is iterated until 1e-6 of it is settled.  The relative test on r.M^-1 r stays as a floor.
+// ------------------------------------------------------------------------------------------------
+constexpr double kProgressSafety = 2., kProgressQMax = 0.95, kProgressResidual = 0.25;
+__device__ __forceinline__ void pcg_progress_kernel_body(PgoDev D)
+{
+    __shared__ double st[16], sr[16], srr[16], sbb[16];
+    if (D.flags[0]) return;
+    const int n = D.nb * 6;
+    double mt = 0., mr = 0., rr = 0., bb = 0.;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double x = D.x[i], d = fabs(x - D.xs[i]), r = D.r[i], b = D.b[i];
+        D.xs[i] = x;
+        if (i % 6 < 3) mt = fmax(mt, d); else mr = fmax(mr, d);
+        rr += r * r; bb += b * b;
+    }
+    for (int o = 32; o; o >>= 1) { mt = fmax(mt, __shfl_xor(mt, o)); mr = fmax(mr, __shfl_xor(mr, o)); rr += __shfl_xor(rr, o); bb += __shfl_xor(bb, o); }
+    if ((threadIdx.x & 63) == 0) { st[threadIdx.x >> 6] = mt; sr[threadIdx.x >> 6] = mr; srr[threadIdx.x >> 6] = rr; sbb[threadIdx.x >> 6] = bb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mt = 0.; mr = 0.; rr = 0.; bb = 0.;
+        for (int w = 0; w < 16; w++) { mt = fmax(mt, st[w]); mr = fmax(mr, sr[w]); rr += srr[w]; bb += sbb[w]; }
+        const double rz = D.scal[0], rz_prev = D.scal[11];
+        double q = (rz_prev > 0. && rz >= 0.) ? sqrt(rz / rz_prev) : kProgressQMax;
+        q = fmin(q, kProgressQMax);
+        const double gain = kProgressSafety * q / (1. - q);
+        const double et = gain * mt, er = gain * mr;
+        D.scal[11] = rz; D.scal[14] = et; D.scal[15] = er;
+        if (et <= D.scal[12] && er <= D.scal[13] && rr <= kProgressResidual * bb && rz >= 0.) D.flags[0] = 1;
+    }
+}
+__global__ __launch_bounds__(1024) void pcg_progress_kernel(PgoDev D)
+{
+    pcg_progress_kernel_body(D);
+}
+void k_pcg_progress(const PgoDev& D, hipStream_t s) { hipLaunchKernelGGL(pcg_progress_kernel, dim3(1), dim3(1024), 0, s, D); }
+__global__ __launch_bounds__(1024) void pcg_progress_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
+{
+    const BatchSlot& S = slots[blockIdx.z];
+    if (!(dyn[blockIdx.z].mask & kPhSolve)) return;
+    pcg_progress_kernel_body(S.D);
+}
+void kb_pcg_progress(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s)
+{
+    hipLaunchKernelGGL(pcg_progress_batch_kernel, dim3(1, 1, nb_), dim3(1024), 0, s, sl, dy);
+}
 
 // After PCG has set `done`: scal[7] = |r|^2 / |b|^2 with the recurrence residual r (= b - (H + lambda) x up to rounding for ANY
 // step lengths and directions, so it is the true residual even when the preconditioner misbehaved).  The host refuses a
@@ -819,6 +879,10 @@ void k_set_scalar(double* dst, double v, hipStream_t s)
 void k_set_scalar2(double* dst_a, double va, double* dst_b, double vb, hipStream_t s)
 {
     hipLaunchKernelGGL(set_scalar2_kernel, dim3(1), dim3(1), 0, s, dst_a, va, dst_b, vb);
+}
+void k_set_trial(double* scal, double lambda, double tol_f2, double eps_t, double eps_r, hipStream_t s)
+{
+    hipLaunchKernelGGL(set_trial_kernel, dim3(1), dim3(1), 0, s, scal, lambda, tol_f2, eps_t, eps_r);
 }
 void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s)
 {

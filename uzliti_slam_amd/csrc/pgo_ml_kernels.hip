@@ -1033,7 +1033,7 @@ __device__ __forceinline__ void ml_init_kernel_body(PgoDev D, MlHot H, double* _
     if (act) {
         const size_t i = (size_t)a * 6 + r;
         rv = D.b[i];
-        D.r[i] = rv; D.x[i] = 0.; p0[i] = 0.; p1[i] = 0.;
+        D.r[i] = rv; D.x[i] = 0.; D.xs[i] = 0.; p0[i] = 0.; p1[i] = 0.;
         const double* __restrict__ gg = H.geo0 + (size_t)a * 12;
 #pragma unroll
         for (int c = 0; c < 12; c++) geo[c] = gg[c];
@@ -1352,7 +1352,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         D.part_a[blockIdx.x] = dtot;
         if (blockIdx.x == 0) {
             D.scal[0] = rz;
-            if (it == 0) D.scal[1] = thresh;
+            if (it == 0) { D.scal[1] = thresh; D.scal[11] = rz; }
             if (!(rz > thresh)) D.flags[0] = 1;
             if (!(rz >= 0.)) D.flags[2] = 1;      // r.M^-1 r < 0 (or NaN): M^-1 is not positive definite - breakdown, not convergence
         }

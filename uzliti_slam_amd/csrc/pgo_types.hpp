@@ -45,6 +45,7 @@ struct PgoDev {
     double* minv;            // [nb][36]  (H_aa + lambda I)^-1   (block-Jacobi path only; the multilevel path uses MlLevel::Winv)
     double* b;               // [nb][6]
     double* x;               // PCG vectors [nb][6]
+    double* xs;              // x as it was at the last progress check (pcg_progress_kernel)
     double* r;
     double* z;
     double* p;
@@ -54,7 +55,9 @@ struct PgoDev {
     double* part_c;          // [kMaxPartials] block partials (max |H_jj|)
     double* scal;            // [16]: 0 rz, 1 rz threshold, 2 rz_prev, 3 lambda, 4 chi2, 5 scale, 6 diagmax, 7 |r|^2 / |b|^2 after PCG,
                              //       8 factor on pcg_tol^2 for this LM iteration's solves (host: do_optimize), 9 alpha and 10 breakdown of the current PCG
-                             //       iteration (ml_alpha_kernel -> ml_cg_kernel); 0..7 go back to the host
+                             //       iteration (ml_alpha_kernel -> ml_cg_kernel); 11 r.z at the last progress check (first: of r_0), 12 / 13 the
+                             //       step accuracy asked for [m] / [rad], 14 / 15 the last estimate of the step's error (pcg_progress_kernel);
+                             //       0..7 go back to the host
     int32_t* flags;          // [4]: 0 done, 1 iterations, 2 breakdown
 };
 
@@ -165,6 +168,7 @@ struct BatchDyn {                              // host -> device once per round
     int32_t build_scal2;                       // 1: those kernels read lambda from scal2
     int32_t pad;
     double  tol_factor2;                       // kPhLambda: factor on pcg_tol^2 of this round's solve (-> D.scal[8])
+    double  eps_t, eps_r;                      // kPhLambda: step accuracy asked of this round's solve (-> D.scal[12], D.scal[13])
 };
 
 // scalars handed back to the host after each LM trial / PCG chunk.  The struct lives in pinned, host-coherent memory
