@@ -63,6 +63,7 @@ def parse():
                     help="skip `sharded_c4` (N > 1: ONE 10000-node/50000-edge graph sharded over all ranks, BASELINE config 4, native RCCL "
                          "all-reduce per PCG iteration) and `c4_1gpu.sharded_world1` (N = 1: the same path with a one-rank communicator)")
     ap.add_argument("--sharded-world1-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--online-cpu-seconds", type=float, default=25.0, help="budget of the CPU replay of config 5 (online_c5.cpu_baseline)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-baseline sample of the primary / secondary block")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 code paths on a box with fewer GPUs than ranks: process group over gloo, rank r on device "
@@ -634,6 +635,7 @@ def main():
         from uzliti_slam_amd import online
         run = synth.make_online_run(a.online_nodes, a.online_pairs, n_kp=a.keypoints)
         o = online.OnlineSlam(run, device=dev, rank=dist.rank, world=dist.world, tdist=dist.dist, match_batch=512)
+        o.keep_poses_per_solve = 40                    # the CPU replay (cpu_baseline below) is compared with the poses at its last interval
         o.upload_frames()
         dist.barrier(); t0 = time.perf_counter()
         o.run_all()
@@ -648,12 +650,54 @@ def main():
                              add_graph_ms_per_solve=round(s["add_graph_ms_per_solve"], 3), structure_ms_per_solve=round(s["structure_ms_per_solve"], 3),
                              optimize_ms_per_solve=round(s["optimize_ms_per_solve"], 3), seconds=s["seconds"], feature_edges_accepted=s["feature_edges_accepted"],
                              feature_edges_valid=s["feature_edges_valid"], pcg_iterations=s["pcg_iterations"], lm_iterations=s["lm_iterations"],
+                             vertices_schur_eliminated_last_solve=o.solves[-1].get("n_eliminated", 0) if o.solves else 0,
                              not_converged=s["not_converged"],
                              ate_dead_reckoning_m=round(float(np.linalg.norm(run["init"][:, :, 3] - gt[:, :, 3], axis=1).mean()), 3),
                              ate_online_m=round(float(np.linalg.norm(o.poses[:, :, 3] - gt[:, :, 3], axis=1).mean()), 3),
                              parallelism="pair jobs sharded over %d rank(s) per batch of 512, results gathered in job order; gate, filter and solver on rank 0, "
                                          "the next batch's matching in flight during the solve" % dist.world,
-                             note="rebuild per re-optimise = add_graph (upload + flattening) + structure (gauge, block-CSR, hierarchy, graph capture)")
+                             note="rebuild per re-optimise = add_graph (upload + flattening) + structure (gauge, block-CSR, Schur plan, hierarchy, graph capture)")
+            # ---- roofline of the kernel this config adds: the Schur elimination of the chain interiors (HBM-bound by construction:
+            #      per eliminated vertex it reads 3 blocks of 288 B + b, writes u | W | T = 624 B; a run is a chain of <= 24 dependent steps)
+            pl = capi.Pgo(device=dev, iterations=a.lm_iters)
+            pl.add_graph(*o.last_input)
+            pl.optimize(a.lm_iters)
+            pl.set_profiling(True); pl.add_graph(*o.last_input); stl = pl.optimize(a.lm_iters); ktl = pl.kernel_times(); pl.close()
+            el = ktl.get("schur_eliminate")
+            if el and el["ms"] > 0 and stl["n_eliminated"] > 0:
+                alg_e = float(stl["n_eliminated"]) * (3 * 288.0 + 48.0 + 624.0)
+                online_c5["roofline"] = roof("schur_eliminate_kernel", "hbm", alg_e * el["launches"] / (el["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", traffic=None,
+                                             algorithmic_bytes_per_launch=alg_e, avg_launch_us=round(1e3 * el["ms"] / el["launches"], 3), launches=el["launches"],
+                                             vertices_eliminated=stl["n_eliminated"],
+                                             note="last re-optimisation of the run (%d vertices, %d edges): one wave per run of <= 24 chain interiors, a chain of dependent 6x6 "
+                                                  "inversions and products - latency-bound, not bandwidth-bound, at this size" % (stl["n_vertices"], stl["n_edges"]))
+                online_c5["last_solve_kernels_ms"] = {k: round(v["ms"], 4) for k, v in sorted(ktl.items(), key=lambda x: -x[1]["ms"])[:8]}
+            # ---- the CPU path on the same run: tests/online_stubs.py drives the SAME schedule through the CPU checker's estimator, gate,
+            #      filter and solver (one thread, as the reference's plugins run).  Budget-capped; compared on the common prefix of intervals.
+            if dist.world == 1 and not a.no_cpu_baseline:
+                import oracle as O
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from online_stubs import oracle_online
+                c = oracle_online(O, run, ransac_iteration=500, match_batch=512)
+                c.upload_frames()
+                t0 = time.perf_counter()
+                while time.perf_counter() - t0 < a.online_cpu_seconds and c.step():
+                    pass
+                k = len(c.solves)
+                if k >= 1 and len(o.solves) >= k:
+                    cpu_s = c.solves[k - 1]["wall_s"]; gpu_s = o.solves[k - 1]["wall_s"]
+                    same = bool(c.solves[k - 1]["n_nodes"] == o.solves[k - 1]["n_nodes"] and c.solves[k - 1]["n_edges"] == o.solves[k - 1]["n_edges"])
+                    dtc, drc = synth.pose_errors(o.poses_at_solve[k - 1], c.poses[:c.solves[k - 1]["n_nodes"]]) if same and len(o.poses_at_solve) >= k else (None, None)
+                    online_c5["cpu_baseline"] = dict(
+                        kind="port", cores=1, unit="s", value=round(cpu_s, 3),
+                        sample="the first %d of %d re-optimisation intervals of the same run (graph grown to %d nodes), %.1f s budget; oracle = CPU checker's estimator "
+                               "(-O3, portable build), gate, filter and LM + sparse Cholesky, one thread" % (k, len(o.solves), c.solves[k - 1]["n_nodes"], a.online_cpu_seconds),
+                        gpu_same_prefix_s=round(gpu_s, 3), speedup_on_prefix=round(cpu_s / max(gpu_s, 1e-9), 1), same_graph_at_that_point=same,
+                        pose_difference_at_that_point=dict(dt_m=dtc, dr_rad=drc),
+                        extrapolated_full_run_s=round(cpu_s * len(o.solves) / k, 1),
+                        extrapolation="linear in the number of intervals: a LOWER bound (later intervals hold larger graphs and cost more)",
+                        nproc=effective_cpus(), cpu=cpu_model())
+                c.close()
         o.close()
 
     # ------------------------------------------------------------------ optional: config 4, one graph sharded over the ranks

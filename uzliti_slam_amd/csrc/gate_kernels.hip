@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cstdint>
+#include <mutex>
 #include "gate_types.hpp"
 
 namespace uzl {
@@ -217,9 +218,10 @@ __global__ __launch_bounds__(64) void gate_wave_kernel(GateWaveArgs a)
         if (vs.st == 1) n_open--;
         if (lane == 0) gst[v].st = 2;
         const double gv = vs.g;
-        for (int base = 0; base < vr.deg; base += 64) {
+        const int vdeg = vr.deg & ~kGateRecMulti;
+        for (int base = 0; base < vdeg; base += 64) {
             const int q = base + lane;
-            const bool has = q < vr.deg;
+            const bool has = q < vdeg;
             int u = -1;
             if (has) {
                 if (q < kGateRecNbr) {                     // select chain: a run-time index into a register array would go through scratch
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(64) void gate_wave_kernel(GateWaveArgs a)
             // a neighbour listed twice (multi-edge): only its first occurrence acts, as in the sequential loop (the second sees
             // the state and g-score the first one wrote and changes nothing)
             bool first = has;
-            for (int j = 0; j < 64 && base + j < vr.deg; j++) {
+            for (int j = 0; j < 64 && base + j < vdeg; j++) {
                 const int uj = __shfl(u, j);
                 if (j < lane && uj == u) first = false;
             }
@@ -288,6 +290,276 @@ __global__ __launch_bounds__(64) void gate_wave_kernel(GateWaveArgs a)
         ok = (2 * a.ssf * dist + 1.0 > dn) && (10 * a.ssf * dist + 30.0 > drot);     // :1074-1075
     }
     a.heur_ok[k] = ok ? 1 : 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same search once more, built around what a step costs on this machine.  The CPU checker expands a node in ~40 ns (cache-resident
+// pointer chasing); gate_wave_kernel needs 2 us - two dependent HBM round trips, three workgroup barriers, a six-level shuffle tree
+// (ds_bpermute) per pop - and the longest search of a call (10^4 expansions between two nodes far apart on the chain) sets the time of
+// the call.  Measured on config 5 the open list never holds more than ~80 entries.  So here:
+//   * the open list lives in REGISTERS, kGateRegSlots entries per lane (h, node, g); pop = lane-local minimum, then a wave minimum of
+//     the 64-bit key through two DPP reductions on its halves (row rotations and broadcasts, no LDS crossbar), winner by ballot;
+//     entries of one node have identical keys (h, node), so the pop takes the one with the smallest g, which IS gs[node] of the
+//     sequential code (a node is pushed again only with a smaller g);
+//   * closed / open flags are two bitmaps of n bits in LDS; the g of a closed node (needed only when one of its stale entries is
+//     popped later - the reference re-expands it) goes to HBM at close and comes back on that rare path;
+//   * node records come through a direct-mapped LDS cache of 64 blocks of 8 consecutive records: ids are time-ordered, so the
+//     neighbours along the chain arrive with the block;
+//   * a step is two LDS round trips (everything addressed by the popped node, then everything addressed by its neighbours), no
+//     barrier: one wave's LDS traffic is processed in order.
+// A search whose list outgrows the registers is redone by gate_kernel.  Same arithmetic, same pop order (a priority queue's pop order
+// depends only on the multiset of its keys): distances and verdicts are bit-identical to gate_kernel / the CPU checker.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+// minimum over the wave, the same value in every lane (rocPRIM's gfx9 pattern: quad swaps, row rotations, row broadcasts; lane 63 ends with it)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    unsigned t;
+    t = dpp_u32<0xb1>(v); v = t < v ? t : v;                 // quad_perm [1,0,3,2]
+    t = dpp_u32<0x4e>(v); v = t < v ? t : v;                 // quad_perm [2,3,0,1]
+    t = dpp_u32<0x124>(v); v = t < v ? t : v;                // row_ror:4
+    t = dpp_u32<0x128>(v); v = t < v ? t : v;                // row_ror:8
+    t = dpp_u32<0x142>(v); v = t < v ? t : v;                // row_bcast:15
+    t = dpp_u32<0x143>(v); v = t < v ? t : v;                // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// minimum of non-negative doubles (their bit patterns order like unsigned integers); `mine` = this lane holds it
+__device__ __forceinline__ double wave_min_pos_f64(double x, bool& mine)
+{
+    const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+    const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+    const unsigned mhi = wave_min_u32(hi);
+    const unsigned mlo = wave_min_u32(hi == mhi ? lo : 0xffffffffu);
+    mine = hi == mhi && lo == mlo;
+    return __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
+}
+__device__ __forceinline__ double readlane_f64(double x, int src)
+{
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// kGateRegSlots = open-list entries per lane (2: 128 per search, the cheaper pop; 4: 256)
+template <int kGateRegSlots>
+__global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
+{
+    extern __shared__ unsigned char gsm[];
+    unsigned long long* __restrict__ cache = reinterpret_cast<unsigned long long*>(gsm);      // [64 blocks][8 records][8 qwords]
+    int32_t* __restrict__ tag = reinterpret_cast<int32_t*>(cache + kGateCacheBlocks * 64);
+    unsigned* __restrict__ closed = reinterpret_cast<unsigned*>(tag + kGateCacheBlocks);
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k >= a.n_query) return;
+    if (!a.run[k] && a.keep_unrun) return;
+    if (lane == 0) { a.pre_ok[k] = 0; a.heur_ok[k] = 0; a.dist[k] = -1.; a.redo[k] = 0; }
+    if (!a.run[k]) return;
+    const uzl_gate_edge c = a.cand[k];
+    if (!(c.matching_score >= a.min_score)) return;                                  // :798
+    const double* T = c.transform;
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    const double diff_rot = fabs(angle_of(R)) * 180 / M_PI;                           // :800-801
+    const double tn = sqrt((T[3] * T[3] + T[7] * T[7]) + T[11] * T[11]);
+    if (!(tn <= a.max_T && diff_rot <= a.max_R)) return;                             // :803
+    if (lane == 0) a.pre_ok[k] = 1;
+
+    const int source = c.from, target = c.to, n = a.n, nwords = (n + 31) / 32;
+    unsigned* __restrict__ opened = closed + nwords;
+    double* __restrict__ gclosed = a.gclosed + (size_t)k * n;
+    for (int i = lane; i < 2 * nwords; i += 64) closed[i] = 0u;
+    if (lane < kGateCacheBlocks) tag[lane] = -1;
+    __syncthreads();
+    // brings the block of 8 records that holds node `u` into the cache (uniform call)
+    auto fetch_block = [&](int u) {
+        const int blk = u >> 3, slot = blk & (kGateCacheBlocks - 1);
+        cache[slot * 64 + lane] = reinterpret_cast<const unsigned long long*>(a.rec)[(size_t)blk * 64 + lane];
+        if (lane == 0) tag[slot] = blk;
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto rec_of = [&](int u) { return reinterpret_cast<const GateNodeRec*>(cache + ((u >> 3) & (kGateCacheBlocks - 1)) * 64 + (u & 7) * 8); };
+    auto tag_ok = [&](int u) { return tag[(u >> 3) & (kGateCacheBlocks - 1)] == (u >> 3); };
+    fetch_block(target);
+    const double tx = rec_of(target)->px, ty = rec_of(target)->py, tz = rec_of(target)->pz;
+    fetch_block(source);
+    const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+    double lw[kGateRegSlots], lg[kGateRegSlots]; int lv[kGateRegSlots];
+#pragma unroll
+    for (int j = 0; j < kGateRegSlots; j++) { lw[j] = kInf; lg[j] = 0.; lv[j] = -1; }
+    int n_list = 1, n_open = 1;
+    {
+        const GateNodeRec* sr = rec_of(source);
+        const double h0 = rec_dist(sr->px, sr->py, sr->pz, tx, ty, tz);
+        if (lane == 0) { lw[0] = h0; lv[0] = source; lg[0] = 0.; opened[source >> 5] |= 1u << (source & 31); }
+    }
+    bool success = false, over = false;
+    double g_target = 0.;
+    long long dbg_steps = 0, dbg_max = 0;
+    const long long dbg_c0 = a.dbg ? clock64() : 0, dbg_w0 = a.dbg ? wall_clock64() : 0;
+    while (n_open > 0 && n_list > 0) {
+        if (a.dbg) { dbg_steps++; dbg_max = n_list > dbg_max ? n_list : dbg_max; }
+        // ---- pop: lane-local minimum over (h, node, g), then the wave's
+        double bw = lw[0], bg = lg[0]; int bv = lv[0], bk = 0;
+#pragma unroll
+        for (int j = 1; j < kGateRegSlots; j++)
+            if (lw[j] < bw || (lw[j] == bw && (lv[j] < bv || (lv[j] == bv && lg[j] < bg)))) { bw = lw[j]; bv = lv[j]; bg = lg[j]; bk = j; }
+        bool mine;
+        wave_min_pos_f64(bw, mine);
+        unsigned long long tie = __ballot(mine);
+        if (__popcll(tie) != 1) {                          // equal h in several lanes (duplicates of a node, or equal distances): node id, then g
+            int mv = mine ? bv : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(mv, o); mv = t < mv ? t : mv; }
+            mine = mine && bv == mv;
+            bool gm;
+            wave_min_pos_f64(mine ? bg : kInf, gm);
+            tie = __ballot(mine && gm);
+        }
+        const int src = __ffsll((long long)tie) - 1;
+        const int v = __builtin_amdgcn_readlane(bv, src);
+        const double gpop = readlane_f64(bg, src);
+        if (v == target) { success = true; g_target = gpop; break; }
+        if (lane == src) {
+#pragma unroll
+            for (int j = 0; j < kGateRegSlots; j++) if (j == bk) lw[j] = kInf;
+        }
+        n_list--;
+        // ---- everything addressed by v: one LDS round trip
+        const GateNodeRec* vrp = rec_of(v);
+        bool have = tag_ok(v);
+        const unsigned cw = closed[v >> 5];
+        if (!have) fetch_block(v);
+        const double vx = vrp->px, vy = vrp->py, vz = vrp->pz;
+        const int degf = vrp->deg, adj = vrp->adj;
+        const int deg = degf & ~kGateRecMulti;
+        const bool multi = (degf & kGateRecMulti) != 0;      // some neighbour is listed twice (multi-edge): host-side flag
+        int u = -1;
+        if (lane < deg) u = lane < kGateRecNbr ? vrp->nbr[lane & (kGateRecNbr - 1)] : a.adj_nbr[adj + lane];
+        const bool was_closed = (cw >> (v & 31)) & 1u;
+        double gv = gpop;
+        if (was_closed) {                                  // a stale entry of a node closed earlier: the reference expands it again with its final g
+            gv = readlane_f64(lane == 0 ? gclosed[v] : 0., 0);          // (lane 0 wrote it: a thread reads its own stores)
+        } else {
+            n_open--;
+            if (lane == 0) { closed[v >> 5] = cw | (1u << (v & 31)); opened[v >> 5] &= ~(1u << (v & 31)); gclosed[v] = gv; }
+        }
+        for (int base = 0; base < deg; base += 64) {
+            if (base > 0) { const int q = base + lane; u = q < deg ? a.adj_nbr[adj + q] : -1; }
+            const bool has = u >= 0;
+            // a neighbour listed twice (multi-edge): only its first occurrence acts, as in the sequential loop
+            bool first = has;
+            if (multi) {
+                const int lim = deg - base < 64 ? deg - base : 64;
+                for (int j = 0; j < lim; j++) { const int uj = __shfl(u, j); if (j < lane && uj == u) first = false; }
+            }
+            // ---- everything addressed by u: one LDS round trip (closed / open words, tag, position)
+            const int us = has ? u : 0;
+            const unsigned cu = closed[us >> 5], ou = opened[us >> 5];
+            bool got = tag_ok(us);
+            const GateNodeRec* urp = rec_of(us);
+            double ux = urp->px, uy = urp->py, uz = urp->pz;
+            const bool act = first && u != v && !((cu >> (us & 31)) & 1u);
+            got = got || !act;
+            while (true) {                                 // blocks not in the cache: loaded one by one (a lane keeps what it read)
+                const unsigned long long miss = __ballot(!got);
+                if (!miss) break;
+                const int um = __builtin_amdgcn_readlane(us, __ffsll((long long)miss) - 1);
+                fetch_block(um);
+                if (!got && (us >> 3) == (um >> 3)) { ux = urp->px; uy = urp->py; uz = urp->pz; got = true; }
+            }
+            const bool is_open = act && ((ou >> (us & 31)) & 1u);
+            // an open neighbour is pushed again only with a smaller g: its current g = the smallest g among its entries
+            double gu = kInf;
+            unsigned long long need = __ballot(is_open);
+            while (need) {
+                const int s0 = __ffsll((long long)need) - 1;
+                need &= need - 1;
+                const int u0 = __builtin_amdgcn_readlane(us, s0);
+                double m = kInf;
+#pragma unroll
+                for (int j = 0; j < kGateRegSlots; j++) if (lv[j] == u0 && lw[j] < kInf && lg[j] < m) m = lg[j];
+                bool dummy;
+                m = wave_min_pos_f64(m, dummy);
+                if (lane == s0) gu = m;
+            }
+            double tent = 0., hw = 0.;
+            bool push = false;
+            if (act) {
+                tent = gv + rec_dist(vx, vy, vz, ux, uy, uz);
+                if (!is_open || tent < gu) { push = true; hw = rec_dist(ux, uy, uz, tx, ty, tz); }
+            }
+            if (push) atomicOr(&opened[us >> 5], 1u << (us & 31));
+            n_open += __popcll(__ballot(push && !is_open));
+            // ---- pushes: one by one into the first lane with a free slot
+            unsigned long long pm = __ballot(push);
+            while (pm) {
+                const int s0 = __ffsll((long long)pm) - 1;
+                pm &= pm - 1;
+                const double pw = readlane_f64(hw, s0), pg = readlane_f64(tent, s0);
+                const int pu = __builtin_amdgcn_readlane(us, s0);
+                bool fr = false;
+#pragma unroll
+                for (int j = 0; j < kGateRegSlots; j++) fr = fr || !(lw[j] < kInf);
+                const unsigned long long fm = __ballot(fr);
+                if (!fm) { over = true; break; }
+                if (lane == __ffsll((long long)fm) - 1) {
+                    bool done = false;
+#pragma unroll
+                    for (int j = 0; j < kGateRegSlots; j++) if (!done && !(lw[j] < kInf)) { lw[j] = pw; lv[j] = pu; lg[j] = pg; done = true; }
+                }
+                n_list++;
+            }
+            if (over) break;
+        }
+        if (over) break;
+    }
+    if (a.dbg && lane == 0) { a.dbg[4 * k] = dbg_steps; a.dbg[4 * k + 1] = clock64() - dbg_c0; a.dbg[4 * k + 2] = wall_clock64() - dbg_w0; a.dbg[4 * k + 3] = dbg_max; }
+    if (over) { if (lane == 0) a.redo[k] = 1; return; }
+    if (lane != 0) return;
+    const double dist = success ? g_target : DBL_MAX;
+    a.dist[k] = dist;
+    // ---- checkEdgeHeuristic (:1064-1085)
+    bool ok = true;
+    if (dist != DBL_MAX) {
+        const double* A = a.poses + 12 * (size_t)source;
+        const double* B = a.poses + 12 * (size_t)target;
+        double Rd[9], ti[3], td[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) Rd[r * 3 + cc] = (A[0 * 4 + r] * B[0 * 4 + cc] + A[1 * 4 + r] * B[1 * 4 + cc]) + A[2 * 4 + r] * B[2 * 4 + cc];
+            ti[r] = -((A[0 * 4 + r] * A[3] + A[1 * 4 + r] * A[7]) + A[2 * 4 + r] * A[11]);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) td[r] = ((A[0 * 4 + r] * B[3] + A[1 * 4 + r] * B[7]) + A[2 * 4 + r] * B[11]) + ti[r];
+        const double dn = sqrt((td[0] * td[0] + td[1] * td[1]) + td[2] * td[2]);
+        const double drot = 180. * angle_of(Rd) / M_PI;
+        ok = (2 * a.ssf * dist + 1.0 > dn) && (10 * a.ssf * dist + 30.0 > drot);     // :1074-1075
+    }
+    a.heur_ok[k] = ok ? 1 : 0;
+}
+
+// false: the graph is too large for the LDS bitmaps (the caller uses gate_wave_kernel)
+bool launch_gate_reg(const GateWaveArgs& a, int slots, hipStream_t s)
+{
+    if (a.n_query <= 0) return true;
+    const int bytes = gate_lds_bytes(a.n);
+    if (bytes > kGateLdsMax) return false;
+    static int configured = 0;                             // process-wide: the kernels are symbols of the code object
+    static std::mutex mu;
+    if (bytes > 48 * 1024) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gate_reg_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kGateLdsMax) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gate_reg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kGateLdsMax) != hipSuccess) return false;
+            configured = 1;
+        }
+    }
+    if (slots <= 2) hipLaunchKernelGGL(gate_reg_kernel<2>, dim3(a.n_query), dim3(64), bytes, s, a);
+    else hipLaunchKernelGGL(gate_reg_kernel<4>, dim3(a.n_query), dim3(64), bytes, s, a);
+    return true;
 }
 
 void launch_gate_wave(const GateWaveArgs& a, hipStream_t s)

@@ -41,8 +41,15 @@ struct GateNodeRec {
     int32_t nbr[8];                 // the first neighbours, in adjacency order
 };
 constexpr int kGateRecNbr = 8;
+constexpr int kGateRecMulti = 1 << 30;   // GateNodeRec::deg flag: the neighbour list names some node twice (multi-edge) - the searches dedupe only then
 constexpr int kGateOpenCap = 2048;  // open-list entries held in LDS per candidate; a search that needs more is redone by gate_kernel
 struct GateState { double g; int32_t st; int32_t pad; };     // per (candidate, node): g-score and 0 none / 1 open / 2 closed
+
+// ---- the same search with the open list in registers and the per-node state in LDS (gate_reg_kernel) ----
+constexpr int kGateCacheBlocks = 64;   // direct-mapped record cache: 64 blocks of 8 consecutive nodes (chain order = index order)
+constexpr int kGateLdsFixed = kGateCacheBlocks * 8 * 64 + kGateCacheBlocks * 4;                // cache + tags
+constexpr int kGateLdsMax = 160 * 1024 - 2048;
+inline int gate_lds_bytes(int n) { return kGateLdsFixed + 2 * 4 * ((n + 31) / 32); }        // + closed / open bitmaps (n <= ~500k nodes)
 
 struct GateWaveArgs {
     int32_t n, n_query;
@@ -51,10 +58,13 @@ struct GateWaveArgs {
     const int32_t* adj_nbr;
     const uzl_gate_edge* cand;
     const uint8_t* run;
-    GateState* gst;                 // [n_query][n], zeroed by the host
+    GateState* gst;                 // [n_query][n], zeroed by the host (gate_wave_kernel)
+    double* gclosed;                // [n_query][n] g-score of closed nodes (gate_reg_kernel; written before it is read: not zeroed)
     double min_score, max_T, max_R, ssf;
     uint8_t* pre_ok; uint8_t* heur_ok; double* dist;
     uint8_t* redo;                  // [n_query] 1 = open list overflowed: search this candidate with gate_kernel
+    int32_t keep_unrun;             // 1: leave the outputs of candidates with run == 0 alone (they hold an earlier launch's verdicts)
+    long long* dbg;                 // diagnostic build: [n_query][4] = expansions, shader clocks, 100 MHz ticks, largest open list (else null)
 };
 
 }  // namespace uzl

@@ -18,6 +18,7 @@
 namespace uzl {
 void launch_gate(const GateArgs& a, hipStream_t s);
 void launch_gate_wave(const GateWaveArgs& a, hipStream_t s);
+bool launch_gate_reg(const GateWaveArgs& a, int slots, hipStream_t s);
 }
 using namespace uzl;
 
@@ -34,7 +35,7 @@ struct uzl_gate {
     std::set<std::tuple<int32_t, int32_t, int32_t>> pair_type;      // (min, max, type) of every edge: existsEdge(from, to, type)
     bool adj_dirty = true, poses_dirty = true;
     std::vector<int32_t> adj_ptr, adj_nbr;
-    DevBuf<double> d_poses, d_gs, d_dist;
+    DevBuf<double> d_poses, d_gs, d_dist, d_gclosed;
     DevBuf<int32_t> d_adj_ptr, d_adj_nbr, d_over;
     DevBuf<uzl_gate_edge> d_cand;
     DevBuf<uint8_t> d_run, d_st, d_pre, d_heur;
@@ -43,8 +44,13 @@ struct uzl_gate {
     DevBuf<GateNodeRec> d_rec;
     DevBuf<GateState> d_gst;
     DevBuf<uint8_t> d_redo;
+    DevBuf<long long> d_dbg;         // diagnostic build (UZL_GATE_DBG=1): per-search counters of gate_reg_kernel
+    std::vector<long long> dbg_last;
+    bool dbg_on = false;
+    int reg_slots = 2;               // open-list entries per lane gate_reg_kernel starts with (4 once a search of this handle outgrew 2)
     PinBuf<uint8_t> h_redo;
     bool lane_kernel_only = false;   // A/B (diagnostic build, UZL_GATE_LANE=1): every search through gate_kernel, as in round 1
+    bool wave_kernel_only = false;   // A/B (UZL_GATE_WAVE=1): gate_wave_kernel (list in LDS, per-node state in HBM) instead of gate_reg_kernel
     int64_t n_wave = 0, n_lane = 0;  // searches run by either kernel (uzl_gate_search_counts)
     PinBuf<uint8_t> h_pre, h_heur;
     PinBuf<double> h_dist;
@@ -85,12 +91,17 @@ void build_adjacency(uzl_gate* h)
         if (e.to != e.from) h->adj_nbr[fill[e.to]++] = e.from;
     }
     // node records of the wave-per-candidate search: position, degree, first neighbours in adjacency order
-    h->rec.assign((size_t)std::max(n, 1), GateNodeRec{});
+    h->rec.assign(((size_t)std::max(n, 1) + 7) / 8 * 8, GateNodeRec{});     // whole blocks of 8: gate_lds_kernel's cache loads them as units
     for (int v = 0; v < n; v++) {
         GateNodeRec& r = h->rec[v];
         r.px = h->poses[12 * (size_t)v + 3]; r.py = h->poses[12 * (size_t)v + 7]; r.pz = h->poses[12 * (size_t)v + 11];
         r.deg = h->adj_ptr[v + 1] - h->adj_ptr[v]; r.adj = h->adj_ptr[v];
         for (int j = 0; j < kGateRecNbr; j++) r.nbr[j] = j < r.deg ? h->adj_nbr[h->adj_ptr[v] + j] : -1;
+        {   // multi-edges: flagged, so that a search only looks for repeated neighbours where there are any
+            std::vector<int32_t> nb(h->adj_nbr.begin() + h->adj_ptr[v], h->adj_nbr.begin() + h->adj_ptr[v + 1]);
+            std::sort(nb.begin(), nb.end());
+            if (std::adjacent_find(nb.begin(), nb.end()) != nb.end()) r.deg |= kGateRecMulti;
+        }
     }
     h->adj_dirty = false;
 }
@@ -129,6 +140,8 @@ int uzl_gate_create(const uzl_gate_cfg* cfg, uzl_gate** out)
     if (!h) return UZL_ERR_OOM;
     h->cfg = c;
     h->lane_kernel_only = diag_flag("UZL_GATE_LANE");
+    h->wave_kernel_only = diag_flag("UZL_GATE_WAVE");
+    h->dbg_on = diag_flag("UZL_GATE_DBG");
     if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return UZL_ERR_HIP;
@@ -211,20 +224,51 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
         }
         UZL_HIP(hipMemcpyAsync(h->d_run.p + first, run.data() + first, (size_t)m, hipMemcpyHostToDevice, s));
         // ---- one wave per candidate, open list in LDS
-        h->d_gst.reserve((size_t)m * std::max(n, 1)); h->d_redo.reserve((size_t)nc); h->h_redo.reserve((size_t)nc);
-        UZL_HIP(hipMemsetAsync(h->d_gst.p, 0, sizeof(GateState) * (size_t)m * std::max(n, 1), s));
+        h->d_redo.reserve((size_t)nc); h->h_redo.reserve((size_t)nc);
+        const bool lds_path = !h->wave_kernel_only && gate_lds_bytes(n) <= kGateLdsMax;
+        if (lds_path) h->d_gclosed.reserve((size_t)m * std::max(n, 1));                       // written before it is read: no clearing
+        else {
+            h->d_gst.reserve((size_t)m * std::max(n, 1));
+            UZL_HIP(hipMemsetAsync(h->d_gst.p, 0, sizeof(GateState) * (size_t)m * std::max(n, 1), s));
+        }
         GateWaveArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.n = n; wa.n_query = m; wa.poses = h->d_poses.p; wa.rec = h->d_rec.p; wa.adj_nbr = h->d_adj_nbr.p;
-        wa.cand = h->d_cand.p + first; wa.run = h->d_run.p + first; wa.gst = h->d_gst.p;
+        wa.cand = h->d_cand.p + first; wa.run = h->d_run.p + first; wa.gst = h->d_gst.p; wa.gclosed = h->d_gclosed.p;
         wa.min_score = h->cfg.min_matching_score; wa.max_T = h->cfg.max_edge_distance_T; wa.max_R = h->cfg.max_edge_distance_R;
         wa.ssf = h->cfg.scope_size_factor;
         wa.pre_ok = h->d_pre.p + first; wa.heur_ok = h->d_heur.p + first; wa.dist = h->d_dist.p + first; wa.redo = h->d_redo.p + first;
+        if (h->dbg_on) { h->d_dbg.reserve((size_t)m * 4); UZL_HIP(hipMemsetAsync(h->d_dbg.p, 0, sizeof(long long) * 4 * (size_t)m, s)); wa.dbg = h->d_dbg.p; }
         if (!h->lane_kernel_only) {
-            launch_gate_wave(wa, s);
+            bool reg_ok = lds_path && launch_gate_reg(wa, h->reg_slots, s);
+            if (!reg_ok) {
+                if (lds_path) {                                                                // the attribute could not be raised: the HBM-state kernel
+                    h->d_gst.reserve((size_t)m * std::max(n, 1));
+                    UZL_HIP(hipMemsetAsync(h->d_gst.p, 0, sizeof(GateState) * (size_t)m * std::max(n, 1), s));
+                    wa.gst = h->d_gst.p;
+                }
+                launch_gate_wave(wa, s);
+            }
             UZL_HIP(hipGetLastError());
             UZL_HIP(hipMemcpyAsync(h->h_redo.p + first, h->d_redo.p + first, (size_t)m, hipMemcpyDeviceToHost, s));
             UZL_HIP(hipStreamSynchronize(s));
+            if (h->dbg_on) { h->dbg_last.assign((size_t)m * 4, 0); UZL_HIP(hipMemcpy(h->dbg_last.data(), h->d_dbg.p, sizeof(long long) * 4 * (size_t)m, hipMemcpyDeviceToHost)); }
+            bool overflowed = false;
+            for (int32_t k = first; k < last && !overflowed; k++) overflowed = h->h_redo.p[k] != 0;
+            if (reg_ok && overflowed && h->reg_slots < 4) {
+                // searches whose open list outgrew two entries per lane: once more with four (and later calls start there)
+                h->reg_slots = 4;
+                std::vector<uint8_t> run4((size_t)m);
+                for (int32_t k = 0; k < m; k++) run4[k] = (run[first + k] && h->h_redo.p[first + k]) ? 1 : 0;
+                UZL_HIP(hipMemcpyAsync(h->d_run.p + first, run4.data(), (size_t)m, hipMemcpyHostToDevice, s));
+                wa.keep_unrun = 1;
+                launch_gate_reg(wa, 4, s);
+                UZL_HIP(hipGetLastError());
+                std::vector<uint8_t> redo4((size_t)m);
+                UZL_HIP(hipMemcpyAsync(redo4.data(), h->d_redo.p + first, (size_t)m, hipMemcpyDeviceToHost, s));
+                UZL_HIP(hipStreamSynchronize(s));                                              // (also: run4 is a local)
+                for (int32_t k = 0; k < m; k++) h->h_redo.p[first + k] = run4[k] ? redo4[k] : 0;
+            }
         }
         bool any_redo = h->lane_kernel_only;
         for (int32_t k = first; k < last && !any_redo; k++) any_redo = h->h_redo.p[k] != 0;
@@ -294,6 +338,16 @@ int uzl_debug_gate_counts(uzl_gate* h, int64_t* n_wave, int64_t* n_lane)
     if (n_wave) *n_wave = h->n_wave;
     if (n_lane) *n_lane = h->n_lane;
     return UZL_OK;
+}
+
+// diagnostic build: counters of the last launch of gate_reg_kernel (4 per search: expansions, shader clocks, 100 MHz ticks, largest list)
+int uzl_debug_gate_profile(uzl_gate* h, long long* out, int32_t cap)
+{
+    if (!h || !out) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    const int32_t nq = (int32_t)std::min<size_t>(h->dbg_last.size() / 4, (size_t)std::max(cap, 0));
+    for (int32_t i = 0; i < 4 * nq; i++) out[i] = h->dbg_last[i];
+    return nq;
 }
 
 int uzl_gate_edge_count(uzl_gate* h)

@@ -34,7 +34,7 @@ void k_set_scalar(double* dst, double v, hipStream_t s);
 void k_set_scalar2(double* dst_a, double va, double* dst_b, double vb, hipStream_t s);
 void k_residual_guard(const PgoDev& D, hipStream_t s);
 void k_pcg_progress(const PgoDev& D, hipStream_t s);
-void kb_pcg_progress(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s);
+void kb_pcg_progress(const BatchSlot* sl, const BatchDyn* dy, int nb_, int max_nb, hipStream_t s);
 void k_set_trial(double* scal, double lambda, double tol_f2, double eps_t, double eps_r, hipStream_t s);
 int k_pcg_init(const PgoDev& D, double* p0, double* p1, hipStream_t s);
 int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
@@ -1608,11 +1608,13 @@ void batch_fetch(uzl_pgo_batch* b)
 // single-graph replay (enqueue_pcg_pairs): the stop decision is part of the arithmetic that must agree bit for bit
 void batch_pcg_replay(uzl_pgo_batch* b, int B, int g_rows, bool small, double tol2, hipStream_t s, hipEvent_t* ev)
 {
+    int max_nb = 1;
+    for (const uzl_pgo* h : b->h) max_nb = std::max(max_nb, h->nb);
     static_assert(kProgressEvery % 2 == 0, "the direction buffers ping-pong: a look falls on an even iteration");
     for (int at = 0; at < 2 * kGraphPairs; at += kProgressEvery) {
         const int chunk = std::min(kProgressEvery, 2 * kGraphPairs - at);
         kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, chunk / 2, tol2, s, ev ? ev + 4 * at : nullptr);
-        kb_pcg_progress(b->d_slots.p, b->d_dyn.p, B, s);
+        kb_pcg_progress(b->d_slots.p, b->d_dyn.p, B, max_nb, s);
     }
 }
 

@@ -83,8 +83,11 @@ class OnlineSlam:
         self._next_batch = 0                          # first pair of the next batch to launch
         self._inflight = None
         self.solves = []
-        self.t = dict(match_wait=0.0, gate=0.0, filter=0.0, add_graph=0.0, optimize=0.0, store=0.0, host=0.0, upload=0.0)
+        self.t = dict(match_wait=0.0, gate=0.0, gate_set_graph=0.0, filter=0.0, add_graph=0.0, optimize=0.0, store=0.0, host=0.0, upload=0.0)
         self.accept_log = []                          # (pair index, accepted) in gate order
+        self.keep_poses_per_solve = 0                 # diagnostics / bench: keep a copy of the solved poses of the first k re-optimisations
+        self.poses_at_solve = []
+        self._t_first = None                          # start of the first interval: every solve records the wall clock since then
 
     def _open_handles(self, device, mc, gate_cfg, filter_cfg, pgo_cfg):
         """The four C-ABI handles of the path (estimator on every rank; gate, filter and solver on the solver rank)."""
@@ -159,6 +162,8 @@ class OnlineSlam:
         """One solve interval: admit nodes up to the next trigger, gate their candidates, filter, re-optimise.  Returns False at the end."""
         if self.cur >= self.N:
             return False
+        if self._t_first is None:
+            self._t_first = time.perf_counter()
         run = self.run
         hi = min(self.N, self.cur + self.lookahead)
         later = run["pair_later"]
@@ -176,6 +181,7 @@ class OnlineSlam:
                              np.concatenate([np.full(hi - 1, synth.EDGE_TYPE_ODOM), np.full(nf, synth.EDGE_TYPE_3D_FULL)]),
                              valid=np.concatenate([np.ones(hi - 1, int), self.f_sticky.astype(int)]))
         self.gate.set_graph(self.poses[:hi].reshape(-1, 12), ge)
+        self.t["gate_set_graph"] += time.perf_counter() - t0
         if len(cand_pair):
             cands = capi.gate_edges(run["pair_from"][cand_pair], run["pair_to"][cand_pair], np.ones(len(cand_pair), int),
                                     score=res["consensus"][ok].astype(np.float64), transform=res["T"][ok])
@@ -248,8 +254,11 @@ class OnlineSlam:
         t3 = time.perf_counter()
         self.t["add_graph"] += t1 - t0; self.t["optimize"] += t2 - t1; self.t["store"] += t3 - t2
         st = dict(st); st.update(n_nodes=n_nodes, n_feature_edges=nf, n_feature_valid=int(in_solve.sum()), clusters_evaluated=n_eval,
-                                 add_graph_ms=1e3 * (t1 - t0), optimize_ms=1e3 * (t2 - t1), store_ms=1e3 * (t3 - t2))
+                                 add_graph_ms=1e3 * (t1 - t0), optimize_ms=1e3 * (t2 - t1), store_ms=1e3 * (t3 - t2),
+                                 wall_s=t3 - self._t_first)
         self.solves.append(st)
+        if len(self.poses_at_solve) < int(self.keep_poses_per_solve):
+            self.poses_at_solve.append(self.poses[:n_nodes].copy())
         self.edges_since = 0
         if self.log:
             self.log("solve %3d: %5d nodes %5d feature edges (%d valid)  chi2 %.4g -> %.4g  %d LM its %d pcg  add %.1f ms opt %.1f ms"
