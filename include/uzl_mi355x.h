@@ -154,8 +154,17 @@ const char* uzl_match_last_error(uzl_match* h);
  * borrowed for the duration of the call only: they are packed into pinned staging memory and go up as one
  * asynchronous copy on the handle's stream, in front of whatever the handle is asked to do next. */
 int  uzl_match_add_frame(uzl_match* h, const uzl_frame* frame, int32_t* frame_id);
+/* n FeatureData in one call (what the adapter's worker has queued; the reference copies one node pair per estimateEdge call,
+ * transformation_estimator.cpp:35-43): one contiguous extent of the frame store, packed into pinned staging by several host
+ * threads and uploaded half by half (32 MB per DMA) while the next half is being packed.  frame_ids: n_frames entries. */
+int  uzl_match_add_frames(uzl_match* h, int32_t n_frames, const uzl_frame* frames, int32_t* frame_ids);
+/* Hands the frame's extent back to the store's free list (first fit, neighbours merged; a frame removed while a batch is in
+ * flight is freed by that batch's collect): a node that adds and removes frames for hours - the reference merges and deletes
+ * nodes continuously, graph_slam_node.cpp:665-777 - holds what is alive, not what was ever uploaded. */
 int  uzl_match_remove_frame(uzl_match* h, int32_t frame_id);
 int  uzl_match_frame_count(uzl_match* h);
+/* bytes of the frame store: held by live frames / high-water mark of the arena / allocated.  Any of the three may be NULL. */
+int  uzl_match_arena_bytes(uzl_match* h, uint64_t* live, uint64_t* high_water, uint64_t* capacity);
 
 /* Batched estimateEdgeImpl: n_jobs independent node pairs in one launch sequence.
  * Optional diagnostics (may each be NULL): per job, at stride max_corr,

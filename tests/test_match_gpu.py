@@ -239,3 +239,67 @@ def test_random_shapes_against_oracle():
     r = subprocess.run([sys.executable, os.path.join(here, "diag", "stress_match.py"), "50", "9"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ", 0 misses" in r.stdout
+
+
+def test_bulk_add_frames_equals_single_adds(capi, oracle):
+    """uzl_match_add_frames (one extent, threaded packing, one DMA per staging half): the frames read back byte for byte and the
+    estimates equal those over frames added one by one."""
+    from uzliti_slam_amd import wire as W
+    pairs = synth.make_pairs(24, n_kp=700, seed=9)
+    rng = np.random.default_rng(1)
+    odd = []                                                 # ragged frames: empty, one keypoint, other descriptor widths
+    for n, b in [(0, 32), (1, 32), (333, 64), (5, 4)]:
+        odd.append((rng.integers(0, 256, (n, b), dtype=np.uint8), rng.normal(size=(3, n)), rng.integers(0, 2, n).astype(np.uint8)))
+    frames = [(f["desc"], f["pos"], f["valid"]) for p in pairs for f in p[:2]] + odd
+    a = capi.Match(ransac_iteration=100, seed=3)
+    b = capi.Match(ransac_iteration=100, seed=3)
+    ids_a = a.add_frames(capi.Match.pack_frames(frames))
+    ids_b = [b.add_frame(*f) for f in frames]
+    assert len(ids_a) == len(frames) and a.frame_count() == len(frames)
+    for k, (d, p, v) in enumerate(frames):
+        gd, gp, gv = W.get_frame(a, ids_a[k])
+        assert np.array_equal(gd, d) and np.array_equal(gp, np.asarray(p, np.float64)) and np.array_equal(gv, v)
+    ra, _ = a.estimate([(ids_a[2 * k], ids_a[2 * k + 1]) for k in range(len(pairs))])
+    rb, _ = b.estimate([(ids_b[2 * k], ids_b[2 * k + 1]) for k in range(len(pairs))])
+    assert np.array_equal(ra["consensus"], rb["consensus"]) and np.array_equal(ra["T"], rb["T"])
+    a.close(); b.close()
+
+
+def test_frame_store_reclaims_removed_frames(capi):
+    """Frames come and go (the reference merges and deletes nodes all the time, graph_slam_node.cpp:665-777): ten times the arena's
+    initial size goes through the store, a third of it alive at any moment - the arena must not grow beyond what is alive (plus
+    fragmentation), and what is alive must stay intact."""
+    from uzliti_slam_amd import wire as W
+    rng = np.random.default_rng(5)
+    m = capi.Match()
+    cap0 = m.arena_bytes()["capacity"]
+    live = {}
+    total = 0
+    k = 0
+    peak = 0
+    while total < 10 * cap0:
+        n = int(rng.integers(200, 3000))
+        fr = [(rng.integers(0, 256, (n, 32), dtype=np.uint8), rng.normal(size=(3, n)), rng.integers(0, 2, n).astype(np.uint8)) for _ in range(16)]
+        if k % 2 == 0:
+            ids = m.add_frames(capi.Match.pack_frames(fr))
+        else:
+            ids = [m.add_frame(*f) for f in fr]
+        for i, f in zip(ids, fr):
+            live[i] = f
+        total += sum(f[0].nbytes + 24 * len(f[2]) + len(f[2]) for f in fr)
+        # keep about 20 MB alive: drop random frames
+        while sum(v[0].nbytes for v in live.values()) > 20e6:
+            victim = list(live.keys())[int(rng.integers(0, len(live)))]
+            m.remove_frame(victim); del live[victim]
+        peak = max(peak, m.arena_bytes()["live"])
+        k += 1
+    ab = m.arena_bytes()
+    assert ab["high_water"] <= 2.5 * peak and ab["capacity"] <= 2 * cap0, (ab, peak)     # 640 MB went through; the store holds what is alive (+ holes)
+    assert ab["live"] <= ab["high_water"] and m.frame_count() == len(live)
+    for i in list(live.keys())[:40]:
+        gd, gp, gv = W.get_frame(m, i)
+        assert np.array_equal(gd, live[i][0]) and np.array_equal(gp, np.asarray(live[i][1], np.float64)) and np.array_equal(gv, live[i][2])
+    for i in list(live.keys()):
+        m.remove_frame(i)
+    assert m.arena_bytes()["high_water"] == 0 and m.arena_bytes()["live"] == 0
+    m.close()

@@ -112,11 +112,47 @@ int32_t Mi355xFeatureTransformationEstimator::frameId(const FeatureDataPtr& fd)
     return id;
 }
 
+// every FeatureData of the queued pairs that is not resident yet: ONE uzl_match_add_frames call (one arena extent, threaded packing,
+// one DMA per staging half) instead of a call and a copy per frame
+void Mi355xFeatureTransformationEstimator::uploadNewFrames(const std::vector<std::pair<SlamNode, SlamNode>>& pairs)
+{
+    std::vector<FeatureDataPtr> fresh;
+    std::unordered_map<const FeatureData*, char> seen;
+    auto visit = [&](const SlamNode& nd) {
+        for (auto& sd : nd.sensor_data_) {
+            if (sd->type_ != SENSOR_TYPE_FEATURE) continue;
+            FeatureDataPtr fd = std::dynamic_pointer_cast<FeatureData>(sd);
+            if (!fd || frame_ids_.count(fd.get()) || seen.count(fd.get())) continue;
+            seen[fd.get()] = 1;
+            fresh.push_back(fd);
+        }
+    };
+    for (auto& pr : pairs) { visit(pr.first); visit(pr.second); }
+    if (fresh.size() < 2) return;                           // a single new frame takes frameId()'s path
+    std::vector<std::vector<uint8_t>> valid(fresh.size());
+    std::vector<uzl_frame> fr(fresh.size());
+    for (size_t k = 0; k < fresh.size(); k++) {
+        const FeatureDataPtr& fd = fresh[k];
+        valid[k].resize(fd->valid_3d_.size());
+        for (size_t i = 0; i < valid[k].size(); i++) valid[k][i] = fd->valid_3d_[i] ? 1 : 0;
+        uzl_frame& f = fr[k];
+        std::memset(&f, 0, sizeof(f));
+        f.desc = fd->features_.data(); f.n = fd->rows; f.bytes_per_desc = fd->bytes_per_row;
+        f.pos_xyz = fd->feature_positions_.data(); f.valid3d = valid[k].data();
+        f.feature_type = fd->feature_type_; f.sensor_frame = sensorKey(fd->sensor_frame_);
+        std::memcpy(f.displacement, fd->displacement_.m.data(), sizeof(f.displacement));
+    }
+    std::vector<int32_t> ids(fresh.size(), -1);
+    if (uzl_match_add_frames(h_, (int32_t)fr.size(), fr.data(), ids.data()) != UZL_OK) return;     // frameId() retries one by one
+    for (size_t k = 0; k < fresh.size(); k++) { frame_ids_[fresh[k].get()] = ids[k]; keep_alive_[fresh[k].get()] = fresh[k]; }
+}
+
 void Mi355xFeatureTransformationEstimator::estimateBatch(std::vector<std::pair<SlamNode, SlamNode>>& pairs,
                                                          std::vector<SlamEdge>& edges, std::vector<char>& ok)
 {
     const int32_t n = (int32_t)pairs.size();
     if (!h_ || n == 0) return;
+    uploadNewFrames(pairs);
     std::vector<uzl_pair_job> jobs((size_t)n);
     std::vector<int32_t> ids;
     std::vector<std::vector<FeatureDataPtr>> lookup;       // frame id -> FeatureData for sensor_from_/displacement_

@@ -59,6 +59,7 @@ protected:
 
 private:
     int32_t frameId(const FeatureDataPtr& fd);
+    void uploadNewFrames(const std::vector<std::pair<SlamNode, SlamNode>>& pairs);
     int32_t sensorKey(const std::string& frame);
     uzl_match* h_ = nullptr;
     uzl_match_cfg cfg_{};

@@ -310,6 +310,37 @@ class Match:
         self._check(lib().uzl_match_add_frame(self._h, C.byref(f), C.byref(fid)))
         return fid.value
 
+    @staticmethod
+    def pack_frames(frames, feature_type=2, sensor_frame=0):
+        """[(desc, pos, valid), ...] -> (ctypes array of uzl_frame, keep-alive list): the marshalling a C++ caller does not have."""
+        arr = (Frame * len(frames))()
+        keep = []
+        eye = np.eye(3, 4).reshape(12).tolist()
+        for k, (desc, pos, valid) in enumerate(frames):
+            d = np.ascontiguousarray(desc, np.uint8)
+            p = np.ascontiguousarray(np.asarray(pos, np.float64).T)
+            v = np.ascontiguousarray(valid, np.uint8)
+            keep.append((d, p, v))
+            f = arr[k]
+            f.desc = _p(d, c_u8p); f.n = d.shape[0]; f.bytes_per_desc = d.shape[1] if d.ndim == 2 else 0
+            f.pos_xyz = _p(p, c_f64p); f.valid3d = _p(v, c_u8p)
+            f.feature_type = int(feature_type); f.sensor_frame = int(sensor_frame)
+            f.displacement[:] = eye
+        return arr, keep
+
+    def add_frames(self, packed):
+        """uzl_match_add_frames over the array pack_frames built -> list of frame ids."""
+        arr = packed[0] if isinstance(packed, tuple) else packed
+        n = len(arr)
+        ids = (C.c_int32 * max(n, 1))()
+        self._check(lib().uzl_match_add_frames(self._h, C.c_int32(n), arr, ids))
+        return list(ids[:n])
+
+    def arena_bytes(self):
+        live = C.c_uint64(); hw = C.c_uint64(); cap = C.c_uint64()
+        self._check(lib().uzl_match_arena_bytes(self._h, C.byref(live), C.byref(hw), C.byref(cap)))
+        return dict(live=live.value, high_water=hw.value, capacity=cap.value)
+
     def remove_frame(self, fid):
         self._check(lib().uzl_match_remove_frame(self._h, C.c_int32(fid)))
 

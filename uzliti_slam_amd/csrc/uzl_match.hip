@@ -3,6 +3,7 @@
 // (transformation_estimation/src/feature_transformation_estimator.cpp) as a batched, device-resident
 // service: frames are uploaded once, every node-pair job references them by id.
 #include "uzl_common.hpp"
+#include <thread>
 #include "match_types.hpp"
 #include "match_internal.hpp"
 #include "wire_types.hpp"
@@ -23,8 +24,10 @@ constexpr size_t kLdsBudget = 152 * 1024;   // of the CU's 160 KiB
 struct FrameRec {
     bool alive = false;
     uint64_t desc_off = 0, pos_off = 0, valid_off = 0;   // byte offsets into the arena
+    uint64_t ext_off = 0, ext_size = 0;                   // the arena extent the frame occupies (handed back by remove_frame)
     int32_t n = 0, words = 0, feature_type = 0, sensor_frame = 0;
 };
+struct Extent { size_t off, size; };
 
 }  // namespace uzl
 
@@ -37,7 +40,10 @@ struct uzl_match {
     hipStream_t stream = nullptr;
     // frame arena: one HBM allocation, frames addressed by offset so it can grow
     DevBuf<uint8_t> arena;
-    size_t arena_used = 0;
+    size_t arena_used = 0;               // high-water mark: [0, arena_used) is handed out or on the free list
+    std::vector<Extent> free_list;       // freed extents, sorted by offset, neighbours merged (first fit)
+    std::vector<Extent> deferred_free;   // frames removed while a batch that may read them is in flight: freed by its collect
+    size_t live_bytes = 0;
     std::vector<FrameRec> frames;
     int32_t live_frames = 0;
     // batch state
@@ -55,6 +61,10 @@ struct uzl_match {
     // asynchronous copy; the call returns without waiting (the inputs are no longer needed once packed).  Two halves: a half is reused
     // only after the copies issued from it have completed (event).
     PinBuf<uint8_t> h_up;
+    // uzl_match_add_frames staging: two larger halves, packed by several host threads while the other half's copy is in flight
+    PinBuf<uint8_t> h_bulk;
+    hipEvent_t bulk_ev[2] = {nullptr, nullptr};
+    bool bulk_pending[2] = {false, false};
     hipEvent_t up_ev[2] = {nullptr, nullptr};
     bool up_pending[2] = {false, false};
     int up_half = 0;
@@ -75,6 +85,52 @@ int fail(uzl_match* h, int code, const char* msg)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr size_t kUpHalf = 8u << 20;          // bytes per half of the add_frame staging buffer
+constexpr size_t kBulkHalf = 32u << 20;       // bytes per half of the add_frames staging buffer (one DMA per half)
+
+// ---- frame arena: first-fit free list over one growing HBM allocation.  The reference removes and merges nodes all the time
+// (graph_slam_node.cpp:665-777); a store that only reclaims space when it is empty leaks HBM in a long-running node.
+size_t arena_alloc(uzl_match* h, size_t size)
+{
+    size = align_up(size, 256);
+    for (size_t i = 0; i < h->free_list.size(); i++) {
+        Extent& e = h->free_list[i];
+        if (e.size >= size) {
+            const size_t off = e.off;
+            e.off += size; e.size -= size;
+            if (e.size == 0) h->free_list.erase(h->free_list.begin() + (std::ptrdiff_t)i);
+            return off;
+        }
+    }
+    const size_t off = h->arena_used;
+    h->arena_used += size;
+    return off;
+}
+void arena_free_now(uzl_match* h, size_t off, size_t size)
+{
+    if (size == 0) return;
+    size = align_up(size, 256);
+    auto it = std::lower_bound(h->free_list.begin(), h->free_list.end(), off, [](const Extent& e, size_t o) { return e.off < o; });
+    it = h->free_list.insert(it, Extent{off, size});
+    if (it + 1 != h->free_list.end() && it->off + it->size == (it + 1)->off) { it->size += (it + 1)->size; h->free_list.erase(it + 1); }
+    if (it != h->free_list.begin() && (it - 1)->off + (it - 1)->size == it->off) { (it - 1)->size += it->size; it = h->free_list.erase(it) - 1; }
+    if (it->off + it->size == h->arena_used) { h->arena_used = it->off; h->free_list.erase(it); }      // the top of the arena comes down
+}
+void arena_free(uzl_match* h, size_t off, size_t size)
+{
+    if (h->in_flight) h->deferred_free.push_back(Extent{off, size});     // the batch in flight may still read the frame
+    else arena_free_now(h, off, size);
+}
+// [desc | pad | pos | pad | valid | tail] of one frame, relative to its extent; returns the extent's size
+size_t frame_layout(size_t n, size_t bytes_per_desc, FrameRec& r, size_t base)
+{
+    size_t off = base;
+    r.desc_off = off; off = align_up(off + n * bytes_per_desc, 16);
+    r.pos_off = off; off = align_up(off + n * 24, 16);
+    r.valid_off = off; off += n;
+    off = align_up(off + 64, 256);      // tail padding: clamped lanes may read one row past nothing, never past the extent
+    r.ext_off = base; r.ext_size = off - base;
+    return off - base;
+}
 
 int next_pow2(int v)
 {
@@ -213,6 +269,8 @@ int do_collect(uzl_match* h, uzl_edge_result* results, int32_t* corr_query, int3
     UZL_HIP(hipSetDevice(h->cfg.device));
     UZL_HIP(hipStreamSynchronize(h->stream));
     h->in_flight = false;
+    for (const Extent& e : h->deferred_free) arena_free_now(h, e.off, e.size);
+    h->deferred_free.clear();
     h->timer.resolve();
     const int32_t n = h->fl_jobs;
     if (n > 0 && !results) return fail(h, UZL_ERR_BAD_ARG, "results is null");
@@ -368,6 +426,7 @@ void uzl_match_destroy(uzl_match* h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     for (auto& e : h->up_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->bulk_ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -395,14 +454,17 @@ int uzl_match_add_frame(uzl_match* h, const uzl_frame* f, int32_t* frame_id)
     UZL_HIP(hipSetDevice(h->cfg.device));
     const size_t n = (size_t)f->n;
     const size_t desc_b = n * (size_t)f->bytes_per_desc, pos_b = n * 24, val_b = n;
-    size_t off = align_up(h->arena_used, 256);
     FrameRec r;
-    r.desc_off = off; off = align_up(off + desc_b, 16);
-    r.pos_off = off; off = align_up(off + pos_b, 16);
-    r.valid_off = off; off += val_b;
-    off = align_up(off + 64, 256);      // tail padding: clamped lanes may read one row past nothing, never past the arena
-    if (h->in_flight && off > h->arena.cap) return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
-    h->arena.reserve(off, /*keep=*/true, h->stream);
+    const size_t need = frame_layout(n, (size_t)f->bytes_per_desc, r, 0);
+    const size_t used_before = h->arena_used;
+    const std::vector<Extent> free_before = h->free_list;
+    const size_t base = arena_alloc(h, need);
+    if (h->in_flight && h->arena_used > h->arena.cap) {               // (growing re-allocates: not under a batch that reads the arena)
+        h->arena_used = used_before; h->free_list = free_before;
+        return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
+    }
+    frame_layout(n, (size_t)f->bytes_per_desc, r, base);
+    h->arena.reserve(h->arena_used, /*keep=*/true, h->stream);
     if (n) {
         const size_t span = r.valid_off + val_b - r.desc_off;        // [desc | pad | pos | pad | valid] as it lies in the arena
         if (span <= kUpHalf) {
@@ -429,14 +491,119 @@ int uzl_match_add_frame(uzl_match* h, const uzl_frame* f, int32_t* frame_id)
             UZL_HIP(hipStreamSynchronize(h->stream));   // inputs are borrowed only for the duration of the call
         }
     }
-    h->arena_used = off;
     r.alive = true; r.n = f->n; r.words = f->bytes_per_desc / 4;
     r.feature_type = f->feature_type; r.sensor_frame = f->sensor_frame;
     h->frames.push_back(r);
-    h->live_frames++;
+    h->live_frames++; h->live_bytes += r.ext_size;
     *frame_id = (int32_t)h->frames.size() - 1;
     return UZL_OK;
     UZL_GUARD_END(h)
+}
+
+// n FeatureData at once (the adapter's batching worker holds that many; transformation_estimator.cpp:35-43 copies one node pair per
+// call).  The frames get ONE contiguous arena extent; host threads pack them into pinned staging, half by half, and every half goes up
+// as one DMA while the next one is being packed.  Returns without waiting for the last copy (the inputs are packed by then).
+int uzl_match_add_frames(uzl_match* h, int32_t n_frames, const uzl_frame* f, int32_t* frame_ids)
+{
+    if (n_frames < 0 || (n_frames > 0 && (!f || !frame_ids))) return UZL_ERR_BAD_ARG;
+    UZL_GUARD_BEGIN(h)
+    if (n_frames == 0) return UZL_OK;
+    for (int32_t k = 0; k < n_frames; k++) {
+        if (f[k].n < 0 || f[k].n > kMaxKeypoints) return fail(h, UZL_ERR_BAD_ARG, "frame.n out of range [0,16384]");
+        if (f[k].bytes_per_desc <= 0 || f[k].bytes_per_desc % 4 != 0 || f[k].bytes_per_desc > 508)
+            return fail(h, UZL_ERR_BAD_ARG, "bytes_per_desc must be a multiple of 4 in [4,508]");
+        if (f[k].n > 0 && (!f[k].desc || !f[k].pos_xyz || !f[k].valid3d)) return fail(h, UZL_ERR_BAD_ARG, "null frame arrays");
+    }
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    std::vector<FrameRec> recs((size_t)n_frames);
+    size_t total = 0;
+    for (int32_t k = 0; k < n_frames; k++) total += frame_layout((size_t)f[k].n, (size_t)f[k].bytes_per_desc, recs[k], total);
+    const size_t used_before = h->arena_used;
+    const std::vector<Extent> free_before = h->free_list;
+    // one contiguous extent when a hole (or the top of the arena) takes the whole batch; otherwise frame by frame into the holes
+    bool one_extent = h->free_list.empty();
+    for (const Extent& e : h->free_list) one_extent = one_extent || e.size >= align_up(total, 256);
+    if (one_extent) {
+        const size_t base = arena_alloc(h, total);
+        for (int32_t k = 0; k < n_frames; k++) { recs[k].desc_off += base; recs[k].pos_off += base; recs[k].valid_off += base; recs[k].ext_off += base; }
+    } else {
+        for (int32_t k = 0; k < n_frames; k++) {
+            const size_t rel = recs[k].ext_off, base = arena_alloc(h, recs[k].ext_size);
+            recs[k].desc_off += base - rel; recs[k].pos_off += base - rel; recs[k].valid_off += base - rel; recs[k].ext_off = base;
+        }
+    }
+    if (h->in_flight && h->arena_used > h->arena.cap) {
+        h->arena_used = used_before; h->free_list = free_before;
+        return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
+    }
+    h->arena.reserve(h->arena_used, /*keep=*/true, h->stream);
+    for (int32_t k = 0; k < n_frames; k++) {
+        FrameRec& r = recs[k];
+        r.alive = true; r.n = f[k].n; r.words = f[k].bytes_per_desc / 4; r.feature_type = f[k].feature_type; r.sensor_frame = f[k].sensor_frame;
+    }
+    if (!h->h_bulk.p) {
+        h->h_bulk.reserve(2 * kBulkHalf);
+        for (auto& e : h->bulk_ev) UZL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    std::vector<size_t> soff((size_t)n_frames);
+    int32_t k0 = 0;
+    int half = 0;
+    while (k0 < n_frames) {
+        // frames [k0, k1): as many as fit one staging half (a frame's extent is at most ~8.7 MB), packed back to back
+        int32_t k1 = k0;
+        size_t bytes = 0;
+        while (k1 < n_frames && bytes + recs[k1].ext_size <= kBulkHalf) { soff[k1] = bytes; bytes += recs[k1].ext_size; k1++; }
+        if (h->bulk_pending[half]) { UZL_HIP(hipEventSynchronize(h->bulk_ev[half])); h->bulk_pending[half] = false; }
+        uint8_t* st = h->h_bulk.p + (size_t)half * kBulkHalf;
+        auto pack = [&](int32_t a, int32_t b) {
+            for (int32_t k = a; k < b; k++) {
+                const size_t n = (size_t)f[k].n;
+                if (!n) continue;
+                uint8_t* d = st + soff[k];
+                memcpy(d + (recs[k].desc_off - recs[k].ext_off), f[k].desc, n * (size_t)f[k].bytes_per_desc);
+                memcpy(d + (recs[k].pos_off - recs[k].ext_off), f[k].pos_xyz, n * 24);
+                memcpy(d + (recs[k].valid_off - recs[k].ext_off), f[k].valid3d, n);
+            }
+        };
+        const int32_t cnt = k1 - k0;
+        const int nt = (int)std::min<size_t>({(size_t)8, (size_t)hw, (size_t)cnt, std::max<size_t>(1, bytes >> 20)});      // ~1 MB per thread at least
+        if (nt <= 1) pack(k0, k1);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; t++) th.emplace_back(pack, k0 + (int32_t)((int64_t)cnt * t / nt), k0 + (int32_t)((int64_t)cnt * (t + 1) / nt));
+            pack(k0, k0 + cnt / nt);
+            for (auto& t : th) t.join();
+        }
+        for (int32_t a = k0; a < k1;) {                              // one DMA per run of frames that are neighbours in the arena too
+            int32_t b = a + 1;
+            while (b < k1 && recs[b].ext_off == recs[b - 1].ext_off + recs[b - 1].ext_size) b++;
+            const size_t run_bytes = soff[b - 1] + recs[b - 1].ext_size - soff[a];
+            UZL_HIP(hipMemcpyAsync(h->arena.p + recs[a].ext_off, st + soff[a], run_bytes, hipMemcpyHostToDevice, h->stream));
+            a = b;
+        }
+        UZL_HIP(hipEventRecord(h->bulk_ev[half], h->stream));
+        h->bulk_pending[half] = true;
+        half ^= 1;
+        k0 = k1;
+    }
+    for (int32_t k = 0; k < n_frames; k++) {
+        h->frames.push_back(recs[k]);
+        h->live_frames++; h->live_bytes += recs[k].ext_size;
+        frame_ids[k] = (int32_t)h->frames.size() - 1;
+    }
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
+int uzl_match_arena_bytes(uzl_match* h, uint64_t* live, uint64_t* high_water, uint64_t* capacity)
+{
+    if (!h) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (live) *live = h->live_bytes;
+    if (high_water) *high_water = h->arena_used;
+    if (capacity) *capacity = h->arena.cap;
+    return UZL_OK;
 }
 
 int uzl_match_remove_frame(uzl_match* h, int32_t frame_id)
@@ -445,8 +612,10 @@ int uzl_match_remove_frame(uzl_match* h, int32_t frame_id)
     std::lock_guard<std::mutex> lock(h->mu);
     if (frame_id < 0 || frame_id >= (int32_t)h->frames.size() || !h->frames[frame_id].alive)
         return fail(h, UZL_ERR_NOT_FOUND, "unknown frame id");
-    h->frames[frame_id].alive = false;     // arena space is reclaimed when the store empties
-    if (--h->live_frames == 0 && !h->in_flight) { h->arena_used = 0; }
+    FrameRec& r = h->frames[frame_id];
+    r.alive = false;
+    h->live_frames--; h->live_bytes -= r.ext_size;
+    arena_free(h, r.ext_off, r.ext_size);      // back to the free list (after the batch in flight, if there is one)
     return UZL_OK;
 }
 
@@ -461,7 +630,7 @@ int uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sen
     UZL_HIP(hipSetDevice(h->cfg.device));
     std::vector<WireSeg> segs((size_t)n_frames + 1);      // + sentinel
     std::vector<FrameRec> recs((size_t)n_frames);
-    size_t off = h->arena_used;
+    size_t off = 0;                                       // relative to the batch's extent, which is allocated below
     uint64_t src = 0;
     int64_t items = 0, feats = 0;
     for (int32_t k = 0; k < n_frames; k++) {
@@ -479,12 +648,8 @@ int uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sen
         }
         const size_t n = (size_t)f.n_features;
         const int32_t D = f.n_features > 0 ? f.desc_len : 32;
-        off = align_up(off, 256);
         FrameRec& r = recs[k];
-        r.desc_off = off; off = align_up(off + n * (size_t)D, 16);
-        r.pos_off = off; off = align_up(off + n * 24, 16);
-        r.valid_off = off; off += n;
-        off = align_up(off + 64, 256);
+        off += frame_layout(n, (size_t)D, r, off);
         r.alive = true; r.n = f.n_features; r.words = D / 4;
         r.feature_type = f.descriptor_type; r.sensor_frame = sensor_frame_keys ? sensor_frame_keys[k] : 0;
         WireSeg& g = segs[k];
@@ -496,8 +661,16 @@ int uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sen
     }
     memset(&segs[(size_t)n_frames], 0, sizeof(WireSeg));
     segs[(size_t)n_frames].item_begin = items;
-    if (h->in_flight && off > h->arena.cap) return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
-    h->arena.reserve(off, /*keep=*/true, h->stream);
+    const size_t used_before = h->arena_used;
+    const std::vector<Extent> free_before = h->free_list;
+    const size_t base = arena_alloc(h, off);
+    auto undo_alloc = [&]() { h->arena_used = used_before; h->free_list = free_before; };
+    if (h->in_flight && h->arena_used > h->arena.cap) { undo_alloc(); return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight"); }
+    for (int32_t k = 0; k < n_frames; k++) {
+        recs[k].desc_off += base; recs[k].pos_off += base; recs[k].valid_off += base; recs[k].ext_off += base;
+        segs[k].desc_off += base; segs[k].pos_off += base; segs[k].valid_off += base;
+    }
+    h->arena.reserve(h->arena_used, /*keep=*/true, h->stream);
     h->d_wire_stage.reserve((size_t)(src / 4) + 8);                              // + tail: the 16 bytes after the last record may be read
     h->d_wire_segs.reserve((size_t)n_frames + 1);
     h->d_wire_bad.reserve(1);
@@ -518,11 +691,10 @@ int uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sen
     if (uv && feats) UZL_HIP(hipMemcpyAsync(uv, h->d_wire_uv.p, (size_t)feats * 8, hipMemcpyDeviceToHost, h->stream));
     UZL_HIP(hipStreamSynchronize(h->stream));                                    // inputs are borrowed only for the duration of the call
     h->timer.resolve();
-    if (bad) return fail(h, UZL_ERR_BAD_ARG, "a Feature record's descriptor count differs from desc_len");
-    h->arena_used = off;
+    if (bad) { undo_alloc(); return fail(h, UZL_ERR_BAD_ARG, "a Feature record's descriptor count differs from desc_len"); }
     for (int32_t k = 0; k < n_frames; k++) {
         h->frames.push_back(recs[k]);
-        h->live_frames++;
+        h->live_frames++; h->live_bytes += recs[k].ext_size;
         frame_ids[k] = (int32_t)h->frames.size() - 1;
     }
     return UZL_OK;
