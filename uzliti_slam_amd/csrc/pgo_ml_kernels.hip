@@ -1091,6 +1091,15 @@ __device__ __forceinline__ double sg_at(const double* __restrict__ Sg, int gl, i
 //   per CU took 15.5 us, two 23.7): 313 workgroups of a 10k-vertex graph on 256 CUs left 57 CUs with twice the work of the rest;
 //   626 half workgroups put at most 1.5 times the mean on one CU.
 constexpr int kSpmvWaves4 = 4;
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx.x mod 8), each with an L2 of its own.  Rows that are neighbours on the
+// trajectory share vectors and odometry blocks, so every XCD gets a CONTIGUOUS range of row groups instead of every eighth one:
+// logical index = start(blockIdx.x mod 8) + blockIdx.x / 8.  A bijection on [0, gridDim.x); partials stay indexed by the logical
+// index, so every sum is taken in the same order as before - results do not change.
+__device__ __forceinline__ int xcd_contiguous(int b, int g)
+{
+    const int q = g >> 3, rem = g & 7, x = b & 7;
+    return x * q + (x < rem ? x : rem) + (b >> 3);
+}
 // Geometry of the workgroup (RPW rows per wave x WAVES waves) is separate from the hierarchy it serves (AGG): the batched solve runs
 // the AGG = 1 hierarchy with four rows per wave in 128-lane workgroups (ml_spmv_batch_kernel) - four times the bytes in flight per
 // wave when sixteen graphs fill the chip - where a single small graph wants one row per wave for the shortest chain.  Both give the
@@ -1113,7 +1122,8 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     const int gl = (AGG == 1 || H.levels < 2) ? 1 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane / 6, r = lane % 6;
     const bool lact = lane < 60;
-    const int row0 = blockIdx.x * kRowsPerBlk + wv * kRowsPerWave;
+    const int bx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);      // this workgroup's row group
+    const int row0 = bx * kRowsPerBlk + wv * kRowsPerWave;
     // ---- prefetch (independent of beta); the r.z partials first: they gate everything else
     double vpart[kGrpU];                      // wave wv takes groups wv, wv + kWaves, ...; lane = element of the group
 #pragma unroll
@@ -1141,7 +1151,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     //  above - nothing waits for them - and saves every working launch the done flag's round trip in front of its first load.)
     if (done) return;
     if (tid < kAggPerBlk * 3) {
-        const int A1 = blockIdx.x * kAggPerBlk + tid / 3;
+        const int A1 = bx * kAggPerBlk + tid / 3;
         sg1[tid] = (gl == 2 && A1 < H.n[1]) ? H.geo[1][(size_t)A1 * 3 + tid % 3] : 0.;
     }
     // Every lane (g, r) multiplies row r of a 6x6 block with the 6-vector z + beta p_old of the block's column.  The six lanes of a
@@ -1334,7 +1344,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         for (int o = 1; o < kRowsPerBlk; o <<= 1) dtot += __shfl_xor(dtot, o);
     }
     if (tid < kAggPerBlk * 6) {
-        const int la = tid / 6, k = tid % 6, A1 = blockIdx.x * kAggPerBlk + la;
+        const int la = tid / 6, k = tid % 6, A1 = bx * kAggPerBlk + la;
         double s = 0.;
 #pragma unroll
         for (int j = 0; j < kMlFanout; j++) s += sw[(la * kMlFanout + j) * 6 + k];
@@ -1345,12 +1355,12 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     if (AGG != 1 && gl == 2 && tid < 6) {
         double s = 0.;
         for (int la = 0; la < kAggPerBlk; la++)
-            if (blockIdx.x * kAggPerBlk + la < H.n[1]) s += restrict_comp(sg1 + la * 3, ss1 + la * 6, tid);
-        H.Sg[((size_t)(blockIdx.x / (8 / kSpmvWaves4)) * 6 + tid) * (8 / kSpmvWaves4) + blockIdx.x % (8 / kSpmvWaves4)] = s;     // [aggregate][component][half]
+            if (bx * kAggPerBlk + la < H.n[1]) s += restrict_comp(sg1 + la * 3, ss1 + la * 6, tid);
+        H.Sg[((size_t)(bx / (8 / kSpmvWaves4)) * 6 + tid) * (8 / kSpmvWaves4) + bx % (8 / kSpmvWaves4)] = s;     // [aggregate][component][half]
     }
     if (tid == 0) {
-        D.part_a[blockIdx.x] = dtot;
-        if (blockIdx.x == 0) {
+        D.part_a[bx] = dtot;
+        if (bx == 0) {
             D.scal[0] = rz;
             if (it == 0) { D.scal[1] = thresh; D.scal[11] = rz; }
             if (!(rz > thresh)) D.flags[0] = 1;
