@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-online", action="store_true", help="skip the BASELINE config 5 block")
     ap.add_argument("--no-batched", action="store_true", help="skip the batched multi-graph block")
     ap.add_argument("--batch", type=int, default=16, help="graphs per batch of the batched block")
+    ap.add_argument("--batch-queue", type=int, default=256, help="graphs in the queue of the batched block's refill measurement (0 = skip)")
     ap.add_argument("--online-nodes", type=int, default=20000)
     ap.add_argument("--online-pairs", type=int, default=4096)
     ap.add_argument("--sharded", action="store_true", help="(default for N > 1; kept for old command lines)")
@@ -575,6 +576,31 @@ def main():
                        ms_per_graph=round(1e3 * t_b / nsteps_b / nB, 4), vs_single_graph=round(vb / value, 2),
                        note="every graph's poses are bit-identical to its own uzl_pgo_optimize (tests/test_batch_gpu.py); the single-graph figure is `value`")
         bt.close()
+        # a queue of config-2 graphs through 16 / 64 resident slots: a finished graph hands its slot to the next one (uzl_pgo_batch_set_resident)
+        nQ = a.batch_queue
+        if nQ > 0:
+            bq = capi.PgoBatch(nQ, device=dev, iterations=a.lm_iters)
+            for k in range(nQ):
+                gk = synth.make_pose_graph(a.nodes, a.edges, seed=ud.replica_seed(12345, dist.rank) + 1000 * k)
+                bq.graphs[k].add_graph(gk["nodes_pose"], gk["nodes_fixed"], gk["edges"])
+            batched["queue"] = dict(graphs=nQ, workload="%d config-2 graphs queued, R resident at a time" % nQ)
+            for R_ in (16, 64):
+                if R_ > nQ:
+                    continue
+                bq.set_resident(R_)
+                for p_ in bq.graphs:
+                    p_.reset()
+                bq.optimize(a.lm_iters)                                   # warm-up: structures, capture for this slot count
+                for p_ in bq.graphs:
+                    p_.reset()
+                dist.barrier(); t0 = time.perf_counter()
+                sts = bq.optimize(a.lm_iters)
+                dist.sync(); tq = dist.max(time.perf_counter() - t0)
+                eq = dist.sum(float(sum(x["n_edges"] * x["iterations_done"] for x in sts)))
+                batched["queue"]["resident_%d" % R_] = dict(value=round(eq / tq, 1), unit="edges/s", ms=round(1e3 * tq, 2), graphs_batched=bq.n_batched,
+                                                             vs_single_graph=round(eq / tq / value, 2),
+                                                             lm_trials_min_max=[min(x["lm_trials"] for x in sts), max(x["lm_trials"] for x in sts)])
+            bq.close()
         # the regime batching is for: many small graphs (BASELINE config 1 size: 100 nodes / 300 edges - local scopes, per-robot graphs)
         nS = 64
         g1 = [synth.make_pose_graph(100, 300, seed=ud.replica_seed(777, dist.rank) + 1000 * k) for k in range(nS)]

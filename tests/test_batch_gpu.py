@@ -79,3 +79,37 @@ def test_chain_like_graphs_in_a_batch(capi, oracle):
         assert np.array_equal(bt.graphs[k].store()[0], poses1), k
         assert stats[k]["iterations_done"] == st1["iterations_done"] and stats[k]["lm_trials"] == st1["lm_trials"]
     bt.close()
+
+
+@pytest.mark.parametrize("resident", [1, 3, 8])
+def test_queue_with_fewer_resident_slots_than_graphs(capi, resident):
+    """uzl_pgo_batch_set_resident: 20 graphs through 1 / 3 / 8 slots - a finished graph hands its slot to the next one of the queue.
+    Graphs with different numbers of LM trials (some start far off, some terminate early) sit in different phases of the loop at the
+    same time; every graph must still come out bit-identical to its own uzl_pgo_optimize."""
+    rng = np.random.default_rng(3)
+    graphs = []
+    for k in range(20):
+        g = synth.make_pose_graph(600, 2600, seed=300 + k, outlier_frac=0.05 * (k % 4))
+        if k % 5 == 0:                                            # a poor start: rejected trials, more rounds than the others
+            P0 = g["nodes_pose"].reshape(-1, 3, 4).copy()
+            P0[1:] = synth.se3_mul(P0[1:], synth.se3_from_noise(rng.normal(0, 0.8, (599, 3)), rng.normal(0, 0.4, (599, 3))))
+            g["nodes_pose"] = P0.reshape(-1, 12)
+        if k % 7 == 3:                                            # already at the optimum of a noise-free graph: Terminate after a trial or two
+            g["nodes_pose"] = g["gt_pose"].copy()
+        graphs.append(g)
+    bt = capi.PgoBatch(len(graphs))
+    bt.set_resident(resident)
+    for k, g in enumerate(graphs):
+        bt.graphs[k].add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    stats = bt.optimize(10)
+    assert bt.n_batched == len(graphs)
+    trials = set()
+    for k, g in enumerate(graphs):
+        st1, poses1, _ = _single(capi, g, 10)
+        assert np.array_equal(bt.graphs[k].store()[0], poses1), k
+        for f in ("iterations_done", "lm_trials", "pcg_iterations", "terminated_early"):
+            assert stats[k][f] == st1[f], (k, f, stats[k][f], st1[f])
+        assert stats[k]["chi2_final"] == st1["chi2_final"]
+        trials.add(st1["lm_trials"])
+    assert len(trials) >= 2                                       # the graphs really did not march in step
+    bt.close()

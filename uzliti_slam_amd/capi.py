@@ -543,6 +543,15 @@ class Pgo:
         return {names[i].decode(): dict(ms=ms[i], launches=ln[i]) for i in range(max(n, 0))}
 
 
+class _BorrowedPgo(Pgo):
+    """A Pgo over a handle the batch owns: neither close() nor the finaliser may destroy it."""
+
+    def close(self):
+        self._h = None
+
+    __del__ = close
+
+
 class PgoBatch:
     """uzl_pgo_batch_*: n independent graphs solved through one launch sequence.  `graphs[i]` is an ordinary Pgo over handle i
     (add_graph / set_graph / reset / store); optimize() solves them all and returns one stats dict per graph."""
@@ -566,9 +575,8 @@ class PgoBatch:
             raise UzlError(rc, L.uzl_status_string(rc).decode())
         self.graphs = []
         for i in range(n_graphs):
-            p = Pgo.__new__(Pgo)
+            p = _BorrowedPgo.__new__(_BorrowedPgo)
             p.cfg = c; p._h = C.c_void_p(L.uzl_pgo_batch_graph(self._b, i)); p.n = 0; p.e_in = 0
-            p.close = lambda: None                       # borrowed: the batch destroys it
             self.graphs.append(p)
         self.n_batched = 0
 
@@ -584,6 +592,12 @@ class PgoBatch:
             d = st[i].as_dict(); d["status"] = rc
             out.append(d)
         return out
+
+    def set_resident(self, n):
+        """graphs solved at a time (0 = all); the rest of the batch waits in a queue and takes the slots of finished graphs"""
+        rc = lib().uzl_pgo_batch_set_resident(self._b, C.c_int32(n))
+        if rc != UZL_OK:
+            raise UzlError(rc, "uzl_pgo_batch_set_resident")
 
     def set_profiling(self, on):
         lib().uzl_pgo_batch_set_profiling(self._b, C.c_int32(1 if on else 0))

@@ -2183,7 +2183,7 @@ __global__ __launch_bounds__(kCgBlk) void ml_init_batch_kernel(const BatchSlot* 
 {
     const BatchSlot& S = slots[blockIdx.z];
     const BatchDyn dy = dyn[blockIdx.z];
-    if (!(dy.mask & kPhSolve)) return;
+    if (!(dy.mask & kPhInit)) return;
     ml_init_kernel_body<1>(S.D, S.hot[dy.ix], S.pbuf[0], S.pbuf[1], S.rg[dy.ix][0]);
 }
 // PCG iteration i of a replay (parity = i & 1): p_old = pbuf[parity], p_new = pbuf[parity ^ 1].  Four rows per wave, two waves per
@@ -2201,7 +2201,7 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_comp_batch_kernel(const BatchSlo
 {
     const BatchSlot& S = slots[blockIdx.z];
     const BatchDyn dy = dyn[blockIdx.z];
-    if (!(dy.mask & kPhSolve)) return;
+    if (!(dy.mask & (init ? kPhInit : kPhSolve))) return;
     if (init) ml_cg_comp_kernel_body<kCompU>(S.D, S.hot[dy.ix], S.pbuf[0], S.rg[dy.ix][0], S.rg[dy.ix][1], 0, 1);
     else ml_cg_comp_kernel_body<kCompU>(S.D, S.hot[dy.ix], S.pbuf[parity ^ 1], S.rg[dy.ix][parity ^ 1], S.rg[dy.ix][parity], S.g_rows, 0);
 }

@@ -144,7 +144,8 @@ struct MlHot {
 // blockIdx.z instead of the kernel-argument segment: same arithmetic, same order, bit-identical results.  The host's scalar
 // decisions (which graphs linearise, rebuild, take another trial) reach the kernels as a phase mask per graph.
 constexpr int kBatchMax = 256;
-enum BatchPhase : int32_t { kPhLin = 1, kPhNumeric = 2, kPhTrialBuild = 4, kPhTrialCur = 8, kPhSolve = 16, kPhEval = 32, kPhLambda = 64 };
+enum BatchPhase : int32_t { kPhLin = 1, kPhNumeric = 2, kPhTrialBuild = 4, kPhTrialCur = 8, kPhSolve = 16, kPhEval = 32, kPhLambda = 64,
+                            kPhInit = 128 /* x = 0, r = b, first preconditioner application: graphs that START a solve this pass */ };
 struct BatchSlot {
     PgoDev D;                                  // pose / pose_trial unused: the pose buffers are picked through BatchDyn::cur
     MlHot hot[2];                              // hot subset of the two hierarchy copies

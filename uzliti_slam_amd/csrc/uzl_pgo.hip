@@ -1548,7 +1548,9 @@ struct uzl_pgo_batch {
     PgoHostScal* d_pub = nullptr;
     uint32_t pub_seq = 0;
     DevBuf<double> d_start;               // poses at the start of the solve (anomaly fallback)
-    std::vector<uint64_t> slot_gen;       // structure generation each slot was built from
+    std::vector<BatchSlot> slot_host;     // host copies of the resident slots (source of the refill copies)
+    int32_t resident = 0;                 // graphs solved at a time (0 = all): uzl_pgo_batch_set_resident
+    int graph_rows = 0, graph_nb = 0, replay_nb = 1;      // grid the captured replay was built for / largest system of this optimize
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     int32_t last_batched = 0;
     KernelTimer timer;                    // profiling (uzl_pgo_batch_set_profiling): the two PCG kernels, launched eagerly with event pairs
@@ -1587,7 +1589,7 @@ void batch_upload_dyn(uzl_pgo_batch* b, const std::vector<BatchDyn>& dyn)
 
 void batch_fetch(uzl_pgo_batch* b)
 {
-    const int B = (int)b->h.size();
+    const int B = (int)b->slot_host.size();          // resident slots
     const uint32_t seq = ++b->pub_seq;
     kb_publish(b->d_slots.p, B, b->d_pub, seq, b->stream);
     const auto t0 = std::chrono::steady_clock::now();
@@ -1608,8 +1610,7 @@ void batch_fetch(uzl_pgo_batch* b)
 // single-graph replay (enqueue_pcg_pairs): the stop decision is part of the arithmetic that must agree bit for bit
 void batch_pcg_replay(uzl_pgo_batch* b, int B, int g_rows, bool small, double tol2, hipStream_t s, hipEvent_t* ev)
 {
-    int max_nb = 1;
-    for (const uzl_pgo* h : b->h) max_nb = std::max(max_nb, h->nb);
+    const int max_nb = b->replay_nb;
     static_assert(kProgressEvery % 2 == 0, "the direction buffers ping-pong: a look falls on an even iteration");
     for (int at = 0; at < 2 * kGraphPairs; at += kProgressEvery) {
         const int chunk = std::min(kProgressEvery, 2 * kGraphPairs - at);
@@ -1629,41 +1630,6 @@ bool batch_eligible(const uzl_pgo_batch* b)
             h->ml_ns_steps != a->ml_ns_steps || h->ml_levels != a->ml_levels || h->cfg.device != a->cfg.device) return false;
     }
     return (int)b->h.size() <= kBatchMax;
-}
-
-void batch_build_slots(uzl_pgo_batch* b)
-{
-    const int B = (int)b->h.size();
-    bool stale = b->slot_gen.size() != (size_t)B;
-    for (int g = 0; g < B && !stale; g++) stale = b->slot_gen[g] != b->h[g]->structure_gen;
-    if (!stale) return;
-    batch_destroy_graph(b);
-    std::vector<BatchSlot> sl((size_t)B);
-    for (int g = 0; g < B; g++) {
-        uzl_pgo* h = b->h[g];
-        BatchSlot& S = sl[g];
-        memset(&S, 0, sizeof(S));
-        S.D = h->D;
-        for (int c = 0; c < 2; c++) {
-            S.hot[c] = h->mlb[c].hot; S.dml[c] = h->mlb[c].dml;
-            S.rg[c][0] = h->mlb[c].rg[0]; S.rg[c][1] = h->mlb[c].rg[1];
-            for (int l = 0; l <= kMlMaxLevels; l++) S.dense[c][l] = h->ml_dense_ptr[c][l];
-            S.nsT[c] = h->mlb[c].nsT; S.nsX[c] = h->mlb[c].nsX;
-        }
-        S.pbuf[0] = h->d_p.p; S.pbuf[1] = h->d_p2.p;
-        S.pose[0] = h->pose_a.p; S.pose[1] = h->pose_b.p;
-        S.scal2 = h->d_scal2.p;
-        S.g_edges = g_edges_for(h->e); S.g_asm = g_asm_for(h->nb); S.g_oplus = g_oplus_for(h->n); S.g_rows = g_ml_rows(h->nb, 1);
-    }
-    b->d_slots.reserve((size_t)B); b->d_dyn.reserve((size_t)B);
-    b->h_dyn.reserve((size_t)B * kDynRing);
-    b->h_pub.reserve((size_t)B + 1, hipHostMallocMapped | hipHostMallocCoherent);
-    memset(b->h_pub.p, 0, sizeof(PgoHostScal) * ((size_t)B + 1));
-    UZL_HIP(hipHostGetDevicePointer((void**)&b->d_pub, b->h_pub.p, 0));
-    UZL_HIP(hipMemcpyAsync(b->d_slots.p, sl.data(), sizeof(BatchSlot) * (size_t)B, hipMemcpyHostToDevice, b->stream));
-    UZL_HIP(hipStreamSynchronize(b->stream));          // sl is a local
-    b->slot_gen.resize((size_t)B);
-    for (int g = 0; g < B; g++) b->slot_gen[g] = b->h[g]->structure_gen;
 }
 
 int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, int32_t* n_batched)
@@ -1706,220 +1672,298 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
         b->last_batched = 0;
         return rc_all;
     }
-    batch_build_slots(b);
+    // ---- R resident slots over a queue of Q graphs: a graph that has finished hands its slot to the next one in the queue, so that
+    //      one graph which needs 29 LM trials where the others need 20 does not hold the chip for everybody (round 2's lock step)
+    const int Q = B;
+    const int R = std::max(1, std::min(b->resident > 0 ? b->resident : Q, Q));
     hipStream_t s = b->stream;
     const uzl_pgo* h0 = b->h[0];
     const int L = h0->ml_levels, cl = h0->ml_cl, g_rows = g_ml_rows(h0->nb, 1);
     const bool small = ml_comp_small(h0->ml_n[1]);
     const double delta = b->cfg.huber_delta, tol2 = b->cfg.pcg_tol * b->cfg.pcg_tol;
-    int max_g_edges = 1, max_g_asm = 1, max_g_oplus = 1, max_inner = 0;
+    int max_g_edges = 1, max_g_asm = 1, max_g_oplus = 1, max_inner = 0, max_nb = 1, max_rows = g_rows;
     std::vector<int> n_lv((size_t)L + 2, 0), max_wt((size_t)L + 2, 0), max_wr((size_t)L + 2, 0);
     for (int l = 0; l <= L; l++) n_lv[l] = h0->ml_n[l];
     for (const uzl_pgo* h : b->h) {
         max_g_edges = std::max(max_g_edges, g_edges_for(h->e)); max_g_asm = std::max(max_g_asm, g_asm_for(h->nb));
         max_g_oplus = std::max(max_g_oplus, g_oplus_for(h->n)); max_inner = std::max(max_inner, h->ml_inner_aggs);
+        max_nb = std::max(max_nb, h->nb); max_rows = std::max(max_rows, g_ml_rows(h->nb, 1));
         for (int l = 0; l <= L; l++) {
             max_wt[l] = std::max(max_wt[l], h->ml_nslots[l] + h->ml_n[l]);
             max_wr[l] = std::max(max_wr[l], h->ml_nslots[l] + h->ml_n[l]);
         }
     }
-    // start poses (anomaly fallback) and LM state
-    size_t tot_n = 0;
-    for (const uzl_pgo* h : b->h) tot_n += (size_t)h->n * 8;
-    b->d_start.reserve(std::max<size_t>(tot_n, 8));
-    std::vector<BatchLM> G((size_t)B);
-    {
-        size_t off = 0;
-        for (int g = 0; g < B; g++) {
-            uzl_pgo* h = b->h[g];
-            UZL_HIP(hipMemcpyAsync(b->d_start.p + off, h->cur, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
-            off += (size_t)h->n * 8;
-            memset(&G[g].S, 0, sizeof(uzl_pgo_stats));
-            G[g].S.n_vertices = h->n; G[g].S.n_edges = h->e; G[g].S.n_gauge_fixed = h->n_gauge;
-            G[g].S.structure_ms = structure_ms[g]; G[g].S.structure_reused = reused[g];
-            G[g].cur = (h->cur == h->pose_a.p) ? 0 : 1;
-            h->ml_ix = 0; h->ml_pending = false;
+    // device tables: R slots; the captured PCG replay reads them at run time, so refilling a slot needs no new capture
+    if ((int)b->slot_host.size() != R || b->graph_rows != max_rows || b->graph_nb != max_nb) batch_destroy_graph(b);
+    b->slot_host.assign((size_t)R, BatchSlot{});
+    b->d_slots.reserve((size_t)R); b->d_dyn.reserve((size_t)R);
+    b->h_dyn.reserve((size_t)R * kDynRing);
+    b->h_pub.reserve((size_t)R + 1, hipHostMallocMapped | hipHostMallocCoherent);
+    memset(b->h_pub.p, 0, sizeof(PgoHostScal) * ((size_t)R + 1));
+    UZL_HIP(hipHostGetDevicePointer((void**)&b->d_pub, b->h_pub.p, 0));
+    auto make_slot = [&](int g) {
+        uzl_pgo* h = b->h[g];
+        BatchSlot S;
+        memset(&S, 0, sizeof(S));
+        S.D = h->D;
+        for (int c = 0; c < 2; c++) {
+            S.hot[c] = h->mlb[c].hot; S.dml[c] = h->mlb[c].dml;
+            S.rg[c][0] = h->mlb[c].rg[0]; S.rg[c][1] = h->mlb[c].rg[1];
+            for (int l = 0; l <= kMlMaxLevels; l++) S.dense[c][l] = h->ml_dense_ptr[c][l];
+            S.nsT[c] = h->mlb[c].nsT; S.nsX[c] = h->mlb[c].nsX;
         }
+        S.pbuf[0] = h->d_p.p; S.pbuf[1] = h->d_p2.p;
+        S.pose[0] = h->pose_a.p; S.pose[1] = h->pose_b.p;
+        S.scal2 = h->d_scal2.p;
+        S.g_edges = g_edges_for(h->e); S.g_asm = g_asm_for(h->nb); S.g_oplus = g_oplus_for(h->n); S.g_rows = g_ml_rows(h->nb, 1);
+        return S;
+    };
+    // start poses (anomaly fallback) and LM state of every graph of the queue
+    size_t tot_n = 0;
+    std::vector<size_t> start_off((size_t)Q, 0);
+    for (int g = 0; g < Q; g++) { start_off[g] = tot_n; tot_n += (size_t)b->h[g]->n * 8; }
+    b->d_start.reserve(std::max<size_t>(tot_n, 8));
+    std::vector<BatchLM> G((size_t)Q);
+    for (int g = 0; g < Q; g++) {
+        uzl_pgo* h = b->h[g];
+        UZL_HIP(hipMemcpyAsync(b->d_start.p + start_off[g], h->cur, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
+        memset(&G[g].S, 0, sizeof(uzl_pgo_stats));
+        G[g].S.n_vertices = h->n; G[g].S.n_edges = h->e; G[g].S.n_gauge_fixed = h->n_gauge;
+        G[g].S.structure_ms = structure_ms[g]; G[g].S.structure_reused = reused[g];
+        G[g].cur = (h->cur == h->pose_a.p) ? 0 : 1;
+        h->ml_ix = 0; h->ml_pending = false;
     }
+    std::vector<int> slot_graph((size_t)R, -1);
+    int next_graph = 0;
+    auto load_slot = [&](int sl) {                       // the next graph of the queue into slot sl (stream-ordered behind what the slot ran)
+        if (next_graph >= Q) { slot_graph[sl] = -1; return; }
+        const int g = next_graph++;
+        slot_graph[sl] = g;
+        b->slot_host[sl] = make_slot(g);
+        UZL_HIP(hipMemcpyAsync(b->d_slots.p + sl, &b->slot_host[sl], sizeof(BatchSlot), hipMemcpyHostToDevice, s));
+    };
+    for (int sl = 0; sl < R; sl++) load_slot(sl);
     const bool eager = h0->no_graph || b->timer.on;      // UZL_NO_GRAPH=1 (rocprofv3 --kernel-trace runs) / profiling: the replay's launches one by one
     b->timer.reset();
-    if (!b->graph_exec && !eager) {       // the PCG replay: 2 x kGraphPairs iterations of all graphs
+    b->replay_nb = max_nb;
+    if (!b->graph_exec && !eager) {       // the PCG replay: 2 x kGraphPairs iterations of all resident graphs
         UZL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        batch_pcg_replay(b, B, g_rows, small, tol2, s, nullptr);
+        batch_pcg_replay(b, R, max_rows, small, tol2, s, nullptr);
         UZL_HIP(hipStreamEndCapture(s, &b->graph));
         UZL_HIP(hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
+        b->graph_rows = max_rows; b->graph_nb = max_nb;
     }
-    std::vector<BatchDyn> dyn((size_t)B);
+    std::vector<BatchDyn> dyn((size_t)R);
     auto base_dyn = [&]() {
-        for (int g = 0; g < B; g++) {
-            memset(&dyn[g], 0, sizeof(BatchDyn));
-            dyn[g].cur = G[g].cur; dyn[g].ix = G[g].ml_ix; dyn[g].build_ix = G[g].ml_ix;
+        for (int sl = 0; sl < R; sl++) {
+            memset(&dyn[sl], 0, sizeof(BatchDyn));
+            const int g = slot_graph[sl];
+            if (g < 0) continue;
+            dyn[sl].cur = G[g].cur; dyn[sl].ix = G[g].ml_ix; dyn[sl].build_ix = G[g].ml_ix;
         }
     };
-    int max_nb = 1;
-    for (const uzl_pgo* h : b->h) max_nb = std::max(max_nb, h->nb);
+    // Every resident graph is in one of four phases; a pass of the loop serves all of them through the phase masks, so graphs that are
+    // at different LM iterations - or solving systems that need different numbers of PCG iterations - never wait for each other longer
+    // than one replay (2 x kGraphPairs iterations):
+    //   Lin    linearise (first iteration: numeric set-up, chi2, lambda_0), rebuilds that run ahead            -> Start
+    //   Start  lambda, trial set-up if due, x = 0 / r = b / first preconditioner application                   -> Solve
+    //   Solve  PCG replays until the graph's `done` flag                                                       -> Eval
+    //   Eval   retraction, chi2 of the trial, rho, accept / reject                                             -> Lin | Start | finished
+    // The order of operations each graph sees is do_optimize's: results do not depend on who shares its launches.
+    enum { PLin = 0, PStart = 1, PSolve = 2, PEval = 3 };
+    std::vector<int> phase((size_t)Q, PLin), launched_g((size_t)Q, 0);
+    auto active = [&](int sl) { return slot_graph[sl] >= 0 && !G[slot_graph[sl]].finished; };
     const int max_it = b->cfg.pcg_max_iter > 0 ? b->cfg.pcg_max_iter : 6 * max_nb;
-    int prev_pcg = 0;
-    int n_active = B;
+    int n_active = 0;
+    for (int sl = 0; sl < R; sl++) n_active += active(sl) ? 1 : 0;
     while (n_active > 0) {
-        // ---- stage 1: linearise the graphs that start a new LM iteration; first iteration: numeric set-up, chi2 and lambda_0
+        // ---- Lin: linearise the graphs that start a new LM iteration; first iteration: numeric set-up, chi2 and lambda_0
         base_dyn();
         bool any_lin = false, any_it0 = false;
-        for (int g = 0; g < B; g++) {
-            BatchLM& X = G[g];
-            if (X.finished || !X.need_lin) continue;
+        for (int sl = 0; sl < R; sl++) {
+            if (!active(sl) || phase[slot_graph[sl]] != PLin) continue;
+            BatchLM& X = G[slot_graph[sl]];
             X.adopted = false;
             if (X.pending) { X.ml_ix ^= 1; X.pending = false; X.adopted = true; }
-            dyn[g].ix = X.ml_ix; dyn[g].build_ix = X.ml_ix;
-            dyn[g].mask |= kPhLin;
+            dyn[sl].ix = X.ml_ix; dyn[sl].build_ix = X.ml_ix;
+            dyn[sl].mask |= kPhLin;
             any_lin = true;
-            if (X.it == 0) { dyn[g].mask |= kPhNumeric; any_it0 = true; }
+            if (X.it == 0) { dyn[sl].mask |= kPhNumeric; any_it0 = true; }
         }
-        std::vector<uint8_t> ahead((size_t)B, 0);
         if (any_lin) {
+            std::vector<uint8_t> ahead((size_t)R, 0);
             batch_upload_dyn(b, dyn);
-            kb_linearize(b->d_slots.p, b->d_dyn.p, B, max_g_edges, max_g_asm, delta, s);
-            for (int g = 0; g < B; g++) {
-                BatchLM& X = G[g];
-                if (!(dyn[g].mask & kPhLin)) continue;
+            kb_linearize(b->d_slots.p, b->d_dyn.p, R, max_g_edges, max_g_asm, delta, s);
+            for (int sl = 0; sl < R; sl++) {
+                if (!(dyn[sl].mask & kPhLin)) continue;
+                BatchLM& X = G[slot_graph[sl]];
                 const bool refresh = X.it == 0 || always_refresh || X.last_rel > refresh_rel || X.pcg_last > X.pcg_ref + X.pcg_ref / 3 + 4;
                 if (refresh) {
                     X.S.precond_builds++;
-                    if (X.it == 0) X.trial_setup = true; else ahead[g] = 1;
+                    if (X.it == 0) X.trial_setup = true; else ahead[sl] = 1;
                 }
+                phase[slot_graph[sl]] = PStart;
             }
             if (any_it0) {
-                kb_ml_numeric(b->d_slots.p, b->d_dyn.p, B, L, n_lv.data(), max_wt.data(), max_wr.data(), s);
+                kb_ml_numeric(b->d_slots.p, b->d_dyn.p, R, L, n_lv.data(), max_wt.data(), max_wr.data(), s);
                 batch_fetch(b);
-                for (int g = 0; g < B; g++) {
-                    BatchLM& X = G[g];
-                    if (!(dyn[g].mask & kPhLin) || X.it != 0) continue;
-                    X.current_chi = b->h_pub.p[g].scal[4];
+                for (int sl = 0; sl < R; sl++) {
+                    if (!(dyn[sl].mask & kPhLin)) continue;
+                    BatchLM& X = G[slot_graph[sl]];
+                    if (X.it != 0) continue;
+                    X.current_chi = b->h_pub.p[sl].scal[4];
                     X.S.chi2_initial = X.current_chi;
-                    X.lambda = 1e-5 * b->h_pub.p[g].scal[6];                        // computeLambdaInit: tau * max diag
+                    X.lambda = 1e-5 * b->h_pub.p[sl].scal[6];                        // computeLambdaInit: tau * max diag
                     X.ni = 2.;
                 }
             }
+            // rebuilds that run ahead: into the copy the PCG does not use, with this iteration's lambda; adopted next iteration
+            bool any_ahead = false;
+            base_dyn();
+            for (int sl = 0; sl < R; sl++) {
+                if (!ahead[sl]) continue;
+                BatchLM& X = G[slot_graph[sl]];
+                dyn[sl].mask = kPhNumeric | kPhTrialBuild; dyn[sl].build_ix = X.ml_ix ^ 1; dyn[sl].build_scal2 = 1; dyn[sl].lambda_build = X.lambda;
+                X.lambda_setup[X.ml_ix ^ 1] = X.lambda; X.pending = true;
+                any_ahead = true;
+            }
+            if (any_ahead) {
+                batch_upload_dyn(b, dyn);
+                kb_set_lambda(b->d_slots.p, b->d_dyn.p, R, s);
+                kb_ml_numeric(b->d_slots.p, b->d_dyn.p, R, L, n_lv.data(), max_wt.data(), max_wr.data(), s);
+                kb_ml_trial(b->d_slots.p, b->d_dyn.p, R, 0, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s);
+            }
         }
-        // ---- stage 2: rebuilds that run ahead: into the copy the PCG does not use, with this iteration's lambda; adopted next iteration
-        bool any_ahead = false;
+        // ---- Start: one LM trial of the graphs that have a system to solve: lambda, trial set-up, PCG initialisation
         base_dyn();
-        for (int g = 0; g < B; g++) {
-            if (!ahead[g]) continue;
+        bool any_start = false, any_trial_cur = false;
+        for (int sl = 0; sl < R; sl++) {
+            if (!active(sl) || phase[slot_graph[sl]] != PStart) continue;
+            const int g = slot_graph[sl];
             BatchLM& X = G[g];
-            dyn[g].mask = kPhNumeric | kPhTrialBuild; dyn[g].build_ix = X.ml_ix ^ 1; dyn[g].build_scal2 = 1; dyn[g].lambda_build = X.lambda;
-            X.lambda_setup[X.ml_ix ^ 1] = X.lambda; X.pending = true;
-            any_ahead = true;
-        }
-        if (any_ahead) {
-            batch_upload_dyn(b, dyn);
-            kb_set_lambda(b->d_slots.p, b->d_dyn.p, B, s);
-            kb_ml_numeric(b->d_slots.p, b->d_dyn.p, B, L, n_lv.data(), max_wt.data(), max_wr.data(), s);
-            kb_ml_trial(b->d_slots.p, b->d_dyn.p, B, 0, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s);
-        }
-        // ---- stage 3: one LM trial of every active graph: (H + lambda I) dx = b
-        base_dyn();
-        bool any_trial_cur = false;
-        for (int g = 0; g < B; g++) {
-            BatchLM& X = G[g];
-            if (X.finished) continue;
-            dyn[g].mask = kPhLambda | kPhSolve; dyn[g].lambda = X.lambda;
+            dyn[sl].mask = kPhLambda | kPhInit; dyn[sl].lambda = X.lambda;
             if (X.qmax == 0) X.tol_f2 = tol_factor2(X.it, X.last_rel, X.pcg_last);           // fixed for the trials of one LM iteration, like do_optimize
-            dyn[g].tol_factor2 = X.tol_f2; dyn[g].eps_t = kStepT * b->h[g]->cfg.pcg_tol; dyn[g].eps_r = kStepR * b->h[g]->cfg.pcg_tol;
+            dyn[sl].tol_factor2 = X.tol_f2; dyn[sl].eps_t = kStepT * b->h[g]->cfg.pcg_tol; dyn[sl].eps_r = kStepR * b->h[g]->cfg.pcg_tol;
             if (X.lambda > 8. * X.lambda_setup[X.ml_ix]) X.trial_setup = true;
             X.fresh = X.trial_setup || (X.adopted && X.qmax == 0);
-            if (X.trial_setup) { dyn[g].mask |= kPhTrialCur; X.lambda_setup[X.ml_ix] = X.lambda; X.trial_setup = false; any_trial_cur = true; }
+            if (X.trial_setup) { dyn[sl].mask |= kPhTrialCur; X.lambda_setup[X.ml_ix] = X.lambda; X.trial_setup = false; any_trial_cur = true; }
+            phase[g] = PSolve; launched_g[g] = 0;
+            any_start = true;
         }
-        batch_upload_dyn(b, dyn);
-        kb_set_lambda(b->d_slots.p, b->d_dyn.p, B, s);
-        if (any_trial_cur) kb_ml_trial(b->d_slots.p, b->d_dyn.p, B, 1, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s);
-        kb_ml_init(b->d_slots.p, b->d_dyn.p, B, g_rows, small, s);
-        {
-            int launched = 0;
-            int want = prev_pcg > 0 ? std::max(2 * kGraphPairs, (prev_pcg * 95) / 100) : 2 * kGraphPairs;
-            while (true) {
-                want = std::min(want, max_it - launched);
-                const int reps = std::max(1, (want + 2 * kGraphPairs - 1) / (2 * kGraphPairs));
-                for (int i = 0; i < reps; i++) {
-                    if (eager && b->timer.on) {
-                        std::vector<hipEvent_t> ev((size_t)8 * kGraphPairs);
-                        for (int q = 0; q < 2 * kGraphPairs; q++) {
-                            b->timer.pair("ml_spmv_batch", &ev[4 * q], &ev[4 * q + 1]);
-                            b->timer.pair("ml_cg_comp_batch", &ev[4 * q + 2], &ev[4 * q + 3]);
-                        }
-                        batch_pcg_replay(b, B, g_rows, small, tol2, s, ev.data());
-                    } else if (eager) batch_pcg_replay(b, B, g_rows, small, tol2, s, nullptr);
-                    else UZL_HIP(hipGraphLaunch(b->graph_exec, s));
-                }
-                launched += reps * 2 * kGraphPairs;
-                kb_residual_guard(b->d_slots.p, b->d_dyn.p, B, s);
-                batch_fetch(b);
-                if (b->timer.on) { UZL_HIP(hipStreamSynchronize(s)); b->timer.resolve(); }
-                bool all_done = true;
-                for (int g = 0; g < B; g++) if ((dyn[g].mask & kPhSolve) && !b->h_pub.p[g].flags[0]) all_done = false;
-                if (all_done || launched >= max_it) break;
-                want = 2 * kGraphPairs;
+        if (any_start) {
+            batch_upload_dyn(b, dyn);
+            kb_set_lambda(b->d_slots.p, b->d_dyn.p, R, s);
+            if (any_trial_cur) kb_ml_trial(b->d_slots.p, b->d_dyn.p, R, 1, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s);
+            kb_ml_init(b->d_slots.p, b->d_dyn.p, R, max_rows, small, s);
+        }
+        // ---- Solve: replays for every graph in a solve.  As many as the graph that is closest to its predicted end still needs (so the
+        //      first one to finish is seen at once), at least one.
+        base_dyn();
+        int reps = 1 << 30;
+        bool any_solve = false;
+        for (int sl = 0; sl < R; sl++) {
+            if (!active(sl) || phase[slot_graph[sl]] != PSolve) continue;
+            const int g = slot_graph[sl];
+            dyn[sl].mask = kPhSolve;
+            any_solve = true;
+            const int want = std::max(2 * kGraphPairs, (G[g].pcg_last * 95) / 100 - launched_g[g]);
+            const int rg = std::max(1, want / (2 * kGraphPairs));
+            reps = (R == Q) ? (reps == (1 << 30) ? rg : std::max(reps, rg)) : std::min(reps, rg);      // in step: everybody waits for the slowest anyway
+        }
+        // With every graph resident (no queue) the graphs are kept in step instead: the solve stage runs until ALL of them are done, so
+        // that they linearise, rebuild their preconditioners and evaluate in the same passes - a rebuild is ~25 small launches whatever
+        // the number of graphs that take part, and sixteen graphs out of step would pay them in almost every pass (measured at 16
+        // config-2 graphs: 47 M edges/s in step, 42 M out of step; with a queue behind 64 slots the free-running loop wins).
+        const bool in_step = R == Q;
+        while (any_solve) {
+            batch_upload_dyn(b, dyn);
+            for (int i = 0; i < reps; i++) {
+                if (eager && b->timer.on) {
+                    std::vector<hipEvent_t> ev((size_t)8 * kGraphPairs);
+                    for (int q = 0; q < 2 * kGraphPairs; q++) {
+                        b->timer.pair("ml_spmv_batch", &ev[4 * q], &ev[4 * q + 1]);
+                        b->timer.pair("ml_cg_comp_batch", &ev[4 * q + 2], &ev[4 * q + 3]);
+                    }
+                    batch_pcg_replay(b, R, max_rows, small, tol2, s, ev.data());
+                } else if (eager) batch_pcg_replay(b, R, max_rows, small, tol2, s, nullptr);
+                else UZL_HIP(hipGraphLaunch(b->graph_exec, s));
             }
+            kb_residual_guard(b->d_slots.p, b->d_dyn.p, R, s);
+            batch_fetch(b);
+            if (b->timer.on) { UZL_HIP(hipStreamSynchronize(s)); b->timer.resolve(); }
             UZL_HIP(hipGetLastError());
-        }
-        prev_pcg = 0;
-        for (int g = 0; g < B; g++) {
-            BatchLM& X = G[g];
-            if (!(dyn[g].mask & kPhSolve)) continue;
-            const PgoHostScal& P = b->h_pub.p[g];
-            bool conv = P.flags[0] != 0 && P.flags[2] == 0;
-            if (conv && !(P.scal[7] <= kResidualGuard)) conv = false;
-            const int its = P.flags[1];
-            X.S.pcg_iterations += its; X.S.lm_trials++;
-            prev_pcg = std::max(prev_pcg, its);
-            if (!conv) {                                                          // the single-graph path sorts it out from the start poses
-                if (b->h[g]->cfg.verbose)
-                    fprintf(stderr, "[uzl_pgo_batch] graph %d it %d trial %d lambda %.3e: pcg %d done %d breakdown %d |r|2/|b|2 %.3e -> single-graph path\n",
-                            g, X.it, X.qmax, X.lambda, its, (int)P.flags[0], (int)P.flags[2], P.scal[7]);
-                X.anomaly = true; X.finished = true; n_active--; continue;
+            bool still = false;
+            for (int sl = 0; sl < R; sl++) {
+                if (!(dyn[sl].mask & kPhSolve)) continue;
+                const int g = slot_graph[sl];
+                BatchLM& X = G[g];
+                launched_g[g] += reps * 2 * kGraphPairs;
+                const PgoHostScal& P = b->h_pub.p[sl];
+                if (!P.flags[0] && launched_g[g] < max_it) { still = true; continue; }    // still iterating
+                dyn[sl].mask = 0;                                                     // (in step: the next replays of this stage are not this graph's)
+                bool conv = P.flags[0] != 0 && P.flags[2] == 0;
+                if (conv && !(P.scal[7] <= kResidualGuard)) conv = false;
+                const int its = P.flags[1];
+                X.S.pcg_iterations += its; X.S.lm_trials++;
+                if (!conv) {                                                          // the single-graph path sorts it out from the start poses
+                    if (b->h[g]->cfg.verbose)
+                        fprintf(stderr, "[uzl_pgo_batch] graph %d it %d trial %d lambda %.3e: pcg %d done %d breakdown %d |r|2/|b|2 %.3e -> single-graph path\n",
+                                g, X.it, X.qmax, X.lambda, its, (int)P.flags[0], (int)P.flags[2], P.scal[7]);
+                    X.anomaly = true; X.finished = true; continue;
+                }
+                if (X.fresh) X.pcg_ref = its;
+                X.pcg_last = its;
+                phase[g] = PEval;
             }
-            if (X.fresh) X.pcg_ref = its;
-            X.pcg_last = its;
+            if (!(in_step && still)) break;
+            reps = 1;
         }
-        // ---- stage 4: retraction, chi2 of the trial, rho, accept / reject
+        // ---- Eval: retraction, chi2 of the trial, rho, accept / reject
         base_dyn();
         bool any_eval = false;
-        for (int g = 0; g < B; g++) if (!G[g].finished) { dyn[g].mask = kPhEval; any_eval = true; }
-        if (!any_eval) break;
-        batch_upload_dyn(b, dyn);
-        kb_eval(b->d_slots.p, b->d_dyn.p, B, max_g_edges, max_g_oplus, delta, s);
-        batch_fetch(b);
-        for (int g = 0; g < B; g++) {
-            BatchLM& X = G[g];
-            if (!(dyn[g].mask & kPhEval)) continue;
-            const double temp_chi = b->h_pub.p[g].scal[4];
-            const double scale = b->h_pub.p[g].scal[5] + 1e-3;                    // computeScale + 1e-3
-            const double rho = (X.current_chi - temp_chi) / scale;
-            if (rho > 0 && std::isfinite(temp_chi)) {                             // good step
-                double alpha = 1. - std::pow(2 * rho - 1, 3);
-                alpha = std::min(alpha, 2. / 3.);
-                X.lambda *= std::max(1. / 3., alpha);
-                X.ni = 2.;
-                X.last_rel = std::fabs(X.current_chi - temp_chi) / std::max(std::fabs(temp_chi), 1e-300);
-                X.current_chi = temp_chi;
-                X.cur ^= 1;                                                       // discardTop
-            } else {
-                X.lambda *= X.ni;
-                X.ni *= 2.;
+        for (int sl = 0; sl < R; sl++) if (active(sl) && phase[slot_graph[sl]] == PEval) { dyn[sl].mask = kPhEval; any_eval = true; }
+        if (any_eval) {
+            batch_upload_dyn(b, dyn);
+            kb_eval(b->d_slots.p, b->d_dyn.p, R, max_g_edges, max_g_oplus, delta, s);
+            batch_fetch(b);
+            for (int sl = 0; sl < R; sl++) {
+                if (!(dyn[sl].mask & kPhEval)) continue;
+                const int g = slot_graph[sl];
+                BatchLM& X = G[g];
+                const double temp_chi = b->h_pub.p[sl].scal[4];
+                const double scale = b->h_pub.p[sl].scal[5] + 1e-3;                    // computeScale + 1e-3
+                const double rho = (X.current_chi - temp_chi) / scale;
+                if (rho > 0 && std::isfinite(temp_chi)) {                             // good step
+                    double alpha = 1. - std::pow(2 * rho - 1, 3);
+                    alpha = std::min(alpha, 2. / 3.);
+                    X.lambda *= std::max(1. / 3., alpha);
+                    X.ni = 2.;
+                    X.last_rel = std::fabs(X.current_chi - temp_chi) / std::max(std::fabs(temp_chi), 1e-300);
+                    X.current_chi = temp_chi;
+                    X.cur ^= 1;                                                       // discardTop
+                } else {
+                    X.lambda *= X.ni;
+                    X.ni *= 2.;
+                }
+                X.qmax++;
+                if (rho < 0 && X.qmax < 10) { phase[g] = PStart; continue; }          // another trial on the same linearisation
+                X.S.iterations_done = X.it + 1;
+                if (X.qmax == 10 || rho == 0) { X.S.terminated_early = 1; X.finished = true; continue; }     // Terminate
+                X.it++; X.qmax = 0; phase[g] = PLin;
+                if (X.it >= iterations) X.finished = true;
             }
-            X.qmax++;
-            if (rho < 0 && X.qmax < 10) { X.need_lin = false; continue; }         // another trial on the same linearisation
-            X.S.iterations_done = X.it + 1;
-            if (X.qmax == 10 || rho == 0) { X.S.terminated_early = 1; X.finished = true; n_active--; continue; }     // Terminate
-            X.it++; X.qmax = 0; X.need_lin = true;
-            if (X.it >= iterations) { X.finished = true; n_active--; }
+        }
+        // ---- slots whose graph is through take the next one of the queue
+        n_active = 0;
+        for (int sl = 0; sl < R; sl++) {
+            if (slot_graph[sl] >= 0 && G[slot_graph[sl]].finished) load_slot(sl);
+            n_active += active(sl) ? 1 : 0;
         }
     }
     UZL_HIP(hipStreamSynchronize(s));
     const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     int batched = 0;
-    size_t off = 0;
-    for (int g = 0; g < B; g++) {
+    for (int g = 0; g < Q; g++) {
         uzl_pgo* h = b->h[g];
         BatchLM& X = G[g];
         if (!X.anomaly) {
@@ -1928,7 +1972,7 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             if (stats) stats[g] = X.S;
             batched++;
         } else {
-            UZL_HIP(hipMemcpyAsync(h->cur, b->d_start.p + off, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
+            UZL_HIP(hipMemcpyAsync(h->cur, b->d_start.p + start_off[g], sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
             UZL_HIP(hipStreamSynchronize(s));
             uzl_pgo_stats S;
             const int rc = do_optimize(h, iterations, &S);
@@ -1936,7 +1980,6 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             if (rc != UZL_OK) rc_all = rc;
             if (stats) stats[g] = S;
         }
-        off += (size_t)h->n * 8;
     }
     b->last_batched = batched;
     if (n_batched) *n_batched = batched;
@@ -1995,6 +2038,14 @@ void uzl_pgo_batch_destroy(uzl_pgo_batch* b)
 const char* uzl_pgo_batch_last_error(uzl_pgo_batch* b) { return b ? b->last_error.c_str() : "null handle"; }
 int uzl_pgo_batch_size(uzl_pgo_batch* b) { return b ? (int)b->h.size() : UZL_ERR_BAD_ARG; }
 uzl_pgo* uzl_pgo_batch_graph(uzl_pgo_batch* b, int32_t i) { return (b && i >= 0 && i < (int32_t)b->h.size()) ? b->h[(size_t)i] : nullptr; }
+
+int uzl_pgo_batch_set_resident(uzl_pgo_batch* b, int32_t n_resident)
+{
+    if (!b || n_resident < 0) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(b->mu);
+    b->resident = n_resident;
+    return UZL_OK;
+}
 
 int uzl_pgo_batch_set_profiling(uzl_pgo_batch* b, int32_t on)
 {
