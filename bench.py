@@ -679,7 +679,7 @@ def main():
         from uzliti_slam_amd import online
         run = synth.make_online_run(a.online_nodes, a.online_pairs, n_kp=a.keypoints)
         o = online.OnlineSlam(run, device=dev, rank=dist.rank, world=dist.world, tdist=dist.dist, match_batch=512)
-        o.keep_poses_per_solve = 40                    # the CPU replay (cpu_baseline below) is compared with the poses at its last interval
+        o.keep_poses_per_solve = 1000                   # the CPU replay (cpu_baseline below) is compared with the poses at its last interval
         o.upload_frames()
         dist.barrier(); t0 = time.perf_counter()
         o.run_all()

@@ -263,6 +263,7 @@ __global__ __launch_bounds__(64) void gate_wave_kernel(GateWaveArgs a)
             }
             n_list += cnt;
             n_open += __popcll(__ballot(push && !was_open));
+            __syncthreads();                               // a hub's next 64 neighbours see the states and g-scores this chunk wrote (a neighbour listed in two chunks)
         }
         if (over) break;
         __syncthreads();                                   // pushes and the removal are visible to the next pop

@@ -11,6 +11,7 @@
 // Per LM trial      : D_l(lambda)^-1 = (G_l + lambda M_l)^-1, dense inverse of the <= 48-dof top level
 // Per PCG iteration : ml_spmv (p, A p, restricted A p) -> ml_cg (alpha, coarse chain in LDS, x, r, z)
 #include <hip/hip_ext.h>
+#include <mutex>
 #include "pgo_device.hpp"
 #include "uzl_common.hpp"
 
@@ -2030,7 +2031,13 @@ void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, d
 hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
                    int init, size_t lds, hipStream_t s, hipEvent_t ev_a, hipEvent_t ev_b)
 {
-    static size_t configured[5] = {0, 0, 0, 0, 0};
+    // largest dynamic-LDS size each kernel variant has been raised to, PER DEVICE (a function attribute is per device), under a lock
+    // (handles of several threads / devices share this table)
+    constexpr int kMaxDev = 16;
+    static size_t configured_tab[kMaxDev][5] = {};
+    static std::mutex configured_mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
     const bool comp4 = agg != 1 && ml.Cmat != nullptr;
     const bool ypre = comp4 && ml.levels >= 2 && 6 * ml.n[2] <= 4 * 32 * kYU;       // the six rows of Y_2 fit the registers
     static const bool no_vpre = diag_flag("UZL_NO_VPRE");                            // A/B switch (diagnostic build)
@@ -2039,6 +2046,8 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
     // vertices) held the kernel at two workgroups per CU - 625 workgroups ran in two rounds
     if (comp4) lds = (size_t)6 * ml.n[2] * 8 + 64;
     const int ci = agg == 1 ? 0 : (comp4 ? (ypre ? 3 : (vpre ? 4 : 2)) : 1);
+    std::unique_lock<std::mutex> cfg_lock(configured_mu);
+    size_t* configured = configured_tab[dev];
     if (lds > configured[ci]) {
         const void* fn = agg == 1 ? reinterpret_cast<const void*>(&ml_cg_kernel<1>)
                                   : (comp4 ? (ypre ? reinterpret_cast<const void*>(&ml_cg_kernel<4, true, true>)
@@ -2048,6 +2057,7 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
         if (e != hipSuccess) return e;
         configured[ci] = lds;
     }
+    cfg_lock.unlock();
     if (agg == 1 && ml.Cmat) {           // small graphs: composite coarse operator
         const bool small = 6 * ml.n[1] <= 5 * kCgBlk;
         if (ev_a) {

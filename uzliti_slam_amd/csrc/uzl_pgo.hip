@@ -1773,7 +1773,6 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
     enum { PLin = 0, PStart = 1, PSolve = 2, PEval = 3 };
     std::vector<int> phase((size_t)Q, PLin), launched_g((size_t)Q, 0);
     auto active = [&](int sl) { return slot_graph[sl] >= 0 && !G[slot_graph[sl]].finished; };
-    const int max_it = b->cfg.pcg_max_iter > 0 ? b->cfg.pcg_max_iter : 6 * max_nb;
     int n_active = 0;
     for (int sl = 0; sl < R; sl++) n_active += active(sl) ? 1 : 0;
     while (n_active > 0) {
@@ -1899,7 +1898,8 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
                 BatchLM& X = G[g];
                 launched_g[g] += reps * 2 * kGraphPairs;
                 const PgoHostScal& P = b->h_pub.p[sl];
-                if (!P.flags[0] && launched_g[g] < max_it) { still = true; continue; }    // still iterating
+                const int max_it_g = b->cfg.pcg_max_iter > 0 ? b->cfg.pcg_max_iter : 6 * std::max(b->h[g]->nb, 1);     // the cap uzl_pgo_optimize gives this graph
+                if (!P.flags[0] && launched_g[g] < max_it_g) { still = true; continue; }  // still iterating
                 dyn[sl].mask = 0;                                                     // (in step: the next replays of this stage are not this graph's)
                 bool conv = P.flags[0] != 0 && P.flags[2] == 0;
                 if (conv && !(P.scal[7] <= kResidualGuard)) conv = false;
