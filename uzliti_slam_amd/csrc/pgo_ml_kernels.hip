@@ -1811,7 +1811,7 @@ __global__ __launch_bounds__(256) void ml_alpha_kernel(PgoDev D, MlHot H, const 
 // restrict / top-solve / prolong walk through LDS and its barriers are gone.  Same preconditioner, same results up to
 // rounding as ml_cg_kernel<1>.
 // ------------------------------------------------------------------------------------------------
-// kCompU gather-level values per lane: 5 covers 6 n_1 <= 960 (<= 1280 free vertices), 8 covers 6 n_1 <= 1536 (<= 2048)
+// kCompU gather-level values per lane: 5 covers 6 n_1 <= 960 (<= 1280 free vertices), 8 covers 6 n_1 <= 1536 (<= 2048), 12 <= 2304 (3072), 16 <= 3072 (4096)
 template <int kCompU>
 __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const double* __restrict__ p,
                                                            const double* __restrict__ rg_old, double* __restrict__ rg_new,
@@ -2059,14 +2059,17 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
     }
     cfg_lock.unlock();
     if (agg == 1 && ml.Cmat) {           // small graphs: composite coarse operator
-        const bool small = 6 * ml.n[1] <= 5 * kCgBlk;
-        if (ev_a) {
-            if (small) hipExtLaunchKernelGGL(ml_cg_comp_kernel<5>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
-            else hipExtLaunchKernelGGL(ml_cg_comp_kernel<8>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);
-        } else {
-            if (small) hipLaunchKernelGGL(ml_cg_comp_kernel<5>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, D, ml, p, rg_old, rg_new, n_part, init);
-            else hipLaunchKernelGGL(ml_cg_comp_kernel<8>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, D, ml, p, rg_old, rg_new, n_part, init);
-        }
+        // columns of the dense level-1 operator a lane holds: 5 (6 n_1 <= 960), 8 (<= 1536), 12 (<= 2304), 16 (<= 3072: 4096 free vertices)
+        const int cols = 6 * ml.n[1];
+        const dim3 g(g_ml_rows(D.nb, 1)), t(kCgBlk);
+#define UZL_COMP_LAUNCH(U)                                                                                                              \
+        do { if (ev_a) hipExtLaunchKernelGGL(ml_cg_comp_kernel<U>, g, t, 0, s, ev_a, ev_b, 0, D, ml, p, rg_old, rg_new, n_part, init);  \
+             else hipLaunchKernelGGL(ml_cg_comp_kernel<U>, g, t, 0, s, D, ml, p, rg_old, rg_new, n_part, init); } while (0)
+        if (cols <= 5 * kCgBlk) UZL_COMP_LAUNCH(5);
+        else if (cols <= 8 * kCgBlk) UZL_COMP_LAUNCH(8);
+        else if (cols <= 12 * kCgBlk) UZL_COMP_LAUNCH(12);
+        else UZL_COMP_LAUNCH(16);
+#undef UZL_COMP_LAUNCH
         return hipSuccess;
     }
     if (ev_a) {

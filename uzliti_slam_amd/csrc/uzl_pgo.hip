@@ -364,7 +364,12 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
 {
     h->ml_levels = 0; h->ml_n.assign(1, nb); h->ml_nslots.assign(1, nslots); h->ml_inner_aggs = 0;
     if (h->cfg.preconditioner == 0 || nb <= kMlTopMax) return;
-    static const int agg1_max = diag_int("UZL_ML_AGG1_MAX", 2048);   // up to here the level-1 dense operator applies (6 n_1 <= 1536); above, AGG = 4 with the level-2 one (measured: 2500 vertices 65.7 -> 38.2 ms)
+    // Up to here the level-1 dense operator applies (6 n_1 <= 3072: ml_cg_comp_kernel<16>); above, AGG = 4 with the level-2 one.  Its
+    // rebuild (Newton-Schulz GEMMs, n^3) outgrows what the exact level-1 solve saves in PCG iterations between 3000 and 4000 vertices on
+    // loopy graphs (>= 3 edges per vertex: 3000/12000 20.6 -> 18.3 ms, 4000/16000 24.5 -> 26.3 ms) and later on sparse ones - the shape of a
+    // Schur-reduced online graph (4000/6000 26.0 -> 17.2 ms; config 5's last solve 2328 -> 1288 PCG iterations).
+    static const int agg1_env = diag_int("UZL_ML_AGG1_MAX", 0);
+    const int agg1_max = agg1_env > 0 ? agg1_env : (nslots >= 6 * nb ? 3072 : 4096);
     h->ml_agg = nb <= agg1_max ? 1 : 4;
     int L = 0;
     h->ml_fan.assign(1, 1);
@@ -461,7 +466,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     // Newton-Schulz GEMMs take 7 ms there) that ml_cg_kernel<4> applies instead of its LDS walk
     static const bool comp4_off = diag_flag("UZL_ML_NO_COMP4");             // A/B switch
     static const int comp4_max = diag_int("UZL_ML_COMP4_MAX", 4096);
-    const bool comp1 = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 1536;     // ml_cg_comp_kernel<5> / <8>
+    const bool comp1 = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 3072;     // ml_cg_comp_kernel<5> / <8> / <12> / <16>
     const bool comp4 = !comp_off && !comp4_off && h->ml_agg == 4 && L >= 3 && 6 * h->ml_n[2] <= comp4_max;
     h->ml_comp = comp1 || comp4;
     h->ml_cl = comp1 ? 1 : (comp4 ? 2 : 0);
@@ -1623,7 +1628,7 @@ bool batch_eligible(const uzl_pgo_batch* b)
 {
     const uzl_pgo* a = b->h[0];
     for (const uzl_pgo* h : b->h) {
-        if (!(h->ml_levels > 0 && h->ml_agg == 1 && h->ml_comp && h->ml_mult && h->ml_cl == 1 && !h->sharded && !h->red.on && h->nb > 0 && h->e > 0 &&
+        if (!(h->ml_levels > 0 && h->ml_agg == 1 && h->ml_comp && h->ml_mult && h->ml_cl == 1 && 6 * h->ml_n[1] <= 1536 && !h->sharded && !h->red.on && h->nb > 0 && h->e > 0 &&
               !h->timer.on && h->stream2 != nullptr)) return false;
         // same shape from level 1 up (the level-0 size may differ by the few vertices the gauge / skip rules remove: only grids depend on it)
         if (h->ml_n.size() != a->ml_n.size() || !std::equal(h->ml_n.begin() + 1, h->ml_n.end(), a->ml_n.begin() + 1) ||
