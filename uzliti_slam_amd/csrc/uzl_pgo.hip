@@ -270,6 +270,15 @@ void fetch_scal(uzl_pgo* h)
 constexpr double kStepT = 1.0, kStepR = 0.1, kTolFloor2 = 1e-4;
 constexpr int kProgressEvery = 8;             // PCG iterations between two looks (even; a graph replay of 2 x kGraphPairs iterations ends with one)
 inline double tol_factor2(int, double, int) { return kTolFloor2; }
+// How stale is a kept preconditioner?  Not the iteration count of the last solve (with an absolute stop test that follows the size of
+// the LM step and lambda, not the operator): the CONTRACTION it delivers, nats of r.M^-1 r per PCG iteration.  rz_stop = scal[1] is
+// pcg_tol^2 * tol_f2 * (r_0.M^-1 r_0).  A rebuild is due when the rate has fallen below kRateDrop of what the operator delivered when fresh.
+constexpr double kRateDrop = 0.6;
+inline double pcg_rate(double rz_stop, double rz_end, int its, double tol2, double tol_f2)
+{
+    const double rz0 = rz_stop / (tol2 * tol_f2);
+    return (its >= 16 && rz0 > 0. && rz_end > 0. && rz_end < rz0) ? std::log(rz0 / rz_end) / its : -1.;      // -1: no estimate (too few iterations)
+}
 
 void set_lambda(uzl_pgo* h, double lambda, double tol_f2)
 {
@@ -1015,7 +1024,8 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     // optimizer_.optimize(iterations) (:148) -> OptimizationAlgorithmLevenberg::solve [EXT]
     double lambda = 0., ni = 2., current_chi = 0.;
     double last_rel = 1e300;
-    int pcg_ref = 1 << 30, pcg_last = 0;
+    int pcg_last = 0;
+    double rate_ref = -1., rate_last = -1.;
     // Asynchronous rebuild: from the second LM iteration on a wanted rebuild runs on stream2 into the OTHER copy of the
     // hierarchy while this iteration's PCG still uses the current one (any SPD preconditioner gives the same solution; one
     // that is one linearisation old costs a few iterations, a rebuild on the critical path costs ~0.4 ms).  The copy is
@@ -1030,9 +1040,20 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         uzl_pgo* h;
         ~DrainRebuild() { if (h->ml_pending) { (void)hipStreamSynchronize(h->stream2); h->ml_pending = false; } }
     } drain{h};
+    // diagnostic build, UZL_PHASES=1: GPU time between phase marks of every LM iteration (events on the solver's stream, graph replays as
+    // in production), printed after the solve
+    static const bool phases_on = diag_flag("UZL_PHASES");
+    std::vector<hipEvent_t> ph_ev;
+    std::vector<int> ph_tag;
+    auto mark = [&](int tag) {
+        if (!phases_on) return;
+        hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, s); ph_ev.push_back(e); ph_tag.push_back(tag);
+    };
     for (int it = 0; it < iterations; it++) {
         int gl, ga;
         adopted = false;
+        mark(0);
         if (h->ml_pending) {                                                      // the copy built during the last iteration
             UZL_HIP(hipStreamWaitEvent(s, h->ev_setup, 0));
             h->ml_ix ^= 1; h->ml_pending = false; adopted = true;
@@ -1051,7 +1072,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         // gives the same PCG solution, and once chi2 changes by less than refresh_rel per step the hierarchy of the
         // previous iteration is as good as a fresh one (geometry + Galerkin + inverses are ~170 us per rebuild).
         // A rebuild is also forced when the iteration count has grown by a third since the last one.
-        const bool refresh = it == 0 || always_refresh || last_rel > refresh_rel || pcg_last > pcg_ref + pcg_ref / 3 + 4;
+        const bool refresh = it == 0 || always_refresh || last_rel > refresh_rel || (rate_ref > 0. && rate_last > 0. && rate_last < kRateDrop * rate_ref);
         bool launch_async = false;
         bool fetched = false;
         if (red) {                                      // the hierarchy is built on the reduced system, which needs lambda: lambda_0 first
@@ -1095,6 +1116,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         double rho = 0.;
         int qmax = 0;
         const double tol_f2 = tol_factor2(it, last_rel, pcg_last);
+        mark(1);
         do {
             set_lambda(h, lambda, tol_f2);                                        // setLambda (+ this iteration's PCG tolerance)
             if (red && qmax > 0) {                                                // a rejected step moved lambda: the Schur complement with it
@@ -1131,13 +1153,17 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
                 pcg_its = pcg_solve(h, &conv);
                 S.pcg_iterations += pcg_its;
             }
-            if (fresh) pcg_ref = pcg_its;
             pcg_last = pcg_its;
+            {
+                const double rate = pcg_rate(h->h_scal.p->scal[1], h->h_scal.p->scal[0], pcg_its, h->cfg.pcg_tol * h->cfg.pcg_tol, tol_f2);
+                if (rate > 0.) { rate_last = rate; if (fresh || rate_ref < 0.) rate_ref = rate; }
+            }
             if (h->cfg.verbose)
                 fprintf(stderr, "[uzl_pgo] it %d trial %d lambda %.3e pcg %d  rz_end %.3e  rz_stop %.3e  |r|2/|b|2 %.3e  conv %d  chi2 %.9g\n", it, qmax, lambda, pcg_its,
                         h->h_scal.p->scal[0], h->h_scal.p->scal[1], h->last_residual_ratio, (int)conv, current_chi);
             if (!conv) { S.pcg_not_converged++; rc = UZL_ERR_NOT_CONVERGED; }
             S.lm_trials++;
+            mark(2);
             if (red) { Timed t(h, "schur_backsub"); k_schur_backsub(D, Dp, SD, s); }   // dx of the eliminated vertices from the separators'
             int go, gc;
             { Timed t(h, "oplus"); go = k_oplus(D, h->cur, h->trial, s); }        // push + update
@@ -1145,6 +1171,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             { Timed t(h, "finalize"); k_finalize(D, gc, go, 0, 1, s); }
             shard_allreduce_chi2(h);
             fetch_scal(h);
+            mark(3);
             const double temp_chi = h->h_scal.p->scal[4];
             const double scale = h->h_scal.p->scal[5] + 1e-3;                     // computeScale + 1e-3
             rho = (current_chi - temp_chi) / scale;
@@ -1169,6 +1196,20 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     S.lambda_final = lambda;
     if (h->ml_pending) { UZL_HIP(hipStreamSynchronize(h->stream2)); h->ml_pending = false; }   // a rebuild nobody will use: let it drain
     UZL_HIP(hipStreamSynchronize(s));
+    if (phases_on && ph_ev.size() > 1) {
+        double acc[4] = {0., 0., 0., 0.};
+        static const char* nm[4] = {"linearise+set-up (0->1)", "solve incl. init (1->2)", "evaluate+round trip (2->3)", "host decision / next (3->0)"};
+        static const bool phases_each = diag_flag("UZL_PHASES_EACH");
+        for (size_t i = 0; i + 1 < ph_ev.size(); i++) {
+            float ms = 0.f; (void)hipEventElapsedTime(&ms, ph_ev[i], ph_ev[i + 1]); acc[ph_tag[i] & 3] += ms;
+            if (phases_each) fprintf(stderr, "%s%d:%.0f", ph_tag[i] == 0 ? "\n[uzl_pgo]   " : " ", ph_tag[i], 1e3 * ms);
+        }
+        if (phases_each) fprintf(stderr, "\n");
+        fprintf(stderr, "[uzl_pgo] phases over %d LM iterations (GPU event time, ms):", S.iterations_done);
+        for (int k = 0; k < 4; k++) fprintf(stderr, "  %s %.3f", nm[k], acc[k]);
+        fprintf(stderr, "\n");
+        for (hipEvent_t e : ph_ev) (void)hipEventDestroy(e);
+    }
     S.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     S.structure_ms = h->structure_ms; S.exchange_ms = h->exchange_ms; S.exchange_calls = h->exchange_calls;
     if (st) *st = S;
@@ -1576,7 +1617,8 @@ void batch_destroy_graph(uzl_pgo_batch* b)
 struct BatchLM {
     int it = 0, qmax = 0;
     double lambda = 0., ni = 2., current_chi = 0., last_rel = 1e300;
-    int pcg_ref = 1 << 30, pcg_last = 0;
+    int pcg_last = 0;
+    double rate_ref = -1., rate_last = -1.;
     int ml_ix = 0, cur = 0;
     bool pending = false, adopted = false, trial_setup = false, need_lin = true, finished = false, anomaly = false, fresh = false;
     double lambda_setup[2] = {0., 0.};
@@ -1801,7 +1843,7 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             for (int sl = 0; sl < R; sl++) {
                 if (!(dyn[sl].mask & kPhLin)) continue;
                 BatchLM& X = G[slot_graph[sl]];
-                const bool refresh = X.it == 0 || always_refresh || X.last_rel > refresh_rel || X.pcg_last > X.pcg_ref + X.pcg_ref / 3 + 4;
+                const bool refresh = X.it == 0 || always_refresh || X.last_rel > refresh_rel || (X.rate_ref > 0. && X.rate_last > 0. && X.rate_last < kRateDrop * X.rate_ref);
                 if (refresh) {
                     X.S.precond_builds++;
                     if (X.it == 0) X.trial_setup = true; else ahead[sl] = 1;
@@ -1916,8 +1958,11 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
                                 g, X.it, X.qmax, X.lambda, its, (int)P.flags[0], (int)P.flags[2], P.scal[7]);
                     X.anomaly = true; X.finished = true; continue;
                 }
-                if (X.fresh) X.pcg_ref = its;
                 X.pcg_last = its;
+                {
+                    const double rate = pcg_rate(P.scal[1], P.scal[0], its, tol2, X.tol_f2);
+                    if (rate > 0.) { X.rate_last = rate; if (X.fresh || X.rate_ref < 0.) X.rate_ref = rate; }
+                }
                 phase[g] = PEval;
             }
             if (!(in_step && still)) break;
