@@ -29,9 +29,9 @@ def keep_set(poses, edges, merged=None):
 def timed_check(c):
     t0 = time.perf_counter(); r = real(c); ms = 1e3 * (time.perf_counter() - t0)
     if os.environ.get("UZL_GATE_DBG") == "1" and ms > saved.get("ms", 0.0):
-        buf = np.zeros(4 * len(c), np.int64)
+        buf = np.zeros(8 * len(c), np.int64)
         nq = capi.lib().uzl_debug_gate_profile(o.gate._h, buf.ctypes.data_as(C.c_void_p), C.c_int32(len(c)))
-        saved["prof"] = buf[:4 * nq].reshape(-1, 4).copy()
+        saved["prof"] = buf[:8 * nq].reshape(-1, 8).copy()
     calls.append((len(c), ms, float(r[2].max(initial=0.0))))
     if ms > saved.get("ms", 0.0):
         saved["ms"] = ms; saved["graph"] = saved["cur"]; saved["cand"] = c.copy()
@@ -68,3 +68,4 @@ if "prof" in saved:
     pr = saved["prof"]; i = int(pr[:, 0].argmax())
     print("kernel counters of that call's longest search: %d steps, %.0f shader clocks per step, %.2f us per step (100 MHz counter), largest list %d"
           % (pr[i, 0], pr[i, 1] / max(pr[i, 0], 1), 1e-2 * pr[i, 2] / max(pr[i, 0], 1), pr[i, 3]))
+    print("   clocks per step: pop %.0f, popped node %.0f, neighbours %.0f, pushes %.0f" % tuple(pr[i, 4:8] / max(pr[i, 0], 1)))

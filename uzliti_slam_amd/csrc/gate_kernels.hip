@@ -334,7 +334,10 @@ __device__ __forceinline__ double wave_min_pos_f64(double x, bool& mine)
     const unsigned long long key = (unsigned long long)__double_as_longlong(x);
     const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
     const unsigned mhi = wave_min_u32(hi);
-    const unsigned mlo = wave_min_u32(hi == mhi ? lo : 0xffffffffu);
+    const unsigned long long top = __ballot(hi == mhi);
+    unsigned mlo;
+    if (__popcll(top) == 1) mlo = (unsigned)__builtin_amdgcn_readlane((int)lo, __ffsll((long long)top) - 1);     // the common case: no second reduction
+    else mlo = wave_min_u32(hi == mhi ? lo : 0xffffffffu);
     mine = hi == mhi && lo == mlo;
     return __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
 }
@@ -350,8 +353,8 @@ template <int kGateRegSlots>
 __global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
 {
     extern __shared__ unsigned char gsm[];
-    unsigned long long* __restrict__ cache = reinterpret_cast<unsigned long long*>(gsm);      // [64 blocks][8 records][8 qwords]
-    int32_t* __restrict__ tag = reinterpret_cast<int32_t*>(cache + kGateCacheBlocks * 64);
+    unsigned long long* __restrict__ cache = reinterpret_cast<unsigned long long*>(gsm);      // [blocks][kGateBlockNodes records][8 qwords]
+    int32_t* __restrict__ tag = reinterpret_cast<int32_t*>(cache + kGateCacheBlocks * kGateBlockNodes * 8);
     unsigned* __restrict__ closed = reinterpret_cast<unsigned*>(tag + kGateCacheBlocks);
     const int k = blockIdx.x, lane = threadIdx.x;
     if (k >= a.n_query) return;
@@ -374,14 +377,18 @@ __global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
     if (lane < kGateCacheBlocks) tag[lane] = -1;
     __syncthreads();
     // brings the block of 8 records that holds node `u` into the cache (uniform call)
+    // a block = kGateBlockNodes records = 2 KB: every lane moves 2 x 16 bytes (the host pads the record array to whole blocks)
     auto fetch_block = [&](int u) {
-        const int blk = u >> 3, slot = blk & (kGateCacheBlocks - 1);
-        cache[slot * 64 + lane] = reinterpret_cast<const unsigned long long*>(a.rec)[(size_t)blk * 64 + lane];
+        const int blk = u >> kGateBlockShift, slot = blk & (kGateCacheBlocks - 1);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.rec) + (size_t)blk * (kGateBlockNodes * 4);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(cache) + slot * (kGateBlockNodes * 4);
+        const uint4 q0 = src[lane], q1 = src[lane + 64];
+        dst[lane] = q0; dst[lane + 64] = q1;
         if (lane == 0) tag[slot] = blk;
         __builtin_amdgcn_wave_barrier();
     };
-    auto rec_of = [&](int u) { return reinterpret_cast<const GateNodeRec*>(cache + ((u >> 3) & (kGateCacheBlocks - 1)) * 64 + (u & 7) * 8); };
-    auto tag_ok = [&](int u) { return tag[(u >> 3) & (kGateCacheBlocks - 1)] == (u >> 3); };
+    auto rec_of = [&](int u) { return reinterpret_cast<const GateNodeRec*>(cache + ((u >> kGateBlockShift) & (kGateCacheBlocks - 1)) * (kGateBlockNodes * 8) + (u & (kGateBlockNodes - 1)) * 8); };
+    auto tag_ok = [&](int u) { return tag[(u >> kGateBlockShift) & (kGateCacheBlocks - 1)] == (u >> kGateBlockShift); };
     fetch_block(target);
     const double tx = rec_of(target)->px, ty = rec_of(target)->py, tz = rec_of(target)->pz;
     fetch_block(source);
@@ -397,10 +404,10 @@ __global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
     }
     bool success = false, over = false;
     double g_target = 0.;
-    long long dbg_steps = 0, dbg_max = 0;
+    long long dbg_steps = 0, dbg_max = 0, dbg_sec[4] = {0, 0, 0, 0}, dbg_t = 0;
     const long long dbg_c0 = a.dbg ? clock64() : 0, dbg_w0 = a.dbg ? wall_clock64() : 0;
     while (n_open > 0 && n_list > 0) {
-        if (a.dbg) { dbg_steps++; dbg_max = n_list > dbg_max ? n_list : dbg_max; }
+        if (a.dbg) { dbg_steps++; dbg_max = n_list > dbg_max ? n_list : dbg_max; dbg_t = clock64(); }
         // ---- pop: lane-local minimum over (h, node, g), then the wave's
         double bw = lw[0], bg = lg[0]; int bv = lv[0], bk = 0;
 #pragma unroll
@@ -421,6 +428,7 @@ __global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
         const int src = __ffsll((long long)tie) - 1;
         const int v = __builtin_amdgcn_readlane(bv, src);
         const double gpop = readlane_f64(bg, src);
+        if (a.dbg) { const long long t = clock64(); dbg_sec[0] += t - dbg_t; dbg_t = t; }
         if (v == target) { success = true; g_target = gpop; break; }
         if (lane == src) {
 #pragma unroll
@@ -446,6 +454,7 @@ __global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
             n_open--;
             if (lane == 0) { closed[v >> 5] = cw | (1u << (v & 31)); opened[v >> 5] &= ~(1u << (v & 31)); gclosed[v] = gv; }
         }
+        if (a.dbg) { const long long t = clock64(); dbg_sec[1] += t - dbg_t; dbg_t = t; }
         for (int base = 0; base < deg; base += 64) {
             if (base > 0) { const int q = base + lane; u = q < deg ? a.adj_nbr[adj + q] : -1; }
             const bool has = u >= 0;
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
                 if (!miss) break;
                 const int um = __builtin_amdgcn_readlane(us, __ffsll((long long)miss) - 1);
                 fetch_block(um);
-                if (!got && (us >> 3) == (um >> 3)) { ux = urp->px; uy = urp->py; uz = urp->pz; got = true; }
+                if (!got && (us >> kGateBlockShift) == (um >> kGateBlockShift)) { ux = urp->px; uy = urp->py; uz = urp->pz; got = true; }
             }
             const bool is_open = act && ((ou >> (us & 31)) & 1u);
             // an open neighbour is pushed again only with a smaller g: its current g = the smallest g among its entries
@@ -491,6 +500,7 @@ __global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
                 tent = gv + rec_dist(vx, vy, vz, ux, uy, uz);
                 if (!is_open || tent < gu) { push = true; hw = rec_dist(ux, uy, uz, tx, ty, tz); }
             }
+            if (a.dbg) { const long long t = clock64(); dbg_sec[2] += t - dbg_t; dbg_t = t; }
             if (push) atomicOr(&opened[us >> 5], 1u << (us & 31));
             n_open += __popcll(__ballot(push && !is_open));
             // ---- pushes: one by one into the first lane with a free slot
@@ -514,9 +524,11 @@ __global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
             }
             if (over) break;
         }
+        if (a.dbg) { const long long t = clock64(); dbg_sec[3] += t - dbg_t; dbg_t = t; }
         if (over) break;
     }
-    if (a.dbg && lane == 0) { a.dbg[4 * k] = dbg_steps; a.dbg[4 * k + 1] = clock64() - dbg_c0; a.dbg[4 * k + 2] = wall_clock64() - dbg_w0; a.dbg[4 * k + 3] = dbg_max; }
+    if (a.dbg && lane == 0) { a.dbg[8 * k] = dbg_steps; a.dbg[8 * k + 1] = clock64() - dbg_c0; a.dbg[8 * k + 2] = wall_clock64() - dbg_w0; a.dbg[8 * k + 3] = dbg_max;
+                              for (int q = 0; q < 4; q++) a.dbg[8 * k + 4 + q] = dbg_sec[q]; }
     if (over) { if (lane == 0) a.redo[k] = 1; return; }
     if (lane != 0) return;
     const double dist = success ? g_target : DBL_MAX;

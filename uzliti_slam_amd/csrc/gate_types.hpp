@@ -46,8 +46,9 @@ constexpr int kGateOpenCap = 2048;  // open-list entries held in LDS per candida
 struct GateState { double g; int32_t st; int32_t pad; };     // per (candidate, node): g-score and 0 none / 1 open / 2 closed
 
 // ---- the same search with the open list in registers and the per-node state in LDS (gate_reg_kernel) ----
-constexpr int kGateCacheBlocks = 64;   // direct-mapped record cache: 64 blocks of 8 consecutive nodes (chain order = index order)
-constexpr int kGateLdsFixed = kGateCacheBlocks * 8 * 64 + kGateCacheBlocks * 4;                // cache + tags
+constexpr int kGateCacheBlocks = 32;   // direct-mapped record cache: 32 blocks of kGateBlockNodes consecutive nodes (chain order = index order)
+constexpr int kGateBlockShift = 5, kGateBlockNodes = 1 << kGateBlockShift;                     // 32 records = 2 KB per block: one miss per ~32 steps along the chain
+constexpr int kGateLdsFixed = kGateCacheBlocks * kGateBlockNodes * 64 + kGateCacheBlocks * 4;  // cache + tags
 constexpr int kGateLdsMax = 160 * 1024 - 2048;
 inline int gate_lds_bytes(int n) { return kGateLdsFixed + 2 * 4 * ((n + 31) / 32); }        // + closed / open bitmaps (n <= ~500k nodes)
 

@@ -91,7 +91,7 @@ void build_adjacency(uzl_gate* h)
         if (e.to != e.from) h->adj_nbr[fill[e.to]++] = e.from;
     }
     // node records of the wave-per-candidate search: position, degree, first neighbours in adjacency order
-    h->rec.assign(((size_t)std::max(n, 1) + 7) / 8 * 8, GateNodeRec{});     // whole blocks of 8: gate_lds_kernel's cache loads them as units
+    h->rec.assign(((size_t)std::max(n, 1) + kGateBlockNodes - 1) / kGateBlockNodes * kGateBlockNodes, GateNodeRec{});     // whole blocks: gate_reg_kernel's cache loads them as units
     for (int v = 0; v < n; v++) {
         GateNodeRec& r = h->rec[v];
         r.px = h->poses[12 * (size_t)v + 3]; r.py = h->poses[12 * (size_t)v + 7]; r.pz = h->poses[12 * (size_t)v + 11];
@@ -238,7 +238,7 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
         wa.min_score = h->cfg.min_matching_score; wa.max_T = h->cfg.max_edge_distance_T; wa.max_R = h->cfg.max_edge_distance_R;
         wa.ssf = h->cfg.scope_size_factor;
         wa.pre_ok = h->d_pre.p + first; wa.heur_ok = h->d_heur.p + first; wa.dist = h->d_dist.p + first; wa.redo = h->d_redo.p + first;
-        if (h->dbg_on) { h->d_dbg.reserve((size_t)m * 4); UZL_HIP(hipMemsetAsync(h->d_dbg.p, 0, sizeof(long long) * 4 * (size_t)m, s)); wa.dbg = h->d_dbg.p; }
+        if (h->dbg_on) { h->d_dbg.reserve((size_t)m * 8); UZL_HIP(hipMemsetAsync(h->d_dbg.p, 0, sizeof(long long) * 8 * (size_t)m, s)); wa.dbg = h->d_dbg.p; }
         if (!h->lane_kernel_only) {
             bool reg_ok = lds_path && launch_gate_reg(wa, h->reg_slots, s);
             if (!reg_ok) {
@@ -252,7 +252,7 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
             UZL_HIP(hipGetLastError());
             UZL_HIP(hipMemcpyAsync(h->h_redo.p + first, h->d_redo.p + first, (size_t)m, hipMemcpyDeviceToHost, s));
             UZL_HIP(hipStreamSynchronize(s));
-            if (h->dbg_on) { h->dbg_last.assign((size_t)m * 4, 0); UZL_HIP(hipMemcpy(h->dbg_last.data(), h->d_dbg.p, sizeof(long long) * 4 * (size_t)m, hipMemcpyDeviceToHost)); }
+            if (h->dbg_on) { h->dbg_last.assign((size_t)m * 8, 0); UZL_HIP(hipMemcpy(h->dbg_last.data(), h->d_dbg.p, sizeof(long long) * 8 * (size_t)m, hipMemcpyDeviceToHost)); }
             bool overflowed = false;
             for (int32_t k = first; k < last && !overflowed; k++) overflowed = h->h_redo.p[k] != 0;
             if (reg_ok && overflowed && h->reg_slots < 4) {
@@ -340,13 +340,14 @@ int uzl_debug_gate_counts(uzl_gate* h, int64_t* n_wave, int64_t* n_lane)
     return UZL_OK;
 }
 
-// diagnostic build: counters of the last launch of gate_reg_kernel (4 per search: expansions, shader clocks, 100 MHz ticks, largest list)
+// diagnostic build: counters of the last launch of gate_reg_kernel (8 per search: expansions, shader clocks, 100 MHz ticks, largest list,
+// shader clocks in the pop / the popped node's loads / the neighbours up to the push decision / the pushes)
 int uzl_debug_gate_profile(uzl_gate* h, long long* out, int32_t cap)
 {
     if (!h || !out) return UZL_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    const int32_t nq = (int32_t)std::min<size_t>(h->dbg_last.size() / 4, (size_t)std::max(cap, 0));
-    for (int32_t i = 0; i < 4 * nq; i++) out[i] = h->dbg_last[i];
+    const int32_t nq = (int32_t)std::min<size_t>(h->dbg_last.size() / 8, (size_t)std::max(cap, 0));
+    for (int32_t i = 0; i < 8 * nq; i++) out[i] = h->dbg_last[i];
     return nq;
 }
 
