@@ -163,6 +163,34 @@ def traffic_of(key, applies):
         return None
 
 
+PHASES_JSON = os.path.join(ROOT, "profiles", "r03_estimate_phases.json")
+
+
+def estimate_phases(applies):
+    """Where a workgroup of estimate_kernel spends its time: in-kernel stamps of the diagnostic build (tests/diag/stamps_match.sh) on the
+    default secondary workload, committed under profiles/; not measured in this run.  Each part with the bound that holds for it."""
+    if not applies or not os.path.exists(PHASES_JSON):
+        return None
+    d = json.load(open(PHASES_JSON))
+    us = d["phase_us_per_workgroup"]; tot = d["total_us_per_workgroup"]
+    short = ["select", "sort", "gather", "poses", "votes", "bookkeeping", "winner_mask", "refit", "recount_mse"]
+    bound = {"select": "LDS latency: ballot-ordered compaction, two workgroup barriers per 256 queries",
+             "sort": "LDS latency: 55 compare-exchange stages at n = 1024, one LDS round trip each (52 inside a wave's quarter, 3 with barriers)",
+             "gather": "HBM / L2 latency: two dependent gathers (key -> train index -> point)",
+             "poses": "instruction latency of one lane: Eigen's two-sided Jacobi SVD in float, 3 - 6 sweeps of dependent divides and square roots; "
+                      "256 hypotheses per round run it side by side, the chain length is what counts",
+             "votes": "f64 matrix cores: three v_mfma_f64_16x16x4_f64 per 16 hypotheses x 16 points (64 cycles each) = 53 us of matrix-pipe time per "
+                      "workgroup with two workgroups per CU; the priced 27 flop per (hypothesis, point) over this phase alone is `vote_phase_frac_of_f64_peak`",
+             "bookkeeping": "two ballots and three barriers per round",
+             "winner_mask": "one lane recomputes the winning pose (same Jacobi chain), then one pass over the points",
+             "refit": "sequential by definition (running mean / covariance in inlier order, float): ~490 dependent three-operation steps on one wave, "
+                      "then the Jacobi chain once more on one lane",
+             "recount_mse": "one lane adds the distances in index order (the reference's summation order)"}
+    names = list(us.keys())
+    return dict(source="profiles/r03_estimate_phases.json (" + d["source"] + ")", us_per_workgroup={k: round(us[n], 2) for k, n in zip(short, names)},
+                fraction={k: round(us[n] / tot, 4) for k, n in zip(short, names)}, bound=bound)
+
+
 def roof(kernel, bound, achieved, peak, unit, **extra):
     d = dict(kernel=kernel, bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit, frac=round(achieved / peak, 5) if peak else None)
     d.update(extra)
@@ -502,7 +530,13 @@ def main():
         est_roof = roof("estimate_kernel", "f64", ach_e, F64_PEAK_TFLOPS, "TFLOP/s (f64; transform on the matrix cores, norm / compare on the vector ALU)",
                         traffic=None, ms=round(est_ms, 4), mean_correspondences=float(res["n_corr"].mean()),
                         note="27 x hypotheses x M flop per pair; the kernel also sorts, samples, fits 500 float poses, refits and scores each job, "
-                             "all inside one workgroup with the point tile in LDS - about 35 % of its time is the vote loop this figure prices")
+                             "all inside one workgroup with the point tile in LDS - `phases` says where a workgroup's time goes and what bounds each part")
+        ph = estimate_phases(is_c3)
+        if ph:
+            est_roof["phases"] = ph
+            vf = ph["fraction"].get("votes")
+            if vf:
+                est_roof["vote_phase_frac_of_f64_peak"] = round(est_roof["frac"] / vf, 4)
         rooflines += [knn_roof, est_roof]
         secondary = dict(metric="node-pairs matched/sec", value=round(pairs_total / t_match, 1), unit="pairs/s",
                          ms_per_step=round(1e3 * t_match / a.steps, 4),

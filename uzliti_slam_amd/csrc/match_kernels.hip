@@ -20,15 +20,20 @@
 
 namespace uzl {
 
-// Diagnostic build only (-DUZL_STAMPS): phase times of estimate_kernel (block 0 / thread 0, 100 MHz clock)
+// Diagnostic build only (-DUZL_STAMPS, tests/diag/stamps_match.sh): phase times of estimate_kernel (thread 0 of every eighth workgroup,
+// 100 MHz clock; [31] counts the workgroups that stamped)
 #ifdef UZL_STAMPS
 __device__ unsigned long long g_mstamps[32];
-#define MSTAMP_DECL unsigned long long st_prev_ = __builtin_amdgcn_s_memrealtime(); int st_i_ = 0;
-#define MSTAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); \
+#define MSTAMP_DECL unsigned long long st_prev_ = __builtin_amdgcn_s_memrealtime(); int st_i_ = 0; \
+                    if ((blockIdx.x & 7) == 0 && threadIdx.x == 0) atomicAdd(&g_mstamps[31], 1ull);
+#define MSTAMP() do { if ((blockIdx.x & 7) == 0 && threadIdx.x == 0) { unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); \
         atomicAdd(&g_mstamps[st_i_], n_ - st_prev_); st_prev_ = n_; } st_i_++; } while (0)
+#define MSTAMP_AT(k) do { if ((blockIdx.x & 7) == 0 && threadIdx.x == 0) { unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); \
+        atomicAdd(&g_mstamps[k], n_ - st_prev_); st_prev_ = n_; } } while (0)
 #else
 #define MSTAMP_DECL
 #define MSTAMP() do { } while (0)
+#define MSTAMP_AT(k) do { } while (0)
 #endif
 
 constexpr int kBlock = 256;
@@ -775,6 +780,7 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
                 pose_add(acc, pq[s2 * 6 + 0], pq[s2 * 6 + 1], pq[s2 * 6 + 2], pq[s2 * 6 + 3], pq[s2 * 6 + 4], pq[s2 * 6 + 5]);
                 pose_finish(acc, T);                                                   // :227
             }
+            MSTAMP_AT(8);       // sample + float pose of this round's hypotheses (thread 0's own: the lanes run in lock step)
             if (!vote_valu) {
                 // ---- votes on the f64 matrix cores (:230).  v_mfma_f64_16x16x4_f64 is, bit for bit, the chain
                 // acc = fma(a_k, b_k, acc) for k = 0..3 from acc = C (measured on 512 000 random outputs), so with
@@ -845,6 +851,7 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
                 s_cnt[it] = cnt;
             }
             __syncthreads();                                // votes of other lanes' hypotheses are in s_cnt
+            MSTAMP_AT(9);       // votes
             // ---- the sequential bookkeeping of :233-242 over this round's votes, without the sequence.  The loop keeps a
             // running strict maximum (first index wins ties) and stops at the first NEW maximum that satisfies
             // stop(c) = c >= 3 && c > break_pct * M.  stop() is monotone in c, so the first iteration whose own count satisfies
@@ -878,6 +885,7 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
                 }
             }
             __syncthreads();
+            MSTAMP_AT(10);      // bookkeeping
             stop = s_misc[3] != 0;
         }
         max_cons = s_misc[0]; best_it = s_misc[1]; it_run = s_misc[2];
