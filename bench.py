@@ -179,8 +179,10 @@ def estimate_phases(applies):
              "gather": "HBM / L2 latency: two dependent gathers (key -> train index -> point)",
              "poses": "instruction latency of one lane: Eigen's two-sided Jacobi SVD in float, 3 - 6 sweeps of dependent divides and square roots; "
                       "256 hypotheses per round run it side by side, the chain length is what counts",
-             "votes": "f64 matrix cores: three v_mfma_f64_16x16x4_f64 per 16 hypotheses x 16 points (64 cycles each) = 53 us of matrix-pipe time per "
-                      "workgroup with two workgroups per CU; the priced 27 flop per (hypothesis, point) over this phase alone is `vote_phase_frac_of_f64_peak`",
+             "votes": "the CU's f64 units, shared by matrix and vector instructions (both peak at 78.6 TFLOP/s): per wave and 16-point step 12 "
+                      "v_mfma_f64_16x16x4_f64 (64 cycles each) + 112 f64 vector instructions (4 cycles each) = ~1220 cycles, two waves per SIMD; the "
+                      "measured ~2870 cycles per step of both waves is 85 % of that.  The priced 27 flop per (hypothesis, point) over this phase alone "
+                      "is `vote_phase_frac_of_f64_peak` (the MFMA's fourth k-slot carries the translation, subtractions and compares count one flop)",
              "bookkeeping": "two ballots and three barriers per round",
              "winner_mask": "one lane recomputes the winning pose (same Jacobi chain), then one pass over the points",
              "refit": "sequential by definition (running mean / covariance in inlier order, float): ~490 dependent three-operation steps on one wave, "

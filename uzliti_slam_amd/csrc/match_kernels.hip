@@ -805,6 +805,10 @@ __global__ __launch_bounds__(kEstBlock) void estimate_kernel(EstimateArgs A)
                 for (int q = 0; q < 4; q++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) cnt4[q][r] = 0;
+                // (The f64 MFMA and the f64 vector instructions share the CU's f64 units on this chip - matrix and vector f64 peaks are the same
+                //  78.6 TFLOP/s: a step of 12 MFMAs x 64 cycles + 112 f64 vector instructions x 4 cycles is ~1200 cycles per wave however the two
+                //  are interleaved.  Double-buffering the MFMA results so that one half step's transforms run under the other half's folds
+                //  changed nothing: 101.8 -> 99.2 us per workgroup, tests/diag/stamps_match.sh.)
                 for (int m0 = 0; m0 < M; m0 += 16) {
                     const int m = (m0 + li < M) ? m0 + li : M - 1;
                     const bool pv = m0 + li < M;
