@@ -23,7 +23,7 @@ for k in ("corr_query", "corr_train", "corr_dist", "mask"):
     h.update(np.ascontiguousarray(diag[k]).tobytes())
 out["match"] = h.hexdigest()
 m.close()
-for name, (n, e, its) in dict(small=(700, 3000, 8), large=(3000, 12000, 5)).items():
+for name, (n, e, its) in dict(small=(700, 3000, 8), large=(6000, 24000, 4)).items():
     g = synth.make_pose_graph(n, e, seed=n)
     p = capi.Pgo()
     p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])

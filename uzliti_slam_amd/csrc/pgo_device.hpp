@@ -300,4 +300,50 @@ __device__ __forceinline__ void spd_inverse6_rs(double* A, double* out)
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// When to stop the PCG: an a-posteriori estimate of the error left in the LM step, in the units of the parity bar.
+// Every kProgressEvery iterations the solve looks at how far x moved since its last look,
+//     s = x_k - x_{k-d},   e_k = x* - x_k = sum_{j >= k} alpha_j p_j,   so   e_{k-d} = s + e_k ;
+// with the error contracting by q per window (q^2 = ratio of r.M^-1 r over the window, the energy norm of the error when M ~ A),
+// |e_k| ~ q / (1 - q) |s|.  The solve stops when kProgressSafety times that estimate - largest translation component [m] and largest
+// rotation (quaternion vector, ~ half-angle) component over all vertices - is below what the host asks for (scal[12], scal[13]:
+// a fraction of BASELINE's 1e-3 m / 1e-4 rad spread over the LM iterations).  A step of 1e-7 m is accepted after the first look; a
+// step of metres is iterated until 1e-6 of it is settled.  The relative test on r.M^-1 r stays as a floor.
+// Multilevel path: the look is part of the iteration - ml_cg leaves, per workgroup, the largest movement of its rows (in units of the
+// accuracy asked for: max(|dx_t| / eps_t, |dx_r| / eps_r)) and |r|^2 of its rows in part_c on the iterations ml_spmv flags (flags[3]);
+// block 0 of the next ml_spmv folds them and decides (progress_decide_ml): no launch of its own, so the look can be taken every 4
+// iterations.  The solve also waits for the residual to come down (|r|^2 <= kProgressResidual |b|^2, |b|^2 in scal[14]: folded by the
+// first ml_spmv from what the first ml_cg left): that is the bar residual_guard_kernel holds a finished solve to, and a converged LM
+// iteration - whose whole step is below the accuracy asked for - would otherwise stop at the first look with |r| barely reduced.
+// Block-Jacobi path (graphs too small or too large for a hierarchy): pcg_progress_kernel, between the iterations.
+// mt / mr: largest |x - xs| over the translation / rotation components; rz: r.M^-1 r of the iteration that ended at the look.
+// ------------------------------------------------------------------------------------------------
+constexpr double kProgressSafety = 2., kProgressQMax = 0.95, kProgressResidual = 0.25;
+__device__ __forceinline__ void progress_decide(PgoDev D, double mt, double mr, double rz)
+{
+    const double rz_prev = D.scal[11];
+    double q = (rz_prev > 0. && rz >= 0.) ? sqrt(rz / rz_prev) : kProgressQMax;
+    q = fmin(q, kProgressQMax);
+    const double gain = kProgressSafety * q / (1. - q);
+    const double et = gain * mt, er = gain * mr;
+    D.scal[11] = rz; D.scal[14] = et; D.scal[15] = er;
+    if (et <= D.scal[12] && er <= D.scal[13] && rz >= 0.) D.flags[0] = 1;
+}
+// m: largest movement in units of the accuracy asked for; rr: |r|^2
+__device__ __forceinline__ void progress_decide_ml(PgoDev D, double m, double rr, double rz)
+{
+    const double rz_prev = D.scal[11];
+    double q = (rz_prev > 0. && rz >= 0.) ? sqrt(rz / rz_prev) : kProgressQMax;
+    q = fmin(q, kProgressQMax);
+    const double est = (kProgressSafety * q / (1. - q)) * m;
+    D.scal[11] = rz; D.scal[15] = est;
+    if (est <= 1. && rr <= kProgressResidual * D.scal[14] && rz >= 0.) D.flags[0] = 1;
+}
+// 1 / (accuracy asked for), for the movement of component `comp` of a row (0..2 translation [m], 3..5 rotation [q_xyz])
+__device__ __forceinline__ double progress_unit(const double* __restrict__ scal, int comp)
+{
+    const double eps = scal[comp < 3 ? 12 : 13];
+    return eps > 0. ? 1. / eps : 1e300;
+}
+
 }  // namespace uzl

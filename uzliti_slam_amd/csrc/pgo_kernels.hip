@@ -789,70 +789,49 @@ __global__ void set_trial_kernel(double* __restrict__ scal, double lambda, doubl
 }
 
 // ------------------------------------------------------------------------------------------------
-// When to stop the PCG: an a-posteriori estimate of the error left in the LM step, in the units of the parity bar.
-// Every kGraphPairs * 2 iterations (one graph replay) one workgroup looks at how far x moved since its last look,
-//     s = x_k - x_{k-d},   e_k = x* - x_k = sum_{j >= k} alpha_j p_j,   so   e_{k-d} = s + e_k ;
-// with the error contracting by q per window (q^2 = ratio of r.M^-1 r over the window, the energy norm of the error when M ~ A),
-// |e_k| ~ q / (1 - q) |s|.  The solve stops when kProgressSafety times that estimate - largest translation component [m] and largest
-// rotation (quaternion vector, ~ half-angle) component over all vertices - is below what the host asks for (scal[12], scal[13]:
-// a fraction of BASELINE's 1e-3 m / 1e-4 rad spread over the LM iterations), and the recurrence residual has come down
-// (|r|^2 <= kProgressResidual |b|^2: a preconditioner that is not SPD does not get past that).  A step of 1e-7 m is accepted after
-// the first look; a step of metres is iterated until 1e-6 of it is settled.  The relative test on r.M^-1 r stays as a floor.
+// The stop test of the block-Jacobi path (progress_decide, pgo_device.hpp): a launch of its own between the iterations.
+// Small systems: one workgroup does it all.  Larger ones: a grid of kProgressChunk-element blocks leaves two partials each in part_c
+// (free between assemble and the next linearisation) and a one-workgroup launch behind it folds them and decides - no hand-off
+// between workgroups inside a launch (per-XCD L2s are not coherent with each other), nothing depends on block timing.
 // ------------------------------------------------------------------------------------------------
-constexpr double kProgressSafety = 2., kProgressQMax = 0.95, kProgressResidual = 0.25;
-// Small systems: one workgroup does it all.  Larger ones: a grid of kProgressChunk-element blocks leaves four partials each in part_c
-// (free between assemble and the next linearisation) and a one-workgroup launch behind it folds them in block order and decides -
-// no hand-off between workgroups inside a launch (per-XCD L2s are not coherent with each other), nothing depends on block timing.
-constexpr int kProgressChunk = 2048, kProgressMaxBlocks = kMaxPartials / 4;
+constexpr int kProgressChunk = 2048, kProgressMaxBlocks = kMaxPartials / 2;
 __host__ __device__ inline int progress_blocks(int nb) { const int g = (nb * 6 + kProgressChunk - 1) / kProgressChunk; return g < 1 ? 1 : (g > kProgressMaxBlocks ? kProgressMaxBlocks : g); }
-__device__ __forceinline__ void progress_decide(PgoDev D, double mt, double mr, double rr, double bb)
-{
-    const double rz = D.scal[0], rz_prev = D.scal[11];
-    double q = (rz_prev > 0. && rz >= 0.) ? sqrt(rz / rz_prev) : kProgressQMax;
-    q = fmin(q, kProgressQMax);
-    const double gain = kProgressSafety * q / (1. - q);
-    const double et = gain * mt, er = gain * mr;
-    D.scal[11] = rz; D.scal[14] = et; D.scal[15] = er;
-    if (et <= D.scal[12] && er <= D.scal[13] && rr <= kProgressResidual * bb && rz >= 0.) D.flags[0] = 1;
-}
 // stage 0: partials of block blockIdx.x (of nblk); with nblk == 1 also the decision
 __device__ __forceinline__ void pcg_progress_kernel_body(PgoDev D)
 {
-    __shared__ double st[4], sr[4], srr[4], sbb[4];
+    __shared__ double st[4], sr[4];
     if (D.flags[0]) return;
     const int n = D.nb * 6, nblk = progress_blocks(D.nb);
     const int per = (n + nblk - 1) / nblk, i0 = blockIdx.x * per, i1 = (i0 + per < n) ? i0 + per : n;
-    double mt = 0., mr = 0., rr = 0., bb = 0.;
+    double mt = 0., mr = 0.;
     for (int i = i0 + threadIdx.x; i < i1; i += kBlk) {
-        const double x = D.x[i], d = fabs(x - D.xs[i]), r = D.r[i], b = D.b[i];
+        const double x = D.x[i], d = fabs(x - D.xs[i]);
         D.xs[i] = x;
         if (i % 6 < 3) mt = fmax(mt, d); else mr = fmax(mr, d);
-        rr += r * r; bb += b * b;
     }
-    for (int o = 32; o; o >>= 1) { mt = fmax(mt, __shfl_xor(mt, o)); mr = fmax(mr, __shfl_xor(mr, o)); rr += __shfl_xor(rr, o); bb += __shfl_xor(bb, o); }
-    if ((threadIdx.x & 63) == 0) { st[threadIdx.x >> 6] = mt; sr[threadIdx.x >> 6] = mr; srr[threadIdx.x >> 6] = rr; sbb[threadIdx.x >> 6] = bb; }
+    for (int o = 32; o; o >>= 1) { mt = fmax(mt, __shfl_xor(mt, o)); mr = fmax(mr, __shfl_xor(mr, o)); }
+    if ((threadIdx.x & 63) == 0) { st[threadIdx.x >> 6] = mt; sr[threadIdx.x >> 6] = mr; }
     __syncthreads();
     if (threadIdx.x != 0) return;
     mt = fmax(fmax(st[0], st[1]), fmax(st[2], st[3])); mr = fmax(fmax(sr[0], sr[1]), fmax(sr[2], sr[3]));
-    rr = (srr[0] + srr[1]) + (srr[2] + srr[3]); bb = (sbb[0] + sbb[1]) + (sbb[2] + sbb[3]);
-    if (nblk == 1) { progress_decide(D, mt, mr, rr, bb); return; }
-    double* __restrict__ pc = D.part_c + 4 * blockIdx.x;
-    pc[0] = mt; pc[1] = mr; pc[2] = rr; pc[3] = bb;
+    if (nblk == 1) { progress_decide(D, mt, mr, D.scal[0]); return; }
+    double* __restrict__ pc = D.part_c + 2 * blockIdx.x;
+    pc[0] = mt; pc[1] = mr;
 }
-// stage 1 (nblk > 1): one wave folds the partials in block order
+// stage 1 (nblk > 1): one wave folds the partials
 __device__ __forceinline__ void pcg_progress_final_body(PgoDev D)
 {
     if (D.flags[0]) return;
     const int nblk = progress_blocks(D.nb);
     if (nblk == 1) return;
     const int lane = threadIdx.x;
-    double mt = 0., mr = 0., rr = 0., bb = 0.;
+    double mt = 0., mr = 0.;
     for (int w = lane; w < nblk; w += 64) {
-        const double* __restrict__ pc = D.part_c + 4 * w;
-        mt = fmax(mt, pc[0]); mr = fmax(mr, pc[1]); rr += pc[2]; bb += pc[3];
+        const double* __restrict__ pc = D.part_c + 2 * w;
+        mt = fmax(mt, pc[0]); mr = fmax(mr, pc[1]);
     }
-    for (int o = 32; o; o >>= 1) { mt = fmax(mt, __shfl_xor(mt, o)); mr = fmax(mr, __shfl_xor(mr, o)); rr += __shfl_xor(rr, o); bb += __shfl_xor(bb, o); }
-    if (lane == 0) progress_decide(D, mt, mr, rr, bb);
+    for (int o = 32; o; o >>= 1) { mt = fmax(mt, __shfl_xor(mt, o)); mr = fmax(mr, __shfl_xor(mr, o)); }
+    if (lane == 0) progress_decide(D, mt, mr, D.scal[0]);
 }
 __global__ __launch_bounds__(kBlk) void pcg_progress_kernel(PgoDev D) { pcg_progress_kernel_body(D); }
 __global__ __launch_bounds__(64) void pcg_progress_final_kernel(PgoDev D) { pcg_progress_final_body(D); }
@@ -861,25 +840,6 @@ void k_pcg_progress(const PgoDev& D, hipStream_t s)
     const int g = progress_blocks(D.nb);
     hipLaunchKernelGGL(pcg_progress_kernel, dim3(g), dim3(kBlk), 0, s, D);
     if (g > 1) hipLaunchKernelGGL(pcg_progress_final_kernel, dim3(1), dim3(64), 0, s, D);
-}
-__global__ __launch_bounds__(kBlk) void pcg_progress_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
-{
-    const BatchSlot& S = slots[blockIdx.z];
-    if (!(dyn[blockIdx.z].mask & kPhSolve)) return;
-    if ((int)blockIdx.x >= progress_blocks(S.D.nb)) return;
-    pcg_progress_kernel_body(S.D);
-}
-__global__ __launch_bounds__(64) void pcg_progress_final_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
-{
-    const BatchSlot& S = slots[blockIdx.z];
-    if (!(dyn[blockIdx.z].mask & kPhSolve)) return;
-    pcg_progress_final_body(S.D);
-}
-void kb_pcg_progress(const BatchSlot* sl, const BatchDyn* dy, int nb_, int max_nb, hipStream_t s)
-{
-    const int g = progress_blocks(max_nb);
-    hipLaunchKernelGGL(pcg_progress_batch_kernel, dim3(g, 1, nb_), dim3(kBlk), 0, s, sl, dy);
-    if (g > 1) hipLaunchKernelGGL(pcg_progress_final_batch_kernel, dim3(1, 1, nb_), dim3(64), 0, s, sl, dy);
 }
 
 // After PCG has set `done`: scal[7] = |r|^2 / |b|^2 with the recurrence residual r (= b - (H + lambda) x up to rounding for ANY

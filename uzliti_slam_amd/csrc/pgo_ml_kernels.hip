@@ -939,6 +939,19 @@ constexpr int kCgBlk = 192;                             // 3 waves; the first 48
 constexpr int kGatherU = 16;                            // gather-level values per thread kept in registers
 constexpr int kChain = 6 * 48 + 3;                      // per ancestor level: 6 rows of its sibling-block inverse + its offset d
 
+// The stop test's share of ml_cg (kCgBlk = 3 waves; progress_decide_ml, pgo_device.hpp).  At a look: the largest movement of the
+// workgroup's rows since the last look, in units of the accuracy asked for, and |r|^2 of its rows; at the first application of the
+// preconditioner (r = b): |b|^2 of its rows.  Per wave into spm[0..2] / spm[3..5]; look_store (lane 0, behind a workgroup barrier)
+// folds the waves - the sum in wave order - into part_c[blk].
+__device__ __forceinline__ void look_partials(double moved, double sq, int tid, double* spm)
+{
+    const double m = wave_max(moved), s = wave_sum(sq);
+    if ((tid & 63) == 0) { spm[tid >> 6] = m; spm[3 + (tid >> 6)] = s; }
+}
+__device__ __forceinline__ void look_store(double* __restrict__ part_c, int blk, const double* spm)
+{
+    reinterpret_cast<double2*>(part_c)[blk] = make_double2(fmax(fmax(spm[0], spm[1]), spm[2]), (spm[3] + spm[4]) + spm[5]);
+}
 template <int NW>
 __device__ __forceinline__ double block_sum_w(double v, double* sN)
 {
@@ -1062,7 +1075,7 @@ __device__ __forceinline__ void ml_init_kernel_body(PgoDev D, MlHot H, double* _
         }
         rg[(size_t)blockIdx.x * 6 + tid] = s;
     }
-    if (blockIdx.x == 0 && tid == 0) { D.flags[0] = 0; D.flags[1] = 0; D.flags[2] = 0; D.scal[2] = 1.; }
+    if (blockIdx.x == 0 && tid == 0) { D.flags[0] = 0; D.flags[1] = 0; D.flags[2] = 0; D.flags[3] = 0; D.scal[2] = 1.; }
 }
 template <int AGG>
 __global__ __launch_bounds__(kCgBlk) void ml_init_kernel(PgoDev D, MlHot H, double* __restrict__ p0, double* __restrict__ p1, double* __restrict__ rg)
@@ -1114,6 +1127,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     constexpr int kRowsPerBlk = kWaves * kRowsPerWave, kAggPerBlk = kRowsPerBlk / kMlFanout;
     constexpr int kGrpU = (kWaves >= 8) ? 2 : 4;          // groups of 64 r.z partials a wave fetches up front (1024 / 1024 / 512 partials in all)
     __shared__ double sgrp[kMaxPartials / 64];
+    __shared__ double slook[2][kMaxPartials / 64];      // block 0: the stop test's maxima per group of 64 ml_cg workgroups
     __shared__ double sd[kRowsPerBlk * 6];
     __shared__ double sw[kRowsPerBlk * 6];
     __shared__ double ss1[kAggPerBlk * 6];
@@ -1133,8 +1147,19 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         const double x = D.part_b[i < n_part ? i : 0];
         vpart[u] = (i < n_part) ? x : 0.;
     }
+    // the stop test (progress_decide, pgo_device.hpp): block 0 folds what the last ml_cg left in part_c - fetched whether or not that
+    // was a look iteration (the iteration count would be a round trip in front of these loads), used only if it was
+    double2 vlook[kGrpU];
+    if (bx == 0) {
+#pragma unroll
+        for (int u = 0; u < kGrpU; u++) {
+            const int i = (wv + u * kWaves) * 64 + lane;
+            const double2 x = reinterpret_cast<const double2*>(D.part_c)[i < n_part ? i : 0];
+            vlook[u] = (i < n_part) ? x : make_double2(0., 0.);
+        }
+    }
     const int it = D.flags[1];
-    const double rz_prev = D.scal[2], thr_old = D.scal[1], lambda = D.scal[3];
+    const double rz_prev = D.scal[2], thr_old = D.scal[1], lambda = D.scal[3], rz_last = D.scal[0];
     // slot range and this lane group's columns of the first TWO slot passes: ONE hop (row header).  Rows have ~10 slots on the
     // BASELINE graphs, i.e. four in ten need a second pass; with its column already here the second pass is one more round trip
     // instead of two per row (column index, then block and vectors), and rows of a wave take it together instead of one by one.
@@ -1221,6 +1246,22 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         const int i = gi * 64 + lane;
         const double sgi = wave_sum(i < n_part ? D.part_b[i] : 0.);
         if (lane == 0) sgrp[gi] = sgi;
+    }
+    if (bx == 0) {                                        // (.x: a maximum - any order gives the same bits; .y: a sum, taken like r.z)
+#pragma unroll
+        for (int u = 0; u < kGrpU; u++) {
+            const int gi = wv + u * kWaves;
+            if (gi < n_grp) {
+                const double a = wave_max(vlook[u].x), b = wave_sum(vlook[u].y);
+                if (lane == 0) { slook[0][gi] = a; slook[1][gi] = b; }
+            }
+        }
+        for (int gi = wv + kGrpU * kWaves; gi < n_grp; gi += kWaves) {
+            const int i = gi * 64 + lane;
+            const double2 x = (i < n_part) ? reinterpret_cast<const double2*>(D.part_c)[i] : make_double2(0., 0.);
+            const double a = wave_max(x.x), b = wave_sum(x.y);
+            if (lane == 0) { slook[0][gi] = a; slook[1][gi] = b; }
+        }
     }
     __syncthreads();
     double rz = 0.;
@@ -1362,6 +1403,16 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     if (tid == 0) {
         D.part_a[bx] = dtot;
         if (bx == 0) {
+            if (it == 0) {                               // the first ml_cg (r = b) left |b|^2
+                double bb = 0.;
+                for (int gi = 0; gi < n_grp; gi++) bb += slook[1][gi];
+                D.scal[14] = bb;
+            } else if (it % kProgressEvery == 0) {       // the ml_cg that ended iteration `it` was a look: how far has x moved since the last one
+                double m = 0., rr = 0.;
+                for (int gi = 0; gi < n_grp; gi++) { m = fmax(m, slook[0][gi]); rr += slook[1][gi]; }
+                progress_decide_ml(D, m, rr, rz_last);   // rz_last: r.M^-1 r at the START of that iteration, as this launch found it in scal[0]
+            }
+            D.flags[3] = ((it + 1) % kProgressEvery == 0) ? 1 : 0;         // is the ml_cg behind this launch a look
             D.scal[0] = rz;
             if (it == 0) { D.scal[1] = thresh; D.scal[11] = rz; }
             if (!(rz > thresh)) D.flags[0] = 1;
@@ -1410,6 +1461,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     __shared__ double sy[kAggPerBlk * 6];
     __shared__ double syc[6];
     __shared__ double szj[kRowsPerBlk * 6];
+    __shared__ double spm[6];
     constexpr int kFan2 = (AGG == 1) ? kMlFanout : kMlFanout2;    // children of a level-2 aggregate (build_ml)
     if (D.flags[0]) return;               // (kept first: post-convergence launches of a graph batch must stay cheap no-ops)
     STAMP_DECL
@@ -1444,11 +1496,13 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     // ---- every global load whose address is known now, before any barrier
     double vpart[4] = {0., 0., 0., 0.};
     if (!init && !VPRE) part_issue<kCgBlk, 4>(D.part_a, n_part, tid, vpart);
-    double xv = 0., rv0 = 0., apv = 0., pv = 0., geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double xv = 0., xsv = 0., rv0 = 0., apv = 0., pv = 0., geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int look = init ? 1 : D.flags[3];       // the stop test wants this workgroup's partials (ml_spmv said so; always with r = b: look_partials)
+    const double unit = progress_unit(D.scal, r);
     if (act) {
         const size_t i = (size_t)a * 6 + r;
         rv0 = D.r[i];
-        if (!init) { xv = D.x[i]; apv = D.ap[i]; pv = p[i]; }
+        if (!init) { xv = D.x[i]; xsv = D.xs[i]; apv = D.ap[i]; pv = p[i]; }
         const double* __restrict__ gg = H.geo0 + (size_t)a * 12;
 #pragma unroll
         for (int c = 0; c < 12; c++) geo[c] = gg[c];
@@ -1702,9 +1756,12 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     if (act && !init) {
         const size_t i = (size_t)a * 6 + r;
         rv = fma(-alpha, apv, rv0);
-        D.x[i] = fma(alpha, pv, xv);
+        const double xn = fma(alpha, pv, xv);
+        D.x[i] = xn;
         D.r[i] = rv;
+        if (look) { D.xs[i] = xn; xsv = fabs(xn - xsv) * unit; }   // (xsv: from here on the distance moved since the last look)
     }
+    if (look) look_partials((act && !init) ? xsv : 0., act ? rv * rv : 0., tid, spm);
     sv[tid] = act ? rv : 0.;
     __syncthreads();
     double zz = 0., w = 0.;
@@ -1772,6 +1829,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     const double tot = block_sum_w<3>(acc, s3);
     if (tid == 0) {
         D.part_b[blockIdx.x] = tot;
+        if (look) look_store(D.part_c, blockIdx.x, spm);
         if (blockIdx.x == 0 && !init) {
             D.scal[2] = rz;
             D.flags[1] += 1;
@@ -1823,6 +1881,7 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
     __shared__ double sy[6];
     __shared__ double szj[48];
     __shared__ double scomp[3][6];
+    __shared__ double spm[6];
     if (D.flags[0]) return;
     const int tid = threadIdx.x;
     const int a = blockIdx.x * kMlFanout + tid / 6, r = tid % 6;
@@ -1831,11 +1890,13 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
     // ---- every global load, before any barrier
     double vpart[4] = {0., 0., 0., 0.};
     if (!init) part_issue<kCgBlk, 4>(D.part_a, n_part, tid, vpart);
-    double xv = 0., rv0 = 0., apv = 0., pv = 0., geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double xv = 0., xsv = 0., rv0 = 0., apv = 0., pv = 0., geo[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int look = init ? 1 : D.flags[3];       // the stop test wants this workgroup's partials (ml_spmv said so; always with r = b: look_partials)
+    const double unit = progress_unit(D.scal, r);
     if (act) {
         const size_t i = (size_t)a * 6 + r;
         rv0 = D.r[i];
-        if (!init) { xv = D.x[i]; apv = D.ap[i]; pv = p[i]; }
+        if (!init) { xv = D.x[i]; xsv = D.xs[i]; apv = D.ap[i]; pv = p[i]; }
         const double* __restrict__ gg = H.geo0 + (size_t)a * 12;
 #pragma unroll
         for (int c = 0; c < 12; c++) geo[c] = gg[c];
@@ -1889,9 +1950,12 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
     if (act && !init) {
         const size_t i = (size_t)a * 6 + r;
         rv = fma(-alpha, apv, rv0);
-        D.x[i] = fma(alpha, pv, xv);
+        const double xn = fma(alpha, pv, xv);
+        D.x[i] = xn;
         D.r[i] = rv;
+        if (look) { D.xs[i] = xn; xsv = fabs(xn - xsv) * unit; }
     }
+    if (look) look_partials((act && !init) ? xsv : 0., act ? rv * rv : 0., tid, spm);
     sv[tid] = act ? rv : 0.;
     __syncthreads();
     double zz = 0., w = 0.;
@@ -1926,6 +1990,7 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
     const double tot = block_sum_w<3>(acc, s3);
     if (tid == 0) {
         D.part_b[blockIdx.x] = tot;
+        if (look) look_store(D.part_c, blockIdx.x, spm);
         if (blockIdx.x == 0 && !init) {
             D.scal[2] = rz;
             D.flags[1] += 1;

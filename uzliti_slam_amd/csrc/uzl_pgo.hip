@@ -34,7 +34,6 @@ void k_set_scalar(double* dst, double v, hipStream_t s);
 void k_set_scalar2(double* dst_a, double va, double* dst_b, double vb, hipStream_t s);
 void k_residual_guard(const PgoDev& D, hipStream_t s);
 void k_pcg_progress(const PgoDev& D, hipStream_t s);
-void kb_pcg_progress(const BatchSlot* sl, const BatchDyn* dy, int nb_, int max_nb, hipStream_t s);
 void k_set_trial(double* scal, double lambda, double tol_f2, double eps_t, double eps_r, hipStream_t s);
 int k_pcg_init(const PgoDev& D, double* p0, double* p1, hipStream_t s);
 int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
@@ -268,7 +267,8 @@ void fetch_scal(uzl_pgo* h)
 // The relative test on r.M^-1 r remains as a floor two orders below pcg_tol (kTolFloor2 on its square): it ends solves whose target is
 // below what the arithmetic can settle.
 constexpr double kStepT = 1.0, kStepR = 0.1, kTolFloor2 = 1e-4;
-constexpr int kProgressEvery = 8;             // PCG iterations between two looks (even; a graph replay of 2 x kGraphPairs iterations ends with one)
+constexpr int kProgressEveryBJ = 8;           // block-Jacobi path: PCG iterations between two looks (a launch of their own; the multilevel path looks every
+                                              // kProgressEvery iterations inside its kernels, pgo_types.hpp)
 inline double tol_factor2(int, double, int) { return kTolFloor2; }
 // How stale is a kept preconditioner?  Not the iteration count of the last solve (with an absolute stop test that follows the size of
 // the LM step and lambda, not the operator): the CONTRACTION it delivers, nats of r.M^-1 r per PCG iteration.  rz_stop = scal[1] is
@@ -316,7 +316,7 @@ void alloc_problem(uzl_pgo* h)
     h->d_zinv.reserve(e * 7); h->d_info.reserve(e * 36); h->d_robust.reserve(e);
     h->d_ei.reserve(e); h->d_ej.reserve(e); h->d_slot_i.reserve(e); h->d_slot_j.reserve(e);
     h->d_v2b.reserve(n);
-    h->d_part_a.reserve(kMaxPartials); h->d_part_b.reserve(kMaxPartials); h->d_part_c.reserve(kMaxPartials);
+    h->d_part_a.reserve(kMaxPartials); h->d_part_b.reserve(kMaxPartials); h->d_part_c.reserve(2 * kMaxPartials);     // (part_c: two maxima per ml_cg workgroup at a look)
     h->d_scal.reserve(16); h->d_flags.reserve(4);
     h->h_scal.reserve(1, hipHostMallocMapped | hipHostMallocCoherent); h->h_lambda.reserve(1);
     memset(h->h_scal.p, 0, sizeof(PgoHostScal));
@@ -871,7 +871,7 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
         if (timed) h->timer.end(s);
     };
     for (int i = 0; i < 2 * pairs; i++) {
-        if (i > 0 && i % kProgressEvery == 0) progress();
+        if (!ml && i > 0 && i % kProgressEveryBJ == 0) progress();
         double* po = pb[i & 1];
         double* pn = pb[(i & 1) ^ 1];
         hipEvent_t ea = nullptr, eb = nullptr;
@@ -891,7 +891,7 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
             if (timed) h->timer.end(s);
         }
     }
-    progress();
+    if (!ml) progress();
 }
 
 // |r|^2 / |b|^2 a solve under the multiplicative operator must reach.  Deliberately loose: legitimate solves end at 1e-10 .. 1e-6 while
@@ -1653,17 +1653,10 @@ void batch_fetch(uzl_pgo_batch* b)
     b->ring = 0;       // everything enqueued before the publish has executed: the staging ring is free again
 }
 
-// one replay of the batch = 2 x kGraphPairs PCG iterations of every graph, with the progress look at the same iterations as the
-// single-graph replay (enqueue_pcg_pairs): the stop decision is part of the arithmetic that must agree bit for bit
+// one replay of the batch = 2 x kGraphPairs PCG iterations of every graph (the stop test is part of the iteration kernels)
 void batch_pcg_replay(uzl_pgo_batch* b, int B, int g_rows, bool small, double tol2, hipStream_t s, hipEvent_t* ev)
 {
-    const int max_nb = b->replay_nb;
-    static_assert(kProgressEvery % 2 == 0, "the direction buffers ping-pong: a look falls on an even iteration");
-    for (int at = 0; at < 2 * kGraphPairs; at += kProgressEvery) {
-        const int chunk = std::min(kProgressEvery, 2 * kGraphPairs - at);
-        kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, chunk / 2, tol2, s, ev ? ev + 4 * at : nullptr);
-        kb_pcg_progress(b->d_slots.p, b->d_dyn.p, B, max_nb, s);
-    }
+    kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, kGraphPairs, tol2, s, ev);
 }
 
 bool batch_eligible(const uzl_pgo_batch* b)
