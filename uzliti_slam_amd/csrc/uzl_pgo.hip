@@ -176,7 +176,8 @@ struct uzl_pgo {
         double* rg[2] = {nullptr, nullptr};    // double-buffered gather-level residual
         double* y1 = nullptr; double* nsT = nullptr; double* nsX = nullptr;
         double* l1_span_ptr = nullptr;         // level-1 Galerkin arrays (blk | G | M), all-reduced once per linearisation
-        hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+        hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;        // 2 x kGraphPairs PCG iterations
+        hipGraph_t graph_s = nullptr; hipGraphExec_t graph_exec_s = nullptr;    // 2 x kShortPairs: the solves of a converged LM iteration end after 2 - 4
         double lambda_setup = 0.;              // lambda of the last trial set-up of this copy
     } mlb[2];
     double* ml_dense_ptr[2][kMlMaxLevels + 1] = {};   // host copy of MlDev::Ydense per hierarchy copy
@@ -905,11 +906,16 @@ void destroy_pcg_graph(uzl_pgo* h)
     for (auto& B : h->mlb) {
         if (B.graph_exec) { (void)hipGraphExecDestroy(B.graph_exec); B.graph_exec = nullptr; }
         if (B.graph) { (void)hipGraphDestroy(B.graph); B.graph = nullptr; }
+        if (B.graph_exec_s) { (void)hipGraphExecDestroy(B.graph_exec_s); B.graph_exec_s = nullptr; }
+        if (B.graph_s) { (void)hipGraphDestroy(B.graph_s); B.graph_s = nullptr; }
     }
 }
 
 // The launch-bound inner loop is captured once per problem structure and preconditioner copy: every kernel argument (pointers,
-// partial counts, tolerance) is fixed, lambda and the CG scalars live in device memory.
+// partial counts, tolerance) is fixed, lambda and the CG scalars live in device memory.  Two lengths: 2 x kGraphPairs iterations,
+// and 2 x kShortPairs for solves expected to end at once (a launch behind convergence is a no-op, but still ~1.2 us of stream time:
+// a converged LM iteration's solve of 2 - 4 iterations used to pay for 28 of them).
+constexpr int kShortPairs = 2;
 void ensure_pcg_graph(uzl_pgo* h)
 {
     uzl_pgo::MlBuf& B = h->mlb[h->ml_ix];
@@ -919,6 +925,10 @@ void ensure_pcg_graph(uzl_pgo* h)
     enqueue_pcg_pairs(h, kGraphPairs, false);
     UZL_HIP(hipStreamEndCapture(h->stream, &B.graph));
     UZL_HIP(hipGraphInstantiate(&B.graph_exec, B.graph, nullptr, nullptr, 0));
+    UZL_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_pcg_pairs(h, kShortPairs, false);
+    UZL_HIP(hipStreamEndCapture(h->stream, &B.graph_s));
+    UZL_HIP(hipGraphInstantiate(&B.graph_exec_s, B.graph_s, nullptr, nullptr, 0));
     h->structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -945,21 +955,26 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     }
     if (!timed) ensure_pcg_graph(h);
     int launched = 0;
-    // first batch sized from the previous solve, then fixed batches; the kernels no-op once `done` is set
+    // first batch sized from the previous solve (in steps of 2 x kShortPairs iterations), then two short ones, then long ones; the
+    // kernels no-op once `done` is set
     static const int first_pct = diag_int("UZL_FIRST_PCT", 95);
-    int want = h->prev_pcg_iters > 0 ? std::max(2 * kGraphPairs, (h->prev_pcg_iters * first_pct) / 100) : 2 * kGraphPairs;
-    while (true) {
-        want = std::min(want, max_it - launched);
-        const int reps = std::max(1, (want + 2 * kGraphPairs - 1) / (2 * kGraphPairs));
-        for (int i = 0; i < reps; i++) {
-            if (timed) enqueue_pcg_pairs(h, kGraphPairs, h->timer.on);
-            else UZL_HIP(hipGraphLaunch(h->mlb[h->ml_ix].graph_exec, s));
+    constexpr int kStep = 2 * kShortPairs;
+    const int kLong = 2 * kGraphPairs;
+    auto round_up = [](int v) { return ((v + kStep - 1) / kStep) * kStep; };
+    // (+ 1: a solve that ends by the stop test after k iterations is declared done by the ml_spmv of iteration k + 1)
+    int want = h->prev_pcg_iters > 0 ? std::max(kStep, round_up((h->prev_pcg_iters * first_pct) / 100 + 1)) : kLong;
+    for (int round = 0;; round++) {
+        want = round_up(std::max(1, std::min(want, max_it - launched)));
+        if (timed) enqueue_pcg_pairs(h, want / 2, h->timer.on);
+        else {
+            for (int i = 0; i < want / kLong; i++) UZL_HIP(hipGraphLaunch(h->mlb[h->ml_ix].graph_exec, s));
+            for (int i = 0; i < (want % kLong + kStep - 1) / kStep; i++) UZL_HIP(hipGraphLaunch(h->mlb[h->ml_ix].graph_exec_s, s));
         }
-        launched += reps * 2 * kGraphPairs;
+        launched += want;
         k_residual_guard(D, s);                                   // a no-op until `done` is set
         fetch_scal(h);
         if (h->h_scal.p->flags[0] || launched >= max_it) break;
-        want = 2 * kGraphPairs;
+        want = round < 2 ? kStep : kLong;
     }
     UZL_HIP(hipGetLastError());
     *converged = h->h_scal.p->flags[0] != 0 && h->h_scal.p->flags[2] == 0;
@@ -1597,7 +1612,8 @@ struct uzl_pgo_batch {
     std::vector<BatchSlot> slot_host;     // host copies of the resident slots (source of the refill copies)
     int32_t resident = 0;                 // graphs solved at a time (0 = all): uzl_pgo_batch_set_resident
     int graph_rows = 0, graph_nb = 0, replay_nb = 1;      // grid the captured replay was built for / largest system of this optimize
-    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;          // 2 x kGraphPairs PCG iterations of every resident graph
+    hipGraph_t graph_s = nullptr; hipGraphExec_t graph_exec_s = nullptr;      // 2 x kShortPairs (ensure_pcg_graph)
     int32_t last_batched = 0;
     KernelTimer timer;                    // profiling (uzl_pgo_batch_set_profiling): the two PCG kernels, launched eagerly with event pairs
 };
@@ -1611,6 +1627,8 @@ void batch_destroy_graph(uzl_pgo_batch* b)
 {
     if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
     if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
+    if (b->graph_exec_s) { (void)hipGraphExecDestroy(b->graph_exec_s); b->graph_exec_s = nullptr; }
+    if (b->graph_s) { (void)hipGraphDestroy(b->graph_s); b->graph_s = nullptr; }
 }
 
 // per-graph state of the Levenberg-Marquardt loop: the locals of do_optimize
@@ -1653,10 +1671,10 @@ void batch_fetch(uzl_pgo_batch* b)
     b->ring = 0;       // everything enqueued before the publish has executed: the staging ring is free again
 }
 
-// one replay of the batch = 2 x kGraphPairs PCG iterations of every graph (the stop test is part of the iteration kernels)
-void batch_pcg_replay(uzl_pgo_batch* b, int B, int g_rows, bool small, double tol2, hipStream_t s, hipEvent_t* ev)
+// one replay of the batch = 2 x pairs PCG iterations of every graph (the stop test is part of the iteration kernels)
+void batch_pcg_replay(uzl_pgo_batch* b, int B, int g_rows, bool small, int pairs, double tol2, hipStream_t s, hipEvent_t* ev)
 {
-    kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, kGraphPairs, tol2, s, ev);
+    kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, pairs, tol2, s, ev);
 }
 
 bool batch_eligible(const uzl_pgo_batch* b)
@@ -1788,9 +1806,13 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
     b->replay_nb = max_nb;
     if (!b->graph_exec && !eager) {       // the PCG replay: 2 x kGraphPairs iterations of all resident graphs
         UZL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        batch_pcg_replay(b, R, max_rows, small, tol2, s, nullptr);
+        batch_pcg_replay(b, R, max_rows, small, kGraphPairs, tol2, s, nullptr);
         UZL_HIP(hipStreamEndCapture(s, &b->graph));
         UZL_HIP(hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
+        UZL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        batch_pcg_replay(b, R, max_rows, small, kShortPairs, tol2, s, nullptr);
+        UZL_HIP(hipStreamEndCapture(s, &b->graph_s));
+        UZL_HIP(hipGraphInstantiate(&b->graph_exec_s, b->graph_s, nullptr, nullptr, 0));
         b->graph_rows = max_rows; b->graph_nb = max_nb;
     }
     std::vector<BatchDyn> dyn((size_t)R);
@@ -1895,37 +1917,43 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             if (any_trial_cur) kb_ml_trial(b->d_slots.p, b->d_dyn.p, R, 1, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s);
             kb_ml_init(b->d_slots.p, b->d_dyn.p, R, max_rows, small, s);
         }
-        // ---- Solve: replays for every graph in a solve.  As many as the graph that is closest to its predicted end still needs (so the
-        //      first one to finish is seen at once), at least one.
+        // ---- Solve: PCG iterations for every graph in a solve, in steps of 2 x kShortPairs.  As many as the graph that is closest to its
+        //      predicted end still needs (so the first one to finish is seen at once); in step: as many as the slowest needs.
         base_dyn();
-        int reps = 1 << 30;
+        constexpr int kStep = 2 * kShortPairs;
+        const int kLong = 2 * kGraphPairs;
+        int its = 1 << 30;
         bool any_solve = false;
         for (int sl = 0; sl < R; sl++) {
             if (!active(sl) || phase[slot_graph[sl]] != PSolve) continue;
             const int g = slot_graph[sl];
             dyn[sl].mask = kPhSolve;
             any_solve = true;
-            const int want = std::max(2 * kGraphPairs, (G[g].pcg_last * 95) / 100 - launched_g[g]);
-            const int rg = std::max(1, want / (2 * kGraphPairs));
-            reps = (R == Q) ? (reps == (1 << 30) ? rg : std::max(reps, rg)) : std::min(reps, rg);      // in step: everybody waits for the slowest anyway
+            // (+ 1: a solve that the stop test ends after k iterations is declared done by the ml_spmv of iteration k + 1)
+            const int want = G[g].pcg_last > 0 ? std::max(kStep, (((G[g].pcg_last * 95) / 100 + 1 - launched_g[g]) + kStep - 1) / kStep * kStep) : kLong;
+            its = (R == Q) ? (its == (1 << 30) ? want : std::max(its, want)) : std::min(its, want);      // in step: everybody waits for the slowest anyway
         }
         // With every graph resident (no queue) the graphs are kept in step instead: the solve stage runs until ALL of them are done, so
         // that they linearise, rebuild their preconditioners and evaluate in the same passes - a rebuild is ~25 small launches whatever
         // the number of graphs that take part, and sixteen graphs out of step would pay them in almost every pass (measured at 16
         // config-2 graphs: 47 M edges/s in step, 42 M out of step; with a queue behind 64 slots the free-running loop wins).
         const bool in_step = R == Q;
-        while (any_solve) {
+        for (int round = 0; any_solve; round++) {
             batch_upload_dyn(b, dyn);
-            for (int i = 0; i < reps; i++) {
-                if (eager && b->timer.on) {
-                    std::vector<hipEvent_t> ev((size_t)8 * kGraphPairs);
-                    for (int q = 0; q < 2 * kGraphPairs; q++) {
-                        b->timer.pair("ml_spmv_batch", &ev[4 * q], &ev[4 * q + 1]);
-                        b->timer.pair("ml_cg_comp_batch", &ev[4 * q + 2], &ev[4 * q + 3]);
-                    }
-                    batch_pcg_replay(b, R, max_rows, small, tol2, s, ev.data());
-                } else if (eager) batch_pcg_replay(b, R, max_rows, small, tol2, s, nullptr);
-                else UZL_HIP(hipGraphLaunch(b->graph_exec, s));
+            if (eager) {
+                for (int done_its = 0; done_its < its; done_its += kStep) {
+                    if (b->timer.on) {
+                        std::vector<hipEvent_t> ev((size_t)4 * kStep);
+                        for (int q = 0; q < kStep; q++) {
+                            b->timer.pair("ml_spmv_batch", &ev[4 * q], &ev[4 * q + 1]);
+                            b->timer.pair("ml_cg_comp_batch", &ev[4 * q + 2], &ev[4 * q + 3]);
+                        }
+                        batch_pcg_replay(b, R, max_rows, small, kShortPairs, tol2, s, ev.data());
+                    } else batch_pcg_replay(b, R, max_rows, small, kShortPairs, tol2, s, nullptr);
+                }
+            } else {
+                for (int i = 0; i < its / kLong; i++) UZL_HIP(hipGraphLaunch(b->graph_exec, s));
+                for (int i = 0; i < (its % kLong) / kStep; i++) UZL_HIP(hipGraphLaunch(b->graph_exec_s, s));
             }
             kb_residual_guard(b->d_slots.p, b->d_dyn.p, R, s);
             batch_fetch(b);
@@ -1936,7 +1964,7 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
                 if (!(dyn[sl].mask & kPhSolve)) continue;
                 const int g = slot_graph[sl];
                 BatchLM& X = G[g];
-                launched_g[g] += reps * 2 * kGraphPairs;
+                launched_g[g] += its;
                 const PgoHostScal& P = b->h_pub.p[sl];
                 const int max_it_g = b->cfg.pcg_max_iter > 0 ? b->cfg.pcg_max_iter : 6 * std::max(b->h[g]->nb, 1);     // the cap uzl_pgo_optimize gives this graph
                 if (!P.flags[0] && launched_g[g] < max_it_g) { still = true; continue; }  // still iterating
@@ -1959,7 +1987,7 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
                 phase[g] = PEval;
             }
             if (!(in_step && still)) break;
-            reps = 1;
+            its = round < 2 ? kStep : kLong;
         }
         // ---- Eval: retraction, chi2 of the trial, rho, accept / reject
         base_dyn();
