@@ -1930,8 +1930,12 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             dyn[sl].mask = kPhSolve;
             any_solve = true;
             // (+ 1: a solve that the stop test ends after k iterations is declared done by the ml_spmv of iteration k + 1)
-            const int want = G[g].pcg_last > 0 ? std::max(kStep, (((G[g].pcg_last * 95) / 100 + 1 - launched_g[g]) + kStep - 1) / kStep * kStep) : kLong;
-            its = (R == Q) ? (its == (1 << 30) ? want : std::max(its, want)) : std::min(its, want);      // in step: everybody waits for the slowest anyway
+            // in step: everybody waits for the slowest anyway, and the steps are fine.  Free-running: every pass costs an upload, a publish and
+            // a host round trip whatever it launches, so a pass is at least one long replay (as fine as in step: 256 queued graphs on 64
+            // slots 53 -> 41 M edges/s)
+            const int fine = G[g].pcg_last > 0 ? std::max(kStep, (((G[g].pcg_last * 95) / 100 + 1 - launched_g[g]) + kStep - 1) / kStep * kStep) : kLong;
+            const int want = (R == Q) ? fine : std::max(kLong, fine / kLong * kLong);
+            its = (R == Q) ? (its == (1 << 30) ? want : std::max(its, want)) : std::min(its, want);
         }
         // With every graph resident (no queue) the graphs are kept in step instead: the solve stage runs until ALL of them are done, so
         // that they linearise, rebuild their preconditioners and evaluate in the same passes - a rebuild is ~25 small launches whatever
