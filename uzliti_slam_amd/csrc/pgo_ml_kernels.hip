@@ -467,12 +467,12 @@ __device__ __forceinline__ void diag6(const MlLevel& F, int i, double lambda, do
 }
 
 // AP[i][p] = sum_j A_ij P_j over the children j of level-2 aggregate p
-__device__ __forceinline__ void ml_mult_ap_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl)
+__device__ __forceinline__ void ml_mult_ap_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl, int blk = blockIdx.x)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
     const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan;
-    const int t = blockIdx.x * kBlk + threadIdx.x;
+    const int t = blk * kBlk + threadIdx.x;
     if (t >= n * np) return;
     const int i = t / np, p = t % np;
     const double lambda = D.scal[3];
@@ -499,12 +499,12 @@ __global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev*
 }
 
 // Q[i][p] = P_i [p == parent(i)] - sum_{j in siblings(i)} S_ij AP[j][p]          (one lane per block ROW: 6x the lanes)
-__device__ __forceinline__ void ml_mult_q_kernel_body(const MlDev* __restrict__ mlp, int cl)
+__device__ __forceinline__ void ml_mult_q_kernel_body(const MlDev* __restrict__ mlp, int cl, int blk = blockIdx.x)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
     const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
-    const int tt = blockIdx.x * kBlk + threadIdx.x;
+    const int tt = blk * kBlk + threadIdx.x;
     if (tt >= n * np * 6) return;
     const int t = tt / 6, r = tt % 6;
     const int i = t / np, p = t % np, g = i / fan;
@@ -557,12 +557,12 @@ __global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restric
 }
 
 // AS[j][i'] = sum_{j' in siblings(i')} A_jj' S_j'i'
-__device__ __forceinline__ void ml_mult_as_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl)
+__device__ __forceinline__ void ml_mult_as_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl, int blk = blockIdx.x)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
     const int n = F.n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
-    const int t = blockIdx.x * kBlk + threadIdx.x;
+    const int t = blk * kBlk + threadIdx.x;
     if (t >= n * n) return;
     const int j = t / n, ip = t % n, gp = ip / fan;
     const double lambda = D.scal[3];
@@ -588,16 +588,16 @@ __global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev*
 }
 
 // Y_1[i][i'] = 2 S_ii' - sum_{j in siblings(i)} S_ij AS[j][i']      (+ sum_p QY[i][p] Q[i'][p]^T: ml_mult_qyqt_kernel, on the matrix cores)
-__device__ __forceinline__ void ml_mult_final_kernel_body(const MlDev* __restrict__ mlp, int cl)
+__device__ __forceinline__ void ml_mult_final_kernel_body(const MlDev* __restrict__ mlp, int cl, int tile = blockIdx.x, int lane = threadIdx.x)
 {
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
     const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
-    // one 64-lane workgroup per (group, group') tile of fan x fan blocks: the tile's rows of AS are shared through L1 instead of
+    // one 64-lane wave per (group, group') tile of fan x fan blocks: the tile's rows of AS are shared through L1 instead of
     // being fetched once per block from L2
-    const int g = blockIdx.x / np, gp = blockIdx.x % np;
-    const int i = g * fan + (int)threadIdx.x / fan, ip = gp * fan + (int)threadIdx.x % fan;
-    if ((int)threadIdx.x >= fan * fan || i >= n || ip >= n) return;
+    const int g = tile / np, gp = tile % np;
+    const int i = g * fan + lane / fan, ip = gp * fan + lane % fan;
+    if (tile >= np * np || lane >= fan * fan || i >= n || ip >= n) return;
     const double* __restrict__ Wi = F.Winv + (size_t)g * m * m + (size_t)((i % fan) * 6) * m;
     double acc[36];
 #pragma unroll
@@ -618,6 +618,18 @@ __device__ __forceinline__ void ml_mult_final_kernel_body(const MlDev* __restric
 __global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restrict__ mlp, int cl)
 {
     ml_mult_final_kernel_body(mlp, cl);
+}
+// Two launches instead of four for a single graph's rebuild (a chain of ~35 small dependent launches that the early LM iterations wait
+// for): A P and A S depend on nothing inside the cycle, Q needs only A P and the 2 S - S (A S) part of Y only A S.
+__global__ __launch_bounds__(kBlk) void ml_mult_ap_as_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl, int g_ap)
+{
+    if ((int)blockIdx.x < g_ap) ml_mult_ap_kernel_body(D, mlp, cl, blockIdx.x);
+    else ml_mult_as_kernel_body(D, mlp, cl, blockIdx.x - g_ap);
+}
+__global__ __launch_bounds__(kBlk) void ml_mult_q_final_kernel(const MlDev* __restrict__ mlp, int cl, int g_q)
+{
+    if ((int)blockIdx.x < g_q) ml_mult_q_kernel_body(mlp, cl, blockIdx.x);
+    else ml_mult_final_kernel_body(mlp, cl, ((int)blockIdx.x - g_q) * (kBlk / 64) + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
 }
 
 // ---- composite path: Newton-Schulz refinement  X <- 2 X - X A_1 X  of the dense level-1 operator (X = Y_1 is already a
@@ -2027,12 +2039,10 @@ void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s)
 void k_ml_mult_level(const PgoDev& D, const MlDev* ml, int lev, int n1, int n2, hipStream_t s)
 {
     const int g12 = (n1 * n2 + kBlk - 1) / kBlk, g11 = (n1 * n1 + kBlk - 1) / kBlk;
-    hipLaunchKernelGGL(ml_mult_ap_kernel, dim3(g12), dim3(kBlk), 0, s, D, ml, lev);
-    hipLaunchKernelGGL(ml_mult_as_kernel, dim3(g11), dim3(kBlk), 0, s, D, ml, lev);
-    const int g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk;
-    hipLaunchKernelGGL(ml_mult_q_kernel, dim3(g12r), dim3(kBlk), 0, s, ml, lev);
+    hipLaunchKernelGGL(ml_mult_ap_as_kernel, dim3(g12 + g11), dim3(kBlk), 0, s, D, ml, lev, g12);
+    const int g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk, gfin = (n2 * n2 + kBlk / 64 - 1) / (kBlk / 64);
+    hipLaunchKernelGGL(ml_mult_q_final_kernel, dim3(g12r + gfin), dim3(kBlk), 0, s, ml, lev, g12r);
     hipLaunchKernelGGL(ml_mult_qy_kernel, dim3(g12r), dim3(kBlk), 0, s, ml, lev);
-    hipLaunchKernelGGL(ml_mult_final_kernel, dim3(n2 * n2), dim3(64), 0, s, ml, lev);
     const int gt = (6 * n1 + kGemmTile - 1) / kGemmTile;
     hipLaunchKernelGGL(ml_mult_qyqt_kernel, dim3(gt * (gt + 1) / 2), dim3(256), 0, s, ml, lev);
 }
