@@ -81,7 +81,10 @@ def oracle_online(oracle, run, ransac_iteration=200, seed=777, gate_cfg=None, **
         def _open_handles(self, device, mc, gate_cfg_, filter_cfg, pgo_cfg):
             self.matcher = OMatch(oracle, ransac_iteration, seed)
             if self.is_solver:
-                self.gate = oracle.Gate(**(gate_cfg_ or {}))
+                class OGate(oracle.Gate):           # the checker always runs the reference's search
+                    def check(self, cand, want_dist=True):
+                        return oracle.Gate.check(self, cand)
+                self.gate = OGate(**(gate_cfg_ or {}))
                 self.filt = OFilter(oracle, run["stamps_ns"], seed=seed)
                 self.pgo = OPgo(oracle)
 

@@ -57,6 +57,30 @@ def test_gate_equals_oracle(capi, oracle, n, e, seed, n_cand, cfg):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("n,e,seed,n_cand,cfg", [
+    (300, 1200, 5, 400, dict()),
+    (1000, 5000, 6, 700, dict()),
+    (400, 1500, 7, 300, dict(min_accept_valid=60.0)),
+    (200, 700, 8, 200, dict(min_matching_score=40.0, max_edge_distance_T=1.5, max_edge_distance_R=35.0, scope_size_factor=0.3)),
+    (300, 1200, 9, 300, dict(scope_size_factor=0.0)),                          # the tests do not depend on the path length at all
+])
+def test_verdicts_without_path_lengths(capi, oracle, n, e, seed, n_cand, cfg):
+    """astar_dist = NULL: uzl_gate_check may skip every search whose verdict the straight-line distance between the two nodes decides
+    (checkEdgeHeuristic is monotone in the path length, and no path is shorter than the straight line).  The verdicts - and the graph
+    the later candidates of the call see - must be the reference's all the same."""
+    P, E, merged, c = scenario(capi, n, e, seed, n_cand)
+    g = capi.Gate(**cfg); o = oracle.Gate(**cfg)
+    g.set_graph(P, E, merged); o.set_graph(P, E, merged)
+    ag, vg, dg = g.check(c, want_dist=False)
+    ao, vo, do = o.check(c)
+    assert dg is None
+    assert np.array_equal(ag, ao) and np.array_equal(vg, vo)
+    assert g.edge_count() == o.edge_count()
+    ag2, _, _ = g.check(c, want_dist=False)
+    assert ag2.sum() == 0
+    g.close(); o.close()
+
+
 def test_gate_known_answers_on_gpu(capi, oracle):
     n = 30
     xyz = np.stack([0.3 * np.arange(n), np.zeros(n), np.zeros(n)], 1)

@@ -738,13 +738,15 @@ class Gate:
         self._check(lib().uzl_gate_set_graph(self._h, C.c_int32(len(P)), _p(P, c_f64p), _p(m, c_u8p), C.c_int32(len(E)),
                                              _p(E, C.c_void_p) if len(E) else None))
 
-    def check(self, cand):
-        """-> (accept u8, valid u8, astar_dist f64) per candidate, in order."""
+    def check(self, cand, want_dist=True):
+        """-> (accept u8, valid u8, astar_dist f64 or None) per candidate, in order.  want_dist=False passes astar_dist = NULL: the verdicts
+        are the same, and the searches whose verdict the straight-line distance between the nodes already decides are not run."""
         Cn = np.ascontiguousarray(cand, GATE_EDGE_DTYPE)
         n = len(Cn)
-        acc = np.zeros(max(n, 1), np.uint8); val = np.zeros(max(n, 1), np.uint8); dist = np.zeros(max(n, 1))
-        self._check(lib().uzl_gate_check(self._h, C.c_int32(n), _p(Cn, C.c_void_p) if n else None, _p(acc, c_u8p), _p(val, c_u8p), _p(dist, c_f64p)))
-        return acc[:n], val[:n], dist[:n]
+        acc = np.zeros(max(n, 1), np.uint8); val = np.zeros(max(n, 1), np.uint8); dist = np.zeros(max(n, 1)) if want_dist else None
+        self._check(lib().uzl_gate_check(self._h, C.c_int32(n), _p(Cn, C.c_void_p) if n else None, _p(acc, c_u8p), _p(val, c_u8p),
+                                         _p(dist, c_f64p) if want_dist else None))
+        return acc[:n], val[:n], (dist[:n] if want_dist else None)
 
     def edge_count(self):
         return self._check(lib().uzl_gate_edge_count(self._h))

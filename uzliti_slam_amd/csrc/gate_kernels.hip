@@ -62,6 +62,41 @@ __device__ __forceinline__ double angle_of(const double* m)
     return 2. * acos(w);
 }
 
+// diff_pose = pose(source)^-1 pose(target): its translation norm [m] and rotation angle [deg] (checkEdgeHeuristic, :1069-1072)
+__device__ __forceinline__ void pose_gap(const double* __restrict__ poses, int source, int target, double& dn, double& drot)
+{
+    const double* A = poses + 12 * (size_t)source;
+    const double* B = poses + 12 * (size_t)target;
+    double Rd[9], ti[3], td[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) Rd[r * 3 + cc] = (A[0 * 4 + r] * B[0 * 4 + cc] + A[1 * 4 + r] * B[1 * 4 + cc]) + A[2 * 4 + r] * B[2 * 4 + cc];
+        ti[r] = -((A[0 * 4 + r] * A[3] + A[1 * 4 + r] * A[7]) + A[2 * 4 + r] * A[11]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) td[r] = ((A[0 * 4 + r] * B[3] + A[1 * 4 + r] * B[7]) + A[2 * 4 + r] * B[11]) + ti[r];
+    dn = sqrt((td[0] * td[0] + td[1] * td[1]) + td[2] * td[2]);
+    drot = 180. * angle_of(Rd) / M_PI;
+}
+// Is checkEdgeHeuristic's verdict already known without the search?  The verdict is `true` when the target is not reachable, and
+// otherwise when  2 ssf dist + 1 > |t|  and  10 ssf dist + 30 > angle  for the path length `dist` the search finds.  Every path is
+// at least as long as the straight line between its end nodes (its pieces are the straight lines between consecutive nodes), both
+// tests are monotone in dist (also in floating point: a product with a non-negative constant and a sum), so if they hold for the
+// straight line - shortened by 1e-9 of itself, a thousand times the rounding a 20 000-piece sum can collect - they hold for whatever
+// the search would return, and so does `true`.  Only a caller that wants the path length itself needs the search then.
+__device__ __forceinline__ bool gate_decided(const double* __restrict__ poses, int source, int target, double ssf)
+{
+    if (!(ssf >= 0.)) return false;
+    double dn, drot;
+    pose_gap(poses, source, target, dn, drot);
+    const double* A = poses + 12 * (size_t)source;
+    const double* B = poses + 12 * (size_t)target;
+    const double dx = B[3] - A[3], dy = B[7] - A[7], dz = B[11] - A[11];
+    const double lower = sqrt((dx * dx + dy * dy) + dz * dz) * (1. - 1e-9);
+    return (2 * ssf * lower + 1.0 > dn) && (10 * ssf * lower + 30.0 > drot);
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(kGateBlock) void gate_kernel(GateArgs a)
@@ -81,6 +116,7 @@ __global__ __launch_bounds__(kGateBlock) void gate_kernel(GateArgs a)
     const double tn = sqrt((T[3] * T[3] + T[7] * T[7]) + T[11] * T[11]);
     if (!(tn <= a.max_T && diff_rot <= a.max_R)) return;                             // :803
     a.pre_ok[k] = 1;
+    if (a.skip_decided && gate_decided(a.poses, c.from, c.to, a.ssf)) { a.heur_ok[k] = 1; a.dist[k] = -2.; return; }
 
     // ---- SlamGraph::astar(source = from, target = to)
     const int source = c.from, target = c.to, n = a.n;
@@ -131,19 +167,8 @@ __global__ __launch_bounds__(kGateBlock) void gate_kernel(GateArgs a)
     // ---- checkEdgeHeuristic (:1064-1085)
     bool ok = true;
     if (dist != DBL_MAX) {
-        const double* A = a.poses + 12 * (size_t)source;
-        const double* B = a.poses + 12 * (size_t)target;
-        double Rd[9], ti[3], td[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-#pragma unroll
-            for (int cc = 0; cc < 3; cc++) Rd[r * 3 + cc] = (A[0 * 4 + r] * B[0 * 4 + cc] + A[1 * 4 + r] * B[1 * 4 + cc]) + A[2 * 4 + r] * B[2 * 4 + cc];
-            ti[r] = -((A[0 * 4 + r] * A[3] + A[1 * 4 + r] * A[7]) + A[2 * 4 + r] * A[11]);
-        }
-#pragma unroll
-        for (int r = 0; r < 3; r++) td[r] = ((A[0 * 4 + r] * B[3] + A[1 * 4 + r] * B[7]) + A[2 * 4 + r] * B[11]) + ti[r];
-        const double dn = sqrt((td[0] * td[0] + td[1] * td[1]) + td[2] * td[2]);
-        const double drot = 180. * angle_of(Rd) / M_PI;
+        double dn, drot;
+        pose_gap(a.poses, source, target, dn, drot);
         ok = (2 * a.ssf * dist + 1.0 > dn) && (10 * a.ssf * dist + 30.0 > drot);     // :1074-1075
     }
     a.heur_ok[k] = ok ? 1 : 0;
@@ -170,6 +195,7 @@ __global__ __launch_bounds__(64) void gate_wave_kernel(GateWaveArgs a)
     __shared__ int32_t sv[kGateOpenCap];
     const int k = blockIdx.x, lane = threadIdx.x;
     if (k >= a.n_query) return;
+    if (!a.run[k] && a.keep_unrun) return;
     if (lane == 0) { a.pre_ok[k] = 0; a.heur_ok[k] = 0; a.dist[k] = -1.; a.redo[k] = 0; }
     if (!a.run[k]) return;
     const uzl_gate_edge c = a.cand[k];
@@ -180,6 +206,7 @@ __global__ __launch_bounds__(64) void gate_wave_kernel(GateWaveArgs a)
     const double tn = sqrt((T[3] * T[3] + T[7] * T[7]) + T[11] * T[11]);
     if (!(tn <= a.max_T && diff_rot <= a.max_R)) return;                             // :803
     if (lane == 0) a.pre_ok[k] = 1;
+    if (a.skip_decided && gate_decided(a.poses, c.from, c.to, a.ssf)) { if (lane == 0) { a.heur_ok[k] = 1; a.dist[k] = -2.; } return; }
 
     // ---- SlamGraph::astar(source = from, target = to)
     const int source = c.from, target = c.to, n = a.n;
@@ -275,19 +302,8 @@ __global__ __launch_bounds__(64) void gate_wave_kernel(GateWaveArgs a)
     // ---- checkEdgeHeuristic (:1064-1085)
     bool ok = true;
     if (dist != DBL_MAX) {
-        const double* A = a.poses + 12 * (size_t)source;
-        const double* B = a.poses + 12 * (size_t)target;
-        double Rd[9], ti[3], td[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-#pragma unroll
-            for (int cc = 0; cc < 3; cc++) Rd[r * 3 + cc] = (A[0 * 4 + r] * B[0 * 4 + cc] + A[1 * 4 + r] * B[1 * 4 + cc]) + A[2 * 4 + r] * B[2 * 4 + cc];
-            ti[r] = -((A[0 * 4 + r] * A[3] + A[1 * 4 + r] * A[7]) + A[2 * 4 + r] * A[11]);
-        }
-#pragma unroll
-        for (int r = 0; r < 3; r++) td[r] = ((A[0 * 4 + r] * B[3] + A[1 * 4 + r] * B[7]) + A[2 * 4 + r] * B[11]) + ti[r];
-        const double dn = sqrt((td[0] * td[0] + td[1] * td[1]) + td[2] * td[2]);
-        const double drot = 180. * angle_of(Rd) / M_PI;
+        double dn, drot;
+        pose_gap(a.poses, source, target, dn, drot);
         ok = (2 * a.ssf * dist + 1.0 > dn) && (10 * a.ssf * dist + 30.0 > drot);     // :1074-1075
     }
     a.heur_ok[k] = ok ? 1 : 0;
@@ -369,6 +385,7 @@ __global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
     const double tn = sqrt((T[3] * T[3] + T[7] * T[7]) + T[11] * T[11]);
     if (!(tn <= a.max_T && diff_rot <= a.max_R)) return;                             // :803
     if (lane == 0) a.pre_ok[k] = 1;
+    if (a.skip_decided && gate_decided(a.poses, c.from, c.to, a.ssf)) { if (lane == 0) { a.heur_ok[k] = 1; a.dist[k] = -2.; } return; }
 
     const int source = c.from, target = c.to, n = a.n, nwords = (n + 31) / 32;
     unsigned* __restrict__ opened = closed + nwords;
@@ -536,22 +553,159 @@ __global__ __launch_bounds__(64) void gate_reg_kernel(GateWaveArgs a)
     // ---- checkEdgeHeuristic (:1064-1085)
     bool ok = true;
     if (dist != DBL_MAX) {
-        const double* A = a.poses + 12 * (size_t)source;
-        const double* B = a.poses + 12 * (size_t)target;
-        double Rd[9], ti[3], td[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-#pragma unroll
-            for (int cc = 0; cc < 3; cc++) Rd[r * 3 + cc] = (A[0 * 4 + r] * B[0 * 4 + cc] + A[1 * 4 + r] * B[1 * 4 + cc]) + A[2 * 4 + r] * B[2 * 4 + cc];
-            ti[r] = -((A[0 * 4 + r] * A[3] + A[1 * 4 + r] * A[7]) + A[2 * 4 + r] * A[11]);
-        }
-#pragma unroll
-        for (int r = 0; r < 3; r++) td[r] = ((A[0 * 4 + r] * B[3] + A[1 * 4 + r] * B[7]) + A[2 * 4 + r] * B[11]) + ti[r];
-        const double dn = sqrt((td[0] * td[0] + td[1] * td[1]) + td[2] * td[2]);
-        const double drot = 180. * angle_of(Rd) / M_PI;
+        double dn, drot;
+        pose_gap(a.poses, source, target, dn, drot);
         ok = (2 * a.ssf * dist + 1.0 > dn) && (10 * a.ssf * dist + 30.0 > drot);     // :1074-1075
     }
     a.heur_ok[k] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// A search that only has to DECIDE (uzl_gate_check without astar_dist).  checkEdgeHeuristic's verdict is `true` when the target is not
+// reachable and otherwise when two tests that are monotone in the found path length `dist` hold; and dist - the length, summed from the
+// source, of SOME path over the valid edges - is at least the shortest-path distance d*.  More precisely, with the same edge lengths
+// (rec_dist) and floating-point sums that are monotone in their first operand: while Dijkstra's search from the source has not
+// closed the target, the smallest key m in its open list is a lower bound of the length of every path to the target as the
+// reference's search would sum it (walk the path from the source to its first node Dijkstra has not closed: that node is in the list
+// with a key no larger than the path's sum up to there).  So: Dijkstra from the source, and
+//   * the list runs empty                        -> the target is not reachable: verdict true;
+//   * the popped key m passes both tests         -> whatever dist the reference's search finds passes them too: verdict true;
+//   * the target is popped first (m = d*)        -> undecided (the greedy path may still be long enough): the real search runs.
+// The ball this search covers has a radius of metres (config 5: at most 10 m of path, against greedy searches that wander over
+// hundreds): a few hundred expansions instead of thousands.  Open list in registers (key = g; duplicates instead of decrease-key,
+// stale ones skipped at the pop), closed bitmap and record cache in LDS as in gate_reg_kernel.
+__global__ __launch_bounds__(64) void gate_bound_kernel(GateWaveArgs a)
+{
+    constexpr int kSlots = 4;
+    extern __shared__ unsigned char gsm[];
+    unsigned long long* __restrict__ cache = reinterpret_cast<unsigned long long*>(gsm);
+    int32_t* __restrict__ tag = reinterpret_cast<int32_t*>(cache + kGateCacheBlocks * kGateBlockNodes * 8);
+    unsigned* __restrict__ closed = reinterpret_cast<unsigned*>(tag + kGateCacheBlocks);
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k >= a.n_query) return;
+    if (lane == 0) { a.pre_ok[k] = 0; a.heur_ok[k] = 0; a.dist[k] = -1.; a.redo[k] = 0; }
+    if (!a.run[k]) return;
+    const uzl_gate_edge c = a.cand[k];
+    if (!(c.matching_score >= a.min_score)) return;                                  // :798
+    const double* T = c.transform;
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    const double diff_rot = fabs(angle_of(R)) * 180 / M_PI;                           // :800-801
+    const double tn = sqrt((T[3] * T[3] + T[7] * T[7]) + T[11] * T[11]);
+    if (!(tn <= a.max_T && diff_rot <= a.max_R)) return;                             // :803
+    if (lane == 0) a.pre_ok[k] = 1;
+    const int source = c.from, target = c.to, n = a.n, nwords = (n + 31) / 32;
+    if (!(a.ssf >= 0.)) { if (lane == 0) a.redo[k] = 2; return; }                     // the tests are not monotone in dist: the real search
+    double dn, drot;
+    pose_gap(a.poses, source, target, dn, drot);
+    auto passes = [&](double d) { return (2 * a.ssf * d + 1.0 > dn) && (10 * a.ssf * d + 30.0 > drot); };
+    if (gate_decided(a.poses, source, target, a.ssf)) { if (lane == 0) { a.heur_ok[k] = 1; a.dist[k] = -2.; } return; }
+
+    for (int i = lane; i < nwords; i += 64) closed[i] = 0u;
+    if (lane < kGateCacheBlocks) tag[lane] = -1;
+    __syncthreads();
+    auto fetch_block = [&](int u) {
+        const int blk = u >> kGateBlockShift, slot = blk & (kGateCacheBlocks - 1);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.rec) + (size_t)blk * (kGateBlockNodes * 4);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(cache) + slot * (kGateBlockNodes * 4);
+        const uint4 q0 = src[lane], q1 = src[lane + 64];
+        dst[lane] = q0; dst[lane + 64] = q1;
+        if (lane == 0) tag[slot] = blk;
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto rec_of = [&](int u) { return reinterpret_cast<const GateNodeRec*>(cache + ((u >> kGateBlockShift) & (kGateCacheBlocks - 1)) * (kGateBlockNodes * 8) + (u & (kGateBlockNodes - 1)) * 8); };
+    auto tag_ok = [&](int u) { return tag[(u >> kGateBlockShift) & (kGateCacheBlocks - 1)] == (u >> kGateBlockShift); };
+    const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+    double lw[kSlots]; int lv[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) { lw[j] = kInf; lv[j] = -1; }
+    if (lane == 0) { lw[0] = 0.; lv[0] = source; }
+    int n_list = 1;
+    int verdict = 1;                                       // 1: decided true, 2: undecided
+    while (n_list > 0) {
+        double bw = lw[0]; int bv = lv[0], bk = 0;
+#pragma unroll
+        for (int j = 1; j < kSlots; j++) if (lw[j] < bw) { bw = lw[j]; bv = lv[j]; bk = j; }
+        bool mine;
+        const double m = wave_min_pos_f64(bw, mine);
+        const int src = __ffsll((long long)__ballot(mine)) - 1;
+        const int v = __builtin_amdgcn_readlane(bv, src);
+        if (passes(m)) break;                              // every path to the target is at least m long
+        if (v == target) { verdict = 2; break; }           // d* itself does not pass: only the real search can tell
+        if (lane == src) {
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) if (j == bk) lw[j] = kInf;
+        }
+        n_list--;
+        const unsigned cw = closed[v >> 5];
+        if ((cw >> (v & 31)) & 1u) continue;               // a stale duplicate
+        if (!tag_ok(v)) fetch_block(v);
+        const GateNodeRec* vrp = rec_of(v);
+        const double vx = vrp->px, vy = vrp->py, vz = vrp->pz;
+        const int deg = vrp->deg & ~kGateRecMulti, adj = vrp->adj;
+        if (lane == 0) closed[v >> 5] = cw | (1u << (v & 31));
+        bool over = false;
+        for (int base = 0; base < deg; base += 64) {
+            const int q = base + lane;
+            int u = -1;
+            if (q < deg) u = q < kGateRecNbr ? vrp->nbr[q & (kGateRecNbr - 1)] : a.adj_nbr[adj + q];
+            const int us = u >= 0 ? u : 0;
+            const unsigned cu = closed[us >> 5];
+            bool got = tag_ok(us);
+            const GateNodeRec* urp = rec_of(us);
+            double ux = urp->px, uy = urp->py, uz = urp->pz;
+            const bool act = u >= 0 && u != v && !((cu >> (us & 31)) & 1u);
+            got = got || !act;
+            while (true) {
+                const unsigned long long miss = __ballot(!got);
+                if (!miss) break;
+                const int um = __builtin_amdgcn_readlane(us, __ffsll((long long)miss) - 1);
+                fetch_block(um);
+                if (!got && (us >> kGateBlockShift) == (um >> kGateBlockShift)) { ux = urp->px; uy = urp->py; uz = urp->pz; got = true; }
+            }
+            const double tent = act ? m + rec_dist(vx, vy, vz, ux, uy, uz) : kInf;
+            unsigned long long pm = __ballot(act);
+            while (pm) {
+                const int s0 = __ffsll((long long)pm) - 1;
+                pm &= pm - 1;
+                const double pw = readlane_f64(tent, s0);
+                const int pu = __builtin_amdgcn_readlane(us, s0);
+                bool fr = false;
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) fr = fr || !(lw[j] < kInf);
+                const unsigned long long fm = __ballot(fr);
+                if (!fm) { over = true; break; }
+                if (lane == __ffsll((long long)fm) - 1) {
+                    bool done = false;
+#pragma unroll
+                    for (int j = 0; j < kSlots; j++) if (!done && !(lw[j] < kInf)) { lw[j] = pw; lv[j] = pu; done = true; }
+                }
+                n_list++;
+            }
+            if (over) break;
+        }
+        if (over) { verdict = 2; break; }                  // the list outgrew the registers: the real search
+    }
+    if (lane != 0) return;
+    if (verdict == 1) { a.heur_ok[k] = 1; a.dist[k] = -2.; }
+    else a.redo[k] = 2;
+}
+
+bool launch_gate_bound(const GateWaveArgs& a, hipStream_t s)
+{
+    if (a.n_query <= 0) return true;
+    const int bytes = gate_lds_bytes(a.n);
+    if (bytes > kGateLdsMax) return false;
+    static int configured = 0;
+    static std::mutex mu;
+    if (bytes > 48 * 1024) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gate_bound_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGateLdsMax) != hipSuccess) return false;
+            configured = 1;
+        }
+    }
+    hipLaunchKernelGGL(gate_bound_kernel, dim3(a.n_query), dim3(64), bytes, s, a);
+    return true;
 }
 
 // false: the graph is too large for the LDS bitmaps (the caller uses gate_wave_kernel)

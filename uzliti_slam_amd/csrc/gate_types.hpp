@@ -30,6 +30,7 @@ struct GateArgs {
     double* dist;                   // astar path length, DBL_MAX = not reachable, -1 = not searched
     int32_t* overflow;              // set when a heap ran out of space
     int32_t keep_unrun;             // 1: leave the outputs of candidates with run == 0 alone (they hold gate_wave_kernel's verdicts)
+    int32_t skip_decided;           // 1: no search for a candidate whose verdict the straight-line distance already decides (dist = -2)
 };
 
 // ---- wave-per-candidate search (gate_wave_kernel) ----
@@ -65,6 +66,7 @@ struct GateWaveArgs {
     uint8_t* pre_ok; uint8_t* heur_ok; double* dist;
     uint8_t* redo;                  // [n_query] 1 = open list overflowed: search this candidate with gate_kernel
     int32_t keep_unrun;             // 1: leave the outputs of candidates with run == 0 alone (they hold an earlier launch's verdicts)
+    int32_t skip_decided;           // 1: no search for a candidate whose verdict the straight-line distance already decides (dist = -2)
     long long* dbg;                 // diagnostic build: [n_query][4] = expansions, shader clocks, 100 MHz ticks, largest open list (else null)
 };
 

@@ -19,6 +19,7 @@ namespace uzl {
 void launch_gate(const GateArgs& a, hipStream_t s);
 void launch_gate_wave(const GateWaveArgs& a, hipStream_t s);
 bool launch_gate_reg(const GateWaveArgs& a, int slots, hipStream_t s);
+bool launch_gate_bound(const GateWaveArgs& a, hipStream_t s);
 }
 using namespace uzl;
 
@@ -52,6 +53,7 @@ struct uzl_gate {
     bool lane_kernel_only = false;   // A/B (diagnostic build, UZL_GATE_LANE=1): every search through gate_kernel, as in round 1
     bool wave_kernel_only = false;   // A/B (UZL_GATE_WAVE=1): gate_wave_kernel (list in LDS, per-node state in HBM) instead of gate_reg_kernel
     int64_t n_wave = 0, n_lane = 0;  // searches run by either kernel (uzl_gate_search_counts)
+    int64_t n_bound = 0;             // candidates the deciding search (gate_bound_kernel) settled without the reference's search
     PinBuf<uint8_t> h_pre, h_heur;
     PinBuf<double> h_dist;
     PinBuf<int32_t> h_over;
@@ -199,7 +201,7 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
     h->d_pre.reserve((size_t)nc); h->d_heur.reserve((size_t)nc); h->d_dist.reserve((size_t)nc); h->d_over.reserve(1);
     h->h_pre.reserve((size_t)nc); h->h_heur.reserve((size_t)nc); h->h_dist.reserve((size_t)nc); h->h_over.reserve(1);
     UZL_HIP(hipMemcpyAsync(h->d_cand.p, cand, sizeof(uzl_gate_edge) * (size_t)nc, hipMemcpyHostToDevice, s));
-    std::vector<uint8_t> run((size_t)nc);
+    std::vector<uint8_t> run((size_t)nc), srch((size_t)nc);
     int32_t first = 0;                                        // candidates before `first` are decided
     constexpr int kChunk = 256;                               // searches per launch (scratch = chunk x (9 n + 16 heap_cap) bytes)
     while (first < nc) {
@@ -231,15 +233,35 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
             h->d_gst.reserve((size_t)m * std::max(n, 1));
             UZL_HIP(hipMemsetAsync(h->d_gst.p, 0, sizeof(GateState) * (size_t)m * std::max(n, 1), s));
         }
+        bool any_left = true;
+        for (int32_t k = first; k < last; k++) srch[k] = run[k];            // which candidates the search stages still have to run
         GateWaveArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.n = n; wa.n_query = m; wa.poses = h->d_poses.p; wa.rec = h->d_rec.p; wa.adj_nbr = h->d_adj_nbr.p;
         wa.cand = h->d_cand.p + first; wa.run = h->d_run.p + first; wa.gst = h->d_gst.p; wa.gclosed = h->d_gclosed.p;
         wa.min_score = h->cfg.min_matching_score; wa.max_T = h->cfg.max_edge_distance_T; wa.max_R = h->cfg.max_edge_distance_R;
         wa.ssf = h->cfg.scope_size_factor;
+        wa.skip_decided = astar_dist ? 0 : 1;             // nobody asked for the path lengths: searches whose verdict is known are skipped
         wa.pre_ok = h->d_pre.p + first; wa.heur_ok = h->d_heur.p + first; wa.dist = h->d_dist.p + first; wa.redo = h->d_redo.p + first;
         if (h->dbg_on) { h->d_dbg.reserve((size_t)m * 8); UZL_HIP(hipMemsetAsync(h->d_dbg.p, 0, sizeof(long long) * 8 * (size_t)m, s)); wa.dbg = h->d_dbg.p; }
-        if (!h->lane_kernel_only) {
+        // Nobody asked for the path lengths: a search that only decides first (gate_bound_kernel).  What it cannot decide goes on to the
+        // reference's search below, the rest keeps its verdict (keep_unrun).
+        if (wa.skip_decided && lds_path && !h->lane_kernel_only && launch_gate_bound(wa, s)) {
+            UZL_HIP(hipGetLastError());
+            UZL_HIP(hipMemcpyAsync(h->h_redo.p + first, h->d_redo.p + first, (size_t)m, hipMemcpyDeviceToHost, s));
+            UZL_HIP(hipStreamSynchronize(s));
+            bool any = false;
+            for (int32_t k = first; k < last; k++) {
+                const bool undecided = run[k] && h->h_redo.p[k] == 2;
+                if (run[k] && !undecided) h->n_bound++;
+                srch[k] = undecided ? 1 : 0; any = any || undecided;
+                h->h_redo.p[k] = 0;
+            }
+            UZL_HIP(hipMemcpyAsync(h->d_run.p + first, srch.data() + first, (size_t)m, hipMemcpyHostToDevice, s));
+            UZL_HIP(hipStreamSynchronize(s));
+            wa.keep_unrun = 1; any_left = any;
+        }
+        if (!h->lane_kernel_only && any_left) {
             bool reg_ok = lds_path && launch_gate_reg(wa, h->reg_slots, s);
             if (!reg_ok) {
                 if (lds_path) {                                                                // the attribute could not be raised: the HBM-state kernel
@@ -259,7 +281,7 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
                 // searches whose open list outgrew two entries per lane: once more with four (and later calls start there)
                 h->reg_slots = 4;
                 std::vector<uint8_t> run4((size_t)m);
-                for (int32_t k = 0; k < m; k++) run4[k] = (run[first + k] && h->h_redo.p[first + k]) ? 1 : 0;
+                for (int32_t k = 0; k < m; k++) run4[k] = (srch[first + k] && h->h_redo.p[first + k]) ? 1 : 0;
                 UZL_HIP(hipMemcpyAsync(h->d_run.p + first, run4.data(), (size_t)m, hipMemcpyHostToDevice, s));
                 wa.keep_unrun = 1;
                 launch_gate_reg(wa, 4, s);
@@ -273,14 +295,14 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
         bool any_redo = h->lane_kernel_only;
         for (int32_t k = first; k < last && !any_redo; k++) any_redo = h->h_redo.p[k] != 0;
         for (int32_t k = first; k < last; k++) {
-            if (!run[k]) continue;
+            if (!srch[k]) continue;
             if (h->lane_kernel_only || h->h_redo.p[k]) h->n_lane++; else h->n_wave++;
         }
         if (any_redo) {
             // candidates whose open list outgrew LDS (or all of them under the A/B switch): the lane kernel with its heap in HBM.
             // Its outputs overwrite pre_ok / heur_ok / dist of every candidate it runs for.
             std::vector<uint8_t> run2((size_t)m);
-            for (int32_t k = 0; k < m; k++) run2[k] = (run[first + k] && (h->lane_kernel_only || h->h_redo.p[first + k])) ? 1 : 0;
+            for (int32_t k = 0; k < m; k++) run2[k] = (srch[first + k] && (h->lane_kernel_only || h->h_redo.p[first + k])) ? 1 : 0;
             UZL_HIP(hipMemcpyAsync(h->d_run.p + first, run2.data(), (size_t)m, hipMemcpyHostToDevice, s));
             UZL_HIP(hipStreamSynchronize(s));
         }
@@ -298,6 +320,7 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
         a.gs = h->d_gs.p; a.st = h->d_st.p; a.heap = h->d_heap.p; a.heap_cap = heap_cap;
         a.min_score = h->cfg.min_matching_score; a.max_T = h->cfg.max_edge_distance_T; a.max_R = h->cfg.max_edge_distance_R;
         a.ssf = h->cfg.scope_size_factor;
+        a.skip_decided = astar_dist ? 0 : 1;
         a.pre_ok = h->d_pre.p + first; a.heur_ok = h->d_heur.p + first; a.dist = h->d_dist.p + first; a.overflow = h->d_over.p;
         a.keep_unrun = h->lane_kernel_only ? 0 : 1;
         if (any_redo) launch_gate(a, s);

@@ -185,7 +185,7 @@ class OnlineSlam:
         if len(cand_pair):
             cands = capi.gate_edges(run["pair_from"][cand_pair], run["pair_to"][cand_pair], np.ones(len(cand_pair), int),
                                     score=res["consensus"][ok].astype(np.float64), transform=res["T"][ok])
-            acc, val, _ = self.gate.check(cands)
+            acc, val, _ = self.gate.check(cands, want_dist=False)
         else:
             acc = np.zeros(0, np.uint8); val = np.zeros(0, np.uint8)
         t_gate = time.perf_counter() - t0
