@@ -518,7 +518,12 @@ int  uzl_gate_set_graph(uzl_gate* h, int32_t n_nodes, const double* poses, const
 /* newEdgeCallback for every candidate in order.  accept[k] = the edge was added to the graph,
  * valid[k] = its valid_ flag (score >= min_accept_valid), astar_dist[k] = path length found
  * (-1: the search was not reached, DBL_MAX: target not reachable).  Outputs may be NULL
- * except accept.  Accepted edges stay in the handle's graph. */
+ * except accept.  Accepted edges stay in the handle's graph.
+ * astar_dist == NULL also means that only the verdicts are wanted: checkEdgeHeuristic's tests are
+ * monotone in the path length, so a lower bound of it that passes them (the straight line between
+ * the nodes, then a shortest-path search that stops at the radius the tests need) decides without
+ * the reference's greedy search; that one runs only for candidates no bound settles.  The verdicts
+ * are the reference's either way. */
 int  uzl_gate_check(uzl_gate* h, int32_t n_candidates, const uzl_gate_edge* candidates,
                     uint8_t* accept, uint8_t* valid, double* astar_dist);
 int  uzl_gate_edge_count(uzl_gate* h);
