@@ -719,9 +719,18 @@ std::vector<int32_t> aggregation_order(const uzl_pgo* h)
 void destroy_pcg_graph(uzl_pgo* h);
 void build_structure(uzl_pgo* h)
 {
+    auto t_prev = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {                       // UZL_VERBOSE: where the host side of a new structure spends its time
+        if (!h->cfg.verbose) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[uzl_pgo] structure: %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     destroy_pcg_graph(h);
+    tick("drop the captured graphs");
     const int n = h->n, e = h->e;
     std::vector<int32_t> v2b((size_t)std::max(n, 1), -1), b2v = aggregation_order(h);
+    tick("aggregation order");
     const int nb = (int)b2v.size();
     for (int b = 0; b < nb; b++) v2b[b2v[b]] = b;
     h->nb = nb;
@@ -792,7 +801,9 @@ void build_structure(uzl_pgo* h)
     const bool may_shard = h->allreduce != nullptr || h->rccl_comm != nullptr;
     std::vector<int32_t> rrow_ptr, rcol;
     if (h->cfg.schur_reduce >= 0 && schur_diag && !may_shard && nb > 0) {
+        tick("block-CSR + uploads");
         SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap);
+        tick("Schur plan");
         if (P.n_int >= 64 && (int64_t)100 * P.n_int >= (int64_t)schur_min_pct * nb) {
             Rd.on = true; Rd.n_int = P.n_int; Rd.n_runs = P.n_runs; Rd.longest_run = P.longest_run;
             const size_t nr = (size_t)std::max(P.nbr, 1), nsr = (size_t)std::max(P.nslots_r, 1), ni = (size_t)P.n_int, nru = (size_t)P.n_runs;
@@ -829,8 +840,10 @@ void build_structure(uzl_pgo* h)
     PgoDev& Dsys = Rd.on ? Dp : D;                                             // what the PCG kernels get
     const int nbp = Dsys.nb;
     double* apbuf = Rd.on ? Rd.ap.p : h->d_ap.p;
+    tick("reduced system uploads");
     if (Rd.on) build_ml(h, rrow_ptr, rcol, nbp, Dsys.nslots, Rd.row_ptr.p, Rd.col.p, Rd.blk.p, Rd.hdiag.p);
     else build_ml(h, row_ptr, col, nb, nslots, h->d_row_ptr.p, h->d_col.p, h->d_blk.p, h->d_hdiag.p);
+    tick("hierarchy (host index arrays + uploads)");
     {   // per-iteration exchange buffer: [A p (6 nb) | restricted A p (6 n_g) | p.Ap partials]
         const int gl = (h->ml_levels == 0) ? 0 : ((h->ml_agg == 1 || h->ml_levels < 2) ? 1 : 2);
         const size_t ng6 = gl ? (size_t)h->ml_n[gl] * 6 * (gl == 2 ? 2 : 1) : 0;      // gather level 2: two half-aggregate parts per entity (sg_at)
@@ -929,6 +942,7 @@ void ensure_pcg_graph(uzl_pgo* h)
     enqueue_pcg_pairs(h, kShortPairs, false);
     UZL_HIP(hipStreamEndCapture(h->stream, &B.graph_s));
     UZL_HIP(hipGraphInstantiate(&B.graph_exec_s, B.graph_s, nullptr, nullptr, 0));
+    if (h->cfg.verbose) fprintf(stderr, "[uzl_pgo] structure: %-28s %.3f ms\n", "PCG graphs of one copy", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     h->structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
