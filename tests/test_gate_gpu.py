@@ -110,6 +110,17 @@ def _counts(capi, g):
     return w.value, l.value
 
 
+def _verdicts_only(capi, P, E, c, accept_ref, cfg, oracle=None):
+    """uzl_gate_check without astar_dist (straight-line shortcut, deciding search, then the reference's search) on the same scenario."""
+    if accept_ref is None:
+        O = oracle.Gate(**cfg); O.set_graph(P, E); accept_ref = O.check(c)[0]; O.close()
+    G = capi.Gate(**cfg)
+    G.set_graph(P, E)
+    a, _, d = G.check(c, want_dist=False)
+    assert d is None and np.array_equal(a, accept_ref)
+    G.close()
+
+
 def test_wave_search_on_long_chains_multi_edges_and_overflow(capi, oracle):
     """The wave-per-candidate search (open list in LDS, neighbours in parallel lanes) against the CPU checker where it differs from
     the lane kernel structurally: paths of thousands of hops along the odometry chain (an online run's shape), a node with more
@@ -134,6 +145,7 @@ def test_wave_search_on_long_chains_multi_edges_and_overflow(capi, oracle):
     w, l = _counts(capi, G)
     assert w > 0 and l == 0                                                  # all of them by the wave kernel
     G.close(); O.close()
+    _verdicts_only(capi, g["nodes_pose"], E, c, ao, dict(max_edge_distance_R=360.0))
     # (b) a hub with 40 neighbours + every edge of the graph listed twice (two edge types between the same nodes)
     g = synth.make_pose_graph(400, 1600, seed=12)
     ed = g["edges"]
@@ -148,6 +160,7 @@ def test_wave_search_on_long_chains_multi_edges_and_overflow(capi, oracle):
     ag, vg, dg = G.check(c); ao, vo, do = O.check(c)
     assert np.array_equal(ag, ao) and dg.tobytes() == do.tobytes()
     G.close(); O.close()
+    _verdicts_only(capi, g["nodes_pose"], E, c, ao, dict(max_edge_distance_T=100.0, max_edge_distance_R=360.0))
     # (c) dense random graph: frontiers of thousands of nodes -> some open lists overflow LDS and fall back to the lane kernel
     n = 6000
     P = np.tile(np.eye(3, 4).reshape(1, 12), (n, 1)); P[:, [3, 7, 11]] = rng.uniform(-30, 30, (n, 3))
@@ -160,3 +173,5 @@ def test_wave_search_on_long_chains_multi_edges_and_overflow(capi, oracle):
     ag, vg, dg = G.check(c); ao, vo, do = O.check(c)
     assert np.array_equal(ag, ao) and dg.tobytes() == do.tobytes()
     G.close(); O.close()
+    _verdicts_only(capi, P, E, c, ao, dict(max_edge_distance_T=100.0, max_edge_distance_R=360.0))      # (the deciding search's list overflows its registers here)
+    _verdicts_only(capi, P, E, c, None, dict(max_edge_distance_T=100.0, max_edge_distance_R=360.0, scope_size_factor=0.004), oracle)   # most need the greedy search

@@ -554,3 +554,36 @@ def test_random_shapes_against_oracle():
     r = subprocess.run([sys.executable, os.path.join(here, "diag", "stress_pgo.py"), "110", "11"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "110 cases, 0 misses" in r.stdout
+
+
+def test_pcg_cap_and_accuracy_settings(capi, oracle):
+    """The replay policy (short and long captured graphs, the stop test inside the iteration kernels) at its edges: a cap of a few PCG
+    iterations ends every solve at the cap and says so; a looser / tighter `pcg_tol` moves the iteration count the right way and both
+    stay inside the north-star tolerance of the CPU checker's direct solve; pcg_tol = 0 (no accuracy target: the relative floor is
+    zero as well) iterates every solve to the cap."""
+    g = synth.make_pose_graph(600, 2400, seed=31)
+    fl = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, _ = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=10)
+
+    def solve(**cfg):
+        p = capi.Pgo(**cfg)
+        p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+        st = p.optimize(10)
+        poses = p.store()[0]
+        p.close()
+        return st, synth.pose_errors(poses.reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+
+    st, _ = solve(pcg_max_iter=3)
+    assert st["status"] == capi.UZL_ERR_NOT_CONVERGED and st["pcg_not_converged"] == st["lm_trials"] > 0
+    # (the cap is checked between replays of 4 iterations, and a solve that did not converge is retried with fresh inverses / the additive operator)
+    assert 3 * st["lm_trials"] <= st["pcg_iterations"] <= 12 * st["lm_trials"]
+    base, (dt, dr) = solve()
+    assert base["status"] == 0 and dt < 1e-3 and dr < 1e-4
+    loose, (dtl, drl) = solve(pcg_tol=1e-4)
+    tight, (dtt, drt) = solve(pcg_tol=1e-7)
+    assert loose["pcg_iterations"] < base["pcg_iterations"] < tight["pcg_iterations"]
+    assert dtl < 1e-3 and drl < 1e-4 and dtt < 1e-3 and drt < 1e-4 and dtt <= dt * 1.5 + 1e-9
+    cap = 40
+    full, _ = solve(pcg_tol=0.0, pcg_max_iter=cap)
+    assert full["pcg_iterations"] >= cap * full["lm_trials"]
