@@ -46,7 +46,7 @@ struct PgoDev {
     double* minv;            // [nb][36]  (H_aa + lambda I)^-1   (block-Jacobi path only; the multilevel path uses MlLevel::Winv)
     double* b;               // [nb][6]
     double* x;               // PCG vectors [nb][6]
-    double* xs;              // x as it was at the last progress check (pcg_progress_kernel)
+    double* xs;              // x as it was at the last look of the stop test (progress_decide, pgo_device.hpp)
     double* r;
     double* z;
     double* p;

@@ -260,8 +260,8 @@ void fetch_scal(uzl_pgo* h)
 // as the metre-sized first one (config 5's last solve spent 5000 of its 6660 PCG iterations on steps below 1e-6 m), and on badly
 // conditioned graphs it still lets too much error through in the soft modes (round 2 carried two corrective heuristics for that:
 // a 10x tighter tolerance while chi2 still moved, and a tolerance shrinking with the previous solve's iteration count).  Both are
-// replaced by an a-posteriori estimate of e itself, taken every 16 iterations from how far x still moves (pcg_progress_kernel,
-// pgo_kernels.hip), against an absolute target derived from cfg.pcg_tol:
+// replaced by an a-posteriori estimate of e itself, taken every kProgressEvery iterations from how far x still moves (progress_decide_ml,
+// pgo_device.hpp: inside the iteration kernels), against an absolute target derived from cfg.pcg_tol:
 //     largest translation component of e  <=  kStepT * pcg_tol  [m]      (default 1e-5: 1e-5 m   = 1/100 of the 1e-3 m bar per LM step)
 //     largest rotation component of e     <=  kStepR * pcg_tol  [q_xyz]  (default       1e-6     ~ 2e-6 rad = 1/50 of the 1e-4 rad bar)
 // LM is self-correcting, so the per-step errors do not add up coherently; twenty of them stay an order of magnitude inside the bar.
