@@ -1140,6 +1140,11 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     constexpr int kGrpU = (kWaves >= 8) ? 2 : 4;          // groups of 64 r.z partials a wave fetches up front (1024 / 1024 / 512 partials in all)
     __shared__ double sgrp[kMaxPartials / 64];
     __shared__ double slook[2][kMaxPartials / 64];      // block 0: the stop test's maxima per group of 64 ml_cg workgroups
+    // The six lanes of a group need the same 6-vector, each holds one component: it goes through a 512-byte LDS line of the wave (one
+    // 8-byte store, three 16-byte broadcast reads; a wave's LDS traffic is processed in order) instead of twelve ds_bpermute - the
+    // kernel is bound by instruction issue as much as by its round trips.  One line per gather: nothing is reused inside a launch.
+    constexpr int kGat = 2 + 3 * kRowsPerWave;
+    __shared__ __attribute__((aligned(16))) double sgat[kWaves][kGat][64];
     __shared__ double sd[kRowsPerBlk * 6];
     __shared__ double sw[kRowsPerBlk * 6];
     __shared__ double ss1[kAggPerBlk * 6];
@@ -1197,6 +1202,14 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     // assembled by shuffles - 4 VGPRs per (row, pass) instead of 24, which is what lets a second workgroup share the CU (the kernel
     // is latency-bound: 313 workgroups of a 10k graph on 256 CUs took two rounds).  Same products, same summation order.
     const int gbase = g * 6;                      // first lane of this lane's group
+    auto gather6 = [&](int slot, double v, int base, double& v0, double& v1, double& v2, double& v3, double& v4, double& v5) {
+        double* line = sgat[wv][slot];
+        line[lane] = v;
+        __builtin_amdgcn_wave_barrier();
+        const double2* __restrict__ p2 = reinterpret_cast<const double2*>(line + base);
+        const double2 a = p2[0], b = p2[1], c = p2[2];
+        v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y; v4 = c.x; v5 = c.y;
+    };
     // lane group q (< AGG) owns the diagonal block, z, p_old and geometry of row q
     double hrow[6] = {0, 0, 0, 0, 0, 0}, zo_r = 0., po_r = 0.;
     const int arow = row0 + g;
@@ -1285,8 +1298,8 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     const double pr = fma(beta, po_r, zo_r);          // component r of the new direction of row `arow` (lanes with dact)
     double acc[kRowsPerWave];
     {
-        const double d0 = __shfl(pr, gbase), d1 = __shfl(pr, gbase + 1), d2 = __shfl(pr, gbase + 2), d3 = __shfl(pr, gbase + 3),
-                     d4 = __shfl(pr, gbase + 4), d5 = __shfl(pr, gbase + 5);
+        double d0, d1, d2, d3, d4, d5;
+        gather6(0, pr, gbase, d0, d1, d2, d3, d4, d5);
 #pragma unroll
         for (int q = 0; q < kRowsPerWave; q++) {
             double dterm = 0.;                        // (H_aa + lambda I) p of row q, in the lanes of group q (they hold H_aa and p)
@@ -1302,8 +1315,8 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
             const double dmov = (kRowsPerWave == 1) ? dterm : __shfl(dterm, 6 * q + (lane < 6 ? lane : 0));
             double aq = (g == 0) ? dmov : 0.;
             const double pc = fma(beta, orr[q], zr[q]);
-            const double v0 = __shfl(pc, gbase), v1 = __shfl(pc, gbase + 1), v2 = __shfl(pc, gbase + 2), v3 = __shfl(pc, gbase + 3),
-                         v4 = __shfl(pc, gbase + 4), v5 = __shfl(pc, gbase + 5);
+            double v0, v1, v2, v3, v4, v5;
+            gather6(2 + q, pc, gbase, v0, v1, v2, v3, v4, v5);
             if (have[q]) aq += dot6(b0[q], b1[q], b2[q], v0, v1, v2, v3, v4, v5);
             acc[q] = aq;
         }
@@ -1328,8 +1341,8 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         double aq = acc[q];
         {
             const double pc = fma(beta, qr[q], yr[q]);
-            const double v0 = __shfl(pc, gbase), v1 = __shfl(pc, gbase + 1), v2 = __shfl(pc, gbase + 2), v3 = __shfl(pc, gbase + 3),
-                         v4 = __shfl(pc, gbase + 4), v5 = __shfl(pc, gbase + 5);
+            double v0, v1, v2, v3, v4, v5;
+            gather6(2 + kRowsPerWave + q, pc, gbase, v0, v1, v2, v3, v4, v5);
             if (have2[q]) aq += dot6(c0[q], c1[q], c2[q], v0, v1, v2, v3, v4, v5);
         }
         // rows with more than 20 slots are rare (hubs): the wave walks their remaining passes together (a uniform trip count, so
@@ -1350,8 +1363,9 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
                 }
             }
             const double pc = fma(beta, wp, wz);
-            const double v0 = __shfl(pc, gbase), v1 = __shfl(pc, gbase + 1), v2 = __shfl(pc, gbase + 2), v3 = __shfl(pc, gbase + 3),
-                         v4 = __shfl(pc, gbase + 4), v5 = __shfl(pc, gbase + 5);
+            double v0, v1, v2, v3, v4, v5;
+            __builtin_amdgcn_wave_barrier();                 // (line 1 is reused from pass to pass: the reads of the last one are done)
+            gather6(1, pc, gbase, v0, v1, v2, v3, v4, v5);
             if (hv) aq += dot6(e0, e1, e2, v0, v1, v2, v3, v4, v5);
         }
         double t;
@@ -1372,8 +1386,8 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     for (int q = 0; q < kRowsPerWave; q++) {
         const int a = row0 + q;
         if (lane < 6 && a < D.nb) D.ap[(size_t)a * 6 + lane] = acc[q];
-        const double t0 = __shfl(acc[q], 0), t1 = __shfl(acc[q], 1), t2 = __shfl(acc[q], 2);
-        const double q0 = __shfl(acc[q], 3), q1 = __shfl(acc[q], 4), q2 = __shfl(acc[q], 5);
+        double t0, t1, t2, q0, q1, q2;
+        gather6(2 + 2 * kRowsPerWave + q, acc[q], 0, t0, t1, t2, q0, q1, q2);
         if (g == q) {                               // the lanes that own row q's p and geometry
             double wq = 0., dq = 0.;
             if (dact) {
