@@ -955,19 +955,20 @@ constexpr int kChain = 6 * 48 + 3;                      // per ancestor level: 6
 // workgroup's rows since the last look, in units of the accuracy asked for, and |r|^2 of its rows; at the first application of the
 // preconditioner (r = b): |b|^2 of its rows.  Per wave into spm[0..2] / spm[3..5]; look_store (lane 0, behind a workgroup barrier)
 // folds the waves - the sum in wave order - into part_c[blk].
+template <bool LDS = false>
 __device__ __forceinline__ void look_partials(double moved, double sq, int tid, double* spm)
 {
-    const double m = wave_max(moved), s = wave_sum(sq);
+    const double m = wave_max<LDS>(moved), s = wave_sum<LDS>(sq);
     if ((tid & 63) == 0) { spm[tid >> 6] = m; spm[3 + (tid >> 6)] = s; }
 }
 __device__ __forceinline__ void look_store(double* __restrict__ part_c, int blk, const double* spm)
 {
     reinterpret_cast<double2*>(part_c)[blk] = make_double2(fmax(fmax(spm[0], spm[1]), spm[2]), (spm[3] + spm[4]) + spm[5]);
 }
-template <int NW>
+template <int NW, bool LDS = false>
 __device__ __forceinline__ double block_sum_w(double v, double* sN)
 {
-    v = wave_sum(v);
+    v = wave_sum<LDS>(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sN[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -1136,6 +1137,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
                                                      double* __restrict__ p_new, int n_part, double tol2)
 {
     constexpr int kWaves = WAVES, kRowsPerWave = RPW;
+    constexpr bool kLds = (WAVES == 2);          // the batched geometry: wave sums through the LDS crossbar (wave_sum, pgo_device.hpp)
     constexpr int kRowsPerBlk = kWaves * kRowsPerWave, kAggPerBlk = kRowsPerBlk / kMlFanout;
     constexpr int kGrpU = (kWaves >= 8) ? 2 : 4;          // groups of 64 r.z partials a wave fetches up front (1024 / 1024 / 512 partials in all)
     __shared__ double sgrp[kMaxPartials / 64];
@@ -1263,13 +1265,13 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     for (int u = 0; u < kGrpU; u++) {
         const int gi = wv + u * kWaves;
         if (gi < n_grp) {                                  // (uniform in the wave)
-            const double sgi = wave_sum(vpart[u]);
+            const double sgi = wave_sum<kLds>(vpart[u]);
             if (lane == 0) sgrp[gi] = sgi;
         }
     }
     for (int gi = wv + kGrpU * kWaves; gi < n_grp; gi += kWaves) {       // beyond kGrpU * kWaves * 64 partials: one group per round trip
         const int i = gi * 64 + lane;
-        const double sgi = wave_sum(i < n_part ? D.part_b[i] : 0.);
+        const double sgi = wave_sum<kLds>(i < n_part ? D.part_b[i] : 0.);
         if (lane == 0) sgrp[gi] = sgi;
     }
     if (bx == 0) {                                        // (.x: a maximum - any order gives the same bits; .y: a sum, taken like r.z)
@@ -1277,14 +1279,14 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         for (int u = 0; u < kGrpU; u++) {
             const int gi = wv + u * kWaves;
             if (gi < n_grp) {
-                const double a = wave_max(vlook[u].x), b = wave_sum(vlook[u].y);
+                const double a = wave_max<kLds>(vlook[u].x), b = wave_sum<kLds>(vlook[u].y);
                 if (lane == 0) { slook[0][gi] = a; slook[1][gi] = b; }
             }
         }
         for (int gi = wv + kGrpU * kWaves; gi < n_grp; gi += kWaves) {
             const int i = gi * 64 + lane;
             const double2 x = (i < n_part) ? reinterpret_cast<const double2*>(D.part_c)[i] : make_double2(0., 0.);
-            const double a = wave_max(x.x), b = wave_sum(x.y);
+            const double a = wave_max<kLds>(x.x), b = wave_sum<kLds>(x.y);
             if (lane == 0) { slook[0][gi] = a; slook[1][gi] = b; }
         }
     }
@@ -1896,7 +1898,7 @@ __global__ __launch_bounds__(256) void ml_alpha_kernel(PgoDev D, MlHot H, const 
 // rounding as ml_cg_kernel<1>.
 // ------------------------------------------------------------------------------------------------
 // kCompU gather-level values per lane: 5 covers 6 n_1 <= 960 (<= 1280 free vertices), 8 covers 6 n_1 <= 1536 (<= 2048), 12 <= 2304 (3072), 16 <= 3072 (4096)
-template <int kCompU>
+template <int kCompU, bool kLds = false>
 __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const double* __restrict__ p,
                                                            const double* __restrict__ rg_old, double* __restrict__ rg_new,
                                                            int n_part, int init)
@@ -1951,7 +1953,7 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
     double alpha = 0.;
     bool bad = false;
     if (!init) {
-        const double pAp = block_sum_w<3>(part_fold<kCgBlk, 4>(D.part_a, n_part, tid, vpart), s3);
+        const double pAp = block_sum_w<3, kLds>(part_fold<kCgBlk, 4>(D.part_a, n_part, tid, vpart), s3);
         bad = !(pAp > 0.);
         alpha = bad ? 0. : rz / pAp;
     }
@@ -1965,7 +1967,7 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
             for (int q = 0; q < 6; q++) ps[q] = fma((double)cm[q][u], v, ps[q]);
         }
 #pragma unroll
-        for (int q = 0; q < 6; q++) ps[q] = wave_sum(ps[q]);
+        for (int q = 0; q < 6; q++) ps[q] = wave_sum<kLds>(ps[q]);
         if ((tid & 63) == 0) {
 #pragma unroll
             for (int q = 0; q < 6; q++) scomp[tid >> 6][q] = ps[q];
@@ -1981,7 +1983,7 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
         D.r[i] = rv;
         if (look) { D.xs[i] = xn; xsv = fabs(xn - xsv) * unit; }
     }
-    if (look) look_partials((act && !init) ? xsv : 0., act ? rv * rv : 0., tid, spm);
+    if (look) look_partials<kLds>((act && !init) ? xsv : 0., act ? rv * rv : 0., tid, spm);
     sv[tid] = act ? rv : 0.;
     __syncthreads();
     double zz = 0., w = 0.;
@@ -2013,7 +2015,7 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
         D.z[(size_t)a * 6 + r] = zz;
         acc = rv * zz;
     }
-    const double tot = block_sum_w<3>(acc, s3);
+    const double tot = block_sum_w<3, kLds>(acc, s3);
     if (tid == 0) {
         D.part_b[blockIdx.x] = tot;
         if (look) look_store(D.part_c, blockIdx.x, spm);
@@ -2304,8 +2306,8 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_comp_batch_kernel(const BatchSlo
     const BatchSlot& S = slots[blockIdx.z];
     const BatchDyn dy = dyn[blockIdx.z];
     if (!(dy.mask & (init ? kPhInit : kPhSolve))) return;
-    if (init) ml_cg_comp_kernel_body<kCompU>(S.D, S.hot[dy.ix], S.pbuf[0], S.rg[dy.ix][0], S.rg[dy.ix][1], 0, 1);
-    else ml_cg_comp_kernel_body<kCompU>(S.D, S.hot[dy.ix], S.pbuf[parity ^ 1], S.rg[dy.ix][parity ^ 1], S.rg[dy.ix][parity], S.g_rows, 0);
+    if (init) ml_cg_comp_kernel_body<kCompU, true>(S.D, S.hot[dy.ix], S.pbuf[0], S.rg[dy.ix][0], S.rg[dy.ix][1], 0, 1);
+    else ml_cg_comp_kernel_body<kCompU, true>(S.D, S.hot[dy.ix], S.pbuf[parity ^ 1], S.rg[dy.ix][parity ^ 1], S.rg[dy.ix][parity], S.g_rows, 0);
 }
 
 // numeric part of a rebuild (geometry, Galerkin products level by level) for every graph with kPhNumeric

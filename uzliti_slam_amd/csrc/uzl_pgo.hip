@@ -268,6 +268,7 @@ void fetch_scal(uzl_pgo* h)
 // The relative test on r.M^-1 r remains as a floor two orders below pcg_tol (kTolFloor2 on its square): it ends solves whose target is
 // below what the arithmetic can settle.
 constexpr double kStepT = 1.0, kStepR = 0.1, kTolFloor2 = 1e-4;
+static const double kLambdaRetake = diag_double("UZL_LAMBDA_RETAKE", 32.);     // lambda grown by this factor since the inverses were taken: take them again
 constexpr int kProgressEveryBJ = 8;           // block-Jacobi path: PCG iterations between two looks (a launch of their own; the multilevel path looks every
                                               // kProgressEvery iterations inside its kernels, pgo_types.hpp)
 inline double tol_factor2(int, double, int) { return kTolFloor2; }
@@ -1155,7 +1156,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             bool conv = false;
             // the lambda-dependent inverses of the hierarchy are kept across trials; after rejected steps lambda grows
             // geometrically and inverses taken at a much smaller lambda stop being a preconditioner at all
-            if (h->ml_levels > 0 && lambda > 8. * h->mlb[h->ml_ix].lambda_setup) h->ml_trial_setup = true;
+            if (h->ml_levels > 0 && lambda > kLambdaRetake * h->mlb[h->ml_ix].lambda_setup) h->ml_trial_setup = true;
             const bool fresh = h->ml_trial_setup || (adopted && qmax == 0);
             int pcg_its = pcg_solve(h, &conv);                                    // _solver->solve()
             S.pcg_iterations += pcg_its;
@@ -1919,7 +1920,7 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             dyn[sl].mask = kPhLambda | kPhInit; dyn[sl].lambda = X.lambda;
             if (X.qmax == 0) X.tol_f2 = tol_factor2(X.it, X.last_rel, X.pcg_last);           // fixed for the trials of one LM iteration, like do_optimize
             dyn[sl].tol_factor2 = X.tol_f2; dyn[sl].eps_t = kStepT * b->h[g]->cfg.pcg_tol; dyn[sl].eps_r = kStepR * b->h[g]->cfg.pcg_tol;
-            if (X.lambda > 8. * X.lambda_setup[X.ml_ix]) X.trial_setup = true;
+            if (X.lambda > kLambdaRetake * X.lambda_setup[X.ml_ix]) X.trial_setup = true;
             X.fresh = X.trial_setup || (X.adopted && X.qmax == 0);
             if (X.trial_setup) { dyn[sl].mask |= kPhTrialCur; X.lambda_setup[X.ml_ix] = X.lambda; X.trial_setup = false; any_trial_cur = true; }
             phase[g] = PSolve; launched_g[g] = 0;
