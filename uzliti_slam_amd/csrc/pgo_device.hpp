@@ -190,6 +190,12 @@ __device__ __forceinline__ double lane63_f64(double v)
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), 63);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// Prefixes of the same butterfly for sums over aligned groups of 4 / 8 / 16 lanes (every lane of the group gets the sum): v + v[lane ^ 1],
+// then + [lane ^ 2], + [lane ^ 4], + [lane ^ 8] - the last two through row mirrors, which reach the right partner because the values are
+// uniform over 4 resp. 8 lanes by then.  Same bits as the __shfl_xor chain they replace; only valid in this order, starting at stride 1.
+__device__ __forceinline__ double xsum4(double v) { v += dpp_mov_f64<0xb1, 0xf>(0., v); v += dpp_mov_f64<0x4e, 0xf>(0., v); return v; }
+__device__ __forceinline__ double xsum8(double v) { v = xsum4(v); v += dpp_mov_f64<0x141, 0xf>(0., v); return v; }
+__device__ __forceinline__ double xsum16(double v) { v = xsum8(v); v += dpp_mov_f64<0x140, 0xf>(0., v); return v; }
 template <bool LDS = false>
 __device__ __forceinline__ double wave_sum(double v)
 {

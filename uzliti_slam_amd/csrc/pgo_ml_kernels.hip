@@ -1724,8 +1724,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
             s0 += s2; s1 += s3q;
             sacc = s0 + s1;
         }
-        sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
-        sacc += __shfl_xor(sacc, 8); sacc += __shfl_xor(sacc, 16);
+        sacc = xsum16(sacc); sacc += __shfl_xor(sacc, 16);
         if (row < 6 && j == 0) syc[row] = sacc;
         __syncthreads();
     }
@@ -1740,7 +1739,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
             const int c = A * fan + j;
             double sacc = 0.;
             if (t < tasks && j < fan && c < nC) sacc = restrict_comp(dyn + goff[l - 1] + c * 3, dyn + roff[l - 1] + c * 6, k);
-            sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
+            sacc = xsum8(sacc);
             if (t < tasks && j == 0) dyn[roff[l] + ak] = sacc;
         }
         __syncthreads();
@@ -1758,7 +1757,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
             const int row = tid >> 3, j = tid & 7;
             double sacc = 0.;
             if (row < 6) for (int c = j; c < ntop; c += 8) sacc += dyn[top_off + row * ntop + c] * rtop[c];
-            sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
+            sacc = xsum8(sacc);
             if (row < 6 && j == 0) syc[row] = sacc;
         }
         __syncthreads();
@@ -1771,7 +1770,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
 #pragma unroll
                 for (int c = 0; c < 6; c++) sacc += ch[k * 48 + part * 6 + c] * rr[c];
             }
-            sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
+            sacc = xsum8(sacc);
             if (tid < 48 && part == 0) sacc += prolong_comp(ch + 288, syc, k);
             __syncthreads();
             if (tid < 48 && part == 0) syc[k] = sacc;
@@ -1798,7 +1797,7 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
         double ps = 0.;
 #pragma unroll
         for (int c = 0; c < 12; c++) ps = fma(w0[c], sv[part * 12 + c], ps);
-        ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2);
+        ps = xsum4(ps);
         if (part == 0) szj[tid >> 2] = ps;
     } else if (act) {
         const int g0 = tid - r;
@@ -1842,8 +1841,8 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
                 for (int c = 0; c < 6; c++) ps = fma(w1[c], rs[c], ps);
             }
         }
-        ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2);
-        if (kFan2 == 8) ps += __shfl_xor(ps, 4);
+        ps = xsum4(ps);
+        if (kFan2 == 8) ps += dpp_mov_f64<0x141, 0xf>(0., ps);
         if (l1thr && part1 == 0) sy[o1] = l1act ? ps + prolong_comp(g1x, syc, o1 % 6) : 0.;
     }
     __syncthreads();
@@ -1992,7 +1991,7 @@ __device__ __forceinline__ void ml_cg_comp_kernel_body(PgoDev D, MlHot H, const 
         double ps = 0.;
 #pragma unroll
         for (int c = 0; c < 12; c++) ps = fma(w0[c], sv[part4 * 12 + c], ps);
-        ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2);
+        ps = xsum4(ps);
         if (part4 == 0) szj[tid >> 2] = ps;
     }
     if (act) {
