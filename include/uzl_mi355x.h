@@ -379,8 +379,8 @@ uzl_pgo* uzl_pgo_batch_graph(uzl_pgo_batch* b, int32_t i);            /* borrowe
 int  uzl_pgo_batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats /* n_graphs entries, may be NULL */,
                             int32_t* n_batched /* may be NULL */);
 /* How many of the batch's graphs are solved at a time (0 = all of them, the default).  With fewer resident slots than graphs the
- * batch is a queue: a graph that has finished its LM iterations hands its slot to the next one, so one graph that needs more trials
- * than the others does not hold the chip for all of them.  Results per graph do not depend on it. */
+ * batch is a queue worked off in cohorts: the resident graphs advance in step (they linearise, rebuild their preconditioners and
+ * evaluate in the same launches) and the slots are refilled when all of them are through.  Results per graph do not depend on it. */
 int  uzl_pgo_batch_set_resident(uzl_pgo_batch* b, int32_t n_resident);
 /* per-kernel timing of the two PCG kernels of the last batch solve (as uzl_pgo_set_profiling / uzl_pgo_kernel_times) */
 int  uzl_pgo_batch_set_profiling(uzl_pgo_batch* b, int32_t on);

@@ -1852,6 +1852,15 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
     auto active = [&](int sl) { return slot_graph[sl] >= 0 && !G[slot_graph[sl]].finished; };
     int n_active = 0;
     for (int sl = 0; sl < R; sl++) n_active += active(sl) ? 1 : 0;
+    // The resident graphs are kept IN STEP: the solve stage runs until all of them are done, so that they linearise, rebuild their
+    // preconditioners and evaluate in the same passes - a rebuild is ~25 small launches whatever the number of graphs that take part, and
+    // graphs out of step pay them in almost every pass.  A queue longer than the slots is worked off in cohorts: the slots are refilled
+    // when every resident graph is through.  Measured on 256 queued config-2 graphs: cohorts of 16 / 64 in step 54 / 68 M edges/s, slots
+    // refilled one by one as they finish (free-running, graphs at different LM iterations sharing launches through the phase masks:
+    // UZL_BATCH_FREE_RUNNING=1 in the diagnostic build) 33 / 57 M - a straggler that holds its cohort costs less than what sixteen
+    // graphs out of step pay for each other's rebuilds.
+    static const bool free_running = diag_flag("UZL_BATCH_FREE_RUNNING");
+    const bool in_step = (R == Q) || !free_running;
     while (n_active > 0) {
         // ---- Lin: linearise the graphs that start a new LM iteration; first iteration: numeric set-up, chi2 and lambda_0
         base_dyn();
@@ -1949,14 +1958,9 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             // a host round trip whatever it launches, so a pass is at least one long replay (as fine as in step: 256 queued graphs on 64
             // slots 53 -> 41 M edges/s)
             const int fine = G[g].pcg_last > 0 ? std::max(kStep, (((G[g].pcg_last * 95) / 100 + 1 - launched_g[g]) + kStep - 1) / kStep * kStep) : kLong;
-            const int want = (R == Q) ? fine : std::max(kLong, fine / kLong * kLong);
-            its = (R == Q) ? (its == (1 << 30) ? want : std::max(its, want)) : std::min(its, want);
+            const int want = in_step ? fine : std::max(kLong, fine / kLong * kLong);
+            its = in_step ? (its == (1 << 30) ? want : std::max(its, want)) : std::min(its, want);
         }
-        // With every graph resident (no queue) the graphs are kept in step instead: the solve stage runs until ALL of them are done, so
-        // that they linearise, rebuild their preconditioners and evaluate in the same passes - a rebuild is ~25 small launches whatever
-        // the number of graphs that take part, and sixteen graphs out of step would pay them in almost every pass (measured at 16
-        // config-2 graphs: 47 M edges/s in step, 42 M out of step; with a queue behind 64 slots the free-running loop wins).
-        const bool in_step = R == Q;
         for (int round = 0; any_solve; round++) {
             batch_upload_dyn(b, dyn);
             if (eager) {
@@ -2045,9 +2049,13 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
         }
         // ---- slots whose graph is through take the next one of the queue
         n_active = 0;
-        for (int sl = 0; sl < R; sl++) {
-            if (slot_graph[sl] >= 0 && G[slot_graph[sl]].finished) load_slot(sl);
-            n_active += active(sl) ? 1 : 0;
+        for (int sl = 0; sl < R; sl++) n_active += active(sl) ? 1 : 0;
+        if (!in_step || n_active == 0) {
+            n_active = 0;
+            for (int sl = 0; sl < R; sl++) {
+                if (slot_graph[sl] >= 0 && G[slot_graph[sl]].finished) load_slot(sl);
+                n_active += active(sl) ? 1 : 0;
+            }
         }
     }
     UZL_HIP(hipStreamSynchronize(s));
