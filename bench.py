@@ -619,7 +619,9 @@ def main():
             for k in range(nQ):
                 gk = synth.make_pose_graph(a.nodes, a.edges, seed=ud.replica_seed(12345, dist.rank) + 1000 * k)
                 bq.graphs[k].add_graph(gk["nodes_pose"], gk["nodes_fixed"], gk["edges"])
-            batched["queue"] = dict(graphs=nQ, workload="%d config-2 graphs queued, R resident at a time" % nQ)
+            batched["queue"] = dict(graphs=nQ, workload="%d config-2 graphs queued, R resident at a time" % nQ,
+                                    policy="cohorts: the R resident graphs advance in step, the slots are refilled when all of them are through "
+                                           "(refilling slot by slot as graphs finish was built and measured slower: DESIGN.md section 7)")
             for R_ in (16, 64):
                 if R_ > nQ:
                     continue
