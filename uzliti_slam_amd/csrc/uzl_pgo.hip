@@ -1102,7 +1102,9 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         // gives the same PCG solution, and once chi2 changes by less than refresh_rel per step the hierarchy of the
         // previous iteration is as good as a fresh one (geometry + Galerkin + inverses are ~170 us per rebuild).
         // A rebuild is also forced when the iteration count has grown by a third since the last one.
-        const bool refresh = it == 0 || always_refresh || last_rel > refresh_rel || (rate_ref > 0. && rate_last > 0. && rate_last < kRateDrop * rate_ref);
+        // (an asynchronous rebuild is for the NEXT iteration: none in the last one)
+        const bool refresh = it == 0 || ((always_refresh || last_rel > refresh_rel || (rate_ref > 0. && rate_last > 0. && rate_last < kRateDrop * rate_ref)) &&
+                                         (!async_ok || it + 1 < iterations));
         bool launch_async = false;
         bool fetched = false;
         if (red) {                                      // the hierarchy is built on the reduced system, which needs lambda: lambda_0 first
@@ -1616,8 +1618,12 @@ struct uzl_pgo_batch {
     uzl_pgo_cfg cfg;
     std::vector<uzl_pgo*> h;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // rebuilds that run ahead (into the hierarchy copy the PCG does not use), beside this iteration's solves
+    hipEvent_t ev_lin = nullptr, ev_build = nullptr;
+    bool build_pending = false;
     DevBuf<BatchSlot> d_slots;
     DevBuf<BatchDyn> d_dyn;
+    DevBuf<BatchDyn> d_dyn2;              // the phase table the kernels on stream2 read
     PinBuf<BatchDyn> h_dyn;               // ring of staging copies (kDynRing x B)
     int ring = 0;
     PinBuf<PgoHostScal> h_pub;            // B entries + one for the sequence word
@@ -1769,7 +1775,7 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
     // device tables: R slots; the captured PCG replay reads them at run time, so refilling a slot needs no new capture
     if ((int)b->slot_host.size() != R || b->graph_rows != max_rows || b->graph_nb != max_nb) batch_destroy_graph(b);
     b->slot_host.assign((size_t)R, BatchSlot{});
-    b->d_slots.reserve((size_t)R); b->d_dyn.reserve((size_t)R);
+    b->d_slots.reserve((size_t)R); b->d_dyn.reserve((size_t)R); b->d_dyn2.reserve((size_t)R);
     b->h_dyn.reserve((size_t)R * kDynRing);
     b->h_pub.reserve((size_t)R + 1, hipHostMallocMapped | hipHostMallocCoherent);
     memset(b->h_pub.p, 0, sizeof(PgoHostScal) * ((size_t)R + 1));
@@ -1877,15 +1883,20 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
         }
         if (any_lin) {
             std::vector<uint8_t> ahead((size_t)R, 0);
+            if (b->build_pending) {                           // the rebuild started at the last linearisation still reads H and the poses
+                UZL_HIP(hipStreamWaitEvent(s, b->ev_build, 0));
+                b->build_pending = false;
+            }
             batch_upload_dyn(b, dyn);
             kb_linearize(b->d_slots.p, b->d_dyn.p, R, max_g_edges, max_g_asm, delta, s);
             for (int sl = 0; sl < R; sl++) {
                 if (!(dyn[sl].mask & kPhLin)) continue;
                 BatchLM& X = G[slot_graph[sl]];
-                const bool refresh = X.it == 0 || always_refresh || X.last_rel > refresh_rel || (X.rate_ref > 0. && X.rate_last > 0. && X.rate_last < kRateDrop * X.rate_ref);
+                // (a rebuild runs ahead for the NEXT iteration: none in the last one)
+                const bool refresh = X.it == 0 || ((always_refresh || X.last_rel > refresh_rel || (X.rate_ref > 0. && X.rate_last > 0. && X.rate_last < kRateDrop * X.rate_ref)) && X.it + 1 < iterations);
                 if (refresh) {
                     X.S.precond_builds++;
-                    if (X.it == 0) X.trial_setup = true; else ahead[sl] = 1;
+                    if (X.it == 0) X.trial_setup = true; else ahead[sl] = 1;          // (never in the last iteration: see `refresh`)
                 }
                 phase[slot_graph[sl]] = PStart;
             }
@@ -1913,10 +1924,22 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
                 any_ahead = true;
             }
             if (any_ahead) {
-                batch_upload_dyn(b, dyn);
-                kb_set_lambda(b->d_slots.p, b->d_dyn.p, R, s);
-                kb_ml_numeric(b->d_slots.p, b->d_dyn.p, R, L, n_lv.data(), max_wt.data(), max_wr.data(), s);
-                kb_ml_trial(b->d_slots.p, b->d_dyn.p, R, 0, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s);
+                // On the second stream, behind this linearisation and beside this iteration's solves (which apply the other copy): the
+                // chain of ~25 small launches and the Newton-Schulz GEMMs (matrix cores) under the PCG replays (latency and vector
+                // issue).  Its phase table is a buffer of its own: the main stream moves on to the next phases of d_dyn.
+                static const bool ahead_sync = diag_flag("UZL_BATCH_SYNC_REBUILD");       // A/B switch
+                hipStream_t s2 = ahead_sync ? s : b->stream2;
+                BatchDyn* stage = b->h_dyn.p + (size_t)(b->ring++ % kDynRing) * R;
+                memcpy(stage, dyn.data(), sizeof(BatchDyn) * (size_t)R);
+                if (!ahead_sync) {
+                    UZL_HIP(hipEventRecord(b->ev_lin, s));
+                    UZL_HIP(hipStreamWaitEvent(s2, b->ev_lin, 0));
+                }
+                UZL_HIP(hipMemcpyAsync(b->d_dyn2.p, stage, sizeof(BatchDyn) * (size_t)R, hipMemcpyHostToDevice, s2));
+                kb_set_lambda(b->d_slots.p, b->d_dyn2.p, R, s2);
+                kb_ml_numeric(b->d_slots.p, b->d_dyn2.p, R, L, n_lv.data(), max_wt.data(), max_wr.data(), s2);
+                kb_ml_trial(b->d_slots.p, b->d_dyn2.p, R, 0, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s2);
+                if (!ahead_sync) { UZL_HIP(hipEventRecord(b->ev_build, s2)); b->build_pending = true; }
             }
         }
         // ---- Start: one LM trial of the graphs that have a system to solve: lambda, trial set-up, PCG initialisation
@@ -2051,6 +2074,10 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
         n_active = 0;
         for (int sl = 0; sl < R; sl++) n_active += active(sl) ? 1 : 0;
         if (!in_step || n_active == 0) {
+            if (b->build_pending && next_graph < Q) {         // (a rebuild of the outgoing graphs may still read the slot table)
+                UZL_HIP(hipStreamWaitEvent(s, b->ev_build, 0));
+                b->build_pending = false;
+            }
             n_active = 0;
             for (int sl = 0; sl < R; sl++) {
                 if (slot_graph[sl] >= 0 && G[slot_graph[sl]].finished) load_slot(sl);
@@ -2058,6 +2085,7 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             }
         }
     }
+    if (b->build_pending) { UZL_HIP(hipStreamSynchronize(b->stream2)); b->build_pending = false; }     // a rebuild nobody will use: let it drain
     UZL_HIP(hipStreamSynchronize(s));
     const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     int batched = 0;
@@ -2113,8 +2141,14 @@ int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch
         if (rc != UZL_OK) { for (uzl_pgo* x : b->h) uzl_pgo_destroy(x); delete b; return rc; }
         b->h.push_back(h);
     }
-    if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, -1) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_lin, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_build, hipEventDisableTiming) != hipSuccess) {
         for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
+        if (b->stream) (void)hipStreamDestroy(b->stream);
+        if (b->stream2) (void)hipStreamDestroy(b->stream2);
+        if (b->ev_lin) (void)hipEventDestroy(b->ev_lin);
+        if (b->ev_build) (void)hipEventDestroy(b->ev_build);
         delete b;
         return UZL_ERR_HIP;
     }
@@ -2126,10 +2160,14 @@ void uzl_pgo_batch_destroy(uzl_pgo_batch* b)
 {
     if (!b) return;
     (void)hipSetDevice(b->cfg.device);
+    if (b->stream2) (void)hipStreamSynchronize(b->stream2);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     batch_destroy_graph(b);
     for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
     if (b->stream) (void)hipStreamDestroy(b->stream);
+    if (b->stream2) (void)hipStreamDestroy(b->stream2);
+    if (b->ev_lin) (void)hipEventDestroy(b->ev_lin);
+    if (b->ev_build) (void)hipEventDestroy(b->ev_build);
     delete b;
 }
 
