@@ -1063,7 +1063,8 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     static const bool async_off = diag_flag("UZL_ML_SYNC_REBUILD");             // A/B switch
     // (small graphs only: at 10k vertices the rebuild's Newton-Schulz GEMMs take more from the overlapped PCG than they give back:
     // 113.2 -> 115.1 ms; config 2: 11.09 -> 10.67 ms with 540 instead of 517 PCG iterations)
-    const bool async_ok = !async_off && h->ml_levels > 0 && h->ml_cl == 1 && !h->sharded && !h->timer.on && h->stream2 != nullptr;
+    static const bool async_large = diag_flag("UZL_ML_ASYNC_LARGE");          // A/B switch
+    const bool async_ok = !async_off && h->ml_levels > 0 && (h->ml_cl == 1 || (async_large && h->ml_cl == 2)) && !h->sharded && !h->timer.on && h->stream2 != nullptr;
     bool adopted = false;
     h->ml_ix = 0; h->ml_pending = false;
     struct DrainRebuild {                      // an exception must not leave a rebuild running on stream2 behind the handle's back
