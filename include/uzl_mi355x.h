@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define UZL_ABI_VERSION 2
+#define UZL_ABI_VERSION 3
 
 /* ---- status codes (reference: bool returns + ROS_ERROR, SURVEY §8b "Errors") ---- */
 #define UZL_OK                 0
@@ -226,7 +226,12 @@ typedef struct uzl_pgo_cfg {
     int32_t optimize_xy_only;         /* 0    project poses/measurements to (x,y,yaw) (g2o_optimizer.cpp:164-170)         */
     /* ---- back-end additions ---- */
     int32_t device;
-    double  pcg_tol;                  /* 1e-5  stop when r.M^-1 r <= pcg_tol^2 * (r0.M^-1 r0)         */
+    double  pcg_tol;                  /* 1e-5  accuracy asked of every linear solve.  pcg_stop = 0 (default): the solve ends when the
+                                         estimated error left in the LM step is below pcg_tol metres in every translation component
+                                         and 0.1 * pcg_tol in every quaternion-vector component (~0.2 * pcg_tol rad) AND the
+                                         residual has come down (see pcg_stop); r.M^-1 r <= 1e-4 * pcg_tol^2 * (r0.M^-1 r0) is kept
+                                         as a floor.  pcg_stop = 1: the plain relative test r.M^-1 r <= pcg_tol^2 * (r0.M^-1 r0)
+                                         (g2o's LinearSolverPCG stops at 1e-6 on that squared norm, i.e. pcg_tol = 1e-3 [EXT]) */
     int32_t pcg_max_iter;             /* per linear solve                                             */
     int32_t schur_reduce;             /* 0 = auto: vertices that carry nothing but their two chain (odometry, g2o_optimizer.cpp:190-259)
                                          edges are eliminated exactly from (H + lambda I) per LM trial and PCG runs on the Schur
@@ -235,6 +240,10 @@ typedef struct uzl_pgo_cfg {
     double  huber_delta;              /* 1.0  (g2o_optimizer.cpp:293)                                 */
     int32_t verbose;
     int32_t preconditioner;           /* 1 = additive multilevel (8-vertex aggregates, rigid-body modes), 0 = block-Jacobi */
+    int32_t pcg_stop;                 /* 0 = step-error estimate (above), 1 = relative residual test only                  */
+    int32_t lm_loop;                  /* 0 = Levenberg-Marquardt decisions on the device, one host look per trial (captured passes);
+                                         1 = host-driven loop (the one sharded and profiled solves always take); same results */
+    int32_t reserved0;
 } uzl_pgo_cfg;
 
 /* SlamNode as the optimizer sees it (slam_node.h:89-107). Array order = std::map iteration order
@@ -282,6 +291,8 @@ typedef struct uzl_pgo_stats {
     double  exchange_ms;       /* sharded solve: host time inside the exchange step (callback) or enqueueing it (native RCCL) */
     int32_t structure_reused;  /* 1: the structure of the previous graph was kept (same vertices / edge endpoints / fixed flags) */
     int32_t n_eliminated;      /* free vertices Schur-eliminated ahead of the PCG (chain interiors), 0 = full system */
+    int32_t lm_passes;         /* device-resident loop: passes enqueued = host looks at the state; 0 = the host-driven loop ran */
+    int32_t reserved0;
 } uzl_pgo_stats;
 
 void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg);

@@ -28,7 +28,7 @@ def test_struct_layouts_match_header(capi):
     assert ctypes.sizeof(capi.EdgeResult) == capi.EDGE_RESULT_DTYPE.itemsize == 432
     assert ctypes.sizeof(capi.PairJob) == capi.PAIR_JOB_DTYPE.itemsize == 24
     assert capi.NODE_DTYPE.itemsize == 104 and capi.EDGE_DTYPE.itemsize == 608
-    assert ctypes.sizeof(capi.MatchCfg) == 56 and ctypes.sizeof(capi.PgoCfg) == 48
+    assert ctypes.sizeof(capi.MatchCfg) == 56 and ctypes.sizeof(capi.PgoCfg) == 64
 
 
 def test_defaults_mirror_the_cfg_files(capi):
@@ -38,7 +38,7 @@ def test_defaults_mirror_the_cfg_files(capi):
     p = capi.PgoCfg(); capi.lib().uzl_pgo_cfg_default(ctypes.byref(p))
     # graph_optimization/cfg/GraphOptimizer.cfg:10-12
     assert (p.iterations, p.use_odometry_parameters, p.optimize_xy_only, p.huber_delta) == (20, 0, 0, 1.0)
-    assert capi.lib().uzl_abi_version() == 2
+    assert capi.lib().uzl_abi_version() == 3
     assert capi.lib().uzl_status_string(-1) == b"bad argument"
 
 

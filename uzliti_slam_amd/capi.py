@@ -72,7 +72,7 @@ class PgoCfg(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("use_odometry_parameters", C.c_int32),
                 ("optimize_xy_only", C.c_int32), ("device", C.c_int32), ("pcg_tol", C.c_double),
                 ("pcg_max_iter", C.c_int32), ("schur_reduce", C.c_int32), ("huber_delta", C.c_double), ("verbose", C.c_int32),
-                ("preconditioner", C.c_int32)]
+                ("preconditioner", C.c_int32), ("pcg_stop", C.c_int32), ("lm_loop", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class PgoStats(C.Structure):
@@ -81,7 +81,8 @@ class PgoStats(C.Structure):
                 ("n_gauge_fixed", C.c_int32), ("pcg_not_converged", C.c_int32),
                 ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
                 ("solve_ms", C.c_double), ("precond_builds", C.c_int32), ("exchange_calls", C.c_int32),
-                ("structure_ms", C.c_double), ("exchange_ms", C.c_double), ("structure_reused", C.c_int32), ("n_eliminated", C.c_int32)]
+                ("structure_ms", C.c_double), ("exchange_ms", C.c_double), ("structure_reused", C.c_int32), ("n_eliminated", C.c_int32),
+                ("lm_passes", C.c_int32), ("reserved0", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

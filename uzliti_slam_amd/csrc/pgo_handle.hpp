@@ -1,0 +1,224 @@
+// pgo_handle.hpp — the pose-graph handle (struct uzl_pgo), the kernel launchers and the host-side pieces shared by the translation
+// units behind uzl_pgo_*: uzl_pgo.hip (C ABI, structure, the host-driven Levenberg-Marquardt loop), uzl_pgo_lm.hip (the device-resident
+// loop: captured passes over slot twins).  Private to csrc/: the product surface is include/uzl_mi355x.h.
+#pragma once
+#include "uzl_common.hpp"
+#include "pgo_types.hpp"
+#include "pgo_schur.hpp"
+#include "pgo_lm.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cmath>
+#include <limits>
+#include <new>
+#include <numeric>
+
+namespace uzl {
+void k_prepare_nodes(const uzl_node* nodes, int n, int xy, double* pose, hipStream_t s);
+void k_prepare_flat_nodes(const double* poses12, int n, double* pose, hipStream_t s);
+void k_prepare_edges(const uzl_edge* edges, const int32_t* src, int e, const double* sensors, int ns, int xy, int odom_params,
+                     double* zinv, double* info, hipStream_t s);
+void k_prepare_flat_edges(const double* meas12, const double* info36, int e, double* zinv, double* info, hipStream_t s);
+int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s);
+int k_linearize(const PgoDev& D, const double* pose, double delta, hipStream_t s);
+int k_assemble(const PgoDev& D, hipStream_t s);
+void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s);
+int k_diagmax(const PgoDev& D, hipStream_t s);
+void k_precond(const PgoDev& D, hipStream_t s);
+void k_publish(const PgoDev& D, PgoHostScal* out_dev, uint32_t seq, hipStream_t s);
+void k_set_scalar(double* dst, double v, hipStream_t s);
+void k_set_scalar2(double* dst_a, double va, double* dst_b, double vb, hipStream_t s);
+void k_residual_guard(const PgoDev& D, hipStream_t s);
+void k_pcg_progress(const PgoDev& D, hipStream_t s);
+void k_set_trial(double* scal, double lambda, double tol_f2, double eps_t, double eps_r, hipStream_t s);
+int k_pcg_init(const PgoDev& D, double* p0, double* p1, hipStream_t s);
+int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
+int k_pcg_update(const PgoDev& D, const double* p, int n_part, hipStream_t s);
+int g_pcg_spmv(int nb);
+int g_pcg_update(int nb);
+void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, int n_l, hipStream_t s);
+void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s);
+void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
+void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
+void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s);
+void k_ml_mult_level(const PgoDev& D, const MlDev* ml, int lev, int n1, int n2, hipStream_t s);
+void k_ml_cmat32(const MlHot& hot, int n6, hipStream_t s);
+void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int lev, int n1, const double* X, double* T, double* Xn, hipStream_t s,
+                  hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
+int g_ml_rows(int nb, int agg);
+int g_ml_spmv(int nb, int agg);
+size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
+bool ml_fits_lds(const int* n_per_level, int levels, int agg);
+void k_ml_init(const PgoDev& D, const MlHot& ml, int agg, double* p0, double* p1, double* rg, hipStream_t s);
+void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s,
+               hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
+hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
+                   int init, size_t lds, hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
+int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s);
+// batched twins (pgo_kernels.hip / pgo_ml_kernels.hip)
+void kb_linearize(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_asm, double delta, hipStream_t s);
+void kb_eval(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_oplus, double delta, hipStream_t s);
+void kb_residual_guard(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s);
+void kb_set_lambda(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s);
+void kb_publish(const BatchSlot* sl, int nb_, PgoHostScal* out_dev, uint32_t seq, hipStream_t s);
+int g_edges_for(int e);
+int g_asm_for(int nb);
+int g_oplus_for(int n);
+void kb_ml_numeric(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int levels, const int* n_lv, const int* max_work_t, const int* max_work_r, hipStream_t s);
+void kb_ml_trial(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int pass, int levels, int cl, const int* n_lv, int inner_aggs, int ns_steps,
+                 int upper_ns, hipStream_t s);
+void kb_ml_init(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, hipStream_t s);
+void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, int pairs, double tol2, hipStream_t s,
+                     hipEvent_t* ev = nullptr);
+bool ml_comp_small(int n1);
+void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
+void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
+void k_schur_eliminate(const PgoDev& D, const SchurDev& S, hipStream_t s);
+void k_schur_assemble(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s);
+void k_schur_backsub(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s);
+// slot twins of the device-resident LM loop (pgo_types.hpp: LmSlot / LmDev / LmShape)
+void k_lm_head(const LmSlot* slots, int nslots, int pass_flags, hipStream_t s);
+void k_lm_tail(const LmSlot* slots, int nslots, hipStream_t s);
+void kl_linearize(const LmSlot* sl, int nslots, int g_edges, int g_asm, hipStream_t s);
+void kl_residual_guard(const LmSlot* sl, int nslots, hipStream_t s);
+void kl_eval(const LmSlot* sl, int nslots, int g_edges, int g_oplus, hipStream_t s);
+void kl_schur_reduce(const LmSlot* sl, int nslots, int max_runs, long max_items, hipStream_t s);
+void kl_schur_backsub(const LmSlot* sl, int nslots, int max_grid, hipStream_t s);
+void kl_ml_numeric(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s);
+void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s);
+void ml_cg_variant(const MlHot& ml, int agg, size_t lds_full, int32_t* variant, int32_t* comp_u, uint64_t* lds);
+hipError_t kl_ml_init(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, hipStream_t s);
+hipError_t kl_ml_pcg_pairs(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, int pairs, hipStream_t s);
+}  // namespace uzl
+
+
+
+namespace uzl { struct LmRun; }
+using namespace uzl;      // (private header of the uzl_pgo_* translation units; the handle itself is the C ABI's global-namespace type)
+
+struct uzl_pgo {
+    std::mutex mu;
+    std::string last_error;
+    uzl_pgo_cfg cfg;
+    hipStream_t stream = nullptr;
+    // ---- host-side structure of the current problem
+    int32_t n = 0, e_in = 0, e = 0, nb = 0, nslots = 0;
+    std::vector<uint8_t> fixed_in, fixed_eff;
+    std::vector<int32_t> ij;       // system edges, 2 per edge
+    std::vector<int32_t> src;      // system edge -> input edge
+    std::vector<uint8_t> robust;
+    std::vector<double> edge_w;    // trace of each system edge's information matrix: the coupling strength the aggregation order follows
+    bool have_graph = false, structure_ready = false;
+    int32_t n_gauge = 0;
+    // ---- device
+    DevBuf<double> pose_a, pose_b, pose_init;
+    double* cur = nullptr;
+    double* trial = nullptr;
+    DevBuf<int32_t> d_v2b, d_b2v, d_ei, d_ej, d_slot_i, d_slot_j, d_row_ptr, d_col, d_rowhdr, d_src, d_flags;
+    DevBuf<double> d_zinv, d_info, d_blk, d_dcon, d_gcon, d_hdiag, d_minv, d_b, d_x, d_xs, d_r, d_z, d_p, d_p2, d_ap;
+    DevBuf<double> d_part_a, d_part_b, d_part_c, d_scal, d_err, d_out12, d_stage;
+    DevBuf<uint8_t> d_robust;
+    DevBuf<uzl_node> d_nodes;
+    DevBuf<uzl_edge> d_edges;
+    PinBuf<PgoHostScal> h_scal;      // pinned + coherent: written by publish_kernel, polled by the host
+    PgoHostScal* d_pub = nullptr;    // its device-side address
+    uint32_t pub_seq = 0;
+    PinBuf<double> h_lambda;
+    PgoDev D;
+    // The system the PCG (and its preconditioner) sees: D itself, or - when chain interiors are Schur-eliminated (pgo_schur.hpp) - the
+    // reduced system over the separator vertices.  scal / flags / part_b / part_c are shared with D.
+    PgoDev Dp;
+    double* pbuf[2] = {nullptr, nullptr};      // PCG direction, ping-pong (of the Dp system)
+    struct Reduced {
+        bool on = false;
+        int32_t n_int = 0, n_runs = 0, longest_run = 0;
+        DevBuf<int32_t> run_ptr, run_rows, slotP, slotN, endL, endR, sep_rows, rsrc, inc_ptr, inc, row_ptr, col, rowhdr, b2v;
+        DevBuf<double> elim, runout, blk, hdiag, minv, x, xs, r, z, p, p2, ap;
+        SchurDev S;
+    } red;
+    int prev_pcg_iters = 0;
+    // multilevel preconditioner
+    int ml_levels = 0;
+    std::vector<int32_t> ml_n, ml_nslots;
+    int ml_inner_aggs = 0;
+    bool ml_trial_setup = false;     // the preconditioner's per-trial part (sibling inverses, top, dense levels) is due
+    bool ml_comp = false;
+    int ml_cl = 0;                   // level of the dense operator (1: small graphs, 2: AGG = 4), 0 = none
+    int ml_ns_steps = 0;             // Newton-Schulz refinements of the dense level-1 operator per rebuild
+    // Two complete copies of the preconditioner's numeric state (arena, device descriptor, kernel-argument block, PCG graph): the
+    // solver applies copy `ml_ix` while a rebuild for the next LM iteration runs on `stream2` into the other one.
+    struct MlBuf {
+        MlDev* dml = nullptr;                  // device copy of the descriptor
+        MlHot hot;                             // hot subset, by-value kernel argument
+        double* rg[2] = {nullptr, nullptr};    // double-buffered gather-level residual
+        double* y1 = nullptr; double* nsT = nullptr; double* nsX = nullptr;
+        double* l1_span_ptr = nullptr;         // level-1 Galerkin arrays (blk | G | M), all-reduced once per linearisation
+        hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;        // 2 x kGraphPairs PCG iterations
+        hipGraph_t graph_s = nullptr; hipGraphExec_t graph_exec_s = nullptr;    // 2 x kShortPairs: the solves of a converged LM iteration end after 2 - 4
+        double lambda_setup = 0.;              // lambda of the last trial set-up of this copy
+    } mlb[2];
+    double* ml_dense_ptr[2][kMlMaxLevels + 1] = {};   // host copy of MlDev::Ydense per hierarchy copy
+    int ml_ix = 0;
+    bool ml_pending = false;                   // a rebuild into copy ml_ix ^ 1 is in flight on stream2
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_lin = nullptr, ev_setup = nullptr;
+    DevBuf<double> d_scal2;                    // lambda slot (scal[3]) for the kernels of an asynchronous rebuild
+    double lambda_now = 0.;          // lambda of the current trial
+    bool ml_mult = false;            // level 1 of the composite operator is multiplicative (pgo_ml_kernels.hip)            // small graphs: hierarchy above level 1 folded into a dense operator (pgo_ml_kernels.hip)
+    std::vector<int32_t> ml_fan;
+    int ml_agg = 4;                            // level-1 aggregates per PCG workgroup (1: small graphs, 4: large)
+    size_t ml_lds = 0;
+    DevBuf<uint8_t> ml_arena;
+    DevBuf<MlDev> d_ml;
+    bool no_graph = false;          // UZL_NO_GRAPH=1: eager launches (rocprofv3 --kernel-trace crashes on hipGraphLaunch here)
+    // shard (BASELINE config 4)
+    int32_t rank = 0, world = 1;
+    uzl_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    void* rccl_comm = nullptr;       // ncclComm_t owned by the handle (uzl_pgo_set_shard_rccl); the exchange then needs no callback
+    bool sharded = false;            // an exchange (callback or communicator) is set and the multilevel path is active for this structure
+    DevBuf<double> d_red;
+    int64_t iter_span = 0;           // doubles all-reduced per PCG iteration: [A p | restricted A p | p.Ap partials]
+    int64_t l1_span = 0;
+    // per-optimize accounting (uzl_pgo_stats)
+    double structure_ms = 0., exchange_ms = 0.;
+    int32_t exchange_calls = 0;
+    bool structure_reused = false;
+    double last_residual_ratio = 0.;
+    int32_t guard_trips = 0;
+    uint64_t structure_gen = 0;      // bumped by build_structure: batches rebuild their slots when it moves
+    bool mult_banned = false;        // the multiplicative operator broke down on a graph of this handle: later structures start additive
+    KernelTimer timer;
+    uzl::LmRun* lm = nullptr;        // the device-resident LM loop's slot table and captured passes (uzl_pgo_lm.hip)
+    bool last_structure_reused = false;
+    std::chrono::steady_clock::time_point t_start;      // start of the running uzl_pgo_optimize (solve_ms)
+};
+
+namespace uzl {
+// ---- when a linear solve stops (uzl_pgo.hip "When a linear solve stops"; cfg.pcg_stop = 1: the plain relative test - no floor factor,
+//      and a step accuracy of 0 switches the look off: progress_unit, pgo_device.hpp)
+inline double pgo_tol_f2(const uzl_pgo_cfg& c) { return c.pcg_stop == 1 ? 1. : kTolFloor2; }
+inline double pgo_eps_t(const uzl_pgo_cfg& c) { return c.pcg_stop == 1 ? 0. : kStepT * c.pcg_tol; }
+inline double pgo_eps_r(const uzl_pgo_cfg& c) { return c.pcg_stop == 1 ? 0. : kStepR * c.pcg_tol; }
+// ---- shared host-side pieces (uzl_pgo.hip)
+int pgo_fail(uzl_pgo* h, int code, const char* msg);
+int32_t gauge_fix(uzl_pgo* h);                        // G2: setFixedNodes (g2o_optimizer.cpp:301-349)
+void build_structure(uzl_pgo* h);                     // block-CSR, Schur plan, hierarchy; bumps structure_gen
+void destroy_pcg_graph(uzl_pgo* h);
+void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
+void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
+int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);      // the host-driven loop (sharded / block-Jacobi / profiled solves, anomaly fallback)
+int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);           // picks the loop
+// ---- the device-resident loop (uzl_pgo_lm.hip)
+struct LmRun;                                          // captured passes + slot table of one handle (or one batch)
+void lm_run_destroy(LmRun* r);
+bool lm_eligible(const uzl_pgo* h);
+int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);
+extern const int kUpperNs;                            // Newton-Schulz steps of the dense levels above the composite level
+extern const bool kAlwaysRefresh;                     // A/B switches (diagnostic build)
+extern const double kRefreshRel, kLambdaRetake;
+extern const int kGraphPairs;                         // one long PCG replay = 2 x kGraphPairs iterations
+constexpr int kShortPairs = 2;                        // ... a short one 2 x kShortPairs
+}  // namespace uzl

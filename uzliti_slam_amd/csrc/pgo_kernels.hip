@@ -696,6 +696,60 @@ __global__ __launch_bounds__(64) void publish_batch_kernel(const BatchSlot* __re
     if (t == 0) __hip_atomic_store(&out[nbatch].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ------------------------------------------------------------------------------------------------
+// slot twins of the device-resident LM loop (pgo_types.hpp: LmSlot / LmDev): graph = blockIdx.z, arguments from its slot, and every
+// kernel predicates itself on the graph's phase - a pass is a fixed launch sequence (uzl_pgo_lm.hip)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlk) void linearize_lm_kernel(const LmSlot* __restrict__ slots)
+{
+    const LmSlot& S = slots[blockIdx.z];
+    const LmDev* lm = S.lm;
+    if (lm->phase != kLmLin || (int)blockIdx.x >= S.g_edges) return;
+    linearize_kernel_body(S.D, S.pose[lm->cur], lm->delta);
+}
+__global__ __launch_bounds__(kBlk) void assemble_lm_kernel(const LmSlot* __restrict__ slots)
+{
+    const LmSlot& S = slots[blockIdx.z];
+    if (S.lm->phase != kLmLin || (int)blockIdx.x >= S.g_asm) return;
+    assemble_kernel_body(S.D);
+}
+// the evaluation of a trial runs once its solve has ended without a breakdown (lm_tail_kernel sorts the rest out)
+__device__ __forceinline__ bool lm_evaluates(const LmDev* lm) { return lm->phase == kLmSolve && lm->flags[0] != 0 && lm->flags[2] == 0; }
+__global__ __launch_bounds__(1024) void residual_guard_lm_kernel(const LmSlot* __restrict__ slots)
+{
+    const LmSlot& S = slots[blockIdx.z];
+    if (!lm_evaluates(S.lm)) return;
+    residual_guard_kernel_body(S.Dp);
+}
+__global__ __launch_bounds__(kBlk) void oplus_lm_kernel(const LmSlot* __restrict__ slots)
+{
+    const LmSlot& S = slots[blockIdx.z];
+    const LmDev* lm = S.lm;
+    if (!lm_evaluates(lm) || (int)blockIdx.x >= S.g_oplus) return;
+    oplus_kernel_body(S.D, S.pose[lm->cur], S.pose[lm->cur ^ 1]);
+}
+__global__ __launch_bounds__(kBlk) void chi2_lm_kernel(const LmSlot* __restrict__ slots)
+{
+    const LmSlot& S = slots[blockIdx.z];
+    const LmDev* lm = S.lm;
+    if (!lm_evaluates(lm) || (int)blockIdx.x >= S.g_edges) return;
+    chi2_kernel_body(S.D, S.pose[lm->cur ^ 1], lm->delta);
+}
+void kl_linearize(const LmSlot* sl, int nslots, int g_edges, int g_asm, hipStream_t s)
+{
+    hipLaunchKernelGGL(linearize_lm_kernel, dim3(g_edges, 1, nslots), dim3(kBlk), 0, s, sl);
+    hipLaunchKernelGGL(assemble_lm_kernel, dim3(g_asm, 1, nslots), dim3(kBlk), 0, s, sl);
+}
+void kl_residual_guard(const LmSlot* sl, int nslots, hipStream_t s)
+{
+    hipLaunchKernelGGL(residual_guard_lm_kernel, dim3(1, 1, nslots), dim3(1024), 0, s, sl);
+}
+void kl_eval(const LmSlot* sl, int nslots, int g_edges, int g_oplus, hipStream_t s)
+{
+    hipLaunchKernelGGL(oplus_lm_kernel, dim3(g_oplus, 1, nslots), dim3(kBlk), 0, s, sl);
+    hipLaunchKernelGGL(chi2_lm_kernel, dim3(g_edges, 1, nslots), dim3(kBlk), 0, s, sl);
+}
+
 void kb_linearize(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_asm, double delta, hipStream_t s)
 {
     hipLaunchKernelGGL(linearize_batch_kernel, dim3(g_edges, 1, nb_), dim3(kBlk), 0, s, sl, dy, delta);

@@ -12,6 +12,8 @@
 // Per PCG iteration : ml_spmv (p, A p, restricted A p) -> ml_cg (alpha, coarse chain in LDS, x, r, z)
 #include <hip/hip_ext.h>
 #include <mutex>
+#include <type_traits>
+
 #include "pgo_device.hpp"
 #include "uzl_common.hpp"
 
@@ -384,7 +386,7 @@ __device__ __forceinline__ double prolong_comp(const double* __restrict__ d, con
 //      Y_1 is what ml_cg applies: the coarse correction of an aggregate is 6 rows of Y_1 times the gather-level
 //      residual - one latency-flat dot product instead of a restrict / solve / prolong walk through LDS.
 //      One lane per 6x6 block (B, B').
-__global__ __launch_bounds__(kBlk) void ml_dense_level_kernel(const MlDev* __restrict__ mlp, int l)
+__device__ __forceinline__ void ml_dense_level_kernel_body(const MlDev* __restrict__ mlp, int l)
 {
     const MlDev& ml = *mlp;
     const int n = ml.lv[l].n, t = blockIdx.x * kBlk + threadIdx.x;
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(kBlk) void ml_dense_level_kernel(const MlDev* __res
 #pragma unroll
     for (int i = 0; i < 36; i++) Y[(size_t)(6 * B + i / 6) * n6 + 6 * Bp + i % 6] = out[i];
 }
+__global__ __launch_bounds__(kBlk) void ml_dense_level_kernel(const MlDev* __restrict__ mlp, int l) { ml_dense_level_kernel_body(mlp, l); }
 
 // ---- composite path, level 1: MULTIPLICATIVE coupling of the level-1 smoother with the levels above,
 //          Y_1 = 2 S - S A S + Q Y_2 Q^T,   Q = P - S A P                     (S = blockdiag of the sibling inverses W_1^-1,
@@ -1476,7 +1479,7 @@ constexpr int kSpmvBatchRpw = 4, kSpmvBatchWaves = 2;      // ml_spmv_batch_kern
 // was most of the kernel (33 us per launch).
 constexpr int kYU = 18;
 template <int AGG, bool COMP = false, bool YPRE = false, bool VPRE = false>
-__global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (YPRE ? 2 : 3) : 1))) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
+__device__ __forceinline__ void ml_cg_kernel_body(PgoDev D, MlHot H, const double* __restrict__ p,
                                                       const double* __restrict__ rg_old, double* __restrict__ rg_new,
                                                       int n_part, int init)
 {
@@ -1868,10 +1871,17 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_stamps[31], 1ull);
 #endif
 }
+template <int AGG, bool COMP = false, bool YPRE = false, bool VPRE = false>
+__global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (YPRE ? 2 : 3) : 1))) void ml_cg_kernel(PgoDev D, MlHot H, const double* __restrict__ p,
+                                                      const double* __restrict__ rg_old, double* __restrict__ rg_new,
+                                                      int n_part, int init)
+{
+    ml_cg_kernel_body<AGG, COMP, YPRE, VPRE>(D, H, p, rg_old, rg_new, n_part, init);
+}
 
 // alpha = r.z / p.Ap and v = rg - alpha Sg for ml_cg_kernel<4, true, false, true>: every workgroup sums the p.Ap partials (same order,
 // same alpha), each writes 256 entries of v; workgroup 0 leaves alpha and the breakdown flag in scal[9], scal[10].
-__global__ __launch_bounds__(256) void ml_alpha_kernel(PgoDev D, MlHot H, const double* __restrict__ rg_old, int n_part)
+__device__ __forceinline__ void ml_alpha_kernel_body(PgoDev D, MlHot H, const double* __restrict__ rg_old, int n_part)
 {
     __shared__ double s4[4];
     const int done = D.flags[0];                  // checked behind the loads: 15 workgroups, nothing to save by leaving before them
@@ -1888,6 +1898,7 @@ __global__ __launch_bounds__(256) void ml_alpha_kernel(PgoDev D, MlHot H, const 
     if (t < n6) H.Vg[t] = rgv - alpha * sgv;
     if (blockIdx.x == 0 && tid == 0) { D.scal[9] = alpha; D.scal[10] = bad ? 1. : 0.; }
 }
+__global__ __launch_bounds__(256) void ml_alpha_kernel(PgoDev D, MlHot H, const double* __restrict__ rg_old, int n_part) { ml_alpha_kernel_body(D, H, rg_old, n_part); }
 
 // ------------------------------------------------------------------------------------------------
 // ml_cg for small graphs (<= 1280 free vertices, one level-1 aggregate per workgroup): the hierarchy above level 1
@@ -2371,6 +2382,316 @@ void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_
     }
 }
 bool ml_comp_small(int n1) { return 6 * n1 <= 5 * kCgBlk; }
+
+// ------------------------------------------------------------------------------------------------
+// slot twins of the device-resident LM loop (pgo_types.hpp: LmSlot / LmDev; uzl_pgo_lm.hip): graph = blockIdx.z, arguments from its
+// slot, every kernel predicated on the graph's LM state.  Same bodies as the by-value kernels above: same arithmetic, same bits.
+// ------------------------------------------------------------------------------------------------
+// Set-up kernels serve two segments of a pass (`which`):
+//   0 = rebuild of copy LmDev::build_ix AHEAD of the trial loop (second stream): numeric + trial part, lambda from LmDev::scal2, poses
+//       of buffer build_cur - all three snapshots lm_head_kernel took, because the main stream moves cur / ix on while this runs;
+//   1 = set-up of the copy in use: numeric part in the pass stamped numeric_pass, trial part in the pass stamped trial_pass.
+#define UZL_LM_SETUP(NUMERIC)                                                                             \
+    const LmSlot& S = slots[blockIdx.z];                                                                  \
+    const LmDev* lm = S.lm;                                                                               \
+    if ((which == 0 ? lm->build_pass : ((NUMERIC) ? lm->numeric_pass : lm->trial_pass)) != lm->pass) return;      \
+    const int c = which == 0 ? lm->build_ix : lm->ix;                                                     \
+    PgoDev D = S.Dp;                                                                                      \
+    if (which == 0) D.scal = const_cast<double*>(lm->scal2);
+
+__global__ __launch_bounds__(kBlk) void ml_geometry_lm_kernel(const LmSlot* __restrict__ slots, int which, int l)
+{
+    UZL_LM_SETUP(true)
+    ml_geometry_kernel_body(D, S.dml[c], S.pose[which == 0 ? lm->build_cur : lm->cur], l);
+}
+__global__ __launch_bounds__(kBlk) void ml_transform_lm_kernel(const LmSlot* __restrict__ slots, int which, int f)
+{
+    UZL_LM_SETUP(true)
+    ml_transform_kernel_body(D, S.dml[c], f);
+}
+__global__ __launch_bounds__(kBlk) void ml_reduce_lm_kernel(const LmSlot* __restrict__ slots, int which, int l)
+{
+    UZL_LM_SETUP(true)
+    (void)D;
+    ml_reduce_kernel_body(S.dml[c], l);
+}
+__global__ __launch_bounds__(kSibBlk) void ml_sibling_lm_kernel(const LmSlot* __restrict__ slots, int which)
+{
+    UZL_LM_SETUP(false)
+    ml_sibling_kernel_body(D, S.dml[c]);
+}
+__global__ __launch_bounds__(kBlk) void ml_top_lm_kernel(const LmSlot* __restrict__ slots, int which)
+{
+    UZL_LM_SETUP(false)
+    ml_top_kernel_body(D, S.dml[c]);
+}
+__global__ __launch_bounds__(kBlk) void ml_dense_level_lm_kernel(const LmSlot* __restrict__ slots, int which, int l)
+{
+    UZL_LM_SETUP(false)
+    (void)D;
+    ml_dense_level_kernel_body(S.dml[c], l);
+}
+__global__ __launch_bounds__(kBlk) void ml_mult_ap_as_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int g_ap)
+{
+    UZL_LM_SETUP(false)
+    if ((int)blockIdx.x < g_ap) ml_mult_ap_kernel_body(D, S.dml[c], lev, blockIdx.x);
+    else ml_mult_as_kernel_body(D, S.dml[c], lev, blockIdx.x - g_ap);
+}
+__global__ __launch_bounds__(kBlk) void ml_mult_q_final_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int g_q)
+{
+    UZL_LM_SETUP(false)
+    (void)D;
+    if ((int)blockIdx.x < g_q) ml_mult_q_kernel_body(S.dml[c], lev, blockIdx.x);
+    else ml_mult_final_kernel_body(S.dml[c], lev, ((int)blockIdx.x - g_q) * (kBlk / 64) + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
+}
+__global__ __launch_bounds__(kBlk) void ml_mult_qy_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev)
+{
+    UZL_LM_SETUP(false)
+    (void)D;
+    ml_mult_qy_kernel_body(S.dml[c], lev);
+}
+__global__ __launch_bounds__(256) void ml_mult_qyqt_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev)
+{
+    UZL_LM_SETUP(false)
+    (void)D;
+    ml_mult_qyqt_kernel_body(S.dml[c], lev);
+}
+// Newton-Schulz step k at level lev: X ping-pongs between Ydense[lev] and nsX, starting in Ydense[lev]
+__global__ __launch_bounds__(kBlk) void ml_ns_ax_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k)
+{
+    UZL_LM_SETUP(false)
+    const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
+    ml_ns_ax_kernel_body(D, S.dml[c], lev, X, S.nsT[c]);
+}
+__global__ __launch_bounds__(256) void ml_ns_gemm_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k, int n6)
+{
+    UZL_LM_SETUP(false)
+    (void)D;
+    const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
+    double* Xn = (k & 1) ? S.dense[c][lev] : S.nsX[c];
+    ml_ns_gemm_kernel_body(n6, X, S.nsT[c], Xn);
+}
+__global__ __launch_bounds__(kBlk) void ml_cmat32_lm_kernel(const LmSlot* __restrict__ slots, int which, int n6)
+{
+    UZL_LM_SETUP(false)
+    (void)D;
+    const MlHot& H = S.hot[c];
+    if (!H.Cmat || !H.Cmat32) return;
+    ml_cmat32_body(H.Cmat, const_cast<float*>(H.Cmat32), n6, H.c32_stride);
+}
+
+// numeric part (geometry, Galerkin products level by level): the launch sequence of ml_setup_numeric (uzl_pgo.hip)
+void kl_ml_numeric(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
+{
+    const int B = sh.nslots;
+    for (int l = 1; l <= sh.levels; l++)
+        hipLaunchKernelGGL(ml_geometry_lm_kernel, dim3((sh.n_lv[l] + kBlk - 1) / kBlk, 1, B), dim3(kBlk), 0, s, sl, which, l);
+    for (int f = 0; f < sh.levels; f++) {
+        if (sh.work_t[f] > 0) hipLaunchKernelGGL(ml_transform_lm_kernel, dim3((sh.work_t[f] + kBlk - 1) / kBlk, 1, B), dim3(kBlk), 0, s, sl, which, f);
+        const long work = (long)sh.work_t[f + 1] * 36;
+        if (work > 0) hipLaunchKernelGGL(ml_reduce_lm_kernel, dim3((unsigned)((work + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, f + 1);
+    }
+}
+// lambda-dependent part: the launch sequence of ml_setup_trial (uzl_pgo.hip)
+void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
+{
+    const int B = sh.nslots, L = sh.levels, cl = sh.cl;
+    if (sh.inner_aggs > 0) hipLaunchKernelGGL(ml_sibling_lm_kernel, dim3(sh.inner_aggs, 1, B), dim3(kSibBlk), 0, s, sl, which);
+    hipLaunchKernelGGL(ml_top_lm_kernel, dim3(1, 1, B), dim3(kBlk), 0, s, sl, which);
+    if (cl == 0) return;                                                       // no dense operator
+    const int n6c = 6 * sh.n_lv[cl];
+    const long work32 = (long)n6c * (((n6c + 3) & ~3) >> 2);
+    if (!sh.mult) {                                                            // additive operator: Y_l = blockdiag(W_l^-1) + P Y_{l+1} P^T
+        for (int l = L - 1; l >= cl; l--)
+            hipLaunchKernelGGL(ml_dense_level_lm_kernel, dim3((sh.n_lv[l] * sh.n_lv[l] + kBlk - 1) / kBlk, 1, B), dim3(kBlk), 0, s, sl, which, l);
+        hipLaunchKernelGGL(ml_cmat32_lm_kernel, dim3((unsigned)((work32 + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, n6c);
+        return;
+    }
+    for (int l = L - 1; l >= cl; l--) {                                        // multiplicative cycle + Newton-Schulz, from the top down
+        const int n1 = sh.n_lv[l], n2 = sh.n_lv[l + 1];
+        const int g12 = (n1 * n2 + kBlk - 1) / kBlk, g11 = (n1 * n1 + kBlk - 1) / kBlk;
+        hipLaunchKernelGGL(ml_mult_ap_as_lm_kernel, dim3(g12 + g11, 1, B), dim3(kBlk), 0, s, sl, which, l, g12);
+        const int g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk, gfin = (n2 * n2 + kBlk / 64 - 1) / (kBlk / 64);
+        hipLaunchKernelGGL(ml_mult_q_final_lm_kernel, dim3(g12r + gfin, 1, B), dim3(kBlk), 0, s, sl, which, l, g12r);
+        hipLaunchKernelGGL(ml_mult_qy_lm_kernel, dim3(g12r, 1, B), dim3(kBlk), 0, s, sl, which, l);
+        const int n6 = 6 * n1, gt = (n6 + kGemmTile - 1) / kGemmTile;
+        hipLaunchKernelGGL(ml_mult_qyqt_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l);
+        const int steps = l > cl ? sh.upper_ns : sh.ns_steps;
+        for (int k = 0; k < steps; k++) {
+            hipLaunchKernelGGL(ml_ns_ax_lm_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk, B), dim3(kBlk), 0, s, sl, which, l, k);
+            hipLaunchKernelGGL(ml_ns_gemm_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l, k, n6);
+        }
+    }
+    hipLaunchKernelGGL(ml_cmat32_lm_kernel, dim3((unsigned)((work32 + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, n6c);
+}
+
+// ---- PCG: init + the two iteration kernels.  SLOT = `const LmSlot*` (blockIdx.z picks the graph) or `LmSlot` BY VALUE for a pass of
+// one graph - the slot then sits in the kernel-argument segment like the by-value kernels' arguments: no pointer hop in front of the
+// first loads of kernels that are a chain of round trips.
+__device__ __forceinline__ const LmSlot& slot_of(const LmSlot* __restrict__ slots) { return slots[blockIdx.z]; }
+__device__ __forceinline__ const LmSlot& slot_of(const LmSlot& slot) { return slot; }
+
+template <int AGG, class SLOT>
+__global__ __launch_bounds__(kCgBlk) void ml_init_lm_kernel(const SLOT slots)
+{
+    const LmSlot& S = slot_of(slots);
+    const LmDev* lm = S.lm;
+    if (lm->phase != kLmSolve || lm->init_pass != lm->pass) return;
+    ml_init_kernel_body<AGG>(S.Dp, S.hot[lm->ix], S.pbuf[0], S.pbuf[1], S.rg[lm->ix][0]);
+}
+// PCG iteration i of a replay (parity = i & 1): p_old = pbuf[parity], p_new = pbuf[parity ^ 1]; a no-op once flags[0] is set
+template <int AGG, int RPW, int WAVES, class SLOT>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 8 ? 4 : 3))) void ml_spmv_lm_kernel(const SLOT slots, int parity)
+{
+    const LmSlot& S = slot_of(slots);
+    const LmDev* lm = S.lm;
+    ml_spmv_kernel_body<AGG, RPW, WAVES>(S.Dp, S.hot[lm->ix], S.pbuf[parity], S.pbuf[parity ^ 1], S.g_rows, lm->tol2);
+}
+// init = 1: the first application of the preconditioner (r = b), in the pass that starts the solve
+template <int kCompU, bool kLds, class SLOT>
+__global__ __launch_bounds__(kCgBlk) void ml_cg_comp_lm_kernel(const SLOT slots, int parity, int init)
+{
+    const LmSlot& S = slot_of(slots);
+    const LmDev* lm = S.lm;
+    const int ix = lm->ix;
+    if (init) {
+        if (lm->phase != kLmSolve || lm->init_pass != lm->pass) return;
+        ml_cg_comp_kernel_body<kCompU, kLds>(S.Dp, S.hot[ix], S.pbuf[0], S.rg[ix][0], S.rg[ix][1], 0, 1);
+    } else ml_cg_comp_kernel_body<kCompU, kLds>(S.Dp, S.hot[ix], S.pbuf[parity ^ 1], S.rg[ix][parity ^ 1], S.rg[ix][parity], S.g_spmv, 0);
+}
+template <int AGG, bool COMP, bool YPRE, bool VPRE, class SLOT>
+__global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (YPRE ? 2 : 3) : 1))) void ml_cg_lm_kernel(const SLOT slots, int parity, int init)
+{
+    const LmSlot& S = slot_of(slots);
+    const LmDev* lm = S.lm;
+    const int ix = lm->ix;
+    if (init) {
+        if (lm->phase != kLmSolve || lm->init_pass != lm->pass) return;
+        ml_cg_kernel_body<AGG, COMP, YPRE, false>(S.Dp, S.hot[ix], S.pbuf[0], S.rg[ix][0], S.rg[ix][1], 0, 1);
+    } else ml_cg_kernel_body<AGG, COMP, YPRE, VPRE>(S.Dp, S.hot[ix], S.pbuf[parity ^ 1], S.rg[ix][parity ^ 1], S.rg[ix][parity], S.g_spmv, 0);
+}
+template <class SLOT>
+__global__ __launch_bounds__(256) void ml_alpha_lm_kernel(const SLOT slots, int parity)
+{
+    const LmSlot& S = slot_of(slots);
+    const LmDev* lm = S.lm;
+    ml_alpha_kernel_body(S.Dp, S.hot[lm->ix], S.rg[lm->ix][parity ^ 1], S.g_spmv);
+}
+
+// raises the dynamic-LDS limit of an ml_cg variant once per device (a function attribute is per device)
+static hipError_t lm_cg_lds(const void* fn, int variant_ix, size_t lds)
+{
+    constexpr int kMaxDev = 16, kVar = 16;
+    static size_t configured_tab[kMaxDev][kVar] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (lds > configured_tab[dev][variant_ix]) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured_tab[dev][variant_ix] = lds;
+    }
+    return hipSuccess;
+}
+
+// the ml_cg launch of iteration parity `parity` (init = 1: first application) for the shape's variant; SLOT as above
+template <class SLOT>
+static hipError_t kl_ml_cg_t(SLOT sl, const LmShape& sh, int parity, int init, hipStream_t s)
+{
+    constexpr bool kPtr = std::is_pointer<SLOT>::value;
+    const dim3 g(sh.g_rows, 1, sh.nslots), t(kCgBlk);
+    size_t lds = (size_t)sh.cg_lds;
+    switch (sh.cg_variant) {
+    case kCgComp1:
+#define UZL_LM_COMP(U, LDS) hipLaunchKernelGGL((ml_cg_comp_lm_kernel<U, LDS, SLOT>), g, t, 0, s, sl, parity, init)
+        if (sh.batch_geometry) { if (sh.comp_u <= 5) UZL_LM_COMP(5, true); else UZL_LM_COMP(8, true); }
+        else if (sh.comp_u <= 5) UZL_LM_COMP(5, false);
+        else if (sh.comp_u <= 8) UZL_LM_COMP(8, false);
+        else if (sh.comp_u <= 12) UZL_LM_COMP(12, false);
+        else UZL_LM_COMP(16, false);
+#undef UZL_LM_COMP
+        return hipSuccess;
+    case kCgPlain1: {
+        const hipError_t e = lm_cg_lds(reinterpret_cast<const void*>(&ml_cg_lm_kernel<1, false, false, false, SLOT>), kPtr ? 0 : 8, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((ml_cg_lm_kernel<1, false, false, false, SLOT>), g, t, lds, s, sl, parity, init);
+        return hipSuccess; }
+    case kCgPlain4: {
+        const hipError_t e = lm_cg_lds(reinterpret_cast<const void*>(&ml_cg_lm_kernel<4, false, false, false, SLOT>), kPtr ? 1 : 9, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((ml_cg_lm_kernel<4, false, false, false, SLOT>), g, t, lds, s, sl, parity, init);
+        return hipSuccess; }
+    case kCgComp4: {
+        const hipError_t e = lm_cg_lds(reinterpret_cast<const void*>(&ml_cg_lm_kernel<4, true, false, false, SLOT>), kPtr ? 2 : 10, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((ml_cg_lm_kernel<4, true, false, false, SLOT>), g, t, lds, s, sl, parity, init);
+        return hipSuccess; }
+    case kCgComp4Ypre: {
+        const hipError_t e = lm_cg_lds(reinterpret_cast<const void*>(&ml_cg_lm_kernel<4, true, true, false, SLOT>), kPtr ? 3 : 11, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((ml_cg_lm_kernel<4, true, true, false, SLOT>), g, t, lds, s, sl, parity, init);
+        return hipSuccess; }
+    case kCgComp4Vpre: {
+        const hipError_t e = lm_cg_lds(reinterpret_cast<const void*>(&ml_cg_lm_kernel<4, true, false, true, SLOT>), kPtr ? 4 : 12, lds);
+        if (e != hipSuccess) return e;
+        // alpha and rg - alpha Sg prepared once by ml_alpha_kernel (not with r = b: the init application takes the plain COMP path)
+        if (!init) hipLaunchKernelGGL((ml_alpha_lm_kernel<SLOT>), dim3((6 * sh.n_lv[2] + 255) / 256, 1, sh.nslots), dim3(256), 0, s, sl, parity);
+        hipLaunchKernelGGL((ml_cg_lm_kernel<4, true, false, true, SLOT>), g, t, lds, s, sl, parity, init);
+        return hipSuccess; }
+    }
+    return hipErrorInvalidValue;
+}
+template <class SLOT>
+static void kl_ml_spmv_t(SLOT sl, const LmShape& sh, int parity, hipStream_t s)
+{
+    if (sh.batch_geometry) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, kSpmvBatchRpw, kSpmvBatchWaves, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvBatchWaves), 0, s, sl, parity);
+    else if (sh.agg == 1) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, 1, 8, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(512), 0, s, sl, parity);
+    else hipLaunchKernelGGL((ml_spmv_lm_kernel<4, 4, kSpmvWaves4, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvWaves4), 0, s, sl, parity);
+}
+template <class SLOT>
+static hipError_t kl_ml_init_t(SLOT sl, const LmShape& sh, hipStream_t s)
+{
+    if (sh.agg == 1) hipLaunchKernelGGL((ml_init_lm_kernel<1, SLOT>), dim3(sh.g_rows, 1, sh.nslots), dim3(kCgBlk), 0, s, sl);
+    else hipLaunchKernelGGL((ml_init_lm_kernel<4, SLOT>), dim3(sh.g_rows, 1, sh.nslots), dim3(kCgBlk), 0, s, sl);
+    return kl_ml_cg_t<SLOT>(sl, sh, 0, 1, s);
+}
+// which ml_cg kernel serves a hierarchy (the choice k_ml_cg makes per launch), and its dynamic LDS
+void ml_cg_variant(const MlHot& ml, int agg, size_t lds_full, int32_t* variant, int32_t* comp_u, uint64_t* lds)
+{
+    static const bool no_vpre = diag_flag("UZL_NO_VPRE");                            // A/B switch (diagnostic build)
+    *comp_u = 0; *lds = lds_full;
+    if (agg == 1) {
+        if (!ml.Cmat) { *variant = kCgPlain1; return; }
+        const int cols = 6 * ml.n[1];
+        *variant = kCgComp1; *lds = 0;
+        *comp_u = cols <= 5 * kCgBlk ? 5 : (cols <= 8 * kCgBlk ? 8 : (cols <= 12 * kCgBlk ? 12 : 16));
+        return;
+    }
+    if (!ml.Cmat) { *variant = kCgPlain4; return; }
+    *lds = (size_t)6 * ml.n[2] * 8 + 64;                                             // COMP stages nothing but the gather-level vector
+    const bool ypre = ml.levels >= 2 && 6 * ml.n[2] <= 4 * 32 * kYU;
+    *variant = ypre ? kCgComp4Ypre : ((ml.Vg != nullptr && !no_vpre) ? kCgComp4Vpre : kCgComp4);
+}
+// x = 0, r = b, first application of the preconditioner - for the graphs whose solve starts in this pass.  by_value: the pass has one
+// graph and `host_slot` is its slot (the device table `sl` is what every other twin reads)
+hipError_t kl_ml_init(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, hipStream_t s)
+{
+    if (host_slot && sh.nslots == 1) return kl_ml_init_t<LmSlot>(*host_slot, sh, s);
+    return kl_ml_init_t<const LmSlot*>(sl, sh, s);
+}
+// PCG iterations 2 * pairs (p0 -> p1 -> p0 ...)
+hipError_t kl_ml_pcg_pairs(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, int pairs, hipStream_t s)
+{
+    const bool by_value = host_slot && sh.nslots == 1;
+    for (int i = 0; i < 2 * pairs; i++) {
+        hipError_t e;
+        if (by_value) { kl_ml_spmv_t<LmSlot>(*host_slot, sh, i & 1, s); e = kl_ml_cg_t<LmSlot>(*host_slot, sh, i & 1, 0, s); }
+        else { kl_ml_spmv_t<const LmSlot*>(sl, sh, i & 1, s); e = kl_ml_cg_t<const LmSlot*>(sl, sh, i & 1, 0, s); }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 }  // namespace uzl
 

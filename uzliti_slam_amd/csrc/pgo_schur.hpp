@@ -17,28 +17,11 @@
 #pragma once
 #include <cstdint>
 #include <vector>
+#include "pgo_types.hpp"
 
 namespace uzl {
 
-constexpr int kSchurElim = 78;        // doubles kept per eliminated vertex: u (6) | W (36) | T (36)
-constexpr int kSchurRunOut = 120;     // doubles written per run: S_L (36) | g_L (6) | S_R (36) | g_R (6) | F (36)
-
-// device view (by-value kernel argument)
-struct SchurDev {
-    int32_t n_runs, n_int, nbr, nslots_r;
-    const int32_t* run_ptr;     // [n_runs+1] into run_rows / slotP / slotN
-    const int32_t* run_rows;    // [n_int] full-system row of every eliminated vertex, in chain order
-    const int32_t* slotP;       // [n_int] slot (full block-CSR) of the block H_{v, previous element of the run / s0}; -1 = none
-    const int32_t* slotN;       // [n_int] slot of H_{v, next element / s1}; -1 = none
-    const int32_t* endL;        // [n_runs] reduced row of s0, -1 = none
-    const int32_t* endR;        // [n_runs] reduced row of s1, -1 = none
-    const int32_t* sep_rows;    // [nbr] full-system row of every reduced row (ascending)
-    const int32_t* rsrc;        // [nslots_r] >= 0: slot of the full system whose block is copied; < 0: -(2 run + side) - 1, fill block F (side 0) / F^T (side 1)
-    const int32_t* inc_ptr;     // [nbr+1] runs incident to each reduced row
-    const int32_t* inc;         // 4 run + side: 0 = row is s0 (S_L, g_L), 1 = row is s1 (S_R, g_R), 2 = s0 == s1 (S_L + S_R + F + F^T, g_L + g_R)
-    double* elim;               // [n_int][kSchurElim]
-    double* runout;             // [n_runs][kSchurRunOut]
-};
+// (SchurDev, kSchurElim, kSchurRunOut: pgo_types.hpp - the device view is part of LmSlot)
 
 // host-side plan: which rows are eliminated, the runs, and the block-CSR of the reduced system
 struct SchurPlan {

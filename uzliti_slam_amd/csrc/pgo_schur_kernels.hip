@@ -149,7 +149,7 @@ __device__ __forceinline__ double mv6(const double* __restrict__ A, const double
 }
 
 // One wave per run.  LDS matrices are private to the wave; with a single-wave workgroup __syncthreads() orders its LDS traffic.
-__global__ __launch_bounds__(64) void schur_eliminate_kernel(PgoDev D, SchurDev S)
+__device__ __forceinline__ void schur_eliminate_kernel_body(PgoDev D, SchurDev S)
 {
     __shared__ double sD[36], sDi[36], sC[36], sE[36], sT[36], sW[36], sg[6], su[6];
     const int run = blockIdx.x;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void schur_eliminate_kernel(PgoDev D, SchurDev 
 }
 
 // Reduced system: item t / 36 = off-diagonal block (copy or fill), then diagonal block, then (6 lanes) right-hand side
-__global__ __launch_bounds__(kBlk) void schur_assemble_kernel(PgoDev D, PgoDev R, SchurDev S)
+__device__ __forceinline__ void schur_assemble_kernel_body(PgoDev D, PgoDev R, SchurDev S)
 {
     const int t = blockIdx.x * kBlk + threadIdx.x;
     const int item = t / 36, k = t % 36, kt = (k % 6) * 6 + k / 6;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kBlk) void schur_assemble_kernel(PgoDev D, PgoDev R
 }
 
 // blocks [0, n_runs): one wave per run, backwards; blocks behind: x of the separators to their full-system rows
-__global__ __launch_bounds__(64) void schur_backsub_kernel(PgoDev D, PgoDev R, SchurDev S)
+__device__ __forceinline__ void schur_backsub_kernel_body(PgoDev D, PgoDev R, SchurDev S)
 {
     __shared__ double sx0[6], sxn[6], sp[36];
     const int lane = threadIdx.x;
@@ -287,6 +287,33 @@ __global__ __launch_bounds__(64) void schur_backsub_kernel(PgoDev D, PgoDev R, S
         __syncthreads();
         w = wn; t = tn; u = un;
     }
+}
+
+__global__ __launch_bounds__(64) void schur_eliminate_kernel(PgoDev D, SchurDev S) { schur_eliminate_kernel_body(D, S); }
+__global__ __launch_bounds__(kBlk) void schur_assemble_kernel(PgoDev D, PgoDev R, SchurDev S) { schur_assemble_kernel_body(D, R, S); }
+__global__ __launch_bounds__(64) void schur_backsub_kernel(PgoDev D, PgoDev R, SchurDev S) { schur_backsub_kernel_body(D, R, S); }
+
+// slot twins of the device-resident LM loop (pgo_types.hpp): graph = blockIdx.z; the reduction runs in the pass lm_head_kernel stamped
+// (a new lambda), the back-substitution with the evaluation of a trial
+__global__ __launch_bounds__(64) void schur_eliminate_lm_kernel(const LmSlot* __restrict__ slots)
+{
+    const LmSlot& S = slots[blockIdx.z];
+    if (!S.red || S.lm->schur_pass != S.lm->pass) return;
+    schur_eliminate_kernel_body(S.D, S.SD);
+}
+__global__ __launch_bounds__(kBlk) void schur_assemble_lm_kernel(const LmSlot* __restrict__ slots)
+{
+    const LmSlot& S = slots[blockIdx.z];
+    if (!S.red || S.lm->schur_pass != S.lm->pass) return;
+    schur_assemble_kernel_body(S.D, S.Dp, S.SD);
+}
+__global__ __launch_bounds__(64) void schur_backsub_lm_kernel(const LmSlot* __restrict__ slots)
+{
+    const LmSlot& S = slots[blockIdx.z];
+    const LmDev* lm = S.lm;
+    if (!S.red || !(lm->phase == kLmSolve && lm->flags[0] != 0 && lm->flags[2] == 0)) return;
+    if ((int)blockIdx.x >= S.SD.n_runs + (S.SD.nbr * 6 + 63) / 64) return;
+    schur_backsub_kernel_body(S.D, S.Dp, S.SD);
 }
 
 }  // namespace uzl
@@ -329,6 +356,16 @@ void k_schur_backsub(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStr
 {
     const int g = S.n_runs + (S.nbr * 6 + 63) / 64;
     if (g > 0) hipLaunchKernelGGL(schur_backsub_kernel, dim3(g), dim3(64), 0, s, D, R, S);
+}
+// grids: the largest over the slots of a pass (a twin leaves at once past its own graph's extent - the bodies check run / item counts)
+void kl_schur_reduce(const LmSlot* sl, int nslots, int max_runs, long max_items, hipStream_t s)
+{
+    if (max_runs > 0) hipLaunchKernelGGL(schur_eliminate_lm_kernel, dim3(max_runs, 1, nslots), dim3(64), 0, s, sl);
+    if (max_items > 0) hipLaunchKernelGGL(schur_assemble_lm_kernel, dim3((unsigned)((max_items + kBlk - 1) / kBlk), 1, nslots), dim3(kBlk), 0, s, sl);
+}
+void kl_schur_backsub(const LmSlot* sl, int nslots, int max_grid, hipStream_t s)
+{
+    if (max_grid > 0) hipLaunchKernelGGL(schur_backsub_lm_kernel, dim3(max_grid, 1, nslots), dim3(64), 0, s, sl);
 }
 
 }  // namespace uzl

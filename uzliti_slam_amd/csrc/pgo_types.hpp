@@ -173,6 +173,110 @@ struct BatchDyn {                              // host -> device once per round
     double  eps_t, eps_r;                      // kPhLambda: step accuracy asked of this round's solve (-> D.scal[12], D.scal[13])
 };
 
+// ---- Schur reduction of chain interiors: device view (recurrences and host-side plan in pgo_schur.hpp) ----------------------------
+constexpr int kSchurElim = 78;        // doubles kept per eliminated vertex: u (6) | W (36) | T (36)
+constexpr int kSchurRunOut = 120;     // doubles written per run: S_L (36) | g_L (6) | S_R (36) | g_R (6) | F (36)
+
+// device view (by-value kernel argument)
+struct SchurDev {
+    int32_t n_runs, n_int, nbr, nslots_r;
+    const int32_t* run_ptr;     // [n_runs+1] into run_rows / slotP / slotN
+    const int32_t* run_rows;    // [n_int] full-system row of every eliminated vertex, in chain order
+    const int32_t* slotP;       // [n_int] slot (full block-CSR) of the block H_{v, previous element of the run / s0}; -1 = none
+    const int32_t* slotN;       // [n_int] slot of H_{v, next element / s1}; -1 = none
+    const int32_t* endL;        // [n_runs] reduced row of s0, -1 = none
+    const int32_t* endR;        // [n_runs] reduced row of s1, -1 = none
+    const int32_t* sep_rows;    // [nbr] full-system row of every reduced row (ascending)
+    const int32_t* rsrc;        // [nslots_r] >= 0: slot of the full system whose block is copied; < 0: -(2 run + side) - 1, fill block F (side 0) / F^T (side 1)
+    const int32_t* inc_ptr;     // [nbr+1] runs incident to each reduced row
+    const int32_t* inc;         // 4 run + side: 0 = row is s0 (S_L, g_L), 1 = row is s1 (S_R, g_R), 2 = s0 == s1 (S_L + S_R + F + F^T, g_L + g_R)
+    double* elim;               // [n_int][kSchurElim]
+    double* runout;             // [n_runs][kSchurRunOut]
+};
+
+// ---- device-resident Levenberg-Marquardt loop (uzl_pgo_lm.hip) --------------------------------------------------------------------
+// The accept / reject decisions of g2o's OptimizationAlgorithmLevenberg::solve [EXT] (graph_optimization/src/g2o_optimizer.cpp:148 calls
+// it) are taken ON THE DEVICE: the state of the loop lives in an LmDev per graph, two one-workgroup kernels (lm_head_kernel in front of a
+// trial's solve, lm_tail_kernel behind its evaluation) advance it, and every other kernel of an LM iteration is a "slot twin" that reads
+// its arguments from an LmSlot and predicates itself on that state.  A PASS is a fixed launch sequence
+//     linearise | head | [Schur reduction] | [set-up of the hierarchy copy in use] | [rebuild of the other copy, second stream]
+//     | PCG init | PCG iterations x K | residual guard, [back-substitution], retraction, chi2 | tail (decide + publish)
+// whose kernels no-op unless the graph is in the phase they serve - so a pass can be captured once per structure and replayed, several
+// graphs at different LM iterations can share one (blockIdx.z = slot: the batched solve), and the host looks at the outcome once per pass.
+enum LmPhase : int32_t {
+    kLmLin = 0,        // the next pass linearises (start of an LM iteration)
+    kLmSolve = 1,      // a trial's PCG is running (flags[0] = done tells whether it still iterates)
+    kLmRetry = 2,      // the last trial was rejected: the next pass starts another one on the same linearisation
+    kLmNeedSetup = 3,  // the head wants a set-up segment the pass did not carry (LmDev::need): the host enqueues a pass that has it
+    kLmDone = 4,       // iterations exhausted or Terminate
+    kLmAnomaly = 5     // PCG breakdown / not converged / residual guard: the host-driven loop solves this graph again from its start poses
+};
+enum LmNeed : int32_t { kNeedNumeric = 1, kNeedTrial = 2, kNeedRebuild = 4 };
+enum LmPassFlags : int32_t { kPassSetup = 1 /* the pass carries the set-up segment of the copy in use */, kPassRebuild = 2 /* ... and a rebuild of the other copy */ };
+struct LmDev {
+    int32_t flags[4];          // = PgoDev::flags of the graph: 0 done (PCG kernels no-op), 1 PCG iterations, 2 breakdown, 3 look
+    int32_t phase;             // LmPhase
+    int32_t cur;               // pose buffer (LmSlot::pose) that holds the current estimate
+    int32_t ix;                // hierarchy copy the PCG applies
+    int32_t pass;              // passes this graph has seen (bumped by lm_head_kernel); the *_pass stamps below mean "due in that pass"
+    int32_t init_pass, schur_pass, numeric_pass, trial_pass;
+    int32_t build_pass, build_ix, build_cur, need;          // rebuild of copy build_ix from the poses in buffer build_cur; need: LmNeed bits
+    int32_t it, qmax, iterations, max_it;                   // LM iteration, trial of it, iterations asked for, PCG iteration cap per solve
+    int32_t pending, adopted, fresh, pcg_last;              // a rebuilt copy waits to be adopted / was adopted this iteration / this trial runs on fresh inverses
+    int32_t always_refresh, sync_rebuild, guarded, tails;   // constants of the solve; tails: lm_tail_kernel launches seen (= sequence word of LmHost)
+    int32_t st_pcg_iterations, st_lm_trials, st_precond_builds, st_iterations_done, st_terminated_early, anomaly_code, pad0, pad1;
+    double lambda, ni, chi_cur, last_rel;
+    double lambda_setup[2];    // lambda the inverses of each hierarchy copy were taken at
+    double rate_ref, rate_last;
+    double chi2_initial, tol_f2, eps_t, eps_r, refresh_rel, tol2, lambda_retake, delta;
+    double scal2[8];           // [3]: lambda of a rebuild that runs ahead of the trial loop (the set-up kernels read scal[3])
+};
+// what the host sees after a pass: written by lm_tail_kernel into pinned coherent memory, `seq` (= LmDev::tails) last
+struct LmHost {
+    int32_t phase, cur, ix, need;
+    int32_t it, qmax, pending, pcg_last;
+    int32_t flags[4];
+    int32_t st_pcg_iterations, st_lm_trials, st_precond_builds, st_iterations_done, st_terminated_early, anomaly_code;
+    uint32_t seq, seq_begin;   // seq_begin is written first, seq last: a host copy is whole when both agree around it
+    double lambda, chi_cur, last_rel, rate_ref, rate_last, chi2_initial;
+    double lambda_setup[2];
+    double scal[8];            // PgoDev::scal[0..8) as the legacy loop fetches them (verbose logs, residual ratio)
+};
+// everything a slot twin needs, per graph; uploaded when the structure of the graph changes
+struct LmSlot {
+    PgoDev D;                                  // the full system (pose / pose_trial unused: LmSlot::pose + LmDev::cur)
+    PgoDev Dp;                                 // the system the PCG solves: D, or the Schur complement over the separator vertices
+    SchurDev SD;                               // the reduction (valid when red)
+    LmDev* lm;
+    LmHost* pub;                               // device address of the pinned snapshot
+    MlHot hot[2];                              // hot subset of the two hierarchy copies
+    const MlDev* dml[2];
+    double* rg[2][2];                          // per copy: double-buffered gather-level residual
+    double* dense[2][kMlMaxLevels + 1];        // per copy: Ydense[l]
+    double* nsT[2];
+    double* nsX[2];
+    double* pbuf[2];                           // PCG direction, ping-pong
+    double* pose[2];
+    int32_t g_edges, g_asm, g_oplus, g_rows, g_spmv, red, pad0, pad1;      // grids (= partial counts) of this graph's launches; red: Schur-reduced
+};
+
+// launch geometry of a pass: what the host needs besides the slot table (one structure, or the common shape of a batch)
+enum LmCgVariant : int32_t { kCgPlain1 = 0, kCgComp1 = 1, kCgPlain4 = 2, kCgComp4 = 3, kCgComp4Ypre = 4, kCgComp4Vpre = 5 };
+struct LmShape {
+    int32_t nslots;                          // graphs of the pass (blockIdx.z)
+    int32_t batch_geometry;                  // 0: the single solve's workgroups (shortest chain), 1: the batch's (most bytes in flight)
+    int32_t levels, cl, agg;                 // hierarchy: coarse levels, level of the dense operator (0 = none), level-1 aggregates per PCG workgroup
+    int32_t mult, ns_steps, upper_ns;        // multiplicative cycle + Newton-Schulz steps (composite level / the dense levels above)
+    int32_t cg_variant, comp_u;              // LmCgVariant; kCgComp1: gather-level values per lane (5 / 8 / 12 / 16)
+    int32_t n_lv[kMlMaxLevels + 2];          // entities per level (level 0: the largest graph)
+    int32_t work_t[kMlMaxLevels + 2];        // Galerkin transform / reduce work per level (largest graph): nslots_l + n_l
+    int32_t inner_aggs;                      // sibling blocks (largest graph)
+    int32_t g_edges, g_asm, g_oplus, g_rows, g_spmv;      // largest grids
+    int32_t red, schur_runs, schur_backsub_grid;
+    int64_t schur_items;
+    uint64_t cg_lds;                         // dynamic LDS of the ml_cg variant
+};
+
 // scalars handed back to the host after each LM trial / PCG chunk.  The struct lives in pinned, host-coherent memory
 // that a one-workgroup kernel (publish_kernel) writes directly; `seq` is stored last with system-scope release, the
 // host spins on it - a few microseconds instead of the copy + stream-synchronise round trip.

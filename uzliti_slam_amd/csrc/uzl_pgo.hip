@@ -5,82 +5,8 @@
 // store = storeImpl.  All arithmetic on poses, measurements and the normal equations runs in the HIP
 // kernels of pgo_kernels.hip; the host only makes the integer/structural decisions and the scalar LM
 // accept/reject logic of g2o's OptimizationAlgorithmLevenberg [EXT].
-#include "uzl_common.hpp"
-#include "pgo_types.hpp"
-#include "pgo_schur.hpp"
-
-#include <algorithm>
-#include <chrono>
-#include <cstdlib>
-#include <cmath>
-#include <limits>
-#include <new>
-#include <numeric>
-
-namespace uzl {
-void k_prepare_nodes(const uzl_node* nodes, int n, int xy, double* pose, hipStream_t s);
-void k_prepare_flat_nodes(const double* poses12, int n, double* pose, hipStream_t s);
-void k_prepare_edges(const uzl_edge* edges, const int32_t* src, int e, const double* sensors, int ns, int xy, int odom_params,
-                     double* zinv, double* info, hipStream_t s);
-void k_prepare_flat_edges(const double* meas12, const double* info36, int e, double* zinv, double* info, hipStream_t s);
-int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s);
-int k_linearize(const PgoDev& D, const double* pose, double delta, hipStream_t s);
-int k_assemble(const PgoDev& D, hipStream_t s);
-void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s);
-int k_diagmax(const PgoDev& D, hipStream_t s);
-void k_precond(const PgoDev& D, hipStream_t s);
-void k_publish(const PgoDev& D, PgoHostScal* out_dev, uint32_t seq, hipStream_t s);
-void k_set_scalar(double* dst, double v, hipStream_t s);
-void k_set_scalar2(double* dst_a, double va, double* dst_b, double vb, hipStream_t s);
-void k_residual_guard(const PgoDev& D, hipStream_t s);
-void k_pcg_progress(const PgoDev& D, hipStream_t s);
-void k_set_trial(double* scal, double lambda, double tol_f2, double eps_t, double eps_r, hipStream_t s);
-int k_pcg_init(const PgoDev& D, double* p0, double* p1, hipStream_t s);
-int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s);
-int k_pcg_update(const PgoDev& D, const double* p, int n_part, hipStream_t s);
-int g_pcg_spmv(int nb);
-int g_pcg_update(int nb);
-void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, int n_l, hipStream_t s);
-void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s);
-void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
-void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
-void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s);
-void k_ml_mult_level(const PgoDev& D, const MlDev* ml, int lev, int n1, int n2, hipStream_t s);
-void k_ml_cmat32(const MlHot& hot, int n6, hipStream_t s);
-void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int lev, int n1, const double* X, double* T, double* Xn, hipStream_t s,
-                  hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
-int g_ml_rows(int nb, int agg);
-int g_ml_spmv(int nb, int agg);
-size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
-bool ml_fits_lds(const int* n_per_level, int levels, int agg);
-void k_ml_init(const PgoDev& D, const MlHot& ml, int agg, double* p0, double* p1, double* rg, hipStream_t s);
-void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s,
-               hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
-hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
-                   int init, size_t lds, hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
-int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s);
-// batched twins (pgo_kernels.hip / pgo_ml_kernels.hip)
-void kb_linearize(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_asm, double delta, hipStream_t s);
-void kb_eval(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_oplus, double delta, hipStream_t s);
-void kb_residual_guard(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s);
-void kb_set_lambda(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s);
-void kb_publish(const BatchSlot* sl, int nb_, PgoHostScal* out_dev, uint32_t seq, hipStream_t s);
-int g_edges_for(int e);
-int g_asm_for(int nb);
-int g_oplus_for(int n);
-void kb_ml_numeric(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int levels, const int* n_lv, const int* max_work_t, const int* max_work_r, hipStream_t s);
-void kb_ml_trial(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int pass, int levels, int cl, const int* n_lv, int inner_aggs, int ns_steps,
-                 int upper_ns, hipStream_t s);
-void kb_ml_init(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, hipStream_t s);
-void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, int pairs, double tol2, hipStream_t s,
-                     hipEvent_t* ev = nullptr);
-bool ml_comp_small(int n1);
-void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
-void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
-void k_schur_eliminate(const PgoDev& D, const SchurDev& S, hipStream_t s);
-void k_schur_assemble(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s);
-void k_schur_backsub(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s);
-}  // namespace uzl
+#include "pgo_handle.hpp"
+#include "pgo_lm.hpp"
 
 using namespace uzl;
 
@@ -119,112 +45,24 @@ RcclApi& rccl()
 }
 }  // namespace
 
-struct uzl_pgo {
-    std::mutex mu;
-    std::string last_error;
-    uzl_pgo_cfg cfg;
-    hipStream_t stream = nullptr;
-    // ---- host-side structure of the current problem
-    int32_t n = 0, e_in = 0, e = 0, nb = 0, nslots = 0;
-    std::vector<uint8_t> fixed_in, fixed_eff;
-    std::vector<int32_t> ij;       // system edges, 2 per edge
-    std::vector<int32_t> src;      // system edge -> input edge
-    std::vector<uint8_t> robust;
-    std::vector<double> edge_w;    // trace of each system edge's information matrix: the coupling strength the aggregation order follows
-    bool have_graph = false, structure_ready = false;
-    int32_t n_gauge = 0;
-    // ---- device
-    DevBuf<double> pose_a, pose_b, pose_init;
-    double* cur = nullptr;
-    double* trial = nullptr;
-    DevBuf<int32_t> d_v2b, d_b2v, d_ei, d_ej, d_slot_i, d_slot_j, d_row_ptr, d_col, d_rowhdr, d_src, d_flags;
-    DevBuf<double> d_zinv, d_info, d_blk, d_dcon, d_gcon, d_hdiag, d_minv, d_b, d_x, d_xs, d_r, d_z, d_p, d_p2, d_ap;
-    DevBuf<double> d_part_a, d_part_b, d_part_c, d_scal, d_err, d_out12, d_stage;
-    DevBuf<uint8_t> d_robust;
-    DevBuf<uzl_node> d_nodes;
-    DevBuf<uzl_edge> d_edges;
-    PinBuf<PgoHostScal> h_scal;      // pinned + coherent: written by publish_kernel, polled by the host
-    PgoHostScal* d_pub = nullptr;    // its device-side address
-    uint32_t pub_seq = 0;
-    PinBuf<double> h_lambda;
-    PgoDev D;
-    // The system the PCG (and its preconditioner) sees: D itself, or - when chain interiors are Schur-eliminated (pgo_schur.hpp) - the
-    // reduced system over the separator vertices.  scal / flags / part_b / part_c are shared with D.
-    PgoDev Dp;
-    double* pbuf[2] = {nullptr, nullptr};      // PCG direction, ping-pong (of the Dp system)
-    struct Reduced {
-        bool on = false;
-        int32_t n_int = 0, n_runs = 0, longest_run = 0;
-        DevBuf<int32_t> run_ptr, run_rows, slotP, slotN, endL, endR, sep_rows, rsrc, inc_ptr, inc, row_ptr, col, rowhdr, b2v;
-        DevBuf<double> elim, runout, blk, hdiag, minv, x, xs, r, z, p, p2, ap;
-        SchurDev S;
-    } red;
-    int prev_pcg_iters = 0;
-    // multilevel preconditioner
-    int ml_levels = 0;
-    std::vector<int32_t> ml_n, ml_nslots;
-    int ml_inner_aggs = 0;
-    bool ml_trial_setup = false;     // the preconditioner's per-trial part (sibling inverses, top, dense levels) is due
-    bool ml_comp = false;
-    int ml_cl = 0;                   // level of the dense operator (1: small graphs, 2: AGG = 4), 0 = none
-    int ml_ns_steps = 0;             // Newton-Schulz refinements of the dense level-1 operator per rebuild
-    // Two complete copies of the preconditioner's numeric state (arena, device descriptor, kernel-argument block, PCG graph): the
-    // solver applies copy `ml_ix` while a rebuild for the next LM iteration runs on `stream2` into the other one.
-    struct MlBuf {
-        MlDev* dml = nullptr;                  // device copy of the descriptor
-        MlHot hot;                             // hot subset, by-value kernel argument
-        double* rg[2] = {nullptr, nullptr};    // double-buffered gather-level residual
-        double* y1 = nullptr; double* nsT = nullptr; double* nsX = nullptr;
-        double* l1_span_ptr = nullptr;         // level-1 Galerkin arrays (blk | G | M), all-reduced once per linearisation
-        hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;        // 2 x kGraphPairs PCG iterations
-        hipGraph_t graph_s = nullptr; hipGraphExec_t graph_exec_s = nullptr;    // 2 x kShortPairs: the solves of a converged LM iteration end after 2 - 4
-        double lambda_setup = 0.;              // lambda of the last trial set-up of this copy
-    } mlb[2];
-    double* ml_dense_ptr[2][kMlMaxLevels + 1] = {};   // host copy of MlDev::Ydense per hierarchy copy
-    int ml_ix = 0;
-    bool ml_pending = false;                   // a rebuild into copy ml_ix ^ 1 is in flight on stream2
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_lin = nullptr, ev_setup = nullptr;
-    DevBuf<double> d_scal2;                    // lambda slot (scal[3]) for the kernels of an asynchronous rebuild
-    double lambda_now = 0.;          // lambda of the current trial
-    bool ml_mult = false;            // level 1 of the composite operator is multiplicative (pgo_ml_kernels.hip)            // small graphs: hierarchy above level 1 folded into a dense operator (pgo_ml_kernels.hip)
-    std::vector<int32_t> ml_fan;
-    int ml_agg = 4;                            // level-1 aggregates per PCG workgroup (1: small graphs, 4: large)
-    size_t ml_lds = 0;
-    DevBuf<uint8_t> ml_arena;
-    DevBuf<MlDev> d_ml;
-    bool no_graph = false;          // UZL_NO_GRAPH=1: eager launches (rocprofv3 --kernel-trace crashes on hipGraphLaunch here)
-    // shard (BASELINE config 4)
-    int32_t rank = 0, world = 1;
-    uzl_allreduce_fn allreduce = nullptr;
-    void* allreduce_user = nullptr;
-    void* rccl_comm = nullptr;       // ncclComm_t owned by the handle (uzl_pgo_set_shard_rccl); the exchange then needs no callback
-    bool sharded = false;            // an exchange (callback or communicator) is set and the multilevel path is active for this structure
-    DevBuf<double> d_red;
-    int64_t iter_span = 0;           // doubles all-reduced per PCG iteration: [A p | restricted A p | p.Ap partials]
-    int64_t l1_span = 0;
-    // per-optimize accounting (uzl_pgo_stats)
-    double structure_ms = 0., exchange_ms = 0.;
-    int32_t exchange_calls = 0;
-    bool structure_reused = false;
-    double last_residual_ratio = 0.;
-    int32_t guard_trips = 0;
-    uint64_t structure_gen = 0;      // bumped by build_structure: batches rebuild their slots when it moves
-    bool mult_banned = false;        // the multiplicative operator broke down on a graph of this handle: later structures start additive
-    KernelTimer timer;
-};
-
-namespace {
-
-constexpr int kUpperNs = 4;               // Newton-Schulz steps of the dense levels above the composite level (even: the result ends in Ydense[l])
-static const bool always_refresh = diag_flag("UZL_ML_ALWAYS_REFRESH");      // A/B switch
-static const double refresh_rel = diag_double("UZL_ML_REFRESH_REL", 1e-3);
-
-int fail(uzl_pgo* h, int code, const char* msg)
+namespace uzl {
+const int kUpperNs = 4;                   // Newton-Schulz steps of the dense levels above the composite level (even: the result ends in Ydense[l])
+const bool kAlwaysRefresh = diag_flag("UZL_ML_ALWAYS_REFRESH");             // A/B switch
+const double kRefreshRel = diag_double("UZL_ML_REFRESH_REL", 1e-3);
+const double kLambdaRetake = diag_double("UZL_LAMBDA_RETAKE", 32.);         // lambda grown by this factor since the inverses were taken: take them again
+const int kGraphPairs = std::max(1, diag_int("UZL_GRAPH_PAIRS", 8));        // one graph replay = 2 x pairs PCG iterations
+int pgo_fail(uzl_pgo* h, int code, const char* msg)
 {
     h->last_error = msg;
     return code;
 }
+}  // namespace uzl
+
+namespace {
+
+static const bool& always_refresh = kAlwaysRefresh;
+static const double& refresh_rel = kRefreshRel;
+inline int fail(uzl_pgo* h, int code, const char* msg) { return pgo_fail(h, code, msg); }
 
 struct Timed {
     uzl_pgo* h;
@@ -267,24 +105,19 @@ void fetch_scal(uzl_pgo* h)
 // LM is self-correcting, so the per-step errors do not add up coherently; twenty of them stay an order of magnitude inside the bar.
 // The relative test on r.M^-1 r remains as a floor two orders below pcg_tol (kTolFloor2 on its square): it ends solves whose target is
 // below what the arithmetic can settle.
-constexpr double kStepT = 1.0, kStepR = 0.1, kTolFloor2 = 1e-4;
-static const double kLambdaRetake = diag_double("UZL_LAMBDA_RETAKE", 32.);     // lambda grown by this factor since the inverses were taken: take them again
+// (kStepT, kStepR, kTolFloor2: pgo_lm.hpp)
 constexpr int kProgressEveryBJ = 8;           // block-Jacobi path: PCG iterations between two looks (a launch of their own; the multilevel path looks every
                                               // kProgressEvery iterations inside its kernels, pgo_types.hpp)
-inline double tol_factor2(int, double, int) { return kTolFloor2; }
+inline double tol_factor2(const uzl_pgo_cfg& c) { return pgo_tol_f2(c); }
 // How stale is a kept preconditioner?  Not the iteration count of the last solve (with an absolute stop test that follows the size of
 // the LM step and lambda, not the operator): the CONTRACTION it delivers, nats of r.M^-1 r per PCG iteration.  rz_stop = scal[1] is
 // pcg_tol^2 * tol_f2 * (r_0.M^-1 r_0).  A rebuild is due when the rate has fallen below kRateDrop of what the operator delivered when fresh.
-constexpr double kRateDrop = 0.6;
-inline double pcg_rate(double rz_stop, double rz_end, int its, double tol2, double tol_f2)
-{
-    const double rz0 = rz_stop / (tol2 * tol_f2);
-    return (its >= 16 && rz0 > 0. && rz_end > 0. && rz_end < rz0) ? std::log(rz0 / rz_end) / its : -1.;      // -1: no estimate (too few iterations)
-}
+// (kRateDrop, lm_pcg_rate: pgo_lm.hpp - shared with the device-resident loop)
+inline double pcg_rate(double rz_stop, double rz_end, int its, double tol2, double tol_f2) { return lm_pcg_rate(rz_stop, rz_end, its, tol2, tol_f2); }
 
 void set_lambda(uzl_pgo* h, double lambda, double tol_f2)
 {
-    k_set_trial(h->D.scal, lambda, tol_f2, kStepT * h->cfg.pcg_tol, kStepR * h->cfg.pcg_tol, h->stream);
+    k_set_trial(h->D.scal, lambda, tol_f2, pgo_eps_t(h->cfg), pgo_eps_r(h->cfg), h->stream);
     h->lambda_now = lambda;
 }
 
@@ -347,6 +180,8 @@ int32_t uf_find(std::vector<int32_t>& p, int32_t x)
     while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; }
     return x;
 }
+}  // namespace
+namespace uzl {
 int32_t gauge_fix(uzl_pgo* h)
 {
     const int n = h->n;
@@ -365,6 +200,8 @@ int32_t gauge_fix(uzl_pgo* h)
     }
     return cnt;
 }
+}  // namespace uzl
+namespace {
 
 // block-CSR structure over the free vertices: one slot per (free endpoint, system edge)
 
@@ -606,6 +443,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
 }
 
 // numeric part, once per linearisation: geometry, then A_{l+1} = P^T A_l P level by level
+}  // namespace
+namespace uzl {
 void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed)
 {
     if (h->ml_levels == 0) return;
@@ -623,8 +462,12 @@ void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool t
         if (f == 0) shard_allreduce(h, h->mlb[bi].l1_span_ptr, h->l1_span);     // level 1 complete on every rank: levels >= 2 need no exchange
     }
 }
+}  // namespace uzl
+namespace {
 
 // lambda-dependent part: inverse sibling blocks, top level, dense operator (+ multiplicative cycle, Newton-Schulz refinement)
+}  // namespace
+namespace uzl {
 void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed)
 {
     uzl_pgo::MlBuf& B = h->mlb[bi];
@@ -662,6 +505,8 @@ void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool tim
         k_ml_cmat32(B.hot, 6 * h->ml_n[cl], s);
     }
 }
+}  // namespace uzl
+namespace {
 
 // Order of the free vertices in the block system.  The multilevel preconditioner aggregates 8 CONSECUTIVE blocks, which is only a
 // good coarse space when consecutive blocks are strongly coupled.  In a single session the node ids are time-ordered (std::map
@@ -717,7 +562,8 @@ std::vector<int32_t> aggregation_order(const uzl_pgo* h)
     return order;
 }
 
-void destroy_pcg_graph(uzl_pgo* h);
+}  // namespace
+namespace uzl {
 void build_structure(uzl_pgo* h)
 {
     auto t_prev = std::chrono::steady_clock::now();
@@ -870,6 +716,8 @@ void build_structure(uzl_pgo* h)
     h->structure_ready = true;
     h->structure_gen++;
 }
+}  // namespace uzl
+namespace {
 
 // enqueue `pairs` x 2 PCG iterations (p0 -> p1 -> p0); kernels no-op once the device `done` flag is set
 void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
@@ -912,9 +760,10 @@ void enqueue_pcg_pairs(uzl_pgo* h, int pairs, bool timed)
 // |r|^2 / |b|^2 a solve under the multiplicative operator must reach.  Deliberately loose: legitimate solves end at 1e-10 .. 1e-6 while
 // the linearisation moves and at ~1e-3 once LM has converged and b itself is rounding noise (a 1e-4 guard tripped there and threw a
 // healthy operator away); an operator that is not SPD leaves |r| of the order of |b| or above.
-constexpr double kResidualGuard = 0.25;
-static const int kGraphPairs = std::max(1, diag_int("UZL_GRAPH_PAIRS", 8));      // one graph replay = 2 x pairs PCG iterations
+// (kResidualGuard = 0.25: pgo_lm.hpp)
 
+}  // namespace
+namespace uzl {
 void destroy_pcg_graph(uzl_pgo* h)
 {
     for (auto& B : h->mlb) {
@@ -924,12 +773,13 @@ void destroy_pcg_graph(uzl_pgo* h)
         if (B.graph_s) { (void)hipGraphDestroy(B.graph_s); B.graph_s = nullptr; }
     }
 }
+}  // namespace uzl
+namespace {
 
 // The launch-bound inner loop is captured once per problem structure and preconditioner copy: every kernel argument (pointers,
 // partial counts, tolerance) is fixed, lambda and the CG scalars live in device memory.  Two lengths: 2 x kGraphPairs iterations,
 // and 2 x kShortPairs for solves expected to end at once (a launch behind convergence is a no-op, but still ~1.2 us of stream time:
 // a converged LM iteration's solve of 2 - 4 iterations used to pay for 28 of them).
-constexpr int kShortPairs = 2;
 void ensure_pcg_graph(uzl_pgo* h)
 {
     uzl_pgo::MlBuf& B = h->mlb[h->ml_ix];
@@ -1004,24 +854,37 @@ int pcg_solve(uzl_pgo* h, bool* converged)
     return iters;
 }
 
-int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
+}  // namespace
+namespace uzl {
+// optimizeImpl's front part (initializeOptimization :139, setFixedNodes :144-146): the structure, cached until the next add_graph / set_graph
+static void prepare_optimize(uzl_pgo* h)
 {
-    if (!h->have_graph) return fail(h, UZL_ERR_STATE, "optimize before add_graph/set_graph");
-    UZL_HIP(hipSetDevice(h->cfg.device));
-    const auto t0 = std::chrono::steady_clock::now();
-    if (iterations <= 0) iterations = h->cfg.iterations;
-    uzl_pgo_stats S;
-    memset(&S, 0, sizeof(S));
-    // optimizeImpl: initializeOptimization (:139), setFixedNodes (:144-146)
+    h->t_start = std::chrono::steady_clock::now();
     h->structure_ms = 0.; h->exchange_ms = 0.; h->exchange_calls = 0;
-    S.structure_reused = h->structure_ready ? 1 : 0;
-    if (!h->structure_ready) {          // cached until the next add_graph/set_graph
+    h->last_structure_reused = h->structure_ready;
+    if (!h->structure_ready) {
         const auto ts = std::chrono::steady_clock::now();
         h->fixed_eff = h->fixed_in;
         h->n_gauge = gauge_fix(h);
         build_structure(h);
         h->structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
     }
+}
+int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
+{
+    if (!h->have_graph) return pgo_fail(h, UZL_ERR_STATE, "optimize before add_graph/set_graph");
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    if (iterations <= 0) iterations = h->cfg.iterations;
+    prepare_optimize(h);
+    return lm_eligible(h) ? do_optimize_lm(h, iterations, st) : do_optimize_host(h, iterations, st);
+}
+// The host-driven loop.  Called through do_optimize (structure prepared, device set), or by do_optimize_lm for a solve that met an anomaly.
+int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
+{
+    const auto t0 = h->t_start;
+    uzl_pgo_stats S;
+    memset(&S, 0, sizeof(S));
+    S.structure_reused = h->last_structure_reused ? 1 : 0;
     S.n_vertices = h->n; S.n_edges = h->e; S.n_gauge_fixed = h->n_gauge;
     hipStream_t s = h->stream;
     PgoDev& D = h->D;
@@ -1104,8 +967,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         // previous iteration is as good as a fresh one (geometry + Galerkin + inverses are ~170 us per rebuild).
         // A rebuild is also forced when the iteration count has grown by a third since the last one.
         // (an asynchronous rebuild is for the NEXT iteration: none in the last one)
-        const bool refresh = it == 0 || ((always_refresh || last_rel > refresh_rel || (rate_ref > 0. && rate_last > 0. && rate_last < kRateDrop * rate_ref)) &&
-                                         (!async_ok || it + 1 < iterations));
+        const bool refresh = lm_refresh(it, iterations, always_refresh, !async_ok, last_rel, refresh_rel, rate_ref, rate_last);
         bool launch_async = false;
         bool fetched = false;
         if (red) {                                      // the hierarchy is built on the reduced system, which needs lambda: lambda_0 first
@@ -1148,7 +1010,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         }
         double rho = 0.;
         int qmax = 0;
-        const double tol_f2 = tol_factor2(it, last_rel, pcg_last);
+        const double tol_f2 = tol_factor2(h->cfg);
         mark(1);
         do {
             set_lambda(h, lambda, tol_f2);                                        // setLambda (+ this iteration's PCG tolerance)
@@ -1182,6 +1044,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
                 h->ml_mult = false; h->ml_ns_steps = 0; h->mult_banned = true;
                 for (auto& B : h->mlb) B.hot.Cmat = B.y1;
                 destroy_pcg_graph(h);                                             // MlHot is a by-value kernel argument
+                h->structure_gen++;                                               // (slot tables that carry it are rebuilt: uzl_pgo_lm.hip, batches)
                 h->ml_trial_setup = true;
                 pcg_its = pcg_solve(h, &conv);
                 S.pcg_iterations += pcg_its;
@@ -1206,20 +1069,13 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             fetch_scal(h);
             mark(3);
             const double temp_chi = h->h_scal.p->scal[4];
-            const double scale = h->h_scal.p->scal[5] + 1e-3;                     // computeScale + 1e-3
-            rho = (current_chi - temp_chi) / scale;
-            if (rho > 0 && std::isfinite(temp_chi)) {                             // good step
-                double alpha = 1. - std::pow(2 * rho - 1, 3);
-                alpha = std::min(alpha, 2. / 3.);
-                lambda *= std::max(1. / 3., alpha);
-                ni = 2.;
-                last_rel = std::fabs(current_chi - temp_chi) / std::max(std::fabs(temp_chi), 1e-300);
+            const LmStep step = lm_step(current_chi, temp_chi, h->h_scal.p->scal[5], lambda, ni);     // rho, lambda, ni (pgo_lm.hpp)
+            rho = step.rho;
+            if (step.accepted) {                                                  // good step
+                last_rel = step.last_rel;
                 current_chi = temp_chi;
                 std::swap(h->cur, h->trial);                                      // discardTop
-            } else {
-                lambda *= ni;
-                ni *= 2.;                                                          // pop: h->cur untouched
-            }
+            }                                                                     // else pop: h->cur untouched
             qmax++;
         } while (rho < 0 && qmax < 10);
         S.iterations_done = it + 1;
@@ -1249,6 +1105,8 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     if (rc != UZL_OK) h->last_error = "PCG hit pcg_max_iter in at least one LM trial";
     return rc;
 }
+}  // namespace uzl
+namespace {
 
 }  // namespace
 
@@ -1302,6 +1160,8 @@ void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg)
     cfg->huber_delta = 1.0;             // g2o_optimizer.cpp:293
     cfg->verbose = 0;
     cfg->preconditioner = 1;            // additive multilevel (rigid-body-mode aggregation); 0 = block-Jacobi
+    cfg->pcg_stop = 0;                  // step-error estimate; 1 = relative residual test only
+    cfg->lm_loop = 0;                   // LM decisions on the device (captured passes); 1 = host-driven loop
 }
 
 int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
@@ -1342,6 +1202,7 @@ void uzl_pgo_destroy(uzl_pgo* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     destroy_pcg_graph(h);
+    lm_run_destroy(h->lm); h->lm = nullptr;
     if (h->rccl_comm) { (void)rccl().CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
     if (h->ev_lin) (void)hipEventDestroy(h->ev_lin);
     if (h->ev_setup) (void)hipEventDestroy(h->ev_setup);
@@ -1894,7 +1755,7 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
                 if (!(dyn[sl].mask & kPhLin)) continue;
                 BatchLM& X = G[slot_graph[sl]];
                 // (a rebuild runs ahead for the NEXT iteration: none in the last one)
-                const bool refresh = X.it == 0 || ((always_refresh || X.last_rel > refresh_rel || (X.rate_ref > 0. && X.rate_last > 0. && X.rate_last < kRateDrop * X.rate_ref)) && X.it + 1 < iterations);
+                const bool refresh = lm_refresh(X.it, iterations, always_refresh, false, X.last_rel, refresh_rel, X.rate_ref, X.rate_last);
                 if (refresh) {
                     X.S.precond_builds++;
                     if (X.it == 0) X.trial_setup = true; else ahead[sl] = 1;          // (never in the last iteration: see `refresh`)
@@ -1951,8 +1812,8 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
             const int g = slot_graph[sl];
             BatchLM& X = G[g];
             dyn[sl].mask = kPhLambda | kPhInit; dyn[sl].lambda = X.lambda;
-            if (X.qmax == 0) X.tol_f2 = tol_factor2(X.it, X.last_rel, X.pcg_last);           // fixed for the trials of one LM iteration, like do_optimize
-            dyn[sl].tol_factor2 = X.tol_f2; dyn[sl].eps_t = kStepT * b->h[g]->cfg.pcg_tol; dyn[sl].eps_r = kStepR * b->h[g]->cfg.pcg_tol;
+            if (X.qmax == 0) X.tol_f2 = tol_factor2(b->h[g]->cfg);           // fixed for the trials of one LM iteration, like do_optimize
+            dyn[sl].tol_factor2 = X.tol_f2; dyn[sl].eps_t = pgo_eps_t(b->h[g]->cfg); dyn[sl].eps_r = pgo_eps_r(b->h[g]->cfg);
             if (X.lambda > kLambdaRetake * X.lambda_setup[X.ml_ix]) X.trial_setup = true;
             X.fresh = X.trial_setup || (X.adopted && X.qmax == 0);
             if (X.trial_setup) { dyn[sl].mask |= kPhTrialCur; X.lambda_setup[X.ml_ix] = X.lambda; X.trial_setup = false; any_trial_cur = true; }
@@ -2049,19 +1910,12 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
                 const int g = slot_graph[sl];
                 BatchLM& X = G[g];
                 const double temp_chi = b->h_pub.p[sl].scal[4];
-                const double scale = b->h_pub.p[sl].scal[5] + 1e-3;                    // computeScale + 1e-3
-                const double rho = (X.current_chi - temp_chi) / scale;
-                if (rho > 0 && std::isfinite(temp_chi)) {                             // good step
-                    double alpha = 1. - std::pow(2 * rho - 1, 3);
-                    alpha = std::min(alpha, 2. / 3.);
-                    X.lambda *= std::max(1. / 3., alpha);
-                    X.ni = 2.;
-                    X.last_rel = std::fabs(X.current_chi - temp_chi) / std::max(std::fabs(temp_chi), 1e-300);
+                const LmStep step = lm_step(X.current_chi, temp_chi, b->h_pub.p[sl].scal[5], X.lambda, X.ni);
+                const double rho = step.rho;
+                if (step.accepted) {                                                  // good step
+                    X.last_rel = step.last_rel;
                     X.current_chi = temp_chi;
                     X.cur ^= 1;                                                       // discardTop
-                } else {
-                    X.lambda *= X.ni;
-                    X.ni *= 2.;
                 }
                 X.qmax++;
                 if (rho < 0 && X.qmax < 10) { phase[g] = PStart; continue; }          // another trial on the same linearisation
