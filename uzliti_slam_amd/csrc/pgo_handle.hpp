@@ -171,6 +171,7 @@ struct uzl_pgo {
     int ml_agg = 4;                            // level-1 aggregates per PCG workgroup (1: small graphs, 4: large)
     size_t ml_lds = 0;
     DevBuf<uint8_t> ml_arena;
+    size_t ml_copy_stride = 0;                 // bytes between the two hierarchy copies inside ml_arena
     DevBuf<MlDev> d_ml;
     bool no_graph = false;          // UZL_NO_GRAPH=1: eager launches (rocprofv3 --kernel-trace crashes on hipGraphLaunch here)
     // shard (BASELINE config 4)

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(kBlk) void lm_head_kernel(const LmSlot* __restrict_
     LmDev* lm = S.lm;
     const int phase = lm->phase;
     double chi = 0., dmax = 0.;
+    __syncthreads();                                         // (lane 0 rewrites the state below: everybody has read it)
     if (phase == kLmLin) {                                   // (uniform) finalize_kernel(what = 2): chi2 + max diagonal
         chi = sum_partials(S.D.part_a, S.g_edges, s4);
         double v = 0.;
@@ -79,67 +80,95 @@ __global__ __launch_bounds__(kBlk) void lm_head_kernel(const LmSlot* __restrict_
     lm->phase = kLmSolve;                                    // (flags[0..3] are cleared by this pass's ml_init)
 }
 
-__device__ __forceinline__ void lm_publish(const LmSlot& S, const LmDev* lm, uint32_t seq)
+// The tail runs 1024 lanes: the residual guard's sums (residual_guard_kernel's order), then the first 256 fold the chi2 / scale
+// partials in finalize_kernel's order, lane 0 decides, and the first lanes copy the state to the host word by word.
+constexpr int kTailBlk = 1024;
+__global__ __launch_bounds__(kTailBlk) void lm_tail_kernel(const LmSlot* __restrict__ slots)
 {
-    LmHost* __restrict__ out = S.pub;
-    __hip_atomic_store(&out->seq_begin, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
-    out->phase = lm->phase; out->cur = lm->cur; out->ix = lm->ix; out->need = lm->need;
-    out->it = lm->it; out->qmax = lm->qmax; out->pending = lm->pending; out->pcg_last = lm->pcg_last;
-    for (int i = 0; i < 4; i++) out->flags[i] = lm->flags[i];
-    out->st_pcg_iterations = lm->st_pcg_iterations; out->st_lm_trials = lm->st_lm_trials; out->st_precond_builds = lm->st_precond_builds;
-    out->st_iterations_done = lm->st_iterations_done; out->st_terminated_early = lm->st_terminated_early; out->anomaly_code = lm->anomaly_code;
-    out->lambda = lm->lambda; out->chi_cur = lm->chi_cur; out->last_rel = lm->last_rel; out->rate_ref = lm->rate_ref; out->rate_last = lm->rate_last;
-    out->chi2_initial = lm->chi2_initial; out->lambda_setup[0] = lm->lambda_setup[0]; out->lambda_setup[1] = lm->lambda_setup[1];
-    for (int i = 0; i < 8; i++) out->scal[i] = S.D.scal[i];
-    __threadfence_system();
-    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ __launch_bounds__(kBlk) void lm_tail_kernel(const LmSlot* __restrict__ slots)
-{
-    __shared__ double s4[4];
+    __shared__ double s4[4], sr[16], sb[16];
     const LmSlot& S = slots[blockIdx.z];
     LmDev* lm = S.lm;
+    const int tid = threadIdx.x;
     const bool solving = lm->phase == kLmSolve;
     const bool done = lm->flags[0] != 0;
     const bool eval = solving && done && lm->flags[2] == 0;      // (uniform) the evaluation kernels of this pass ran for this graph
-    double chi_t = 0., sc = 0.;
-    if (eval) {                                              // finalize_kernel(what = 1): chi2 of the trial + computeScale
-        chi_t = sum_partials(S.D.part_a, S.g_edges, s4);
-        sc = sum_partials(S.D.part_b, S.g_oplus, s4);
+    __syncthreads();                                         // (lane 0 rewrites the state below: everybody has read it)
+    double chi_t = 0., sc = 0., ratio = 0.;
+    if (eval) {
+        // |r|^2 / |b|^2 with the recurrence residual r (= b - (H + lambda) x up to rounding whatever the preconditioner did): what
+        // residual_guard_kernel leaves in scal[7] for the host-driven loop
+        const PgoDev& P = S.Dp;
+        const int n = P.nb * 6;
+        double rr = 0., bb = 0.;
+        for (int i = tid; i < n; i += kTailBlk) { const double r = P.r[i], b = P.b[i]; rr += r * r; bb += b * b; }
+        for (int o = 32; o; o >>= 1) { rr += __shfl_xor(rr, o); bb += __shfl_xor(bb, o); }
+        if ((tid & 63) == 0) { sr[tid >> 6] = rr; sb[tid >> 6] = bb; }
+        // finalize_kernel(what = 1): chi2 of the trial + computeScale, sum_partials' order (256 lanes)
+        double va = 0., vb = 0.;
+        if (tid < kBlk) {
+            for (int i = tid; i < S.g_edges; i += kBlk) va += S.D.part_a[i];
+            for (int i = tid; i < S.g_oplus; i += kBlk) vb += S.D.part_b[i];
+            va = wave_sum(va);
+        }
+        __syncthreads();
+        if (tid < kBlk && (tid & 63) == 0) s4[tid >> 6] = va;
+        __syncthreads();
+        chi_t = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        if (tid < kBlk) vb = wave_sum(vb);
+        __syncthreads();
+        if (tid < kBlk && (tid & 63) == 0) s4[tid >> 6] = vb;
+        __syncthreads();
+        sc = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        rr = 0.; bb = 0.;
+        for (int w = 0; w < 16; w++) { rr += sr[w]; bb += sb[w]; }
+        ratio = bb > 0. ? rr / bb : 0.;
     }
-    if (threadIdx.x != 0) return;
-    const uint32_t seq = (uint32_t)(lm->tails + 1);
-    lm->tails = (int32_t)seq;
-    double* __restrict__ scal = S.D.scal;
-    if (solving && !done) {
-        if (lm->flags[1] >= lm->max_it) { lm->phase = kLmAnomaly; lm->anomaly_code = 1; lm->flags[0] = 1; }      // PCG hit its cap
-    } else if (solving) {
-        const int its = lm->flags[1];
-        bool conv = lm->flags[2] == 0;
-        if (conv && lm->guarded && !(scal[7] <= kResidualGuard)) conv = false;      // (DESIGN.md "Safeguards": not SPD by construction)
-        if (!conv) { lm->phase = kLmAnomaly; lm->anomaly_code = lm->flags[2] ? 2 : 3; }
-        else {
-            scal[4] = chi_t; scal[5] = sc;
-            lm->st_pcg_iterations += its; lm->st_lm_trials++; lm->pcg_last = its;
-            const double rate = lm_pcg_rate(scal[1], scal[0], its, lm->tol2, lm->tol_f2);
-            if (rate > 0.) { lm->rate_last = rate; if (lm->fresh || lm->rate_ref < 0.) lm->rate_ref = rate; }
-            double lambda = lm->lambda, ni = lm->ni;
-            const LmStep st = lm_step(lm->chi_cur, chi_t, sc, lambda, ni);
-            lm->lambda = lambda; lm->ni = ni;
-            if (st.accepted) { lm->last_rel = st.last_rel; lm->chi_cur = chi_t; lm->cur ^= 1; }      // discardTop
-            const int qmax = lm->qmax + 1;
-            lm->qmax = qmax;
-            if (st.rho < 0 && qmax < 10) lm->phase = kLmRetry;                    // another trial on the same linearisation
+    __shared__ uint32_t s_seq;
+    if (tid == 0) {
+        const uint32_t seq = (uint32_t)(lm->tails + 1);
+        lm->tails = (int32_t)seq;
+        s_seq = seq;
+        double* __restrict__ scal = S.D.scal;
+        if (solving && !done) {
+            if (lm->flags[1] >= lm->max_it) { lm->phase = kLmAnomaly; lm->anomaly_code = 1; lm->flags[0] = 1; }      // PCG hit its cap
+        } else if (solving) {
+            const int its = lm->flags[1];
+            bool conv = lm->flags[2] == 0;
+            if (conv) scal[7] = ratio;
+            if (conv && lm->guarded && !(ratio <= kResidualGuard)) conv = false;      // (DESIGN.md "Safeguards": not SPD by construction)
+            if (!conv) { lm->phase = kLmAnomaly; lm->anomaly_code = lm->flags[2] ? 2 : 3; }
             else {
-                lm->st_iterations_done = lm->it + 1;
-                if (qmax == 10 || st.rho == 0) { lm->st_terminated_early = 1; lm->phase = kLmDone; }      // Terminate
-                else { lm->it += 1; lm->qmax = 0; lm->phase = (lm->it >= lm->iterations) ? kLmDone : kLmLin; }
+                scal[4] = chi_t; scal[5] = sc;
+                lm->st_pcg_iterations += its; lm->st_lm_trials++; lm->pcg_last = its;
+                const double rate = lm_pcg_rate(scal[1], scal[0], its, lm->tol2, lm->tol_f2);
+                if (rate > 0.) { lm->rate_last = rate; if (lm->fresh || lm->rate_ref < 0.) lm->rate_ref = rate; }
+                double lambda = lm->lambda, ni = lm->ni;
+                const LmStep st = lm_step(lm->chi_cur, chi_t, sc, lambda, ni);
+                lm->lambda = lambda; lm->ni = ni;
+                if (st.accepted) { lm->last_rel = st.last_rel; lm->chi_cur = chi_t; lm->cur ^= 1; }      // discardTop
+                const int qmax = lm->qmax + 1;
+                lm->qmax = qmax;
+                if (st.rho < 0 && qmax < 10) lm->phase = kLmRetry;                    // another trial on the same linearisation
+                else {
+                    lm->st_iterations_done = lm->it + 1;
+                    if (qmax == 10 || st.rho == 0) { lm->st_terminated_early = 1; lm->phase = kLmDone; }      // Terminate
+                    else { lm->it += 1; lm->qmax = 0; lm->phase = (lm->it >= lm->iterations) ? kLmDone : kLmLin; }
+                }
             }
         }
+        __hip_atomic_store(&S.pub->seq_begin, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence();
     }
-    lm_publish(S, lm, seq);
+    __syncthreads();
+    // ---- the snapshot the host polls: one word per lane
+    constexpr int kLmWords = (int)(sizeof(LmDev) / 8);
+    static_assert(sizeof(LmDev) % 8 == 0 && kLmWords + 8 <= kTailBlk, "LmDev is copied as 8-byte words");
+    unsigned long long* __restrict__ dst = reinterpret_cast<unsigned long long*>(S.pub);
+    if (tid < kLmWords) dst[tid] = reinterpret_cast<const unsigned long long*>(lm)[tid];
+    else if (tid < kLmWords + 8) reinterpret_cast<double*>(dst)[tid] = S.D.scal[tid - kLmWords];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&S.pub->seq, s_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 void k_lm_head(const LmSlot* slots, int nslots, int pass_flags, hipStream_t s)
@@ -148,7 +177,7 @@ void k_lm_head(const LmSlot* slots, int nslots, int pass_flags, hipStream_t s)
 }
 void k_lm_tail(const LmSlot* slots, int nslots, hipStream_t s)
 {
-    hipLaunchKernelGGL(lm_tail_kernel, dim3(1, 1, nslots), dim3(kBlk), 0, s, slots);
+    hipLaunchKernelGGL(lm_tail_kernel, dim3(1, 1, nslots), dim3(kTailBlk), 0, s, slots);
 }
 
 }  // namespace uzl

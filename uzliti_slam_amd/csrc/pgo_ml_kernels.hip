@@ -2531,13 +2531,30 @@ void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
 __device__ __forceinline__ const LmSlot& slot_of(const LmSlot* __restrict__ slots) { return slots[blockIdx.z]; }
 __device__ __forceinline__ const LmSlot& slot_of(const LmSlot& slot) { return slot; }
 
+// The hot subset of hierarchy copy `ix`.  Both copies sit in one arena, `copy_stride` bytes apart, and share every size: copy 0's
+// struct with its arena pointers moved - an add behind the ix load, where indexing hot[] with ix would be a second, dependent load of the slot
+// (kernel-argument memory) in front of kernels that are chains of round trips already (10k/50k: 1.0 us per PCG iteration).
+template <class T>
+__device__ __forceinline__ const T* moved(const T* p, int64_t bytes) { return p ? reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + bytes) : nullptr; }
+__device__ __forceinline__ MlHot hot_of(const LmSlot& S, int ix)
+{
+    MlHot H = S.hot[0];
+    const int64_t off = ix ? S.copy_stride : 0;
+    H.geo0 = moved(H.geo0, off); H.top_inv = moved(H.top_inv, off); H.Cmat = moved(H.Cmat, off); H.Cmat32 = moved(H.Cmat32, off);
+    H.Vg = const_cast<double*>(moved(const_cast<const double*>(H.Vg), off));
+#pragma unroll
+    for (int l = 0; l <= kMlMaxLevels; l++) { H.geo[l] = moved(H.geo[l], off); H.Winv[l] = moved(H.Winv[l], off); }
+    return H;                                   // (Sg lives in the PCG vectors' buffer: the same for both copies)
+}
+__device__ __forceinline__ double* rg_of(const LmSlot& S, int ix, int k) { return reinterpret_cast<double*>(reinterpret_cast<char*>(S.rg[0][k]) + (ix ? S.copy_stride : 0)); }
+
 template <int AGG, class SLOT>
 __global__ __launch_bounds__(kCgBlk) void ml_init_lm_kernel(const SLOT slots)
 {
     const LmSlot& S = slot_of(slots);
     const LmDev* lm = S.lm;
     if (lm->phase != kLmSolve || lm->init_pass != lm->pass) return;
-    ml_init_kernel_body<AGG>(S.Dp, S.hot[lm->ix], S.pbuf[0], S.pbuf[1], S.rg[lm->ix][0]);
+    ml_init_kernel_body<AGG>(S.Dp, hot_of(S, lm->ix), S.pbuf[0], S.pbuf[1], rg_of(S, lm->ix, 0));
 }
 // PCG iteration i of a replay (parity = i & 1): p_old = pbuf[parity], p_new = pbuf[parity ^ 1]; a no-op once flags[0] is set
 template <int AGG, int RPW, int WAVES, class SLOT>
@@ -2545,7 +2562,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
 {
     const LmSlot& S = slot_of(slots);
     const LmDev* lm = S.lm;
-    ml_spmv_kernel_body<AGG, RPW, WAVES>(S.Dp, S.hot[lm->ix], S.pbuf[parity], S.pbuf[parity ^ 1], S.g_rows, lm->tol2);
+    ml_spmv_kernel_body<AGG, RPW, WAVES>(S.Dp, hot_of(S, lm->ix), S.pbuf[parity], S.pbuf[parity ^ 1], S.g_rows, lm->tol2);
 }
 // init = 1: the first application of the preconditioner (r = b), in the pass that starts the solve
 template <int kCompU, bool kLds, class SLOT>
@@ -2556,8 +2573,8 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_comp_lm_kernel(const SLOT slots,
     const int ix = lm->ix;
     if (init) {
         if (lm->phase != kLmSolve || lm->init_pass != lm->pass) return;
-        ml_cg_comp_kernel_body<kCompU, kLds>(S.Dp, S.hot[ix], S.pbuf[0], S.rg[ix][0], S.rg[ix][1], 0, 1);
-    } else ml_cg_comp_kernel_body<kCompU, kLds>(S.Dp, S.hot[ix], S.pbuf[parity ^ 1], S.rg[ix][parity ^ 1], S.rg[ix][parity], S.g_spmv, 0);
+        ml_cg_comp_kernel_body<kCompU, kLds>(S.Dp, hot_of(S, ix), S.pbuf[0], rg_of(S, ix, 0), rg_of(S, ix, 1), 0, 1);
+    } else ml_cg_comp_kernel_body<kCompU, kLds>(S.Dp, hot_of(S, ix), S.pbuf[parity ^ 1], rg_of(S, ix, parity ^ 1), rg_of(S, ix, parity), S.g_spmv, 0);
 }
 template <int AGG, bool COMP, bool YPRE, bool VPRE, class SLOT>
 __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (YPRE ? 2 : 3) : 1))) void ml_cg_lm_kernel(const SLOT slots, int parity, int init)
@@ -2567,15 +2584,15 @@ __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (
     const int ix = lm->ix;
     if (init) {
         if (lm->phase != kLmSolve || lm->init_pass != lm->pass) return;
-        ml_cg_kernel_body<AGG, COMP, YPRE, false>(S.Dp, S.hot[ix], S.pbuf[0], S.rg[ix][0], S.rg[ix][1], 0, 1);
-    } else ml_cg_kernel_body<AGG, COMP, YPRE, VPRE>(S.Dp, S.hot[ix], S.pbuf[parity ^ 1], S.rg[ix][parity ^ 1], S.rg[ix][parity], S.g_spmv, 0);
+        ml_cg_kernel_body<AGG, COMP, YPRE, false>(S.Dp, hot_of(S, ix), S.pbuf[0], rg_of(S, ix, 0), rg_of(S, ix, 1), 0, 1);
+    } else ml_cg_kernel_body<AGG, COMP, YPRE, VPRE>(S.Dp, hot_of(S, ix), S.pbuf[parity ^ 1], rg_of(S, ix, parity ^ 1), rg_of(S, ix, parity), S.g_spmv, 0);
 }
 template <class SLOT>
 __global__ __launch_bounds__(256) void ml_alpha_lm_kernel(const SLOT slots, int parity)
 {
     const LmSlot& S = slot_of(slots);
     const LmDev* lm = S.lm;
-    ml_alpha_kernel_body(S.Dp, S.hot[lm->ix], S.rg[lm->ix][parity ^ 1], S.g_spmv);
+    ml_alpha_kernel_body(S.Dp, hot_of(S, lm->ix), rg_of(S, lm->ix, parity ^ 1), S.g_spmv);
 }
 
 // raises the dynamic-LDS limit of an ml_cg variant once per device (a function attribute is per device)

@@ -231,16 +231,12 @@ struct LmDev {
     double chi2_initial, tol_f2, eps_t, eps_r, refresh_rel, tol2, lambda_retake, delta;
     double scal2[8];           // [3]: lambda of a rebuild that runs ahead of the trial loop (the set-up kernels read scal[3])
 };
-// what the host sees after a pass: written by lm_tail_kernel into pinned coherent memory, `seq` (= LmDev::tails) last
+// what the host sees after a pass: an image of the LM state and of PgoDev::scal[0..8), written by lm_tail_kernel into pinned coherent
+// memory (one 8-byte word per lane); seq_begin first, seq (= LmDev::tails) last: a host copy is whole when both agree around it
 struct LmHost {
-    int32_t phase, cur, ix, need;
-    int32_t it, qmax, pending, pcg_last;
-    int32_t flags[4];
-    int32_t st_pcg_iterations, st_lm_trials, st_precond_builds, st_iterations_done, st_terminated_early, anomaly_code;
-    uint32_t seq, seq_begin;   // seq_begin is written first, seq last: a host copy is whole when both agree around it
-    double lambda, chi_cur, last_rel, rate_ref, rate_last, chi2_initial;
-    double lambda_setup[2];
-    double scal[8];            // PgoDev::scal[0..8) as the legacy loop fetches them (verbose logs, residual ratio)
+    LmDev lm;
+    double scal[8];            // as the host-driven loop fetches them (verbose logs, residual ratio)
+    uint32_t seq_begin, seq;
 };
 // everything a slot twin needs, per graph; uploaded when the structure of the graph changes
 struct LmSlot {
@@ -258,6 +254,7 @@ struct LmSlot {
     double* pbuf[2];                           // PCG direction, ping-pong
     double* pose[2];
     int32_t g_edges, g_asm, g_oplus, g_rows, g_spmv, red, pad0, pad1;      // grids (= partial counts) of this graph's launches; red: Schur-reduced
+    int64_t copy_stride;                       // bytes from an array of hierarchy copy 0 to the same array of copy 1 (one arena, two halves)
 };
 
 // launch geometry of a pass: what the host needs besides the slot table (one structure, or the common shape of a batch)

@@ -364,6 +364,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     const size_t o_sg = take(ngz), o_rga = take(ngz), o_rgb = take(ngz), o_vg = take(ngz);
     const size_t buf_bytes = (bytes + 255) / 256 * 256;
     h->ml_arena.reserve(2 * buf_bytes);
+    h->ml_copy_stride = buf_bytes;
     std::vector<uint8_t> stage(int_bytes, 0);
     auto put = [&](size_t o, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage.data() + o, v.data(), v.size() * 4); };
     for (int l = 0; l <= L; l++) {

@@ -35,6 +35,7 @@ struct LmRun {
     bool join_pending = false;               // a rebuild is in flight on the second stream
     uint32_t tails = 0;                      // lm_tail launches enqueued = sequence word expected next
     uint64_t gen = ~0ull;                    // structure generation the slot and the captured segments belong to
+    int first_solve_its = 0;                 // PCG iterations of the first solve of the last optimize (sizes the first pass of the next)
     struct Seg { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; };
     Seg head[4], setup, reb, init, pcg_long, pcg_short, tail;
     void drop(Seg& q) { if (q.x) { (void)hipGraphExecDestroy(q.x); q.x = nullptr; } if (q.g) { (void)hipGraphDestroy(q.g); q.g = nullptr; } }
@@ -74,7 +75,6 @@ void enq_pcg(LmRun* R, int pairs, hipStream_t s) { UZL_HIP(kl_ml_pcg_pairs(R->d_
 void enq_tail(LmRun* R, hipStream_t s)
 {
     const LmShape& sh = R->shape;
-    kl_residual_guard(R->d_slots.p, sh.nslots, s);
     if (sh.red) kl_schur_backsub(R->d_slots.p, sh.nslots, sh.schur_backsub_grid, s);
     kl_eval(R->d_slots.p, sh.nslots, sh.g_edges, sh.g_oplus, s);
     k_lm_tail(R->d_slots.p, sh.nslots, s);
@@ -113,6 +113,7 @@ LmSlot make_slot(const uzl_pgo* h, LmDev* d_lm, LmHost* d_pub)
     S.pose[0] = h->pose_a.p; S.pose[1] = h->pose_b.p;
     S.g_edges = g_edges_for(h->e); S.g_asm = g_asm_for(h->nb); S.g_oplus = g_oplus_for(h->n);
     S.g_rows = g_ml_rows(h->Dp.nb, h->ml_agg); S.g_spmv = g_ml_spmv(h->Dp.nb, h->ml_agg);
+    S.copy_stride = (int64_t)h->ml_copy_stride;
     return S;
 }
 
@@ -231,14 +232,15 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     //   * the set-up segments from the refresh rule on the old state - lm_head stalls a graph whose pass lacks what it needs, and a
     //     segment nobody wants no-ops.
     // The DEVICE takes every decision from the graph's own state, so the result does not depend on what the host guessed or when it looked.
-    LmHost v;                                // the latest snapshot (the start state before the first pass)
-    memset(&v, 0, sizeof(v));
-    v.phase = kLmLin; v.last_rel = 1e300; v.rate_ref = -1.; v.rate_last = -1.;
+    LmHost snap;                             // the latest snapshot (the start state before the first pass)
+    memset(&snap, 0, sizeof(snap));
+    snap.lm = I;
+    LmDev& v = snap.lm;
     constexpr int kStep = 2 * kShortPairs;
     const int kLong = 2 * kGraphPairs;
     auto round_up = [](int x) { return ((x + kStep - 1) / kStep) * kStep; };
-    static const bool no_run_ahead = diag_flag("UZL_LM_NO_RUN_AHEAD");      // A/B switch (diagnostic build): look at every pass before the next is enqueued
-    int32_t passes = 0, in_flight = 0;
+    static const bool run_ahead = diag_flag("UZL_LM_RUN_AHEAD");            // A/B switch (diagnostic build): the next pass is enqueued before this one has been looked at
+    int32_t passes = 0, in_flight = 0, solve_passes = 0;
     uint32_t seen = 0;                       // snapshots consumed
     double enq_ms = 0., wait_ms = 0.;
     // enqueue one full pass; `ahead` = passes in flight whose outcome `v` does not know yet (each assumed to complete one LM iteration)
@@ -254,7 +256,8 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     auto enqueue_pass = [&](int ahead) {
         const auto tp0 = std::chrono::steady_clock::now();
         int pf = 0;
-        if (v.phase == kLmNeedSetup) pf = ((v.need & (kNeedNumeric | kNeedTrial)) ? kPassSetup : 0) | ((v.need & kNeedRebuild) ? kPassRebuild : 0);
+        if (ahead == 0 && v.phase == kLmSolve) pf = 0;
+        else if (v.phase == kLmNeedSetup) pf = ((v.need & (kNeedNumeric | kNeedTrial)) ? kPassSetup : 0) | ((v.need & kNeedRebuild) ? kPassRebuild : 0);
         else {
             const int it_guess = v.it + ahead;
             if (v.phase == kLmLin || ahead > 0) {
@@ -264,10 +267,11 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             if (ahead == 0 && v.phase == kLmLin && v.it > 0 && v.lambda > kLambdaRetake * v.lambda_setup[v.ix ^ (v.pending ? 1 : 0)]) pf |= kPassSetup;
             if (ahead == 0 && v.phase == kLmRetry && v.lambda > kLambdaRetake * v.lambda_setup[v.ix]) pf |= kPassSetup;
         }
+        const bool goes_on = ahead == 0 && v.phase == kLmSolve;      // a solve that outlasted its pass (known, not guessed): PCG + tail only
         mark(0);
-        if (R->join_pending) { UZL_HIP(hipStreamWaitEvent(s, R->ev_join, 0)); R->join_pending = false; }      // the rebuild of an earlier pass reads H and the poses
+        if (!goes_on && R->join_pending) { UZL_HIP(hipStreamWaitEvent(s, R->ev_join, 0)); R->join_pending = false; }      // the rebuild of an earlier pass reads H and the poses
         mark(1);
-        enq_head(R, pf, s);
+        if (!goes_on) enq_head(R, pf, s);
         mark(2);
         if (pf & kPassSetup) run_seg(R->setup, eager, s, [&](hipStream_t q) { enq_setup(R, 1, q); });
         if (pf & kPassRebuild) {
@@ -278,17 +282,22 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             R->join_pending = true;
         }
         mark(3);
-        enq_init(R, s);
+        if (!goes_on) enq_init(R, s);
         mark(4);
-        // the solve's length: the previous solve's count (+ 1: a solve that the stop test ends after k iterations is declared done by the
-        // ml_spmv of iteration k + 1; + 1 more: a launch too many is a 1.2-us no-op, one too few another pass), in steps of 2 x kShortPairs
-        int want = v.pcg_last > 0 ? round_up(v.pcg_last + 2) : kLong;
-        if (v.phase == kLmSolve && ahead == 0) want = kLong;      // a solve that outlasted its pass: nothing says how much longer
-        want = std::max(kStep, std::min(want, round_up(I.max_it)));
-        if (eager) enq_pcg(R, want / 2, s);
-        else {
-            for (int i = 0; i < want / kLong; i++) run_seg(R->pcg_long, false, s, [&](hipStream_t q) { enq_pcg(R, kGraphPairs, q); });
-            for (int i = 0; i < (want % kLong + kStep - 1) / kStep; i++) run_seg(R->pcg_short, false, s, [&](hipStream_t q) { enq_pcg(R, kShortPairs, q); });
+        // the solve's length: the previous solve's count + 1 (a solve that the stop test ends after k iterations is declared done by the
+        // ml_spmv of iteration k + 1), rounded up to a pair.  Too many is a 1.2-us no-op per launch, too few another pass.  Short solves
+        // are launched kernel by kernel (~3 us of host time each, and no fixed cost: a hipGraphLaunch costs ~10 us whatever it holds),
+        // long ones as captured replays of 2 x kGraphPairs iterations plus a remainder.
+        // The first solve of an optimize has no predecessor: the first solve of the handle's last optimize stands in (same structure or a
+        // grown one: a re-optimisation), a fresh handle starts with two long replays.
+        int want = v.pcg_last > 0 ? ((v.pcg_last + 2) & ~1) : (R->first_solve_its > 0 ? ((R->first_solve_its + 2) & ~1) : 2 * kLong);
+        if (goes_on) want = solve_passes < 2 ? kStep : kLong;     // nothing says how much longer: two short batches, then long ones
+        solve_passes = goes_on ? solve_passes + 1 : 0;
+        want = std::max(2, std::min(want, round_up(I.max_it)));
+        {
+            const int n_long = eager ? 0 : want / kLong, rem = want - n_long * kLong;
+            for (int i = 0; i < n_long; i++) run_seg(R->pcg_long, false, s, [&](hipStream_t q) { enq_pcg(R, kGraphPairs, q); });
+            if (rem > 0) enq_pcg(R, rem / 2, s);
         }
         mark(5);
         enq_tail(R, s);
@@ -301,14 +310,15 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     for (;;) {
         // another pass behind the one in flight - unless the known state says the in-flight passes should finish the job
         const bool more_likely = v.phase == kLmNeedSetup || v.it + in_flight < iterations;
-        if (!no_run_ahead && in_flight < 2 && more_likely) enqueue_pass(in_flight);
+        if (run_ahead && in_flight < 2 && more_likely) enqueue_pass(in_flight);
         const auto tw0 = std::chrono::steady_clock::now();
-        const uint32_t got = wait_pub(h, R, 0, seen + 1, &v);      // the oldest pass in flight (or a later one, if the host was slow)
+        const uint32_t got = wait_pub(h, R, 0, seen + 1, &snap);      // the oldest pass in flight (or a later one, if the host was slow)
         wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
         in_flight -= (int32_t)(got - seen); seen = got;
         if (h->cfg.verbose)
             fprintf(stderr, "[uzl_pgo] pass %u done -> it %d trial %d phase %d: pcg %d done %d (last solve %d) lambda %.3e chi2 %.9g |r|2/|b|2 %.3e need %d\n", got - 1, v.it, v.qmax,
-                    v.phase, v.flags[1], v.flags[0], v.pcg_last, v.lambda, v.chi_cur, v.scal[7], v.need);
+                    v.phase, v.flags[1], v.flags[0], v.pcg_last, v.lambda, v.chi_cur, snap.scal[7], v.need);
+        if (v.st_lm_trials == 1 && v.pcg_last > 0) R->first_solve_its = v.pcg_last;
         if (v.phase == kLmDone || v.phase == kLmAnomaly) break;
         if (in_flight == 0) enqueue_pass(0);
     }
@@ -338,7 +348,7 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     }
     h->cur = v.cur ? h->pose_b.p : h->pose_a.p; h->trial = v.cur ? h->pose_a.p : h->pose_b.p;
     h->prev_pcg_iters = v.pcg_last;
-    h->last_residual_ratio = v.scal[7];
+    h->last_residual_ratio = snap.scal[7];
     if (st) {
         uzl_pgo_stats S;
         memset(&S, 0, sizeof(S));
