@@ -66,8 +66,38 @@ def test_mixed_shapes_fall_back_to_single_solves(capi):
 
 
 def test_chain_like_graphs_in_a_batch(capi, oracle):
-    """Chain-like graphs (few loop closures) and zero-residual graphs: rejected trials, early termination and, where the solver
-    meets an anomaly, the per-graph fallback - results still equal the single solves."""
+    """Chain-like graphs - an odometry chain plus a few loop closures, the shape of the reference's local-scope graphs
+    (graph_slam_node.cpp:578-663, g2o_optimizer.cpp:190-259) - are Schur-reduced (csrc/pgo_schur.hpp) and batch on their REDUCED systems,
+    whose sizes differ from graph to graph: every launch takes the largest graph's grid.  Results equal the single solves bit for bit."""
+    graphs = [synth.make_pose_graph(1500, 1530, seed=40 + k) for k in range(16)]
+    bt = capi.PgoBatch(len(graphs))
+    for k, g in enumerate(graphs):
+        bt.graphs[k].add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    stats = bt.optimize(12)
+    assert bt.n_batched == len(graphs), "chain-like graphs must batch (round 3 sent them one by one through the single-graph path)"
+    sizes = set()
+    for k, g in enumerate(graphs):
+        st1, poses1, err1 = _single(capi, g, 12)
+        assert st1["n_eliminated"] > 0 and stats[k]["n_eliminated"] == st1["n_eliminated"]
+        sizes.add(st1["n_vertices"] - st1["n_eliminated"])
+        poses, err, _ = bt.graphs[k].store()
+        assert np.array_equal(poses, poses1), k
+        assert np.array_equal(err, err1, equal_nan=True)
+        for f in ("iterations_done", "lm_trials", "pcg_iterations", "precond_builds", "terminated_early", "chi2_final", "lambda_final"):
+            assert stats[k][f] == st1[f], (k, f, stats[k][f], st1[f])
+    assert len(sizes) > 1                                          # the reduced systems really were of different sizes
+    g = graphs[5]
+    fl = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, _ = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=12)
+    dt, dr = synth.pose_errors(bt.graphs[5].store()[0].reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+    assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+    bt.close()
+
+
+def test_zero_residual_and_anomalous_graphs_in_a_batch(capi):
+    """Few loop closures and a zero-residual graph in one batch: rejected trials, early termination and, where the solver meets an
+    anomaly, the per-graph fallback - results still equal the single solves."""
     graphs = [synth.make_pose_graph(1500, 1500 + 10 * k, seed=40 + k) for k in range(4)]
     graphs[3] = synth.make_pose_graph(1500, 1499, seed=9)              # a pure odometry chain: chi2 = 0 from the start
     bt = capi.PgoBatch(len(graphs))

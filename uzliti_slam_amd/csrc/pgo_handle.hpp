@@ -57,22 +57,9 @@ void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, d
 hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, const double* rg_old, double* rg_new, int n_part,
                    int init, size_t lds, hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s);
-// batched twins (pgo_kernels.hip / pgo_ml_kernels.hip)
-void kb_linearize(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_asm, double delta, hipStream_t s);
-void kb_eval(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_oplus, double delta, hipStream_t s);
-void kb_residual_guard(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s);
-void kb_set_lambda(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s);
-void kb_publish(const BatchSlot* sl, int nb_, PgoHostScal* out_dev, uint32_t seq, hipStream_t s);
 int g_edges_for(int e);
 int g_asm_for(int nb);
 int g_oplus_for(int n);
-void kb_ml_numeric(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int levels, const int* n_lv, const int* max_work_t, const int* max_work_r, hipStream_t s);
-void kb_ml_trial(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int pass, int levels, int cl, const int* n_lv, int inner_aggs, int ns_steps,
-                 int upper_ns, hipStream_t s);
-void kb_ml_init(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, hipStream_t s);
-void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, int pairs, double tol2, hipStream_t s,
-                     hipEvent_t* ev = nullptr);
-bool ml_comp_small(int n1);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
 void k_schur_eliminate(const PgoDev& D, const SchurDev& S, hipStream_t s);
@@ -82,7 +69,6 @@ void k_schur_backsub(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStr
 void k_lm_head(const LmSlot* slots, int nslots, int pass_flags, hipStream_t s);
 void k_lm_tail(const LmSlot* slots, int nslots, hipStream_t s);
 void kl_linearize(const LmSlot* sl, int nslots, int g_edges, int g_asm, hipStream_t s);
-void kl_residual_guard(const LmSlot* sl, int nslots, hipStream_t s);
 void kl_eval(const LmSlot* sl, int nslots, int g_edges, int g_oplus, hipStream_t s);
 void kl_schur_reduce(const LmSlot* sl, int nslots, int max_runs, long max_items, hipStream_t s);
 void kl_schur_backsub(const LmSlot* sl, int nslots, int max_grid, hipStream_t s);
@@ -90,7 +76,7 @@ void kl_ml_numeric(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s
 void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s);
 void ml_cg_variant(const MlHot& ml, int agg, size_t lds_full, int32_t* variant, int32_t* comp_u, uint64_t* lds);
 hipError_t kl_ml_init(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, hipStream_t s);
-hipError_t kl_ml_pcg_pairs(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, int pairs, hipStream_t s);
+hipError_t kl_ml_pcg_pairs(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, int pairs, hipStream_t s, hipEvent_t* ev = nullptr);
 }  // namespace uzl
 
 
@@ -210,6 +196,7 @@ void build_structure(uzl_pgo* h);                     // block-CSR, Schur plan, 
 void destroy_pcg_graph(uzl_pgo* h);
 void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
+void prepare_optimize(uzl_pgo* h);                    // optimizeImpl's front part: gauge + structure (cached), t_start
 int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);      // the host-driven loop (sharded / block-Jacobi / profiled solves, anomaly fallback)
 int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);           // picks the loop
 // ---- the device-resident loop (uzl_pgo_lm.hip)
@@ -217,6 +204,9 @@ struct LmRun;                                          // captured passes + slot
 void lm_run_destroy(LmRun* r);
 bool lm_eligible(const uzl_pgo* h);
 int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);
+bool lm_batch_eligible(const std::vector<uzl_pgo*>& hs);
+int batch_optimize_lm(LmRun*& R, const std::vector<uzl_pgo*>& hs, int resident, hipStream_t s, hipStream_t s2, int32_t iterations, bool eager, bool verbose, KernelTimer* timer,
+                      uzl_pgo_stats* stats, int* rc_all);
 extern const int kUpperNs;                            // Newton-Schulz steps of the dense levels above the composite level
 extern const bool kAlwaysRefresh;                     // A/B switches (diagnostic build)
 extern const double kRefreshRel, kLambdaRetake;

@@ -629,73 +629,7 @@ static inline int grid_for(int items, int per_block, int cap)
     return g > cap ? cap : g;
 }
 
-// ------------------------------------------------------------------------------------------------
-// batched twins (uzl_pgo_batch_*): graph = blockIdx.z, arguments from its slot, phase from its mask
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void residual_guard_kernel_body(PgoDev D);
-#define UZL_BATCH_ENTER(PHASE)                                   \
-    const BatchSlot& S = slots[blockIdx.z];                      \
-    const BatchDyn dy = dyn[blockIdx.z];                         \
-    if (!(dy.mask & (PHASE))) return;
-
-__global__ __launch_bounds__(kBlk) void linearize_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, double delta)
-{
-    UZL_BATCH_ENTER(kPhLin)
-    if ((int)blockIdx.x >= S.g_edges) return;
-    linearize_kernel_body(S.D, S.pose[dy.cur], delta);
-}
-__global__ __launch_bounds__(kBlk) void assemble_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
-{
-    UZL_BATCH_ENTER(kPhLin)
-    if ((int)blockIdx.x >= S.g_asm) return;
-    assemble_kernel_body(S.D);
-}
-// what = 2: after linearize + assemble (kPhLin); what = 1: after oplus + chi2 (kPhEval)
-__global__ __launch_bounds__(kBlk) void finalize_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int what)
-{
-    UZL_BATCH_ENTER(what == 2 ? kPhLin : kPhEval)
-    if (what == 2) finalize_kernel_body(S.D, S.g_edges, 0, S.g_asm, 2);
-    else finalize_kernel_body(S.D, S.g_edges, S.g_oplus, 0, 1);
-}
-__global__ __launch_bounds__(kBlk) void oplus_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
-{
-    UZL_BATCH_ENTER(kPhEval)
-    if ((int)blockIdx.x >= S.g_oplus) return;
-    oplus_kernel_body(S.D, S.pose[dy.cur], S.pose[dy.cur ^ 1]);
-}
-__global__ __launch_bounds__(kBlk) void chi2_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, double delta)
-{
-    UZL_BATCH_ENTER(kPhEval)
-    if ((int)blockIdx.x >= S.g_edges) return;
-    chi2_kernel_body(S.D, S.pose[dy.cur ^ 1], delta);
-}
-__global__ __launch_bounds__(1024) void residual_guard_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
-{
-    UZL_BATCH_ENTER(kPhSolve)
-    residual_guard_kernel_body(S.D);
-}
-// lambda of the round's trial into every graph's scal[3]; lambda of a run-ahead rebuild into scal2[3]
-__global__ __launch_bounds__(kBlk) void set_lambda_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int nbatch)
-{
-    const int g = blockIdx.x * kBlk + threadIdx.x;
-    if (g >= nbatch) return;
-    const BatchDyn dy = dyn[g];
-    if (dy.mask & kPhLambda) { slots[g].D.scal[3] = dy.lambda; slots[g].D.scal[8] = dy.tol_factor2; slots[g].D.scal[12] = dy.eps_t; slots[g].D.scal[13] = dy.eps_r; }
-    if ((dy.mask & (kPhNumeric | kPhTrialBuild)) && dy.build_scal2) slots[g].scal2[3] = dy.lambda_build;
-}
-// every graph's scal[0..8) / flags[0..4) into the pinned array, then one sequence word
-__global__ __launch_bounds__(64) void publish_batch_kernel(const BatchSlot* __restrict__ slots, int nbatch, PgoHostScal* __restrict__ out, uint32_t seq)
-{
-    const int t = threadIdx.x;
-    for (int g = 0; g < nbatch; g++) {
-        if (t < 8) out[g].scal[t] = slots[g].D.scal[t];
-        else if (t < 12) out[g].flags[t - 8] = slots[g].D.flags[t - 8];
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0) __hip_atomic_store(&out[nbatch].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // ------------------------------------------------------------------------------------------------
 // slot twins of the device-resident LM loop (pgo_types.hpp: LmSlot / LmDev): graph = blockIdx.z, arguments from its slot, and every
 // kernel predicates itself on the graph's phase - a pass is a fixed launch sequence (uzl_pgo_lm.hip)
@@ -715,12 +649,6 @@ __global__ __launch_bounds__(kBlk) void assemble_lm_kernel(const LmSlot* __restr
 }
 // the evaluation of a trial runs once its solve has ended without a breakdown (lm_tail_kernel sorts the rest out)
 __device__ __forceinline__ bool lm_evaluates(const LmDev* lm) { return lm->phase == kLmSolve && lm->flags[0] != 0 && lm->flags[2] == 0; }
-__global__ __launch_bounds__(1024) void residual_guard_lm_kernel(const LmSlot* __restrict__ slots)
-{
-    const LmSlot& S = slots[blockIdx.z];
-    if (!lm_evaluates(S.lm)) return;
-    residual_guard_kernel_body(S.Dp);
-}
 __global__ __launch_bounds__(kBlk) void oplus_lm_kernel(const LmSlot* __restrict__ slots)
 {
     const LmSlot& S = slots[blockIdx.z];
@@ -740,40 +668,12 @@ void kl_linearize(const LmSlot* sl, int nslots, int g_edges, int g_asm, hipStrea
     hipLaunchKernelGGL(linearize_lm_kernel, dim3(g_edges, 1, nslots), dim3(kBlk), 0, s, sl);
     hipLaunchKernelGGL(assemble_lm_kernel, dim3(g_asm, 1, nslots), dim3(kBlk), 0, s, sl);
 }
-void kl_residual_guard(const LmSlot* sl, int nslots, hipStream_t s)
-{
-    hipLaunchKernelGGL(residual_guard_lm_kernel, dim3(1, 1, nslots), dim3(1024), 0, s, sl);
-}
 void kl_eval(const LmSlot* sl, int nslots, int g_edges, int g_oplus, hipStream_t s)
 {
     hipLaunchKernelGGL(oplus_lm_kernel, dim3(g_oplus, 1, nslots), dim3(kBlk), 0, s, sl);
     hipLaunchKernelGGL(chi2_lm_kernel, dim3(g_edges, 1, nslots), dim3(kBlk), 0, s, sl);
 }
 
-void kb_linearize(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_asm, double delta, hipStream_t s)
-{
-    hipLaunchKernelGGL(linearize_batch_kernel, dim3(g_edges, 1, nb_), dim3(kBlk), 0, s, sl, dy, delta);
-    hipLaunchKernelGGL(assemble_batch_kernel, dim3(g_asm, 1, nb_), dim3(kBlk), 0, s, sl, dy);
-    hipLaunchKernelGGL(finalize_batch_kernel, dim3(1, 1, nb_), dim3(kBlk), 0, s, sl, dy, 2);
-}
-void kb_eval(const BatchSlot* sl, const BatchDyn* dy, int nb_, int g_edges, int g_oplus, double delta, hipStream_t s)
-{
-    hipLaunchKernelGGL(oplus_batch_kernel, dim3(g_oplus, 1, nb_), dim3(kBlk), 0, s, sl, dy);
-    hipLaunchKernelGGL(chi2_batch_kernel, dim3(g_edges, 1, nb_), dim3(kBlk), 0, s, sl, dy, delta);
-    hipLaunchKernelGGL(finalize_batch_kernel, dim3(1, 1, nb_), dim3(kBlk), 0, s, sl, dy, 1);
-}
-void kb_residual_guard(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s)
-{
-    hipLaunchKernelGGL(residual_guard_batch_kernel, dim3(1, 1, nb_), dim3(1024), 0, s, sl, dy);
-}
-void kb_set_lambda(const BatchSlot* sl, const BatchDyn* dy, int nb_, hipStream_t s)
-{
-    hipLaunchKernelGGL(set_lambda_batch_kernel, dim3((nb_ + kBlk - 1) / kBlk), dim3(kBlk), 0, s, sl, dy, nb_);
-}
-void kb_publish(const BatchSlot* sl, int nb_, PgoHostScal* out_dev, uint32_t seq, hipStream_t s)
-{
-    hipLaunchKernelGGL(publish_batch_kernel, dim3(1), dim3(64), 0, s, sl, nb_, out_dev, seq);
-}
 int g_edges_for(int e) { return grid_for(e, kBlk, kMaxPartials); }
 int g_asm_for(int nb) { return grid_for(nb, kBlk / 6, kMaxPartials); }
 int g_oplus_for(int n) { return grid_for(n, kBlk, kMaxPartials); }

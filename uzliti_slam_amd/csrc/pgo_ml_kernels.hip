@@ -2195,193 +2195,6 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
     return hipSuccess;
 }
 
-// ------------------------------------------------------------------------------------------------
-// batched twins (uzl_pgo_batch_*): graph = blockIdx.z; see pgo_types.hpp (BatchSlot / BatchDyn)
-// ------------------------------------------------------------------------------------------------
-// set-up kernels run in two passes per round: pass 0 = (re)build into BatchDyn::build_ix (numeric part and / or trial part, lambda
-// from scal2 when the rebuild runs ahead of the trial loop), pass 1 = trial part on the copy the PCG applies (lambda from scal)
-#define UZL_BATCH_SETUP(PHASE0, PHASE1)                                                  \
-    const BatchSlot& S = slots[blockIdx.z];                                              \
-    const BatchDyn dy = dyn[blockIdx.z];                                                 \
-    if (!(dy.mask & (pass == 0 ? (PHASE0) : (PHASE1)))) return;                          \
-    const int c = pass == 0 ? dy.build_ix : dy.ix;                                       \
-    PgoDev D = S.D;                                                                      \
-    if (pass == 0 && dy.build_scal2) D.scal = S.scal2;
-
-__global__ __launch_bounds__(kBlk) void ml_geometry_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int l)
-{
-    const int pass = 0;
-    UZL_BATCH_SETUP(kPhNumeric, 0)
-    ml_geometry_kernel_body(D, S.dml[c], S.pose[dy.cur], l);
-}
-__global__ __launch_bounds__(kBlk) void ml_transform_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int f)
-{
-    const int pass = 0;
-    UZL_BATCH_SETUP(kPhNumeric, 0)
-    ml_transform_kernel_body(D, S.dml[c], f);
-}
-__global__ __launch_bounds__(kBlk) void ml_reduce_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int l)
-{
-    const int pass = 0;
-    UZL_BATCH_SETUP(kPhNumeric, 0)
-    (void)D;
-    ml_reduce_kernel_body(S.dml[c], l);
-}
-__global__ __launch_bounds__(kSibBlk) void ml_sibling_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    ml_sibling_kernel_body(D, S.dml[c]);
-}
-__global__ __launch_bounds__(kBlk) void ml_top_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    ml_top_kernel_body(D, S.dml[c]);
-}
-__global__ __launch_bounds__(kBlk) void ml_mult_ap_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    ml_mult_ap_kernel_body(D, S.dml[c], lev);
-}
-__global__ __launch_bounds__(kBlk) void ml_mult_as_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    ml_mult_as_kernel_body(D, S.dml[c], lev);
-}
-__global__ __launch_bounds__(kBlk) void ml_mult_q_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    (void)D;
-    ml_mult_q_kernel_body(S.dml[c], lev);
-}
-__global__ __launch_bounds__(kBlk) void ml_mult_qy_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    (void)D;
-    ml_mult_qy_kernel_body(S.dml[c], lev);
-}
-__global__ __launch_bounds__(64) void ml_mult_final_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    (void)D;
-    ml_mult_final_kernel_body(S.dml[c], lev);
-}
-__global__ __launch_bounds__(256) void ml_mult_qyqt_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    (void)D;
-    ml_mult_qyqt_kernel_body(S.dml[c], lev);
-}
-// Newton-Schulz step k at level lev: X ping-pongs between Ydense[lev] and nsX, starting in Ydense[lev]
-__global__ __launch_bounds__(kBlk) void ml_ns_ax_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev, int k)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
-    ml_ns_ax_kernel_body(D, S.dml[c], lev, X, S.nsT[c]);
-}
-__global__ __launch_bounds__(256) void ml_ns_gemm_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int lev, int k, int n6)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    (void)D;
-    const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
-    double* Xn = (k & 1) ? S.dense[c][lev] : S.nsX[c];
-    ml_ns_gemm_kernel_body(n6, X, S.nsT[c], Xn);
-}
-__global__ __launch_bounds__(kBlk) void ml_cmat32_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int pass, int n6)
-{
-    UZL_BATCH_SETUP(kPhTrialBuild, kPhTrialCur)
-    (void)D;
-    const MlHot& H = S.hot[c];
-    ml_cmat32_body(H.Cmat, const_cast<float*>(H.Cmat32), n6, H.c32_stride);
-}
-__global__ __launch_bounds__(kCgBlk) void ml_init_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn)
-{
-    const BatchSlot& S = slots[blockIdx.z];
-    const BatchDyn dy = dyn[blockIdx.z];
-    if (!(dy.mask & kPhInit)) return;
-    ml_init_kernel_body<1>(S.D, S.hot[dy.ix], S.pbuf[0], S.pbuf[1], S.rg[dy.ix][0]);
-}
-// PCG iteration i of a replay (parity = i & 1): p_old = pbuf[parity], p_new = pbuf[parity ^ 1].  Four rows per wave, two waves per
-// level-1 aggregate (see ml_spmv_kernel_body): with B graphs in flight the kernel is bound by the bytes it keeps in flight, not by the
-// length of one wave's chain - the same body as the single solve's kernel, the same bits.
-__global__ __launch_bounds__(64 * kSpmvBatchWaves) __attribute__((amdgpu_waves_per_eu(3))) void ml_spmv_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int parity, double tol2)
-{
-    const BatchSlot& S = slots[blockIdx.z];
-    const BatchDyn dy = dyn[blockIdx.z];
-    if (!(dy.mask & kPhSolve)) return;
-    ml_spmv_kernel_body<1, kSpmvBatchRpw, kSpmvBatchWaves>(S.D, S.hot[dy.ix], S.pbuf[parity], S.pbuf[parity ^ 1], S.g_rows, tol2);
-}
-template <int kCompU>
-__global__ __launch_bounds__(kCgBlk) void ml_cg_comp_batch_kernel(const BatchSlot* __restrict__ slots, const BatchDyn* __restrict__ dyn, int parity, int init)
-{
-    const BatchSlot& S = slots[blockIdx.z];
-    const BatchDyn dy = dyn[blockIdx.z];
-    if (!(dy.mask & (init ? kPhInit : kPhSolve))) return;
-    if (init) ml_cg_comp_kernel_body<kCompU, true>(S.D, S.hot[dy.ix], S.pbuf[0], S.rg[dy.ix][0], S.rg[dy.ix][1], 0, 1);
-    else ml_cg_comp_kernel_body<kCompU, true>(S.D, S.hot[dy.ix], S.pbuf[parity ^ 1], S.rg[dy.ix][parity ^ 1], S.rg[dy.ix][parity], S.g_rows, 0);
-}
-
-// numeric part of a rebuild (geometry, Galerkin products level by level) for every graph with kPhNumeric
-void kb_ml_numeric(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int levels, const int* n_lv, const int* max_work_t, const int* max_work_r, hipStream_t s)
-{
-    for (int l = 1; l <= levels; l++)
-        hipLaunchKernelGGL(ml_geometry_batch_kernel, dim3((n_lv[l] + kBlk - 1) / kBlk, 1, nbatch), dim3(kBlk), 0, s, sl, dy, l);
-    for (int f = 0; f < levels; f++) {
-        if (max_work_t[f] > 0) hipLaunchKernelGGL(ml_transform_batch_kernel, dim3((max_work_t[f] + kBlk - 1) / kBlk, 1, nbatch), dim3(kBlk), 0, s, sl, dy, f);
-        const long work = (long)max_work_r[f + 1] * 36;
-        if (work > 0) hipLaunchKernelGGL(ml_reduce_batch_kernel, dim3((unsigned)((work + kBlk - 1) / kBlk), 1, nbatch), dim3(kBlk), 0, s, sl, dy, f + 1);
-    }
-}
-// lambda-dependent part (multiplicative operator, composite level cl = 1): the launch sequence of ml_setup_trial
-void kb_ml_trial(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int pass, int levels, int cl, const int* n_lv, int inner_aggs, int ns_steps,
-                 int upper_ns, hipStream_t s)
-{
-    if (inner_aggs > 0) hipLaunchKernelGGL(ml_sibling_batch_kernel, dim3(inner_aggs, 1, nbatch), dim3(kSibBlk), 0, s, sl, dy, pass);
-    hipLaunchKernelGGL(ml_top_batch_kernel, dim3(1, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass);
-    for (int l = levels - 1; l >= cl; l--) {
-        const int n1 = n_lv[l], n2 = n_lv[l + 1];
-        const int g12 = (n1 * n2 + kBlk - 1) / kBlk, g11 = (n1 * n1 + kBlk - 1) / kBlk, g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk;
-        hipLaunchKernelGGL(ml_mult_ap_batch_kernel, dim3(g12, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l);
-        hipLaunchKernelGGL(ml_mult_as_batch_kernel, dim3(g11, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l);
-        hipLaunchKernelGGL(ml_mult_q_batch_kernel, dim3(g12r, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l);
-        hipLaunchKernelGGL(ml_mult_qy_batch_kernel, dim3(g12r, 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l);
-        hipLaunchKernelGGL(ml_mult_final_batch_kernel, dim3(n2 * n2, 1, nbatch), dim3(64), 0, s, sl, dy, pass, l);
-        { const int gt = (6 * n1 + kGemmTile - 1) / kGemmTile;
-          hipLaunchKernelGGL(ml_mult_qyqt_batch_kernel, dim3(gt * (gt + 1) / 2, 1, nbatch), dim3(256), 0, s, sl, dy, pass, l); }
-        const int steps = l > cl ? upper_ns : ns_steps;
-        const int n6 = 6 * n1, gg = (n6 + kGemmTile - 1) / kGemmTile;
-        for (int k = 0; k < steps; k++) {
-            hipLaunchKernelGGL(ml_ns_ax_batch_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk, nbatch), dim3(kBlk), 0, s, sl, dy, pass, l, k);
-            hipLaunchKernelGGL(ml_ns_gemm_batch_kernel, dim3(gg * (gg + 1) / 2, 1, nbatch), dim3(256), 0, s, sl, dy, pass, l, k, n6);
-        }
-    }
-    const int n6 = 6 * n_lv[cl];
-    const long work = (long)n6 * (((n6 + 3) & ~3) >> 2);
-    hipLaunchKernelGGL(ml_cmat32_batch_kernel, dim3((unsigned)((work + kBlk - 1) / kBlk), 1, nbatch), dim3(kBlk), 0, s, sl, dy, pass, n6);
-}
-void kb_ml_init(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, hipStream_t s)
-{
-    hipLaunchKernelGGL(ml_init_batch_kernel, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy);
-    if (small) hipLaunchKernelGGL(ml_cg_comp_batch_kernel<5>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, 0, 1);
-    else hipLaunchKernelGGL(ml_cg_comp_batch_kernel<8>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, 0, 1);
-}
-// PCG iterations 2 * pairs (p0 -> p1 -> p0 ...), every graph with kPhSolve; kernels no-op for graphs whose `done` flag is set
-// ev (profiling only, may be null): 4 events per iteration - spmv start / stop, cg start / stop (dispatch timestamps)
-void kb_ml_pcg_pairs(const BatchSlot* sl, const BatchDyn* dy, int nbatch, int g_rows, bool small, int pairs, double tol2, hipStream_t s,
-                     hipEvent_t* ev)
-{
-    for (int i = 0; i < 2 * pairs; i++) {
-        if (ev) {
-            hipExtLaunchKernelGGL(ml_spmv_batch_kernel, dim3(g_rows, 1, nbatch), dim3(64 * kSpmvBatchWaves), 0, s, ev[4 * i], ev[4 * i + 1], 0, sl, dy, i & 1, tol2);
-            if (small) hipExtLaunchKernelGGL(ml_cg_comp_batch_kernel<5>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, ev[4 * i + 2], ev[4 * i + 3], 0, sl, dy, i & 1, 0);
-            else hipExtLaunchKernelGGL(ml_cg_comp_batch_kernel<8>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, ev[4 * i + 2], ev[4 * i + 3], 0, sl, dy, i & 1, 0);
-            continue;
-        }
-        hipLaunchKernelGGL(ml_spmv_batch_kernel, dim3(g_rows, 1, nbatch), dim3(64 * kSpmvBatchWaves), 0, s, sl, dy, i & 1, tol2);
-        if (small) hipLaunchKernelGGL(ml_cg_comp_batch_kernel<5>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, i & 1, 0);
-        else hipLaunchKernelGGL(ml_cg_comp_batch_kernel<8>, dim3(g_rows, 1, nbatch), dim3(kCgBlk), 0, s, sl, dy, i & 1, 0);
-    }
-}
-bool ml_comp_small(int n1) { return 6 * n1 <= 5 * kCgBlk; }
 
 // ------------------------------------------------------------------------------------------------
 // slot twins of the device-resident LM loop (pgo_types.hpp: LmSlot / LmDev; uzl_pgo_lm.hip): graph = blockIdx.z, arguments from its
@@ -2454,29 +2267,34 @@ __global__ __launch_bounds__(256) void ml_mult_qyqt_lm_kernel(const LmSlot* __re
 {
     UZL_LM_SETUP(false)
     (void)D;
+    { const int gt = (6 * S.hot[0].n[lev] + kGemmTile - 1) / kGemmTile; if ((int)blockIdx.x >= gt * (gt + 1) / 2) return; }      // (a batch launches the largest graph's grid)
     ml_mult_qyqt_kernel_body(S.dml[c], lev);
 }
 // Newton-Schulz step k at level lev: X ping-pongs between Ydense[lev] and nsX, starting in Ydense[lev]
 __global__ __launch_bounds__(kBlk) void ml_ns_ax_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k)
 {
     UZL_LM_SETUP(false)
+    if ((int)blockIdx.x >= S.hot[0].n[lev]) return;
     const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
     ml_ns_ax_kernel_body(D, S.dml[c], lev, X, S.nsT[c]);
 }
-__global__ __launch_bounds__(256) void ml_ns_gemm_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k, int n6)
+__global__ __launch_bounds__(256) void ml_ns_gemm_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k)
 {
     UZL_LM_SETUP(false)
     (void)D;
+    const int n6 = 6 * S.hot[0].n[lev];
+    { const int gt = (n6 + kGemmTile - 1) / kGemmTile; if ((int)blockIdx.x >= gt * (gt + 1) / 2) return; }
     const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
     double* Xn = (k & 1) ? S.dense[c][lev] : S.nsX[c];
     ml_ns_gemm_kernel_body(n6, X, S.nsT[c], Xn);
 }
-__global__ __launch_bounds__(kBlk) void ml_cmat32_lm_kernel(const LmSlot* __restrict__ slots, int which, int n6)
+__global__ __launch_bounds__(kBlk) void ml_cmat32_lm_kernel(const LmSlot* __restrict__ slots, int which, int cl)
 {
     UZL_LM_SETUP(false)
     (void)D;
     const MlHot& H = S.hot[c];
     if (!H.Cmat || !H.Cmat32) return;
+    const int n6 = 6 * H.n[cl];
     ml_cmat32_body(H.Cmat, const_cast<float*>(H.Cmat32), n6, H.c32_stride);
 }
 
@@ -2504,7 +2322,7 @@ void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
     if (!sh.mult) {                                                            // additive operator: Y_l = blockdiag(W_l^-1) + P Y_{l+1} P^T
         for (int l = L - 1; l >= cl; l--)
             hipLaunchKernelGGL(ml_dense_level_lm_kernel, dim3((sh.n_lv[l] * sh.n_lv[l] + kBlk - 1) / kBlk, 1, B), dim3(kBlk), 0, s, sl, which, l);
-        hipLaunchKernelGGL(ml_cmat32_lm_kernel, dim3((unsigned)((work32 + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, n6c);
+        hipLaunchKernelGGL(ml_cmat32_lm_kernel, dim3((unsigned)((work32 + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, cl);
         return;
     }
     for (int l = L - 1; l >= cl; l--) {                                        // multiplicative cycle + Newton-Schulz, from the top down
@@ -2519,10 +2337,10 @@ void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
         const int steps = l > cl ? sh.upper_ns : sh.ns_steps;
         for (int k = 0; k < steps; k++) {
             hipLaunchKernelGGL(ml_ns_ax_lm_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk, B), dim3(kBlk), 0, s, sl, which, l, k);
-            hipLaunchKernelGGL(ml_ns_gemm_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l, k, n6);
+            hipLaunchKernelGGL(ml_ns_gemm_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l, k);
         }
     }
-    hipLaunchKernelGGL(ml_cmat32_lm_kernel, dim3((unsigned)((work32 + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, n6c);
+    hipLaunchKernelGGL(ml_cmat32_lm_kernel, dim3((unsigned)((work32 + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, cl);
 }
 
 // ---- PCG: init + the two iteration kernels.  SLOT = `const LmSlot*` (blockIdx.z picks the graph) or `LmSlot` BY VALUE for a pass of
@@ -2553,7 +2371,7 @@ __global__ __launch_bounds__(kCgBlk) void ml_init_lm_kernel(const SLOT slots)
 {
     const LmSlot& S = slot_of(slots);
     const LmDev* lm = S.lm;
-    if (lm->phase != kLmSolve || lm->init_pass != lm->pass) return;
+    if (lm->phase != kLmSolve || lm->init_pass != lm->pass || (int)blockIdx.x >= S.g_rows) return;
     ml_init_kernel_body<AGG>(S.Dp, hot_of(S, lm->ix), S.pbuf[0], S.pbuf[1], rg_of(S, lm->ix, 0));
 }
 // PCG iteration i of a replay (parity = i & 1): p_old = pbuf[parity], p_new = pbuf[parity ^ 1]; a no-op once flags[0] is set
@@ -2569,6 +2387,7 @@ template <int kCompU, bool kLds, class SLOT>
 __global__ __launch_bounds__(kCgBlk) void ml_cg_comp_lm_kernel(const SLOT slots, int parity, int init)
 {
     const LmSlot& S = slot_of(slots);
+    if ((int)blockIdx.x >= S.g_rows) return;                 // (a batch launches the largest graph's grid)
     const LmDev* lm = S.lm;
     const int ix = lm->ix;
     if (init) {
@@ -2580,6 +2399,7 @@ template <int AGG, bool COMP, bool YPRE, bool VPRE, class SLOT>
 __global__ __launch_bounds__(kCgBlk) __attribute__((amdgpu_waves_per_eu(COMP ? (YPRE ? 2 : 3) : 1))) void ml_cg_lm_kernel(const SLOT slots, int parity, int init)
 {
     const LmSlot& S = slot_of(slots);
+    if ((int)blockIdx.x >= S.g_rows) return;
     const LmDev* lm = S.lm;
     const int ix = lm->ix;
     if (init) {
@@ -2613,15 +2433,17 @@ static hipError_t lm_cg_lds(const void* fn, int variant_ix, size_t lds)
 }
 
 // the ml_cg launch of iteration parity `parity` (init = 1: first application) for the shape's variant; SLOT as above
+// (ev_a / ev_b, profiling only: the dispatch's own start / stop timestamps - the throughput-geometry variants a batch runs)
 template <class SLOT>
-static hipError_t kl_ml_cg_t(SLOT sl, const LmShape& sh, int parity, int init, hipStream_t s)
+static hipError_t kl_ml_cg_t(SLOT sl, const LmShape& sh, int parity, int init, hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr)
 {
     constexpr bool kPtr = std::is_pointer<SLOT>::value;
     const dim3 g(sh.g_rows, 1, sh.nslots), t(kCgBlk);
     size_t lds = (size_t)sh.cg_lds;
     switch (sh.cg_variant) {
     case kCgComp1:
-#define UZL_LM_COMP(U, LDS) hipLaunchKernelGGL((ml_cg_comp_lm_kernel<U, LDS, SLOT>), g, t, 0, s, sl, parity, init)
+#define UZL_LM_COMP(U, LDS) do { if (ev_a) hipExtLaunchKernelGGL((ml_cg_comp_lm_kernel<U, LDS, SLOT>), g, t, 0, s, ev_a, ev_b, 0, sl, parity, init); \
+                                 else hipLaunchKernelGGL((ml_cg_comp_lm_kernel<U, LDS, SLOT>), g, t, 0, s, sl, parity, init); } while (0)
         if (sh.batch_geometry) { if (sh.comp_u <= 5) UZL_LM_COMP(5, true); else UZL_LM_COMP(8, true); }
         else if (sh.comp_u <= 5) UZL_LM_COMP(5, false);
         else if (sh.comp_u <= 8) UZL_LM_COMP(8, false);
@@ -2660,9 +2482,10 @@ static hipError_t kl_ml_cg_t(SLOT sl, const LmShape& sh, int parity, int init, h
     return hipErrorInvalidValue;
 }
 template <class SLOT>
-static void kl_ml_spmv_t(SLOT sl, const LmShape& sh, int parity, hipStream_t s)
+static void kl_ml_spmv_t(SLOT sl, const LmShape& sh, int parity, hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr)
 {
-    if (sh.batch_geometry) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, kSpmvBatchRpw, kSpmvBatchWaves, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvBatchWaves), 0, s, sl, parity);
+    if (sh.batch_geometry && ev_a) hipExtLaunchKernelGGL((ml_spmv_lm_kernel<1, kSpmvBatchRpw, kSpmvBatchWaves, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvBatchWaves), 0, s, ev_a, ev_b, 0, sl, parity);
+    else if (sh.batch_geometry) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, kSpmvBatchRpw, kSpmvBatchWaves, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvBatchWaves), 0, s, sl, parity);
     else if (sh.agg == 1) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, 1, 8, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(512), 0, s, sl, parity);
     else hipLaunchKernelGGL((ml_spmv_lm_kernel<4, 4, kSpmvWaves4, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvWaves4), 0, s, sl, parity);
 }
@@ -2697,13 +2520,15 @@ hipError_t kl_ml_init(const LmSlot* sl, const LmSlot* host_slot, const LmShape& 
     if (host_slot && sh.nslots == 1) return kl_ml_init_t<LmSlot>(*host_slot, sh, s);
     return kl_ml_init_t<const LmSlot*>(sl, sh, s);
 }
-// PCG iterations 2 * pairs (p0 -> p1 -> p0 ...)
-hipError_t kl_ml_pcg_pairs(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, int pairs, hipStream_t s)
+// PCG iterations 2 * pairs (p0 -> p1 -> p0 ...).  ev (profiling only, may be null): 4 events per iteration - spmv start / stop, cg
+// start / stop (dispatch timestamps; the batch's kernels)
+hipError_t kl_ml_pcg_pairs(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, int pairs, hipStream_t s, hipEvent_t* ev)
 {
-    const bool by_value = host_slot && sh.nslots == 1;
+    const bool by_value = host_slot && sh.nslots == 1 && !ev;
     for (int i = 0; i < 2 * pairs; i++) {
         hipError_t e;
-        if (by_value) { kl_ml_spmv_t<LmSlot>(*host_slot, sh, i & 1, s); e = kl_ml_cg_t<LmSlot>(*host_slot, sh, i & 1, 0, s); }
+        if (ev) { kl_ml_spmv_t<const LmSlot*>(sl, sh, i & 1, s, ev[4 * i], ev[4 * i + 1]); e = kl_ml_cg_t<const LmSlot*>(sl, sh, i & 1, 0, s, ev[4 * i + 2], ev[4 * i + 3]); }
+        else if (by_value) { kl_ml_spmv_t<LmSlot>(*host_slot, sh, i & 1, s); e = kl_ml_cg_t<LmSlot>(*host_slot, sh, i & 1, 0, s); }
         else { kl_ml_spmv_t<const LmSlot*>(sl, sh, i & 1, s); e = kl_ml_cg_t<const LmSlot*>(sl, sh, i & 1, 0, s); }
         if (e != hipSuccess) return e;
     }

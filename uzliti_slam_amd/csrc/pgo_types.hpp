@@ -140,38 +140,7 @@ struct MlHot {
     double* Vg;                            // [6 n_2] gather-level residual estimate rg - alpha Sg prepared by ml_alpha_kernel (graphs of 12k .. 21.8k vertices)
 };
 
-// ---- batched solve: B graphs of identical hierarchy shape advance through one launch sequence (uzl_pgo_batch_*) ----------------
-// Every batched kernel is the single-graph kernel's body, instantiated a second time with its arguments taken from slot
-// blockIdx.z instead of the kernel-argument segment: same arithmetic, same order, bit-identical results.  The host's scalar
-// decisions (which graphs linearise, rebuild, take another trial) reach the kernels as a phase mask per graph.
-constexpr int kBatchMax = 256;
-enum BatchPhase : int32_t { kPhLin = 1, kPhNumeric = 2, kPhTrialBuild = 4, kPhTrialCur = 8, kPhSolve = 16, kPhEval = 32, kPhLambda = 64,
-                            kPhInit = 128 /* x = 0, r = b, first preconditioner application: graphs that START a solve this pass */ };
-struct BatchSlot {
-    PgoDev D;                                  // pose / pose_trial unused: the pose buffers are picked through BatchDyn::cur
-    MlHot hot[2];                              // hot subset of the two hierarchy copies
-    const MlDev* dml[2];
-    double* rg[2][2];                          // per copy: double-buffered gather-level residual
-    double* dense[2][kMlMaxLevels + 1];        // per copy: Ydense[l]
-    double* nsT[2];
-    double* nsX[2];
-    double* pbuf[2];                           // PCG direction, ping-pong
-    double* pose[2];
-    double* scal2;                             // [8] lambda slot ([3]) of a rebuild that runs ahead of the trial loop
-    int32_t g_edges, g_asm, g_oplus, g_rows;   // grids (= partial counts) of the single-graph launches
-};
-struct BatchDyn {                              // host -> device once per round
-    double  lambda;                            // kPhLambda: lambda of this round's trial (-> D.scal[3])
-    double  lambda_build;                      // lambda of a rebuild into build_ix (-> scal2[3]) when build_scal2
-    int32_t mask;                              // BatchPhase bits
-    int32_t cur;                               // pose buffer holding the current estimate
-    int32_t ix;                                // hierarchy copy the PCG applies
-    int32_t build_ix;                          // copy the kPhNumeric / kPhTrialBuild set-up kernels write
-    int32_t build_scal2;                       // 1: those kernels read lambda from scal2
-    int32_t pad;
-    double  tol_factor2;                       // kPhLambda: factor on pcg_tol^2 of this round's solve (-> D.scal[8])
-    double  eps_t, eps_r;                      // kPhLambda: step accuracy asked of this round's solve (-> D.scal[12], D.scal[13])
-};
+constexpr int kBatchMax = 256;      // graphs per uzl_pgo_batch
 
 // ---- Schur reduction of chain interiors: device view (recurrences and host-side plan in pgo_schur.hpp) ----------------------------
 constexpr int kSchurElim = 78;        // doubles kept per eliminated vertex: u (6) | W (36) | T (36)

@@ -858,7 +858,7 @@ int pcg_solve(uzl_pgo* h, bool* converged)
 }  // namespace
 namespace uzl {
 // optimizeImpl's front part (initializeOptimization :139, setFixedNodes :144-146): the structure, cached until the next add_graph / set_graph
-static void prepare_optimize(uzl_pgo* h)
+void prepare_optimize(uzl_pgo* h)
 {
     h->t_start = std::chrono::steady_clock::now();
     h->structure_ms = 0.; h->exchange_ms = 0.; h->exchange_calls = 0;
@@ -1467,13 +1467,13 @@ int uzl_pgo_set_shard_rccl(uzl_pgo* h, int32_t rank, int32_t world_size, const v
 //
 //  One config-2-sized graph leaves the chip ~97 % idle (125 workgroups per launch, two dependent launches per PCG iteration);
 //  several handles on several streams do not recover it (tests/diag/multi_handle.py: 4 handles 1.9x, 16 handles 1.5x - the
-//  launches serialise).  Here every kernel of the solve is launched once for all graphs (blockIdx.z = graph, arguments from a slot
-//  array, per-graph phase mask), so a PCG iteration of B graphs costs two launches, like one graph's.  The kernels are the
-//  single-graph kernels' bodies; the host below replays do_optimize's scalar logic per graph, in lock step, one LM trial per
-//  round: every graph's poses, chi2 and iteration counts are bit-identical to a uzl_pgo_optimize of that graph alone.
-//  Batched together are graphs of the "small graph" class (<= 2048 free vertices: dense level-1 operator) with identical
-//  hierarchy shape; anything else - and any graph that meets an anomaly (PCG not converged, breakdown) - is solved by the
-//  single-graph path, so results never depend on whether a graph was batched.
+//  launches serialise).  Here every kernel of the solve is launched once for all graphs (blockIdx.z = slot, arguments from a slot
+//  table, each graph's Levenberg-Marquardt state on the device: uzl_pgo_lm.hip), so a PCG iteration of B graphs costs two launches,
+//  like one graph's.  The kernels are the single-graph kernels' bodies and every graph's loop takes its own decisions from its own
+//  state: poses, chi2 and iteration counts are bit-identical to a uzl_pgo_optimize of that graph alone.  Batched together are
+//  graphs of the small-graph class (dense level-1 operator) with one hierarchy shape of the system the PCG solves - full or
+//  Schur-reduced: chain-like graphs batch on their reduced systems; anything else - and any graph that meets an anomaly (PCG not
+//  converged, breakdown) - is solved by the single-graph path, so results never depend on whether a graph was batched.
 // =====================================================================================================================
 struct uzl_pgo_batch {
     std::mutex mu;
@@ -1482,97 +1482,15 @@ struct uzl_pgo_batch {
     std::vector<uzl_pgo*> h;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // rebuilds that run ahead (into the hierarchy copy the PCG does not use), beside this iteration's solves
-    hipEvent_t ev_lin = nullptr, ev_build = nullptr;
-    bool build_pending = false;
-    DevBuf<BatchSlot> d_slots;
-    DevBuf<BatchDyn> d_dyn;
-    DevBuf<BatchDyn> d_dyn2;              // the phase table the kernels on stream2 read
-    PinBuf<BatchDyn> h_dyn;               // ring of staging copies (kDynRing x B)
-    int ring = 0;
-    PinBuf<PgoHostScal> h_pub;            // B entries + one for the sequence word
-    PgoHostScal* d_pub = nullptr;
-    uint32_t pub_seq = 0;
-    DevBuf<double> d_start;               // poses at the start of the solve (anomaly fallback)
-    std::vector<BatchSlot> slot_host;     // host copies of the resident slots (source of the refill copies)
     int32_t resident = 0;                 // graphs solved at a time (0 = all): uzl_pgo_batch_set_resident
-    int graph_rows = 0, graph_nb = 0, replay_nb = 1;      // grid the captured replay was built for / largest system of this optimize
-    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;          // 2 x kGraphPairs PCG iterations of every resident graph
-    hipGraph_t graph_s = nullptr; hipGraphExec_t graph_exec_s = nullptr;      // 2 x kShortPairs (ensure_pcg_graph)
     int32_t last_batched = 0;
+    uzl::LmRun* lm = nullptr;             // slot table, LM states, captured segments (uzl_pgo_lm.hip)
     KernelTimer timer;                    // profiling (uzl_pgo_batch_set_profiling): the two PCG kernels, launched eagerly with event pairs
 };
 
 namespace {
-constexpr int kDynRing = 16;
 
 int bfail(uzl_pgo_batch* b, int code, const char* msg) { b->last_error = msg; return code; }
-
-void batch_destroy_graph(uzl_pgo_batch* b)
-{
-    if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
-    if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
-    if (b->graph_exec_s) { (void)hipGraphExecDestroy(b->graph_exec_s); b->graph_exec_s = nullptr; }
-    if (b->graph_s) { (void)hipGraphDestroy(b->graph_s); b->graph_s = nullptr; }
-}
-
-// per-graph state of the Levenberg-Marquardt loop: the locals of do_optimize
-struct BatchLM {
-    int it = 0, qmax = 0;
-    double lambda = 0., ni = 2., current_chi = 0., last_rel = 1e300;
-    int pcg_last = 0;
-    double rate_ref = -1., rate_last = -1.;
-    int ml_ix = 0, cur = 0;
-    bool pending = false, adopted = false, trial_setup = false, need_lin = true, finished = false, anomaly = false, fresh = false;
-    double lambda_setup[2] = {0., 0.};
-    double tol_f2 = 1.;
-    uzl_pgo_stats S;
-};
-
-void batch_upload_dyn(uzl_pgo_batch* b, const std::vector<BatchDyn>& dyn)
-{
-    const size_t B = dyn.size();
-    BatchDyn* stage = b->h_dyn.p + (size_t)(b->ring++ % kDynRing) * B;
-    memcpy(stage, dyn.data(), sizeof(BatchDyn) * B);
-    UZL_HIP(hipMemcpyAsync(b->d_dyn.p, stage, sizeof(BatchDyn) * B, hipMemcpyHostToDevice, b->stream));
-}
-
-void batch_fetch(uzl_pgo_batch* b)
-{
-    const int B = (int)b->slot_host.size();          // resident slots
-    const uint32_t seq = ++b->pub_seq;
-    kb_publish(b->d_slots.p, B, b->d_pub, seq, b->stream);
-    const auto t0 = std::chrono::steady_clock::now();
-    bool seen = false;
-    for (int spin = 0; !seen; spin++) {
-        seen = __atomic_load_n(&b->h_pub.p[B].seq, __ATOMIC_ACQUIRE) == seq;
-        if (!seen && (spin & 1023) == 1023 &&
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 200.0) break;
-    }
-    if (!seen) {
-        UZL_HIP(hipStreamSynchronize(b->stream));
-        if (__atomic_load_n(&b->h_pub.p[B].seq, __ATOMIC_ACQUIRE) != seq) throw HipError{hipErrorUnknown, "publish_batch_kernel did not run", __FILE__, __LINE__};
-    }
-    b->ring = 0;       // everything enqueued before the publish has executed: the staging ring is free again
-}
-
-// one replay of the batch = 2 x pairs PCG iterations of every graph (the stop test is part of the iteration kernels)
-void batch_pcg_replay(uzl_pgo_batch* b, int B, int g_rows, bool small, int pairs, double tol2, hipStream_t s, hipEvent_t* ev)
-{
-    kb_ml_pcg_pairs(b->d_slots.p, b->d_dyn.p, B, g_rows, small, pairs, tol2, s, ev);
-}
-
-bool batch_eligible(const uzl_pgo_batch* b)
-{
-    const uzl_pgo* a = b->h[0];
-    for (const uzl_pgo* h : b->h) {
-        if (!(h->ml_levels > 0 && h->ml_agg == 1 && h->ml_comp && h->ml_mult && h->ml_cl == 1 && 6 * h->ml_n[1] <= 1536 && !h->sharded && !h->red.on && h->nb > 0 && h->e > 0 &&
-              !h->timer.on && h->stream2 != nullptr)) return false;
-        // same shape from level 1 up (the level-0 size may differ by the few vertices the gauge / skip rules remove: only grids depend on it)
-        if (h->ml_n.size() != a->ml_n.size() || !std::equal(h->ml_n.begin() + 1, h->ml_n.end(), a->ml_n.begin() + 1) ||
-            h->ml_ns_steps != a->ml_ns_steps || h->ml_levels != a->ml_levels || h->cfg.device != a->cfg.device) return false;
-    }
-    return (int)b->h.size() <= kBatchMax;
-}
 
 int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, int32_t* n_batched)
 {
@@ -1580,391 +1498,35 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
     if (n_batched) *n_batched = 0;
     for (uzl_pgo* h : b->h) if (!h->have_graph) return bfail(b, UZL_ERR_STATE, "optimize before every graph of the batch has been set");
     UZL_HIP(hipSetDevice(b->cfg.device));
-    const auto t0 = std::chrono::steady_clock::now();
     // per graph: optimizeImpl's initializeOptimization + setFixedNodes (:139-146), structure
-    std::vector<double> structure_ms((size_t)B, 0.);
-    std::vector<int32_t> reused((size_t)B, 0);
     for (int g = 0; g < B; g++) {
         uzl_pgo* h = b->h[g];
         if (iterations <= 0) iterations = h->cfg.iterations;
-        reused[g] = h->structure_ready ? 1 : 0;
-        if (!h->structure_ready) {
-            const auto ts = std::chrono::steady_clock::now();
-            h->fixed_eff = h->fixed_in;
-            h->n_gauge = gauge_fix(h);
-            build_structure(h);
-            structure_ms[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
-        }
+        prepare_optimize(h);
         UZL_HIP(hipStreamSynchronize(h->stream));
     }
     int rc_all = UZL_OK;
-    if (!batch_eligible(b)) {            // not one class / one shape: every graph through the single-graph path
+    if (!lm_batch_eligible(b->h)) {      // not one class / one shape: every graph through the single-graph path
         if (b->cfg.verbose)
             for (const uzl_pgo* h : b->h)
-                fprintf(stderr, "[uzl_pgo_batch] not batched: levels %d agg %d comp %d mult %d cl %d sharded %d nb %d e %d timer %d no_graph %d n1 %d ns %d\n", h->ml_levels,
-                        h->ml_agg, (int)h->ml_comp, (int)h->ml_mult, h->ml_cl, (int)h->sharded, h->nb, h->e, (int)h->timer.on, (int)h->no_graph,
-                        h->ml_n.size() > 1 ? h->ml_n[1] : -1, h->ml_ns_steps);
+                fprintf(stderr, "[uzl_pgo_batch] not batched: levels %d agg %d comp %d mult %d cl %d sharded %d nb %d (pcg system %d) e %d timer %d n1 %d ns %d\n", h->ml_levels,
+                        h->ml_agg, (int)h->ml_comp, (int)h->ml_mult, h->ml_cl, (int)h->sharded, h->nb, h->Dp.nb, h->e, (int)h->timer.on, h->ml_n.size() > 1 ? h->ml_n[1] : -1, h->ml_ns_steps);
         for (int g = 0; g < B; g++) {
+            uzl_pgo* h = b->h[g];
+            h->t_start = std::chrono::steady_clock::now();
             uzl_pgo_stats S;
-            const int rc = do_optimize(b->h[g], iterations, &S);
-            if (rc != UZL_OK && rc != UZL_ERR_NOT_CONVERGED) { b->last_error = b->h[g]->last_error; return rc; }
+            const int rc = lm_eligible(h) ? do_optimize_lm(h, iterations, &S) : do_optimize_host(h, iterations, &S);
+            if (rc != UZL_OK && rc != UZL_ERR_NOT_CONVERGED) { b->last_error = h->last_error; return rc; }
             if (rc != UZL_OK) rc_all = rc;
             if (stats) stats[g] = S;
         }
         b->last_batched = 0;
         return rc_all;
     }
-    // ---- R resident slots over a queue of Q graphs: a graph that has finished hands its slot to the next one in the queue, so that
-    //      one graph which needs 29 LM trials where the others need 20 does not hold the chip for everybody (round 2's lock step)
-    const int Q = B;
-    const int R = std::max(1, std::min(b->resident > 0 ? b->resident : Q, Q));
-    hipStream_t s = b->stream;
-    const uzl_pgo* h0 = b->h[0];
-    const int L = h0->ml_levels, cl = h0->ml_cl, g_rows = g_ml_rows(h0->nb, 1);
-    const bool small = ml_comp_small(h0->ml_n[1]);
-    const double delta = b->cfg.huber_delta, tol2 = b->cfg.pcg_tol * b->cfg.pcg_tol;
-    int max_g_edges = 1, max_g_asm = 1, max_g_oplus = 1, max_inner = 0, max_nb = 1, max_rows = g_rows;
-    std::vector<int> n_lv((size_t)L + 2, 0), max_wt((size_t)L + 2, 0), max_wr((size_t)L + 2, 0);
-    for (int l = 0; l <= L; l++) n_lv[l] = h0->ml_n[l];
-    for (const uzl_pgo* h : b->h) {
-        max_g_edges = std::max(max_g_edges, g_edges_for(h->e)); max_g_asm = std::max(max_g_asm, g_asm_for(h->nb));
-        max_g_oplus = std::max(max_g_oplus, g_oplus_for(h->n)); max_inner = std::max(max_inner, h->ml_inner_aggs);
-        max_nb = std::max(max_nb, h->nb); max_rows = std::max(max_rows, g_ml_rows(h->nb, 1));
-        for (int l = 0; l <= L; l++) {
-            max_wt[l] = std::max(max_wt[l], h->ml_nslots[l] + h->ml_n[l]);
-            max_wr[l] = std::max(max_wr[l], h->ml_nslots[l] + h->ml_n[l]);
-        }
-    }
-    // device tables: R slots; the captured PCG replay reads them at run time, so refilling a slot needs no new capture
-    if ((int)b->slot_host.size() != R || b->graph_rows != max_rows || b->graph_nb != max_nb) batch_destroy_graph(b);
-    b->slot_host.assign((size_t)R, BatchSlot{});
-    b->d_slots.reserve((size_t)R); b->d_dyn.reserve((size_t)R); b->d_dyn2.reserve((size_t)R);
-    b->h_dyn.reserve((size_t)R * kDynRing);
-    b->h_pub.reserve((size_t)R + 1, hipHostMallocMapped | hipHostMallocCoherent);
-    memset(b->h_pub.p, 0, sizeof(PgoHostScal) * ((size_t)R + 1));
-    UZL_HIP(hipHostGetDevicePointer((void**)&b->d_pub, b->h_pub.p, 0));
-    auto make_slot = [&](int g) {
-        uzl_pgo* h = b->h[g];
-        BatchSlot S;
-        memset(&S, 0, sizeof(S));
-        S.D = h->D;
-        for (int c = 0; c < 2; c++) {
-            S.hot[c] = h->mlb[c].hot; S.dml[c] = h->mlb[c].dml;
-            S.rg[c][0] = h->mlb[c].rg[0]; S.rg[c][1] = h->mlb[c].rg[1];
-            for (int l = 0; l <= kMlMaxLevels; l++) S.dense[c][l] = h->ml_dense_ptr[c][l];
-            S.nsT[c] = h->mlb[c].nsT; S.nsX[c] = h->mlb[c].nsX;
-        }
-        S.pbuf[0] = h->d_p.p; S.pbuf[1] = h->d_p2.p;
-        S.pose[0] = h->pose_a.p; S.pose[1] = h->pose_b.p;
-        S.scal2 = h->d_scal2.p;
-        S.g_edges = g_edges_for(h->e); S.g_asm = g_asm_for(h->nb); S.g_oplus = g_oplus_for(h->n); S.g_rows = g_ml_rows(h->nb, 1);
-        return S;
-    };
-    // start poses (anomaly fallback) and LM state of every graph of the queue
-    size_t tot_n = 0;
-    std::vector<size_t> start_off((size_t)Q, 0);
-    for (int g = 0; g < Q; g++) { start_off[g] = tot_n; tot_n += (size_t)b->h[g]->n * 8; }
-    b->d_start.reserve(std::max<size_t>(tot_n, 8));
-    std::vector<BatchLM> G((size_t)Q);
-    for (int g = 0; g < Q; g++) {
-        uzl_pgo* h = b->h[g];
-        UZL_HIP(hipMemcpyAsync(b->d_start.p + start_off[g], h->cur, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
-        memset(&G[g].S, 0, sizeof(uzl_pgo_stats));
-        G[g].S.n_vertices = h->n; G[g].S.n_edges = h->e; G[g].S.n_gauge_fixed = h->n_gauge;
-        G[g].S.structure_ms = structure_ms[g]; G[g].S.structure_reused = reused[g];
-        G[g].cur = (h->cur == h->pose_a.p) ? 0 : 1;
-        h->ml_ix = 0; h->ml_pending = false;
-    }
-    std::vector<int> slot_graph((size_t)R, -1);
-    int next_graph = 0;
-    auto load_slot = [&](int sl) {                       // the next graph of the queue into slot sl (stream-ordered behind what the slot ran)
-        if (next_graph >= Q) { slot_graph[sl] = -1; return; }
-        const int g = next_graph++;
-        slot_graph[sl] = g;
-        b->slot_host[sl] = make_slot(g);
-        UZL_HIP(hipMemcpyAsync(b->d_slots.p + sl, &b->slot_host[sl], sizeof(BatchSlot), hipMemcpyHostToDevice, s));
-    };
-    for (int sl = 0; sl < R; sl++) load_slot(sl);
-    const bool eager = h0->no_graph || b->timer.on;      // UZL_NO_GRAPH=1 (rocprofv3 --kernel-trace runs) / profiling: the replay's launches one by one
-    b->timer.reset();
-    b->replay_nb = max_nb;
-    if (!b->graph_exec && !eager) {       // the PCG replay: 2 x kGraphPairs iterations of all resident graphs
-        UZL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        batch_pcg_replay(b, R, max_rows, small, kGraphPairs, tol2, s, nullptr);
-        UZL_HIP(hipStreamEndCapture(s, &b->graph));
-        UZL_HIP(hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
-        UZL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        batch_pcg_replay(b, R, max_rows, small, kShortPairs, tol2, s, nullptr);
-        UZL_HIP(hipStreamEndCapture(s, &b->graph_s));
-        UZL_HIP(hipGraphInstantiate(&b->graph_exec_s, b->graph_s, nullptr, nullptr, 0));
-        b->graph_rows = max_rows; b->graph_nb = max_nb;
-    }
-    std::vector<BatchDyn> dyn((size_t)R);
-    auto base_dyn = [&]() {
-        for (int sl = 0; sl < R; sl++) {
-            memset(&dyn[sl], 0, sizeof(BatchDyn));
-            const int g = slot_graph[sl];
-            if (g < 0) continue;
-            dyn[sl].cur = G[g].cur; dyn[sl].ix = G[g].ml_ix; dyn[sl].build_ix = G[g].ml_ix;
-        }
-    };
-    // Every resident graph is in one of four phases; a pass of the loop serves all of them through the phase masks, so graphs that are
-    // at different LM iterations - or solving systems that need different numbers of PCG iterations - never wait for each other longer
-    // than one replay (2 x kGraphPairs iterations):
-    //   Lin    linearise (first iteration: numeric set-up, chi2, lambda_0), rebuilds that run ahead            -> Start
-    //   Start  lambda, trial set-up if due, x = 0 / r = b / first preconditioner application                   -> Solve
-    //   Solve  PCG replays until the graph's `done` flag                                                       -> Eval
-    //   Eval   retraction, chi2 of the trial, rho, accept / reject                                             -> Lin | Start | finished
-    // The order of operations each graph sees is do_optimize's: results do not depend on who shares its launches.
-    enum { PLin = 0, PStart = 1, PSolve = 2, PEval = 3 };
-    std::vector<int> phase((size_t)Q, PLin), launched_g((size_t)Q, 0);
-    auto active = [&](int sl) { return slot_graph[sl] >= 0 && !G[slot_graph[sl]].finished; };
-    int n_active = 0;
-    for (int sl = 0; sl < R; sl++) n_active += active(sl) ? 1 : 0;
-    // The resident graphs are kept IN STEP: the solve stage runs until all of them are done, so that they linearise, rebuild their
-    // preconditioners and evaluate in the same passes - a rebuild is ~25 small launches whatever the number of graphs that take part, and
-    // graphs out of step pay them in almost every pass.  A queue longer than the slots is worked off in cohorts: the slots are refilled
-    // when every resident graph is through.  Measured on 256 queued config-2 graphs: cohorts of 16 / 64 in step 54 / 68 M edges/s, slots
-    // refilled one by one as they finish (free-running, graphs at different LM iterations sharing launches through the phase masks:
-    // UZL_BATCH_FREE_RUNNING=1 in the diagnostic build) 33 / 57 M - a straggler that holds its cohort costs less than what sixteen
-    // graphs out of step pay for each other's rebuilds.
-    static const bool free_running = diag_flag("UZL_BATCH_FREE_RUNNING");
-    const bool in_step = (R == Q) || !free_running;
-    while (n_active > 0) {
-        // ---- Lin: linearise the graphs that start a new LM iteration; first iteration: numeric set-up, chi2 and lambda_0
-        base_dyn();
-        bool any_lin = false, any_it0 = false;
-        for (int sl = 0; sl < R; sl++) {
-            if (!active(sl) || phase[slot_graph[sl]] != PLin) continue;
-            BatchLM& X = G[slot_graph[sl]];
-            X.adopted = false;
-            if (X.pending) { X.ml_ix ^= 1; X.pending = false; X.adopted = true; }
-            dyn[sl].ix = X.ml_ix; dyn[sl].build_ix = X.ml_ix;
-            dyn[sl].mask |= kPhLin;
-            any_lin = true;
-            if (X.it == 0) { dyn[sl].mask |= kPhNumeric; any_it0 = true; }
-        }
-        if (any_lin) {
-            std::vector<uint8_t> ahead((size_t)R, 0);
-            if (b->build_pending) {                           // the rebuild started at the last linearisation still reads H and the poses
-                UZL_HIP(hipStreamWaitEvent(s, b->ev_build, 0));
-                b->build_pending = false;
-            }
-            batch_upload_dyn(b, dyn);
-            kb_linearize(b->d_slots.p, b->d_dyn.p, R, max_g_edges, max_g_asm, delta, s);
-            for (int sl = 0; sl < R; sl++) {
-                if (!(dyn[sl].mask & kPhLin)) continue;
-                BatchLM& X = G[slot_graph[sl]];
-                // (a rebuild runs ahead for the NEXT iteration: none in the last one)
-                const bool refresh = lm_refresh(X.it, iterations, always_refresh, false, X.last_rel, refresh_rel, X.rate_ref, X.rate_last);
-                if (refresh) {
-                    X.S.precond_builds++;
-                    if (X.it == 0) X.trial_setup = true; else ahead[sl] = 1;          // (never in the last iteration: see `refresh`)
-                }
-                phase[slot_graph[sl]] = PStart;
-            }
-            if (any_it0) {
-                kb_ml_numeric(b->d_slots.p, b->d_dyn.p, R, L, n_lv.data(), max_wt.data(), max_wr.data(), s);
-                batch_fetch(b);
-                for (int sl = 0; sl < R; sl++) {
-                    if (!(dyn[sl].mask & kPhLin)) continue;
-                    BatchLM& X = G[slot_graph[sl]];
-                    if (X.it != 0) continue;
-                    X.current_chi = b->h_pub.p[sl].scal[4];
-                    X.S.chi2_initial = X.current_chi;
-                    X.lambda = 1e-5 * b->h_pub.p[sl].scal[6];                        // computeLambdaInit: tau * max diag
-                    X.ni = 2.;
-                }
-            }
-            // rebuilds that run ahead: into the copy the PCG does not use, with this iteration's lambda; adopted next iteration
-            bool any_ahead = false;
-            base_dyn();
-            for (int sl = 0; sl < R; sl++) {
-                if (!ahead[sl]) continue;
-                BatchLM& X = G[slot_graph[sl]];
-                dyn[sl].mask = kPhNumeric | kPhTrialBuild; dyn[sl].build_ix = X.ml_ix ^ 1; dyn[sl].build_scal2 = 1; dyn[sl].lambda_build = X.lambda;
-                X.lambda_setup[X.ml_ix ^ 1] = X.lambda; X.pending = true;
-                any_ahead = true;
-            }
-            if (any_ahead) {
-                // On the second stream, behind this linearisation and beside this iteration's solves (which apply the other copy): the
-                // chain of ~25 small launches and the Newton-Schulz GEMMs (matrix cores) under the PCG replays (latency and vector
-                // issue).  Its phase table is a buffer of its own: the main stream moves on to the next phases of d_dyn.
-                static const bool ahead_sync = diag_flag("UZL_BATCH_SYNC_REBUILD");       // A/B switch
-                hipStream_t s2 = ahead_sync ? s : b->stream2;
-                BatchDyn* stage = b->h_dyn.p + (size_t)(b->ring++ % kDynRing) * R;
-                memcpy(stage, dyn.data(), sizeof(BatchDyn) * (size_t)R);
-                if (!ahead_sync) {
-                    UZL_HIP(hipEventRecord(b->ev_lin, s));
-                    UZL_HIP(hipStreamWaitEvent(s2, b->ev_lin, 0));
-                }
-                UZL_HIP(hipMemcpyAsync(b->d_dyn2.p, stage, sizeof(BatchDyn) * (size_t)R, hipMemcpyHostToDevice, s2));
-                kb_set_lambda(b->d_slots.p, b->d_dyn2.p, R, s2);
-                kb_ml_numeric(b->d_slots.p, b->d_dyn2.p, R, L, n_lv.data(), max_wt.data(), max_wr.data(), s2);
-                kb_ml_trial(b->d_slots.p, b->d_dyn2.p, R, 0, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s2);
-                if (!ahead_sync) { UZL_HIP(hipEventRecord(b->ev_build, s2)); b->build_pending = true; }
-            }
-        }
-        // ---- Start: one LM trial of the graphs that have a system to solve: lambda, trial set-up, PCG initialisation
-        base_dyn();
-        bool any_start = false, any_trial_cur = false;
-        for (int sl = 0; sl < R; sl++) {
-            if (!active(sl) || phase[slot_graph[sl]] != PStart) continue;
-            const int g = slot_graph[sl];
-            BatchLM& X = G[g];
-            dyn[sl].mask = kPhLambda | kPhInit; dyn[sl].lambda = X.lambda;
-            if (X.qmax == 0) X.tol_f2 = tol_factor2(b->h[g]->cfg);           // fixed for the trials of one LM iteration, like do_optimize
-            dyn[sl].tol_factor2 = X.tol_f2; dyn[sl].eps_t = pgo_eps_t(b->h[g]->cfg); dyn[sl].eps_r = pgo_eps_r(b->h[g]->cfg);
-            if (X.lambda > kLambdaRetake * X.lambda_setup[X.ml_ix]) X.trial_setup = true;
-            X.fresh = X.trial_setup || (X.adopted && X.qmax == 0);
-            if (X.trial_setup) { dyn[sl].mask |= kPhTrialCur; X.lambda_setup[X.ml_ix] = X.lambda; X.trial_setup = false; any_trial_cur = true; }
-            phase[g] = PSolve; launched_g[g] = 0;
-            any_start = true;
-        }
-        if (any_start) {
-            batch_upload_dyn(b, dyn);
-            kb_set_lambda(b->d_slots.p, b->d_dyn.p, R, s);
-            if (any_trial_cur) kb_ml_trial(b->d_slots.p, b->d_dyn.p, R, 1, L, cl, n_lv.data(), max_inner, h0->ml_ns_steps, kUpperNs, s);
-            kb_ml_init(b->d_slots.p, b->d_dyn.p, R, max_rows, small, s);
-        }
-        // ---- Solve: PCG iterations for every graph in a solve, in steps of 2 x kShortPairs.  As many as the graph that is closest to its
-        //      predicted end still needs (so the first one to finish is seen at once); in step: as many as the slowest needs.
-        base_dyn();
-        constexpr int kStep = 2 * kShortPairs;
-        const int kLong = 2 * kGraphPairs;
-        int its = 1 << 30;
-        bool any_solve = false;
-        for (int sl = 0; sl < R; sl++) {
-            if (!active(sl) || phase[slot_graph[sl]] != PSolve) continue;
-            const int g = slot_graph[sl];
-            dyn[sl].mask = kPhSolve;
-            any_solve = true;
-            // (+ 1: a solve that the stop test ends after k iterations is declared done by the ml_spmv of iteration k + 1)
-            // in step: everybody waits for the slowest anyway, and the steps are fine.  Free-running: every pass costs an upload, a publish and
-            // a host round trip whatever it launches, so a pass is at least one long replay (as fine as in step: 256 queued graphs on 64
-            // slots 53 -> 41 M edges/s)
-            const int fine = G[g].pcg_last > 0 ? std::max(kStep, (((G[g].pcg_last * 95) / 100 + 1 - launched_g[g]) + kStep - 1) / kStep * kStep) : kLong;
-            const int want = in_step ? fine : std::max(kLong, fine / kLong * kLong);
-            its = in_step ? (its == (1 << 30) ? want : std::max(its, want)) : std::min(its, want);
-        }
-        for (int round = 0; any_solve; round++) {
-            batch_upload_dyn(b, dyn);
-            if (eager) {
-                for (int done_its = 0; done_its < its; done_its += kStep) {
-                    if (b->timer.on) {
-                        std::vector<hipEvent_t> ev((size_t)4 * kStep);
-                        for (int q = 0; q < kStep; q++) {
-                            b->timer.pair("ml_spmv_batch", &ev[4 * q], &ev[4 * q + 1]);
-                            b->timer.pair("ml_cg_comp_batch", &ev[4 * q + 2], &ev[4 * q + 3]);
-                        }
-                        batch_pcg_replay(b, R, max_rows, small, kShortPairs, tol2, s, ev.data());
-                    } else batch_pcg_replay(b, R, max_rows, small, kShortPairs, tol2, s, nullptr);
-                }
-            } else {
-                for (int i = 0; i < its / kLong; i++) UZL_HIP(hipGraphLaunch(b->graph_exec, s));
-                for (int i = 0; i < (its % kLong) / kStep; i++) UZL_HIP(hipGraphLaunch(b->graph_exec_s, s));
-            }
-            kb_residual_guard(b->d_slots.p, b->d_dyn.p, R, s);
-            batch_fetch(b);
-            if (b->timer.on) { UZL_HIP(hipStreamSynchronize(s)); b->timer.resolve(); }
-            UZL_HIP(hipGetLastError());
-            bool still = false;
-            for (int sl = 0; sl < R; sl++) {
-                if (!(dyn[sl].mask & kPhSolve)) continue;
-                const int g = slot_graph[sl];
-                BatchLM& X = G[g];
-                launched_g[g] += its;
-                const PgoHostScal& P = b->h_pub.p[sl];
-                const int max_it_g = b->cfg.pcg_max_iter > 0 ? b->cfg.pcg_max_iter : 6 * std::max(b->h[g]->nb, 1);     // the cap uzl_pgo_optimize gives this graph
-                if (!P.flags[0] && launched_g[g] < max_it_g) { still = true; continue; }  // still iterating
-                dyn[sl].mask = 0;                                                     // (in step: the next replays of this stage are not this graph's)
-                bool conv = P.flags[0] != 0 && P.flags[2] == 0;
-                if (conv && !(P.scal[7] <= kResidualGuard)) conv = false;
-                const int its = P.flags[1];
-                X.S.pcg_iterations += its; X.S.lm_trials++;
-                if (!conv) {                                                          // the single-graph path sorts it out from the start poses
-                    if (b->h[g]->cfg.verbose)
-                        fprintf(stderr, "[uzl_pgo_batch] graph %d it %d trial %d lambda %.3e: pcg %d done %d breakdown %d |r|2/|b|2 %.3e -> single-graph path\n",
-                                g, X.it, X.qmax, X.lambda, its, (int)P.flags[0], (int)P.flags[2], P.scal[7]);
-                    X.anomaly = true; X.finished = true; continue;
-                }
-                X.pcg_last = its;
-                {
-                    const double rate = pcg_rate(P.scal[1], P.scal[0], its, tol2, X.tol_f2);
-                    if (rate > 0.) { X.rate_last = rate; if (X.fresh || X.rate_ref < 0.) X.rate_ref = rate; }
-                }
-                phase[g] = PEval;
-            }
-            if (!(in_step && still)) break;
-            its = round < 2 ? kStep : kLong;
-        }
-        // ---- Eval: retraction, chi2 of the trial, rho, accept / reject
-        base_dyn();
-        bool any_eval = false;
-        for (int sl = 0; sl < R; sl++) if (active(sl) && phase[slot_graph[sl]] == PEval) { dyn[sl].mask = kPhEval; any_eval = true; }
-        if (any_eval) {
-            batch_upload_dyn(b, dyn);
-            kb_eval(b->d_slots.p, b->d_dyn.p, R, max_g_edges, max_g_oplus, delta, s);
-            batch_fetch(b);
-            for (int sl = 0; sl < R; sl++) {
-                if (!(dyn[sl].mask & kPhEval)) continue;
-                const int g = slot_graph[sl];
-                BatchLM& X = G[g];
-                const double temp_chi = b->h_pub.p[sl].scal[4];
-                const LmStep step = lm_step(X.current_chi, temp_chi, b->h_pub.p[sl].scal[5], X.lambda, X.ni);
-                const double rho = step.rho;
-                if (step.accepted) {                                                  // good step
-                    X.last_rel = step.last_rel;
-                    X.current_chi = temp_chi;
-                    X.cur ^= 1;                                                       // discardTop
-                }
-                X.qmax++;
-                if (rho < 0 && X.qmax < 10) { phase[g] = PStart; continue; }          // another trial on the same linearisation
-                X.S.iterations_done = X.it + 1;
-                if (X.qmax == 10 || rho == 0) { X.S.terminated_early = 1; X.finished = true; continue; }     // Terminate
-                X.it++; X.qmax = 0; phase[g] = PLin;
-                if (X.it >= iterations) X.finished = true;
-            }
-        }
-        // ---- slots whose graph is through take the next one of the queue
-        n_active = 0;
-        for (int sl = 0; sl < R; sl++) n_active += active(sl) ? 1 : 0;
-        if (!in_step || n_active == 0) {
-            if (b->build_pending && next_graph < Q) {         // (a rebuild of the outgoing graphs may still read the slot table)
-                UZL_HIP(hipStreamWaitEvent(s, b->ev_build, 0));
-                b->build_pending = false;
-            }
-            n_active = 0;
-            for (int sl = 0; sl < R; sl++) {
-                if (slot_graph[sl] >= 0 && G[slot_graph[sl]].finished) load_slot(sl);
-                n_active += active(sl) ? 1 : 0;
-            }
-        }
-    }
-    if (b->build_pending) { UZL_HIP(hipStreamSynchronize(b->stream2)); b->build_pending = false; }     // a rebuild nobody will use: let it drain
-    UZL_HIP(hipStreamSynchronize(s));
-    const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    int batched = 0;
-    for (int g = 0; g < Q; g++) {
-        uzl_pgo* h = b->h[g];
-        BatchLM& X = G[g];
-        if (!X.anomaly) {
-            h->cur = X.cur ? h->pose_b.p : h->pose_a.p; h->trial = X.cur ? h->pose_a.p : h->pose_b.p;
-            X.S.chi2_final = X.current_chi; X.S.lambda_final = X.lambda; X.S.solve_ms = wall;
-            if (stats) stats[g] = X.S;
-            batched++;
-        } else {
-            UZL_HIP(hipMemcpyAsync(h->cur, b->d_start.p + start_off[g], sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
-            UZL_HIP(hipStreamSynchronize(s));
-            uzl_pgo_stats S;
-            const int rc = do_optimize(h, iterations, &S);
-            if (rc != UZL_OK && rc != UZL_ERR_NOT_CONVERGED) { b->last_error = h->last_error; return rc; }
-            if (rc != UZL_OK) rc_all = rc;
-            if (stats) stats[g] = S;
-        }
-    }
-    b->last_batched = batched;
-    if (n_batched) *n_batched = batched;
+    const int done = batch_optimize_lm(b->lm, b->h, b->resident, b->stream, b->stream2, iterations, b->h[0]->no_graph, b->cfg.verbose != 0, &b->timer, stats, &rc_all);
+    if (done < 0) { b->last_error = b->h[(size_t)(-1 - done)]->last_error; return rc_all; }
+    b->last_batched = done;
+    if (n_batched) *n_batched = done;
     return rc_all;
 }
 
@@ -1998,13 +1560,10 @@ int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch
         b->h.push_back(h);
     }
     if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, -1) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_lin, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_build, hipEventDisableTiming) != hipSuccess) {
+        hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, -1) != hipSuccess) {
         for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
         if (b->stream) (void)hipStreamDestroy(b->stream);
         if (b->stream2) (void)hipStreamDestroy(b->stream2);
-        if (b->ev_lin) (void)hipEventDestroy(b->ev_lin);
-        if (b->ev_build) (void)hipEventDestroy(b->ev_build);
         delete b;
         return UZL_ERR_HIP;
     }
@@ -2018,12 +1577,10 @@ void uzl_pgo_batch_destroy(uzl_pgo_batch* b)
     (void)hipSetDevice(b->cfg.device);
     if (b->stream2) (void)hipStreamSynchronize(b->stream2);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    batch_destroy_graph(b);
+    lm_run_destroy(b->lm); b->lm = nullptr;
     for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     if (b->stream2) (void)hipStreamDestroy(b->stream2);
-    if (b->ev_lin) (void)hipEventDestroy(b->ev_lin);
-    if (b->ev_build) (void)hipEventDestroy(b->ev_build);
     delete b;
 }
 
