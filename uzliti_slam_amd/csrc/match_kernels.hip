@@ -155,24 +155,31 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef int v16i32 __attribute__((ext_vector_type(16)));
 
-// 4 bits -> 4 bytes of 0 / 1 (bit i -> byte i)
-__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return (nib * 0x00204081u) & 0x01010101u; }
+// 4 bits -> 4 bytes of 0 / V (bit i -> byte i), V = 1 << S: the nibble times 0x00204081 puts bit i at positions i, i + 7, i + 14,
+// i + 21 - no two bits on one position, so no carries - and the mask keeps bit 0 of every byte; shifting the multiplier by S moves
+// the kept bit to position S of its byte (15 * (0x00204081 << 7) < 2^32).
+template <int S>
+__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return (nib * (0x00204081u << S)) & (0x01010101u << S); }
+template <int S>
 __device__ __forceinline__ v4i32 spread16(uint32_t bits16)
 {
     v4i32 v;
-    v.x = (int)spread4(bits16 & 0xfu); v.y = (int)spread4((bits16 >> 4) & 0xfu);
-    v.z = (int)spread4((bits16 >> 8) & 0xfu); v.w = (int)spread4((bits16 >> 12) & 0xfu);
+    v.x = (int)spread4<S>(bits16 & 0xfu); v.y = (int)spread4<S>((bits16 >> 4) & 0xfu);
+    v.z = (int)spread4<S>((bits16 >> 8) & 0xfu); v.w = (int)spread4<S>((bits16 >> 12) & 0xfu);
     return v;
 }
-__device__ __forceinline__ int med3_i32(int a, int b, int c)
-{
-    int d;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
+// (written with min / max: the compiler folds it to one v_med3_i32 AND pads the MFMA -> VALU read hazard in front of it, which it does
+//  not do for inline asm - an inline-asm reader of a matrix-core result returned stale values)
+__device__ __forceinline__ int med3_i32(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 
-constexpr int kNegTwoDot = -(1 << (kIdxBits + 1));
-constexpr int kMmInvalid = 1023 << kIdxBits;      // key of a padded train row before |q| is added: above every real key
+// The matrix cores emit the SORT KEY itself.  Train bits are expanded to int8 {0, -128}, query bits to {0, 64}: every common bit adds
+// -2^13 to the accumulator, and the accumulator of train row t starts at |t| << 12 | t, so after the k-steps it holds
+//     (|t| - 2 <t, q>) << 12 | t            (two's complement: ordered by (partial distance, t) under signed compares)
+// - the fold is v_med3_i32 + v_min_i32, two vector instructions per distance where building the key from <t, q> took a multiply-add
+// more (round 3: 96 instructions per 16 MFMAs; the fold, not the matrix pipe, bounds the kernel).  12 index bits cover 4096 train rows
+// per sweep; a longer train set is swept in pieces whose winners are merged as full keys.  |q| is lane-constant and added at the end.
+constexpr int kKeyBits = 12, kSweep = 1 << kKeyBits;
+constexpr int kMmInvalid = 1023 << kKeyBits;      // key of a padded train row before |q| is added: above every real key
 
 template <int W, int UT>
 __global__ __launch_bounds__(kBlock) void knn2_mfma_kernel(const uint32_t* __restrict__ arena,
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void knn2_mfma_kernel(const uint32_t* __res
     const int q0 = blockIdx.x * QPB;
     if (q0 >= c.nq) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, h = lane >> 5;
-    // ---- this lane's queries: B fragments (0 / 1 bytes) and |q|
+    // ---- this lane's queries: B fragments (0 / 64 bytes) and |q|
     v4i32 bf[UT][W];
     int pa[UT], qi[UT];
 #pragma unroll
@@ -205,91 +212,100 @@ __global__ __launch_bounds__(kBlock) void knn2_mfma_kernel(const uint32_t* __res
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 pc += __popc(w4[j]);
-                bf[u][4 * k + j] = spread16((w4[j] >> (16 * h)) & 0xffffu);
+                bf[u][4 * k + j] = spread16<6>((w4[j] >> (16 * h)) & 0xffffu);
             }
         }
         pa[u] = pc;
     }
-    int b1[UT], b2[UT];
+    uint32_t g1[UT], g2[UT];                        // winners so far as full keys (distance << kIdxBits | train index)
 #pragma unroll
-    for (int u = 0; u < UT; u++) { b1[u] = 0x7fffffff; b2[u] = 0x7fffffff; }
-    // -2^21 as an opaque uniform value: with a literal the compiler rewrites the multiply-add as shift + subtract (two
-    // instructions).  The instruction is left to the compiler (not inline asm): it is the first reader of the MFMA result and
-    // the compiler, not the hardware, pads the MFMA -> VALU read hazard.
-    int neg2dot = kNegTwoDot;
-    asm volatile("" : "+s"(neg2dot));
+    for (int u = 0; u < UT; u++) { g1[u] = 0xffffffffu; g2[u] = 0xffffffffu; }
     const uint32_t* __restrict__ td = arena + c.desc_from_off;
     const int nt = c.nt;
-    // descriptor words of the next chunk are fetched while the matrix cores work on the current one
-    uint32_t nxt[4];
+    for (int base = 0; base < nt; base += kSweep) {
+        const int nt_s = min(nt, base + kSweep);     // this sweep: train rows [base, nt_s)
+        int b1[UT], b2[UT];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int widx = i * kBlock + tid, t = widx / W;
-        nxt[i] = (t < nt) ? td[(size_t)t * W + widx % W] : 0u;
-    }
-    for (int t0 = 0; t0 < nt; t0 += TR) {
-        __syncthreads();
-        // ---- expand TR train rows: lane -> 4 descriptor words (coalesced), 32 bytes of 0 / 1 each; R[row] = |t| << 20 | t
+        for (int u = 0; u < UT; u++) { b1[u] = 0x7fffffff; b2[u] = 0x7fffffff; }
+        // descriptor words of the next chunk are fetched while the matrix cores work on the current one
+        uint32_t nxt[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int widx = i * kBlock + tid, row = widx / W, word = widx % W, t = t0 + row;
-            const uint32_t wd = nxt[i];
-            uint4* dst = reinterpret_cast<uint4*>(sA + row * ROWB + word * 32);
-            const v4i32 lo = spread16(wd & 0xffffu), hi = spread16(wd >> 16);
-            dst[0] = make_uint4((uint32_t)lo.x, (uint32_t)lo.y, (uint32_t)lo.z, (uint32_t)lo.w);
-            dst[1] = make_uint4((uint32_t)hi.x, (uint32_t)hi.y, (uint32_t)hi.z, (uint32_t)hi.w);
-            int pc = __popc(wd);
-#pragma unroll
-            for (int m = 1; m < W; m <<= 1) pc += __shfl_xor(pc, m);          // the W lanes of a row are consecutive
-            if (word == 0) sR[row] = (t < nt) ? ((pc << kIdxBits) | t) : (kMmInvalid | (t & (int)kIdxMask));
+            const int widx = i * kBlock + tid, t = base + widx / W;
+            nxt[i] = (t < nt_s) ? td[(size_t)t * W + widx % W] : 0u;
         }
+        for (int t0 = base; t0 < nt_s; t0 += TR) {
+            __syncthreads();
+            // ---- expand TR train rows: lane -> 4 descriptor words (coalesced), 32 bytes of 0 / -128 each; R[row] = |t| << 12 | (t - base)
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int widx = i * kBlock + tid, t = t0 + TR + widx / W;
-            nxt[i] = (t < nt) ? td[(size_t)t * W + widx % W] : 0u;
-        }
-        __syncthreads();
-        const int rows_here = min(TR, nt - t0);
-        for (int r0 = 0; r0 < rows_here; r0 += 32) {
-            v16i32 acc[UT];
+            for (int i = 0; i < 4; i++) {
+                const int widx = i * kBlock + tid, row = widx / W, word = widx % W, t = t0 + row;
+                const uint32_t wd = nxt[i];
+                uint4* dst = reinterpret_cast<uint4*>(sA + row * ROWB + word * 32);
+                const v4i32 lo = spread16<7>(wd & 0xffffu), hi = spread16<7>(wd >> 16);
+                dst[0] = make_uint4((uint32_t)lo.x, (uint32_t)lo.y, (uint32_t)lo.z, (uint32_t)lo.w);
+                dst[1] = make_uint4((uint32_t)hi.x, (uint32_t)hi.y, (uint32_t)hi.z, (uint32_t)hi.w);
+                int pc = __popc(wd);
 #pragma unroll
-            for (int u = 0; u < UT; u++)
-#pragma unroll
-                for (int k = 0; k < 16; k++) acc[u][k] = 0;
-            const uint8_t* arow = sA + (r0 + col) * ROWB + 16 * h;
-#pragma unroll
-            for (int s_ = 0; s_ < W; s_++) {
-                const v4i32 a = *reinterpret_cast<const v4i32*>(arow + 32 * s_);
-#pragma unroll
-                for (int u = 0; u < UT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[u][s_], acc[u], 0, 0, 0);
+                for (int m = 1; m < W; m <<= 1) pc += __shfl_xor(pc, m);          // the W lanes of a row are consecutive
+                if (word == 0) sR[row] = (t < nt_s) ? ((pc << kKeyBits) | (t - base)) : (kMmInvalid | ((t - base) & (kSweep - 1)));
             }
-            // rows of this lane's registers: 8 (reg>>2) + 4 h + (reg&3)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                const v4i32 rr = *reinterpret_cast<const v4i32*>(sR + r0 + 8 * g4 + 4 * h);
+            for (int i = 0; i < 4; i++) {
+                const int widx = i * kBlock + tid, t = t0 + TR + widx / W;
+                nxt[i] = (t < nt_s) ? td[(size_t)t * W + widx % W] : 0u;
+            }
+            __syncthreads();
+            const int rows_here = min(TR, nt_s - t0);
+            for (int r0 = 0; r0 < rows_here; r0 += 32) {
+                // rows of this lane's registers: 8 (reg>>2) + 4 h + (reg&3): their accumulators start at the rows' key words
+                v16i32 acc[UT];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const v4i32 rr = *reinterpret_cast<const v4i32*>(sR + r0 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int u = 0; u < UT; u++) acc[u][4 * g4 + j] = rr[j];
+                }
+                const uint8_t* arow = sA + (r0 + col) * ROWB + 16 * h;
+#pragma unroll
+                for (int s_ = 0; s_ < W; s_++) {
+                    const v4i32 a = *reinterpret_cast<const v4i32*>(arow + 32 * s_);
+#pragma unroll
+                    for (int u = 0; u < UT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[u][s_], acc[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
 #pragma unroll
                     for (int u = 0; u < UT; u++) {
-                        const int kk = __mul24(acc[u][4 * g4 + j], neg2dot) + rr[j];          // v_mad_i32_i24: R - (<t,q> << 21)
+                        const int kk = acc[u][k];                                   // (|t| - 2 <t, q>) << 12 | t: the matrix cores built the key
                         b2[u] = med3_i32(b1[u], b2[u], kk);
                         b1[u] = min(b1[u], kk);
                     }
                 }
             }
         }
+        // ---- this sweep's winners as full keys (padded rows stay the missing-neighbour sentinel), merged into the winners so far
+#pragma unroll
+        for (int u = 0; u < UT; u++) {
+            // (a partial distance may be negative; |q| >= 2 <t, q> - |t| makes the total non-negative, and unsigned arithmetic mod 2^32
+            //  carries it through: keys are merged with |q| added - monotone - and a padded row stays the missing-neighbour sentinel)
+            const uint32_t qa = (uint32_t)pa[u] << kIdxBits;
+            const uint32_t f1 = (b1[u] >= kMmInvalid) ? 0xffffffffu : (((uint32_t)(b1[u] >> kKeyBits) << kIdxBits) + (uint32_t)((b1[u] & (kSweep - 1)) + base) + qa);
+            const uint32_t f2 = (b2[u] >= kMmInvalid) ? 0xffffffffu : (((uint32_t)(b2[u] >> kKeyBits) << kIdxBits) + (uint32_t)((b2[u] & (kSweep - 1)) + base) + qa);
+            const uint32_t m1 = min(g1[u], f1);
+            const uint32_t m2 = min(max(g1[u], f1), min(g2[u], f2));
+            g1[u] = m1; g2[u] = m2;
+        }
     }
-    // ---- merge the two lane halves (same query, disjoint train rows), add |q|, restore the sentinel
+    // ---- merge the two lane halves (same query, disjoint train rows)
 #pragma unroll
     for (int u = 0; u < UT; u++) {
-        const int c1 = __shfl_xor(b1[u], 32), c2 = __shfl_xor(b2[u], 32);
-        const int m1 = min(b1[u], c1);
-        const int m2 = min(max(b1[u], c1), min(b2[u], c2));
-        if (h == 0 && qi[u] < c.nq) {
-            const uint32_t k1 = (m1 >= kMmInvalid) ? 0xffffffffu : (uint32_t)(m1 + (pa[u] << kIdxBits));
-            const uint32_t k2 = (m2 >= kMmInvalid) ? 0xffffffffu : (uint32_t)(m2 + (pa[u] << kIdxBits));
-            knn[c.knn_off + qi[u]] = make_uint2(k1, k2);
-        }
+        const uint32_t c1 = (uint32_t)__shfl_xor((int)g1[u], 32), c2 = (uint32_t)__shfl_xor((int)g2[u], 32);
+        const uint32_t m1 = min(g1[u], c1);
+        const uint32_t m2 = min(max(g1[u], c1), min(g2[u], c2));
+        if (h == 0 && qi[u] < c.nq) knn[c.knn_off + qi[u]] = make_uint2(m1, m2);
     }
 }
 
