@@ -22,8 +22,7 @@ void k_prepare_edges(const uzl_edge* edges, const int32_t* src, int e, const dou
                      double* zinv, double* info, hipStream_t s);
 void k_prepare_flat_edges(const double* meas12, const double* info36, int e, double* zinv, double* info, hipStream_t s);
 int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s);
-int k_linearize(const PgoDev& D, const double* pose, double delta, hipStream_t s);
-int k_assemble(const PgoDev& D, hipStream_t s);
+hipError_t k_hessian(const PgoDev& D, const double* pose, double delta, int* g_edges, int* g_rows, hipStream_t s);
 void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s);
 int k_diagmax(const PgoDev& D, hipStream_t s);
 void k_precond(const PgoDev& D, hipStream_t s);
@@ -58,7 +57,7 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
                    int init, size_t lds, hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s);
 int g_edges_for(int e);
-int g_asm_for(int nb);
+void k_edge_records(const double* zinv, const double* info, int e, double* rec, hipStream_t s);
 int g_oplus_for(int n);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
@@ -68,7 +67,7 @@ void k_schur_backsub(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStr
 // slot twins of the device-resident LM loop (pgo_types.hpp: LmSlot / LmDev / LmShape)
 void k_lm_head(const LmSlot* slots, int nslots, int pass_flags, hipStream_t s);
 void k_lm_tail(const LmSlot* slots, int nslots, hipStream_t s);
-void kl_linearize(const LmSlot* sl, int nslots, int g_edges, int g_asm, hipStream_t s);
+hipError_t kl_linearize(const LmSlot* sl, int nslots, int g_edges, int g_asm, hipStream_t s);
 void kl_eval(const LmSlot* sl, int nslots, int g_edges, int g_oplus, hipStream_t s);
 void kl_schur_reduce(const LmSlot* sl, int nslots, int max_runs, long max_items, hipStream_t s);
 void kl_schur_backsub(const LmSlot* sl, int nslots, int max_grid, hipStream_t s);
@@ -103,7 +102,9 @@ struct uzl_pgo {
     double* cur = nullptr;
     double* trial = nullptr;
     DevBuf<int32_t> d_v2b, d_b2v, d_ei, d_ej, d_slot_i, d_slot_j, d_row_ptr, d_col, d_rowhdr, d_src, d_flags;
-    DevBuf<double> d_zinv, d_info, d_blk, d_dcon, d_gcon, d_hdiag, d_minv, d_b, d_x, d_xs, d_r, d_z, d_p, d_p2, d_ap;
+    DevBuf<int32_t> d_slot_edge, d_rb_ptr;
+    DevBuf<double> d_erec;                     // edge records (pgo_kernels.hip: edge_records_kernel), written with the edges
+    DevBuf<double> d_zinv, d_info, d_blk, d_hdiag, d_minv, d_b, d_x, d_xs, d_r, d_z, d_p, d_p2, d_ap;
     DevBuf<double> d_part_a, d_part_b, d_part_c, d_scal, d_err, d_out12, d_stage;
     DevBuf<uint8_t> d_robust;
     DevBuf<uzl_node> d_nodes;

@@ -9,6 +9,8 @@
 // Poses live as (t, unit quaternion): the error e = toVectorMQT(Z^-1 Xi^-1 Xj)
 // (graph_slam_common/thirdparty/src/isometry3d_mappings.cpp:94-99) is then pure quaternion algebra
 // with no matrix->quaternion branches in the hot loop.
+#include <mutex>
+
 #include "pgo_device.hpp"
 
 namespace uzl {
@@ -132,11 +134,11 @@ __device__ __forceinline__ void huber(double e2, double delta, double& rho0, dou
 }
 
 // activeRobustChi2 over `pose`; block partials -> part_a
-__device__ __forceinline__ void chi2_kernel_body(PgoDev D, const double* __restrict__ pose, double delta)
+__device__ __forceinline__ void chi2_kernel_body(PgoDev D, const double* __restrict__ pose, double delta, int blk = blockIdx.x, int nblk = gridDim.x)
 {
     __shared__ double s4[4];
     double acc = 0.;
-    for (int k = D.e_begin + blockIdx.x * kBlk + threadIdx.x; k < D.e_end; k += gridDim.x * kBlk) {
+    for (int k = D.e_begin + blk * kBlk + threadIdx.x; k < D.e_end; k += nblk * kBlk) {
         const EdgeGeom G = edge_geom(D, pose, k);
         const double ev[6] = {G.te.x, G.te.y, G.te.z, G.qe.x, G.qe.y, G.qe.z};
         const double chi = edge_chi(D, k, ev);
@@ -145,7 +147,7 @@ __device__ __forceinline__ void chi2_kernel_body(PgoDev D, const double* __restr
         acc += r0;
     }
     const double tot = block_sum(acc, s4);
-    if (threadIdx.x == 0) D.part_a[blockIdx.x] = tot;
+    if (threadIdx.x == 0) D.part_a[blk] = tot;
 }
 __global__ __launch_bounds__(kBlk) void chi2_kernel(PgoDev D, const double* __restrict__ pose, double delta)
 {
@@ -193,174 +195,243 @@ __device__ __forceinline__ void mat3mul(const double* A, const double* B, double
         for (int c = 0; c < 3; c++) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
 }
 
-__device__ __forceinline__ void linearize_kernel_body(PgoDev D, const double* __restrict__ pose, double delta)
+// ------------------------------------------------------------------------------------------------
+// The sparse Hessian build (north star): ONE kernel where rounds 1-3 had linearize_kernel (a lane per edge writing two 624-byte slot
+// records: H_ac block, the edge's share of H_aa, its share of -b) and assemble_kernel (reading all of them back to sum H_aa and b per
+// row).  Here a workgroup owns 42 consecutive block rows and walks their slots - contiguous, sorted by edge - 256 at a time:
+//   phase 1: a lane per SLOT (edge, side) recomputes the edge's error and Jacobians (3.5 kflop, done on both sides of an edge: free
+//            against the round trip through HBM it replaces), writes the slot's H_ac block and leaves its share of H_aa | -b in LDS;
+//   phase 2: lane (row, r) adds the shares of its row's slots IN SLOT ORDER (assemble_kernel's order: bit-reproducible, no atomics),
+//            and after the last chunk writes H_aa | b once per row and the workgroup's largest diagonal entry (computeLambdaInit).
+// The shares never reach HBM: 2 x 336 B per edge less written and read back; the per-slot input (two poses, Z^-1, Omega: 476 B) is read
+// by both of an edge's slots - from L2 when they sit in one workgroup (odometry edges: neighbouring rows).
+// Workgroups behind the row blocks compute the chi2 partials (chi2_kernel's lanes, one per edge: computeActiveErrors).
+// Sharded solve: a slot whose edge another rank linearises contributes nothing here (its block stays zero).
+// ------------------------------------------------------------------------------------------------
+constexpr int kLaRows = kBlk / 6;                     // <= 42 rows per pass of a workgroup: lane (row, r) owns row r of H_aa and b[r]
+constexpr int kLaShare = 27;                          // doubles per slot in LDS: upper triangle of its share of H_aa (21) | share of -b (6)
+constexpr int kEdgeRec = 44;                          // doubles per edge record: Z^-1 (7) | Omega (36) | pad
+// (r, c) -> index in the packed upper triangle, r <= c
+__device__ __forceinline__ constexpr int tri6(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
+
+// the edge's inputs as ONE record (the lanes of the Hessian build walk slots, not edges: the SoA arrays the lane-per-edge kernels read
+// coalesced would cost them 43 scattered 8-byte loads each)
+__global__ __launch_bounds__(kBlk) void edge_records_kernel(const double* __restrict__ zinv, const double* __restrict__ info, int e, double* __restrict__ rec)
 {
-    __shared__ double s4[4];
-    double chi_acc = 0.;
-    const size_t E = (size_t)D.e;
-    for (int k = D.e_begin + blockIdx.x * kBlk + threadIdx.x; k < D.e_end; k += gridDim.x * kBlk) {
-        const EdgeGeom G = edge_geom(D, pose, k);
-        const double ev[6] = {G.te.x, G.te.y, G.te.z, G.qe.x, G.qe.y, G.qe.z};
-        // Omega (row-major 6x6) from the SoA array, robustified: Omega' = rho1 * Omega
-        double Om[36];
+    const int k = blockIdx.x * kBlk + threadIdx.x;
+    if (k >= e) return;
+    double* __restrict__ o = rec + (size_t)k * kEdgeRec;
 #pragma unroll
-        for (int i = 0; i < 36; i++) Om[i] = D.info[(size_t)i * E + k];
-        double Oe[6];
-        double chi = 0.;
+    for (int i = 0; i < 7; i++) o[i] = zinv[(size_t)i * e + k];
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-            double s = 0.;
-#pragma unroll
-            for (int c = 0; c < 6; c++) s += Om[r * 6 + c] * ev[c];
-            Oe[r] = s;
-            chi += ev[r] * s;
-        }
-        double r0 = chi, r1 = 1.;
-        if (D.robust[k]) huber(chi, delta, r0, r1);
-        chi_acc += r0;
-        const int si = D.slot_i[k], sj = D.slot_j[k];
-        if (si < 0 && sj < 0) continue;
-#pragma unroll
-        for (int i = 0; i < 36; i++) Om[i] *= r1;
-#pragma unroll
-        for (int i = 0; i < 6; i++) Oe[i] *= r1;
-
-        // ---- Jacobian blocks
-        const M33 Ra = qrot(G.qa);
-        const M33 Re = qrot(G.qe);
-        double A11[9], A12[9], A22[9], B22[9];
-        {
-            double S[9], T[9];
-            skew(G.tb.x, G.tb.y, G.tb.z, S);
-            mat3mul(Ra.m, S, T);
-#pragma unroll
-            for (int i = 0; i < 9; i++) { A11[i] = -Ra.m[i]; A12[i] = 2. * T[i]; }
-            double Sa[9], Sb[9], L[9], R[9], P[9];
-            skew(G.qa.x, G.qa.y, G.qa.z, Sa);
-            skew(G.qb.x, G.qb.y, G.qb.z, Sb);
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const double id = (i % 4 == 0) ? 1. : 0.;
-                L[i] = id * G.qb.w - Sb[i];
-                R[i] = id * G.qa.w + Sa[i];
-            }
-            mat3mul(L, R, P);
-            const double vb[3] = {G.qb.x, G.qb.y, G.qb.z}, va[3] = {G.qa.x, G.qa.y, G.qa.z};
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) A22[r * 3 + c] = -G.s * (P[r * 3 + c] - vb[r] * va[c]);
-            double Se[9];
-            skew(G.qe.x, G.qe.y, G.qe.z, Se);
-#pragma unroll
-            for (int i = 0; i < 9; i++) B22[i] = ((i % 4 == 0) ? G.qe.w : 0.) + Se[i];
-        }
-        const double* B11 = Re.m;
-
-        // ---- W_j = Omega' Jj   (Jj = diag(B11, B22))
-        double Wj[36];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                Wj[r * 6 + c] = Om[r * 6 + 0] * B11[0 * 3 + c] + Om[r * 6 + 1] * B11[1 * 3 + c] + Om[r * 6 + 2] * B11[2 * 3 + c];
-                Wj[r * 6 + 3 + c] = Om[r * 6 + 3] * B22[0 * 3 + c] + Om[r * 6 + 4] * B22[1 * 3 + c] + Om[r * 6 + 5] * B22[2 * 3 + c];
-            }
-        // ---- row i:  H_ij = Ji^T Wj ; row j: H_ji = H_ij^T, H_jj = Jj^T Wj
-        double Hij[36];
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                Hij[r * 6 + c] = A11[0 * 3 + r] * Wj[0 * 6 + c] + A11[1 * 3 + r] * Wj[1 * 6 + c] + A11[2 * 3 + r] * Wj[2 * 6 + c];
-                Hij[(3 + r) * 6 + c] = A12[0 * 3 + r] * Wj[0 * 6 + c] + A12[1 * 3 + r] * Wj[1 * 6 + c] + A12[2 * 3 + r] * Wj[2 * 6 + c] +
-                                       A22[0 * 3 + r] * Wj[3 * 6 + c] + A22[1 * 3 + r] * Wj[4 * 6 + c] + A22[2 * 3 + r] * Wj[5 * 6 + c];
-            }
-        }
-        if (sj >= 0) {
-            double* __restrict__ bj = D.blk + (size_t)sj * 36;
-            double* __restrict__ dj = D.dcon + (size_t)sj * 36;
-            double* __restrict__ gj = D.gcon + (size_t)sj * 6;
-            if (si >= 0) {
-#pragma unroll
-                for (int r = 0; r < 6; r++)
-#pragma unroll
-                    for (int c = 0; c < 6; c++) bj[r * 6 + c] = Hij[c * 6 + r];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    dj[r * 6 + c] = B11[0 * 3 + r] * Wj[0 * 6 + c] + B11[1 * 3 + r] * Wj[1 * 6 + c] + B11[2 * 3 + r] * Wj[2 * 6 + c];
-                    dj[(3 + r) * 6 + c] = B22[0 * 3 + r] * Wj[3 * 6 + c] + B22[1 * 3 + r] * Wj[4 * 6 + c] + B22[2 * 3 + r] * Wj[5 * 6 + c];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                gj[r] = B11[0 * 3 + r] * Oe[0] + B11[1 * 3 + r] * Oe[1] + B11[2 * 3 + r] * Oe[2];
-                gj[3 + r] = B22[0 * 3 + r] * Oe[3] + B22[1 * 3 + r] * Oe[4] + B22[2 * 3 + r] * Oe[5];
-            }
-        }
-        if (si >= 0) {
-            double* __restrict__ bi = D.blk + (size_t)si * 36;
-            double* __restrict__ di = D.dcon + (size_t)si * 36;
-            double* __restrict__ gi = D.gcon + (size_t)si * 6;
-            if (sj >= 0) {
-#pragma unroll
-                for (int i = 0; i < 36; i++) bi[i] = Hij[i];
-            }
-            // W_i = Omega' Ji, reusing Wj's registers
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    Wj[r * 6 + c] = Om[r * 6 + 0] * A11[0 * 3 + c] + Om[r * 6 + 1] * A11[1 * 3 + c] + Om[r * 6 + 2] * A11[2 * 3 + c];
-                    Wj[r * 6 + 3 + c] = Om[r * 6 + 0] * A12[0 * 3 + c] + Om[r * 6 + 1] * A12[1 * 3 + c] + Om[r * 6 + 2] * A12[2 * 3 + c] +
-                                        Om[r * 6 + 3] * A22[0 * 3 + c] + Om[r * 6 + 4] * A22[1 * 3 + c] + Om[r * 6 + 5] * A22[2 * 3 + c];
-                }
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    di[r * 6 + c] = A11[0 * 3 + r] * Wj[0 * 6 + c] + A11[1 * 3 + r] * Wj[1 * 6 + c] + A11[2 * 3 + r] * Wj[2 * 6 + c];
-                    di[(3 + r) * 6 + c] = A12[0 * 3 + r] * Wj[0 * 6 + c] + A12[1 * 3 + r] * Wj[1 * 6 + c] + A12[2 * 3 + r] * Wj[2 * 6 + c] +
-                                          A22[0 * 3 + r] * Wj[3 * 6 + c] + A22[1 * 3 + r] * Wj[4 * 6 + c] + A22[2 * 3 + r] * Wj[5 * 6 + c];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                gi[r] = A11[0 * 3 + r] * Oe[0] + A11[1 * 3 + r] * Oe[1] + A11[2 * 3 + r] * Oe[2];
-                gi[3 + r] = A12[0 * 3 + r] * Oe[0] + A12[1 * 3 + r] * Oe[1] + A12[2 * 3 + r] * Oe[2] +
-                            A22[0 * 3 + r] * Oe[3] + A22[1 * 3 + r] * Oe[4] + A22[2 * 3 + r] * Oe[5];
-            }
-        }
-    }
-    const double tot = block_sum(chi_acc, s4);
-    if (threadIdx.x == 0) D.part_a[blockIdx.x] = tot;
+    for (int i = 0; i < 36; i++) o[7 + i] = info[(size_t)i * e + k];
+    o[43] = 0.;
 }
-__global__ __launch_bounds__(kBlk) void linearize_kernel(PgoDev D, const double* __restrict__ pose, double delta)
+void k_edge_records(const double* zinv, const double* info, int e, double* rec, hipStream_t s)
 {
-    linearize_kernel_body(D, pose, delta);
+    if (e > 0) hipLaunchKernelGGL(edge_records_kernel, dim3((e + kBlk - 1) / kBlk), dim3(kBlk), 0, s, zinv, info, e, rec);
+}
+// edge_geom on a record (same arithmetic, same numbers)
+__device__ __forceinline__ EdgeGeom edge_geom_rec(const PgoDev& D, const double* __restrict__ pose, int k, const double* __restrict__ rc)
+{
+    const Pose Xi = load_pose(pose, D.ei[k]);
+    const Pose Xj = load_pose(pose, D.ej[k]);
+    const V3 ta{rc[0], rc[1], rc[2]};
+    EdgeGeom G;
+    G.qa = Q4{rc[3], rc[4], rc[5], rc[6]};
+    const V3 d{Xj.t.x - Xi.t.x, Xj.t.y - Xi.t.y, Xj.t.z - Xi.t.z};
+    G.tb = mulTv(qrot(Xi.q), d);
+    G.qb = qmul(qconj(Xi.q), Xj.q);
+    const V3 rt = mulv(qrot(G.qa), G.tb);
+    G.te = V3{rt.x + ta.x, rt.y + ta.y, rt.z + ta.z};
+    Q4 qab = qnormalize(qmul(G.qa, G.qb));
+    G.s = (qab.w < 0.) ? -1. : 1.;
+    G.qe = Q4{G.s * qab.w, G.s * qab.x, G.s * qab.y, G.s * qab.z};
+    return G;
 }
 
-// H_aa = sum of the row's dcon, b_a = -sum of gcon; 36+6 lanes... one lane per (row, entry): 42 entries
-// Grid-stride over rows with 6 lanes per row (lane r owns row r of the 6x6 block and b[r]).
-__device__ __forceinline__ void assemble_kernel_body(PgoDev D)
+// row block `rb` of D.rb_ptr (host-side partition: consecutive rows with <= 256 slots and <= 42 rows wherever the graph allows, so that a
+// workgroup makes ONE pass: a chunk of slots, a group of rows; hub rows and very large graphs loop)
+__device__ __forceinline__ void hessian_rows_body(PgoDev D, const double* __restrict__ pose, double delta, int rb)
 {
     __shared__ double s4[4];
+    __shared__ double sh[kBlk * kLaShare];             // 55 KB
+    const int tid = threadIdx.x;
     double dmax = 0.;
-    const int lanes_per_blk = kBlk / 6 * 6;       // 252
-    for (int base = blockIdx.x * (kBlk / 6); base < D.nb; base += gridDim.x * (kBlk / 6)) {
-        const int a = base + (int)threadIdx.x / 6, r = (int)threadIdx.x % 6;
-        if ((int)threadIdx.x < lanes_per_blk && a < D.nb) {
-            double h[6] = {0., 0., 0., 0., 0., 0.};
-            double g = 0.;
-            for (int s = D.row_ptr[a]; s < D.row_ptr[a + 1]; s++) {
-                const double* __restrict__ dc = D.dcon + (size_t)s * 36 + r * 6;
-#pragma unroll
-                for (int c = 0; c < 6; c++) h[c] += dc[c];
-                g += D.gcon[(size_t)s * 6 + r];
+    const int rows_begin = D.rb_ptr[rb], rows_end = D.rb_ptr[rb + 1];
+    for (int row0 = rows_begin; row0 < rows_end; row0 += kLaRows) {
+        const int row1 = (row0 + kLaRows < rows_end) ? row0 + kLaRows : rows_end;
+        const int s_begin = D.row_ptr[row0], s_end = D.row_ptr[row1];
+        const int a = row0 + tid / 6, r = tid % 6;
+        const bool rowlane = tid < kLaRows * 6 && a < row1;
+        const int ra0 = rowlane ? D.row_ptr[a] : 0, ra1 = rowlane ? D.row_ptr[a + 1] : 0;
+        double h[6] = {0., 0., 0., 0., 0., 0.};
+        double g = 0.;
+        for (int base = s_begin; base < s_end; base += kBlk) {
+            const int s = base + tid;
+            double* __restrict__ mine = sh + (size_t)tid * kLaShare;
+            bool live = false;
+            int k = 0, side = 0;
+            if (s < s_end) {
+                const int se = D.slot_edge[s];
+                k = se >> 1; side = se & 1;
+                live = k >= D.e_begin && k < D.e_end;
             }
+            if (!live) {
+                if (s < s_end) {                       // (sharded solve: an edge of another rank - its shares are that rank's)
+#pragma unroll
+                    for (int i = 0; i < kLaShare; i++) mine[i] = 0.;
+                }
+            } else {
+                // the record: 22 x 16 bytes, contiguous
+                double rc[kEdgeRec];
+                {
+                    const double2* __restrict__ src = reinterpret_cast<const double2*>(D.erec + (size_t)k * kEdgeRec);
+#pragma unroll
+                    for (int i = 0; i < kEdgeRec / 2; i++) { const double2 v = src[i]; rc[2 * i] = v.x; rc[2 * i + 1] = v.y; }
+                }
+                const EdgeGeom G = edge_geom_rec(D, pose, k, rc);
+                const double ev[6] = {G.te.x, G.te.y, G.te.z, G.qe.x, G.qe.y, G.qe.z};
+                // Omega (row-major 6x6), robustified: Omega' = rho1 * Omega
+                double Om[36];
+#pragma unroll
+                for (int i = 0; i < 36; i++) Om[i] = rc[7 + i];
+                double Oe[6];
+                double chi = 0.;
+#pragma unroll
+                for (int rr = 0; rr < 6; rr++) {
+                    double sacc = 0.;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) sacc += Om[rr * 6 + c] * ev[c];
+                    Oe[rr] = sacc;
+                    chi += ev[rr] * sacc;
+                }
+                double r0 = chi, r1 = 1.;
+                if (D.robust[k]) huber(chi, delta, r0, r1);
+#pragma unroll
+                for (int i = 0; i < 36; i++) Om[i] *= r1;
+#pragma unroll
+                for (int i = 0; i < 6; i++) Oe[i] *= r1;
+                // ---- Jacobian blocks
+                const M33 Ra = qrot(G.qa);
+                const M33 Re = qrot(G.qe);
+                double A11[9], A12[9], A22[9], B22[9];
+                {
+                    double S[9], T[9];
+                    skew(G.tb.x, G.tb.y, G.tb.z, S);
+                    mat3mul(Ra.m, S, T);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) { A11[i] = -Ra.m[i]; A12[i] = 2. * T[i]; }
+                    double Sa[9], Sb[9], L[9], R[9], P[9];
+                    skew(G.qa.x, G.qa.y, G.qa.z, Sa);
+                    skew(G.qb.x, G.qb.y, G.qb.z, Sb);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) {
+                        const double id = (i % 4 == 0) ? 1. : 0.;
+                        L[i] = id * G.qb.w - Sb[i];
+                        R[i] = id * G.qa.w + Sa[i];
+                    }
+                    mat3mul(L, R, P);
+                    const double vb[3] = {G.qb.x, G.qb.y, G.qb.z}, va[3] = {G.qa.x, G.qa.y, G.qa.z};
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) A22[rr * 3 + c] = -G.s * (P[rr * 3 + c] - vb[rr] * va[c]);
+                    double Se[9];
+                    skew(G.qe.x, G.qe.y, G.qe.z, Se);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) B22[i] = ((i % 4 == 0) ? G.qe.w : 0.) + Se[i];
+                }
+                const double* B11 = Re.m;
+                // ---- W_j = Omega' Jj   (Jj = diag(B11, B22)), H_ij = Ji^T Wj: ONE code path for both sides of the edge, so that the block
+                //      row i stores and the transposed block row j stores are the same numbers
+                double Wj[36];
+#pragma unroll
+                for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        Wj[rr * 6 + c] = Om[rr * 6 + 0] * B11[0 * 3 + c] + Om[rr * 6 + 1] * B11[1 * 3 + c] + Om[rr * 6 + 2] * B11[2 * 3 + c];
+                        Wj[rr * 6 + 3 + c] = Om[rr * 6 + 3] * B22[0 * 3 + c] + Om[rr * 6 + 4] * B22[1 * 3 + c] + Om[rr * 6 + 5] * B22[2 * 3 + c];
+                    }
+                const int other = side == 0 ? D.slot_j[k] : D.slot_i[k];        // the edge's slot in the other endpoint's row (-1: that vertex is fixed)
+                if (other >= 0) {
+                    double Hij[36];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+#pragma unroll
+                        for (int rr = 0; rr < 3; rr++) {
+                            Hij[rr * 6 + c] = A11[0 * 3 + rr] * Wj[0 * 6 + c] + A11[1 * 3 + rr] * Wj[1 * 6 + c] + A11[2 * 3 + rr] * Wj[2 * 6 + c];
+                            Hij[(3 + rr) * 6 + c] = A12[0 * 3 + rr] * Wj[0 * 6 + c] + A12[1 * 3 + rr] * Wj[1 * 6 + c] + A12[2 * 3 + rr] * Wj[2 * 6 + c] +
+                                                   A22[0 * 3 + rr] * Wj[3 * 6 + c] + A22[1 * 3 + rr] * Wj[4 * 6 + c] + A22[2 * 3 + rr] * Wj[5 * 6 + c];
+                        }
+                    }
+                    double2* __restrict__ bk = reinterpret_cast<double2*>(D.blk + (size_t)s * 36);
+                    if (side == 0) {
+#pragma unroll
+                        for (int i = 0; i < 18; i++) bk[i] = make_double2(Hij[2 * i], Hij[2 * i + 1]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 18; i++) bk[i] = make_double2(Hij[((2 * i) % 6) * 6 + (2 * i) / 6], Hij[((2 * i + 1) % 6) * 6 + (2 * i + 1) / 6]);
+                    }
+                }
+                // ---- the slot's share of H_aa (upper triangle: the sum is then symmetric to the last bit) and of -b
+                if (side == 1) {                       // row j: Jj^T Wj, Jj^T Omega' e
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                        for (int c = rr; c < 6; c++)
+                            mine[tri6(rr, c)] = B11[0 * 3 + rr] * Wj[0 * 6 + c] + B11[1 * 3 + rr] * Wj[1 * 6 + c] + B11[2 * 3 + rr] * Wj[2 * 6 + c];
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                        for (int c = 3 + rr; c < 6; c++)
+                            mine[tri6(3 + rr, c)] = B22[0 * 3 + rr] * Wj[3 * 6 + c] + B22[1 * 3 + rr] * Wj[4 * 6 + c] + B22[2 * 3 + rr] * Wj[5 * 6 + c];
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++) {
+                        mine[21 + rr] = B11[0 * 3 + rr] * Oe[0] + B11[1 * 3 + rr] * Oe[1] + B11[2 * 3 + rr] * Oe[2];
+                        mine[24 + rr] = B22[0 * 3 + rr] * Oe[3] + B22[1 * 3 + rr] * Oe[4] + B22[2 * 3 + rr] * Oe[5];
+                    }
+                } else {                               // row i: W_i = Omega' Ji (reusing Wj's registers), Ji^T Wi, Ji^T Omega' e
+#pragma unroll
+                    for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            Wj[rr * 6 + c] = Om[rr * 6 + 0] * A11[0 * 3 + c] + Om[rr * 6 + 1] * A11[1 * 3 + c] + Om[rr * 6 + 2] * A11[2 * 3 + c];
+                            Wj[rr * 6 + 3 + c] = Om[rr * 6 + 0] * A12[0 * 3 + c] + Om[rr * 6 + 1] * A12[1 * 3 + c] + Om[rr * 6 + 2] * A12[2 * 3 + c] +
+                                                Om[rr * 6 + 3] * A22[0 * 3 + c] + Om[rr * 6 + 4] * A22[1 * 3 + c] + Om[rr * 6 + 5] * A22[2 * 3 + c];
+                        }
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                        for (int c = rr; c < 6; c++)
+                            mine[tri6(rr, c)] = A11[0 * 3 + rr] * Wj[0 * 6 + c] + A11[1 * 3 + rr] * Wj[1 * 6 + c] + A11[2 * 3 + rr] * Wj[2 * 6 + c];
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                        for (int c = 3 + rr; c < 6; c++)
+                            mine[tri6(3 + rr, c)] = A12[0 * 3 + rr] * Wj[0 * 6 + c] + A12[1 * 3 + rr] * Wj[1 * 6 + c] + A12[2 * 3 + rr] * Wj[2 * 6 + c] +
+                                                    A22[0 * 3 + rr] * Wj[3 * 6 + c] + A22[1 * 3 + rr] * Wj[4 * 6 + c] + A22[2 * 3 + rr] * Wj[5 * 6 + c];
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++) {
+                        mine[21 + rr] = A11[0 * 3 + rr] * Oe[0] + A11[1 * 3 + rr] * Oe[1] + A11[2 * 3 + rr] * Oe[2];
+                        mine[24 + rr] = A12[0 * 3 + rr] * Oe[0] + A12[1 * 3 + rr] * Oe[1] + A12[2 * 3 + rr] * Oe[2] +
+                                        A22[0 * 3 + rr] * Oe[3] + A22[1 * 3 + rr] * Oe[4] + A22[2 * 3 + rr] * Oe[5];
+                    }
+                }
+            }
+            __syncthreads();
+            if (rowlane) {                             // this chunk's slots of the lane's row, in slot order
+                const int q0 = ra0 > base ? ra0 : base, q1 = ra1 < base + kBlk ? ra1 : base + kBlk;
+                for (int q = q0; q < q1; q++) {
+                    const double* __restrict__ dc = sh + (size_t)(q - base) * kLaShare;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) h[c] += dc[r <= c ? tri6(r, c) : tri6(c, r)];
+                    g += dc[21 + r];
+                }
+            }
+            __syncthreads();
+        }
+        if (rowlane) {
             double* __restrict__ out = D.hdiag + (size_t)a * 36 + r * 6;
 #pragma unroll
             for (int c = 0; c < 6; c++) out[c] = h[c];
@@ -369,11 +440,13 @@ __device__ __forceinline__ void assemble_kernel_body(PgoDev D)
         }
     }
     const double m = block_max(dmax, s4);
-    if (threadIdx.x == 0) D.part_c[blockIdx.x] = m;
+    if (tid == 0) D.part_c[rb] = m;
 }
-__global__ __launch_bounds__(kBlk) void assemble_kernel(PgoDev D)
+// grid = g_rows row workgroups + g_edges chi2 workgroups
+__global__ __launch_bounds__(kBlk) void hessian_kernel(PgoDev D, const double* __restrict__ pose, double delta, int g_rows, int g_edges)
 {
-    assemble_kernel_body(D);
+    if ((int)blockIdx.x < g_rows) hessian_rows_body(D, pose, delta, blockIdx.x);
+    else chi2_kernel_body(D, pose, delta, (int)blockIdx.x - g_rows, g_edges);
 }
 
 // max |H_jj| over the assembled diagonal blocks -> part_c (sharded solve: after the all-reduce of hdiag)
@@ -634,18 +707,15 @@ __device__ __forceinline__ void residual_guard_kernel_body(PgoDev D);
 // slot twins of the device-resident LM loop (pgo_types.hpp: LmSlot / LmDev): graph = blockIdx.z, arguments from its slot, and every
 // kernel predicates itself on the graph's phase - a pass is a fixed launch sequence (uzl_pgo_lm.hip)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlk) void linearize_lm_kernel(const LmSlot* __restrict__ slots)
+// grid = the largest graph's row workgroups (g_rows_launch) + chi2 workgroups
+__global__ __launch_bounds__(kBlk) void hessian_lm_kernel(const LmSlot* __restrict__ slots, int g_rows_launch)
 {
     const LmSlot& S = slots[blockIdx.z];
     const LmDev* lm = S.lm;
-    if (lm->phase != kLmLin || (int)blockIdx.x >= S.g_edges) return;
-    linearize_kernel_body(S.D, S.pose[lm->cur], lm->delta);
-}
-__global__ __launch_bounds__(kBlk) void assemble_lm_kernel(const LmSlot* __restrict__ slots)
-{
-    const LmSlot& S = slots[blockIdx.z];
-    if (S.lm->phase != kLmLin || (int)blockIdx.x >= S.g_asm) return;
-    assemble_kernel_body(S.D);
+    if (lm->phase != kLmLin) return;
+    const int b = blockIdx.x;
+    if (b < g_rows_launch) { if (b < S.g_asm) hessian_rows_body(S.D, S.pose[lm->cur], lm->delta, b); }
+    else if (b - g_rows_launch < S.g_edges) chi2_kernel_body(S.D, S.pose[lm->cur], lm->delta, b - g_rows_launch, S.g_edges);
 }
 // the evaluation of a trial runs once its solve has ended without a breakdown (lm_tail_kernel sorts the rest out)
 __device__ __forceinline__ bool lm_evaluates(const LmDev* lm) { return lm->phase == kLmSolve && lm->flags[0] != 0 && lm->flags[2] == 0; }
@@ -663,10 +733,10 @@ __global__ __launch_bounds__(kBlk) void chi2_lm_kernel(const LmSlot* __restrict_
     if (!lm_evaluates(lm) || (int)blockIdx.x >= S.g_edges) return;
     chi2_kernel_body(S.D, S.pose[lm->cur ^ 1], lm->delta);
 }
-void kl_linearize(const LmSlot* sl, int nslots, int g_edges, int g_asm, hipStream_t s)
+hipError_t kl_linearize(const LmSlot* sl, int nslots, int g_edges, int g_asm, hipStream_t s)
 {
-    hipLaunchKernelGGL(linearize_lm_kernel, dim3(g_edges, 1, nslots), dim3(kBlk), 0, s, sl);
-    hipLaunchKernelGGL(assemble_lm_kernel, dim3(g_asm, 1, nslots), dim3(kBlk), 0, s, sl);
+    hipLaunchKernelGGL(hessian_lm_kernel, dim3(g_asm + g_edges, 1, nslots), dim3(kBlk), 0, s, sl, g_asm);
+    return hipSuccess;
 }
 void kl_eval(const LmSlot* sl, int nslots, int g_edges, int g_oplus, hipStream_t s)
 {
@@ -675,7 +745,7 @@ void kl_eval(const LmSlot* sl, int nslots, int g_edges, int g_oplus, hipStream_t
 }
 
 int g_edges_for(int e) { return grid_for(e, kBlk, kMaxPartials); }
-int g_asm_for(int nb) { return grid_for(nb, kBlk / 6, kMaxPartials); }
+
 int g_oplus_for(int n) { return grid_for(n, kBlk, kMaxPartials); }
 
 // ------------------------------------------------------------------------------------------------
@@ -705,17 +775,13 @@ int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s)
     hipLaunchKernelGGL(chi2_kernel, dim3(g), dim3(kBlk), 0, s, D, pose, delta);
     return g;
 }
-int k_linearize(const PgoDev& D, const double* pose, double delta, hipStream_t s)
+// the Hessian build (G3-G6): *g_edges chi2 partials in part_a, *g_rows diagonal maxima in part_c
+hipError_t k_hessian(const PgoDev& D, const double* pose, double delta, int* g_edges, int* g_rows, hipStream_t s)
 {
-    const int g = grid_for(D.e_end - D.e_begin, kBlk, kMaxPartials);
-    hipLaunchKernelGGL(linearize_kernel, dim3(g), dim3(kBlk), 0, s, D, pose, delta);
-    return g;
-}
-int k_assemble(const PgoDev& D, hipStream_t s)
-{
-    const int g = grid_for(D.nb, kBlk / 6, kMaxPartials);
-    hipLaunchKernelGGL(assemble_kernel, dim3(g), dim3(kBlk), 0, s, D);
-    return g;
+    *g_edges = grid_for(D.e_end - D.e_begin, kBlk, kMaxPartials);
+    *g_rows = D.n_rb;
+    hipLaunchKernelGGL(hessian_kernel, dim3(*g_rows + *g_edges), dim3(kBlk), 0, s, D, pose, delta, *g_rows, *g_edges);
+    return hipSuccess;
 }
 int k_diagmax(const PgoDev& D, hipStream_t s)
 {

@@ -6,9 +6,8 @@
 //   block-CSR of H over the free vertices ("half-edge slots"): row a holds one slot per incident
 //   system edge, sorted by edge index; slot s carries
 //       blk [s][36]   H_{a,col[s]} = J_a^T W J_col      (col = -1 when the neighbour is fixed)
-//       dcon[s][36]   this edge's share of H_aa = J_a^T W J_a
-//       gcon[s][6]    this edge's share of -b_a = J_a^T W e
-//   so assembly is a gather over contiguous slots: no atomics, bit-reproducible.
+//   and contributes its edge's share of H_aa = J_a^T W J_a and of -b_a = J_a^T W e; the Hessian build (pgo_kernels.hip: hessian_kernel)
+//   computes the shares of a row's slots side by side and adds them in slot order: no atomics, bit-reproducible, nothing but H itself in HBM.
 #pragma once
 #include <cstdint>
 #include "../../include/uzl_mi355x.h"
@@ -39,9 +38,11 @@ struct PgoDev {
     const int32_t* row_ptr;  // [nb+1]
     const int32_t* col;      // [nslots]
     const int32_t* rowhdr;   // [nb][kRowHdr] = {row_ptr[a], row_ptr[a+1], col of the first 20 slots (-1 past the end), pad}: one hop instead of two
+    const int32_t* slot_edge; // [nslots] 2 * system edge + side (0: the row is the edge's first vertex, 1: its second)
+    const int32_t* rb_ptr;    // [n_rb + 1] row blocks of the Hessian build: consecutive rows with <= 256 slots, <= 42 rows where the graph allows
+    int32_t n_rb, pad_rb;
+    const double* erec;       // [e][44] the edge's inputs as one record: Z^-1 (7) | Omega (36) | pad
     double* blk;
-    double* dcon;
-    double* gcon;
     double* hdiag;           // [nb][36]
     double* minv;            // [nb][36]  (H_aa + lambda I)^-1   (block-Jacobi path only; the multilevel path uses MlLevel::Winv)
     double* b;               // [nb][6]

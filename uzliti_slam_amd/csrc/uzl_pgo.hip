@@ -163,6 +163,8 @@ void upload_edges_common(uzl_pgo* h)
 {
     hipStream_t s = h->stream;
     const int e = h->e;
+    h->d_erec.reserve((size_t)std::max(e, 1) * 44);
+    k_edge_records(h->d_zinv.p, h->d_info.p, e, h->d_erec.p, s);       // (values, not structure: also when the structure is kept)
     if (e > 0) {
         std::vector<int32_t> ei((size_t)e), ej((size_t)e);
         for (int k = 0; k < e; k++) { ei[k] = h->ij[2 * k]; ej[k] = h->ij[2 * k + 1]; }
@@ -592,28 +594,45 @@ void build_structure(uzl_pgo* h)
     const int nslots = row_ptr[nb];
     h->nslots = nslots;
     std::vector<int32_t> fill(row_ptr.begin(), row_ptr.end() - 1);
-    std::vector<int32_t> col((size_t)std::max(nslots, 1)), slot_i((size_t)std::max(e, 1)), slot_j((size_t)std::max(e, 1));
+    std::vector<int32_t> col((size_t)std::max(nslots, 1)), slot_i((size_t)std::max(e, 1)), slot_j((size_t)std::max(e, 1)), slot_edge((size_t)std::max(nslots, 1));
     for (int k = 0; k < e; k++) {
         const int a = v2b[h->ij[2 * k]], b = v2b[h->ij[2 * k + 1]];
         slot_i[k] = -1; slot_j[k] = -1;
-        if (a >= 0) { const int s = fill[a]++; slot_i[k] = s; col[s] = b; }
-        if (b >= 0) { const int s = fill[b]++; slot_j[k] = s; col[s] = a; }
+        if (a >= 0) { const int s = fill[a]++; slot_i[k] = s; col[s] = b; slot_edge[s] = 2 * k; }
+        if (b >= 0) { const int s = fill[b]++; slot_j[k] = s; col[s] = a; slot_edge[s] = 2 * k + 1; }
     }
     hipStream_t s = h->stream;
     const size_t nbz = std::max(nb, 1), nsz = std::max(nslots, 1);
     h->d_b2v.reserve(nbz); h->d_row_ptr.reserve(nbz + 1); h->d_col.reserve(nsz);
-    h->d_blk.reserve(nsz * 36); h->d_dcon.reserve(nsz * 36); h->d_gcon.reserve(nsz * 6);
+    h->d_blk.reserve(nsz * 36); h->d_slot_edge.reserve(nsz);
     h->d_hdiag.reserve(nbz * 42); h->d_minv.reserve(nbz * 36);              // [H_aa | b] contiguous: one all-reduce when sharded
     h->d_x.reserve(nbz * 6); h->d_xs.reserve(nbz * 6); h->d_r.reserve(nbz * 6); h->d_z.reserve(nbz * 6); h->d_p.reserve(nbz * 6); h->d_p2.reserve(nbz * 6); h->d_ap.reserve(nbz * 12 + kMaxPartials);   // [A p | restricted A p | partials]
     if (n > 0) UZL_HIP(hipMemcpyAsync(h->d_v2b.p, v2b.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
     if (nb > 0) UZL_HIP(hipMemcpyAsync(h->d_b2v.p, b2v.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, s));
     UZL_HIP(hipMemcpyAsync(h->d_row_ptr.p, row_ptr.data(), sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice, s));
     if (nslots > 0) UZL_HIP(hipMemcpyAsync(h->d_col.p, col.data(), sizeof(int32_t) * nslots, hipMemcpyHostToDevice, s));
+    if (nslots > 0) UZL_HIP(hipMemcpyAsync(h->d_slot_edge.p, slot_edge.data(), sizeof(int32_t) * nslots, hipMemcpyHostToDevice, s));
     std::vector<int32_t> rowhdr((size_t)nbz * kRowHdr, -1);
     for (int a = 0; a < nb; a++) {
         rowhdr[(size_t)a * kRowHdr] = row_ptr[a]; rowhdr[(size_t)a * kRowHdr + 1] = row_ptr[a + 1];
         for (int k = 0; k < 20 && row_ptr[a] + k < row_ptr[a + 1]; k++) rowhdr[(size_t)a * kRowHdr + 2 + k] = col[row_ptr[a] + k];
     }
+    // row blocks of the Hessian build: consecutive rows with <= 256 slots and <= 42 rows, so that a workgroup makes one pass (a row with
+    // more slots is a block of its own and loops); beyond kMaxPartials blocks (> ~1M slots) blocks hold more and loop as well
+    std::vector<int32_t> rb_ptr(1, 0);
+    {
+        const int cap_slots = std::max(256, (int)(((int64_t)nslots + kMaxPartials / 2 - 1) / (kMaxPartials / 2) + 255) / 256 * 256);
+        const int cap_rows = std::max(42, (nb + kMaxPartials / 2 - 1) / (kMaxPartials / 2));
+        int rows = 0, slots = 0;
+        for (int a = 0; a < nb; a++) {
+            const int d = row_ptr[a + 1] - row_ptr[a];
+            if (rows > 0 && (rows >= cap_rows || slots + d > cap_slots)) { rb_ptr.push_back(a); rows = 0; slots = 0; }
+            rows++; slots += d;
+        }
+        rb_ptr.push_back(nb);
+    }
+    h->d_rb_ptr.reserve(rb_ptr.size());
+    UZL_HIP(hipMemcpyAsync(h->d_rb_ptr.p, rb_ptr.data(), sizeof(int32_t) * rb_ptr.size(), hipMemcpyHostToDevice, s));
     h->d_rowhdr.reserve(nbz * kRowHdr);
     UZL_HIP(hipMemcpyAsync(h->d_rowhdr.p, rowhdr.data(), sizeof(int32_t) * nbz * kRowHdr, hipMemcpyHostToDevice, s));
     if (e > 0) {
@@ -621,11 +640,7 @@ void build_structure(uzl_pgo* h)
         UZL_HIP(hipMemcpyAsync(h->d_slot_j.p, slot_j.data(), sizeof(int32_t) * e, hipMemcpyHostToDevice, s));
     }
     // blocks of slots whose neighbour is fixed are never written: keep them defined
-    if (nslots > 0) {
-        UZL_HIP(hipMemsetAsync(h->d_blk.p, 0, sizeof(double) * 36 * (size_t)nslots, s));
-        UZL_HIP(hipMemsetAsync(h->d_dcon.p, 0, sizeof(double) * 36 * (size_t)nslots, s));   // slots of edges other ranks own stay 0
-        UZL_HIP(hipMemsetAsync(h->d_gcon.p, 0, sizeof(double) * 6 * (size_t)nslots, s));
-    }
+    if (nslots > 0) UZL_HIP(hipMemsetAsync(h->d_blk.p, 0, sizeof(double) * 36 * (size_t)nslots, s));      // (and slots of edges other ranks own stay 0)
     UZL_HIP(hipStreamSynchronize(s));       // host vectors go out of scope
     PgoDev& D = h->D;
     D.n = n; D.nb = nb; D.e = e; D.nslots = nslots;
@@ -633,7 +648,7 @@ void build_structure(uzl_pgo* h)
     D.v2b = h->d_v2b.p; D.b2v = h->d_b2v.p; D.ei = h->d_ei.p; D.ej = h->d_ej.p;
     D.zinv = h->d_zinv.p; D.info = h->d_info.p; D.robust = h->d_robust.p;
     D.slot_i = h->d_slot_i.p; D.slot_j = h->d_slot_j.p; D.row_ptr = h->d_row_ptr.p; D.col = h->d_col.p; D.rowhdr = h->d_rowhdr.p;
-    D.blk = h->d_blk.p; D.dcon = h->d_dcon.p; D.gcon = h->d_gcon.p; D.hdiag = h->d_hdiag.p; D.minv = h->d_minv.p;
+    D.slot_edge = h->d_slot_edge.p; D.rb_ptr = h->d_rb_ptr.p; D.n_rb = (int32_t)rb_ptr.size() - 1; D.pad_rb = 0; D.erec = h->d_erec.p; D.blk = h->d_blk.p; D.hdiag = h->d_hdiag.p; D.minv = h->d_minv.p;
     D.b = h->d_hdiag.p + (size_t)nb * 36; D.x = h->d_x.p; D.xs = h->d_xs.p; D.r = h->d_r.p; D.z = h->d_z.p; D.p = h->d_p.p; D.ap = h->d_ap.p;
     D.part_a = h->d_ap.p + (size_t)nbz * 12; D.part_b = h->d_part_b.p; D.part_c = h->d_part_c.p;
     D.scal = h->d_scal.p; D.flags = h->d_flags.p;
@@ -681,7 +696,7 @@ void build_structure(uzl_pgo* h)
             Dp.nb = P.nbr; Dp.nslots = P.nslots_r; Dp.b2v = Rd.b2v.p; Dp.row_ptr = Rd.row_ptr.p; Dp.col = Rd.col.p; Dp.rowhdr = Rd.rowhdr.p;
             Dp.blk = Rd.blk.p; Dp.hdiag = Rd.hdiag.p; Dp.minv = Rd.minv.p; Dp.b = Rd.hdiag.p + (size_t)P.nbr * 36;
             Dp.x = Rd.x.p; Dp.xs = Rd.xs.p; Dp.r = Rd.r.p; Dp.z = Rd.z.p; Dp.p = Rd.p.p; Dp.ap = Rd.ap.p; Dp.part_a = Rd.ap.p + nr * 12;
-            Dp.dcon = nullptr; Dp.gcon = nullptr;                              // the reduced system is assembled by schur_assemble_kernel
+            Dp.slot_edge = nullptr;                                           // the reduced system is assembled by schur_assemble_kernel
             rrow_ptr.swap(P.row_ptr); rcol.swap(P.col);
         }
     }
@@ -955,8 +970,7 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         }
         D.pose = h->cur; D.pose_trial = h->trial;
         Dp.pose = h->cur; Dp.pose_trial = h->trial;
-        { Timed t(h, "linearize"); gl = k_linearize(D, h->cur, delta, s); }     // computeActiveErrors + buildSystem
-        { Timed t(h, "assemble"); ga = k_assemble(D, s); }
+        { Timed t(h, "linearize"); UZL_HIP(k_hessian(D, h->cur, delta, &gl, &ga, s)); }     // computeActiveErrors + buildSystem
         if (h->sharded) {                                                         // H_aa, b: sums over all ranks' edges
             shard_allreduce(h, h->d_hdiag.p, (int64_t)h->nb * 42);
             ga = k_diagmax(D, s);

@@ -83,7 +83,7 @@ void reserve_slots(LmRun* R, int n)
 void enq_head(LmRun* R, int pass_flags, hipStream_t s)
 {
     const LmShape& sh = R->shape;
-    kl_linearize(R->d_slots.p, sh.nslots, sh.g_edges, sh.g_asm, s);
+    UZL_HIP(kl_linearize(R->d_slots.p, sh.nslots, sh.g_edges, sh.g_asm, s));
     k_lm_head(R->d_slots.p, sh.nslots, pass_flags, s);
     if (sh.red) kl_schur_reduce(R->d_slots.p, sh.nslots, sh.schur_runs, (long)sh.schur_items, s);
 }
@@ -135,7 +135,7 @@ LmSlot make_slot(const uzl_pgo* h, LmDev* d_lm, LmHost* d_pub)
     }
     S.pbuf[0] = h->pbuf[0]; S.pbuf[1] = h->pbuf[1];
     S.pose[0] = h->pose_a.p; S.pose[1] = h->pose_b.p;
-    S.g_edges = g_edges_for(h->e); S.g_asm = g_asm_for(h->nb); S.g_oplus = g_oplus_for(h->n);
+    S.g_edges = g_edges_for(h->e); S.g_asm = h->D.n_rb; S.g_oplus = g_oplus_for(h->n);
     S.g_rows = g_ml_rows(h->Dp.nb, h->ml_agg); S.g_spmv = g_ml_spmv(h->Dp.nb, h->ml_agg);
     S.copy_stride = (int64_t)h->ml_copy_stride;
     return S;
@@ -155,7 +155,7 @@ LmShape make_shape(const std::vector<uzl_pgo*>& hs, int nslots, bool batch_geome
     for (const uzl_pgo* g : hs) {
         for (int l = 0; l <= g->ml_levels; l++) { sh.n_lv[l] = std::max(sh.n_lv[l], g->ml_n[l]); sh.work_t[l] = std::max(sh.work_t[l], g->ml_nslots[l] + g->ml_n[l]); }
         sh.inner_aggs = std::max(sh.inner_aggs, g->ml_inner_aggs);
-        sh.g_edges = std::max(sh.g_edges, g_edges_for(g->e)); sh.g_asm = std::max(sh.g_asm, g_asm_for(g->nb)); sh.g_oplus = std::max(sh.g_oplus, g_oplus_for(g->n));
+        sh.g_edges = std::max(sh.g_edges, g_edges_for(g->e)); sh.g_asm = std::max(sh.g_asm, g->D.n_rb); sh.g_oplus = std::max(sh.g_oplus, g_oplus_for(g->n));
         sh.g_rows = std::max(sh.g_rows, g_ml_rows(g->Dp.nb, g->ml_agg)); sh.g_spmv = std::max(sh.g_spmv, g_ml_spmv(g->Dp.nb, g->ml_agg));
         if (g->red.on) {
             const SchurDev& SD = g->red.S;
