@@ -546,8 +546,8 @@ def main():
                                               "2-NN Hamming + %d-hypothesis PROSAC, early exit off" % (per_rank, a.keypoints, a.hypotheses)),
                          upload_inclusive=dict(value=round(dist.sum(float(per_rank)) / t_incl, 1), unit="pairs/s", ms=round(1e3 * t_incl, 3),
                                                add_frames_call_ms=round(1e3 * t_h2d_bulk, 3), h2d_mbytes=round(2e-6 * per_rank * a.keypoints * (32 + 24 + 1), 1),
-                                               add_frames_gbytes_per_s=round(2e-9 * per_rank * a.keypoints * (32 + 24 + 1) / max(t_h2d_bulk, 1e-9), 2),
-                                               add_frames_note="the call returns when the frames are packed and the last DMA is enqueued; `ms` runs until the results are back",
+                                               add_frames_enqueue_gbytes_per_s=round(2e-9 * per_rank * a.keypoints * (32 + 24 + 1) / max(t_h2d_bulk, 1e-9), 2),
+                                               add_frames_note="an ENQUEUE rate, not transfer bandwidth: the call returns when the frames are packed and the last DMA (up to 32 MB) is enqueued; `ms` (upload + one estimate) runs until the results are back",
                                                one_add_frame_per_frame=dict(value=round(dist.sum(float(per_rank)) / t_incl_single, 1), unit="pairs/s", ms=round(1e3 * t_incl_single, 3),
                                                                             note="uzl_match_add_frame once per frame through ctypes, as round 2 measured it"),
                                                note="uzl_match_add_frames of all %d frames from pageable host memory (threads pack into pinned staging, one DMA per 32 MB) + one "

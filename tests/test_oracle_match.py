@@ -227,3 +227,35 @@ def test_vote_recipe_fused_vs_reference_order(oracle):
     assert tests > 4e7
     assert diffs == 0, (diffs, tests)
     assert margin > 1e-13            # the closest any point came to the threshold: orders of magnitude above the recipes' ~1e-16 m difference
+
+
+def test_hamming_primitive_vs_reference_hammingsse(oracle):
+    """Known-answer pin from the REFERENCE ITSELF: graph_slam_common/thirdparty/include/graph_slam_tools/hammingsse.hpp:60-160 (cv::HammingSse)
+    is the one source file near the hot path that compiles without ROS / OpenCV / PCL / g2o; oracle/Makefile (target `ref`) builds it from
+    where it lies into oracle/_ref/libref_hamming.so.  The oracle's 2-NN distances (M1) must be that functor's for the same bytes.  This
+    pins the Hamming primitive only - parity of the whole path stays unpinned."""
+    import ctypes
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_hamming.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_hamming.so not built (make -C oracle ref, where /root/reference exists)")
+    ref = ctypes.CDLL(so)
+    ref.ref_hamming.restype = ctypes.c_int
+    ref.ref_hamming.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    rng = np.random.default_rng(2024)
+    for nbytes in (32, 64, 16):
+        # 16-byte aligned rows (the functor uses aligned 128-bit loads)
+        def aligned(n):
+            raw = np.zeros(n * nbytes + 16, np.uint8)
+            off = (-raw.ctypes.data) % 16
+            return raw[off:off + n * nbytes].reshape(n, nbytes)
+        q = aligned(40); t = aligned(57)
+        q[:] = rng.integers(0, 256, q.shape, dtype=np.uint8); t[:] = rng.integers(0, 256, t.shape, dtype=np.uint8)
+        t[3] = q[5]; t[9] = ~q[5]; q[7] = 0; t[11] = 255              # distance 0, all bits, sparse / dense rows
+        want = np.array([[ref.ref_hamming(q[i].ctypes.data, t[j].ctypes.data, nbytes) for j in range(len(t))] for i in range(len(q))])
+        assert np.array_equal(want, np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(axis=2))
+        i0, d0, i1, d1 = oracle.knn2(np.ascontiguousarray(q), np.ascontiguousarray(t))
+        srt = np.sort(want, axis=1)
+        assert np.array_equal(d0, srt[:, 0]) and np.array_equal(d1, srt[:, 1])
+        assert np.array_equal(want[np.arange(len(q)), i0], d0) and np.array_equal(want[np.arange(len(q)), i1], d1)
+

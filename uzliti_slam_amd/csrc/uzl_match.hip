@@ -89,6 +89,15 @@ constexpr size_t kBulkHalf = 32u << 20;       // bytes per half of the add_frame
 
 // ---- frame arena: first-fit free list over one growing HBM allocation.  The reference removes and merges nodes all the time
 // (graph_slam_node.cpp:665-777); a store that only reclaims space when it is empty leaks HBM in a long-running node.
+// grows the arena to hold arena_used; if that throws (out of memory) the extents just handed out go back - the caller's frames were not
+// registered, so nothing refers to them
+template <class Undo>
+void arena_grow(uzl_match* h, Undo&& undo)
+{
+    try { h->arena.reserve(h->arena_used, /*keep=*/true, h->stream); }
+    catch (...) { undo(); throw; }
+}
+
 size_t arena_alloc(uzl_match* h, size_t size)
 {
     size = align_up(size, 256);
@@ -464,7 +473,7 @@ int uzl_match_add_frame(uzl_match* h, const uzl_frame* f, int32_t* frame_id)
         return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
     }
     frame_layout(n, (size_t)f->bytes_per_desc, r, base);
-    h->arena.reserve(h->arena_used, /*keep=*/true, h->stream);
+    arena_grow(h, [&]() { h->arena_used = used_before; h->free_list = free_before; });
     if (n) {
         const size_t span = r.valid_off + val_b - r.desc_off;        // [desc | pad | pos | pad | valid] as it lies in the arena
         if (span <= kUpHalf) {
@@ -536,7 +545,7 @@ int uzl_match_add_frames(uzl_match* h, int32_t n_frames, const uzl_frame* f, int
         h->arena_used = used_before; h->free_list = free_before;
         return fail(h, UZL_ERR_BUSY, "arena must grow while a batch is in flight");
     }
-    h->arena.reserve(h->arena_used, /*keep=*/true, h->stream);
+    arena_grow(h, [&]() { h->arena_used = used_before; h->free_list = free_before; });
     for (int32_t k = 0; k < n_frames; k++) {
         FrameRec& r = recs[k];
         r.alive = true; r.n = f[k].n; r.words = f[k].bytes_per_desc / 4; r.feature_type = f[k].feature_type; r.sensor_frame = f[k].sensor_frame;
@@ -670,7 +679,7 @@ int uzl_match_add_frames_wire(uzl_match* h, int32_t n_frames, const uzl_wire_sen
         recs[k].desc_off += base; recs[k].pos_off += base; recs[k].valid_off += base; recs[k].ext_off += base;
         segs[k].desc_off += base; segs[k].pos_off += base; segs[k].valid_off += base;
     }
-    h->arena.reserve(h->arena_used, /*keep=*/true, h->stream);
+    arena_grow(h, undo_alloc);
     h->d_wire_stage.reserve((size_t)(src / 4) + 8);                              // + tail: the 16 bytes after the last record may be read
     h->d_wire_segs.reserve((size_t)n_frames + 1);
     h->d_wire_bad.reserve(1);
