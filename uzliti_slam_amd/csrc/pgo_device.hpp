@@ -365,6 +365,11 @@ __device__ __forceinline__ void spd_inverse6_rs(double* A, double* out)
 // mt / mr: largest |x - xs| over the translation / rotation components; rz: r.M^-1 r of the iteration that ended at the look.
 // ------------------------------------------------------------------------------------------------
 constexpr double kProgressSafety = 2., kProgressQMax = 0.95;
+// The extrapolation |e_k| ~ q / (1 - q) |s| holds while CG contracts.  CG is not monotone: on a stiff system x can sit almost still for a
+// window while far from the solution (a plateau: the Ritz values have not found the soft modes yet), r.M^-1 r barely moves, q ~ 1 - and a
+// tiny |s| would pass for convergence.  A window that contracted by less than this is not trusted: the solve goes on until contraction
+// resumes (or the relative floor ends it).  With the multilevel operator q is 0.2 - 0.7 on the BASELINE graphs: no look is lost there.
+constexpr double kProgressQTrust = 0.9;
 // (below residual_guard_kernel's 0.25 - kResidualGuard, uzl_pgo.hip - by more than the two kernels' different summation orders can move
 //  the ratio: a solve the look lets go at 0.2499 must not read 0.2501 there)
 constexpr double kProgressResidual = 0.2;
@@ -372,21 +377,23 @@ __device__ __forceinline__ void progress_decide(PgoDev D, double mt, double mr, 
 {
     const double rz_prev = D.scal[11];
     double q = (rz_prev > 0. && rz >= 0.) ? sqrt(rz / rz_prev) : kProgressQMax;
+    const bool trusted = q <= kProgressQTrust;
     q = fmin(q, kProgressQMax);
     const double gain = kProgressSafety * q / (1. - q);
     const double et = gain * mt, er = gain * mr;
     D.scal[11] = rz; D.scal[14] = et; D.scal[15] = er;
-    if (et <= D.scal[12] && er <= D.scal[13] && rz >= 0.) D.flags[0] = 1;
+    if (trusted && et <= D.scal[12] && er <= D.scal[13] && rz >= 0.) D.flags[0] = 1;
 }
 // m: largest movement in units of the accuracy asked for; rr: |r|^2
 __device__ __forceinline__ void progress_decide_ml(PgoDev D, double m, double rr, double rz)
 {
     const double rz_prev = D.scal[11];
     double q = (rz_prev > 0. && rz >= 0.) ? sqrt(rz / rz_prev) : kProgressQMax;
+    const bool trusted = q <= kProgressQTrust;
     q = fmin(q, kProgressQMax);
     const double est = (kProgressSafety * q / (1. - q)) * m;
     D.scal[11] = rz; D.scal[15] = est;
-    if (est <= 1. && rr <= kProgressResidual * D.scal[14] && rz >= 0.) D.flags[0] = 1;
+    if (trusted && est <= 1. && rr <= kProgressResidual * D.scal[14] && rz >= 0.) D.flags[0] = 1;
 }
 // 1 / (accuracy asked for), for the movement of component `comp` of a row (0..2 translation [m], 3..5 rotation [q_xyz])
 __device__ __forceinline__ double progress_unit(const double* __restrict__ scal, int comp)
