@@ -136,3 +136,34 @@ def test_two_ranks_equal_one_rank(capi, tmp_path):
     assert np.array_equal(z["poses"], o.poses)
     assert len(o.solves) >= 4 and int(o.f_sticky.sum()) > 0
     o.close()
+
+
+def test_online_two_ranks_native(capi, tmp_path):
+    """Config 5's multi-process path with ONE GPU PER RANK (skipped on a one-GPU box; the first multi-GPU box validates it by itself):
+    pair jobs sharded per batch over two devices, gate / filter / solver on rank 0.  Outcome identical to the one-rank run, bit for bit."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    if capi.device_count() < 2:
+        pytest.skip("needs two GPUs (one process per GPU)")
+    n_nodes, n_pairs, n_kp = 1200, 300, 200
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UZL_ONE_GPU_PER_RANK="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "two_ranks_native.npz")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(here, "_online_worker.py"), out, str(n_nodes), str(n_pairs), str(n_kp)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "ONLINE_OK world=2 rank=0 device=0" in r.stdout and "ONLINE_OK world=2 rank=1 device=1" in r.stdout
+    z = np.load(out)
+    run = synth.make_online_run(n_nodes, n_pairs, n_kp=n_kp)
+    o = online.OnlineSlam(run, match_batch=300, lm_iterations=6, match_cfg=dict(ransac_iteration=100))
+    o.upload_frames()
+    o.run_all()
+    assert np.array_equal(z["consensus"], o.results["consensus"]) and np.array_equal(z["T"], o.results["T"])
+    assert np.array_equal(z["accept"], np.array(o.accept_log)) and np.array_equal(z["poses"], o.poses)
+    o.close()
+

@@ -40,7 +40,8 @@ class InProcessAllReduce:
 
 
 @pytest.mark.parametrize("n,e,world", [(300, 1200, 2), (1000, 5000, 2), (600, 2500, 3), (3000, 12000, 2), (10000, 50000, 2),   # BASELINE config 4 at its size
-                                       (13000, 16000, 2)])        # the ml_alpha_kernel path (12k .. 21.8k vertices)
+                                       (13000, 16000, 2),        # the ml_alpha_kernel path (12k .. 21.8k vertices)
+                                       (2000, 2040, 2), (20000, 21800, 2), (5000, 5400, 3)])      # chain-like: chain interiors Schur-eliminated by every rank
 def test_sharded_equals_unsharded(capi, oracle, n, e, world):
     g = synth.make_pose_graph(n, e, seed=n + world)
     ref = capi.Pgo()
@@ -75,6 +76,7 @@ def test_sharded_equals_unsharded(capi, oracle, n, e, world):
     for r in range(world):
         poses, st, err = out[r]
         assert st["status"] == 0 and st["iterations_done"] == st_ref["iterations_done"]
+        assert st["n_eliminated"] == st_ref["n_eliminated"] and (st["n_eliminated"] > 0) == (e < 2 * n)      # the sharded solve reduces what the plain one does
         assert abs(st["chi2_initial"] - st_ref["chi2_initial"]) <= 1e-9 * st_ref["chi2_initial"]
         assert st["exchange_calls"] == ar.calls and st["exchange_ms"] > 0          # uzl_pgo_stats accounts for the exchange
         dt, dr = synth.pose_errors(poses.reshape(-1, 3, 4), poses_ref.reshape(-1, 3, 4))
@@ -136,3 +138,44 @@ def test_native_rccl_world1(capi, n, e):
     exchange step of a solve with world_size 1.  Must equal the plain solve; the same graph through the callback path must give
     the same bits (identical arithmetic, only the transport differs)."""
     assert "RCCL_NATIVE_OK" in _rccl_child("native", n, e)
+
+
+def _torchrun(worker, nproc, *args, timeout=900):
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(here, worker)] + [str(a) for a in args],
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("n,e", [(3000, 12000), (10000, 50000), (20000, 21800)])
+def test_native_rccl_world2(capi, oracle, tmp_path, n, e):
+    """SURVEY 8(e) row 3 on REAL links: two processes, two GPUs, the handle-owned RCCL communicator with world_size 2 - ncclAllReduce
+    between ranks on every exchange step (per linearisation, per LM trial, per PCG iteration).  Skipped on a one-GPU box: the first
+    multi-GPU box that runs the suite validates the path by itself.  Every rank must end with bit-identical poses (same numbers after
+    every exchange, same scalar logic), within the north-star bar of the oracle's direct solve, and - for the chain-like graph - with its
+    chain interiors Schur-eliminated."""
+    if capi.device_count() < 2:
+        pytest.skip("needs two GPUs (one process per GPU, RCCL between them)")
+    its = 6
+    out = str(tmp_path / "w2")
+    stdout = _torchrun("_rccl_world2_worker.py", 2, out, n, e, its)
+    assert stdout.count("RCCL_WORLD_OK world=2") == 2
+    z0, z1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    assert np.array_equal(z0["poses"], z1["poses"]) and int(z0["pcg"]) == int(z1["pcg"]) and int(z0["trials"]) == int(z1["trials"])
+    g = synth.make_pose_graph(n, e, seed=5)
+    fl = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, _ = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=its)
+    dt, dr = synth.pose_errors(z0["poses"].reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+    assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+    if e < 2 * n:
+        assert int(z0["n_eliminated"]) > 0
+

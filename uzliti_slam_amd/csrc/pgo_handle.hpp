@@ -61,6 +61,7 @@ void k_edge_records(const double* zinv, const double* info, int e, double* rec, 
 int g_oplus_for(int n);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
+void k_schur_gather(const PgoDev& D, const SchurDev& S, hipStream_t s);
 void k_schur_eliminate(const PgoDev& D, const SchurDev& S, hipStream_t s);
 void k_schur_assemble(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s);
 void k_schur_backsub(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s);
@@ -122,7 +123,7 @@ struct uzl_pgo {
         bool on = false;
         int32_t n_int = 0, n_runs = 0, longest_run = 0;
         DevBuf<int32_t> run_ptr, run_rows, slotP, slotN, endL, endR, sep_rows, rsrc, inc_ptr, inc, row_ptr, col, rowhdr, b2v;
-        DevBuf<double> elim, runout, blk, hdiag, minv, x, xs, r, z, p, p2, ap;
+        DevBuf<double> elim, runout, runblk, blk, hdiag, minv, x, xs, r, z, p, p2, ap;
         SchurDev S;
     } red;
     int prev_pcg_iters = 0;

@@ -162,14 +162,16 @@ __device__ __forceinline__ void schur_eliminate_kernel_body(PgoDev D, SchurDev S
     const bool hasR = S.endR[run] >= 0;
     double dupd = 0., gupd = 0.;              // D'_m - (H_mm + lambda I), g'_m - b_m: what the eliminated predecessor left
     double accSL = 0., accgL = 0., cval = 0.;
-    if (hasL && act) cval = D.blk[(size_t)S.slotP[p0] * 36 + c * 6 + r];          // C_1 = H_{s0,v1} = H_{v1,s0}^T
+    // (sharded solve: the chain blocks come summed over the ranks - schur_gather_kernel + one all-reduce per linearisation)
+    const double* __restrict__ cblk = S.runblk ? S.runblk + (size_t)(S.n_int + run) * 36 : D.blk + (size_t)(hasL ? S.slotP[p0] : 0) * 36;
+    if (hasL && act) cval = cblk[c * 6 + r];                                      // C_1 = H_{s0,v1} = H_{v1,s0}^T
     for (int p = p0; p < p1; p++) {
         const int v = S.run_rows[p];
         const int sn = S.slotN[p];
         const bool hasN = sn >= 0 && (p + 1 < p1 || hasR);
         if (act) {
             sD[lane] = D.hdiag[(size_t)v * 36 + lane] + ((r == c) ? lambda : 0.) + dupd;
-            sE[lane] = hasN ? D.blk[(size_t)sn * 36 + lane] : 0.;
+            sE[lane] = hasN ? (S.runblk ? S.runblk[(size_t)p * 36 + lane] : D.blk[(size_t)sn * 36 + lane]) : 0.;
             sC[lane] = cval;
         }
         if (vec) sg[lane] = D.b[(size_t)v * 6 + lane] + gupd;
@@ -226,6 +228,7 @@ __device__ __forceinline__ void schur_assemble_kernel_body(PgoDev D, PgoDev R, S
             const int code = -src - 1, run = code >> 1, side = code & 1;
             const double* __restrict__ F = S.runout + (size_t)run * kSchurRunOut + 84;
             v = side == 0 ? F[k] : F[kt];
+            if (!D.diag_owner) v = 0.;                 // sharded solve: every rank eliminated the run - its fill block enters the summed A p once
         }
         R.blk[(size_t)item * 36 + k] = v;
         return;
@@ -289,6 +292,17 @@ __device__ __forceinline__ void schur_backsub_kernel_body(PgoDev D, PgoDev R, Sc
     }
 }
 
+// sharded solve: this rank's share of the runs' chain blocks (zero where another rank linearised the edge) into one contiguous buffer
+__global__ __launch_bounds__(kBlk) void schur_gather_kernel(PgoDev D, SchurDev S)
+{
+    const long t = (long)blockIdx.x * kBlk + threadIdx.x;
+    const long item = t / 36; const int k = (int)(t % 36);
+    if (item >= S.n_int + S.n_runs) return;
+    int slot;
+    if (item < S.n_int) slot = S.slotN[item];
+    else { const int run = (int)(item - S.n_int); slot = S.endL[run] >= 0 ? S.slotP[S.run_ptr[run]] : -1; }
+    S.runblk[item * 36 + k] = slot >= 0 ? D.blk[(size_t)slot * 36 + k] : 0.;
+}
 __global__ __launch_bounds__(64) void schur_eliminate_kernel(PgoDev D, SchurDev S) { schur_eliminate_kernel_body(D, S); }
 __global__ __launch_bounds__(kBlk) void schur_assemble_kernel(PgoDev D, PgoDev R, SchurDev S) { schur_assemble_kernel_body(D, R, S); }
 __global__ __launch_bounds__(64) void schur_backsub_kernel(PgoDev D, PgoDev R, SchurDev S) { schur_backsub_kernel_body(D, R, S); }
@@ -343,6 +357,11 @@ extern "C" int uzl_pgo_schur_plan(int32_t nb, const int32_t* row_ptr, const int3
 
 namespace uzl {
 
+void k_schur_gather(const PgoDev& D, const SchurDev& S, hipStream_t s)
+{
+    const long items = (long)(S.n_int + S.n_runs) * 36;
+    if (items > 0 && S.runblk) hipLaunchKernelGGL(schur_gather_kernel, dim3((unsigned)((items + kBlk - 1) / kBlk)), dim3(kBlk), 0, s, D, S);
+}
 void k_schur_eliminate(const PgoDev& D, const SchurDev& S, hipStream_t s)
 {
     if (S.n_runs > 0) hipLaunchKernelGGL(schur_eliminate_kernel, dim3(S.n_runs), dim3(64), 0, s, D, S);

@@ -160,6 +160,8 @@ struct SchurDev {
     const int32_t* rsrc;        // [nslots_r] >= 0: slot of the full system whose block is copied; < 0: -(2 run + side) - 1, fill block F (side 0) / F^T (side 1)
     const int32_t* inc_ptr;     // [nbr+1] runs incident to each reduced row
     const int32_t* inc;         // 4 run + side: 0 = row is s0 (S_L, g_L), 1 = row is s1 (S_R, g_R), 2 = s0 == s1 (S_L + S_R + F + F^T, g_L + g_R)
+    double* runblk;             // sharded solve: [n_int + n_runs][36] the runs' chain blocks (E_m per eliminated vertex, then C_1 per run) summed
+                                //                over the ranks - every rank holds only its own edges' blocks; null = read them from PgoDev::blk
     double* elim;               // [n_int][kSchurElim]
     double* runout;             // [n_runs][kSchurRunOut]
 };

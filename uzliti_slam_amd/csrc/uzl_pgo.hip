@@ -654,7 +654,7 @@ void build_structure(uzl_pgo* h)
     D.scal = h->d_scal.p; D.flags = h->d_flags.p;
     D.e_begin = 0; D.e_end = e; D.diag_owner = 1; D.sibling0 = 1;      // sibling0 finalised after build_ml
     // ---- Schur reduction of the chain interiors (pgo_schur.hpp): when a third or more of the free vertices carry nothing but their two
-    //      chain edges, the PCG runs on the Schur complement over the others.  Not with a sharded solve (its ranks hold partial blocks).
+    //      chain edges, the PCG runs on the Schur complement over the others (sharded solves included: see SchurDev::runblk).
     uzl_pgo::Reduced& Rd = h->red;
     Rd.on = false; Rd.n_int = 0; Rd.n_runs = 0; Rd.longest_run = 0;
     PgoDev& Dp = h->Dp;
@@ -663,7 +663,7 @@ void build_structure(uzl_pgo* h)
     static const int schur_min_pct = diag_int("UZL_SCHUR_MIN_PCT", 33);
     const bool may_shard = h->allreduce != nullptr || h->rccl_comm != nullptr;
     std::vector<int32_t> rrow_ptr, rcol;
-    if (h->cfg.schur_reduce >= 0 && schur_diag && !may_shard && nb > 0) {
+    if (h->cfg.schur_reduce >= 0 && schur_diag && nb > 0) {
         tick("block-CSR + uploads");
         SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap);
         tick("Schur plan");
@@ -692,6 +692,11 @@ void build_structure(uzl_pgo* h)
             S.n_runs = P.n_runs; S.n_int = P.n_int; S.nbr = P.nbr; S.nslots_r = P.nslots_r;
             S.run_ptr = Rd.run_ptr.p; S.run_rows = Rd.run_rows.p; S.slotP = Rd.slotP.p; S.slotN = Rd.slotN.p; S.endL = Rd.endL.p; S.endR = Rd.endR.p;
             S.sep_rows = Rd.sep_rows.p; S.rsrc = Rd.rsrc.p; S.inc_ptr = Rd.inc_ptr.p; S.inc = Rd.inc.p; S.elim = Rd.elim.p; S.runout = Rd.runout.p;
+            // Sharded solve: a run is eliminated by EVERY rank (the reduced system's diagonal blocks and right-hand side are then complete
+            // everywhere, like H_aa | b after its all-reduce), so each needs the run's chain blocks whole - one more all-reduce per
+            // linearisation, [E_m per eliminated vertex | C_1 per run] gathered into a contiguous buffer.  Fill blocks enter A p on rank 0 only.
+            S.runblk = nullptr;
+            if (may_shard) { Rd.runblk.reserve((ni + nru) * 36); S.runblk = Rd.runblk.p; }
             Dp = D;
             Dp.nb = P.nbr; Dp.nslots = P.nslots_r; Dp.b2v = Rd.b2v.p; Dp.row_ptr = Rd.row_ptr.p; Dp.col = Rd.col.p; Dp.rowhdr = Rd.rowhdr.p;
             Dp.blk = Rd.blk.p; Dp.hdiag = Rd.hdiag.p; Dp.minv = Rd.minv.p; Dp.b = Rd.hdiag.p + (size_t)P.nbr * 36;
@@ -726,6 +731,10 @@ void build_structure(uzl_pgo* h)
         D.e_end = D.e_begin + base + (h->rank < rem ? 1 : 0);
         D.diag_owner = h->rank == 0 ? 1 : 0;
         D.sibling0 = 0;
+    }
+    if (Rd.on) {                                                              // (Dp was copied from D before the rank's share was known)
+        Dp.e_begin = D.e_begin; Dp.e_end = D.e_end; Dp.diag_owner = D.diag_owner; Dp.sibling0 = D.sibling0;
+        Rd.S.runblk = h->sharded ? Rd.runblk.p : nullptr;
     }
     if (!Rd.on) Dp = D;
     h->pbuf[0] = Rd.on ? Rd.p.p : h->d_p.p; h->pbuf[1] = Rd.on ? Rd.p2.p : h->d_p2.p;
@@ -986,6 +995,10 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         bool launch_async = false;
         bool fetched = false;
         if (red) {                                      // the hierarchy is built on the reduced system, which needs lambda: lambda_0 first
+            if (h->sharded && SD.runblk) {              // the runs' chain blocks, summed over the ranks (once per linearisation)
+                k_schur_gather(D, SD, s);
+                shard_allreduce(h, SD.runblk, (int64_t)(SD.n_int + SD.n_runs) * 36);
+            }
             if (it == 0) {
                 fetch_scal(h); fetched = true;
                 current_chi = h->h_scal.p->scal[4];
