@@ -409,7 +409,7 @@ def sharded_block(capi, synth, dist, dev, a, rank, world, budget_s=20.0):
         acc["ex_ms"] += st_["exchange_ms"]; acc["ex_calls"] += st_["exchange_calls"]
     t4 = timed(dist, timed_step, n4)
     out = dict(metric="SE(3) edges optimized/sec, one 10k-node / 50k-edge graph sharded over all ranks (BASELINE config 4)", unit="edges/s", scaling="strong",
-               value=round(st4["n_edges"] * st4["iterations_done"] * n4 / t4, 1), n_ranks=world,
+               value=round(st4["n_edges"] * st4["iterations_done"] * n4 / t4, 1), n_ranks=world, rccl_ranks_seen=p4.rccl_ranks(), n_eliminated=st4["n_eliminated"],
                ms_per_solve=round(1e3 * t4 / n4, 3), solves_timed=n4, pcg_iterations_per_solve=st4["pcg_iterations"], lm_trials_per_solve=st4["lm_trials"],
                exchange="native RCCL (communicator owned by the handle): 1 all-reduce per PCG iteration + 3 per LM trial, on the solver's stream",
                exchange_calls_per_solve=acc["ex_calls"] // n4,

@@ -368,6 +368,9 @@ int  uzl_pgo_set_shard(uzl_pgo* h, int32_t rank, int32_t world_size,
 #define UZL_RCCL_UNIQUE_ID_BYTES 128
 int  uzl_rccl_unique_id(void* id_out, int32_t cap);
 int  uzl_pgo_set_shard_rccl(uzl_pgo* h, int32_t rank, int32_t world_size, const void* unique_id, int32_t id_bytes);
+/* Ranks of the handle's communicator as RCCL itself counts them (ncclCommCount): what a multi-GPU run reports next to its numbers to
+ * show that the exchange really spans the devices; 0 = no communicator (unsharded, or the callback form), < 0 = error code. */
+int  uzl_pgo_rccl_ranks(uzl_pgo* h);
 
 /* ---- batched solve: many small graphs through one launch sequence ---------------------------
  * A 1k-node graph uses ~3 % of an MI355X (125 workgroups per launch, two dependent launches per PCG iteration).  Independent

@@ -517,6 +517,10 @@ class Pgo:
         buf = (C.c_char * RCCL_UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
         self._check(lib().uzl_pgo_set_shard_rccl(self._h, C.c_int32(rank), C.c_int32(world), buf, C.c_int32(RCCL_UNIQUE_ID_BYTES)))
 
+    def rccl_ranks(self):
+        """ncclCommCount of the handle's communicator (0: none)."""
+        return int(lib().uzl_pgo_rccl_ranks(self._h))
+
     def optimize(self, iterations=0):
         st = PgoStats()
         rc = self._check(lib().uzl_pgo_optimize(self._h, C.c_int32(iterations), C.byref(st)),

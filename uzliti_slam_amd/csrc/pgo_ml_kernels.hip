@@ -1445,7 +1445,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
             }
             D.flags[3] = ((it + 1) % kProgressEvery == 0) ? 1 : 0;         // is the ml_cg behind this launch a look
             D.scal[0] = rz;
-            if (it == 0) { D.scal[1] = thresh; D.scal[11] = rz; }
+            if (it == 0) { D.scal[1] = thresh; D.scal[11] = rz; D.scal[15] = 0.; }      // ([15]: no movement seen yet)
             if (!(rz > thresh)) D.flags[0] = 1;
             if (!(rz >= 0.)) D.flags[2] = 1;      // r.M^-1 r < 0 (or NaN): M^-1 is not positive definite - breakdown, not convergence
         }

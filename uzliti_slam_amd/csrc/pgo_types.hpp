@@ -58,7 +58,7 @@ struct PgoDev {
     double* scal;            // [16]: 0 rz, 1 rz threshold, 2 rz_prev, 3 lambda, 4 chi2, 5 scale, 6 diagmax, 7 |r|^2 / |b|^2 after PCG,
                              //       8 factor on pcg_tol^2 for this LM iteration's solves (host: do_optimize), 9 alpha and 10 breakdown of the current PCG
                              //       iteration (ml_alpha_kernel -> ml_cg_kernel); 11 r.z at the last progress check (first: of r_0), 12 / 13 the
-                             //       step accuracy asked for [m] / [rad], 14 |b|^2 and 15 the last estimate of the step's error in units of 12 / 13 (multilevel path; block-Jacobi path: 14 / 15 the estimates in m / rad);
+                             //       step accuracy asked for [m] / [rad], 14 |b|^2 and 15 the movement of x over the last look's window in units of 12 / 13 (multilevel path; block-Jacobi path: 14 / 15 the estimates in m / rad);
                              //       0..7 go back to the host
     int32_t* flags;          // [4]: 0 done, 1 iterations, 2 breakdown, 3 this iteration's ml_cg leaves the stop test's partials (set by ml_spmv)
 };

@@ -19,6 +19,7 @@ struct RcclApi {
     int (*GetUniqueId)(UniqueId*) = nullptr;                                   // ncclResult_t: 0 = ncclSuccess
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommCount)(Comm, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     static constexpr int kDouble = 8, kSum = 0;                                // ncclDouble (rccl.h:467), ncclSum (rccl.h:448)
@@ -36,6 +37,7 @@ RcclApi& rccl()
         api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(so, "ncclGetUniqueId"));
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(so, "ncclCommInitRank"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(so, "ncclCommDestroy"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(so, "ncclCommCount"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(so, "ncclAllReduce"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(so, "ncclGetErrorString"));
         api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce;
@@ -1485,6 +1487,17 @@ int uzl_pgo_set_shard_rccl(uzl_pgo* h, int32_t rank, int32_t world_size, const v
     h->structure_ready = false;
     return UZL_OK;
     UZL_GUARD_END(h)
+}
+
+int uzl_pgo_rccl_ranks(uzl_pgo* h)
+{
+    if (!h) return UZL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->rccl_comm) return 0;
+    RcclApi& R = rccl();
+    int n = 0;
+    if (!R.CommCount || R.CommCount(h->rccl_comm, &n) != 0) return UZL_ERR_HIP;
+    return n;
 }
 
 }  // extern "C"
