@@ -28,7 +28,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         v = float(r["Counter_Value"])
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         # launches that exit at the `done` flag move (almost) nothing: keep them out of the per-launch mean
-        if v < 1.0 and ("ml_" in k or "pcg_" in k):
+        if v < 1.0 and ("ml_" in k or "pcg_" in k or "_lm_kernel" in k):      # (slot twins no-op unless their graph is in the phase they serve)
             continue
         agg[k][0] += 1
         agg[k][1] += v
@@ -55,7 +55,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
         v = float(r["Counter_Value"])
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if v < 1.0 and ("ml_" in k or "pcg_" in k):
+        if v < 1.0 and ("ml_" in k or "pcg_" in k or "_lm_kernel" in k):
             continue
         agg[k][0] += 1
         agg[k][1] += v
@@ -70,16 +70,19 @@ for k, d in pmc4.items():
         pmc[k] = d
 json.dump(pmc, open(out + "_pmc.json", "w"), indent=1, sort_keys=True)
 t = {}
-for key, names in (("pcg_spmv_bytes_per_launch", ("uzl::ml_spmv_kernel<1>", "uzl::pcg_spmv_kernel")),
-                   ("pcg_spmv4_bytes_per_launch", ("uzl::ml_spmv_kernel<4>",)),
-                   ("c4_linearize_bytes_per_launch", ("c4:uzl::linearize_kernel",)),
-                   ("linearize_bytes_per_launch", ("uzl::linearize_kernel",)),
+# (round 4: the timed solves launch the slot twins of the device-resident LM loop - ml_spmv_lm_kernel<...>, hessian_lm_kernel - the
+#  profiled solve the by-value instantiations of the same bodies; a key takes the first name PREFIX that was seen)
+for key, names in (("pcg_spmv_bytes_per_launch", ("uzl::ml_spmv_lm_kernel<1, 1, 8", "uzl::ml_spmv_kernel<1>", "uzl::pcg_spmv_kernel")),
+                   ("pcg_spmv4_bytes_per_launch", ("c4:uzl::ml_spmv_lm_kernel<4, 4, 4", "uzl::ml_spmv_lm_kernel<4, 4, 4", "c4:uzl::ml_spmv_kernel<4>", "uzl::ml_spmv_kernel<4>")),
+                   ("c4_hessian_bytes_per_launch", ("c4:uzl::hessian_lm_kernel", "c4:uzl::hessian_kernel")),
+                   ("hessian_bytes_per_launch", ("uzl::hessian_lm_kernel", "uzl::hessian_kernel")),
                    ("knn2_bytes_per_launch", ("uzl::knn2_mfma_kernel<8, 2>", "uzl::knn2_lds_kernel<8, 1>", "uzl::knn2_kernel<8>")),
                    ("estimate_bytes_per_launch", ("uzl::estimate_kernel",)),
                    ("wire_unpack_bytes_per_launch", ("uzl::wire_unpack_kernel",))):
     for nm in names:
-        if nm in pmc:
-            t[key] = pmc[nm]["hbm_bytes_per_launch"]
+        hit = [k for k in sorted(pmc) if k.startswith(nm)]
+        if hit:
+            t[key] = pmc[hit[0]]["hbm_bytes_per_launch"]
             break
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(t))
