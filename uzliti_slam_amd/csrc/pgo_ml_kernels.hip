@@ -234,101 +234,62 @@ __global__ __launch_bounds__(kBlk) void ml_reduce_kernel(const MlDev* __restrict
     ml_reduce_kernel_body(mlp, l);
 }
 
-// ---- per LM trial: the sibling-block smoothers.  One single-wave workgroup per (level l < L, aggregate A of level
-//      l+1): A_l(lambda) restricted to A's children is gathered into LDS ((6 fan)^2 <= 48^2: diagonal blocks plus
-//      every off-diagonal block whose column is a sibling; multi-edges add up in slot order), inverted in place
-//      by Gauss-Jordan without pivoting (SPD), and written to Winv[l][A].  Missing children (last aggregate of a
-//      level) are padded with identity rows.
-constexpr int kSibBlk = 192;
-constexpr int kSibCols = 2048;                          // slot columns of one aggregate staged in LDS
-
-// In-place inverse of the M x M SPD matrix in sW (row stride ld) by BLOCK Gauss-Jordan with 6 x 6 pivots: M/6
-// dependent steps instead of M.  Lane (row, part) = tid / 4, tid % 4 holds columns [part*M/4, +M/4) of its row in
-// registers (loops over them unrolled; pivot positions are only ever compared, so register indices stay static).
-// Per pivot block K:  P = A_KK^-1 (every lane, redundantly);  A_Kj <- P A_Kj;  A_iK <- -A_iK P;
-//                     A_ij <- A_ij - A_iK (P A_Kj);  A_KK <- P.
-template <int M>
-__device__ __forceinline__ void block_gauss_jordan(double* __restrict__ sW, double* __restrict__ sPiv, double* __restrict__ sNew,
-                                                   double* __restrict__ sP, int ld, int tid)
+// ---- per LM trial: the sibling-block smoothers and the top level: dense SPD inverses of 24 .. 96 rows.
+// In-place Gauss-Jordan (no pivoting: SPD) of a matrix held as 6 x 6 tiles IN REGISTERS: lane (I, J) of an LW x LW square of lanes owns tile
+// (I, J); of step k only row k and column k travel, through two LDS buffers (one barrier per step).  6 nt dependent steps of ~0.1 us - the
+// round-3 kernels (block pivots of 6 with the matrix in LDS, four barriers and a redundant 6 x 6 inverse per pivot block) took 50 us for a
+// 48-row block and 390 us for 96 rows, which is why the top level stopped at 48 rows and the levels between were built by ten more launches.
+template <int LW>
+__device__ __forceinline__ void gj_tiles(double (&a)[36], int I, int J, int nt, double* __restrict__ sRow, double* __restrict__ sCol)
 {
-    constexpr int CW = M / 4;                         // 12 or 6: whole 6-blocks
-    const int row = tid >> 2, part = tid & 3, c0 = part * CW;
-    const bool own = row < M;
-    double a[CW];
+    for (int K = 0; K < nt; K++) {
 #pragma unroll
-    for (int j = 0; j < CW; j++) a[j] = own ? sW[row * ld + c0 + j] : 0.;
-    for (int K = 0; K < M / 6; K++) {
-        const int k0 = 6 * K, kp = k0 / CW, kj0 = k0 - kp * CW;         // pivot columns live in part kp at offset kj0
-        const bool piv = row >= k0 && row < k0 + 6;
-        __syncthreads();                                                // sPiv / sNew of the previous step consumed
-        if (piv) {
+        for (int kk = 0; kk < 6; kk++) {
+            double* __restrict__ rb = sRow + (kk & 1) * 6 * LW;            // (6 K + kk) & 1 = kk & 1
+            double* __restrict__ cb = sCol + (kk & 1) * 6 * LW;
+            if (I == K) {
 #pragma unroll
-            for (int j = 0; j < CW; j++) sPiv[(row - k0) * M + c0 + j] = a[j];
-        }
-        __syncthreads();
-        double Akk[36], P[36];
-#pragma unroll
-        for (int i = 0; i < 36; i++) Akk[i] = sPiv[(i / 6) * M + k0 + i % 6];
-        spd_inverse6_rs(Akk, P);
-        {   // P goes to LDS so that it can be indexed by run-time row / column numbers
-            double pv = 0.;
-#pragma unroll
-            for (int u = 0; u < 36; u++) pv = (u == (int)threadIdx.x) ? P[u] : pv;
-            if (threadIdx.x < 36) sP[threadIdx.x] = pv;
-        }
-        __syncthreads();
-        if (piv) {
-            const int r = row - k0;
-#pragma unroll
-            for (int j = 0; j < CW; j++) {
-                double v = 0.;
-#pragma unroll
-                for (int q = 0; q < 6; q++) v += sP[r * 6 + q] * sPiv[q * M + c0 + j];
-                sNew[r * M + c0 + j] = v;
-                const int qc = j - kj0;
-                a[j] = (part == kp && qc >= 0 && qc < 6) ? sP[r * 6 + (qc < 0 ? 0 : (qc > 5 ? 5 : qc))] : v;
+                for (int c = 0; c < 6; c++) rb[6 * J + c] = a[kk * 6 + c];
             }
-        }
-        __syncthreads();
-        // multipliers f[q] = A_{row, k0+q}: held by the lane (row, kp) at a[kj0 + q]
-        double f[6];
+            if (J == K) {
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            double sel = (CW == 12 && kj0 == 6) ? a[(CW == 12 ? 6 : 0) + q] : a[q];
-            f[q] = __shfl(sel, (threadIdx.x & 60) | kp);
-        }
-        if (own && !piv) {
-#pragma unroll
-            for (int j = 0; j < CW; j++) {
-                const int qc = j - kj0;
-                double v;
-                if (part == kp && qc >= 0 && qc < 6) {
-                    v = 0.;
-#pragma unroll
-                    for (int u = 0; u < 6; u++) v -= f[u] * sP[u * 6 + qc];
-                } else {
-                    v = a[j];
-#pragma unroll
-                    for (int u = 0; u < 6; u++) v -= f[u] * sNew[u * M + c0 + j];
-                }
-                a[j] = v;
+                for (int r = 0; r < 6; r++) cb[6 * I + r] = a[r * 6 + kk];
             }
+            __syncthreads();
+            const double p = 1. / rb[6 * K + kk];
+            double rk[6], m[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) rk[c] = rb[6 * J + c];
+#pragma unroll
+            for (int r = 0; r < 6; r++) m[r] = cb[6 * I + r] * p;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) a[r * 6 + c] = fma(-m[r], rk[c], a[r * 6 + c]);
+            if (I == K) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) a[kk * 6 + c] = rk[c] * p;
+            }
+            if (J == K) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) a[r * 6 + kk] = -m[r];
+            }
+            if (I == K && J == K) a[kk * 6 + kk] = p;
         }
     }
-    __syncthreads();
-    if (own) {
-#pragma unroll
-        for (int j = 0; j < CW; j++) sW[row * ld + c0 + j] = a[j];
-    }
-    __syncthreads();
 }
+
+//      Sibling blocks: one single-wave workgroup per (level l < L, aggregate A of level l+1).  A_l(lambda) restricted to A's children
+//      ((6 fan)^2 <= 48^2: diagonal blocks plus every off-diagonal block whose column is a sibling; multi-edges add up in slot order) is
+//      gathered tile by tile - lane (I, J) = children (I, J) - inverted in registers and written to Winv[l][A].  Missing children (last
+//      aggregate of a level) are padded with identity rows.
+constexpr int kSibBlk = 64;
+constexpr int kSibCols = 2048;                          // slot columns of one aggregate staged in LDS
+constexpr int kSibHits = 2;                             // blocks of one tile fetched in one round trip
 
 __device__ __forceinline__ void ml_sibling_kernel_body(PgoDev D, const MlDev* __restrict__ mlp)
 {
-    __shared__ double sW[48 * 49];
-    __shared__ double sPiv[6 * 48];
-    __shared__ double sNew[6 * 48];
-    __shared__ double sP[36];
+    __shared__ double sRow[2 * 48], sCol[2 * 48];
     __shared__ int scol[kSibCols];
     const MlDev& ml = *mlp;
     const double lambda = D.scal[3];
@@ -336,43 +297,69 @@ __device__ __forceinline__ void ml_sibling_kernel_body(PgoDev D, const MlDev* __
     while (l < ml.levels && A >= ml.lv[l + 1].n) { A -= ml.lv[l + 1].n; l++; }
     if (l >= ml.levels) return;
     const MlLevel& F = ml.lv[l];
-    const int fan = ml.lv[l + 1].fan, m = 6 * fan, ld = 49, nc = F.n;
-    const int t = threadIdx.x;
-    for (int i = t; i < m * ld; i += kSibBlk) sW[i] = 0.;
+    const int fan = ml.lv[l + 1].fan, m = 6 * fan, nc = F.n;
+    const int t = threadIdx.x, I = t >> 3, J = t & 7;
     // column indices of the aggregate's rows (one contiguous slot range): all loads in flight at once, so the
     // per-row scan below walks LDS instead of paying a memory round trip per slot (hub rows have dozens)
     const int cfirst = A * fan, clast = (cfirst + fan < nc) ? cfirst + fan : nc;
     const int sbeg = F.row_ptr[cfirst], send = F.row_ptr[clast];
     for (int i = sbeg + t; i < send && i - sbeg < kSibCols; i += kSibBlk) scol[i - sbeg] = F.col[i];
-    __syncthreads();
-    if (t < m) {
-        const int ch = t / 6, r = t % 6, c = A * fan + ch;
-        if (c >= nc) {
-            sW[t * ld + t] = 1.;
+    const int ci = cfirst + I, cj = cfirst + J;
+    const bool act = I < fan && J < fan;
+    double a[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) a[k] = 0.;
+    int r0 = 0, r1 = 0;
+    if (act && ci < nc && cj < nc && I != J && (l > 0 || D.sibling0)) { r0 = F.row_ptr[ci]; r1 = F.row_ptr[ci + 1]; }
+    if (act && I == J) {
+        if (ci >= nc) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) a[k * 7] = 1.;
         } else {
-            const double* __restrict__ G = F.G + (size_t)c * 36 + r * 6;
-            for (int k = 0; k < 6; k++) {
-                double v = G[k];
-                if (l == 0) { if (k == r) v += lambda; } else v += lambda * F.M[(size_t)c * 36 + r * 6 + k];
-                sW[t * ld + ch * 6 + k] = v;
-            }
-            if (l > 0 || D.sibling0) {
-                for (int s = F.row_ptr[c]; s < F.row_ptr[c + 1]; s++) {
-                    const int cc = (s - sbeg < kSibCols) ? scol[s - sbeg] : F.col[s];
-                    if (cc >= 0 && cc / fan == A) {
-                        const int jc = cc - A * fan;
-                        const double* __restrict__ bk = F.blk + (size_t)s * 36 + r * 6;
-                        for (int k = 0; k < 6; k++) sW[t * ld + jc * 6 + k] += bk[k];
-                    }
-                }
+#pragma unroll
+            for (int k = 0; k < 36; k++) {
+                double v = F.G[(size_t)ci * 36 + k];
+                if (l == 0) { if (k % 7 == 0) v += lambda; } else v += lambda * F.M[(size_t)ci * 36 + k];
+                a[k] = v;
             }
         }
     }
     __syncthreads();
-    if (m == 48) block_gauss_jordan<48>(sW, sPiv, sNew, sP, ld, t);
-    else block_gauss_jordan<24>(sW, sPiv, sNew, sP, ld, t);     // fan-out 4 (level 2 of large graphs)
-    double* __restrict__ out = F.Winv + (size_t)A * m * m;
-    for (int i = t; i < m * m; i += kSibBlk) out[i] = sW[(i / m) * ld + i % m];
+    // the slots of row ci whose column is cj: the first kSibHits fetched together, in slot order
+    int hit[kSibHits], nh = 0;
+#pragma unroll
+    for (int q = 0; q < kSibHits; q++) hit[q] = -1;
+    int s = r0;
+    for (; s < r1 && nh < kSibHits; s++) {
+        const int cc = (s - sbeg < kSibCols) ? scol[s - sbeg] : F.col[s];
+        if (cc == cj) {
+#pragma unroll
+            for (int q = 0; q < kSibHits; q++) if (q == nh) hit[q] = s;
+            nh++;
+        }
+    }
+    double hb[kSibHits][36];
+#pragma unroll
+    for (int q = 0; q < kSibHits; q++)
+#pragma unroll
+        for (int k = 0; k < 36; k++) hb[q][k] = (hit[q] >= 0) ? F.blk[(size_t)hit[q] * 36 + k] : 0.;
+#pragma unroll
+    for (int q = 0; q < kSibHits; q++)
+#pragma unroll
+        for (int k = 0; k < 36; k++) a[k] += hb[q][k];
+    for (; s < r1; s++) {                                           // more parallel edges than that: one at a time
+        const int cc = (s - sbeg < kSibCols) ? scol[s - sbeg] : F.col[s];
+        if (cc == cj) {
+#pragma unroll
+            for (int k = 0; k < 36; k++) a[k] += F.blk[(size_t)s * 36 + k];
+        }
+    }
+    gj_tiles<8>(a, I, J, fan, sRow, sCol);
+    if (act) {
+        double* __restrict__ out = F.Winv + (size_t)A * m * m + (size_t)(6 * I) * m + 6 * J;
+#pragma unroll
+        for (int k = 0; k < 36; k++) out[(k / 6) * m + k % 6] = a[k];
+    }
 }
 __global__ __launch_bounds__(kSibBlk) void ml_sibling_kernel(PgoDev D, const MlDev* __restrict__ mlp)
 {
@@ -865,43 +852,38 @@ __global__ __launch_bounds__(256) void ml_mult_qyqt_kernel(const MlDev* __restri
     ml_mult_qyqt_kernel_body(mlp, cl);
 }
 
-// ---- per LM trial: dense inverse of the top level A_L(lambda) (<= 48 x 48), one workgroup, in LDS
+// ---- per LM trial: dense inverse of the top level A_L(lambda) (<= 96 x 96: kMlTopWide aggregates), one workgroup of 16 x 16 lanes,
+//      one 6 x 6 tile per lane (gj_tiles above)
 __device__ __forceinline__ void ml_top_kernel_body(PgoDev D, const MlDev* __restrict__ mlp)
 {
-    __shared__ double sA[48 * 97];      // [A | I], row stride 97 (odd: no bank pile-up on column walks)
+    __shared__ double sRow[2 * 6 * kMlTopWide], sCol[2 * 6 * kMlTopWide];
     const MlDev& ml = *mlp;
     const MlLevel& L = ml.lv[ml.levels];
     const double lambda = D.scal[3];
-    const int n = 6 * L.n, W = 2 * n, ld = 97;
-    for (int i = threadIdx.x; i < n * W; i += kBlk) {
-        const int r = i / W, c = i % W;
-        sA[r * ld + c] = (c >= n) ? ((c - n == r) ? 1. : 0.) : 0.;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < L.n * 36; i += kBlk) {
-        const int A = i / 36, k = i % 36;
-        sA[(6 * A + k / 6) * ld + 6 * A + k % 6] = L.G[i] + lambda * L.M[i];
-    }
-    for (int i = threadIdx.x; i < L.nslots * 36; i += kBlk) {
-        const int s = i / 36, k = i % 36;
-        sA[(6 * L.srow[s] + k / 6) * ld + 6 * L.col[s] + k % 6] = L.blk[i];
-    }
-    __syncthreads();
-    // Gauss-Jordan without pivoting (SPD)
-    for (int p = 0; p < n; p++) {
-        const double piv = 1. / sA[p * ld + p];
-        __syncthreads();
-        for (int c = threadIdx.x; c < W; c += kBlk) sA[p * ld + c] *= piv;
-        __syncthreads();
-        for (int i = threadIdx.x; i < n * W; i += kBlk) {
-            const int r = i / W, c = i % W;
-            if (r != p && c != p) sA[r * ld + c] -= sA[r * ld + p] * sA[p * ld + c];
+    const int nt = L.n, n = 6 * nt;
+    const int I = threadIdx.x >> 4, J = threadIdx.x & 15;
+    const bool act = I < nt && J < nt;
+    double a[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) a[k] = 0.;
+    if (act && I == J) {
+#pragma unroll
+        for (int k = 0; k < 36; k++) a[k] = L.G[(size_t)I * 36 + k] + lambda * L.M[(size_t)I * 36 + k];
+    } else if (act) {                                    // blocks of a coarse level are unique per (row, column)
+        const int s0 = L.row_ptr[I], s1 = L.row_ptr[I + 1];
+        int hit = -1;
+        for (int s = s0; s < s1; s++) if (L.col[s] == J) hit = s;
+        if (hit >= 0) {
+#pragma unroll
+            for (int k = 0; k < 36; k++) a[k] = L.blk[(size_t)hit * 36 + k];
         }
-        __syncthreads();
-        for (int r = threadIdx.x; r < n; r += kBlk) if (r != p) sA[r * ld + p] = 0.;
-        __syncthreads();
     }
-    for (int i = threadIdx.x; i < n * n; i += kBlk) ml.top_inv[i] = sA[(i / n) * ld + n + i % n];
+    gj_tiles<kMlTopWide>(a, I, J, nt, sRow, sCol);
+    if (act) {
+        double* __restrict__ out = ml.top_inv + (size_t)(6 * I) * n + 6 * J;
+#pragma unroll
+        for (int k = 0; k < 36; k++) out[(k / 6) * n + k % 6] = a[k];
+    }
 }
 // The dense operator the PCG kernels apply, rounded to f32 once per rebuild (MlHot::Cmat32).  It is the largest stream of an
 // iteration (config 2: 4.5 of 10 MB; 20k vertices: 112 MB); a preconditioner does not need the last 29 bits, and being rounded once,

@@ -78,7 +78,9 @@ struct PgoDev {
 constexpr int kMlMaxLevels = 8;
 constexpr int kMlFanout = 8;         // level 1: 8 vertices per aggregate; levels >= 3: 8 children
 constexpr int kMlFanout2 = 4;        // level 2: 4 level-1 aggregates = 32 vertices = one workgroup of the PCG kernels
-constexpr int kMlTopMax = 8;          // aggregates at the top level (<= 48 dof dense)
+constexpr int kMlTopMax = 8;          // aggregates at the top level (<= 48 dof dense) when the PCG kernels walk the hierarchy themselves
+constexpr int kMlTopWide = 16;        // ... when they apply the dense composite operator instead: the top level is then only ever touched by
+                                      // the rebuild, whose one-workgroup inverse (ml_top_kernel) takes 96 rows as readily as 48
 
 struct MlLevel {
     int32_t n;                 // entities at this level (level 0: nb)

@@ -225,7 +225,21 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     h->ml_agg = nb <= agg1_max ? 1 : 4;
     int L = 0;
     h->ml_fan.assign(1, 1);
-    while (h->ml_n.back() > kMlTopMax && L < kMlMaxLevels) {
+    // composite path: one aggregate per workgroup, at least two coarse levels, 6 n_1 <= 960 (<= 1280 free vertices)
+    static const bool comp_off = diag_flag("UZL_ML_NO_COMP");                // A/B switch
+    // large graphs (AGG = 4, gather level 2): the same construction one level up - the hierarchy above level 2 as one dense
+    // operator (6 n_2 <= 4096: up to ~21.8k free vertices, 134 MB; measured 733 -> 332 ms at 20k / 100k, the rebuild's two
+    // Newton-Schulz GEMMs take 7 ms there) that ml_cg_kernel<4> applies instead of its LDS walk
+    static const bool comp4_off = diag_flag("UZL_ML_NO_COMP4");             // A/B switch
+    static const int comp4_max = diag_int("UZL_ML_COMP4_MAX", 4096);
+    static const int top_wide = diag_int("UZL_ML_TOP_WIDE", kMlTopWide);    // A/B switch (8 = the round-3 hierarchy)
+    // A level above the composite one may be the top with up to kMlTopWide aggregates: config 2 (1000 vertices: 125 / 16 / 2) loses its
+    // 2-aggregate level and with it ten launches per rebuild (the cycle around it and four Newton-Schulz steps of the 96-row level)
+    auto top_max = [&](int lvl) {
+        const bool comp_here = h->ml_agg == 1 ? (lvl >= 2 && 6 * h->ml_n[1] <= 3072) : (!comp4_off && lvl >= 3 && 6 * h->ml_n[2] <= comp4_max);
+        return (!comp_off && comp_here) ? std::min(std::max(top_wide, kMlTopMax), kMlTopWide) : kMlTopMax;
+    };
+    while (h->ml_n.back() > top_max(L) && L < kMlMaxLevels) {
         const int fan = (L == 1 && h->ml_agg == 4) ? kMlFanout2 : kMlFanout;     // large graphs: level 2 = 4 level-1 aggregates
         h->ml_fan.push_back(fan);
         h->ml_n.push_back((h->ml_n.back() + fan - 1) / fan);
@@ -311,13 +325,6 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     std::vector<size_t> geo_sub((size_t)L + 1, 0);
     for (int l = 1; l <= L; l++) { geo_sub[l] = geo_blob_doubles; geo_blob_doubles += (size_t)std::max(h->ml_n[l], 1) * 3; }
     const size_t o_geo_blob = take(geo_blob_doubles * 8 + 64);     // ml_cg copies levels g..L-1 with one linear loop
-    // composite path: one aggregate per workgroup, at least two coarse levels, 6 n_1 <= 960 (<= 1280 free vertices)
-    static const bool comp_off = diag_flag("UZL_ML_NO_COMP");                // A/B switch
-    // large graphs (AGG = 4, gather level 2): the same construction one level up - the hierarchy above level 2 as one dense
-    // operator (6 n_2 <= 4096: up to ~21.8k free vertices, 134 MB; measured 733 -> 332 ms at 20k / 100k, the rebuild's two
-    // Newton-Schulz GEMMs take 7 ms there) that ml_cg_kernel<4> applies instead of its LDS walk
-    static const bool comp4_off = diag_flag("UZL_ML_NO_COMP4");             // A/B switch
-    static const int comp4_max = diag_int("UZL_ML_COMP4_MAX", 4096);
     const bool comp1 = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 3072;     // ml_cg_comp_kernel<5> / <8> / <12> / <16>
     const bool comp4 = !comp_off && !comp4_off && h->ml_agg == 4 && L >= 3 && 6 * h->ml_n[2] <= comp4_max;
     h->ml_comp = comp1 || comp4;
@@ -362,7 +369,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         }
     }
     const size_t o_tmp = take(max_contrib * 36 * 8), o_tmpG = take(max_n * 36 * 8), o_tmpM = take(max_n * 36 * 8);
-    const size_t o_top = take((size_t)(6 * kMlTopMax) * (6 * kMlTopMax) * 8);
+    const size_t o_top = take((size_t)(6 * kMlTopWide) * (6 * kMlTopWide) * 8);
     const int gl = (h->ml_agg == 1 || L < 2) ? 1 : 2;
     const size_t ngz = (size_t)std::max(h->ml_n[gl], 1) * 6 * 8 * 2;          // (x 2: the gather-level-2 Sg holds two parts per entity)
     const size_t o_sg = take(ngz), o_rga = take(ngz), o_rgb = take(ngz), o_vg = take(ngz);
