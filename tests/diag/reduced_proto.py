@@ -42,7 +42,8 @@ X = fl["poses"].reshape(-1, 3, 4)[free_v][sep]
 R, t = X[:, :, :3], X[:, :, 3]
 # reduced graph: weights = trace of the off-diagonal blocks' "stiffness" (Frobenius norm of the 6x6 block)
 Ab = Ar.tobsr((6, 6)); Ab.sort_indices()
-W = sp.csr_matrix((np.linalg.norm(Ab.data.reshape(-1, 36), axis=1), Ab.indices, Ab.indptr), shape=(nr, nr))
+W = sp.csr_matrix((np.linalg.norm(Ab.data.reshape(-1, 36), axis=1), Ab.indices.copy(), Ab.indptr.copy()), shape=(nr, nr))
+dn = W.diagonal().copy()
 W.setdiag(0); W.eliminate_zeros()
 deg = np.diff(W.indptr)
 print("reduced graph: %d off-diagonal blocks, degree mean %.2f max %d" % (W.nnz, deg.mean(), deg.max()))
@@ -171,3 +172,60 @@ two_level(greedy_grow(W, 8, False), "greedy growth to 8, no fragment merge")
 two_level(greedy_grow(W, 8, True), "greedy growth to 8, fragments merged (groups <= 10)")
 gm = greedy_match(W, 8)
 print("matching x3 group sizes:", np.bincount(np.bincount(gm)))
+
+def forced_match(Wm, rounds):
+    """heavy-edge matching, leftovers paired with each other in index order: groups of exactly 2^rounds (but for one remainder)"""
+    groups = np.arange(Wm.shape[0]); Wc = Wm.copy()
+    for _ in range(rounds):
+        n = Wc.shape[0]; mate = -np.ones(n, int)
+        coo = Wc.tocoo(); o = np.argsort(-coo.data, kind="stable")
+        for k in o:
+            a, c = coo.row[k], coo.col[k]
+            if a != c and mate[a] < 0 and mate[c] < 0: mate[a] = c; mate[c] = a
+        left = np.nonzero(mate < 0)[0]
+        for k in range(0, len(left) - 1, 2): mate[left[k]] = left[k + 1]; mate[left[k + 1]] = left[k]
+        new = -np.ones(n, int); cnt = 0
+        for v in range(n):
+            if new[v] < 0:
+                new[v] = cnt
+                if mate[v] >= 0: new[mate[v]] = cnt
+                cnt += 1
+        Pm = sp.coo_matrix((np.ones(n), (np.arange(n), new)), shape=(n, cnt)).tocsr()
+        Wc = (Pm.T @ Wc @ Pm).tocsr(); Wc.setdiag(0); Wc.eliminate_zeros()
+        groups = new[groups]
+    return groups
+
+two_level(forced_match(W, 3), "heavy-edge matching x3, leftovers paired in index order (exact 8)")
+two_level(forced_match(W, 2), "heavy-edge matching x2, leftovers paired (exact 4)")
+# normalised strength: |A_ij| / sqrt(|A_ii| |A_jj|)
+Wn = sp.diags(1 / np.sqrt(dn)) @ W @ sp.diags(1 / np.sqrt(dn)); Wn = Wn.tocsr()
+two_level(forced_match(Wn, 3), "same, normalised strengths (exact 8)")
+two_level(greedy_match(Wn, 8), "heavy-edge matching x3, normalised strengths (groups <= 8)")
+
+def capped_match(Wm, cap, rounds, theta=0.0):
+    """size-capped agglomeration: per round, heaviest-edge matching of groups whose sizes add up to <= cap; an edge only counts if it is
+    at least theta x the heaviest edge at either end"""
+    groups = np.arange(Wm.shape[0]); Wc = Wm.copy(); sizes = np.ones(Wm.shape[0], int)
+    for _ in range(rounds):
+        n = Wc.shape[0]; mate = -np.ones(n, int)
+        coo = Wc.tocoo(); o = np.argsort(-coo.data, kind="stable")
+        wmax = np.zeros(n); np.maximum.at(wmax, coo.row, coo.data)
+        for k in o:
+            a, c = coo.row[k], coo.col[k]
+            if a != c and mate[a] < 0 and mate[c] < 0 and sizes[a] + sizes[c] <= cap and coo.data[k] >= theta * max(wmax[a], wmax[c]): mate[a] = c; mate[c] = a
+        new = -np.ones(n, int); cnt = 0
+        for v in range(n):
+            if new[v] < 0:
+                new[v] = cnt
+                if mate[v] >= 0: new[mate[v]] = cnt
+                cnt += 1
+        if cnt == n: break
+        Pm = sp.coo_matrix((np.ones(n), (np.arange(n), new)), shape=(n, cnt)).tocsr()
+        Wc = (Pm.T @ Wc @ Pm).tocsr(); Wc.setdiag(0); Wc.eliminate_zeros()
+        sizes = np.bincount(new, sizes, cnt).astype(int)
+        groups = new[groups]
+    return groups
+
+for rounds in (4, 6, 10):
+    for theta in (0.0, 0.25, 0.5):
+        two_level(capped_match(W, 8, rounds, theta), "size-capped (<= 8) matching, %d rounds, theta %.2f" % (rounds, theta))

@@ -45,7 +45,7 @@ void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s);
 void k_ml_mult_level(const PgoDev& D, const MlDev* ml, int lev, int n1, int n2, hipStream_t s);
 void k_ml_cmat32(const MlHot& hot, int n6, hipStream_t s);
 void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int lev, int n1, const double* X, double* T, double* Xn, hipStream_t s,
-                  hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
+                  hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr, float* c32 = nullptr, int c32_stride = 0);
 int g_ml_rows(int nb, int agg);
 int g_ml_spmv(int nb, int agg);
 size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
@@ -120,7 +120,7 @@ struct uzl_pgo {
     PgoDev Dp;
     double* pbuf[2] = {nullptr, nullptr};      // PCG direction, ping-pong (of the Dp system)
     struct Reduced {
-        bool on = false;
+        bool on = false, strong = false;           // strong: numbered by strong aggregates, with empty rows (SchurPlan)
         int32_t n_int = 0, n_runs = 0, longest_run = 0;
         DevBuf<int32_t> run_ptr, run_rows, slotP, slotN, endL, endR, sep_rows, rsrc, inc_ptr, inc, row_ptr, col, rowhdr, b2v;
         DevBuf<double> elim, runout, runblk, blk, hdiag, minv, x, xs, r, z, p, p2, ap;
@@ -209,6 +209,7 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);
 bool lm_batch_eligible(const std::vector<uzl_pgo*>& hs);
 int batch_optimize_lm(LmRun*& R, const std::vector<uzl_pgo*>& hs, int resident, hipStream_t s, hipStream_t s2, int32_t iterations, bool eager, bool verbose, KernelTimer* timer,
                       uzl_pgo_stats* stats, int* rc_all);
+constexpr int kSchurStrongMin = 1024;                 // separators from which on the reduced system is numbered by strong aggregates
 extern const int kUpperNs;                            // Newton-Schulz steps of the dense levels above the composite level
 extern const bool kAlwaysRefresh;                     // A/B switches (diagnostic build)
 extern const double kRefreshRel, kLambdaRetake;

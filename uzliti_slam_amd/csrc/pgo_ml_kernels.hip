@@ -109,15 +109,9 @@ __device__ __forceinline__ void galerkin(const P3& L, const double* __restrict__
         }
 }
 
-// number of level-0 blocks under entity i of a level whose aggregates span `span` blocks
-__device__ __forceinline__ int leaves_under(int span, int i, int nb)
-{
-    const int lo = i * span;
-    const int hi = lo + span < nb ? lo + span : nb;
-    return hi > lo ? hi - lo : 0;
-}
-
-// ---- geometry of level l (>= 1): centroid of every aggregate, then the children's offsets d
+// ---- geometry of level l (>= 1): centroid of every aggregate, then the children's offsets d.  cen = {x, y, z, vertices underneath}.
+//      An EMPTY row (b2v < 0: padding of a strong-aggregate numbering, pgo_schur.hpp) has no pose: it carries no weight and gets a zero
+//      prolongation block (R^T = 0), so it adds nothing to any coarse operator.
 __device__ __forceinline__ void ml_geometry_kernel_body(PgoDev D, const MlDev* __restrict__ mlp,
                                                           const double* __restrict__ pose, int l)
 {
@@ -131,29 +125,37 @@ __device__ __forceinline__ void ml_geometry_kernel_body(PgoDev D, const MlDev* _
     for (int c = c0; c < c1; c++) {
         double px, py, pz, w;
         if (l == 1) {
-            const Pose P = load_pose(pose, D.b2v[c]);
+            const int v = D.b2v[c];
+            if (v < 0) continue;
+            const Pose P = load_pose(pose, v);
             px = P.t.x; py = P.t.y; pz = P.t.z; w = 1.;
         } else {
-            const double* cc = ml.lv[l - 1].cen + (size_t)c * 3;
-            px = cc[0]; py = cc[1]; pz = cc[2]; w = (double)leaves_under(ml.lv[l - 1].span, c, D.nb);
+            const double* cc = ml.lv[l - 1].cen + (size_t)c * 4;
+            px = cc[0]; py = cc[1]; pz = cc[2]; w = cc[3];
         }
         cx += w * px; cy += w * py; cz += w * pz; wsum += w;
     }
-    cx /= wsum; cy /= wsum; cz /= wsum;
-    double* cen = ml.lv[l].cen + (size_t)A * 3;
-    cen[0] = cx; cen[1] = cy; cen[2] = cz;
+    if (wsum > 0.) { cx /= wsum; cy /= wsum; cz /= wsum; }
+    double* cen = ml.lv[l].cen + (size_t)A * 4;
+    cen[0] = cx; cen[1] = cy; cen[2] = cz; cen[3] = wsum;
     for (int c = c0; c < c1; c++) {
         if (l == 1) {
-            const Pose P = load_pose(pose, D.b2v[c]);
-            const M33 R = qrot(P.q);
             double* g = ml.lv[0].geo + (size_t)c * 12;
+            const int v = D.b2v[c];
+            if (v < 0) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) g[k] = 0.;
+                continue;
+            }
+            const Pose P = load_pose(pose, v);
+            const M33 R = qrot(P.q);
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
                 for (int k = 0; k < 3; k++) g[r * 3 + k] = R.m[k * 3 + r];       // R^T
             g[9] = P.t.x - cx; g[10] = P.t.y - cy; g[11] = P.t.z - cz;
         } else {
-            const double* cc = ml.lv[l - 1].cen + (size_t)c * 3;
+            const double* cc = ml.lv[l - 1].cen + (size_t)c * 4;
             double* g = ml.lv[l - 1].geo + (size_t)c * 3;
             g[0] = cc[0] - cx; g[1] = cc[1] - cy; g[2] = cc[2] - cz;
         }
@@ -279,48 +281,61 @@ __device__ __forceinline__ void gj_tiles(double (&a)[36], int I, int J, int nt, 
     }
 }
 
-//      Sibling blocks: one single-wave workgroup per (level l < L, aggregate A of level l+1).  A_l(lambda) restricted to A's children
+//      Sibling blocks: one WAVE per (level l < L, aggregate A of level l+1), four to a workgroup.  A_l(lambda) restricted to A's children
 //      ((6 fan)^2 <= 48^2: diagonal blocks plus every off-diagonal block whose column is a sibling; multi-edges add up in slot order) is
 //      gathered tile by tile - lane (I, J) = children (I, J) - inverted in registers and written to Winv[l][A].  Missing children (last
-//      aggregate of a level) are padded with identity rows.
-constexpr int kSibBlk = 64;
-constexpr int kSibCols = 2048;                          // slot columns of one aggregate staged in LDS
+//      aggregate of a level, fan-out 4) are padded with identity rows: every wave takes the same 48 steps, so the workgroup's barriers
+//      line up whatever its four aggregates are.
+//      Top level: the LAST workgroup of the same launch (the two depend on nothing but the Galerkin products): <= kMlTopWide aggregates,
+//      16 x 16 lanes, one tile each.
+constexpr int kSibPerBlk = kBlk / 64;                   // aggregates per workgroup
+constexpr int kSibCols = 1024;                          // slot columns of one aggregate staged in LDS
 constexpr int kSibHits = 2;                             // blocks of one tile fetched in one round trip
 
-__device__ __forceinline__ void ml_sibling_kernel_body(PgoDev D, const MlDev* __restrict__ mlp)
+__device__ __forceinline__ void ml_top_tiles(PgoDev D, const MlDev* __restrict__ mlp, double* __restrict__ sRow, double* __restrict__ sCol);
+
+__device__ __forceinline__ void ml_inverses_kernel_body(PgoDev D, const MlDev* __restrict__ mlp)
 {
-    __shared__ double sRow[2 * 48], sCol[2 * 48];
-    __shared__ int scol[kSibCols];
+    __shared__ double sRow[kSibPerBlk * 2 * 48], sCol[kSibPerBlk * 2 * 48];      // (the top level uses the first 2 x 96 of each)
+    __shared__ int scol_all[kSibPerBlk * kSibCols];
+    if (blockIdx.x == gridDim.x - 1) { ml_top_tiles(D, mlp, sRow, sCol); return; }
     const MlDev& ml = *mlp;
     const double lambda = D.scal[3];
-    int A = blockIdx.x, l = 0;
+    const int wv = threadIdx.x >> 6, t = threadIdx.x & 63, I = t >> 3, J = t & 7;
+    int* __restrict__ scol = scol_all + wv * kSibCols;
+    int A = blockIdx.x * kSibPerBlk + wv, l = 0;
     while (l < ml.levels && A >= ml.lv[l + 1].n) { A -= ml.lv[l + 1].n; l++; }
-    if (l >= ml.levels) return;
+    const bool live = l < ml.levels;                    // (a batch launches the largest graph's grid; the last workgroup may be short)
+    if (!live) { l = 0; A = 0; }
     const MlLevel& F = ml.lv[l];
     const int fan = ml.lv[l + 1].fan, m = 6 * fan, nc = F.n;
-    const int t = threadIdx.x, I = t >> 3, J = t & 7;
     // column indices of the aggregate's rows (one contiguous slot range): all loads in flight at once, so the
     // per-row scan below walks LDS instead of paying a memory round trip per slot (hub rows have dozens)
     const int cfirst = A * fan, clast = (cfirst + fan < nc) ? cfirst + fan : nc;
-    const int sbeg = F.row_ptr[cfirst], send = F.row_ptr[clast];
-    for (int i = sbeg + t; i < send && i - sbeg < kSibCols; i += kSibBlk) scol[i - sbeg] = F.col[i];
+    const int sbeg = F.row_ptr[cfirst], send = live ? F.row_ptr[clast] : sbeg;
+    for (int i = sbeg + t; i < send && i - sbeg < kSibCols; i += 64) scol[i - sbeg] = F.col[i];
     const int ci = cfirst + I, cj = cfirst + J;
-    const bool act = I < fan && J < fan;
+    const bool act = live && I < fan && J < fan;
     double a[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) a[k] = 0.;
     int r0 = 0, r1 = 0;
     if (act && ci < nc && cj < nc && I != J && (l > 0 || D.sibling0)) { r0 = F.row_ptr[ci]; r1 = F.row_ptr[ci + 1]; }
-    if (act && I == J) {
-        if (ci >= nc) {
+    if (I == J) {
+        if (!act || ci >= nc) {
 #pragma unroll
             for (int k = 0; k < 6; k++) a[k * 7] = 1.;
         } else {
+            double any = 0.;
 #pragma unroll
             for (int k = 0; k < 36; k++) {
                 double v = F.G[(size_t)ci * 36 + k];
                 if (l == 0) { if (k % 7 == 0) v += lambda; } else v += lambda * F.M[(size_t)ci * 36 + k];
-                a[k] = v;
+                a[k] = v; any = fmax(any, fabs(v));
+            }
+            if (any == 0.) {                             // an aggregate of empty rows only (strong-aggregate numbering): nothing to correct
+#pragma unroll
+                for (int k = 0; k < 6; k++) a[k * 7] = 1.;
             }
         }
     }
@@ -354,18 +369,13 @@ __device__ __forceinline__ void ml_sibling_kernel_body(PgoDev D, const MlDev* __
             for (int k = 0; k < 36; k++) a[k] += F.blk[(size_t)s * 36 + k];
         }
     }
-    gj_tiles<8>(a, I, J, fan, sRow, sCol);
+    gj_tiles<8>(a, I, J, 8, sRow + wv * 2 * 48, sCol + wv * 2 * 48);
     if (act) {
         double* __restrict__ out = F.Winv + (size_t)A * m * m + (size_t)(6 * I) * m + 6 * J;
 #pragma unroll
         for (int k = 0; k < 36; k++) out[(k / 6) * m + k % 6] = a[k];
     }
 }
-__global__ __launch_bounds__(kSibBlk) void ml_sibling_kernel(PgoDev D, const MlDev* __restrict__ mlp)
-{
-    ml_sibling_kernel_body(D, mlp);
-}
-
 __device__ __forceinline__ double prolong_comp(const double* __restrict__ d, const double* __restrict__ yp, int k);
 
 // ---- composite path (small graphs), per LM trial, for l = L-1 .. 1: the whole hierarchy above level l as ONE dense
@@ -626,9 +636,15 @@ __global__ __launch_bounds__(kBlk) void ml_mult_q_final_kernel(const MlDev* __re
 //      good approximate inverse of A_1: one step squares the error of the cycle, two make it exact to PCG's eyes).
 //      ml_ns_ax_kernel:   T = A_1 X        block-sparse (6x6 blocks) times dense, one lane per (row block, column)
 //      ml_ns_gemm_kernel: X' = 2 X - X T   dense f64 GEMM on the matrix cores (2 n^3 flops, n = 6 n_1 <= 960)
-// one workgroup per (row block i, 256 columns): the row's 6x6 blocks go through LDS once (broadcast reads), every lane owns
-// one column of X and walks the row's neighbours (X rows are read coalesced across the lanes)
+// one workgroup per (row block i, <= 256 columns): the row's 6x6 blocks go through LDS once (broadcast reads), every lane owns
+// one column of X and walks the row's neighbours (X rows are read coalesced across the lanes).
+// XCD-aware: workgroup b runs on XCD b % 8, and X - written by the previous kernel on all eight - comes out of the Infinity Cache into
+// that XCD's L2.  With the column range as the slow index every XCD pulled ALL of X (8 x 4.5 MB at n = 750: the kernel's 20 us);
+// with columns split into eight slabs, slab b % 8, every XCD pulls one eighth.
 constexpr int kAxChunk = 16;          // off-diagonal blocks staged per pass
+constexpr int kXcds = 8;
+__host__ __device__ __forceinline__ int ax_slab(int n6) { return ((n6 + kXcds - 1) / kXcds + 31) & ~31; }          // columns per XCD
+__host__ __device__ __forceinline__ int ax_parts(int n6) { return (ax_slab(n6) + kBlk - 1) / kBlk; }             // workgroups per (row block, slab)
 __device__ __forceinline__ void ml_ns_ax_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl, const double* __restrict__ X,
                                                        double* __restrict__ T)
 {
@@ -636,9 +652,11 @@ __device__ __forceinline__ void ml_ns_ax_kernel_body(PgoDev D, const MlDev* __re
     __shared__ int sc[kAxChunk + 1];
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
-    const int n6 = 6 * F.n;
-    const int i = blockIdx.x, c = blockIdx.y * kBlk + threadIdx.x, tid = threadIdx.x;
-    const bool act = c < n6;
+    const int n6 = 6 * F.n, slab = ax_slab(n6), parts = ax_parts(n6);
+    const int xcd = blockIdx.x % kXcds, rest = blockIdx.x / kXcds, i = rest / parts, part = rest % parts, tid = threadIdx.x;
+    if (i >= F.n) return;                                          // (a batch launches the largest graph's grid)
+    const int cin = part * kBlk + tid, c = xcd * slab + cin;
+    const bool act = cin < slab && c < n6;
     const double lambda = D.scal[3];
     const int s0 = F.row_ptr[i], s1 = F.row_ptr[i + 1];
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -694,7 +712,7 @@ __device__ __forceinline__ void tri_tile(int gt, int b, int& ti, int& tj)
 // but the slab's own MFMAs hides the global-load latency of the next slab: with slabs of 16 (47 dependent slabs, 0.2 us
 // of MFMA each) about 1 us per slab stayed exposed (55 us); slabs of 64 leave 12 exposures.
 __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __restrict__ X, const double* __restrict__ T,
-                                                        double* __restrict__ Xn)
+                                                        double* __restrict__ Xn, float* __restrict__ c32 = nullptr, int c32_stride = 0)
 {
     // Both operand tiles sit k-major in LDS, s[k][i ^ 16 (k & 1)]: the 16 x 4 (row or column, k) doubles one MFMA operand read takes
     // then fall into 64 different banks per half wave (rows padded to 65 doubles put (i, k) and (i + 1, k - 1) on the same bank: 2- to
@@ -765,12 +783,19 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
                     const double v = 2. * X[(size_t)gr * n + gc] - acc[a][b][r];
                     Xn[(size_t)gr * n + gc] = v;
                     if (ti != tj) Xn[(size_t)gc * n + gr] = v;
+                    if (c32) {                                                   // last step of a rebuild: the f32 copy the PCG kernels read (ml_cmat32_body)
+                        c32[(size_t)gr * c32_stride + gc] = (float)v;
+                        if (ti != tj) c32[(size_t)gc * c32_stride + gr] = (float)v;
+                    }
                 }
             }
+    if (c32 && tj == gt - 1 && tid < kGemmTile && row0 + tid < n)               // pad columns [n, stride) stay zero
+        for (int q = n; q < c32_stride; q++) c32[(size_t)(row0 + tid) * c32_stride + q] = 0.f;
 }
-__global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __restrict__ X, const double* __restrict__ T, double* __restrict__ Xn)
+__global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __restrict__ X, const double* __restrict__ T, double* __restrict__ Xn,
+                                                        float* __restrict__ c32, int c32_stride)
 {
-    ml_ns_gemm_kernel_body(n, X, T, Xn);
+    ml_ns_gemm_kernel_body(n, X, T, Xn, c32, c32_stride);
 }
 
 // Y_cl += QY Q^T on the f64 matrix cores - the last term of the multiplicative cycle, 2 (6 n_cl)^2 (6 n_{cl+1}) flops (13 GFLOP at 20k
@@ -853,10 +878,10 @@ __global__ __launch_bounds__(256) void ml_mult_qyqt_kernel(const MlDev* __restri
 }
 
 // ---- per LM trial: dense inverse of the top level A_L(lambda) (<= 96 x 96: kMlTopWide aggregates), one workgroup of 16 x 16 lanes,
-//      one 6 x 6 tile per lane (gj_tiles above)
-__device__ __forceinline__ void ml_top_kernel_body(PgoDev D, const MlDev* __restrict__ mlp)
+//      one 6 x 6 tile per lane (gj_tiles above); the last workgroup of ml_inverses_kernel
+__device__ __forceinline__ void ml_top_tiles(PgoDev D, const MlDev* __restrict__ mlp, double* __restrict__ sRow, double* __restrict__ sCol)
 {
-    __shared__ double sRow[2 * 6 * kMlTopWide], sCol[2 * 6 * kMlTopWide];
+    static_assert(kSibPerBlk * 48 >= 6 * kMlTopWide, "the pivot row / column buffers are shared with the sibling blocks");
     const MlDev& ml = *mlp;
     const MlLevel& L = ml.lv[ml.levels];
     const double lambda = D.scal[3];
@@ -885,6 +910,10 @@ __device__ __forceinline__ void ml_top_kernel_body(PgoDev D, const MlDev* __rest
         for (int k = 0; k < 36; k++) out[(k / 6) * n + k % 6] = a[k];
     }
 }
+__global__ __launch_bounds__(kBlk) void ml_inverses_kernel(PgoDev D, const MlDev* __restrict__ mlp)
+{
+    ml_inverses_kernel_body(D, mlp);
+}
 // The dense operator the PCG kernels apply, rounded to f32 once per rebuild (MlHot::Cmat32).  It is the largest stream of an
 // iteration (config 2: 4.5 of 10 MB; 20k vertices: 112 MB); a preconditioner does not need the last 29 bits, and being rounded once,
 // outside the iteration, it is still one fixed linear operator for the whole solve.  Four columns per lane; pad columns are zero.
@@ -907,10 +936,6 @@ __global__ __launch_bounds__(kBlk) void ml_cmat32_kernel(const double* __restric
     ml_cmat32_body(src, dst, n6, stride);
 }
 
-__global__ __launch_bounds__(kBlk) void ml_top_kernel(PgoDev D, const MlDev* __restrict__ mlp)
-{
-    ml_top_kernel_body(D, mlp);
-}
 
 // ------------------------------------------------------------------------------------------------
 // PCG-iteration kernels: two launches per iteration with the full multilevel preconditioner.
@@ -2056,13 +2081,13 @@ void k_ml_mult_level(const PgoDev& D, const MlDev* ml, int lev, int n1, int n2, 
 }
 // one Newton-Schulz step at level `lev`: Xn = 2 X - X (A_lev X); T is scratch
 void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int lev, int n1, const double* X, double* T, double* Xn, hipStream_t s,
-                  hipEvent_t ev_a, hipEvent_t ev_b)
+                  hipEvent_t ev_a, hipEvent_t ev_b, float* c32, int c32_stride)
 {
     const int n6 = 6 * n1;
-    hipLaunchKernelGGL(ml_ns_ax_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, lev, X, T);
+    hipLaunchKernelGGL(ml_ns_ax_kernel, dim3(kXcds * n1 * ax_parts(n6)), dim3(kBlk), 0, s, D, ml, lev, X, T);
     const int g = (n6 + kGemmTile - 1) / kGemmTile, gtri = g * (g + 1) / 2;     // tiles on and above the diagonal
-    if (ev_a) hipExtLaunchKernelGGL(ml_ns_gemm_kernel, dim3(gtri), dim3(256), 0, s, ev_a, ev_b, 0, n6, X, T, Xn);     // dispatch timestamps of the GEMM alone
-    else hipLaunchKernelGGL(ml_ns_gemm_kernel, dim3(gtri), dim3(256), 0, s, n6, X, T, Xn);
+    if (ev_a) hipExtLaunchKernelGGL(ml_ns_gemm_kernel, dim3(gtri), dim3(256), 0, s, ev_a, ev_b, 0, n6, X, T, Xn, c32, c32_stride);     // dispatch timestamps of the GEMM alone
+    else hipLaunchKernelGGL(ml_ns_gemm_kernel, dim3(gtri), dim3(256), 0, s, n6, X, T, Xn, c32, c32_stride);
 }
 void k_ml_cmat32(const MlHot& hot, int n6, hipStream_t s)
 {
@@ -2072,8 +2097,7 @@ void k_ml_cmat32(const MlHot& hot, int n6, hipStream_t s)
 }
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s)
 {
-    if (total_aggs > 0) hipLaunchKernelGGL(ml_sibling_kernel, dim3(total_aggs), dim3(kSibBlk), 0, s, D, ml);
-    hipLaunchKernelGGL(ml_top_kernel, dim3(1), dim3(kBlk), 0, s, D, ml);
+    hipLaunchKernelGGL(ml_inverses_kernel, dim3((total_aggs + kSibPerBlk - 1) / kSibPerBlk + 1), dim3(kBlk), 0, s, D, ml);
 }
 int g_ml_rows(int nb, int agg) { return (nb + kMlFanout * agg - 1) / (kMlFanout * agg); }
 // workgroups of ml_spmv (= p.Ap partials ml_cg sums): AGG = 4 runs two half workgroups per level-2 aggregate
@@ -2210,15 +2234,10 @@ __global__ __launch_bounds__(kBlk) void ml_reduce_lm_kernel(const LmSlot* __rest
     (void)D;
     ml_reduce_kernel_body(S.dml[c], l);
 }
-__global__ __launch_bounds__(kSibBlk) void ml_sibling_lm_kernel(const LmSlot* __restrict__ slots, int which)
+__global__ __launch_bounds__(kBlk) void ml_inverses_lm_kernel(const LmSlot* __restrict__ slots, int which)
 {
     UZL_LM_SETUP(false)
-    ml_sibling_kernel_body(D, S.dml[c]);
-}
-__global__ __launch_bounds__(kBlk) void ml_top_lm_kernel(const LmSlot* __restrict__ slots, int which)
-{
-    UZL_LM_SETUP(false)
-    ml_top_kernel_body(D, S.dml[c]);
+    ml_inverses_kernel_body(D, S.dml[c]);
 }
 __global__ __launch_bounds__(kBlk) void ml_dense_level_lm_kernel(const LmSlot* __restrict__ slots, int which, int l)
 {
@@ -2256,11 +2275,11 @@ __global__ __launch_bounds__(256) void ml_mult_qyqt_lm_kernel(const LmSlot* __re
 __global__ __launch_bounds__(kBlk) void ml_ns_ax_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k)
 {
     UZL_LM_SETUP(false)
-    if ((int)blockIdx.x >= S.hot[0].n[lev]) return;
+    if ((int)blockIdx.x >= kXcds * S.hot[0].n[lev] * ax_parts(6 * S.hot[0].n[lev])) return;
     const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
     ml_ns_ax_kernel_body(D, S.dml[c], lev, X, S.nsT[c]);
 }
-__global__ __launch_bounds__(256) void ml_ns_gemm_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k)
+__global__ __launch_bounds__(256) void ml_ns_gemm_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k, int last)
 {
     UZL_LM_SETUP(false)
     (void)D;
@@ -2268,7 +2287,8 @@ __global__ __launch_bounds__(256) void ml_ns_gemm_lm_kernel(const LmSlot* __rest
     { const int gt = (n6 + kGemmTile - 1) / kGemmTile; if ((int)blockIdx.x >= gt * (gt + 1) / 2) return; }
     const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
     double* Xn = (k & 1) ? S.dense[c][lev] : S.nsX[c];
-    ml_ns_gemm_kernel_body(n6, X, S.nsT[c], Xn);
+    const MlHot& H = S.hot[c];
+    ml_ns_gemm_kernel_body(n6, X, S.nsT[c], Xn, last ? const_cast<float*>(H.Cmat32) : nullptr, H.c32_stride);      // (last step: Xn = H.Cmat)
 }
 __global__ __launch_bounds__(kBlk) void ml_cmat32_lm_kernel(const LmSlot* __restrict__ slots, int which, int cl)
 {
@@ -2296,8 +2316,7 @@ void kl_ml_numeric(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s
 void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
 {
     const int B = sh.nslots, L = sh.levels, cl = sh.cl;
-    if (sh.inner_aggs > 0) hipLaunchKernelGGL(ml_sibling_lm_kernel, dim3(sh.inner_aggs, 1, B), dim3(kSibBlk), 0, s, sl, which);
-    hipLaunchKernelGGL(ml_top_lm_kernel, dim3(1, 1, B), dim3(kBlk), 0, s, sl, which);
+    hipLaunchKernelGGL(ml_inverses_lm_kernel, dim3((sh.inner_aggs + kSibPerBlk - 1) / kSibPerBlk + 1, 1, B), dim3(kBlk), 0, s, sl, which);
     if (cl == 0) return;                                                       // no dense operator
     const int n6c = 6 * sh.n_lv[cl];
     const long work32 = (long)n6c * (((n6c + 3) & ~3) >> 2);
@@ -2318,11 +2337,11 @@ void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
         hipLaunchKernelGGL(ml_mult_qyqt_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l);
         const int steps = l > cl ? sh.upper_ns : sh.ns_steps;
         for (int k = 0; k < steps; k++) {
-            hipLaunchKernelGGL(ml_ns_ax_lm_kernel, dim3(n1, (n6 + kBlk - 1) / kBlk, B), dim3(kBlk), 0, s, sl, which, l, k);
-            hipLaunchKernelGGL(ml_ns_gemm_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l, k);
+            hipLaunchKernelGGL(ml_ns_ax_lm_kernel, dim3(kXcds * n1 * ax_parts(n6), 1, B), dim3(kBlk), 0, s, sl, which, l, k);
+            hipLaunchKernelGGL(ml_ns_gemm_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l, k, (l == cl && k == steps - 1) ? 1 : 0);
         }
     }
-    hipLaunchKernelGGL(ml_cmat32_lm_kernel, dim3((unsigned)((work32 + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, cl);
+    if (sh.ns_steps == 0) hipLaunchKernelGGL(ml_cmat32_lm_kernel, dim3((unsigned)((work32 + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, cl);
 }
 
 // ---- PCG: init + the two iteration kernels.  SLOT = `const LmSlot*` (blockIdx.z picks the graph) or `LmSlot` BY VALUE for a pass of
@@ -2538,7 +2557,7 @@ extern "C" int uzl_debug_ns_gemm(int n, const double* X, const double* T, double
     (void)hipMemcpy(dX, X, b, hipMemcpyHostToDevice);
     (void)hipMemcpy(dT, T, b, hipMemcpyHostToDevice);
     const int g = (n + uzl::kGemmTile - 1) / uzl::kGemmTile;
-    hipLaunchKernelGGL(uzl::ml_ns_gemm_kernel, dim3(g * (g + 1) / 2), dim3(256), 0, nullptr, n, dX, dT, dO);
+    hipLaunchKernelGGL(uzl::ml_ns_gemm_kernel, dim3(g * (g + 1) / 2), dim3(256), 0, nullptr, n, dX, dT, dO, (float*)nullptr, 0);
     const hipError_t e = hipDeviceSynchronize();
     (void)hipMemcpy(out, dO, b, hipMemcpyDeviceToHost);
     (void)hipFree(dX); (void)hipFree(dT); (void)hipFree(dO);

@@ -25,13 +25,15 @@ namespace uzl {
 
 // host-side plan: which rows are eliminated, the runs, and the block-CSR of the reduced system
 struct SchurPlan {
-    int32_t nb = 0, nbr = 0, n_int = 0, n_runs = 0, nslots_r = 0, longest_run = 0;
-    std::vector<int32_t> full2red;                            // [nb] reduced row or -1
+    int32_t nb = 0, nbr = 0, n_sep = 0, n_int = 0, n_runs = 0, nslots_r = 0, longest_run = 0;      // nbr: rows of the reduced system (n_sep separators + empty rows)
+    bool strong = false; int32_t n_strong1 = 0, n_strong2 = 0;                                    // numbered by strong aggregates: their counts
+    std::vector<int32_t> full2red;                            // [nb] reduced row or -1   (sep_rows: [nbr] full row, or -1 = an empty row)
     std::vector<int32_t> run_ptr, run_rows, slotP, slotN, endL, endR, sep_rows, rsrc, inc_ptr, inc;
     std::vector<int32_t> row_ptr, col;                        // reduced block-CSR
 };
 
 // Plans the reduction of a block-CSR (row_ptr / col over free vertices, col = -1 for a fixed neighbour).  `cap` = longest run.
-SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vector<int32_t>& col, int cap);
+SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vector<int32_t>& col, int cap, const double* slot_w = nullptr,
+                     int strong_min = 0, double theta = 0.25);
 
 }  // namespace uzl

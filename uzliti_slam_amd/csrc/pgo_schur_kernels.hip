@@ -17,7 +17,67 @@
 namespace uzl {
 
 // ------------------------------------------------------------------------------------------------------------------ host: the plan
-SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vector<int32_t>& col, int cap)
+namespace {
+struct WEdge { int32_t a, c; double w; };
+// sorted by (a, c), parallel edges summed, self loops dropped
+void merge_edges(std::vector<WEdge>& E)
+{
+    std::sort(E.begin(), E.end(), [](const WEdge& x, const WEdge& y) { return x.a != y.a ? x.a < y.a : x.c < y.c; });
+    size_t o = 0;
+    for (size_t k = 0; k < E.size(); k++) {
+        if (E[k].a == E[k].c) continue;
+        if (o > 0 && E[o - 1].a == E[k].a && E[o - 1].c == E[k].c) E[o - 1].w += E[k].w; else E[o++] = E[k];
+    }
+    E.resize(o);
+}
+// Size-capped agglomeration along STRONG edges: per round a heaviest-edge matching of the current groups, an edge counting only if it is at
+// least theta x the heaviest edge at either end and the two groups together stay within `cap`; rounds until nothing merges.  Returns the
+// group of every node (groups numbered by their lowest node) and leaves the contracted graph in E.  Deterministic (ties: lower indices).
+std::vector<int32_t> strong_groups(int n, std::vector<WEdge>& E, int cap, double theta, int* n_groups)
+{
+    std::vector<int32_t> grp((size_t)n), size((size_t)n, 1);
+    for (int v = 0; v < n; v++) grp[v] = v;
+    int cur = n;
+    merge_edges(E);
+    for (int round = 0; round < 16 && cur > 1; round++) {
+        std::vector<int32_t> ord(E.size()), mate((size_t)cur, -1), nid((size_t)cur, -1);
+        std::vector<double> wmax((size_t)cur, 0.);
+        for (size_t k = 0; k < E.size(); k++) { ord[k] = (int32_t)k; wmax[E[k].a] = std::max(wmax[E[k].a], E[k].w); wmax[E[k].c] = std::max(wmax[E[k].c], E[k].w); }
+        std::sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return E[x].w != E[y].w ? E[x].w > E[y].w : x < y; });
+        bool any = false;
+        for (int32_t k : ord) {
+            const WEdge& e = E[k];
+            if (mate[e.a] >= 0 || mate[e.c] >= 0 || size[e.a] + size[e.c] > cap) continue;
+            if (e.w < theta * std::max(wmax[e.a], wmax[e.c])) continue;
+            mate[e.a] = e.c; mate[e.c] = e.a; any = true;
+        }
+        if (!any) break;
+        int cnt = 0;
+        for (int v = 0; v < cur; v++) {
+            if (nid[v] >= 0) continue;
+            nid[v] = cnt; if (mate[v] >= 0) nid[mate[v]] = cnt;
+            cnt++;
+        }
+        std::vector<int32_t> nsize((size_t)cnt, 0);
+        for (int v = 0; v < cur; v++) nsize[nid[v]] += size[v];
+        size.swap(nsize);
+        for (WEdge& e : E) { const int32_t x = nid[e.a], y = nid[e.c]; e.a = std::min(x, y); e.c = std::max(x, y); }
+        merge_edges(E);
+        for (int v = 0; v < n; v++) grp[v] = nid[grp[v]];
+        cur = cnt;
+    }
+    *n_groups = cur;
+    return grp;
+}
+}  // namespace
+
+// `slot_w` (optional): a stiffness per slot of the block-CSR (trace of the edge's information matrix).  With it, and at least
+// `strong_min` separators, the reduced system is numbered by STRONG AGGREGATES instead of in row order (pgo_schur.hpp): groups of <= 8
+// separators that hang together by edges at least `theta` x as stiff as the stiffest at either end, four such groups - again the
+// strongly coupled ones - to a block of 32 rows, every group padded to 8 rows and every block to 4 groups with EMPTY rows
+// (sep_rows = -1: identity diagonal block, zero right-hand side, no off-diagonal blocks).  A removed run counts as springs in series.
+SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vector<int32_t>& col, int cap, const double* slot_w, int strong_min,
+                     double theta)
 {
     SchurPlan P;
     P.nb = nb;
@@ -69,11 +129,12 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
         const int nx = col[row_ptr[a]];
         if (nx >= 0) walk_promote(nx, slot_to(nx, a));
     }
-    // reduced numbering
+    // reduced numbering: row order first (the runs are found with it) ...
     P.full2red.assign((size_t)std::max(nb, 1), -1);
     for (int a = 0; a < nb; a++) if (!is_int[a]) { P.full2red[a] = (int32_t)P.sep_rows.size(); P.sep_rows.push_back(a); }
-    P.nbr = (int32_t)P.sep_rows.size();
-    P.n_int = nb - P.nbr;
+    P.n_sep = (int32_t)P.sep_rows.size();
+    P.nbr = P.n_sep;
+    P.n_int = nb - P.n_sep;
     // pass 2: the runs
     std::vector<uint8_t> in_run((size_t)std::max(nb, 1), 0);
     P.run_ptr.push_back(0);
@@ -100,6 +161,41 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
         P.run_ptr.push_back((int32_t)P.run_rows.size());
     }
     P.n_runs = (int32_t)P.endL.size();
+    // ... then, for a system large enough to gain from it, by strong aggregates
+    if (slot_w && strong_min > 0 && P.n_sep >= strong_min) {
+        std::vector<WEdge> E;
+        for (int i = 0; i < P.n_sep; i++) {
+            const int a = P.sep_rows[i];
+            for (int s = row_ptr[a]; s < row_ptr[a + 1]; s++) {
+                const int c = col[s];
+                if (c >= 0 && !is_int[c] && P.full2red[c] > i) E.push_back({i, P.full2red[c], slot_w[s]});      // every edge has a slot at both ends: taken at the lower
+            }
+        }
+        for (int r = 0; r < P.n_runs; r++) {
+            const int L = P.endL[r], R = P.endR[r];
+            if (L < 0 || R < 0 || L == R) continue;
+            double inv = 0.;
+            const int p0 = P.run_ptr[r], p1 = P.run_ptr[r + 1];
+            if (P.slotP[p0] >= 0) inv += 1. / std::max(slot_w[P.slotP[p0]], 1e-300);
+            for (int q = p0; q < p1; q++) if (P.slotN[q] >= 0) inv += 1. / std::max(slot_w[P.slotN[q]], 1e-300);
+            E.push_back({std::min(L, R), std::max(L, R), inv > 0. ? 1. / inv : 0.});
+        }
+        int n1 = 0, n2 = 0;
+        const std::vector<int32_t> g1 = strong_groups(P.n_sep, E, kMlFanout, theta, &n1);      // E: now the graph of the groups
+        const std::vector<int32_t> g2 = strong_groups(n1, E, kMlFanout2, theta, &n2);
+        // position of group j of block G = 32 G + 8 j; groups and blocks are numbered by their lowest member: row order survives inside them
+        std::vector<int32_t> first1((size_t)n1, -1), slot_in2((size_t)n1, 0), fill2((size_t)n2, 0), fill1((size_t)n1, 0), perm((size_t)P.n_sep);
+        for (int a1 = 0; a1 < n1; a1++) slot_in2[a1] = fill2[g2[a1]]++;
+        const int rows_per_blk = kMlFanout * kMlFanout2;
+        for (int i = 0; i < P.n_sep; i++) { const int a1 = g1[i]; perm[i] = g2[a1] * rows_per_blk + slot_in2[a1] * kMlFanout + fill1[a1]++; }
+        P.nbr = n2 * rows_per_blk;
+        P.strong = true; P.n_strong1 = n1; P.n_strong2 = n2;
+        std::vector<int32_t> sep((size_t)P.nbr, -1);
+        for (int i = 0; i < P.n_sep; i++) sep[perm[i]] = P.sep_rows[i];
+        P.sep_rows.swap(sep);
+        for (int i = 0; i < P.nbr; i++) if (P.sep_rows[i] >= 0) P.full2red[P.sep_rows[i]] = i;
+        for (int r = 0; r < P.n_runs; r++) { if (P.endL[r] >= 0) P.endL[r] = perm[P.endL[r]]; if (P.endR[r] >= 0) P.endR[r] = perm[P.endR[r]]; }
+    }
     // reduced block-CSR: kept blocks in slot order, then the fill blocks of the incident runs in run order
     std::vector<std::vector<int32_t>> inc((size_t)std::max(P.nbr, 1));
     for (int r = 0; r < P.n_runs; r++) {
@@ -111,16 +207,18 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
     P.inc_ptr.assign((size_t)P.nbr + 1, 0);
     for (int i = 0; i < P.nbr; i++) {
         const int a = P.sep_rows[i];
-        for (int s = row_ptr[a]; s < row_ptr[a + 1]; s++) {
-            const int c = col[s];
-            if (c >= 0 && !is_int[c]) { P.col.push_back(P.full2red[c]); P.rsrc.push_back(s); }
-        }
-        for (int32_t code : inc[i]) {
-            const int r = code >> 2, side = code & 3;
-            P.inc.push_back(code);
-            if (side == 2) continue;                     // both ends here: diagonal only
-            const int other = side == 0 ? P.endR[r] : P.endL[r];
-            if (other >= 0) { P.col.push_back(other); P.rsrc.push_back(-(2 * r + side) - 1); }
+        if (a >= 0) {
+            for (int s = row_ptr[a]; s < row_ptr[a + 1]; s++) {
+                const int c = col[s];
+                if (c >= 0 && !is_int[c]) { P.col.push_back(P.full2red[c]); P.rsrc.push_back(s); }
+            }
+            for (int32_t code : inc[i]) {
+                const int r = code >> 2, side = code & 3;
+                P.inc.push_back(code);
+                if (side == 2) continue;                     // both ends here: diagonal only
+                const int other = side == 0 ? P.endR[r] : P.endL[r];
+                if (other >= 0) { P.col.push_back(other); P.rsrc.push_back(-(2 * r + side) - 1); }
+            }
         }
         P.row_ptr[i + 1] = (int32_t)P.col.size();
         P.inc_ptr[i + 1] = (int32_t)P.inc.size();
@@ -236,6 +334,11 @@ __device__ __forceinline__ void schur_assemble_kernel_body(PgoDev D, PgoDev R, S
     const int i = item - S.nslots_r;
     if (i >= S.nbr) return;
     const int a = S.sep_rows[i];
+    if (a < 0) {                                        // an empty row of a strong-aggregate numbering: x_i = 0
+        R.hdiag[(size_t)i * 36 + k] = (k % 7 == 0) ? 1. : 0.;
+        if (k < 6) R.b[(size_t)i * 6 + k] = 0.;
+        return;
+    }
     double h = D.hdiag[(size_t)a * 36 + k];
     double g = (k < 6) ? D.b[(size_t)a * 6 + k] : 0.;
     for (int q = S.inc_ptr[i]; q < S.inc_ptr[i + 1]; q++) {
@@ -256,7 +359,7 @@ __device__ __forceinline__ void schur_backsub_kernel_body(PgoDev D, PgoDev R, Sc
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= S.n_runs) {
         const int t = ((int)blockIdx.x - S.n_runs) * 64 + lane;
-        if (t < S.nbr * 6) D.x[(size_t)S.sep_rows[t / 6] * 6 + t % 6] = R.x[t];
+        if (t < S.nbr * 6 && S.sep_rows[t / 6] >= 0) D.x[(size_t)S.sep_rows[t / 6] * 6 + t % 6] = R.x[t];
         return;
     }
     const int run = blockIdx.x, c = lane % 6;
@@ -343,7 +446,7 @@ extern "C" int uzl_pgo_schur_plan(int32_t nb, const int32_t* row_ptr, const int3
     try {
         const std::vector<int32_t> rp(row_ptr, row_ptr + nb + 1), cl(col, col + (nb > 0 ? row_ptr[nb] : 0));
         for (int32_t c : cl) if (c < -1 || c >= nb) return UZL_ERR_BAD_ARG;
-        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap);
+        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap, nullptr, 0, 0.);
         if (P.nslots_r > cap_slots || (P.nslots_r > 0 && !red_col)) return UZL_ERR_BAD_ARG;
         for (int a = 0; a < nb; a++) { red_row[a] = P.full2red[a]; run_id[a] = -1; run_pos[a] = -1; }
         for (int r = 0; r < P.n_runs; r++)

@@ -100,7 +100,7 @@ struct MlLevel {
     double* G;                 // [n][36]   diagonal blocks of A_l(lambda = 0)
     double* M;                 // [n][36]   diagonal blocks of P^T P chain (lambda multiplier)
     double* geo;               // level 0: [n][12] = R^T (9), d (3); levels >= 1: [n][3] = d = c_self - c_parent
-    double* cen;               // [n][3]  centroid (levels >= 1)
+    double* cen;               // [n][4]  centroid, vertices underneath (levels >= 1)
     double* r;                 // [n][6]  restricted residual
     double* y;                 // [n][6]  coarse correction
     double* Winv;              // [n_{l+1}][(6 fan_{l+1})^2]  inverse sibling blocks of THIS level's entities (levels < L)

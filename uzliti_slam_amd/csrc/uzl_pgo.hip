@@ -222,7 +222,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     // Schur-reduced online graph (4000/6000 26.0 -> 17.2 ms; config 5's last solve 2328 -> 1288 PCG iterations).
     static const int agg1_env = diag_int("UZL_ML_AGG1_MAX", 0);
     const int agg1_max = agg1_env > 0 ? agg1_env : (nslots >= 6 * nb ? 3072 : 4096);
-    h->ml_agg = nb <= agg1_max ? 1 : 4;
+    h->ml_agg = (nb <= agg1_max && !h->red.strong) ? 1 : 4;                  // (a strong-aggregate numbering is laid out for AGG = 4: blocks of 4 x 8 rows)
     int L = 0;
     h->ml_fan.assign(1, 1);
     // composite path: one aggregate per workgroup, at least two coarse levels, 6 n_1 <= 960 (<= 1280 free vertices)
@@ -317,7 +317,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         dof[l].M = (l == 0) ? 0 : take(n * 36 * 8);
         dof[l].Winv = (l < L) ? take((size_t)std::max(h->ml_n[l + 1], 1) * (size_t)(36 * h->ml_fan[l + 1] * h->ml_fan[l + 1]) * 8) : 0;
         dof[l].geo = (l == 0) ? take(n * 12 * 8) : 0;          // levels >= 1: one contiguous blob (geo_blob below)
-        dof[l].cen = take(n * 3 * 8);
+        dof[l].cen = take(n * 4 * 8);
         dof[l].r = take(n * 6 * 8);
         dof[l].y = take(n * 6 * 8);
     }
@@ -511,10 +511,11 @@ void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool tim
         for (int k = 0; k < h->ml_ns_steps; k++) {
             hipEvent_t ea = nullptr, eb = nullptr;
             if (timed) h->timer.pair("ml_ns_gemm", &ea, &eb);                  // the f64 matrix-core GEMM of the refinement, on its own
-            k_ml_ns_step(D, B.dml, cl, h->ml_n[cl], xa, B.nsT, xb, s, ea, eb);
+            const bool last = k == h->ml_ns_steps - 1;                         // its epilogue also writes the f32 copy the PCG kernels read
+            k_ml_ns_step(D, B.dml, cl, h->ml_n[cl], xa, B.nsT, xb, s, ea, eb, last ? const_cast<float*>(B.hot.Cmat32) : nullptr, B.hot.c32_stride);
             std::swap(xa, xb);
         }
-        k_ml_cmat32(B.hot, 6 * h->ml_n[cl], s);
+        if (h->ml_ns_steps == 0) k_ml_cmat32(B.hot, 6 * h->ml_n[cl], s);
     }
 }
 }  // namespace uzl
@@ -665,7 +666,7 @@ void build_structure(uzl_pgo* h)
     // ---- Schur reduction of the chain interiors (pgo_schur.hpp): when a third or more of the free vertices carry nothing but their two
     //      chain edges, the PCG runs on the Schur complement over the others (sharded solves included: see SchurDev::runblk).
     uzl_pgo::Reduced& Rd = h->red;
-    Rd.on = false; Rd.n_int = 0; Rd.n_runs = 0; Rd.longest_run = 0;
+    Rd.on = false; Rd.n_int = 0; Rd.n_runs = 0; Rd.longest_run = 0; Rd.strong = false;
     PgoDev& Dp = h->Dp;
     static const int schur_diag = diag_int("UZL_SCHUR", 1);                  // A/B switches (diagnostic build)
     static const int schur_cap = diag_int("UZL_SCHUR_CAP", 24);
@@ -674,10 +675,22 @@ void build_structure(uzl_pgo* h)
     std::vector<int32_t> rrow_ptr, rcol;
     if (h->cfg.schur_reduce >= 0 && schur_diag && nb > 0) {
         tick("block-CSR + uploads");
-        SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap);
+        // The reduced system of a large chain-like graph is numbered by strong aggregates (pgo_schur.hpp) and takes the AGG = 4 hierarchy: the
+        // separators an aggregate holds then move (nearly) rigidly together, which is what its six coarse modes can represent.  In row order
+        // "8 consecutive separators" put loop-closure partners into different aggregates and the two ends of a long soft run into the same
+        // one: config 5's last re-optimisation took 70 - 140 PCG iterations per LM iteration (tests/diag/reduced_proto.py: 70 -> 23).
+        static const int strong_env = diag_int("UZL_SCHUR_STRONG_MIN", -1);     // A/B switch: separators from which on (0 = never)
+        static const int strong_theta_pct = diag_int("UZL_SCHUR_STRONG_THETA", 25);
+        const int strong_min = (may_shard || h->cfg.preconditioner == 0) ? 0 : (strong_env >= 0 ? strong_env : kSchurStrongMin);
+        std::vector<double> slot_w;
+        if (strong_min > 0 && h->edge_w.size() == (size_t)e) {
+            slot_w.resize((size_t)std::max(nslots, 1));
+            for (int q = 0; q < nslots; q++) slot_w[q] = h->edge_w[slot_edge[q] >> 1];
+        }
+        SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap, slot_w.empty() ? nullptr : slot_w.data(), strong_min, 0.01 * strong_theta_pct);
         tick("Schur plan");
         if (P.n_int >= 64 && (int64_t)100 * P.n_int >= (int64_t)schur_min_pct * nb) {
-            Rd.on = true; Rd.n_int = P.n_int; Rd.n_runs = P.n_runs; Rd.longest_run = P.longest_run;
+            Rd.on = true; Rd.n_int = P.n_int; Rd.n_runs = P.n_runs; Rd.longest_run = P.longest_run; Rd.strong = P.strong;
             const size_t nr = (size_t)std::max(P.nbr, 1), nsr = (size_t)std::max(P.nslots_r, 1), ni = (size_t)P.n_int, nru = (size_t)P.n_runs;
             auto up = [&](DevBuf<int32_t>& b, const std::vector<int32_t>& v, size_t min_n) {
                 b.reserve(std::max(v.size(), min_n));
@@ -688,7 +701,7 @@ void build_structure(uzl_pgo* h)
             up(Rd.inc_ptr, P.inc_ptr, 1); up(Rd.inc, P.inc, 1); up(Rd.row_ptr, P.row_ptr, 1); up(Rd.col, P.col, 1);
             std::vector<int32_t> rb2v((size_t)P.nbr), rhdr(nr * kRowHdr, -1);
             for (int i = 0; i < P.nbr; i++) {
-                rb2v[i] = b2v[P.sep_rows[i]];
+                rb2v[i] = P.sep_rows[i] >= 0 ? b2v[P.sep_rows[i]] : -1;
                 rhdr[(size_t)i * kRowHdr] = P.row_ptr[i]; rhdr[(size_t)i * kRowHdr + 1] = P.row_ptr[i + 1];
                 for (int k = 0; k < 20 && P.row_ptr[i] + k < P.row_ptr[i + 1]; k++) rhdr[(size_t)i * kRowHdr + 2 + k] = P.col[P.row_ptr[i] + k];
             }
@@ -951,7 +964,6 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     // optimizer_.optimize(iterations) (:148) -> OptimizationAlgorithmLevenberg::solve [EXT]
     double lambda = 0., ni = 2., current_chi = 0.;
     double last_rel = 1e300;
-    int pcg_last = 0;
     double rate_ref = -1., rate_last = -1.;
     // Asynchronous rebuild: from the second LM iteration on a wanted rebuild runs on stream2 into the OTHER copy of the
     // hierarchy while this iteration's PCG still uses the current one (any SPD preconditioner gives the same solution; one
@@ -1086,7 +1098,6 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
                 pcg_its = pcg_solve(h, &conv);
                 S.pcg_iterations += pcg_its;
             }
-            pcg_last = pcg_its;
             {
                 const double rate = pcg_rate(h->h_scal.p->scal[1], h->h_scal.p->scal[0], pcg_its, h->cfg.pcg_tol * h->cfg.pcg_tol, tol_f2);
                 if (rate > 0.) { rate_last = rate; if (fresh || rate_ref < 0.) rate_ref = rate; }
