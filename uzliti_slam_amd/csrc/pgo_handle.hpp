@@ -196,6 +196,7 @@ int pgo_fail(uzl_pgo* h, int code, const char* msg);
 int32_t gauge_fix(uzl_pgo* h);                        // G2: setFixedNodes (g2o_optimizer.cpp:301-349)
 void build_structure(uzl_pgo* h);                     // block-CSR, Schur plan, hierarchy; bumps structure_gen
 void destroy_pcg_graph(uzl_pgo* h);
+bool ml_async_level(const uzl_pgo* h);
 void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void prepare_optimize(uzl_pgo* h);                    // optimizeImpl's front part: gauge + structure (cached), t_start
@@ -209,7 +210,7 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);
 bool lm_batch_eligible(const std::vector<uzl_pgo*>& hs);
 int batch_optimize_lm(LmRun*& R, const std::vector<uzl_pgo*>& hs, int resident, hipStream_t s, hipStream_t s2, int32_t iterations, bool eager, bool verbose, KernelTimer* timer,
                       uzl_pgo_stats* stats, int* rc_all);
-constexpr int kSchurStrongMin = 1024;                 // separators from which on the reduced system is numbered by strong aggregates
+constexpr int kSchurStrongMin = 128;                  // separators from which on the reduced system is numbered by strong aggregates
 extern const int kUpperNs;                            // Newton-Schulz steps of the dense levels above the composite level
 extern const bool kAlwaysRefresh;                     // A/B switches (diagnostic build)
 extern const double kRefreshRel, kLambdaRetake;

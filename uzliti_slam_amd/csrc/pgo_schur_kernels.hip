@@ -82,6 +82,7 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
     SchurPlan P;
     P.nb = nb;
     if (cap < 1) cap = 1;
+    if (cap > 64) cap = 64;                              // (schur_eliminate_kernel keeps a run's rows in the lanes of one wave)
     auto deg = [&](int a) { return row_ptr[a + 1] - row_ptr[a]; };
     // a chain interior: one or two incident edges, to different neighbours (a double edge makes both ends separators)
     std::vector<uint8_t> cand((size_t)std::max(nb, 1), 0);
@@ -263,16 +264,29 @@ __device__ __forceinline__ void schur_eliminate_kernel_body(PgoDev D, SchurDev S
     // (sharded solve: the chain blocks come summed over the ranks - schur_gather_kernel + one all-reduce per linearisation)
     const double* __restrict__ cblk = S.runblk ? S.runblk + (size_t)(S.n_int + run) * 36 : D.blk + (size_t)(hasL ? S.slotP[p0] : 0) * 36;
     if (hasL && act) cval = cblk[c * 6 + r];                                      // C_1 = H_{s0,v1} = H_{v1,s0}^T
+    // A run is a chain of <= cap dependent steps, each a handful of round trips if it fetches its own operands: the rows and slots of the
+    // whole run are fetched once (lane q: step q; runs are <= 64 long, schur_plan), and every step's blocks one step ahead.
+    const int len = p1 - p0;
+    const int vq = lane < len ? S.run_rows[p0 + lane] : 0, sq = lane < len ? S.slotN[p0 + lane] : -1;
+    auto fetch = [&](int q, double& hd, double& ev, double& bv) {
+        const int v = __shfl(vq, q), sn = __shfl(sq, q);
+        const bool hasN = sn >= 0 && (q + 1 < len || hasR);
+        hd = act ? D.hdiag[(size_t)v * 36 + lane] : 0.;
+        ev = (act && hasN) ? (S.runblk ? S.runblk[(size_t)(p0 + q) * 36 + lane] : D.blk[(size_t)sn * 36 + lane]) : 0.;
+        bv = vec ? D.b[(size_t)v * 6 + lane] : 0.;
+    };
+    double hd, ev, bv;
+    fetch(0, hd, ev, bv);
     for (int p = p0; p < p1; p++) {
-        const int v = S.run_rows[p];
-        const int sn = S.slotN[p];
+        const int sn = __shfl(sq, p - p0);
         const bool hasN = sn >= 0 && (p + 1 < p1 || hasR);
         if (act) {
-            sD[lane] = D.hdiag[(size_t)v * 36 + lane] + ((r == c) ? lambda : 0.) + dupd;
-            sE[lane] = hasN ? (S.runblk ? S.runblk[(size_t)p * 36 + lane] : D.blk[(size_t)sn * 36 + lane]) : 0.;
+            sD[lane] = hd + ((r == c) ? lambda : 0.) + dupd;
+            sE[lane] = ev;
             sC[lane] = cval;
         }
-        if (vec) sg[lane] = D.b[(size_t)v * 6 + lane] + gupd;
+        if (vec) sg[lane] = bv + gupd;
+        if (p + 1 < p1) fetch(p + 1 - p0, hd, ev, bv);
         __syncthreads();
         // Dinv: every lane inverts the same 36 numbers (Cholesky, registers only) and keeps its own element
         double A[36], Di[36];

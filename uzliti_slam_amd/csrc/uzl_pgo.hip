@@ -457,6 +457,15 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
 // numeric part, once per linearisation: geometry, then A_{l+1} = P^T A_l P level by level
 }  // namespace
 namespace uzl {
+// Asynchronous rebuild (second stream, second copy of the hierarchy) pays on the composite level-1 path, and for the reduced system of a
+// chain-like graph on the level-2 path: there a rebuild (0.8 ms) is as long as the LM iteration it would otherwise hold up.  (Other
+// level-2 graphs - config 4 - measured +9 % PCG iterations for no net gain: UZL_ML_ASYNC_LARGE.)
+bool ml_async_level(const uzl_pgo* h)
+{
+    static const bool async_large = diag_flag("UZL_ML_ASYNC_LARGE");          // A/B switches
+    static const int async_strong = diag_int("UZL_ML_ASYNC_STRONG", 1);
+    return h->ml_cl == 1 || (h->ml_cl == 2 && (async_large || (h->red.on && h->red.strong && async_strong)));
+}
 void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed)
 {
     if (h->ml_levels == 0) return;
@@ -972,8 +981,7 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     static const bool async_off = diag_flag("UZL_ML_SYNC_REBUILD");             // A/B switch
     // (small graphs only: at 10k vertices the rebuild's Newton-Schulz GEMMs take more from the overlapped PCG than they give back:
     // 113.2 -> 115.1 ms; config 2: 11.09 -> 10.67 ms with 540 instead of 517 PCG iterations)
-    static const bool async_large = diag_flag("UZL_ML_ASYNC_LARGE");          // A/B switch
-    const bool async_ok = !async_off && h->ml_levels > 0 && (h->ml_cl == 1 || (async_large && h->ml_cl == 2)) && !h->sharded && !h->timer.on && h->stream2 != nullptr;
+    const bool async_ok = !async_off && h->ml_levels > 0 && ml_async_level(h) && !h->sharded && !h->timer.on && h->stream2 != nullptr;
     bool adopted = false;
     h->ml_ix = 0; h->ml_pending = false;
     struct DrainRebuild {                      // an exception must not leave a rebuild running on stream2 behind the handle's back

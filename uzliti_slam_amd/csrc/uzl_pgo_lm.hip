@@ -181,7 +181,7 @@ LmDev initial_state(const uzl_pgo* h, int iterations)
     I.always_refresh = kAlwaysRefresh ? 1 : 0;
     // (do_optimize_host's async_ok: rebuilds run ahead for the small-graph class only - at 10k vertices the rebuild's GEMMs take more from
     //  the overlapped PCG than they give back)
-    I.sync_rebuild = (h->ml_cl == 1 && h->ml_comp) ? 0 : 1;
+    I.sync_rebuild = (h->ml_comp && ml_async_level(h)) ? 0 : 1;
     I.guarded = (h->ml_mult || h->ml_ns_steps > 0) ? 1 : 0;
     I.ni = 2.; I.last_rel = 1e300; I.rate_ref = -1.; I.rate_last = -1.;
     I.tol_f2 = pgo_tol_f2(h->cfg); I.eps_t = pgo_eps_t(h->cfg); I.eps_r = pgo_eps_r(h->cfg);
