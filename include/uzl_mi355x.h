@@ -313,6 +313,19 @@ int  uzl_pgo_add_graph(uzl_pgo* h,
                        int32_t n_edges, const uzl_edge* edges,
                        int32_t n_sensors, const double* sensors);
 
+/* The graph of the last uzl_pgo_add_graph / uzl_pgo_append_graph, GROWN in place: n_new_nodes nodes and n_new_edges edges are appended
+ * (node ids continue: the first new node is node n_nodes of the graph so far; edges may name any node), and the `valid` flag of the
+ * old edges edge_index[0 .. n_flags) is set to edge_valid[.].  An online session re-optimises a graph that gained a few hundred nodes
+ * and edges since the last time (graph_slam_node.cpp:1138-1150 -> g2o_optimizer.cpp:55-104 rebuilds it from the SlamGraph every time);
+ * with the graph resident in HBM only the new part crosses PCIe and only the new part is flattened.
+ * The result is what uzl_pgo_add_graph gives for the grown arrays with the old nodes' poses as uzl_pgo_store last returned them - the
+ * handle's current estimates, i.e. what storeImpl wrote back into the SlamGraph (:106-135) - and the same skip rules (node `fixed`
+ * flags of old nodes stay as given).  Sensors stay as given to uzl_pgo_add_graph.  Only copies. */
+int  uzl_pgo_append_graph(uzl_pgo* h,
+                          int32_t n_new_nodes, const uzl_node* new_nodes,
+                          int32_t n_new_edges, const uzl_edge* new_edges,
+                          int32_t n_flags, const int32_t* edge_index, const uint8_t* edge_valid);
+
 /* Already-flattened form of the same problem (what addGraphImpl leaves inside g2o):
  * poses n x 12, fixed n, ij e x 2, meas e x 12, info e x 36, robust e. */
 int  uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t* fixed,

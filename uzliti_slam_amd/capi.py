@@ -483,6 +483,39 @@ class Pgo:
                                             C.c_int32(0 if S is None else S.shape[0]), _p(S, c_f64p)))
         self.n = n; self.e_in = ne
 
+    @staticmethod
+    def pack_edges(edges, lo=0, hi=None):
+        """SlamEdge dict-of-arrays (synth.make_pose_graph) -> EDGE_DTYPE array of edges [lo, hi)."""
+        hi = len(edges["from"]) if hi is None else hi
+        ne = hi - lo
+        ea = np.zeros(max(ne, 1), EDGE_DTYPE)
+        for k in ("from", "to", "type", "sensor_from", "sensor_to", "valid"):
+            ea[k][:ne] = edges[k][lo:hi]
+        for k, w in (("transform", 12), ("displacement_from", 12), ("displacement_to", 12), ("information", 36)):
+            ea[k][:ne] = np.asarray(edges[k][lo:hi], np.float64).reshape(ne, w)
+        if "diff_time" in edges:
+            ea["diff_time"][:ne] = edges["diff_time"][lo:hi]
+        return ea, ne
+
+    def append_graph(self, new_pose, new_fixed, new_edges, flag_index=None, flag_valid=None):
+        """uzl_pgo_append_graph: the resident graph grown by new nodes / edges (`new_edges`: dict like add_graph's, or a packed EDGE_DTYPE
+        array), the valid flag of old input edges flag_index set to flag_valid.  Old nodes keep the handle's current estimates."""
+        n = len(new_fixed)
+        na = np.zeros(max(n, 1), NODE_DTYPE)
+        na["pose"][:n] = np.asarray(new_pose, np.float64).reshape(n, 12); na["fixed"][:n] = new_fixed
+        if isinstance(new_edges, np.ndarray):
+            ea, ne = np.ascontiguousarray(new_edges), len(new_edges)
+            if ne == 0:
+                ea = np.zeros(1, EDGE_DTYPE)
+        else:
+            ea, ne = self.pack_edges(new_edges)
+        fi = np.ascontiguousarray(flag_index if flag_index is not None else [], np.int32)
+        fv = np.ascontiguousarray(flag_valid if flag_valid is not None else [], np.uint8)
+        assert fi.shape == fv.shape
+        self._check(lib().uzl_pgo_append_graph(self._h, C.c_int32(n), _p(na, C.c_void_p), C.c_int32(ne), _p(ea, C.c_void_p),
+                                               C.c_int32(len(fi)), _p(fi, c_i32p), _p(fv, c_u8p)))
+        self.n += n; self.e_in += ne
+
     def set_graph(self, poses, fixed, ij, meas, info, robust):
         P = np.ascontiguousarray(poses, np.float64).reshape(-1, 12); f = np.ascontiguousarray(fixed, np.uint8)
         ijc = np.ascontiguousarray(ij, np.int32).reshape(-1, 2)

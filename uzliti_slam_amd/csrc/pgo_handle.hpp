@@ -94,6 +94,11 @@ struct uzl_pgo {
     std::vector<uint8_t> fixed_in, fixed_eff;
     std::vector<int32_t> ij;       // system edges, 2 per edge
     std::vector<int32_t> src;      // system edge -> input edge
+    // what the skip rules need of every INPUT edge of uzl_pgo_add_graph (kept so that uzl_pgo_append_graph can grow the graph in place)
+    struct InEdge { int32_t from, to; uint8_t odom, valid; double w; };
+    std::vector<InEdge> in_edges;
+    bool in_ready = false;         // in_edges / d_edges describe the current graph (add_graph or append_graph, not set_graph)
+    int32_t n_sensors_in = 0;
     std::vector<uint8_t> robust;
     std::vector<double> edge_w;    // trace of each system edge's information matrix: the coupling strength the aggregation order follows
     bool have_graph = false, structure_ready = false;

@@ -146,10 +146,11 @@ void shard_allreduce_chi2(uzl_pgo* h)
 }
 
 // allocate everything that depends on (n, e) only
-void alloc_problem(uzl_pgo* h)
+void alloc_problem(uzl_pgo* h, bool keep_poses = false)
 {
     const size_t n = std::max(h->n, 1), e = std::max(h->e, 1);
-    h->pose_a.reserve(n * 8); h->pose_b.reserve(n * 8); h->pose_init.reserve(n * 8);
+    const bool cur_b = keep_poses && h->cur != nullptr && h->cur == h->pose_b.p;       // (the estimate sits in whichever buffer the last solve left it)
+    h->pose_a.reserve(n * 8, keep_poses, h->stream); h->pose_b.reserve(n * 8, keep_poses, h->stream); h->pose_init.reserve(n * 8);
     h->d_zinv.reserve(e * 7); h->d_info.reserve(e * 36); h->d_robust.reserve(e);
     h->d_ei.reserve(e); h->d_ej.reserve(e); h->d_slot_i.reserve(e); h->d_slot_j.reserve(e);
     h->d_v2b.reserve(n);
@@ -158,7 +159,38 @@ void alloc_problem(uzl_pgo* h)
     h->h_scal.reserve(1, hipHostMallocMapped | hipHostMallocCoherent); h->h_lambda.reserve(1);
     memset(h->h_scal.p, 0, sizeof(PgoHostScal));
     UZL_HIP(hipHostGetDevicePointer((void**)&h->d_pub, h->h_scal.p, 0));
-    h->cur = h->pose_a.p; h->trial = h->pose_b.p;
+    h->cur = cur_b ? h->pose_b.p : h->pose_a.p; h->trial = cur_b ? h->pose_a.p : h->pose_b.p;
+}
+
+// the skip rules of addGraphImpl over uzl_pgo::in_edges: odometry edges are added while iterating (:78-79), filtered feature edges after (:100-103)
+void flatten_edges(uzl_pgo* h)
+{
+    h->ij.clear(); h->src.clear(); h->robust.clear(); h->edge_w.clear();
+    const int n_nodes = h->n, n_edges = (int)h->in_edges.size();
+    for (int pass = 0; pass < 2; pass++) {
+        for (int k = 0; k < n_edges; k++) {
+            const uzl_pgo::InEdge& ed = h->in_edges[k];
+            if (ed.from < 0 || ed.to < 0 || ed.from >= n_nodes || ed.to >= n_nodes) continue;     // :77, :194-201, :263-268
+            if (ed.from == ed.to) continue;                                                        // degenerate self edge
+            if ((pass == 0) != (ed.odom != 0)) continue;
+            if (ed.odom) {
+                if (h->fixed_in[ed.from] && !h->fixed_in[ed.to]) continue;                         // :203-206
+            } else {
+                if (!ed.valid) continue;                                                           // not in validEdges() (:98)
+                if (h->fixed_in[ed.from] && h->fixed_in[ed.to]) continue;                          // :270-274
+            }
+            h->ij.push_back(ed.from); h->ij.push_back(ed.to);
+            h->src.push_back(k);
+            h->edge_w.push_back(ed.w);
+            h->robust.push_back(ed.odom ? 0 : 1);                                                  // Huber on feature edges (:292-294)
+        }
+    }
+    h->e = (int32_t)h->src.size();
+}
+uzl_pgo::InEdge in_edge_of(const uzl_edge& ed)
+{
+    double tr = 0.; for (int r = 0; r < 6; r++) tr += ed.information[r * 7];
+    return {ed.from, ed.to, (uint8_t)(ed.type == UZL_EDGE_TYPE_2D_WHEEL_ODOMETRY ? 1 : 0), (uint8_t)(ed.valid ? 1 : 0), tr};
 }
 
 void upload_edges_common(uzl_pgo* h)
@@ -1298,28 +1330,10 @@ int uzl_pgo_add_graph(uzl_pgo* h, int32_t n_nodes, const uzl_node* nodes, int32_
     h->n = n_nodes; h->e_in = n_edges;
     h->fixed_in.assign((size_t)n_nodes, 0);
     for (int v = 0; v < n_nodes; v++) h->fixed_in[v] = nodes[v].fixed ? 1 : 0;
-    // skip rules; odometry edges are added while iterating (:78-79), filtered feature edges after (:100-103)
-    h->ij.clear(); h->src.clear(); h->robust.clear(); h->edge_w.clear();
-    for (int pass = 0; pass < 2; pass++) {
-        for (int k = 0; k < n_edges; k++) {
-            const uzl_edge& ed = edges[k];
-            if (ed.from < 0 || ed.to < 0 || ed.from >= n_nodes || ed.to >= n_nodes) continue;     // :77, :194-201, :263-268
-            if (ed.from == ed.to) continue;                                                        // degenerate self edge
-            const bool odom = ed.type == UZL_EDGE_TYPE_2D_WHEEL_ODOMETRY;
-            if ((pass == 0) != odom) continue;
-            if (odom) {
-                if (nodes[ed.from].fixed && !nodes[ed.to].fixed) continue;                         // :203-206
-            } else {
-                if (!ed.valid) continue;                                                           // not in validEdges() (:98)
-                if (nodes[ed.from].fixed && nodes[ed.to].fixed) continue;                          // :270-274
-            }
-            h->ij.push_back(ed.from); h->ij.push_back(ed.to);
-            h->src.push_back(k);
-            { double tr = 0.; for (int r = 0; r < 6; r++) tr += ed.information[r * 7]; h->edge_w.push_back(tr); }
-            h->robust.push_back(odom ? 0 : 1);                                                     // Huber on feature edges (:292-294)
-        }
-    }
-    h->e = (int32_t)h->src.size();
+    h->in_edges.resize((size_t)n_edges);
+    for (int k = 0; k < n_edges; k++) h->in_edges[k] = in_edge_of(edges[k]);
+    h->in_ready = true; h->n_sensors_in = n_sensors;
+    flatten_edges(h);
     alloc_problem(h);
     hipStream_t s = h->stream;
     h->d_nodes.reserve((size_t)std::max(n_nodes, 1));
@@ -1343,6 +1357,46 @@ int uzl_pgo_add_graph(uzl_pgo* h, int32_t n_nodes, const uzl_node* nodes, int32_
     UZL_GUARD_END(h)
 }
 
+int uzl_pgo_append_graph(uzl_pgo* h, int32_t n_new_nodes, const uzl_node* new_nodes, int32_t n_new_edges, const uzl_edge* new_edges,
+                         int32_t n_flags, const int32_t* edge_index, const uint8_t* edge_valid)
+{
+    UZL_GUARD_BEGIN(h)
+    if (n_new_nodes < 0 || n_new_edges < 0 || n_flags < 0 || (n_new_nodes > 0 && !new_nodes) || (n_new_edges > 0 && !new_edges) ||
+        (n_flags > 0 && (!edge_index || !edge_valid)))
+        return fail(h, UZL_ERR_BAD_ARG, "null or negative-size input");
+    if (!h->have_graph || !h->in_ready) return fail(h, UZL_ERR_BAD_ARG, "uzl_pgo_append_graph needs a graph from uzl_pgo_add_graph to grow");
+    const int32_t n_old = h->n, e_old = h->e_in;
+    for (int q = 0; q < n_flags; q++) if (edge_index[q] < 0 || edge_index[q] >= e_old) return fail(h, UZL_ERR_BAD_ARG, "edge index out of range");
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    StructureKey old_key = take_structure_key(h);
+    h->have_graph = false; h->structure_ready = false;
+    h->n = n_old + n_new_nodes; h->e_in = e_old + n_new_edges;
+    if (old_key.ready) { h->fixed_in = old_key.fixed_in; }               // (the key took the vectors; the old flags are the first n_old of the new)
+    for (int v = 0; v < n_new_nodes; v++) h->fixed_in.push_back(new_nodes[v].fixed ? 1 : 0);
+    for (int q = 0; q < n_flags; q++) h->in_edges[edge_index[q]].valid = edge_valid[q] ? 1 : 0;
+    for (int k = 0; k < n_new_edges; k++) h->in_edges.push_back(in_edge_of(new_edges[k]));
+    flatten_edges(h);
+    hipStream_t s = h->stream;
+    alloc_problem(h, true);                                             // the estimates of the old nodes stay where the last solve left them
+    h->d_nodes.reserve((size_t)std::max(n_new_nodes, 1));
+    h->d_edges.reserve((size_t)std::max(h->e_in, 1), true, s);
+    h->d_src.reserve((size_t)std::max(h->e, 1));
+    if (n_new_nodes) UZL_HIP(hipMemcpyAsync(h->d_nodes.p, new_nodes, sizeof(uzl_node) * (size_t)n_new_nodes, hipMemcpyHostToDevice, s));
+    if (n_new_edges) UZL_HIP(hipMemcpyAsync(h->d_edges.p + e_old, new_edges, sizeof(uzl_edge) * (size_t)n_new_edges, hipMemcpyHostToDevice, s));
+    if (h->e) UZL_HIP(hipMemcpyAsync(h->d_src.p, h->src.data(), sizeof(int32_t) * (size_t)h->e, hipMemcpyHostToDevice, s));
+    if (n_new_nodes) k_prepare_nodes(h->d_nodes.p, n_new_nodes, h->cfg.optimize_xy_only, h->cur + (size_t)n_old * 8, s);
+    k_prepare_edges(h->d_edges.p, h->d_src.p, h->e, h->d_stage.p, h->n_sensors_in, h->cfg.optimize_xy_only, h->cfg.use_odometry_parameters,
+                    h->d_zinv.p, h->d_info.p, s);
+    UZL_HIP(hipGetLastError());
+    if (h->n) UZL_HIP(hipMemcpyAsync(h->pose_init.p, h->cur, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
+    UZL_HIP(hipStreamSynchronize(s));                          // inputs are borrowed for the duration of the call only
+    upload_edges_common(h);
+    h->have_graph = true;
+    h->structure_ready = same_structure(h, old_key);
+    return UZL_OK;
+    UZL_GUARD_END(h)
+}
+
 int uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t* fixed, int32_t e,
                       const int32_t* ij, const double* meas, const double* info, const uint8_t* robust)
 {
@@ -1356,6 +1410,7 @@ int uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t*
     StructureKey old_key = take_structure_key(h);
     h->have_graph = false; h->structure_ready = false;
     h->n = n; h->e_in = e; h->e = e;
+    h->in_ready = false; h->in_edges.clear();                            // (d_stage, the sensors' place, is this call's staging area)
     h->fixed_in.assign(fixed, fixed + n);
     for (auto& f : h->fixed_in) f = f ? 1 : 0;
     h->ij.assign(ij, ij + 2 * (size_t)e);

@@ -52,7 +52,7 @@ class OnlineSlam:
     """State of one online run.  `run` = synth.make_online_run(...) (or any dict of the same layout)."""
 
     def __init__(self, run, device=0, reopt_edges=256, lm_iterations=20, lookahead=None, match_cfg=None, gate_cfg=None,
-                 filter_cfg=None, pgo_cfg=None, match_batch=512, rank=0, world=1, tdist=None, solve_rank=0, log=None):
+                 filter_cfg=None, pgo_cfg=None, match_batch=512, rank=0, world=1, tdist=None, solve_rank=0, log=None, incremental=True):
         self.run = run
         self.N = len(run["fixed"])
         self.P = len(run["pair_from"])
@@ -88,6 +88,8 @@ class OnlineSlam:
         self.keep_poses_per_solve = 0                 # diagnostics / bench: keep a copy of the solved poses of the first k re-optimisations
         self.poses_at_solve = []
         self._t_first = None                          # start of the first interval: every solve records the wall clock since then
+        self.incremental = bool(incremental)          # grow the solver's resident graph (uzl_pgo_append_graph) instead of re-sending all of it
+        self._pgo_nodes = 0; self._pgo_feats = 0; self._pgo_edges = 0; self._f_in_idx = np.zeros(0, np.int32); self._last = None
 
     def _open_handles(self, device, mc, gate_cfg, filter_cfg, pgo_cfg):
         """The four C-ABI handles of the path (estimator on every rank; gate, filter and solver on the solver rank)."""
@@ -157,6 +159,20 @@ class OnlineSlam:
              "information": np.concatenate([self.odo_info[:no], self.f_info]),
              "diff_time": np.concatenate([np.full(no, 0.5), np.zeros(nf)])}
         return e
+
+    @property
+    def last_input(self):
+        """(poses, fixed, edges) of the last re-optimisation as addGraphImpl gets them: the full arrays (tests, diagnostics)."""
+        n_nodes, poses, in_solve = self._last
+        nf = len(in_solve)
+        keep = (self.f_key, self.f_from, self.f_to, self.f_T, self.f_info, self.f_sticky)
+        try:        # (feature edges accepted after that solve are not part of it)
+            self.f_key, self.f_from, self.f_to, self.f_T, self.f_info, self.f_sticky = (x[:nf] for x in keep)
+            e = self._graph_edges(n_nodes)
+        finally:
+            self.f_key, self.f_from, self.f_to, self.f_T, self.f_info, self.f_sticky = keep
+        e["valid"][n_nodes - 1:] = in_solve                                         # only validEdges() enter the solve (:98-103)
+        return poses, self.run["fixed"][:n_nodes], e
 
     def step(self):
         """One solve interval: admit nodes up to the next trigger, gate their candidates, filter, re-optimise.  Returns False at the end."""
@@ -242,11 +258,31 @@ class OnlineSlam:
         t_filter = time.perf_counter() - t0
         self.t["filter"] += t_filter
         # ---- re-optimise (addGraphImpl: full rebuild; optimizeImpl; storeImpl)
-        e = self._graph_edges(n_nodes)
-        e["valid"][n_nodes - 1:] = in_solve                                         # only validEdges() enter the solve (:98-103)
-        self.last_input = (self.poses[:n_nodes].reshape(-1, 12).copy(), run["fixed"][:n_nodes], e)     # what addGraphImpl was given
+        self._last = (n_nodes, self.poses[:n_nodes].reshape(-1, 12).copy(), in_solve.copy())      # what addGraphImpl is given (last_input)
         t0 = time.perf_counter()
-        self.pgo.add_graph(*self.last_input)
+        if self.incremental and self._pgo_nodes > 0 and hasattr(self.pgo, "append_graph"):
+            # the graph resident in the solver, grown: the nodes and edges admitted since the last solve (odometry edge i-1 -> i of every
+            # new node i, then the feature edges in acceptance order - the order addGraphImpl's two passes give the full arrays), and the
+            # filter's verdict on the old feature edges.  The old nodes' poses ARE the solver's estimates (storeImpl wrote them here).
+            a = self._pgo_nodes; f0 = self._pgo_feats
+            no = n_nodes - a; nfn = nf - f0; E = no + nfn
+            ne = {"from": np.concatenate([np.arange(a - 1, n_nodes - 1, dtype=np.int32), self.f_from[f0:]]),
+                  "to": np.concatenate([np.arange(a, n_nodes, dtype=np.int32), self.f_to[f0:]]),
+                  "type": np.concatenate([np.full(no, synth.EDGE_TYPE_ODOM, np.int32), np.full(nfn, synth.EDGE_TYPE_3D_FULL, np.int32)]),
+                  "sensor_from": np.full(E, -1, np.int32), "sensor_to": np.full(E, -1, np.int32),
+                  "valid": np.concatenate([np.ones(no, np.int32), in_solve[f0:].astype(np.int32)]),
+                  "transform": np.concatenate([self.odo_T[a - 1:n_nodes - 1].reshape(no, 12), self.f_T[f0:]]),
+                  "displacement_from": np.tile(I12, (E, 1)), "displacement_to": np.tile(I12, (E, 1)),
+                  "information": np.concatenate([self.odo_info[a - 1:n_nodes - 1], self.f_info[f0:]]),
+                  "diff_time": np.concatenate([np.full(no, 0.5), np.zeros(nfn)])}
+            self.pgo.append_graph(self.poses[a:n_nodes].reshape(-1, 12), run["fixed"][a:n_nodes], ne, self._f_in_idx[:f0], in_solve[:f0])
+            self._f_in_idx = np.concatenate([self._f_in_idx, (self._pgo_edges + no + np.arange(nfn)).astype(np.int32)])
+            self._pgo_edges += E
+        else:
+            self.pgo.add_graph(*self.last_input)
+            self._f_in_idx = (n_nodes - 1 + np.arange(nf)).astype(np.int32)
+            self._pgo_edges = n_nodes - 1 + nf
+        self._pgo_nodes = n_nodes; self._pgo_feats = nf
         t1 = time.perf_counter()
         st = self.pgo.optimize(self.lm_iterations)
         t2 = time.perf_counter()
