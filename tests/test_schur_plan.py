@@ -109,3 +109,89 @@ def test_random_graphs(capi):
         if (np.diff(rp) == 0).any():
             continue
         _check(capi, rp, col, cap=int(rng.integers(1, 12)))
+
+
+# ---- strong-aggregate numbering of the reduced system (SchurPlan::strong; csrc/pgo_schur.hpp)
+def _strong_case(seed, n=4000, closures=260):
+    """an odometry chain with loop closures; closure edges are 50x stiffer than odometry, a few odometry edges are very soft"""
+    rng = np.random.default_rng(seed)
+    edges = [(i, i + 1) for i in range(n - 1)]
+    w = list(np.where(rng.random(n - 1) < 0.02, 0.05, 1.0))
+    for _ in range(closures):
+        a, b = sorted(rng.choice(n, 2, replace=False))
+        if b - a > 3:
+            edges.append((int(a), int(b))); w.append(50.0)
+    return n, edges, np.array(w)
+
+
+def _slot_weights(n, edges, w, fixed=()):
+    free = [v for v in range(n) if v not in set(fixed)]
+    v2b = {v: i for i, v in enumerate(free)}
+    rows = [[] for _ in free]
+    for k, (a, b) in enumerate(edges):
+        if a in v2b:
+            rows[v2b[a]].append(w[k])
+        if b in v2b:
+            rows[v2b[b]].append(w[k])
+    return np.array([x for r in rows for x in r], np.float64)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_strong_numbering_is_a_padded_permutation(capi, seed):
+    n, edges, w = _strong_case(seed)
+    rp, col = _csr(n, edges, fixed=(0,))
+    sw = _slot_weights(n, edges, w, fixed=(0,))
+    plain = capi.schur_plan(rp, col, 24)
+    P = capi.schur_plan_strong(rp, col, sw, 24, strong_min=1, theta=0.25)
+    Q = capi.schur_plan_strong(rp, col, sw, 24, strong_min=1, theta=0.25)
+    assert np.array_equal(P["red_row"], Q["red_row"]) and np.array_equal(P["sep_rows"], Q["sep_rows"])         # deterministic
+    red, sep = P["red_row"], P["sep_rows"]
+    # the same separators as the plain plan, renumbered; 32 rows per block, 8 per group
+    assert np.array_equal(red >= 0, plain["red_row"] >= 0) and P["n_sep"] == plain["n_reduced"]
+    assert P["n_reduced"] == 32 * P["n_blocks"] == len(sep) and P["n_groups"] <= 4 * P["n_blocks"]
+    real = np.nonzero(sep >= 0)[0]
+    assert len(real) == P["n_sep"] and np.array_equal(red[sep[real]], real) and len(set(sep[real])) == len(real)
+    occupied_groups = 0
+    for g in range(len(sep) // 8):
+        rows = sep[8 * g: 8 * g + 8]
+        k = int((rows >= 0).sum())
+        assert (rows[:k] >= 0).all() and (rows[k:] < 0).all()            # a group's rows come first, the padding behind them
+        assert (np.diff(rows[:k]) > 0).all()                             # ... in row order
+        occupied_groups += k > 0
+        if k == 0:
+            assert g % 4 != 0                                             # a block starts with an occupied group
+    assert occupied_groups == P["n_groups"]
+    for b in range(P["n_blocks"]):
+        occ = [(sep[32 * b + 8 * j] >= 0) for j in range(4)]
+        assert occ[0] and occ == sorted(occ, reverse=True)               # occupied groups first
+    # below the threshold (or without weights) the plan is the plain one
+    Z = capi.schur_plan_strong(rp, col, sw, 24, strong_min=10 ** 6, theta=0.25)
+    assert Z["n_groups"] == 0 and np.array_equal(Z["red_row"], plain["red_row"])
+
+
+def test_strong_numbering_groups_what_is_stiffly_coupled(capi):
+    """Two separators tied by a stiff loop closure share a group of 8; the two ends of a soft odometry edge do not (unless something
+    stiffer ties them another way round)."""
+    n, edges, w = _strong_case(7)
+    rp, col = _csr(n, edges, fixed=(0,))
+    sw = _slot_weights(n, edges, w, fixed=(0,))
+    P = capi.schur_plan_strong(rp, col, sw, 24, strong_min=1, theta=0.25)
+    red = P["red_row"]
+    v2b = {v: i for i, v in enumerate(range(1, n))}
+    deg = np.zeros(n, int)
+    for a, b in edges:
+        deg[a] += 1; deg[b] += 1
+    same = tot = 0
+    for (a, b), wk in zip(edges, w):
+        if wk == 50.0 and a in v2b and b in v2b and deg[a] == 3 and deg[b] == 3:      # a closure between two plain chain vertices
+            ra, rb = red[v2b[a]], red[v2b[b]]
+            assert ra >= 0 and rb >= 0
+            tot += 1; same += (ra // 8 == rb // 8)
+    assert tot > 50 and same >= 0.9 * tot, (same, tot)
+    soft_same = soft_tot = 0
+    for (a, b), wk in zip(edges, w):
+        if wk == 0.05 and a in v2b and b in v2b:
+            ra, rb = red[v2b[a]], red[v2b[b]]
+            if ra >= 0 and rb >= 0:
+                soft_tot += 1; soft_same += (ra // 8 == rb // 8)
+    assert soft_tot == 0 or soft_same <= 0.2 * soft_tot, (soft_same, soft_tot)

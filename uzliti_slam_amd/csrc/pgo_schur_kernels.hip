@@ -10,6 +10,7 @@
 // HBM-bound in principle (algorithmic bytes per eliminated vertex: 3 blocks of 288 B in, 78 doubles out and in again), latency-bound
 // in practice: a run is a chain of <= cap dependent 6x6 steps.
 #include <algorithm>
+#include <cstring>
 
 #include "pgo_device.hpp"
 #include "pgo_schur.hpp"
@@ -22,31 +23,38 @@ struct WEdge { int32_t a, c; double w; };
 // sorted by (a, c), parallel edges summed, self loops dropped
 void merge_edges(std::vector<WEdge>& E)
 {
-    std::sort(E.begin(), E.end(), [](const WEdge& x, const WEdge& y) { return x.a != y.a ? x.a < y.a : x.c < y.c; });
-    size_t o = 0;
-    for (size_t k = 0; k < E.size(); k++) {
-        if (E[k].a == E[k].c) continue;
-        if (o > 0 && E[o - 1].a == E[k].a && E[o - 1].c == E[k].c) E[o - 1].w += E[k].w; else E[o++] = E[k];
+    std::vector<std::pair<uint64_t, double>> K; K.reserve(E.size());
+    for (const WEdge& e : E) if (e.a != e.c) K.push_back({((uint64_t)(uint32_t)e.a << 32) | (uint32_t)e.c, e.w});
+    std::sort(K.begin(), K.end(), [](const std::pair<uint64_t, double>& x, const std::pair<uint64_t, double>& y) { return x.first < y.first; });
+    E.clear();
+    for (size_t k = 0; k < K.size(); k++) {
+        if (!E.empty() && k > 0 && K[k].first == K[k - 1].first) E.back().w += K[k].second;
+        else E.push_back({(int32_t)(K[k].first >> 32), (int32_t)(K[k].first & 0xffffffffu), K[k].second});
     }
-    E.resize(o);
 }
 // Size-capped agglomeration along STRONG edges: per round a heaviest-edge matching of the current groups, an edge counting only if it is at
 // least theta x the heaviest edge at either end and the two groups together stay within `cap`; rounds until nothing merges.  Returns the
 // group of every node (groups numbered by their lowest node) and leaves the contracted graph in E.  Deterministic (ties: lower indices).
-std::vector<int32_t> strong_groups(int n, std::vector<WEdge>& E, int cap, double theta, int* n_groups)
+std::vector<int32_t> strong_groups(int n, std::vector<WEdge>& E, int cap, double theta, int max_rounds, int* n_groups)
 {
     std::vector<int32_t> grp((size_t)n), size((size_t)n, 1);
     for (int v = 0; v < n; v++) grp[v] = v;
     int cur = n;
     merge_edges(E);
-    for (int round = 0; round < 16 && cur > 1; round++) {
-        std::vector<int32_t> ord(E.size()), mate((size_t)cur, -1), nid((size_t)cur, -1);
+    std::vector<std::pair<uint64_t, uint32_t>> ord;                       // (weight, heaviest first; index): weights are positive doubles, whose bits order like integers
+    for (int round = 0; round < max_rounds && cur > 1; round++) {
+        std::vector<int32_t> mate((size_t)cur, -1), nid((size_t)cur, -1);
         std::vector<double> wmax((size_t)cur, 0.);
-        for (size_t k = 0; k < E.size(); k++) { ord[k] = (int32_t)k; wmax[E[k].a] = std::max(wmax[E[k].a], E[k].w); wmax[E[k].c] = std::max(wmax[E[k].c], E[k].w); }
-        std::sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return E[x].w != E[y].w ? E[x].w > E[y].w : x < y; });
+        ord.clear();
+        for (size_t k = 0; k < E.size(); k++) {
+            wmax[E[k].a] = std::max(wmax[E[k].a], E[k].w); wmax[E[k].c] = std::max(wmax[E[k].c], E[k].w);
+            uint64_t bits; const double w = E[k].w > 0. ? E[k].w : 0.; memcpy(&bits, &w, 8);
+            ord.push_back({~bits, (uint32_t)k});
+        }
+        std::sort(ord.begin(), ord.end());
         bool any = false;
-        for (int32_t k : ord) {
-            const WEdge& e = E[k];
+        for (const auto& o : ord) {
+            const WEdge& e = E[o.second];
             if (mate[e.a] >= 0 || mate[e.c] >= 0 || size[e.a] + size[e.c] > cap) continue;
             if (e.w < theta * std::max(wmax[e.a], wmax[e.c])) continue;
             mate[e.a] = e.c; mate[e.c] = e.a; any = true;
@@ -182,8 +190,8 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
             E.push_back({std::min(L, R), std::max(L, R), inv > 0. ? 1. / inv : 0.});
         }
         int n1 = 0, n2 = 0;
-        const std::vector<int32_t> g1 = strong_groups(P.n_sep, E, kMlFanout, theta, &n1);      // E: now the graph of the groups
-        const std::vector<int32_t> g2 = strong_groups(n1, E, kMlFanout2, theta, &n2);
+        const std::vector<int32_t> g1 = strong_groups(P.n_sep, E, kMlFanout, theta, 5, &n1);      // E: now the graph of the groups
+        const std::vector<int32_t> g2 = strong_groups(n1, E, kMlFanout2, theta, 4, &n2);
         // position of group j of block G = 32 G + 8 j; groups and blocks are numbered by their lowest member: row order survives inside them
         std::vector<int32_t> first1((size_t)n1, -1), slot_in2((size_t)n1, 0), fill2((size_t)n2, 0), fill1((size_t)n1, 0), perm((size_t)P.n_sep);
         for (int a1 = 0; a1 < n1; a1++) slot_in2[a1] = fill2[g2[a1]]++;
@@ -468,6 +476,26 @@ extern "C" int uzl_pgo_schur_plan(int32_t nb, const int32_t* row_ptr, const int3
         for (int i = 0; i <= P.nbr; i++) red_row_ptr[i] = P.row_ptr[i];
         for (int k = 0; k < P.nslots_r; k++) red_col[k] = P.col[k];
         *n_reduced = P.nbr; *n_runs = P.n_runs;
+        return UZL_OK;
+    } catch (...) { return UZL_ERR_OOM; }
+}
+
+// The same with the strong-aggregate numbering (SchurPlan::strong): red_row = full row -> reduced row, sep_rows = reduced row -> full row
+// or -1 for an empty row; counts = {reduced rows, separators, groups of <= 8, blocks of <= 4 groups}.  Pure host code.
+extern "C" int uzl_pgo_schur_plan_strong(int32_t nb, const int32_t* row_ptr, const int32_t* col, int32_t cap, const double* slot_w, int32_t strong_min,
+                                         double theta, int32_t* red_row, int32_t* sep_rows, int32_t cap_rows, int32_t* counts)
+{
+    if (nb < 0 || !row_ptr || !slot_w || (nb > 0 && !red_row) || !sep_rows || !counts) return UZL_ERR_BAD_ARG;
+    for (int a = 0; a < nb; a++) if (row_ptr[a + 1] < row_ptr[a]) return UZL_ERR_BAD_ARG;
+    if (nb > 0 && row_ptr[nb] > 0 && !col) return UZL_ERR_BAD_ARG;
+    try {
+        const std::vector<int32_t> rp(row_ptr, row_ptr + nb + 1), cl(col, col + (nb > 0 ? row_ptr[nb] : 0));
+        for (int32_t c : cl) if (c < -1 || c >= nb) return UZL_ERR_BAD_ARG;
+        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap, slot_w, strong_min, theta);
+        if (P.nbr > cap_rows) return UZL_ERR_BAD_ARG;
+        for (int a = 0; a < nb; a++) red_row[a] = P.full2red[a];
+        for (int i = 0; i < P.nbr; i++) sep_rows[i] = P.sep_rows[i];
+        counts[0] = P.nbr; counts[1] = P.n_sep; counts[2] = P.strong ? P.n_strong1 : 0; counts[3] = P.strong ? P.n_strong2 : 0;
         return UZL_OK;
     } catch (...) { return UZL_ERR_OOM; }
 }
