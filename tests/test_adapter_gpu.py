@@ -223,3 +223,26 @@ def test_rosbag_storage_mirror_round_trip_and_files_parse_with_the_oracle(tmp_pa
                 assert used == len(m["data"]) and e["type"] == (1 if k % 2 else 104) and e["valid"] == int(k % 3 != 1)
                 want = -1.25 if k % 3 == 0 else 2.5 + k
                 assert e["diff_time_sec"] + 1e-9 * e["diff_time_nsec"] == want and 0 <= e["diff_time_nsec"] < 10**9
+
+
+@pytest.mark.parametrize("n,ne,n1", [(300, 900, 200), (2500, 2760, 2300)])
+def test_optimizer_plugin_grows_the_resident_graph(capi, tmp_path, n, ne, n1):
+    """An online session through the plugin-shaped class: the second addGraph finds the SlamGraph grown only (old ids in front, the poses
+    storeImpl wrote back) and sends the tail through uzl_pgo_append_graph; the result must be a full rebuild's (adapter_selftest `grow`)."""
+    exe = os.path.join(ADAPTER, "adapter_selftest")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", ADAPTER])
+    g = synth.make_pose_graph(n, ne, seed=n)
+    e = g["edges"]
+    inp = tmp_path / "grow.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<iiii", n, len(e["from"]), 6, 0))
+        for i in range(n):
+            f.write(g["nodes_pose"][i].astype("<f8").tobytes()); f.write(struct.pack("<i", int(g["nodes_fixed"][i])))
+        for k in range(len(e["from"])):
+            f.write(struct.pack("<iiii", int(e["from"][k]), int(e["to"][k]), int(e["type"][k]), int(e["valid"][k])))
+            f.write(e["transform"][k].astype("<f8").tobytes()); f.write(e["information"][k].astype("<f8").tobytes())
+    r = subprocess.run([exe, "grow", str(inp), str(n1)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("GROW_OK")
+    assert float(r.stdout.split()[1]) < 1e-6, r.stdout

@@ -175,8 +175,76 @@ static int storage_mode(const char* dir, const char* out)
     return bad ? 6 : 0;
 }
 
+// ---- "grow" mode: an online session in two steps.  The graph section of in.bin (same layout as the default mode) is split at node n1:
+// the optimizer first gets the nodes below n1 and the edges among them (addGraph + optimize + store), then the whole graph - which it must
+// recognise as GROWN ONLY and send through uzl_pgo_append_graph - and the result must be the one a second optimizer gets from a full
+// rebuild of the same SlamGraph state.  Prints "GROW_OK <max |pose difference|>".
+static void solve_sync(Mi355xOptimizer& opt, SlamGraph& g)
+{
+    std::mutex m; std::condition_variable cv; bool done = false;
+    if (!opt.optimize(g, [&] { std::lock_guard<std::mutex> l(m); done = true; cv.notify_all(); })) { fprintf(stderr, "optimize refused\n"); exit(3); }
+    { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return done; }); }
+    opt.storeOptimizationResults(g);
+}
+static int grow_mode(const char* in, int n1)
+{
+    FILE* f = fopen(in, "rb");
+    if (!f) return 2;
+    int32_t n, e, iters, xy;
+    rd(f, &n, 4); rd(f, &e, 4); rd(f, &iters, 4); rd(f, &xy, 4);
+    std::vector<SlamNode> nodes(n); std::vector<SlamEdge> edges(e); std::vector<int32_t> efrom(e), eto(e);
+    for (int i = 0; i < n; i++) { int32_t fixed; nodes[i].id_ = node_id(i); rd(f, nodes[i].pose_.m.data(), 96); rd(f, &fixed, 4); nodes[i].fixed_ = fixed != 0; }
+    for (int k = 0; k < e; k++) {
+        SlamEdge& ed = edges[k]; int32_t type, valid;
+        rd(f, &efrom[k], 4); rd(f, &eto[k], 4); rd(f, &type, 4); rd(f, &valid, 4);
+        ed.id_from_ = node_id(efrom[k]); ed.id_to_ = node_id(eto[k]); ed.type_ = (unsigned char)type; ed.valid_ = valid != 0;
+        rd(f, ed.transform_.m.data(), 96); rd(f, ed.information_.data(), 288);
+    }
+    fclose(f);
+    // edge ids in the order they enter the graph: the old edges must sort in front of the new ones (time-ordered ids, graph_slam_node.cpp:294)
+    int seq = 0;
+    SlamGraph graph;
+    for (int i = 0; i < n1; i++) graph.addNode(nodes[i]);
+    for (int k = 0; k < e; k++) if (efrom[k] < n1 && eto[k] < n1) { char b[32]; snprintf(b, sizeof(b), "e%08d", seq++); edges[k].id_ = b; graph.addEdge(edges[k]); }
+    GraphOptimizerConfig cfg; cfg.iterations = iters; cfg.optimize_xy_only = xy != 0;
+    Mi355xOptimizer opt(0, /*use_edge_filter=*/false);
+    opt.setConfig(cfg);
+    solve_sync(opt, graph);
+    if (opt.lastWasAppend() || opt.lastStatus() < 0) { fprintf(stderr, "first solve: append %d status %d\n", (int)opt.lastWasAppend(), opt.lastStatus()); return 3; }
+    for (int i = n1; i < n; i++) graph.addNode(nodes[i]);
+    int flipped = 0;
+    for (int k = 0; k < e; k++) {
+        if (efrom[k] < n1 && eto[k] < n1) {        // the filter changes its mind about a few old feature edges
+            if (edges[k].type_ != TYPE_2D_WHEEL_ODOMETRY && flipped < 5 && k % 7 == 0) { SlamEdge& ge = graph.edge(edges[k].id_); ge.valid_ = !ge.valid_; flipped++; }
+        } else { char b[32]; snprintf(b, sizeof(b), "e%08d", seq++); edges[k].id_ = b; graph.addEdge(edges[k]); }
+    }
+    SlamGraph copy = graph;                       // the state a full rebuild starts from
+    solve_sync(opt, graph);
+    if (!opt.lastWasAppend() || opt.lastStatus() < 0) { fprintf(stderr, "second solve: append %d status %d\n", (int)opt.lastWasAppend(), opt.lastStatus()); return 3; }
+    Mi355xOptimizer fresh(0, /*use_edge_filter=*/false);
+    fresh.setConfig(cfg);
+    solve_sync(fresh, copy);
+    if (fresh.lastWasAppend() || fresh.lastStatus() < 0) return 3;
+    double worst = 0.;
+    for (auto& kv : graph.nodes()) {
+        const SlamNode& o = copy.node(kv.first);
+        for (int q = 0; q < 12; q++) worst = std::max(worst, std::fabs(kv.second.pose_.m[q] - o.pose_.m[q]));
+    }
+    if (opt.lastStats().n_edges != fresh.lastStats().n_edges || opt.lastStats().iterations_done != fresh.lastStats().iterations_done) return 4;
+    // a solve of the unchanged graph grows nothing: still the append path, with nothing to send
+    solve_sync(opt, graph);
+    if (!opt.lastWasAppend()) return 5;
+    // moving an old node from outside makes it a full rebuild again
+    graph.node(node_id(1)).pose_.m[3] += 0.01;
+    solve_sync(opt, graph);
+    if (opt.lastWasAppend()) return 6;
+    printf("GROW_OK %.3e flipped %d\n", worst, flipped);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 4 && std::string(argv[1]) == "grow") return grow_mode(argv[2], atoi(argv[3]));
     if (argc == 4 && std::string(argv[1]) == "storage") return storage_mode(argv[2], argv[3]);
     if (argc == 4 && std::string(argv[1]) == "filter") return filter_mode(argv[2], argv[3]);
     if (argc < 3) { fprintf(stderr, "usage: adapter_selftest in.bin out.bin\n"); return 2; }

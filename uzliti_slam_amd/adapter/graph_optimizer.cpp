@@ -75,6 +75,48 @@ Mi355xOptimizer::~Mi355xOptimizer()
     if (h_) uzl_pgo_destroy(h_);
 }
 
+// Has the SlamGraph only GROWN since the handle got it - same nodes (ids, fixed flags, the poses storeImpl wrote back) and edges in front,
+// new ones behind, same sensors and projection flags?  Then only the tail crosses the C ABI (uzl_pgo_append_graph).
+bool Mi355xOptimizer::growsOnly(SlamGraph& graph, const std::vector<double>& sensors) const
+{
+    if (!have_graph_ || status_ < 0 || stored_poses_.size() != 12 * node_ids_.size()) return false;
+    if (sensors != sent_sensors_ || sent_xy_ != config_.optimize_xy_only || sent_odom_ != config_.use_odometry_parameters) return false;
+    if (graph.nodes().size() < node_ids_.size() || graph.edges().size() < edge_ids_.size()) return false;
+    size_t i = 0;
+    for (auto& kv : graph.nodes()) {
+        if (i == node_ids_.size()) break;
+        if (kv.first != node_ids_[i] || (kv.second.fixed_ ? 1 : 0) != sent_fixed_[i]) return false;
+        if (std::memcmp(kv.second.pose_.m.data(), stored_poses_.data() + 12 * i, 12 * sizeof(double)) != 0) return false;
+        i++;
+    }
+    size_t k = 0;
+    for (auto& kv : graph.edges()) {
+        if (k == edge_ids_.size()) break;
+        if (kv.first != edge_ids_[k]) return false;
+        k++;
+    }
+    return true;
+}
+
+void Mi355xOptimizer::packEdge(const SlamEdge& e, const std::string& key, uzl_edge& u) const
+{
+    std::memset(&u, 0, sizeof(u));
+    auto f = index_.find(e.id_from_), t = index_.find(e.id_to_);
+    u.from = f == index_.end() ? -1 : f->second;        // missing endpoints are skipped by the back end (:77)
+    u.to = t == index_.end() ? -1 : t->second;
+    u.type = e.type_;
+    auto sf = sensor_index_.find(e.sensor_from_), st = sensor_index_.find(e.sensor_to_);
+    u.sensor_from = sf == sensor_index_.end() ? -1 : sf->second;
+    u.sensor_to = st == sensor_index_.end() ? -1 : st->second;
+    // TransformationFilter verdict (:97-103); odometry edges bypass the filter (:78-79)
+    u.valid = (e.type_ == TYPE_2D_WHEEL_ODOMETRY) ? 1 : (edge_filter_ ? (filtered_.count(key) ? 1 : 0) : (e.valid_ ? 1 : 0));
+    std::memcpy(u.transform, e.transform_.m.data(), sizeof(u.transform));
+    std::memcpy(u.displacement_from, e.displacement_from_.m.data(), sizeof(u.displacement_from));
+    std::memcpy(u.displacement_to, e.displacement_to_.m.data(), sizeof(u.displacement_to));
+    std::memcpy(u.information, e.information_.data(), sizeof(u.information));
+    u.diff_time = e.diff_time_;
+}
+
 void Mi355xOptimizer::addGraphImpl(SlamGraph& graph)
 {
     if (!h_) return;
@@ -84,20 +126,8 @@ void Mi355xOptimizer::addGraphImpl(SlamGraph& graph)
     c.optimize_xy_only = config_.optimize_xy_only ? 1 : 0;
     c.use_odometry_parameters = config_.use_odometry_parameters ? 1 : 0;
     uzl_pgo_set_config(h_, &c);
-    // vertices in std::map order = lexicographic id = the order g2o ids are assigned in (g2o_optimizer.cpp:64-66)
-    node_ids_.clear(); edge_ids_.clear();
-    std::map<std::string, int32_t> index;
-    std::vector<uzl_node> nodes;
-    for (auto& kv : graph.nodes()) {
-        uzl_node n;
-        std::memcpy(n.pose, kv.second.pose_.m.data(), sizeof(n.pose));
-        n.fixed = kv.second.fixed_ ? 1 : 0;
-        index[kv.first] = (int32_t)nodes.size();
-        node_ids_.push_back(kv.first);
-        nodes.push_back(n);
-    }
-    std::map<std::string, int32_t> sensor_index;
     std::vector<double> sensors;
+    std::map<std::string, int32_t> sensor_index;
     for (auto& kv : graph.sensors()) {          // sensor transforms (:68-71)
         sensor_index[kv.first] = (int32_t)(sensors.size() / 12);
         sensors.insert(sensors.end(), kv.second.m.begin(), kv.second.m.end());
@@ -116,38 +146,55 @@ void Mi355xOptimizer::addGraphImpl(SlamGraph& graph)
         for (const auto& id : edges_to_remove) edge_filter_->remove(id);                      // :89-92
         edge_filter_->calcValidEdges();                                                       // :96
     }
-    std::set<std::string>& filtered = filtered_;
-    filtered.clear();
+    filtered_.clear();
     if (edge_filter_)
         for (const SlamEdge& fe : edge_filter_->validEdges()) {                               // :97-102
             if (!graph.existsEdge(fe.id_)) continue;
             graph.edge(fe.id_).valid_ = true;
-            filtered.insert(fe.id_);
+            filtered_.insert(fe.id_);
         }
-    std::vector<uzl_edge> edges;
-    for (auto& kv : graph.edges()) {
-        const SlamEdge& e = kv.second;
-        uzl_edge u;
-        std::memset(&u, 0, sizeof(u));
-        auto f = index.find(e.id_from_), t = index.find(e.id_to_);
-        u.from = f == index.end() ? -1 : f->second;        // missing endpoints are skipped by the back end (:77)
-        u.to = t == index.end() ? -1 : t->second;
-        u.type = e.type_;
-        auto sf = sensor_index.find(e.sensor_from_), st = sensor_index.find(e.sensor_to_);
-        u.sensor_from = sf == sensor_index.end() ? -1 : sf->second;
-        u.sensor_to = st == sensor_index.end() ? -1 : st->second;
-        // TransformationFilter verdict (:97-103); odometry edges bypass the filter (:78-79)
-        u.valid = (e.type_ == TYPE_2D_WHEEL_ODOMETRY) ? 1 : (edge_filter_ ? (filtered.count(kv.first) ? 1 : 0) : (e.valid_ ? 1 : 0));
-        std::memcpy(u.transform, e.transform_.m.data(), sizeof(u.transform));
-        std::memcpy(u.displacement_from, e.displacement_from_.m.data(), sizeof(u.displacement_from));
-        std::memcpy(u.displacement_to, e.displacement_to_.m.data(), sizeof(u.displacement_to));
-        std::memcpy(u.information, e.information_.data(), sizeof(u.information));
-        u.diff_time = e.diff_time_;
-        edge_ids_.push_back(kv.first);
-        edges.push_back(u);
+    const bool grow = growsOnly(graph, sensors);
+    last_append_ = grow;
+    if (!grow) { node_ids_.clear(); edge_ids_.clear(); index_.clear(); sent_fixed_.clear(); sent_valid_.clear(); sensor_index_ = sensor_index; }
+    // vertices in std::map order = lexicographic id = the order g2o ids are assigned in (g2o_optimizer.cpp:64-66)
+    const size_t n_old = node_ids_.size(), e_old = edge_ids_.size();
+    std::vector<uzl_node> nodes;
+    size_t i = 0;
+    for (auto& kv : graph.nodes()) {
+        if (i++ < n_old) continue;
+        uzl_node n;
+        std::memcpy(n.pose, kv.second.pose_.m.data(), sizeof(n.pose));
+        n.fixed = kv.second.fixed_ ? 1 : 0;
+        index_[kv.first] = (int32_t)node_ids_.size();
+        node_ids_.push_back(kv.first);
+        sent_fixed_.push_back((uint8_t)n.fixed);
+        nodes.push_back(n);
     }
-    status_ = uzl_pgo_add_graph(h_, (int32_t)nodes.size(), nodes.data(), (int32_t)edges.size(), edges.data(),
-                                (int32_t)(sensors.size() / 12), sensors.data());
+    std::vector<uzl_edge> edges;
+    std::vector<int32_t> flag_index;
+    std::vector<uint8_t> flag_valid;
+    size_t k = 0;
+    for (auto& kv : graph.edges()) {
+        uzl_edge u;
+        packEdge(kv.second, kv.first, u);
+        if (k < e_old) {                         // an old edge: only the filter's verdict can have changed
+            if ((uint8_t)u.valid != sent_valid_[k]) { flag_index.push_back((int32_t)k); flag_valid.push_back((uint8_t)u.valid); sent_valid_[k] = (uint8_t)u.valid; }
+        } else {
+            edge_ids_.push_back(kv.first);
+            sent_valid_.push_back((uint8_t)u.valid);
+            edges.push_back(u);
+        }
+        k++;
+    }
+    if (grow)
+        status_ = uzl_pgo_append_graph(h_, (int32_t)nodes.size(), nodes.data(), (int32_t)edges.size(), edges.data(), (int32_t)flag_index.size(),
+                                       flag_index.data(), flag_valid.data());
+    else
+        status_ = uzl_pgo_add_graph(h_, (int32_t)nodes.size(), nodes.data(), (int32_t)edges.size(), edges.data(),
+                                    (int32_t)(sensors.size() / 12), sensors.data());
+    have_graph_ = status_ >= 0;
+    sent_sensors_ = sensors; sent_xy_ = config_.optimize_xy_only; sent_odom_ = config_.use_odometry_parameters;
+    stored_poses_.clear();                       // (valid again once storeImpl has run for this graph)
 }
 
 void Mi355xOptimizer::optimizeImpl()
@@ -163,6 +210,7 @@ void Mi355xOptimizer::storeImpl(SlamGraph& graph)
     std::vector<double> poses(node_ids_.size() * 12), err(edge_ids_.size() + 1);
     std::vector<uint8_t> used(edge_ids_.size() + 1);
     if (uzl_pgo_store(h_, poses.data(), err.data(), used.data()) != UZL_OK) return;
+    stored_poses_ = poses;                      // what the handle's estimates look like from outside: growsOnly compares the SlamGraph with it
     for (size_t i = 0; i < node_ids_.size(); i++) {        // :110-117: the graph may have changed meanwhile
         if (!graph.existsNode(node_ids_[i])) continue;
         SlamNode& n = graph.node(node_ids_[i]);

@@ -56,6 +56,7 @@ public:
     int lastStatus() const { return status_; }
     TransformationFilter* edgeFilter() { return edge_filter_.get(); }
     const std::set<std::string>& lastFiltered() const { return filtered_; }   // ids the filter passed to the solver in the last addGraph
+    bool lastWasAppend() const { return last_append_; }                       // the last addGraph grew the resident graph (uzl_pgo_append_graph)
 
 protected:
     void addGraphImpl(SlamGraph& graph) override;     // g2o_optimizer.cpp:55-104
@@ -70,6 +71,14 @@ private:
     uzl_pgo_stats stats_{};
     int status_ = 0;
     bool applied_xy_ = false;
+    // what the handle holds, for the grown-only path of an online session (graph_slam_node.cpp:1138-1150 re-optimises a graph that gained
+    // nodes and edges; ids are time-ordered, :294, so they sort behind the old ones)
+    bool growsOnly(SlamGraph& graph, const std::vector<double>& sensors) const;
+    void packEdge(const SlamEdge& e, const std::string& key, uzl_edge& u) const;
+    std::map<std::string, int32_t> index_, sensor_index_;
+    std::vector<double> stored_poses_, sent_sensors_;   // poses storeImpl wrote back (12 per node); sensors as sent
+    std::vector<uint8_t> sent_fixed_, sent_valid_;
+    bool have_graph_ = false, last_append_ = false, sent_xy_ = false, sent_odom_ = false;
 };
 
 }  // namespace uzl_adapter
