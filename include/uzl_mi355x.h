@@ -243,7 +243,13 @@ typedef struct uzl_pgo_cfg {
     int32_t pcg_stop;                 /* 0 = step-error estimate (above), 1 = relative residual test only                  */
     int32_t lm_loop;                  /* 0 = Levenberg-Marquardt decisions on the device, one host look per trial (captured passes);
                                          1 = host-driven loop (the one sharded and profiled solves always take); same results */
-    int32_t reserved0;
+    int32_t reduced_numbering;        /* how the Schur-reduced system (schur_reduce) of a graph with >= 128 separators is laid out:
+                                         1 = row (trajectory) order, 8 consecutive separators per aggregate; 2 = by strong aggregates
+                                         (separators that are stiffly tied - loop-closure partners, short runs - share an aggregate);
+                                         0 = the handle chooses: strong aggregates when they differ from the row order (fewer than 60 %
+                                         of the separators in groups that are consecutive anyway), and it changes its mind when the PCG
+                                         iterations per LM trial of its own last solves say so.  Same linear system either way.
+                                         (was reserved0: layout unchanged)                                              */
 } uzl_pgo_cfg;
 
 /* SlamNode as the optimizer sees it (slam_node.h:89-107). Array order = std::map iteration order

@@ -12,14 +12,16 @@ def _sub(e, idx):
     return {k: np.asarray(v)[idx] for k, v in e.items()}
 
 
+@pytest.mark.parametrize("numbering", [1, 2])
 @pytest.mark.parametrize("n,e,n1", [(600, 2400, 400), (3000, 3300, 2000), (6000, 6600, 5800)])
-def test_append_equals_full_rebuild(capi, n, e, n1):
+def test_append_equals_full_rebuild(capi, n, e, n1, numbering):
+    # (reduced_numbering fixed: left to the handle it depends on the handle's own history, which the two handles below do not share)
     g = synth.make_pose_graph(n, e, seed=n + 1)
     ed = g["edges"]
     first = np.nonzero((ed["from"] < n1) & (ed["to"] < n1))[0]
     rest = np.nonzero(~((ed["from"] < n1) & (ed["to"] < n1)))[0]
     assert len(first) > 0 and len(rest) > 0
-    p = capi.Pgo()
+    p = capi.Pgo(reduced_numbering=numbering)
     p.add_graph(g["nodes_pose"][:n1], g["nodes_fixed"][:n1], _sub(ed, first))
     st0 = p.optimize(4)
     P1 = p.store()[0]
@@ -35,7 +37,7 @@ def test_append_equals_full_rebuild(capi, n, e, n1):
     full = _sub(ed, np.concatenate([first, rest]))
     full["valid"] = np.concatenate([valid_old, np.asarray(ed["valid"])[rest]])
     poses = np.concatenate([P1.reshape(-1, 12), np.asarray(g["nodes_pose"], np.float64).reshape(-1, 12)[n1:]])
-    q = capi.Pgo()
+    q = capi.Pgo(reduced_numbering=numbering)
     q.add_graph(poses, g["nodes_fixed"], full)
     sb = q.optimize(6)
     Pb = q.store()[0]

@@ -613,3 +613,32 @@ def test_ill_conditioned_long_chain_one_far_closure(capi, oracle):
         finally:
             p.close()
 
+
+
+@pytest.mark.parametrize("n,e", [(6000, 6500), (20000, 21700)])
+def test_reduced_numbering_row_order_and_strong_aggregates_agree(capi, oracle, n, e):
+    """uzl_pgo_cfg::reduced_numbering: the Schur-reduced system in row order (1) and numbered by strong aggregates with empty rows (2) is the
+    same linear system - same LM trajectory within the PCG's accuracy, both within the bar of the oracle's direct solve; 0 lets the handle
+    choose (by the shape of the groups at first)."""
+    g = synth.make_pose_graph(n, e, seed=n + 3)
+    out = {}
+    for mode in (1, 2, 0):
+        p = capi.Pgo(reduced_numbering=mode)
+        p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+        st = p.optimize(8)
+        out[mode] = (p.store()[0].reshape(-1, 3, 4), st)
+        p.close()
+        assert st["status"] == 0 and st["n_eliminated"] > n // 2
+    for mode in (2, 0):
+        a, b = out[1][1], out[mode][1]
+        assert (a["iterations_done"], a["lm_trials"], a["n_eliminated"]) == (b["iterations_done"], b["lm_trials"], b["n_eliminated"])
+        assert abs(a["chi2_final"] - b["chi2_final"]) <= 1e-6 * a["chi2_final"]
+        dt, dr = synth.pose_errors(out[1][0], out[mode][0])
+        assert dt < 1e-4 and dr < 1e-5, (mode, dt, dr)
+    assert out[1][1]["pcg_iterations"] != out[2][1]["pcg_iterations"]          # (they ARE different preconditioners)
+    fl = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    P, _ = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=8)
+    for mode in (1, 2):
+        dt, dr = synth.pose_errors(out[mode][0], P.reshape(-1, 3, 4))
+        assert dt < 1e-3 and dr < 1e-4, (mode, dt, dr)

@@ -72,7 +72,7 @@ class PgoCfg(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("use_odometry_parameters", C.c_int32),
                 ("optimize_xy_only", C.c_int32), ("device", C.c_int32), ("pcg_tol", C.c_double),
                 ("pcg_max_iter", C.c_int32), ("schur_reduce", C.c_int32), ("huber_delta", C.c_double), ("verbose", C.c_int32),
-                ("preconditioner", C.c_int32), ("pcg_stop", C.c_int32), ("lm_loop", C.c_int32), ("reserved0", C.c_int32)]
+                ("preconditioner", C.c_int32), ("pcg_stop", C.c_int32), ("lm_loop", C.c_int32), ("reduced_numbering", C.c_int32)]
 
 
 class PgoStats(C.Structure):
@@ -812,7 +812,7 @@ def schur_plan_strong(row_ptr, col, slot_w, cap=24, strong_min=1, theta=0.25):
     rp = np.ascontiguousarray(row_ptr, np.int32); cl = np.ascontiguousarray(col, np.int32); w = np.ascontiguousarray(slot_w, np.float64)
     nb = len(rp) - 1
     assert len(w) == len(cl)
-    red_row = np.empty(max(nb, 1), np.int32); cap_rows = 32 * nb + 32; sep = np.empty(cap_rows, np.int32); counts = np.zeros(4, np.int32)
+    red_row = np.empty(max(nb, 1), np.int32); cap_rows = 32 * nb + 32; sep = np.empty(cap_rows, np.int32); counts = np.zeros(5, np.int32)
     i32 = C.POINTER(C.c_int32)
     rc = lib().uzl_pgo_schur_plan_strong(C.c_int32(nb), rp.ctypes.data_as(i32), cl.ctypes.data_as(i32), C.c_int32(cap), w.ctypes.data_as(c_f64p),
                                          C.c_int32(strong_min), C.c_double(theta), red_row.ctypes.data_as(i32), sep.ctypes.data_as(i32),
@@ -820,7 +820,7 @@ def schur_plan_strong(row_ptr, col, slot_w, cap=24, strong_min=1, theta=0.25):
     if rc != UZL_OK:
         raise UzlError(rc, lib().uzl_status_string(rc).decode())
     return dict(red_row=red_row[:nb], sep_rows=sep[:counts[0]].copy(), n_reduced=int(counts[0]), n_sep=int(counts[1]), n_groups=int(counts[2]),
-                n_blocks=int(counts[3]))
+                n_blocks=int(counts[3]), contiguous=counts[4] / 1000.)
 
 
 # --------------------------------------------------------------------------------------- distance loop-closure candidates

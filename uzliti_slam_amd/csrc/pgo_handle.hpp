@@ -126,12 +126,14 @@ struct uzl_pgo {
     double* pbuf[2] = {nullptr, nullptr};      // PCG direction, ping-pong (of the Dp system)
     struct Reduced {
         bool on = false, strong = false;           // strong: numbered by strong aggregates, with empty rows (SchurPlan)
-        int32_t n_int = 0, n_runs = 0, longest_run = 0;
+        int32_t n_int = 0, n_runs = 0, longest_run = 0, n_sep = 0;
         DevBuf<int32_t> run_ptr, run_rows, slotP, slotN, endL, endR, sep_rows, rsrc, inc_ptr, inc, row_ptr, col, rowhdr, b2v;
         DevBuf<double> elim, runout, runblk, blk, hdiag, minv, x, xs, r, z, p, p2, ap;
         SchurDev S;
     } red;
     int prev_pcg_iters = 0;
+    double num_its[2] = {-1., -1.};            // PCG iterations per LM trial of the last solve with the reduced system in row order / by strong aggregates
+    int num_last = -1;                         // numbering of that solve (-1: none yet); see build_structure
     // multilevel preconditioner
     int ml_levels = 0;
     std::vector<int32_t> ml_n, ml_nslots;

@@ -2488,7 +2488,12 @@ static void kl_ml_spmv_t(SLOT sl, const LmShape& sh, int parity, hipStream_t s, 
     if (sh.batch_geometry && ev_a) hipExtLaunchKernelGGL((ml_spmv_lm_kernel<1, kSpmvBatchRpw, kSpmvBatchWaves, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvBatchWaves), 0, s, ev_a, ev_b, 0, sl, parity);
     else if (sh.batch_geometry) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, kSpmvBatchRpw, kSpmvBatchWaves, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvBatchWaves), 0, s, sl, parity);
     else if (sh.agg == 1) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, 1, 8, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(512), 0, s, sl, parity);
-    else hipLaunchKernelGGL((ml_spmv_lm_kernel<4, 4, kSpmvWaves4, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvWaves4), 0, s, sl, parity);
+    else {
+        static const int rpw = diag_int("UZL_SPMV4_RPW", 4);                // A/B switch: rows per wave of the AGG = 4 geometry (16 rows per workgroup)
+        if (rpw == 2) hipLaunchKernelGGL((ml_spmv_lm_kernel<4, 2, 8, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(512), 0, s, sl, parity);
+        else if (rpw == 1) hipLaunchKernelGGL((ml_spmv_lm_kernel<4, 1, 16, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(1024), 0, s, sl, parity);
+        else hipLaunchKernelGGL((ml_spmv_lm_kernel<4, 4, kSpmvWaves4, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvWaves4), 0, s, sl, parity);
+    }
 }
 template <class SLOT>
 static hipError_t kl_ml_init_t(SLOT sl, const LmShape& sh, hipStream_t s)

@@ -85,7 +85,7 @@ std::vector<int32_t> strong_groups(int n, std::vector<WEdge>& E, int cap, double
 // strongly coupled ones - to a block of 32 rows, every group padded to 8 rows and every block to 4 groups with EMPTY rows
 // (sep_rows = -1: identity diagonal block, zero right-hand side, no off-diagonal blocks).  A removed run counts as springs in series.
 SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vector<int32_t>& col, int cap, const double* slot_w, int strong_min,
-                     double theta)
+                     double theta, double max_contiguous)
 {
     SchurPlan P;
     P.nb = nb;
@@ -192,6 +192,17 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
         int n1 = 0, n2 = 0;
         const std::vector<int32_t> g1 = strong_groups(P.n_sep, E, kMlFanout, theta, 5, &n1);      // E: now the graph of the groups
         const std::vector<int32_t> g2 = strong_groups(n1, E, kMlFanout2, theta, 4, &n2);
+        // Do the groups differ from the row order at all?  Where the runs between separators are stiffer than the loop closures the matching
+        // follows the chain and most groups are consecutive separators anyway: then the row order with its level-1 path (exact 48 x 48
+        // blocks, dense level 1) is the better preconditioner (tests/diag/strong_ab.py: 9.0 against 18.0 ms at 3000 / 3100).
+        {
+            std::vector<int32_t> lo((size_t)n1, P.n_sep), hi((size_t)n1, -1), cnt((size_t)n1, 0);
+            for (int i = 0; i < P.n_sep; i++) { lo[g1[i]] = std::min(lo[g1[i]], i); hi[g1[i]] = std::max(hi[g1[i]], i); cnt[g1[i]]++; }
+            int64_t in_contig = 0;
+            for (int a1 = 0; a1 < n1; a1++) if (hi[a1] - lo[a1] == cnt[a1] - 1) in_contig += cnt[a1];
+            P.strong_contiguous = P.n_sep > 0 ? (double)in_contig / P.n_sep : 1.;
+        }
+        if (P.strong_contiguous < max_contiguous) {
         // position of group j of block G = 32 G + 8 j; groups and blocks are numbered by their lowest member: row order survives inside them
         std::vector<int32_t> first1((size_t)n1, -1), slot_in2((size_t)n1, 0), fill2((size_t)n2, 0), fill1((size_t)n1, 0), perm((size_t)P.n_sep);
         for (int a1 = 0; a1 < n1; a1++) slot_in2[a1] = fill2[g2[a1]]++;
@@ -204,6 +215,7 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
         P.sep_rows.swap(sep);
         for (int i = 0; i < P.nbr; i++) if (P.sep_rows[i] >= 0) P.full2red[P.sep_rows[i]] = i;
         for (int r = 0; r < P.n_runs; r++) { if (P.endL[r] >= 0) P.endL[r] = perm[P.endL[r]]; if (P.endR[r] >= 0) P.endR[r] = perm[P.endR[r]]; }
+        }
     }
     // reduced block-CSR: kept blocks in slot order, then the fill blocks of the incident runs in run order
     std::vector<std::vector<int32_t>> inc((size_t)std::max(P.nbr, 1));
@@ -468,7 +480,7 @@ extern "C" int uzl_pgo_schur_plan(int32_t nb, const int32_t* row_ptr, const int3
     try {
         const std::vector<int32_t> rp(row_ptr, row_ptr + nb + 1), cl(col, col + (nb > 0 ? row_ptr[nb] : 0));
         for (int32_t c : cl) if (c < -1 || c >= nb) return UZL_ERR_BAD_ARG;
-        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap, nullptr, 0, 0.);
+        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap, nullptr, 0, 0., 2.);
         if (P.nslots_r > cap_slots || (P.nslots_r > 0 && !red_col)) return UZL_ERR_BAD_ARG;
         for (int a = 0; a < nb; a++) { red_row[a] = P.full2red[a]; run_id[a] = -1; run_pos[a] = -1; }
         for (int r = 0; r < P.n_runs; r++)
@@ -491,11 +503,12 @@ extern "C" int uzl_pgo_schur_plan_strong(int32_t nb, const int32_t* row_ptr, con
     try {
         const std::vector<int32_t> rp(row_ptr, row_ptr + nb + 1), cl(col, col + (nb > 0 ? row_ptr[nb] : 0));
         for (int32_t c : cl) if (c < -1 || c >= nb) return UZL_ERR_BAD_ARG;
-        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap, slot_w, strong_min, theta);
+        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap, slot_w, strong_min, theta, 2.);
         if (P.nbr > cap_rows) return UZL_ERR_BAD_ARG;
         for (int a = 0; a < nb; a++) red_row[a] = P.full2red[a];
         for (int i = 0; i < P.nbr; i++) sep_rows[i] = P.sep_rows[i];
         counts[0] = P.nbr; counts[1] = P.n_sep; counts[2] = P.strong ? P.n_strong1 : 0; counts[3] = P.strong ? P.n_strong2 : 0;
+        counts[4] = (int32_t)(1000. * P.strong_contiguous + 0.5);
         return UZL_OK;
     } catch (...) { return UZL_ERR_OOM; }
 }

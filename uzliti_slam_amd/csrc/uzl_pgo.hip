@@ -707,7 +707,7 @@ void build_structure(uzl_pgo* h)
     // ---- Schur reduction of the chain interiors (pgo_schur.hpp): when a third or more of the free vertices carry nothing but their two
     //      chain edges, the PCG runs on the Schur complement over the others (sharded solves included: see SchurDev::runblk).
     uzl_pgo::Reduced& Rd = h->red;
-    Rd.on = false; Rd.n_int = 0; Rd.n_runs = 0; Rd.longest_run = 0; Rd.strong = false;
+    Rd.on = false; Rd.n_int = 0; Rd.n_runs = 0; Rd.longest_run = 0; Rd.strong = false; Rd.n_sep = 0;
     PgoDev& Dp = h->Dp;
     static const int schur_diag = diag_int("UZL_SCHUR", 1);                  // A/B switches (diagnostic build)
     static const int schur_cap = diag_int("UZL_SCHUR_CAP", 24);
@@ -722,16 +722,34 @@ void build_structure(uzl_pgo* h)
         // one: config 5's last re-optimisation took 70 - 140 PCG iterations per LM iteration (tests/diag/reduced_proto.py: 70 -> 23).
         static const int strong_env = diag_int("UZL_SCHUR_STRONG_MIN", -1);     // A/B switch: separators from which on (0 = never)
         static const int strong_theta_pct = diag_int("UZL_SCHUR_STRONG_THETA", 25);
-        const int strong_min = (may_shard || h->cfg.preconditioner == 0) ? 0 : (strong_env >= 0 ? strong_env : kSchurStrongMin);
+        int strong_min = (may_shard || h->cfg.preconditioner == 0) ? 0 : (strong_env >= 0 ? strong_env : kSchurStrongMin);
+        // Which numbering (uzl_pgo_cfg::reduced_numbering)?  Strong aggregates pay where loop closures are stiffer than the runs between
+        // separators (config 5: 71 -> 31 PCG iterations per LM iteration); where the runs are the stiff part the matching follows the chain,
+        // the groups are runs of consecutive separators anyway, and the row order with its level-1 path is better (tests/diag/strong_ab.py).
+        // A handle's first structure goes by that shape; afterwards by what its own solves measured - PCG iterations per LM trial of the last
+        // solve in either numbering, an iteration on the padded AGG = 4 layout counted as 1.5 (20 against 13 us) - so an online session that
+        // started on the wrong foot corrects itself.  Iteration counts only: deterministic.
+        double max_contig = 2.;
+        const double cost_strong = 1.5;
+        if (h->cfg.reduced_numbering == 1) strong_min = 0;
+        else if (h->cfg.reduced_numbering != 2 && strong_min > 0) {
+            const double ir = h->num_its[0], is = h->num_its[1];
+            bool strong;
+            if (ir >= 0. && is >= 0.) strong = cost_strong * is < ir * (h->num_last == 1 ? 1.15 : 0.87);      // both known: the cheaper, with hysteresis
+            else if (h->num_last == 0) strong = ir > 40.;                                                         // row order is doing badly: try
+            else if (h->num_last == 1) strong = !(is > 60.);                                                      // strong is doing badly: try the row order
+            else { strong = true; max_contig = 0.6; }                                                             // first structure: by the shape of the groups
+            if (!strong) strong_min = 0;
+        }
         std::vector<double> slot_w;
         if (strong_min > 0 && h->edge_w.size() == (size_t)e) {
             slot_w.resize((size_t)std::max(nslots, 1));
             for (int q = 0; q < nslots; q++) slot_w[q] = h->edge_w[slot_edge[q] >> 1];
         }
-        SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap, slot_w.empty() ? nullptr : slot_w.data(), strong_min, 0.01 * strong_theta_pct);
+        SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap, slot_w.empty() ? nullptr : slot_w.data(), strong_min, 0.01 * strong_theta_pct, max_contig);
         tick("Schur plan");
         if (P.n_int >= 64 && (int64_t)100 * P.n_int >= (int64_t)schur_min_pct * nb) {
-            Rd.on = true; Rd.n_int = P.n_int; Rd.n_runs = P.n_runs; Rd.longest_run = P.longest_run; Rd.strong = P.strong;
+            Rd.on = true; Rd.n_int = P.n_int; Rd.n_runs = P.n_runs; Rd.longest_run = P.longest_run; Rd.strong = P.strong; Rd.n_sep = P.n_sep;
             const size_t nr = (size_t)std::max(P.nbr, 1), nsr = (size_t)std::max(P.nslots_r, 1), ni = (size_t)P.n_int, nru = (size_t)P.n_runs;
             auto up = [&](DevBuf<int32_t>& b, const std::vector<int32_t>& v, size_t min_n) {
                 b.reserve(std::max(v.size(), min_n));
@@ -964,7 +982,14 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     UZL_HIP(hipSetDevice(h->cfg.device));
     if (iterations <= 0) iterations = h->cfg.iterations;
     prepare_optimize(h);
-    return lm_eligible(h) ? do_optimize_lm(h, iterations, st) : do_optimize_host(h, iterations, st);
+    uzl_pgo_stats local;
+    uzl_pgo_stats* sp = st ? st : &local;
+    const int rc = lm_eligible(h) ? do_optimize_lm(h, iterations, sp) : do_optimize_host(h, iterations, sp);
+    if (h->red.on && h->red.n_sep >= kSchurStrongMin && sp->lm_trials > 0 && (rc == UZL_OK || rc == UZL_ERR_NOT_CONVERGED)) {      // what the next structure's numbering goes by
+        h->num_last = h->red.strong ? 1 : 0;
+        h->num_its[h->num_last] = (double)sp->pcg_iterations / sp->lm_trials;
+    }
+    return rc;
 }
 // The host-driven loop.  Called through do_optimize (structure prepared, device set), or by do_optimize_lm for a solve that met an anomaly.
 int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
@@ -1250,6 +1275,7 @@ void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg)
     cfg->preconditioner = 1;            // additive multilevel (rigid-body-mode aggregation); 0 = block-Jacobi
     cfg->pcg_stop = 0;                  // step-error estimate; 1 = relative residual test only
     cfg->lm_loop = 0;                   // LM decisions on the device (captured passes); 1 = host-driven loop
+    cfg->reduced_numbering = 0;         // the handle chooses between row order and strong aggregates (pgo_schur.hpp)
 }
 
 int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
@@ -1306,7 +1332,7 @@ int uzl_pgo_set_config(uzl_pgo* h, const uzl_pgo_cfg* cfg)
     if (cfg->device != h->cfg.device) return fail(h, UZL_ERR_BAD_ARG, "device cannot change after create");
     if (cfg->iterations < 1 || cfg->pcg_tol <= 0. || cfg->huber_delta <= 0.) return fail(h, UZL_ERR_BAD_ARG, "bad config value");
     if (cfg->pcg_tol != h->cfg.pcg_tol) destroy_pcg_graph(h);      // the tolerance is a captured kernel argument
-    if (cfg->preconditioner != h->cfg.preconditioner || cfg->schur_reduce != h->cfg.schur_reduce) h->structure_ready = false;
+    if (cfg->preconditioner != h->cfg.preconditioner || cfg->schur_reduce != h->cfg.schur_reduce || cfg->reduced_numbering != h->cfg.reduced_numbering) h->structure_ready = false;
     h->cfg = *cfg;
     return UZL_OK;
 }

@@ -39,6 +39,7 @@ struct LmRun {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool join_pending = false;               // a rebuild is in flight on the second stream
     uint64_t gen = ~0ull;                    // single handle: structure generation the slot and the captured segments belong to
+    int solves_of_gen = 0;                   // optimizes of the current structure so far (single-graph driver)
     int first_solve_its = 0;                 // PCG iterations of the first solve of the last optimize (sizes the first pass of the next)
     struct Seg { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; };
     Seg setup, reb, pcg_long;
@@ -468,12 +469,19 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         reserve_slots(R, 1);
         R->shape = make_shape({h}, 1, false);
         R->gen = h->structure_gen;
+        R->solves_of_gen = 0;
         h->structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
     }
     std::vector<LmJob> jobs(1);
     jobs[0].h = h;
     LmDriveOpts o;
-    o.s = s; o.s2 = h->stream2; o.iterations = iterations; o.eager = h->no_graph; o.verbose = h->cfg.verbose != 0;
+    // The FIRST solve of a structure launches everything kernel by kernel: capturing and instantiating its segments costs ~0.5 ms and dropping
+    // them again ~0.7 ms, which a structure that is solved once - every re-optimisation of a growing graph - never earns back (config 5:
+    // 16.2 -> 15.7 ms per solve, structure 1.9 -> 1.2 ms).  A structure that comes back (uzl_pgo_reset, a timer-driven re-optimisation of an
+    // unchanged graph) replays captured segments from its second solve on.  Same kernels, same results either way.
+    static const bool capture_first = diag_flag("UZL_LM_CAPTURE_FIRST");       // A/B switch
+    o.s = s; o.s2 = h->stream2; o.iterations = iterations; o.eager = h->no_graph || (R->solves_of_gen == 0 && !capture_first); o.verbose = h->cfg.verbose != 0;
+    R->solves_of_gen++;
     lm_drive(R, jobs, o);
     LmJob& J = jobs[0];
     if (J.anomaly) {             // the host-driven loop knows the remedies (retake the inverses, additive operator): from the start poses
