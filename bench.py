@@ -784,6 +784,7 @@ def main():
                              optimize_ms_per_solve=round(s["optimize_ms_per_solve"], 3), seconds=s["seconds"], feature_edges_accepted=s["feature_edges_accepted"],
                              feature_edges_valid=s["feature_edges_valid"], pcg_iterations=s["pcg_iterations"], lm_iterations=s["lm_iterations"],
                              vertices_schur_eliminated_last_solve=o.solves[-1].get("n_eliminated", 0) if o.solves else 0,
+                             solves_reduced=s.get("solves_reduced"), solves_strong_aggregates=s.get("solves_strong_aggregates"),
                              not_converged=s["not_converged"],
                              ate_dead_reckoning_m=round(float(np.linalg.norm(run["init"][:, :, 3] - gt[:, :, 3], axis=1).mean()), 3),
                              ate_online_m=round(float(np.linalg.norm(o.poses[:, :, 3] - gt[:, :, 3], axis=1).mean()), 3),

@@ -298,7 +298,7 @@ typedef struct uzl_pgo_stats {
     int32_t structure_reused;  /* 1: the structure of the previous graph was kept (same vertices / edge endpoints / fixed flags) */
     int32_t n_eliminated;      /* free vertices Schur-eliminated ahead of the PCG (chain interiors), 0 = full system */
     int32_t lm_passes;         /* device-resident loop: passes enqueued = host looks at the state; 0 = the host-driven loop ran */
-    int32_t reserved0;
+    int32_t reduced_strong;    /* 1: the Schur-reduced system was numbered by strong aggregates (uzl_pgo_cfg::reduced_numbering); was reserved0 */
 } uzl_pgo_stats;
 
 void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg);

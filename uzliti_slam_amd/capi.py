@@ -82,7 +82,7 @@ class PgoStats(C.Structure):
                 ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
                 ("solve_ms", C.c_double), ("precond_builds", C.c_int32), ("exchange_calls", C.c_int32),
                 ("structure_ms", C.c_double), ("exchange_ms", C.c_double), ("structure_reused", C.c_int32), ("n_eliminated", C.c_int32),
-                ("lm_passes", C.c_int32), ("reserved0", C.c_int32)]
+                ("lm_passes", C.c_int32), ("reduced_strong", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

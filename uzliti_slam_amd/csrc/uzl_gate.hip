@@ -13,6 +13,7 @@
 #include <cfloat>
 #include <new>
 #include <set>
+#include <unordered_set>
 #include <tuple>
 
 namespace uzl {
@@ -33,7 +34,8 @@ struct uzl_gate {
     std::vector<uint8_t> merged;
     struct E { int32_t from, to, type, valid; };
     std::vector<E> edges;
-    std::set<std::tuple<int32_t, int32_t, int32_t>> pair_type;      // (min, max, type) of every edge: existsEdge(from, to, type)
+    std::vector<int32_t> nb_tmp;
+    std::unordered_set<uint64_t> pair_type;                         // (min, max, type) of every edge, packed (pair_key): existsEdge(from, to, type)
     bool adj_dirty = true, poses_dirty = true;
     std::vector<int32_t> adj_ptr, adj_nbr;
     DevBuf<double> d_poses, d_gs, d_dist, d_gclosed;
@@ -67,10 +69,15 @@ int fail(uzl_gate* h, int code, const char* msg)
     return code;
 }
 
+// node indices are below 2^28 (a graph of that size does not fit the search's scratch anyway), edge types below 2^8
+inline uint64_t pair_key(int32_t from, int32_t to, int32_t type)
+{
+    return ((uint64_t)(uint32_t)std::min(from, to) << 36) | ((uint64_t)(uint32_t)std::max(from, to) << 8) | (uint64_t)(uint32_t)(type & 0xff);
+}
 void add_edge(uzl_gate* h, int32_t from, int32_t to, int32_t type, int32_t valid)
 {
     h->edges.push_back({from, to, type, valid});
-    h->pair_type.insert(std::make_tuple(std::min(from, to), std::max(from, to), type));
+    h->pair_type.insert(pair_key(from, to, type));
     if (valid && type != UZL_EDGE_TYPE_2D_LASER) h->adj_dirty = true;
 }
 
@@ -100,9 +107,12 @@ void build_adjacency(uzl_gate* h)
         r.deg = h->adj_ptr[v + 1] - h->adj_ptr[v]; r.adj = h->adj_ptr[v];
         for (int j = 0; j < kGateRecNbr; j++) r.nbr[j] = j < r.deg ? h->adj_nbr[h->adj_ptr[v] + j] : -1;
         {   // multi-edges: flagged, so that a search only looks for repeated neighbours where there are any
-            std::vector<int32_t> nb(h->adj_nbr.begin() + h->adj_ptr[v], h->adj_nbr.begin() + h->adj_ptr[v + 1]);
-            std::sort(nb.begin(), nb.end());
-            if (std::adjacent_find(nb.begin(), nb.end()) != nb.end()) r.deg |= kGateRecMulti;
+            const int32_t* nb = h->adj_nbr.data() + h->adj_ptr[v];
+            const int d = h->adj_ptr[v + 1] - h->adj_ptr[v];
+            bool multi = false;
+            if (d <= 16) { for (int a = 1; a < d && !multi; a++) for (int b = 0; b < a; b++) if (nb[a] == nb[b]) { multi = true; break; } }
+            else { h->nb_tmp.assign(nb, nb + d); std::sort(h->nb_tmp.begin(), h->nb_tmp.end()); multi = std::adjacent_find(h->nb_tmp.begin(), h->nb_tmp.end()) != h->nb_tmp.end(); }
+            if (multi) r.deg |= kGateRecMulti;
         }
     }
     h->adj_dirty = false;
@@ -172,6 +182,7 @@ int uzl_gate_set_graph(uzl_gate* h, int32_t n_nodes, const double* poses, const 
     h->merged.assign((size_t)n_nodes, 0);
     if (merged) h->merged.assign(merged, merged + n_nodes);
     h->edges.clear(); h->pair_type.clear();
+    h->edges.reserve((size_t)n_edges + 64); h->pair_type.reserve((size_t)n_edges * 2 + 64);
     for (int32_t k = 0; k < n_edges; k++) {
         const uzl_gate_edge& e = edges[k];
         if (e.from < 0 || e.to < 0 || e.from >= n_nodes || e.to >= n_nodes) continue;
@@ -221,7 +232,7 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
             const uzl_gate_edge& c = cand[k];
             bool ok = c.from >= 0 && c.to >= 0 && c.from < n && c.to < n;
             if (ok) ok = !h->merged[c.from] && !h->merged[c.to];
-            if (ok) ok = h->pair_type.count(std::make_tuple(std::min(c.from, c.to), std::max(c.from, c.to), c.type)) == 0;
+            if (ok) ok = h->pair_type.count(pair_key(c.from, c.to, c.type)) == 0;
             run[k] = ok ? 1 : 0;
         }
         UZL_HIP(hipMemcpyAsync(h->d_run.p + first, run.data() + first, (size_t)m, hipMemcpyHostToDevice, s));
@@ -337,7 +348,7 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
             const uzl_gate_edge& c = cand[k];
             if (astar_dist) astar_dist[k] = -1.;
             if (!run[k]) continue;
-            const auto key = std::make_tuple(std::min(c.from, c.to), std::max(c.from, c.to), c.type);
+            const uint64_t key = pair_key(c.from, c.to, c.type);
             if (h->pair_type.count(key)) continue;                                  // joined the graph earlier in this call
             if (!h->h_pre.p[k]) continue;
             if (astar_dist) astar_dist[k] = h->h_dist.p[k];

@@ -1004,7 +1004,7 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     PgoDev& Dp = h->Dp;                       // the system the PCG solves: D, or the Schur complement over the separator vertices
     const bool red = h->red.on;
     const SchurDev& SD = h->red.S;
-    S.n_eliminated = red ? h->red.n_int : 0;
+    S.n_eliminated = red ? h->red.n_int : 0; S.reduced_strong = (red && h->red.strong) ? 1 : 0;
     // (H + lambda I) with the chain interiors eliminated: once per lambda, i.e. per LM trial (pgo_schur.hpp)
     auto schur_reduce = [&]() {
         { Timed t(h, "schur_eliminate"); k_schur_eliminate(D, SD, s); }

@@ -437,7 +437,7 @@ void finish_job(LmJob& J, uzl_pgo_stats* st, double wall_ms)
     uzl_pgo_stats S;
     memset(&S, 0, sizeof(S));
     S.structure_reused = h->last_structure_reused ? 1 : 0;
-    S.n_vertices = h->n; S.n_edges = h->e; S.n_gauge_fixed = h->n_gauge; S.n_eliminated = h->red.on ? h->red.n_int : 0;
+    S.n_vertices = h->n; S.n_edges = h->e; S.n_gauge_fixed = h->n_gauge; S.n_eliminated = h->red.on ? h->red.n_int : 0; S.reduced_strong = (h->red.on && h->red.strong) ? 1 : 0;
     S.iterations_done = v.st_iterations_done; S.lm_trials = v.st_lm_trials; S.pcg_iterations = v.st_pcg_iterations;
     S.terminated_early = v.st_terminated_early; S.precond_builds = v.st_precond_builds;
     S.chi2_initial = v.chi2_initial; S.chi2_final = v.chi_cur; S.lambda_final = v.lambda;

@@ -326,7 +326,8 @@ class OnlineSlam:
             structure_ms_per_solve=float(np.mean([x.get("structure_ms", 0.0) for x in s])) if s else 0.0,
             seconds=dict((k, round(v, 4)) for k, v in self.t.items()),
             pcg_iterations=sum(x["pcg_iterations"] for x in s), lm_iterations=sum(x["iterations_done"] for x in s),
-            not_converged=sum(1 for x in s if x["status"] != 0))
+            not_converged=sum(1 for x in s if x["status"] != 0),
+            solves_reduced=sum(1 for x in s if x.get("n_eliminated", 0) > 0), solves_strong_aggregates=sum(1 for x in s if x.get("reduced_strong", 0)))
 
     def close(self):
         for h in (self.matcher, self.gate, self.filt, self.pgo):
