@@ -46,7 +46,7 @@ def test_append_equals_full_rebuild(capi, n, e, n1, numbering):
     assert abs(sa["chi2_initial"] - sb["chi2_initial"]) <= 1e-9 * sb["chi2_initial"]      # (matrix -> quaternion -> matrix of the old poses)
     assert abs(sa["chi2_final"] - sb["chi2_final"]) <= 1e-6 * sb["chi2_final"]
     dt, dr = synth.pose_errors(Pa.reshape(-1, 3, 4), Pb.reshape(-1, 3, 4))
-    assert dt < 1e-6 and dr < 1e-7, (dt, dr)
+    assert dt < 1e-5 and dr < 1e-6, (dt, dr)                 # (two runs of the same LM iterations whose start poses differ in the last bit: the PCG's accuracy, pcg_tol = 1e-5 m)
     # reset() goes back to the state the append left, and a second append keeps working (buffers grown once more)
     p.reset(); sc = p.optimize(6)
     assert np.array_equal(p.store()[0], Pa) and sc["chi2_final"] == sa["chi2_final"]

@@ -333,7 +333,7 @@ def test_rejected_trials_multi_edges_and_hub(capi, oracle):
 @pytest.mark.parametrize("n", [16, 64, 100, 750, 959])
 def test_ns_gemm_matrix_core_layout(capi, n):
     """the f64 MFMA tile kernel of the Newton-Schulz refinement (X' = 2 X - X T) against numpy, including edge tiles.  The kernel
-    computes the 64 x 64 tiles on and above the diagonal and mirrors them (X, A and X A X are symmetric in the refinement)."""
+    computes the tiles on and above the diagonal and mirrors them (X, A and X A X are symmetric in the refinement)."""
     import ctypes
     rng = np.random.default_rng(n)
     f64p = ctypes.POINTER(ctypes.c_double)
@@ -346,11 +346,12 @@ def test_ns_gemm_matrix_core_layout(capi, n):
         return out
 
     # arbitrary operands: the X tile of the product is read through X's symmetry (as X[k][row]), so upper tiles = 2 X - X^T T,
-    # lower tiles = their mirror images
+    # lower tiles = their mirror images ("tiles" of 32: inside a 64 x 64 tile on the diagonal the quarter below the diagonal is a mirror
+    # image too, as in the 32 x 32 tiling of the small-graph kernel)
     X = rng.normal(size=(n, n)); T = rng.normal(size=(n, n))
     full = 2 * X - X.T @ T
-    ti = np.arange(n) // 64
-    upper = ti[:, None] <= ti[None, :]
+    t32 = np.arange(n) // 32
+    upper = t32[:, None] <= t32[None, :]
     want = np.where(upper, full, full.T)
     out = run(X, T)
     assert np.abs(out - want).max() <= 1e-11 * np.abs(want).max()
@@ -360,8 +361,17 @@ def test_ns_gemm_matrix_core_layout(capi, n):
     out = run(X, A @ X)
     want = 2 * X - X @ A @ X
     assert np.abs(out - want).max() <= 1e-10 * np.abs(want).max()
-    off = ti[:, None] != ti[None, :]
+    off = t32[:, None] != t32[None, :]
     assert np.array_equal(out[off], out.T[off])
+    # the small-graph kernel (32 x 32 tiles, K split over the four waves): the same sums in the same order - the same bits wherever both
+    # kernels compute the entry themselves (tiles on and above the diagonal of BOTH tilings; the rest are mirror images)
+    out32 = np.zeros((n, n))
+    rc = capi.lib().uzl_debug_ns_gemm32(ctypes.c_int(n), np.ascontiguousarray(X).ctypes.data_as(f64p), np.ascontiguousarray(A @ X).ctypes.data_as(f64p),
+                                        out32.ctypes.data_as(f64p))
+    assert rc == 0
+    assert np.abs(out32 - want).max() <= 1e-10 * np.abs(want).max()
+    assert np.array_equal(out32, out)
+    assert np.array_equal(out32[off], out32.T[off])
 
 
 def test_handles_driven_from_concurrent_threads(capi):

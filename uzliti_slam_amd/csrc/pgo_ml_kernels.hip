@@ -695,6 +695,7 @@ __global__ __launch_bounds__(kBlk) void ml_ns_ax_kernel(PgoDev D, const MlDev* _
 
 constexpr int kGemmTile = 64, kGemmK = 64;
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+__host__ __device__ __forceinline__ int gemm_slabs_per_quarter(int n) { const int slabs = (n + kGemmK - 1) / kGemmK; return (slabs + 3) / 4; }
 // tile (ti <= tj) number `b` of the gt (gt + 1) / 2 tiles on and above the diagonal, counted row by row
 __device__ __forceinline__ void tri_tile(int gt, int b, int& ti, int& tj)
 {
@@ -751,7 +752,13 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
     };
     fetch(0);
     const int sw = (lk & 1) << 4;                       // k4 is a multiple of 4: (k4 + lk) & 1 = lk & 1
-    for (int k0 = 0; k0 < n; k0 += kGemmK) {
+    // ONE summation order for this kernel and ml_ns_gemm32_kernel (small n, one graph): K in four quarters of whole slabs, each summed on
+    // its own, then ((q0 + q1) + q2) + q3 - the 32 x 32 kernel gives a quarter to each of its four waves.  Same bits from both, so a
+    // graph solved alone and in a batch (which keeps this kernel) agree.
+    const int spq = gemm_slabs_per_quarter(n);
+    v4f64 tot[2][2];
+    int slab = 0;
+    for (int k0 = 0; k0 < n; k0 += kGemmK, slab++) {
 #pragma unroll
         for (int u = 0; u < kPer; u++) {
             const int e = u * 256 + tid;
@@ -771,7 +778,18 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
+        if ((slab + 1) % spq == 0 || k0 + kGemmK >= n) {          // a quarter is complete
+            const bool first = slab < spq;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) { tot[a][b] = first ? acc[a][b] : tot[a][b] + acc[a][b]; acc[a][b] = v4f64{0., 0., 0., 0.}; }
+        }
     }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = tot[a][b];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -779,13 +797,16 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int gr = row0 + wr + a * 16 + lk + 4 * r, gc = col0 + wc + b * 16 + li;
-                if (gr < n && gc < n) {
+                // (in a diagonal tile the quarter BELOW the diagonal is the mirror image of the one above - what the 32 x 32 tiling of
+                //  ml_ns_gemm32_kernel stores there: the two kernels agree entry for entry)
+                if (gr < n && gc < n && !(ti == tj && wr > wc)) {
+                    const bool mirror = ti != tj || wr < wc;
                     const double v = 2. * X[(size_t)gr * n + gc] - acc[a][b][r];
                     Xn[(size_t)gr * n + gc] = v;
-                    if (ti != tj) Xn[(size_t)gc * n + gr] = v;
+                    if (mirror) Xn[(size_t)gc * n + gr] = v;
                     if (c32) {                                                   // last step of a rebuild: the f32 copy the PCG kernels read (ml_cmat32_body)
                         c32[(size_t)gr * c32_stride + gc] = (float)v;
-                        if (ti != tj) c32[(size_t)gc * c32_stride + gr] = (float)v;
+                        if (mirror) c32[(size_t)gc * c32_stride + gr] = (float)v;
                     }
                 }
             }
@@ -796,6 +817,110 @@ __global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __
                                                         float* __restrict__ c32, int c32_stride)
 {
     ml_ns_gemm_kernel_body(n, X, T, Xn, c32, c32_stride);
+}
+
+// The same product for ONE small graph (n <= kGemm32Max): 78 tiles of 64 x 64 leave two thirds of the chip idle at n = 750 and every
+// workgroup walks all of K alone (53 us = 0.11 of the f64 matrix-core peak).  Here a workgroup owns a 32 x 32 tile and its four waves a
+// QUARTER OF K each (the quarters of ml_ns_gemm_kernel_body, summed in the same order: same bits): 300 workgroups at n = 750, a quarter
+// of the dependent steps per wave.  Operands go straight from global memory to the MFMA registers (lane (li, lk) of a 16 x 4 operand reads
+// X[k + lk][row + li]: 128-byte runs), kGemm32Ahead steps ahead; the partial tiles meet in LDS.  Tiles are dealt to the XCDs by tile
+// column, serpentine, so that an XCD's L2 holds its few columns of T and streams X.
+constexpr int kGemm32Max = 960, kGemm32Ahead = 8;
+__device__ __forceinline__ bool gemm32_tile(int gt, int b, int& ti, int& tj)
+{
+    const int x = b % kXcds;
+    int idx = b / kXcds;
+    for (int m = 0; ; m++) {
+        const int c = (m & 1) ? 8 * m + 7 - x : 8 * m + x;             // columns of XCD x: x, 15 - x, 16 + x, 31 - x, ...
+        if (8 * m >= gt) return false;
+        if (c >= gt) continue;
+        if (idx <= c) { ti = idx; tj = c; return true; }
+        idx -= c + 1;
+    }
+}
+__host__ __device__ __forceinline__ int gemm32_grid(int gt)      // workgroups: 8 x the most tiles any XCD gets
+{
+    int most = 0;
+    for (int x = 0; x < kXcds; x++) {
+        int cnt = 0;
+        for (int m = 0; 8 * m < gt; m++) { const int c = (m & 1) ? 8 * m + 7 - x : 8 * m + x; if (c < gt) cnt += c + 1; }
+        most = cnt > most ? cnt : most;
+    }
+    return kXcds * most;
+}
+__device__ __forceinline__ void ml_ns_gemm32_kernel_body(int n, const double* __restrict__ X, const double* __restrict__ T,
+                                                          double* __restrict__ Xn, float* __restrict__ c32, int c32_stride)
+{
+    __shared__ double sP[4][32][33];
+    const int gt = (n + 31) / 32;
+    int ti, tj;
+    if (!gemm32_tile(gt, (int)blockIdx.x, ti, tj)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row0 = ti * 32, col0 = tj * 32;
+    const int li = lane & 15, lk = lane >> 4;
+    const int spq = gemm_slabs_per_quarter(n), slabs = (n + kGemmK - 1) / kGemmK;
+    const int kbeg = wv * spq * kGemmK, kend = min((wv + 1) * spq, slabs) * kGemmK;          // whole slabs, zero-padded like the 64 x 64 kernel's
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = v4f64{0., 0., 0., 0.};
+    const bool ra0 = row0 + li < n, ra1 = row0 + 16 + li < n, cb0 = col0 + li < n, cb1 = col0 + 16 + li < n;
+    const double* __restrict__ xa = X + row0 + li;
+    const double* __restrict__ tb = T + col0 + li;
+    double pa0[kGemm32Ahead], pa1[kGemm32Ahead], pb0[kGemm32Ahead], pb1[kGemm32Ahead];
+    auto fetch = [&](int u, int k4) {
+        const int k = k4 + lk;
+        const bool kin = k < n;
+        const size_t o = (size_t)(kin ? k : 0) * n;
+        pa0[u] = (kin && ra0) ? xa[o] : 0.;            // = X[row][k] through X's symmetry
+        pa1[u] = (kin && ra1) ? xa[o + 16] : 0.;
+        pb0[u] = (kin && cb0) ? tb[o] : 0.;
+        pb1[u] = (kin && cb1) ? tb[o + 16] : 0.;
+    };
+#pragma unroll
+    for (int u = 0; u < kGemm32Ahead; u++) fetch(u, kbeg + 4 * u);
+    for (int k4 = kbeg; k4 < kend; k4 += 4 * kGemm32Ahead) {
+#pragma unroll
+        for (int u = 0; u < kGemm32Ahead; u++) {
+            if (k4 + 4 * u < kend) {
+                const double a0 = pa0[u], a1 = pa1[u], b0 = pb0[u], b1 = pb1[u];
+                fetch(u, k4 + 4 * (u + kGemm32Ahead));
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sP[wv][a * 16 + lk + 4 * r][b * 16 + li] = acc[a][b][r];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int e = tid + 256 * u, r = e >> 5, c = e & 31, gr = row0 + r, gc = col0 + c;
+        if (gr < n && gc < n) {
+            const double sum = ((sP[0][r][c] + sP[1][r][c]) + sP[2][r][c]) + sP[3][r][c];
+            const double v = 2. * X[(size_t)gr * n + gc] - sum;
+            Xn[(size_t)gr * n + gc] = v;
+            if (ti != tj) Xn[(size_t)gc * n + gr] = v;
+            if (c32) {
+                c32[(size_t)gr * c32_stride + gc] = (float)v;
+                if (ti != tj) c32[(size_t)gc * c32_stride + gr] = (float)v;
+            }
+        }
+    }
+    if (c32 && tj == gt - 1 && tid < 32 && row0 + tid < n)                       // pad columns [n, stride) stay zero
+        for (int q = n; q < c32_stride; q++) c32[(size_t)(row0 + tid) * c32_stride + q] = 0.f;
+}
+__global__ __launch_bounds__(256) void ml_ns_gemm32_kernel(int n, const double* __restrict__ X, const double* __restrict__ T, double* __restrict__ Xn,
+                                                          float* __restrict__ c32, int c32_stride)
+{
+    ml_ns_gemm32_kernel_body(n, X, T, Xn, c32, c32_stride);
 }
 
 // Y_cl += QY Q^T on the f64 matrix cores - the last term of the multiplicative cycle, 2 (6 n_cl)^2 (6 n_{cl+1}) flops (13 GFLOP at 20k
@@ -2086,6 +2211,12 @@ void k_ml_ns_step(const PgoDev& D, const MlDev* ml, int lev, int n1, const doubl
     const int n6 = 6 * n1;
     hipLaunchKernelGGL(ml_ns_ax_kernel, dim3(kXcds * n1 * ax_parts(n6)), dim3(kBlk), 0, s, D, ml, lev, X, T);
     const int g = (n6 + kGemmTile - 1) / kGemmTile, gtri = g * (g + 1) / 2;     // tiles on and above the diagonal
+    if (n6 <= kGemm32Max) {                                                       // one small graph: 32 x 32 tiles, K split over the waves (same bits)
+        const int g32 = gemm32_grid((n6 + 31) / 32);
+        if (ev_a) hipExtLaunchKernelGGL(ml_ns_gemm32_kernel, dim3(g32), dim3(256), 0, s, ev_a, ev_b, 0, n6, X, T, Xn, c32, c32_stride);
+        else hipLaunchKernelGGL(ml_ns_gemm32_kernel, dim3(g32), dim3(256), 0, s, n6, X, T, Xn, c32, c32_stride);
+        return;
+    }
     if (ev_a) hipExtLaunchKernelGGL(ml_ns_gemm_kernel, dim3(gtri), dim3(256), 0, s, ev_a, ev_b, 0, n6, X, T, Xn, c32, c32_stride);     // dispatch timestamps of the GEMM alone
     else hipLaunchKernelGGL(ml_ns_gemm_kernel, dim3(gtri), dim3(256), 0, s, n6, X, T, Xn, c32, c32_stride);
 }
@@ -2290,6 +2421,16 @@ __global__ __launch_bounds__(256) void ml_ns_gemm_lm_kernel(const LmSlot* __rest
     const MlHot& H = S.hot[c];
     ml_ns_gemm_kernel_body(n6, X, S.nsT[c], Xn, last ? const_cast<float*>(H.Cmat32) : nullptr, H.c32_stride);      // (last step: Xn = H.Cmat)
 }
+__global__ __launch_bounds__(256) void ml_ns_gemm32_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k, int last)
+{
+    UZL_LM_SETUP(false)
+    (void)D;
+    const int n6 = 6 * S.hot[0].n[lev];
+    const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
+    double* Xn = (k & 1) ? S.dense[c][lev] : S.nsX[c];
+    const MlHot& H = S.hot[c];
+    ml_ns_gemm32_kernel_body(n6, X, S.nsT[c], Xn, last ? const_cast<float*>(H.Cmat32) : nullptr, H.c32_stride);
+}
 __global__ __launch_bounds__(kBlk) void ml_cmat32_lm_kernel(const LmSlot* __restrict__ slots, int which, int cl)
 {
     UZL_LM_SETUP(false)
@@ -2338,7 +2479,9 @@ void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
         const int steps = l > cl ? sh.upper_ns : sh.ns_steps;
         for (int k = 0; k < steps; k++) {
             hipLaunchKernelGGL(ml_ns_ax_lm_kernel, dim3(kXcds * n1 * ax_parts(n6), 1, B), dim3(kBlk), 0, s, sl, which, l, k);
-            hipLaunchKernelGGL(ml_ns_gemm_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l, k, (l == cl && k == steps - 1) ? 1 : 0);
+            const int last = (l == cl && k == steps - 1) ? 1 : 0;
+            if (B == 1 && n6 <= kGemm32Max) hipLaunchKernelGGL(ml_ns_gemm32_lm_kernel, dim3(gemm32_grid((n6 + 31) / 32), 1, 1), dim3(256), 0, s, sl, which, l, k, last);
+            else hipLaunchKernelGGL(ml_ns_gemm_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l, k, last);
         }
     }
     if (sh.ns_steps == 0) hipLaunchKernelGGL(ml_cmat32_lm_kernel, dim3((unsigned)((work32 + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, cl);
@@ -2553,6 +2696,20 @@ extern "C" int uzl_debug_read_stamps(unsigned long long* out, int reset)
 #endif
 
 // test hook (not part of include/uzl_mi355x.h): out = 2 X - X T for host matrices, through ml_ns_gemm_kernel
+extern "C" int uzl_debug_ns_gemm32(int n, const double* X, const double* T, double* out)
+{
+    if (n <= 0 || n > uzl::kGemm32Max || !X || !T || !out) return -1;
+    double *dX = nullptr, *dT = nullptr, *dO = nullptr;
+    const size_t b = (size_t)n * n * 8;
+    if (hipMalloc((void**)&dX, b) != hipSuccess || hipMalloc((void**)&dT, b) != hipSuccess || hipMalloc((void**)&dO, b) != hipSuccess) return -3;
+    (void)hipMemcpy(dX, X, b, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dT, T, b, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(uzl::ml_ns_gemm32_kernel, dim3(uzl::gemm32_grid((n + 31) / 32)), dim3(256), 0, nullptr, n, dX, dT, dO, (float*)nullptr, 0);
+    const hipError_t e = hipDeviceSynchronize();
+    (void)hipMemcpy(out, dO, b, hipMemcpyDeviceToHost);
+    (void)hipFree(dX); (void)hipFree(dT); (void)hipFree(dO);
+    return e == hipSuccess ? 0 : -3;
+}
 extern "C" int uzl_debug_ns_gemm(int n, const double* X, const double* T, double* out)
 {
     if (n <= 0 || !X || !T || !out) return -1;
