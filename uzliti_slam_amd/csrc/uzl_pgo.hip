@@ -727,18 +727,19 @@ void build_structure(uzl_pgo* h)
         // separators (config 5: 71 -> 31 PCG iterations per LM iteration); where the runs are the stiff part the matching follows the chain,
         // the groups are runs of consecutive separators anyway, and the row order with its level-1 path is better (tests/diag/strong_ab.py).
         // A handle's first structure goes by that shape; afterwards by what its own solves measured - PCG iterations per LM trial of the last
-        // solve in either numbering, an iteration on the padded AGG = 4 layout counted as 1.5 (20 against 13 us) - so an online session that
+        // solve in either numbering, an iteration on the padded AGG = 4 layout counted as 1.3 (the measured 1.5x per iteration less the rebuilds it saves) - so an online session that
         // started on the wrong foot corrects itself.  Iteration counts only: deterministic.
         double max_contig = 2.;
-        const double cost_strong = 1.5;
+        const double cost_strong = 1.3;
         if (h->cfg.reduced_numbering == 1) strong_min = 0;
         else if (h->cfg.reduced_numbering != 2 && strong_min > 0) {
             const double ir = h->num_its[0], is = h->num_its[1];
             bool strong;
-            if (ir >= 0. && is >= 0.) strong = cost_strong * is < ir * (h->num_last == 1 ? 1.15 : 0.87);      // both known: the cheaper, with hysteresis
-            else if (h->num_last == 0) strong = ir > 40.;                                                         // row order is doing badly: try
-            else if (h->num_last == 1) strong = !(is > 60.);                                                      // strong is doing badly: try the row order
-            else { strong = true; max_contig = 0.6; }                                                             // first structure: by the shape of the groups
+            if (ir >= 0. && is >= 0.) strong = cost_strong * is < ir;        // both known: the cheaper (the figures are of different solves: a hard
+                                                                              // interval can send it the wrong way for one solve - whose own figure sets it right)
+            else if (ir >= 0.) strong = ir > 40.;                            // only the row order known: if it is doing badly, try
+            else if (is >= 0.) strong = !(is > 40.);                         // only strong aggregates known: likewise
+            else { strong = true; max_contig = 0.6; }                        // first structure: by the shape of the groups
             if (!strong) strong_min = 0;
         }
         std::vector<double> slot_w;
