@@ -195,3 +195,29 @@ def test_strong_numbering_groups_what_is_stiffly_coupled(capi):
             if ra >= 0 and rb >= 0:
                 soft_tot += 1; soft_same += (ra // 8 == rb // 8)
     assert soft_tot == 0 or soft_same <= 0.2 * soft_tot, (soft_same, soft_tot)
+
+
+def test_strong_numbering_one_level_layout(capi):
+    """Up to `one_level_max` groups the strong aggregates are laid out as blocks of ONE group (8 rows): the level-1 path's geometry."""
+    n, edges, w = _strong_case(5, n=1500, closures=90)
+    rp, col = _csr(n, edges, fixed=(0,))
+    sw = _slot_weights(n, edges, w, fixed=(0,))
+    two = capi.schur_plan_strong(rp, col, sw, 24, strong_min=1, theta=0.25, one_level_max=0)
+    one = capi.schur_plan_strong(rp, col, sw, 24, strong_min=1, theta=0.25, one_level_max=10 ** 6)
+    assert one["n_groups"] == two["n_groups"] and one["n_blocks"] == 0 and two["n_blocks"] > 0
+    assert one["n_reduced"] == 8 * one["n_groups"] and two["n_reduced"] == 32 * two["n_blocks"]
+    sep = one["sep_rows"]
+    for g in range(one["n_groups"]):
+        rows = sep[8 * g: 8 * g + 8]
+        k = int((rows >= 0).sum())
+        assert k >= 1 and (rows[:k] >= 0).all() and (rows[k:] < 0).all() and (np.diff(rows[:k]) > 0).all()
+
+    def groups(P):
+        out = set()
+        s_ = P["sep_rows"]
+        for g in range(len(s_) // 8):
+            m = tuple(int(x) for x in s_[8 * g: 8 * g + 8] if x >= 0)
+            if m:
+                out.add(m)
+        return out
+    assert groups(one) == groups(two)                     # the same groups either way

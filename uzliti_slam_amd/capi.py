@@ -807,7 +807,7 @@ def schur_plan(row_ptr, col, cap=24):
                 n_reduced=nr.value, n_runs=nruns.value)
 
 
-def schur_plan_strong(row_ptr, col, slot_w, cap=24, strong_min=1, theta=0.25):
+def schur_plan_strong(row_ptr, col, slot_w, cap=24, strong_min=1, theta=0.25, one_level_max=0):
     """uzl_pgo_schur_plan_strong (host only) -> dict(red_row, sep_rows, n_reduced, n_sep, n_groups, n_blocks)."""
     rp = np.ascontiguousarray(row_ptr, np.int32); cl = np.ascontiguousarray(col, np.int32); w = np.ascontiguousarray(slot_w, np.float64)
     nb = len(rp) - 1
@@ -815,7 +815,7 @@ def schur_plan_strong(row_ptr, col, slot_w, cap=24, strong_min=1, theta=0.25):
     red_row = np.empty(max(nb, 1), np.int32); cap_rows = 32 * nb + 32; sep = np.empty(cap_rows, np.int32); counts = np.zeros(5, np.int32)
     i32 = C.POINTER(C.c_int32)
     rc = lib().uzl_pgo_schur_plan_strong(C.c_int32(nb), rp.ctypes.data_as(i32), cl.ctypes.data_as(i32), C.c_int32(cap), w.ctypes.data_as(c_f64p),
-                                         C.c_int32(strong_min), C.c_double(theta), red_row.ctypes.data_as(i32), sep.ctypes.data_as(i32),
+                                         C.c_int32(strong_min), C.c_double(theta), C.c_int32(one_level_max), red_row.ctypes.data_as(i32), sep.ctypes.data_as(i32),
                                          C.c_int32(cap_rows), counts.ctypes.data_as(i32))
     if rc != UZL_OK:
         raise UzlError(rc, lib().uzl_status_string(rc).decode())

@@ -125,7 +125,7 @@ struct uzl_pgo {
     PgoDev Dp;
     double* pbuf[2] = {nullptr, nullptr};      // PCG direction, ping-pong (of the Dp system)
     struct Reduced {
-        bool on = false, strong = false;           // strong: numbered by strong aggregates, with empty rows (SchurPlan)
+        bool on = false, strong = false, strong_blocks = false;      // strong: numbered by strong aggregates, with empty rows (SchurPlan); _blocks: in blocks of 4 groups
         int32_t n_int = 0, n_runs = 0, longest_run = 0, n_sep = 0;
         DevBuf<int32_t> run_ptr, run_rows, slotP, slotN, endL, endR, sep_rows, rsrc, inc_ptr, inc, row_ptr, col, rowhdr, b2v;
         DevBuf<double> elim, runout, runblk, blk, hdiag, minv, x, xs, r, z, p, p2, ap;
@@ -217,6 +217,7 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);
 bool lm_batch_eligible(const std::vector<uzl_pgo*>& hs);
 int batch_optimize_lm(LmRun*& R, const std::vector<uzl_pgo*>& hs, int resident, hipStream_t s, hipStream_t s2, int32_t iterations, bool eager, bool verbose, KernelTimer* timer,
                       uzl_pgo_stats* stats, int* rc_all);
+constexpr int kSchurStrongOneMax = 256;                // strong aggregates: up to this many groups as ONE level (level-1 path), beyond in blocks of 4 (pgo_schur.hpp)
 constexpr int kSchurStrongMin = 128;                  // separators from which on the reduced system is numbered by strong aggregates
 extern const int kUpperNs;                            // Newton-Schulz steps of the dense levels above the composite level
 extern const bool kAlwaysRefresh;                     // A/B switches (diagnostic build)

@@ -37,7 +37,7 @@ namespace uzl {
 // host-side plan: which rows are eliminated, the runs, and the block-CSR of the reduced system
 struct SchurPlan {
     int32_t nb = 0, nbr = 0, n_sep = 0, n_int = 0, n_runs = 0, nslots_r = 0, longest_run = 0;      // nbr: rows of the reduced system (n_sep separators + empty rows)
-    bool strong = false; int32_t n_strong1 = 0, n_strong2 = 0;                                    // numbered by strong aggregates: their counts
+    bool strong = false; int32_t n_strong1 = 0, n_strong2 = 0;                                    // numbered by strong aggregates: groups, blocks of <= 4 groups (0: blocks of one group)
     double strong_contiguous = 1.;                           // share of the separators whose strong group is a run of consecutive separators anyway
     std::vector<int32_t> full2red;                            // [nb] reduced row or -1   (sep_rows: [nbr] full row, or -1 = an empty row)
     std::vector<int32_t> run_ptr, run_rows, slotP, slotN, endL, endR, sep_rows, rsrc, inc_ptr, inc;
@@ -46,6 +46,6 @@ struct SchurPlan {
 
 // Plans the reduction of a block-CSR (row_ptr / col over free vertices, col = -1 for a fixed neighbour).  `cap` = longest run.
 SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vector<int32_t>& col, int cap, const double* slot_w = nullptr,
-                     int strong_min = 0, double theta = 0.25, double max_contiguous = 2.);
+                     int strong_min = 0, double theta = 0.25, double max_contiguous = 2., int one_level_max = 0);
 
 }  // namespace uzl

@@ -85,7 +85,7 @@ std::vector<int32_t> strong_groups(int n, std::vector<WEdge>& E, int cap, double
 // strongly coupled ones - to a block of 32 rows, every group padded to 8 rows and every block to 4 groups with EMPTY rows
 // (sep_rows = -1: identity diagonal block, zero right-hand side, no off-diagonal blocks).  A removed run counts as springs in series.
 SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vector<int32_t>& col, int cap, const double* slot_w, int strong_min,
-                     double theta, double max_contiguous)
+                     double theta, double max_contiguous, int one_level_max)
 {
     SchurPlan P;
     P.nb = nb;
@@ -191,7 +191,12 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
         }
         int n1 = 0, n2 = 0;
         const std::vector<int32_t> g1 = strong_groups(P.n_sep, E, kMlFanout, theta, 5, &n1);      // E: now the graph of the groups
-        const std::vector<int32_t> g2 = strong_groups(n1, E, kMlFanout2, theta, 4, &n2);
+        // Few groups: every group one aggregate of the level-1 path (one aggregate per workgroup, exact 48 x 48 blocks, the dense operator at
+        // level 1: n1 <= one_level_max keeps its n^3 rebuild affordable), blocks of ONE group.  More: blocks of <= 4 strongly tied groups.
+        const bool one_level = n1 <= one_level_max;
+        std::vector<int32_t> g2;
+        if (one_level) { g2.resize((size_t)n1); for (int a1 = 0; a1 < n1; a1++) g2[a1] = a1; n2 = n1; }
+        else g2 = strong_groups(n1, E, kMlFanout2, theta, 4, &n2);
         // Do the groups differ from the row order at all?  Where the runs between separators are stiffer than the loop closures the matching
         // follows the chain and most groups are consecutive separators anyway: then the row order with its level-1 path (exact 48 x 48
         // blocks, dense level 1) is the better preconditioner (tests/diag/strong_ab.py: 9.0 against 18.0 ms at 3000 / 3100).
@@ -206,10 +211,10 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
         // position of group j of block G = 32 G + 8 j; groups and blocks are numbered by their lowest member: row order survives inside them
         std::vector<int32_t> first1((size_t)n1, -1), slot_in2((size_t)n1, 0), fill2((size_t)n2, 0), fill1((size_t)n1, 0), perm((size_t)P.n_sep);
         for (int a1 = 0; a1 < n1; a1++) slot_in2[a1] = fill2[g2[a1]]++;
-        const int rows_per_blk = kMlFanout * kMlFanout2;
+        const int rows_per_blk = one_level ? kMlFanout : kMlFanout * kMlFanout2;
         for (int i = 0; i < P.n_sep; i++) { const int a1 = g1[i]; perm[i] = g2[a1] * rows_per_blk + slot_in2[a1] * kMlFanout + fill1[a1]++; }
         P.nbr = n2 * rows_per_blk;
-        P.strong = true; P.n_strong1 = n1; P.n_strong2 = n2;
+        P.strong = true; P.n_strong1 = n1; P.n_strong2 = one_level ? 0 : n2;
         std::vector<int32_t> sep((size_t)P.nbr, -1);
         for (int i = 0; i < P.n_sep; i++) sep[perm[i]] = P.sep_rows[i];
         P.sep_rows.swap(sep);
@@ -480,7 +485,7 @@ extern "C" int uzl_pgo_schur_plan(int32_t nb, const int32_t* row_ptr, const int3
     try {
         const std::vector<int32_t> rp(row_ptr, row_ptr + nb + 1), cl(col, col + (nb > 0 ? row_ptr[nb] : 0));
         for (int32_t c : cl) if (c < -1 || c >= nb) return UZL_ERR_BAD_ARG;
-        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap, nullptr, 0, 0., 2.);
+        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap, nullptr, 0, 0., 2., 0);
         if (P.nslots_r > cap_slots || (P.nslots_r > 0 && !red_col)) return UZL_ERR_BAD_ARG;
         for (int a = 0; a < nb; a++) { red_row[a] = P.full2red[a]; run_id[a] = -1; run_pos[a] = -1; }
         for (int r = 0; r < P.n_runs; r++)
@@ -495,7 +500,7 @@ extern "C" int uzl_pgo_schur_plan(int32_t nb, const int32_t* row_ptr, const int3
 // The same with the strong-aggregate numbering (SchurPlan::strong): red_row = full row -> reduced row, sep_rows = reduced row -> full row
 // or -1 for an empty row; counts = {reduced rows, separators, groups of <= 8, blocks of <= 4 groups}.  Pure host code.
 extern "C" int uzl_pgo_schur_plan_strong(int32_t nb, const int32_t* row_ptr, const int32_t* col, int32_t cap, const double* slot_w, int32_t strong_min,
-                                         double theta, int32_t* red_row, int32_t* sep_rows, int32_t cap_rows, int32_t* counts)
+                                         double theta, int32_t one_level_max, int32_t* red_row, int32_t* sep_rows, int32_t cap_rows, int32_t* counts)
 {
     if (nb < 0 || !row_ptr || !slot_w || (nb > 0 && !red_row) || !sep_rows || !counts) return UZL_ERR_BAD_ARG;
     for (int a = 0; a < nb; a++) if (row_ptr[a + 1] < row_ptr[a]) return UZL_ERR_BAD_ARG;
@@ -503,7 +508,7 @@ extern "C" int uzl_pgo_schur_plan_strong(int32_t nb, const int32_t* row_ptr, con
     try {
         const std::vector<int32_t> rp(row_ptr, row_ptr + nb + 1), cl(col, col + (nb > 0 ? row_ptr[nb] : 0));
         for (int32_t c : cl) if (c < -1 || c >= nb) return UZL_ERR_BAD_ARG;
-        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap, slot_w, strong_min, theta, 2.);
+        const uzl::SchurPlan P = uzl::schur_plan(nb, rp, cl, cap, slot_w, strong_min, theta, 2., one_level_max);
         if (P.nbr > cap_rows) return UZL_ERR_BAD_ARG;
         for (int a = 0; a < nb; a++) red_row[a] = P.full2red[a];
         for (int i = 0; i < P.nbr; i++) sep_rows[i] = P.sep_rows[i];

@@ -254,7 +254,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     // Schur-reduced online graph (4000/6000 26.0 -> 17.2 ms; config 5's last solve 2328 -> 1288 PCG iterations).
     static const int agg1_env = diag_int("UZL_ML_AGG1_MAX", 0);
     const int agg1_max = agg1_env > 0 ? agg1_env : (nslots >= 6 * nb ? 3072 : 4096);
-    h->ml_agg = (nb <= agg1_max && !h->red.strong) ? 1 : 4;                  // (a strong-aggregate numbering is laid out for AGG = 4: blocks of 4 x 8 rows)
+    h->ml_agg = (nb <= agg1_max && !h->red.strong_blocks) ? 1 : 4;           // (strong aggregates in blocks of 4 x 8 rows are laid out for AGG = 4)
     int L = 0;
     h->ml_fan.assign(1, 1);
     // composite path: one aggregate per workgroup, at least two coarse levels, 6 n_1 <= 960 (<= 1280 free vertices)
@@ -707,7 +707,7 @@ void build_structure(uzl_pgo* h)
     // ---- Schur reduction of the chain interiors (pgo_schur.hpp): when a third or more of the free vertices carry nothing but their two
     //      chain edges, the PCG runs on the Schur complement over the others (sharded solves included: see SchurDev::runblk).
     uzl_pgo::Reduced& Rd = h->red;
-    Rd.on = false; Rd.n_int = 0; Rd.n_runs = 0; Rd.longest_run = 0; Rd.strong = false; Rd.n_sep = 0;
+    Rd.on = false; Rd.n_int = 0; Rd.n_runs = 0; Rd.longest_run = 0; Rd.strong = false; Rd.strong_blocks = false; Rd.n_sep = 0;
     PgoDev& Dp = h->Dp;
     static const int schur_diag = diag_int("UZL_SCHUR", 1);                  // A/B switches (diagnostic build)
     static const int schur_cap = diag_int("UZL_SCHUR_CAP", 24);
@@ -727,10 +727,11 @@ void build_structure(uzl_pgo* h)
         // separators (config 5: 71 -> 31 PCG iterations per LM iteration); where the runs are the stiff part the matching follows the chain,
         // the groups are runs of consecutive separators anyway, and the row order with its level-1 path is better (tests/diag/strong_ab.py).
         // A handle's first structure goes by that shape; afterwards by what its own solves measured - PCG iterations per LM trial of the last
-        // solve in either numbering, an iteration on the padded AGG = 4 layout counted as 1.3 (the measured 1.5x per iteration less the rebuilds it saves) - so an online session that
+        // solve in either numbering, an iteration on the padded AGG = 4 layout counted as 1.3 (the measured 1.5x per iteration less the rebuilds it saves; up to 256 groups
+        // the strong layout runs on the level-1 path, at the row order's cost per iteration) - so an online session that
         // started on the wrong foot corrects itself.  Iteration counts only: deterministic.
         double max_contig = 2.;
-        const double cost_strong = 1.3;
+        const double cost_strong = 1.;                                       // (the weight of the layout is in the figure: do_optimize)
         if (h->cfg.reduced_numbering == 1) strong_min = 0;
         else if (h->cfg.reduced_numbering != 2 && strong_min > 0) {
             const double ir = h->num_its[0], is = h->num_its[1];
@@ -747,10 +748,11 @@ void build_structure(uzl_pgo* h)
             slot_w.resize((size_t)std::max(nslots, 1));
             for (int q = 0; q < nslots; q++) slot_w[q] = h->edge_w[slot_edge[q] >> 1];
         }
-        SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap, slot_w.empty() ? nullptr : slot_w.data(), strong_min, 0.01 * strong_theta_pct, max_contig);
+        static const int one_level_max = diag_int("UZL_SCHUR_STRONG_ONE_MAX", kSchurStrongOneMax);
+        SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap, slot_w.empty() ? nullptr : slot_w.data(), strong_min, 0.01 * strong_theta_pct, max_contig, one_level_max);
         tick("Schur plan");
         if (P.n_int >= 64 && (int64_t)100 * P.n_int >= (int64_t)schur_min_pct * nb) {
-            Rd.on = true; Rd.n_int = P.n_int; Rd.n_runs = P.n_runs; Rd.longest_run = P.longest_run; Rd.strong = P.strong; Rd.n_sep = P.n_sep;
+            Rd.on = true; Rd.n_int = P.n_int; Rd.n_runs = P.n_runs; Rd.longest_run = P.longest_run; Rd.strong = P.strong; Rd.strong_blocks = P.strong && P.n_strong2 > 0; Rd.n_sep = P.n_sep;
             const size_t nr = (size_t)std::max(P.nbr, 1), nsr = (size_t)std::max(P.nslots_r, 1), ni = (size_t)P.n_int, nru = (size_t)P.n_runs;
             auto up = [&](DevBuf<int32_t>& b, const std::vector<int32_t>& v, size_t min_n) {
                 b.reserve(std::max(v.size(), min_n));
@@ -988,7 +990,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
     const int rc = lm_eligible(h) ? do_optimize_lm(h, iterations, sp) : do_optimize_host(h, iterations, sp);
     if (h->red.on && h->red.n_sep >= kSchurStrongMin && sp->lm_trials > 0 && (rc == UZL_OK || rc == UZL_ERR_NOT_CONVERGED)) {      // what the next structure's numbering goes by
         h->num_last = h->red.strong ? 1 : 0;
-        h->num_its[h->num_last] = (double)sp->pcg_iterations / sp->lm_trials;
+        h->num_its[h->num_last] = (h->red.strong_blocks ? 1.3 : 1.) * (double)sp->pcg_iterations / sp->lm_trials;      // an iteration on the padded AGG = 4 layout: 20 against 14 us, less the rebuilds it saves
     }
     return rc;
 }
