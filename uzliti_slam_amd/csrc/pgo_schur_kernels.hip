@@ -197,9 +197,11 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
         std::vector<int32_t> g2;
         if (one_level) { g2.resize((size_t)n1); for (int a1 = 0; a1 < n1; a1++) g2[a1] = a1; n2 = n1; }
         else g2 = strong_groups(n1, E, kMlFanout2, theta, 4, &n2);
-        // Do the groups differ from the row order at all?  Where the runs between separators are stiffer than the loop closures the matching
-        // follows the chain and most groups are consecutive separators anyway: then the row order with its level-1 path (exact 48 x 48
-        // blocks, dense level 1) is the better preconditioner (tests/diag/strong_ab.py: 9.0 against 18.0 ms at 3000 / 3100).
+        // Few groups: every group one aggregate of the level-1 path - never worse than 8 consecutive separators on that path
+        // (tests/diag/strong_ab.py: 9.0 -> 7.8 ms at 3000 / 3100, 17.0 -> 14.7 at 12000 / 12700).  More groups need the blocks-of-4 layout,
+        // whose path has weaker smoothers and a dearer iteration: do the groups differ from the row order at all?  Where the runs between
+        // separators are stiffer than the loop closures the matching follows the chain and most groups are consecutive separators anyway:
+        // then the row order with its level-1 path is the better preconditioner (15.6 against 23.1 ms at 8000 / 9000).
         {
             std::vector<int32_t> lo((size_t)n1, P.n_sep), hi((size_t)n1, -1), cnt((size_t)n1, 0);
             for (int i = 0; i < P.n_sep; i++) { lo[g1[i]] = std::min(lo[g1[i]], i); hi[g1[i]] = std::max(hi[g1[i]], i); cnt[g1[i]]++; }
@@ -207,7 +209,7 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
             for (int a1 = 0; a1 < n1; a1++) if (hi[a1] - lo[a1] == cnt[a1] - 1) in_contig += cnt[a1];
             P.strong_contiguous = P.n_sep > 0 ? (double)in_contig / P.n_sep : 1.;
         }
-        if (P.strong_contiguous < max_contiguous) {
+        if (n1 <= one_level_max || P.strong_contiguous < max_contiguous) {
         // position of group j of block G = 32 G + 8 j; groups and blocks are numbered by their lowest member: row order survives inside them
         std::vector<int32_t> first1((size_t)n1, -1), slot_in2((size_t)n1, 0), fill2((size_t)n2, 0), fill1((size_t)n1, 0), perm((size_t)P.n_sep);
         for (int a1 = 0; a1 < n1; a1++) slot_in2[a1] = fill2[g2[a1]]++;
