@@ -246,9 +246,10 @@ typedef struct uzl_pgo_cfg {
     int32_t reduced_numbering;        /* how the Schur-reduced system (schur_reduce) of a graph with >= 128 separators is laid out:
                                          1 = row (trajectory) order, 8 consecutive separators per aggregate; 2 = by strong aggregates
                                          (separators that are stiffly tied - loop-closure partners, short runs - share an aggregate);
-                                         0 = the handle chooses: strong aggregates when they differ from the row order (fewer than 60 %
-                                         of the separators in groups that are consecutive anyway), and it changes its mind when the PCG
-                                         iterations per LM trial of its own last solves say so.  Same linear system either way.
+                                         0 = the handle chooses: strong aggregates while they are few enough for the level-1 path
+                                         (<= 256 groups) or differ from the row order (fewer than 60 % of the separators in groups that
+                                         are consecutive anyway), and it changes its mind when the PCG iterations per LM trial of its
+                                         own last solves say so.  Same linear system either way.
                                          (was reserved0: layout unchanged)                                              */
 } uzl_pgo_cfg;
 

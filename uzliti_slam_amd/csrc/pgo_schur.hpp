@@ -16,15 +16,16 @@
 //   back-substitution, m = k..1:   x_m = u_m - W_m x_{s0} - T_m x_{next}
 //
 // Numbering of the reduced system (round 4).  Small systems keep the separators in row (= trajectory) order.  From kSchurStrongMin
-// separators on they are numbered by STRONG AGGREGATES: the multilevel preconditioner gives every aggregate of 8 consecutive rows the six
+// separators on they can be numbered by STRONG AGGREGATES: the multilevel preconditioner gives every aggregate of 8 consecutive rows the six
 // rigid-body modes as its coarse space, which only helps if those rows DO move nearly rigidly together - and in row order a group of 8
 // consecutive separators holds the two ends of long soft runs while loop-closure partners sit in different groups (config 5's last
 // re-optimisation: 70 - 140 PCG iterations per LM iteration).  schur_plan therefore weighs the reduced graph's edges (trace of the
-// information matrix; a removed run = its edges as springs in series), groups the separators by size-capped heavy-edge matching along
-// edges that are at least theta = 0.25 x the stiffest edge at either end (<= 8 separators per group, then <= 4 groups per block), and lays
-// the system out in blocks of 4 x 8 rows - the AGG = 4 geometry of the PCG kernels - padding with EMPTY rows (sep_rows = -1: identity
-// diagonal block, zero right-hand side and prolongation block; x stays 0).  Same linear system, same solution; 22 - 30 PCG iterations per
-// LM iteration instead of 70 (tests/diag/reduced_proto.py is the numpy study behind the choice, DESIGN.md section 6 has the measurements).
+// information matrix; a removed run = its edges as springs in series) and groups the separators by size-capped heavy-edge matching along
+// edges that are at least theta = 0.25 x the stiffest edge at either end (<= 8 separators per group).  Up to one_level_max groups every
+// group becomes one aggregate of the level-1 path (blocks of 8 rows); beyond, the groups are matched once more (<= 4 to a block) and laid
+// out in blocks of 4 x 8 rows - the AGG = 4 geometry of the PCG kernels.  Either way groups and blocks are padded with EMPTY rows
+// (sep_rows = -1: identity diagonal block, zero right-hand side and prolongation block; x stays 0).  Same linear system, same solution;
+// which numbering a handle takes: uzl_pgo_cfg::reduced_numbering, build_structure (uzl_pgo.hip), DESIGN.md section 6.
 #pragma once
 #include <cstdint>
 #include <vector>
