@@ -1,0 +1,7 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export UZL_LIB=uzliti_slam_amd/libuzl_mi355x_diag.so
+run() { echo "--- $*"; env "$@" NUMBERING=2 timeout -k 10 300 python3 tests/diag/online_modes.py 2>/dev/null | tail -1; }
+run UZL_ML_REFRESH_REL=1e-3
+run UZL_ML_REFRESH_REL=1e-2
+run UZL_ML_REFRESH_REL=1e-4
