@@ -18,7 +18,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"
 ONLY = int(os.environ.get("ONLY", "-1"))          # run case ONLY alone (same random stream), with the solver's trial log
 bad = 0
-p = capi.Pgo()
+p = capi.Pgo(reduced_numbering=int(os.environ.get("NUMBERING", "0")))      # 0 = the handle chooses (with the history of the cases before), 1 / 2 = fixed
 for k in range(n_cases):
     if LARGE:
         n = int(rng.choice([7000, 9500, 12000, 12500, 15000, 19000, 23000]))
