@@ -37,6 +37,7 @@ int k_pcg_spmv(const PgoDev& D, const double* p_old, double* p_new, int n_part, 
 int k_pcg_update(const PgoDev& D, const double* p, int n_part, hipStream_t s);
 int g_pcg_spmv(int nb);
 int g_pcg_update(int nb);
+constexpr int kGeoAllMaxHost = 1024;                  // (= kGeoAllMax of pgo_ml_kernels.hip)
 void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, int n_l, hipStream_t s);
 void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s);
 void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);

@@ -112,13 +112,9 @@ __device__ __forceinline__ void galerkin(const P3& L, const double* __restrict__
 // ---- geometry of level l (>= 1): centroid of every aggregate, then the children's offsets d.  cen = {x, y, z, vertices underneath}.
 //      An EMPTY row (b2v < 0: padding of a strong-aggregate numbering, pgo_schur.hpp) has no pose: it carries no weight and gets a zero
 //      prolongation block (R^T = 0), so it adds nothing to any coarse operator.
-__device__ __forceinline__ void ml_geometry_kernel_body(PgoDev D, const MlDev* __restrict__ mlp,
-                                                          const double* __restrict__ pose, int l)
+__device__ __forceinline__ void ml_geometry_one(const PgoDev& D, const MlDev& ml, const double* __restrict__ pose, int l, int A)
 {
-    const MlDev& ml = *mlp;
-    const int A = blockIdx.x * kBlk + threadIdx.x;
-    const int n = ml.lv[l].n, nc = ml.lv[l - 1].n;
-    if (A >= n) return;
+    const int nc = ml.lv[l - 1].n;
     const int fan = ml.lv[l].fan;
     const int c0 = A * fan, c1 = (c0 + fan < nc) ? c0 + fan : nc;
     double cx = 0, cy = 0, cz = 0, wsum = 0;
@@ -159,6 +155,24 @@ __device__ __forceinline__ void ml_geometry_kernel_body(PgoDev D, const MlDev* _
             double* g = ml.lv[l - 1].geo + (size_t)c * 3;
             g[0] = cc[0] - cx; g[1] = cc[1] - cy; g[2] = cc[2] - cz;
         }
+    }
+}
+// l >= 1: that level, one lane per aggregate.  l = 0: ALL levels by one workgroup, level after level (a level needs the centroids of the
+// one below; hierarchies of up to kGeoAllMax level-1 aggregates: two launches less per rebuild of a config-2-sized graph)
+constexpr int kGeoAllMax = 1024;
+__device__ __forceinline__ void ml_geometry_kernel_body(PgoDev D, const MlDev* __restrict__ mlp,
+                                                          const double* __restrict__ pose, int l)
+{
+    const MlDev& ml = *mlp;
+    if (l > 0) {
+        const int A = blockIdx.x * kBlk + threadIdx.x;
+        if (A < ml.lv[l].n) ml_geometry_one(D, ml, pose, l, A);
+        return;
+    }
+    if (blockIdx.x != 0) return;
+    for (int q = 1; q <= ml.levels; q++) {
+        for (int A = threadIdx.x; A < ml.lv[q].n; A += kBlk) ml_geometry_one(D, ml, pose, q, A);
+        __syncthreads();                                   // (workgroup-scope release / acquire: the centroids just written are read next)
     }
 }
 __global__ __launch_bounds__(kBlk) void ml_geometry_kernel(PgoDev D, const MlDev* __restrict__ mlp, const double* __restrict__ pose, int l)
@@ -2179,7 +2193,7 @@ __global__ __launch_bounds__(kCgBlk) void ml_cg_comp_kernel(PgoDev D, MlHot H, c
 // ------------------------------------------------------------------------------------------------
 void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, int n_l, hipStream_t s)
 {
-    hipLaunchKernelGGL(ml_geometry_kernel, dim3((n_l + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, pose, l);
+    hipLaunchKernelGGL(ml_geometry_kernel, dim3(l == 0 ? 1 : (n_l + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, pose, l);
 }
 void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s)
 {
@@ -2445,8 +2459,10 @@ __global__ __launch_bounds__(kBlk) void ml_cmat32_lm_kernel(const LmSlot* __rest
 void kl_ml_numeric(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
 {
     const int B = sh.nslots;
-    for (int l = 1; l <= sh.levels; l++)
-        hipLaunchKernelGGL(ml_geometry_lm_kernel, dim3((sh.n_lv[l] + kBlk - 1) / kBlk, 1, B), dim3(kBlk), 0, s, sl, which, l);
+    if (sh.n_lv[1] <= kGeoAllMax) hipLaunchKernelGGL(ml_geometry_lm_kernel, dim3(1, 1, B), dim3(kBlk), 0, s, sl, which, 0);     // all levels, one workgroup per graph
+    else
+        for (int l = 1; l <= sh.levels; l++)
+            hipLaunchKernelGGL(ml_geometry_lm_kernel, dim3((sh.n_lv[l] + kBlk - 1) / kBlk, 1, B), dim3(kBlk), 0, s, sl, which, l);
     for (int f = 0; f < sh.levels; f++) {
         if (sh.work_t[f] > 0) hipLaunchKernelGGL(ml_transform_lm_kernel, dim3((sh.work_t[f] + kBlk - 1) / kBlk, 1, B), dim3(kBlk), 0, s, sl, which, f);
         const long work = (long)sh.work_t[f + 1] * 36;

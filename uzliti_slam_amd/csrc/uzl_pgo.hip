@@ -504,7 +504,8 @@ void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool t
     const int L = h->ml_levels;
     MlDev* dml = h->mlb[bi].dml;
     if (timed) h->timer.begin("ml_geometry", s);
-    for (int l = 1; l <= L; l++) k_ml_geometry(D, dml, h->cur, l, h->ml_n[l], s);
+    if (h->ml_n[1] <= kGeoAllMaxHost) k_ml_geometry(D, dml, h->cur, 0, 1, s);            // all levels by one workgroup
+    else for (int l = 1; l <= L; l++) k_ml_geometry(D, dml, h->cur, l, h->ml_n[l], s);
     if (timed) h->timer.end(s);
     for (int f = 0; f < L; f++) {
         if (timed) h->timer.begin("ml_transform", s);
