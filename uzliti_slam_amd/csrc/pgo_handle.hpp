@@ -39,6 +39,7 @@ int g_pcg_spmv(int nb);
 int g_pcg_update(int nb);
 constexpr int kGeoAllMaxHost = 1024;                  // (= kGeoAllMax of pgo_ml_kernels.hip)
 void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, int n_l, hipStream_t s);
+void k_ml_galerkin(const PgoDev& D, const MlDev* ml, int f, int n_chunks, hipStream_t s);
 void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s);
 void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
@@ -137,7 +138,7 @@ struct uzl_pgo {
     int num_last = -1;                         // numbering of that solve (-1: none yet); see build_structure
     // multilevel preconditioner
     int ml_levels = 0;
-    std::vector<int32_t> ml_n, ml_nslots;
+    std::vector<int32_t> ml_n, ml_nslots, ml_chunks;       // per level: entities, off-diagonal blocks, work chunks of ml_galerkin_kernel
     int ml_inner_aggs = 0;
     bool ml_trial_setup = false;     // the preconditioner's per-trial part (sibling inverses, top, dense levels) is due
     bool ml_comp = false;

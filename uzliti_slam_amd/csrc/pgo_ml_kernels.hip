@@ -250,6 +250,122 @@ __global__ __launch_bounds__(kBlk) void ml_reduce_kernel(const MlDev* __restrict
     ml_reduce_kernel_body(mlp, l);
 }
 
+// ---- the same Galerkin product as ONE kernel per level: a GATHER.  The host cuts the coarse level's output blocks into chunks of
+//      consecutive blocks with <= kGalItems contributions (MlLevel::chunk / cslot, build_ml); a workgroup transforms its chunk's
+//      contributions into LDS (one lane each: the work of ml_transform_kernel) and sums them per output block in contribution order (the
+//      work of ml_reduce_kernel: the same sums in the same order, the same bits) - no contribution array in memory, one launch per level
+//      instead of two.  A block with more contributions than fit (the top of a dense hierarchy) is a chunk of its own, in passes.
+__device__ __forceinline__ void ml_galerkin_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int f)
+{
+    __shared__ double sc[kGalItems * 36];
+    const MlDev& ml = *mlp;
+    const MlLevel& L = ml.lv[f];
+    const MlLevel& C = ml.lv[f + 1];
+    if ((int)blockIdx.x >= C.n_chunks) return;
+    const int32_t* __restrict__ ch = C.chunk + 5 * (size_t)blockIdx.x;
+    const int kind = ch[0], o0 = ch[1], no = ch[2], q0 = ch[3], nq = ch[4];
+    const int tid = threadIdx.x, ko = tid % 36, oo = tid / 36;          // reduce: lane (output oo of a round of 7, element ko)
+    const double* __restrict__ geo = L.geo;
+    const double* __restrict__ Fblk = (f == 0) ? D.blk : L.blk;
+    const int32_t* __restrict__ Fcol = (f == 0) ? D.col : L.col;
+    auto contribution = [&](int q, int slot_in_lds) {                    // P_row^T F P_col of fine slot cslot[q]
+        const int s = C.cslot[q];
+        P3 PL, PR;
+        make_P(f, geo, L.srow[s], PL);
+        make_P(f, geo, Fcol[s], PR);
+        double T[36];
+        galerkin(PL, Fblk + (size_t)s * 36, PR, T);
+#pragma unroll
+        for (int k = 0; k < 36; k++) sc[slot_in_lds * 36 + k] = T[k];
+    };
+    if (kind == 0) {                                                     // ---- off-diagonal blocks [o0, o0 + no)
+        double acc = 0.;
+        for (int base = 0; base < nq; base += kGalItems) {
+            const int cnt = min(kGalItems, nq - base);
+            __syncthreads();
+            if (tid < cnt) contribution(q0 + base + tid, tid);
+            __syncthreads();
+            if (no == 1) { if (tid < 36) for (int i = 0; i < cnt; i++) acc += sc[i * 36 + tid]; }
+            else if (tid < 252) {
+                for (int o = oo; o < no; o += 7) {
+                    const int b = o0 + o;
+                    double t = 0.;
+                    for (int q = C.off_ptr[b] - q0; q < C.off_ptr[b + 1] - q0; q++) t += sc[q * 36 + ko];
+                    C.blk[(size_t)b * 36 + ko] = t;
+                }
+            }
+        }
+        if (no == 1 && tid < 36) C.blk[(size_t)o0 * 36 + tid] = acc;
+        return;
+    }
+    // ---- diagonal blocks of aggregates [o0, o0 + no): same-aggregate off-diagonal contributions, then the children's G and M
+    const int fan = C.fan, nf = L.n;
+    const int c_first = o0 * fan, c_last = min(nf, (o0 + no) * fan), nch = c_last - c_first;
+    const bool zero_children = f == 0 && !D.diag_owner;                  // sharded solve: level-1 arrays are summed over ranks afterwards
+    auto children = [&](int at) {                                        // items [at, at + nch): P^T G P, [at + nch, at + 2 nch): P^T M P
+        if (tid < 2 * nch) {
+            const int j = tid % nch, c = c_first + j, which = tid / nch;
+            double T[36];
+            if (zero_children) {
+#pragma unroll
+                for (int k = 0; k < 36; k++) T[k] = 0.;
+            } else {
+                P3 P;
+                make_P(f, geo, c, P);
+                if (which == 0) galerkin(P, ((f == 0) ? D.hdiag : L.G) + (size_t)c * 36, P, T);
+                else if (f == 0) {
+                    const double I6[36] = {1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1};
+                    galerkin(P, I6, P, T);
+                } else galerkin(P, L.M + (size_t)c * 36, P, T);
+            }
+#pragma unroll
+            for (int k = 0; k < 36; k++) sc[(at + tid) * 36 + k] = T[k];
+        }
+    };
+    const int qd0 = q0 - C.n_off_contrib;                                // = diag_ptr[o0]
+    if (nq + 2 * nch <= kGalItems) {                                     // one pass
+        if (tid < nq) contribution(q0 + tid, tid);
+        else if (tid - nq < 2 * nch) { /* children below: their lanes are the first 2 nch - keep the mapping simple */ }
+        __syncthreads();
+        children(nq);
+        __syncthreads();
+        if (tid < 252) {
+            for (int o = oo; o < no; o += 7) {
+                const int A = o0 + o;
+                double t = 0., m = 0.;
+                for (int q = C.diag_ptr[A] - qd0; q < C.diag_ptr[A + 1] - qd0; q++) t += sc[q * 36 + ko];
+                const int ca = A * fan, cb = min(nf, ca + fan);
+                for (int c = ca; c < cb; c++) { t += sc[(nq + c - c_first) * 36 + ko]; m += sc[(nq + nch + c - c_first) * 36 + ko]; }
+                C.G[(size_t)A * 36 + ko] = t;
+                C.M[(size_t)A * 36 + ko] = m;
+            }
+        }
+        return;
+    }
+    // one aggregate with more contributions than fit: in passes, then its children
+    double acc = 0.;
+    for (int base = 0; base < nq; base += kGalItems) {
+        const int cnt = min(kGalItems, nq - base);
+        __syncthreads();
+        if (tid < cnt) contribution(q0 + base + tid, tid);
+        __syncthreads();
+        if (tid < 36) for (int i = 0; i < cnt; i++) acc += sc[i * 36 + tid];
+    }
+    __syncthreads();
+    children(0);
+    __syncthreads();
+    if (tid < 36) {
+        double m = 0.;
+        for (int j = 0; j < nch; j++) { acc += sc[j * 36 + tid]; m += sc[(nch + j) * 36 + tid]; }
+        C.G[(size_t)o0 * 36 + tid] = acc;
+        C.M[(size_t)o0 * 36 + tid] = m;
+    }
+}
+__global__ __launch_bounds__(kBlk) void ml_galerkin_kernel(PgoDev D, const MlDev* __restrict__ mlp, int f)
+{
+    ml_galerkin_kernel_body(D, mlp, f);
+}
+
 // ---- per LM trial: the sibling-block smoothers and the top level: dense SPD inverses of 24 .. 96 rows.
 // In-place Gauss-Jordan (no pivoting: SPD) of a matrix held as 6 x 6 tiles IN REGISTERS: lane (I, J) of an LW x LW square of lanes owns tile
 // (I, J); of step k only row k and column k travel, through two LDS buffers (one barrier per step).  6 nt dependent steps of ~0.1 us - the
@@ -2195,6 +2311,10 @@ void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, 
 {
     hipLaunchKernelGGL(ml_geometry_kernel, dim3(l == 0 ? 1 : (n_l + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, pose, l);
 }
+void k_ml_galerkin(const PgoDev& D, const MlDev* ml, int f, int n_chunks, hipStream_t s)
+{
+    if (n_chunks > 0) hipLaunchKernelGGL(ml_galerkin_kernel, dim3(n_chunks), dim3(kBlk), 0, s, D, ml, f);
+}
 void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s)
 {
     if (work > 0) hipLaunchKernelGGL(ml_transform_kernel, dim3((work + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, f);
@@ -2373,6 +2493,11 @@ __global__ __launch_bounds__(kBlk) void ml_transform_lm_kernel(const LmSlot* __r
     UZL_LM_SETUP(true)
     ml_transform_kernel_body(D, S.dml[c], f);
 }
+__global__ __launch_bounds__(kBlk) void ml_galerkin_lm_kernel(const LmSlot* __restrict__ slots, int which, int f)
+{
+    UZL_LM_SETUP(true)
+    ml_galerkin_kernel_body(D, S.dml[c], f);
+}
 __global__ __launch_bounds__(kBlk) void ml_reduce_lm_kernel(const LmSlot* __restrict__ slots, int which, int l)
 {
     UZL_LM_SETUP(true)
@@ -2463,11 +2588,8 @@ void kl_ml_numeric(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s
     else
         for (int l = 1; l <= sh.levels; l++)
             hipLaunchKernelGGL(ml_geometry_lm_kernel, dim3((sh.n_lv[l] + kBlk - 1) / kBlk, 1, B), dim3(kBlk), 0, s, sl, which, l);
-    for (int f = 0; f < sh.levels; f++) {
-        if (sh.work_t[f] > 0) hipLaunchKernelGGL(ml_transform_lm_kernel, dim3((sh.work_t[f] + kBlk - 1) / kBlk, 1, B), dim3(kBlk), 0, s, sl, which, f);
-        const long work = (long)sh.work_t[f + 1] * 36;
-        if (work > 0) hipLaunchKernelGGL(ml_reduce_lm_kernel, dim3((unsigned)((work + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, f + 1);
-    }
+    for (int f = 0; f < sh.levels; f++)
+        if (sh.chunks[f + 1] > 0) hipLaunchKernelGGL(ml_galerkin_lm_kernel, dim3(sh.chunks[f + 1], 1, B), dim3(kBlk), 0, s, sl, which, f);
 }
 // lambda-dependent part: the launch sequence of ml_setup_trial (uzl_pgo.hip)
 void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)

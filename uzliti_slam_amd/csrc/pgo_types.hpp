@@ -78,6 +78,8 @@ struct PgoDev {
 constexpr int kMlMaxLevels = 8;
 constexpr int kMlFanout = 8;         // level 1: 8 vertices per aggregate; levels >= 3: 8 children
 constexpr int kMlFanout2 = 4;        // level 2: 4 level-1 aggregates = 32 vertices = one workgroup of the PCG kernels
+constexpr int kGalItems = 256;        // contributions one workgroup of ml_galerkin_kernel transforms per pass (LDS: 36 doubles each)
+constexpr int kGalOutputs = 64;       // output blocks per chunk
 constexpr int kMlTopMax = 8;          // aggregates at the top level (<= 48 dof dense) when the PCG kernels walk the hierarchy themselves
 constexpr int kMlTopWide = 16;        // ... when they apply the dense composite operator instead: the top level is then only ever touched by
                                       // the rebuild, whose one-workgroup inverse (ml_top_kernel) takes 96 rows as readily as 48
@@ -96,6 +98,9 @@ struct MlLevel {
     const int32_t* off_ptr;    // [nslots+1] contributions of each off-diagonal block
     const int32_t* diag_ptr;   // [n+1]      same-aggregate contributions of each diagonal block
     int32_t n_off_contrib;     // diag contributions start here in the contribution array
+    const int32_t* cslot;      // [contributions] the fine-level slot behind each (ml_galerkin_kernel gathers)
+    const int32_t* chunk;      // [n_chunks][5] = {0 off-diagonal / 1 diagonal outputs, first output, outputs, first contribution, contributions}
+    int32_t n_chunks;
     double* blk;               // [nslots][36]
     double* G;                 // [n][36]   diagonal blocks of A_l(lambda = 0)
     double* M;                 // [n][36]   diagonal blocks of P^T P chain (lambda multiplier)
@@ -241,6 +246,7 @@ struct LmShape {
     int32_t cg_variant, comp_u;              // LmCgVariant; kCgComp1: gather-level values per lane (5 / 8 / 12 / 16)
     int32_t n_lv[kMlMaxLevels + 2];          // entities per level (level 0: the largest graph)
     int32_t work_t[kMlMaxLevels + 2];        // Galerkin transform / reduce work per level (largest graph): nslots_l + n_l
+    int32_t chunks[kMlMaxLevels + 2];        // ml_galerkin_kernel's workgroups per coarse level (largest graph)
     int32_t inner_aggs;                      // sibling blocks (largest graph)
     int32_t g_edges, g_asm, g_oplus, g_rows, g_spmv;      // largest grids
     int32_t red, schur_runs, schur_backsub_grid;

@@ -246,7 +246,7 @@ namespace {
 void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vector<int32_t>& col0, int nb, int nslots,
               const int32_t* d_row_ptr, const int32_t* d_col, double* d_blk, double* d_hdiag)
 {
-    h->ml_levels = 0; h->ml_n.assign(1, nb); h->ml_nslots.assign(1, nslots); h->ml_inner_aggs = 0;
+    h->ml_levels = 0; h->ml_n.assign(1, nb); h->ml_nslots.assign(1, nslots); h->ml_chunks.assign(1, 0); h->ml_inner_aggs = 0;
     if (h->cfg.preconditioner == 0 || nb <= kMlTopMax) return;
     // Up to here the level-1 dense operator applies (6 n_1 <= 3072: ml_cg_comp_kernel<16>); above, AGG = 4 with the level-2 one.  Its
     // rebuild (Newton-Schulz GEMMs, n^3) outgrows what the exact level-1 solve saves in PCG iterations between 3000 and 4000 vertices on
@@ -281,7 +281,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     h->ml_levels = L;
     h->ml_lds = ml_cg_lds_bytes(h->ml_n.data(), L, h->ml_agg);
     // per-level host index arrays
-    struct Lv { std::vector<int32_t> row_ptr, col, srow, tpos, off_ptr, diag_ptr; int32_t n_off = 0; };
+    struct Lv { std::vector<int32_t> row_ptr, col, srow, tpos, off_ptr, diag_ptr, cslot, chunk; int32_t n_off = 0; };      // cslot / chunk: ml_galerkin_kernel's work list
     std::vector<Lv> lv((size_t)L + 1);
     lv[0].col = col0;
     lv[0].srow.resize(col0.size());
@@ -320,7 +320,33 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         C.diag_ptr.assign((size_t)nc + 1, 0);
         for (size_t k = 0; k < dg.size(); k++) { C.diag_ptr[dg[k].first + 1]++; F.tpos[dg[k].second] = C.n_off + (int32_t)k; }
         for (int a = 0; a < nc; a++) C.diag_ptr[a + 1] += C.diag_ptr[a];
+        // The Galerkin product as a GATHER (ml_galerkin_kernel): contribution q comes from fine slot cslot[q]; a workgroup takes a chunk of
+        // consecutive output blocks whose contributions (<= kGalItems) it transforms into LDS and sums in order.  chunk = {kind (0: off-
+        // diagonal blocks, 1: diagonal blocks), first output, outputs, first contribution, contributions}.
+        C.cslot.resize(off.size() + dg.size());
+        for (size_t k = 0; k < off.size(); k++) C.cslot[k] = off[k].s;
+        for (size_t k = 0; k < dg.size(); k++) C.cslot[off.size() + k] = dg[k].second;
+        {
+            const int nso = (int)C.col.size();
+            for (int b = 0; b < nso;) {                                      // off-diagonal outputs
+                int e = b, items = 0;
+                while (e < nso && (e == b || items + (C.off_ptr[e + 1] - C.off_ptr[e]) <= kGalItems) && e - b < kGalOutputs) { items += C.off_ptr[e + 1] - C.off_ptr[e]; e++; }
+                const int32_t c5[5] = {0, b, e - b, C.off_ptr[b], items};
+                C.chunk.insert(C.chunk.end(), c5, c5 + 5);
+                b = e;
+            }
+            const int nf = h->ml_n[f];
+            for (int a = 0; a < nc;) {                                       // diagonal outputs: + two items (G, M) per child
+                int e = a, items = 0;
+                auto cost = [&](int A) { return (C.diag_ptr[A + 1] - C.diag_ptr[A]) + 2 * (std::min(nf, (A + 1) * fan_c) - A * fan_c); };
+                while (e < nc && (e == a || items + cost(e) <= kGalItems) && e - a < kGalOutputs) { items += cost(e); e++; }
+                const int32_t c5[5] = {1, a, e - a, C.n_off + C.diag_ptr[a], C.diag_ptr[e] - C.diag_ptr[a]};
+                C.chunk.insert(C.chunk.end(), c5, c5 + 5);
+                a = e;
+            }
+        }
         h->ml_nslots.push_back((int32_t)C.col.size());
+        h->ml_chunks.push_back((int32_t)(C.chunk.size() / 5));
         max_contrib = std::max(max_contrib, off.size() + dg.size());
         max_n = std::max(max_n, (size_t)nc);
         h->ml_inner_aggs += nc;                                   // one sibling block per aggregate of every coarse level
@@ -328,7 +354,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     // ---- one arena for everything: first the int arrays (staged on the host), then the doubles
     size_t bytes = 0;
     auto take = [&](size_t b) { size_t o = bytes; bytes = (bytes + b + 255) / 256 * 256; return o; };
-    struct IntOff { size_t row_ptr, col, srow, tpos, off_ptr, diag_ptr; };
+    struct IntOff { size_t row_ptr, col, srow, tpos, off_ptr, diag_ptr, cslot, chunk; };
     std::vector<IntOff> io((size_t)L + 1);
     for (int l = 0; l <= L; l++) {
         Lv& X = lv[l];
@@ -338,6 +364,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         io[l].tpos = take(std::max<size_t>(X.tpos.size(), 1) * 4);
         io[l].off_ptr = take(std::max<size_t>(X.off_ptr.size(), 1) * 4);
         io[l].diag_ptr = take(std::max<size_t>(X.diag_ptr.size(), 1) * 4);
+        io[l].cslot = take(std::max<size_t>(X.cslot.size(), 1) * 4);
+        io[l].chunk = take(std::max<size_t>(X.chunk.size(), 1) * 4);
     }
     const size_t int_bytes = bytes;
     struct DblOff { size_t blk, G, M, Winv, geo, cen, r, y; };
@@ -413,6 +441,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     for (int l = 0; l <= L; l++) {
         put(io[l].row_ptr, lv[l].row_ptr); put(io[l].col, lv[l].col); put(io[l].srow, lv[l].srow);
         put(io[l].tpos, lv[l].tpos); put(io[l].off_ptr, lv[l].off_ptr); put(io[l].diag_ptr, lv[l].diag_ptr);
+        put(io[l].cslot, lv[l].cslot); put(io[l].chunk, lv[l].chunk);
     }
     hipStream_t s = h->stream;
     h->d_ml.reserve(2);
@@ -437,6 +466,9 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
             X.off_ptr = reinterpret_cast<const int32_t*>(base + io[l].off_ptr);
             X.diag_ptr = reinterpret_cast<const int32_t*>(base + io[l].diag_ptr);
             X.n_off_contrib = lv[l].n_off;
+            X.cslot = reinterpret_cast<const int32_t*>(base + io[l].cslot);
+            X.chunk = reinterpret_cast<const int32_t*>(base + io[l].chunk);
+            X.n_chunks = (int32_t)(lv[l].chunk.size() / 5);
             X.blk = (l == 0) ? d_blk : reinterpret_cast<double*>(base + dof[l].blk);
             X.G = (l == 0) ? d_hdiag : reinterpret_cast<double*>(base + dof[l].G);
             X.M = (l == 0) ? nullptr : reinterpret_cast<double*>(base + dof[l].M);
@@ -508,10 +540,8 @@ void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool t
     else for (int l = 1; l <= L; l++) k_ml_geometry(D, dml, h->cur, l, h->ml_n[l], s);
     if (timed) h->timer.end(s);
     for (int f = 0; f < L; f++) {
-        if (timed) h->timer.begin("ml_transform", s);
-        k_ml_transform(D, dml, f, h->ml_nslots[f] + h->ml_n[f], s);
-        if (timed) { h->timer.end(s); h->timer.begin("ml_reduce", s); }
-        k_ml_reduce(dml, f + 1, h->ml_nslots[f + 1] + h->ml_n[f + 1], s);
+        if (timed) h->timer.begin("ml_galerkin", s);
+        k_ml_galerkin(D, dml, f, h->ml_chunks[f + 1], s);
         if (timed) h->timer.end(s);
         if (f == 0) shard_allreduce(h, h->mlb[bi].l1_span_ptr, h->l1_span);     // level 1 complete on every rank: levels >= 2 need no exchange
     }

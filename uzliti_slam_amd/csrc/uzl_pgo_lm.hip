@@ -154,7 +154,7 @@ LmShape make_shape(const std::vector<uzl_pgo*>& hs, int nslots, bool batch_geome
     sh.mult = h->ml_mult ? 1 : 0; sh.ns_steps = h->ml_ns_steps; sh.upper_ns = kUpperNs;
     ml_cg_variant(h->mlb[0].hot, h->ml_agg, h->ml_lds, &sh.cg_variant, &sh.comp_u, &sh.cg_lds);
     for (const uzl_pgo* g : hs) {
-        for (int l = 0; l <= g->ml_levels; l++) { sh.n_lv[l] = std::max(sh.n_lv[l], g->ml_n[l]); sh.work_t[l] = std::max(sh.work_t[l], g->ml_nslots[l] + g->ml_n[l]); }
+        for (int l = 0; l <= g->ml_levels; l++) { sh.n_lv[l] = std::max(sh.n_lv[l], g->ml_n[l]); sh.work_t[l] = std::max(sh.work_t[l], g->ml_nslots[l] + g->ml_n[l]); sh.chunks[l] = std::max(sh.chunks[l], g->ml_chunks[l]); }
         sh.inner_aggs = std::max(sh.inner_aggs, g->ml_inner_aggs);
         sh.g_edges = std::max(sh.g_edges, g_edges_for(g->e)); sh.g_asm = std::max(sh.g_asm, g->D.n_rb); sh.g_oplus = std::max(sh.g_oplus, g_oplus_for(g->n));
         sh.g_rows = std::max(sh.g_rows, g_ml_rows(g->Dp.nb, g->ml_agg)); sh.g_spmv = std::max(sh.g_spmv, g_ml_spmv(g->Dp.nb, g->ml_agg));
