@@ -749,6 +749,137 @@ __global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restri
 {
     ml_mult_final_kernel_body(mlp, cl);
 }
+// ---- the cycle's operands per PAIR of sibling groups, in one launch (round 4; was A P | A S, then Q | 2 S - S (A S): two launches of
+//      one lane per 6 x 6 block, 57 us at config 2).  Workgroup (g, p): the block A_gp of A_l(lambda) between the children of level-(l+1)
+//      aggregates g and p (48 x 48, assembled in LDS from the slot ranges grp_beg / grp_end), the sibling inverses S_g and S_p, and
+//          Y_l[g, p]  = [g == p] 2 S_g - (S_g A_gp) S_p                  (the cycle without its coarse term, which ml_mult_qyqt adds)
+//          Q[g][p]    = [g == p] P_p  - S_g (A_gp P_p)                    (48 x 6; P_p = the children's prolongation blocks stacked)
+//      Pairs without a block between them (and g != p) only write zeros.  Dense products of 48 x 48 LDS tiles, 256 lanes.
+constexpr int kPairLd = 49;
+__device__ __forceinline__ void ml_mult_pair_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl)
+{
+    __shared__ double sA[48 * kPairLd], sSg[48 * kPairLd], sSp[48 * kPairLd], sT[48 * kPairLd];
+    __shared__ double sPp[48 * 6], sAP[48 * 6];
+    __shared__ int s_any;
+    const MlDev& ml = *mlp;
+    const MlLevel& F = ml.lv[cl];
+    const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan, m = 6 * fan, n6 = 6 * n;
+    const int g = blockIdx.x / np, p = blockIdx.x % np, tid = threadIdx.x;
+    if ((int)blockIdx.x >= np * np) return;
+    const double lambda = D.scal[3];
+    const int* __restrict__ gb = ml.grp_beg[cl];
+    const int* __restrict__ ge = ml.grp_end[cl];
+    if (tid == 0) s_any = (g == p) ? 1 : 0;
+    __syncthreads();
+    if (tid < fan) {
+        const int i = g * fan + tid;
+        if (i < n && gb[(size_t)i * np + p] < ge[(size_t)i * np + p]) s_any = 1;
+    }
+    __syncthreads();
+    double* __restrict__ Y = ml.Ydense[cl];
+    if (!s_any) {                                                        // no coupling: Y tile and Q blocks are zero
+        for (int e = tid; e < m * m; e += kBlk) {
+            const int r = e / m, c = e % m, gi = g * fan + r / 6, pi = p * fan + c / 6;
+            if (gi < n && pi < n) Y[(size_t)(6 * gi + r % 6) * n6 + 6 * pi + c % 6] = 0.;
+        }
+        for (int e = tid; e < fan * 36; e += kBlk) {
+            const int i = g * fan + e / 36;
+            if (i < n) ml.mQ[((size_t)i * np + p) * 36 + e % 36] = 0.;
+        }
+        return;
+    }
+    // ---- operands into LDS
+    for (int e = tid; e < m * m; e += kBlk) {
+        const int r = e / m, c = e % m;
+        sSg[r * kPairLd + c] = F.Winv[(size_t)g * m * m + e];
+        sSp[r * kPairLd + c] = F.Winv[(size_t)p * m * m + e];
+        sA[r * kPairLd + c] = 0.;
+    }
+    for (int e = tid; e < fan * 36; e += kBlk) {                         // P_p: pmat6 of every child of p (zero rows for missing children)
+        const int j = e / 36, k = e % 36, c = p * fan + j;
+        double v = 0.;
+        if (c < n) {
+            const double* __restrict__ d = F.geo + (size_t)c * 3;
+            const int r = k / 6, q = k % 6;
+            v = (r == q) ? 1. : 0.;
+            if (r == 0 && q == 4) v = d[2];  if (r == 0 && q == 5) v = -d[1];
+            if (r == 1 && q == 3) v = -d[2]; if (r == 1 && q == 5) v = d[0];
+            if (r == 2 && q == 3) v = d[1];  if (r == 2 && q == 4) v = -d[0];
+        }
+        sPp[(j * 6 + k / 6) * 6 + k % 6] = v;
+    }
+    __syncthreads();
+    if (g == p) {                                                        // diagonal blocks D_i = G_i + lambda M_i
+        for (int e = tid; e < fan * 36; e += kBlk) {
+            const int j = e / 36, k = e % 36, i = g * fan + j;
+            if (i < n) sA[(j * 6 + k / 6) * kPairLd + j * 6 + k % 6] = F.G[(size_t)i * 36 + k] + lambda * F.M[(size_t)i * 36 + k];
+        }
+    }
+    for (int j = 0; j < fan; j++) {                                      // off-diagonal blocks of row i whose column is a child of p
+        const int i = g * fan + j;
+        if (i >= n) break;
+        const int s0 = gb[(size_t)i * np + p], s1 = ge[(size_t)i * np + p];
+        for (int e = tid; e < (s1 - s0) * 36; e += kBlk) {
+            const int s_ = s0 + e / 36, k = e % 36, jc = F.col[s_] - p * fan;
+            sA[(j * 6 + k / 6) * kPairLd + jc * 6 + k % 6] = F.blk[(size_t)s_ * 36 + k];       // (blocks of a coarse level are unique per (row, column))
+        }
+    }
+    __syncthreads();
+    // ---- T = S_g A, AP = A P_p.  The two m x m x m products in 3 x 3 register tiles: lane (tr, tc) of (m / 3)^2 <= 256
+    const int m3 = m / 3, tr = tid / m3, tc = tid % m3;
+    const bool tile = tid < m3 * m3;
+    if (tile) {
+        double t[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int k = 0; k < m; k++) {
+            const double a0 = sSg[(3 * tr) * kPairLd + k], a1 = sSg[(3 * tr + 1) * kPairLd + k], a2 = sSg[(3 * tr + 2) * kPairLd + k];
+            const double b0 = sA[k * kPairLd + 3 * tc], b1 = sA[k * kPairLd + 3 * tc + 1], b2 = sA[k * kPairLd + 3 * tc + 2];
+            t[0][0] = fma(a0, b0, t[0][0]); t[0][1] = fma(a0, b1, t[0][1]); t[0][2] = fma(a0, b2, t[0][2]);
+            t[1][0] = fma(a1, b0, t[1][0]); t[1][1] = fma(a1, b1, t[1][1]); t[1][2] = fma(a1, b2, t[1][2]);
+            t[2][0] = fma(a2, b0, t[2][0]); t[2][1] = fma(a2, b1, t[2][1]); t[2][2] = fma(a2, b2, t[2][2]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) sT[(3 * tr + i) * kPairLd + 3 * tc + j] = t[i][j];
+    }
+    for (int e = tid; e < m * 6; e += kBlk) {
+        const int r = e / 6, c = e % 6;
+        double t = 0.;
+        for (int k = 0; k < m; k++) t = fma(sA[r * kPairLd + k], sPp[k * 6 + c], t);
+        sAP[e] = t;
+    }
+    __syncthreads();
+    // ---- Y tile = [g == p] 2 S_g - T S_p;  Q = [g == p] P_p - S_g AP
+    if (tile) {
+        double t[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int k = 0; k < m; k++) {
+            const double a0 = sT[(3 * tr) * kPairLd + k], a1 = sT[(3 * tr + 1) * kPairLd + k], a2 = sT[(3 * tr + 2) * kPairLd + k];
+            const double b0 = sSp[k * kPairLd + 3 * tc], b1 = sSp[k * kPairLd + 3 * tc + 1], b2 = sSp[k * kPairLd + 3 * tc + 2];
+            t[0][0] = fma(a0, b0, t[0][0]); t[0][1] = fma(a0, b1, t[0][1]); t[0][2] = fma(a0, b2, t[0][2]);
+            t[1][0] = fma(a1, b0, t[1][0]); t[1][1] = fma(a1, b1, t[1][1]); t[1][2] = fma(a1, b2, t[1][2]);
+            t[2][0] = fma(a2, b0, t[2][0]); t[2][1] = fma(a2, b1, t[2][1]); t[2][2] = fma(a2, b2, t[2][2]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int r = 3 * tr + i, c = 3 * tc + j, gi = g * fan + r / 6, pi = p * fan + c / 6;
+                if (gi < n && pi < n) Y[(size_t)(6 * gi + r % 6) * n6 + 6 * pi + c % 6] = ((g == p) ? 2. * sSg[r * kPairLd + c] : 0.) - t[i][j];
+            }
+    }
+    for (int e = tid; e < m * 6; e += kBlk) {
+        const int r = e / 6, c = e % 6, i = g * fan + r / 6;
+        if (i >= n) continue;
+        double t = 0.;
+        for (int k = 0; k < m; k++) t = fma(sSg[r * kPairLd + k], sAP[k * 6 + c], t);
+        ml.mQ[((size_t)i * np + p) * 36 + (r % 6) * 6 + c] = ((g == p) ? sPp[r * 6 + c] : 0.) - t;
+    }
+}
+__global__ __launch_bounds__(kBlk) void ml_mult_pair_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl)
+{
+    ml_mult_pair_kernel_body(D, mlp, cl);
+}
+
 // Two launches instead of four for a single graph's rebuild (a chain of ~35 small dependent launches that the early LM iterations wait
 // for): A P and A S depend on nothing inside the cycle, Q needs only A P and the 2 S - S (A S) part of Y only A S.
 __global__ __launch_bounds__(kBlk) void ml_mult_ap_as_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl, int g_ap)
@@ -2330,10 +2461,8 @@ void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s)
 }
 void k_ml_mult_level(const PgoDev& D, const MlDev* ml, int lev, int n1, int n2, hipStream_t s)
 {
-    const int g12 = (n1 * n2 + kBlk - 1) / kBlk, g11 = (n1 * n1 + kBlk - 1) / kBlk;
-    hipLaunchKernelGGL(ml_mult_ap_as_kernel, dim3(g12 + g11), dim3(kBlk), 0, s, D, ml, lev, g12);
-    const int g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk, gfin = (n2 * n2 + kBlk / 64 - 1) / (kBlk / 64);
-    hipLaunchKernelGGL(ml_mult_q_final_kernel, dim3(g12r + gfin), dim3(kBlk), 0, s, ml, lev, g12r);
+    hipLaunchKernelGGL(ml_mult_pair_kernel, dim3(n2 * n2), dim3(kBlk), 0, s, D, ml, lev);
+    const int g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk;
     hipLaunchKernelGGL(ml_mult_qy_kernel, dim3(g12r), dim3(kBlk), 0, s, ml, lev);
     const int gt = (6 * n1 + kGemmTile - 1) / kGemmTile;
     hipLaunchKernelGGL(ml_mult_qyqt_kernel, dim3(gt * (gt + 1) / 2), dim3(256), 0, s, ml, lev);
@@ -2515,6 +2644,11 @@ __global__ __launch_bounds__(kBlk) void ml_dense_level_lm_kernel(const LmSlot* _
     (void)D;
     ml_dense_level_kernel_body(S.dml[c], l);
 }
+__global__ __launch_bounds__(kBlk) void ml_mult_pair_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev)
+{
+    UZL_LM_SETUP(false)
+    ml_mult_pair_kernel_body(D, S.dml[c], lev);
+}
 __global__ __launch_bounds__(kBlk) void ml_mult_ap_as_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int g_ap)
 {
     UZL_LM_SETUP(false)
@@ -2607,10 +2741,8 @@ void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
     }
     for (int l = L - 1; l >= cl; l--) {                                        // multiplicative cycle + Newton-Schulz, from the top down
         const int n1 = sh.n_lv[l], n2 = sh.n_lv[l + 1];
-        const int g12 = (n1 * n2 + kBlk - 1) / kBlk, g11 = (n1 * n1 + kBlk - 1) / kBlk;
-        hipLaunchKernelGGL(ml_mult_ap_as_lm_kernel, dim3(g12 + g11, 1, B), dim3(kBlk), 0, s, sl, which, l, g12);
-        const int g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk, gfin = (n2 * n2 + kBlk / 64 - 1) / (kBlk / 64);
-        hipLaunchKernelGGL(ml_mult_q_final_lm_kernel, dim3(g12r + gfin, 1, B), dim3(kBlk), 0, s, sl, which, l, g12r);
+        hipLaunchKernelGGL(ml_mult_pair_lm_kernel, dim3(n2 * n2, 1, B), dim3(kBlk), 0, s, sl, which, l);
+        const int g12r = (n1 * n2 * 6 + kBlk - 1) / kBlk;
         hipLaunchKernelGGL(ml_mult_qy_lm_kernel, dim3(g12r, 1, B), dim3(kBlk), 0, s, sl, which, l);
         const int n6 = 6 * n1, gt = (n6 + kGemmTile - 1) / kGemmTile;
         hipLaunchKernelGGL(ml_mult_qyqt_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l);
