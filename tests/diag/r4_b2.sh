@@ -1,0 +1,5 @@
+set -e
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python3 -m pytest tests/test_batch_gpu.py tests/test_lm_loops_gpu.py -x -q -m gpu 2>&1 | tail -3
+python3 tests/diag/batch_phases.py 16 2>&1 | tail -1
+python3 tests/diag/batch_phases.py 16 2>&1 | tail -1

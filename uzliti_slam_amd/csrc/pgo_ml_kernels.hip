@@ -906,18 +906,26 @@ constexpr int kAxChunk = 16;          // off-diagonal blocks staged per pass
 constexpr int kXcds = 8;
 __host__ __device__ __forceinline__ int ax_slab(int n6) { return ((n6 + kXcds - 1) / kXcds + 31) & ~31; }          // columns per XCD
 __host__ __device__ __forceinline__ int ax_parts(int n6) { return (ax_slab(n6) + kBlk - 1) / kBlk; }             // workgroups per (row block, slab)
+// (a batch fills the chip anyway and its graphs' X live in different places: there the plain mapping - row block, 256 columns per
+//  workgroup, every lane busy - is the faster one: `by_xcd` = false)
 __device__ __forceinline__ void ml_ns_ax_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl, const double* __restrict__ X,
-                                                       double* __restrict__ T)
+                                                       double* __restrict__ T, bool by_xcd = true)
 {
     __shared__ double sb[(kAxChunk + 1) * 36];
     __shared__ int sc[kAxChunk + 1];
     const MlDev& ml = *mlp;
     const MlLevel& F = ml.lv[cl];
-    const int n6 = 6 * F.n, slab = ax_slab(n6), parts = ax_parts(n6);
-    const int xcd = blockIdx.x % kXcds, rest = blockIdx.x / kXcds, i = rest / parts, part = rest % parts, tid = threadIdx.x;
+    const int n6 = 6 * F.n, slab = ax_slab(n6), parts = ax_parts(n6), tid = threadIdx.x;
+    int i, c;
+    bool act;
+    if (by_xcd) {
+        const int xcd = blockIdx.x % kXcds, rest = blockIdx.x / kXcds, part = rest % parts, cin = part * kBlk + tid;
+        i = rest / parts; c = xcd * slab + cin; act = cin < slab && c < n6;
+    } else {
+        const int chunks = (n6 + kBlk - 1) / kBlk;
+        i = blockIdx.x / chunks; c = (blockIdx.x % chunks) * kBlk + tid; act = c < n6;
+    }
     if (i >= F.n) return;                                          // (a batch launches the largest graph's grid)
-    const int cin = part * kBlk + tid, c = xcd * slab + cin;
-    const bool act = cin < slab && c < n6;
     const double lambda = D.scal[3];
     const int s0 = F.row_ptr[i], s1 = F.row_ptr[i + 1];
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -2679,9 +2687,10 @@ __global__ __launch_bounds__(256) void ml_mult_qyqt_lm_kernel(const LmSlot* __re
 __global__ __launch_bounds__(kBlk) void ml_ns_ax_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k)
 {
     UZL_LM_SETUP(false)
-    if ((int)blockIdx.x >= kXcds * S.hot[0].n[lev] * ax_parts(6 * S.hot[0].n[lev])) return;
+    const bool by_xcd = gridDim.z == 1;
+    if (by_xcd && (int)blockIdx.x >= kXcds * S.hot[0].n[lev] * ax_parts(6 * S.hot[0].n[lev])) return;
     const double* X = (k & 1) ? S.nsX[c] : S.dense[c][lev];
-    ml_ns_ax_kernel_body(D, S.dml[c], lev, X, S.nsT[c]);
+    ml_ns_ax_kernel_body(D, S.dml[c], lev, X, S.nsT[c], by_xcd);
 }
 __global__ __launch_bounds__(256) void ml_ns_gemm_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int k, int last)
 {
@@ -2748,7 +2757,7 @@ void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s)
         hipLaunchKernelGGL(ml_mult_qyqt_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l);
         const int steps = l > cl ? sh.upper_ns : sh.ns_steps;
         for (int k = 0; k < steps; k++) {
-            hipLaunchKernelGGL(ml_ns_ax_lm_kernel, dim3(kXcds * n1 * ax_parts(n6), 1, B), dim3(kBlk), 0, s, sl, which, l, k);
+            hipLaunchKernelGGL(ml_ns_ax_lm_kernel, dim3(B == 1 ? kXcds * n1 * ax_parts(n6) : n1 * ((n6 + kBlk - 1) / kBlk), 1, B), dim3(kBlk), 0, s, sl, which, l, k);
             const int last = (l == cl && k == steps - 1) ? 1 : 0;
             if (B == 1 && n6 <= kGemm32Max) hipLaunchKernelGGL(ml_ns_gemm32_lm_kernel, dim3(gemm32_grid((n6 + 31) / 32), 1, 1), dim3(256), 0, s, sl, which, l, k, last);
             else hipLaunchKernelGGL(ml_ns_gemm_lm_kernel, dim3(gt * (gt + 1) / 2, 1, B), dim3(256), 0, s, sl, which, l, k, last);
