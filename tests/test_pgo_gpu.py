@@ -652,3 +652,45 @@ def test_reduced_numbering_row_order_and_strong_aggregates_agree(capi, oracle, n
     for mode in (1, 2):
         dt, dr = synth.pose_errors(out[mode][0], P.reshape(-1, 3, 4))
         assert dt < 1e-3 and dr < 1e-4, (mode, dt, dr)
+
+
+def test_blocks_with_hundreds_of_contributions(capi, oracle):
+    """ml_galerkin_kernel's passes: one coarse block with more contributions than a workgroup transforms at once - 400 parallel edges
+    between two vertices of DIFFERENT aggregates (an off-diagonal block of level 1) and 300 between two vertices of the SAME aggregate (a
+    diagonal block) - plus the ordinary chunks around them.  Against the oracle."""
+    g = synth.make_pose_graph(300, 900, seed=41)
+    e = g["edges"]
+    gt = g["gt_pose"].reshape(-1, 3, 4)
+    rng = np.random.default_rng(9)
+
+    def bundle(a, b, count):
+        T = synth.se3_mul(synth.se3_inv(gt[[a] * count]), gt[[b] * count])
+        T = synth.se3_mul(T, synth.se3_from_noise(rng.normal(0, 0.01, (count, 3)), rng.normal(0, 0.002, (count, 3))))
+        return np.full(count, a, np.int32), np.full(count, b, np.int32), T.reshape(-1, 12)
+    fa, ta, Ta = bundle(40, 170, 400)
+    fb, tb, Tb = bundle(80, 81, 300)
+    nx = 700
+    ident = np.tile(np.eye(3, 4).reshape(1, 12), (nx, 1))
+    info = np.tile((np.eye(6) * 20.0).reshape(1, 36), (nx, 1))
+
+    def cat(k, extra):
+        return np.concatenate([np.asarray(e[k]), extra])
+    e2 = {"from": cat("from", np.concatenate([fa, fb])), "to": cat("to", np.concatenate([ta, tb])),
+          "type": cat("type", np.ones(nx, np.int32)), "sensor_from": cat("sensor_from", np.full(nx, -1, np.int32)),
+          "sensor_to": cat("sensor_to", np.full(nx, -1, np.int32)), "valid": cat("valid", np.ones(nx, np.int32)),
+          "transform": cat("transform", np.concatenate([Ta, Tb])), "displacement_from": cat("displacement_from", ident),
+          "displacement_to": cat("displacement_to", ident), "information": cat("information", info),
+          "diff_time": cat("diff_time", np.zeros(nx))}
+    fl = oracle.flatten_graph(g["nodes_pose"], g["nodes_fixed"], e2)
+    fixed, _ = oracle.set_fixed_nodes(fl["fixed"], fl["ij"])
+    its = 8
+    P, so = oracle.pgo_optimize(fl["poses"], fixed, fl["ij"], fl["meas"], fl["info"], fl["robust"], iterations=its)
+    for loop in (0, 1):
+        p = capi.Pgo(lm_loop=loop)
+        p.add_graph(g["nodes_pose"], g["nodes_fixed"], e2)
+        st = p.optimize(its)
+        poses, _, _ = p.store()
+        p.close()
+        assert st["status"] == 0 and st["iterations_done"] == so["iterations_done"]
+        dt, dr = synth.pose_errors(poses.reshape(-1, 3, 4), P.reshape(-1, 3, 4))
+        assert dt < 1e-3 and dr < 1e-4, (loop, dt, dr)
