@@ -220,7 +220,7 @@ bool lm_batch_eligible(const std::vector<uzl_pgo*>& hs);
 int batch_optimize_lm(LmRun*& R, const std::vector<uzl_pgo*>& hs, int resident, hipStream_t s, hipStream_t s2, int32_t iterations, bool eager, bool verbose, KernelTimer* timer,
                       uzl_pgo_stats* stats, int* rc_all);
 constexpr int kSchurStrongOneMax = 256;                // strong aggregates: up to this many groups as ONE level (level-1 path), beyond in blocks of 4 (pgo_schur.hpp)
-constexpr int kSchurStrongMin = 128;                  // separators from which on the reduced system is numbered by strong aggregates
+constexpr int kSchurStrongMin = 32;                   // separators from which on the reduced system is numbered by strong aggregates
 extern const int kUpperNs;                            // Newton-Schulz steps of the dense levels above the composite level
 extern const bool kAlwaysRefresh;                     // A/B switches (diagnostic build)
 extern const double kRefreshRel, kLambdaRetake;
