@@ -243,7 +243,7 @@ typedef struct uzl_pgo_cfg {
     int32_t pcg_stop;                 /* 0 = step-error estimate (above), 1 = relative residual test only                  */
     int32_t lm_loop;                  /* 0 = Levenberg-Marquardt decisions on the device, one host look per trial (captured passes);
                                          1 = host-driven loop (the one sharded and profiled solves always take); same results */
-    int32_t reduced_numbering;        /* how the Schur-reduced system (schur_reduce) of a graph with >= 128 separators is laid out:
+    int32_t reduced_numbering;        /* how the Schur-reduced system (schur_reduce) of a graph with >= 32 separators is laid out:
                                          1 = row (trajectory) order, 8 consecutive separators per aggregate; 2 = by strong aggregates
                                          (separators that are stiffly tied - loop-closure partners, short runs - share an aggregate);
                                          0 = the handle chooses: strong aggregates while they are few enough for the level-1 path
