@@ -112,7 +112,7 @@ __device__ __forceinline__ void galerkin(const P3& L, const double* __restrict__
 // ---- geometry of level l (>= 1): centroid of every aggregate, then the children's offsets d.  cen = {x, y, z, vertices underneath}.
 //      An EMPTY row (b2v < 0: padding of a strong-aggregate numbering, pgo_schur.hpp) has no pose: it carries no weight and gets a zero
 //      prolongation block (R^T = 0), so it adds nothing to any coarse operator.
-__device__ __forceinline__ void ml_geometry_one(const PgoDev& D, const MlDev& ml, const double* __restrict__ pose, int l, int A)
+__device__ __forceinline__ void ml_geometry_one(const PgoDev& D, const MlDev& ml, const double* __restrict__ pose, int l, int A, bool centroid_only = false)
 {
     const int nc = ml.lv[l - 1].n;
     const int fan = ml.lv[l].fan;
@@ -134,6 +134,7 @@ __device__ __forceinline__ void ml_geometry_one(const PgoDev& D, const MlDev& ml
     if (wsum > 0.) { cx /= wsum; cy /= wsum; cz /= wsum; }
     double* cen = ml.lv[l].cen + (size_t)A * 4;
     cen[0] = cx; cen[1] = cy; cen[2] = cz; cen[3] = wsum;
+    if (centroid_only) return;
     for (int c = c0; c < c1; c++) {
         if (l == 1) {
             double* g = ml.lv[0].geo + (size_t)c * 12;
@@ -171,8 +172,35 @@ __device__ __forceinline__ void ml_geometry_kernel_body(PgoDev D, const MlDev* _
     }
     if (blockIdx.x != 0) return;
     for (int q = 1; q <= ml.levels; q++) {
-        for (int A = threadIdx.x; A < ml.lv[q].n; A += kBlk) ml_geometry_one(D, ml, pose, q, A);
+        // centroids: a lane per aggregate; the children's offsets (level 1: R^T and the offset of every vertex): a lane per CHILD - eight
+        // times the lanes for the part that was eight sequential pose loads and rotations per lane
+        for (int A = threadIdx.x; A < ml.lv[q].n; A += kBlk) ml_geometry_one(D, ml, pose, q, A, true);
         __syncthreads();                                   // (workgroup-scope release / acquire: the centroids just written are read next)
+        const int fan = ml.lv[q].fan, nc = ml.lv[q - 1].n;
+        for (int c = threadIdx.x; c < nc; c += kBlk) {
+            const double* __restrict__ cen = ml.lv[q].cen + (size_t)(c / fan) * 4;
+            if (q == 1) {
+                double* g = ml.lv[0].geo + (size_t)c * 12;
+                const int v = D.b2v[c];
+                if (v < 0) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++) g[k] = 0.;
+                } else {
+                    const Pose P = load_pose(pose, v);
+                    const M33 R = qrot(P.q);
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) g[r * 3 + k] = R.m[k * 3 + r];       // R^T
+                    g[9] = P.t.x - cen[0]; g[10] = P.t.y - cen[1]; g[11] = P.t.z - cen[2];
+                }
+            } else {
+                const double* cc = ml.lv[q - 1].cen + (size_t)c * 4;
+                double* g = ml.lv[q - 1].geo + (size_t)c * 3;
+                g[0] = cc[0] - cen[0]; g[1] = cc[1] - cen[1]; g[2] = cc[2] - cen[2];
+            }
+        }
+        __syncthreads();
     }
 }
 __global__ __launch_bounds__(kBlk) void ml_geometry_kernel(PgoDev D, const MlDev* __restrict__ mlp, const double* __restrict__ pose, int l)
