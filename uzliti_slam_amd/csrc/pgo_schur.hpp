@@ -14,6 +14,10 @@
 //       S_L -= C_m W_m;  g_L -= C_m u_m;  C_{m+1} = -C_m T_m;  D'_{m+1} = H_{m+1,m+1} + lambda I - E_m^T T_m;  g'_{m+1} = b_{m+1} - E_m^T u_m
 //   after vk:  S_R = -E_k^T T_k,  g_R = -E_k^T u_k,  F = C_{k+1} = fill block H'_{s0,s1}
 //   back-substitution, m = k..1:   x_m = u_m - W_m x_{s0} - T_m x_{next}
+// Round 4: a run is eliminated from BOTH ends at once (two waves per run): the sweep above over v1 .. v(j-1), its mirror image (s1 in the
+// role of s0, E'_m = E_(m-1)^T) over vk .. v(j+1), then the middle vertex vj, which couples to s0 through C_L and to s1 through C_R:
+//       W^L = Dinv C_L^T;  W^R = Dinv C_R^T;  S_L -= C_L W^L;  S_R -= C_R W^R;  g_L -= C_L u;  g_R -= C_R u;  F = -C_L W^R
+//   and x_j = u_j - W^L x_{s0} - W^R x_{s1} first, then both halves outwards.  Half the chain of dependent steps; the same Schur complement.
 //
 // Numbering of the reduced system (round 4).  Small systems keep the separators in row (= trajectory) order.  From kSchurStrongMin
 // separators on they can be numbered by STRONG AGGREGATES: the multilevel preconditioner gives every aggregate of 8 consecutive rows the six

@@ -1,12 +1,13 @@
 // pgo_schur_kernels.hip — Schur reduction of chain interiors: host-side plan + the three kernels (pgo_schur.hpp has the recurrences).
 //
-//   schur_eliminate_kernel : one wave per run; forward block-tridiagonal elimination of (H + lambda I) along the run.  Lane (r, c) of
-//                            the first 36 owns element (r, c) of every 6x6 block; operands of a product are staged in LDS (broadcast
-//                            reads).  Writes u | W | T per eliminated vertex and S_L | g_L | S_R | g_R | F per run.
+//   schur_eliminate_kernel : two waves per run, block-tridiagonal elimination of (H + lambda I) from both ends of the run towards its middle
+//                            vertex.  Lane (r, c) of a wave's first 36 owns element (r, c) of every 6x6 block; operands of a product are
+//                            staged in LDS (broadcast reads); the 6x6 inverses by the 36 lanes together.  Writes u | W | T per eliminated
+//                            vertex and S_L | g_L | S_R | g_R | F per run.
 //   schur_assemble_kernel  : the reduced system: off-diagonal blocks (copies of the separator-separator blocks + the runs' fill
 //                            blocks), diagonal blocks and right-hand side (own + contributions of the incident runs, in run order:
 //                            a gather, no atomics, bit-reproducible).
-//   schur_backsub_kernel   : x of the separators copied to their full-system rows; one wave per run walks it backwards.
+//   schur_backsub_kernel   : x of the separators copied to their full-system rows; per run the middle vertex, then two waves outwards.
 // HBM-bound in principle (algorithmic bytes per eliminated vertex: 3 blocks of 288 B in, 78 doubles out and in again), latency-bound
 // in practice: a run is a chain of <= cap dependent 6x6 steps.
 #include <algorithm>
@@ -274,84 +275,154 @@ __device__ __forceinline__ double mv6(const double* __restrict__ A, const double
     return s;
 }
 
-// One wave per run.  LDS matrices are private to the wave; with a single-wave workgroup __syncthreads() orders its LDS traffic.
+// TWO waves per run, eliminating from BOTH ENDS towards the run's middle vertex (round 4: a run is a chain of dependent 6 x 6 steps of
+// ~3 us; one wave walking all of it took 67 us at 24 steps).  Wave 0 takes v_0 .. v_{j-1} with the recurrences of pgo_schur.hpp, wave 1
+// the mirror image from the other end (v_{k-1} .. v_{j+1}: "left separator" = s1, "next" = the vertex before; E'_q = E_{q-1}^T), then
+// wave 0 eliminates the middle vertex v_j, which by then couples to s0 through C_L and to s1 through C_R:
+//     Dinv = (H_jj + lambda I + what both halves left)^-1;  u = Dinv g';  W^L = Dinv C_L^T;  W^R = Dinv C_R^T
+//     S_L -= C_L W^L;  g_L -= C_L u;  S_R -= C_R W^R;  g_R -= C_R u;  F = -C_L W^R;      x_j = u - W^L x_s0 - W^R x_s1
+// Records: u | W | T per vertex - W multiplies the x of the half's own separator, T the x of the vertex eliminated after it (towards the
+// middle); the middle keeps W^L | W^R.  LDS matrices are private to a wave; the two waves' step counts differ by at most one and the
+// shorter one idles through the barriers of the longer.
+struct SchurWaveLds { double D[36], Di[36], C[36], E[36], T[36], W[36], g[6], u[6]; };
+// Di = D^-1 for the SPD 6 x 6 in L.D, by the wave's first 36 lanes TOGETHER: in-place Gauss-Jordan, lane (r, c) owns element (r, c), six
+// pivot steps through LDS, then the mean with the transpose (the inverse of a symmetric matrix, symmetric to the last bit like the
+// Cholesky-based routine's).  Every lane used to invert the same matrix on its own (spd_inverse6_rs: ~600 flops x 64 lanes): with 1285
+// runs in flight that made the elimination a throughput problem - half the chain length per wave changed nothing.  Called by all lanes
+// of the workgroup (`on` = this wave has a matrix): its barriers are workgroup barriers.
+__device__ __forceinline__ void schur_inverse6_coop(SchurWaveLds& L, bool on, bool act, int lane, int r, int c)
+{
+    double a = (on && act) ? L.D[lane] : 0.;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (on && act) L.Di[lane] = a;
+        __syncthreads();
+        if (on && act) {
+            const double p = 1. / L.Di[k * 6 + k], rk = L.Di[r * 6 + k], kc = L.Di[k * 6 + c];
+            a = (r == k) ? ((c == k) ? p : kc * p) : ((c == k) ? -rk * p : fma(-rk * p, kc, a));
+        }
+        __syncthreads();
+    }
+    if (on && act) L.Di[lane] = a;
+    __syncthreads();
+    if (on && act) a = 0.5 * (a + L.Di[c * 6 + r]);
+    __syncthreads();
+    if (on && act) L.Di[lane] = a;
+}
 __device__ __forceinline__ void schur_eliminate_kernel_body(PgoDev D, SchurDev S)
 {
-    __shared__ double sD[36], sDi[36], sC[36], sE[36], sT[36], sW[36], sg[6], su[6];
+    __shared__ SchurWaveLds sw[2];
+    __shared__ double xch[2][36 + 36 + 6 + 36 + 6];          // per half, for the middle step: C | dupd | gupd | acc S | acc g
     const int run = blockIdx.x;
     if (run >= S.n_runs) return;
-    const int lane = threadIdx.x, r = lane / 6, c = lane % 6;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane / 6, c = lane % 6;
     const bool act = lane < 36, vec = lane < 6;
+    SchurWaveLds& L = sw[wv];
     const double lambda = D.scal[3];
-    const int p0 = S.run_ptr[run], p1 = S.run_ptr[run + 1];
-    const bool hasL = S.endL[run] >= 0;
-    const bool hasR = S.endR[run] >= 0;
-    double dupd = 0., gupd = 0.;              // D'_m - (H_mm + lambda I), g'_m - b_m: what the eliminated predecessor left
-    double accSL = 0., accgL = 0., cval = 0.;
-    // (sharded solve: the chain blocks come summed over the ranks - schur_gather_kernel + one all-reduce per linearisation)
-    const double* __restrict__ cblk = S.runblk ? S.runblk + (size_t)(S.n_int + run) * 36 : D.blk + (size_t)(hasL ? S.slotP[p0] : 0) * 36;
-    if (hasL && act) cval = cblk[c * 6 + r];                                      // C_1 = H_{s0,v1} = H_{v1,s0}^T
-    // A run is a chain of <= cap dependent steps, each a handful of round trips if it fetches its own operands: the rows and slots of the
-    // whole run are fetched once (lane q: step q; runs are <= 64 long, schur_plan), and every step's blocks one step ahead.
-    const int len = p1 - p0;
+    const int p0 = S.run_ptr[run], p1 = S.run_ptr[run + 1], len = p1 - p0;
+    const bool hasL = S.endL[run] >= 0, hasR = S.endR[run] >= 0;
+    const int j = len / 2;                                    // the middle vertex; wave 0: q = 0 .. j - 1, wave 1: q = len - 1 .. j + 1
+    const int my_steps = wv == 0 ? j : len - 1 - j, steps = max(j, len - 1 - j);
+    const bool has_sep = wv == 0 ? hasL : hasR;               // this half's own separator exists
+    // the rows and slots of the whole run once (lane q: vertex q; runs are <= 64 long, schur_plan)
     const int vq = lane < len ? S.run_rows[p0 + lane] : 0, sq = lane < len ? S.slotN[p0 + lane] : -1;
-    auto fetch = [&](int q, double& hd, double& ev, double& bv) {
-        const int v = __shfl(vq, q), sn = __shfl(sq, q);
-        const bool hasN = sn >= 0 && (q + 1 < len || hasR);
+    auto eblk = [&](int q, int idx) -> double {               // element idx of E_q = H_{v_q, next} (sharded solve: summed over the ranks)
+        return S.runblk ? S.runblk[(size_t)(p0 + q) * 36 + idx] : D.blk[(size_t)__shfl(sq, q) * 36 + idx];
+    };
+    // coupling of this half's first vertex to its own separator: C = H_{s0,v_0} = (H_{v_0,s0})^T, or H_{s1,v_{k-1}} = E_{k-1}^T
+    double cval = 0.;
+    if (wv == 0) {
+        const double* __restrict__ cblk = S.runblk ? S.runblk + (size_t)(S.n_int + run) * 36 : D.blk + (size_t)(hasL ? S.slotP[p0] : 0) * 36;
+        if (hasL && act) cval = cblk[c * 6 + r];
+    } else if (hasR) {
+        const double e = eblk(len - 1, act ? c * 6 + r : 0);
+        if (act) cval = e;
+    }
+    double dupd = 0., gupd = 0., accS = 0., accg = 0.;
+    auto fetch = [&](int it, double& hd, double& ev, double& bv) {          // operands of this half's step `it`
+        const int q = wv == 0 ? it : len - 1 - it;
+        const int v = __shfl(vq, q);
         hd = act ? D.hdiag[(size_t)v * 36 + lane] : 0.;
-        ev = (act && hasN) ? (S.runblk ? S.runblk[(size_t)(p0 + q) * 36 + lane] : D.blk[(size_t)sn * 36 + lane]) : 0.;
+        const double e = wv == 0 ? eblk(q, act ? lane : 0) : eblk(q - 1, act ? c * 6 + r : 0);      // wave 1: E'_q = E_{q-1}^T
+        ev = act ? e : 0.;
         bv = vec ? D.b[(size_t)v * 6 + lane] : 0.;
     };
-    double hd, ev, bv;
-    fetch(0, hd, ev, bv);
-    for (int p = p0; p < p1; p++) {
-        const int sn = __shfl(sq, p - p0);
-        const bool hasN = sn >= 0 && (p + 1 < p1 || hasR);
-        if (act) {
-            sD[lane] = hd + ((r == c) ? lambda : 0.) + dupd;
-            sE[lane] = ev;
-            sC[lane] = cval;
+    double hd = 0., ev = 0., bv = 0.;
+    if (my_steps > 0) fetch(0, hd, ev, bv);
+    for (int it = 0; it < steps; it++) {
+        const bool on = it < my_steps;                       // (wave-uniform)
+        const int q = wv == 0 ? it : len - 1 - it;
+        if (on) {
+            if (act) { L.D[lane] = hd + ((r == c) ? lambda : 0.) + dupd; L.E[lane] = ev; L.C[lane] = cval; }
+            if (vec) L.g[lane] = bv + gupd;
+            if (it + 1 < my_steps) fetch(it + 1, hd, ev, bv);
         }
-        if (vec) sg[lane] = bv + gupd;
-        if (p + 1 < p1) fetch(p + 1 - p0, hd, ev, bv);
         __syncthreads();
-        // Dinv: every lane inverts the same 36 numbers (Cholesky, registers only) and keeps its own element
-        double A[36], Di[36];
-#pragma unroll
-        for (int i = 0; i < 36; i++) A[i] = sD[i];
-        spd_inverse6_rs(A, Di);
-        double mine = 0.;
-#pragma unroll
-        for (int i = 0; i < 36; i++) mine = (i == lane) ? Di[i] : mine;
-        if (act) sDi[lane] = mine;
+        schur_inverse6_coop(L, on, act, lane, r, c);
         __syncthreads();
-        double tval = 0., wval = 0., uval = 0.;
-        if (act) {
-            if (hasN) tval = mm6<false, false>(sDi, sE, r, c);        // T = Dinv E
-            if (hasL) wval = mm6<false, true>(sDi, sC, r, c);         // W = Dinv C^T
-            sT[lane] = tval; sW[lane] = wval;
+        if (on) {
+            double tval = 0., wval = 0., uval = 0.;
+            if (act) {
+                tval = mm6<false, false>(L.Di, L.E, r, c);                    // T = Dinv E
+                if (has_sep) wval = mm6<false, true>(L.Di, L.C, r, c);        // W = Dinv C^T
+                L.T[lane] = tval; L.W[lane] = wval;
+            }
+            if (vec) { uval = mv6<false>(L.Di, L.g, lane); L.u[lane] = uval; }
+            double* __restrict__ out = S.elim + (size_t)(p0 + q) * kSchurElim;
+            if (vec) out[lane] = uval;
+            if (act) { out[6 + lane] = wval; out[42 + lane] = tval; }
         }
-        if (vec) { uval = mv6<false>(sDi, sg, lane); su[lane] = uval; }
-        double* __restrict__ out = S.elim + (size_t)p * kSchurElim;
-        if (vec) out[lane] = uval;
-        if (act) { out[6 + lane] = wval; out[42 + lane] = tval; }
         __syncthreads();
-        dupd = 0.; gupd = 0.;
-        if (act) {
-            if (hasL) accSL -= mm6<false, false>(sC, sW, r, c);      // S_L -= C W
-            if (hasL && hasN) cval = -mm6<false, false>(sC, sT, r, c);   // C' = -C T
-            else cval = 0.;
-            if (hasN) dupd = -mm6<true, false>(sE, sT, r, c);         // -E^T T
-        }
-        if (vec) {
-            if (hasL) accgL -= mv6<false>(sC, su, lane);
-            if (hasN) gupd = -mv6<true>(sE, su, lane);
+        if (on) {
+            if (act) {
+                if (has_sep) { accS -= mm6<false, false>(L.C, L.W, r, c); cval = -mm6<false, false>(L.C, L.T, r, c); }      // S -= C W;  C' = -C T
+                dupd = -mm6<true, false>(L.E, L.T, r, c);                      // -E^T T
+            }
+            if (vec) {
+                if (has_sep) accg -= mv6<false>(L.C, L.u, lane);
+                gupd = -mv6<true>(L.E, L.u, lane);
+            }
         }
         __syncthreads();                                               // LDS is rewritten at the top of the next step
     }
-    double* __restrict__ ro = S.runout + (size_t)run * kSchurRunOut;
-    if (act) { ro[lane] = accSL; ro[42 + lane] = hasR ? dupd : 0.; ro[84 + lane] = (hasL && hasR) ? cval : 0.; }
-    if (vec) { ro[36 + lane] = accgL; ro[78 + lane] = hasR ? gupd : 0.; }
+    // ---- the middle vertex: both halves hand over what they left on it
+    if (act) { xch[wv][lane] = cval; xch[wv][36 + lane] = dupd; xch[wv][78 + lane] = accS; }
+    if (vec) { xch[wv][72 + lane] = gupd; xch[wv][114 + lane] = accg; }
+    __syncthreads();
+    if (wv != 0) return;
+    {
+        const int v = __shfl(vq, j);
+        if (act) {
+            L.D[lane] = D.hdiag[(size_t)v * 36 + lane] + ((r == c) ? lambda : 0.) + (xch[0][36 + lane] + xch[1][36 + lane]);
+            L.C[lane] = xch[0][lane];                                   // C_L
+            L.E[lane] = xch[1][lane];                                   // C_R
+        }
+        if (vec) L.g[lane] = D.b[(size_t)v * 6 + lane] + (xch[0][72 + lane] + xch[1][72 + lane]);
+        __syncthreads();                                               // (one wave left in the workgroup: orders its LDS traffic)
+        schur_inverse6_coop(L, true, act, lane, r, c);
+        __syncthreads();
+        double wl = 0., wr = 0., uval = 0.;
+        if (act) {
+            if (hasL) wl = mm6<false, true>(L.Di, L.C, r, c);           // W^L = Dinv C_L^T
+            if (hasR) wr = mm6<false, true>(L.Di, L.E, r, c);           // W^R = Dinv C_R^T
+            L.W[lane] = wl; L.T[lane] = wr;
+        }
+        if (vec) { uval = mv6<false>(L.Di, L.g, lane); L.u[lane] = uval; }
+        double* __restrict__ out = S.elim + (size_t)(p0 + j) * kSchurElim;
+        if (vec) out[lane] = uval;
+        if (act) { out[6 + lane] = wl; out[42 + lane] = wr; }
+        __syncthreads();
+        double* __restrict__ ro = S.runout + (size_t)run * kSchurRunOut;
+        if (act) {
+            ro[lane] = hasL ? xch[0][78 + lane] - mm6<false, false>(L.C, L.W, r, c) : 0.;                 // S_L
+            ro[42 + lane] = hasR ? xch[1][78 + lane] - mm6<false, false>(L.E, L.T, r, c) : 0.;            // S_R
+            ro[84 + lane] = (hasL && hasR) ? -mm6<false, false>(L.C, L.T, r, c) : 0.;                     // F = -C_L W^R
+        }
+        if (vec) {
+            ro[36 + lane] = hasL ? xch[0][114 + lane] - mv6<false>(L.C, L.u, lane) : 0.;                  // g_L
+            ro[78 + lane] = hasR ? xch[1][114 + lane] - mv6<false>(L.E, L.u, lane) : 0.;                  // g_R
+        }
+    }
 }
 
 // Reduced system: item t / 36 = off-diagonal block (copy or fill), then diagonal block, then (6 lanes) right-hand side
@@ -396,41 +467,52 @@ __device__ __forceinline__ void schur_assemble_kernel_body(PgoDev D, PgoDev R, S
 // blocks [0, n_runs): one wave per run, backwards; blocks behind: x of the separators to their full-system rows
 __device__ __forceinline__ void schur_backsub_kernel_body(PgoDev D, PgoDev R, SchurDev S)
 {
-    __shared__ double sx0[6], sxn[6], sp[36];
-    const int lane = threadIdx.x;
+    __shared__ double sxs[2][6], sxn[2][6], sp[2][36];          // per wave: x of its own separator, x of the vertex solved last, products
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if ((int)blockIdx.x >= S.n_runs) {
         const int t = ((int)blockIdx.x - S.n_runs) * 64 + lane;
-        if (t < S.nbr * 6 && S.sep_rows[t / 6] >= 0) D.x[(size_t)S.sep_rows[t / 6] * 6 + t % 6] = R.x[t];
+        if (wv == 0 && t < S.nbr * 6 && S.sep_rows[t / 6] >= 0) D.x[(size_t)S.sep_rows[t / 6] * 6 + t % 6] = R.x[t];
         return;
     }
     const int run = blockIdx.x, c = lane % 6;
     const bool act = lane < 36, vec = lane < 6;
-    const int p0 = S.run_ptr[run], p1 = S.run_ptr[run + 1];
+    const int p0 = S.run_ptr[run], p1 = S.run_ptr[run + 1], len = p1 - p0, j = len / 2;
     const int eL = S.endL[run], eR = S.endR[run];
-    if (vec) {
-        sx0[lane] = eL >= 0 ? R.x[(size_t)eL * 6 + lane] : 0.;
-        sxn[lane] = eR >= 0 ? R.x[(size_t)eR * 6 + lane] : 0.;
-    }
-    // the next step's operands are fetched before this step's chain link: they do not depend on it
-    const double* __restrict__ e = S.elim + (size_t)(p1 - 1) * kSchurElim;
-    double w = act ? e[6 + lane] : 0., t = act ? e[42 + lane] : 0., u = vec ? e[lane] : 0.;
+    const int my_steps = wv == 0 ? j : len - 1 - j, steps = max(j, len - 1 - j);
+    if (vec) { const int es = wv == 0 ? eL : eR; sxs[wv][lane] = es >= 0 ? R.x[(size_t)es * 6 + lane] : 0.; }
+    // the operands of this half's first vertex are fetched before the middle's chain link: they do not depend on it
+    auto rec = [&](int it) { return S.elim + (size_t)(p0 + (wv == 0 ? j - 1 - it : j + 1 + it)) * kSchurElim; };
+    double w = 0., t = 0., u = 0.;
+    if (my_steps > 0) { const double* __restrict__ e = rec(0); if (act) { w = e[6 + lane]; t = e[42 + lane]; } if (vec) u = e[lane]; }
     __syncthreads();
-    for (int p = p1 - 1; p >= p0; p--) {
+    if (wv == 0) {                                            // the middle vertex: x_j = u - W^L x_s0 - W^R x_s1
+        const double* __restrict__ e = S.elim + (size_t)(p0 + j) * kSchurElim;
+        if (act) sp[0][lane] = fma(e[6 + lane], sxs[0][c], e[42 + lane] * sxs[1][c]);
+    }
+    __syncthreads();
+    if (wv == 0 && vec) {
+        const double* __restrict__ q = sp[0] + lane * 6;
+        const double x = S.elim[(size_t)(p0 + j) * kSchurElim + lane] - (((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]));
+        D.x[(size_t)S.run_rows[p0 + j] * 6 + lane] = x;
+        sxn[0][lane] = x; sxn[1][lane] = x;
+    }
+    __syncthreads();
+    for (int it = 0; it < steps; it++) {                      // outwards from the middle, both halves at once
+        const bool on = it < my_steps;
         double wn = 0., tn = 0., un = 0.;
-        if (p > p0) {
-            const double* __restrict__ en = S.elim + (size_t)(p - 1) * kSchurElim;
+        if (on && it + 1 < my_steps) {
+            const double* __restrict__ en = rec(it + 1);
             if (act) { wn = en[6 + lane]; tn = en[42 + lane]; }
             if (vec) un = en[lane];
         }
-        if (act) sp[lane] = fma(w, sx0[c], t * sxn[c]);
+        if (on && act) sp[wv][lane] = fma(w, sxs[wv][c], t * sxn[wv][c]);
         __syncthreads();
-        double x = 0.;
-        if (vec) {
-            const double* __restrict__ q = sp + lane * 6;
-            x = u - (((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]));
-            D.x[(size_t)S.run_rows[p] * 6 + lane] = x;
+        if (on && vec) {
+            const double* __restrict__ q = sp[wv] + lane * 6;
+            const double x = u - (((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]));
+            D.x[(size_t)S.run_rows[p0 + (wv == 0 ? j - 1 - it : j + 1 + it)] * 6 + lane] = x;
+            sxn[wv][lane] = x;
         }
-        if (vec) sxn[lane] = x;                                         // (read by all lanes before the barrier above, next read behind the one below)
         __syncthreads();
         w = wn; t = tn; u = un;
     }
@@ -447,13 +529,13 @@ __global__ __launch_bounds__(kBlk) void schur_gather_kernel(PgoDev D, SchurDev S
     else { const int run = (int)(item - S.n_int); slot = S.endL[run] >= 0 ? S.slotP[S.run_ptr[run]] : -1; }
     S.runblk[item * 36 + k] = slot >= 0 ? D.blk[(size_t)slot * 36 + k] : 0.;
 }
-__global__ __launch_bounds__(64) void schur_eliminate_kernel(PgoDev D, SchurDev S) { schur_eliminate_kernel_body(D, S); }
+__global__ __launch_bounds__(128) void schur_eliminate_kernel(PgoDev D, SchurDev S) { schur_eliminate_kernel_body(D, S); }
 __global__ __launch_bounds__(kBlk) void schur_assemble_kernel(PgoDev D, PgoDev R, SchurDev S) { schur_assemble_kernel_body(D, R, S); }
-__global__ __launch_bounds__(64) void schur_backsub_kernel(PgoDev D, PgoDev R, SchurDev S) { schur_backsub_kernel_body(D, R, S); }
+__global__ __launch_bounds__(128) void schur_backsub_kernel(PgoDev D, PgoDev R, SchurDev S) { schur_backsub_kernel_body(D, R, S); }
 
 // slot twins of the device-resident LM loop (pgo_types.hpp): graph = blockIdx.z; the reduction runs in the pass lm_head_kernel stamped
 // (a new lambda), the back-substitution with the evaluation of a trial
-__global__ __launch_bounds__(64) void schur_eliminate_lm_kernel(const LmSlot* __restrict__ slots)
+__global__ __launch_bounds__(128) void schur_eliminate_lm_kernel(const LmSlot* __restrict__ slots)
 {
     const LmSlot& S = slots[blockIdx.z];
     if (!S.red || S.lm->schur_pass != S.lm->pass) return;
@@ -465,7 +547,7 @@ __global__ __launch_bounds__(kBlk) void schur_assemble_lm_kernel(const LmSlot* _
     if (!S.red || S.lm->schur_pass != S.lm->pass) return;
     schur_assemble_kernel_body(S.D, S.Dp, S.SD);
 }
-__global__ __launch_bounds__(64) void schur_backsub_lm_kernel(const LmSlot* __restrict__ slots)
+__global__ __launch_bounds__(128) void schur_backsub_lm_kernel(const LmSlot* __restrict__ slots)
 {
     const LmSlot& S = slots[blockIdx.z];
     const LmDev* lm = S.lm;
@@ -529,7 +611,7 @@ void k_schur_gather(const PgoDev& D, const SchurDev& S, hipStream_t s)
 }
 void k_schur_eliminate(const PgoDev& D, const SchurDev& S, hipStream_t s)
 {
-    if (S.n_runs > 0) hipLaunchKernelGGL(schur_eliminate_kernel, dim3(S.n_runs), dim3(64), 0, s, D, S);
+    if (S.n_runs > 0) hipLaunchKernelGGL(schur_eliminate_kernel, dim3(S.n_runs), dim3(128), 0, s, D, S);
 }
 void k_schur_assemble(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s)
 {
@@ -539,17 +621,17 @@ void k_schur_assemble(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipSt
 void k_schur_backsub(const PgoDev& D, const PgoDev& R, const SchurDev& S, hipStream_t s)
 {
     const int g = S.n_runs + (S.nbr * 6 + 63) / 64;
-    if (g > 0) hipLaunchKernelGGL(schur_backsub_kernel, dim3(g), dim3(64), 0, s, D, R, S);
+    if (g > 0) hipLaunchKernelGGL(schur_backsub_kernel, dim3(g), dim3(128), 0, s, D, R, S);
 }
 // grids: the largest over the slots of a pass (a twin leaves at once past its own graph's extent - the bodies check run / item counts)
 void kl_schur_reduce(const LmSlot* sl, int nslots, int max_runs, long max_items, hipStream_t s)
 {
-    if (max_runs > 0) hipLaunchKernelGGL(schur_eliminate_lm_kernel, dim3(max_runs, 1, nslots), dim3(64), 0, s, sl);
+    if (max_runs > 0) hipLaunchKernelGGL(schur_eliminate_lm_kernel, dim3(max_runs, 1, nslots), dim3(128), 0, s, sl);
     if (max_items > 0) hipLaunchKernelGGL(schur_assemble_lm_kernel, dim3((unsigned)((max_items + kBlk - 1) / kBlk), 1, nslots), dim3(kBlk), 0, s, sl);
 }
 void kl_schur_backsub(const LmSlot* sl, int nslots, int max_grid, hipStream_t s)
 {
-    if (max_grid > 0) hipLaunchKernelGGL(schur_backsub_lm_kernel, dim3(max_grid, 1, nslots), dim3(64), 0, s, sl);
+    if (max_grid > 0) hipLaunchKernelGGL(schur_backsub_lm_kernel, dim3(max_grid, 1, nslots), dim3(128), 0, s, sl);
 }
 
 }  // namespace uzl
