@@ -741,11 +741,9 @@ void build_structure(uzl_pgo* h)
     Rd.on = false; Rd.n_int = 0; Rd.n_runs = 0; Rd.longest_run = 0; Rd.strong = false; Rd.strong_blocks = false; Rd.n_sep = 0;
     PgoDev& Dp = h->Dp;
     static const int schur_diag = diag_int("UZL_SCHUR", 1);                  // A/B switches (diagnostic build)
-    // longest run: a run is a chain of dependent 6 x 6 steps (3 us each) in front of every trial's solve - 24 for large graphs, where the
-    // extra separators of shorter runs cost more PCG work than the chain saves, 12 for small ones (600 / 630: 5.5 -> 5.4 ms, 1500 / 1600:
-    // 6.3 -> 5.8, 2500 / 2600: 6.9 -> 6.3; config 5 over its whole run 1.63 -> 1.68 s with 12 everywhere)
-    static const int schur_cap_env = diag_int("UZL_SCHUR_CAP", 0);
-    const int schur_cap = schur_cap_env > 0 ? schur_cap_env : (nb <= 3000 ? 12 : 24);
+    // longest run: 24.  (Twelve for small graphs paid 3 - 8 % while one wave walked a whole run; with a run eliminated from both ends the
+    // chain is twelve steps anyway, and stars of 20-vertex arms keep being eliminated completely: tests/test_schur_gpu.py.)
+    static const int schur_cap = diag_int("UZL_SCHUR_CAP", 24);
     static const int schur_min_pct = diag_int("UZL_SCHUR_MIN_PCT", 33);
     const bool may_shard = h->allreduce != nullptr || h->rccl_comm != nullptr;
     std::vector<int32_t> rrow_ptr, rcol;
