@@ -1089,7 +1089,10 @@ void launch_knn2(const uint32_t* arena, const Combo* combos, int n_combos, int m
         if (has16) hipLaunchKernelGGL((knn2_lds_kernel<16, 1>), grid, dim3(kBlock), 0, s, arena, combos, knn);
     } else {
         // matrix-core path: 256 (W = 8) / 128 (W = 16) queries per workgroup
-        if (has8) hipLaunchKernelGGL((knn2_mfma_kernel<8, 2>), dim3((max_nq + 255) / 256, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
+        static const int ut8 = diag_int("UZL_KNN2_UT", 2);                     // A/B switch: 32-query tiles per wave (W = 8)
+        if (has8 && ut8 == 4) hipLaunchKernelGGL((knn2_mfma_kernel<8, 4>), dim3((max_nq + 511) / 512, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
+        else if (has8 && ut8 == 3) hipLaunchKernelGGL((knn2_mfma_kernel<8, 3>), dim3((max_nq + 383) / 384, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
+        else if (has8) hipLaunchKernelGGL((knn2_mfma_kernel<8, 2>), dim3((max_nq + 255) / 256, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
         if (has16) hipLaunchKernelGGL((knn2_mfma_kernel<16, 1>), dim3((max_nq + 127) / 128, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
     }
     if (has_generic) hipLaunchKernelGGL(knn2_generic_kernel, grid, dim3(kBlock), 0, s, arena, combos, knn);
