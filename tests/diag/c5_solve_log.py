@@ -9,7 +9,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from uzliti_slam_amd import capi   # noqa: E402
 
-z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "c5_last.npz"))
+_here = os.path.dirname(os.path.abspath(__file__))
+_cands = [os.path.join(_here, "data", "c5_last.npz"), os.path.join(os.path.dirname(os.path.dirname(_here)), "gpurun_out", "c5_last.npz")]
+_found = [f for f in _cands if os.path.exists(f)]
+if not _found:
+    sys.exit("no c5_last.npz: run tests/diag/c5_last.py on a GPU box first (it writes gpurun_out/c5_last.npz; 4 MB, not tracked)")
+z = np.load(_found[0])
 e = {k[2:]: z[k] for k in z.files if k.startswith("e_")}
 p = capi.Pgo(**({"lm_loop": int(os.environ["LM_LOOP"])} if "LM_LOOP" in os.environ else {}))
 p.add_graph(z["poses"], z["fixed"], e); p.optimize(20)
