@@ -40,8 +40,6 @@ int g_pcg_update(int nb);
 constexpr int kGeoAllMaxHost = 1024;                  // (= kGeoAllMax of pgo_ml_kernels.hip)
 void k_ml_geometry(const PgoDev& D, const MlDev* ml, const double* pose, int l, int n_l, hipStream_t s);
 void k_ml_galerkin(const PgoDev& D, const MlDev* ml, int f, int n_chunks, hipStream_t s);
-void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s);
-void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s);
 void k_ml_sibling(const PgoDev& D, const MlDev* ml, int total_aggs, hipStream_t s);
 void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s);
 void k_ml_mult_level(const PgoDev& D, const MlDev* ml, int lev, int n1, int n2, hipStream_t s);

@@ -208,81 +208,12 @@ __global__ __launch_bounds__(kBlk) void ml_geometry_kernel(PgoDev D, const MlDev
     ml_geometry_kernel_body(D, mlp, pose, l);
 }
 
-// ---- Galerkin transform of level f: every off-diagonal block and every diagonal block of A_f (and of M_f)
-//      is mapped through its two prolongation blocks and dropped into its sorted contribution position
-__device__ __forceinline__ void ml_transform_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int f)
-{
-    const MlDev& ml = *mlp;
-    const MlLevel& L = ml.lv[f];
-    const int t = blockIdx.x * kBlk + threadIdx.x;
-    const int ns = L.nslots, n = L.n;
-    const double* geo = L.geo;
-    if (t < ns) {
-        const int c = (f == 0) ? D.col[t] : L.col[t];
-        const int pos = L.tpos[t];
-        if (c >= 0 && pos >= 0) {
-            const int a = L.srow[t];
-            P3 PL, PR;
-            make_P(f, geo, a, PL);
-            make_P(f, geo, c, PR);
-            const double* F = ((f == 0) ? D.blk : L.blk) + (size_t)t * 36;
-            galerkin(PL, F, PR, ml.tmp + (size_t)pos * 36);
-        }
-    } else if (t < ns + n) {
-        const int i = t - ns;
-        if (f == 0 && !D.diag_owner) {          // sharded solve: level-1 arrays are summed over ranks afterwards
-            for (int k = 0; k < 36; k++) { ml.tmpG[(size_t)i * 36 + k] = 0.; ml.tmpM[(size_t)i * 36 + k] = 0.; }
-            return;
-        }
-        P3 P;
-        make_P(f, geo, i, P);
-        const double* G = ((f == 0) ? D.hdiag : L.G) + (size_t)i * 36;
-        galerkin(P, G, P, ml.tmpG + (size_t)i * 36);
-        if (f == 0) {
-            const double I6[36] = {1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1};
-            galerkin(P, I6, P, ml.tmpM + (size_t)i * 36);
-        } else {
-            galerkin(P, L.M + (size_t)i * 36, P, ml.tmpM + (size_t)i * 36);
-        }
-    }
-}
-__global__ __launch_bounds__(kBlk) void ml_transform_kernel(PgoDev D, const MlDev* __restrict__ mlp, int f)
-{
-    ml_transform_kernel_body(D, mlp, f);
-}
-
-// ---- ordered reduction of the contributions into A_l (off-diagonal blocks), G_l and M_l
-__device__ __forceinline__ void ml_reduce_kernel_body(const MlDev* __restrict__ mlp, int l)
-{
-    const MlDev& ml = *mlp;
-    const MlLevel& L = ml.lv[l];
-    const int nc = ml.lv[l - 1].n;
-    const int t = blockIdx.x * kBlk + threadIdx.x;
-    const int blk_id = t / 36, k = t % 36;
-    if (blk_id < L.nslots) {
-        double s = 0.;
-        for (int q = L.off_ptr[blk_id]; q < L.off_ptr[blk_id + 1]; q++) s += ml.tmp[(size_t)q * 36 + k];
-        L.blk[(size_t)blk_id * 36 + k] = s;
-    } else if (blk_id < L.nslots + L.n) {
-        const int A = blk_id - L.nslots;
-        double s = 0., m = 0.;
-        for (int q = L.diag_ptr[A]; q < L.diag_ptr[A + 1]; q++) s += ml.tmp[(size_t)(L.n_off_contrib + q) * 36 + k];
-        const int c0 = A * L.fan, c1 = (c0 + L.fan < nc) ? c0 + L.fan : nc;
-        for (int c = c0; c < c1; c++) { s += ml.tmpG[(size_t)c * 36 + k]; m += ml.tmpM[(size_t)c * 36 + k]; }
-        L.G[(size_t)A * 36 + k] = s;
-        L.M[(size_t)A * 36 + k] = m;
-    }
-}
-__global__ __launch_bounds__(kBlk) void ml_reduce_kernel(const MlDev* __restrict__ mlp, int l)
-{
-    ml_reduce_kernel_body(mlp, l);
-}
-
 // ---- the same Galerkin product as ONE kernel per level: a GATHER.  The host cuts the coarse level's output blocks into chunks of
 //      consecutive blocks with <= kGalItems contributions (MlLevel::chunk / cslot, build_ml); a workgroup transforms its chunk's
-//      contributions into LDS (one lane each: the work of ml_transform_kernel) and sums them per output block in contribution order (the
-//      work of ml_reduce_kernel: the same sums in the same order, the same bits) - no contribution array in memory, one launch per level
-//      instead of two.  A block with more contributions than fit (the top of a dense hierarchy) is a chunk of its own, in passes.
+//      contributions into LDS (one lane each, through its two prolongation blocks) and sums them per output block in contribution
+//      order - the sums of rounds 1-3's transform + ordered-reduce pair in the same order, the same bits - with no contribution array in
+//      memory and one launch per level instead of two.  A block with more contributions than fit (the top of a dense hierarchy) is a
+//      chunk of its own, in passes.
 __device__ __forceinline__ void ml_galerkin_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int f)
 {
     __shared__ double sc[kGalItems * 36];
@@ -586,27 +517,8 @@ __global__ __launch_bounds__(kBlk) void ml_dense_level_kernel(const MlDev* __res
 //      A = A_1(lambda), P = P_2, Y_2 = the dense operator of level 2): the symmetric pre-smooth / coarse-correct /
 //      post-smooth cycle written as one matrix.  It costs ~0.25 GFLOP of 6x6 block products per rebuild and nothing per
 //      iteration (ml_cg_comp applies whatever Y_1 holds), and takes a third off the PCG iteration count compared with the
-//      additive S + P Y_2 P^T (numpy prototype: 41 -> 29 and 57 -> 38 on config 2).  One lane per 6x6 block throughout.
-__device__ __forceinline__ void pmat6(const double* d, double* P)           // P(d) = [[I, -[d]x], [0, I]] (row-major 6x6)
-{
-#pragma unroll
-    for (int i = 0; i < 36; i++) P[i] = (i % 7 == 0) ? 1. : 0.;
-    P[0 * 6 + 4] = d[2];  P[0 * 6 + 5] = -d[1];
-    P[1 * 6 + 3] = -d[2]; P[1 * 6 + 5] = d[0];
-    P[2 * 6 + 3] = d[1];  P[2 * 6 + 4] = -d[0];
-}
-__device__ __forceinline__ void mm6_acc(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, double* C, double sgn)
-{                                                                              // C += sgn * A(6x6, ld lda) * B(6x6, ld ldb)
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            double s = 0.;
-#pragma unroll
-            for (int k = 0; k < 6; k++) s += A[r * lda + k] * B[k * ldb + c];
-            C[r * 6 + c] += sgn * s;
-        }
-}
+//      additive S + P Y_2 P^T (numpy prototype: 41 -> 29 and 57 -> 38 on config 2).  ml_mult_pair_kernel forms the cycle's operands per pair of
+//      sibling groups, ml_mult_qy_kernel and ml_mult_qyqt_kernel add the coarse term.
 __device__ __forceinline__ void mr6_acc(const double* __restrict__ Arow, const double* __restrict__ B, int ldb, double* c6, double sgn)
 {                                                                              // c6 += sgn * Arow(1x6) * B(6x6, ld ldb)
 #pragma unroll
@@ -616,81 +528,6 @@ __device__ __forceinline__ void mr6_acc(const double* __restrict__ Arow, const d
         for (int k = 0; k < 6; k++) s += Arow[k] * B[k * ldb + c];
         c6[c] += sgn * s;
     }
-}
-// diagonal block D_i = G_i + lambda M_i of A_1
-__device__ __forceinline__ void diag6(const MlLevel& F, int i, double lambda, double* Dm)
-{
-#pragma unroll
-    for (int k = 0; k < 36; k++) Dm[k] = F.G[(size_t)i * 36 + k] + lambda * F.M[(size_t)i * 36 + k];
-}
-
-// AP[i][p] = sum_j A_ij P_j over the children j of level-2 aggregate p
-__device__ __forceinline__ void ml_mult_ap_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl, int blk = blockIdx.x)
-{
-    const MlDev& ml = *mlp;
-    const MlLevel& F = ml.lv[cl];
-    const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan;
-    const int t = blk * kBlk + threadIdx.x;
-    if (t >= n * np) return;
-    const int i = t / np, p = t % np;
-    const double lambda = D.scal[3];
-    double acc[36], Pm[36];
-#pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = 0.;
-    if (i / fan == p) {
-        double Dm[36];
-        diag6(F, i, lambda, Dm);
-        pmat6(F.geo + (size_t)i * 3, Pm);
-        mm6_acc(Dm, 6, Pm, 6, acc, 1.);
-    }
-    for (int s = ml.grp_beg[cl][t]; s < ml.grp_end[cl][t]; s++) {              // the slots of row i whose column is a child of p
-        pmat6(F.geo + (size_t)F.col[s] * 3, Pm);
-        mm6_acc(F.blk + (size_t)s * 36, 6, Pm, 6, acc, 1.);
-    }
-    double* o = ml.mAP + (size_t)t * 36;
-#pragma unroll
-    for (int k = 0; k < 36; k++) o[k] = acc[k];
-}
-__global__ __launch_bounds__(kBlk) void ml_mult_ap_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl)
-{
-    ml_mult_ap_kernel_body(D, mlp, cl);
-}
-
-// Q[i][p] = P_i [p == parent(i)] - sum_{j in siblings(i)} S_ij AP[j][p]          (one lane per block ROW: 6x the lanes)
-__device__ __forceinline__ void ml_mult_q_kernel_body(const MlDev* __restrict__ mlp, int cl, int blk = blockIdx.x)
-{
-    const MlDev& ml = *mlp;
-    const MlLevel& F = ml.lv[cl];
-    const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
-    const int tt = blk * kBlk + threadIdx.x;
-    if (tt >= n * np * 6) return;
-    const int t = tt / 6, r = tt % 6;
-    const int i = t / np, p = t % np, g = i / fan;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (g == p) {
-        double Pm[36];
-        pmat6(F.geo + (size_t)i * 3, Pm);
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            double v = 0.;
-#pragma unroll
-            for (int k = 0; k < 6; k++) v = (k == r) ? Pm[k * 6 + c] : v;
-            acc[c] = v;
-        }
-    }
-    const double* __restrict__ W = F.Winv + (size_t)g * m * m + (size_t)((i % fan) * 6 + r) * m;
-    for (int q = 0; q < fan; q++) {
-        const int j = g * fan + q;
-        if (j >= n) break;
-        mr6_acc(W + q * 6, ml.mAP + ((size_t)j * np + p) * 36, 6, acc, -1.);
-    }
-    double* o = ml.mQ + (size_t)t * 36 + r * 6;
-#pragma unroll
-    for (int c = 0; c < 6; c++) o[c] = acc[c];
-}
-__global__ __launch_bounds__(kBlk) void ml_mult_q_kernel(const MlDev* __restrict__ mlp, int cl)
-{
-    ml_mult_q_kernel_body(mlp, cl);
 }
 
 // QY[i][p] = sum_p' Q[i][p'] Y_2[p'][p]                                           (one lane per block row)
@@ -714,69 +551,6 @@ __global__ __launch_bounds__(kBlk) void ml_mult_qy_kernel(const MlDev* __restric
     ml_mult_qy_kernel_body(mlp, cl);
 }
 
-// AS[j][i'] = sum_{j' in siblings(i')} A_jj' S_j'i'
-__device__ __forceinline__ void ml_mult_as_kernel_body(PgoDev D, const MlDev* __restrict__ mlp, int cl, int blk = blockIdx.x)
-{
-    const MlDev& ml = *mlp;
-    const MlLevel& F = ml.lv[cl];
-    const int n = F.n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
-    const int t = blk * kBlk + threadIdx.x;
-    if (t >= n * n) return;
-    const int j = t / n, ip = t % n, gp = ip / fan;
-    const double lambda = D.scal[3];
-    const double* __restrict__ W = F.Winv + (size_t)gp * m * m + (ip % fan) * 6;       // column block of i' in its group's inverse
-    double acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = 0.;
-    if (j / fan == gp) {
-        double Dm[36];
-        diag6(F, j, lambda, Dm);
-        mm6_acc(Dm, 6, W + (size_t)((j % fan) * 6) * m, m, acc, 1.);
-    }
-    const int np = ml.lv[cl + 1].n;
-    for (int s = ml.grp_beg[cl][(size_t)j * np + gp]; s < ml.grp_end[cl][(size_t)j * np + gp]; s++)
-        mm6_acc(F.blk + (size_t)s * 36, 6, W + (size_t)((F.col[s] % fan) * 6) * m, m, acc, 1.);
-    double* o = ml.mAS + (size_t)t * 36;
-#pragma unroll
-    for (int k = 0; k < 36; k++) o[k] = acc[k];
-}
-__global__ __launch_bounds__(kBlk) void ml_mult_as_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl)
-{
-    ml_mult_as_kernel_body(D, mlp, cl);
-}
-
-// Y_1[i][i'] = 2 S_ii' - sum_{j in siblings(i)} S_ij AS[j][i']      (+ sum_p QY[i][p] Q[i'][p]^T: ml_mult_qyqt_kernel, on the matrix cores)
-__device__ __forceinline__ void ml_mult_final_kernel_body(const MlDev* __restrict__ mlp, int cl, int tile = blockIdx.x, int lane = threadIdx.x)
-{
-    const MlDev& ml = *mlp;
-    const MlLevel& F = ml.lv[cl];
-    const int n = F.n, np = ml.lv[cl + 1].n, fan = ml.lv[cl + 1].fan, m = 6 * fan;
-    // one 64-lane wave per (group, group') tile of fan x fan blocks: the tile's rows of AS are shared through L1 instead of
-    // being fetched once per block from L2
-    const int g = tile / np, gp = tile % np;
-    const int i = g * fan + lane / fan, ip = gp * fan + lane % fan;
-    if (tile >= np * np || lane >= fan * fan || i >= n || ip >= n) return;
-    const double* __restrict__ Wi = F.Winv + (size_t)g * m * m + (size_t)((i % fan) * 6) * m;
-    double acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = (g == gp) ? 2. * Wi[(k / 6) * m + (ip % fan) * 6 + k % 6] : 0.;
-    for (int q = 0; q < fan; q++) {
-        const int j = g * fan + q;
-        if (j >= n) break;
-        // AS[j][.] is zero in the columns of group gp unless j belongs to gp or row j of A has a block there (ml_mult_as_kernel):
-        // almost every tile of a large graph skips its reads
-        if (g != gp && ml.grp_beg[cl][(size_t)j * np + gp] == ml.grp_end[cl][(size_t)j * np + gp]) continue;
-        mm6_acc(Wi + q * 6, m, ml.mAS + ((size_t)j * n + ip) * 36, 6, acc, -1.);
-    }
-    double* __restrict__ Y = ml.Ydense[cl];
-    const int n6 = 6 * n;
-#pragma unroll
-    for (int k = 0; k < 36; k++) Y[(size_t)(6 * i + k / 6) * n6 + 6 * ip + k % 6] = acc[k];
-}
-__global__ __launch_bounds__(64) void ml_mult_final_kernel(const MlDev* __restrict__ mlp, int cl)
-{
-    ml_mult_final_kernel_body(mlp, cl);
-}
 // ---- the cycle's operands per PAIR of sibling groups, in one launch (round 4; was A P | A S, then Q | 2 S - S (A S): two launches of
 //      one lane per 6 x 6 block, 57 us at config 2).  Workgroup (g, p): the block A_gp of A_l(lambda) between the children of level-(l+1)
 //      aggregates g and p (48 x 48, assembled in LDS from the slot ranges grp_beg / grp_end), the sibling inverses S_g and S_p, and
@@ -906,19 +680,6 @@ __device__ __forceinline__ void ml_mult_pair_kernel_body(PgoDev D, const MlDev* 
 __global__ __launch_bounds__(kBlk) void ml_mult_pair_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl)
 {
     ml_mult_pair_kernel_body(D, mlp, cl);
-}
-
-// Two launches instead of four for a single graph's rebuild (a chain of ~35 small dependent launches that the early LM iterations wait
-// for): A P and A S depend on nothing inside the cycle, Q needs only A P and the 2 S - S (A S) part of Y only A S.
-__global__ __launch_bounds__(kBlk) void ml_mult_ap_as_kernel(PgoDev D, const MlDev* __restrict__ mlp, int cl, int g_ap)
-{
-    if ((int)blockIdx.x < g_ap) ml_mult_ap_kernel_body(D, mlp, cl, blockIdx.x);
-    else ml_mult_as_kernel_body(D, mlp, cl, blockIdx.x - g_ap);
-}
-__global__ __launch_bounds__(kBlk) void ml_mult_q_final_kernel(const MlDev* __restrict__ mlp, int cl, int g_q)
-{
-    if ((int)blockIdx.x < g_q) ml_mult_q_kernel_body(mlp, cl, blockIdx.x);
-    else ml_mult_final_kernel_body(mlp, cl, ((int)blockIdx.x - g_q) * (kBlk / 64) + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
 }
 
 // ---- composite path: Newton-Schulz refinement  X <- 2 X - X A_1 X  of the dense level-1 operator (X = Y_1 is already a
@@ -2482,15 +2243,6 @@ void k_ml_galerkin(const PgoDev& D, const MlDev* ml, int f, int n_chunks, hipStr
 {
     if (n_chunks > 0) hipLaunchKernelGGL(ml_galerkin_kernel, dim3(n_chunks), dim3(kBlk), 0, s, D, ml, f);
 }
-void k_ml_transform(const PgoDev& D, const MlDev* ml, int f, int work, hipStream_t s)
-{
-    if (work > 0) hipLaunchKernelGGL(ml_transform_kernel, dim3((work + kBlk - 1) / kBlk), dim3(kBlk), 0, s, D, ml, f);
-}
-void k_ml_reduce(const MlDev* ml, int l, int blocks36, hipStream_t s)
-{
-    const long work = (long)blocks36 * 36;
-    if (work > 0) hipLaunchKernelGGL(ml_reduce_kernel, dim3((unsigned)((work + kBlk - 1) / kBlk)), dim3(kBlk), 0, s, ml, l);
-}
 void k_ml_dense_level(const MlDev* ml, int l, int n_l, hipStream_t s)
 {
     hipLaunchKernelGGL(ml_dense_level_kernel, dim3((n_l * n_l + kBlk - 1) / kBlk), dim3(kBlk), 0, s, ml, l);
@@ -2653,21 +2405,10 @@ __global__ __launch_bounds__(kBlk) void ml_geometry_lm_kernel(const LmSlot* __re
     UZL_LM_SETUP(true)
     ml_geometry_kernel_body(D, S.dml[c], S.pose[which == 0 ? lm->build_cur : lm->cur], l);
 }
-__global__ __launch_bounds__(kBlk) void ml_transform_lm_kernel(const LmSlot* __restrict__ slots, int which, int f)
-{
-    UZL_LM_SETUP(true)
-    ml_transform_kernel_body(D, S.dml[c], f);
-}
 __global__ __launch_bounds__(kBlk) void ml_galerkin_lm_kernel(const LmSlot* __restrict__ slots, int which, int f)
 {
     UZL_LM_SETUP(true)
     ml_galerkin_kernel_body(D, S.dml[c], f);
-}
-__global__ __launch_bounds__(kBlk) void ml_reduce_lm_kernel(const LmSlot* __restrict__ slots, int which, int l)
-{
-    UZL_LM_SETUP(true)
-    (void)D;
-    ml_reduce_kernel_body(S.dml[c], l);
 }
 __global__ __launch_bounds__(kBlk) void ml_inverses_lm_kernel(const LmSlot* __restrict__ slots, int which)
 {
@@ -2684,19 +2425,6 @@ __global__ __launch_bounds__(kBlk) void ml_mult_pair_lm_kernel(const LmSlot* __r
 {
     UZL_LM_SETUP(false)
     ml_mult_pair_kernel_body(D, S.dml[c], lev);
-}
-__global__ __launch_bounds__(kBlk) void ml_mult_ap_as_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int g_ap)
-{
-    UZL_LM_SETUP(false)
-    if ((int)blockIdx.x < g_ap) ml_mult_ap_kernel_body(D, S.dml[c], lev, blockIdx.x);
-    else ml_mult_as_kernel_body(D, S.dml[c], lev, blockIdx.x - g_ap);
-}
-__global__ __launch_bounds__(kBlk) void ml_mult_q_final_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev, int g_q)
-{
-    UZL_LM_SETUP(false)
-    (void)D;
-    if ((int)blockIdx.x < g_q) ml_mult_q_kernel_body(S.dml[c], lev, blockIdx.x);
-    else ml_mult_final_kernel_body(S.dml[c], lev, ((int)blockIdx.x - g_q) * (kBlk / 64) + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
 }
 __global__ __launch_bounds__(kBlk) void ml_mult_qy_lm_kernel(const LmSlot* __restrict__ slots, int which, int lev)
 {

@@ -92,9 +92,7 @@ struct MlLevel {
     const int32_t* row_ptr;    // [n+1]  (levels >= 1)
     const int32_t* col;        // [nslots]
     const int32_t* srow;       // [nslots] row of each slot (levels >= 1)
-    // contribution map used when this level is the FINE side of a Galerkin product A_{l+1} = P^T A_l P
-    const int32_t* tpos;       // [nslots] position of slot s in the sorted contribution array (or -1)
-    // ranges used when this level is the COARSE side
+    // contribution ranges used when this level is the COARSE side of a Galerkin product A_{l+1} = P^T A_l P
     const int32_t* off_ptr;    // [nslots+1] contributions of each off-diagonal block
     const int32_t* diag_ptr;   // [n+1]      same-aggregate contributions of each diagonal block
     int32_t n_off_contrib;     // diag contributions start here in the contribution array
@@ -115,15 +113,11 @@ struct MlDev {
     int32_t levels;            // number of coarse levels L (0 = plain block-Jacobi)
     int32_t comp_level;        // composite path: level whose dense operator Ydense[comp_level] the PCG kernel applies (1 or 2); 0 = off
     MlLevel lv[kMlMaxLevels + 1];
-    double* tmp;               // contribution scratch [max contributions][36]
-    double* tmpG;              // [max n][36]
-    double* tmpM;              // [max n][36]
     double* top_inv;           // [(6 n_top)^2] dense inverse of A_L(lambda)
     const int32_t* grp_beg[kMlMaxLevels + 1];   // composite path, levels comp_level .. L-1: [n_l][n_{l+1}] first / one-past-last slot of
     const int32_t* grp_end[kMlMaxLevels + 1];   // level-l row i whose column lies in level-(l+1) aggregate p (slots of a row are sorted by
                                                 // column, so the range is contiguous)
-    double* mAP; double* mQ; double* mQY;   // composite path, level 1: [n_1][n_2][36] scratch of the multiplicative operator
-    double* mAS;               // [n_1][n_1][36]
+    double* mQ; double* mQY;    // composite path, level 1: [n_1][n_2][36] Q and Q Y_2 of the multiplicative operator
     double* nsT; double* nsX;   // composite path: (6 n_1)^2 scratch of the Newton-Schulz refinement of Y_1
     double* Ydense[kMlMaxLevels + 1];   // composite path: Y_l = dense (6 n_l)^2 operator "residual of level l -> correction of
                                // level l" of the whole hierarchy above, 1 <= l < L (Y_L = top_inv); null otherwise

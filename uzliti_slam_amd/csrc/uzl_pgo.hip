@@ -281,12 +281,11 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     h->ml_levels = L;
     h->ml_lds = ml_cg_lds_bytes(h->ml_n.data(), L, h->ml_agg);
     // per-level host index arrays
-    struct Lv { std::vector<int32_t> row_ptr, col, srow, tpos, off_ptr, diag_ptr, cslot, chunk; int32_t n_off = 0; };      // cslot / chunk: ml_galerkin_kernel's work list
+    struct Lv { std::vector<int32_t> row_ptr, col, srow, off_ptr, diag_ptr, cslot, chunk; int32_t n_off = 0; };      // cslot / chunk: ml_galerkin_kernel's work list
     std::vector<Lv> lv((size_t)L + 1);
     lv[0].col = col0;
     lv[0].srow.resize(col0.size());
     for (int a = 0; a < nb; a++) for (int s = row_ptr0[a]; s < row_ptr0[a + 1]; s++) lv[0].srow[s] = a;
-    size_t max_contrib = 1, max_n = (size_t)nb;
     for (int f = 0; f < L; f++) {
         Lv& F = lv[f]; Lv& C = lv[f + 1];
         const int nc = h->ml_n[f + 1];
@@ -305,20 +304,18 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
             if (x.C != y.C) return x.C < y.C;
             return x.s < y.s; });
         std::sort(dg.begin(), dg.end());
-        F.tpos.assign((size_t)std::max(ns, 1), -1);
         C.row_ptr.assign((size_t)nc + 1, 0);
         for (size_t k = 0; k < off.size(); k++) {
             if (k == 0 || off[k].A != off[k - 1].A || off[k].C != off[k - 1].C) {
                 C.srow.push_back(off[k].A); C.col.push_back(off[k].C); C.off_ptr.push_back((int32_t)k);
                 C.row_ptr[off[k].A + 1]++;
             }
-            F.tpos[off[k].s] = (int32_t)k;
         }
         C.off_ptr.push_back((int32_t)off.size());
         for (int a = 0; a < nc; a++) C.row_ptr[a + 1] += C.row_ptr[a];
         C.n_off = (int32_t)off.size();
         C.diag_ptr.assign((size_t)nc + 1, 0);
-        for (size_t k = 0; k < dg.size(); k++) { C.diag_ptr[dg[k].first + 1]++; F.tpos[dg[k].second] = C.n_off + (int32_t)k; }
+        for (size_t k = 0; k < dg.size(); k++) C.diag_ptr[dg[k].first + 1]++;
         for (int a = 0; a < nc; a++) C.diag_ptr[a + 1] += C.diag_ptr[a];
         // The Galerkin product as a GATHER (ml_galerkin_kernel): contribution q comes from fine slot cslot[q]; a workgroup takes a chunk of
         // consecutive output blocks whose contributions (<= kGalItems) it transforms into LDS and sums in order.  chunk = {kind (0: off-
@@ -347,21 +344,18 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         }
         h->ml_nslots.push_back((int32_t)C.col.size());
         h->ml_chunks.push_back((int32_t)(C.chunk.size() / 5));
-        max_contrib = std::max(max_contrib, off.size() + dg.size());
-        max_n = std::max(max_n, (size_t)nc);
         h->ml_inner_aggs += nc;                                   // one sibling block per aggregate of every coarse level
     }
     // ---- one arena for everything: first the int arrays (staged on the host), then the doubles
     size_t bytes = 0;
     auto take = [&](size_t b) { size_t o = bytes; bytes = (bytes + b + 255) / 256 * 256; return o; };
-    struct IntOff { size_t row_ptr, col, srow, tpos, off_ptr, diag_ptr, cslot, chunk; };
+    struct IntOff { size_t row_ptr, col, srow, off_ptr, diag_ptr, cslot, chunk; };
     std::vector<IntOff> io((size_t)L + 1);
     for (int l = 0; l <= L; l++) {
         Lv& X = lv[l];
         io[l].row_ptr = take(std::max<size_t>(X.row_ptr.size(), 1) * 4);
         io[l].col = take(std::max<size_t>(X.col.size(), 1) * 4);
         io[l].srow = take(std::max<size_t>(X.srow.size(), 1) * 4);
-        io[l].tpos = take(std::max<size_t>(X.tpos.size(), 1) * 4);
         io[l].off_ptr = take(std::max<size_t>(X.off_ptr.size(), 1) * 4);
         io[l].diag_ptr = take(std::max<size_t>(X.diag_ptr.size(), 1) * 4);
         io[l].cslot = take(std::max<size_t>(X.cslot.size(), 1) * 4);
@@ -396,8 +390,8 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     // A handle whose graphs made the multiplicative operator break down (chain-like graphs: few loop closures per vertex, the
     // shape of an online run) keeps the additive operator for its later structures instead of failing once per add_graph.
     h->ml_mult = h->ml_comp && !mult_off && !h->mult_banned;
-    const size_t n12 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl + 1] * 36 * 8 : 0, n11 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl] * 36 * 8 : 0;
-    const size_t o_mAP = take(n12), o_mQ = take(n12), o_mQY = take(n12), o_mAS = take(n11);
+    const size_t n12 = h->ml_mult ? (size_t)h->ml_n[cl] * h->ml_n[cl + 1] * 36 * 8 : 0;
+    const size_t o_mQ = take(n12), o_mQY = take(n12);
     // Newton-Schulz steps of the composite operator per rebuild: 2; 4 on large loopy graphs (AGG = 4, >= 6 slots per row), where two
     // more GEMM pairs per rebuild buy a quarter of the PCG iterations (10k/50k 1882 -> 1455 per solve, 107.7 -> 94.1 ms; 5k/25k 68.6 ->
     // 62.3; 20k/100k 242 -> 224) - on chain-like graphs of that size they cost more than they save (20k/21.7k: 209 -> 261 ms), on
@@ -428,7 +422,6 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
             o_grp[l] = take(grp[l].size() * 4);
         }
     }
-    const size_t o_tmp = take(max_contrib * 36 * 8), o_tmpG = take(max_n * 36 * 8), o_tmpM = take(max_n * 36 * 8);
     const size_t o_top = take((size_t)(6 * kMlTopWide) * (6 * kMlTopWide) * 8);
     const int gl = (h->ml_agg == 1 || L < 2) ? 1 : 2;
     const size_t ngz = (size_t)std::max(h->ml_n[gl], 1) * 6 * 8 * 2;          // (x 2: the gather-level-2 Sg holds two parts per entity)
@@ -440,7 +433,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     auto put = [&](size_t o, const std::vector<int32_t>& v) { if (!v.empty()) memcpy(stage.data() + o, v.data(), v.size() * 4); };
     for (int l = 0; l <= L; l++) {
         put(io[l].row_ptr, lv[l].row_ptr); put(io[l].col, lv[l].col); put(io[l].srow, lv[l].srow);
-        put(io[l].tpos, lv[l].tpos); put(io[l].off_ptr, lv[l].off_ptr); put(io[l].diag_ptr, lv[l].diag_ptr);
+        put(io[l].off_ptr, lv[l].off_ptr); put(io[l].diag_ptr, lv[l].diag_ptr);
         put(io[l].cslot, lv[l].cslot); put(io[l].chunk, lv[l].chunk);
     }
     hipStream_t s = h->stream;
@@ -462,7 +455,6 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
             X.row_ptr = (l == 0) ? d_row_ptr : reinterpret_cast<const int32_t*>(base + io[l].row_ptr);
             X.col = (l == 0) ? d_col : reinterpret_cast<const int32_t*>(base + io[l].col);
             X.srow = reinterpret_cast<const int32_t*>(base + io[l].srow);
-            X.tpos = reinterpret_cast<const int32_t*>(base + io[l].tpos);
             X.off_ptr = reinterpret_cast<const int32_t*>(base + io[l].off_ptr);
             X.diag_ptr = reinterpret_cast<const int32_t*>(base + io[l].diag_ptr);
             X.n_off_contrib = lv[l].n_off;
@@ -478,9 +470,6 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
             X.r = reinterpret_cast<double*>(base + dof[l].r);
             X.y = reinterpret_cast<double*>(base + dof[l].y);
         }
-        M.tmp = reinterpret_cast<double*>(base + o_tmp);
-        M.tmpG = reinterpret_cast<double*>(base + o_tmpG);
-        M.tmpM = reinterpret_cast<double*>(base + o_tmpM);
         M.top_inv = reinterpret_cast<double*>(base + o_top);
         for (int l = 1; l < L; l++) M.Ydense[l] = (h->ml_comp && l >= cl) ? reinterpret_cast<double*>(base + o_dense[l]) : nullptr;
         for (int l = 0; l <= kMlMaxLevels; l++) h->ml_dense_ptr[bi][l] = (l >= 1 && l < L) ? M.Ydense[l] : nullptr;
@@ -493,8 +482,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
             }
         }
         M.nsT = reinterpret_cast<double*>(base + o_nsT); M.nsX = reinterpret_cast<double*>(base + o_nsX);
-        M.mAP = reinterpret_cast<double*>(base + o_mAP); M.mQ = reinterpret_cast<double*>(base + o_mQ);
-        M.mQY = reinterpret_cast<double*>(base + o_mQY); M.mAS = reinterpret_cast<double*>(base + o_mAS);
+        M.mQ = reinterpret_cast<double*>(base + o_mQ); M.mQY = reinterpret_cast<double*>(base + o_mQY);
         M.Sg = reinterpret_cast<double*>(base + o_sg);
         uzl_pgo::MlBuf& B = h->mlb[bi];
         B.dml = h->d_ml.p + bi;
