@@ -1,10 +1,10 @@
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 1100 python3 bench.py > gpurun_out/r4/bench_b.json 2> gpurun_out/r4/bench_b.err || { tail -30 gpurun_out/r4/bench_b.err; exit 1; }
-tail -5 gpurun_out/r4/bench_b.err
+timeout -k 10 1100 python3 bench.py > gpurun_out/r4/bench_c.json 2> gpurun_out/r4/bench_c.err || { tail -30 gpurun_out/r4/bench_c.err; exit 1; }
+tail -5 gpurun_out/r4/bench_c.err
 python3 - <<'PY'
 import json
-d=json.loads(open('gpurun_out/r4/bench_b.json').read().strip().splitlines()[-1])
+d=json.loads(open('gpurun_out/r4/bench_c.json').read().strip().splitlines()[-1])
 print({k: d[k] for k in ('metric','value','unit','ms_per_step','lm_overhead_ms')})
 print('roofline', d['roofline'])
 print('parity', d.get('parity'))

@@ -1,0 +1,11 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export UZL_LIB=uzliti_slam_amd/libuzl_mi355x_diag.so
+UZL_STREAM_DBG=1 UZL_BATCH_LANES=2 python3 bench.py --no-cpu-baseline --no-c4 --no-online --no-formats --no-sharded --no-secondary --batch-queue 0 > gpurun_out/r4/bq.json 2> gpurun_out/r4/bq.err || { tail -20 gpurun_out/r4/bq.err; exit 1; }
+grep "uzl\]" gpurun_out/r4/bq.err | sort | uniq -c | sort -rn | head -40
+python3 - <<PY
+import json
+d=json.loads(open('gpurun_out/r4/bq.json').read().strip().splitlines()[-1])
+b=d['batched']
+print('c2', b['ms_per_batch'], 'small', b['small_graphs']['ms_per_batch'], 'chain', b['chain_like']['ms_per_batch'], 'primary', d['ms_per_step'])
+PY

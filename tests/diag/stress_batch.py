@@ -13,16 +13,20 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 bad = tot = nb_tot = 0
 for b in range(n_batches):
     n = int(rng.choice([120, 400, 900, 1500, 2040]))
-    B = int(rng.integers(2, 9))
+    B = int(rng.integers(2, 9)) if rng.random() < 0.5 else int(rng.integers(12, 25))     # (from 12 graphs on: two launch sequences)
     its = int(rng.choice([3, 8, 20]))
     graphs = []
+    one_class = rng.random() < 0.7                     # most batches: one density class, so that the graphs share a hierarchy shape and batch
+    dens0 = float(rng.choice([1.02, 1.5, 3.0, 5.0]))
     for k in range(B):
-        dens = float(rng.choice([1.0, 1.02, 1.5, 3.0, 5.0]))
+        dens = dens0 * (1. + 0.01 * float(rng.integers(0, 4))) if one_class else float(rng.choice([1.0, 1.02, 1.5, 3.0, 5.0]))
         g = synth.make_pose_graph(n, max(n - 1, int(n * dens)), seed=int(rng.integers(1, 10**6)), outlier_frac=float(rng.choice([0.0, 0.05, 0.3])))
         if rng.random() < 0.2:
             g = synth.permute_graph(g, rng.permutation(n))
         graphs.append(g)
     bt = capi.PgoBatch(B)
+    if rng.random() < 0.3:
+        bt.set_resident(int(rng.integers(1, B + 1)))
     for k, g in enumerate(graphs):
         bt.graphs[k].add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
     st = bt.optimize(its)

@@ -111,6 +111,25 @@ def test_zero_residual_and_anomalous_graphs_in_a_batch(capi):
     bt.close()
 
 
+def test_two_launch_sequences_with_an_odd_split_and_fallbacks(capi):
+    """From 12 graphs on a batch runs as two launch sequences on streams of their own, the second half driven by a second host thread
+    (uzl_pgo.hip: kBatchLaneMin).  13 chain-like graphs split 7 + 6; the second half holds a zero-residual chain and graphs with few
+    loop closures (rejected trials, the per-graph fallback where the solver meets an anomaly).  Every graph must equal its own solve."""
+    graphs = [synth.make_pose_graph(1500, 1530 + 3 * k, seed=70 + k) for k in range(13)]
+    graphs[9] = synth.make_pose_graph(1500, 1499, seed=9)              # a pure odometry chain: chi2 = 0 from the start
+    graphs[11] = synth.make_pose_graph(1500, 1503, seed=11)
+    bt = capi.PgoBatch(len(graphs))
+    for k, g in enumerate(graphs):
+        bt.graphs[k].add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    stats = bt.optimize(12)
+    for k, g in enumerate(graphs):
+        st1, poses1, _ = _single(capi, g, 12)
+        assert np.array_equal(bt.graphs[k].store()[0], poses1), k
+        for f in ("iterations_done", "lm_trials", "pcg_iterations", "terminated_early", "n_eliminated"):
+            assert stats[k][f] == st1[f], (k, f, stats[k][f], st1[f])
+    bt.close()
+
+
 @pytest.mark.parametrize("resident", [1, 3, 8])
 def test_queue_with_fewer_resident_slots_than_graphs(capi, resident):
     """uzl_pgo_batch_set_resident: 20 graphs through 1 / 3 / 8 slots - a finished graph hands its slot to the next one of the queue.

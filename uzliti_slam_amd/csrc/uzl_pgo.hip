@@ -10,8 +10,79 @@
 
 using namespace uzl;
 
+// ---- streams whose kernels really overlap ---------------------------------------------------------------------------------------
+// A HIP stream is served by one of the runtime's hardware queues (four by default: GPU_MAX_HW_QUEUES), handed out at hipStreamCreate,
+// least used first - ten streams made in a row land on queues A B C D D C B A D C (tests/diag/stream_overlap.py) - and every packet of
+// a queue waits for the one before it.  Two streams that share a queue therefore run one behind the other: a rebuild on stream2
+// "beside" the PCG then sits IN FRONT of it, and two batch sequences take turns (two batches of five config-2 graphs from two host
+// threads: 2.3x slower than one batch of ten).  Nothing tells a process which queue a stream got, but it can be seen: a kernel that
+// waits 200 us on one stream, an empty one on the other - if the empty one ends first, the two overlap.  Streams that have to overlap
+// are made until they do; the rejects are held until then, so that the next one lands elsewhere.
+namespace {
+__global__ void spin_kernel(unsigned ticks)
+{
+    const unsigned long long t0 = wall_clock64();            // 100 MHz
+    while (wall_clock64() - t0 < ticks) {}
+}
+__global__ void noop_kernel() {}
+bool streams_overlap(hipStream_t a, hipStream_t b)
+{
+    hipEvent_t ea = nullptr, eb = nullptr;
+    bool overlap = true;                                       // (on any error: leave the streams as they are)
+    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess) {
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, a, 20000u);
+        (void)hipEventRecord(ea, a);
+        hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(1), 0, b);
+        (void)hipEventRecord(eb, b);
+        if (hipEventSynchronize(eb) == hipSuccess) overlap = hipEventQuery(ea) == hipErrorNotReady;
+        (void)hipEventSynchronize(ea);
+        (void)hipGetLastError();
+    }
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    return overlap;
+}
+// a new stream (priority 0 or -1) that overlaps with every stream of `others`; after eight attempts the last one made (a shared queue
+// is slower, not wrong); nullptr only if the runtime makes no stream at all
+hipStream_t overlapping_stream(int priority, std::initializer_list<hipStream_t> others)
+{
+    std::vector<hipStream_t> rejects;
+    hipStream_t got = nullptr;
+    for (int attempt = 0; attempt < 8 && !got; attempt++) {
+        hipStream_t q = nullptr;
+        if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, priority) != hipSuccess) break;
+        bool ok = true;
+        for (hipStream_t o : others) if (o && !streams_overlap(o, q)) { ok = false; break; }
+        if (ok) got = q; else rejects.push_back(q);
+        static const bool dbg = diag_flag("UZL_STREAM_DBG");
+        if (dbg) fprintf(stderr, "[uzl] overlapping_stream(priority %d, %d other(s)): attempt %d %s\n", priority, (int)others.size(), attempt, ok ? "overlaps" : "shares a queue");
+    }
+    if (!got && !rejects.empty()) { got = rejects.back(); rejects.pop_back(); }
+    for (hipStream_t r : rejects) (void)hipStreamDestroy(r);
+    return got;
+}
+}  // namespace
+
+namespace uzl {
+// before the first solve of a handle: its rebuild stream must overlap with its solver stream (checked once; the batch's member handles
+// never get here unless one of them falls back to a solve of its own)
+void ensure_overlapping_streams(uzl_pgo* h)
+{
+    if (h->streams_checked) return;
+    h->streams_checked = true;
+    if (!h->stream || !h->stream2 || streams_overlap(h->stream, h->stream2)) return;
+    hipStream_t q = overlapping_stream(-1, {h->stream, h->stream2});      // (the old one stays alive meanwhile: it holds its place on the shared queue)
+    if (!q) return;
+    (void)hipStreamSynchronize(h->stream2);
+    (void)hipStreamDestroy(h->stream2);
+    h->stream2 = q;
+}
+}  // namespace uzl
+
 // ---- RCCL through dlopen: the collective library is only loaded by processes that shard a graph -----------------------------
 #include <dlfcn.h>
+#include <exception>
+#include <thread>
 namespace {
 struct RcclApi {
     typedef struct { char internal[UZL_RCCL_UNIQUE_ID_BYTES]; } UniqueId;     // ncclUniqueId (rccl.h:43)
@@ -1018,6 +1089,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 // The host-driven loop.  Called through do_optimize (structure prepared, device set), or by do_optimize_lm for a solve that met an anomaly.
 int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 {
+    ensure_overlapping_streams(h);
     const auto t0 = h->t_start;
     uzl_pgo_stats S;
     memset(&S, 0, sizeof(S));
@@ -1318,7 +1390,7 @@ int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
     { const char* ng = getenv("UZL_NO_GRAPH"); h->no_graph = ng && ng[0] == '1'; }
     if (getenv("UZL_VERBOSE")) h->cfg.verbose = 1;                                    // diagnostic: per-trial PCG log on stderr
     if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, -1) != hipSuccess ||      // rebuilds ahead of the PCG they overlap with
+        hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, diag_int("UZL_S2_PRIO", -1)) != hipSuccess ||      // rebuilds ahead of the PCG they overlap with
 
         hipEventCreateWithFlags(&h->ev_lin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_setup, hipEventDisableTiming) != hipSuccess) {
@@ -1656,6 +1728,11 @@ struct uzl_pgo_batch {
     int32_t resident = 0;                 // graphs solved at a time (0 = all): uzl_pgo_batch_set_resident
     int32_t last_batched = 0;
     uzl::LmRun* lm = nullptr;             // slot table, LM states, captured segments (uzl_pgo_lm.hip)
+    // second launch sequence (batches of >= kBatchLaneMin graphs): the second half of the graphs on streams of its own, driven by a second
+    // host thread for the duration of the call - its kernels fill the tails of the first half's and a pass is as long as the longest solve
+    // of eight graphs, not sixteen
+    hipStream_t stream_b = nullptr, stream2_b = nullptr;
+    uzl::LmRun* lm_b = nullptr;
     KernelTimer timer;                    // profiling (uzl_pgo_batch_set_profiling): the two PCG kernels, launched eagerly with event pairs
 };
 
@@ -1694,10 +1771,46 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
         b->last_batched = 0;
         return rc_all;
     }
-    const int done = batch_optimize_lm(b->lm, b->h, b->resident, b->stream, b->stream2, iterations, b->h[0]->no_graph, b->cfg.verbose != 0, &b->timer, stats, &rc_all);
-    if (done < 0) { b->last_error = b->h[(size_t)(-1 - done)]->last_error; return rc_all; }
-    b->last_batched = done;
-    if (n_batched) *n_batched = done;
+    static const int lanes_env = diag_int("UZL_BATCH_LANES", 2);               // A/B switch (diagnostic build): 1 = one launch sequence
+    {
+        static const bool dbg = diag_flag("UZL_STREAM_DBG");
+        if (dbg) {
+            hipStream_t q[4] = {b->stream, b->stream2, b->stream_b, b->stream2_b};
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (i != j && q[i] && q[j]) fprintf(stderr, "[uzl] batch streams %d -> %d: %s\n", i, j, streams_overlap(q[i], q[j]) ? "overlap" : "SHARE A QUEUE");
+        }
+    }
+    const bool eager = b->h[0]->no_graph, verbose = b->cfg.verbose != 0;
+    if (B < kBatchLaneMin || lanes_env < 2 || b->resident == 1 || b->timer.on || !b->stream_b || !b->stream2_b) {
+        const int done = batch_optimize_lm(b->lm, b->h, b->resident, b->stream, b->stream2, iterations, eager, verbose, &b->timer, stats, &rc_all);
+        if (done < 0) { b->last_error = b->h[(size_t)(-1 - done)]->last_error; return rc_all; }
+        b->last_batched = done;
+        if (n_batched) *n_batched = done;
+        return rc_all;
+    }
+    // ---- two launch sequences: graphs [0, n0) from this thread, [n0, B) from a second one.  The halves share nothing but the device (every
+    //      graph has its handle, every half its streams, slot table and captured segments), and a graph's result does not depend on its
+    //      neighbours in the batch, so the split changes no bit of any result.
+    const int n0 = (B + 1) / 2;
+    const std::vector<uzl_pgo*> h0(b->h.begin(), b->h.begin() + n0), h1(b->h.begin() + n0, b->h.end());
+    const int r0 = b->resident > 0 ? (b->resident + 1) / 2 : 0, r1 = b->resident > 0 ? b->resident / 2 : 0;      // (resident >= 2 here: r0 + r1 = resident)
+    int rc0 = UZL_OK, rc1 = UZL_OK, done0 = 0, done1 = 0;
+    std::exception_ptr ex1;
+    std::thread lane([&] {
+        try {
+            UZL_HIP(hipSetDevice(b->cfg.device));
+            done1 = batch_optimize_lm(b->lm_b, h1, r1, b->stream_b, b->stream2_b, iterations, eager, verbose, nullptr, stats ? stats + n0 : nullptr, &rc1);
+        } catch (...) { ex1 = std::current_exception(); }
+    });
+    try {
+        done0 = batch_optimize_lm(b->lm, h0, r0, b->stream, b->stream2, iterations, eager, verbose, nullptr, stats, &rc0);
+    } catch (...) { lane.join(); throw; }
+    lane.join();
+    if (ex1) std::rethrow_exception(ex1);
+    if (done0 < 0) { b->last_error = h0[(size_t)(-1 - done0)]->last_error; return rc0; }
+    if (done1 < 0) { b->last_error = h1[(size_t)(-1 - done1)]->last_error; return rc1; }
+    rc_all = rc0 != UZL_OK ? rc0 : rc1;
+    b->last_batched = done0 + done1;
+    if (n_batched) *n_batched = done0 + done1;
     return rc_all;
 }
 
@@ -1730,11 +1843,20 @@ int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch
         if (rc != UZL_OK) { for (uzl_pgo* x : b->h) uzl_pgo_destroy(x); delete b; return rc; }
         b->h.push_back(h);
     }
-    if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, -1) != hipSuccess) {
+    // The batch's launch sequences and their rebuild streams, every one on a hardware queue of its own (streams_overlap, above).  The
+    // rebuild streams have NORMAL priority: with high-priority ones (as a single handle's stream2 has) a batch's rate depended on what the
+    // process had done before - bench.py with / without its matcher block in front: 16 chain-like graphs 14.3 / 20.9 ms, 16 config-2
+    // graphs 25.9 / 30.3 ms, 64 small graphs 11.2 / 13.2 ms; with normal priority 14.1 / 23.7 / 10.0 ms either way
+    // (tests/diag/r4_hwq4.sh).  A single handle's solve showed no such dependence (6.0 ms with either priority).
+    const bool two = n_graphs >= kBatchLaneMin;
+    bool ok = hipSetDevice(c.device) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
+    static const int prio2 = diag_int("UZL_BATCH_S2_PRIO", 0);                     // A/B switch (diagnostic build): priority of the rebuild streams
+    if (ok) ok = (b->stream2 = overlapping_stream(prio2, {b->stream})) != nullptr;
+    if (ok && two) ok = (b->stream_b = overlapping_stream(0, {b->stream, b->stream2})) != nullptr;
+    if (ok && two) ok = (b->stream2_b = overlapping_stream(prio2, {b->stream, b->stream2, b->stream_b})) != nullptr;
+    if (!ok) {
         for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
-        if (b->stream) (void)hipStreamDestroy(b->stream);
-        if (b->stream2) (void)hipStreamDestroy(b->stream2);
+        for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b}) if (q) (void)hipStreamDestroy(q);
         delete b;
         return UZL_ERR_HIP;
     }
@@ -1746,12 +1868,11 @@ void uzl_pgo_batch_destroy(uzl_pgo_batch* b)
 {
     if (!b) return;
     (void)hipSetDevice(b->cfg.device);
-    if (b->stream2) (void)hipStreamSynchronize(b->stream2);
-    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (hipStream_t q : {b->stream2, b->stream, b->stream2_b, b->stream_b}) if (q) (void)hipStreamSynchronize(q);
     lm_run_destroy(b->lm); b->lm = nullptr;
+    lm_run_destroy(b->lm_b); b->lm_b = nullptr;
     for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
-    if (b->stream) (void)hipStreamDestroy(b->stream);
-    if (b->stream2) (void)hipStreamDestroy(b->stream2);
+    for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b}) if (q) (void)hipStreamDestroy(q);
     delete b;
 }
 
@@ -1790,3 +1911,15 @@ int uzl_pgo_batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* 
 }
 
 }  // extern "C"
+
+// test hook (tests/diag/stream_overlap.py): n streams of priority `priority`, out[i * n + j] = 1 if a kernel on stream j overtakes one that
+// waits on stream i (streams_overlap), 0 if the two share a hardware queue
+extern "C" int uzl_debug_stream_overlap(int n, int priority, int32_t* out)
+{
+    if (n < 2 || n > 32 || !out) return UZL_ERR_BAD_ARG;
+    std::vector<hipStream_t> q((size_t)n, nullptr);
+    for (int i = 0; i < n; i++) if (hipStreamCreateWithPriority(&q[i], hipStreamNonBlocking, priority) != hipSuccess) return UZL_ERR_HIP;
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) out[i * n + j] = (i == j) ? -1 : (streams_overlap(q[i], q[j]) ? 1 : 0);
+    for (hipStream_t s : q) (void)hipStreamDestroy(s);
+    return UZL_OK;
+}
