@@ -111,10 +111,9 @@ def test_zero_residual_and_anomalous_graphs_in_a_batch(capi):
     bt.close()
 
 
-def test_two_launch_sequences_with_an_odd_split_and_fallbacks(capi):
-    """From 12 graphs on a batch runs as two launch sequences on streams of their own, the second half driven by a second host thread
-    (uzl_pgo.hip: kBatchLaneMin).  13 chain-like graphs split 7 + 6; the second half holds a zero-residual chain and graphs with few
-    loop closures (rejected trials, the per-graph fallback where the solver meets an anomaly).  Every graph must equal its own solve."""
+def test_thirteen_chain_like_graphs_with_fallbacks(capi):
+    """13 chain-like graphs, among them a zero-residual chain and graphs with few loop closures (rejected trials, the per-graph fallback
+    where the solver meets an anomaly).  Every graph must equal its own solve."""
     graphs = [synth.make_pose_graph(1500, 1530 + 3 * k, seed=70 + k) for k in range(13)]
     graphs[9] = synth.make_pose_graph(1500, 1499, seed=9)              # a pure odometry chain: chi2 = 0 from the start
     graphs[11] = synth.make_pose_graph(1500, 1503, seed=11)
@@ -162,3 +161,35 @@ def test_queue_with_fewer_resident_slots_than_graphs(capi, resident):
         trials.add(st1["lm_trials"])
     assert len(trials) >= 2                                       # the graphs really did not march in step
     bt.close()
+
+
+def test_stream_overlap_probe_is_consistent(capi):
+    """uzl_pgo.hip: streams_overlap decides which streams the library keeps (a handle's solver / rebuild pair, a batch's two launch
+    sequences must not share one of the runtime's hardware queues).  Sharing a queue is a property of the pair: the probe must see
+    it from both sides."""
+    import ctypes
+    n = 6
+    lib = capi.lib()
+    a = np.zeros((n, n), np.int32)
+    assert lib.uzl_debug_stream_overlap(ctypes.c_int(n), ctypes.c_int(0), a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) == 0
+    assert np.all(np.diag(a) == -1)
+    off = ~np.eye(n, dtype=bool)
+    assert set(np.unique(a[off])) <= {0, 1}
+    assert np.array_equal(a, a.T)
+    assert a[off].sum() >= 2                                      # streams that overlap exist at all (the probe does not just say no)
+
+
+def test_two_launch_sequences_in_the_diagnostic_build():
+    """UZL_BATCH_LANES=2 (diagnostic build): from 12 graphs on the second half of a batch is driven by a second host thread on streams of
+    its own (uzl_pgo.hip; not the default - DESIGN_APPENDIX.md (h)).  Random batches of 2 - 24 graphs, some through a queue: every graph
+    bit-identical to its own solve."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    diag = os.path.join(os.path.dirname(here), "uzliti_slam_amd", "libuzl_mi355x_diag.so")
+    assert os.path.exists(diag), "build the diagnostic library: make -C uzliti_slam_amd/csrc diag"
+    e = dict(os.environ, UZL_LIB=diag, UZL_BATCH_LANES="2")
+    out = subprocess.run([sys.executable, os.path.join(here, "diag", "stress_batch.py"), "5", "11"], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    assert "0 misses" in out.stdout

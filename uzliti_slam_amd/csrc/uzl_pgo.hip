@@ -11,13 +11,13 @@
 using namespace uzl;
 
 // ---- streams whose kernels really overlap ---------------------------------------------------------------------------------------
-// A HIP stream is served by one of the runtime's hardware queues (four by default: GPU_MAX_HW_QUEUES), handed out at hipStreamCreate,
-// least used first - ten streams made in a row land on queues A B C D D C B A D C (tests/diag/stream_overlap.py) - and every packet of
-// a queue waits for the one before it.  Two streams that share a queue therefore run one behind the other: a rebuild on stream2
-// "beside" the PCG then sits IN FRONT of it, and two batch sequences take turns (two batches of five config-2 graphs from two host
-// threads: 2.3x slower than one batch of ten).  Nothing tells a process which queue a stream got, but it can be seen: a kernel that
-// waits 200 us on one stream, an empty one on the other - if the empty one ends first, the two overlap.  Streams that have to overlap
-// are made until they do; the rejects are held until then, so that the next one lands elsewhere.
+// A HIP stream is served by one of the runtime's hardware queues (four per priority by default: GPU_MAX_HW_QUEUES), handed out at
+// hipStreamCreate, least used first - ten streams of one priority made in a row land on queues A B C D D C B A D C
+// (tests/diag/stream_overlap.py) - and every packet of a queue waits for the one before it.  Two streams that share a queue therefore
+// run one behind the other: a rebuild "beside" the PCG then sits IN FRONT of it (a batch of 16 config-2 graphs 25.8 -> 28.2 ms).
+// Nothing tells a process which queue a stream got, but it can be seen: a kernel that waits 200 us on one stream, an empty one on the
+// other - if the empty one ends first, the two overlap.  A stream that has to overlap with another of its priority is made until it
+// does; the rejects are held until then, so that the next one lands elsewhere.
 namespace {
 __global__ void spin_kernel(unsigned ticks)
 {
@@ -30,12 +30,19 @@ bool streams_overlap(hipStream_t a, hipStream_t b)
     hipEvent_t ea = nullptr, eb = nullptr;
     bool overlap = true;                                       // (on any error: leave the streams as they are)
     if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess) {
-        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, a, 20000u);
-        (void)hipEventRecord(ea, a);
+        // (a stream's first launch can take longer than the wait it is measured against: both streams have run a kernel before the probe)
+        hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(1), 0, a);
         hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(1), 0, b);
-        (void)hipEventRecord(eb, b);
-        if (hipEventSynchronize(eb) == hipSuccess) overlap = hipEventQuery(ea) == hipErrorNotReady;
-        (void)hipEventSynchronize(ea);
+        (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+        for (int probe = 0; probe < 2; probe++) {              // "shares a queue" must be seen twice: anything else on the GPU can hold the empty kernel back once
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, a, 20000u);
+            (void)hipEventRecord(ea, a);
+            hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(1), 0, b);
+            (void)hipEventRecord(eb, b);
+            overlap = hipEventSynchronize(eb) != hipSuccess || hipEventQuery(ea) == hipErrorNotReady;
+            (void)hipEventSynchronize(ea);
+            if (overlap) break;
+        }
         (void)hipGetLastError();
     }
     if (ea) (void)hipEventDestroy(ea);
@@ -63,21 +70,6 @@ hipStream_t overlapping_stream(int priority, std::initializer_list<hipStream_t> 
 }
 }  // namespace
 
-namespace uzl {
-// before the first solve of a handle: its rebuild stream must overlap with its solver stream (checked once; the batch's member handles
-// never get here unless one of them falls back to a solve of its own)
-void ensure_overlapping_streams(uzl_pgo* h)
-{
-    if (h->streams_checked) return;
-    h->streams_checked = true;
-    if (!h->stream || !h->stream2 || streams_overlap(h->stream, h->stream2)) return;
-    hipStream_t q = overlapping_stream(-1, {h->stream, h->stream2});      // (the old one stays alive meanwhile: it holds its place on the shared queue)
-    if (!q) return;
-    (void)hipStreamSynchronize(h->stream2);
-    (void)hipStreamDestroy(h->stream2);
-    h->stream2 = q;
-}
-}  // namespace uzl
 
 // ---- RCCL through dlopen: the collective library is only loaded by processes that shard a graph -----------------------------
 #include <dlfcn.h>
@@ -1089,7 +1081,6 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 // The host-driven loop.  Called through do_optimize (structure prepared, device set), or by do_optimize_lm for a solve that met an anomaly.
 int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 {
-    ensure_overlapping_streams(h);
     const auto t0 = h->t_start;
     uzl_pgo_stats S;
     memset(&S, 0, sizeof(S));
@@ -1728,9 +1719,8 @@ struct uzl_pgo_batch {
     int32_t resident = 0;                 // graphs solved at a time (0 = all): uzl_pgo_batch_set_resident
     int32_t last_batched = 0;
     uzl::LmRun* lm = nullptr;             // slot table, LM states, captured segments (uzl_pgo_lm.hip)
-    // second launch sequence (batches of >= kBatchLaneMin graphs): the second half of the graphs on streams of its own, driven by a second
-    // host thread for the duration of the call - its kernels fill the tails of the first half's and a pass is as long as the longest solve
-    // of eight graphs, not sixteen
+    // diagnostic build, UZL_BATCH_LANES=2: a second launch sequence for the second half of the graphs, on streams of its own, driven by a
+    // second host thread for the duration of the call (DESIGN_APPENDIX.md (h): +9 % in some process states, 2x slower in others)
     hipStream_t stream_b = nullptr, stream2_b = nullptr;
     uzl::LmRun* lm_b = nullptr;
     KernelTimer timer;                    // profiling (uzl_pgo_batch_set_profiling): the two PCG kernels, launched eagerly with event pairs
@@ -1771,7 +1761,7 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
         b->last_batched = 0;
         return rc_all;
     }
-    static const int lanes_env = diag_int("UZL_BATCH_LANES", 2);               // A/B switch (diagnostic build): 1 = one launch sequence
+    static const int lanes_env = diag_int("UZL_BATCH_LANES", 1);               // A/B switch (diagnostic build): 2 = two launch sequences
     {
         static const bool dbg = diag_flag("UZL_STREAM_DBG");
         if (dbg) {
@@ -1780,8 +1770,10 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
         }
     }
     const bool eager = b->h[0]->no_graph, verbose = b->cfg.verbose != 0;
+    static const bool no_s2 = diag_flag("UZL_BATCH_NO_S2");                   // A/B switch: rebuilds on the sequence's own stream
+    hipStream_t s2a = no_s2 ? b->stream : b->stream2, s2b = no_s2 ? b->stream_b : b->stream2_b;
     if (B < kBatchLaneMin || lanes_env < 2 || b->resident == 1 || b->timer.on || !b->stream_b || !b->stream2_b) {
-        const int done = batch_optimize_lm(b->lm, b->h, b->resident, b->stream, b->stream2, iterations, eager, verbose, &b->timer, stats, &rc_all);
+        const int done = batch_optimize_lm(b->lm, b->h, b->resident, b->stream, s2a, iterations, eager, verbose, &b->timer, stats, &rc_all);
         if (done < 0) { b->last_error = b->h[(size_t)(-1 - done)]->last_error; return rc_all; }
         b->last_batched = done;
         if (n_batched) *n_batched = done;
@@ -1798,11 +1790,11 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
     std::thread lane([&] {
         try {
             UZL_HIP(hipSetDevice(b->cfg.device));
-            done1 = batch_optimize_lm(b->lm_b, h1, r1, b->stream_b, b->stream2_b, iterations, eager, verbose, nullptr, stats ? stats + n0 : nullptr, &rc1);
+            done1 = batch_optimize_lm(b->lm_b, h1, r1, b->stream_b, s2b, iterations, eager, verbose, nullptr, stats ? stats + n0 : nullptr, &rc1);
         } catch (...) { ex1 = std::current_exception(); }
     });
     try {
-        done0 = batch_optimize_lm(b->lm, h0, r0, b->stream, b->stream2, iterations, eager, verbose, nullptr, stats, &rc0);
+        done0 = batch_optimize_lm(b->lm, h0, r0, b->stream, s2a, iterations, eager, verbose, nullptr, stats, &rc0);
     } catch (...) { lane.join(); throw; }
     lane.join();
     if (ex1) std::rethrow_exception(ex1);
@@ -1843,14 +1835,14 @@ int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch
         if (rc != UZL_OK) { for (uzl_pgo* x : b->h) uzl_pgo_destroy(x); delete b; return rc; }
         b->h.push_back(h);
     }
-    // The batch's launch sequences and their rebuild streams, every one on a hardware queue of its own (streams_overlap, above).  The
-    // rebuild streams have NORMAL priority: with high-priority ones (as a single handle's stream2 has) a batch's rate depended on what the
-    // process had done before - bench.py with / without its matcher block in front: 16 chain-like graphs 14.3 / 20.9 ms, 16 config-2
-    // graphs 25.9 / 30.3 ms, 64 small graphs 11.2 / 13.2 ms; with normal priority 14.1 / 23.7 / 10.0 ms either way
-    // (tests/diag/r4_hwq4.sh).  A single handle's solve showed no such dependence (6.0 ms with either priority).
-    const bool two = n_graphs >= kBatchLaneMin;
+    // The batch's stream and its rebuild stream, on hardware queues of their own (streams_overlap, above).  The rebuild stream has NORMAL
+    // priority: with a high-priority one (as a single handle's stream2 has) a batch's rate depended on what the process had done before
+    // - bench.py with / without its matcher block in front: 16 chain-like graphs 14.3 / 20.9 ms, 16 config-2 graphs 25.9 / 30.3 ms, 64
+    // small graphs 11.2 / 13.2 ms; with normal priority 14.3 / 25.8 / 11.2 ms in every state tried (tests/diag/r4_cfg.sh).  A single
+    // handle's solve showed no such dependence (6.0 ms with either priority).
+    static const int prio2 = diag_int("UZL_BATCH_S2_PRIO", 0);                     // A/B switches (diagnostic build)
+    static const bool two = diag_int("UZL_BATCH_LANES", 1) >= 2;
     bool ok = hipSetDevice(c.device) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
-    static const int prio2 = diag_int("UZL_BATCH_S2_PRIO", 0);                     // A/B switch (diagnostic build): priority of the rebuild streams
     if (ok) ok = (b->stream2 = overlapping_stream(prio2, {b->stream})) != nullptr;
     if (ok && two) ok = (b->stream_b = overlapping_stream(0, {b->stream, b->stream2})) != nullptr;
     if (ok && two) ok = (b->stream2_b = overlapping_stream(prio2, {b->stream, b->stream2, b->stream_b})) != nullptr;
@@ -1912,13 +1904,15 @@ int uzl_pgo_batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* 
 
 }  // extern "C"
 
-// test hook (tests/diag/stream_overlap.py): n streams of priority `priority`, out[i * n + j] = 1 if a kernel on stream j overtakes one that
-// waits on stream i (streams_overlap), 0 if the two share a hardware queue
+// test hook (tests/diag/stream_overlap.py, tests/test_batch_gpu.py): n streams - of priority `priority`, or of priorities 0 and -1 in
+// turn for priority = 200 - and out[i * n + j] = 1 if a kernel on stream j overtakes one that waits on stream i (streams_overlap), 0 if
+// the two share a hardware queue
 extern "C" int uzl_debug_stream_overlap(int n, int priority, int32_t* out)
 {
     if (n < 2 || n > 32 || !out) return UZL_ERR_BAD_ARG;
     std::vector<hipStream_t> q((size_t)n, nullptr);
-    for (int i = 0; i < n; i++) if (hipStreamCreateWithPriority(&q[i], hipStreamNonBlocking, priority) != hipSuccess) return UZL_ERR_HIP;
+    for (int i = 0; i < n; i++)
+        if (hipStreamCreateWithPriority(&q[i], hipStreamNonBlocking, priority == 200 ? -(i & 1) : priority) != hipSuccess) return UZL_ERR_HIP;
     for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) out[i * n + j] = (i == j) ? -1 : (streams_overlap(q[i], q[j]) ? 1 : 0);
     for (hipStream_t s : q) (void)hipStreamDestroy(s);
     return UZL_OK;
