@@ -403,7 +403,9 @@ int  uzl_pgo_rccl_ranks(uzl_pgo* h);
  * (same number of free vertices per level, e.g. same-size graphs); otherwise, and for any graph whose solve meets an anomaly, the
  * call falls back to one uzl_pgo_optimize per graph - same results, no batching.  *n_batched = graphs solved in the batch.
  * stats[g].solve_ms of a batched graph is the wall time of the whole batch call.  The graphs' handles must not be used from other
- * threads while uzl_pgo_batch_optimize runs (it drives them without taking their mutexes). */
+ * threads while uzl_pgo_batch_optimize runs (it drives them without taking their mutexes).  From 12 graphs on the call solves the
+ * second half of the graphs as a launch sequence of its own, from a helper thread that it starts and joins before it returns
+ * (results per graph are the same either way). */
 typedef struct uzl_pgo_batch uzl_pgo_batch;
 int  uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch** out);
 void uzl_pgo_batch_destroy(uzl_pgo_batch* b);

@@ -143,7 +143,7 @@ struct MlHot {
 };
 
 constexpr int kBatchMax = 256;      // graphs per uzl_pgo_batch
-constexpr int kBatchLaneMin = 12;   // diagnostic build, UZL_BATCH_LANES=2: from this many graphs on a batch runs as two launch sequences
+constexpr int kBatchLaneMin = 12;   // from this many graphs on a batch runs as two launch sequences (uzl_pgo_batch, uzl_pgo.hip)
 
 // ---- Schur reduction of chain interiors: device view (recurrences and host-side plan in pgo_schur.hpp) ----------------------------
 constexpr int kSchurElim = 78;        // doubles kept per eliminated vertex: u (6) | W (36) | T (36)

@@ -10,66 +10,86 @@
 
 using namespace uzl;
 
-// ---- streams whose kernels really overlap ---------------------------------------------------------------------------------------
+// ---- streams that do not stand in each other's way ---------------------------------------------------------------------------------
 // A HIP stream is served by one of the runtime's hardware queues (four per priority by default: GPU_MAX_HW_QUEUES), handed out at
-// hipStreamCreate, least used first - ten streams of one priority made in a row land on queues A B C D D C B A D C
-// (tests/diag/stream_overlap.py) - and every packet of a queue waits for the one before it.  Two streams that share a queue therefore
-// run one behind the other: a rebuild "beside" the PCG then sits IN FRONT of it (a batch of 16 config-2 graphs 25.8 -> 28.2 ms).
-// Nothing tells a process which queue a stream got, but it can be seen: a kernel that waits 200 us on one stream, an empty one on the
-// other - if the empty one ends first, the two overlap.  A stream that has to overlap with another of its priority is made until it
-// does; the rejects are held until then, so that the next one lands elsewhere.
+// hipStreamCreate, least used first, and the driver puts the queues on the GPU's four compute pipes in the order they were first made.
+// Streams on one queue run strictly one behind the other.  Streams on two queues of one PIPE do overlap for a single kernel - but two
+// chains of dependent kernels, one on each, take 2.7x the time of one chain (measured: tests/diag/stream_overlap.py chain), worse than
+// running them one after the other.  Which streams of a process collide either way depends on every stream it has made before: a batch
+// whose rebuild stream sat on the solver stream's pipe lost 15 - 45 % (16 chain-like graphs 14.3 -> 20.9 ms), two launch sequences on
+// one pipe ran 2x slower than one sequence.  Nothing tells a process where a stream landed, but it can be measured: a chain of 32
+// dependent ~4-us kernels on one stream alone, then the same chain on both at once.  Streams that have to run side by side are made -
+// first at the priority asked for, then at the other one: the two priorities' queues sit on different pipes more often than not - until
+// the pair takes less than 1.5x the single chain (independent pairs: 1.05 - 1.25x; one pipe: 2.7x; one queue: 2.0x); the rejects are
+// held until then, so that the next stream lands elsewhere.
 namespace {
-__global__ void spin_kernel(unsigned ticks)
+__global__ void chain_kernel(unsigned ticks)
 {
     const unsigned long long t0 = wall_clock64();            // 100 MHz
     while (wall_clock64() - t0 < ticks) {}
 }
-__global__ void noop_kernel() {}
-bool streams_overlap(hipStream_t a, hipStream_t b)
+bool streams_independent(hipStream_t a, hipStream_t b, double* ratio = nullptr)
 {
-    hipEvent_t ea = nullptr, eb = nullptr;
-    bool overlap = true;                                       // (on any error: leave the streams as they are)
-    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess) {
-        // (a stream's first launch can take longer than the wait it is measured against: both streams have run a kernel before the probe)
-        hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(1), 0, a);
-        hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(1), 0, b);
-        (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
-        for (int probe = 0; probe < 2; probe++) {              // "shares a queue" must be seen twice: anything else on the GPU can hold the empty kernel back once
-            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, a, 20000u);
-            (void)hipEventRecord(ea, a);
-            hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(1), 0, b);
-            (void)hipEventRecord(eb, b);
-            overlap = hipEventSynchronize(eb) != hipSuccess || hipEventQuery(ea) == hipErrorNotReady;
-            (void)hipEventSynchronize(ea);
-            if (overlap) break;
+    constexpr int kLen = 32, kWgs = 1000;
+    auto run = [&](bool both) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < kLen; k++) {
+            hipLaunchKernelGGL(chain_kernel, dim3(kWgs), dim3(256), 0, a, 400u);
+            if (both) hipLaunchKernelGGL(chain_kernel, dim3(kWgs), dim3(256), 0, b, 400u);
         }
-        (void)hipGetLastError();
-    }
-    if (ea) (void)hipEventDestroy(ea);
-    if (eb) (void)hipEventDestroy(eb);
-    return overlap;
+        (void)hipStreamSynchronize(a);
+        if (both) (void)hipStreamSynchronize(b);
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    };
+    (void)run(true);                                            // (first launches of a stream take longer)
+    const double alone = std::min(run(false), run(false));
+    const double pair = std::min(run(true), run(true));          // (anything else on the GPU can hold a run back once)
+    (void)hipGetLastError();
+    if (ratio) *ratio = pair / alone;
+    return pair < 1.5 * alone;
 }
-// a new stream (priority 0 or -1) that overlaps with every stream of `others`; after eight attempts the last one made (a shared queue
-// is slower, not wrong); nullptr only if the runtime makes no stream at all
-hipStream_t overlapping_stream(int priority, std::initializer_list<hipStream_t> others)
+// a new stream that is independent of every stream of `others`, of priority `priority` (0 or -1) if one can be had, else of the other
+// one; nullptr if eight attempts found none (or the runtime makes no stream at all)
+hipStream_t independent_stream(int priority, std::initializer_list<hipStream_t> others)
 {
+    static const bool dbg = diag_flag("UZL_STREAM_DBG");
     std::vector<hipStream_t> rejects;
     hipStream_t got = nullptr;
     for (int attempt = 0; attempt < 8 && !got; attempt++) {
+        const int pr = attempt < 4 ? priority : (priority == 0 ? -1 : 0);
         hipStream_t q = nullptr;
-        if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, priority) != hipSuccess) break;
+        if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, pr) != hipSuccess) break;
         bool ok = true;
-        for (hipStream_t o : others) if (o && !streams_overlap(o, q)) { ok = false; break; }
+        double worst = 0.;
+        for (hipStream_t o : others) {
+            double r = 0.;
+            if (o && !streams_independent(o, q, &r)) ok = false;
+            worst = std::max(worst, r);
+            if (!ok) break;
+        }
+        if (dbg) fprintf(stderr, "[uzl] independent_stream(%d other(s)): attempt %d, priority %d: pair / single chain %.2f -> %s\n", (int)others.size(), attempt, pr, worst, ok ? "kept" : "rejected");
         if (ok) got = q; else rejects.push_back(q);
-        static const bool dbg = diag_flag("UZL_STREAM_DBG");
-        if (dbg) fprintf(stderr, "[uzl] overlapping_stream(priority %d, %d other(s)): attempt %d %s\n", priority, (int)others.size(), attempt, ok ? "overlaps" : "shares a queue");
     }
-    if (!got && !rejects.empty()) { got = rejects.back(); rejects.pop_back(); }
     for (hipStream_t r : rejects) (void)hipStreamDestroy(r);
     return got;
 }
 }  // namespace
 
+namespace uzl {
+// before the first solve of a handle: its rebuild stream must not stand in its solver stream's way (checked once, ~1 ms; the batch's
+// member handles never get here unless one of them falls back to a solve of its own)
+void ensure_independent_streams(uzl_pgo* h)
+{
+    if (h->streams_checked) return;
+    h->streams_checked = true;
+    if (!h->stream || !h->stream2 || streams_independent(h->stream, h->stream2)) return;
+    hipStream_t q = independent_stream(-1, {h->stream});         // (the old one stays alive meanwhile: it holds its place)
+    if (!q) return;
+    (void)hipStreamSynchronize(h->stream2);
+    (void)hipStreamDestroy(h->stream2);
+    h->stream2 = q;
+}
+}  // namespace uzl
 
 // ---- RCCL through dlopen: the collective library is only loaded by processes that shard a graph -----------------------------
 #include <dlfcn.h>
@@ -1081,6 +1101,7 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 // The host-driven loop.  Called through do_optimize (structure prepared, device set), or by do_optimize_lm for a solve that met an anomaly.
 int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 {
+    ensure_independent_streams(h);
     const auto t0 = h->t_start;
     uzl_pgo_stats S;
     memset(&S, 0, sizeof(S));
@@ -1719,8 +1740,9 @@ struct uzl_pgo_batch {
     int32_t resident = 0;                 // graphs solved at a time (0 = all): uzl_pgo_batch_set_resident
     int32_t last_batched = 0;
     uzl::LmRun* lm = nullptr;             // slot table, LM states, captured segments (uzl_pgo_lm.hip)
-    // diagnostic build, UZL_BATCH_LANES=2: a second launch sequence for the second half of the graphs, on streams of its own, driven by a
-    // second host thread for the duration of the call (DESIGN_APPENDIX.md (h): +9 % in some process states, 2x slower in others)
+    // second launch sequence (batches of >= kBatchLaneMin graphs): the second half of the graphs on streams of its own, driven by a second
+    // host thread for the duration of the call - its kernels fill the tails of the first half's and a pass is as long as the longest solve
+    // of eight graphs, not sixteen.  Only with four streams that do not stand in each other's way (uzl_pgo_batch_create).
     hipStream_t stream_b = nullptr, stream2_b = nullptr;
     uzl::LmRun* lm_b = nullptr;
     KernelTimer timer;                    // profiling (uzl_pgo_batch_set_profiling): the two PCG kernels, launched eagerly with event pairs
@@ -1761,12 +1783,12 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
         b->last_batched = 0;
         return rc_all;
     }
-    static const int lanes_env = diag_int("UZL_BATCH_LANES", 1);               // A/B switch (diagnostic build): 2 = two launch sequences
+    static const int lanes_env = diag_int("UZL_BATCH_LANES", 2);               // A/B switch (diagnostic build): 1 = one launch sequence
     {
         static const bool dbg = diag_flag("UZL_STREAM_DBG");
         if (dbg) {
             hipStream_t q[4] = {b->stream, b->stream2, b->stream_b, b->stream2_b};
-            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (i != j && q[i] && q[j]) fprintf(stderr, "[uzl] batch streams %d -> %d: %s\n", i, j, streams_overlap(q[i], q[j]) ? "overlap" : "SHARE A QUEUE");
+            for (int i = 0; i < 4; i++) for (int j = i + 1; j < 4; j++) if (q[i] && q[j]) { double r = 0.; (void)streams_independent(q[i], q[j], &r); fprintf(stderr, "[uzl] batch streams %d, %d: pair / single chain %.2f\n", i, j, r); }
         }
     }
     const bool eager = b->h[0]->no_graph, verbose = b->cfg.verbose != 0;
@@ -1835,17 +1857,20 @@ int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch
         if (rc != UZL_OK) { for (uzl_pgo* x : b->h) uzl_pgo_destroy(x); delete b; return rc; }
         b->h.push_back(h);
     }
-    // The batch's stream and its rebuild stream, on hardware queues of their own (streams_overlap, above).  The rebuild stream has NORMAL
-    // priority: with a high-priority one (as a single handle's stream2 has) a batch's rate depended on what the process had done before
-    // - bench.py with / without its matcher block in front: 16 chain-like graphs 14.3 / 20.9 ms, 16 config-2 graphs 25.9 / 30.3 ms, 64
-    // small graphs 11.2 / 13.2 ms; with normal priority 14.3 / 25.8 / 11.2 ms in every state tried (tests/diag/r4_cfg.sh).  A single
-    // handle's solve showed no such dependence (6.0 ms with either priority).
+    // The batch's streams: none in another's way (streams_independent, above).  Batches of kBatchLaneMin graphs and more get a second
+    // launch sequence if four such streams can be had; a rebuild stream that cannot is replaced by any stream (slower, not wrong).
     static const int prio2 = diag_int("UZL_BATCH_S2_PRIO", 0);                     // A/B switches (diagnostic build)
-    static const bool two = diag_int("UZL_BATCH_LANES", 1) >= 2;
+    static const bool two_on = diag_int("UZL_BATCH_LANES", 2) >= 2;
     bool ok = hipSetDevice(c.device) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
-    if (ok) ok = (b->stream2 = overlapping_stream(prio2, {b->stream})) != nullptr;
-    if (ok && two) ok = (b->stream_b = overlapping_stream(0, {b->stream, b->stream2})) != nullptr;
-    if (ok && two) ok = (b->stream2_b = overlapping_stream(prio2, {b->stream, b->stream2, b->stream_b})) != nullptr;
+    if (ok && two_on && n_graphs >= kBatchLaneMin) b->stream_b = independent_stream(0, {b->stream});
+    if (ok) {
+        b->stream2 = independent_stream(prio2, {b->stream, b->stream_b});
+        if (!b->stream2) ok = hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, prio2) == hipSuccess;
+    }
+    if (ok && b->stream_b) {
+        b->stream2_b = independent_stream(prio2, {b->stream, b->stream_b, b->stream2});
+        if (!b->stream2_b) { (void)hipStreamDestroy(b->stream_b); b->stream_b = nullptr; }      // no fourth: one sequence
+    }
     if (!ok) {
         for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
         for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b}) if (q) (void)hipStreamDestroy(q);
@@ -1905,15 +1930,20 @@ int uzl_pgo_batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* 
 }  // extern "C"
 
 // test hook (tests/diag/stream_overlap.py, tests/test_batch_gpu.py): n streams - of priority `priority`, or of priorities 0 and -1 in
-// turn for priority = 200 - and out[i * n + j] = 1 if a kernel on stream j overtakes one that waits on stream i (streams_overlap), 0 if
-// the two share a hardware queue
-extern "C" int uzl_debug_stream_overlap(int n, int priority, int32_t* out)
+// turn for priority = 200 - and out[i * n + j] = 100 x (two chains of dependent kernels on streams i and j at once / one chain on
+// stream i): streams_independent's measurement
+extern "C" int uzl_debug_stream_pairs(int n, int priority, int32_t* out)
 {
-    if (n < 2 || n > 32 || !out) return UZL_ERR_BAD_ARG;
+    if (n < 2 || n > 16 || !out) return UZL_ERR_BAD_ARG;
     std::vector<hipStream_t> q((size_t)n, nullptr);
     for (int i = 0; i < n; i++)
         if (hipStreamCreateWithPriority(&q[i], hipStreamNonBlocking, priority == 200 ? -(i & 1) : priority) != hipSuccess) return UZL_ERR_HIP;
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) out[i * n + j] = (i == j) ? -1 : (streams_overlap(q[i], q[j]) ? 1 : 0);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double r = 0.;
+            if (i != j) (void)streams_independent(q[i], q[j], &r);
+            out[i * n + j] = (i == j) ? -1 : (int32_t)(100. * r + 0.5);
+        }
     for (hipStream_t s : q) (void)hipStreamDestroy(s);
     return UZL_OK;
 }
