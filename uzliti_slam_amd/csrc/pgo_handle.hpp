@@ -158,7 +158,6 @@ struct uzl_pgo {
     int ml_ix = 0;
     bool ml_pending = false;                   // a rebuild into copy ml_ix ^ 1 is in flight on stream2
     hipStream_t stream2 = nullptr;
-    bool streams_checked = false;              // stream and stream2 measured side by side (ensure_independent_streams, uzl_pgo.hip)
     hipEvent_t ev_lin = nullptr, ev_setup = nullptr;
     DevBuf<double> d_scal2;                    // lambda slot (scal[3]) for the kernels of an asynchronous rebuild
     double lambda_now = 0.;          // lambda of the current trial
@@ -215,7 +214,6 @@ struct LmRun;                                          // captured passes + slot
 void lm_run_destroy(LmRun* r);
 bool lm_eligible(const uzl_pgo* h);
 int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);
-void ensure_independent_streams(uzl_pgo* h);
 bool lm_batch_eligible(const std::vector<uzl_pgo*>& hs);
 int batch_optimize_lm(LmRun*& R, const std::vector<uzl_pgo*>& hs, int resident, hipStream_t s, hipStream_t s2, int32_t iterations, bool eager, bool verbose, KernelTimer* timer,
                       uzl_pgo_stats* stats, int* rc_all);

@@ -17,8 +17,9 @@ using namespace uzl;
 // chains of dependent kernels, one on each, take 2.7x the time of one chain (measured: tests/diag/stream_overlap.py chain), worse than
 // running them one after the other.  Which streams of a process collide either way depends on every stream it has made before: a batch
 // whose rebuild stream sat on the solver stream's pipe lost 15 - 45 % (16 chain-like graphs 14.3 -> 20.9 ms), two launch sequences on
-// one pipe ran 2x slower than one sequence.  Nothing tells a process where a stream landed, but it can be measured: a chain of 32
-// dependent ~4-us kernels on one stream alone, then the same chain on both at once.  Streams that have to run side by side are made -
+// one pipe ran 2x slower than one sequence (a single handle's solve with its 0.25-ms rebuilds did not move measurably: handles take
+// their streams as they come).  Nothing tells a process where a stream landed, but it can be measured: a chain of 32 dependent ~4-us
+// kernels on one stream alone, then the same chain on both at once.  A batch's streams, which have to run side by side, are made -
 // first at the priority asked for, then at the other one: the two priorities' queues sit on different pipes more often than not - until
 // the pair takes less than 1.5x the single chain (independent pairs: 1.05 - 1.25x; one pipe: 2.7x; one queue: 2.0x); the rejects are
 // held until then, so that the next stream lands elsewhere.
@@ -75,21 +76,6 @@ hipStream_t independent_stream(int priority, std::initializer_list<hipStream_t> 
 }
 }  // namespace
 
-namespace uzl {
-// before the first solve of a handle: its rebuild stream must not stand in its solver stream's way (checked once, ~1 ms; the batch's
-// member handles never get here unless one of them falls back to a solve of its own)
-void ensure_independent_streams(uzl_pgo* h)
-{
-    if (h->streams_checked) return;
-    h->streams_checked = true;
-    if (!h->stream || !h->stream2 || streams_independent(h->stream, h->stream2)) return;
-    hipStream_t q = independent_stream(-1, {h->stream});         // (the old one stays alive meanwhile: it holds its place)
-    if (!q) return;
-    (void)hipStreamSynchronize(h->stream2);
-    (void)hipStreamDestroy(h->stream2);
-    h->stream2 = q;
-}
-}  // namespace uzl
 
 // ---- RCCL through dlopen: the collective library is only loaded by processes that shard a graph -----------------------------
 #include <dlfcn.h>
@@ -1101,7 +1087,6 @@ int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 // The host-driven loop.  Called through do_optimize (structure prepared, device set), or by do_optimize_lm for a solve that met an anomaly.
 int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 {
-    ensure_independent_streams(h);
     const auto t0 = h->t_start;
     uzl_pgo_stats S;
     memset(&S, 0, sizeof(S));

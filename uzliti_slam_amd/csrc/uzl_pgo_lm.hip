@@ -467,7 +467,6 @@ bool lm_eligible(const uzl_pgo* h)
 
 int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
 {
-    ensure_independent_streams(h);
     hipStream_t s = h->stream;
     if (!h->lm) h->lm = new_run();
     LmRun* R = h->lm;
