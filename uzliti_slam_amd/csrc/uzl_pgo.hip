@@ -80,6 +80,7 @@ hipStream_t independent_stream(int priority, std::initializer_list<hipStream_t> 
 // ---- RCCL through dlopen: the collective library is only loaded by processes that shard a graph -----------------------------
 #include <dlfcn.h>
 #include <exception>
+#include <system_error>
 #include <thread>
 namespace {
 struct RcclApi {
@@ -1779,13 +1780,14 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
     const bool eager = b->h[0]->no_graph, verbose = b->cfg.verbose != 0;
     static const bool no_s2 = diag_flag("UZL_BATCH_NO_S2");                   // A/B switch: rebuilds on the sequence's own stream
     hipStream_t s2a = no_s2 ? b->stream : b->stream2, s2b = no_s2 ? b->stream_b : b->stream2_b;
-    if (B < kBatchLaneMin || lanes_env < 2 || b->resident == 1 || b->timer.on || !b->stream_b || !b->stream2_b) {
+    auto one_sequence = [&]() {
         const int done = batch_optimize_lm(b->lm, b->h, b->resident, b->stream, s2a, iterations, eager, verbose, &b->timer, stats, &rc_all);
         if (done < 0) { b->last_error = b->h[(size_t)(-1 - done)]->last_error; return rc_all; }
         b->last_batched = done;
         if (n_batched) *n_batched = done;
         return rc_all;
-    }
+    };
+    if (B < kBatchLaneMin || lanes_env < 2 || b->resident == 1 || b->timer.on || !b->stream_b || !b->stream2_b) return one_sequence();
     // ---- two launch sequences: graphs [0, n0) from this thread, [n0, B) from a second one.  The halves share nothing but the device (every
     //      graph has its handle, every half its streams, slot table and captured segments), and a graph's result does not depend on its
     //      neighbours in the batch, so the split changes no bit of any result.
@@ -1794,12 +1796,15 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
     const int r0 = b->resident > 0 ? (b->resident + 1) / 2 : 0, r1 = b->resident > 0 ? b->resident / 2 : 0;      // (resident >= 2 here: r0 + r1 = resident)
     int rc0 = UZL_OK, rc1 = UZL_OK, done0 = 0, done1 = 0;
     std::exception_ptr ex1;
-    std::thread lane([&] {
-        try {
-            UZL_HIP(hipSetDevice(b->cfg.device));
-            done1 = batch_optimize_lm(b->lm_b, h1, r1, b->stream_b, s2b, iterations, eager, verbose, nullptr, stats ? stats + n0 : nullptr, &rc1);
-        } catch (...) { ex1 = std::current_exception(); }
-    });
+    std::thread lane;
+    try {
+        lane = std::thread([&] {
+            try {
+                UZL_HIP(hipSetDevice(b->cfg.device));
+                done1 = batch_optimize_lm(b->lm_b, h1, r1, b->stream_b, s2b, iterations, eager, verbose, nullptr, stats ? stats + n0 : nullptr, &rc1);
+            } catch (...) { ex1 = std::current_exception(); }
+        });
+    } catch (const std::system_error&) { return one_sequence(); }              // (no second thread to be had)
     try {
         done0 = batch_optimize_lm(b->lm, h0, r0, b->stream, s2a, iterations, eager, verbose, nullptr, stats, &rc0);
     } catch (...) { lane.join(); throw; }
