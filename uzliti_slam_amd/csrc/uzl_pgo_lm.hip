@@ -41,11 +41,12 @@ struct LmRun {
     uint64_t gen = ~0ull;                    // single handle: structure generation the slot and the captured segments belong to
     int solves_of_gen = 0;                   // optimizes of the current structure so far (single-graph driver)
     int first_solve_its = 0;                 // PCG iterations of the first solve of the last optimize (sizes the first pass of the next)
-    // single-graph driver: PCG iterations of every trial of the last optimize of THIS structure and of the running one.  A re-optimisation
+    // PCG iterations of every trial of the last drive's jobs and of the running one's.  A re-optimisation
     // of an unchanged graph (uzl_pgo_reset, a timer-driven one) walks through much the same solves, trial for trial: where the count RISES from one trial to
     // the next (config 2: 24 -> 40 iterations from the first trial to the second) the last solve alone under-predicts and the solve
     // needs a second and third pass (tail, look and a fresh launch sequence each)
-    std::vector<int> trial_its_prev, trial_its_cur;
+    std::vector<std::vector<int>> trial_its_prev, trial_its_cur;      // [job][trial]
+    std::vector<uint64_t> hist_gen;          // structure generation of every job the counts belong to (a batch: its graphs in order)
     struct Seg { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; };
     Seg setup, reb, pcg_long;
     void drop(Seg& q) { if (q.x) { (void)hipGraphExecDestroy(q.x); q.x = nullptr; } if (q.g) { (void)hipGraphDestroy(q.g); q.g = nullptr; } }
@@ -293,7 +294,15 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
     };
     for (int sl = 0; sl < nS; sl++) load_slot(sl);
     R->join_pending = false;
-    if (Q == 1) { R->trial_its_prev.swap(R->trial_its_cur); R->trial_its_cur.clear(); } else { R->trial_its_prev.clear(); R->trial_its_cur.clear(); }
+    {   // the last drive's counts are this drive's history where job j is the same structure again
+        bool same = R->hist_gen.size() == (size_t)Q;
+        for (int j = 0; same && j < Q; j++) same = R->hist_gen[(size_t)j] == jobs[(size_t)j].h->structure_gen;
+        if (same) R->trial_its_prev.swap(R->trial_its_cur); else R->trial_its_prev.clear();
+        R->trial_its_prev.resize((size_t)Q);
+        R->trial_its_cur.assign((size_t)Q, std::vector<int>());
+        R->hist_gen.resize((size_t)Q);
+        for (int j = 0; j < Q; j++) R->hist_gen[(size_t)j] = jobs[(size_t)j].h->structure_gen;
+    }
     struct Drain {                           // an exception must not leave a rebuild running on stream2 behind the caller's back
         LmRun* R; hipStream_t s2;
         ~Drain() { if (R->join_pending) { (void)hipStreamSynchronize(s2); R->join_pending = false; } }
@@ -338,7 +347,10 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
                 // one: a re-optimisation), a fresh run starts with two long replays.
                 w = v.pcg_last > 0 ? ((v.pcg_last + 2) & ~1) : (R->first_solve_its > 0 ? ((R->first_solve_its + 2) & ~1) : 2 * kLong);
                 static const bool no_history = diag_flag("UZL_LM_NO_HISTORY");               // A/B switch
-                if (!no_history && Q == 1 && (size_t)v.st_lm_trials < R->trial_its_prev.size()) w = std::max(w, (R->trial_its_prev[(size_t)v.st_lm_trials] + 2) & ~1);
+                {
+                    const std::vector<int>& hist = R->trial_its_prev[(size_t)slot_job[sl]];
+                    if (!no_history && (size_t)v.st_lm_trials < hist.size()) w = std::max(w, (hist[(size_t)v.st_lm_trials] + 2) & ~1);
+                }
                 w = std::min(w, ((v.max_it + 1) & ~1));
             }
             want = std::max(want, w);
@@ -392,7 +404,10 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
                 fprintf(stderr, "[uzl_pgo] pass %d, graph %d -> it %d trial %d phase %d: pcg %d done %d (last solve %d) lambda %.3e chi2 %.9g |r|2/|b|2 %.3e need %d\n", passes - 1,
                         slot_job[sl], v.it, v.qmax, v.phase, v.flags[1], v.flags[0], v.pcg_last, v.lambda, v.chi_cur, snap[sl].scal[7], v.need);
             if (v.st_lm_trials == 1 && v.pcg_last > 0 && slot_job[sl] == 0) R->first_solve_its = v.pcg_last;
-            if (Q == 1 && v.st_lm_trials > 0 && (size_t)v.st_lm_trials > R->trial_its_cur.size()) R->trial_its_cur.resize((size_t)v.st_lm_trials, v.pcg_last);
+            {
+                std::vector<int>& cur = R->trial_its_cur[(size_t)slot_job[sl]];
+                if (v.st_lm_trials > 0 && (size_t)v.st_lm_trials > cur.size()) cur.resize((size_t)v.st_lm_trials, v.pcg_last);
+            }
             if (v.phase == kLmDone || v.phase == kLmAnomaly) {
                 J.last = snap[sl]; J.finished = true; J.anomaly = v.phase == kLmAnomaly;
                 n_active--; refill = true;
@@ -479,7 +494,7 @@ int do_optimize_lm(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         R->shape = make_shape({h}, 1, false);
         R->gen = h->structure_gen;
         R->solves_of_gen = 0;
-        R->trial_its_prev.clear(); R->trial_its_cur.clear();      // (a grown graph's solves are not the old graph's: measured on config 5, +5 % per solve with the old counts)
+        R->hist_gen.clear();                                       // (a grown graph's solves are not the old graph's: measured on config 5, +5 % per solve with the old counts)
         h->structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
     }
     std::vector<LmJob> jobs(1);
