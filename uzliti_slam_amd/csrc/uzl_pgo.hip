@@ -1787,7 +1787,8 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
         if (n_batched) *n_batched = done;
         return rc_all;
     };
-    if (B < kBatchLaneMin || lanes_env < 2 || b->resident == 1 || b->timer.on || !b->stream_b || !b->stream2_b) return one_sequence();
+    static const int lane_min = diag_int("UZL_BATCH_LANE_MIN", kBatchLaneMin);      // A/B switch (diagnostic build)
+    if (B < lane_min || lanes_env < 2 || b->resident == 1 || b->timer.on || !b->stream_b || !b->stream2_b) return one_sequence();
     // ---- two launch sequences: graphs [0, n0) from this thread, [n0, B) from a second one.  The halves share nothing but the device (every
     //      graph has its handle, every half its streams, slot table and captured segments), and a graph's result does not depend on its
     //      neighbours in the batch, so the split changes no bit of any result.
@@ -1852,7 +1853,7 @@ int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch
     static const int prio2 = diag_int("UZL_BATCH_S2_PRIO", 0);                     // A/B switches (diagnostic build)
     static const bool two_on = diag_int("UZL_BATCH_LANES", 2) >= 2;
     bool ok = hipSetDevice(c.device) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
-    if (ok && two_on && n_graphs >= kBatchLaneMin) b->stream_b = independent_stream(0, {b->stream});
+    if (ok && two_on && n_graphs >= diag_int("UZL_BATCH_LANE_MIN", kBatchLaneMin)) b->stream_b = independent_stream(0, {b->stream});
     if (ok) {
         b->stream2 = independent_stream(prio2, {b->stream, b->stream_b});
         if (!b->stream2) ok = hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, prio2) == hipSuccess;
