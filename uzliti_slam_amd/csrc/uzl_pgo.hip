@@ -1731,6 +1731,9 @@ struct uzl_pgo_batch {
     // of eight graphs, not sixteen.  Only with four streams that do not stand in each other's way (uzl_pgo_batch_create).
     hipStream_t stream_b = nullptr, stream2_b = nullptr;
     uzl::LmRun* lm_b = nullptr;
+    // diagnostic build, UZL_BATCH_LANES=4: four sequences, one per compute pipe, each with its rebuilds on its own stream
+    hipStream_t stream_x[2] = {nullptr, nullptr};
+    uzl::LmRun* lm_x[2] = {nullptr, nullptr};
     KernelTimer timer;                    // profiling (uzl_pgo_batch_set_profiling): the two PCG kernels, launched eagerly with event pairs
 };
 
@@ -1789,33 +1792,49 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
     };
     static const int lane_min = diag_int("UZL_BATCH_LANE_MIN", kBatchLaneMin);      // A/B switch (diagnostic build)
     if (B < lane_min || lanes_env < 2 || b->resident == 1 || b->timer.on || !b->stream_b || !b->stream2_b) return one_sequence();
-    // ---- two launch sequences: graphs [0, n0) from this thread, [n0, B) from a second one.  The halves share nothing but the device (every
-    //      graph has its handle, every half its streams, slot table and captured segments), and a graph's result does not depend on its
-    //      neighbours in the batch, so the split changes no bit of any result.
-    const int n0 = (B + 1) / 2;
-    const std::vector<uzl_pgo*> h0(b->h.begin(), b->h.begin() + n0), h1(b->h.begin() + n0, b->h.end());
-    const int r0 = b->resident > 0 ? (b->resident + 1) / 2 : 0, r1 = b->resident > 0 ? b->resident / 2 : 0;      // (resident >= 2 here: r0 + r1 = resident)
-    int rc0 = UZL_OK, rc1 = UZL_OK, done0 = 0, done1 = 0;
-    std::exception_ptr ex1;
-    std::thread lane;
+    // ---- L launch sequences: the graphs in L runs, the first from this thread, the others from helper threads.  The sequences share
+    //      nothing but the device (every graph has its handle, every sequence its streams, slot table and captured segments), and a graph's
+    //      result does not depend on its neighbours in the batch, so the split changes no bit of any result.
+    const bool four = lanes_env >= 4 && b->stream_x[0] && b->stream_x[1] && B >= 4 * (lane_min / 2) && (b->resident == 0 || b->resident >= 4);
+    const int L = four ? 4 : 2;
+    struct Lane { uzl::LmRun** lm; hipStream_t s, s2; int first, count, resident, rc, done; std::exception_ptr ex; };
+    std::vector<Lane> lanes((size_t)L);
+    {
+        uzl::LmRun** lms[4] = {&b->lm, &b->lm_b, &b->lm_x[0], &b->lm_x[1]};
+        hipStream_t ss[4] = {b->stream, b->stream_b, b->stream_x[0], b->stream_x[1]};
+        hipStream_t s2s[4] = {s2a, s2b, b->stream_x[0], b->stream_x[1]};
+        int first = 0, res_left = b->resident;
+        for (int l = 0; l < L; l++) {
+            const int count = (B - first + (L - l) - 1) / (L - l);
+            const int res = b->resident > 0 ? (res_left + (L - l) - 1) / (L - l) : 0;
+            lanes[(size_t)l] = Lane{lms[l], ss[l], four ? ss[l] : s2s[l], first, count, res, UZL_OK, 0, nullptr};
+            first += count; res_left -= res;
+        }
+    }
+    auto run_lane = [&](Lane& ln) {
+        try {
+            UZL_HIP(hipSetDevice(b->cfg.device));
+            const std::vector<uzl_pgo*> hs(b->h.begin() + ln.first, b->h.begin() + ln.first + ln.count);
+            ln.done = batch_optimize_lm(*ln.lm, hs, ln.resident, ln.s, ln.s2, iterations, eager, verbose, nullptr, stats ? stats + ln.first : nullptr, &ln.rc);
+        } catch (...) { ln.ex = std::current_exception(); }
+    };
+    std::vector<std::thread> helpers;
     try {
-        lane = std::thread([&] {
-            try {
-                UZL_HIP(hipSetDevice(b->cfg.device));
-                done1 = batch_optimize_lm(b->lm_b, h1, r1, b->stream_b, s2b, iterations, eager, verbose, nullptr, stats ? stats + n0 : nullptr, &rc1);
-            } catch (...) { ex1 = std::current_exception(); }
-        });
-    } catch (const std::system_error&) { return one_sequence(); }              // (no second thread to be had)
-    try {
-        done0 = batch_optimize_lm(b->lm, h0, r0, b->stream, s2a, iterations, eager, verbose, nullptr, stats, &rc0);
-    } catch (...) { lane.join(); throw; }
-    lane.join();
-    if (ex1) std::rethrow_exception(ex1);
-    if (done0 < 0) { b->last_error = h0[(size_t)(-1 - done0)]->last_error; return rc0; }
-    if (done1 < 0) { b->last_error = h1[(size_t)(-1 - done1)]->last_error; return rc1; }
-    rc_all = rc0 != UZL_OK ? rc0 : rc1;
-    b->last_batched = done0 + done1;
-    if (n_batched) *n_batched = done0 + done1;
+        for (int l = 1; l < L; l++) helpers.emplace_back([&, l] { run_lane(lanes[(size_t)l]); });
+    } catch (const std::system_error&) {                                       // (no more threads to be had: the sequences not started run from this one)
+        for (int l = (int)helpers.size() + 1; l < L; l++) run_lane(lanes[(size_t)l]);
+    }
+    run_lane(lanes[0]);
+    for (std::thread& t : helpers) t.join();
+    for (Lane& ln : lanes) if (ln.ex) std::rethrow_exception(ln.ex);
+    int total = 0;
+    for (Lane& ln : lanes) {
+        if (ln.done < 0) { b->last_error = b->h[(size_t)(ln.first - 1 - ln.done)]->last_error; return ln.rc; }
+        if (ln.rc != UZL_OK && rc_all == UZL_OK) rc_all = ln.rc;
+        total += ln.done;
+    }
+    b->last_batched = total;
+    if (n_batched) *n_batched = total;
     return rc_all;
 }
 
@@ -1854,17 +1873,22 @@ int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch
     static const bool two_on = diag_int("UZL_BATCH_LANES", 2) >= 2;
     bool ok = hipSetDevice(c.device) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
     if (ok && two_on && n_graphs >= diag_int("UZL_BATCH_LANE_MIN", kBatchLaneMin)) b->stream_b = independent_stream(0, {b->stream});
+    if (ok && b->stream_b && diag_int("UZL_BATCH_LANES", 2) >= 4) {             // diagnostic build: two more solver streams, four pipes in all
+        b->stream_x[0] = independent_stream(0, {b->stream, b->stream_b});
+        if (b->stream_x[0]) b->stream_x[1] = independent_stream(0, {b->stream, b->stream_b, b->stream_x[0]});
+    }
+    const bool four = b->stream_x[1] != nullptr;                // (then the rebuild streams only serve batches too small for four sequences)
     if (ok) {
-        b->stream2 = independent_stream(prio2, {b->stream, b->stream_b});
+        b->stream2 = four ? independent_stream(prio2, {b->stream}) : independent_stream(prio2, {b->stream, b->stream_b});
         if (!b->stream2) ok = hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, prio2) == hipSuccess;
     }
     if (ok && b->stream_b) {
-        b->stream2_b = independent_stream(prio2, {b->stream, b->stream_b, b->stream2});
+        b->stream2_b = four ? independent_stream(prio2, {b->stream, b->stream_b}) : independent_stream(prio2, {b->stream, b->stream_b, b->stream2});
         if (!b->stream2_b) { (void)hipStreamDestroy(b->stream_b); b->stream_b = nullptr; }      // no fourth: one sequence
     }
     if (!ok) {
         for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
-        for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b}) if (q) (void)hipStreamDestroy(q);
+        for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b, b->stream_x[0], b->stream_x[1]}) if (q) (void)hipStreamDestroy(q);
         delete b;
         return UZL_ERR_HIP;
     }
@@ -1876,11 +1900,12 @@ void uzl_pgo_batch_destroy(uzl_pgo_batch* b)
 {
     if (!b) return;
     (void)hipSetDevice(b->cfg.device);
-    for (hipStream_t q : {b->stream2, b->stream, b->stream2_b, b->stream_b}) if (q) (void)hipStreamSynchronize(q);
+    for (hipStream_t q : {b->stream2, b->stream, b->stream2_b, b->stream_b, b->stream_x[0], b->stream_x[1]}) if (q) (void)hipStreamSynchronize(q);
     lm_run_destroy(b->lm); b->lm = nullptr;
     lm_run_destroy(b->lm_b); b->lm_b = nullptr;
+    for (uzl::LmRun*& r : b->lm_x) { lm_run_destroy(r); r = nullptr; }
     for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
-    for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b}) if (q) (void)hipStreamDestroy(q);
+    for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b, b->stream_x[0], b->stream_x[1]}) if (q) (void)hipStreamDestroy(q);
     delete b;
 }
 
