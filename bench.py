@@ -5,7 +5,7 @@
 
 Primary metric   : SE(3) edges optimised / s   on BASELINE config 2 (1k nodes / 5k edges, 20 LM iterations)
 `secondary`      : node pairs matched / s      on BASELINE config 3 (512 pairs x 1000 ORB-256, 500 hypotheses)
-`batched`        : 16 independent config-2 graphs per GPU through one launch sequence (uzl_pgo_batch_*)
+`batched`        : 16 independent config-2 graphs per GPU in one batch call (uzl_pgo_batch_*: shared launches, two launch sequences from 12 graphs on)
 `c4_1gpu`        : the north-star line: 10k nodes / 50k edges on ONE GPU against the CPU path (1 thread and all cores)   [N = 1]
 `online_c5`      : BASELINE config 5: 4096 pair jobs feeding a graph that grows to 20k nodes, re-optimised every 256 edges
 `formats`        : Feature records -> frame arena for the 1024 frames of config 3 (HBM-bound byte shuffle)           [rank 0]
@@ -585,7 +585,7 @@ def main():
     if matcher is not None and dist.rank == 0 and not a.no_formats:
         formats = bench_formats(capi, dev, pairs, a.keypoints)
 
-    # ------------------------------------------------------------------ batched: B independent config-2 graphs, one launch sequence
+    # ------------------------------------------------------------------ batched: B independent config-2 graphs, one batch call
     batched = None
     if not a.no_batched and is_c2:
         nB = a.batch
@@ -630,7 +630,7 @@ def main():
             b_roofs.append(roof("ml_cg_comp_batch_kernel<5>", "hbm", ach_c, HBM_PEAK_GBS, "GB/s", traffic=None, avg_launch_us=round(1e3 * cg_b["ms"] / cg_b["launches"], 3),
                                 launches=cg_b["launches"], algorithmic_bytes_per_graph_iteration=alg_y,
                                 note="every workgroup streams its 6 rows of the graph's dense level-1 operator (f32 copy, 2.25 MB per graph) and its 48 x 48 smoother block"))
-        batched = dict(metric="SE(3) edges optimized/sec, %d independent config-2 graphs per GPU in one launch sequence (uzl_pgo_batch_*)" % nB,
+        batched = dict(metric="SE(3) edges optimized/sec, %d independent config-2 graphs per GPU in one batch call (uzl_pgo_batch_*)" % nB,
                        rooflines=b_roofs,
                        value=round(vb, 1), unit="edges/s", graphs=nB, graphs_batched=bt.n_batched, ms_per_batch=round(1e3 * t_b / nsteps_b, 3),
                        ms_per_graph=round(1e3 * t_b / nsteps_b / nB, 4), vs_single_graph=round(vb / value, 2),

@@ -392,7 +392,7 @@ int  uzl_pgo_set_shard_rccl(uzl_pgo* h, int32_t rank, int32_t world_size, const 
  * show that the exchange really spans the devices; 0 = no communicator (unsharded, or the callback form), < 0 = error code. */
 int  uzl_pgo_rccl_ranks(uzl_pgo* h);
 
-/* ---- batched solve: many small graphs through one launch sequence ---------------------------
+/* ---- batched solve: many small graphs through shared launches ---------------------------
  * A 1k-node graph uses ~3 % of an MI355X (125 workgroups per launch, two dependent launches per PCG iteration).  Independent
  * graphs - the disjoint subgraphs / local scopes / per-robot graphs of SURVEY section 8e row 2, or the disconnected components
  * setFixedNodes() finds (g2o_optimizer.cpp:301-349) given as separate graphs - are therefore solved together: every kernel is

@@ -1,4 +1,4 @@
-"""Batched multi-graph solve (uzl_pgo_batch_*): B independent graphs through one launch sequence.  Every graph's result must be
+"""Batched multi-graph solve (uzl_pgo_batch_*): B independent graphs through shared launches.  Every graph's result must be
 bit-identical to uzl_pgo_optimize of that graph alone, and (through that) within the north-star tolerance of the oracle."""
 import numpy as np
 import pytest

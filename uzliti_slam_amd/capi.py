@@ -591,7 +591,7 @@ class _BorrowedPgo(Pgo):
 
 
 class PgoBatch:
-    """uzl_pgo_batch_*: n independent graphs solved through one launch sequence.  `graphs[i]` is an ordinary Pgo over handle i
+    """uzl_pgo_batch_*: n independent graphs solved through shared launches.  `graphs[i]` is an ordinary Pgo over handle i
     (add_graph / set_graph / reset / store); optimize() solves them all and returns one stats dict per graph."""
 
     def __init__(self, n_graphs, **cfg):
