@@ -38,6 +38,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the declarations between this push and the pop at the end of the file are its
+ * whole dynamic symbol table (tests/test_capi_exports.py holds `nm -D --defined-only` to exactly this list). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 #define UZL_ABI_VERSION 3
 
 /* ---- status codes (reference: bool returns + ROS_ERROR, SURVEY §8b "Errors") ---- */
@@ -71,6 +77,14 @@ extern "C" {
 #define UZL_EDGE_TYPE_2D_LASER          105
 
 int         uzl_abi_version(void);
+/* The library's long-lived HIP streams on `device`.  Streams that have to run side by side (the launch sequences of a batch and their
+ * rebuild streams, uzl_pgo_batch_create) are leased from one pool per device and process: a pair of streams is measured against each
+ * other at most once per process (~1 ms of short kernels), its verdict is remembered, streams go back to the pool when their handle is
+ * destroyed.  UZL_STREAM_PROBE=0 in the environment skips every measurement (a batch then runs as one launch sequence).  Out
+ * (any may be NULL): streams in the pool / leased right now / made by handles for themselves and registered; pairs measured so far /
+ * found independent; leases that found no independent stream within the budget; host time spent measuring [ms]. */
+int         uzl_stream_stats(int32_t device, int32_t* n_pooled, int32_t* n_leased, int32_t* n_registered, int32_t* pairs_measured,
+                             int32_t* pairs_independent, int32_t* fallbacks, double* probe_ms);
 /* Number of visible HIP devices, or <0 (UZL_ERR_NO_DEVICE) when there is none. */
 int         uzl_device_count(void);
 /* Static string for a status code. */
@@ -251,6 +265,14 @@ typedef struct uzl_pgo_cfg {
                                          are consecutive anyway), and it changes its mind when the PCG iterations per LM trial of its
                                          own last solves say so.  Same linear system either way.
                                          (was reserved0: layout unchanged)                                              */
+    int32_t pass_history;             /* The device-resident loop (lm_loop = 0) enqueues one pass per LM trial and has to size its PCG
+                                         segment before the solve runs.  0 (default): a handle that is asked to optimise the SAME
+                                         structure again (uzl_pgo_reset, a timer-driven re-optimisation, graph_slam_node.cpp:1138-1150)
+                                         also uses the PCG iteration count every trial took in its previous uzl_pgo_optimize;
+                                         1: sizes come from the running optimize alone (the previous solve's count), as on a fresh
+                                         handle.  Results are the same either way - a pass that is too short is followed by another -
+                                         only the number of passes and idle launches changes.
+                                         (occupies the struct's tail padding: layout unchanged)                          */
 } uzl_pgo_cfg;
 
 /* SlamNode as the optimizer sees it (slam_node.h:89-107). Array order = std::map iteration order
@@ -314,7 +336,11 @@ const char* uzl_pgo_last_error(uzl_pgo* h);
 /* G2oOptimizer::addGraphImpl (g2o_optimizer.cpp:55-104): full rebuild.  Applies the skip rules
  * (:77, :203-206, :270-274), composes the measurements (:229, :281), the optional xy-only
  * projection (:164-170, :231-237, :282-288) and marks non-odometry edges robust (:292-294).
- * sensors: n_sensors x 12 doubles (SlamGraph sensor transforms, :68-71).  Only copies. */
+ * sensors: n_sensors x 12 doubles (SlamGraph sensor transforms, :68-71).  Only copies.
+ * The poses a solve returns do not depend on what the handle solved before, up to the accuracy of the linear solve (pcg_tol): with
+ * reduced_numbering = 0 a handle remembers how many PCG iterations its last solves took in either numbering of the Schur-reduced
+ * system and lays the next one out accordingly (another preconditioner for the same system).  That memory is kept while the graph
+ * grows (same or more nodes: an online session, graph_slam_node.cpp:1138-1150) and dropped when a graph with fewer nodes arrives. */
 int  uzl_pgo_add_graph(uzl_pgo* h,
                        int32_t n_nodes, const uzl_node* nodes,
                        int32_t n_edges, const uzl_edge* edges,
@@ -325,7 +351,7 @@ int  uzl_pgo_add_graph(uzl_pgo* h,
  * old edges edge_index[0 .. n_flags) is set to edge_valid[.].  An online session re-optimises a graph that gained a few hundred nodes
  * and edges since the last time (graph_slam_node.cpp:1138-1150 -> g2o_optimizer.cpp:55-104 rebuilds it from the SlamGraph every time);
  * with the graph resident in HBM only the new part crosses PCIe and only the new part is flattened.
- * The result is what uzl_pgo_add_graph gives for the grown arrays with the old nodes' poses as uzl_pgo_store last returned them - the
+ * The result is what uzl_pgo_add_graph on the same handle gives for the grown arrays with the old nodes' poses as uzl_pgo_store last returned them - the
  * handle's current estimates, i.e. what storeImpl wrote back into the SlamGraph (:106-135) - and the same skip rules (node `fixed`
  * flags of old nodes stay as given).  Sensors stay as given to uzl_pgo_add_graph.  Only copies. */
 int  uzl_pgo_append_graph(uzl_pgo* h,
@@ -367,6 +393,14 @@ int  uzl_pgo_kernel_times(uzl_pgo* h, int32_t cap, const char** names, double* m
  * cap_slots entries (UZL_ERR_BAD_ARG if the reduced system has more blocks). */
 int  uzl_pgo_schur_plan(int32_t nb, const int32_t* row_ptr, const int32_t* col, int32_t cap, int32_t* red_row, int32_t* run_id,
                         int32_t* run_pos, int32_t* red_row_ptr, int32_t* red_col, int32_t cap_slots, int32_t* n_reduced, int32_t* n_runs);
+/* The same plan with the reduced system numbered by strong aggregates (uzl_pgo_cfg::reduced_numbering = 2): slot_w = one weight per
+ * block of `col` (trace of the edge's information matrix), strong_min = separators from which on the numbering applies, theta = how
+ * stiff an edge must be against the stiffest at either end to tie two separators (0.25), one_level_max = groups up to which the layout
+ * is one level (256).  red_row: full row -> reduced row (-1: eliminated); sep_rows (cap_rows entries): reduced row -> full row, -1 for
+ * an EMPTY padding row; counts[5] = {reduced rows, separators, groups of <= 8, blocks of <= 4 groups, 1000 x the share of separators in
+ * groups that are consecutive in row order anyway}.  Host code only. */
+int  uzl_pgo_schur_plan_strong(int32_t nb, const int32_t* row_ptr, const int32_t* col, int32_t cap, const double* slot_w, int32_t strong_min,
+                               double theta, int32_t one_level_max, int32_t* red_row, int32_t* sep_rows, int32_t cap_rows, int32_t* counts);
 
 /* ---- sharded single-graph solve (BASELINE config 4): one handle per rank ------------------
  * The graph is edge-partitioned: every rank holds all vertices and the edges
@@ -563,6 +597,9 @@ int  uzl_gate_set_graph(uzl_gate* h, int32_t n_nodes, const double* poses, const
 int  uzl_gate_check(uzl_gate* h, int32_t n_candidates, const uzl_gate_edge* candidates,
                     uint8_t* accept, uint8_t* valid, double* astar_dist);
 int  uzl_gate_edge_count(uzl_gate* h);
+/* Introspection for parity tests: searches run so far by the reference's greedy search (one wave per candidate) and by the
+ * deciding lane-per-candidate search of the verdicts-only form.  Either may be NULL. */
+int  uzl_gate_search_counts(uzl_gate* h, int64_t* n_wave, int64_t* n_lane);
 
 /* ======================================================================================
  *  Distance loop-closure candidates  
@@ -755,6 +792,10 @@ int  uzl_bag_read(const uint8_t* file, uint64_t len, int32_t cap, uzl_bag_msg* m
  * are ros::message_traits::{MD5Sum,Definition}<M>::value() of the caller's message type. */
 uint64_t uzl_bag_single_size(const uzl_bag_msg* m);
 int  uzl_bag_write_single(const uzl_bag_msg* m, uint8_t* out, uint64_t cap, uint64_t* written);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

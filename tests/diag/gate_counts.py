@@ -42,7 +42,7 @@ o.gate.set_graph = keep_set
 o.gate.check = timed_check
 o.run_all()
 nw = C.c_int64(); nl = C.c_int64()
-capi.lib().uzl_debug_gate_counts(o.gate._h, C.byref(nw), C.byref(nl))
+capi.lib().uzl_gate_search_counts(o.gate._h, C.byref(nw), C.byref(nl))
 print("searches: wave/lds kernel %d, lane-kernel fallback %d; gate %.3f s over %d calls" % (nw.value, nl.value, o.t["gate"], len(calls)))
 for k in range(0, len(calls), 8):
     print("  call %3d: %3d candidates %7.2f ms  longest path %.1f m" % (k, calls[k][0], calls[k][1], calls[k][2]))

@@ -13,7 +13,7 @@ from uzliti_slam_amd import capi    # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 prio = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-lib = capi.lib()
+lib = capi.diag_lib()
 out = np.zeros((n, n), np.int32)
 rc = lib.uzl_debug_stream_pairs(ctypes.c_int(n), ctypes.c_int(prio), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
 print("rc", rc, "priority", prio, "GPU_MAX_HW_QUEUES", os.environ.get("GPU_MAX_HW_QUEUES"))

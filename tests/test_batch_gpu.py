@@ -163,22 +163,6 @@ def test_queue_with_fewer_resident_slots_than_graphs(capi, resident):
     bt.close()
 
 
-def test_stream_pair_measurement_is_consistent(capi):
-    """uzl_pgo.hip: streams_independent decides which streams the library keeps (a handle's solver / rebuild pair, a batch's launch
-    sequences must not share a hardware queue or a compute pipe).  Standing in each other's way is a property of the pair: the
-    measurement must see it from both sides, and independent pairs must exist."""
-    import ctypes
-    n = 6
-    lib = capi.lib()
-    a = np.zeros((n, n), np.int32)
-    assert lib.uzl_debug_stream_pairs(ctypes.c_int(n), ctypes.c_int(200), a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) == 0
-    assert np.all(np.diag(a) == -1)
-    off = ~np.eye(n, dtype=bool)
-    assert a[off].min() >= 80 and a[off].max() < 600              # percent of a single chain's time
-    assert np.array_equal(a < 150, (a < 150).T)
-    assert (a[off] < 150).sum() >= 2
-
-
 def test_one_launch_sequence_in_the_diagnostic_build():
     """UZL_BATCH_LANES=1 (diagnostic build): every batch as ONE launch sequence (the default drives the second half of 12 and more graphs
     from a second host thread on streams of its own).  Random batches of 2 - 24 graphs, some through a queue: every graph bit-identical

@@ -24,6 +24,16 @@ def test_every_declared_symbol_is_exported(capi):
     assert not missing, missing
 
 
+def test_nothing_but_the_header_is_exported(capi):
+    """the reference-side binding sees uzl_* and nothing else - no kernel stubs, no internals, no test hooks."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(line.split()[-1] for line in out.splitlines() if line.strip()))
+    extra = [n for n in exported if n not in set(_declared())]
+    assert not extra, extra[:20]
+    assert not [n for n in exported if "debug" in n]
+
+
 def test_struct_layouts_match_header(capi):
     assert ctypes.sizeof(capi.EdgeResult) == capi.EDGE_RESULT_DTYPE.itemsize == 432
     assert ctypes.sizeof(capi.PairJob) == capi.PAIR_JOB_DTYPE.itemsize == 24

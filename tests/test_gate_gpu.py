@@ -106,7 +106,7 @@ def test_gate_known_answers_on_gpu(capi, oracle):
 def _counts(capi, g):
     import ctypes as C
     w = C.c_int64(); l = C.c_int64()
-    capi.lib().uzl_debug_gate_counts(g._h, C.byref(w), C.byref(l))
+    capi.lib().uzl_gate_search_counts(g._h, C.byref(w), C.byref(l))
     return w.value, l.value
 
 

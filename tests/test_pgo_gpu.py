@@ -340,7 +340,7 @@ def test_ns_gemm_matrix_core_layout(capi, n):
 
     def run(X, T):
         out = np.zeros((n, n))
-        rc = capi.lib().uzl_debug_ns_gemm(ctypes.c_int(n), np.ascontiguousarray(X).ctypes.data_as(f64p), np.ascontiguousarray(T).ctypes.data_as(f64p),
+        rc = capi.diag_lib().uzl_debug_ns_gemm(ctypes.c_int(n), np.ascontiguousarray(X).ctypes.data_as(f64p), np.ascontiguousarray(T).ctypes.data_as(f64p),
                                           out.ctypes.data_as(f64p))
         assert rc == 0
         return out
@@ -366,7 +366,7 @@ def test_ns_gemm_matrix_core_layout(capi, n):
     # the small-graph kernel (32 x 32 tiles, K split over the four waves): the same sums in the same order - the same bits wherever both
     # kernels compute the entry themselves (tiles on and above the diagonal of BOTH tilings; the rest are mirror images)
     out32 = np.zeros((n, n))
-    rc = capi.lib().uzl_debug_ns_gemm32(ctypes.c_int(n), np.ascontiguousarray(X).ctypes.data_as(f64p), np.ascontiguousarray(A @ X).ctypes.data_as(f64p),
+    rc = capi.diag_lib().uzl_debug_ns_gemm32(ctypes.c_int(n), np.ascontiguousarray(X).ctypes.data_as(f64p), np.ascontiguousarray(A @ X).ctypes.data_as(f64p),
                                         out32.ctypes.data_as(f64p))
     assert rc == 0
     assert np.abs(out32 - want).max() <= 1e-10 * np.abs(want).max()

@@ -1,0 +1,55 @@
+"""The device's stream pool (csrc/uzl_streams.hip): streams that have to run side by side - a batch's launch sequences and their rebuild
+streams - are leased from one pool per device and process, measured against each other at most once.  The file sorts last on purpose:
+what it looks at is a property of the box's queues and pipes under whatever else runs on the GPU, and the driver runs the suite with
+-x - a noisy box must not hide the parity tests behind it.  Nothing here asserts a timing ratio."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from uzliti_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stream_pair_verdicts_have_the_shape_of_queues_and_pipes(capi):
+    """Standing in each other's way is a property of the PAIR: the decision (not the ratio) must come out the same from both sides, a
+    stream is never measured against itself, and independent pairs must exist.  One retry: anything else on the GPU can hold a
+    measurement back once."""
+    n = 6
+    lib = capi.diag_lib()
+    last = None
+    for _ in range(2):
+        a = np.zeros((n, n), np.int32)
+        assert lib.uzl_debug_stream_pairs(ctypes.c_int(n), ctypes.c_int(200), a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) == 0
+        assert np.all(np.diag(a) == -1)
+        off = ~np.eye(n, dtype=bool)
+        ind = a < 150
+        last = a
+        if np.array_equal(ind & off, (ind & off).T) and (ind & off).sum() >= 2:
+            return
+    pytest.fail("stream pairs: decisions not symmetric or no independent pair in two attempts:\n%s" % last)
+
+
+def test_pool_measures_a_pair_once_and_hands_the_same_streams_back(capi):
+    """Two batches of 16 graphs one after the other: the second one's streams are the first one's (leased again from the pool), so it is
+    created without a single probe launch; both solve as the same number of graphs with bit-identical results."""
+    graphs = [synth.make_pose_graph(300, 1200, seed=900 + k) for k in range(16)]
+    res = []
+    s0 = capi.stream_stats(0)
+    for rnd in range(2):
+        bt = capi.PgoBatch(len(graphs))
+        for k, g in enumerate(graphs):
+            bt.graphs[k].add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+        bt.optimize(6)
+        res.append([bt.graphs[k].store()[0].copy() for k in range(len(graphs))])
+        st = capi.stream_stats(0)
+        assert st["leased"] >= 2
+        if rnd == 0:
+            s1 = st
+        bt.close()
+    s2 = capi.stream_stats(0)
+    assert s2["pairs_measured"] == s1["pairs_measured"], (s0, s1, s2)          # the second create found every verdict it needed
+    assert s2["pooled"] == s1["pooled"] and s2["leased"] == s0["leased"]
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x, y)

@@ -238,6 +238,22 @@ static int grow_mode(const char* in, int n1)
     graph.node(node_id(1)).pose_.m[3] += 0.01;
     solve_sync(opt, graph);
     if (opt.lastWasAppend()) return 6;
+    // an old edge rewritten in place (mergeNodes moves displacement_from_ under the same edge id, graph_slam_node.cpp:947-976) with
+    // ids, flags and poses untouched: the tail alone would leave the resident graph behind - full rebuild, same result as a fresh handle
+    solve_sync(opt, graph);                       // (poses written back: the graph is "grown only" again)
+    if (!opt.lastWasAppend()) return 7;
+    for (int k = 0; k < e; k++)
+        if (edges[k].type_ != TYPE_2D_WHEEL_ODOMETRY) { graph.edge(edges[k].id_).displacement_from_.m[3] += 0.05; break; }
+    SlamGraph copy2 = graph;
+    solve_sync(opt, graph);
+    if (opt.lastWasAppend() || opt.lastStatus() < 0) { fprintf(stderr, "rewritten edge: append %d status %d\n", (int)opt.lastWasAppend(), opt.lastStatus()); return 8; }
+    Mi355xOptimizer fresh2(0, /*use_edge_filter=*/false);
+    fresh2.setConfig(cfg);
+    solve_sync(fresh2, copy2);
+    for (auto& kv : graph.nodes()) {
+        const SlamNode& o = copy2.node(kv.first);
+        for (int q = 0; q < 12; q++) worst = std::max(worst, std::fabs(kv.second.pose_.m[q] - o.pose_.m[q]));
+    }
     printf("GROW_OK %.3e flipped %d\n", worst, flipped);
     return 0;
 }

@@ -98,6 +98,17 @@ bool Mi355xOptimizer::growsOnly(SlamGraph& graph, const std::vector<double>& sen
     return true;
 }
 
+// FNV-1a over the packed edge with its `valid` flag left out (the one field uzl_pgo_append_graph can change on an old edge)
+uint64_t Mi355xOptimizer::edgeHash(const uzl_edge& e)
+{
+    uzl_edge u = e;
+    u.valid = 0;
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(&u);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < sizeof(u); i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
 void Mi355xOptimizer::packEdge(const SlamEdge& e, const std::string& key, uzl_edge& u) const
 {
     std::memset(&u, 0, sizeof(u));
@@ -153,38 +164,51 @@ void Mi355xOptimizer::addGraphImpl(SlamGraph& graph)
             graph.edge(fe.id_).valid_ = true;
             filtered_.insert(fe.id_);
         }
-    const bool grow = growsOnly(graph, sensors);
-    last_append_ = grow;
-    if (!grow) { node_ids_.clear(); edge_ids_.clear(); index_.clear(); sent_fixed_.clear(); sent_valid_.clear(); sensor_index_ = sensor_index; }
-    // vertices in std::map order = lexicographic id = the order g2o ids are assigned in (g2o_optimizer.cpp:64-66)
-    const size_t n_old = node_ids_.size(), e_old = edge_ids_.size();
+    // growsOnly looks at ids, flags and poses; the reference also rewrites existing edges in place (mergeNodes moves displacement_from_ /
+    // displacement_to_ and id_from_ / id_to_ under the same edge id, graph_slam_node.cpp:947-976), and an old edge whose end node was
+    // missing when it was sent resolves once the node appears: every old edge is therefore packed again and compared (a hash of the
+    // packed uzl_edge without its `valid` flag) with what was sent - any difference sends the whole graph (uzl_pgo_add_graph)
+    bool grow = growsOnly(graph, sensors);
     std::vector<uzl_node> nodes;
-    size_t i = 0;
-    for (auto& kv : graph.nodes()) {
-        if (i++ < n_old) continue;
-        uzl_node n;
-        std::memcpy(n.pose, kv.second.pose_.m.data(), sizeof(n.pose));
-        n.fixed = kv.second.fixed_ ? 1 : 0;
-        index_[kv.first] = (int32_t)node_ids_.size();
-        node_ids_.push_back(kv.first);
-        sent_fixed_.push_back((uint8_t)n.fixed);
-        nodes.push_back(n);
-    }
     std::vector<uzl_edge> edges;
     std::vector<int32_t> flag_index;
     std::vector<uint8_t> flag_valid;
-    size_t k = 0;
-    for (auto& kv : graph.edges()) {
-        uzl_edge u;
-        packEdge(kv.second, kv.first, u);
-        if (k < e_old) {                         // an old edge: only the filter's verdict can have changed
-            if ((uint8_t)u.valid != sent_valid_[k]) { flag_index.push_back((int32_t)k); flag_valid.push_back((uint8_t)u.valid); sent_valid_[k] = (uint8_t)u.valid; }
-        } else {
-            edge_ids_.push_back(kv.first);
-            sent_valid_.push_back((uint8_t)u.valid);
-            edges.push_back(u);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        last_append_ = grow;
+        if (!grow) { node_ids_.clear(); edge_ids_.clear(); index_.clear(); sent_fixed_.clear(); sent_valid_.clear(); sent_hash_.clear(); sensor_index_ = sensor_index; }
+        nodes.clear(); edges.clear(); flag_index.clear(); flag_valid.clear();
+        // vertices in std::map order = lexicographic id = the order g2o ids are assigned in (g2o_optimizer.cpp:64-66)
+        const size_t n_old = node_ids_.size(), e_old = edge_ids_.size();
+        size_t i = 0;
+        for (auto& kv : graph.nodes()) {
+            if (i++ < n_old) continue;
+            uzl_node n;
+            std::memcpy(n.pose, kv.second.pose_.m.data(), sizeof(n.pose));
+            n.fixed = kv.second.fixed_ ? 1 : 0;
+            index_[kv.first] = (int32_t)node_ids_.size();
+            node_ids_.push_back(kv.first);
+            sent_fixed_.push_back((uint8_t)n.fixed);
+            nodes.push_back(n);
         }
-        k++;
+        bool rewritten = false;
+        size_t k = 0;
+        for (auto& kv : graph.edges()) {
+            uzl_edge u;
+            packEdge(kv.second, kv.first, u);
+            const uint64_t hash = edgeHash(u);
+            if (k < e_old) {                         // an old edge: only the filter's verdict may have changed
+                if (hash != sent_hash_[k]) { rewritten = true; break; }
+                if ((uint8_t)u.valid != sent_valid_[k]) { flag_index.push_back((int32_t)k); flag_valid.push_back((uint8_t)u.valid); sent_valid_[k] = (uint8_t)u.valid; }
+            } else {
+                edge_ids_.push_back(kv.first);
+                sent_valid_.push_back((uint8_t)u.valid);
+                sent_hash_.push_back(hash);
+                edges.push_back(u);
+            }
+            k++;
+        }
+        if (!rewritten) break;
+        grow = false;                                // (second round: everything is sent)
     }
     if (grow)
         status_ = uzl_pgo_append_graph(h_, (int32_t)nodes.size(), nodes.data(), (int32_t)edges.size(), edges.data(), (int32_t)flag_index.size(),

@@ -75,9 +75,11 @@ private:
     // nodes and edges; ids are time-ordered, :294, so they sort behind the old ones)
     bool growsOnly(SlamGraph& graph, const std::vector<double>& sensors) const;
     void packEdge(const SlamEdge& e, const std::string& key, uzl_edge& u) const;
+    static uint64_t edgeHash(const uzl_edge& u);
     std::map<std::string, int32_t> index_, sensor_index_;
     std::vector<double> stored_poses_, sent_sensors_;   // poses storeImpl wrote back (12 per node); sensors as sent
     std::vector<uint8_t> sent_fixed_, sent_valid_;
+    std::vector<uint64_t> sent_hash_;            // per sent edge: edgeHash of what went across the C ABI
     bool have_graph_ = false, last_append_ = false, sent_xy_ = false, sent_odom_ = false;
 };
 

@@ -72,7 +72,7 @@ class PgoCfg(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("use_odometry_parameters", C.c_int32),
                 ("optimize_xy_only", C.c_int32), ("device", C.c_int32), ("pcg_tol", C.c_double),
                 ("pcg_max_iter", C.c_int32), ("schur_reduce", C.c_int32), ("huber_delta", C.c_double), ("verbose", C.c_int32),
-                ("preconditioner", C.c_int32), ("pcg_stop", C.c_int32), ("lm_loop", C.c_int32), ("reduced_numbering", C.c_int32)]
+                ("preconditioner", C.c_int32), ("pcg_stop", C.c_int32), ("lm_loop", C.c_int32), ("reduced_numbering", C.c_int32), ("pass_history", C.c_int32)]
 
 
 class PgoStats(C.Structure):
@@ -251,6 +251,31 @@ def _p(a, t):
 
 def device_count():
     return lib().uzl_device_count()
+
+
+DIAG_LIB_PATH = os.path.join(_HERE, "libuzl_mi355x_diag.so")
+_diag = None
+
+
+def diag_lib():
+    """The diagnostic twin (same sources, -DUZL_DIAG): the only place the uzl_debug_* test hooks exist - the product library exports
+    include/uzl_mi355x.h and nothing else.  Loaded beside the product library (both keep their symbols to themselves)."""
+    global _diag
+    if _diag is None:
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise UzlError(UZL_ERR_STATE, f"{DIAG_LIB_PATH} is missing: make -C {CSRC} diag")
+        _diag = C.CDLL(DIAG_LIB_PATH)
+    return _diag
+
+
+def stream_stats(device=0):
+    """uzl_stream_stats: the device's stream pool (uzl_streams.hip)"""
+    v = [C.c_int32() for _ in range(6)]
+    ms = C.c_double()
+    rc = lib().uzl_stream_stats(C.c_int32(device), *[C.byref(x) for x in v], C.byref(ms))
+    if rc != UZL_OK:
+        raise UzlError(rc, "uzl_stream_stats")
+    return dict(zip(("pooled", "leased", "registered", "pairs_measured", "pairs_independent", "fallbacks"), [x.value for x in v]), probe_ms=ms.value)
 
 
 RCCL_UNIQUE_ID_BYTES = 128

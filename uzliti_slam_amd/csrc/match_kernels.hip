@@ -1125,7 +1125,7 @@ hipError_t launch_estimate(const EstimateArgs& a, int n_jobs, bool in_lds, size_
 }  // namespace uzl
 
 #ifdef UZL_STAMPS
-extern "C" int uzl_debug_read_mstamps(unsigned long long* out, int reset)
+extern "C" UZL_DIAG_EXPORT int uzl_debug_read_mstamps(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(uzl::g_mstamps), sizeof(unsigned long long) * 32) != hipSuccess) return -3;
     if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(uzl::g_mstamps), z, sizeof(z)) != hipSuccess) return -3; }

@@ -2722,7 +2722,7 @@ hipError_t kl_ml_pcg_pairs(const LmSlot* sl, const LmSlot* host_slot, const LmSh
 }  // namespace uzl
 
 #ifdef UZL_STAMPS
-extern "C" int uzl_debug_read_stamps(unsigned long long* out, int reset)
+extern "C" UZL_DIAG_EXPORT int uzl_debug_read_stamps(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(uzl::g_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return -3;
     if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(uzl::g_stamps), z, sizeof(z)) != hipSuccess) return -3; }
@@ -2730,8 +2730,9 @@ extern "C" int uzl_debug_read_stamps(unsigned long long* out, int reset)
 }
 #endif
 
-// test hook (not part of include/uzl_mi355x.h): out = 2 X - X T for host matrices, through ml_ns_gemm_kernel
-extern "C" int uzl_debug_ns_gemm32(int n, const double* X, const double* T, double* out)
+// test hooks of the diagnostic build (not part of include/uzl_mi355x.h): out = 2 X - X T for host matrices, through ml_ns_gemm_kernel
+#ifdef UZL_DIAG
+extern "C" UZL_DIAG_EXPORT int uzl_debug_ns_gemm32(int n, const double* X, const double* T, double* out)
 {
     if (n <= 0 || n > uzl::kGemm32Max || !X || !T || !out) return -1;
     double *dX = nullptr, *dT = nullptr, *dO = nullptr;
@@ -2745,7 +2746,7 @@ extern "C" int uzl_debug_ns_gemm32(int n, const double* X, const double* T, doub
     (void)hipFree(dX); (void)hipFree(dT); (void)hipFree(dO);
     return e == hipSuccess ? 0 : -3;
 }
-extern "C" int uzl_debug_ns_gemm(int n, const double* X, const double* T, double* out)
+extern "C" UZL_DIAG_EXPORT int uzl_debug_ns_gemm(int n, const double* X, const double* T, double* out)
 {
     if (n <= 0 || !X || !T || !out) return -1;
     double *dX = nullptr, *dT = nullptr, *dO = nullptr;
@@ -2760,4 +2761,4 @@ extern "C" int uzl_debug_ns_gemm(int n, const double* X, const double* T, double
     (void)hipFree(dX); (void)hipFree(dT); (void)hipFree(dO);
     return e == hipSuccess ? 0 : -3;
 }
-
+#endif

@@ -19,6 +19,8 @@ namespace uzl {
 // -DUZL_DIAG; tests and tests/diag scripts select it with UZL_LIB); in the shipped library every one of them is a compile-time
 // constant.  Two run-time switches remain in both builds because a profiler / a debugging session needs them on the product:
 // UZL_NO_GRAPH=1 (eager launches: rocprofv3's kernel tracer cannot follow hipGraph replays on this image) and UZL_VERBOSE=1.
+// Test hooks (uzl_debug_*) exist in the diagnostic build only; the product library exports include/uzl_mi355x.h and nothing else.
+#define UZL_DIAG_EXPORT __attribute__((visibility("default")))
 #ifdef UZL_DIAG
 inline bool diag_flag(const char* name) { return getenv(name) != nullptr; }
 inline int diag_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }

@@ -7,6 +7,7 @@
 // earlier in the same call is dropped, and when an accepted edge is valid (score >= min_accept_valid: it changes what
 // astar can reach) the remaining candidates are searched again on the updated adjacency.
 #include "uzl_common.hpp"
+#include "uzl_streams.hpp"
 #include "gate_types.hpp"
 
 #include <algorithm>
@@ -158,6 +159,7 @@ int uzl_gate_create(const uzl_gate_cfg* cfg, uzl_gate** out)
         delete h;
         return UZL_ERR_HIP;
     }
+    stream_register(c.device, h->stream, false);
     *out = h;
     return UZL_OK;
 }
@@ -166,7 +168,7 @@ void uzl_gate_destroy(uzl_gate* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); stream_unregister(h->cfg.device, h->stream); (void)hipStreamDestroy(h->stream); }
     delete h;
 }
 
@@ -364,8 +366,8 @@ int uzl_gate_check(uzl_gate* h, int32_t nc, const uzl_gate_edge* cand, uint8_t* 
     UZL_GUARD_END(h)
 }
 
-// parity tests / diagnostics (not part of include/uzl_mi355x.h): searches run so far by the wave kernel and by the lane kernel
-int uzl_debug_gate_counts(uzl_gate* h, int64_t* n_wave, int64_t* n_lane)
+// parity tests: searches run so far by the wave kernel and by the lane kernel
+int uzl_gate_search_counts(uzl_gate* h, int64_t* n_wave, int64_t* n_lane)
 {
     if (!h) return UZL_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
@@ -374,9 +376,11 @@ int uzl_debug_gate_counts(uzl_gate* h, int64_t* n_wave, int64_t* n_lane)
     return UZL_OK;
 }
 
-// diagnostic build: counters of the last launch of gate_reg_kernel (8 per search: expansions, shader clocks, 100 MHz ticks, largest list,
-// shader clocks in the pop / the popped node's loads / the neighbours up to the push decision / the pushes)
-int uzl_debug_gate_profile(uzl_gate* h, long long* out, int32_t cap)
+// diagnostic build only (not part of include/uzl_mi355x.h): counters of the last launch of gate_reg_kernel (8 per search: expansions,
+// shader clocks, 100 MHz ticks, largest list, shader clocks in the pop / the popped node's loads / the neighbours up to the push decision /
+// the pushes)
+#ifdef UZL_DIAG
+UZL_DIAG_EXPORT int uzl_debug_gate_profile(uzl_gate* h, long long* out, int32_t cap)
 {
     if (!h || !out) return UZL_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
@@ -384,6 +388,8 @@ int uzl_debug_gate_profile(uzl_gate* h, long long* out, int32_t cap)
     for (int32_t i = 0; i < 8 * nq; i++) out[i] = h->dbg_last[i];
     return nq;
 }
+
+#endif
 
 int uzl_gate_edge_count(uzl_gate* h)
 {

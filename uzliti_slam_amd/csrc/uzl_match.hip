@@ -3,6 +3,7 @@
 // (transformation_estimation/src/feature_transformation_estimator.cpp) as a batched, device-resident
 // service: frames are uploaded once, every node-pair job references them by id.
 #include "uzl_common.hpp"
+#include "uzl_streams.hpp"
 #include <thread>
 #include "match_types.hpp"
 #include "match_internal.hpp"
@@ -417,11 +418,12 @@ int uzl_match_create(const uzl_match_cfg* cfg, uzl_match** out)
     try {
         UZL_HIP(hipSetDevice(c.device));
         UZL_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        stream_register(c.device, h->stream, true);               // (its launch sequences run beside a solve: config 5)
         h->arena.reserve((size_t)64 << 20);
     } catch (const HipError& e) {
         std::string msg;
         int code = report(msg, e);
-        if (h->stream) (void)hipStreamDestroy(h->stream);
+        if (h->stream) { stream_unregister(c.device, h->stream); (void)hipStreamDestroy(h->stream); }
         delete h;
         return code;
     }
@@ -433,7 +435,7 @@ void uzl_match_destroy(uzl_match* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); stream_unregister(h->cfg.device, h->stream); (void)hipStreamDestroy(h->stream); }
     for (auto& e : h->up_ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : h->bulk_ev) if (e) (void)hipEventDestroy(e);
     delete h;

@@ -7,75 +7,9 @@
 // accept/reject logic of g2o's OptimizationAlgorithmLevenberg [EXT].
 #include "pgo_handle.hpp"
 #include "pgo_lm.hpp"
+#include "uzl_streams.hpp"
 
 using namespace uzl;
-
-// ---- streams that do not stand in each other's way ---------------------------------------------------------------------------------
-// A HIP stream is served by one of the runtime's hardware queues (four per priority by default: GPU_MAX_HW_QUEUES), handed out at
-// hipStreamCreate, least used first, and the driver puts the queues on the GPU's four compute pipes in the order they were first made.
-// Streams on one queue run strictly one behind the other.  Streams on two queues of one PIPE do overlap for a single kernel - but two
-// chains of dependent kernels, one on each, take 2.7x the time of one chain (measured: tests/diag/stream_overlap.py chain), worse than
-// running them one after the other.  Which streams of a process collide either way depends on every stream it has made before: a batch
-// whose rebuild stream sat on the solver stream's pipe lost 15 - 45 % (16 chain-like graphs 14.3 -> 20.9 ms), two launch sequences on
-// one pipe ran 2x slower than one sequence (a single handle's solve with its 0.25-ms rebuilds did not move measurably: handles take
-// their streams as they come).  Nothing tells a process where a stream landed, but it can be measured: a chain of 32 dependent ~4-us
-// kernels on one stream alone, then the same chain on both at once.  A batch's streams, which have to run side by side, are made -
-// first at the priority asked for, then at the other one: the two priorities' queues sit on different pipes more often than not - until
-// the pair takes less than 1.5x the single chain (independent pairs: 1.05 - 1.25x; one pipe: 2.7x; one queue: 2.0x); the rejects are
-// held until then, so that the next stream lands elsewhere.
-namespace {
-__global__ void chain_kernel(unsigned ticks)
-{
-    const unsigned long long t0 = wall_clock64();            // 100 MHz
-    while (wall_clock64() - t0 < ticks) {}
-}
-bool streams_independent(hipStream_t a, hipStream_t b, double* ratio = nullptr)
-{
-    constexpr int kLen = 32, kWgs = 1000;
-    auto run = [&](bool both) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int k = 0; k < kLen; k++) {
-            hipLaunchKernelGGL(chain_kernel, dim3(kWgs), dim3(256), 0, a, 400u);
-            if (both) hipLaunchKernelGGL(chain_kernel, dim3(kWgs), dim3(256), 0, b, 400u);
-        }
-        (void)hipStreamSynchronize(a);
-        if (both) (void)hipStreamSynchronize(b);
-        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    };
-    (void)run(true);                                            // (first launches of a stream take longer)
-    const double alone = std::min(run(false), run(false));
-    const double pair = std::min(run(true), run(true));          // (anything else on the GPU can hold a run back once)
-    (void)hipGetLastError();
-    if (ratio) *ratio = pair / alone;
-    return pair < 1.5 * alone;
-}
-// a new stream that is independent of every stream of `others`, of priority `priority` (0 or -1) if one can be had, else of the other
-// one; nullptr if eight attempts found none (or the runtime makes no stream at all)
-hipStream_t independent_stream(int priority, std::initializer_list<hipStream_t> others)
-{
-    static const bool dbg = diag_flag("UZL_STREAM_DBG");
-    std::vector<hipStream_t> rejects;
-    hipStream_t got = nullptr;
-    for (int attempt = 0; attempt < 8 && !got; attempt++) {
-        const int pr = attempt < 4 ? priority : (priority == 0 ? -1 : 0);
-        hipStream_t q = nullptr;
-        if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, pr) != hipSuccess) break;
-        bool ok = true;
-        double worst = 0.;
-        for (hipStream_t o : others) {
-            double r = 0.;
-            if (o && !streams_independent(o, q, &r)) ok = false;
-            worst = std::max(worst, r);
-            if (!ok) break;
-        }
-        if (dbg) fprintf(stderr, "[uzl] independent_stream(%d other(s)): attempt %d, priority %d: pair / single chain %.2f -> %s\n", (int)others.size(), attempt, pr, worst, ok ? "kept" : "rejected");
-        if (ok) got = q; else rejects.push_back(q);
-    }
-    for (hipStream_t r : rejects) (void)hipStreamDestroy(r);
-    return got;
-}
-}  // namespace
-
 
 // ---- RCCL through dlopen: the collective library is only loaded by processes that shard a graph -----------------------------
 #include <dlfcn.h>
@@ -1350,6 +1284,8 @@ static bool same_structure(const uzl_pgo* h, const StructureKey& k)
 
 extern "C" {
 
+static_assert(sizeof(uzl_pgo_cfg) == 64, "uzl_pgo_cfg::pass_history occupies the former tail padding: the layout of ABI version 3 is unchanged");
+
 void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg)
 {
     if (!cfg) return;
@@ -1370,6 +1306,7 @@ void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg)
     cfg->pcg_stop = 0;                  // step-error estimate; 1 = relative residual test only
     cfg->lm_loop = 0;                   // LM decisions on the device (captured passes); 1 = host-driven loop
     cfg->reduced_numbering = 0;         // the handle chooses between row order and strong aggregates (pgo_schur.hpp)
+    cfg->pass_history = 0;              // pass sizes of a repeated optimize may come from the previous one's per-trial counts; 1 = never
 }
 
 int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
@@ -1399,6 +1336,9 @@ int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
         delete h;
         return UZL_ERR_HIP;
     }
+    // (a single handle's solve with its 0.25-ms rebuilds never moved measurably with the placement of its two streams: they are taken as
+    //  they come and entered in the device's registry; the streams that must run side by side are a batch's, uzl_streams.hip)
+    stream_register(c.device, h->stream, false); stream_register(c.device, h->stream2, false);
     *out = h;
     return UZL_OK;
 }
@@ -1414,8 +1354,8 @@ void uzl_pgo_destroy(uzl_pgo* h)
     if (h->rccl_comm) { (void)rccl().CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
     if (h->ev_lin) (void)hipEventDestroy(h->ev_lin);
     if (h->ev_setup) (void)hipEventDestroy(h->ev_setup);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream2) { stream_unregister(h->cfg.device, h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->stream) { stream_unregister(h->cfg.device, h->stream); (void)hipStreamDestroy(h->stream); }
     delete h;
 }
 
@@ -1446,6 +1386,9 @@ int uzl_pgo_add_graph(uzl_pgo* h, int32_t n_nodes, const uzl_node* nodes, int32_
     // weights - a timer-driven re-optimisation of an unchanged graph, or one whose poses / measurements only moved - and rebuilt
     // otherwise; either way the solve is the one a fresh handle would run (same order, same operators).
     StructureKey old_key = take_structure_key(h);
+    // what the handle learned about the numbering of ITS reduced systems (num_its, build_structure) belongs to the session it came from: a
+    // graph that is not the previous one grown (fewer nodes than before) starts as on a fresh handle
+    if (n_nodes < h->n) { h->num_its[0] = h->num_its[1] = -1.; h->num_last = -1; }
     h->have_graph = false; h->structure_ready = false;
     h->n = n_nodes; h->e_in = n_edges;
     h->fixed_in.assign((size_t)n_nodes, 0);
@@ -1528,6 +1471,7 @@ int uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t*
             return fail(h, UZL_ERR_BAD_ARG, "edge endpoint out of range");
     UZL_HIP(hipSetDevice(h->cfg.device));
     StructureKey old_key = take_structure_key(h);
+    if (n < h->n) { h->num_its[0] = h->num_its[1] = -1.; h->num_last = -1; }      // (as uzl_pgo_add_graph)
     h->have_graph = false; h->structure_ready = false;
     h->n = n; h->e_in = e; h->e = e;
     h->in_ready = false; h->in_edges.clear();                            // (d_stage, the sensors' place, is this call's staging area)
@@ -1773,13 +1717,6 @@ int batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* stats, i
         return rc_all;
     }
     static const int lanes_env = diag_int("UZL_BATCH_LANES", 2);               // A/B switch (diagnostic build): 1 = one launch sequence
-    {
-        static const bool dbg = diag_flag("UZL_STREAM_DBG");
-        if (dbg) {
-            hipStream_t q[4] = {b->stream, b->stream2, b->stream_b, b->stream2_b};
-            for (int i = 0; i < 4; i++) for (int j = i + 1; j < 4; j++) if (q[i] && q[j]) { double r = 0.; (void)streams_independent(q[i], q[j], &r); fprintf(stderr, "[uzl] batch streams %d, %d: pair / single chain %.2f\n", i, j, r); }
-        }
-    }
     const bool eager = b->h[0]->no_graph, verbose = b->cfg.verbose != 0;
     static const bool no_s2 = diag_flag("UZL_BATCH_NO_S2");                   // A/B switch: rebuilds on the sequence's own stream
     hipStream_t s2a = no_s2 ? b->stream : b->stream2, s2b = no_s2 ? b->stream_b : b->stream2_b;
@@ -1867,28 +1804,32 @@ int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch
         if (rc != UZL_OK) { for (uzl_pgo* x : b->h) uzl_pgo_destroy(x); delete b; return rc; }
         b->h.push_back(h);
     }
-    // The batch's streams: none in another's way (streams_independent, above).  Batches of kBatchLaneMin graphs and more get a second
-    // launch sequence if four such streams can be had; a rebuild stream that cannot is replaced by any stream (slower, not wrong).
+    // The batch's streams come from the device's pool (uzl_streams.hip): none in another's way.  Batches of kBatchLaneMin graphs and more
+    // get a second launch sequence if four such streams can be had within the pool's budget - otherwise, and with UZL_STREAM_PROBE=0,
+    // the batch runs as ONE launch sequence whatever streams it got; a rebuild stream that cannot be had apart from the solver's is
+    // replaced by any stream (slower, not wrong).
     static const int prio2 = diag_int("UZL_BATCH_S2_PRIO", 0);                     // A/B switches (diagnostic build)
     static const bool two_on = diag_int("UZL_BATCH_LANES", 2) >= 2;
-    bool ok = hipSetDevice(c.device) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
-    if (ok && two_on && n_graphs >= diag_int("UZL_BATCH_LANE_MIN", kBatchLaneMin)) b->stream_b = independent_stream(0, {b->stream});
+    const int dev = c.device;
+    b->stream = stream_lease(dev, 0, {}, false);
+    bool ok = b->stream != nullptr;
+    if (ok && two_on && n_graphs >= diag_int("UZL_BATCH_LANE_MIN", kBatchLaneMin)) b->stream_b = stream_lease(dev, 0, {b->stream}, true);
     if (ok && b->stream_b && diag_int("UZL_BATCH_LANES", 2) >= 4) {             // diagnostic build: two more solver streams, four pipes in all
-        b->stream_x[0] = independent_stream(0, {b->stream, b->stream_b});
-        if (b->stream_x[0]) b->stream_x[1] = independent_stream(0, {b->stream, b->stream_b, b->stream_x[0]});
+        b->stream_x[0] = stream_lease(dev, 0, {b->stream, b->stream_b}, true);
+        if (b->stream_x[0]) b->stream_x[1] = stream_lease(dev, 0, {b->stream, b->stream_b, b->stream_x[0]}, true);
     }
     const bool four = b->stream_x[1] != nullptr;                // (then the rebuild streams only serve batches too small for four sequences)
     if (ok) {
-        b->stream2 = four ? independent_stream(prio2, {b->stream}) : independent_stream(prio2, {b->stream, b->stream_b});
-        if (!b->stream2) ok = hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, prio2) == hipSuccess;
+        b->stream2 = four ? stream_lease(dev, prio2, {b->stream}, false) : stream_lease(dev, prio2, {b->stream, b->stream_b}, false);
+        ok = b->stream2 != nullptr;
     }
     if (ok && b->stream_b) {
-        b->stream2_b = four ? independent_stream(prio2, {b->stream, b->stream_b}) : independent_stream(prio2, {b->stream, b->stream_b, b->stream2});
-        if (!b->stream2_b) { (void)hipStreamDestroy(b->stream_b); b->stream_b = nullptr; }      // no fourth: one sequence
+        b->stream2_b = four ? stream_lease(dev, prio2, {b->stream, b->stream_b}, true) : stream_lease(dev, prio2, {b->stream, b->stream_b, b->stream2}, true);
+        if (!b->stream2_b) { stream_release(dev, b->stream_b); b->stream_b = nullptr; }      // no fourth: one sequence
     }
     if (!ok) {
         for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
-        for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b, b->stream_x[0], b->stream_x[1]}) if (q) (void)hipStreamDestroy(q);
+        for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b, b->stream_x[0], b->stream_x[1]}) stream_release(dev, q);
         delete b;
         return UZL_ERR_HIP;
     }
@@ -1905,7 +1846,7 @@ void uzl_pgo_batch_destroy(uzl_pgo_batch* b)
     lm_run_destroy(b->lm_b); b->lm_b = nullptr;
     for (uzl::LmRun*& r : b->lm_x) { lm_run_destroy(r); r = nullptr; }
     for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
-    for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b, b->stream_x[0], b->stream_x[1]}) if (q) (void)hipStreamDestroy(q);
+    for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b, b->stream_x[0], b->stream_x[1]}) stream_release(b->cfg.device, q);      // back to the pool, verdicts kept
     delete b;
 }
 
@@ -1944,22 +1885,3 @@ int uzl_pgo_batch_optimize(uzl_pgo_batch* b, int32_t iterations, uzl_pgo_stats* 
 }
 
 }  // extern "C"
-
-// test hook (tests/diag/stream_overlap.py, tests/test_batch_gpu.py): n streams - of priority `priority`, or of priorities 0 and -1 in
-// turn for priority = 200 - and out[i * n + j] = 100 x (two chains of dependent kernels on streams i and j at once / one chain on
-// stream i): streams_independent's measurement
-extern "C" int uzl_debug_stream_pairs(int n, int priority, int32_t* out)
-{
-    if (n < 2 || n > 16 || !out) return UZL_ERR_BAD_ARG;
-    std::vector<hipStream_t> q((size_t)n, nullptr);
-    for (int i = 0; i < n; i++)
-        if (hipStreamCreateWithPriority(&q[i], hipStreamNonBlocking, priority == 200 ? -(i & 1) : priority) != hipSuccess) return UZL_ERR_HIP;
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) {
-            double r = 0.;
-            if (i != j) (void)streams_independent(q[i], q[j], &r);
-            out[i * n + j] = (i == j) ? -1 : (int32_t)(100. * r + 0.5);
-        }
-    for (hipStream_t s : q) (void)hipStreamDestroy(s);
-    return UZL_OK;
-}

@@ -117,7 +117,14 @@ void run_seg(LmRun::Seg& q, bool eager, hipStream_t s, F&& enqueue)
     if (eager) { enqueue(s); return; }
     if (!q.x) {
         UZL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        enqueue(s);
+        try { enqueue(s); }
+        catch (...) {                                           // a launch that fails must not leave the stream in capture mode: every later
+            hipGraph_t part = nullptr;                          // call on the handle (synchronize, store, destroy) would fail with it
+            (void)hipStreamEndCapture(s, &part);
+            if (part) (void)hipGraphDestroy(part);
+            (void)hipGetLastError();
+            throw;
+        }
         UZL_HIP(hipStreamEndCapture(s, &q.g));
         UZL_HIP(hipGraphInstantiate(&q.x, q.g, nullptr, nullptr, 0));
     }
@@ -272,7 +279,12 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
     std::vector<uint32_t> sent((size_t)nS, 0);               // per slot: lm_tail launches enqueued since its load (= the sequence word expected)
     std::vector<LmHost> snap((size_t)nS);
     int next_job = 0, n_active = 0;
-    auto load_slot = [&](int sl) {                           // the next job of the queue into slot sl (stream-ordered behind what the slot ran)
+    // The next job of the queue into slot sl (stream-ordered behind what the slot ran).  A REFILL keeps the slot's sequence word running
+    // (LmDev::tails starts at what the slot has sent): lm_tail_kernel publishes for every slot in every pass and the look waits for the
+    // unfinished ones only, so the last snapshot of a finished or idle slot may still be on its way to h_pub when the slot is reloaded -
+    // with the sequence restarted at 0 that late write (an old, larger number with phase = done) would pass for the new graph's.  Only
+    // the first load of a drive (everything drained by the previous drive's final synchronize) zeroes the snapshot.
+    auto load_slot = [&](int sl, bool first) {
         LmDev I;
         if (next_job < Q) {
             const int j = next_job++;
@@ -285,14 +297,15 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
             slot_job[sl] = -1;
             I = idle_state();                                // (the slot keeps its last graph's arguments: every kernel no-ops on the state)
         }
+        if (first) { memset(R->h_pub.p + sl, 0, sizeof(LmHost)); sent[sl] = 0; }
+        I.tails = (int32_t)sent[sl];
         R->h_init.p[sl] = I;
         UZL_HIP(hipMemcpyAsync(R->d_lm.p + sl, R->h_init.p + sl, sizeof(LmDev), hipMemcpyHostToDevice, s));
-        memset(R->h_pub.p + sl, 0, sizeof(LmHost));
         memset(&snap[sl], 0, sizeof(LmHost));
         snap[sl].lm = I;
-        sent[sl] = 0; solve_passes[sl] = 0;
+        solve_passes[sl] = 0;
     };
-    for (int sl = 0; sl < nS; sl++) load_slot(sl);
+    for (int sl = 0; sl < nS; sl++) load_slot(sl, true);
     R->join_pending = false;
     {   // the last drive's counts are this drive's history where job j is the same structure again
         bool same = R->hist_gen.size() == (size_t)Q;
@@ -345,8 +358,11 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
                 // the ml_spmv of iteration k + 1), rounded up to a pair: too many is a 1.2-us no-op per launch, too few another pass.  The
                 // first solve of an optimize has no predecessor: the first solve of the last optimize stands in (same structure or a grown
                 // one: a re-optimisation), a fresh run starts with two long replays.
-                w = v.pcg_last > 0 ? ((v.pcg_last + 2) & ~1) : (R->first_solve_its > 0 ? ((R->first_solve_its + 2) & ~1) : 2 * kLong);
-                static const bool no_history = diag_flag("UZL_LM_NO_HISTORY");               // A/B switch
+                // uzl_pgo_cfg::pass_history = 1: nothing an earlier optimize of this handle learned sizes a pass (the first solve starts with
+                // two long replays, every later one follows its predecessor in the same optimize)
+                static const bool no_history_env = diag_flag("UZL_LM_NO_HISTORY");           // A/B switch
+                const bool no_history = no_history_env || jobs[(size_t)slot_job[sl]].h->cfg.pass_history == 1;
+                w = v.pcg_last > 0 ? ((v.pcg_last + 2) & ~1) : ((R->first_solve_its > 0 && !no_history) ? ((R->first_solve_its + 2) & ~1) : 2 * kLong);
                 {
                     const std::vector<int>& hist = R->trial_its_prev[(size_t)slot_job[sl]];
                     if (!no_history && (size_t)v.st_lm_trials < hist.size()) w = std::max(w, (hist[(size_t)v.st_lm_trials] + 2) & ~1);
@@ -423,7 +439,7 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
             // (a rebuild of the outgoing graphs may still read the slot table and their LM state)
             if (R->join_pending && next_job < Q) { UZL_HIP(hipStreamWaitEvent(s, R->ev_join, 0)); R->join_pending = false; }
             for (int sl = 0; sl < nS; sl++)
-                if (slot_job[sl] >= 0 && jobs[slot_job[sl]].finished) load_slot(sl);
+                if (slot_job[sl] >= 0 && jobs[slot_job[sl]].finished) load_slot(sl, false);
         }
         const auto tp2 = std::chrono::steady_clock::now();
         enq_ms += std::chrono::duration<double, std::milli>(tp1 - tp0).count(); wait_ms += std::chrono::duration<double, std::milli>(tp2 - tp1).count();

@@ -8,6 +8,7 @@
 // the slot with a 64-bit CAS and prepends an entry with an atomic exchange; "unlink" marks a place's entries dead.
 // Byte / integer work bound by dependent HBM/L2 accesses (hash probe -> list walk); nothing to tile.
 #include "uzl_common.hpp"
+#include "uzl_streams.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -308,6 +309,7 @@ int uzl_places_create(const uzl_places_cfg* cfg, uzl_places** out)
     try {
         UZL_HIP(hipSetDevice(c.device));
         UZL_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        stream_register(c.device, h->stream, false);
         for (int t = 0; t < h->nt; t++) alloc_table(h, h->tab[t], 1u << 16);
         h->d_n_entries.reserve(1); h->d_used.reserve(8); h->h_small.reserve(16);
         UZL_HIP(hipMemsetAsync(h->d_n_entries.p, 0, 4, h->stream));
@@ -323,7 +325,7 @@ void uzl_places_destroy(uzl_places* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); stream_unregister(h->cfg.device, h->stream); (void)hipStreamDestroy(h->stream); }
     delete h;
 }
 

@@ -8,6 +8,7 @@
 // Two passes (count, then write at the exclusive prefix offsets) keep the jobs of all queries contiguous.
 // -ffp-contract=off: the distance / angle tests are bit-identical to the CPU checker.
 #include "uzl_common.hpp"
+#include "uzl_streams.hpp"
 
 #include <algorithm>
 #include <new>
@@ -171,6 +172,7 @@ int uzl_radius_create(const uzl_radius_cfg* cfg, uzl_radius** out)
     if (!h) return UZL_ERR_OOM;
     h->cfg = c;
     if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return UZL_ERR_HIP; }
+    stream_register(c.device, h->stream, false);
     *out = h;
     return UZL_OK;
 }
@@ -179,7 +181,7 @@ void uzl_radius_destroy(uzl_radius* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); stream_unregister(h->cfg.device, h->stream); (void)hipStreamDestroy(h->stream); }
     delete h;
 }
 

@@ -1,0 +1,228 @@
+// uzl_streams.hip — streams that do not stand in each other's way, chosen once per process.
+//
+// A HIP stream is served by one of the runtime's hardware queues (four per priority by default: GPU_MAX_HW_QUEUES), handed out at
+// hipStreamCreate, least used first, and the driver puts the queues on the GPU's four compute pipes in the order they were first made.
+// Streams on one queue run strictly one behind the other.  Streams on two queues of one PIPE do overlap for a single kernel - but two
+// chains of dependent kernels, one on each, take 2.7x the time of one chain (measured: tests/diag/stream_overlap.py), worse than
+// running them one after the other.  Which streams of a process collide either way depends on every stream it has made before: a batch
+// whose rebuild stream sat on the solver stream's pipe lost 15 - 45 % (16 chain-like graphs 14.3 -> 20.9 ms), two launch sequences on one
+// pipe ran 2x slower than one sequence.  Nothing tells a process where a stream landed, but it can be measured: a chain of 32 dependent
+// ~4-us kernels on one stream alone, then the same chain on both at once (independent pairs: 1.05 - 1.25x; one pipe: 2.7x; one queue: 2.0x;
+// the threshold is 1.5x).
+//
+// Round 4 measured at every uzl_pgo_batch_create and threw the rejected streams away.  Now the streams that have to run side by side
+// (a batch's launch sequences and their rebuild streams) come from ONE POOL PER DEVICE that lives as long as the process:
+//   * a pair of streams is measured at most once; the verdict is remembered, so the second batch of a process gets the first one's
+//     streams back without a single probe launch, and a process's choices do not change while it runs;
+//   * rejected streams stay in the pool (they keep their hardware queue, so the next stream lands elsewhere - and they are the first
+//     candidates of the next lease with other partners);
+//   * the search is bounded: at most kNewPerLease new streams per lease and kPoolMax per device; a lease that is `required` and finds
+//     nothing returns nullptr and the caller takes the layout that needs no such stream (a batch: one launch sequence) - the same
+//     layout UZL_STREAM_PROBE=0 selects without any measurement, for deployments that share the GPU (a probe under foreign load proves
+//     nothing);
+//   * the streams the handles make for themselves are registered, so that uzl_stream_stats shows every long-lived stream of the library.
+#include "uzl_streams.hpp"
+
+#include <algorithm>
+#include <chrono>
+
+namespace uzl {
+namespace {
+
+constexpr int kPoolMax = 16;            // streams per device
+constexpr int kNewPerLease = 6;         // new streams a single lease may add (three of the priority asked for, three of the other)
+constexpr int kMaxDevices = 16;
+
+__global__ void chain_kernel(unsigned ticks)
+{
+    const unsigned long long t0 = wall_clock64();            // 100 MHz
+    while (wall_clock64() - t0 < ticks) {}
+}
+
+// two chains of dependent kernels side by side against one chain alone
+double pair_over_single(hipStream_t a, hipStream_t b)
+{
+    constexpr int kLen = 32, kWgs = 1000;
+    auto run = [&](bool both) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < kLen; k++) {
+            hipLaunchKernelGGL(chain_kernel, dim3(kWgs), dim3(256), 0, a, 400u);
+            if (both) hipLaunchKernelGGL(chain_kernel, dim3(kWgs), dim3(256), 0, b, 400u);
+        }
+        (void)hipStreamSynchronize(a);
+        if (both) (void)hipStreamSynchronize(b);
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    };
+    (void)run(true);                                            // (first launches of a stream take longer)
+    const double alone = std::min(run(false), run(false));
+    const double pair = std::min(run(true), run(true));          // (anything else on the GPU can hold a run back once)
+    (void)hipGetLastError();
+    return pair / std::max(alone, 1e-9);
+}
+
+struct Pool {
+    std::mutex mu;
+    struct Entry { hipStream_t s; int prio; bool leased; };
+    std::vector<Entry> pooled;
+    struct Ext { hipStream_t s; bool beside; };
+    std::vector<Ext> registered;
+    std::map<std::pair<hipStream_t, hipStream_t>, bool> verdict;       // (lower pointer, higher pointer) -> independent
+    StreamPoolStats st;
+
+    bool independent(hipStream_t a, hipStream_t b)
+    {
+        if (a == b) return false;
+        const auto key = a < b ? std::make_pair(a, b) : std::make_pair(b, a);
+        auto it = verdict.find(key);
+        if (it != verdict.end()) return it->second;
+        const auto t0 = std::chrono::steady_clock::now();
+        const double r = pair_over_single(a, b);
+        st.probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const bool ok = r < 1.5;
+        st.pairs_measured++; if (ok) st.pairs_independent++;
+        static const bool dbg = diag_flag("UZL_STREAM_DBG");
+        if (dbg) fprintf(stderr, "[uzl] stream pair %p %p: pair / single chain %.2f -> %s\n", (void*)a, (void*)b, r, ok ? "independent" : "in each other's way");
+        verdict[key] = ok;
+        return ok;
+    }
+    void forget(hipStream_t s)
+    {
+        for (auto it = verdict.begin(); it != verdict.end();) it = (it->first.first == s || it->first.second == s) ? verdict.erase(it) : std::next(it);
+    }
+};
+
+Pool& pool_of(int device)
+{
+    static Pool pools[kMaxDevices];
+    return pools[std::min(std::max(device, 0), kMaxDevices - 1)];
+}
+
+bool probing_enabled()
+{
+    static const bool on = [] { const char* v = getenv("UZL_STREAM_PROBE"); return !(v && v[0] == '0'); }();
+    return on;
+}
+
+}  // namespace
+
+hipStream_t stream_lease(int device, int priority, const std::vector<hipStream_t>& apart_from, bool required)
+{
+    Pool& P = pool_of(device);
+    std::lock_guard<std::mutex> lock(P.mu);
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    std::vector<hipStream_t> hard;
+    for (hipStream_t o : apart_from) if (o) hard.push_back(o);
+    auto take = [&](Pool::Entry& e) { e.leased = true; return e.s; };
+    auto any = [&]() -> hipStream_t {                          // not required: whatever the pool has, or a fresh stream nobody measured
+        for (Pool::Entry& e : P.pooled) if (!e.leased && e.prio == priority) return take(e);
+        for (Pool::Entry& e : P.pooled) if (!e.leased) return take(e);
+        hipStream_t q = nullptr;                               // (kPoolMax bounds the search for independent streams, not the pool)
+        if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, priority) != hipSuccess) return nullptr;
+        P.pooled.push_back({q, priority, true});
+        return q;
+    };
+    if (!probing_enabled() || hard.empty()) {
+        if (required && !hard.empty()) { P.st.fallbacks++; return nullptr; }
+        return any();
+    }
+    // the estimator's streams run long launch sequences beside a solve: avoided when that costs no more than the measurement
+    std::vector<hipStream_t> soft;
+    for (const Pool::Ext& x : P.registered) if (x.beside && soft.size() < 2 && std::find(hard.begin(), hard.end(), x.s) == hard.end()) soft.push_back(x.s);
+    auto fits = [&](hipStream_t q) { for (hipStream_t o : hard) if (!P.independent(o, q)) return false; return true; };
+    auto soft_hits = [&](hipStream_t q) { int n = 0; for (hipStream_t o : soft) if (!P.independent(o, q)) n++; return n; };
+    int best = -1, best_hits = 1 << 30;
+    auto consider = [&](int i) {
+        if (!fits(P.pooled[(size_t)i].s)) return false;
+        const int hits = soft_hits(P.pooled[(size_t)i].s);
+        if (hits < best_hits) { best = i; best_hits = hits; }
+        return hits == 0;
+    };
+    // 1) what the pool holds, the priority asked for first, in the order the streams were made (a process's choices repeat)
+    bool done = false;
+    for (int pass = 0; pass < 2 && !done; pass++)
+        for (int i = 0; i < (int)P.pooled.size() && !done; i++)
+            if (!P.pooled[(size_t)i].leased && (P.pooled[(size_t)i].prio == priority) == (pass == 0)) done = consider(i);
+    // 2) new streams: the two priorities' queues sit on different pipes more often than not
+    for (int attempt = 0; attempt < kNewPerLease && !done && (int)P.pooled.size() < kPoolMax; attempt++) {
+        const int pr = attempt < kNewPerLease / 2 ? priority : (priority == 0 ? -1 : 0);
+        hipStream_t q = nullptr;
+        if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, pr) != hipSuccess) break;
+        P.pooled.push_back({q, pr, false});
+        done = consider((int)P.pooled.size() - 1);
+        if (best >= 0 && !soft.empty() && attempt >= 1) break;       // (a stream that fits the hard set is enough after one more try for the soft one)
+    }
+    if (best >= 0) return take(P.pooled[(size_t)best]);
+    P.st.fallbacks++;
+    return required ? nullptr : any();
+}
+
+void stream_release(int device, hipStream_t s)
+{
+    if (!s) return;
+    Pool& P = pool_of(device);
+    std::lock_guard<std::mutex> lock(P.mu);
+    for (Pool::Entry& e : P.pooled) if (e.s == s) { e.leased = false; return; }
+}
+
+void stream_register(int device, hipStream_t s, bool beside_solver)
+{
+    if (!s) return;
+    Pool& P = pool_of(device);
+    std::lock_guard<std::mutex> lock(P.mu);
+    P.registered.push_back({s, beside_solver});
+}
+
+void stream_unregister(int device, hipStream_t s)
+{
+    if (!s) return;
+    Pool& P = pool_of(device);
+    std::lock_guard<std::mutex> lock(P.mu);
+    for (size_t i = 0; i < P.registered.size(); i++)
+        if (P.registered[i].s == s) { P.registered.erase(P.registered.begin() + (long)i); break; }
+    P.forget(s);                                                // (the runtime may hand the address to another stream)
+}
+
+StreamPoolStats stream_pool_stats(int device)
+{
+    Pool& P = pool_of(device);
+    std::lock_guard<std::mutex> lock(P.mu);
+    StreamPoolStats s = P.st;
+    s.pooled = (int32_t)P.pooled.size();
+    s.leased = 0; for (const Pool::Entry& e : P.pooled) if (e.leased) s.leased++;
+    s.registered = (int32_t)P.registered.size();
+    return s;
+}
+
+}  // namespace uzl
+
+extern "C" int uzl_stream_stats(int32_t device, int32_t* n_pooled, int32_t* n_leased, int32_t* n_registered, int32_t* pairs_measured,
+                                int32_t* pairs_independent, int32_t* fallbacks, double* probe_ms)
+{
+    if (device < 0 || device >= uzl::kMaxDevices) return UZL_ERR_BAD_ARG;
+    const uzl::StreamPoolStats s = uzl::stream_pool_stats(device);
+    if (n_pooled) *n_pooled = s.pooled;
+    if (n_leased) *n_leased = s.leased;
+    if (n_registered) *n_registered = s.registered;
+    if (pairs_measured) *pairs_measured = s.pairs_measured;
+    if (pairs_independent) *pairs_independent = s.pairs_independent;
+    if (fallbacks) *fallbacks = s.fallbacks;
+    if (probe_ms) *probe_ms = s.probe_ms;
+    return UZL_OK;
+}
+
+// test hook of the diagnostic build (tests/diag/stream_overlap.py, tests/test_zz_streams_gpu.py): n fresh streams - of priority
+// `priority`, or of priorities 0 and -1 in turn for priority = 200 - and out[i * n + j] = 100 x (two chains of dependent kernels on
+// streams i and j at once / one chain on stream i): the pool's measurement, uncached
+#ifdef UZL_DIAG
+extern "C" UZL_DIAG_EXPORT int uzl_debug_stream_pairs(int n, int priority, int32_t* out)
+{
+    if (n < 2 || n > 16 || !out) return UZL_ERR_BAD_ARG;
+    std::vector<hipStream_t> q((size_t)n, nullptr);
+    for (int i = 0; i < n; i++)
+        if (hipStreamCreateWithPriority(&q[i], hipStreamNonBlocking, priority == 200 ? -(i & 1) : priority) != hipSuccess) return UZL_ERR_HIP;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) out[i * n + j] = (i == j) ? -1 : (int32_t)(100. * uzl::pair_over_single(q[i], q[j]) + 0.5);
+    for (hipStream_t s : q) (void)hipStreamDestroy(s);
+    return UZL_OK;
+}
+#endif
