@@ -76,6 +76,8 @@ for key, names in (("pcg_spmv_bytes_per_launch", ("uzl::ml_spmv_lm_kernel<1, 1, 
                    ("pcg_spmv4_bytes_per_launch", ("c4:uzl::ml_spmv_lm_kernel<4, 4, 4", "uzl::ml_spmv_lm_kernel<4, 4, 4", "c4:uzl::ml_spmv_kernel<4>", "uzl::ml_spmv_kernel<4>")),
                    ("c4_hessian_bytes_per_launch", ("c4:uzl::hessian_lm_kernel", "c4:uzl::hessian_kernel")),
                    ("hessian_bytes_per_launch", ("uzl::hessian_lm_kernel", "uzl::hessian_kernel")),
+                   ("c4_ns_gemm_bytes_per_launch", ("c4:uzl::ml_ns_gemm_lm_kernel", "c4:uzl::ml_ns_gemm_kernel")),
+                   ("ns_gemm32_bytes_per_launch", ("uzl::ml_ns_gemm32_lm_kernel", "uzl::ml_ns_gemm32_kernel")),
                    ("knn2_bytes_per_launch", ("uzl::knn2_mfma_kernel<8, 2>", "uzl::knn2_lds_kernel<8, 1>", "uzl::knn2_kernel<8>")),
                    ("estimate_bytes_per_launch", ("uzl::estimate_kernel",)),
                    ("wire_unpack_bytes_per_launch", ("uzl::wire_unpack_kernel",))):

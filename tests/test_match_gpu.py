@@ -235,6 +235,34 @@ def test_c3_full_batch_properties(capi, oracle):
     m.close()
 
 
+def test_deployed_operating_point_all_pairs(capi, oracle):
+    """The estimator as the reference deploys it: BRISK-512 (64-byte descriptors), 300 keypoints per frame
+    (feature_extraction_service_node.cpp:63-66), ransac_threshold 0.1 / 100 iterations (iti_slam_launch/yaml/slam.yaml:34-38), early exit
+    at 60 % consensus (cfg/FeatureLinkEstimation.cfg:12): 512 pairs, every one against the oracle bit for bit - `iterations_run` included,
+    i.e. the early exit fires in the same iteration."""
+    cfg = dict(ransac_threshold=0.1, ransac_iteration=100, ransac_break_percentage=0.6, do_prosac=1, seed=777)
+    pairs = synth.make_pairs(512, n_kp=300, desc_bytes=64, seed=4242)
+    m = capi.Match(**cfg)
+    ids = [(m.add_frame(f["desc"], f["pos"], f["valid"]), m.add_frame(t["desc"], t["pos"], t["valid"])) for f, t, _ in pairs]
+    res, diag = m.estimate(ids, max_corr=300)
+    assert res["ok"].all()
+    assert (res["iterations_run"] < 100).mean() > 0.5          # the early exit is what this operating point is about
+    for j in range(512):
+        f, t, _ = pairs[j]
+        w = oracle.estimate_edge([f], [t], ransac_threshold=0.1, ransac_iteration=100, break_percentage=0.6, do_prosac=True, seed=777, job_id=j)
+        k = w["n_corr"]
+        assert res[j]["consensus"] == w["consensus"] and res[j]["n_corr"] == k and res[j]["n_matches"] == w["n_matches"]
+        assert res[j]["iterations_run"] == w["iterations_run"] and res[j]["best_iteration"] == w["best_iteration"]
+        assert np.array_equal(diag["mask"][j, :k], w["mask"]) and np.array_equal(diag["corr_query"][j, :k], w["corr_query"])
+        assert np.array_equal(diag["corr_train"][j, :k], w["corr_train"])
+        assert np.array_equal(res[j]["T"].reshape(3, 4), w["T"]) and res[j]["mse"] == w["mse"]
+        assert np.array_equal(res[j]["information"].reshape(6, 6), w["information"])
+    Tgt = np.array([p[2] for p in pairs])
+    dt, dr = synth.pose_errors(res["T"].reshape(-1, 3, 4), Tgt)
+    assert dt < 0.03 and dr < np.deg2rad(0.6), (dt, dr)
+    m.close()
+
+
 def test_random_shapes_against_oracle():
     """Randomized sweep (tests/diag/stress_match.py): frame sizes 7 .. 2700, 256- and 512-bit descriptors, outlier / validity fractions,
     thresholds, 1 .. 1000 iterations, early exit, PROSAC on / off, duplicate descriptors (2-NN ties), smaller train than query sets,

@@ -715,7 +715,11 @@ __global__ __launch_bounds__(kBlk) void hessian_lm_kernel(const LmSlot* __restri
     if (lm->phase != kLmLin) return;
     const int b = blockIdx.x;
     if (b < g_rows_launch) { if (b < S.g_asm) hessian_rows_body(S.D, S.pose[lm->cur], lm->delta, b); }
-    else if (b - g_rows_launch < S.g_edges) chi2_kernel_body(S.D, S.pose[lm->cur], lm->delta, b - g_rows_launch, S.g_edges);
+    // chi2 of the linearisation point (computeActiveErrors): the loop needs it in its first iteration only - later ones start from an
+    // accepted trial, whose chi2 the evaluation of that trial computed from the same poses with the same kernel body (lm_head_kernel
+    // takes chi_cur from the partials at it == 0 and carries it afterwards).  Skipping the workgroups saves their second pass over every
+    // edge's measurement and information matrix (17 MB of the kernel's 92 MB of traffic at 10k / 50k).
+    else if (lm->it == 0 && b - g_rows_launch < S.g_edges) chi2_kernel_body(S.D, S.pose[lm->cur], lm->delta, b - g_rows_launch, S.g_edges);
 }
 // the evaluation of a trial runs once its solve has ended without a breakdown (lm_tail_kernel sorts the rest out)
 __device__ __forceinline__ bool lm_evaluates(const LmDev* lm) { return lm->phase == kLmSolve && lm->flags[0] != 0 && lm->flags[2] == 0; }
@@ -776,11 +780,12 @@ int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s)
     return g;
 }
 // the Hessian build (G3-G6): *g_edges chi2 partials in part_a, *g_rows diagonal maxima in part_c
-hipError_t k_hessian(const PgoDev& D, const double* pose, double delta, int* g_edges, int* g_rows, hipStream_t s)
+// (with_chi2 = false: the caller carries chi2 over from the accepted trial - the chi2 workgroups are not launched, part_a keeps that trial's partials)
+hipError_t k_hessian(const PgoDev& D, const double* pose, double delta, int* g_edges, int* g_rows, hipStream_t s, bool with_chi2)
 {
     *g_edges = grid_for(D.e_end - D.e_begin, kBlk, kMaxPartials);
     *g_rows = D.n_rb;
-    hipLaunchKernelGGL(hessian_kernel, dim3(*g_rows + *g_edges), dim3(kBlk), 0, s, D, pose, delta, *g_rows, *g_edges);
+    hipLaunchKernelGGL(hessian_kernel, dim3(*g_rows + (with_chi2 ? *g_edges : 0)), dim3(kBlk), 0, s, D, pose, delta, *g_rows, *g_edges);
     return hipSuccess;
 }
 int k_diagmax(const PgoDev& D, hipStream_t s)

@@ -827,15 +827,31 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = v4f64{0., 0., 0., 0.};
-    double pa[kPer], pb[kPer];
+    // A lane fetches PAIRS of neighbouring rows / columns (16-byte loads; n = 6 n_c is even and the tiles start at multiples of 64, so a
+    // pair is aligned and never straddles the matrix edge); slabs and tiles that lie inside the matrix - all but the last of each - load
+    // without a bounds test (round 4's element-wise predicated loads were 32 branches per slab and operand).
+    double2 pa[kPer / 2], pb[kPer / 2];
+    const bool tile_inside = row0 + kGemmTile <= n && col0 + kGemmTile <= n && (n & 1) == 0;
     auto fetch = [&](int k0) {
+        if (tile_inside && k0 + kGemmK <= n) {
 #pragma unroll
-        for (int u = 0; u < kPer; u++) {
-            const int e = u * 256 + tid;
-            const int ek = e / kGemmTile, ei = e % kGemmTile;                    // consecutive lanes walk the row / column index
-            const int gk = k0 + ek, gr = row0 + ei, gc = col0 + ei;
-            pa[u] = (gk < n && gr < n) ? X[(size_t)gk * n + gr] : 0.;            // = X[gr][gk]
-            pb[u] = (gk < n && gc < n) ? T[(size_t)gk * n + gc] : 0.;
+            for (int u = 0; u < kPer / 2; u++) {
+                const int e = u * 256 + tid;
+                const int ek = e / (kGemmTile / 2), ei = 2 * (e % (kGemmTile / 2));      // consecutive lanes walk the row / column index
+                pa[u] = *reinterpret_cast<const double2*>(X + (size_t)(k0 + ek) * n + row0 + ei);      // = X[row][k], X symmetric
+                pb[u] = *reinterpret_cast<const double2*>(T + (size_t)(k0 + ek) * n + col0 + ei);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kPer / 2; u++) {
+                const int e = u * 256 + tid;
+                const int ek = e / (kGemmTile / 2), ei = 2 * (e % (kGemmTile / 2));
+                const int gk = k0 + ek, gr = row0 + ei, gc = col0 + ei;
+                pa[u].x = (gk < n && gr < n) ? X[(size_t)gk * n + gr] : 0.;
+                pa[u].y = (gk < n && gr + 1 < n) ? X[(size_t)gk * n + gr + 1] : 0.;
+                pb[u].x = (gk < n && gc < n) ? T[(size_t)gk * n + gc] : 0.;
+                pb[u].y = (gk < n && gc + 1 < n) ? T[(size_t)gk * n + gc + 1] : 0.;
+            }
         }
     };
     fetch(0);
@@ -848,15 +864,18 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
     int slab = 0;
     for (int k0 = 0; k0 < n; k0 += kGemmK, slab++) {
 #pragma unroll
-        for (int u = 0; u < kPer; u++) {
+        for (int u = 0; u < kPer / 2; u++) {
             const int e = u * 256 + tid;
-            const int ek = e / kGemmTile, ei = (e % kGemmTile) ^ ((ek & 1) << 4);
-            sA[ek][ei] = pa[u];
-            sB[ek][ei] = pb[u];
+            const int ek = e / (kGemmTile / 2), ei = (2 * (e % (kGemmTile / 2))) ^ ((ek & 1) << 4);      // (the swizzle moves pairs as pairs)
+            *reinterpret_cast<double2*>(&sA[ek][ei]) = pa[u];
+            *reinterpret_cast<double2*>(&sB[ek][ei]) = pb[u];
         }
         __syncthreads();
         if (k0 + kGemmK < n) fetch(k0 + kGemmK);
-#pragma unroll 4
+        // (Measured and not kept: the next pair of k-steps' operands read from LDS ahead of this pair's MFMAs, the order pinned with
+        //  __builtin_amdgcn_sched_group_barrier - eight LDS reads in flight per wave instead of four: 200 -> 253 us at n = 1878, 1253 -> 1523 us
+        //  at n = 3750.  With two workgroups per CU the other wave's MFMAs already cover a wave's LDS round trip.)
+#pragma unroll
         for (int k4 = 0; k4 < kGemmK; k4 += 4) {
             const double a0 = sA[k4 + lk][(wr + li) ^ sw], a1 = sA[k4 + lk][(wr + 16 + li) ^ sw];
             const double b0 = sB[k4 + lk][(wc + li) ^ sw], b1 = sB[k4 + lk][(wc + 16 + li) ^ sw];

@@ -34,7 +34,9 @@ struct uzl_gate {
     std::vector<double> poses;
     std::vector<uint8_t> merged;
     struct E { int32_t from, to, type, valid; };
-    std::vector<E> edges;
+    std::vector<E> edges;                 // the graph's edges: those of the last uzl_gate_set_graph that are in range, then the accepted candidates
+    std::vector<E> given;                 // the edge list of the last uzl_gate_set_graph as given (a grown graph repeats it: set_graph)
+    size_t n_base = 0;                    // edges[0 .. n_base) came with set_graph
     std::vector<int32_t> nb_tmp;
     std::unordered_set<uint64_t> pair_type;                         // (min, max, type) of every edge, packed (pair_key): existsEdge(from, to, type)
     bool adj_dirty = true, poses_dirty = true;
@@ -179,17 +181,50 @@ int uzl_gate_set_graph(uzl_gate* h, int32_t n_nodes, const double* poses, const 
 {
     UZL_GUARD_BEGIN(h)
     if (n_nodes < 0 || n_edges < 0 || (n_nodes > 0 && !poses) || (n_edges > 0 && !edges)) return fail(h, UZL_ERR_BAD_ARG, "null arrays");
+    // An online session calls this once per re-optimisation interval with a graph that has only GROWN (graph_slam_node.cpp:779-829 sees the
+    // SlamGraph of the moment; edge ids are time-ordered, :294): the edges of the last call come first again, at most their `valid` flags
+    // differ, new edges follow.  Then only the tail is entered (the existsEdge index was ~1 ms of hash inserts per call at 20k nodes,
+    // config 5) - the resulting state is the one the full rebuild below leaves: same edge list in the same order, so the same
+    // adjacency order and the same searches.  Edges uzl_gate_check accepted since the last call are not part of the caller's graph
+    // unless they come back in `edges`.
+    bool grown = h->given.size() <= (size_t)n_edges && n_nodes >= h->n && !h->given.empty();
+    for (size_t k = 0; grown && k < h->given.size(); k++) {
+        const uzl_gate::E& g = h->given[k];
+        grown = g.from == edges[k].from && g.to == edges[k].to && g.type == edges[k].type;
+    }
+    // (an edge that was out of range with fewer nodes and is in range now would have to be inserted in the middle of the list)
+    for (size_t k = 0; grown && k < h->given.size(); k++) {
+        const uzl_gate::E& g = h->given[k];
+        const bool was_in = g.from >= 0 && g.to >= 0 && g.from < h->n && g.to < h->n, is_in = g.from >= 0 && g.to >= 0 && g.from < n_nodes && g.to < n_nodes;
+        grown = was_in == is_in;
+    }
+    if (grown) {
+        for (size_t k = h->n_base; k < h->edges.size(); k++) h->pair_type.erase(pair_key(h->edges[k].from, h->edges[k].to, h->edges[k].type));      // accepted candidates
+        h->edges.resize(h->n_base);
+        size_t own = 0;
+        for (size_t k = 0; k < h->given.size(); k++) {
+            uzl_gate::E& g = h->given[k];
+            if (g.from < 0 || g.to < 0 || g.from >= h->n || g.to >= h->n) continue;
+            const int32_t v = edges[k].valid ? 1 : 0;
+            if (h->edges[own].valid != v) { h->edges[own].valid = v; g.valid = v; }
+            own++;
+        }
+    } else {
+        h->edges.clear(); h->pair_type.clear(); h->given.clear();
+        h->edges.reserve((size_t)n_edges + 64); h->pair_type.reserve((size_t)n_edges * 2 + 64);
+    }
+    h->given.reserve((size_t)n_edges);
+    for (int32_t k = (int32_t)h->given.size(); k < n_edges; k++) {
+        const uzl_gate_edge& e = edges[k];
+        h->given.push_back({e.from, e.to, e.type, e.valid ? 1 : 0});
+        if (e.from < 0 || e.to < 0 || e.from >= n_nodes || e.to >= n_nodes) continue;
+        add_edge(h, e.from, e.to, e.type, e.valid ? 1 : 0);
+    }
+    h->n_base = h->edges.size();
     h->n = n_nodes;
     h->poses.assign(poses, poses + 12 * (size_t)n_nodes);
     h->merged.assign((size_t)n_nodes, 0);
     if (merged) h->merged.assign(merged, merged + n_nodes);
-    h->edges.clear(); h->pair_type.clear();
-    h->edges.reserve((size_t)n_edges + 64); h->pair_type.reserve((size_t)n_edges * 2 + 64);
-    for (int32_t k = 0; k < n_edges; k++) {
-        const uzl_gate_edge& e = edges[k];
-        if (e.from < 0 || e.to < 0 || e.from >= n_nodes || e.to >= n_nodes) continue;
-        add_edge(h, e.from, e.to, e.type, e.valid ? 1 : 0);
-    }
     h->adj_dirty = true; h->poses_dirty = true;
     return UZL_OK;
     UZL_GUARD_END(h)

@@ -1093,7 +1093,9 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         }
         D.pose = h->cur; D.pose_trial = h->trial;
         Dp.pose = h->cur; Dp.pose_trial = h->trial;
-        { Timed t(h, "linearize"); UZL_HIP(k_hessian(D, h->cur, delta, &gl, &ga, s)); }     // computeActiveErrors + buildSystem
+        // (computeActiveErrors: chi2 of the linearisation point is needed in the first iteration, and by every rank of a sharded solve,
+        //  which exchanges it; later iterations carry the accepted trial's over - as lm_head_kernel does)
+        { Timed t(h, "linearize"); UZL_HIP(k_hessian(D, h->cur, delta, &gl, &ga, s, it == 0 || h->sharded)); }     // computeActiveErrors + buildSystem
         if (h->sharded) {                                                         // H_aa, b: sums over all ranks' edges
             shard_allreduce(h, h->d_hdiag.p, (int64_t)h->nb * 42);
             ga = k_diagmax(D, s);

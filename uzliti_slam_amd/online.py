@@ -39,12 +39,24 @@ class OnlineStats(dict):
 
 
 def _se3_chain(pose_prev, odo):
-    """poses of consecutive new nodes: pose_prev * odo[0], that * odo[1], ...  (k,3,4)"""
-    out = np.empty((len(odo), 3, 4))
-    p = pose_prev
-    for k in range(len(odo)):
-        p = synth.se3_mul(p, odo[k])
-        out[k] = p
+    """poses of consecutive new nodes: pose_prev * odo[0], that * odo[1], ...  (k,3,4).  A prefix product by doubling (log2 k batched
+    3 x 3 products instead of k small ones in a Python loop, which was most of this driver's own time: 1 ms per interval)."""
+    k = len(odo)
+    if k == 0:
+        return np.empty((0, 3, 4))
+    A = np.asarray(odo, np.float64).reshape(k, 3, 4)
+    Rm = A[:, :, :3].copy(); t = A[:, :, 3].copy()
+    d = 1
+    while d < k:                                    # after the step, entry i holds odo[i - 2d + 1 .. i] multiplied in order
+        Rn = Rm.copy(); tn = t.copy()
+        Rn[d:] = Rm[:-d] @ Rm[d:]
+        tn[d:] = np.einsum("nij,nj->ni", Rm[:-d], t[d:]) + t[:-d]
+        Rm, t = Rn, tn
+        d *= 2
+    P = np.asarray(pose_prev, np.float64).reshape(3, 4)
+    out = np.empty((k, 3, 4))
+    out[:, :, :3] = P[:, :3] @ Rm
+    out[:, :, 3] = t @ P[:, :3].T + P[:, 3]
     return out
 
 
@@ -90,6 +102,11 @@ class OnlineSlam:
         self._t_first = None                          # start of the first interval: every solve records the wall clock since then
         self.incremental = bool(incremental)          # grow the solver's resident graph (uzl_pgo_append_graph) instead of re-sending all of it
         self._pgo_nodes = 0; self._pgo_feats = 0; self._pgo_edges = 0; self._f_in_idx = np.zeros(0, np.int32); self._last = None
+        # the graph the gate sees, in the order its edges came into being (the reference's edge ids are time-ordered, graph_slam_node.cpp:294):
+        # the odometry edges and accepted feature edges of every interval behind those of the interval before.  Kept as one growing array -
+        # every interval's list repeats the last one's and adds a tail, which is what uzl_gate_set_graph recognises.
+        self._ge = np.zeros(1024, capi.GATE_EDGE_DTYPE); self._ge["transform"] = I12
+        self._ge_n = 0; self._ge_nodes = 1; self._ge_feats = 0; self._ge_fidx = np.zeros(0, np.int64)
 
     def _open_handles(self, device, mc, gate_cfg, filter_cfg, pgo_cfg):
         """The four C-ABI handles of the path (estimator on every rank; gate, filter and solver on the solver rank)."""
@@ -105,10 +122,19 @@ class OnlineSlam:
         """FeatureData of this rank's pairs -> HBM (once; outside any timed region of the bench)."""
         t0 = time.perf_counter()
         self.fid = {}
+        mine = []
         for b0 in range(0, self.P, self.match_batch):
             b1 = min(self.P, b0 + self.match_batch)
             lo, hi = ud.shard_range(b1 - b0, self.rank, self.world)
-            for k in range(b0 + lo, b0 + hi):
+            mine += list(range(b0 + lo, b0 + hi))
+        if hasattr(self.matcher, "add_frames") and hasattr(capi.Match, "pack_frames") and mine:
+            # one uzl_match_add_frames call for all of this rank's frames (what the adapter's batching worker does)
+            packed = capi.Match.pack_frames([(x["desc"], x["pos"], x["valid"]) for k in mine for x in self.run["frames"][k]])
+            flat = self.matcher.add_frames(packed)
+            for q, k in enumerate(mine):
+                self.fid[k] = (int(flat[2 * q]), int(flat[2 * q + 1]))
+        else:
+            for k in mine:
                 f, t = self.run["frames"][k]
                 self.fid[k] = (self.matcher.add_frame(f["desc"], f["pos"], f["valid"]), self.matcher.add_frame(t["desc"], t["pos"], t["valid"]))
         self.t["upload"] = time.perf_counter() - t0
@@ -160,6 +186,28 @@ class OnlineSlam:
              "diff_time": np.concatenate([np.full(no, 0.5), np.zeros(nf)])}
         return e
 
+    def _gate_graph(self, hi, nf):
+        """The gate's edge list for nodes [0, hi) and the first nf accepted feature edges: last interval's list, the `valid` flags of its
+        feature edges as they are now, then the new odometry edges (node i-1 -> i) and the feature edges accepted since."""
+        no = hi - self._ge_nodes; nfn = nf - self._ge_feats
+        need = self._ge_n + no + nfn
+        if need > len(self._ge):
+            grown = np.zeros(max(need, 2 * len(self._ge)), capi.GATE_EDGE_DTYPE); grown["transform"] = I12
+            grown[:self._ge_n] = self._ge[:self._ge_n]
+            self._ge = grown
+        g = self._ge
+        if self._ge_feats:
+            g["valid"][self._ge_fidx] = self.f_sticky[:self._ge_feats]
+        a = self._ge_n
+        g["from"][a:a + no] = np.arange(self._ge_nodes - 1, hi - 1); g["to"][a:a + no] = np.arange(self._ge_nodes, hi)
+        g["type"][a:a + no] = synth.EDGE_TYPE_ODOM; g["valid"][a:a + no] = 1
+        b = a + no
+        g["from"][b:b + nfn] = self.f_from[self._ge_feats:nf]; g["to"][b:b + nfn] = self.f_to[self._ge_feats:nf]
+        g["type"][b:b + nfn] = synth.EDGE_TYPE_3D_FULL; g["valid"][b:b + nfn] = self.f_sticky[self._ge_feats:nf]
+        self._ge_fidx = np.concatenate([self._ge_fidx, np.arange(b, b + nfn, dtype=np.int64)])
+        self._ge_n = need; self._ge_nodes = hi; self._ge_feats = nf
+        return g[:need]
+
     @property
     def last_input(self):
         """(poses, fixed, edges) of the last re-optimisation as addGraphImpl gets them: the full arrays (tests, diagnostics)."""
@@ -193,10 +241,7 @@ class OnlineSlam:
         # ---- acceptance gate (newEdgeCallback) over the graph up to `hi`
         t0 = time.perf_counter()
         nf = len(self.f_key)
-        ge = capi.gate_edges(np.concatenate([np.arange(hi - 1), self.f_from]), np.concatenate([np.arange(1, hi), self.f_to]),
-                             np.concatenate([np.full(hi - 1, synth.EDGE_TYPE_ODOM), np.full(nf, synth.EDGE_TYPE_3D_FULL)]),
-                             valid=np.concatenate([np.ones(hi - 1, int), self.f_sticky.astype(int)]))
-        self.gate.set_graph(self.poses[:hi].reshape(-1, 12), ge)
+        self.gate.set_graph(self.poses[:hi].reshape(-1, 12), self._gate_graph(hi, nf))
         self.t["gate_set_graph"] += time.perf_counter() - t0
         if len(cand_pair):
             cands = capi.gate_edges(run["pair_from"][cand_pair], run["pair_to"][cand_pair], np.ones(len(cand_pair), int),
