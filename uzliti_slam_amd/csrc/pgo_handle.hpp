@@ -158,6 +158,7 @@ struct uzl_pgo {
     int ml_ix = 0;
     bool ml_pending = false;                   // a rebuild into copy ml_ix ^ 1 is in flight on stream2
     hipStream_t stream2 = nullptr;
+    bool streams_borrowed = false;             // stream / stream2 are a batch's (uzl_pgo_batch_create): not this handle's to destroy
     hipEvent_t ev_lin = nullptr, ev_setup = nullptr;
     DevBuf<double> d_scal2;                    // lambda slot (scal[3]) for the kernels of an asynchronous rebuild
     double lambda_now = 0.;          // lambda of the current trial
@@ -207,6 +208,7 @@ bool ml_async_level(const uzl_pgo* h);
 void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void prepare_optimize(uzl_pgo* h);                    // optimizeImpl's front part: gauge + structure (cached), t_start
+void own_streams(uzl_pgo* h);               // a batch's handle takes streams of its own (uzl_pgo.hip)
 int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);      // the host-driven loop (sharded / block-Jacobi / profiled solves, anomaly fallback)
 int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);           // picks the loop
 // ---- the device-resident loop (uzl_pgo_lm.hip)

@@ -86,7 +86,7 @@ std::vector<int32_t> strong_groups(int n, std::vector<WEdge>& E, int cap, double
 // strongly coupled ones - to a block of 32 rows, every group padded to 8 rows and every block to 4 groups with EMPTY rows
 // (sep_rows = -1: identity diagonal block, zero right-hand side, no off-diagonal blocks).  A removed run counts as springs in series.
 SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vector<int32_t>& col, int cap, const double* slot_w, int strong_min,
-                     double theta, double max_contiguous, int one_level_max)
+                     double theta, double max_contiguous, int one_level_max, int min_interiors)
 {
     SchurPlan P;
     P.nb = nb;
@@ -145,6 +145,7 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
     P.n_sep = (int32_t)P.sep_rows.size();
     P.nbr = P.n_sep;
     P.n_int = nb - P.n_sep;
+    if (P.n_int < min_interiors) return P;                  // the caller will not reduce: nothing below is looked at
     // pass 2: the runs
     std::vector<uint8_t> in_run((size_t)std::max(nb, 1), 0);
     P.run_ptr.push_back(0);

@@ -303,11 +303,26 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
             const int A = F.srow[s] / fan_c, Cc = c / fan_c;
             if (A != Cc) off.push_back({A, Cc, s}); else dg.push_back({A, s});
         }
-        std::sort(off.begin(), off.end(), [](const Off& x, const Off& y) {
-            if (x.A != y.A) return x.A < y.A;
-            if (x.C != y.C) return x.C < y.C;
-            return x.s < y.s; });
-        std::sort(dg.begin(), dg.end());
+        // order by (A, C, s) / (A, s).  The slots come in ascending s and a coarse row holds a few dozen of them: a stable counting pass by A,
+        // then a small sort inside every row (one std::sort over all of level 0's 100k slots was most of the 4 ms this function took at 10k / 50k)
+        {
+            std::vector<int32_t> cnt((size_t)nc + 1, 0);
+            for (const Off& o : off) cnt[o.A + 1]++;
+            for (int a = 0; a < nc; a++) cnt[a + 1] += cnt[a];
+            std::vector<Off> tmp(off.size());
+            std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
+            for (const Off& o : off) tmp[pos[o.A]++] = o;
+            off.swap(tmp);
+            for (int a = 0; a < nc; a++)
+                std::sort(off.begin() + cnt[a], off.begin() + cnt[a + 1], [](const Off& x, const Off& y) { return x.C != y.C ? x.C < y.C : x.s < y.s; });
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (const auto& d : dg) cnt[d.first + 1]++;
+            for (int a = 0; a < nc; a++) cnt[a + 1] += cnt[a];
+            std::vector<std::pair<int32_t, int32_t>> dt(dg.size());
+            pos.assign(cnt.begin(), cnt.end() - 1);
+            for (const auto& d : dg) dt[pos[d.first]++] = d;                  // (s ascending within A already)
+            dg.swap(dt);
+        }
         C.row_ptr.assign((size_t)nc + 1, 0);
         for (size_t k = 0; k < off.size(); k++) {
             if (k == 0 || off[k].A != off[k - 1].A || off[k].C != off[k - 1].C) {
@@ -774,7 +789,9 @@ void build_structure(uzl_pgo* h)
             for (int q = 0; q < nslots; q++) slot_w[q] = h->edge_w[slot_edge[q] >> 1];
         }
         static const int one_level_max = diag_int("UZL_SCHUR_STRONG_ONE_MAX", kSchurStrongOneMax);
-        SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap, slot_w.empty() ? nullptr : slot_w.data(), strong_min, 0.01 * strong_theta_pct, max_contig, one_level_max);
+        // (reduced when >= 64 rows and >= schur_min_pct of the rows go: the plan stops early otherwise)
+        const int min_int = std::max(64, (int)(((int64_t)schur_min_pct * nb + 99) / 100));
+        SchurPlan P = schur_plan(nb, row_ptr, col, schur_cap, slot_w.empty() ? nullptr : slot_w.data(), strong_min, 0.01 * strong_theta_pct, max_contig, one_level_max, min_int);
         tick("Schur plan");
         if (P.n_int >= 64 && (int64_t)100 * P.n_int >= (int64_t)schur_min_pct * nb) {
             Rd.on = true; Rd.n_int = P.n_int; Rd.n_runs = P.n_runs; Rd.longest_run = P.longest_run; Rd.strong = P.strong; Rd.strong_blocks = P.strong && P.n_strong2 > 0; Rd.n_sep = P.n_sep;
@@ -1284,6 +1301,60 @@ static bool same_structure(const uzl_pgo* h, const StructureKey& k)
     catch (const std::bad_alloc&) { (h)->last_error = "host out of memory"; return UZL_ERR_OOM; } \
     catch (...) { (h)->last_error = "unexpected exception"; return UZL_ERR_HIP; }
 
+// A handle with streams of its own (uzl_pgo_create), or - the graphs of a batch - on the batch's streams: a stream costs the runtime
+// ~3.5 ms to make and ~2 ms to destroy (uzl_pgo_create 6.9 ms, measured: tests/diag/create_cost.py), which a batch of 64 graphs paid
+// 128 times over although its solves never use its handles' streams.  A batch's handle takes streams of its own the first time it is
+// solved through uzl_pgo_optimize (own_streams).
+static int pgo_create_on(const uzl_pgo_cfg* cfg, hipStream_t shared, hipStream_t shared2, uzl_pgo** out)
+{
+    if (!out) return UZL_ERR_BAD_ARG;
+    *out = nullptr;
+    uzl_pgo_cfg c;
+    if (cfg) c = *cfg; else uzl_pgo_cfg_default(&c);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return UZL_ERR_NO_DEVICE;
+    if (c.device < 0 || c.device >= ndev) return UZL_ERR_NO_DEVICE;
+    uzl_pgo* h = new (std::nothrow) uzl_pgo();
+    if (!h) return UZL_ERR_OOM;
+    h->cfg = c;
+    memset(&h->D, 0, sizeof(h->D));
+    { const char* ng = getenv("UZL_NO_GRAPH"); h->no_graph = ng && ng[0] == '1'; }
+    if (getenv("UZL_VERBOSE")) h->cfg.verbose = 1;                                    // diagnostic: per-trial PCG log on stderr
+    bool ok = hipSetDevice(c.device) == hipSuccess;
+    if (ok && shared) { h->stream = shared; h->stream2 = shared2; h->streams_borrowed = true; }
+    else if (ok) {
+        ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
+             hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, diag_int("UZL_S2_PRIO", -1)) == hipSuccess;      // rebuilds ahead of the PCG they overlap with
+    }
+    ok = ok && hipEventCreateWithFlags(&h->ev_lin, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->ev_setup, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        if (!h->streams_borrowed) { if (h->stream) (void)hipStreamDestroy(h->stream); if (h->stream2) (void)hipStreamDestroy(h->stream2); }
+        if (h->ev_lin) (void)hipEventDestroy(h->ev_lin);
+        if (h->ev_setup) (void)hipEventDestroy(h->ev_setup);
+        delete h;
+        return UZL_ERR_HIP;
+    }
+    // (a single handle's solve with its 0.25-ms rebuilds never moved measurably with the placement of its two streams: they are taken as
+    //  they come and entered in the device's registry; the streams that must run side by side are a batch's, uzl_streams.hip)
+    if (!h->streams_borrowed) { stream_register(c.device, h->stream, false); stream_register(c.device, h->stream2, false); }
+    *out = h;
+    return UZL_OK;
+}
+// a batch's handle that is solved on its own: from now on with its own streams (captures and rebuild events of two such handles driven
+// from two threads must not meet on one stream)
+void uzl::own_streams(uzl_pgo* h)
+{
+    if (!h->streams_borrowed) return;
+    UZL_HIP(hipSetDevice(h->cfg.device));
+    UZL_HIP(hipStreamSynchronize(h->stream));
+    if (h->stream2) UZL_HIP(hipStreamSynchronize(h->stream2));
+    hipStream_t a = nullptr, b = nullptr;
+    UZL_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    if (hipStreamCreateWithPriority(&b, hipStreamNonBlocking, diag_int("UZL_S2_PRIO", -1)) != hipSuccess) { (void)hipStreamDestroy(a); throw HipError{hipErrorUnknown, "hipStreamCreateWithPriority", __FILE__, __LINE__}; }
+    h->stream = a; h->stream2 = b; h->streams_borrowed = false;
+    stream_register(h->cfg.device, a, false); stream_register(h->cfg.device, b, false);
+}
+
 extern "C" {
 
 static_assert(sizeof(uzl_pgo_cfg) == 64, "uzl_pgo_cfg::pass_history occupies the former tail padding: the layout of ABI version 3 is unchanged");
@@ -1311,39 +1382,7 @@ void uzl_pgo_cfg_default(uzl_pgo_cfg* cfg)
     cfg->pass_history = 0;              // pass sizes of a repeated optimize may come from the previous one's per-trial counts; 1 = never
 }
 
-int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out)
-{
-    if (!out) return UZL_ERR_BAD_ARG;
-    *out = nullptr;
-    uzl_pgo_cfg c;
-    if (cfg) c = *cfg; else uzl_pgo_cfg_default(&c);
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return UZL_ERR_NO_DEVICE;
-    if (c.device < 0 || c.device >= ndev) return UZL_ERR_NO_DEVICE;
-    uzl_pgo* h = new (std::nothrow) uzl_pgo();
-    if (!h) return UZL_ERR_OOM;
-    h->cfg = c;
-    memset(&h->D, 0, sizeof(h->D));
-    { const char* ng = getenv("UZL_NO_GRAPH"); h->no_graph = ng && ng[0] == '1'; }
-    if (getenv("UZL_VERBOSE")) h->cfg.verbose = 1;                                    // diagnostic: per-trial PCG log on stderr
-    if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, diag_int("UZL_S2_PRIO", -1)) != hipSuccess ||      // rebuilds ahead of the PCG they overlap with
-
-        hipEventCreateWithFlags(&h->ev_lin, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_setup, hipEventDisableTiming) != hipSuccess) {
-        if (h->stream) (void)hipStreamDestroy(h->stream);
-        if (h->stream2) (void)hipStreamDestroy(h->stream2);
-        if (h->ev_lin) (void)hipEventDestroy(h->ev_lin);
-        if (h->ev_setup) (void)hipEventDestroy(h->ev_setup);
-        delete h;
-        return UZL_ERR_HIP;
-    }
-    // (a single handle's solve with its 0.25-ms rebuilds never moved measurably with the placement of its two streams: they are taken as
-    //  they come and entered in the device's registry; the streams that must run side by side are a batch's, uzl_streams.hip)
-    stream_register(c.device, h->stream, false); stream_register(c.device, h->stream2, false);
-    *out = h;
-    return UZL_OK;
-}
+int uzl_pgo_create(const uzl_pgo_cfg* cfg, uzl_pgo** out) { return pgo_create_on(cfg, nullptr, nullptr, out); }
 
 void uzl_pgo_destroy(uzl_pgo* h)
 {
@@ -1356,8 +1395,10 @@ void uzl_pgo_destroy(uzl_pgo* h)
     if (h->rccl_comm) { (void)rccl().CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
     if (h->ev_lin) (void)hipEventDestroy(h->ev_lin);
     if (h->ev_setup) (void)hipEventDestroy(h->ev_setup);
-    if (h->stream2) { stream_unregister(h->cfg.device, h->stream2); (void)hipStreamDestroy(h->stream2); }
-    if (h->stream) { stream_unregister(h->cfg.device, h->stream); (void)hipStreamDestroy(h->stream); }
+    if (!h->streams_borrowed) {
+        if (h->stream2) { stream_unregister(h->cfg.device, h->stream2); (void)hipStreamDestroy(h->stream2); }
+        if (h->stream) { stream_unregister(h->cfg.device, h->stream); (void)hipStreamDestroy(h->stream); }
+    }
     delete h;
 }
 
@@ -1522,6 +1563,7 @@ int uzl_pgo_reset(uzl_pgo* h)
 int uzl_pgo_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* stats)
 {
     UZL_GUARD_BEGIN(h)
+    own_streams(h);
     return do_optimize(h, iterations, stats);
     UZL_GUARD_END(h)
 }
@@ -1796,16 +1838,14 @@ int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch
     *out = nullptr;
     uzl_pgo_cfg c;
     if (cfg) c = *cfg; else uzl_pgo_cfg_default(&c);
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c.device < 0 || c.device >= ndev) return UZL_ERR_NO_DEVICE;
+    }
     uzl_pgo_batch* b = new (std::nothrow) uzl_pgo_batch();
     if (!b) return UZL_ERR_OOM;
     b->cfg = c;
     if (getenv("UZL_VERBOSE")) b->cfg.verbose = 1;
-    for (int32_t g = 0; g < n_graphs; g++) {
-        uzl_pgo* h = nullptr;
-        const int rc = uzl_pgo_create(&c, &h);
-        if (rc != UZL_OK) { for (uzl_pgo* x : b->h) uzl_pgo_destroy(x); delete b; return rc; }
-        b->h.push_back(h);
-    }
     // The batch's streams come from the device's pool (uzl_streams.hip): none in another's way.  Batches of kBatchLaneMin graphs and more
     // get a second launch sequence if four such streams can be had within the pool's budget - otherwise, and with UZL_STREAM_PROBE=0,
     // the batch runs as ONE launch sequence whatever streams it got; a rebuild stream that cannot be had apart from the solver's is
@@ -1829,11 +1869,18 @@ int uzl_pgo_batch_create(const uzl_pgo_cfg* cfg, int32_t n_graphs, uzl_pgo_batch
         b->stream2_b = four ? stream_lease(dev, prio2, {b->stream, b->stream_b}, true) : stream_lease(dev, prio2, {b->stream, b->stream_b, b->stream2}, true);
         if (!b->stream2_b) { stream_release(dev, b->stream_b); b->stream_b = nullptr; }      // no fourth: one sequence
     }
+    int rc_h = UZL_OK;
+    for (int32_t g = 0; ok && g < n_graphs; g++) {              // the graphs' handles, on the batch's first launch sequence's streams
+        uzl_pgo* h = nullptr;
+        rc_h = pgo_create_on(&c, b->stream, b->stream2, &h);
+        if (rc_h != UZL_OK) { ok = false; break; }
+        b->h.push_back(h);
+    }
     if (!ok) {
         for (uzl_pgo* x : b->h) uzl_pgo_destroy(x);
         for (hipStream_t q : {b->stream, b->stream2, b->stream_b, b->stream2_b, b->stream_x[0], b->stream_x[1]}) stream_release(dev, q);
         delete b;
-        return UZL_ERR_HIP;
+        return rc_h != UZL_OK ? rc_h : UZL_ERR_HIP;
     }
     *out = b;
     return UZL_OK;

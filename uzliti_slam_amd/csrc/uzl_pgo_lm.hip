@@ -585,6 +585,7 @@ int batch_optimize_lm(LmRun*& Rp, const std::vector<uzl_pgo*>& hs, int resident,
         UZL_HIP(hipMemcpyAsync(h->pose_a.p, R->d_start.p + J.start_off, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
         UZL_HIP(hipStreamSynchronize(s));
         h->cur = h->pose_a.p; h->trial = h->pose_b.p;
+        own_streams(h);                                    // (another launch sequence of the batch may be capturing on the stream it borrowed)
         h->t_start = std::chrono::steady_clock::now();
         uzl_pgo_stats S;
         const int rc = do_optimize_host(h, iterations, &S);
