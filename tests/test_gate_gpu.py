@@ -175,3 +175,37 @@ def test_wave_search_on_long_chains_multi_edges_and_overflow(capi, oracle):
     G.close(); O.close()
     _verdicts_only(capi, P, E, c, ao, dict(max_edge_distance_T=100.0, max_edge_distance_R=360.0))      # (the deciding search's list overflows its registers here)
     _verdicts_only(capi, P, E, c, None, dict(max_edge_distance_T=100.0, max_edge_distance_R=360.0, scope_size_factor=0.004), oracle)   # most need the greedy search
+
+
+def test_grown_graph_equals_fresh_handle(capi, oracle):
+    """uzl_gate_set_graph recognises a graph that only grew (the last call's edges first, flags possibly changed, a tail of new edges, more
+    nodes) and enters only the tail; the verdicts and search distances must be those of a handle that is given the whole graph for the
+    first time - and the oracle's.  Calls in between accept candidates (which are NOT part of the next graph unless they come back), flip
+    `valid` flags of old edges, and once change an old edge's endpoint (not a growth: the full rebuild must take over)."""
+    n, e = 600, 2400
+    P, E, merged, c = scenario(capi, n, e, 21, 500)
+    P = np.asarray(P).reshape(n, 12)
+    rng = np.random.default_rng(5)
+    order = np.argsort(np.maximum(E["from"], E["to"]), kind="stable")          # edges in the order their later node came into being
+    E = E[order]
+    g = capi.Gate(min_accept_valid=60.0)
+    cuts = [150, 300, 301, 450, 600]
+    for step, nn in enumerate(cuts):
+        ne = int(np.searchsorted(np.maximum(E["from"], E["to"]), nn, side="left"))
+        Ek = E[:ne].copy()
+        flip = rng.random(ne) < 0.03                                             # the filter changed its mind about some old edges
+        Ek["valid"] = np.where(flip & (Ek["type"] != synth.EDGE_TYPE_ODOM), 1 - Ek["valid"], Ek["valid"])
+        if step == 3:
+            Ek["to"][5] = (Ek["to"][5] + 1) % nn if (Ek["to"][5] + 1) % nn != Ek["from"][5] else (Ek["to"][5] + 2) % nn      # an old edge rewritten
+        Pk = P[:nn] + rng.normal(0, 1e-3, (nn, 12))                              # a re-optimisation moved every pose a little
+        ck = c[(c["from"] < nn) & (c["to"] < nn)][:200]
+        g.set_graph(Pk, Ek, merged[:nn])
+        fresh = capi.Gate(min_accept_valid=60.0); fresh.set_graph(Pk, Ek, merged[:nn])
+        o = oracle.Gate(min_accept_valid=60.0); o.set_graph(Pk, Ek, merged[:nn])
+        a1, v1, d1 = g.check(ck); a2, v2, d2 = fresh.check(ck); a3, v3, d3 = o.check(ck)
+        assert np.array_equal(a1, a2) and np.array_equal(v1, v2) and d1.tobytes() == d2.tobytes(), step
+        assert np.array_equal(a1, a3) and np.array_equal(v1, v3) and d1.tobytes() == d3.tobytes(), step
+        assert g.edge_count() == fresh.edge_count() == o.edge_count()
+        assert a1.sum() > 0
+        fresh.close(); o.close()
+    g.close()

@@ -99,3 +99,28 @@ def test_relative_stop_test_switch(capi, oracle):
     st = _same(capi, g, 10, pcg_stop=1, pcg_tol=1e-6)
     st0 = _same(capi, g, 10)
     assert st["pcg_iterations"] > st0["pcg_iterations"]
+
+
+@pytest.mark.parametrize("n,e", [(1000, 5000), (1500, 1530)])
+def test_pass_history_changes_passes_not_results(capi, n, e):
+    """uzl_pgo_cfg::pass_history: whether a repeated optimize sizes its passes from the previous one's per-trial counts (0) or from the
+    running optimize alone (1) changes how many passes the host enqueues - never a bit of the result."""
+    g = synth.make_pose_graph(n, e, seed=77)
+    out = []
+    for hist in (0, 1):
+        p = capi.Pgo(pass_history=hist)
+        p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+        runs = []
+        for _ in range(3):
+            p.reset(); st = p.optimize(12)
+            runs.append((st, p.store()[0].copy()))
+        p.close()
+        out.append(runs)
+    for k in range(3):
+        (s0, P0), (s1, P1) = out[0][k], out[1][k]
+        assert np.array_equal(P0, P1)
+        for f in ("iterations_done", "lm_trials", "pcg_iterations", "chi2_final", "lambda_final"):
+            assert s0[f] == s1[f], (k, f)
+    assert out[0][0][0]["lm_passes"] > 0 and out[1][2][0]["lm_passes"] >= out[0][2][0]["lm_passes"]
+    for k in (1, 2):                                          # every repetition of a handle solves the same problem to the same bits
+        assert np.array_equal(out[1][0][1], out[1][k][1])

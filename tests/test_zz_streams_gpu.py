@@ -53,3 +53,31 @@ def test_pool_measures_a_pair_once_and_hands_the_same_streams_back(capi):
     assert s2["pooled"] == s1["pooled"] and s2["leased"] == s0["leased"]
     for x, y in zip(res[0], res[1]):
         assert np.array_equal(x, y)
+
+
+def test_no_probe_means_one_launch_sequence_and_the_same_results(capi):
+    """UZL_STREAM_PROBE=0: no stream pair is measured, a batch of 16 runs as one launch sequence on whatever streams it gets - the
+    deterministic layout for a GPU that is shared with other processes.  Results are those of the default layout, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "from uzliti_slam_amd import capi, synth\n"
+        "bt = capi.PgoBatch(16)\n"
+        "for k in range(16):\n"
+        "    g = synth.make_pose_graph(300, 1200, seed=900 + k); bt.graphs[k].add_graph(g['nodes_pose'], g['nodes_fixed'], g['edges'])\n"
+        "bt.optimize(6)\n"
+        "h = hashlib.sha256()\n"
+        "for k in range(16): h.update(bt.graphs[k].store()[0].tobytes())\n"
+        "st = capi.stream_stats(0)\n"
+        "print(h.hexdigest(), st['pairs_measured'], bt.n_batched)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for probe in ("0", "1"):
+        env = dict(os.environ, UZL_STREAM_PROBE=probe, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(r.stdout.strip().split())
+    assert res[0][1] == "0"                                   # nothing measured without the probe
+    assert res[0][0] == res[1][0] and res[0][2] == res[1][2] == "16"
