@@ -275,7 +275,7 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
         }
         UZL_HIP(hipMemcpyAsync(R->d_start.p + j.start_off, h->cur, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
     }
-    std::vector<int> slot_job((size_t)nS, -1), solve_passes((size_t)nS, 0);
+    std::vector<int> slot_job((size_t)nS, -1), solve_passes((size_t)nS, 0), prev_last((size_t)nS, 0), seen_trials((size_t)nS, 0), cur_last((size_t)nS, 0);
     std::vector<uint32_t> sent((size_t)nS, 0);               // per slot: lm_tail launches enqueued since its load (= the sequence word expected)
     std::vector<LmHost> snap((size_t)nS);
     int next_job = 0, n_active = 0;
@@ -303,7 +303,7 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
         UZL_HIP(hipMemcpyAsync(R->d_lm.p + sl, R->h_init.p + sl, sizeof(LmDev), hipMemcpyHostToDevice, s));
         memset(&snap[sl], 0, sizeof(LmHost));
         snap[sl].lm = I;
-        solve_passes[sl] = 0;
+        solve_passes[sl] = 0; prev_last[sl] = 0; cur_last[sl] = 0; seen_trials[sl] = 0;
     };
     for (int sl = 0; sl < nS; sl++) load_slot(sl, true);
     R->join_pending = false;
@@ -341,8 +341,11 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
             if (slot_job[sl] < 0 || jobs[slot_job[sl]].finished) continue;      // (a finished graph waits in its slot for its cohort: every kernel no-ops on its state)
             const LmDev& v = snap[sl].lm;
             int w;
-            if (v.phase == kLmSolve) {                        // a solve that outlasted its pass: nothing says how much longer - two short batches, then long ones
-                w = solve_passes[sl] < 2 ? kStep : kLong;
+            if (v.phase == kLmSolve) {
+                // A solve that outlasted its pass.  Nothing says how much longer it takes, but a launch past the end is a 1.2-us no-op
+                // and another pass is 50 - 100 us of tail, look and restart: a short batch, then half of what the solve has taken so far (round
+                // 4: two batches of 4, then 16s - config 2's second trial, 48 iterations against 30 predicted, took four passes; now three)
+                w = solve_passes[sl] == 0 ? kStep : std::min(std::max(kStep, (v.flags[1] / 2 + 1) & ~1), 4 * kLong);      // (most often it was one launch short: a short batch first)
                 solve_passes[sl]++;
             } else {
                 any_start = true; solve_passes[sl] = 0;
@@ -363,6 +366,9 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
                 static const bool no_history_env = diag_flag("UZL_LM_NO_HISTORY");           // A/B switch
                 const bool no_history = no_history_env || jobs[(size_t)slot_job[sl]].h->cfg.pass_history == 1;
                 w = v.pcg_last > 0 ? ((v.pcg_last + 2) & ~1) : ((R->first_solve_its > 0 && !no_history) ? ((R->first_solve_its + 2) & ~1) : 2 * kLong);
+                // counts that RISE from trial to trial (lambda falls after accepted steps, the system gets harder: chain-like graphs climb by 2
+                // per trial for ten trials, each time one launch short of `last + 2`): extrapolate the last rise
+                if (v.pcg_last > 0 && prev_last[sl] > 0 && v.pcg_last > prev_last[sl]) w = (v.pcg_last + std::min(v.pcg_last - prev_last[sl], 16) + 3) & ~1;
                 {
                     const std::vector<int>& hist = R->trial_its_prev[(size_t)slot_job[sl]];
                     if (!no_history && (size_t)v.st_lm_trials < hist.size()) w = std::max(w, (hist[(size_t)v.st_lm_trials] + 2) & ~1);
@@ -419,6 +425,7 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
             if (o.verbose)
                 fprintf(stderr, "[uzl_pgo] pass %d, graph %d -> it %d trial %d phase %d: pcg %d done %d (last solve %d) lambda %.3e chi2 %.9g |r|2/|b|2 %.3e need %d\n", passes - 1,
                         slot_job[sl], v.it, v.qmax, v.phase, v.flags[1], v.flags[0], v.pcg_last, v.lambda, v.chi_cur, snap[sl].scal[7], v.need);
+            if (v.st_lm_trials > seen_trials[sl]) { seen_trials[sl] = v.st_lm_trials; prev_last[sl] = cur_last[sl]; cur_last[sl] = v.pcg_last; }      // a trial ended: its count and the one before
             if (v.st_lm_trials == 1 && v.pcg_last > 0 && slot_job[sl] == 0) R->first_solve_its = v.pcg_last;
             {
                 std::vector<int>& cur = R->trial_its_cur[(size_t)slot_job[sl]];
