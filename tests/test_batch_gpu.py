@@ -177,3 +177,38 @@ def test_one_launch_sequence_in_the_diagnostic_build():
     out = subprocess.run([sys.executable, os.path.join(here, "diag", "stress_batch.py"), "5", "11"], env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
     assert "0 misses" in out.stdout
+
+
+def test_a_batch_handle_solved_on_its_own_and_from_two_threads(capi):
+    """The graphs of a batch run on the batch's streams (a handle of its own costs two hipStreamCreates).  A batch's handle is still an
+    ordinary handle: solved directly through uzl_pgo_optimize it takes streams of its own at that moment - two such handles driven from
+    two threads at once (captures, rebuild events) give what fresh handles give, and the batch still solves all of its graphs afterwards."""
+    import threading
+    graphs = [synth.make_pose_graph(700, 3000, seed=500 + k) for k in range(4)]
+    ref = [_single(capi, g, 10) for g in graphs]
+    bt = capi.PgoBatch(len(graphs))
+    for k, g in enumerate(graphs):
+        bt.graphs[k].add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+    out = {}
+
+    def work(k):
+        for _ in range(3):                                        # the second and third solve replay captured segments
+            bt.graphs[k].reset()
+            st = bt.graphs[k].optimize(10)
+        out[k] = (st, bt.graphs[k].store()[0].copy())
+    th = [threading.Thread(target=work, args=(k,)) for k in (1, 2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in (1, 2):
+        assert np.array_equal(out[k][1], ref[k][1]), k
+        assert out[k][0]["pcg_iterations"] == ref[k][0]["pcg_iterations"]
+    for p in bt.graphs:
+        p.reset()
+    stats = bt.optimize(10)
+    assert bt.n_batched == len(graphs)
+    for k in range(len(graphs)):
+        assert np.array_equal(bt.graphs[k].store()[0], ref[k][1]), k
+        assert stats[k]["lm_trials"] == ref[k][0]["lm_trials"]
+    bt.close()
