@@ -181,7 +181,9 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) { return max(min(a,
 constexpr int kKeyBits = 12, kSweep = 1 << kKeyBits;
 constexpr int kMmInvalid = 1023 << kKeyBits;      // key of a padded train row before |q| is added: above every real key
 
-template <int W, int UT>
+// RB: 32-row train blocks a wave works on side by side (the same query fragments against two row fragments): with UT = 1 (W = 16: the
+// query fragments of one 32-query tile already take 64 VGPRs) a wave would otherwise run ONE chain of sixteen dependent MFMAs per block.
+template <int W, int UT, int RB = 1>
 __global__ __launch_bounds__(kBlock) void knn2_mfma_kernel(const uint32_t* __restrict__ arena,
                                                            const Combo* __restrict__ combos,
                                                            uint2* __restrict__ knn)
@@ -257,33 +259,41 @@ __global__ __launch_bounds__(kBlock) void knn2_mfma_kernel(const uint32_t* __res
             }
             __syncthreads();
             const int rows_here = min(TR, nt_s - t0);
-            for (int r0 = 0; r0 < rows_here; r0 += 32) {
+            static_assert(TR % (32 * RB) == 0, "a chunk holds whole groups of row blocks (rows past the train set carry the invalid key)");
+            for (int r0 = 0; r0 < rows_here; r0 += 32 * RB) {
                 // rows of this lane's registers: 8 (reg>>2) + 4 h + (reg&3): their accumulators start at the rows' key words
-                v16i32 acc[UT];
+                v16i32 acc[RB][UT];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    const v4i32 rr = *reinterpret_cast<const v4i32*>(sR + r0 + 8 * g4 + 4 * h);
+                for (int rb = 0; rb < RB; rb++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int g4 = 0; g4 < 4; g4++) {
+                        const v4i32 rr = *reinterpret_cast<const v4i32*>(sR + r0 + 32 * rb + 8 * g4 + 4 * h);
 #pragma unroll
-                        for (int u = 0; u < UT; u++) acc[u][4 * g4 + j] = rr[j];
-                }
+                        for (int j = 0; j < 4; j++)
+#pragma unroll
+                            for (int u = 0; u < UT; u++) acc[rb][u][4 * g4 + j] = rr[j];
+                    }
                 const uint8_t* arow = sA + (r0 + col) * ROWB + 16 * h;
 #pragma unroll
                 for (int s_ = 0; s_ < W; s_++) {
-                    const v4i32 a = *reinterpret_cast<const v4i32*>(arow + 32 * s_);
 #pragma unroll
-                    for (int u = 0; u < UT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[u][s_], acc[u], 0, 0, 0);
-                }
+                    for (int rb = 0; rb < RB; rb++) {
+                        const v4i32 a = *reinterpret_cast<const v4i32*>(arow + 32 * rb * ROWB + 32 * s_);
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-#pragma unroll
-                    for (int u = 0; u < UT; u++) {
-                        const int kk = acc[u][k];                                   // (|t| - 2 <t, q>) << 12 | t: the matrix cores built the key
-                        b2[u] = med3_i32(b1[u], b2[u], kk);
-                        b1[u] = min(b1[u], kk);
+                        for (int u = 0; u < UT; u++) acc[rb][u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[u][s_], acc[rb][u], 0, 0, 0);
                     }
                 }
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+#pragma unroll
+                        for (int u = 0; u < UT; u++) {
+                            const int kk = acc[rb][u][k];                           // (|t| - 2 <t, q>) << 12 | t: the matrix cores built the key
+                            b2[u] = med3_i32(b1[u], b2[u], kk);
+                            b1[u] = min(b1[u], kk);
+                        }
+                    }
             }
         }
         // ---- this sweep's winners as full keys (padded rows stay the missing-neighbour sentinel), merged into the winners so far
@@ -1093,7 +1103,13 @@ void launch_knn2(const uint32_t* arena, const Combo* combos, int n_combos, int m
         if (has8 && ut8 == 4) hipLaunchKernelGGL((knn2_mfma_kernel<8, 4>), dim3((max_nq + 511) / 512, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
         else if (has8 && ut8 == 3) hipLaunchKernelGGL((knn2_mfma_kernel<8, 3>), dim3((max_nq + 383) / 384, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
         else if (has8) hipLaunchKernelGGL((knn2_mfma_kernel<8, 2>), dim3((max_nq + 255) / 256, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
-        if (has16) hipLaunchKernelGGL((knn2_mfma_kernel<16, 1>), dim3((max_nq + 127) / 128, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
+        // A/B switch (diagnostic build): two 32-row blocks side by side for W = 16, i.e. two independent MFMA chains per wave instead of one.
+        // Measured slower (512 pairs, 64-byte descriptors: 300 keypoints 0.0422 -> 0.0464 ms, 1000 keypoints 0.262 -> 0.309 ms): the single
+        // chain was not what the kernel waited for - at 1000 keypoints W = 16 reaches the same 0.40 of the int8 peak as W = 8 with two chains
+        // (vector ALU and LDS port beside the matrix pipe: DESIGN_APPENDIX.md, round 5)
+        static const int rb16 = diag_int("UZL_KNN2_RB16", 1);
+        if (has16 && rb16 == 2) hipLaunchKernelGGL((knn2_mfma_kernel<16, 1, 2>), dim3((max_nq + 127) / 128, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
+        else if (has16) hipLaunchKernelGGL((knn2_mfma_kernel<16, 1>), dim3((max_nq + 127) / 128, n_combos), dim3(kBlock), 0, s, arena, combos, knn);
     }
     if (has_generic) hipLaunchKernelGGL(knn2_generic_kernel, grid, dim3(kBlock), 0, s, arena, combos, knn);
 }
