@@ -71,6 +71,7 @@ def parse():
                     help="skip `sharded_c4` (N > 1: ONE 10000-node/50000-edge graph sharded over all ranks, BASELINE config 4, native RCCL "
                          "all-reduce per PCG iteration) and `c4_1gpu.sharded_world1` (N = 1: the same path with a one-rank communicator)")
     ap.add_argument("--sharded-world1-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--online-cpu-seconds", type=float, default=25.0, help="budget of the CPU replay of config 5 (online_c5.cpu_baseline)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-baseline sample of the primary / secondary block")
     ap.add_argument("--rehearse-gloo", action="store_true",
@@ -648,6 +649,8 @@ def compact_record(out):
     s4 = out.get("sharded_c4")
     if s4:
         c["sharded_c4"] = _pick(s4, ("value", "unit", "scaling", "n_ranks", "rccl_ranks_seen", "ms_per_solve", "exchange_calls_per_solve", "pcg_iterations_per_solve"))
+        if "error" in s4:
+            c["sharded_c4"]["error"] = str(s4["error"])[-200:]
     c = _finite(c)
     line = json.dumps(c, separators=(",", ":"), allow_nan=False)
     for drop in ("streams", "formats", "xy_only", "rooflines"):            # (never needed so far: the record is ~4 KB)
@@ -672,10 +675,55 @@ def emit(out):
     print(compact_record(out), flush=True)
 
 
+def sharded_child(a):
+    """`sharded_c4` in processes of its own (rank 0 of the bench starts `torch.distributed.run ... bench.py --sharded-child` and waits with a
+    time limit): the handle-owned RCCL communicator over N ranks has never run on hardware - no multi-GPU box in five rounds - and a stalled
+    bootstrap must cost this one block, not the whole record.  Rendezvous and the barrier / max of the timed region over gloo; the
+    data path is the library's own ncclAllReduce."""
+    d = Dist(a.gpus, rehearse_gloo=True)
+    from uzliti_slam_amd import capi, synth
+    capi.lib()
+    out = sharded_block(capi, synth, d, d.local_rank, a, d.rank, d.world)
+    if d.rank == 0:
+        print(json.dumps(_finite(out), allow_nan=False), flush=True)
+    d.close()
+
+
+def run_sharded_child(a, world, timeout_s=240):
+    """rank 0 of the bench: the N-rank sharded block as a child job; returns its record or {"error": ...}"""
+    import signal
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), "--sharded-child", "--gpus", str(world), "--steps", str(a.steps), "--lm-iters", str(a.lm_iters)]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    try:
+        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)      # its own process group: killed as one
+        try:
+            so, se = pr.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(pr.pid, signal.SIGKILL)
+            pr.communicate()
+            return dict(error="the %d-rank sharded solve did not finish within %d s (killed)" % (world, timeout_s))
+        lines = [ln for ln in so.strip().splitlines() if ln.startswith("{")]
+        if pr.returncode != 0 or not lines:
+            return dict(error=("rc %d: " % pr.returncode) + (se or so)[-400:])
+        return json.loads(lines[-1])
+    except Exception as ex:
+        return dict(error=repr(ex)[:400])
+
+
 def main():
     a = parse()
     if a.sharded_world1_child:
         return sharded_world1_child(a)
+    if a.sharded_child:
+        return sharded_child(a)
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(a))
     dist = Dist(a.gpus, a.rehearse_gloo)
@@ -1120,7 +1168,10 @@ def main():
     # ------------------------------------------------------------------ optional: config 4, one graph sharded over the ranks
     sharded_c4 = None
     if dist.world > 1 and not a.no_sharded and not dist.rehearsal:
-        sharded_c4 = sharded_block(capi, synth, dist, dev, a, dist.rank, dist.world)
+        # (a child job with a time limit: see sharded_child; the other ranks wait at the barrier and leave their GPUs to it)
+        if dist.rank == 0:
+            sharded_c4 = run_sharded_child(a, dist.world)
+        dist.barrier()
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     cpu = None

@@ -155,3 +155,48 @@ for cell in (0.5, 1.0, 1.5):
 # same coarse space as today, larger smoother blocks: what do exact 96 x 96 sibling blocks buy?
 two_level(np.arange(nb) // 8, "8 consecutive for the coarse space, 16 consecutive for the smoother", smooth_groups=np.arange(nb) // 16)
 two_level(np.arange(nb) // 4, "4 consecutive for the coarse space, 8 consecutive for the smoother", smooth_groups=np.arange(nb) // 8)
+
+
+# ---- overlapping blocks (additive Schwarz) with the same coarse space: does an overlap along the chain order buy iterations?
+def overlap_blocks(ov, size=8):
+    blocks = []
+    for k in range((nb + size - 1) // size):
+        lo, hi = max(0, size * k - ov), min(nb, size * k + size + ov)
+        blocks.append(np.arange(lo, hi))
+    return blocks
+
+
+def schwarz(blocks, restricted=False, size=8, weight=None):
+    invs = []
+    for ent in blocks:
+        idx = (6 * ent[:, None] + np.arange(6)).ravel()
+        invs.append((idx, ent, np.linalg.inv(A[idx][:, idx].toarray())))
+    def apply(r):
+        y = np.zeros_like(r)
+        for k, (idx, ent, Wm) in enumerate(invs):
+            z = Wm @ r[idx]
+            if restricted:                      # only the block's own rows keep their result
+                own = (ent // size == k)
+                z = z * np.repeat(own, 6)
+            elif weight is not None:
+                z = z * np.repeat(weight[ent], 6)
+            y[idx] += z
+        return y
+    return apply
+
+
+P8 = prolong(np.arange(nb) // 8); lu8 = spl.splu((P8.T @ A @ P8).tocsc())
+for ov in (0, 1, 2, 4):
+    bl = overlap_blocks(ov)
+    cnt = np.zeros(nb); [np.add.at(cnt, b, 1) for b in bl]
+    S_as = schwarz(bl)
+    S_w = schwarz(bl, weight=1. / np.sqrt(cnt))       # symmetric weighting D^-1/2 ... D^-1/2 needs both sides: applied on the way out only -> not symmetric; kept as a data point
+    S_ras = schwarz(bl, restricted=True)
+    for om in (1.0,):
+        it_as = pcg(lambda r: S_as(r) + om * (P8 @ lu8.solve(P8.T @ r)))
+    it_ras = pcg(lambda r: S_ras(r) + P8 @ lu8.solve(P8.T @ r))
+    print("overlap %d along the chain order (blocks of %d vertices): additive Schwarz + coarse %4d its; restricted (non-symmetric, CG not guaranteed) %4d its" % (ov, 8 + 2 * ov, it_as, it_ras), flush=True)
+# relative weight of the coarse term in the additive combination
+S8 = block_inv(np.arange(nb) // 8)
+for om in (0.5, 0.75, 1.0, 1.5, 2.0, 3.0):
+    print("coarse term x %.2f: %4d its" % (om, pcg(lambda r: S8 @ r + om * (P8 @ lu8.solve(P8.T @ r)))), flush=True)
