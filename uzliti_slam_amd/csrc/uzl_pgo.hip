@@ -1292,6 +1292,16 @@ static bool same_structure(const uzl_pgo* h, const StructureKey& k)
     return k.ready && k.n == h->n && k.fixed_in == h->fixed_in && k.ij == h->ij && k.robust == h->robust && k.edge_w == h->edge_w;
 }
 
+// What a handle learned about the numbering of its reduced systems (num_its, build_structure) belongs to the session it came from: it is
+// kept while the graph is the previous one, unchanged or GROWN (at least as many nodes, the old nodes' fixed flags in front: an online
+// session, graph_slam_node.cpp:1138-1150), and dropped for anything else - an unrelated graph then solves as on a fresh handle.
+static void keep_or_drop_numbering_history(uzl_pgo* h, const StructureKey& k)
+{
+    if (!k.ready || h->structure_ready) return;                     // nothing learned yet / the same structure again
+    const bool grown = h->n >= k.n && (size_t)k.n <= k.fixed_in.size() && std::equal(k.fixed_in.begin(), k.fixed_in.begin() + k.n, h->fixed_in.begin());
+    if (!grown) { h->num_its[0] = h->num_its[1] = -1.; h->num_last = -1; }
+}
+
 #define UZL_GUARD_BEGIN(h)                       \
     if (!(h)) return UZL_ERR_BAD_ARG;            \
     std::lock_guard<std::mutex> lock_((h)->mu);  \
@@ -1459,6 +1469,7 @@ int uzl_pgo_add_graph(uzl_pgo* h, int32_t n_nodes, const uzl_node* nodes, int32_
     upload_edges_common(h);
     h->have_graph = true;
     h->structure_ready = same_structure(h, old_key);
+    keep_or_drop_numbering_history(h, old_key);
     return UZL_OK;
     UZL_GUARD_END(h)
 }
@@ -1499,6 +1510,7 @@ int uzl_pgo_append_graph(uzl_pgo* h, int32_t n_new_nodes, const uzl_node* new_no
     upload_edges_common(h);
     h->have_graph = true;
     h->structure_ready = same_structure(h, old_key);
+    keep_or_drop_numbering_history(h, old_key);
     return UZL_OK;
     UZL_GUARD_END(h)
 }
@@ -1546,6 +1558,7 @@ int uzl_pgo_set_graph(uzl_pgo* h, int32_t n, const double* poses, const uint8_t*
     upload_edges_common(h);
     h->have_graph = true;
     h->structure_ready = same_structure(h, old_key);
+    keep_or_drop_numbering_history(h, old_key);
     return UZL_OK;
     UZL_GUARD_END(h)
 }
