@@ -77,8 +77,8 @@ extern "C" {
 #define UZL_EDGE_TYPE_2D_LASER          105
 
 int         uzl_abi_version(void);
-/* The library's long-lived HIP streams on `device`.  Streams that have to run side by side (the launch sequences of a batch and their
- * rebuild streams, uzl_pgo_batch_create) are leased from one pool per device and process: a pair of streams is measured against each
+/* The library's long-lived HIP streams on `device`.  Streams that have to run side by side (a solver handle's solver / rebuild pair,
+ * the launch sequences of a batch and their rebuild streams) are leased from one pool per device and process: a pair of streams is measured against each
  * other at most once per process (~1 ms of short kernels), its verdict is remembered, streams go back to the pool when their handle is
  * destroyed.  UZL_STREAM_PROBE=0 in the environment skips every measurement (a batch then runs as one launch sequence).  Out
  * (any may be NULL): streams in the pool / leased right now / made by handles for themselves and registered; pairs measured so far /

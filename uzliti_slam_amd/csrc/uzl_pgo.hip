@@ -1311,10 +1311,10 @@ static void keep_or_drop_numbering_history(uzl_pgo* h, const StructureKey& k)
     catch (const std::bad_alloc&) { (h)->last_error = "host out of memory"; return UZL_ERR_OOM; } \
     catch (...) { (h)->last_error = "unexpected exception"; return UZL_ERR_HIP; }
 
-// A handle with streams of its own (uzl_pgo_create), or - the graphs of a batch - on the batch's streams: a stream costs the runtime
-// ~3.5 ms to make and ~2 ms to destroy (uzl_pgo_create 6.9 ms, measured: tests/diag/create_cost.py), which a batch of 64 graphs paid
-// 128 times over although its solves never use its handles' streams.  A batch's handle takes streams of its own the first time it is
-// solved through uzl_pgo_optimize (own_streams).
+// A handle with a stream pair of its own from the device's pool (uzl_pgo_create), or - the graphs of a batch - on the batch's streams: a
+// stream costs the runtime ~3.5 ms to make and ~2 ms to destroy (round 4's uzl_pgo_create 6.9 ms, measured: tests/diag/create_cost.py),
+// which a batch of 64 graphs paid 128 times over although its solves never use its handles' streams.  A batch's handle takes a pair
+// of its own the first time it is solved through uzl_pgo_optimize (own_streams).
 static int pgo_create_on(const uzl_pgo_cfg* cfg, hipStream_t shared, hipStream_t shared2, uzl_pgo** out)
 {
     if (!out) return UZL_ERR_BAD_ARG;
@@ -1333,20 +1333,23 @@ static int pgo_create_on(const uzl_pgo_cfg* cfg, hipStream_t shared, hipStream_t
     bool ok = hipSetDevice(c.device) == hipSuccess;
     if (ok && shared) { h->stream = shared; h->stream2 = shared2; h->streams_borrowed = true; }
     else if (ok) {
-        ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
-             hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, diag_int("UZL_S2_PRIO", -1)) == hipSuccess;      // rebuilds ahead of the PCG they overlap with
+        // The solver's stream and the stream its rebuilds run ahead on (at the higher priority: they overlap with the PCG they are for)
+        // come from the device's pool too: a pair that shares a compute pipe costs a config-5 run a quarter of its solver time (two
+        // OnlineSlam sessions in one process: 1.34 against 1.67 s of optimize, tests/diag/online_passes.py - the second session's handle
+        // had taken its streams as they came).  Streams go back to the pool with the handle: making a handle no longer costs two
+        // hipStreamCreates (7 ms) once the pool holds a pair.
+        h->stream = stream_lease(c.device, 0, {}, false);
+        h->stream2 = h->stream ? stream_lease(c.device, diag_int("UZL_S2_PRIO", -1), {h->stream}, false) : nullptr;
+        ok = h->stream && h->stream2;
     }
     ok = ok && hipEventCreateWithFlags(&h->ev_lin, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->ev_setup, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
-        if (!h->streams_borrowed) { if (h->stream) (void)hipStreamDestroy(h->stream); if (h->stream2) (void)hipStreamDestroy(h->stream2); }
+        if (!h->streams_borrowed) { stream_release(c.device, h->stream); stream_release(c.device, h->stream2); }
         if (h->ev_lin) (void)hipEventDestroy(h->ev_lin);
         if (h->ev_setup) (void)hipEventDestroy(h->ev_setup);
         delete h;
         return UZL_ERR_HIP;
     }
-    // (a single handle's solve with its 0.25-ms rebuilds never moved measurably with the placement of its two streams: they are taken as
-    //  they come and entered in the device's registry; the streams that must run side by side are a batch's, uzl_streams.hip)
-    if (!h->streams_borrowed) { stream_register(c.device, h->stream, false); stream_register(c.device, h->stream2, false); }
     *out = h;
     return UZL_OK;
 }
@@ -1358,11 +1361,10 @@ void uzl::own_streams(uzl_pgo* h)
     UZL_HIP(hipSetDevice(h->cfg.device));
     UZL_HIP(hipStreamSynchronize(h->stream));
     if (h->stream2) UZL_HIP(hipStreamSynchronize(h->stream2));
-    hipStream_t a = nullptr, b = nullptr;
-    UZL_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
-    if (hipStreamCreateWithPriority(&b, hipStreamNonBlocking, diag_int("UZL_S2_PRIO", -1)) != hipSuccess) { (void)hipStreamDestroy(a); throw HipError{hipErrorUnknown, "hipStreamCreateWithPriority", __FILE__, __LINE__}; }
+    hipStream_t a = stream_lease(h->cfg.device, 0, {}, false);
+    hipStream_t b = a ? stream_lease(h->cfg.device, diag_int("UZL_S2_PRIO", -1), {a}, false) : nullptr;
+    if (!a || !b) { stream_release(h->cfg.device, a); throw HipError{hipErrorUnknown, "stream_lease", __FILE__, __LINE__}; }
     h->stream = a; h->stream2 = b; h->streams_borrowed = false;
-    stream_register(h->cfg.device, a, false); stream_register(h->cfg.device, b, false);
 }
 
 extern "C" {
@@ -1405,10 +1407,7 @@ void uzl_pgo_destroy(uzl_pgo* h)
     if (h->rccl_comm) { (void)rccl().CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
     if (h->ev_lin) (void)hipEventDestroy(h->ev_lin);
     if (h->ev_setup) (void)hipEventDestroy(h->ev_setup);
-    if (!h->streams_borrowed) {
-        if (h->stream2) { stream_unregister(h->cfg.device, h->stream2); (void)hipStreamDestroy(h->stream2); }
-        if (h->stream) { stream_unregister(h->cfg.device, h->stream); (void)hipStreamDestroy(h->stream); }
-    }
+    if (!h->streams_borrowed) { stream_release(h->cfg.device, h->stream2); stream_release(h->cfg.device, h->stream); }      // back to the pool, verdicts kept
     delete h;
 }
 

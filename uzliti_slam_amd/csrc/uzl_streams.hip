@@ -11,7 +11,8 @@
 // the threshold is 1.5x).
 //
 // Round 4 measured at every uzl_pgo_batch_create and threw the rejected streams away.  Now the streams that have to run side by side
-// (a batch's launch sequences and their rebuild streams) come from ONE POOL PER DEVICE that lives as long as the process:
+// (a solver handle's solver / rebuild pair, a batch's launch sequences and their rebuild streams) come from ONE POOL PER DEVICE that
+// lives as long as the process:
 //   * a pair of streams is measured at most once; the verdict is remembered, so the second batch of a process gets the first one's
 //     streams back without a single probe launch, and a process's choices do not change while it runs;
 //   * rejected streams stay in the pool (they keep their hardware queue, so the next stream lands elsewhere - and they are the first
@@ -20,7 +21,8 @@
 //     nothing returns nullptr and the caller takes the layout that needs no such stream (a batch: one launch sequence) - the same
 //     layout UZL_STREAM_PROBE=0 selects without any measurement, for deployments that share the GPU (a probe under foreign load proves
 //     nothing);
-//   * the streams the handles make for themselves are registered, so that uzl_stream_stats shows every long-lived stream of the library.
+//   * the streams the other handles make for themselves (estimator, gate, places, radius) are registered, so that uzl_stream_stats
+//     shows every long-lived stream of the library, and a lease prefers streams independent of the estimator's as well.
 #include "uzl_streams.hpp"
 
 #include <algorithm>

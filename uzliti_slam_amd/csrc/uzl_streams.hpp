@@ -11,7 +11,7 @@ namespace uzl {
 hipStream_t stream_lease(int device, int priority, const std::vector<hipStream_t>& apart_from, bool required);
 void stream_release(int device, hipStream_t s);
 
-// Streams the handles make for themselves (estimator, gate, filter, single solver handles) are entered so that the pool knows every
+// Streams the other handles make for themselves (estimator, gate, places, radius) are entered so that the pool knows every
 // long-lived stream of the library; `beside_solver`: long launch sequences run on it while a solve is in flight (the estimator's), so
 // leases prefer streams that are independent of it too when that costs nothing.
 void stream_register(int device, hipStream_t s, bool beside_solver);
