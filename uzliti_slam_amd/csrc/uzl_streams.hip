@@ -34,6 +34,7 @@ namespace {
 constexpr int kPoolMax = 16;            // streams per device
 constexpr int kNewPerLease = 6;         // new streams a single lease may add (three of the priority asked for, three of the other)
 constexpr int kMaxDevices = 16;
+constexpr int kKeepFree = 32;           // idle streams the pool keeps
 
 __global__ void chain_kernel(unsigned ticks)
 {
@@ -163,7 +164,22 @@ void stream_release(int device, hipStream_t s)
     if (!s) return;
     Pool& P = pool_of(device);
     std::lock_guard<std::mutex> lock(P.mu);
-    for (Pool::Entry& e : P.pooled) if (e.s == s) { e.leased = false; return; }
+    size_t at = P.pooled.size(), free_now = 0;
+    for (size_t i = 0; i < P.pooled.size(); i++) {
+        if (P.pooled[i].s == s) at = i;
+        else if (!P.pooled[i].leased) free_now++;
+    }
+    if (at == P.pooled.size()) return;
+    // a process that once had hundreds of handles alive does not keep their streams for ever: beyond kKeepFree idle streams a returned
+    // one is destroyed (its verdicts with it)
+    if (free_now >= (size_t)kKeepFree) {
+        P.forget(s);
+        P.pooled.erase(P.pooled.begin() + (long)at);
+        (void)hipSetDevice(device);
+        (void)hipStreamDestroy(s);
+        return;
+    }
+    P.pooled[at].leased = false;
 }
 
 void stream_register(int device, hipStream_t s, bool beside_solver)
