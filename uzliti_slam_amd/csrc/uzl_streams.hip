@@ -124,13 +124,13 @@ hipStream_t stream_lease(int device, int priority, const std::vector<hipStream_t
         P.pooled.push_back({q, priority, true});
         return q;
     };
-    if (!probing_enabled() || hard.empty()) {
-        if (required && !hard.empty()) { P.st.fallbacks++; return nullptr; }
-        return any();
-    }
     // the estimator's streams run long launch sequences beside a solve: avoided when that costs no more than the measurement
     std::vector<hipStream_t> soft;
     for (const Pool::Ext& x : P.registered) if (x.beside && soft.size() < 2 && std::find(hard.begin(), hard.end(), x.s) == hard.end()) soft.push_back(x.s);
+    if (!probing_enabled() || (hard.empty() && soft.empty())) {
+        if (required && !hard.empty()) { P.st.fallbacks++; return nullptr; }
+        return any();
+    }
     auto fits = [&](hipStream_t q) { for (hipStream_t o : hard) if (!P.independent(o, q)) return false; return true; };
     auto soft_hits = [&](hipStream_t q) { int n = 0; for (hipStream_t o : soft) if (!P.independent(o, q)) n++; return n; };
     int best = -1, best_hits = 1 << 30;
