@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "uzl_common.hpp"
 #include "pgo_device.hpp"
 #include "pgo_schur.hpp"
 
@@ -198,7 +199,28 @@ SchurPlan schur_plan(int nb, const std::vector<int32_t>& row_ptr, const std::vec
         const bool one_level = n1 <= one_level_max;
         std::vector<int32_t> g2;
         if (one_level) { g2.resize((size_t)n1); for (int a1 = 0; a1 < n1; a1++) g2[a1] = a1; n2 = n1; }
-        else g2 = strong_groups(n1, E, kMlFanout2, theta, 4, &n2);
+        else {
+            g2 = strong_groups(n1, E, kMlFanout2, theta, 4, &n2);
+            // A/B switch (diagnostic build): blocks that stayed below four groups are packed together in the order of their lowest group,
+            // tie or no tie - fewer, fuller blocks (every block is 32 rows of every PCG kernel's work, filled or not).  Measured on config
+            // 5 (round 5, tests/diag/online_passes.py): 35 % fewer rows (3328 -> 2176 at the first interval on this layout), 6 % more PCG
+            // iterations (57.3 k -> 61.0 k), optimize 1.39 -> 1.36 s: the kernels are latency-bound, the rows were nearly free.  Off.
+            static const int pack = diag_int("UZL_SCHUR_BLOCK_PACK", 0);
+            if (pack) {
+                std::vector<int32_t> bsize((size_t)n2, 0), nid((size_t)n2, -1);
+                for (int a1 = 0; a1 < n1; a1++) bsize[g2[a1]]++;
+                int cnt = 0, open_id = -1, open_fill = 0;
+                for (int b = 0; b < n2; b++) {                                      // blocks are numbered by their lowest group
+                    if (bsize[b] >= kMlFanout2) { nid[b] = cnt++; continue; }
+                    if (open_id < 0 || open_fill + bsize[b] > kMlFanout2) { open_id = cnt++; open_fill = 0; }
+                    nid[b] = open_id; open_fill += bsize[b];
+                }
+                for (int a1 = 0; a1 < n1; a1++) g2[a1] = nid[g2[a1]];
+                n2 = cnt;
+            }
+            static const bool verbose_plan = diag_flag("UZL_SCHUR_PLAN_DBG");
+            if (verbose_plan) fprintf(stderr, "[uzl] schur plan: %d separators, %d groups, %d blocks -> %d rows\n", P.n_sep, n1, n2, n2 * kMlFanout * kMlFanout2);
+        }
         // Few groups: every group one aggregate of the level-1 path - never worse than 8 consecutive separators on that path
         // (tests/diag/strong_ab.py: 9.0 -> 7.8 ms at 3000 / 3100, 17.0 -> 14.7 at 12000 / 12700).  More groups need the blocks-of-4 layout,
         // whose path has weaker smoothers and a dearer iteration: do the groups differ from the row order at all?  Where the runs between
