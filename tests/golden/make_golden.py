@@ -20,9 +20,9 @@ import np_reference as NP               # noqa: E402
 from uzliti_slam_amd import synth       # noqa: E402
 
 
-def match_fixture():
-    cfg = dict(ransac_threshold=0.1, ransac_iteration=150, break_percentage=0.6, seed=4242)
-    pairs = synth.make_pairs(3, n_kp=160, seed=99)
+def match_fixture(name="match_3pairs.npz", n_kp=160, desc_bytes=32, iterations=150, seed_pairs=99):
+    cfg = dict(ransac_threshold=0.1, ransac_iteration=iterations, break_percentage=0.6, seed=4242)
+    pairs = synth.make_pairs(3, n_kp=n_kp, desc_bytes=desc_bytes, seed=seed_pairs)
     out = dict(n_pairs=3, **{k: np.array(v) for k, v in cfg.items()})
     for j, (f, t, T) in enumerate(pairs):
         r = O.estimate_edge([f], [t], do_prosac=True, job_id=10 + j, **cfg)
@@ -38,7 +38,13 @@ def match_fixture():
             out[f"p{j}_{k}"] = r[k]
         out[f"p{j}_scalars"] = np.array([r["ok"], r["consensus"], r["n_matches"], r["n_corr"], r["iterations_run"], r["best_iteration"]], np.int64)
         out[f"p{j}_mse"] = np.array(r["mse"])
-    np.savez_compressed(os.path.join(HERE, "match_3pairs.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
+def match_deployed_fixture():
+    """the operating point the reference deploys: BRISK-512 (64-byte descriptors), 300 keypoints, 100 iterations, early exit at 60 %
+    (feature_extraction_service_node.cpp:63-66, iti_slam_launch/yaml/slam.yaml:34-38, cfg/FeatureLinkEstimation.cfg:12)"""
+    match_fixture("match_deployed_3pairs.npz", n_kp=300, desc_bytes=64, iterations=100, seed_pairs=4243)
 
 
 def ransac_fixture():
@@ -182,5 +188,5 @@ def wire_fixture():
 
 
 if __name__ == "__main__":
-    match_fixture(); ransac_fixture(); pgo_fixture(); filter_fixture(); wire_fixture()
+    match_fixture(); match_deployed_fixture(); ransac_fixture(); pgo_fixture(); filter_fixture(); wire_fixture()
     print("golden fixtures written to", HERE)

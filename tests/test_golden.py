@@ -17,8 +17,9 @@ def _frames(z, j):
     return f, t
 
 
-def test_oracle_reproduces_match_golden(oracle):
-    z = np.load(os.path.join(G, "match_3pairs.npz"))
+@pytest.mark.parametrize("fixture", ["match_3pairs.npz", "match_deployed_3pairs.npz"])
+def test_oracle_reproduces_match_golden(oracle, fixture):
+    z = np.load(os.path.join(G, fixture))
     for j in range(int(z["n_pairs"])):
         f, t = _frames(z, j)
         got = oracle.knn2(t["desc"], f["desc"])
@@ -57,8 +58,9 @@ def test_oracle_reproduces_ransac_golden(oracle):
 
 
 @pytest.mark.gpu
-def test_hip_reproduces_match_golden(capi):
-    z = np.load(os.path.join(G, "match_3pairs.npz"))
+@pytest.mark.parametrize("fixture", ["match_3pairs.npz", "match_deployed_3pairs.npz"])
+def test_hip_reproduces_match_golden(capi, fixture):
+    z = np.load(os.path.join(G, fixture))
     m = capi.Match(ransac_threshold=float(z["ransac_threshold"]), ransac_iteration=int(z["ransac_iteration"]),
                    ransac_break_percentage=float(z["break_percentage"]), seed=int(z["seed"]))
     n = int(z["n_pairs"])
@@ -69,7 +71,7 @@ def test_hip_reproduces_match_golden(capi):
     for j in range(n):
         got = m.knn2(ids[j][0], ids[j][1], z[f"p{j}_to_desc"].shape[0])
         assert np.array_equal(np.stack(got), z[f"p{j}_knn"])
-    res, diag = m.estimate(ids, job_ids=[10 + j for j in range(n)], max_corr=160)
+    res, diag = m.estimate(ids, job_ids=[10 + j for j in range(n)], max_corr=int(z["p0_to_desc"].shape[0]))
     for j in range(n):
         sc = z[f"p{j}_scalars"].tolist()
         r = res[j]
