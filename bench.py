@@ -1170,8 +1170,23 @@ def main():
     sharded_c4 = None
     if dist.world > 1 and not a.no_sharded and not dist.rehearsal:
         # (a child job with a time limit: see sharded_child; the other ranks wait at the barrier and leave their GPUs to it)
+        # the other ranks wait on the rendezvous store (a CPU wait: an NCCL barrier would park a spinning kernel on every GPU the child uses)
+        store = None
+        try:
+            from torch.distributed import distributed_c10d as _c10d
+            store = _c10d._get_default_store()
+        except Exception:
+            store = None
         if dist.rank == 0:
             sharded_c4 = run_sharded_child(a, dist.world)
+            if store is not None:
+                store.set("uzl_sharded_child_done", "1")
+        elif store is not None:
+            import datetime
+            try:
+                store.wait(["uzl_sharded_child_done"], datetime.timedelta(seconds=400))
+            except Exception:
+                pass
         dist.barrier()
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
