@@ -1168,7 +1168,7 @@ def main():
 
     # ------------------------------------------------------------------ optional: config 4, one graph sharded over the ranks
     sharded_c4 = None
-    if dist.world > 1 and not a.no_sharded and not dist.rehearsal:
+    if dist.world > 1 and not a.no_sharded and (not dist.rehearsal or os.environ.get("UZL_BENCH_FORCE_SHARDED") == "1"):      # (the env switch: rehearsal of this block's control flow on one GPU)
         # (a child job with a time limit: see sharded_child; the other ranks wait at the barrier and leave their GPUs to it)
         # the other ranks wait on the rendezvous store (a CPU wait: an NCCL barrier would park a spinning kernel on every GPU the child uses)
         store = None
