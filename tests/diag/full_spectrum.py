@@ -34,3 +34,30 @@ print("smallest 12:", np.round(ev[:12], 4)); print("largest 8:", np.round(ev[-8:
 for q in (0.05, 0.1, 0.2, 0.3, 0.5): print("eigenvalues below %.2f: %d" % (q, (ev < q).sum()))
 for k in (0, 4, 8, 16, 32):
     c = ev[-1] / ev[k]; print("deflating the %2d smallest: cond %.1f -> CG bound ~ %.0f its for 1e-5" % (k, c, 0.5 * np.sqrt(c) * np.log(2e5)))
+
+# ---- does taking the coarse modes OUT of the smoother blocks (they are solved exactly on the coarse level) remove the double counting?
+def pcg_dense(Mi, tol=1e-5, maxit=500):
+    bf = b[fidx]; x = np.zeros(n); r = bf.copy(); z = Mi @ r; p = z.copy(); rz = r @ z; thr = tol * tol * rz
+    for it in range(1, maxit + 1):
+        Ap = Ad @ p; a = rz / (p @ Ap); x += a * p; r -= a * Ap; z = Mi @ r; rzn = r @ z
+        if not rzn > thr: return it
+        p = z + (rzn / rz) * p; rz = rzn
+    return maxit
+S = np.zeros((n, n))
+for gi in range(ng):
+    idx = np.arange(48 * gi, min(n, 48 * gi + 48)); S[np.ix_(idx, idx)] = np.linalg.inv(Ad[np.ix_(idx, idx)])
+C = P @ np.linalg.inv(P.T @ Ad @ P) @ P.T
+print("additive S + C: %d its" % pcg_dense(S + C))
+Pi2 = np.eye(n) - P @ np.linalg.inv(P.T @ P) @ P.T                       # l2 projection off the coarse modes (block diagonal per aggregate)
+for name, Sm in (("Pi S Pi^T (l2 projection)", Pi2 @ S @ Pi2.T),):
+    Mi = Sm + C; ev2 = la.eigvalsh(np.linalg.cholesky(Mi + 1e-12 * np.eye(n)).T @ Ad @ np.linalg.cholesky(Mi + 1e-12 * np.eye(n)))
+    print("%-34s + C: %d its, eig %.4f .. %.3f cond %.1f" % (name, pcg_dense(Mi), ev2[0], ev2[-1], ev2[-1] / ev2[0]))
+# A-orthogonal version: S' = S - S A P (P^T A S A P)^-1 P^T A S  (the block's solve with the coarse modes constrained out, per aggregate)
+Sa = np.zeros((n, n))
+for gi in range(ng):
+    idx = np.arange(48 * gi, min(n, 48 * gi + 48)); Pk = P[idx][:, 6 * gi:6 * gi + 6]; Ak = Ad[np.ix_(idx, idx)]; Sk = np.linalg.inv(Ak)
+    # minimise over block corrections A-orthogonal to the block's own rigid modes: Sk - Pk (Pk^T Ak Pk)^-1 Pk^T
+    Sa[np.ix_(idx, idx)] = Sk - Pk @ np.linalg.inv(Pk.T @ Ak @ Pk) @ Pk.T
+Mi = Sa + C; w = la.eigvalsh(Mi); print("min eig of M^-1 (must be > 0):", w[0])
+ev3 = la.eigvalsh(np.linalg.cholesky(Mi).T @ Ad @ np.linalg.cholesky(Mi)) if w[0] > 0 else None
+print("S_k - P_k (P_k^T A_k P_k)^-1 P_k^T     + C: %d its" % pcg_dense(Mi), ("eig %.4f .. %.3f cond %.1f" % (ev3[0], ev3[-1], ev3[-1] / ev3[0])) if ev3 is not None else "")
