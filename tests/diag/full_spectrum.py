@@ -61,3 +61,9 @@ for gi in range(ng):
 Mi = Sa + C; w = la.eigvalsh(Mi); print("min eig of M^-1 (must be > 0):", w[0])
 ev3 = la.eigvalsh(np.linalg.cholesky(Mi).T @ Ad @ np.linalg.cholesky(Mi)) if w[0] > 0 else None
 print("S_k - P_k (P_k^T A_k P_k)^-1 P_k^T     + C: %d its" % pcg_dense(Mi), ("eig %.4f .. %.3f cond %.1f" % (ev3[0], ev3[-1], ev3[-1] / ev3[0])) if ev3 is not None else "")
+
+# ---- smoothed aggregation: P_s = (I - w S A) P (a denser prolongation; the coarse operator is dense anyway) - what would it buy?
+for w_ in (0.5, 0.67, 1.0):
+    Ps = P - w_ * (S @ (Ad @ P))
+    Cs = Ps @ np.linalg.inv(Ps.T @ Ad @ Ps) @ Ps.T
+    print("smoothed aggregation, omega %.2f: additive S + C_s %d its" % (w_, pcg_dense(S + Cs)))
