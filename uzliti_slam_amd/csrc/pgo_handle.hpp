@@ -57,7 +57,7 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
                    int init, size_t lds, hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 int k_oplus(const PgoDev& D, const double* pose_in, double* pose_out, hipStream_t s);
 int g_edges_for(int e);
-void k_edge_records(const double* zinv, const double* info, int e, double* rec, hipStream_t s);
+void k_slot_records(const double* zinv, const double* info, int e, const int32_t* slot_edge, int nslots, double* srec, hipStream_t s);
 int g_oplus_for(int n);
 void k_edge_error(const PgoDev& D, const double* pose, double* err, hipStream_t s);
 void k_poses_out(const double* pose, int n, double* out12, hipStream_t s);
@@ -109,7 +109,9 @@ struct uzl_pgo {
     double* trial = nullptr;
     DevBuf<int32_t> d_v2b, d_b2v, d_ei, d_ej, d_slot_i, d_slot_j, d_row_ptr, d_col, d_rowhdr, d_src, d_flags;
     DevBuf<int32_t> d_slot_edge, d_rb_ptr;
-    DevBuf<double> d_erec;                     // edge records (pgo_kernels.hip: edge_records_kernel), written with the edges
+    DevBuf<double> d_srec;                     // slot records (pgo_kernels.hip: slot_records_kernel): values of the edges in the order of the structure's slots
+    DevBuf<int4> d_smeta;
+    bool srec_stale = true;                    // edges' values or the structure changed since d_srec was written
     DevBuf<double> d_zinv, d_info, d_blk, d_hdiag, d_minv, d_b, d_x, d_xs, d_r, d_z, d_p, d_p2, d_ap;
     DevBuf<double> d_part_a, d_part_b, d_part_c, d_scal, d_err, d_out12, d_stage;
     DevBuf<uint8_t> d_robust;

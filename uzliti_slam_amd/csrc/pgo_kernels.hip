@@ -199,43 +199,53 @@ __device__ __forceinline__ void mat3mul(const double* A, const double* B, double
 // The sparse Hessian build (north star): ONE kernel where rounds 1-3 had linearize_kernel (a lane per edge writing two 624-byte slot
 // records: H_ac block, the edge's share of H_aa, its share of -b) and assemble_kernel (reading all of them back to sum H_aa and b per
 // row).  Here a workgroup owns 42 consecutive block rows and walks their slots - contiguous, sorted by edge - 256 at a time:
-//   phase 1: a lane per SLOT (edge, side) recomputes the edge's error and Jacobians (3.5 kflop, done on both sides of an edge: free
-//            against the round trip through HBM it replaces), writes the slot's H_ac block and leaves its share of H_aa | -b in LDS;
-//   phase 2: lane (row, r) adds the shares of its row's slots IN SLOT ORDER (assemble_kernel's order: bit-reproducible, no atomics),
-//            and after the last chunk writes H_aa | b once per row and the workgroup's largest diagonal entry (computeLambdaInit).
-// The shares never reach HBM: 2 x 336 B per edge less written and read back; the per-slot input (two poses, Z^-1, Omega: 476 B) is read
-// by both of an edge's slots - from L2 when they sit in one workgroup (odometry edges: neighbouring rows).
+//   phase 1: a lane per SLOT (edge, side) reads the slot's record (slot-major: coalesced), recomputes the edge's error and Jacobians
+//            (3.5 kflop, done on both sides of an edge: free against the round trip through HBM it replaces) and leaves the slot's
+//            H_ac block and its share of H_aa | -b in LDS;
+//   phase 2: the workgroup writes the chunk's blocks - one contiguous piece of D.blk - 16 bytes a lane, lane after lane; lane (row, r)
+//            adds the shares of its row's slots IN SLOT ORDER (assemble_kernel's order: bit-reproducible, no atomics), and after the
+//            last chunk writes H_aa | b once per row and the workgroup's largest diagonal entry (computeLambdaInit).
+// The shares never reach HBM: 2 x 336 B per edge less written and read back; the per-slot input (two poses, Z^-1, Omega: 464 B) is read
+// by both of an edge's slots.
 // Workgroups behind the row blocks compute the chi2 partials (chi2_kernel's lanes, one per edge: computeActiveErrors).
 // Sharded solve: a slot whose edge another rank linearises contributes nothing here (its block stays zero).
 // ------------------------------------------------------------------------------------------------
 constexpr int kLaRows = kBlk / 6;                     // <= 42 rows per pass of a workgroup: lane (row, r) owns row r of H_aa and b[r]
 constexpr int kLaShare = 27;                          // doubles per slot in LDS: upper triangle of its share of H_aa (21) | share of -b (6)
-constexpr int kEdgeRec = 44;                          // doubles per edge record: Z^-1 (7) | Omega (36) | pad
+constexpr int kLaStage = 37;                          // doubles per slot in LDS: its H_ac block (36) | pad (an odd stride: the lanes' writes spread over the banks)
+constexpr int kSlotRec = 44;                          // doubles per slot record: Z^-1 (7) | Omega (36) | pad
 // (r, c) -> index in the packed upper triangle, r <= c
 __device__ __forceinline__ constexpr int tri6(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
 
-// the edge's inputs as ONE record (the lanes of the Hessian build walk slots, not edges: the SoA arrays the lane-per-edge kernels read
-// coalesced would cost them 43 scattered 8-byte loads each)
-__global__ __launch_bounds__(kBlk) void edge_records_kernel(const double* __restrict__ zinv, const double* __restrict__ info, int e, double* __restrict__ rec)
+// The inputs of a slot's edge, SLOT-MAJOR in 16-byte pieces (values 2i, 2i + 1 of slot s at srec[(i * nslots + s) * 2]): the lanes of
+// the Hessian build walk slots, and a wave's 64 consecutive slots then read every piece as one contiguous kilobyte.  (Rounds 4-5 kept
+// one 352-byte record per EDGE and each lane fetched its own - 64 cache lines per wave instruction; the lane-per-edge kernels read the
+// edge-major SoA arrays coalesced and are not concerned.)
+__global__ __launch_bounds__(kBlk) void slot_records_kernel(const double* __restrict__ zinv, const double* __restrict__ info, int e,
+                                                            const int32_t* __restrict__ slot_edge, int nslots, double* __restrict__ srec)
 {
-    const int k = blockIdx.x * kBlk + threadIdx.x;
-    if (k >= e) return;
-    double* __restrict__ o = rec + (size_t)k * kEdgeRec;
+    const int s = blockIdx.x * kBlk + threadIdx.x;
+    if (s >= nslots) return;
+    const int k = slot_edge[s] >> 1;
+    double v[kSlotRec];
 #pragma unroll
-    for (int i = 0; i < 7; i++) o[i] = zinv[(size_t)i * e + k];
+    for (int i = 0; i < 7; i++) v[i] = zinv[(size_t)i * e + k];
 #pragma unroll
-    for (int i = 0; i < 36; i++) o[7 + i] = info[(size_t)i * e + k];
-    o[43] = 0.;
+    for (int i = 0; i < 36; i++) v[7 + i] = info[(size_t)i * e + k];
+    v[43] = 0.;
+    double2* __restrict__ o = reinterpret_cast<double2*>(srec);
+#pragma unroll
+    for (int i = 0; i < kSlotRec / 2; i++) o[(size_t)i * nslots + s] = make_double2(v[2 * i], v[2 * i + 1]);
 }
-void k_edge_records(const double* zinv, const double* info, int e, double* rec, hipStream_t s)
+void k_slot_records(const double* zinv, const double* info, int e, const int32_t* slot_edge, int nslots, double* srec, hipStream_t s)
 {
-    if (e > 0) hipLaunchKernelGGL(edge_records_kernel, dim3((e + kBlk - 1) / kBlk), dim3(kBlk), 0, s, zinv, info, e, rec);
+    if (nslots > 0) hipLaunchKernelGGL(slot_records_kernel, dim3((nslots + kBlk - 1) / kBlk), dim3(kBlk), 0, s, zinv, info, e, slot_edge, nslots, srec);
 }
-// edge_geom on a record (same arithmetic, same numbers)
-__device__ __forceinline__ EdgeGeom edge_geom_rec(const PgoDev& D, const double* __restrict__ pose, int k, const double* __restrict__ rc)
+// edge_geom on a slot record (same arithmetic, same numbers)
+__device__ __forceinline__ EdgeGeom edge_geom_rec(const double* __restrict__ pose, int vi, int vj, const double* __restrict__ rc)
 {
-    const Pose Xi = load_pose(pose, D.ei[k]);
-    const Pose Xj = load_pose(pose, D.ej[k]);
+    const Pose Xi = load_pose(pose, vi);
+    const Pose Xj = load_pose(pose, vj);
     const V3 ta{rc[0], rc[1], rc[2]};
     EdgeGeom G;
     G.qa = Q4{rc[3], rc[4], rc[5], rc[6]};
@@ -250,12 +260,81 @@ __device__ __forceinline__ EdgeGeom edge_geom_rec(const PgoDev& D, const double*
     return G;
 }
 
+// column c of W_j = Omega' Jj (Jj = diag(B11, B22)) and of W_i = Omega' Ji (Ji = [[A11, A12], [0, A22]])
+template <int C>
+__device__ __forceinline__ void wj_col(const double* Om, const double* B11, const double* B22, double* w)
+{
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++)
+        w[rr] = C < 3 ? Om[rr * 6 + 0] * B11[0 * 3 + C] + Om[rr * 6 + 1] * B11[1 * 3 + C] + Om[rr * 6 + 2] * B11[2 * 3 + C]
+                      : Om[rr * 6 + 3] * B22[0 * 3 + (C % 3)] + Om[rr * 6 + 4] * B22[1 * 3 + (C % 3)] + Om[rr * 6 + 5] * B22[2 * 3 + (C % 3)];
+}
+template <int C>
+__device__ __forceinline__ void wi_col(const double* Om, const double* A11, const double* A12, const double* A22, double* w)
+{
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++)
+        w[rr] = C < 3 ? Om[rr * 6 + 0] * A11[0 * 3 + C] + Om[rr * 6 + 1] * A11[1 * 3 + C] + Om[rr * 6 + 2] * A11[2 * 3 + C]
+                      : Om[rr * 6 + 0] * A12[0 * 3 + (C % 3)] + Om[rr * 6 + 1] * A12[1 * 3 + (C % 3)] + Om[rr * 6 + 2] * A12[2 * 3 + (C % 3)] +
+                        Om[rr * 6 + 3] * A22[0 * 3 + (C % 3)] + Om[rr * 6 + 4] * A22[1 * 3 + (C % 3)] + Om[rr * 6 + 5] * A22[2 * 3 + (C % 3)];
+}
+// column C of the blocks, and of the shares of H_aa (upper triangle: rows <= C)
+template <int C>
+__device__ __forceinline__ void hij_col(const double* Om, const double* A11, const double* A12, const double* A22, const double* B11, const double* B22,
+                                        bool write, int side, double* __restrict__ blk_out)
+{
+    double w[6], hc[6];
+    wj_col<C>(Om, B11, B22, w);
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+        hc[rr] = A11[0 * 3 + rr] * w[0] + A11[1 * 3 + rr] * w[1] + A11[2 * 3 + rr] * w[2];
+        hc[3 + rr] = A12[0 * 3 + rr] * w[0] + A12[1 * 3 + rr] * w[1] + A12[2 * 3 + rr] * w[2] +
+                     A22[0 * 3 + rr] * w[3] + A22[1 * 3 + rr] * w[4] + A22[2 * 3 + rr] * w[5];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++) {
+        const double v = write ? hc[rr] : 0.;         // (a slot whose neighbour is fixed keeps a zero block)
+        if (side == 0) blk_out[rr * 6 + C] = v;       // H_ij, row-major
+        else blk_out[C * 6 + rr] = v;                 // its transpose: a column of H_ij is a row of the stored block
+    }
+}
+template <int C>
+__device__ __forceinline__ void share_col(const double* Om, const double* A11, const double* A12, const double* A22, const double* B11, const double* B22,
+                                          int side, double* __restrict__ mine)
+{
+    double w[6];
+    if (side == 1) {                                   // row j: Jj^T Wj
+        wj_col<C>(Om, B11, B22, w);
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+            if (rr <= C) mine[tri6(rr, C)] = B11[0 * 3 + rr] * w[0] + B11[1 * 3 + rr] * w[1] + B11[2 * 3 + rr] * w[2];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+            if (3 + rr <= C) mine[tri6(3 + rr, C)] = B22[0 * 3 + rr] * w[3] + B22[1 * 3 + rr] * w[4] + B22[2 * 3 + rr] * w[5];
+    } else {                                           // row i: Ji^T Wi
+        wi_col<C>(Om, A11, A12, A22, w);
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+            if (rr <= C) mine[tri6(rr, C)] = A11[0 * 3 + rr] * w[0] + A11[1 * 3 + rr] * w[1] + A11[2 * 3 + rr] * w[2];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+            if (3 + rr <= C) mine[tri6(3 + rr, C)] = A12[0 * 3 + rr] * w[0] + A12[1 * 3 + rr] * w[1] + A12[2 * 3 + rr] * w[2] +
+                                                     A22[0 * 3 + rr] * w[3] + A22[1 * 3 + rr] * w[4] + A22[2 * 3 + rr] * w[5];
+    }
+}
+
 // row block `rb` of D.rb_ptr (host-side partition: consecutive rows with <= 256 slots and <= 42 rows wherever the graph allows, so that a
-// workgroup makes ONE pass: a chunk of slots, a group of rows; hub rows and very large graphs loop)
+// workgroup makes ONE pass: a chunk of slots, a group of rows; hub rows and very large graphs loop).
+// The lanes leave their H_ac blocks in LDS and the workgroup writes them out after the barrier - the chunk's blocks are one contiguous
+// piece of D.blk - 16 bytes a lane, lane after lane: written by their own lanes (18 x 16 bytes each, 288 bytes apart) the stores were
+// half of the kernel's time (tests/diag/r5_hessian_abl.sh).  131 KB of LDS: one workgroup per CU.  Measured and not kept: blocks and
+// shares in turn through ONE 76-KB piece with the lane's state held in registers under 256, so that two workgroups share a CU
+// (10k / 50k 34.4 -> 34.3 us, config 2 13.0 -> 17.1: two more barriers and a few spills on a path that is a latency chain).
 __device__ __forceinline__ void hessian_rows_body(PgoDev D, const double* __restrict__ pose, double delta, int rb)
 {
     __shared__ double s4[4];
-    __shared__ double sh[kBlk * kLaShare];             // 55 KB
+    __shared__ double sh[kBlk * kLaShare];             // 55 KB: the chunk's shares of H_aa | -b
+    __shared__ double st[kBlk * kLaStage];             // 76 KB: the chunk's H_ac blocks on their way out
     const int tid = threadIdx.x;
     double dmax = 0.;
     const int rows_begin = D.rb_ptr[rb], rows_end = D.rb_ptr[rb + 1];
@@ -270,33 +349,36 @@ __device__ __forceinline__ void hessian_rows_body(PgoDev D, const double* __rest
         for (int base = s_begin; base < s_end; base += kBlk) {
             const int s = base + tid;
             double* __restrict__ mine = sh + (size_t)tid * kLaShare;
+            double* __restrict__ blk_out = st + (size_t)tid * kLaStage;
             bool live = false;
-            int k = 0, side = 0;
+            int side = 0;
+            int4 sm = make_int4(0, 0, 0, 0);
             if (s < s_end) {
-                const int se = D.slot_edge[s];
-                k = se >> 1; side = se & 1;
+                sm = D.smeta[s];
+                const int k = sm.x >> 1;
+                side = sm.x & 1;
                 live = k >= D.e_begin && k < D.e_end;
             }
+            double Om[36], Oe[6], A11[9], A12[9], A22[9], B11[9], B22[9];      // Omega' (row-major, robustified), Omega' e, Ji, Jj
             if (!live) {
-                if (s < s_end) {                       // (sharded solve: an edge of another rank - its shares are that rank's)
+                if (s < s_end) {                       // (sharded solve: an edge of another rank - block and shares are that rank's)
+#pragma unroll
+                    for (int i = 0; i < 36; i++) blk_out[i] = 0.;
 #pragma unroll
                     for (int i = 0; i < kLaShare; i++) mine[i] = 0.;
                 }
             } else {
-                // the record: 22 x 16 bytes, contiguous
-                double rc[kEdgeRec];
+                // the slot's record: 22 x 16 bytes, each piece contiguous over the wave's slots
+                double rc[kSlotRec];
                 {
-                    const double2* __restrict__ src = reinterpret_cast<const double2*>(D.erec + (size_t)k * kEdgeRec);
+                    const double2* __restrict__ src = reinterpret_cast<const double2*>(D.srec) + s;
 #pragma unroll
-                    for (int i = 0; i < kEdgeRec / 2; i++) { const double2 v = src[i]; rc[2 * i] = v.x; rc[2 * i + 1] = v.y; }
+                    for (int i = 0; i < kSlotRec / 2; i++) { const double2 v = src[(size_t)i * D.nslots]; rc[2 * i] = v.x; rc[2 * i + 1] = v.y; }
                 }
-                const EdgeGeom G = edge_geom_rec(D, pose, k, rc);
+                const EdgeGeom G = edge_geom_rec(pose, sm.y, sm.z, rc);
                 const double ev[6] = {G.te.x, G.te.y, G.te.z, G.qe.x, G.qe.y, G.qe.z};
-                // Omega (row-major 6x6), robustified: Omega' = rho1 * Omega
-                double Om[36];
 #pragma unroll
                 for (int i = 0; i < 36; i++) Om[i] = rc[7 + i];
-                double Oe[6];
                 double chi = 0.;
 #pragma unroll
                 for (int rr = 0; rr < 6; rr++) {
@@ -307,7 +389,7 @@ __device__ __forceinline__ void hessian_rows_body(PgoDev D, const double* __rest
                     chi += ev[rr] * sacc;
                 }
                 double r0 = chi, r1 = 1.;
-                if (D.robust[k]) huber(chi, delta, r0, r1);
+                if (sm.w >> 30) huber(chi, delta, r0, r1);
 #pragma unroll
                 for (int i = 0; i < 36; i++) Om[i] *= r1;
 #pragma unroll
@@ -315,13 +397,12 @@ __device__ __forceinline__ void hessian_rows_body(PgoDev D, const double* __rest
                 // ---- Jacobian blocks
                 const M33 Ra = qrot(G.qa);
                 const M33 Re = qrot(G.qe);
-                double A11[9], A12[9], A22[9], B22[9];
                 {
                     double S[9], T[9];
                     skew(G.tb.x, G.tb.y, G.tb.z, S);
                     mat3mul(Ra.m, S, T);
 #pragma unroll
-                    for (int i = 0; i < 9; i++) { A11[i] = -Ra.m[i]; A12[i] = 2. * T[i]; }
+                    for (int i = 0; i < 9; i++) { A11[i] = -Ra.m[i]; A12[i] = 2. * T[i]; B11[i] = Re.m[i]; }
                     double Sa[9], Sb[9], L[9], R[9], P[9];
                     skew(G.qa.x, G.qa.y, G.qa.z, Sa);
                     skew(G.qb.x, G.qb.y, G.qb.z, Sb);
@@ -342,77 +423,22 @@ __device__ __forceinline__ void hessian_rows_body(PgoDev D, const double* __rest
 #pragma unroll
                     for (int i = 0; i < 9; i++) B22[i] = ((i % 4 == 0) ? G.qe.w : 0.) + Se[i];
                 }
-                const double* B11 = Re.m;
-                // ---- W_j = Omega' Jj   (Jj = diag(B11, B22)), H_ij = Ji^T Wj: ONE code path for both sides of the edge, so that the block
-                //      row i stores and the transposed block row j stores are the same numbers
-                double Wj[36];
-#pragma unroll
-                for (int rr = 0; rr < 6; rr++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        Wj[rr * 6 + c] = Om[rr * 6 + 0] * B11[0 * 3 + c] + Om[rr * 6 + 1] * B11[1 * 3 + c] + Om[rr * 6 + 2] * B11[2 * 3 + c];
-                        Wj[rr * 6 + 3 + c] = Om[rr * 6 + 3] * B22[0 * 3 + c] + Om[rr * 6 + 4] * B22[1 * 3 + c] + Om[rr * 6 + 5] * B22[2 * 3 + c];
-                    }
-                const int other = side == 0 ? D.slot_j[k] : D.slot_i[k];        // the edge's slot in the other endpoint's row (-1: that vertex is fixed)
-                if (other >= 0) {
-                    double Hij[36];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) {
-#pragma unroll
-                        for (int rr = 0; rr < 3; rr++) {
-                            Hij[rr * 6 + c] = A11[0 * 3 + rr] * Wj[0 * 6 + c] + A11[1 * 3 + rr] * Wj[1 * 6 + c] + A11[2 * 3 + rr] * Wj[2 * 6 + c];
-                            Hij[(3 + rr) * 6 + c] = A12[0 * 3 + rr] * Wj[0 * 6 + c] + A12[1 * 3 + rr] * Wj[1 * 6 + c] + A12[2 * 3 + rr] * Wj[2 * 6 + c] +
-                                                   A22[0 * 3 + rr] * Wj[3 * 6 + c] + A22[1 * 3 + rr] * Wj[4 * 6 + c] + A22[2 * 3 + rr] * Wj[5 * 6 + c];
-                        }
-                    }
-                    double2* __restrict__ bk = reinterpret_cast<double2*>(D.blk + (size_t)s * 36);
-                    if (side == 0) {
-#pragma unroll
-                        for (int i = 0; i < 18; i++) bk[i] = make_double2(Hij[2 * i], Hij[2 * i + 1]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 18; i++) bk[i] = make_double2(Hij[((2 * i) % 6) * 6 + (2 * i) / 6], Hij[((2 * i + 1) % 6) * 6 + (2 * i + 1) / 6]);
-                    }
-                }
+                // ---- H_ij = Ji^T W_j, W_j = Omega' Jj: ONE code path for both sides of the edge, so that the block row i stores and the
+                //      transposed block row j stores are the same numbers
+                const bool write = (sm.w & 0x3fffffff) != 0;                    // the edge's other endpoint has a row (it is not fixed)
+                hij_col<0>(Om, A11, A12, A22, B11, B22, write, side, blk_out); hij_col<1>(Om, A11, A12, A22, B11, B22, write, side, blk_out);
+                hij_col<2>(Om, A11, A12, A22, B11, B22, write, side, blk_out); hij_col<3>(Om, A11, A12, A22, B11, B22, write, side, blk_out);
+                hij_col<4>(Om, A11, A12, A22, B11, B22, write, side, blk_out); hij_col<5>(Om, A11, A12, A22, B11, B22, write, side, blk_out);
                 // ---- the slot's share of H_aa (upper triangle: the sum is then symmetric to the last bit) and of -b
-                if (side == 1) {                       // row j: Jj^T Wj, Jj^T Omega' e
+                share_col<0>(Om, A11, A12, A22, B11, B22, side, mine); share_col<1>(Om, A11, A12, A22, B11, B22, side, mine);
+                share_col<2>(Om, A11, A12, A22, B11, B22, side, mine); share_col<3>(Om, A11, A12, A22, B11, B22, side, mine);
+                share_col<4>(Om, A11, A12, A22, B11, B22, side, mine); share_col<5>(Om, A11, A12, A22, B11, B22, side, mine);
 #pragma unroll
-                    for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                        for (int c = rr; c < 6; c++)
-                            mine[tri6(rr, c)] = B11[0 * 3 + rr] * Wj[0 * 6 + c] + B11[1 * 3 + rr] * Wj[1 * 6 + c] + B11[2 * 3 + rr] * Wj[2 * 6 + c];
-#pragma unroll
-                    for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                        for (int c = 3 + rr; c < 6; c++)
-                            mine[tri6(3 + rr, c)] = B22[0 * 3 + rr] * Wj[3 * 6 + c] + B22[1 * 3 + rr] * Wj[4 * 6 + c] + B22[2 * 3 + rr] * Wj[5 * 6 + c];
-#pragma unroll
-                    for (int rr = 0; rr < 3; rr++) {
+                for (int rr = 0; rr < 3; rr++) {
+                    if (side == 1) {                   // Jj^T Omega' e
                         mine[21 + rr] = B11[0 * 3 + rr] * Oe[0] + B11[1 * 3 + rr] * Oe[1] + B11[2 * 3 + rr] * Oe[2];
                         mine[24 + rr] = B22[0 * 3 + rr] * Oe[3] + B22[1 * 3 + rr] * Oe[4] + B22[2 * 3 + rr] * Oe[5];
-                    }
-                } else {                               // row i: W_i = Omega' Ji (reusing Wj's registers), Ji^T Wi, Ji^T Omega' e
-#pragma unroll
-                    for (int rr = 0; rr < 6; rr++)
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            Wj[rr * 6 + c] = Om[rr * 6 + 0] * A11[0 * 3 + c] + Om[rr * 6 + 1] * A11[1 * 3 + c] + Om[rr * 6 + 2] * A11[2 * 3 + c];
-                            Wj[rr * 6 + 3 + c] = Om[rr * 6 + 0] * A12[0 * 3 + c] + Om[rr * 6 + 1] * A12[1 * 3 + c] + Om[rr * 6 + 2] * A12[2 * 3 + c] +
-                                                Om[rr * 6 + 3] * A22[0 * 3 + c] + Om[rr * 6 + 4] * A22[1 * 3 + c] + Om[rr * 6 + 5] * A22[2 * 3 + c];
-                        }
-#pragma unroll
-                    for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                        for (int c = rr; c < 6; c++)
-                            mine[tri6(rr, c)] = A11[0 * 3 + rr] * Wj[0 * 6 + c] + A11[1 * 3 + rr] * Wj[1 * 6 + c] + A11[2 * 3 + rr] * Wj[2 * 6 + c];
-#pragma unroll
-                    for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                        for (int c = 3 + rr; c < 6; c++)
-                            mine[tri6(3 + rr, c)] = A12[0 * 3 + rr] * Wj[0 * 6 + c] + A12[1 * 3 + rr] * Wj[1 * 6 + c] + A12[2 * 3 + rr] * Wj[2 * 6 + c] +
-                                                    A22[0 * 3 + rr] * Wj[3 * 6 + c] + A22[1 * 3 + rr] * Wj[4 * 6 + c] + A22[2 * 3 + rr] * Wj[5 * 6 + c];
-#pragma unroll
-                    for (int rr = 0; rr < 3; rr++) {
+                    } else {                           // Ji^T Omega' e
                         mine[21 + rr] = A11[0 * 3 + rr] * Oe[0] + A11[1 * 3 + rr] * Oe[1] + A11[2 * 3 + rr] * Oe[2];
                         mine[24 + rr] = A12[0 * 3 + rr] * Oe[0] + A12[1 * 3 + rr] * Oe[1] + A12[2 * 3 + rr] * Oe[2] +
                                         A22[0 * 3 + rr] * Oe[3] + A22[1 * 3 + rr] * Oe[4] + A22[2 * 3 + rr] * Oe[5];
@@ -420,6 +446,17 @@ __device__ __forceinline__ void hessian_rows_body(PgoDev D, const double* __rest
                 }
             }
             __syncthreads();
+            {
+                const int nq = (s_end - base < kBlk ? s_end - base : kBlk) * 18;
+                double2* __restrict__ out = reinterpret_cast<double2*>(D.blk + (size_t)base * 36);
+                int q = tid / 18, part = tid - q * 18;
+                for (int gq = tid; gq < nq; gq += kBlk) {
+                    const double* __restrict__ src = st + (size_t)q * kLaStage + 2 * part;
+                    out[gq] = make_double2(src[0], src[1]);
+                    q += kBlk / 18; part += kBlk % 18;
+                    if (part >= 18) { part -= 18; q++; }
+                }
+            }
             if (rowlane) {                             // this chunk's slots of the lane's row, in slot order
                 const int q0 = ra0 > base ? ra0 : base, q1 = ra1 < base + kBlk ? ra1 : base + kBlk;
                 for (int q = q0; q < q1; q++) {

@@ -41,7 +41,8 @@ struct PgoDev {
     const int32_t* slot_edge; // [nslots] 2 * system edge + side (0: the row is the edge's first vertex, 1: its second)
     const int32_t* rb_ptr;    // [n_rb + 1] row blocks of the Hessian build: consecutive rows with <= 256 slots, <= 42 rows where the graph allows
     int32_t n_rb, pad_rb;
-    const double* erec;       // [e][44] the edge's inputs as one record: Z^-1 (7) | Omega (36) | pad
+    const double* srec;       // [22][nslots][2] the inputs of the slot's edge, slot-major in 16-byte pieces: Z^-1 (7) | Omega (36) | pad - a wave of the Hessian build reads 64 slots' k-th piece as one contiguous kilobyte
+    const int4* smeta;        // [nslots] {2 * edge + side, pose index of the edge's first vertex, of its second, (slot in the other endpoint's row + 1) | robust << 30}
     double* blk;
     double* hdiag;           // [nb][36]
     double* minv;            // [nb][36]  (H_aa + lambda I)^-1   (block-Jacobi path only; the multilevel path uses MlLevel::Winv)

@@ -201,8 +201,7 @@ void upload_edges_common(uzl_pgo* h)
 {
     hipStream_t s = h->stream;
     const int e = h->e;
-    h->d_erec.reserve((size_t)std::max(e, 1) * 44);
-    k_edge_records(h->d_zinv.p, h->d_info.p, e, h->d_erec.p, s);       // (values, not structure: also when the structure is kept)
+    h->srec_stale = true;               // (values, not structure: the slot records follow in prepare_optimize, also when the structure is kept)
     if (e > 0) {
         std::vector<int32_t> ei((size_t)e), ej((size_t)e);
         for (int k = 0; k < e; k++) { ei[k] = h->ij[2 * k]; ej[k] = h->ij[2 * k + 1]; }
@@ -693,7 +692,14 @@ void build_structure(uzl_pgo* h)
     hipStream_t s = h->stream;
     const size_t nbz = std::max(nb, 1), nsz = std::max(nslots, 1);
     h->d_b2v.reserve(nbz); h->d_row_ptr.reserve(nbz + 1); h->d_col.reserve(nsz);
-    h->d_blk.reserve(nsz * 36); h->d_slot_edge.reserve(nsz);
+    h->d_blk.reserve(nsz * 36); h->d_slot_edge.reserve(nsz); h->d_srec.reserve(nsz * 44); h->d_smeta.reserve(nsz);
+    h->srec_stale = true;
+    std::vector<int4> smeta(nsz);
+    for (int q = 0; q < nslots; q++) {
+        const int k = slot_edge[q] >> 1, other = (slot_edge[q] & 1) ? slot_i[k] : slot_j[k];
+        smeta[q] = make_int4(slot_edge[q], h->ij[2 * k], h->ij[2 * k + 1], (other + 1) | (h->robust[k] ? 1 << 30 : 0));
+    }
+    if (nslots > 0) UZL_HIP(hipMemcpyAsync(h->d_smeta.p, smeta.data(), sizeof(int4) * nslots, hipMemcpyHostToDevice, s));
     h->d_hdiag.reserve(nbz * 42); h->d_minv.reserve(nbz * 36);              // [H_aa | b] contiguous: one all-reduce when sharded
     h->d_x.reserve(nbz * 6); h->d_xs.reserve(nbz * 6); h->d_r.reserve(nbz * 6); h->d_z.reserve(nbz * 6); h->d_p.reserve(nbz * 6); h->d_p2.reserve(nbz * 6); h->d_ap.reserve(nbz * 12 + kMaxPartials);   // [A p | restricted A p | partials]
     if (n > 0) UZL_HIP(hipMemcpyAsync(h->d_v2b.p, v2b.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
@@ -737,7 +743,7 @@ void build_structure(uzl_pgo* h)
     D.v2b = h->d_v2b.p; D.b2v = h->d_b2v.p; D.ei = h->d_ei.p; D.ej = h->d_ej.p;
     D.zinv = h->d_zinv.p; D.info = h->d_info.p; D.robust = h->d_robust.p;
     D.slot_i = h->d_slot_i.p; D.slot_j = h->d_slot_j.p; D.row_ptr = h->d_row_ptr.p; D.col = h->d_col.p; D.rowhdr = h->d_rowhdr.p;
-    D.slot_edge = h->d_slot_edge.p; D.rb_ptr = h->d_rb_ptr.p; D.n_rb = (int32_t)rb_ptr.size() - 1; D.pad_rb = 0; D.erec = h->d_erec.p; D.blk = h->d_blk.p; D.hdiag = h->d_hdiag.p; D.minv = h->d_minv.p;
+    D.slot_edge = h->d_slot_edge.p; D.rb_ptr = h->d_rb_ptr.p; D.n_rb = (int32_t)rb_ptr.size() - 1; D.pad_rb = 0; D.srec = h->d_srec.p; D.smeta = h->d_smeta.p; D.blk = h->d_blk.p; D.hdiag = h->d_hdiag.p; D.minv = h->d_minv.p;
     D.b = h->d_hdiag.p + (size_t)nb * 36; D.x = h->d_x.p; D.xs = h->d_xs.p; D.r = h->d_r.p; D.z = h->d_z.p; D.p = h->d_p.p; D.ap = h->d_ap.p;
     D.part_a = h->d_ap.p + (size_t)nbz * 12; D.part_b = h->d_part_b.p; D.part_c = h->d_part_c.p;
     D.scal = h->d_scal.p; D.flags = h->d_flags.p;
@@ -1019,6 +1025,10 @@ void prepare_optimize(uzl_pgo* h)
         h->n_gauge = gauge_fix(h);
         build_structure(h);
         h->structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
+    }
+    if (h->srec_stale) {                // the edges' values in slot order (new values on a kept structure, or a new structure)
+        k_slot_records(h->d_zinv.p, h->d_info.p, h->e, h->d_slot_edge.p, h->nslots, h->d_srec.p, h->stream);
+        h->srec_stale = false;
     }
 }
 int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
