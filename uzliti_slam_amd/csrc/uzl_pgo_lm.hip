@@ -87,10 +87,15 @@ void reserve_slots(LmRun* R, int n)
 }
 
 // ---- the segments of a pass, as launch sequences
-void enq_head(LmRun* R, int pass_flags, hipStream_t s)
+void enq_linearize(LmRun* R, hipStream_t s)
 {
     const LmShape& sh = R->shape;
     UZL_HIP(kl_linearize(R->d_slots.p, sh.nslots, sh.g_edges, sh.g_asm, s));
+}
+void enq_head(LmRun* R, int pass_flags, bool linearized, hipStream_t s)
+{
+    const LmShape& sh = R->shape;
+    if (!linearized) enq_linearize(R, s);
     k_lm_head(R->d_slots.p, sh.nslots, pass_flags, s);
     if (sh.red) kl_schur_reduce(R->d_slots.p, sh.nslots, sh.schur_runs, (long)sh.schur_items, s);
 }
@@ -331,6 +336,12 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
     };
     int passes = 0;
     double enq_ms = 0., wait_ms = 0.;
+    // The next pass's linearisation goes out right behind a pass's tail, BEFORE the look: hessian_lm_kernel takes nothing from the host
+    // (it works on the graphs the tail has left in phase kLmLin and is a no-op for the others), so the GPU builds the Hessian while the
+    // host reads the snapshot, chooses the next pass and launches it - otherwise ~12 us of idle GPU per pass (tail -> hessian in the
+    // kernel trace).  Not while a rebuild on the second stream still reads H, and a refill sends the linearisation again.
+    static const bool lin_ahead_on = diag_int("UZL_LM_LIN_AHEAD", 1) != 0;      // A/B switch
+    bool lin_ahead = false;
     while (n_active > 0) {
         const auto tp0 = std::chrono::steady_clock::now();
         // ---- what this pass carries: predictions from the slots' last snapshots
@@ -384,7 +395,8 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
         mark(0);
         if (any_start && R->join_pending) { UZL_HIP(hipStreamWaitEvent(s, R->ev_join, 0)); R->join_pending = false; }      // the rebuild of an earlier pass reads H and the poses
         mark(1);
-        if (any_start) enq_head(R, pf, s);
+        if (any_start) enq_head(R, pf, lin_ahead, s);
+        lin_ahead = false;
         mark(2);
         if (pf & kPassSetup) run_seg(R->setup, eager, s, [&](hipStream_t q) { enq_setup(R, 1, q); });
         if (pf & kPassRebuild) {
@@ -409,6 +421,7 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
         }
         mark(5);
         enq_tail(R, s);
+        if (lin_ahead_on && !R->join_pending && !(o.timer && o.timer->on)) { enq_linearize(R, s); lin_ahead = true; }
         mark(6);
         passes++;
         for (int sl = 0; sl < nS; sl++) sent[sl]++;
@@ -447,6 +460,7 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
             if (R->join_pending && next_job < Q) { UZL_HIP(hipStreamWaitEvent(s, R->ev_join, 0)); R->join_pending = false; }
             for (int sl = 0; sl < nS; sl++)
                 if (slot_job[sl] >= 0 && jobs[slot_job[sl]].finished) load_slot(sl, false);
+            lin_ahead = false;                              // (the new graphs were not in their slots when the linearisation ran)
         }
         const auto tp2 = std::chrono::steady_clock::now();
         enq_ms += std::chrono::duration<double, std::milli>(tp1 - tp0).count(); wait_ms += std::chrono::duration<double, std::milli>(tp2 - tp1).count();
