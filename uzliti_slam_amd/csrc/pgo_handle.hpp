@@ -22,6 +22,7 @@ void k_prepare_edges(const uzl_edge* edges, const int32_t* src, int e, const dou
                      double* zinv, double* info, hipStream_t s);
 void k_prepare_flat_edges(const double* meas12, const double* info36, int e, double* zinv, double* info, hipStream_t s);
 int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s);
+int k_chi2_trial(const PgoDev& D, const double* pose, double delta, hipStream_t s);
 hipError_t k_hessian(const PgoDev& D, const double* pose, double delta, int* g_edges, int* g_rows, hipStream_t s, bool with_chi2 = true);
 void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s);
 int k_diagmax(const PgoDev& D, hipStream_t s);

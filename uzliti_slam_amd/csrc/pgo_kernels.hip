@@ -91,10 +91,8 @@ struct EdgeGeom {
     Q4 qa, qb, qe;
     double s;
 };
-__device__ __forceinline__ EdgeGeom edge_geom(const PgoDev& D, const double* __restrict__ pose, int k)
+__device__ __forceinline__ EdgeGeom edge_geom_of(const PgoDev& D, const Pose& Xi, const Pose& Xj, int k)
 {
-    const Pose Xi = load_pose(pose, D.ei[k]);
-    const Pose Xj = load_pose(pose, D.ej[k]);
     const size_t e = (size_t)D.e;
     const V3 ta{D.zinv[0 * e + k], D.zinv[1 * e + k], D.zinv[2 * e + k]};
     EdgeGeom G;
@@ -109,7 +107,38 @@ __device__ __forceinline__ EdgeGeom edge_geom(const PgoDev& D, const double* __r
     G.qe = Q4{G.s * qab.w, G.s * qab.x, G.s * qab.y, G.s * qab.z};
     return G;
 }
+__device__ __forceinline__ EdgeGeom edge_geom(const PgoDev& D, const double* __restrict__ pose, int k)
+{
+    return edge_geom_of(D, load_pose(pose, D.ei[k]), load_pose(pose, D.ej[k]), k);
+}
 
+// G9  VertexSE3::oplusImpl [EXT]: X <- X * fromVectorMQT(d)   (isometry3d_mappings.cpp:84-91,117-122).  Written out with contraction
+// off: ONE sequence of roundings wherever it is inlined - the evaluation of a trial in the device-resident loop recomputes the trial
+// poses of an edge's endpoints (eval_lm_kernel) instead of waiting for oplus to have stored them, and must get the stored bits.
+__device__ __forceinline__ Pose retract_pose(const Pose& P0, const double* __restrict__ d)
+{
+#pragma clang fp contract(off)
+    Pose P = P0;
+    const Q4 q = P0.q;
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    P.t.x = P0.t.x + (((1 - (tyy + tzz)) * d[0] + (txy - twz) * d[1]) + (txz + twy) * d[2]);
+    P.t.y = P0.t.y + (((txy + twz) * d[0] + (1 - (txx + tzz)) * d[1]) + (tyz - twx) * d[2]);
+    P.t.z = P0.t.z + (((txz - twy) * d[0] + (tyz + twx) * d[1]) + (1 - (txx + tyy)) * d[2]);
+    const double w2 = 1. - ((d[3] * d[3] + d[4] * d[4]) + d[5] * d[5]);
+    if (w2 >= 0.) {                                                 // identity rotation if w2 < 0
+        const double bw = sqrt(w2), bx = d[3], by = d[4], bz = d[5];
+        const double aw = ((q.w * bw - q.x * bx) - q.y * by) - q.z * bz;
+        const double ax = ((q.w * bx + q.x * bw) + q.y * bz) - q.z * by;
+        const double ay = ((q.w * by - q.x * bz) + q.y * bw) + q.z * bx;
+        const double az = ((q.w * bz + q.x * by) - q.y * bx) + q.z * bw;
+        const double n = 1.0 / sqrt(((aw * aw + ax * ax) + ay * ay) + az * az);
+        P.q = Q4{aw * n, ax * n, ay * n, az * n};
+    }
+    return P;
+}
 // chi = e^T Omega e, reading Omega from the SoA array
 __device__ __forceinline__ double edge_chi(const PgoDev& D, int k, const double* ev)
 {
@@ -134,12 +163,21 @@ __device__ __forceinline__ void huber(double e2, double delta, double& rho0, dou
 }
 
 // activeRobustChi2 over `pose`; block partials -> part_a
+// kRetract: `pose` is the estimate the trial starts from, and the trial poses are made here from D.x (retract_pose: the bits oplus stores)
+template <bool kRetract = false>
 __device__ __forceinline__ void chi2_kernel_body(PgoDev D, const double* __restrict__ pose, double delta, int blk = blockIdx.x, int nblk = gridDim.x)
 {
     __shared__ double s4[4];
     double acc = 0.;
     for (int k = D.e_begin + blk * kBlk + threadIdx.x; k < D.e_end; k += nblk * kBlk) {
-        const EdgeGeom G = edge_geom(D, pose, k);
+        const int vi = D.ei[k], vj = D.ej[k];
+        Pose Xi = load_pose(pose, vi), Xj = load_pose(pose, vj);
+        if (kRetract) {
+            const int a = D.v2b[vi], b = D.v2b[vj];
+            if (a >= 0) Xi = retract_pose(Xi, D.x + (size_t)a * 6);
+            if (b >= 0) Xj = retract_pose(Xj, D.x + (size_t)b * 6);
+        }
+        const EdgeGeom G = edge_geom_of(D, Xi, Xj, k);
         const double ev[6] = {G.te.x, G.te.y, G.te.z, G.qe.x, G.qe.y, G.qe.z};
         const double chi = edge_chi(D, k, ev);
         double r0 = chi, r1 = 1.;
@@ -699,16 +737,15 @@ __global__ __launch_bounds__(kBlk) void pcg_update_kernel(PgoDev D, const double
 }
 
 // ------------------------------------------------------------------------------------------------
-// G9  VertexSE3::oplusImpl [EXT]: X <- X * fromVectorMQT(dx)   (isometry3d_mappings.cpp:84-91,117-122)
-//     plus the partials of computeScale = sum dx (lambda dx + b) -> part_b
+// G9  VertexSE3::oplusImpl [EXT] over the vertices (retract_pose), plus the partials of computeScale = sum dx (lambda dx + b) -> part_b
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void oplus_kernel_body(PgoDev D, const double* __restrict__ pose_in,
-                                                     double* __restrict__ pose_out)
+                                                     double* __restrict__ pose_out, int blk = blockIdx.x, int nblk = gridDim.x)
 {
     __shared__ double s4[4];
     const double lambda = D.scal[3];
     double acc = 0.;
-    for (int v = blockIdx.x * kBlk + threadIdx.x; v < D.n; v += gridDim.x * kBlk) {
+    for (int v = blk * kBlk + threadIdx.x; v < D.n; v += nblk * kBlk) {
         Pose P = load_pose(pose_in, v);
         const int a = D.v2b[v];
         if (a >= 0) {
@@ -717,15 +754,12 @@ __device__ __forceinline__ void oplus_kernel_body(PgoDev D, const double* __rest
             const double d[6] = {dx[0], dx[1], dx[2], dx[3], dx[4], dx[5]};
 #pragma unroll
             for (int i = 0; i < 6; i++) acc += d[i] * (lambda * d[i] + bb[i]);
-            const V3 rt = mulv(qrot(P.q), V3{d[0], d[1], d[2]});
-            P.t = V3{P.t.x + rt.x, P.t.y + rt.y, P.t.z + rt.z};
-            const double w2 = 1. - (d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
-            if (w2 >= 0.) P.q = qnormalize(qmul(P.q, Q4{sqrt(w2), d[3], d[4], d[5]}));   // identity rotation if w2 < 0
+            P = retract_pose(P, d);
         }
         store_pose(pose_out, v, P);
     }
     const double tot = block_sum(acc, s4);
-    if (threadIdx.x == 0) D.part_b[blockIdx.x] = tot;
+    if (threadIdx.x == 0) D.part_b[blk] = tot;
 }
 __global__ __launch_bounds__(kBlk) void oplus_kernel(PgoDev D, const double* __restrict__ pose_in, double* __restrict__ pose_out)
 {
@@ -760,19 +794,16 @@ __global__ __launch_bounds__(kBlk) void hessian_lm_kernel(const LmSlot* __restri
 }
 // the evaluation of a trial runs once its solve has ended without a breakdown (lm_tail_kernel sorts the rest out)
 __device__ __forceinline__ bool lm_evaluates(const LmDev* lm) { return lm->phase == kLmSolve && lm->flags[0] != 0 && lm->flags[2] == 0; }
-__global__ __launch_bounds__(kBlk) void oplus_lm_kernel(const LmSlot* __restrict__ slots)
+// retraction and chi2 of the trial in ONE launch: the workgroups behind the vertex workgroups evaluate the edges at trial poses they make
+// themselves (one launch less per trial: ~4 us; an edge lane's two retractions are ~100 flop beside its error's 500)
+__global__ __launch_bounds__(kBlk) void eval_lm_kernel(const LmSlot* __restrict__ slots, int g_oplus_launch)
 {
     const LmSlot& S = slots[blockIdx.z];
     const LmDev* lm = S.lm;
-    if (!lm_evaluates(lm) || (int)blockIdx.x >= S.g_oplus) return;
-    oplus_kernel_body(S.D, S.pose[lm->cur], S.pose[lm->cur ^ 1]);
-}
-__global__ __launch_bounds__(kBlk) void chi2_lm_kernel(const LmSlot* __restrict__ slots)
-{
-    const LmSlot& S = slots[blockIdx.z];
-    const LmDev* lm = S.lm;
-    if (!lm_evaluates(lm) || (int)blockIdx.x >= S.g_edges) return;
-    chi2_kernel_body(S.D, S.pose[lm->cur ^ 1], lm->delta);
+    if (!lm_evaluates(lm)) return;
+    const int b = blockIdx.x;
+    if (b < g_oplus_launch) { if (b < S.g_oplus) oplus_kernel_body(S.D, S.pose[lm->cur], S.pose[lm->cur ^ 1], b, S.g_oplus); }
+    else if (b - g_oplus_launch < S.g_edges) chi2_kernel_body<true>(S.D, S.pose[lm->cur], lm->delta, b - g_oplus_launch, S.g_edges);
 }
 hipError_t kl_linearize(const LmSlot* sl, int nslots, int g_edges, int g_asm, hipStream_t s)
 {
@@ -781,8 +812,7 @@ hipError_t kl_linearize(const LmSlot* sl, int nslots, int g_edges, int g_asm, hi
 }
 void kl_eval(const LmSlot* sl, int nslots, int g_edges, int g_oplus, hipStream_t s)
 {
-    hipLaunchKernelGGL(oplus_lm_kernel, dim3(g_oplus, 1, nslots), dim3(kBlk), 0, s, sl);
-    hipLaunchKernelGGL(chi2_lm_kernel, dim3(g_edges, 1, nslots), dim3(kBlk), 0, s, sl);
+    hipLaunchKernelGGL(eval_lm_kernel, dim3(g_oplus + g_edges, 1, nslots), dim3(kBlk), 0, s, sl, g_oplus);
 }
 
 int g_edges_for(int e) { return grid_for(e, kBlk, kMaxPartials); }
@@ -814,6 +844,17 @@ int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s)
 {
     const int g = grid_for(D.e_end - D.e_begin, kBlk, kMaxPartials);
     hipLaunchKernelGGL(chi2_kernel, dim3(g), dim3(kBlk), 0, s, D, pose, delta);
+    return g;
+}
+// chi2 of the trial `pose` (+) D.x: eval_lm_kernel's edge workgroups as a launch of their own (the host-driven loop; same body, same bits)
+__global__ __launch_bounds__(kBlk) void chi2_trial_kernel(PgoDev D, const double* __restrict__ pose, double delta)
+{
+    chi2_kernel_body<true>(D, pose, delta);
+}
+int k_chi2_trial(const PgoDev& D, const double* pose, double delta, hipStream_t s)
+{
+    const int g = grid_for(D.e_end - D.e_begin, kBlk, kMaxPartials);
+    hipLaunchKernelGGL(chi2_trial_kernel, dim3(g), dim3(kBlk), 0, s, D, pose, delta);
     return g;
 }
 // the Hessian build (G3-G6): *g_edges chi2 partials in part_a, *g_rows diagonal maxima in part_c

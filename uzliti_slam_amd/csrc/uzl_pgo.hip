@@ -1233,7 +1233,7 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             if (red) { Timed t(h, "schur_backsub"); k_schur_backsub(D, Dp, SD, s); }   // dx of the eliminated vertices from the separators'
             int go, gc;
             { Timed t(h, "oplus"); go = k_oplus(D, h->cur, h->trial, s); }        // push + update
-            { Timed t(h, "chi2"); gc = k_chi2(D, h->trial, delta, s); }           // computeActiveErrors
+            { Timed t(h, "chi2"); gc = k_chi2_trial(D, h->cur, delta, s); }       // computeActiveErrors (at trial poses made on the fly: the arithmetic of the device-resident loop's eval_lm_kernel)
             { Timed t(h, "finalize"); k_finalize(D, gc, go, 0, 1, s); }
             shard_allreduce_chi2(h);
             fetch_scal(h);
