@@ -876,12 +876,14 @@ int k_diagmax(const PgoDev& D, hipStream_t s)
 __global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ scal, const int32_t* __restrict__ flags,
                                                     PgoHostScal* __restrict__ out, uint32_t seq)
 {
+    // (system-scope stores into the uncached host block, acknowledged before the sequence word goes: as lm_tail_kernel, no fence - a
+    //  system-scope release also writes the L2's dirty lines back, and the host reads nothing of them)
     const int t = threadIdx.x;
-    if (t < 8) out->scal[t] = scal[t];
-    else if (t < 12) out->flags[t - 8] = flags[t - 8];
-    __threadfence_system();
+    if (t < 8) __hip_atomic_store(&out->scal[t], scal[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (t < 12) __hip_atomic_store(&out->flags[t - 8], flags[t - 8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void set_scalar_kernel(double* __restrict__ dst, double v) { *dst = v; }
 __global__ void set_scalar2_kernel(double* __restrict__ dst_a, double va, double* __restrict__ dst_b, double vb) { *dst_a = va; *dst_b = vb; }

@@ -17,21 +17,9 @@
 
 namespace uzl {
 
-__global__ __launch_bounds__(kBlk) void lm_head_kernel(const LmSlot* __restrict__ slots, int pass_flags)
+// lane 0 of lm_head_kernel, on the staged state
+__device__ __forceinline__ void lm_head_decide(const LmSlot& S, LmDev* lm, int phase, double chi, double dmax, int pass_flags)
 {
-    __shared__ double s4[4];
-    const LmSlot& S = slots[blockIdx.z];
-    LmDev* lm = S.lm;
-    const int phase = lm->phase;
-    double chi = 0., dmax = 0.;
-    __syncthreads();                                         // (lane 0 rewrites the state below: everybody has read it)
-    if (phase == kLmLin) {                                   // (uniform) finalize_kernel(what = 2): chi2 + max diagonal
-        chi = sum_partials(S.D.part_a, S.g_edges, s4);
-        double v = 0.;
-        for (int i = threadIdx.x; i < S.g_asm; i += kBlk) v = fmax(v, S.D.part_c[i]);
-        dmax = block_max(v, s4);
-    }
-    if (threadIdx.x != 0) return;
     const int p = lm->pass + 1;
     lm->pass = p;
     double* __restrict__ scal = S.D.scal;
@@ -80,19 +68,49 @@ __global__ __launch_bounds__(kBlk) void lm_head_kernel(const LmSlot* __restrict_
     lm->phase = kLmSolve;                                    // (flags[0..3] are cleared by this pass's ml_init)
 }
 
+
+__global__ __launch_bounds__(kBlk) void lm_head_kernel(const LmSlot* __restrict__ slots, int pass_flags)
+{
+    __shared__ double s4[4];
+    __shared__ LmDev L;                                      // the state, staged: lane 0's decisions are a chain of reads and writes of its
+                                                             // fields, each a round trip to memory when taken from the global copy
+    const LmSlot& S = slots[blockIdx.z];
+    LmDev* lm = &L;
+    constexpr int kLmWords = (int)(sizeof(LmDev) / 8);
+    static_assert(sizeof(LmDev) % 8 == 0 && kLmWords <= kBlk, "LmDev is copied as 8-byte words");
+    if ((int)threadIdx.x < kLmWords) reinterpret_cast<unsigned long long*>(&L)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(S.lm)[threadIdx.x];
+    __syncthreads();
+    const int phase = lm->phase;
+    double chi = 0., dmax = 0.;
+    if (phase == kLmLin) {                                   // (uniform) finalize_kernel(what = 2): chi2 + max diagonal
+        chi = sum_partials(S.D.part_a, S.g_edges, s4);
+        double v = 0.;
+        for (int i = threadIdx.x; i < S.g_asm; i += kBlk) v = fmax(v, S.D.part_c[i]);
+        dmax = block_max(v, s4);
+    }
+    if (threadIdx.x == 0) lm_head_decide(S, lm, phase, chi, dmax, pass_flags);
+    __syncthreads();
+    if ((int)threadIdx.x < kLmWords) reinterpret_cast<unsigned long long*>(S.lm)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(&L)[threadIdx.x];
+}
+
 // The tail runs 1024 lanes: the residual guard's sums (residual_guard_kernel's order), then the first 256 fold the chi2 / scale
 // partials in finalize_kernel's order, lane 0 decides, and the first lanes copy the state to the host word by word.
 constexpr int kTailBlk = 1024;
 __global__ __launch_bounds__(kTailBlk) void lm_tail_kernel(const LmSlot* __restrict__ slots)
 {
-    __shared__ double s4[4], sr[16], sb[16];
+    __shared__ double s4[4], sr[16], sb[16], sscal[16];
+    __shared__ LmDev L;                                      // the state and the scalars, staged (as in lm_head_kernel)
     const LmSlot& S = slots[blockIdx.z];
-    LmDev* lm = S.lm;
+    LmDev* lm = &L;
     const int tid = threadIdx.x;
+    constexpr int kLmWords = (int)(sizeof(LmDev) / 8);
+    static_assert(sizeof(LmDev) % 8 == 0 && kLmWords + 16 <= kTailBlk, "LmDev is copied as 8-byte words");
+    if (tid < kLmWords) reinterpret_cast<unsigned long long*>(&L)[tid] = reinterpret_cast<const unsigned long long*>(S.lm)[tid];
+    else if (tid < kLmWords + 16) sscal[tid - kLmWords] = S.D.scal[tid - kLmWords];
+    __syncthreads();
     const bool solving = lm->phase == kLmSolve;
     const bool done = lm->flags[0] != 0;
     const bool eval = solving && done && lm->flags[2] == 0;      // (uniform) the evaluation kernels of this pass ran for this graph
-    __syncthreads();                                         // (lane 0 rewrites the state below: everybody has read it)
     double chi_t = 0., sc = 0., ratio = 0.;
     if (eval) {
         // |r|^2 / |b|^2 with the recurrence residual r (= b - (H + lambda) x up to rounding whatever the preconditioner did): what
@@ -128,7 +146,7 @@ __global__ __launch_bounds__(kTailBlk) void lm_tail_kernel(const LmSlot* __restr
         const uint32_t seq = (uint32_t)(lm->tails + 1);
         lm->tails = (int32_t)seq;
         s_seq = seq;
-        double* __restrict__ scal = S.D.scal;
+        double* __restrict__ scal = sscal;                   // (0, 1 read; 4, 5, 7 written: stored below)
         if (solving && !done) {
             if (lm->flags[1] >= lm->max_it) { lm->phase = kLmAnomaly; lm->anomaly_code = 1; lm->flags[0] = 1; }      // PCG hit its cap
         } else if (solving) {
@@ -156,19 +174,30 @@ __global__ __launch_bounds__(kTailBlk) void lm_tail_kernel(const LmSlot* __restr
                 }
             }
         }
-        __hip_atomic_store(&S.pub->seq_begin, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __threadfence();
     }
     __syncthreads();
-    // ---- the snapshot the host polls: one word per lane
-    constexpr int kLmWords = (int)(sizeof(LmDev) / 8);
-    static_assert(sizeof(LmDev) % 8 == 0 && kLmWords + 8 <= kTailBlk, "LmDev is copied as 8-byte words");
+    // ---- the state back to its place, and the snapshot the host polls: one word per lane.  The snapshot lives in pinned, coherent
+    //      (uncached) host memory: its stores go out as system-scope stores, the lanes wait for their acknowledgement (vmcnt) and the
+    //      sequence word follows behind the barrier.  No fence: a system-scope release fence also writes back every dirty line of the L2
+    //      - the whole solve's working set, 16 waves each - which was most of this kernel's 11 us, and nothing the host reads is there.
     unsigned long long* __restrict__ dst = reinterpret_cast<unsigned long long*>(S.pub);
-    if (tid < kLmWords) dst[tid] = reinterpret_cast<const unsigned long long*>(lm)[tid];
-    else if (tid < kLmWords + 8) reinterpret_cast<double*>(dst)[tid] = S.D.scal[tid - kLmWords];
-    __threadfence_system();
+    if (tid < kLmWords) {
+        const unsigned long long w = reinterpret_cast<const unsigned long long*>(&L)[tid];
+        reinterpret_cast<unsigned long long*>(S.lm)[tid] = w;
+        __hip_atomic_store(dst + tid, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (tid < kLmWords + 8) {
+        const double v = sscal[tid - kLmWords];
+        if (tid - kLmWords == 4 || tid - kLmWords == 5 || tid - kLmWords == 7) S.D.scal[tid - kLmWords] = v;
+        __hip_atomic_store(reinterpret_cast<double*>(dst) + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (tid == kLmWords + 8) {
+        // seq_begin travels with the fields and seq follows behind them: a snapshot whose two words agree is whole.  (Rounds 4-5 sent
+        // seq_begin ahead behind a fence of its own; the host reads a slot's snapshot before it enqueues the pass whose tail writes the
+        // next one, so nothing can overwrite the fields under its copy.)
+        __hip_atomic_store(&S.pub->seq_begin, s_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this lane's stores have been acknowledged
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&S.pub->seq, s_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(&S.pub->seq, s_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 void k_lm_head(const LmSlot* slots, int nslots, int pass_flags, hipStream_t s)

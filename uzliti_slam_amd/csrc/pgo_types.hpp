@@ -207,7 +207,7 @@ struct LmDev {
     double scal2[8];           // [3]: lambda of a rebuild that runs ahead of the trial loop (the set-up kernels read scal[3])
 };
 // what the host sees after a pass: an image of the LM state and of PgoDev::scal[0..8), written by lm_tail_kernel into pinned coherent
-// memory (one 8-byte word per lane); seq_begin first, seq (= LmDev::tails) last: a host copy is whole when both agree around it
+// memory (one 8-byte word per lane); seq_begin with the fields, seq (= LmDev::tails) behind a fence: a host copy is whole when both agree around it
 struct LmHost {
     LmDev lm;
     double scal[8];            // as the host-driven loop fetches them (verbose logs, residual ratio)

@@ -217,7 +217,7 @@ LmDev idle_state()
 }
 
 // Waits until lm_tail launch number `seq` (or a later one) of slot `sl` has published and copies the snapshot; returns its number.
-// lm_tail writes seq_begin, the fields, then seq (release): a copy is whole when both words agree around it.
+// lm_tail writes the fields and seq_begin, a system-scope fence, then seq (release): a copy is whole when both words agree around it.
 uint32_t wait_pub(hipStream_t s, LmRun* R, int sl, uint32_t seq, LmHost* out)
 {
     const auto t0 = std::chrono::steady_clock::now();
