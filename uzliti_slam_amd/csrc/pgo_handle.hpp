@@ -77,7 +77,7 @@ void kl_ml_numeric(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s
 void kl_ml_trial(const LmSlot* sl, const LmShape& sh, int which, hipStream_t s);
 void ml_cg_variant(const MlHot& ml, int agg, size_t lds_full, int32_t* variant, int32_t* comp_u, uint64_t* lds);
 hipError_t kl_ml_init(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, hipStream_t s);
-hipError_t kl_ml_pcg_pairs(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, int pairs, hipStream_t s, hipEvent_t* ev = nullptr);
+hipError_t kl_ml_pcg_its(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, int first, int n, hipStream_t s, hipEvent_t* ev = nullptr);
 }  // namespace uzl
 
 

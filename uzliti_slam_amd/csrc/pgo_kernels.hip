@@ -956,7 +956,13 @@ __device__ __forceinline__ void residual_guard_kernel_body(PgoDev D)
     if (!D.flags[0]) return;
     const int n = D.nb * 6;
     double rr = 0., bb = 0.;
-    for (int i = threadIdx.x; i < n; i += 1024) { const double r = D.r[i], b = D.b[i]; rr += r * r; bb += b * b; }
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {       // (eight entries in flight per lane, as in lm_tail_kernel)
+        double rv[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * 1024; rv[u] = i < n ? D.r[i] : 0.; bv[u] = i < n ? D.b[i] : 0.; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { rr += rv[u] * rv[u]; bb += bv[u] * bv[u]; }
+    }
     for (int o = 32; o; o >>= 1) { rr += __shfl_xor(rr, o); bb += __shfl_xor(bb, o); }
     if ((threadIdx.x & 63) == 0) { sr[threadIdx.x >> 6] = rr; sb[threadIdx.x >> 6] = bb; }
     __syncthreads();

@@ -2753,16 +2753,17 @@ hipError_t kl_ml_init(const LmSlot* sl, const LmSlot* host_slot, const LmShape& 
     if (host_slot && sh.nslots == 1) return kl_ml_init_t<LmSlot>(*host_slot, sh, s);
     return kl_ml_init_t<const LmSlot*>(sl, sh, s);
 }
-// PCG iterations 2 * pairs (p0 -> p1 -> p0 ...).  ev (profiling only, may be null): 4 events per iteration - spmv start / stop, cg
-// start / stop (dispatch timestamps; the batch's kernels)
-hipError_t kl_ml_pcg_pairs(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, int pairs, hipStream_t s, hipEvent_t* ev)
+// PCG iterations first .. first + n - 1 of a solve (iteration i: p_old = pbuf[i & 1], p_new = pbuf[(i & 1) ^ 1]).  ev (profiling only, may
+// be null): 4 events per iteration - spmv start / stop, cg start / stop (dispatch timestamps; the batch's kernels)
+hipError_t kl_ml_pcg_its(const LmSlot* sl, const LmSlot* host_slot, const LmShape& sh, int first, int n, hipStream_t s, hipEvent_t* ev)
 {
     const bool by_value = host_slot && sh.nslots == 1 && !ev;
-    for (int i = 0; i < 2 * pairs; i++) {
+    for (int q = 0; q < n; q++) {
+        const int par = (first + q) & 1;
         hipError_t e;
-        if (ev) { kl_ml_spmv_t<const LmSlot*>(sl, sh, i & 1, s, ev[4 * i], ev[4 * i + 1]); e = kl_ml_cg_t<const LmSlot*>(sl, sh, i & 1, 0, s, ev[4 * i + 2], ev[4 * i + 3]); }
-        else if (by_value) { kl_ml_spmv_t<LmSlot>(*host_slot, sh, i & 1, s); e = kl_ml_cg_t<LmSlot>(*host_slot, sh, i & 1, 0, s); }
-        else { kl_ml_spmv_t<const LmSlot*>(sl, sh, i & 1, s); e = kl_ml_cg_t<const LmSlot*>(sl, sh, i & 1, 0, s); }
+        if (ev) { kl_ml_spmv_t<const LmSlot*>(sl, sh, par, s, ev[4 * q], ev[4 * q + 1]); e = kl_ml_cg_t<const LmSlot*>(sl, sh, par, 0, s, ev[4 * q + 2], ev[4 * q + 3]); }
+        else if (by_value) { kl_ml_spmv_t<LmSlot>(*host_slot, sh, par, s); e = kl_ml_cg_t<LmSlot>(*host_slot, sh, par, 0, s); }
+        else { kl_ml_spmv_t<const LmSlot*>(sl, sh, par, s); e = kl_ml_cg_t<const LmSlot*>(sl, sh, par, 0, s); }
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -106,7 +106,7 @@ void enq_setup(LmRun* R, int which, hipStream_t s)
 }
 const LmSlot* by_value_slot(LmRun* R) { return (R->shape.nslots == 1 && !R->shape.batch_geometry && !lm_slot_ptr) ? R->slots.data() : nullptr; }
 void enq_init(LmRun* R, hipStream_t s) { UZL_HIP(kl_ml_init(R->d_slots.p, by_value_slot(R), R->shape, s)); }
-void enq_pcg(LmRun* R, int pairs, hipStream_t s, hipEvent_t* ev = nullptr) { UZL_HIP(kl_ml_pcg_pairs(R->d_slots.p, by_value_slot(R), R->shape, pairs, s, ev)); }
+void enq_pcg(LmRun* R, int first, int n, hipStream_t s, hipEvent_t* ev = nullptr) { UZL_HIP(kl_ml_pcg_its(R->d_slots.p, by_value_slot(R), R->shape, first, n, s, ev)); }
 void enq_tail(LmRun* R, hipStream_t s)
 {
     const LmShape& sh = R->shape;
@@ -369,20 +369,24 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
                     if (v.lambda > kLambdaRetake * v.lambda_setup[v.ix]) pf |= kPassSetup;
                 }
                 // The solve's length: the previous solve's count + 1 (a solve that the stop test ends after k iterations is declared done by
-                // the ml_spmv of iteration k + 1), rounded up to a pair: too many is a 1.2-us no-op per launch, too few another pass.  The
+                // the ml_spmv of iteration k + 1): too many is a ~3.5-us no-op per launch, too few another pass.  The
                 // first solve of an optimize has no predecessor: the first solve of the last optimize stands in (same structure or a grown
                 // one: a re-optimisation), a fresh run starts with two long replays.
                 // uzl_pgo_cfg::pass_history = 1: nothing an earlier optimize of this handle learned sizes a pass (the first solve starts with
                 // two long replays, every later one follows its predecessor in the same optimize)
                 static const bool no_history_env = diag_flag("UZL_LM_NO_HISTORY");           // A/B switch
                 const bool no_history = no_history_env || jobs[(size_t)slot_job[sl]].h->cfg.pass_history == 1;
-                w = v.pcg_last > 0 ? ((v.pcg_last + 2) & ~1) : ((R->first_solve_its > 0 && !no_history) ? ((R->first_solve_its + 2) & ~1) : 2 * kLong);
+                // One graph: exactly count + 1 launches (odd or even; a continuation pass picks the parity up from the solve's own
+                // iteration count).  A batch keeps whole pairs: its graphs share the launches' parity.
+                static const bool odd_ok = diag_int("UZL_LM_ODD_K", 1) != 0;      // A/B switch
+                auto up = [&](int count) { return (nS == 1 && odd_ok) ? count + 1 : ((count + 2) & ~1); };
+                w = v.pcg_last > 0 ? up(v.pcg_last) : ((R->first_solve_its > 0 && !no_history) ? up(R->first_solve_its) : 2 * kLong);
                 // counts that RISE from trial to trial (lambda falls after accepted steps, the system gets harder: chain-like graphs climb by 2
                 // per trial for ten trials, each time one launch short of `last + 2`): extrapolate the last rise
-                if (v.pcg_last > 0 && prev_last[sl] > 0 && v.pcg_last > prev_last[sl]) w = (v.pcg_last + std::min(v.pcg_last - prev_last[sl], 16) + 3) & ~1;
+                if (v.pcg_last > 0 && prev_last[sl] > 0 && v.pcg_last > prev_last[sl]) w = up(v.pcg_last + std::min(v.pcg_last - prev_last[sl], 16));
                 {
                     const std::vector<int>& hist = R->trial_its_prev[(size_t)slot_job[sl]];
-                    if (!no_history && (size_t)v.st_lm_trials < hist.size()) w = std::max(w, (hist[(size_t)v.st_lm_trials] + 2) & ~1);
+                    if (!no_history && (size_t)v.st_lm_trials < hist.size()) w = std::max(w, up(hist[(size_t)v.st_lm_trials]));
                 }
                 w = std::min(w, ((v.max_it + 1) & ~1));
             }
@@ -392,6 +396,9 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
         static const int k_pct = diag_int("UZL_BATCH_K_PCT", 100);      // A/B switch: the pass's PCG count as a percentile of the slots' predictions (100 = the longest)
         if (k_pct < 100 && wants.size() > 1) { std::sort(wants.begin(), wants.end()); want = wants[std::min(wants.size() - 1, (wants.size() * (size_t)k_pct) / 100)]; }
         want = std::max(2, want);
+        // iteration index of the pass's first PCG launch: a single graph's continuation goes on where its solve stands (its count may be
+        // odd); in a batch every pass holds whole pairs, so every solve stands at an even count
+        const int base = (nS == 1 && slot_job[0] >= 0 && snap[0].lm.phase == kLmSolve) ? snap[0].lm.flags[1] : 0;
         mark(0);
         if (any_start && R->join_pending) { UZL_HIP(hipStreamWaitEvent(s, R->ev_join, 0)); R->join_pending = false; }      // the rebuild of an earlier pass reads H and the poses
         mark(1);
@@ -413,11 +420,13 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
         if (o.timer && o.timer->on) {
             std::vector<hipEvent_t> ev((size_t)4 * want);
             for (int q = 0; q < want; q++) { o.timer->pair(o.spmv_name, &ev[4 * q], &ev[4 * q + 1]); o.timer->pair(o.cg_name, &ev[4 * q + 2], &ev[4 * q + 3]); }
-            enq_pcg(R, want / 2, s, ev.data());
+            enq_pcg(R, base, want, s, ev.data());
         } else {
-            const int n_long = eager ? 0 : want / kLong, rem = want - n_long * kLong;
-            for (int i = 0; i < n_long; i++) run_seg(R->pcg_long, false, s, [&](hipStream_t q) { enq_pcg(R, kGraphPairs, q); });
-            if (rem > 0) enq_pcg(R, rem / 2, s);
+            int first = base, left = want;
+            if (!eager && (first & 1)) { enq_pcg(R, first, 1, s); first++; left--; }      // (the captured replay starts at an even iteration)
+            const int n_long = eager ? 0 : left / kLong, rem = left - n_long * kLong;
+            for (int i = 0; i < n_long; i++) run_seg(R->pcg_long, false, s, [&](hipStream_t q) { enq_pcg(R, 0, kLong, q); });
+            if (rem > 0) enq_pcg(R, first + n_long * kLong, rem, s);
         }
         mark(5);
         enq_tail(R, s);
