@@ -291,9 +291,9 @@ def pgo_rooflines(pgo, st, st_prof, kt, nodes, edges, is_default):
                         traffic=traffic_of("c4_hessian_bytes_per_launch" if agg4 else "hessian_bytes_per_launch", is_default), algorithmic_bytes_per_launch=alg_l,
                         avg_launch_us=round(1e3 * lin["ms"] / lin["launches"], 3), launches=lin["launches"],
                         timing="hipEventRecord pair around the launch (reads ~1.5x a short kernel's own time; the rocprofv3 summary under profiles/ has the dispatch time)",
-                        note="the sparse Hessian build as ONE row-gather kernel (round 4; rounds 1-3: linearize_kernel + assemble_kernel): a lane per slot recomputes its "
-                             "edge's Jacobians, writes the H_ac block and leaves its share of H_aa | b in LDS; lane (row, r) adds the shares in slot order - no atomics, "
-                             "nothing but H itself in HBM"))
+                        note="the sparse Hessian build as ONE row-gather kernel (rounds 1-3: linearize_kernel + assemble_kernel): a lane per slot reads its slot-major "
+                             "record, recomputes its edge's Jacobians and leaves the H_ac block and its share of H_aa | b in LDS; the workgroup writes the blocks out "
+                             "contiguously, lane (row, r) adds the shares in slot order - no atomics, nothing but H itself in HBM"))
     gm = kt.get("ml_ns_gemm")
     if gm and gm["ms"] > 0:
         n1 = (nb + 7) // 8
