@@ -108,7 +108,7 @@ struct uzl_pgo {
     DevBuf<double> pose_a, pose_b, pose_init;
     double* cur = nullptr;
     double* trial = nullptr;
-    DevBuf<int32_t> d_v2b, d_b2v, d_ei, d_ej, d_slot_i, d_slot_j, d_row_ptr, d_col, d_rowhdr, d_src, d_flags;
+    DevBuf<int32_t> d_v2b, d_b2v, d_ei, d_ej, d_row_ptr, d_col, d_rowhdr, d_src, d_flags;
     DevBuf<int32_t> d_slot_edge, d_rb_ptr;
     DevBuf<double> d_srec;                     // slot records (pgo_kernels.hip: slot_records_kernel): values of the edges in the order of the structure's slots
     DevBuf<int4> d_smeta;

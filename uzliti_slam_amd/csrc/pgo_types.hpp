@@ -33,12 +33,9 @@ struct PgoDev {
     const double* zinv;      // [7][e]
     const double* info;      // [36][e]
     const uint8_t* robust;   // [e]
-    const int32_t* slot_i;   // [e] slot of the edge in row v2b[ei], -1 if ei is fixed
-    const int32_t* slot_j;
     const int32_t* row_ptr;  // [nb+1]
     const int32_t* col;      // [nslots]
     const int32_t* rowhdr;   // [nb][kRowHdr] = {row_ptr[a], row_ptr[a+1], col of the first 20 slots (-1 past the end), pad}: one hop instead of two
-    const int32_t* slot_edge; // [nslots] 2 * system edge + side (0: the row is the edge's first vertex, 1: its second)
     const int32_t* rb_ptr;    // [n_rb + 1] row blocks of the Hessian build: consecutive rows with <= 256 slots, <= 42 rows where the graph allows
     int32_t n_rb, pad_rb;
     const double* srec;       // [22][nslots][2] the inputs of the slot's edge, slot-major in 16-byte pieces: Z^-1 (7) | Omega (36) | pad - a wave of the Hessian build reads 64 slots' k-th piece as one contiguous kilobyte

@@ -156,7 +156,7 @@ void alloc_problem(uzl_pgo* h, bool keep_poses = false)
     const bool cur_b = keep_poses && h->cur != nullptr && h->cur == h->pose_b.p;       // (the estimate sits in whichever buffer the last solve left it)
     h->pose_a.reserve(n * 8, keep_poses, h->stream); h->pose_b.reserve(n * 8, keep_poses, h->stream); h->pose_init.reserve(n * 8);
     h->d_zinv.reserve(e * 7); h->d_info.reserve(e * 36); h->d_robust.reserve(e);
-    h->d_ei.reserve(e); h->d_ej.reserve(e); h->d_slot_i.reserve(e); h->d_slot_j.reserve(e);
+    h->d_ei.reserve(e); h->d_ej.reserve(e);
     h->d_v2b.reserve(n);
     h->d_part_a.reserve(kMaxPartials); h->d_part_b.reserve(kMaxPartials); h->d_part_c.reserve(2 * kMaxPartials);     // (part_c: two maxima per ml_cg workgroup at a look)
     h->d_scal.reserve(16); h->d_flags.reserve(4);
@@ -730,10 +730,6 @@ void build_structure(uzl_pgo* h)
     UZL_HIP(hipMemcpyAsync(h->d_rb_ptr.p, rb_ptr.data(), sizeof(int32_t) * rb_ptr.size(), hipMemcpyHostToDevice, s));
     h->d_rowhdr.reserve(nbz * kRowHdr);
     UZL_HIP(hipMemcpyAsync(h->d_rowhdr.p, rowhdr.data(), sizeof(int32_t) * nbz * kRowHdr, hipMemcpyHostToDevice, s));
-    if (e > 0) {
-        UZL_HIP(hipMemcpyAsync(h->d_slot_i.p, slot_i.data(), sizeof(int32_t) * e, hipMemcpyHostToDevice, s));
-        UZL_HIP(hipMemcpyAsync(h->d_slot_j.p, slot_j.data(), sizeof(int32_t) * e, hipMemcpyHostToDevice, s));
-    }
     // blocks of slots whose neighbour is fixed are never written: keep them defined
     if (nslots > 0) UZL_HIP(hipMemsetAsync(h->d_blk.p, 0, sizeof(double) * 36 * (size_t)nslots, s));      // (and slots of edges other ranks own stay 0)
     UZL_HIP(hipStreamSynchronize(s));       // host vectors go out of scope
@@ -742,8 +738,8 @@ void build_structure(uzl_pgo* h)
     D.pose = h->cur; D.pose_trial = h->trial;
     D.v2b = h->d_v2b.p; D.b2v = h->d_b2v.p; D.ei = h->d_ei.p; D.ej = h->d_ej.p;
     D.zinv = h->d_zinv.p; D.info = h->d_info.p; D.robust = h->d_robust.p;
-    D.slot_i = h->d_slot_i.p; D.slot_j = h->d_slot_j.p; D.row_ptr = h->d_row_ptr.p; D.col = h->d_col.p; D.rowhdr = h->d_rowhdr.p;
-    D.slot_edge = h->d_slot_edge.p; D.rb_ptr = h->d_rb_ptr.p; D.n_rb = (int32_t)rb_ptr.size() - 1; D.pad_rb = 0; D.srec = h->d_srec.p; D.smeta = h->d_smeta.p; D.blk = h->d_blk.p; D.hdiag = h->d_hdiag.p; D.minv = h->d_minv.p;
+    D.row_ptr = h->d_row_ptr.p; D.col = h->d_col.p; D.rowhdr = h->d_rowhdr.p;
+    D.rb_ptr = h->d_rb_ptr.p; D.n_rb = (int32_t)rb_ptr.size() - 1; D.pad_rb = 0; D.srec = h->d_srec.p; D.smeta = h->d_smeta.p; D.blk = h->d_blk.p; D.hdiag = h->d_hdiag.p; D.minv = h->d_minv.p;
     D.b = h->d_hdiag.p + (size_t)nb * 36; D.x = h->d_x.p; D.xs = h->d_xs.p; D.r = h->d_r.p; D.z = h->d_z.p; D.p = h->d_p.p; D.ap = h->d_ap.p;
     D.part_a = h->d_ap.p + (size_t)nbz * 12; D.part_b = h->d_part_b.p; D.part_c = h->d_part_c.p;
     D.scal = h->d_scal.p; D.flags = h->d_flags.p;
@@ -833,7 +829,7 @@ void build_structure(uzl_pgo* h)
             Dp.nb = P.nbr; Dp.nslots = P.nslots_r; Dp.b2v = Rd.b2v.p; Dp.row_ptr = Rd.row_ptr.p; Dp.col = Rd.col.p; Dp.rowhdr = Rd.rowhdr.p;
             Dp.blk = Rd.blk.p; Dp.hdiag = Rd.hdiag.p; Dp.minv = Rd.minv.p; Dp.b = Rd.hdiag.p + (size_t)P.nbr * 36;
             Dp.x = Rd.x.p; Dp.xs = Rd.xs.p; Dp.r = Rd.r.p; Dp.z = Rd.z.p; Dp.p = Rd.p.p; Dp.ap = Rd.ap.p; Dp.part_a = Rd.ap.p + nr * 12;
-            Dp.slot_edge = nullptr;                                           // the reduced system is assembled by schur_assemble_kernel
+            Dp.smeta = nullptr; Dp.srec = nullptr;                            // the reduced system is assembled by schur_assemble_kernel
             rrow_ptr.swap(P.row_ptr); rcol.swap(P.col);
         }
     }
