@@ -1160,7 +1160,7 @@ def main():
                         online_c5["cpu_baseline"]["pose_difference_at_that_point"].update(ok=ok5, bar=dict(dt_m=PARITY_T, dr_rad=PARITY_R),
                             note="every interval starts from the previous interval's result: the difference is what twenty LM iterations leave of the earlier "
                                  "ones' plus this interval's; tests/diag/c5_tolerance.py shows it follows the linear solver's accuracy (default stop test against "
-                                 "a tightly solved run: median 1e-5 m, largest 1.8e-4 m over the 94 intervals)")
+                                 "a tightly solved run: median 4e-6 m, largest 2.2e-4 m over the 94 intervals)")
                         if not ok5:
                             parity_fail.append(("online_c5", online_c5["cpu_baseline"]["pose_difference_at_that_point"]))
                 c.close()
