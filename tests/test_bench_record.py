@@ -65,3 +65,16 @@ def test_emit_prints_one_compact_line_on_stdout(capsys, tmp_path, monkeypatch):
     _check(lines[0])
     assert json.loads(cap.err.strip().splitlines()[-1])["online_c5"]["metric"]            # the full record is on stderr ...
     assert json.load(open(tmp_path / "gpurun_out" / "bench_full.json"))["c4_1gpu"]        # ... and in gpurun_out/
+
+
+def test_every_traffic_key_the_bench_reads_is_in_traffic_json():
+    """`roofline.traffic` comes from profiles/traffic.json (PMC passes of profiles/collect.sh): a kernel renamed since the last collection
+    (a template argument more) silently drops its key there and the bench reports `traffic: null`."""
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    keys = set(re.findall(r'traffic_of\((.*?), ', src))                      # the key argument: one name, or `"a" if cond else "b"`
+    keys = set(k for arg in keys for k in re.findall(r'"([a-z0-9_]+_bytes_per_launch)"', arg))
+    assert len(keys) >= 8, keys
+    have = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    missing = sorted(k for k in keys if not (isinstance(have.get(k), (int, float)) and have[k] > 0))
+    assert not missing, missing
