@@ -365,7 +365,7 @@ __device__ __forceinline__ void share_col(const double* Om, const double* A11, c
 // workgroup makes ONE pass: a chunk of slots, a group of rows; hub rows and very large graphs loop).
 // The lanes leave their H_ac blocks in LDS and the workgroup writes them out after the barrier - the chunk's blocks are one contiguous
 // piece of D.blk - 16 bytes a lane, lane after lane: written by their own lanes (18 x 16 bytes each, 288 bytes apart) the stores were
-// half of the kernel's time (tests/diag/r5_hessian_abl.sh).  131 KB of LDS: one workgroup per CU.  Measured and not kept: blocks and
+// half of the kernel's time (ablations: DESIGN_APPENDIX.md, "Hessian build").  131 KB of LDS: one workgroup per CU.  Measured and not kept: blocks and
 // shares in turn through ONE 76-KB piece with the lane's state held in registers under 256, so that two workgroups share a CU
 // (10k / 50k 34.4 -> 34.3 us, config 2 13.0 -> 17.1: two more barriers and a few spills on a path that is a latency chain).
 __device__ __forceinline__ void hessian_rows_body(PgoDev D, const double* __restrict__ pose, double delta, int rb)
