@@ -308,28 +308,37 @@ __device__ __forceinline__ double mv6(const double* __restrict__ A, const double
 // middle); the middle keeps W^L | W^R.  LDS matrices are private to a wave; the two waves' step counts differ by at most one and the
 // shorter one idles through the barriers of the longer.
 struct SchurWaveLds { double D[36], Di[36], C[36], E[36], T[36], W[36], g[6], u[6]; };
+// The LDS matrices of a half are private to its wave: what one lane writes the wave's other lanes read a few instructions later.  A wave's
+// LDS operations execute in program order, so all that is needed between the write and the reads is that the COMPILER keeps that order -
+// no s_barrier.  (Round 5: the elimination's 19 workgroup barriers per step made its two waves march in lock step; without them 37.9 ->
+// 34.5 us at 20k / 21.7k - tests/diag/r5_schur_ab.sh; the step is a chain of ~60 LDS round trips and six divisions either way.)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 // Di = D^-1 for the SPD 6 x 6 in L.D, by the wave's first 36 lanes TOGETHER: in-place Gauss-Jordan, lane (r, c) owns element (r, c), six
 // pivot steps through LDS, then the mean with the transpose (the inverse of a symmetric matrix, symmetric to the last bit like the
 // Cholesky-based routine's).  Every lane used to invert the same matrix on its own (spd_inverse6_rs: ~600 flops x 64 lanes): with 1285
 // runs in flight that made the elimination a throughput problem - half the chain length per wave changed nothing.  Called by all lanes
-// of the workgroup (`on` = this wave has a matrix): its barriers are workgroup barriers.
+// of the wave (`on` = this wave has a matrix).
 __device__ __forceinline__ void schur_inverse6_coop(SchurWaveLds& L, bool on, bool act, int lane, int r, int c)
 {
     double a = (on && act) ? L.D[lane] : 0.;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         if (on && act) L.Di[lane] = a;
-        __syncthreads();
+        wave_sync();
         if (on && act) {
             const double p = 1. / L.Di[k * 6 + k], rk = L.Di[r * 6 + k], kc = L.Di[k * 6 + c];
             a = (r == k) ? ((c == k) ? p : kc * p) : ((c == k) ? -rk * p : fma(-rk * p, kc, a));
         }
-        __syncthreads();
+        wave_sync();
     }
     if (on && act) L.Di[lane] = a;
-    __syncthreads();
+    wave_sync();
     if (on && act) a = 0.5 * (a + L.Di[c * 6 + r]);
-    __syncthreads();
+    wave_sync();
     if (on && act) L.Di[lane] = a;
 }
 __device__ __forceinline__ void schur_eliminate_kernel_body(PgoDev D, SchurDev S)
@@ -380,9 +389,9 @@ __device__ __forceinline__ void schur_eliminate_kernel_body(PgoDev D, SchurDev S
             if (vec) L.g[lane] = bv + gupd;
             if (it + 1 < my_steps) fetch(it + 1, hd, ev, bv);
         }
-        __syncthreads();
+        wave_sync();
         schur_inverse6_coop(L, on, act, lane, r, c);
-        __syncthreads();
+        wave_sync();
         if (on) {
             double tval = 0., wval = 0., uval = 0.;
             if (act) {
@@ -395,7 +404,7 @@ __device__ __forceinline__ void schur_eliminate_kernel_body(PgoDev D, SchurDev S
             if (vec) out[lane] = uval;
             if (act) { out[6 + lane] = wval; out[42 + lane] = tval; }
         }
-        __syncthreads();
+        wave_sync();
         if (on) {
             if (act) {
                 if (has_sep) { accS -= mm6<false, false>(L.C, L.W, r, c); cval = -mm6<false, false>(L.C, L.T, r, c); }      // S -= C W;  C' = -C T
@@ -406,7 +415,7 @@ __device__ __forceinline__ void schur_eliminate_kernel_body(PgoDev D, SchurDev S
                 gupd = -mv6<true>(L.E, L.u, lane);
             }
         }
-        __syncthreads();                                               // LDS is rewritten at the top of the next step
+        wave_sync();                                               // LDS is rewritten at the top of the next step
     }
     // ---- the middle vertex: both halves hand over what they left on it
     if (act) { xch[wv][lane] = cval; xch[wv][36 + lane] = dupd; xch[wv][78 + lane] = accS; }
@@ -421,9 +430,9 @@ __device__ __forceinline__ void schur_eliminate_kernel_body(PgoDev D, SchurDev S
             L.E[lane] = xch[1][lane];                                   // C_R
         }
         if (vec) L.g[lane] = D.b[(size_t)v * 6 + lane] + (xch[0][72 + lane] + xch[1][72 + lane]);
-        __syncthreads();                                               // (one wave left in the workgroup: orders its LDS traffic)
+        wave_sync();                                               // (one wave left in the workgroup: orders its LDS traffic)
         schur_inverse6_coop(L, true, act, lane, r, c);
-        __syncthreads();
+        wave_sync();
         double wl = 0., wr = 0., uval = 0.;
         if (act) {
             if (hasL) wl = mm6<false, true>(L.Di, L.C, r, c);           // W^L = Dinv C_L^T
@@ -434,7 +443,7 @@ __device__ __forceinline__ void schur_eliminate_kernel_body(PgoDev D, SchurDev S
         double* __restrict__ out = S.elim + (size_t)(p0 + j) * kSchurElim;
         if (vec) out[lane] = uval;
         if (act) { out[6 + lane] = wl; out[42 + lane] = wr; }
-        __syncthreads();
+        wave_sync();
         double* __restrict__ ro = S.runout + (size_t)run * kSchurRunOut;
         if (act) {
             ro[lane] = hasL ? xch[0][78 + lane] - mm6<false, false>(L.C, L.W, r, c) : 0.;                 // S_L
