@@ -538,14 +538,14 @@ __device__ __forceinline__ void schur_backsub_kernel_body(PgoDev D, PgoDev R, Sc
             if (vec) un = en[lane];
         }
         if (on && act) sp[wv][lane] = fma(w, sxs[wv][c], t * sxn[wv][c]);
-        __syncthreads();
+        wave_sync();                                          // (sp, sxn, sxs of a half are its wave's own)
         if (on && vec) {
             const double* __restrict__ q = sp[wv] + lane * 6;
             const double x = u - (((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]));
             D.x[(size_t)S.run_rows[p0 + (wv == 0 ? j - 1 - it : j + 1 + it)] * 6 + lane] = x;
             sxn[wv][lane] = x;
         }
-        __syncthreads();
+        wave_sync();
         w = wn; t = tn; u = un;
     }
 }
