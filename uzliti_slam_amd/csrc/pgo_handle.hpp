@@ -226,7 +226,7 @@ constexpr int kSchurStrongOneMax = 256;                // strong aggregates: up 
 constexpr int kSchurStrongMin = 32;                   // separators from which on the reduced system is numbered by strong aggregates
 extern const int kUpperNs;                            // Newton-Schulz steps of the dense levels above the composite level
 extern const bool kAlwaysRefresh;                     // A/B switches (diagnostic build)
-extern const double kRefreshRel, kLambdaRetake;
+extern const double kRefreshRel, kRefreshRelSync, kLambdaRetake;
 extern const int kGraphPairs;                         // one long PCG replay = 2 x kGraphPairs iterations
 constexpr int kShortPairs = 2;                        // ... a short one 2 x kShortPairs
 }  // namespace uzl
