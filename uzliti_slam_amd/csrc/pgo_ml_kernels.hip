@@ -2716,7 +2716,13 @@ static void kl_ml_spmv_t(SLOT sl, const LmShape& sh, int parity, hipStream_t s, 
     else if (sh.batch_geometry) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, kSpmvBatchRpw, kSpmvBatchWaves, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvBatchWaves), 0, s, sl, parity);
     else if (sh.agg == 1) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, 1, 8, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(512), 0, s, sl, parity);
     else {
-        static const int rpw = diag_int("UZL_SPMV4_RPW", 4);                // A/B switch: rows per wave of the AGG = 4 geometry (16 rows per workgroup)
+        // rows per wave of the AGG = 4 geometry (16 rows per workgroup; the same bits either way).  Up to two such workgroups per CU the
+        // kernel is a latency chain per row and twice the lanes per row shorten it (5k / 25k 23.4 -> 21.8 ms, 6k / 30k 25.5 -> 23.8, 8k / 24k
+        // 35.8 -> 34.2); beyond, four rows per wave keep three workgroups on a CU (10k / 50k: 626 workgroups in one round; 47.0 -> 49.2 ms
+        // at two rows per wave).  tests/diag/knob_sweep.sh; UZL_SPMV4_RPW (diagnostic build) fixes it
+        static const int rpw_env = diag_int("UZL_SPMV4_RPW", 0);
+        static const int two_per_cu = [] { int dev = 0, cu = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); return 2 * cu; }();
+        const int rpw = rpw_env ? rpw_env : (sh.g_spmv <= two_per_cu ? 2 : 4);
         if (rpw == 2) hipLaunchKernelGGL((ml_spmv_lm_kernel<4, 2, 8, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(512), 0, s, sl, parity);
         else if (rpw == 1) hipLaunchKernelGGL((ml_spmv_lm_kernel<4, 1, 16, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(1024), 0, s, sl, parity);
         else hipLaunchKernelGGL((ml_spmv_lm_kernel<4, 4, kSpmvWaves4, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvWaves4), 0, s, sl, parity);
