@@ -1,12 +1,12 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5
-python3 -m pytest tests -m gpu -x -q > gpurun_out/r5/gputest_o.log 2>&1 || { tail -40 gpurun_out/r5/gputest_o.log; exit 1; }
-tail -2 gpurun_out/r5/gputest_o.log
-python3 bench.py --steps 20 --warmup 5 > gpurun_out/r5/bench_o.json 2> gpurun_out/r5/bench_o.err || { tail -20 gpurun_out/r5/bench_o.err; exit 1; }
-wc -c gpurun_out/r5/bench_o.json
+python3 -m pytest tests -m gpu -x -q > gpurun_out/r5/gputest_p.log 2>&1 || { tail -40 gpurun_out/r5/gputest_p.log; exit 1; }
+tail -2 gpurun_out/r5/gputest_p.log
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/r5/bench_p.json 2> gpurun_out/r5/bench_p.err || { tail -20 gpurun_out/r5/bench_p.err; exit 1; }
+wc -c gpurun_out/r5/bench_p.json
 python3 - <<'PY'
 import json
-c=json.loads(open('gpurun_out/r5/bench_o.json').read().strip().splitlines()[-1])
+c=json.loads(open('gpurun_out/r5/bench_p.json').read().strip().splitlines()[-1])
 print('C2', c['value'], c['ms_per_step'], 'first', c['first_solve_ms'], 'repeat', c['repeat_identical'], 'lm_overhead', c['lm_overhead_ms'], c['roofline'])
 print('rooflines', c['rooflines'])
 print('C4', {k:v for k,v in c['c4_1gpu'].items() if k not in ('roofline',)})
