@@ -3,6 +3,7 @@ mkdir -p gpurun_out/r5
 python3 -m pytest tests -m gpu -x -q > gpurun_out/r5/gputest_p.log 2>&1 || { tail -40 gpurun_out/r5/gputest_p.log; exit 1; }
 tail -2 gpurun_out/r5/gputest_p.log
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/r5/bench_p.json 2> gpurun_out/r5/bench_p.err || { tail -20 gpurun_out/r5/bench_p.err; exit 1; }
+cp gpurun_out/bench_full.json gpurun_out/r5/bench_p_full.json      # (a later bench.py run - profiles/collect.sh - overwrites gpurun_out/bench_full.json)
 wc -c gpurun_out/r5/bench_p.json
 python3 - <<'PY'
 import json
