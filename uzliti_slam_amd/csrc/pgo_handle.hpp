@@ -208,6 +208,7 @@ int32_t gauge_fix(uzl_pgo* h);                        // G2: setFixedNodes (g2o_
 void build_structure(uzl_pgo* h);                     // block-CSR, Schur plan, hierarchy; bumps structure_gen
 void destroy_pcg_graph(uzl_pgo* h);
 bool ml_async_level(const uzl_pgo* h);
+double ml_rate_drop(const uzl_pgo* h);
 void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void prepare_optimize(uzl_pgo* h);                    // optimizeImpl's front part: gauge + structure (cached), t_start

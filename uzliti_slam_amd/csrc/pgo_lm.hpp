@@ -64,10 +64,11 @@ UZL_HD double lm_pcg_rate(double rz_stop, double rz_end, int its, double tol2, d
 }
 
 // does this linearisation rebuild the multilevel preconditioner?  (lazy refresh)
-UZL_HD bool lm_refresh(int it, int iterations, bool always_refresh, bool may_run_last, double last_rel, double refresh_rel, double rate_ref, double rate_last)
+UZL_HD bool lm_refresh(int it, int iterations, bool always_refresh, bool may_run_last, double last_rel, double refresh_rel, double rate_ref, double rate_last,
+                       double rate_drop = kRateDrop)
 {
 #pragma clang fp contract(off)
-    return it == 0 || ((always_refresh || last_rel > refresh_rel || (rate_ref > 0. && rate_last > 0. && rate_last < kRateDrop * rate_ref)) &&
+    return it == 0 || ((always_refresh || last_rel > refresh_rel || (rate_ref > 0. && rate_last > 0. && rate_last < rate_drop * rate_ref)) &&
                        (may_run_last || it + 1 < iterations));
 }
 

@@ -33,7 +33,7 @@ __device__ __forceinline__ void lm_head_decide(const LmSlot& S, LmDev* lm, int p
         }
         lm->adopted = 0;
         if (lm->pending) { lm->ix ^= 1; lm->pending = 0; lm->adopted = 1; }      // the copy built during the last iteration
-        if (lm_refresh(lm->it, lm->iterations, lm->always_refresh != 0, lm->sync_rebuild != 0, lm->last_rel, lm->refresh_rel, lm->rate_ref, lm->rate_last)) {
+        if (lm_refresh(lm->it, lm->iterations, lm->always_refresh != 0, lm->sync_rebuild != 0, lm->last_rel, lm->refresh_rel, lm->rate_ref, lm->rate_last, lm->rate_drop)) {
             lm->st_precond_builds++;
             need |= (lm->it == 0 || lm->sync_rebuild) ? (kNeedNumeric | kNeedTrial) : kNeedRebuild;
         }

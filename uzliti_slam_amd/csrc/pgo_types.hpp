@@ -202,6 +202,7 @@ struct LmDev {
     double rate_ref, rate_last;
     double chi2_initial, tol_f2, eps_t, eps_r, refresh_rel, tol2, lambda_retake, delta;
     double scal2[8];           // [3]: lambda of a rebuild that runs ahead of the trial loop (the set-up kernels read scal[3])
+    double rate_drop;          // share of its fresh PCG rate below which the hierarchy is rebuilt (lm_refresh)
 };
 // what the host sees after a pass: an image of the LM state and of PgoDev::scal[0..8), written by lm_tail_kernel into pinned coherent
 // memory (one 8-byte word per lane); seq_begin with the fields, seq (= LmDev::tails) behind a fence: a host copy is whole when both agree around it

@@ -58,6 +58,10 @@ const double kRefreshRel = diag_double("UZL_ML_REFRESH_REL", 1e-3);
 // ... and where the rebuild is synchronous (large loopy graphs: its GEMMs are 1.4 ms at 10k / 50k, 7 ms at 20k / 100k, in front of the
 // solve): the chi2 rule only while the problem still changes wholesale, the PCG-rate rule (kRateDrop, pgo_lm.hpp) from then on
 const double kRefreshRelSync = diag_double("UZL_ML_REFRESH_REL_SYNC", 3e-2);
+// ... and its rate rule: with the dense operator of that class a rebuild pays as soon as the rate has fallen to 0.75 of the fresh one
+// (0.6 elsewhere; tests/diag/r5_ratedrop.sh: -3 ... -8 % on eight of nine such shapes, the 30k / 150k graph - no dense operator - +14 %)
+const double kRateDropSyncDense = diag_double("UZL_ML_RATE_DROP_SYNC", 0.75);
+double ml_rate_drop(const uzl_pgo* h) { return (!ml_async_level(h) && h->ml_comp) ? kRateDropSyncDense : kRateDrop; }
 const double kLambdaRetake = diag_double("UZL_LAMBDA_RETAKE", 32.);         // lambda grown by this factor since the inverses were taken: take them again
 const int kGraphPairs = std::max(1, diag_int("UZL_GRAPH_PAIRS", 8));        // one graph replay = 2 x pairs PCG iterations
 int pgo_fail(uzl_pgo* h, int code, const char* msg)
@@ -1133,7 +1137,7 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         // previous iteration is as good as a fresh one (geometry + Galerkin + inverses are ~170 us per rebuild).
         // A rebuild is also forced when the iteration count has grown by a third since the last one.
         // (an asynchronous rebuild is for the NEXT iteration: none in the last one)
-        const bool refresh = lm_refresh(it, iterations, always_refresh, !async_ok, last_rel, ml_async_level(h) ? refresh_rel : kRefreshRelSync, rate_ref, rate_last);
+        const bool refresh = lm_refresh(it, iterations, always_refresh, !async_ok, last_rel, ml_async_level(h) ? refresh_rel : kRefreshRelSync, rate_ref, rate_last, ml_rate_drop(h));
         bool launch_async = false;
         bool fetched = false;
         if (red) {                                      // the hierarchy is built on the reduced system, which needs lambda: lambda_0 first

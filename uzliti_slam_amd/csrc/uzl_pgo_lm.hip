@@ -204,7 +204,7 @@ LmDev initial_state(const uzl_pgo* h, int iterations)
     I.guarded = (h->ml_mult || h->ml_ns_steps > 0) ? 1 : 0;
     I.ni = 2.; I.last_rel = 1e300; I.rate_ref = -1.; I.rate_last = -1.;
     I.tol_f2 = pgo_tol_f2(h->cfg); I.eps_t = pgo_eps_t(h->cfg); I.eps_r = pgo_eps_r(h->cfg);
-    I.refresh_rel = ml_async_level(h) ? kRefreshRel : kRefreshRelSync; I.tol2 = h->cfg.pcg_tol * h->cfg.pcg_tol; I.lambda_retake = kLambdaRetake; I.delta = h->cfg.huber_delta;
+    I.refresh_rel = ml_async_level(h) ? kRefreshRel : kRefreshRelSync; I.rate_drop = ml_rate_drop(h); I.tol2 = h->cfg.pcg_tol * h->cfg.pcg_tol; I.lambda_retake = kLambdaRetake; I.delta = h->cfg.huber_delta;
     return I;
 }
 LmDev idle_state()
@@ -362,7 +362,7 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
                 any_start = true; solve_passes[sl] = 0;
                 if (v.phase == kLmNeedSetup) pf |= ((v.need & (kNeedNumeric | kNeedTrial)) ? kPassSetup : 0) | ((v.need & kNeedRebuild) ? kPassRebuild : 0);
                 else if (v.phase == kLmLin) {
-                    if (lm_refresh(v.it, v.iterations, kAlwaysRefresh, v.sync_rebuild != 0, v.last_rel, v.refresh_rel, v.rate_ref, v.rate_last))
+                    if (lm_refresh(v.it, v.iterations, kAlwaysRefresh, v.sync_rebuild != 0, v.last_rel, v.refresh_rel, v.rate_ref, v.rate_last, v.rate_drop))
                         pf |= (v.it == 0 || v.sync_rebuild) ? kPassSetup : kPassRebuild;
                     if (v.it > 0 && v.lambda > kLambdaRetake * v.lambda_setup[v.ix ^ (v.pending ? 1 : 0)]) pf |= kPassSetup;
                 } else if (v.phase == kLmRetry) {
