@@ -219,6 +219,26 @@ def test_large_graph_path_with_dense_level2_operator_matches_oracle(capi, oracle
     assert st["pcg_iterations"] < 6 * 150
 
 
+def test_dense_level2_operator_beyond_20k_vertices(capi):
+    """30k vertices (6 n_2 = 5628: the dense level-2 operator's range since round 5, a 253-MB matrix): the CPU checker's direct solve of
+    this size takes minutes, so the reference here is the SAME problem under the block-Jacobi preconditioner - another solver for the same
+    linear systems - within the bar after the same LM iterations; and the operator must be what makes the solve short."""
+    g = synth.make_pose_graph(30000, 150000, seed=8)
+    res = {}
+    for pre in (1, 0):
+        p = capi.Pgo(preconditioner=pre)
+        p.add_graph(g["nodes_pose"], g["nodes_fixed"], g["edges"])
+        st = p.optimize(5)
+        res[pre] = (p.store()[0].reshape(-1, 3, 4), st)
+        p.close()
+        assert st["status"] == 0 and st["pcg_not_converged"] == 0
+    dt, dr = synth.pose_errors(res[1][0], res[0][0])
+    assert dt < TOL_T and dr < TOL_R, (dt, dr)
+    assert res[1][1]["lm_trials"] == res[0][1]["lm_trials"]
+    assert abs(res[1][1]["chi2_final"] - res[0][1]["chi2_final"]) <= 1e-6 * res[0][1]["chi2_final"]
+    assert res[1][1]["pcg_iterations"] * 8 < res[0][1]["pcg_iterations"]
+
+
 def test_degenerate_inputs(capi, pgo):
     pgo.set_config(optimize_xy_only=0)
     g = synth.make_pose_graph(20, 40, seed=8)
