@@ -112,6 +112,7 @@ struct uzl_pgo {
     DevBuf<int32_t> d_slot_edge, d_rb_ptr;
     DevBuf<double> d_srec;                     // slot records (pgo_kernels.hip: slot_records_kernel): values of the edges in the order of the structure's slots
     DevBuf<int4> d_smeta;
+    int ml_ns_now = -1;                        // Newton-Schulz steps of the set-up in progress (-1: ml_ns_steps; host-driven loop)
     bool srec_stale = true;                    // edges' values or the structure changed since d_srec was written
     DevBuf<double> d_zinv, d_info, d_blk, d_hdiag, d_minv, d_b, d_x, d_xs, d_r, d_z, d_p, d_p2, d_ap;
     DevBuf<double> d_part_a, d_part_b, d_part_c, d_scal, d_err, d_out12, d_stage;
@@ -209,6 +210,7 @@ void build_structure(uzl_pgo* h);                     // block-CSR, Schur plan, 
 void destroy_pcg_graph(uzl_pgo* h);
 bool ml_async_level(const uzl_pgo* h);
 double ml_rate_drop(const uzl_pgo* h);
+int ml_ns_steps_at(int structure_steps, int lm_iteration);
 void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void prepare_optimize(uzl_pgo* h);                    // optimizeImpl's front part: gauge + structure (cached), t_start

@@ -61,6 +61,14 @@ const double kRefreshRelSync = diag_double("UZL_ML_REFRESH_REL_SYNC", 3e-2);
 // ... and its rate rule: with the dense operator of that class a rebuild pays as soon as the rate has fallen to 0.75 of the fresh one
 // (0.6 elsewhere; tests/diag/r5_ratedrop.sh: -3 ... -8 % on eight of nine such shapes, the 30k / 150k graph - no dense operator - +14 %)
 const double kRateDropSyncDense = diag_double("UZL_ML_RATE_DROP_SYNC", 0.75);
+// Newton-Schulz steps of a synchronous set-up at LM iteration `it` for a structure that asks for `structure_steps` (4 on large loopy
+// graphs): 2 in the first kNsEarlyIts iterations (tests/diag/knob_sweep.sh "UZL_ML_NS_EARLY_ITS=0" against the default: -3.4 % over fourteen
+// large shapes at the same PCG iteration count; 4 iterations instead of 2 gain on the largest and lose at 10k, 8 lose everywhere)
+int ml_ns_steps_at(int structure_steps, int it)
+{
+    static const int early_its = diag_int("UZL_ML_NS_EARLY_ITS", 2);
+    return (structure_steps > 2 && it < early_its) ? 2 : structure_steps;
+}
 double ml_rate_drop(const uzl_pgo* h) { return (!ml_async_level(h) && h->ml_comp) ? kRateDropSyncDense : kRateDrop; }
 const double kLambdaRetake = diag_double("UZL_LAMBDA_RETAKE", 32.);         // lambda grown by this factor since the inverses were taken: take them again
 const int kGraphPairs = std::max(1, diag_int("UZL_GRAPH_PAIRS", 8));        // one graph replay = 2 x pairs PCG iterations
@@ -601,10 +609,11 @@ void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool tim
         k_ml_mult_level(D, B.dml, cl, h->ml_n[cl], h->ml_n[cl + 1], s);
         if (timed) h->timer.end(s);
         double* xa = B.y1; double* xb = B.nsX;
-        for (int k = 0; k < h->ml_ns_steps; k++) {
+        const int ns_now = h->ml_ns_now >= 0 ? h->ml_ns_now : h->ml_ns_steps;    // (the same parity as ml_ns_steps: the result lands in the same buffer)
+        for (int k = 0; k < ns_now; k++) {
             hipEvent_t ea = nullptr, eb = nullptr;
             if (timed) h->timer.pair("ml_ns_gemm", &ea, &eb);                  // the f64 matrix-core GEMM of the refinement, on its own
-            const bool last = k == h->ml_ns_steps - 1;                         // its epilogue also writes the f32 copy the PCG kernels read
+            const bool last = k == ns_now - 1;                                 // its epilogue also writes the f32 copy the PCG kernels read
             k_ml_ns_step(D, B.dml, cl, h->ml_n[cl], xa, B.nsT, xb, s, ea, eb, last ? const_cast<float*>(B.hot.Cmat32) : nullptr, B.hot.c32_stride);
             std::swap(xa, xb);
         }
@@ -1163,6 +1172,7 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             k_set_scalar(D.scal + 3, lambda, s);
             schur_reduce();
         }
+        h->ml_ns_now = ml_ns_steps_at(h->ml_ns_steps, it);       // synchronous set-ups of this iteration (the device-resident loop: lm_drive)
         if (refresh) {
             S.precond_builds++;
             if (it == 0 || !async_ok) { ml_setup_numeric(h, h->ml_ix, s, Dp, true); h->ml_trial_setup = true; }
@@ -1185,7 +1195,7 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
             D2.scal = h->d_scal2.p;                                               // the trial loop below moves scal[3] on the main stream
             k_set_scalar(D2.scal + 3, lambda, h->stream2);
             ml_setup_numeric(h, nb_ix, h->stream2, D2, false);
-            ml_setup_trial(h, nb_ix, h->stream2, D2, false);
+            { const int keep = h->ml_ns_now; h->ml_ns_now = -1; ml_setup_trial(h, nb_ix, h->stream2, D2, false); h->ml_ns_now = keep; }      // (a rebuild that runs ahead: the structure's steps)
             h->mlb[nb_ix].lambda_setup = lambda;
             UZL_HIP(hipEventRecord(h->ev_setup, h->stream2));
             h->ml_pending = true;
@@ -1262,6 +1272,7 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         S.iterations_done = it + 1;
         if (qmax == 10 || rho == 0) { S.terminated_early = 1; break; }           // Terminate
     }
+    h->ml_ns_now = -1;
     S.chi2_final = current_chi;
     S.lambda_final = lambda;
     if (h->ml_pending) { UZL_HIP(hipStreamSynchronize(h->stream2)); h->ml_pending = false; }   // a rebuild nobody will use: let it drain

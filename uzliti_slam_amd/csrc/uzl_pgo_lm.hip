@@ -405,7 +405,14 @@ int lm_drive(LmRun* R, std::vector<LmJob>& jobs, const LmDriveOpts& o)
         if (any_start) enq_head(R, pf, lin_ahead, s);
         lin_ahead = false;
         mark(2);
-        if (pf & kPassSetup) run_seg(R->setup, eager, s, [&](hipStream_t q) { enq_setup(R, 1, q); });
+        if (pf & kPassSetup) {
+            // The synchronous set-ups of the first kNsEarlyIts linearisations refine the dense operator with two Newton-Schulz steps where the
+            // structure asks for four (large loopy graphs): the problem still changes wholesale there and a rougher operator costs no PCG
+            // iterations (ml_ns_steps_at, uzl_pgo.hip).  Launched as they are - the captured segment holds the full sequence.
+            const int steps = nS == 1 ? ml_ns_steps_at(R->shape.ns_steps, snap[0].lm.it) : R->shape.ns_steps;
+            if (steps != R->shape.ns_steps) { const int keep = R->shape.ns_steps; R->shape.ns_steps = steps; enq_setup(R, 1, s); R->shape.ns_steps = keep; }
+            else run_seg(R->setup, eager, s, [&](hipStream_t q) { enq_setup(R, 1, q); });
+        }
         if (pf & kPassRebuild) {
             UZL_HIP(hipEventRecord(R->ev_fork, s));
             UZL_HIP(hipStreamWaitEvent(o.s2, R->ev_fork, 0));
