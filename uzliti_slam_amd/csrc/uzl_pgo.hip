@@ -63,11 +63,13 @@ const double kRefreshRelSync = diag_double("UZL_ML_REFRESH_REL_SYNC", 3e-2);
 const double kRateDropSyncDense = diag_double("UZL_ML_RATE_DROP_SYNC", 0.75);
 // Newton-Schulz steps of a synchronous set-up at LM iteration `it` for a structure that asks for `structure_steps` (4 on large loopy
 // graphs): 2 in the first kNsEarlyIts iterations (tests/diag/knob_sweep.sh "UZL_ML_NS_EARLY_ITS=0" against the default: -3.4 % over fourteen
-// large shapes at the same PCG iteration count; 4 iterations instead of 2 gain on the largest and lose at 10k, 8 lose everywhere)
+// large shapes at the same PCG iteration count; 4 iterations instead of 2 gain on the largest and lose at 10k, 8 lose everywhere; NO step at
+// all in those two - the cycle's operator as it comes, UZL_ML_NS_EARLY_STEPS=0 - another -2.5 %, not taken: that operator is what the
+// residual guard exists for)
 int ml_ns_steps_at(int structure_steps, int it)
 {
-    static const int early_its = diag_int("UZL_ML_NS_EARLY_ITS", 2);
-    return (structure_steps > 2 && it < early_its) ? 2 : structure_steps;
+    static const int early_its = diag_int("UZL_ML_NS_EARLY_ITS", 2), early_steps = diag_int("UZL_ML_NS_EARLY_STEPS", 2);
+    return (structure_steps > 2 && it < early_its) ? early_steps : structure_steps;
 }
 double ml_rate_drop(const uzl_pgo* h) { return (!ml_async_level(h) && h->ml_comp) ? kRateDropSyncDense : kRateDrop; }
 const double kLambdaRetake = diag_double("UZL_LAMBDA_RETAKE", 32.);         // lambda grown by this factor since the inverses were taken: take them again
