@@ -1235,7 +1235,7 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
                     UZL_HIP(hipStreamSynchronize(h->stream2));                    // multiplicative operator: drop it and rebuild
                     h->ml_pending = false; last_rel = 1e300;                      // synchronously at the next linearisation
                 }
-                h->ml_mult = false; h->ml_ns_steps = 0; h->mult_banned = true;
+                h->ml_mult = false; h->ml_ns_steps = 0; h->ml_ns_now = -1; h->mult_banned = true;      // (the additive operator takes no refinement steps)
                 for (auto& B : h->mlb) B.hot.Cmat = B.y1;
                 destroy_pcg_graph(h);                                             // MlHot is a by-value kernel argument
                 h->structure_gen++;                                               // (slot tables that carry it are rebuilt: uzl_pgo_lm.hip, batches)
