@@ -14,7 +14,7 @@
 
 namespace uzl {
 
-constexpr int kMaxPartials = 4096;
+constexpr int kMaxPartials = 8192;        // block partials of a reduction = workgroups of a launch that leaves some (4096 until round 5: ml_spmv's 16-row workgroups ended at 65k vertices)
 constexpr int kProgressEvery = 2;    // PCG iterations between two looks of the stop test (see pgo_device.hpp, progress_decide)
 constexpr int kRowHdr = 24;          // ints per row header (96 B: one and a half cache lines)
 

@@ -281,12 +281,13 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     static const bool comp_off = diag_flag("UZL_ML_NO_COMP");                // A/B switch
     // large graphs (AGG = 4, gather level 2): the same construction one level up - the hierarchy above level 2 as one dense
     // operator that ml_cg_kernel<4> applies instead of its LDS walk (measured 733 -> 332 ms at 20k / 100k, the rebuild's
-    // Newton-Schulz GEMMs take 7 ms there).  6 n_2 <= 16384 - the cap was 4096 (21.8k vertices)
+    // Newton-Schulz GEMMs take 7 ms there).  6 n_2 <= 18432 - the cap was 4096 (21.8k vertices)
     // until round 5, and a 30k / 150k graph took 2.39 s (11.9 k PCG iterations on the walked hierarchy) where it takes 0.32 s with the
     // operator (1.8 k), 40k / 200k 5.13 -> 0.62 s, 50k / 250k 10.9 -> 1.56 s (tests/diag/big_graphs.py; at n = 7500 a GEMM is 10 ms, half of
-    // that solve).  The cap is above what kMaxPartials ml_spmv workgroups admit (65k vertices: 6 n_2 = 12288, 1.2 GB per matrix)
+    // that solve), 64k / 320k ~11 -> 2.3 s, 90k / 450k 29.3 -> 6.3 s.  The path ends where ml_cg's gather-level vector no longer fits the LDS
+    // (95k vertices: 6 n_2 = 17.9k, 2.6 GB per matrix, a GEMM 136 ms); kMaxPartials ml_spmv workgroups admit 131k
     static const bool comp4_off = diag_flag("UZL_ML_NO_COMP4");             // A/B switch
-    static const int comp4_max = diag_int("UZL_ML_COMP4_MAX", 16384);
+    static const int comp4_max = diag_int("UZL_ML_COMP4_MAX", 18432);
     static const int top_wide = diag_int("UZL_ML_TOP_WIDE", kMlTopWide);    // A/B switch (8 = the round-3 hierarchy)
     // A level above the composite one may be the top with up to kMlTopWide aggregates: config 2 (1000 vertices: 125 / 16 / 2) loses its
     // 2-aggregate level and with it ten launches per rebuild (the cycle around it and four Newton-Schulz steps of the 96-row level)
@@ -301,7 +302,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
         L++;
     }
     // the PCG kernels' LDS: with the dense level-2 operator ml_cg stages nothing but the gather-level vector (ml_cg_variant); the walked
-    // hierarchy needs every level above the gather level.  Beyond either limit (and beyond kMaxPartials ml_spmv workgroups = 65k
+    // hierarchy needs every level above the gather level.  Beyond either limit (and beyond kMaxPartials ml_spmv workgroups = 131k
     // vertices): block-Jacobi
     const bool comp4_here = !comp_off && !comp4_off && h->ml_agg == 4 && L >= 3 && 6 * h->ml_n[2] <= comp4_max;
     const bool fits = comp4_here ? ((size_t)6 * h->ml_n[2] * 8 + 64 <= (size_t)140 * 1024 && g_ml_spmv(nb, 4) <= kMaxPartials) : ml_fits_lds(h->ml_n.data(), L, h->ml_agg);
