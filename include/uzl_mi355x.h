@@ -253,7 +253,10 @@ typedef struct uzl_pgo_cfg {
                                          (occupies what used to be padding: layout unchanged)           */
     double  huber_delta;              /* 1.0  (g2o_optimizer.cpp:293)                                 */
     int32_t verbose;
-    int32_t preconditioner;           /* 1 = additive multilevel (8-vertex aggregates, rigid-body modes), 0 = block-Jacobi */
+    int32_t preconditioner;           /* 1 = additive multilevel (8-vertex aggregates, rigid-body modes), 0 = block-Jacobi.  The multilevel
+                                         hierarchy serves systems of up to ~95 000 free vertices (after the elimination of chain interiors:
+                                         a 400 000-node chain-like graph reduces far below that); larger ones are solved with block-Jacobi
+                                         whatever this says - correct, but an order of magnitude slower on loopy graphs */
     int32_t pcg_stop;                 /* 0 = step-error estimate (above), 1 = relative residual test only                  */
     int32_t lm_loop;                  /* 0 = Levenberg-Marquardt decisions on the device, one host look per trial (captured passes);
                                          1 = host-driven loop (the one sharded and profiled solves always take); same results */
