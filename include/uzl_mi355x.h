@@ -764,6 +764,35 @@ uint64_t uzl_wire_node_size(const uzl_wire_node* n, const uzl_span* edge_ids, co
 int  uzl_wire_node_encode(const uzl_wire_node* n, const int64_t* stamps_ns, const uzl_span* edge_ids,
                           const uzl_wire_sensor* sensors, uint8_t* buf, uint64_t cap, uint64_t* written);
 
+/* graph_slam_msgs/GraphMeta <-> the graph's meta data: SlamGraph::toMetaData / updateMetaData
+ * (graph_slam_common/src/slam_graph.cpp:592-633), written by RosbagStorage::storeMetaData
+ * (graph_slam_common/src/rosbag_storage.cpp:94-107, file <path>/meta/meta, topic "meta") and read back by loadGraph (:187-207).
+ * Field order of GraphMeta.msg: header, name, map_transform, sensor_transforms[], sensor_transforms_initial[],
+ * odometry_parameters[6]; a SensorTransform is (string sensor_name, geometry_msgs/Pose transform).  The sensor
+ * transforms and odometry parameters are exactly what G2oOptimizer::addGraphImpl takes from the graph
+ * (graph_optimization/src/g2o_optimizer.cpp:209-227,281), i.e. uzl_pgo_add_graph's sensor table. */
+typedef struct uzl_wire_sensor_transform {
+    uzl_span sensor_name;
+    double   transform[12];
+} uzl_wire_sensor_transform;
+typedef struct uzl_wire_meta {
+    uint32_t stamp_sec, stamp_nsec;       /* header.stamp (header.seq is written 0, ignored on decode)  */
+    uzl_span frame_id;                    /* header.frame_id = SlamGraph::frame_                        */
+    uzl_span name;                        /* SlamGraph::name_                                           */
+    double   map_transform[12];           /* /map -> /base_footprint at store time; sub_transform_ on load */
+    int32_t  n_sensor_transforms, n_sensor_transforms_initial;
+    double   odometry_parameters[6];
+} uzl_wire_meta;
+uint64_t uzl_wire_meta_size(const uzl_wire_meta* m, const uzl_wire_sensor_transform* sensor_transforms,
+                            const uzl_wire_sensor_transform* sensor_transforms_initial);
+int  uzl_wire_meta_encode(const uzl_wire_meta* m, const uzl_wire_sensor_transform* sensor_transforms,
+                          const uzl_wire_sensor_transform* sensor_transforms_initial, uint8_t* buf, uint64_t cap,
+                          uint64_t* written);
+/* Counts are always reported in *out, entries beyond a capacity are parsed but not stored; spans point into buf. */
+int  uzl_wire_meta_decode(const uint8_t* buf, uint64_t len, uzl_wire_meta* out, int32_t cap,
+                          uzl_wire_sensor_transform* sensor_transforms, int32_t cap_initial,
+                          uzl_wire_sensor_transform* sensor_transforms_initial, uint64_t* consumed);
+
 /* bytes of n Feature records with desc_len descriptor elements each */
 uint64_t uzl_wire_features_size(int32_t n, int32_t desc_len);
 

@@ -6,7 +6,7 @@ An independent struct / numpy restatement of
   Conversions::toMsg / fromMsg               graph_slam_common/src/conversions.cpp:43-70, 217-322
   SensorData / FeatureData::toMsg / fromMsg  graph_slam_common/src/sensor_data.cpp:40-167
   RosbagStorage::storeNode / storeEdge / loadGraph   graph_slam_common/src/rosbag_storage.cpp:62-209
-for the message layouts of graph_slam_msgs/msg/{Edge,Node,SensorData,SensorDataArray,Features,Feature}.msg.
+for the message layouts of graph_slam_msgs/msg/{Edge,Node,SensorData,SensorDataArray,Features,Feature,GraphMeta,SensorTransform}.msg.
 ROS 1 serialisation: little-endian scalars, string = u32 length + bytes, T[] = u32 count + elements, T[N] = elements,
 time / duration = two 32-bit words, bool = one byte.
 """
@@ -129,6 +129,35 @@ def decode_edge(b):
     e["valid"] = int(r.get("<B") != 0)
     e["diff_time_sec"], e["diff_time_nsec"] = r.get("<ii")
     return e, r.o
+
+
+# ------------------------------------------------------------------------------------------------ GraphMeta
+def encode_meta(m):
+    """SlamGraph::toMetaData (graph_slam_common/src/slam_graph.cpp:592-619) serialised in GraphMeta.msg field order, as
+    RosbagStorage::storeMetaData writes it (rosbag_storage.cpp:94-107).  m: stamp_sec, stamp_nsec, frame_id, name,
+    map_transform (12), sensor_transforms / sensor_transforms_initial = [(name, 12 doubles)], odometry_parameters (6)."""
+    out = [_header(int(m["stamp_sec"]), int(m["stamp_nsec"]), m["frame_id"]), _str(m["name"]), _pose_bytes(m["map_transform"])]
+    for key in ("sensor_transforms", "sensor_transforms_initial"):
+        out.append(struct.pack("<I", len(m[key])))
+        for name, T in m[key]:
+            out += [_str(name), _pose_bytes(T)]
+    out.append(np.asarray(m["odometry_parameters"], "<f8").reshape(6).tobytes())      # conversions.cpp:338-343
+    return b"".join(out)
+
+
+def decode_meta(b):
+    """SlamGraph::updateMetaData (slam_graph.cpp:621-633) / loadGraph (rosbag_storage.cpp:187-207)."""
+    r = _R(b)
+    h = r.header()
+    m = dict(stamp_sec=h["sec"], stamp_nsec=h["nsec"], frame_id=h["frame_id"], name=r.str())
+    m["map_transform"] = r.pose()
+    for key in ("sensor_transforms", "sensor_transforms_initial"):
+        m[key] = []
+        for _ in range(r.get("<I")):
+            name = r.str()
+            m[key].append((name, r.pose()))
+    m["odometry_parameters"] = np.array(r.get("<6d"))
+    return m, r.o
 
 
 # ------------------------------------------------------------------------------------------------ Feature records

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostic: which of n freshly made streams stand in each other's way (uzl_debug_stream_pairs: two chains of 32 dependent ~4-us kernels
-on streams i and j at once against one chain on stream i, in percent)?  ~105 - 125: independent; ~200: one hardware queue; ~270: two
-queues on one compute pipe.   python tests/diag/stream_overlap.py [n] [priority | 200 = priorities 0 and -1 in turn]"""
+"""Diagnostic: which of n freshly made streams stand in each other's way (uzl_debug_stream_pairs: the stream pool's own decision, one
+measurement per unordered pair - two chains of 8 dependent 10-us kernels side by side against one chain alone, timed on the device,
+best of 3, in percent)?  ~100 - 112: independent; ~200: one hardware queue; ~240 - 280: two queues on one compute pipe.
+python tests/diag/stream_overlap.py [n] [priority | 200 = priorities 0 and -1 in turn] [repeats]"""
 import ctypes
 import os
 import sys
@@ -13,9 +14,19 @@ from uzliti_slam_amd import capi    # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 prio = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 lib = capi.diag_lib()
-out = np.zeros((n, n), np.int32)
-rc = lib.uzl_debug_stream_pairs(ctypes.c_int(n), ctypes.c_int(prio), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
-print("rc", rc, "priority", prio, "GPU_MAX_HW_QUEUES", os.environ.get("GPU_MAX_HW_QUEUES"))
-for i in range(n):
-    print(" ".join("    ." if v < 0 else "%5d" % v for v in out[i]))
+P32 = ctypes.POINTER(ctypes.c_int32)
+lo, hi = [], []
+for _ in range(reps):
+    v = np.zeros((n, n), np.int32)
+    r = np.zeros((n, n), np.int32)
+    ms = ctypes.c_double(0.)
+    rc = lib.uzl_debug_stream_pairs(ctypes.c_int(n), ctypes.c_int(prio), v.ctypes.data_as(P32), r.ctypes.data_as(P32), ctypes.byref(ms))
+    print("rc", rc, "priority", prio, "GPU_MAX_HW_QUEUES", os.environ.get("GPU_MAX_HW_QUEUES"), "probe_ms %.2f for %d pairs" % (ms.value, n * (n - 1) // 2))
+    for i in range(n):
+        print(" ".join("    ." if x < 0 else "%5d" % x for x in r[i]), "  |  ", " ".join("." if x < 0 else str(x) for x in v[i]))
+    off = ~np.eye(n, dtype=bool)
+    lo += list(r[off & (v == 1)]); hi += list(r[off & (v == 0)])
+print("independent pairs: %d, ratio %s .. %s; colliding pairs: %d, ratio %s .. %s" % (
+    len(lo) // 2, min(lo, default=None), max(lo, default=None), len(hi) // 2, min(hi, default=None), max(hi, default=None)))

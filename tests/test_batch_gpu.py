@@ -179,6 +179,40 @@ def test_one_launch_sequence_in_the_diagnostic_build():
     assert "0 misses" in out.stdout
 
 
+def test_anomaly_fallback_from_a_helper_thread_leaves_the_other_sequence_alone():
+    """A graph of the SECOND launch sequence (driven from a helper thread) that meets an anomaly is solved again by the host-driven loop
+    on streams of its own.  Every handle of a batch borrows sequence 0's streams, and sequence 0 may be capturing on them at that
+    moment: the fallback must not synchronize them (round 5's advisor finding).  UZL_BATCH_FORCE_ANOMALY_N (diagnostic build) sends the
+    one graph of 301 nodes down that path in the batch's FIRST optimize (the one that captures); all 16 graphs still equal their own
+    solves bit for bit, 15 of them batched."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    diag = os.path.join(root, "uzliti_slam_amd", "libuzl_mi355x_diag.so")
+    assert os.path.exists(diag), "build the diagnostic library: make -C uzliti_slam_amd/csrc diag"
+    code = (
+        "import numpy as np\n"
+        "from uzliti_slam_amd import capi, synth\n"
+        "gs = [synth.make_pose_graph(301 if k == 12 else 300, 1200, seed=900 + k) for k in range(16)]\n"
+        "bt = capi.PgoBatch(16)\n"
+        "for k, g in enumerate(gs): bt.graphs[k].add_graph(g['nodes_pose'], g['nodes_fixed'], g['edges'])\n"
+        "for rnd in range(2):\n"
+        "    for p in bt.graphs: p.reset()\n"
+        "    st = bt.optimize(8)\n"
+        "    assert bt.n_batched == 15, bt.n_batched\n"
+        "    for k, g in enumerate(gs):\n"
+        "        p = capi.Pgo(); p.add_graph(g['nodes_pose'], g['nodes_fixed'], g['edges']); s1 = p.optimize(8); ref = p.store()[0].copy(); p.close()\n"
+        "        assert np.array_equal(bt.graphs[k].store()[0], ref), (rnd, k)\n"
+        "        assert st[k]['lm_trials'] == s1['lm_trials'] and st[k]['chi2_final'] == s1['chi2_final'], (rnd, k)\n"
+        "bt.close()\n"
+        "print('fallback ok')\n")
+    e = dict(os.environ, UZL_LIB=diag, UZL_BATCH_FORCE_ANOMALY_N="301", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "fallback ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
 def test_a_batch_handle_solved_on_its_own_and_from_two_threads(capi):
     """The graphs of a batch run on the batch's streams (a handle of its own costs two hipStreamCreates).  A batch's handle is still an
     ordinary handle: solved directly through uzl_pgo_optimize it takes streams of its own at that moment - two such handles driven from

@@ -203,6 +203,75 @@ def test_bag_with_two_chunks_and_two_topics_reads_in_file_order():
     assert [(m["topic"], m["data"]) for m in OW.bag_read(img)] == [(m["topic"], m["data"]) for m in got]
 
 
+def _meta(rng, k=0, n0=3, n1=2):
+    return dict(stamp_sec=1400000000 + k, stamp_nsec=int(rng.integers(0, 10**9)), frame_id="/map", name=f"graph{k}",
+                map_transform=_rot(rng, big=k % 2 == 1),
+                sensor_transforms=[(f"/camera{j}_rgb_optical_frame" if j else "", _rot(rng, big=j == 1)) for j in range(n0)],
+                sensor_transforms_initial=[(f"/camera{j}_rgb_optical_frame", _rot(rng)) for j in range(n1)],
+                odometry_parameters=rng.normal(size=6))
+
+
+def test_graph_meta_encode_decode_match_the_oracle_bytewise():
+    """graph_slam_msgs/GraphMeta (SlamGraph::toMetaData / updateMetaData, slam_graph.cpp:592-633; RosbagStorage::storeMetaData,
+    rosbag_storage.cpp:94-107): the product's host-side codec against oracle/wire.py byte for byte, incl. empty arrays and names."""
+    rng = np.random.default_rng(21)
+    for k, (n0, n1) in enumerate([(3, 2), (0, 0), (1, 0), (0, 4), (7, 7)]):
+        m = _meta(rng, k, n0, n1)
+        b = W.encode_meta(m)
+        assert b == OW.encode_meta(m)
+        d, used = W.decode_meta(b + b"trailing")
+        o, used_o = OW.decode_meta(b)
+        assert used == used_o == len(b)
+        assert (d["stamp_sec"], d["stamp_nsec"], d["frame_id"], d["name"]) == (o["stamp_sec"], o["stamp_nsec"], o["frame_id"], o["name"])
+        assert np.array_equal(d["map_transform"], o["map_transform"]) and np.array_equal(d["odometry_parameters"], o["odometry_parameters"])
+        assert np.array_equal(d["odometry_parameters"], np.asarray(m["odometry_parameters"]))
+        for key in ("sensor_transforms", "sensor_transforms_initial"):
+            assert [x[0] for x in d[key]] == [x[0] for x in o[key]] == [x[0].encode() for x in m[key]]
+            for (_, Td), (_, To), (_, Tm) in zip(d[key], o[key], m[key]):
+                assert np.array_equal(Td, To) and np.abs(Td - Tm).max() < 1e-14
+        assert W.encode_meta(d) == OW.encode_meta(o)                     # decode -> encode is stable on both sides
+        for cut in sorted(set(rng.integers(0, len(b), size=12).tolist() + [0, len(b) - 1])):
+            with pytest.raises(Exception) as ei:
+                W.decode_meta(b[:cut])
+            assert getattr(ei.value, "code", W.UZL_ERR_TRUNCATED) == W.UZL_ERR_TRUNCATED
+    # an array count the message cannot hold is a truncation, not an allocation
+    m = _meta(rng, 0, 1, 0)
+    b = bytearray(OW.encode_meta(m))
+    off = 12 + 4 + len(b"/map") + 4 + len(b"graph0") + 56
+    assert struct.unpack_from("<I", b, off)[0] == 1
+    struct.pack_into("<I", b, off, 0xFFFFFFF0)
+    with pytest.raises(Exception):
+        W.decode_meta(bytes(b))
+
+
+def test_graph_meta_known_answer():
+    m = dict(stamp_sec=5, stamp_nsec=6, frame_id="/map", name="g", map_transform=np.eye(3, 4).reshape(12),
+             sensor_transforms=[("cam", np.array([-1, 0, 0, 1.0, 0, -1, 0, 2.0, 0, 0, 1, 3.0]))], sensor_transforms_initial=[],
+             odometry_parameters=np.arange(6.0))
+    b = W.encode_meta(m)
+    want = (struct.pack("<III", 0, 5, 6) + struct.pack("<I", 4) + b"/map" + struct.pack("<I", 1) + b"g" + struct.pack("<7d", 0, 0, 0, 0, 0, 0, 1) +
+            struct.pack("<I", 1) + struct.pack("<I", 3) + b"cam" + struct.pack("<7d", 1, 2, 3, 0, 0, 1, 0) + struct.pack("<I", 0) +
+            struct.pack("<6d", 0, 1, 2, 3, 4, 5))
+    assert b == want
+
+
+def test_storage_meta_round_trip(tmp_path):
+    """storeMetaData writes <path>/meta/meta with topic "meta"; loadGraph's meta pass reads it back (rosbag_storage.cpp:94-107,187-207)."""
+    rng = np.random.default_rng(22)
+    st = W.RosbagStorage(str(tmp_path / "graph"), clear_storage=True)
+    assert st.load_meta() is None
+    m = _meta(rng, 3)
+    st.store_meta(_meta(rng, 1), now_ns=5)
+    st.store_meta(m, now_ns=10**9)                                       # overwrites the file, as bag.open(Write) does
+    assert [p.name for p in (tmp_path / "graph" / "meta").iterdir()] == ["meta"]
+    img = (tmp_path / "graph" / "meta" / "meta").read_bytes()
+    got = OW.bag_read(img)
+    assert len(got) == 1 and got[0]["topic"] == b"meta" and got[0]["datatype"] == b"graph_slam_msgs/GraphMeta" and got[0]["data"] == OW.encode_meta(m)
+    d = W.RosbagStorage(str(tmp_path / "graph")).load_meta()
+    assert d["name"] == b"graph3" and np.array_equal(d["odometry_parameters"], m["odometry_parameters"])
+    assert [x[0] for x in d["sensor_transforms"]] == [x[0].encode() for x in m["sensor_transforms"]]
+
+
 def test_storage_directory_round_trip_on_the_host(tmp_path):
     """RosbagStorage layout (rosbag_storage.cpp:62-136, 211-235) without a device: nodes keep their Feature records as bytes."""
     rng = np.random.default_rng(6)

@@ -214,7 +214,7 @@ int ml_ns_steps_at(int structure_steps, int lm_iteration);
 void ml_setup_numeric(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void ml_setup_trial(uzl_pgo* h, int bi, hipStream_t s, const PgoDev& D, bool timed);
 void prepare_optimize(uzl_pgo* h);                    // optimizeImpl's front part: gauge + structure (cached), t_start
-void own_streams(uzl_pgo* h);               // a batch's handle takes streams of its own (uzl_pgo.hip)
+void own_streams(uzl_pgo* h, bool drain_borrowed);               // a batch's handle takes streams of its own (uzl_pgo.hip)
 int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);      // the host-driven loop (sharded / block-Jacobi / profiled solves, anomaly fallback)
 int do_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st);           // picks the loop
 // ---- the device-resident loop (uzl_pgo_lm.hip)

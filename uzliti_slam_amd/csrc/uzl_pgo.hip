@@ -1389,13 +1389,18 @@ static int pgo_create_on(const uzl_pgo_cfg* cfg, hipStream_t shared, hipStream_t
     return UZL_OK;
 }
 // a batch's handle that is solved on its own: from now on with its own streams (captures and rebuild events of two such handles driven
-// from two threads must not meet on one stream)
-void uzl::own_streams(uzl_pgo* h)
+// from two threads must not meet on one stream).  `drain_borrowed`: wait for the borrowed streams first - right for a handle that is
+// taken out of an idle batch (uzl_pgo_optimize), WRONG from inside a running batch: every handle of a batch borrows launch sequence 0's
+// streams, sequence 0 may be capturing on them on another thread (a synchronize fails with hipErrorStreamCaptureUnsupported and
+// invalidates that capture), and the handle has no work of its own on them - its sequence has synchronized the stream it ran on.
+void uzl::own_streams(uzl_pgo* h, bool drain_borrowed)
 {
     if (!h->streams_borrowed) return;
     UZL_HIP(hipSetDevice(h->cfg.device));
-    UZL_HIP(hipStreamSynchronize(h->stream));
-    if (h->stream2) UZL_HIP(hipStreamSynchronize(h->stream2));
+    if (drain_borrowed) {
+        UZL_HIP(hipStreamSynchronize(h->stream));
+        if (h->stream2) UZL_HIP(hipStreamSynchronize(h->stream2));
+    }
     hipStream_t a = stream_lease(h->cfg.device, 0, {}, false);
     hipStream_t b = a ? stream_lease(h->cfg.device, diag_int("UZL_S2_PRIO", -1), {a}, false) : nullptr;
     if (!a || !b) { stream_release(h->cfg.device, a); throw HipError{hipErrorUnknown, "stream_lease", __FILE__, __LINE__}; }
@@ -1610,7 +1615,7 @@ int uzl_pgo_reset(uzl_pgo* h)
 int uzl_pgo_optimize(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* stats)
 {
     UZL_GUARD_BEGIN(h)
-    own_streams(h);
+    own_streams(h, true);
     return do_optimize(h, iterations, stats);
     UZL_GUARD_END(h)
 }

@@ -617,12 +617,14 @@ int batch_optimize_lm(LmRun*& Rp, const std::vector<uzl_pgo*>& hs, int resident,
     for (int g = 0; g < Q; g++) {
         LmJob& J = jobs[g];
         uzl_pgo* h = hs[g];
-        if (!J.anomaly) { finish_job(J, stats ? stats + g : nullptr, wall); batched++; continue; }
+        // (diagnostic build: UZL_BATCH_FORCE_ANOMALY_N = n sends every graph of n nodes down the anomaly path - tests/test_batch_gpu.py)
+        static const int force_n = diag_int("UZL_BATCH_FORCE_ANOMALY_N", -1);
+        if (!J.anomaly && h->n != force_n) { finish_job(J, stats ? stats + g : nullptr, wall); batched++; continue; }
         if (verbose) fprintf(stderr, "[uzl_pgo_batch] graph %d: anomaly %d at it %d trial %d -> single-graph path\n", g, J.last.lm.anomaly_code, J.last.lm.it, J.last.lm.qmax);
         UZL_HIP(hipMemcpyAsync(h->pose_a.p, R->d_start.p + J.start_off, sizeof(double) * 8 * (size_t)h->n, hipMemcpyDeviceToDevice, s));
         UZL_HIP(hipStreamSynchronize(s));
         h->cur = h->pose_a.p; h->trial = h->pose_b.p;
-        own_streams(h);                                    // (another launch sequence of the batch may be capturing on the stream it borrowed)
+        own_streams(h, false);                             // (sequence 0 may be capturing on the streams h borrowed: not synchronized, h has nothing on them)
         h->t_start = std::chrono::steady_clock::now();
         uzl_pgo_stats S;
         const int rc = do_optimize_host(h, iterations, &S);

@@ -6,6 +6,7 @@
 // Only message headers, strings and fixed-size fields are handled here (host work: a few dozen fields per message);
 // the Feature[] payload is located and handed on as a byte span - the device unpacks / packs it (wire_kernels.hip).
 // Built with -ffp-contract=off: the pose <-> quaternion arithmetic rounds after every operation.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -482,6 +483,72 @@ int uzl_wire_edge_decode(const uint8_t* buf, uint64_t len, uzl_wire_edge* out, u
     e.diff_time_sec = r.get<int32_t>(); e.diff_time_nsec = r.get<int32_t>();
     if (!r.ok) return UZL_ERR_TRUNCATED;
     *out = e;
+    if (consumed) *consumed = r.o;
+    return UZL_OK;
+}
+
+// SlamGraph::toMetaData (slam_graph.cpp:592-619) serialised in GraphMeta.msg field order
+static void put_meta(Writer& w, const uzl_wire_meta& m, const uzl_wire_sensor_transform* st, const uzl_wire_sensor_transform* sti)
+{
+    put_header(w, m.stamp_sec, m.stamp_nsec, m.frame_id);
+    w.str(m.name);
+    put_pose(w, m.map_transform);
+    const int32_t n0 = st ? std::max(m.n_sensor_transforms, 0) : 0, n1 = sti ? std::max(m.n_sensor_transforms_initial, 0) : 0;
+    w.val<uint32_t>((uint32_t)n0);
+    for (int32_t i = 0; i < n0; i++) { w.str(st[i].sensor_name); put_pose(w, st[i].transform); }
+    w.val<uint32_t>((uint32_t)n1);
+    for (int32_t i = 0; i < n1; i++) { w.str(sti[i].sensor_name); put_pose(w, sti[i].transform); }
+    for (int i = 0; i < 6; i++) w.val(m.odometry_parameters[i]);              // Conversions::toMsg(Vector6d) (conversions.cpp:338-343)
+}
+
+uint64_t uzl_wire_meta_size(const uzl_wire_meta* m, const uzl_wire_sensor_transform* st, const uzl_wire_sensor_transform* sti)
+{
+    if (!m) return 0;
+    Writer w(nullptr, 0);
+    put_meta(w, *m, st, sti);
+    return w.o;
+}
+
+int uzl_wire_meta_encode(const uzl_wire_meta* m, const uzl_wire_sensor_transform* st, const uzl_wire_sensor_transform* sti, uint8_t* buf,
+                         uint64_t cap, uint64_t* written)
+{
+    if (!m || !buf || (m->n_sensor_transforms > 0 && !st) || (m->n_sensor_transforms_initial > 0 && !sti) || m->n_sensor_transforms < 0 ||
+        m->n_sensor_transforms_initial < 0) return UZL_ERR_BAD_ARG;
+    Writer w(buf, cap);
+    put_meta(w, *m, st, sti);
+    if (written) *written = w.o;
+    return w.fits() ? UZL_OK : UZL_ERR_TRUNCATED;
+}
+
+int uzl_wire_meta_decode(const uint8_t* buf, uint64_t len, uzl_wire_meta* out, int32_t cap, uzl_wire_sensor_transform* st, int32_t cap_initial,
+                         uzl_wire_sensor_transform* sti, uint64_t* consumed)
+{
+    if (!buf || !out) return UZL_ERR_BAD_ARG;
+    Reader r(buf, len);
+    uzl_wire_meta m;
+    memset(&m, 0, sizeof(m));
+    // SlamGraph::updateMetaData (slam_graph.cpp:621-633)
+    const Header h = get_header(r);
+    m.stamp_sec = h.sec; m.stamp_nsec = h.nsec; m.frame_id = h.frame_id;
+    m.name = r.str();
+    get_pose(r, m.map_transform);
+    for (int which = 0; which < 2 && r.ok; which++) {
+        const uint32_t c = r.get<uint32_t>();
+        uzl_wire_sensor_transform* dst = which ? sti : st;
+        const int32_t room = which ? cap_initial : cap;
+        // (a count the rest of the message cannot hold: every entry takes at least 4 + 56 bytes)
+        if (r.ok && (uint64_t)c > (r.n - r.o) / 60) { r.ok = false; break; }
+        for (uint32_t i = 0; i < c && r.ok; i++) {
+            uzl_wire_sensor_transform e;
+            e.sensor_name = r.str();
+            get_pose(r, e.transform);
+            if (r.ok && dst && (int64_t)i < room) dst[i] = e;
+        }
+        (which ? m.n_sensor_transforms_initial : m.n_sensor_transforms) = (int32_t)c;
+    }
+    for (int i = 0; i < 6; i++) m.odometry_parameters[i] = r.get<double>();
+    if (!r.ok) return UZL_ERR_TRUNCATED;
+    *out = m;
     if (consumed) *consumed = r.o;
     return UZL_OK;
 }

@@ -41,6 +41,16 @@ class WireNode(C.Structure):
                 ("n_stamps", C.c_int32), ("n_edge_ids", C.c_int32), ("n_sensors", C.c_int32), ("uncertainty", C.c_double)]
 
 
+class WireSensorTransform(C.Structure):
+    _fields_ = [("sensor_name", Span), ("transform", C.c_double * 12)]
+
+
+class WireMeta(C.Structure):
+    _fields_ = [("stamp_sec", C.c_uint32), ("stamp_nsec", C.c_uint32), ("frame_id", Span), ("name", Span),
+                ("map_transform", C.c_double * 12), ("n_sensor_transforms", C.c_int32), ("n_sensor_transforms_initial", C.c_int32),
+                ("odometry_parameters", C.c_double * 6)]
+
+
 class BagMsg(C.Structure):
     _fields_ = [("topic", Span), ("datatype", Span), ("md5sum", Span), ("definition", Span), ("data", Span),
                 ("time_sec", C.c_uint32), ("time_nsec", C.c_uint32)]
@@ -53,7 +63,7 @@ def _lib():
     global _proto_done
     L = capi.lib()
     if not _proto_done:
-        for f in ("uzl_wire_edge_size", "uzl_wire_node_size", "uzl_wire_features_size", "uzl_bag_single_size"):
+        for f in ("uzl_wire_edge_size", "uzl_wire_node_size", "uzl_wire_meta_size", "uzl_wire_features_size", "uzl_bag_single_size"):
             getattr(L, f).restype = C.c_uint64
         _proto_done = True
     return L
@@ -125,6 +135,52 @@ def decode_edge(b):
     for f in _EDGE_NUM:
         e[f] = getattr(w, f)
     return e, used.value
+
+
+# ---------------------------------------------------------------------------------------------------- GraphMeta
+def _transforms_in(k, items):
+    arr = (WireSensorTransform * max(len(items), 1))()
+    for i, (name, T) in enumerate(items):
+        arr[i].sensor_name = k.span(name)
+        arr[i].transform[:] = _arr(T, 12)
+    return arr
+
+
+def encode_meta(m):
+    """The graph's meta data (dict: stamp_sec, stamp_nsec, frame_id, name, map_transform, sensor_transforms /
+    sensor_transforms_initial = [(name, 12 doubles)], odometry_parameters) -> serialised graph_slam_msgs/GraphMeta."""
+    L = _lib()
+    k = _Keep()
+    w = WireMeta()
+    w.stamp_sec, w.stamp_nsec = int(m["stamp_sec"]), int(m["stamp_nsec"])
+    w.frame_id, w.name = k.span(m["frame_id"]), k.span(m["name"])
+    w.map_transform[:] = _arr(m["map_transform"], 12)
+    w.n_sensor_transforms, w.n_sensor_transforms_initial = len(m["sensor_transforms"]), len(m["sensor_transforms_initial"])
+    w.odometry_parameters[:] = _arr(m["odometry_parameters"], 6)
+    st, sti = _transforms_in(k, m["sensor_transforms"]), _transforms_in(k, m["sensor_transforms_initial"])
+    size = L.uzl_wire_meta_size(C.byref(w), st, sti)
+    buf = (C.c_uint8 * size)()
+    wr = C.c_uint64(0)
+    _check(L.uzl_wire_meta_encode(C.byref(w), st, sti, buf, C.c_uint64(size), C.byref(wr)), "meta_encode")
+    assert wr.value == size
+    return bytes(buf)
+
+
+def decode_meta(b):
+    L = _lib()
+    src = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(bytes(b) or b"\0")
+    w = WireMeta()
+    used = C.c_uint64(0)
+    _check(L.uzl_wire_meta_decode(src, C.c_uint64(len(b)), C.byref(w), 0, None, 0, None, C.byref(used)), "meta_decode")      # counts
+    st = (WireSensorTransform * max(w.n_sensor_transforms, 1))()
+    sti = (WireSensorTransform * max(w.n_sensor_transforms_initial, 1))()
+    _check(L.uzl_wire_meta_decode(src, C.c_uint64(len(b)), C.byref(w), w.n_sensor_transforms, st, w.n_sensor_transforms_initial, sti,
+                                  C.byref(used)), "meta_decode")
+    m = dict(stamp_sec=w.stamp_sec, stamp_nsec=w.stamp_nsec, frame_id=_bytes(w.frame_id), name=_bytes(w.name),
+             map_transform=np.array(w.map_transform[:]), odometry_parameters=np.array(w.odometry_parameters[:]))
+    m["sensor_transforms"] = [(_bytes(st[i].sensor_name), np.array(st[i].transform[:])) for i in range(w.n_sensor_transforms)]
+    m["sensor_transforms_initial"] = [(_bytes(sti[i].sensor_name), np.array(sti[i].transform[:])) for i in range(w.n_sensor_transforms_initial)]
+    return m, used.value
 
 
 # ---------------------------------------------------------------------------------------------------- Node
@@ -263,7 +319,7 @@ class RosbagStorage:
     loadGraph reads every file of nodes/ and edges/.  md5sum / definition are the message traits of the caller's ROS build
     (ros::message_traits::MD5Sum<M> / Definition<M>); they are stored, never interpreted."""
 
-    NODE_TYPE, EDGE_TYPE = b"graph_slam_msgs/Node", b"graph_slam_msgs/Edge"
+    NODE_TYPE, EDGE_TYPE, META_TYPE = b"graph_slam_msgs/Node", b"graph_slam_msgs/Edge", b"graph_slam_msgs/GraphMeta"
 
     def __init__(self, storage_path, clear_storage=False, traits=None):
         self.path = storage_path
@@ -292,6 +348,21 @@ class RosbagStorage:
 
     def store_edge(self, edge, now_ns=0):                                # storeEdge (:78-92)
         self._write("edges", edge["id"], b"edge", self.EDGE_TYPE, encode_edge(edge), now_ns)
+
+    def store_meta(self, meta, now_ns=0):                                # storeMetaData (:94-107): <path>/meta/meta, topic "meta"
+        self._write("meta", "meta", b"meta", self.META_TYPE, encode_meta(meta), now_ns)
+
+    def load_meta(self):
+        """loadGraph's meta pass (:187-207): every file under <path>/meta, every "meta" message, the last one read wins
+        (updateMetaData overwrites); None when there is none."""
+        meta = None
+        d = os.path.join(self.path, "meta")
+        for name in sorted(os.listdir(d)):
+            with open(os.path.join(d, name), "rb") as f:
+                for m in bag_read(f.read()):
+                    if m["topic"] == b"meta":
+                        meta, _ = decode_meta(m["data"])
+        return meta
 
     def _remove(self, sub, name):
         p = os.path.join(self.path, sub, name if isinstance(name, str) else name.decode())
