@@ -3,12 +3,16 @@
 // A HIP stream is served by one of the runtime's hardware queues (four per priority by default: GPU_MAX_HW_QUEUES), handed out at
 // hipStreamCreate, least used first, and the driver puts the queues on the GPU's four compute pipes in the order they were first made.
 // Streams on one queue run strictly one behind the other.  Streams on two queues of one PIPE do overlap for a single kernel - but two
-// chains of dependent kernels, one on each, take 2.7x the time of one chain (measured: tests/diag/stream_overlap.py), worse than
+// chains of dependent kernels, one on each, take 2.4x the time of one chain (measured: tests/diag/stream_overlap.py), worse than
 // running them one after the other.  Which streams of a process collide either way depends on every stream it has made before: a batch
 // whose rebuild stream sat on the solver stream's pipe lost 15 - 45 % (16 chain-like graphs 14.3 -> 20.9 ms), two launch sequences on one
-// pipe ran 2x slower than one sequence.  Nothing tells a process where a stream landed, but it can be measured: a chain of 32 dependent
-// ~4-us kernels on one stream alone, then the same chain on both at once (independent pairs: 1.05 - 1.25x; one pipe: 2.7x; one queue: 2.0x;
-// the threshold is 1.5x).
+// pipe ran 2x slower than one sequence.  Nothing tells a process where a stream landed, but it can be measured: a chain of 8 dependent
+// 10-us kernels on one stream alone, then the same chain on both at once, TIMED ON THE DEVICE (first link's start to last link's
+// end).  Round 6, two boxes, 116 pairs (tests/diag/stream_overlap.py): independent pairs 1.01 - 1.17x; one hardware queue 2.01x; two
+// queues in each other's way 2.38 - 2.42x; nothing in between - the threshold is 1.5x, best of three (anything else on the GPU can only
+// hold a run back).  Rounds 4 - 5 timed 32 4-us links from the host: two chains cost the host twice the launches, so independent pairs
+// read 1.05 - 1.56x depending on the box's CPU and the verdict was noise-driven (round 5's red GPU test).  A pair costs 0.2 ms
+// (independent: one run) to 0.7 ms (three runs); the chain alone is measured once per process.
 //
 // Round 4 measured at every uzl_pgo_batch_create and threw the rejected streams away.  Now the streams that have to run side by side
 // (a solver handle's solver / rebuild pair, a batch's launch sequences and their rebuild streams) come from ONE POOL PER DEVICE that
@@ -36,28 +40,29 @@ constexpr int kNewPerLease = 6;         // new streams a single lease may add (t
 constexpr int kMaxDevices = 16;
 constexpr int kKeepFree = 32;           // idle streams the pool keeps
 
-// One link of a chain: every workgroup spins for `ticks` of the 100 MHz wall clock; the chain's first link leaves the earliest start
-// and its last link the latest end in stamp[0] / stamp[1] (pinned host memory), so a measurement is taken ON THE DEVICE: neither the
+// One link of a chain: every workgroup spins for `ticks` of the 100 MHz wall clock.  The chain's first link leaves its start in
+// stamp[2 slot] and its last link its latest end in stamp[2 slot + 1] (DEVICE memory: a plain store by one lane, an atomicMax by
+// every 64th workgroup - the clock only grows, so the end needs no reset), so a measurement is taken ON THE DEVICE: neither the
 // host's launch rate (two chains cost it twice the launches: on a slow host that alone read as 1.4 - 1.56x with host timing) nor the
 // latency of the synchronize is in it.
-__global__ void chain_kernel(unsigned ticks, unsigned long long* stamp, int where)
+__global__ void chain_kernel(unsigned ticks, unsigned long long* stamp, int where, int slot)
 {
     const unsigned long long t0 = wall_clock64();            // 100 MHz
-    if (where == 1 && threadIdx.x == 0) atomicMin(&stamp[0], t0);
+    if (where == 1 && blockIdx.x == 0 && threadIdx.x == 0) stamp[2 * slot] = t0;
     while (wall_clock64() - t0 < ticks) {}
-    if (where == 2 && threadIdx.x == 0) atomicMax(&stamp[1], wall_clock64());
+    if (where == 2 && (blockIdx.x & 63) == 63 && threadIdx.x == 0) atomicMax(&stamp[2 * slot + 1], wall_clock64());
 }
 
 constexpr int kChainLen = 8;            // links per chain
 constexpr unsigned kChainTicks = 1000;  // 10 us a link: the host (2.8 us a launch) stays ahead of two chains
 constexpr int kChainWgs = 1000;
-// Independent iff two chains side by side take < kIndependentBelow x one chain, best of kProbeTries.  Device-timed classes (r06,
-// tests/diag/stream_overlap.py, two boxes): other pipe 1.00 - 1.12; same pipe, other queue 2.4 - 2.8; same queue 2.0 - 2.1.
+// Independent iff two chains side by side take < kIndependentBelow x one chain, best of kProbeTries (classes: file header).
 constexpr double kIndependentBelow = 1.5;
 constexpr int kProbeTries = 3;
 
 struct Probe {                          // per device: the stamps and the time of one chain alone (measured once per process)
-    unsigned long long* stamp = nullptr;
+    unsigned long long* stamp = nullptr;                        // device: {start, end} of chain a, of chain b
+    unsigned long long* host = nullptr;                         // pinned: where they are read
     double alone = 0.;
     std::vector<hipStream_t> warmed;
 };
@@ -65,23 +70,31 @@ struct Probe {                          // per device: the stamps and the time o
 // ticks from the first link's start to the last link's end, one chain on `a` (b == nullptr) or one on each
 double chain_ticks(Probe& pr, hipStream_t a, hipStream_t b)
 {
-    if (!pr.stamp && hipHostMalloc((void**)&pr.stamp, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return -1.;
+    if (!pr.stamp) {
+        if (hipMalloc((void**)&pr.stamp, 4 * sizeof(unsigned long long)) != hipSuccess) { pr.stamp = nullptr; return -1.; }
+        if (hipMemset(pr.stamp, 0, 4 * sizeof(unsigned long long)) != hipSuccess) return -1.;
+        if (hipHostMalloc((void**)&pr.host, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { pr.host = nullptr; return -1.; }
+    }
+    if (!pr.host) return -1.;
     for (hipStream_t q : {a, b})                                // (the first launch on a stream sets its queue up)
         if (q && std::find(pr.warmed.begin(), pr.warmed.end(), q) == pr.warmed.end()) {
-            hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, q, 1u, pr.stamp, 0);
+            hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, q, 1u, pr.stamp, 0, 0);
             (void)hipStreamSynchronize(q);
             pr.warmed.push_back(q);
         }
-    pr.stamp[0] = ~0ull; pr.stamp[1] = 0ull;
     for (int k = 0; k < kChainLen; k++) {
         const int where = k == 0 ? 1 : (k == kChainLen - 1 ? 2 : 0);
-        hipLaunchKernelGGL(chain_kernel, dim3(kChainWgs), dim3(256), 0, a, kChainTicks, pr.stamp, where);
-        if (b) hipLaunchKernelGGL(chain_kernel, dim3(kChainWgs), dim3(256), 0, b, kChainTicks, pr.stamp, where);
+        hipLaunchKernelGGL(chain_kernel, dim3(kChainWgs), dim3(256), 0, a, kChainTicks, pr.stamp, where, 0);
+        if (b) hipLaunchKernelGGL(chain_kernel, dim3(kChainWgs), dim3(256), 0, b, kChainTicks, pr.stamp, where, 1);
     }
-    (void)hipStreamSynchronize(a);
     if (b) (void)hipStreamSynchronize(b);
+    const bool ok = hipMemcpyAsync(pr.host, pr.stamp, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, a) == hipSuccess;
+    (void)hipStreamSynchronize(a);
     (void)hipGetLastError();
-    return pr.stamp[1] > pr.stamp[0] ? (double)(pr.stamp[1] - pr.stamp[0]) : -1.;
+    if (!ok) return -1.;
+    const unsigned long long* t = pr.host;
+    const unsigned long long start = b ? std::min(t[0], t[2]) : t[0], end = b ? std::max(t[1], t[3]) : t[1];
+    return end > start ? (double)(end - start) : -1.;
 }
 
 // two chains of dependent kernels side by side against one chain alone: the smallest of up to kProbeTries ratios (anything else on the
