@@ -160,15 +160,29 @@ def timed(dist, fn, steps):
     return dist.max(dt)
 
 
+def _traffic_file():
+    try:
+        return json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))
+    except Exception:
+        return {}
+
+
 def traffic_of(key, applies):
     """PMC-measured HBM bytes per launch, collected by profiles/collect.sh on the default workloads (separate --pmc passes); this
     run does not measure it - `traffic_source` in the JSON says where it comes from."""
-    if not applies:
-        return None
-    try:
-        return json.load(open(os.path.join(ROOT, TRAFFIC_JSON))).get(key)
-    except Exception:
-        return None
+    return _traffic_file().get(key) if applies else None
+
+
+def rocprof_us(key, applies):
+    """the kernel's average dispatch duration in the committed rocprofv3 --kernel-trace --stats summary of the same collection
+    (bench.py's own `avg_launch_us` is measured live in THIS run from the dispatch's begin / end timestamps - hipExtLaunchKernelGGL
+    start / stop events on the launching stream -, which is what rocprofv3 reports; `timing` says so per kernel)"""
+    return _traffic_file().get(key + "_rocprof_avg_us") if applies else None
+
+
+def traffic_source():
+    m = _traffic_file().get("_meta") or {}
+    return "%s@%s (%s, %s)" % (TRAFFIC_JSON, m.get("commit", "unknown"), m.get("tag", "?"), m.get("collected_utc", "?"))
 
 
 PHASES_JSON = os.path.join(ROOT, "profiles", "r03_estimate_phases.json")
@@ -282,6 +296,7 @@ def pgo_rooflines(pgo, st, st_prof, kt, nodes, edges, is_default):
     out.append(roof("ml_spmv_kernel<%d>" % (4 if agg4 else 1) if pgo.cfg.preconditioner else "pcg_spmv_kernel", "hbm", ach, HBM_PEAK_GBS, "GB/s",
                     traffic=traffic_of("pcg_spmv_bytes_per_launch" if not agg4 else "pcg_spmv4_bytes_per_launch", is_default),
                     algorithmic_bytes_per_launch=alg, avg_launch_us=round(1e3 * spmv["ms"] / max(spmv["launches"], 1), 3),
+                    rocprof_avg_us=rocprof_us("pcg_spmv4" if agg4 else "pcg_spmv", is_default), timing="dispatch_timestamps",
                     launches=spmv["launches"], active_launches=active,
                     note="working set (H = %.1f MB) is L2 / Infinity-Cache resident; launch-latency bound at this size" % (288e-6 * (nb + 2 * E))))
     lin = kt.get("linearize")
@@ -290,7 +305,7 @@ def pgo_rooflines(pgo, st, st_prof, kt, nodes, edges, is_default):
         out.append(roof("hessian_kernel", "hbm", alg_l * lin["launches"] / (lin["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s",
                         traffic=traffic_of("c4_hessian_bytes_per_launch" if agg4 else "hessian_bytes_per_launch", is_default), algorithmic_bytes_per_launch=alg_l,
                         avg_launch_us=round(1e3 * lin["ms"] / lin["launches"], 3), launches=lin["launches"],
-                        timing="hipEventRecord pair around the launch (reads ~1.5x a short kernel's own time; the rocprofv3 summary under profiles/ has the dispatch time)",
+                        rocprof_avg_us=rocprof_us("c4_hessian" if agg4 else "hessian", is_default), timing="dispatch_timestamps",
                         note="the sparse Hessian build as ONE row-gather kernel (rounds 1-3: linearize_kernel + assemble_kernel): a lane per slot reads its slot-major "
                              "record, recomputes its edge's Jacobians and leaves the H_ac block and its share of H_aa | b in LDS; the workgroup writes the blocks out "
                              "contiguously, lane (row, r) adds the shares in slot order - no atomics, nothing but H itself in HBM"))
@@ -306,6 +321,7 @@ def pgo_rooflines(pgo, st, st_prof, kt, nodes, edges, is_default):
         out.append(roof("ml_ns_gemm_kernel" if agg4 else "ml_ns_gemm32_kernel", "mfma", flop * gm["launches"] / (gm["ms"] * 1e-3) / 1e12, F64_PEAK_TFLOPS, "TFLOP/s (f64 matrix cores)",
                         traffic=traffic_of("c4_ns_gemm_bytes_per_launch" if agg4 else "ns_gemm32_bytes_per_launch", is_default),
                         operand_bytes_per_launch=3.0 * 8.0 * n6 * n6, flop_per_launch=flop, n=n6, avg_launch_us=round(1e3 * gm["ms"] / gm["launches"], 3), launches=gm["launches"],
+                        rocprof_avg_us=rocprof_us("c4_ns_gemm" if agg4 else "ns_gemm32", is_default), timing="dispatch_timestamps",
                         note="the block-GEMM of the path: X' = 2X - X(AX), v_mfma_f64_16x16x4_f64, 64 x 64 tiles on and above the diagonal (the product is symmetric: "
                              "%.0f %% of 2 n^3); %d launches per solve" % (100.0 * flop / (2.0 * n6 ** 3), gm["launches"])))
     return out
@@ -477,7 +493,7 @@ def bench_formats(capi, dev, pairs, n_kp):
     return dict(kernel="wire_unpack_kernel", workload="%d frames x %d keypoints, ORB-256: Feature records -> frame arena, one launch" % (len(frames), n_kp),
                 ms=round(best or 0.0, 4),
                 roofline=roof("wire_unpack_kernel", "hbm", ach, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=alg,
-                              traffic=traffic_of("wire_unpack_bytes_per_launch", len(frames) == 1024 and n_kp == 1000), traffic_source=TRAFFIC_JSON),
+                              traffic=traffic_of("wire_unpack_bytes_per_launch", len(frames) == 1024 and n_kp == 1000), traffic_source=traffic_source()),
                 matches_source_arrays=ok)
 
 
@@ -558,7 +574,8 @@ def _pick(d, keys):
     return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None} if isinstance(d, dict) else None
 
 
-ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "flop_per_launch", "avg_launch_us", "launches", "active_launches")
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "flop_per_launch", "avg_launch_us", "timing",
+             "rocprof_avg_us", "launches", "active_launches")
 CPU_KEYS = ("value", "unit", "cores", "kind", "nproc", "cpu", "sample", "seconds_per_solve")
 
 
@@ -590,7 +607,7 @@ def compact_record(out):
     cf = out.get("continued_from_solution") or {}
     c["continued_from_solution"] = [[x.get("ms"), x.get("lm_iterations_done"), x.get("pcg_iterations")] for x in cf.get("calls", [])] or None
     c["roofline"] = _roof(out.get("roofline"))
-    c["rooflines"] = [_pick(r, ("kernel", "bound", "frac", "avg_launch_us", "traffic")) for r in (out.get("rooflines") or [])][:6]
+    c["rooflines"] = [_pick(r, ("kernel", "bound", "frac", "avg_launch_us", "rocprof_avg_us", "traffic")) for r in (out.get("rooflines") or [])][:6]
     c["cpu_baseline"] = _cpu(out.get("cpu_baseline"))
     c["parity"] = _pick(out.get("parity"), ("ok", "dt_m", "dr_rad", "lm_trials_equal"))
     c["lm_overhead_ms"] = out.get("lm_overhead_ms")
@@ -632,7 +649,7 @@ def compact_record(out):
         d["first_solve_ms"] = (c4.get("first_solve") or {}).get("first_solve_ms")
         d["repeat_identical"] = (c4.get("repeat_identical") or {}).get("value")
         d["roofline"] = _roof(c4.get("roofline"))
-        d["rooflines"] = [_pick(r, ("kernel", "bound", "frac", "avg_launch_us", "traffic")) for r in (c4.get("rooflines") or [])]
+        d["rooflines"] = [_pick(r, ("kernel", "bound", "frac", "avg_launch_us", "rocprof_avg_us", "traffic")) for r in (c4.get("rooflines") or [])]
         d["cpu_baseline"] = _pick(c4.get("cpu_baseline"), ("value", "unit", "cores", "kind", "seconds_per_solve"))
         d["parity"] = _pick(c4.get("parity"), ("ok", "dt_m", "dr_rad", "lm_trials_equal"))
         w1 = c4.get("sharded_world1") or {}
@@ -741,7 +758,7 @@ def main():
     value = dist.sum(float(B["edges"])) / t_pgo
     st_prof, kt = pgo_profile(pgo, a)
     rooflines = pgo_rooflines(pgo, st, st_prof, kt, a.nodes, a.edges, is_c2)
-    roofline = dict(rooflines[0]); roofline["traffic_source"] = TRAFFIC_JSON
+    roofline = dict(rooflines[0]); roofline["traffic_source"] = traffic_source()
     kernels_ms = {k: round(v["ms"], 4) for k, v in sorted(kt.items(), key=lambda x: -x[1]["ms"])}
     cfg_name = {(1000, 5000): "BASELINE config 2", (10000, 50000): "BASELINE config 4 size on one GPU", (100, 300): "BASELINE config 1"}.get((a.nodes, a.edges), "custom size")
     # What a solve costs besides its PCG iterations: the same graph solved so loosely that every solve stops at its first look; the slope
@@ -845,7 +862,7 @@ def main():
         ops = 2.0 * per_rank * a.keypoints * a.keypoints * 256.0
         ach = ops / (knn_ms * 1e-3) / 1e12 if knn_ms > 0 else 0.0
         knn_roof = roof("knn2_mfma_kernel<8, 2>", "mfma", ach, MFMA_I8_PEAK_TOPS, "TOP/s (int8, dense)", traffic=traffic_of("knn2_bytes_per_launch", is_c3),
-                        traffic_source=TRAFFIC_JSON, ms=round(knn_ms, 4),
+                        traffic_source=traffic_source(), ms=round(knn_ms, 4),
                         note="v_mfma_i32_32x32x32_i8 over 0/1-expanded 256-bit descriptors (2 x 1000 x 1000 x 256 ops per pair); `peak` = 2 x the "
                              "~2.5 PFLOP/s dense bf16 rate (MI355X_MICROARCH.md); the vector ALU that folds each 32 x 32 tile into the per-query "
                              "top-2 (2 instructions per distance: the matrix cores emit the sort key) issues beside the matrix pipe")
@@ -1047,7 +1064,7 @@ def main():
         st4p, kt4 = pgo_profile(B4["pgo"], a)
         r4 = pgo_rooflines(B4["pgo"], B4["st"], st4p, kt4, 10000, 50000, True)
         for r in r4:
-            r["traffic_source"] = TRAFFIC_JSON
+            r["traffic_source"] = traffic_source()
         c4 = dict(metric="SE(3) edges optimized/sec, 10k nodes / 50k edges, one GPU", value=round(B4["edges"] / B4["t"], 1), unit="edges/s",
                   ms_per_solve=round(1e3 * B4["t"] / steps4, 3), solves_timed=steps4, h2d_ms=round(B4["h2d_ms"], 3), d2h_ms=round(B4["d2h_ms"], 3),
                   first_solve=B4["first"], repeat_identical=B4.get("repeat"),
@@ -1247,7 +1264,7 @@ def main():
             timing="uzl_pgo_cfg::pass_history = 1: no pass of the LM loop is sized from an earlier optimize of the same graph",
             first_solve_ms=first_warm["first_solve_ms"], first_solve=first_warm, repeat_identical=B.get("repeat"), continued_from_solution=B.get("continued"),
             streams=capi.stream_stats(dev),
-            roofline=roofline, rooflines=rooflines, traffic_source=TRAFFIC_JSON + " (rocprofv3 --pmc passes of profiles/collect.sh on the default workloads; not measured in this run)",
+            roofline=roofline, rooflines=rooflines, traffic_source=traffic_source() + " (rocprofv3 --pmc passes of profiles/collect.sh on the default workloads; not measured in this run)",
             kernels_ms_per_solve=kernels_ms, kernels_ms_note="profiled solve: eager launches of the by-value instantiations of the kernel bodies (host-driven loop); "
                                                             "the timed solves run the same bodies as slot twins (ml_spmv_lm_kernel, ...) under the device-resident loop",
             lm_overhead_ms=(lm_overhead or {}).get("lm_overhead_ms"), lm_overhead=lm_overhead,

@@ -343,8 +343,8 @@ const char* uzl_pgo_last_error(uzl_pgo* h);
  * The poses a solve returns do not depend on what the handle solved before, up to the accuracy of the linear solve (pcg_tol): with
  * reduced_numbering = 0 a handle remembers how many PCG iterations its last solves took in either numbering of the Schur-reduced
  * system and lays the next one out accordingly (another preconditioner for the same system).  That memory is kept while the graph is
- * the previous one, unchanged or grown (at least as many nodes, the old nodes' fixed flags in front: an online session,
- * graph_slam_node.cpp:1138-1150), and dropped for any other graph. */
+ * the previous one, unchanged or grown (at least as many nodes, the old nodes' fixed flags in front, nine in ten of the old system
+ * edges still present in their order: an online session, graph_slam_node.cpp:1138-1150), and dropped for any other graph. */
 int  uzl_pgo_add_graph(uzl_pgo* h,
                        int32_t n_nodes, const uzl_node* nodes,
                        int32_t n_edges, const uzl_edge* edges,

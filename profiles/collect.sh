@@ -1,10 +1,12 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence behind bench.py's roofline block.  Run on the GPU box from the repo root:
-#   bash profiles/collect.sh <tag>          (writes gpurun_out/prof_<tag>_summary/: kernel stats, counters, traffic.json)
+#   bash profiles/collect.sh <tag> [commit]  (writes gpurun_out/prof_<tag>_summary/: kernel stats, counters, traffic.json;
+#                                             `commit` = git rev-parse --short HEAD of the tree sent to the box, recorded in traffic.json)
 # hipGraph replay crashes rocprofv3's kernel tracer on this image, so profiling runs use eager launches
 # (UZL_NO_GRAPH=1); counters are collected in their own passes (no --kernel-trace mixed with --pmc).
 set -u
 TAG=${1:-r01}
+COMMIT=${2:-unknown}
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
@@ -30,7 +32,7 @@ cd $OLDPWD
 # gpurun_out/prof_<tag>_summary/ into profiles/ afterwards
 SUM=$PWD/gpurun_out/prof_${TAG}_summary
 rm -rf $SUM; mkdir -p $SUM
-python3 profiles/summarize.py $OUT $SUM/$TAG
+python3 profiles/summarize.py $OUT $SUM/$TAG $COMMIT
 cp profiles/traffic.json $SUM/traffic.json
 for f in trace c4_trace online_trace; do cp $OUT/$f.json $SUM/${TAG}_${f}_bench_under_rocprof.json 2>/dev/null; done
 cp $OUT/batch_trace.log $SUM/${TAG}_batch_under_rocprof.log 2>/dev/null

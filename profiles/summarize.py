@@ -86,5 +86,40 @@ for key, names in (("pcg_spmv_bytes_per_launch", ("uzl::ml_spmv_lm_kernel<1, 1, 
         if hit:
             t[key] = pmc[hit[0]]["hbm_bytes_per_launch"]
             break
+# the same kernels' average dispatch duration in the rocprofv3 --kernel-trace --stats summaries of this collection (the by-value
+# instantiations the profiled solve of bench.py launches): bench.py prints them beside its own event-timed figures
+def stats_avg_us(path, prefixes):
+    try:
+        rows = list(csv.DictReader(open(path)))
+    except OSError:
+        return None
+    for pre in prefixes:
+        for r in rows:
+            if r["Name"].replace("void ", "").startswith(pre):
+                return round(float(r["AverageNs"]) / 1e3, 3)
+    return None
+
+
+rp = {}
+for key, path, prefixes in (("pcg_spmv", out + "_kernel_stats.csv", ("uzl::ml_spmv_kernel<1>",)),
+                            ("hessian", out + "_kernel_stats.csv", ("uzl::hessian_kernel",)),
+                            ("ns_gemm32", out + "_kernel_stats.csv", ("uzl::ml_ns_gemm32_kernel",)),
+                            ("knn2", out + "_kernel_stats.csv", ("uzl::knn2_mfma_kernel<8, 2",)),
+                            ("estimate", out + "_kernel_stats.csv", ("uzl::estimate_kernel",)),
+                            ("wire_unpack", out + "_kernel_stats.csv", ("uzl::wire_unpack_kernel",)),
+                            ("pcg_spmv4", out + "_c4_kernel_stats.csv", ("uzl::ml_spmv_kernel<4>",)),
+                            ("pcg_cg4", out + "_c4_kernel_stats.csv", ("uzl::ml_cg_kernel<4",)),
+                            ("c4_hessian", out + "_c4_kernel_stats.csv", ("uzl::hessian_kernel",)),
+                            ("c4_ns_gemm", out + "_c4_kernel_stats.csv", ("uzl::ml_ns_gemm_kernel",))):
+    v = stats_avg_us(path, prefixes)
+    if v is not None:
+        rp[key + "_rocprof_avg_us"] = v
+t.update(rp)
+# provenance: the tag of this collection and the commit of the tree it ran on (profiles/collect.sh <tag> <commit>)
+import datetime
+t["_meta"] = dict(tag=os.path.basename(out), commit=(sys.argv[3] if len(sys.argv) > 3 else "unknown"),
+                  collected_utc=datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+                  how="rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, bytes = (2 FETCH + WRITE) KB x 1024 (gfx950 correction); "
+                      "*_rocprof_avg_us from the --kernel-trace --stats pass of the same collection")
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(t))

@@ -7,6 +7,22 @@
 
 namespace uzl {
 
+// Hand-over of a snapshot to the host through pinned, coherent memory (lm_tail_kernel, publish_kernel): the fields go out as relaxed
+// system-scope stores, every lane waits until ITS stores have been acknowledged, a workgroup barrier, then one lane stores the sequence
+// word.  On gfx9-family targets (gfx90a / gfx942 / gfx950) vmcnt counts stores as well as loads, so `s_waitcnt vmcnt(0)` is that wait -
+// without the system-scope release fence, which also writes back every dirty line of the L2 (the solve's whole working set: 11.0 ->
+// 7.4 us per tail, and the host reads none of it).  This is outside the HIP memory model and only right where vmcnt counts stores
+// (gfx10+ tracks them with vscnt): any other target takes the fence, and the caller's sequence store is then a release.
+#if defined(__gfx90a__) || defined(__gfx942__) || defined(__gfx950__)
+#define UZL_PUBLISH_SEQ_ORDER __ATOMIC_RELAXED
+__device__ __forceinline__ void publish_wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
+#define UZL_PUBLISH_SEQ_ORDER __ATOMIC_RELEASE
+__device__ __forceinline__ void publish_wait_own_stores() { __threadfence_system(); }
+#endif
+
+
+
 constexpr int kBlk = 256;
 
 // ------------------------------------------------------------------------------------------------

@@ -23,7 +23,8 @@ void k_prepare_edges(const uzl_edge* edges, const int32_t* src, int e, const dou
 void k_prepare_flat_edges(const double* meas12, const double* info36, int e, double* zinv, double* info, hipStream_t s);
 int k_chi2(const PgoDev& D, const double* pose, double delta, hipStream_t s);
 int k_chi2_trial(const PgoDev& D, const double* pose, double delta, hipStream_t s);
-hipError_t k_hessian(const PgoDev& D, const double* pose, double delta, int* g_edges, int* g_rows, hipStream_t s, bool with_chi2 = true);
+hipError_t k_hessian(const PgoDev& D, const double* pose, double delta, int* g_edges, int* g_rows, hipStream_t s, bool with_chi2 = true, hipEvent_t ev_a = nullptr,
+                     hipEvent_t ev_b = nullptr);
 void k_finalize(const PgoDev& D, int na, int nb_, int nc, int what, hipStream_t s);
 int k_diagmax(const PgoDev& D, hipStream_t s);
 void k_precond(const PgoDev& D, hipStream_t s);
@@ -51,6 +52,11 @@ int g_ml_rows(int nb, int agg);
 int g_ml_spmv(int nb, int agg);
 size_t ml_cg_lds_bytes(const int* n, int levels, int agg);
 bool ml_fits_lds(const int* n_per_level, int levels, int agg);
+// The ONE statement of the PCG kernels' LDS budget and of what ml_cg stages when the dense level-2 operator is present (the gather-level
+// vector and nothing else): build_ml's admission test, k_ml_cg, ml_cg_variant and ml_fits_lds all read these (tests/test_ml_admission.py
+// holds the boundaries through uzl_debug_ml_admission)
+// (kMlLdsLimit, ml_comp4_lds: pgo_types.hpp)
+bool ml_comp4_fits(int nb, int n2);          // LDS of the comp4 variant and ml_spmv's partial count
 void k_ml_init(const PgoDev& D, const MlHot& ml, int agg, double* p0, double* p1, double* rg, hipStream_t s);
 void k_ml_spmv(const PgoDev& D, const MlHot& ml, int agg, const double* p_old, double* p_new, int n_part, double tol2, hipStream_t s,
                hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);

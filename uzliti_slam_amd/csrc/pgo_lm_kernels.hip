@@ -196,14 +196,15 @@ __global__ __launch_bounds__(kTailBlk) void lm_tail_kernel(const LmSlot* __restr
         if (tid - kLmWords == 4 || tid - kLmWords == 5 || tid - kLmWords == 7) S.D.scal[tid - kLmWords] = v;
         __hip_atomic_store(reinterpret_cast<double*>(dst) + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else if (tid == kLmWords + 8) {
-        // seq_begin travels with the fields and seq follows behind them: a snapshot whose two words agree is whole.  (Rounds 4-5 sent
-        // seq_begin ahead behind a fence of its own; the host reads a slot's snapshot before it enqueues the pass whose tail writes the
-        // next one, so nothing can overwrite the fields under its copy.)
+        // seq_begin travels with the fields (unordered among them) and seq follows behind them all.  HOST-SIDE INVARIANT this rests on
+        // (wait_pub / load_slot, uzl_pgo_lm.hip): the host copies a slot's snapshot BEFORE it enqueues the pass whose tail writes the next
+        // one, so no tail can overwrite the fields under its copy; seq_begin == seq around a copy is a cross-check, not the protection.
+        // (Round 4 sent seq_begin ahead behind a fence of its own.)
         __hip_atomic_store(&S.pub->seq_begin, s_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this lane's stores have been acknowledged
+    publish_wait_own_stores();                              // this lane's stores have been acknowledged (uzl_common.hpp: gfx9 only without a fence)
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&S.pub->seq, s_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(&S.pub->seq, s_seq, UZL_PUBLISH_SEQ_ORDER, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 void k_lm_head(const LmSlot* slots, int nslots, int pass_flags, hipStream_t s)

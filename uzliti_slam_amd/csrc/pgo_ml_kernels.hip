@@ -2347,8 +2347,9 @@ size_t ml_cg_lds_bytes(const int* n, int levels, int agg)
 }
 bool ml_fits_lds(const int* n_per_level, int levels, int agg)
 {
-    return ml_cg_lds_bytes(n_per_level, levels, agg) <= 140 * 1024 && g_ml_spmv(n_per_level[0], agg) <= kMaxPartials;
+    return ml_cg_lds_bytes(n_per_level, levels, agg) <= kMlLdsLimit && g_ml_spmv(n_per_level[0], agg) <= kMaxPartials;
 }
+bool ml_comp4_fits(int nb, int n2) { return ml_comp4_lds(n2) <= kMlLdsLimit && g_ml_spmv(nb, 4) <= kMaxPartials; }
 void k_ml_init(const PgoDev& D, const MlHot& ml, int agg, double* p0, double* p1, double* rg, hipStream_t s)
 {
     if (agg == 1) hipLaunchKernelGGL(ml_init_kernel<1>, dim3(g_ml_rows(D.nb, 1)), dim3(kCgBlk), 0, s, D, ml, p0, p1, rg);
@@ -2382,7 +2383,8 @@ hipError_t k_ml_cg(const PgoDev& D, const MlHot& ml, int agg, const double* p, c
     const bool vpre = comp4 && !ypre && !init && ml.Vg != nullptr && !no_vpre;      // alpha and rg - alpha Sg prepared once, by ml_alpha_kernel
     // COMP stages nothing but the gather-level vector: asking for the LDS of the full restrict / top / chain walk (52 KB at 20k
     // vertices) held the kernel at two workgroups per CU - 625 workgroups ran in two rounds
-    if (comp4) lds = (size_t)6 * ml.n[2] * 8 + 64;
+    if (comp4) lds = ml_comp4_lds(ml.n[2]);
+    if (lds > kMlLdsLimit) return hipErrorInvalidValue;                             // (build_ml admits no such hierarchy)
     const int ci = agg == 1 ? 0 : (comp4 ? (ypre ? 3 : (vpre ? 4 : 2)) : 1);
     std::unique_lock<std::mutex> cfg_lock(configured_mu);
     size_t* configured = configured_tab[dev];
@@ -2748,7 +2750,7 @@ void ml_cg_variant(const MlHot& ml, int agg, size_t lds_full, int32_t* variant, 
         return;
     }
     if (!ml.Cmat) { *variant = kCgPlain4; return; }
-    *lds = (size_t)6 * ml.n[2] * 8 + 64;                                             // COMP stages nothing but the gather-level vector
+    *lds = ml_comp4_lds(ml.n[2]);                                                    // COMP stages nothing but the gather-level vector
     const bool ypre = ml.levels >= 2 && 6 * ml.n[2] <= 4 * 32 * kYU;
     *variant = ypre ? kCgComp4Ypre : ((ml.Vg != nullptr && !no_vpre) ? kCgComp4Vpre : kCgComp4);
 }
@@ -2816,5 +2818,15 @@ extern "C" UZL_DIAG_EXPORT int uzl_debug_ns_gemm(int n, const double* X, const d
     (void)hipMemcpy(out, dO, b, hipMemcpyDeviceToHost);
     (void)hipFree(dX); (void)hipFree(dT); (void)hipFree(dO);
     return e == hipSuccess ? 0 : -3;
+}
+// admission of the dense level-2 operator's PCG variant (host arithmetic only: runs without a device - tests/test_ml_admission.py):
+// the LDS ml_cg asks for with n2 level-2 aggregates, ml_spmv's workgroups (= partials) for nb free vertices, and build_ml's verdict
+extern "C" UZL_DIAG_EXPORT int uzl_debug_ml_admission(int nb, int n2, uint64_t* lds, int* spmv_groups, int* fits)
+{
+    if (nb <= 0 || n2 <= 0) return -1;
+    if (lds) *lds = uzl::ml_comp4_lds(n2);
+    if (spmv_groups) *spmv_groups = uzl::g_ml_spmv(nb, 4);
+    if (fits) *fits = uzl::ml_comp4_fits(nb, n2) ? 1 : 0;
+    return 0;
 }
 #endif

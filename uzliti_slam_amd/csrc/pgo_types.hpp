@@ -13,6 +13,10 @@
 #include "../../include/uzl_mi355x.h"
 
 namespace uzl {
+// LDS budget of the PCG kernels and what ml_cg stages when the dense level-2 operator is present (pgo_handle.hpp: ml_comp4_fits)
+constexpr size_t kMlLdsLimit = (size_t)140 * 1024;
+__host__ __device__ inline size_t ml_comp4_lds(int n2) { return (size_t)6 * (size_t)n2 * 8 + 64; }
+
 
 constexpr int kMaxPartials = 8192;        // block partials of a reduction = workgroups of a launch that leaves some (4096 until round 5: ml_spmv's 16-row workgroups ended at 65k vertices)
 constexpr int kProgressEvery = 2;    // PCG iterations between two looks of the stop test (see pgo_device.hpp, progress_decide)
@@ -205,7 +209,9 @@ struct LmDev {
     double rate_drop;          // share of its fresh PCG rate below which the hierarchy is rebuilt (lm_refresh)
 };
 // what the host sees after a pass: an image of the LM state and of PgoDev::scal[0..8), written by lm_tail_kernel into pinned coherent
-// memory (one 8-byte word per lane); seq_begin with the fields, seq (= LmDev::tails) behind a fence: a host copy is whole when both agree around it
+// memory (one 8-byte word per lane); seq_begin with the fields, seq (= LmDev::tails) after every lane's stores have been acknowledged
+// (publish_wait_own_stores, uzl_common.hpp - no fence on gfx9).  The host copies a snapshot before it enqueues the pass whose tail writes
+// the next one: that ordering, not the two words, keeps a copy whole; seq_begin == seq around it is the cross-check
 struct LmHost {
     LmDev lm;
     double scal[8];            // as the host-driven loop fetches them (verbose logs, residual ratio)

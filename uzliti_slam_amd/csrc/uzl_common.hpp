@@ -187,4 +187,5 @@ private:
     std::map<const char*, std::pair<double, int32_t>, CStrLess> acc_;
 };
 
+
 }  // namespace uzl

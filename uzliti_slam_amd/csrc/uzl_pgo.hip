@@ -305,10 +305,10 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     // hierarchy needs every level above the gather level.  Beyond either limit (and beyond kMaxPartials ml_spmv workgroups = 131k
     // vertices): block-Jacobi
     const bool comp4_here = !comp_off && !comp4_off && h->ml_agg == 4 && L >= 3 && 6 * h->ml_n[2] <= comp4_max;
-    const bool fits = comp4_here ? ((size_t)6 * h->ml_n[2] * 8 + 64 <= (size_t)140 * 1024 && g_ml_spmv(nb, 4) <= kMaxPartials) : ml_fits_lds(h->ml_n.data(), L, h->ml_agg);
+    const bool fits = comp4_here ? ml_comp4_fits(nb, h->ml_n[2]) : ml_fits_lds(h->ml_n.data(), L, h->ml_agg);
     if (!fits) { h->ml_n.assign(1, nb); return; }
     h->ml_levels = L;
-    h->ml_lds = ml_cg_lds_bytes(h->ml_n.data(), L, h->ml_agg);
+    h->ml_lds = comp4_here ? ml_comp4_lds(h->ml_n[2]) : ml_cg_lds_bytes(h->ml_n.data(), L, h->ml_agg);      // what the variant in use asks for: never above kMlLdsLimit
     // per-level host index arrays
     struct Lv { std::vector<int32_t> row_ptr, col, srow, off_ptr, diag_ptr, cslot, chunk; int32_t n_off = 0; };      // cslot / chunk: ml_galerkin_kernel's work list
     std::vector<Lv> lv((size_t)L + 1);
@@ -424,7 +424,7 @@ void build_ml(uzl_pgo* h, const std::vector<int32_t>& row_ptr0, const std::vecto
     for (int l = 1; l <= L; l++) { geo_sub[l] = geo_blob_doubles; geo_blob_doubles += (size_t)std::max(h->ml_n[l], 1) * 3; }
     const size_t o_geo_blob = take(geo_blob_doubles * 8 + 64);     // ml_cg copies levels g..L-1 with one linear loop
     const bool comp1 = !comp_off && h->ml_agg == 1 && L >= 2 && 6 * h->ml_n[1] <= 3072;     // ml_cg_comp_kernel<5> / <8> / <12> / <16>
-    const bool comp4 = !comp_off && !comp4_off && h->ml_agg == 4 && L >= 3 && 6 * h->ml_n[2] <= comp4_max;
+    const bool comp4 = comp4_here;                  // (one predicate: the admission test above)
     h->ml_comp = comp1 || comp4;
     h->ml_cl = comp1 ? 1 : (comp4 ? 2 : 0);
     const int cl = h->ml_cl;
@@ -1145,7 +1145,11 @@ int do_optimize_host(uzl_pgo* h, int32_t iterations, uzl_pgo_stats* st)
         Dp.pose = h->cur; Dp.pose_trial = h->trial;
         // (computeActiveErrors: chi2 of the linearisation point is needed in the first iteration, and by every rank of a sharded solve,
         //  which exchanges it; later iterations carry the accepted trial's over - as lm_head_kernel does)
-        { Timed t(h, "linearize"); UZL_HIP(k_hessian(D, h->cur, delta, &gl, &ga, s, it == 0 || h->sharded)); }     // computeActiveErrors + buildSystem
+        {                                                                       // computeActiveErrors + buildSystem
+            hipEvent_t ea = nullptr, eb = nullptr;
+            h->timer.pair("linearize", &ea, &eb);                               // (profiling: dispatch timestamps, as rocprofv3 reports the kernel)
+            UZL_HIP(k_hessian(D, h->cur, delta, &gl, &ga, s, it == 0 || h->sharded, ea, eb));
+        }
         if (h->sharded) {                                                         // H_aa, b: sums over all ranks' edges
             shard_allreduce(h, h->d_hdiag.p, (int64_t)h->nb * 42);
             ga = k_diagmax(D, s);
@@ -1328,12 +1332,29 @@ static bool same_structure(const uzl_pgo* h, const StructureKey& k)
 }
 
 // What a handle learned about the numbering of its reduced systems (num_its, build_structure) belongs to the session it came from: it is
-// kept while the graph is the previous one, unchanged or GROWN (at least as many nodes, the old nodes' fixed flags in front: an online
-// session, graph_slam_node.cpp:1138-1150), and dropped for anything else - an unrelated graph then solves as on a fresh handle.
+// kept while the graph is the previous one, unchanged or GROWN - at least as many nodes, the old nodes' fixed flags in front, AND the old
+// system edges still there in their order (nine in ten of them found in order in the new list: an online session appends edges and
+// invalidates a few, graph_slam_node.cpp:1138-1150) - and dropped for anything else: an unrelated graph on a reused handle then solves
+// as on a fresh one (round 5 looked at the fixed flags only, which for most graphs is "node 0 is fixed").
+static bool edges_survive_in_order(const std::vector<int32_t>& old_ij, const std::vector<int32_t>& new_ij)
+{
+    const size_t n_old = old_ij.size() / 2, n_new = new_ij.size() / 2;
+    if (n_old == 0) return true;
+    constexpr size_t kWindow = 4096;                                 // how far ahead a surviving edge may have moved
+    size_t at = 0, found = 0;
+    for (size_t k = 0; k < n_old; k++) {
+        const int32_t a = old_ij[2 * k], c = old_ij[2 * k + 1];
+        const size_t end = std::min(n_new, at + kWindow);
+        for (size_t q = at; q < end; q++)
+            if (new_ij[2 * q] == a && new_ij[2 * q + 1] == c) { found++; at = q + 1; break; }
+    }
+    return 10 * found >= 9 * n_old;
+}
 static void keep_or_drop_numbering_history(uzl_pgo* h, const StructureKey& k)
 {
     if (!k.ready || h->structure_ready) return;                     // nothing learned yet / the same structure again
-    const bool grown = h->n >= k.n && (size_t)k.n <= k.fixed_in.size() && std::equal(k.fixed_in.begin(), k.fixed_in.begin() + k.n, h->fixed_in.begin());
+    const bool grown = h->n >= k.n && (size_t)k.n <= k.fixed_in.size() && std::equal(k.fixed_in.begin(), k.fixed_in.begin() + k.n, h->fixed_in.begin()) &&
+                       edges_survive_in_order(k.ij, h->ij);
     if (!grown) { h->num_its[0] = h->num_its[1] = -1.; h->num_last = -1; }
 }
 

@@ -217,7 +217,9 @@ LmDev idle_state()
 }
 
 // Waits until lm_tail launch number `seq` (or a later one) of slot `sl` has published and copies the snapshot; returns its number.
-// lm_tail writes the fields and seq_begin, a system-scope fence, then seq (release): a copy is whole when both words agree around it.
+// lm_tail writes the fields and seq_begin (unordered among themselves), waits until they have been acknowledged, then seq
+// (publish_wait_own_stores, uzl_common.hpp).  What keeps a copy whole is the DRIVER'S ORDER: a slot's snapshot is copied here before the
+// pass whose tail writes the next one is enqueued; seq_begin == seq around the copy cross-checks it.
 uint32_t wait_pub(hipStream_t s, LmRun* R, int sl, uint32_t seq, LmHost* out)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -233,7 +235,8 @@ uint32_t wait_pub(hipStream_t s, LmRun* R, int sl, uint32_t seq, LmHost* out)
             UZL_HIP(hipStreamSynchronize(s));
             const uint32_t s2 = __atomic_load_n(&R->h_pub.p[sl].seq, __ATOMIC_ACQUIRE);
             if ((int32_t)(s2 - seq) < 0) throw HipError{hipErrorUnknown, "lm_tail_kernel did not publish", __FILE__, __LINE__};
-            memcpy(out, const_cast<const LmHost*>(R->h_pub.p + sl), sizeof(LmHost));
+            memcpy(out, const_cast<const LmHost*>(R->h_pub.p + sl), sizeof(LmHost));      // (the stream is idle: nothing writes the snapshot now)
+            if (out->seq_begin != out->seq) throw HipError{hipErrorUnknown, "lm_tail_kernel: torn snapshot on an idle stream", __FILE__, __LINE__};
             return s2;
         }
     }
