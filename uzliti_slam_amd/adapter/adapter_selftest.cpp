@@ -137,11 +137,18 @@ static int storage_mode(const char* dir, const char* out)
     RosbagStorage st(est, dir, /*clear_storage=*/true);
     for (auto& kv : g.nodes()) if (!st.storeNode(kv.second, 1500000000000000000ll)) { fprintf(stderr, "storeNode: %s\n", st.lastError().c_str()); return 4; }
     for (auto& kv : g.edges()) if (!st.storeEdge(kv.second, 1500000000000000000ll)) { fprintf(stderr, "storeEdge: %s\n", st.lastError().c_str()); return 4; }
+    g.name_ = "selftest"; g.frame_ = "/map";
+    g.addSensor("cam_left", lcg_pose(s)); g.addSensor("cam_right", lcg_pose(s)); g.sensorInitial("cam_left") = lcg_pose(s);
+    for (int i = 0; i < 6; i++) g.odom()[(size_t)i] = 0.25 * (i + 1);
+    if (!st.storeMetaData(g, lcg_pose(s), 1500000000000000000ll)) { fprintf(stderr, "storeMetaData: %s\n", st.lastError().c_str()); return 4; }
     st.removeNode(node_id(1)); st.removeEdge("e00000003"); st.removeEdge("never-stored");
     SlamGraph back;
     RosbagStorage st2(est, dir, false);
     if (!st2.loadGraph(back)) { fprintf(stderr, "loadGraph: %s\n", st2.lastError().c_str()); return 5; }
     int bad = 0;
+    if (back.name_ != g.name_ || back.frame_ != g.frame_ || back.odom() != g.odom() || back.sensors().size() != 2 || back.sensorsInitial().size() != 1 ||
+        max_abs_diff(back.sensors().at("cam_right"), g.sensors().at("cam_right")) > 1e-14 ||
+        max_abs_diff(back.sensorInitial("cam_left"), g.sensorInitial("cam_left")) > 1e-14) bad |= 128;
     if (back.nodes().size() != (size_t)N - 1 || back.edges().size() != (size_t)E - 1 || back.existsNode(node_id(1)) || back.existsEdge("e00000003")) bad |= 1;
     for (auto& kv : back.nodes()) {
         const SlamNode& a = g.node(kv.first); const SlamNode& b = kv.second;

@@ -25,7 +25,7 @@ void GraphOptimizer::stopThread()
     if (graph_optimization_thread_.joinable()) graph_optimization_thread_.join();
 }
 
-bool GraphOptimizer::optimize(SlamGraph& graph, std::function<void()> callback)
+bool GraphOptimizer::optimize(SlamGraph& graph, uzl_adapter::function<void()> callback)
 {
     std::lock_guard<std::mutex> lock(opt_mutex_);
     if (do_optimization_) return false;        // a solve is already in flight
@@ -51,7 +51,7 @@ void GraphOptimizer::graphOptimizationThread()
     while (running) {
         opt_cv_.wait(lock, [this] { return do_optimization_ || !running; });
         if (!running) break;
-        std::function<void()> cb = callback_;
+        uzl_adapter::function<void()> cb = callback_;
         lock.unlock();                         // no plugin lock while solving / calling back (graph_optimizer.cpp:63-67)
         optimizeImpl();
         if (cb) cb();

@@ -23,7 +23,7 @@ class GraphOptimizer {
 public:
     GraphOptimizer();
     virtual ~GraphOptimizer();
-    bool optimize(SlamGraph& graph, std::function<void()> callback);      // graph_optimizer.cpp:35-47
+    bool optimize(SlamGraph& graph, uzl_adapter::function<void()> callback);      // graph_optimizer.cpp:35-47
     void storeOptimizationResults(SlamGraph& graph);                      // :49-52
     void setConfig(GraphOptimizerConfig config);                          // :54-57
 
@@ -39,7 +39,7 @@ protected:
     std::mutex opt_mutex_;
     std::condition_variable opt_cv_;
     bool do_optimization_ = false;
-    std::function<void()> callback_;
+    uzl_adapter::function<void()> callback_;
     GraphOptimizerConfig config_;
 };
 

@@ -137,6 +137,26 @@ bool RosbagStorage::storeEdge(const SlamEdge& edge, int64_t now_ns)
     return writeBag((fs::path(storage_path_) / "edges" / edge.id_).string(), "edge", "graph_slam_msgs/Edge", traits_.edge_md5, traits_.edge_def, now_ns, msg);
 }
 
+bool RosbagStorage::storeMetaData(SlamGraph& graph, const Isometry3d& map_pose, int64_t now_ns)
+{
+    std::lock_guard<std::mutex> lock(rosbag_mutex_);
+    // SlamGraph::toMetaData (slam_graph.cpp:592-619)
+    uzl_wire_meta m;
+    memset(&m, 0, sizeof(m));
+    m.stamp_sec = (uint32_t)(now_ns / 1000000000); m.stamp_nsec = (uint32_t)(now_ns % 1000000000);
+    m.frame_id = span_of(graph.frame_); m.name = span_of(graph.name_);
+    memcpy(m.map_transform, map_pose.m.data(), 96);
+    std::vector<uzl_wire_sensor_transform> st, sti;
+    for (const auto& kv : graph.sensors()) { uzl_wire_sensor_transform t; t.sensor_name = span_of(kv.first); memcpy(t.transform, kv.second.m.data(), 96); st.push_back(t); }
+    for (const auto& kv : graph.sensorsInitial()) { uzl_wire_sensor_transform t; t.sensor_name = span_of(kv.first); memcpy(t.transform, kv.second.m.data(), 96); sti.push_back(t); }
+    m.n_sensor_transforms = (int32_t)st.size(); m.n_sensor_transforms_initial = (int32_t)sti.size();
+    memcpy(m.odometry_parameters, graph.odom().data(), 48);
+    std::vector<uint8_t> msg(uzl_wire_meta_size(&m, st.data(), sti.data()));
+    uint64_t w = 0;
+    if (uzl_wire_meta_encode(&m, st.data(), sti.data(), msg.data(), msg.size(), &w) != UZL_OK) { last_error_ = "meta_encode failed"; return false; }
+    return writeBag((fs::path(storage_path_) / "meta" / "meta").string(), "meta", "graph_slam_msgs/GraphMeta", traits_.meta_md5, traits_.meta_def, now_ns, msg);
+}
+
 void RosbagStorage::removeNode(const std::string& id)
 {
     std::lock_guard<std::mutex> lock(rosbag_mutex_);
@@ -239,6 +259,29 @@ bool RosbagStorage::loadGraph(SlamGraph& graph)
             graph.addEdge(e);
         }
     }
+    // ---- meta: every "meta" message of every file under <path>/meta (:187-207) -> SlamGraph::updateMetaData (slam_graph.cpp:621-633)
+    const fs::path meta_dir = fs::path(storage_path_) / "meta";
+    if (fs::exists(meta_dir))
+        for (const auto& it : fs::directory_iterator(meta_dir)) {
+            std::vector<uint8_t> file;
+            if (!read_file(it.path(), file)) { ok = false; continue; }
+            std::vector<uzl_bag_msg> msgs(16);
+            int32_t nm = 0;
+            if (uzl_bag_read(file.data(), file.size(), (int32_t)msgs.size(), msgs.data(), &nm) != UZL_OK) { ok = false; continue; }
+            for (int32_t k = 0; k < nm && k < (int32_t)msgs.size(); k++) {
+                if (str_of(msgs[k].topic) != "meta") continue;
+                const uint8_t* b = reinterpret_cast<const uint8_t*>(msgs[k].data.p);
+                uzl_wire_meta wm;
+                if (uzl_wire_meta_decode(b, msgs[k].data.n, &wm, 0, nullptr, 0, nullptr, nullptr) != UZL_OK) { ok = false; continue; }
+                std::vector<uzl_wire_sensor_transform> st((size_t)wm.n_sensor_transforms), sti((size_t)wm.n_sensor_transforms_initial);
+                uzl_wire_meta_decode(b, msgs[k].data.n, &wm, wm.n_sensor_transforms, st.data(), wm.n_sensor_transforms_initial, sti.data(), nullptr);
+                graph.frame_ = str_of(wm.frame_id); graph.name_ = str_of(wm.name);
+                memcpy(graph.sub_transform_.m.data(), wm.map_transform, 96);
+                for (const auto& t : st) { Isometry3d T; memcpy(T.m.data(), t.transform, 96); graph.addSensor(str_of(t.sensor_name), T); }
+                for (const auto& t : sti) { Isometry3d T; memcpy(T.m.data(), t.transform, 96); graph.sensorInitial(str_of(t.sensor_name)) = T; }
+                memcpy(graph.odom().data(), wm.odometry_parameters, 48);
+            }
+        }
     return ok;
 }
 

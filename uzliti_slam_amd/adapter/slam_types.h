@@ -8,13 +8,29 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <set>
 #include <string>
 #include <vector>
 
+// The reference's plugin bases take their callbacks as boost::function (transformation_estimator.h:48,66; graph_optimizer.h:35,54).
+// Where boost exists the mirror takes the same type, so that a caller's boost::function / boost::bind expression binds without a
+// conversion; in this image (no boost) std::function stands in - same call syntax, same copy semantics.
+#if defined(__has_include)
+#if __has_include(<boost/function.hpp>)
+#include <boost/function.hpp>
+#define UZL_ADAPTER_HAVE_BOOST_FUNCTION 1
+#endif
+#endif
+
 namespace uzl_adapter {
+#ifdef UZL_ADAPTER_HAVE_BOOST_FUNCTION
+template <class Sig> using function = boost::function<Sig>;
+#else
+template <class Sig> using function = std::function<Sig>;
+#endif
 
 // Eigen::Isometry3d stand-in: top three rows of the 4x4 matrix, row-major [R|t]
 struct Isometry3d {
@@ -87,11 +103,18 @@ public:
     std::map<std::string, SlamNode>& nodes() { return nodes_; }
     std::map<std::string, SlamEdge>& edges() { return edges_; }
     std::map<std::string, Isometry3d>& sensors() { return sensors_; }
+    // meta data (slam_graph.h:165-182; toMetaData / updateMetaData, slam_graph.cpp:592-633)
+    Isometry3d& sensorInitial(const std::string& name) { return sensors_initial_[name]; }
+    std::map<std::string, Isometry3d>& sensorsInitial() { return sensors_initial_; }
+    std::array<double, 6>& odom() { return odometry_parameters_; }
+    std::string frame_ = "/map", name_;
+    Isometry3d sub_transform_;              // meta.map_transform on load (updateMetaData :625)
 
 private:
     std::map<std::string, SlamNode> nodes_;
     std::map<std::string, SlamEdge> edges_;
-    std::map<std::string, Isometry3d> sensors_;
+    std::map<std::string, Isometry3d> sensors_, sensors_initial_;
+    std::array<double, 6> odometry_parameters_{{0, 0, 0, 0, 0, 0}};
 };
 
 // dynamic_reconfigure-generated config structs (cfg/GraphOptimizer.cfg:10-12, cfg/FeatureLinkEstimation.cfg:9-13)

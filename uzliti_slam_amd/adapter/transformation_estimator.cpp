@@ -4,7 +4,7 @@
 
 namespace uzl_adapter {
 
-TransformationEstimator::TransformationEstimator(std::function<void(SlamEdge)> callback) : callback_(callback)
+TransformationEstimator::TransformationEstimator(uzl_adapter::function<void(SlamEdge)> callback) : callback_(callback)
 {
     estimation_thread_ = std::thread(&TransformationEstimator::estimationThread, this);
 }
@@ -56,7 +56,7 @@ void TransformationEstimator::estimationThread()
     }
 }
 
-Mi355xFeatureTransformationEstimator::Mi355xFeatureTransformationEstimator(std::function<void(SlamEdge)> callback,
+Mi355xFeatureTransformationEstimator::Mi355xFeatureTransformationEstimator(uzl_adapter::function<void(SlamEdge)> callback,
                                                                            int device, uint64_t seed)
     : TransformationEstimator(callback)
 {

@@ -21,7 +21,7 @@ namespace uzl_adapter {
 
 class TransformationEstimator {
 public:
-    explicit TransformationEstimator(std::function<void(SlamEdge)> callback);
+    explicit TransformationEstimator(uzl_adapter::function<void(SlamEdge)> callback);
     virtual ~TransformationEstimator();
     void estimateEdge(SlamNode& from, SlamNode& to);                               // transformation_estimator.cpp:35-43
     virtual bool estimateEdgeImpl(SlamNode& from, SlamNode& to, SlamEdge& edge) = 0;   // .h:54
@@ -39,12 +39,12 @@ protected:
     std::condition_variable estimation_cv_;
     std::atomic<bool> running_{true};
     std::vector<std::pair<SlamNode, SlamNode>> est_queue_;
-    std::function<void(SlamEdge)> callback_;
+    uzl_adapter::function<void(SlamEdge)> callback_;
 };
 
 class Mi355xFeatureTransformationEstimator : public TransformationEstimator {
 public:
-    Mi355xFeatureTransformationEstimator(std::function<void(SlamEdge)> callback, int device = 0, uint64_t seed = 0);
+    Mi355xFeatureTransformationEstimator(uzl_adapter::function<void(SlamEdge)> callback, int device = 0, uint64_t seed = 0);
     ~Mi355xFeatureTransformationEstimator() override;
     bool estimateEdgeImpl(SlamNode& from, SlamNode& to, SlamEdge& edge) override;
     void setConfig(FeatureLinkEstimationConfig config);                             // feature_transformation_estimator.cpp:350-353
