@@ -800,8 +800,13 @@ __device__ __forceinline__ void tri_tile_xcd(int gt, int b, int& ti, int& tj)
 // while the matrix cores work on the current one.  One workgroup per CU at this size (144 tiles at n = 750), so nothing
 // but the slab's own MFMAs hides the global-load latency of the next slab: with slabs of 16 (47 dependent slabs, 0.2 us
 // of MFMA each) about 1 us per slab stayed exposed (55 us); slabs of 64 leave 12 exposures.
-__device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __restrict__ X, const double* __restrict__ T,
-                                                        double* __restrict__ Xn, float* __restrict__ c32 = nullptr, int c32_stride = 0)
+// TILE: 0 = a tile inside the matrix (bounds-free loads for whole slabs), 1 = a tile on the matrix edge, n even (clamped loads),
+// 2 = n odd (element-wise: diagnostic sizes only, n = 6 n_c is even).  One instantiation per class, chosen per workgroup: with the
+// three kinds of load behind branches of ONE loop the interior tiles lost 4 - 15 % (n = 3750: 1138 -> 1340 us).
+template <int TILE>
+__device__ __forceinline__ void ml_ns_gemm_tile(int n, int ti, int tj, const double* __restrict__ X, const double* __restrict__ T,
+                                                double* __restrict__ Xn, float* __restrict__ c32, int c32_stride,
+                                                double (*__restrict__ sA)[kGemmTile], double (*__restrict__ sB)[kGemmTile])
 {
     // Both operand tiles sit k-major in LDS, s[k][i ^ 16 (k & 1)]: the 16 x 4 (row or column, k) doubles one MFMA operand read takes
     // then fall into 64 different banks per half wave (rows padded to 65 doubles put (i, k) and (i + 1, k - 1) on the same bank: 2- to
@@ -809,16 +814,13 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
     // and in LDS) - X is symmetric in the refinement.  Measured: no faster than the padded layout (1.32 ms at n = 3750, 40 TFLOP/s) -
     // with 64 x 64 tiles the kernel moves 8 flops per operand byte, 5.4 TB/s out of the Infinity Cache at that rate: the operand
     // stream, not the LDS and not the matrix pipe, sets the pace (slabs of 32 with four workgroups per CU: 1.21 ms, and slower at n = 750).
-    __shared__ double sA[kGemmK][kGemmTile];          // sA[k][row ^ swz(k)] = X[row][k]
-    __shared__ double sB[kGemmK][kGemmTile];          // sB[k][col ^ swz(k)] = T[k][col]
+    // (sA[k][row ^ swz(k)] = X[row][k], sB[k][col ^ swz(k)] = T[k][col]: the caller's LDS, shared by the three instantiations)
     constexpr int kPer = kGemmTile * kGemmK / 256;     // values per lane and operand per slab
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // X, A and therefore X (A X) are symmetric: only the tiles on and above the diagonal are computed (blockIdx.x counts them row by
     // row), every result is stored twice.  Half the flops of the rebuild's dominant kernel, and X' is symmetric to the last bit
     // outside the diagonal tiles - which PCG wants from its preconditioner anyway.
     const int gt = (n + kGemmTile - 1) / kGemmTile;
-    int ti, tj;
-    tri_tile_xcd(gt, (int)blockIdx.x, ti, tj);
     const int row0 = ti * kGemmTile, col0 = tj * kGemmTile;
     const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;          // this wave's quarter
     const int li = lane & 15, lk = lane >> 4;
@@ -831,15 +833,32 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
     // pair is aligned and never straddles the matrix edge); slabs and tiles that lie inside the matrix - all but the last of each - load
     // without a bounds test (round 4's element-wise predicated loads were 32 branches per slab and operand).
     double2 pa[kPer / 2], pb[kPer / 2];
-    const bool tile_inside = row0 + kGemmTile <= n && col0 + kGemmTile <= n && (n & 1) == 0;
+    // Operand fetch: 16-byte loads (a pair of neighbouring rows / columns; n = 6 n_c is even and tiles start at multiples of 64, so a
+    // pair is aligned and lies inside or outside the matrix as a whole).  On the matrix edge (TILE 1) and in an interior tile's last,
+    // partial slab the address of a pair outside the matrix is CLAMPED to the matrix's first element and the value replaced by zero.
+    // Rounds 4-5 took 32 predicated 8-byte loads there, each in a branch of its own with a wait behind it - and since a 10k-vertex
+    // graph's 465 tiles are two to a CU, the launch lasted as long as its slowest EDGE tile (n = 1878, 59 edge tiles: 189 us against
+    // 160 us at n = 1920, which has none; now 165 us; tests/diag/ns_gemm_lab.hip).
     auto fetch = [&](int k0) {
-        if (tile_inside && k0 + kGemmK <= n) {
+        if (TILE == 0 && k0 + kGemmK <= n) {
 #pragma unroll
             for (int u = 0; u < kPer / 2; u++) {
                 const int e = u * 256 + tid;
                 const int ek = e / (kGemmTile / 2), ei = 2 * (e % (kGemmTile / 2));      // consecutive lanes walk the row / column index
                 pa[u] = *reinterpret_cast<const double2*>(X + (size_t)(k0 + ek) * n + row0 + ei);      // = X[row][k], X symmetric
                 pb[u] = *reinterpret_cast<const double2*>(T + (size_t)(k0 + ek) * n + col0 + ei);
+            }
+        } else if (TILE != 2) {
+#pragma unroll
+            for (int u = 0; u < kPer / 2; u++) {
+                const int e = u * 256 + tid;
+                const int ek = e / (kGemmTile / 2), ei = 2 * (e % (kGemmTile / 2));
+                const int gk = k0 + ek, gr = row0 + ei, gc = col0 + ei;
+                const bool oka = gk < n && gr < n, okb = gk < n && gc < n;
+                const double2 va = *reinterpret_cast<const double2*>(X + (oka ? (size_t)gk * n + gr : 0));
+                const double2 vb = *reinterpret_cast<const double2*>(T + (okb ? (size_t)gk * n + gc : 0));
+                pa[u] = oka ? va : make_double2(0., 0.);
+                pb[u] = okb ? vb : make_double2(0., 0.);
             }
         } else {
 #pragma unroll
@@ -920,6 +939,18 @@ __device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __re
     if (c32 && tj == gt - 1 && tid < kGemmTile && row0 + tid < n)               // pad columns [n, stride) stay zero
         for (int q = n; q < c32_stride; q++) c32[(size_t)(row0 + tid) * c32_stride + q] = 0.f;
 }
+__device__ __forceinline__ void ml_ns_gemm_kernel_body(int n, const double* __restrict__ X, const double* __restrict__ T,
+                                                        double* __restrict__ Xn, float* __restrict__ c32 = nullptr, int c32_stride = 0)
+{
+    const int gt = (n + kGemmTile - 1) / kGemmTile;
+    __shared__ double sA[kGemmK][kGemmTile];
+    __shared__ double sB[kGemmK][kGemmTile];
+    int ti, tj;
+    tri_tile_xcd(gt, (int)blockIdx.x, ti, tj);
+    if (n & 1) ml_ns_gemm_tile<2>(n, ti, tj, X, T, Xn, c32, c32_stride, sA, sB);                       // (uniform in the workgroup)
+    else if ((tj + 1) * kGemmTile <= n) ml_ns_gemm_tile<0>(n, ti, tj, X, T, Xn, c32, c32_stride, sA, sB);      // (ti <= tj: the rows are inside too)
+    else ml_ns_gemm_tile<1>(n, ti, tj, X, T, Xn, c32, c32_stride, sA, sB);
+}
 __global__ __launch_bounds__(256) void ml_ns_gemm_kernel(int n, const double* __restrict__ X, const double* __restrict__ T, double* __restrict__ Xn,
                                                         float* __restrict__ c32, int c32_stride)
 {
@@ -955,14 +986,23 @@ __host__ __device__ __forceinline__ int gemm32_grid(int gt)      // workgroups: 
     }
     return kXcds * most;
 }
-__device__ __forceinline__ void ml_ns_gemm32_kernel_body(int n, const double* __restrict__ X, const double* __restrict__ T,
-                                                          double* __restrict__ Xn, float* __restrict__ c32, int c32_stride)
+// EDGE: the tile touches the matrix edge (rows or columns beyond n).  Operands beyond the matrix - an edge tile's, and every tile's k
+// beyond n in the zero-padded last slab - come through BUFFER loads over the matrix (`buffer_load_dwordx2`: an offset beyond the
+// resource's n^2 doubles returns zero, and a lane whose row or column lies beyond n is given such an offset): no branch, so the
+// kGemm32Ahead steps of loads really are in flight together.  (Rounds 4-5 predicated every load: each sat in a branch of its own and
+// the compiler put a full `s_waitcnt vmcnt(0)` in front of every step's MFMAs - the read-ahead never happened; address selects in front
+// of plain loads were turned back into branches.)
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {
-    __shared__ double sP[4][32][33];
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
+}
+template <bool EDGE>
+__device__ __forceinline__ void ml_ns_gemm32_tile(int n, int ti, int tj, const double* __restrict__ X, const double* __restrict__ T,
+                                                  double* __restrict__ Xn, float* __restrict__ c32, int c32_stride, double (*__restrict__ sP)[32][33])
+{
     const int gt = (n + 31) / 32;
-    int ti, tj;
-    if (!gemm32_tile(gt, (int)blockIdx.x, ti, tj)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // (a scalar: the wave's K range and the branches on it are uniform)
     const int row0 = ti * 32, col0 = tj * 32;
     const int li = lane & 15, lk = lane >> 4;
     const int spq = gemm_slabs_per_quarter(n), slabs = (n + kGemmK - 1) / kGemmK;
@@ -972,32 +1012,36 @@ __device__ __forceinline__ void ml_ns_gemm32_kernel_body(int n, const double* __
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = v4f64{0., 0., 0., 0.};
-    const bool ra0 = row0 + li < n, ra1 = row0 + 16 + li < n, cb0 = col0 + li < n, cb1 = col0 + 16 + li < n;
-    const double* __restrict__ xa = X + row0 + li;
-    const double* __restrict__ tb = T + col0 + li;
+    const bool ra0 = !EDGE || row0 + li < n, ra1 = !EDGE || row0 + 16 + li < n, cb0 = !EDGE || col0 + li < n, cb1 = !EDGE || col0 + 16 + li < n;
+    // (word 3 of the resource: raw buffer, 32-bit data format - the value the gfx90a / gfx942 / gfx950 family takes)
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(X), 0, n * n * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T), 0, n * n * 8, 0x00020000);
     double pa0[kGemm32Ahead], pa1[kGemm32Ahead], pb0[kGemm32Ahead], pb1[kGemm32Ahead];
+    // (one kind of load for every step - a branch between plain and buffer loads inside the loop made the compiler wait for ALL loads in
+    //  flight at every step: its count of outstanding loads does not survive a join)
     auto fetch = [&](int u, int k4) {
         const int k = k4 + lk;
-        const bool kin = k < n;
-        const size_t o = (size_t)(kin ? k : 0) * n;
-        pa0[u] = (kin && ra0) ? xa[o] : 0.;            // = X[row][k] through X's symmetry
-        pa1[u] = (kin && ra1) ? xa[o + 16] : 0.;
-        pb0[u] = (kin && cb0) ? tb[o] : 0.;
-        pb1[u] = (kin && cb1) ? tb[o + 16] : 0.;
+        constexpr unsigned kOut = 0xFFFFFFF8u;                                // beyond any matrix: reads as zero
+        const unsigned o = (k < n) ? (unsigned)k * (unsigned)n * 8u : kOut;     // (n <= 960: the matrix is < 8 MB)
+        const unsigned oa = o + (unsigned)(row0 + li) * 8u, ob = o + (unsigned)(col0 + li) * 8u;
+        pa0[u] = buf_load_f64(rX, (o != kOut && ra0) ? oa : kOut); pa1[u] = buf_load_f64(rX, (o != kOut && ra1) ? oa + 128u : kOut);      // = X[row][k] through X's symmetry
+        pb0[u] = buf_load_f64(rT, (o != kOut && cb0) ? ob : kOut); pb1[u] = buf_load_f64(rT, (o != kOut && cb1) ? ob + 128u : kOut);
     };
 #pragma unroll
     for (int u = 0; u < kGemm32Ahead; u++) fetch(u, kbeg + 4 * u);
+    // (a wave's K range is whole 64-slabs, i.e. a multiple of the 8 x 4 steps of one trip: no test per step - one would put every step
+    //  into a basic block of its own, and the loads would be waited for where they are issued.  The read-ahead past kend fetches operands
+    //  nobody uses; buffer loads cannot fault.)
+    static_assert(kGemmK % (4 * kGemm32Ahead) == 0, "a slab is a whole number of trips");
     for (int k4 = kbeg; k4 < kend; k4 += 4 * kGemm32Ahead) {
 #pragma unroll
         for (int u = 0; u < kGemm32Ahead; u++) {
-            if (k4 + 4 * u < kend) {
-                const double a0 = pa0[u], a1 = pa1[u], b0 = pb0[u], b1 = pb1[u];
-                fetch(u, k4 + 4 * (u + kGemm32Ahead));
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-            }
+            const double a0 = pa0[u], a1 = pa1[u], b0 = pb0[u], b1 = pb1[u];
+            fetch(u, k4 + 4 * (u + kGemm32Ahead));
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -1023,6 +1067,16 @@ __device__ __forceinline__ void ml_ns_gemm32_kernel_body(int n, const double* __
     }
     if (c32 && tj == gt - 1 && tid < 32 && row0 + tid < n)                       // pad columns [n, stride) stay zero
         for (int q = n; q < c32_stride; q++) c32[(size_t)(row0 + tid) * c32_stride + q] = 0.f;
+}
+__device__ __forceinline__ void ml_ns_gemm32_kernel_body(int n, const double* __restrict__ X, const double* __restrict__ T,
+                                                          double* __restrict__ Xn, float* __restrict__ c32, int c32_stride)
+{
+    __shared__ double sP[4][32][33];
+    const int gt = (n + 31) / 32;
+    int ti, tj;
+    if (!gemm32_tile(gt, (int)blockIdx.x, ti, tj)) return;
+    if ((tj + 1) * 32 <= n) ml_ns_gemm32_tile<false>(n, ti, tj, X, T, Xn, c32, c32_stride, sP);       // (ti <= tj: the rows are inside too)
+    else ml_ns_gemm32_tile<true>(n, ti, tj, X, T, Xn, c32, c32_stride, sP);
 }
 __global__ __launch_bounds__(256) void ml_ns_gemm32_kernel(int n, const double* __restrict__ X, const double* __restrict__ T, double* __restrict__ Xn,
                                                           float* __restrict__ c32, int c32_stride)
