@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: which of n freshly made streams stand in each other's way (uzl_debug_stream_pairs: the stream pool's own decision, one
-measurement per unordered pair - two chains of 6 dependent 8-us kernels side by side against one chain alone, timed on the device,
+measurement per unordered pair - two chains of 5 dependent 7-us kernels side by side against one chain alone, timed on the device,
 best of 3, in percent)?  ~100 - 112: independent; ~200: one hardware queue; ~240 - 280: two queues on one compute pipe.
 python tests/diag/stream_overlap.py [n] [priority | 200 = priorities 0 and -1 in turn] [repeats]"""
 import ctypes

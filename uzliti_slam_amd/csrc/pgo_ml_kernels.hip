@@ -1491,9 +1491,14 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     // (a launch after convergence must stay cheap: 16-iteration graph batches overshoot.  Leaving here costs it the issue of the loads
     //  above - nothing waits for them - and saves every working launch the done flag's round trip in front of its first load.)
     if (done) return;
+    // offsets of the workgroup's level-1 aggregates (the restriction of A p at the end): the LOAD here, the store into LDS behind the
+    // prefetch below.  (Rounds 1-5 stored at once: a full `s_waitcnt vmcnt(0)` between the row headers and the diagonal blocks, and - the
+    // counts of loads in flight do not survive the divergent `dact` block - a second one behind the diagonal blocks' loads, in front of
+    // the first slot pass: one whole memory round trip of the AGG = 4 kernel spent waiting for the diagonal block alone.)
+    double g1v = 0.;
     if (tid < kAggPerBlk * 3) {
         const int A1 = bx * kAggPerBlk + tid / 3;
-        sg1[tid] = (gl == 2 && A1 < H.n[1]) ? H.geo[1][(size_t)A1 * 3 + tid % 3] : 0.;
+        if (gl == 2 && A1 < H.n[1]) g1v = H.geo[1][(size_t)A1 * 3 + tid % 3];
     }
     // Every lane (g, r) multiplies row r of a 6x6 block with the 6-vector z + beta p_old of the block's column.  The six lanes of a
     // group need the same vector: each loads ONE component (the six loads of a group are one contiguous 48 B) and the vector is
@@ -1555,6 +1560,7 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
         }
     }
     STAMP(16);     // 16: prefetch issue
+    if (tid < kAggPerBlk * 3) sg1[tid] = g1v;      // (read behind the barriers below)
     // ---- beta
     const int n_grp = (n_part + 63) >> 6;
 #pragma unroll

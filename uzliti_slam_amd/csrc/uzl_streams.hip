@@ -6,8 +6,8 @@
 // chains of dependent kernels, one on each, take 2.4x the time of one chain (measured: tests/diag/stream_overlap.py), worse than
 // running them one after the other.  Which streams of a process collide either way depends on every stream it has made before: a batch
 // whose rebuild stream sat on the solver stream's pipe lost 15 - 45 % (16 chain-like graphs 14.3 -> 20.9 ms), two launch sequences on one
-// pipe ran 2x slower than one sequence.  Nothing tells a process where a stream landed, but it can be measured: a chain of 6 dependent
-// 8-us kernels on one stream alone, then the same chain on both at once, TIMED ON THE DEVICE (first link's start to last link's
+// pipe ran 2x slower than one sequence.  Nothing tells a process where a stream landed, but it can be measured: a chain of 5 dependent
+// 7-us kernels on one stream alone, then the same chain on both at once, TIMED ON THE DEVICE (first link's start to last link's
 // end).  Round 6, two boxes, 116 pairs (tests/diag/stream_overlap.py): independent pairs 1.01 - 1.17x; one hardware queue 2.01x; two
 // queues in each other's way 2.38 - 2.42x; nothing in between - the threshold is 1.5x, best of three (anything else on the GPU can only
 // hold a run back).  Rounds 4 - 5 timed 32 4-us links from the host: two chains cost the host twice the launches, so independent pairs
@@ -53,8 +53,8 @@ __global__ void chain_kernel(unsigned ticks, unsigned long long* stamp, int wher
     if (where == 2 && (blockIdx.x & 63) == 63 && threadIdx.x == 0) atomicMax(&stamp[2 * slot + 1], wall_clock64());
 }
 
-constexpr int kChainLen = 6;            // links per chain
-constexpr unsigned kChainTicks = 800;   // 8 us a link: the host (2.8 us a launch) stays ahead of two chains
+constexpr int kChainLen = 5;            // links per chain
+constexpr unsigned kChainTicks = 700;   // 7 us a link: the host (2.8 us a launch) stays ahead of two chains
 constexpr int kChainWgs = 1000;
 // Independent iff two chains side by side take < kIndependentBelow x one chain, best of kProbeTries (classes: file header).
 constexpr double kIndependentBelow = 1.5;
