@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: which of n freshly made streams stand in each other's way (uzl_debug_stream_pairs: the stream pool's own decision, one
 measurement per unordered pair - two chains of 5 dependent 7-us kernels side by side against one chain alone, timed on the device,
-best of 3, in percent)?  ~100 - 112: independent; ~200: one hardware queue; ~240 - 280: two queues on one compute pipe.
+best of 3, in percent)?  ~104 - 148: independent; ~202: one hardware queue; ~250 - 260: two queues in each other's way.
 python tests/diag/stream_overlap.py [n] [priority | 200 = priorities 0 and -1 in turn] [repeats]"""
 import ctypes
 import os

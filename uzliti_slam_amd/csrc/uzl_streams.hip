@@ -8,11 +8,14 @@
 // whose rebuild stream sat on the solver stream's pipe lost 15 - 45 % (16 chain-like graphs 14.3 -> 20.9 ms), two launch sequences on one
 // pipe ran 2x slower than one sequence.  Nothing tells a process where a stream landed, but it can be measured: a chain of 5 dependent
 // 7-us kernels on one stream alone, then the same chain on both at once, TIMED ON THE DEVICE (first link's start to last link's
-// end).  Round 6, two boxes, 116 pairs (tests/diag/stream_overlap.py): independent pairs 1.01 - 1.17x; one hardware queue 2.01x; two
-// queues in each other's way 2.38 - 2.42x; nothing in between - the threshold is 1.5x, best of three (anything else on the GPU can only
-// hold a run back).  Rounds 4 - 5 timed 32 4-us links from the host: two chains cost the host twice the launches, so independent pairs
-// read 1.05 - 1.56x depending on the box's CPU and the verdict was noise-driven (round 5's red GPU test).  A pair costs 0.2 ms
-// (independent: one run) to 0.7 ms (three runs); the chain alone is measured once per process.
+// end).  Round 6, three boxes, > 200 pairs (tests/diag/stream_overlap.py; links of one workgroup per CU, so that up to four chains fit
+// the chip side by side): independent pairs 1.04 - 1.48x; one hardware queue 2.02x; two queues in each other's way 2.5 - 2.6x; nothing in
+// between - the threshold is 1.75x, best of three (anything else on the GPU can only hold a run back).  (Links of 1000 workgroups: 1.01 -
+// 1.17x / 2.01x / 2.4x.)  Rounds 4 - 5 timed 32 4-us links from the host: two chains cost the host twice the launches, so independent pairs
+// read 1.05 - 1.56x depending on the box's CPU and the verdict was noise-driven (round 5's red GPU test).  A pair costs 0.1 - 0.2 ms
+// (independent: one run, one host synchronize) to 0.5 ms (three runs); a candidate is measured against ALL its unmeasured partners at
+// once first (one run if they are all independent); the chain alone is measured once per process.  The first launch on a fresh stream
+// (the runtime sets its queue up: ~1 ms) is not counted as measuring.
 //
 // Round 4 measured at every uzl_pgo_batch_create and threw the rejected streams away.  Now the streams that have to run side by side
 // (a solver handle's solver / rebuild pair, a batch's launch sequences and their rebuild streams) come from ONE POOL PER DEVICE that
@@ -55,60 +58,74 @@ __global__ void chain_kernel(unsigned ticks, unsigned long long* stamp, int wher
 
 constexpr int kChainLen = 5;            // links per chain
 constexpr unsigned kChainTicks = 700;   // 7 us a link: the host (2.8 us a launch) stays ahead of two chains
-constexpr int kChainWgs = 1000;
+constexpr int kChainWgs = 256;             // one workgroup per CU: four chains side by side fit the chip (a group measurement)
 // Independent iff two chains side by side take < kIndependentBelow x one chain, best of kProbeTries (classes: file header).
-constexpr double kIndependentBelow = 1.5;
+constexpr double kIndependentBelow = 1.75;
 constexpr int kProbeTries = 3;
 
+constexpr int kGroupMax = 4;            // chains side by side in one measurement
 struct Probe {                          // per device: the stamps and the time of one chain alone (measured once per process)
-    unsigned long long* stamp = nullptr;                        // device: {start, end} of chain a, of chain b
+    unsigned long long* stamp = nullptr;                        // device: {start, end} per chain
     unsigned long long* host = nullptr;                         // pinned: where they are read
+    hipEvent_t ev[kGroupMax] = {nullptr, nullptr, nullptr, nullptr};
     double alone = 0.;
+    double warm_ms = 0.;                                        // first launches on fresh streams (the runtime sets their queues up: ~1 ms each)
     std::vector<hipStream_t> warmed;
 };
 
-// ticks from the first link's start to the last link's end, one chain on `a` (b == nullptr) or one on each
-double chain_ticks(Probe& pr, hipStream_t a, hipStream_t b)
+// ticks from the earliest first link's start to the latest last link's end, one chain on each of the n (<= kGroupMax) streams of q.
+// ONE host synchronize per measurement: the other chains are ordered in front of the first stream's read-back by events.
+double chain_ticks(Probe& pr, const hipStream_t* q, int n)
 {
     if (!pr.stamp) {
-        if (hipMalloc((void**)&pr.stamp, 4 * sizeof(unsigned long long)) != hipSuccess) { pr.stamp = nullptr; return -1.; }
-        if (hipMemset(pr.stamp, 0, 4 * sizeof(unsigned long long)) != hipSuccess) return -1.;
-        if (hipHostMalloc((void**)&pr.host, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { pr.host = nullptr; return -1.; }
+        if (hipMalloc((void**)&pr.stamp, 2 * kGroupMax * sizeof(unsigned long long)) != hipSuccess) { pr.stamp = nullptr; return -1.; }
+        if (hipMemset(pr.stamp, 0, 2 * kGroupMax * sizeof(unsigned long long)) != hipSuccess) return -1.;
+        if (hipHostMalloc((void**)&pr.host, 2 * kGroupMax * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { pr.host = nullptr; return -1.; }
+        for (hipEvent_t& e : pr.ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return -1.; }
     }
-    if (!pr.host) return -1.;
-    for (hipStream_t q : {a, b})                                // (the first launch on a stream sets its queue up)
-        if (q && std::find(pr.warmed.begin(), pr.warmed.end(), q) == pr.warmed.end()) {
-            hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, q, 1u, pr.stamp, 0, 0);
-            (void)hipStreamSynchronize(q);
-            pr.warmed.push_back(q);
+    if (!pr.host || n < 1 || n > kGroupMax) return -1.;
+    for (int i = 0; i < n; i++)                                 // (the first launch on a stream sets its queue up: whoever uses the stream first pays that)
+        if (std::find(pr.warmed.begin(), pr.warmed.end(), q[i]) == pr.warmed.end()) {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, q[i], 1u, pr.stamp, 0, 0);
+            (void)hipStreamSynchronize(q[i]);
+            pr.warmed.push_back(q[i]);
+            pr.warm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     for (int k = 0; k < kChainLen; k++) {
         const int where = k == 0 ? 1 : (k == kChainLen - 1 ? 2 : 0);
-        hipLaunchKernelGGL(chain_kernel, dim3(kChainWgs), dim3(256), 0, a, kChainTicks, pr.stamp, where, 0);
-        if (b) hipLaunchKernelGGL(chain_kernel, dim3(kChainWgs), dim3(256), 0, b, kChainTicks, pr.stamp, where, 1);
+        for (int i = 0; i < n; i++) hipLaunchKernelGGL(chain_kernel, dim3(kChainWgs), dim3(256), 0, q[i], kChainTicks, pr.stamp, where, i);
     }
-    if (b) (void)hipStreamSynchronize(b);
-    const bool ok = hipMemcpyAsync(pr.host, pr.stamp, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, a) == hipSuccess;
-    (void)hipStreamSynchronize(a);
+    bool ok = true;
+    for (int i = 1; i < n; i++) ok = ok && hipEventRecord(pr.ev[i], q[i]) == hipSuccess && hipStreamWaitEvent(q[0], pr.ev[i], 0) == hipSuccess;
+    ok = ok && hipMemcpyAsync(pr.host, pr.stamp, 2 * kGroupMax * sizeof(unsigned long long), hipMemcpyDeviceToHost, q[0]) == hipSuccess;
+    (void)hipStreamSynchronize(q[0]);
+    if (!ok) { for (int i = 1; i < n; i++) (void)hipStreamSynchronize(q[i]); }
     (void)hipGetLastError();
     if (!ok) return -1.;
     const unsigned long long* t = pr.host;
-    const unsigned long long start = b ? std::min(t[0], t[2]) : t[0], end = b ? std::max(t[1], t[3]) : t[1];
+    unsigned long long start = t[0], end = t[1];
+    for (int i = 1; i < n; i++) { start = std::min(start, t[2 * i]); end = std::max(end, t[2 * i + 1]); }
     return end > start ? (double)(end - start) : -1.;
 }
 
-// two chains of dependent kernels side by side against one chain alone: the smallest of up to kProbeTries ratios (anything else on the
+// n chains of dependent kernels side by side against one chain alone: the smallest of up to kProbeTries ratios (anything else on the
 // GPU can only hold a run back), stopping at the first one below the threshold
-double pair_over_single(Probe& pr, hipStream_t a, hipStream_t b)
+double group_over_single(Probe& pr, const hipStream_t* q, int n)
 {
-    if (pr.alone <= 0.) pr.alone = std::min(chain_ticks(pr, a, nullptr), chain_ticks(pr, a, nullptr));
+    if (pr.alone <= 0.) pr.alone = std::min(chain_ticks(pr, q, 1), chain_ticks(pr, q, 1));
     if (pr.alone <= 0.) return 1e9;
     double best = 1e9;
     for (int t = 0; t < kProbeTries && best >= kIndependentBelow; t++) {
-        const double p = chain_ticks(pr, a, b);
+        const double p = chain_ticks(pr, q, n);
         if (p > 0.) best = std::min(best, p / pr.alone);
     }
     return best;
+}
+double pair_over_single(Probe& pr, hipStream_t a, hipStream_t b)
+{
+    const hipStream_t q[2] = {a, b};
+    return group_over_single(pr, q, 2);
 }
 
 struct Pool {
@@ -132,8 +149,9 @@ struct Pool {
         auto it = verdict.find(key);
         if (it != verdict.end()) return it->second;
         const auto t0 = std::chrono::steady_clock::now();
+        const double w0 = probe.warm_ms;
         const double r = pair_over_single(probe, a, b);
-        st.probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        st.probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - (probe.warm_ms - w0);      // (queue set-up of a fresh stream is not the measurement's)
         const bool ok = r < kIndependentBelow;
         st.pairs_measured++; if (ok) st.pairs_independent++;
         static const bool dbg = diag_flag("UZL_STREAM_DBG");
@@ -186,7 +204,24 @@ hipStream_t stream_lease(int device, int priority, const std::vector<hipStream_t
         if (required && !hard.empty()) { P.st.fallbacks++; return nullptr; }
         return any();
     }
-    auto fits = [&](hipStream_t q) { for (hipStream_t o : hard) if (!P.independent(o, q)) return false; return true; };
+    // a candidate against its hard partners: those it has not been measured with all at once (one chain on each, <= kGroupMax side by
+    // side): if together they take no longer than one chain, every one of those pairs is independent - the common case costs one
+    // measurement instead of one per partner; otherwise pair by pair
+    auto fits = [&](hipStream_t q) {
+        for (hipStream_t o : hard) if (P.known(o, q) && !P.independent(o, q)) return false;
+        std::vector<hipStream_t> grp(1, q);
+        for (hipStream_t o : hard) if (o != q && !P.known(o, q) && (int)grp.size() < kGroupMax) grp.push_back(o);
+        if (grp.size() >= 3) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const double w0 = P.probe.warm_ms;
+            const double r = group_over_single(P.probe, grp.data(), (int)grp.size());
+            P.st.probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - (P.probe.warm_ms - w0);
+            if (r < kIndependentBelow)
+                for (size_t i = 1; i < grp.size(); i++) { P.verdict[q < grp[i] ? std::make_pair(q, grp[i]) : std::make_pair(grp[i], q)] = true; P.st.pairs_measured++; P.st.pairs_independent++; }
+        }
+        for (hipStream_t o : hard) if (!P.independent(o, q)) return false;
+        return true;
+    };
     // (a registered stream belongs to another handle, whose worker may be enqueueing on it right now: a measurement under its load
     //  proves nothing and would stall it, so an unmeasured pair with a busy stream stays unmeasured and counts as no hit)
     auto soft_hits = [&](hipStream_t q) {
