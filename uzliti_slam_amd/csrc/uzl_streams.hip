@@ -56,6 +56,16 @@ __global__ void chain_kernel(unsigned ticks, unsigned long long* stamp, int wher
     if (where == 2 && (blockIdx.x & 63) == 63 && threadIdx.x == 0) atomicMax(&stamp[2 * slot + 1], wall_clock64());
 }
 
+// the stamps handed to the host without a copy engine and without a stream synchronize: eight system-scope stores into pinned memory,
+// a fence, then the sequence word the host spins on (a hipMemcpyAsync + hipStreamSynchronize pair cost the host ~100 us per measurement)
+__global__ void stamps_out_kernel(const unsigned long long* __restrict__ stamp, unsigned long long* __restrict__ host, unsigned long long seq, int n)
+{
+    if ((int)threadIdx.x < n) __hip_atomic_store(&host[threadIdx.x], stamp[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&host[n], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 constexpr int kChainLen = 5;            // links per chain
 constexpr unsigned kChainTicks = 700;   // 7 us a link: the host (2.8 us a launch) stays ahead of two chains
 constexpr int kChainWgs = 256;             // one workgroup per CU: four chains side by side fit the chip (a group measurement)
@@ -66,7 +76,8 @@ constexpr int kProbeTries = 3;
 constexpr int kGroupMax = 4;            // chains side by side in one measurement
 struct Probe {                          // per device: the stamps and the time of one chain alone (measured once per process)
     unsigned long long* stamp = nullptr;                        // device: {start, end} per chain
-    unsigned long long* host = nullptr;                         // pinned: where they are read
+    unsigned long long* host = nullptr;                         // pinned: where they are read (+ the sequence word behind them)
+    unsigned long long seq = 0;
     hipEvent_t ev[kGroupMax] = {nullptr, nullptr, nullptr, nullptr};
     double alone = 0.;
     double warm_ms = 0.;                                        // first launches on fresh streams (the runtime sets their queues up: ~1 ms each)
@@ -78,10 +89,20 @@ struct Probe {                          // per device: the stamps and the time o
 double chain_ticks(Probe& pr, const hipStream_t* q, int n)
 {
     if (!pr.stamp) {
+        // once per process and device: two small allocations, four events and the first launch of this file's kernels (with which the
+        // runtime loads the library's code object if nothing has been launched yet: ~8 ms that the first real kernel would pay otherwise).
+        // Counted as set-up, not as measuring.
+        const auto t_init = std::chrono::steady_clock::now();
+        struct Done { Probe& p; std::chrono::steady_clock::time_point t; ~Done() { p.warm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } } done{pr, t_init};
         if (hipMalloc((void**)&pr.stamp, 2 * kGroupMax * sizeof(unsigned long long)) != hipSuccess) { pr.stamp = nullptr; return -1.; }
         if (hipMemset(pr.stamp, 0, 2 * kGroupMax * sizeof(unsigned long long)) != hipSuccess) return -1.;
-        if (hipHostMalloc((void**)&pr.host, 2 * kGroupMax * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { pr.host = nullptr; return -1.; }
+        if (hipHostMalloc((void**)&pr.host, (2 * kGroupMax + 1) * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { pr.host = nullptr; return -1.; }
+        pr.host[2 * kGroupMax] = 0;
         for (hipEvent_t& e : pr.ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return -1.; }
+        hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, q[0], 1u, pr.stamp, 0, 0);
+        hipLaunchKernelGGL(stamps_out_kernel, dim3(1), dim3(64), 0, q[0], pr.stamp, pr.host, 0ull, 2 * kGroupMax);
+        (void)hipStreamSynchronize(q[0]);
+        pr.warmed.push_back(q[0]);
     }
     if (!pr.host || n < 1 || n > kGroupMax) return -1.;
     for (int i = 0; i < n; i++)                                 // (the first launch on a stream sets its queue up: whoever uses the stream first pays that)
@@ -98,9 +119,20 @@ double chain_ticks(Probe& pr, const hipStream_t* q, int n)
     }
     bool ok = true;
     for (int i = 1; i < n; i++) ok = ok && hipEventRecord(pr.ev[i], q[i]) == hipSuccess && hipStreamWaitEvent(q[0], pr.ev[i], 0) == hipSuccess;
-    ok = ok && hipMemcpyAsync(pr.host, pr.stamp, 2 * kGroupMax * sizeof(unsigned long long), hipMemcpyDeviceToHost, q[0]) == hipSuccess;
-    (void)hipStreamSynchronize(q[0]);
-    if (!ok) { for (int i = 1; i < n; i++) (void)hipStreamSynchronize(q[i]); }
+    const unsigned long long seq = ++pr.seq;
+    if (ok) hipLaunchKernelGGL(stamps_out_kernel, dim3(1), dim3(64), 0, q[0], pr.stamp, pr.host, seq, 2 * kGroupMax);
+    ok = ok && hipGetLastError() == hipSuccess;
+    if (ok) {                                                   // spin on the sequence word; a stream synchronize if it does not come (50 ms)
+        const auto t0 = std::chrono::steady_clock::now();
+        volatile unsigned long long* flag = pr.host + 2 * kGroupMax;
+        for (long spin = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; spin++)
+            if ((spin & 4095) == 4095 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 50.) {
+                (void)hipStreamSynchronize(q[0]);
+                ok = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
+                break;
+            }
+    }
+    if (!ok) { for (int i = 0; i < n; i++) (void)hipStreamSynchronize(q[i]); }
     (void)hipGetLastError();
     if (!ok) return -1.;
     const unsigned long long* t = pr.host;
@@ -151,11 +183,12 @@ struct Pool {
         const auto t0 = std::chrono::steady_clock::now();
         const double w0 = probe.warm_ms;
         const double r = pair_over_single(probe, a, b);
-        st.probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - (probe.warm_ms - w0);      // (queue set-up of a fresh stream is not the measurement's)
+        const double took = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - (probe.warm_ms - w0);
+        st.probe_ms += took;                                     // (queue set-up of a fresh stream is not the measurement's)
         const bool ok = r < kIndependentBelow;
         st.pairs_measured++; if (ok) st.pairs_independent++;
         static const bool dbg = diag_flag("UZL_STREAM_DBG");
-        if (dbg) fprintf(stderr, "[uzl] stream pair %p %p: pair / single chain %.2f -> %s\n", (void*)a, (void*)b, r, ok ? "independent" : "in each other's way");
+        if (dbg) fprintf(stderr, "[uzl] stream pair %p %p: pair / single chain %.2f -> %s (%.3f ms, queue set-up %.3f ms)\n", (void*)a, (void*)b, r, ok ? "independent" : "in each other's way", took, probe.warm_ms - w0);
         if (ratio) *ratio = r;
         verdict[key] = ok;
         return ok;
