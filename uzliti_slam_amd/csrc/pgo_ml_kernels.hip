@@ -1450,7 +1450,8 @@ __device__ __forceinline__ void ml_spmv_kernel_body(PgoDev D, MlHot H, const dou
     const int done = D.flags[0];            // looked at behind the first loads (below): its round trip runs beside theirs, not in front
     STAMP_DECL
     const int gl = (AGG == 1 || H.levels < 2) ? 1 : 2;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane / 6, r = lane % 6;
+    // (the wave index as a scalar: rows, row headers and the loops over partial groups are then uniform to the compiler as well)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane / 6, r = lane % 6;
     const bool lact = lane < 60;
     const int bx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);      // this workgroup's row group
     const int row0 = bx * kRowsPerBlk + wv * kRowsPerWave;
