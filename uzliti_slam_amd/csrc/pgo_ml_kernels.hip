@@ -1029,21 +1029,31 @@ __device__ __forceinline__ void ml_ns_gemm32_tile(int n, int ti, int tj, const d
     };
 #pragma unroll
     for (int u = 0; u < kGemm32Ahead; u++) fetch(u, kbeg + 4 * u);
-    // (a wave's K range is whole 64-slabs, i.e. a multiple of the 8 x 4 steps of one trip: no test per step - one would put every step
-    //  into a basic block of its own, and the loads would be waited for where they are issued.  The read-ahead past kend fetches operands
-    //  nobody uses; buffer loads cannot fault.)
-    static_assert(kGemmK % (4 * kGemm32Ahead) == 0, "a slab is a whole number of trips");
-    for (int k4 = kbeg; k4 < kend; k4 += 4 * kGemm32Ahead) {
+    // A wave's K range is whole 64-slabs: spq <= 4 of them (n <= kGemm32Max), i.e. 16 spq steps - unrolled COMPLETELY, one
+    // instantiation per spq.  As a loop of 8-step trips the compiler drained all 32 loads in flight at every trip's head (its count of
+    // loads in flight does not survive the loop's back edge); straight-line, every step waits for its own four loads and nothing else.
+    // No test per step either (a wave whose range ends early - the last quarter - multiplies zeros: buffer loads beyond the matrix
+    // read as zero, and the read-ahead past the range fetches operands nobody uses).
+    static_assert(kGemm32Max <= 960 + 64, "spq <= 4");
+    const int steps = (kend > kbeg) ? (kend - kbeg) / 4 : 0;
+    auto run = [&](auto nsteps_c) {
+        constexpr int NS = decltype(nsteps_c)::value;
 #pragma unroll
-        for (int u = 0; u < kGemm32Ahead; u++) {
-            const double a0 = pa0[u], a1 = pa1[u], b0 = pb0[u], b1 = pb1[u];
-            fetch(u, k4 + 4 * (u + kGemm32Ahead));
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        for (int st = 0; st < NS; st++) {
+            const int u = st % kGemm32Ahead;
+            // the step's MFMAs FIRST, then the fetch into the registers they have just read (with the fetch in front the old operands
+            // lived on in copies and the loads went into fresh registers that had to be moved back)
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa0[u], pb0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa0[u], pb1[u], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa1[u], pb0[u], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa1[u], pb1[u], acc[1][1], 0, 0, 0);
+            if (st + kGemm32Ahead < NS) fetch(u, kbeg + 4 * (st + kGemm32Ahead));
         }
-    }
+    };
+    if (steps == 64) run(std::integral_constant<int, 64>{});
+    else if (steps == 48) run(std::integral_constant<int, 48>{});
+    else if (steps == 32) run(std::integral_constant<int, 32>{});
+    else if (steps == 16) run(std::integral_constant<int, 16>{});
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
