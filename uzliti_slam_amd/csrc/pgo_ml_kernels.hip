@@ -1029,6 +1029,13 @@ __device__ __forceinline__ void ml_ns_gemm32_tile(int n, int ti, int tj, const d
     };
 #pragma unroll
     for (int u = 0; u < kGemm32Ahead; u++) fetch(u, kbeg + 4 * u);
+    // the tile's own entries of X (for 2 X - X T at the end) are asked for now: behind the K range they were one more round trip
+    double xown[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int e = tid + 256 * u, r = e >> 5, c = e & 31, gr = row0 + r, gc = col0 + c;
+        xown[u] = buf_load_f64(rX, (gr < n && gc < n) ? ((unsigned)gr * (unsigned)n + (unsigned)gc) * 8u : 0xFFFFFFF8u);
+    }
     // A wave's K range is whole 64-slabs: spq <= 4 of them (n <= kGemm32Max), i.e. 16 spq steps - unrolled COMPLETELY, one
     // instantiation per spq.  As a loop of 8-step trips the compiler drained all 32 loads in flight at every trip's head (its count of
     // loads in flight does not survive the loop's back edge); straight-line, every step waits for its own four loads and nothing else.
@@ -1066,7 +1073,7 @@ __device__ __forceinline__ void ml_ns_gemm32_tile(int n, int ti, int tj, const d
         const int e = tid + 256 * u, r = e >> 5, c = e & 31, gr = row0 + r, gc = col0 + c;
         if (gr < n && gc < n) {
             const double sum = ((sP[0][r][c] + sP[1][r][c]) + sP[2][r][c]) + sP[3][r][c];
-            const double v = 2. * X[(size_t)gr * n + gc] - sum;
+            const double v = 2. * xown[u] - sum;
             Xn[(size_t)gr * n + gc] = v;
             if (ti != tj) Xn[(size_t)gc * n + gr] = v;
             if (c32) {
