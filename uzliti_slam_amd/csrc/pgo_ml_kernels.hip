@@ -1129,6 +1129,9 @@ __device__ __forceinline__ void ml_mult_qyqt_kernel_body(const MlDev* __restrict
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = v4f64{0., 0., 0., 0.};
     double pa[kPer], pb[kPer];
+    const unsigned qbytes = (unsigned)ml.lv[cl].n * (unsigned)np * 288u;           // both operands: n_cl x n_{cl+1} blocks of 6 x 6 (< 4 GB: n_cl n_{cl+1} < 14.9 M)
+    const __amdgpu_buffer_rsrc_t rQY = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(QY), 0, (int)qbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Q), 0, (int)qbytes, 0x00020000);
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < kPer; u++) {
@@ -1136,8 +1139,12 @@ __device__ __forceinline__ void ml_mult_qyqt_kernel_body(const MlDev* __restrict
             const int er = e / kGemmK, ek = e % kGemmK;                           // consecutive lanes walk k
             const int gk = k0 + ek, p = gk / 6, c = gk % 6;
             const int gr = row0 + er, gc = col0 + er;
-            pa[u] = (gr < n && gk < kd) ? QY[((size_t)(gr / 6) * np + p) * 36 + (gr % 6) * 6 + c] : 0.;
-            pb[u] = (gc < n && gk < kd) ? Q[((size_t)(gc / 6) * np + p) * 36 + (gc % 6) * 6 + c] : 0.;
+            // (buffer loads: an entry outside the operands is given an offset beyond them and reads as zero - no branch per element,
+            //  all 32 loads of a slab in flight together)
+            const unsigned oa = (unsigned)((gr / 6) * np + p) * 288u + (unsigned)((gr % 6) * 6 + c) * 8u;
+            const unsigned ob = (unsigned)((gc / 6) * np + p) * 288u + (unsigned)((gc % 6) * 6 + c) * 8u;
+            pa[u] = buf_load_f64(rQY, (gr < n && gk < kd) ? oa : 0xFFFFFFF8u);
+            pb[u] = buf_load_f64(rQ, (gc < n && gk < kd) ? ob : 0xFFFFFFF8u);
         }
     };
     fetch(0);
