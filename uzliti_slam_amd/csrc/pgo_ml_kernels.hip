@@ -2801,7 +2801,13 @@ static void kl_ml_spmv_t(SLOT sl, const LmShape& sh, int parity, hipStream_t s, 
 {
     if (sh.batch_geometry && ev_a) hipExtLaunchKernelGGL((ml_spmv_lm_kernel<1, kSpmvBatchRpw, kSpmvBatchWaves, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvBatchWaves), 0, s, ev_a, ev_b, 0, sl, parity);
     else if (sh.batch_geometry) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, kSpmvBatchRpw, kSpmvBatchWaves, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(64 * kSpmvBatchWaves), 0, s, sl, parity);
-    else if (sh.agg == 1) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, 1, 8, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(512), 0, s, sl, parity);
+    else if (sh.agg == 1) {
+        // one row per wave (8 waves) or two (4 waves: half the waves to launch, the same 8 rows per workgroup, the same bits);
+        // UZL_SPMV1_RPW (diagnostic build) picks
+        static const int rpw1 = diag_int("UZL_SPMV1_RPW", 1);
+        if (rpw1 == 2) hipLaunchKernelGGL((ml_spmv_lm_kernel<1, 2, 4, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(256), 0, s, sl, parity);
+        else hipLaunchKernelGGL((ml_spmv_lm_kernel<1, 1, 8, SLOT>), dim3(sh.g_spmv, 1, sh.nslots), dim3(512), 0, s, sl, parity);
+    }
     else {
         // rows per wave of the AGG = 4 geometry (16 rows per workgroup; the same bits either way).  Up to two such workgroups per CU the
         // kernel is a latency chain per row and twice the lanes per row shorten it (5k / 25k 23.4 -> 21.8 ms, 6k / 30k 25.5 -> 23.8, 8k / 24k
