@@ -79,10 +79,12 @@ extern "C" {
 int         uzl_abi_version(void);
 /* The library's long-lived HIP streams on `device`.  Streams that have to run side by side (a solver handle's solver / rebuild pair,
  * the launch sequences of a batch and their rebuild streams) are leased from one pool per device and process: a pair of streams is measured against each
- * other at most once per process (~1 ms of short kernels), its verdict is remembered, streams go back to the pool when their handle is
- * destroyed.  UZL_STREAM_PROBE=0 in the environment skips every measurement (a batch then runs as one launch sequence).  Out
- * (any may be NULL): streams in the pool / leased right now / made by handles for themselves and registered; pairs measured so far /
- * found independent; leases that found no independent stream within the budget; host time spent measuring [ms]. */
+ * other at most once per process (0.1 - 0.5 ms: chains of short kernels timed on the device), its verdict is remembered, streams go back
+ * to the pool when their handle is destroyed.  UZL_STREAM_PROBE=0 in the environment skips every measurement (a batch then runs as one
+ * launch sequence).  Out (any may be NULL): streams in the pool / leased right now / made by handles for themselves and registered;
+ * pairs measured so far / found independent; leases that found no independent stream within the budget; host time spent measuring
+ * [ms] (without the one-time set-up - two small allocations and the process's first kernel launches - and without the first launch
+ * on a fresh stream, which whoever uses the stream first pays). */
 int         uzl_stream_stats(int32_t device, int32_t* n_pooled, int32_t* n_leased, int32_t* n_registered, int32_t* pairs_measured,
                              int32_t* pairs_independent, int32_t* fallbacks, double* probe_ms);
 /* Number of visible HIP devices, or <0 (UZL_ERR_NO_DEVICE) when there is none. */
