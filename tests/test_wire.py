@@ -392,8 +392,8 @@ def test_stored_graph_loads_into_the_estimator_and_estimates_like_array_frames(c
 
 
 def test_parsers_under_address_and_ub_sanitizers(tmp_path):
-    """The decoders take bytes from disk: 100k mutated / truncated Edge, Node and bag images through an ASan + UBSan build of the
-    host-side codec (sanitizers run on the CPU build only)."""
+    """The decoders take bytes from disk: 100k mutated / truncated Edge, Node, GraphMeta and bag images through an ASan + UBSan build of
+    the host-side codec (sanitizers run on the CPU build only)."""
     import os
     import shutil
     import subprocess
@@ -404,6 +404,7 @@ def test_parsers_under_address_and_ub_sanitizers(tmp_path):
     seeds = []
     for k in ("edge_bytes", "node_bytes", "bag_bytes"):
         p = tmp_path / (k + ".bin"); p.write_bytes(z[k].tobytes()); seeds.append(str(p))
+    p = tmp_path / "meta_bytes.bin"; p.write_bytes(OW.encode_meta(_meta(np.random.default_rng(5), 2, 3, 2))); seeds.append(str(p))
     exe = str(tmp_path / "fuzz_wire")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-x", "c++",
                            os.path.join(root, "uzliti_slam_amd", "csrc", "uzl_wire.hip"), os.path.join(root, "tests", "fuzz_wire.cpp"), "-o", exe])
